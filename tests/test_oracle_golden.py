@@ -1,0 +1,249 @@
+"""Pin the CPU oracle (oracle/tjm_oracle.py) to fixtures generated from the reference.
+
+Fixtures: tests/golden/*.npz, produced by tools/make_golden.py importing /root/reference.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import tjm_oracle as o
+
+Z = o.PAULI["z"]
+X = o.PAULI["x"]
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def tensors(g, prefix):
+    out = []
+    i = 0
+    while f"{prefix}{i}" in g:
+        out.append(g[f"{prefix}{i}"])
+        i += 1
+    return out
+
+
+def phase_align(a, b):
+    """Return b rotated by the global phase that best matches a."""
+    ov = np.vdot(b, a)
+    return b * (ov / abs(ov)) if abs(ov) > 0 else b
+
+
+def test_rng_streams():
+    g = load("rng_streams")
+    for a, s in enumerate(g["seeds"]):
+        for b, t in enumerate(g["trajs"]):
+            assert np.array_equal(o.trajectory_rng(int(s), int(t)).random(8), g["traj"][a, b])
+            for c, k in enumerate(g["steps"]):
+                assert np.array_equal(o.sample_rng(int(s), int(t), int(k)).random(8), g["sample"][a, b, c])
+    # first doubles quoted in SURVEY.md section 8(c)
+    assert o.trajectory_rng(42, 0).random() == 0.8577260219363377
+    assert o.sample_rng(42, 0, 1).random() == 0.6952053372292888
+
+
+def test_choice_is_one_uniform_searchsorted():
+    g = load("rng_streams")
+    for case in range(len(g["choice_idx"])):
+        p = g["choice_p"][case]
+        p = p[p > 0]
+        rng = o.trajectory_rng(7, case)
+        rng.random()
+        u = rng.random()
+        cdf = np.cumsum(p)
+        cdf /= cdf[-1]
+        assert int(np.searchsorted(cdf, u, side="right")) == g["choice_idx"][case]
+        assert rng.random() == g["choice_next"][case]
+
+
+def test_truncate_kat_table():
+    g = load("truncate_kat")
+    modes = ["discarded_weight", "relative", "hard_cutoff", "relative_discarded_weight"]
+    for row, spec in zip(g["spectra"], g["specs"]):
+        n, mode, thr, cap, min_keep, keep = int(spec[0]), modes[int(spec[1])], spec[2], int(spec[3]), int(spec[4]), int(spec[5])
+        got = o.truncate(row[:n], mode=mode, threshold=thr, max_bond_dim=None if cap < 0 else cap, min_keep=min_keep)
+        assert got == keep
+
+
+def test_truncate_reference_unit_cases():
+    # hand-computed cases of tests/core/linalg/test_svd_utils.py:20-80
+    t = o.truncate
+    assert t(np.array([10.0, 3.0, 1.0, 0.5]), mode="discarded_weight", threshold=10.0) == 2
+    assert t(np.array([2.0, 1.0, 0.4]), mode="relative", threshold=0.45) == 2
+    assert t(np.array([0.0, 1.0]), mode="relative", threshold=0.1) == 1
+    s = np.array([5.0, 2.0, 0.5, 0.1])
+    assert t(s, mode="hard_cutoff", threshold=0.2) == 3
+    assert t(s, mode="hard_cutoff", threshold=0.2, max_bond_dim=2) == 2
+    s = np.array([10.0, 1.0, 0.1, 0.01])
+    assert t(s, mode="relative_discarded_weight", threshold=1e-3) == 2
+    assert t(s, mode="relative_discarded_weight", threshold=0.02) == 1
+    assert t(np.array([3.0, 2.0, 0.0, 0.0]), mode="relative_discarded_weight", threshold=0.0) == 2
+    assert t(np.zeros(4), mode="relative_discarded_weight", threshold=0.1) == 1
+    # tests/core/methods/tdvp/test_sweep_utils.py:136-143
+    assert t(np.array([1.0, 0.5, 0.1, 0.0100001]), mode="discarded_weight", threshold=1e-4, min_keep=2) == 4
+    assert t(np.array([1.0, 0.5, 0.01, 0.001]), mode="discarded_weight", threshold=1e-4, min_keep=2) == 3
+    with pytest.raises(ValueError):
+        t(np.ones(3), mode="invalid", threshold=1.0)
+
+
+def test_local_kernels():
+    g = load("kernels")
+    a, b = g["A"], g["B"]
+    assert np.allclose(o.merge_two_site(a, b), g["merge"], atol=1e-13)
+    w = o.merge_mpo_tensors(g["W1"], g["W2"])
+    assert np.allclose(w, g["merge_mpo"], atol=1e-13)
+    assert np.allclose(o.project_site(g["L"], g["R"], w, g["merge"]), g["project_site_2"], atol=1e-11)
+    assert np.allclose(o.project_site(g["L"], g["R1"], g["W1"], a), g["project_site_1"], atol=1e-11)
+    assert np.allclose(o.update_left_environment(a, a, g["W1"], g["L"]), g["env_left"], atol=1e-11)
+    assert np.allclose(o.update_right_environment(b, b, g["W2"], g["R"]), g["env_right"], atol=1e-11)
+    assert np.allclose(o.project_bond(g["LB"], g["R"], g["C"]), g["project_bond"], atol=1e-11)
+    mps, mpo = tensors(g, "mps"), tensors(g, "mpo")
+    rb = o.right_environments(mps, mpo)
+    for mine, ref in zip(rb, tensors(g, "renv")):
+        assert np.allclose(mine, ref, atol=1e-12)
+    th = o.merge_two_site(mps[0], mps[1])
+    w2 = o.merge_mpo_tensors(mpo[0], mpo[1])
+    l0 = np.ones((1, 1, 1), dtype=complex)
+    for tol in (1e-4, 1e-12):
+        got = o.update_site(l0, rb[1], w2, th, 0.05, tol)
+        assert np.allclose(got, g[f"krylov_site2_tol{tol:g}"], atol=1e-12)
+    for dist in ("left", "right", "sqrt"):
+        l_, r_ = o.split_two_site(g["theta_split"], [2, 2], svd_distribution=dist, trunc_mode="discarded_weight", threshold=1e-3, max_bond_dim=4)
+        assert l_.shape[2] == int(g[f"split_{dist}_keep"])
+        assert np.allclose(o.merge_two_site(l_, r_), g[f"split_{dist}_recon"], atol=1e-12)
+
+
+def test_one_tdvp_call_matches_reference():
+    g = load("tdvp_step")
+    for key in g["cases"]:
+        key = str(key)
+        L, chi, mode, sweeps = key.split("_")
+        chi = int(chi[3:])
+        st = o.MPSState(tensors(g, key + "_in"), 0)
+        mpo = tensors(g, key + "_mpo")
+        p = o.Params(dt=0.1, elapsed_time=0.1, max_bond_dim=chi, svd_threshold=1e-9, krylov_tol=1e-12, tdvp_sweeps=int(sweeps[1:]), tdvp_mode=mode)
+        o.tdvp(st, mpo, p)
+        assert [t.shape[2] for t in st.tensors] == list(g[key + "_bonds"]), key
+        assert np.allclose(st.to_vec(), g[key + "_vec"], atol=1e-10), key
+        assert abs(st.norm_sq() - float(g[key + "_norm"])) < 1e-12
+
+
+def test_tdvp_against_dense_exponential():
+    # tests/core/methods/tdvp/test_integrators.py:74-105: one exact 2TDVP step == expm(-i dt H) psi
+    import scipy.linalg
+
+    L = 5
+    rng = np.random.default_rng(0)
+    st = o.MPSState.haar(L, 4, rng)
+    st.normalize("B")
+    mpo = o.ising_mpo(L, 1.0, 0.5)
+    psi0 = st.to_vec()
+    p = o.Params(dt=0.05, elapsed_time=0.05, max_bond_dim=None, svd_threshold=1e-16, krylov_tol=1e-12)
+    o.tdvp(st, mpo, p)
+    H = o.mpo_to_matrix(mpo)
+    assert np.allclose(H, H.conj().T)
+    exact = scipy.linalg.expm(-1j * 0.05 * H) @ psi0
+    assert np.allclose(st.to_vec(), exact, atol=1e-6)
+
+
+def _noise_sets(L):
+    kx = np.kron(X, X)
+    return {
+        "pauli": [o.make_process(n, [i], 0.1 + 0.01 * i) for i in range(L) for n in ("pauli_z", "pauli_x")],
+        "lowering": [o.make_process("lowering", [i], 0.2) for i in range(L)],
+        "mixed": [o.make_process(n, [i], 0.1) for i in range(L) for n in ("lowering", "pauli_z")],
+        "twosite": [o.make_process("pauli_z", [i], 0.05) for i in range(L)]
+        + [o.make_process("crosstalk_xx", [i, i + 1], 0.07, matrix=kx) for i in range(L - 1)]
+        + [o.make_process("longrange_crosstalk_zz", [0, 3], 0.03, factors=(Z, Z))],
+    }
+
+
+class Scripted:
+    def __init__(self, vals):
+        self.vals = list(vals)
+
+    def random(self):
+        return self.vals.pop(0)
+
+    def choice(self, n, p=None):
+        u = self.vals.pop(0)
+        cdf = np.cumsum(p)
+        cdf /= cdf[-1]
+        return int(np.searchsorted(cdf, u, side="right"))
+
+
+def test_dissipation_and_jump_step():
+    g = load("noise_step")
+    sets = _noise_sets(6)
+    for key in g["cases"]:
+        key = str(key)
+        nname, mode = key.split("_")
+        st = o.MPSState(tensors(g, key + "_in"), 0)
+        p = o.Params(dt=0.1, max_bond_dim=8, svd_threshold=1e-10)
+        o.apply_dissipation(st, sets[nname], 0.1, p)
+        assert np.allclose(phase_align(g[key + "_after_diss_vec"], st.to_vec()), g[key + "_after_diss_vec"], atol=1e-11), key
+        dp = 1.0 - st.norm_sq(0)
+        assert abs(dp - float(g[key + "_dp"])) < 1e-12, key
+        if mode != "nojump":
+            _, probs = o.jump_distribution(st.copy(), sets[nname], 0.1, p)
+            assert np.allclose(probs, g[key + "_probs"], atol=1e-12), key
+        st = o.stochastic_process(st, sets[nname], 0.1, p, Scripted(g[key + "_u"]))
+        assert [t.shape[2] for t in st.tensors] == list(g[key + "_bonds"]), key
+        ref = g[key + "_final_vec"]
+        assert np.allclose(phase_align(ref, st.to_vec()), ref, atol=1e-10), key
+
+
+def test_trajectories_match_reference_and_pinned_golden():
+    g = load("trajectories")
+    L = 5
+    mpo = tensors(g, "mpo")
+    noise = [o.make_process(n, [i], 0.1) for i in range(L) for n in ("lowering", "pauli_z")]
+    init = o.MPSState.product(L, "zeros")
+    for order in (1, 2):
+        for sample in (False, True):
+            p = o.Params(observables=[o.Obs(Z, s) for s in range(L)], elapsed_time=1, dt=0.1, max_bond_dim=4, svd_threshold=1e-6,
+                         krylov_tol=1e-4, order=order, sample_timesteps=sample, random_seed=42)
+            key = f"order{order}_sample{int(sample)}"
+            res = []
+            for i in range(10):
+                o.JUMP_LOG = []
+                r, dg, _ = o.run_trajectory(i, init, noise, p, mpo)
+                dps = [e["dp"] for e in o.JUMP_LOG]
+                ref_dp = g[key + "_dp"][i]
+                ref_dp = ref_dp[~np.isnan(ref_dp)]
+                assert len(dps) == len(ref_dp), (key, i)
+                assert np.allclose(dps, ref_dp, atol=1e-9), (key, i)
+                assert np.allclose(r, g[key + "_results"][i], atol=1e-9), (key, i)
+                assert np.array_equal(dg, g[key + "_diag"][i]), (key, i)
+                res.append(r)
+            o.JUMP_LOG = None
+            if order == 2 and not sample:
+                mean = np.mean(res, axis=0).ravel()
+                # the reference's own pinned golden, tests/test_simulator.py:191-197 (its tolerance is 2e-4)
+                assert np.allclose(mean, g["pinned_expected_z"], atol=1e-9)
+
+
+def test_closed_and_dephasing_configs():
+    g = load("trajectories")
+    mpo = tensors(g, "c1_mpo")
+    init = o.MPSState.product(10, "zeros")
+    for order in (1, 2):
+        p = o.Params(observables=[o.Obs(Z, s) for s in range(10)], elapsed_time=1.0, dt=0.1, max_bond_dim=16, svd_threshold=1e-9,
+                     krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=42)
+        r, dg, _ = o.run_trajectory(0, init, None, p, mpo)
+        assert np.allclose(r, g[f"c1_order{order}_results"], atol=1e-10)
+        assert np.array_equal(dg, g[f"c1_order{order}_diag"])
+    mpo = tensors(g, "c2_mpo")
+    init = o.MPSState.product(8, "x+")
+    noise = [o.make_process("pauli_z", [i], 0.1) for i in range(8)]
+    p = o.Params(observables=[o.Obs(Z, s) for s in range(8)] + [o.Obs(X, s) for s in range(8)], elapsed_time=1.0, dt=0.1, max_bond_dim=8,
+                 svd_threshold=1e-12, krylov_tol=1e-12, order=1, sample_timesteps=True, random_seed=42)
+    sorted_rows = p.observable_sorted_indices
+    for i in range(8):
+        r, dg, _ = o.run_trajectory(i, init, noise, p, mpo)
+        assert np.allclose(r, g["c2_results"][i], atol=1e-9), i
+        assert np.array_equal(dg, g["c2_diag"][i]), i
+    assert sorted_rows[0] == 0 and sorted_rows[8] == 1  # Z0 -> row 0, X0 -> row 1 (site-sorted, stable)

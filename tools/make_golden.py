@@ -1,0 +1,339 @@
+"""Generate golden fixtures under tests/golden/ by importing the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference); provenance script for the
+committed ``tests/golden/*.npz`` data.  Fixtures hold inputs and reference outputs
+only - never reference source text.
+
+    python tools/make_golden.py
+"""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(__file__))
+from ref_boot import ref  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(__file__), "..", "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+MPS = ref("core.data_structures.mps").MPS
+MPO = ref("core.data_structures.mpo").MPO
+NoiseModel = ref("core.data_structures.noise_model").NoiseModel
+sp = ref("core.data_structures.simulation_parameters")
+gl = ref("core.libraries.gate_library")
+tjm = ref("analog.analog_tjm")
+tdvp_mod = ref("core.methods.tdvp.tdvp")
+diss = ref("core.methods.dissipation")
+stoch = ref("core.methods.stochastic_process")
+rutil = ref("core.random_utils")
+linalg = ref("core.linalg")
+decomp = ref("core.methods.decompositions")
+prim = ref("core.methods.tdvp.primitives")
+mexp = ref("core.methods.matrix_exponential")
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def pack_tensors(prefix, tensors):
+    return {f"{prefix}{i}": np.asarray(t, dtype=np.complex128) for i, t in enumerate(tensors)}
+
+
+def haar_mps(length, chi, seed):
+    """Seeded Haar MPS built with the same recipe as mps.py:170-221, then normalize('B')."""
+    rng = np.random.default_rng(seed)
+    caps = [1] * (length + 1)
+    left = 1
+    for i in range(1, length):
+        left *= 2
+        caps[i] = left
+    right = 1
+    for i in range(length - 1, 0, -1):
+        right *= 2
+        caps[i] = min(caps[i], right, chi)
+    tensors = []
+    for i in range(length):
+        cl, cr = caps[i], caps[i + 1]
+        x = rng.standard_normal((2 * cl, cr)) + 1j * rng.standard_normal((2 * cl, cr))
+        q, r = np.linalg.qr(x, mode="reduced")
+        d = np.diag(r)
+        q = q / (d / np.abs(d))[np.newaxis, :]
+        tensors.append(q.reshape(2, cl, cr).astype(np.complex128))
+    m = MPS(length, tensors=tensors)
+    m.normalize("B")
+    return m
+
+
+# ------------------------------------------------------------------ 1. RNG streams
+def gen_rng():
+    seeds = [0, 1, 42, 12345]
+    trajs = [0, 1, 2, 7, 1023]
+    steps = [0, 1, 2, 10]
+    traj_tab = np.zeros((len(seeds), len(trajs), 8))
+    samp_tab = np.zeros((len(seeds), len(trajs), len(steps), 8))
+    for a, s in enumerate(seeds):
+        for b, t in enumerate(trajs):
+            traj_tab[a, b] = rutil.make_trajectory_rng(t, base_seed=s).random(8)
+            for c, k in enumerate(steps):
+                samp_tab[a, b, c] = rutil.make_sample_rng(t, base_seed=s, timestep=k).random(8)
+    # rng.choice equivalence table: (p vectors, drawn index, next double)
+    rng = np.random.default_rng(99)
+    ps, idxs, nxt = [], [], []
+    for case in range(64):
+        n = int(rng.integers(2, 9))
+        p = rng.random(n)
+        p /= p.sum()
+        g = rutil.make_trajectory_rng(case, base_seed=7)
+        g.random()
+        idxs.append(int(g.choice(n, p=p)))
+        nxt.append(g.random())
+        pp = np.zeros(8)
+        pp[:n] = p
+        ps.append(pp)
+    save("rng_streams", seeds=np.array(seeds), trajs=np.array(trajs), steps=np.array(steps), traj=traj_tab, sample=samp_tab,
+         choice_p=np.array(ps), choice_idx=np.array(idxs), choice_next=np.array(nxt))
+
+
+# ------------------------------------------------------------------ 2. truncation KATs
+def gen_truncate():
+    rng = np.random.default_rng(5)
+    rows = []
+    specs = []
+    modes = ["discarded_weight", "relative", "hard_cutoff", "relative_discarded_weight"]
+    for case in range(200):
+        n = int(rng.integers(1, 12))
+        s = np.sort(np.abs(rng.standard_normal(n)) * 10.0 ** rng.integers(-8, 1, size=n))[::-1].copy()
+        if case % 17 == 0:
+            s[n // 2:] = 0.0
+        mode = modes[case % 4]
+        thr = float(10.0 ** rng.integers(-14, 1))
+        cap = [None, 1, 2, 4, 8][case % 5]
+        min_keep = [1, 2][case % 2]
+        if cap is not None and cap < min_keep:
+            cap = min_keep
+        keep = linalg.truncate(s, mode=mode, threshold=thr, max_bond_dim=cap, min_keep=min_keep)
+        pad = np.full(12, -1.0)
+        pad[:n] = s
+        rows.append(pad)
+        specs.append([n, modes.index(mode), thr, -1 if cap is None else cap, min_keep, keep])
+    save("truncate_kat", spectra=np.array(rows), specs=np.array(specs, dtype=np.float64))
+
+
+# ------------------------------------------------------------------ 3. local kernels
+def gen_kernels():
+    rng = np.random.default_rng(11)
+
+    def crand(*shape):
+        return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+    out = {}
+    d, D = 2, 3
+    cl, cm, cr = 5, 6, 4
+    a = crand(d, cl, cm)
+    b = crand(d, cm, cr)
+    out["A"], out["B"] = a, b
+    out["merge"] = decomp.merge_two_site(a, b)
+    w1, w2 = crand(d, d, D, D), crand(d, d, D, D)
+    out["W1"], out["W2"] = w1, w2
+    out["merge_mpo"] = prim.merge_mpo_tensors(w1, w2)
+    lenv = crand(cl, D, cl)
+    renv = crand(cr, D, cr)
+    out["L"], out["R"] = lenv, renv
+    out["project_site_2"] = prim.project_site(lenv, renv, out["merge_mpo"], out["merge"])
+    renv1 = crand(cm, D, cm)
+    out["R1"] = renv1
+    out["project_site_1"] = prim.project_site(lenv, renv1, w1, a)
+    out["env_left"] = prim.update_left_environment(a, a, w1, lenv)
+    out["env_right"] = prim.update_right_environment(b, b, w2, renv)
+    c = crand(cl, cr)
+    lb = crand(cl, D, cl)
+    out["C"], out["LB"] = c, lb
+    out["project_bond"] = prim.project_bond(lb, renv, c)
+    # hermitian H_eff from real environments: build from an actual MPS / MPO
+    L = 6
+    m = haar_mps(L, 8, 3)
+    H = MPO.ising(L, 1.0, 0.5)
+    rb = prim.initialize_right_environments(m, H)
+    out.update(pack_tensors("mps", m.tensors))
+    out.update(pack_tensors("mpo", H.tensors))
+    out.update(pack_tensors("renv", rb))
+    th = decomp.merge_two_site(m.tensors[0], m.tensors[1])
+    w = prim.merge_mpo_tensors(H.tensors[0], H.tensors[1])
+    l0 = np.zeros((1, 1, 1), dtype=complex)
+    l0[0, 0, 0] = 1
+    for tol in (1e-4, 1e-12):
+        out[f"krylov_site2_tol{tol:g}"] = prim.update_site(l0, rb[1], w, th, 0.05, krylov_tol=tol)
+    # split with each distribution
+    th2 = crand(4, 3, 5)
+    out["theta_split"] = th2
+    for dist in ("left", "right", "sqrt"):
+        l_, r_ = decomp.split_two_site(th2, [2, 2], svd_distribution=dist, trunc_mode="discarded_weight", threshold=1e-3, max_bond_dim=4)
+        out[f"split_{dist}_recon"] = decomp.merge_two_site(l_, r_)
+        out[f"split_{dist}_keep"] = np.array(l_.shape[2])
+    save("kernels", **out)
+
+
+# ------------------------------------------------------------------ 4. one tdvp() call
+def gen_tdvp():
+    out = {}
+    cases = []
+    for (L, chi, mode, sweeps, seed) in [(2, 2, "2site", 1, 1), (4, 4, "2site", 1, 2), (5, 4, "2site", 2, 3), (10, 16, "2site", 1, 4),
+                                          (4, 4, "1site", 1, 5), (6, 8, "1site", 1, 6), (10, 16, "1site", 2, 7), (6, 2, "2site", 1, 8)]:
+        m = haar_mps(L, chi, seed)
+        H = MPO.ising(L, 1.0, 0.5)
+        params = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), 0)], elapsed_time=0.1, dt=0.1, max_bond_dim=chi,
+                                    svd_threshold=1e-9, krylov_tol=1e-12, tdvp_sweeps=sweeps, tdvp_mode=mode, sample_timesteps=False)
+        key = f"L{L}_chi{chi}_{mode}_s{sweeps}"
+        cases.append(key)
+        out.update(pack_tensors(key + "_in", m.tensors))
+        out.update(pack_tensors(key + "_mpo", H.tensors))
+        tdvp_mod.tdvp(m, H, params)
+        out[key + "_vec"] = m.to_vec()
+        out[key + "_bonds"] = np.array([t.shape[2] for t in m.tensors])
+        out[key + "_norm"] = np.array(m.norm())
+    out["cases"] = np.array(cases)
+    save("tdvp_step", **out)
+
+
+# ------------------------------------------------------------------ 5. dissipation + jumps
+class ScriptedRng:
+    def __init__(self, values):
+        self.values = list(values)
+
+    def random(self):
+        return self.values.pop(0)
+
+    def choice(self, n, p=None):
+        u = self.values.pop(0)
+        cdf = np.cumsum(p)
+        cdf /= cdf[-1]
+        return int(np.searchsorted(cdf, u, side="right"))
+
+
+def gen_noise():
+    out = {}
+    L = 6
+    noise_sets = {
+        "pauli": [{"name": n, "sites": [i], "strength": 0.1 + 0.01 * i} for i in range(L) for n in ("pauli_z", "pauli_x")],
+        "lowering": [{"name": "lowering", "sites": [i], "strength": 0.2} for i in range(L)],
+        "mixed": [{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")],
+        "twosite": [{"name": "pauli_z", "sites": [i], "strength": 0.05} for i in range(L)]
+        + [{"name": "crosstalk_xx", "sites": [i, i + 1], "strength": 0.07} for i in range(L - 1)]
+        + [{"name": "longrange_crosstalk_zz", "sites": [0, 3], "strength": 0.03}],
+    }
+    names = []
+    for nname, procs in noise_sets.items():
+        nm = NoiseModel(procs)
+        for mode, uvals in (("nojump", [0.999999]), ("jump", [0.0, 0.37]), ("jump2", [0.0, 0.93])):
+            m = haar_mps(L, 8, 21)
+            params = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), 0)], elapsed_time=0.1, dt=0.1, max_bond_dim=8,
+                                        svd_threshold=1e-10, sample_timesteps=False)
+            key = f"{nname}_{mode}"
+            names.append(key)
+            out.update(pack_tensors(key + "_in", m.tensors))
+            diss.apply_dissipation(m, nm, 0.1, params)
+            out[key + "_after_diss_vec"] = m.to_vec()
+            out[key + "_dp"] = np.array(float(stoch.calculate_stochastic_factor(m)))
+            if mode != "nojump":
+                mm = copy.deepcopy(m)
+                _, probs = stoch.create_probability_distribution(mm, nm, 0.1, params)
+                out[key + "_probs"] = np.array(probs)
+            m = stoch.stochastic_process(m, nm, 0.1, params, rng=ScriptedRng(uvals))
+            out[key + "_final_vec"] = m.to_vec()
+            out[key + "_bonds"] = np.array([t.shape[2] for t in m.tensors])
+            out[key + "_u"] = np.array(uvals)
+    out["cases"] = np.array(names)
+    save("noise_step", **out)
+
+
+# ------------------------------------------------------------------ 6. full trajectories
+def gen_traj():
+    out = {}
+    L = 5
+    H = MPO.ising(L, 1, 0.5)
+    out.update(pack_tensors("mpo", H.tensors))
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
+    st = MPS(L, state="zeros")
+    st.normalize("B")
+    dps = []
+    orig = stoch.calculate_stochastic_factor
+
+    def spy(state):
+        v = orig(state)
+        dps.append(float(v))
+        return v
+
+    stoch.calculate_stochastic_factor = spy
+    try:
+        for order in (1, 2):
+            for sample in (False, True):
+                params = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), s) for s in range(L)], elapsed_time=1, dt=0.1, num_traj=10,
+                                            max_bond_dim=4, svd_threshold=1e-6, order=order, sample_timesteps=sample, random_seed=42)
+                backend = tjm.analog_tjm_2 if order == 2 else tjm.analog_tjm_1
+                res, diag, dplog = [], [], []
+                for i in range(10):
+                    dps.clear()
+                    r, dg, _ = backend((i, st, noise, params, H))
+                    res.append(np.asarray(r, dtype=np.float64))
+                    diag.append(dg)
+                    dplog.append(np.array(dps + [np.nan] * (64 - len(dps)))[:64])
+                key = f"order{order}_sample{int(sample)}"
+                out[key + "_results"] = np.array(res)
+                out[key + "_diag"] = np.array(diag)
+                out[key + "_dp"] = np.array(dplog)
+    finally:
+        stoch.calculate_stochastic_factor = orig
+    # the reference's own pinned golden (tests/test_simulator.py:191-197)
+    out["pinned_expected_z"] = np.array([0.748947146695782, 0.8720515025769692, 0.8652609567462763, 0.8673233347433466, 0.6872036335377433])
+
+    # closed system, config-1-like: L=10 TFIM chi 16 order 2, traj 0 (all trajectories identical)
+    L2 = 10
+    H2 = MPO.ising(L2, 1, 0.5)
+    out.update(pack_tensors("c1_mpo", H2.tensors))
+    st2 = MPS(L2, state="zeros")
+    st2.normalize("B")
+    for order in (1, 2):
+        p2 = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), s) for s in range(L2)], elapsed_time=1.0, dt=0.1, max_bond_dim=16,
+                                svd_threshold=1e-9, krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=42)
+        backend = tjm.analog_tjm_2 if order == 2 else tjm.analog_tjm_1
+        r, dg, _ = backend((0, st2, None, p2, H2))
+        out[f"c1_order{order}_results"] = np.asarray(r, dtype=np.float64)
+        out[f"c1_order{order}_diag"] = dg
+    # dephasing only (config-2-like, small): L=8 chi 8
+    L3 = 8
+    H3 = MPO.ising(L3, 1, 0.5)
+    out.update(pack_tensors("c2_mpo", H3.tensors))
+    st3 = MPS(L3, state="x+")
+    st3.normalize("B")
+    n3 = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.1} for i in range(L3)])
+    p3 = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), s) for s in range(L3)] + [sp.Observable(gl.X(), s) for s in range(L3)],
+                            elapsed_time=1.0, dt=0.1, max_bond_dim=8, svd_threshold=1e-12, krylov_tol=1e-12, order=1,
+                            sample_timesteps=True, random_seed=42)
+    res, diag, dplog = [], [], []
+    stoch.calculate_stochastic_factor = spy
+    try:
+        for i in range(8):
+            dps.clear()
+            r, dg, _ = tjm.analog_tjm_1((i, st3, n3, p3, H3))
+            res.append(np.asarray(r, dtype=np.float64))
+            diag.append(dg)
+            dplog.append(np.array(dps + [np.nan] * 16)[:16])
+    finally:
+        stoch.calculate_stochastic_factor = orig
+    out["c2_results"] = np.array(res)
+    out["c2_diag"] = np.array(diag)
+    out["c2_dp"] = np.array(dplog)
+    save("trajectories", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["rng", "truncate", "kernels", "tdvp", "noise", "traj"]
+    for w in which:
+        globals()["gen_" + w]()
