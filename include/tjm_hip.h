@@ -1,0 +1,113 @@
+/* C ABI of the MI355X-native Tensor-Jump-Method hot path (libtjm_hip.so).
+ *
+ * Plain pointers and sizes only; device buffers are caller-allocated (the Python host
+ * passes torch.Tensor.data_ptr()).  Every function returns 0 (TJM_OK) or a negative
+ * error code.  All complex data is complex128 stored interleaved (re, im).
+ *
+ * The reference (munich-quantum-toolkit/yaqs) has no FFI; the seam this library sits
+ * behind is its backend-function contract, simulator.py:164-185 / 1539-1547:
+ *     backend((traj_idx, MPS, NoiseModel|None, AnalogSimParams, MPO))
+ *         -> (results[n_obs, T], diagnostics[3, T], MPS|None)
+ * whose body is analog/analog_tjm.py:206-462.  Each entry point below cites the
+ * reference function(s) it replaces (paths relative to src/mqt/yaqs).
+ */
+#ifndef TJM_HIP_H
+#define TJM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TJM_OK 0
+#define TJM_ERR_ARG (-1)
+#define TJM_ERR_HIP (-2)
+#define TJM_ERR_WORKSPACE (-3)
+#define TJM_ERR_NOT_IMPLEMENTED (-4) /* maps to NotImplementedError (dissipation.py:136-138) */
+#define TJM_ERR_NUMERIC (-5)         /* maps to ValueError (stochastic_process.py:178-186)   */
+#define TJM_ERR_STATE (-6)
+
+/* ---- library ------------------------------------------------------------------------ */
+int tjm_version(void);
+const char* tjm_error_string(int code);
+
+/* ---- batched engine: B trajectories in lock-step on one GPU ------------------------- *
+ * Replaces the fork pool of core/parallel_utils.py:331-390 (run_backend_parallel): the
+ * trajectory axis becomes the batch axis of every kernel launch.                          */
+typedef struct tjm_engine tjm_engine;
+
+/* mpo_bond[L+1]: MPO bond dimensions, mpo_bond[0] = mpo_bond[L] = 1 (mpo.py:45-50). */
+int tjm_engine_create(tjm_engine** out, int32_t L, int32_t d, int32_t chi_max, int32_t B, const int32_t* mpo_bond);
+void tjm_engine_destroy(tjm_engine* e);
+size_t tjm_engine_workspace_bytes(const tjm_engine* e);
+/* workspace: device memory of at least workspace_bytes; stream: hipStream_t (0 = default). */
+int tjm_engine_bind(tjm_engine* e, void* dev_workspace, size_t bytes, void* hip_stream);
+/* AnalogSimParams knobs of the path (simulation_parameters.py:520-613).
+ * trunc_mode: 0 discarded_weight, 1 relative, 2 hard_cutoff, 3 relative_discarded_weight.
+ * max_bond <= 0: no cap.  tdvp_mode: 2 = "2site". */
+int tjm_engine_set_params(tjm_engine* e, double dt, double svd_threshold, int32_t trunc_mode, int32_t max_bond,
+                          double krylov_tol, int32_t tdvp_mode, int32_t tdvp_sweeps);
+/* host pointer: per site the tensor (phys_out, phys_in, chi_l, chi_r) C-contiguous, sites concatenated. */
+int tjm_engine_set_mpo(tjm_engine* e, const double* host_mpo);
+/* NoiseModel.processes (noise_model.py:227-243), one entry per process:
+ *   nsites[k] in {1,2}; sites[2k], sites[2k+1]; gamma[k]; pauli[k] = is_pauli(process);
+ *   mats: 32 doubles per process (1-site: 2x2 row-major in the first 8 doubles);
+ *   factors: 16 doubles per process (two 2x2 matrices) when has_factors[k]. */
+int tjm_engine_set_noise(tjm_engine* e, int32_t nproc, const int32_t* nsites, const int32_t* sites, const double* gamma,
+                         const int32_t* pauli, const double* mats, const double* factors, const int32_t* has_factors);
+/* MPS tensors (sigma, chi_l, chi_r) C-contiguous (mps.py:58), sites concatenated; bonds[L+1].
+ * The state is broadcast to all B slots of state set `set` (0 = trajectory state, 1 = measurement copy). */
+int tjm_engine_load_state(tjm_engine* e, int32_t set, const double* host_tensors, const int32_t* bonds);
+int tjm_engine_copy_state(tjm_engine* e, int32_t dst_set, int32_t src_set); /* copy.deepcopy(phi), analog_tjm.py:179 */
+size_t tjm_engine_padded_state_elems(const tjm_engine* e);                   /* complex elements per trajectory */
+int tjm_engine_bond_caps(const tjm_engine* e, int32_t* caps);                /* L+1 padded bond extents */
+int tjm_engine_export_state(tjm_engine* e, int32_t set, int32_t b, double* host_padded, int32_t* bonds);
+/* host uniforms [B][n_per_traj]: the per-trajectory PCG64 double streams of core/random_utils.py:20-69 */
+int tjm_engine_set_uniforms(tjm_engine* e, const double* host_u, int32_t n_per_traj);
+
+/* apply_unitary_evolution -> tdvp -> sweep_2site (analog/evolution.py:24-51, tdvp/tdvp.py:69-111,
+ * tdvp/integrators.py:161-291) on every trajectory of the set. */
+int tjm_engine_tdvp(tjm_engine* e, int32_t set);
+/* apply_dissipation (core/methods/dissipation.py:50-183). */
+int tjm_engine_dissipate(tjm_engine* e, int32_t set, double dt);
+/* stochastic_process (core/methods/stochastic_process.py:190-292); jumped[B], dp[B] optional host outputs. */
+int tjm_engine_stochastic(tjm_engine* e, int32_t set, double dt, int32_t* jumped, double* dp);
+/* Physical-leg moment matrices M[site][b][p][q] = <psi| |p><q|_site |psi> (host, complex128);
+ * <O_site> = sum_pq O[p][q] M[p][q].  Replaces MPS.evaluate_observables / local_expect
+ * (mps.py:961-1047, 1178-1234) for one-site observables. */
+int tjm_engine_site_moments(tjm_engine* e, int32_t set, double* host_M);
+int tjm_engine_bond_dims(tjm_engine* e, int32_t set, int32_t* host_chi); /* [B][L+1]; record_diagnostics mps.py:549-602 */
+int tjm_engine_site0_normsq(tjm_engine* e, int32_t set, double* host_out); /* MPS.norm(0), mps.py:1539-1565 */
+/* counters: matvecs, krylov calls, svds, svd sweeps, two-site updates */
+int tjm_engine_stats(const tjm_engine* e, int64_t* out5);
+
+/* ---- single kernels, exported for parity tests -------------------------------------- */
+typedef struct {
+  const void* A; const void* B; void* C;
+  int32_t M, N, K;
+  int64_t a_rs, a_cs, b_rs, b_cs, c_rs;
+  int32_t nks; int64_t a_ks, b_ks;
+  int32_t nb0, nb1, nb2;
+  int64_t a_b0, a_b1, a_b2, b_b0, b_b1, b_b2, c_b0, c_b1, c_b2;
+  int32_t conjA, conjB;
+} tjm_gemm_desc;
+/* np.tensordot / merge_two_site contractions (decompositions.py:87-102, primitives.py:77-226) */
+int tjm_zgemm_batched(const tjm_gemm_desc* desc, void* hip_stream);
+/* split_two_site (decompositions.py:105-185) + truncate (linalg/svd_utils.py:22-104):
+ * theta[B][m][n] row-major with m = d*capL, n = d*capR;
+ * left[B][d][capL][capM], right[B][d][capM][capR], chi_lrm int32[B][3] = (chiL, chiR, out chiM),
+ * spectrum[B][spec_ld] optional, work = device scratch of tjm_svd_workspace_bytes(max(m,n), B). */
+size_t tjm_svd_workspace_bytes(int32_t max_dim, int32_t B);
+int tjm_svd_split(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t capR, int32_t capM, void* left, void* right,
+                  int32_t distribution, int32_t trunc_mode, double threshold, int32_t max_bond, int32_t min_keep,
+                  int32_t* chi_lrm, double* spectrum, int32_t spec_ld, void* work, size_t work_bytes, int32_t* sweeps_out,
+                  void* hip_stream);
+/* exp(-i dt T_k) e_1 of the Lanczos tridiagonal (matrix_exponential.py:147-163); device pointers. */
+int tjm_tridiag_expm(const double* alpha, const double* beta, int32_t k, double dt, double* out_k_complex, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TJM_HIP_H */

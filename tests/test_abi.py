@@ -1,0 +1,91 @@
+"""CPU-side checks of the C-ABI library: it loads and exports every symbol the header declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "tjm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tjm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from yaqs_amd import _lib
+
+    lib = _lib.load()
+    names = header_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/tjm_hip.h but not exported"
+        assert n in _lib.EXPORTS, f"{n} has no ctypes signature in yaqs_amd/_lib.py"
+    assert lib.tjm_version() >= 100
+    assert lib.tjm_error_string(-4) == b"not implemented"
+
+
+def test_engine_argument_validation_without_gpu():
+    from yaqs_amd import _lib
+
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    bonds = np.array([1, 3, 3, 1], dtype=np.int32)
+    assert lib.tjm_engine_create(ctypes.byref(h), 3, 2, 8, 4, bonds.ctypes.data) == 0
+    assert lib.tjm_engine_workspace_bytes(h) > 0
+    caps = np.zeros(4, dtype=np.int32)
+    lib.tjm_engine_bond_caps(h, caps.ctypes.data)
+    assert list(caps) == [1, 2, 2, 1]
+    # params validation happens on the host
+    assert lib.tjm_engine_set_params(h, -1.0, 1e-6, 0, 8, 1e-4, 2, 1) == -1
+    assert lib.tjm_engine_set_params(h, 0.1, 1e-6, 7, 8, 1e-4, 2, 1) == -1
+    assert lib.tjm_engine_set_params(h, 0.1, 1e-6, 0, 16, 1e-4, 2, 1) == -1  # cap above chi_max
+    assert lib.tjm_engine_set_params(h, 0.1, 1e-6, 0, 8, 1e-4, 2, 1) == 0
+    # operations before bind() are refused, not executed
+    assert lib.tjm_engine_tdvp(h, 0) == -6
+    lib.tjm_engine_destroy(h)
+    bad = np.array([2, 3, 3, 1], dtype=np.int32)
+    assert lib.tjm_engine_create(ctypes.byref(h), 3, 2, 8, 4, bad.ctypes.data) == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+
+    from yaqs_amd import _lib
+    from yaqs_amd.engine import BatchEngine
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.TjmError):
+        BatchEngine(4, 4, 2, [np.zeros((2, 2, 1, 1))] * 4)
+
+
+def test_host_mirror_of_reference_interface():
+    from yaqs_amd.api import AnalogSimParams, NoiseModel, Observable, X, Z, is_pauli
+
+    p = AnalogSimParams(observables=[Observable(Z(), 2), Observable(X(), 0), Observable(Z(), 0)], elapsed_time=1.0, dt=0.1)
+    assert len(p.times) == 11 and p.times[-1] == 1.0
+    assert p.max_bond_dim == 128 and p.svd_threshold == 1e-6 and p.krylov_tol == 1e-4 and p.num_traj == 256  # "balanced"
+    assert p.observable_sorted_indices == (2, 0, 1)  # site-sorted, stable (simulation_parameters.py:419-456)
+    with pytest.raises(ValueError):
+        AnalogSimParams(elapsed_time=0.25, dt=0.1)
+    nm = NoiseModel([{"name": "pauli_z", "sites": [0], "strength": 0.1}, {"name": "lowering", "sites": [1], "strength": 0.1},
+                     {"name": "crosstalk_xy", "sites": [1, 0], "strength": 0.1}, {"name": "longrange_crosstalk_zz", "sites": [0, 3], "strength": 0.1}])
+    assert [is_pauli(q) for q in nm.processes] == [True, False, True, True]
+    assert nm.processes[2]["sites"] == [0, 1]
+    assert np.allclose(nm.processes[2]["matrix"], np.kron([[0, -1j], [1j, 0]], [[0, 1], [1, 0]]))  # swapped -> Y on 0, X on 1
+    with pytest.raises(ValueError):
+        NoiseModel([{"name": "pauli_z", "sites": [0], "strength": -1.0}])
+
+
+def test_trajectory_uniform_streams_match_oracle():
+    from oracle import tjm_oracle as o
+    from yaqs_amd.tjm import sample_uniforms, shard_range, trajectory_uniforms
+
+    assert np.array_equal(trajectory_uniforms(42, 3, 6), o.trajectory_rng(42, 3).random(6))
+    assert np.array_equal(sample_uniforms(42, 3, 5), o.sample_rng(42, 3, 5).random(2))
+    parts = [shard_range(1024, r, 8) for r in range(8)]
+    assert parts[0][0] == 0 and parts[-1][1] == 1024 and all(parts[i][1] == parts[i + 1][0] for i in range(7))

@@ -1,0 +1,201 @@
+"""GPU parity tests for the individual HIP kernels, called through the C ABI, checked against
+NumPy / the CPU oracle on the same seeded inputs."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def crand(rng, *shape):
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from yaqs_amd import _lib
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _lib.load()
+
+
+def run_gemm(lib, **kw):
+    from yaqs_amd._lib import GemmDesc, check
+
+    d = GemmDesc()
+    defaults = dict(nks=1, nb0=1, nb1=1, nb2=1)
+    defaults.update(kw)
+    for k, v in defaults.items():
+        setattr(d, k, v)
+    check(lib.tjm_zgemm_batched(C.byref(d), None), "gemm")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (70, 50, 37), (256, 384, 128), (3, 5, 2), (128, 128, 384), (512, 384, 128)])
+@pytest.mark.parametrize("conjA,conjB", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm_nn_batched(lib, M, N, K, conjA, conjB):
+    rng = np.random.default_rng(M * 1000 + N + K)
+    nb = 3
+    a, b = crand(rng, nb, M, K), crand(rng, nb, K, N)
+    A, B = dev(a), dev(b)
+    Cc = torch.zeros((nb, M, N), dtype=torch.complex128, device="cuda:0")
+    run_gemm(lib, A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, a_rs=K, a_cs=1, b_rs=N, b_cs=1, c_rs=N,
+             nb0=nb, a_b0=M * K, b_b0=K * N, c_b0=M * N, conjA=conjA, conjB=conjB)
+    ref = np.einsum("bmk,bkn->bmn", a.conj() if conjA else a, b.conj() if conjB else b)
+    assert np.allclose(Cc.cpu().numpy(), ref, atol=1e-11 * K)
+
+
+def test_gemm_transposed_operands_ksplit_and_inner_batches(lib):
+    rng = np.random.default_rng(7)
+    # C[b][o] = A^T B_o  (A stored [K][M]), inner batch over o
+    M, N, K, nb, P = 96, 80, 150, 2, 4
+    a, b = crand(rng, nb, K, M), crand(rng, nb, P, K, N)
+    A, B = dev(a), dev(b)
+    Cc = torch.zeros((nb, P, M, N), dtype=torch.complex128, device="cuda:0")
+    run_gemm(lib, A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, a_rs=1, a_cs=M, b_rs=N, b_cs=1, c_rs=N,
+             nb0=nb, nb1=P, a_b0=K * M, b_b0=P * K * N, b_b1=K * N, c_b0=P * M * N, c_b1=M * N, conjA=1)
+    ref = np.einsum("bkm,bpkn->bpmn", a.conj(), b)
+    assert np.allclose(Cc.cpu().numpy(), ref, atol=1e-10)
+    # C = sum_o A[:, o-block] B_o^H  (B stored [N][K], K-split over o)
+    M, N, K, O = 40, 33, 29, 2
+    a, b = crand(rng, nb, M, O, K), crand(rng, nb, O, N, K)
+    A, B = dev(a), dev(b)
+    Cc = torch.zeros((nb, M, N), dtype=torch.complex128, device="cuda:0")
+    run_gemm(lib, A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, a_rs=O * K, a_cs=1, b_rs=1, b_cs=K, c_rs=N,
+             nks=O, a_ks=K, b_ks=N * K, nb0=nb, a_b0=M * O * K, b_b0=O * N * K, c_b0=M * N, conjB=1)
+    ref = np.einsum("bmok,bonk->bmn", a, b.conj())
+    assert np.allclose(Cc.cpu().numpy(), ref, atol=1e-10)
+    # two inner batch levels (merge_two_site into tensor layout)
+    d, ca, cm, cc = 2, 7, 5, 6
+    x, y = crand(rng, nb, d, ca, cm), crand(rng, nb, d, cm, cc)
+    X, Y = dev(x), dev(y)
+    Cc = torch.zeros((nb, d, d, ca, cc), dtype=torch.complex128, device="cuda:0")
+    run_gemm(lib, A=X.data_ptr(), B=Y.data_ptr(), C=Cc.data_ptr(), M=ca, N=cc, K=cm, a_rs=cm, a_cs=1, b_rs=cc, b_cs=1, c_rs=cc,
+             nb0=nb, nb1=d, nb2=d, a_b0=d * ca * cm, a_b1=ca * cm, b_b0=d * cm * cc, b_b2=cm * cc, c_b0=d * d * ca * cc,
+             c_b1=d * ca * cc, c_b2=ca * cc)
+    ref = np.einsum("bsam,btmc->bstac", x, y)
+    assert np.allclose(Cc.cpu().numpy(), ref, atol=1e-11)
+
+
+@pytest.mark.parametrize("k,dt,scale", [(1, 0.05, 1.0), (2, 0.1, 3.0), (7, -0.05, 20.0), (25, 0.1, 60.0), (12, 1.0, 40.0)])
+def test_tridiag_expm_matches_dense(lib, k, dt, scale):
+    import scipy.linalg
+
+    from yaqs_amd._lib import check
+
+    rng = np.random.default_rng(k)
+    alpha = rng.standard_normal(25) * scale
+    beta = np.abs(rng.standard_normal(25)) * scale * 0.5
+    T = np.diag(alpha[:k]) + np.diag(beta[: k - 1], 1) + np.diag(beta[: k - 1], -1)
+    ref = scipy.linalg.expm(-1j * dt * T)[:, 0]
+    a, b = dev(alpha), dev(beta)
+    out = torch.zeros(2 * k, dtype=torch.float64, device="cuda:0")
+    check(lib.tjm_tridiag_expm(a.data_ptr(), b.data_ptr(), k, dt, out.data_ptr(), None), "expm")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.complex128)
+    assert np.allclose(got, ref, atol=5e-13)
+
+
+def svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, min_keep, chiL, chiR):
+    from yaqs_amd._lib import check
+
+    B = theta.shape[0]
+    th = dev(theta)
+    left = torch.zeros((B, d, capL, capM), dtype=torch.complex128, device="cuda:0")
+    right = torch.zeros((B, d, capM, capR), dtype=torch.complex128, device="cuda:0")
+    chi = dev(np.stack([chiL, chiR, np.zeros(B, dtype=np.int32)], axis=1).astype(np.int32))
+    spec_ld = d * max(capL, capR)
+    spec = torch.zeros((B, spec_ld), dtype=torch.float64, device="cuda:0")
+    nbytes = lib.tjm_svd_workspace_bytes(d * max(capL, capR), B)
+    work = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
+    sweeps = C.c_int32(0)
+    check(lib.tjm_svd_split(th.data_ptr(), B, d, capL, capR, capM, left.data_ptr(), right.data_ptr(), dist, mode, thr, max_bond, min_keep,
+                            chi.data_ptr(), spec.data_ptr(), spec_ld, work.data_ptr(), nbytes, C.byref(sweeps), None), "svd_split")
+    torch.cuda.synchronize()
+    return left.cpu().numpy(), right.cpu().numpy(), chi.cpu().numpy()[:, 2], spec.cpu().numpy(), sweeps.value
+
+
+@pytest.mark.parametrize("capL,capR,dist", [(4, 4, 0), (4, 4, 1), (8, 3, 0), (3, 8, 1), (16, 16, 0), (32, 32, 1), (1, 2, 0), (2, 1, 1)])
+def test_svd_split_matches_oracle(lib, capL, capR, dist):
+    from oracle import tjm_oracle as o
+
+    rng = np.random.default_rng(capL * 10 + capR + dist)
+    d, B = 2, 5
+    capM = min(d * capL, d * capR)
+    theta = crand(rng, B, d * capL, d * capR)
+    # make two of them low rank and one tiny
+    theta[1] = crand(rng, d * capL, 1) @ crand(rng, 1, d * capR)
+    theta[2] *= 1e-3
+    chiL = np.full(B, capL, dtype=np.int32)
+    chiR = np.full(B, capR, dtype=np.int32)
+    thr, maxb, mk = 1e-6, max(1, capM - 1), 2 if capM >= 2 else 1
+    left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, capL, capR, capM, dist, 0, thr, maxb, mk, chiL, chiR)
+    for b in range(B):
+        merged = theta[b].reshape(d, capL, d, capR).transpose(0, 2, 1, 3).reshape(d * d, capL, capR)
+        l_ref, r_ref, s_ref = o.split_two_site(merged, [d, d], svd_distribution="right" if dist == 0 else "left", trunc_mode="discarded_weight",
+                                                threshold=thr, max_bond_dim=maxb, min_keep=mk, return_spectrum=True)
+        k = l_ref.shape[2]
+        assert keep[b] == k, (b, keep[b], k)
+        assert np.allclose(spec[b, : len(s_ref)], s_ref, atol=1e-12 * max(1.0, s_ref[0])), b
+        got = o.merge_two_site(left[b][:, :, :k], right[b][:, :k, :])
+        ref = o.merge_two_site(l_ref, r_ref)
+        assert np.allclose(got, ref, atol=1e-11 * max(1.0, s_ref[0])), b
+        # padding beyond keep is exactly zero and the isometric side is isometric
+        assert np.all(left[b][:, :, k:] == 0) and np.all(right[b][:, k:, :] == 0)
+        if dist == 0:
+            iso = left[b][:, :, :k].reshape(d * capL, k)
+            assert np.allclose(iso.conj().T @ iso, np.eye(k), atol=1e-12)
+        else:
+            iso = right[b][:, :k, :].transpose(1, 0, 2).reshape(k, d * capR)
+            assert np.allclose(iso @ iso.conj().T, np.eye(k), atol=1e-12)
+
+
+def test_svd_split_ragged_bonds_and_modes(lib):
+    from oracle import tjm_oracle as o
+
+    rng = np.random.default_rng(3)
+    d, capL, capR, capM, B = 2, 8, 8, 8, 4
+    chiL = np.array([8, 3, 1, 5], dtype=np.int32)
+    chiR = np.array([8, 2, 4, 5], dtype=np.int32)
+    theta = np.zeros((B, d * capL, d * capR), dtype=np.complex128)
+    for b in range(B):
+        t = crand(rng, d, chiL[b], d, chiR[b])
+        full = np.zeros((d, capL, d, capR), dtype=np.complex128)
+        full[:, : chiL[b], :, : chiR[b]] = t
+        theta[b] = full.reshape(d * capL, d * capR)
+    for mode, name, thr in [(0, "discarded_weight", 0.3), (1, "relative", 0.4), (2, "hard_cutoff", 1.5), (3, "relative_discarded_weight", 0.05)]:
+        left, right, keep, spec, _ = svd_split_gpu(lib, theta, d, capL, capR, capM, 0, mode, thr, 8, 1, chiL, chiR)
+        for b in range(B):
+            t = theta[b].reshape(d, capL, d, capR)[:, : chiL[b], :, : chiR[b]]
+            merged = t.transpose(0, 2, 1, 3).reshape(d * d, chiL[b], chiR[b])
+            l_ref, r_ref = o.split_two_site(merged, [d, d], svd_distribution="right", trunc_mode=name, threshold=thr, max_bond_dim=8, min_keep=1)
+            k = l_ref.shape[2]
+            assert keep[b] == k, (name, b, keep[b], k)
+            got = o.merge_two_site(left[b][:, : chiL[b], :k], right[b][:, :k, : chiR[b]])
+            assert np.allclose(got, o.merge_two_site(l_ref, r_ref), atol=1e-11), (name, b)
+
+
+def test_svd_split_chi128_rank_deficient(lib):
+    """Full-size case of the headline config: 256 x 256 theta of rank 128 (a centre-shift merge)."""
+    rng = np.random.default_rng(11)
+    d, cap, B = 2, 128, 2
+    a = crand(rng, B, d * cap, cap) / np.sqrt(d * cap * cap)
+    q = np.linalg.qr(crand(rng, B, d * cap, cap))[0].conj().transpose(0, 2, 1)  # right-isometric (cap x d*cap)
+    theta = a @ q
+    chi = np.full(B, cap, dtype=np.int32)
+    left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, cap, cap, cap, 0, 0, 1e-12, 0, 1, chi, chi)
+    for b in range(B):
+        s_ref = np.linalg.svd(theta[b], compute_uv=False)
+        assert keep[b] == cap
+        assert np.allclose(spec[b, :cap], s_ref[:cap], atol=1e-12)
+        rec = left[b].reshape(d * cap, cap) @ right[b].transpose(1, 0, 2).reshape(cap, d * cap)
+        assert np.allclose(rec, theta[b], atol=1e-12)
+    assert sweeps < 25

@@ -1,0 +1,102 @@
+"""ctypes binding of libtjm_hip.so (the C ABI in include/tjm_hip.h).
+
+The HIP library is the product path: loading raises if the shared object is missing -
+there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtjm_hip.so")
+
+ERRORS = {
+    -1: ValueError,
+    -2: RuntimeError,
+    -3: MemoryError,
+    -4: NotImplementedError,
+    -5: ValueError,
+    -6: RuntimeError,
+}
+
+
+class TjmError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("a_rs", C.c_int64), ("a_cs", C.c_int64), ("b_rs", C.c_int64), ("b_cs", C.c_int64), ("c_rs", C.c_int64),
+        ("nks", C.c_int32), ("a_ks", C.c_int64), ("b_ks", C.c_int64),
+        ("nb0", C.c_int32), ("nb1", C.c_int32), ("nb2", C.c_int32),
+        ("a_b0", C.c_int64), ("a_b1", C.c_int64), ("a_b2", C.c_int64),
+        ("b_b0", C.c_int64), ("b_b1", C.c_int64), ("b_b2", C.c_int64),
+        ("c_b0", C.c_int64), ("c_b1", C.c_int64), ("c_b2", C.c_int64),
+        ("conjA", C.c_int32), ("conjB", C.c_int32),
+    ]
+
+
+V = C.c_void_p
+I = C.c_int32
+D = C.c_double
+EXPORTS = {
+    # name: (restype, argtypes) - every symbol declared in include/tjm_hip.h
+    "tjm_version": (C.c_int, []),
+    "tjm_error_string": (C.c_char_p, [C.c_int]),
+    "tjm_engine_create": (C.c_int, [C.POINTER(V), I, I, I, I, V]),
+    "tjm_engine_destroy": (None, [V]),
+    "tjm_engine_workspace_bytes": (C.c_size_t, [V]),
+    "tjm_engine_bind": (C.c_int, [V, V, C.c_size_t, V]),
+    "tjm_engine_set_params": (C.c_int, [V, D, D, I, I, D, I, I]),
+    "tjm_engine_set_mpo": (C.c_int, [V, V]),
+    "tjm_engine_set_noise": (C.c_int, [V, I, V, V, V, V, V, V, V]),
+    "tjm_engine_load_state": (C.c_int, [V, I, V, V]),
+    "tjm_engine_copy_state": (C.c_int, [V, I, I]),
+    "tjm_engine_padded_state_elems": (C.c_size_t, [V]),
+    "tjm_engine_bond_caps": (C.c_int, [V, V]),
+    "tjm_engine_export_state": (C.c_int, [V, I, I, V, V]),
+    "tjm_engine_set_uniforms": (C.c_int, [V, V, I]),
+    "tjm_engine_tdvp": (C.c_int, [V, I]),
+    "tjm_engine_dissipate": (C.c_int, [V, I, D]),
+    "tjm_engine_stochastic": (C.c_int, [V, I, D, V, V]),
+    "tjm_engine_site_moments": (C.c_int, [V, I, V]),
+    "tjm_engine_bond_dims": (C.c_int, [V, I, V]),
+    "tjm_engine_site0_normsq": (C.c_int, [V, I, V]),
+    "tjm_engine_stats": (C.c_int, [V, V]),
+    "tjm_zgemm_batched": (C.c_int, [C.POINTER(GemmDesc), V]),
+    "tjm_svd_workspace_bytes": (C.c_size_t, [I, I]),
+    "tjm_svd_split": (C.c_int, [V, I, I, I, I, I, V, V, I, I, D, I, I, V, V, I, V, C.c_size_t, V, V]),
+    "tjm_tridiag_expm": (C.c_int, [V, V, I, D, V, V]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libtjm_hip.so and attach signatures.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TjmError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C yaqs_amd/csrc).  yaqs_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code == 0:
+        return
+    msg = load().tjm_error_string(code).decode()
+    exc = ERRORS.get(code, TjmError)
+    raise exc(f"tjm_hip {what}: {msg} (code {code})")

@@ -1,0 +1,371 @@
+"""Host-side mirror of the reference's simulation interface for the TJM path.
+
+Same names, argument meaning and error behaviour as the reference objects the path
+touches (paths relative to /root/reference/src/mqt/yaqs):
+
+* ``Observable``, ``AnalogSimParams``   core/data_structures/simulation_parameters.py:330-613
+* ``NoiseModel`` / ``is_pauli``         core/data_structures/noise_model.py:227-665
+* ``MPS`` (product / Haar states)       core/data_structures/mps.py:54-301
+* ``MPO.ising`` / ``MPO.heisenberg``    core/data_structures/mpo.py:326-406 (plain FSM form)
+* ``Result``                            core/data_structures/result.py:34-189
+* ``Simulator.run``                     simulator.py:1173-1312, 1444-1679 (MPS analog branch)
+
+Only host bookkeeping lives here; every tensor operation runs in the HIP library.
+"""
+from __future__ import annotations
+
+import re
+from dataclasses import dataclass
+from typing import Any, Sequence
+
+import numpy as np
+
+C128 = np.complex128
+
+_X = np.array([[0, 1], [1, 0]], dtype=C128)
+_Y = np.array([[0, -1j], [1j, 0]], dtype=C128)
+_Z = np.array([[1, 0], [0, -1]], dtype=C128)
+_I = np.eye(2, dtype=C128)
+PAULI_MAP = {"x": _X, "y": _Y, "z": _Z}
+
+
+# ------------------------------------------------------------------ gates / observables
+@dataclass
+class BaseGate:
+    name: str
+    matrix: np.ndarray
+    interaction: int = 1
+    sites: Any = None
+
+    def set_sites(self, sites):
+        self.sites = sites
+
+
+def X() -> BaseGate:
+    return BaseGate("x", _X.copy())
+
+
+def Y() -> BaseGate:
+    return BaseGate("y", _Y.copy())
+
+
+def Z() -> BaseGate:
+    return BaseGate("z", _Z.copy())
+
+
+def Id() -> BaseGate:
+    return BaseGate("id", _I.copy())
+
+
+class Observable:
+    """``Observable(gate, sites)`` (simulation_parameters.py:330-416); one-site local observables."""
+
+    def __init__(self, gate: BaseGate | str | np.ndarray, sites: int | list[int] | None = None):
+        if isinstance(gate, str):
+            table = {"x": X, "y": Y, "z": Z, "id": Id}
+            if gate.lower() not in table:
+                raise ValueError(f"Unknown observable {gate!r}")
+            gate = table[gate.lower()]()
+        elif isinstance(gate, np.ndarray):
+            gate = BaseGate("local", np.asarray(gate, dtype=C128), interaction=1 if gate.shape == (2, 2) else 2)
+        self.gate = gate
+        assert sites is not None
+        self.sites = sites
+        self.gate.set_sites(sites)
+
+    @property
+    def first_site(self) -> int:
+        return self.sites[0] if isinstance(self.sites, (list, tuple)) else int(self.sites)
+
+
+# ------------------------------------------------------------------ parameters
+SIMULATION_PRESETS = {
+    # simulation_parameters.py:46-51
+    "fast": dict(svd_threshold=1e-4, max_bond_dim=64, num_traj=64, krylov_tol=1e-3),
+    "balanced": dict(svd_threshold=1e-6, max_bond_dim=128, num_traj=256, krylov_tol=1e-4),
+    "accurate": dict(svd_threshold=1e-9, max_bond_dim=256, num_traj=1024, krylov_tol=1e-6),
+    "exact": dict(svd_threshold=1e-12, max_bond_dim=None, num_traj=1024, krylov_tol=1e-12),
+}
+_USE_PRESET = object()
+_TRUNC = ("discarded_weight", "relative", "hard_cutoff", "relative_discarded_weight")
+
+
+class AnalogSimParams:
+    """Numerical knobs of the analog TJM path (simulation_parameters.py:520-613)."""
+
+    def __init__(self, observables=None, elapsed_time: float = 0.1, dt: float = 0.1, num_traj: int | None = None,
+                 max_bond_dim=_USE_PRESET, trunc_mode: str = "discarded_weight", svd_threshold: float | None = None,
+                 krylov_tol: float | None = None, order: int = 1, *, preset: str = "balanced", sample_timesteps: bool = True,
+                 get_state: bool = False, random_seed: int | None = None, tdvp_sweeps: int = 1, tdvp_mode: str = "2site"):
+        if preset not in SIMULATION_PRESETS:
+            raise ValueError(f"Unknown preset {preset!r}")
+        pv = SIMULATION_PRESETS[preset]
+        if not (np.isfinite(dt) and dt > 0):
+            raise ValueError("dt must be finite and > 0")
+        if not (np.isfinite(elapsed_time) and elapsed_time >= 0):
+            raise ValueError("elapsed_time must be finite and >= 0")
+        n_steps = int(round(elapsed_time / dt))
+        if abs(n_steps * dt - elapsed_time) > 1e-9 * max(1.0, abs(elapsed_time)):
+            raise ValueError("elapsed_time must be an integer multiple of dt")
+        if trunc_mode not in _TRUNC:
+            raise ValueError(f"Unknown truncation mode: {trunc_mode!r}")
+        if tdvp_sweeps < 1:
+            raise ValueError("tdvp_sweeps must be >= 1")
+        if tdvp_mode not in ("1site", "2site", "dynamic"):
+            raise ValueError(f"Unknown tdvp_mode {tdvp_mode!r}")
+        self.preset = preset
+        self.observables = [] if observables is None else list(observables)
+        self.elapsed_time = float(elapsed_time)
+        self.dt = float(dt)
+        self.times = self.dt * np.arange(n_steps + 1, dtype=np.float64)
+        if n_steps > 0:
+            self.times[-1] = self.elapsed_time
+        self.sample_timesteps = sample_timesteps
+        self.num_traj = num_traj if num_traj is not None else pv["num_traj"]
+        self.max_bond_dim = pv["max_bond_dim"] if max_bond_dim is _USE_PRESET else max_bond_dim
+        self.trunc_mode = trunc_mode
+        self.svd_threshold = svd_threshold if svd_threshold is not None else pv["svd_threshold"]
+        self.krylov_tol = krylov_tol if krylov_tol is not None else pv["krylov_tol"]
+        self.order = order
+        self.get_state = get_state
+        self.random_seed = random_seed
+        self.tdvp_sweeps = tdvp_sweeps
+        self.tdvp_mode = tdvp_mode
+
+    def _ordering(self):
+        idx = sorted(range(len(self.observables)), key=lambda i: (self.observables[i].first_site, i))
+        return idx
+
+    @property
+    def sorted_observables(self):
+        return [self.observables[i] for i in self._ordering()]
+
+    @property
+    def observable_sorted_indices(self):
+        out = [0] * len(self.observables)
+        for row, user in enumerate(self._ordering()):
+            out[user] = row
+        return tuple(out)
+
+
+# ------------------------------------------------------------------ noise
+_LIB_OPS = {
+    "pauli_x": _X, "pauli_y": _Y, "pauli_z": _Z,
+    "x": _X, "y": _Y, "z": _Z,
+    "lowering": np.array([[0, 1], [0, 0]], dtype=C128),
+    "raising": np.array([[0, 0], [1, 0]], dtype=C128),
+    "dephasing": _Z, "bitflip": _X, "bitphaseflip": _Y,
+}
+
+
+def _unit_phase_of(m: np.ndarray, refs) -> bool:
+    for ref in refs:
+        nz = np.abs(ref) > 0
+        if np.any(np.abs(m[~nz]) > 1e-12):
+            continue
+        r = m[nz] / ref[nz]
+        if np.allclose(r, r[0], atol=1e-12) and abs(abs(r[0]) - 1.0) < 1e-12:
+            return True
+    return False
+
+
+def is_pauli(proc: dict[str, Any]) -> bool:
+    """noise_model.py:644-665."""
+    sites = proc["sites"]
+    singles = [_X, _Y, _Z]
+    if len(sites) == 1:
+        return "matrix" in proc and np.shape(proc["matrix"]) == (2, 2) and _unit_phase_of(np.asarray(proc["matrix"], dtype=C128), singles)
+    if len(sites) != 2:
+        return False
+    if abs(sites[1] - sites[0]) == 1 and "matrix" in proc:
+        return np.shape(proc["matrix"]) == (4, 4) and _unit_phase_of(np.asarray(proc["matrix"], dtype=C128), [np.kron(a, b) for a in singles for b in singles])
+    if abs(sites[1] - sites[0]) > 1 and "factors" in proc:
+        return all(np.shape(f) == (2, 2) and _unit_phase_of(np.asarray(f, dtype=C128), singles) for f in proc["factors"])
+    return False
+
+
+class NoiseModel:
+    """``NoiseModel(processes)`` (noise_model.py:227-490): list of {name, sites, strength[, matrix|factors]}."""
+
+    def __init__(self, processes: Sequence[dict[str, Any]] | None = None):
+        self.processes: list[dict[str, Any]] = []
+        if processes is None:
+            return
+        if not isinstance(processes, (list, tuple)):
+            raise TypeError("processes must be a list or tuple of dictionaries.")
+        for original in processes:
+            for key in ("name", "sites", "strength"):
+                if key not in original:
+                    raise ValueError(f"Each process must have a '{key}' key.")
+            p = dict(original)
+            sites = [int(s) for s in p["sites"]]
+            g = float(p["strength"])
+            if not np.isfinite(g) or g < 0:
+                raise ValueError("Noise strengths must be finite and nonnegative.")
+            p["strength"] = g
+            if len(sites) == 1:
+                if "matrix" in p:
+                    p["matrix"] = np.asarray(p["matrix"], dtype=C128)
+                else:
+                    if p["name"] not in _LIB_OPS:
+                        raise ValueError(f"Unknown noise operator {p['name']!r}")
+                    p["matrix"] = _LIB_OPS[p["name"]].copy()
+            elif len(sites) == 2:
+                swapped = sites[0] > sites[1]
+                sites = sorted(sites)
+                m = re.fullmatch(r"(?:longrange_)?crosstalk_([xyz])([xyz])", str(p["name"]))
+                if abs(sites[1] - sites[0]) == 1:
+                    if "matrix" in p:
+                        if swapped:
+                            raise ValueError("Custom full two-site matrices require ascending site order.")
+                        p["matrix"] = np.asarray(p["matrix"], dtype=C128)
+                    elif m:
+                        a, b = (m.group(2), m.group(1)) if swapped else (m.group(1), m.group(2))
+                        p["matrix"] = np.kron(PAULI_MAP[a], PAULI_MAP[b])
+                    else:
+                        raise ValueError(f"Unknown two-site noise operator {p['name']!r}")
+                else:
+                    if "factors" in p:
+                        f = p["factors"]
+                        p["factors"] = (np.asarray(f[0], dtype=C128), np.asarray(f[1], dtype=C128))
+                    elif m:
+                        a, b = (m.group(2), m.group(1)) if swapped else (m.group(1), m.group(2))
+                        p["factors"] = (PAULI_MAP[a].copy(), PAULI_MAP[b].copy())
+                    else:
+                        raise ValueError("Long-range two-site processes need 'factors' or a crosstalk name.")
+            else:
+                raise ValueError("Noise processes must act on one or two sites.")
+            p["sites"] = sites
+            self.processes.append(p)
+
+
+# ------------------------------------------------------------------ states / operators
+class MPS:
+    """Tensor list with index order (sigma, chi_left, chi_right) (mps.py:58)."""
+
+    def __init__(self, length: int, tensors: list[np.ndarray] | None = None, state: str = "zeros", pad: int | None = None,
+                 rng: np.random.Generator | None = None):
+        self.length = length
+        self.physical_dimensions = [2] * length
+        if tensors is not None:
+            assert len(tensors) == length
+            self.tensors = [np.asarray(t, dtype=C128) for t in tensors]
+            return
+        s = 1 / np.sqrt(2)
+        self.tensors = []
+        if state == "haar-random":
+            chi = 1 if pad is None else pad
+            caps = self.bond_caps(length, chi)
+            rng = rng if rng is not None else np.random.default_rng()
+            for i in range(length):
+                cl, cr = caps[i], caps[i + 1]
+                x = rng.standard_normal((2 * cl, cr)) + 1j * rng.standard_normal((2 * cl, cr))
+                q, r = np.linalg.qr(x, mode="reduced")
+                dg = np.diag(r)
+                ph = np.ones_like(dg, dtype=C128)
+                nz = np.abs(dg) > 0
+                ph[nz] = dg[nz] / np.abs(dg[nz])
+                self.tensors.append((q / ph[np.newaxis, :]).reshape(2, cl, cr).astype(C128))
+            return
+        for i in range(length):
+            v = np.zeros(2, dtype=C128)
+            if state == "zeros":
+                v[0] = 1
+            elif state == "ones":
+                v[1] = 1
+            elif state == "x+":
+                v[:] = (s, s)
+            elif state == "x-":
+                v[:] = (s, -s)
+            elif state == "y+":
+                v[:] = (s, 1j * s)
+            elif state == "y-":
+                v[:] = (s, -1j * s)
+            elif state == "Neel":
+                v[0 if i % 2 else 1] = 1
+            elif state == "wall":
+                v[0 if i < length // 2 else 1] = 1
+            else:
+                raise ValueError("Invalid state string")
+            self.tensors.append(v.reshape(2, 1, 1))
+
+    @staticmethod
+    def bond_caps(length: int, target: int, d: int = 2) -> list[int]:
+        caps = [1] * (length + 1)
+        left = 1
+        for i in range(1, length):
+            left *= d
+            caps[i] = left
+        right = 1
+        for i in range(length - 1, 0, -1):
+            right *= d
+            caps[i] = min(caps[i], right, target)
+        return caps
+
+
+class MPO:
+    """MPO tensors with index order (phys_out, phys_in, chi_left, chi_right) (mpo.py:45-50)."""
+
+    def __init__(self, tensors: list[np.ndarray] | None = None):
+        self.tensors = [] if tensors is None else [np.asarray(t, dtype=C128) for t in tensors]
+
+    @property
+    def length(self) -> int:
+        return len(self.tensors)
+
+    @classmethod
+    def _fsm(cls, length: int, w: np.ndarray) -> "MPO":
+        D = w.shape[0]
+        bulk = w.transpose(2, 3, 0, 1)
+        t = []
+        for i in range(length):
+            if i == 0:
+                t.append(bulk[:, :, 0:1, :].copy())
+            elif i == length - 1:
+                t.append(bulk[:, :, :, D - 1:D].copy())
+            else:
+                t.append(bulk.copy())
+        return cls(t)
+
+    @classmethod
+    def ising(cls, length: int, J: float, g: float) -> "MPO":
+        """H = -J sum Z_i Z_{i+1} - g sum X_i (sign convention of mpo.py:326-363)."""
+        w = np.zeros((3, 3, 2, 2), dtype=C128)
+        w[0, 0] = _I
+        w[0, 1] = -J * _Z
+        w[0, 2] = -g * _X
+        w[1, 2] = _Z
+        w[2, 2] = _I
+        return cls._fsm(length, w)
+
+    @classmethod
+    def heisenberg(cls, length: int, Jx: float, Jy: float, Jz: float, h: float = 0.0) -> "MPO":
+        """H = -sum (Jx XX + Jy YY + Jz ZZ) - h sum Z (mpo.py:365-406)."""
+        w = np.zeros((5, 5, 2, 2), dtype=C128)
+        w[0, 0] = _I
+        w[0, 1] = -Jx * _X
+        w[0, 2] = -Jy * _Y
+        w[0, 3] = -Jz * _Z
+        w[0, 4] = -h * _Z
+        w[1, 4] = _X
+        w[2, 4] = _Y
+        w[3, 4] = _Z
+        w[4, 4] = _I
+        return cls._fsm(length, w)
+
+
+# ------------------------------------------------------------------ result
+class Result:
+    """Averaged observables and diagnostics (result.py:34-189)."""
+
+    def __init__(self, sim_params: AnalogSimParams, results_sorted: np.ndarray, diagnostics: np.ndarray):
+        # results_sorted: [num_traj, n_obs_sorted, T]; diagnostics: [num_traj, 3, T]
+        self.sim_params = sim_params
+        self.observables = list(sim_params.observables)
+        self.times = sim_params.times if sim_params.sample_timesteps else sim_params.times[-1:]
+        idx = sim_params.observable_sorted_indices
+        self.trajectories = [results_sorted[:, idx[u], :] for u in range(len(self.observables))]
+        self.expectation_values = [np.mean(t, axis=0) for t in self.trajectories]
+        d = np.mean(diagnostics, axis=0)
+        self.runtime_cost, self.max_bond, self.total_bond = d[0], d[1], d[2]
+        self.trajectory_diagnostics = diagnostics

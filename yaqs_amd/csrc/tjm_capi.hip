@@ -1,0 +1,172 @@
+// extern "C" surface of libtjm_hip.so (declared in include/tjm_hip.h).
+#include <cstring>
+#include <new>
+
+#include "../../include/tjm_hip.h"
+#include "tjm_engine.h"
+
+using namespace tjm;
+
+struct tjm_engine {
+  Engine impl;
+};
+
+extern "C" {
+
+int tjm_version(void) { return 100; }
+
+const char* tjm_error_string(int code) {
+  switch (code) {
+    case TJM_OK: return "ok";
+    case TJM_ERR_ARG: return "invalid argument";
+    case TJM_ERR_HIP: return "HIP runtime error";
+    case TJM_ERR_WORKSPACE: return "workspace too small";
+    case TJM_ERR_NOT_IMPLEMENTED: return "not implemented";
+    case TJM_ERR_NUMERIC: return "numerical failure";
+    case TJM_ERR_STATE: return "engine state error";
+    default: return "unknown";
+  }
+}
+
+int tjm_engine_create(tjm_engine** out, int32_t L, int32_t d, int32_t chi_max, int32_t B, const int32_t* mpo_bond) {
+  if (!out || !mpo_bond) return TJM_ERR_ARG;
+  tjm_engine* e = new (std::nothrow) tjm_engine();
+  if (!e) return TJM_ERR_ARG;
+  const int rc = e->impl.create(L, d, chi_max, B, mpo_bond);
+  if (rc != TJM_OK) { delete e; return rc; }
+  *out = e;
+  return TJM_OK;
+}
+
+void tjm_engine_destroy(tjm_engine* e) { delete e; }
+
+size_t tjm_engine_workspace_bytes(const tjm_engine* e) { return e ? e->impl.workspace_bytes() : 0; }
+
+int tjm_engine_bind(tjm_engine* e, void* ws, size_t bytes, void* stream) {
+  if (!e || !ws) return TJM_ERR_ARG;
+  return e->impl.bind(ws, bytes, static_cast<hipStream_t>(stream));
+}
+
+int tjm_engine_set_params(tjm_engine* e, double dt, double svd_threshold, int32_t trunc_mode, int32_t max_bond, double krylov_tol,
+                          int32_t tdvp_mode, int32_t tdvp_sweeps) {
+  if (!e || !(dt > 0) || trunc_mode < 0 || trunc_mode > 3 || tdvp_sweeps < 1) return TJM_ERR_ARG;
+  if (max_bond > 0 && max_bond > e->impl.chi_max) return TJM_ERR_ARG;
+  e->impl.dt = dt; e->impl.svd_threshold = svd_threshold; e->impl.trunc_mode = trunc_mode; e->impl.max_bond = max_bond;
+  e->impl.krylov_tol = krylov_tol; e->impl.tdvp_mode = tdvp_mode; e->impl.tdvp_sweeps = tdvp_sweeps;
+  return TJM_OK;
+}
+
+int tjm_engine_set_mpo(tjm_engine* e, const double* host_mpo) { return (e && host_mpo) ? e->impl.set_mpo(host_mpo) : TJM_ERR_ARG; }
+
+int tjm_engine_set_noise(tjm_engine* e, int32_t nproc, const int32_t* nsites, const int32_t* sites, const double* gamma,
+                         const int32_t* pauli, const double* mats, const double* factors, const int32_t* has_factors) {
+  if (!e || nproc < 0) return TJM_ERR_ARG;
+  std::vector<NoiseProc> v(nproc);
+  for (int k = 0; k < nproc; ++k) {
+    NoiseProc& p = v[k];
+    std::memset(&p, 0, sizeof(p));
+    p.nsites = nsites[k]; p.site0 = sites[2 * k]; p.site1 = sites[2 * k + 1]; p.gamma = gamma[k]; p.pauli = pauli[k];
+    std::memcpy(p.mat, mats + 32 * (size_t)k, 32 * sizeof(double));
+    p.has_factors = has_factors ? has_factors[k] : 0;
+    if (p.has_factors && factors) {
+      std::memcpy(p.f0, factors + 16 * (size_t)k, 8 * sizeof(double));
+      std::memcpy(p.f1, factors + 16 * (size_t)k + 8, 8 * sizeof(double));
+    }
+    if (p.nsites == 2 && p.site1 - p.site0 > 1 && !p.has_factors) return TJM_ERR_ARG;
+  }
+  return e->impl.set_noise(v);
+}
+
+int tjm_engine_load_state(tjm_engine* e, int32_t set, const double* t, const int32_t* bonds) {
+  return (e && t && bonds) ? e->impl.load_state(set, t, bonds) : TJM_ERR_ARG;
+}
+int tjm_engine_copy_state(tjm_engine* e, int32_t dst, int32_t src) { return e ? e->impl.copy_state(dst, src) : TJM_ERR_ARG; }
+
+size_t tjm_engine_padded_state_elems(const tjm_engine* e) {
+  size_t n = 0;
+  for (int i = 0; i < e->impl.L; ++i) n += (size_t)e->impl.d * e->impl.cap[i] * e->impl.cap[i + 1];
+  return n;
+}
+int tjm_engine_bond_caps(const tjm_engine* e, int32_t* caps) {
+  for (int i = 0; i <= e->impl.L; ++i) caps[i] = e->impl.cap[i];
+  return TJM_OK;
+}
+int tjm_engine_export_state(tjm_engine* e, int32_t set, int32_t b, double* out, int32_t* bonds) {
+  return (e && out && bonds && set >= 0 && set < 2) ? e->impl.export_state(set, b, out, bonds) : TJM_ERR_ARG;
+}
+int tjm_engine_set_uniforms(tjm_engine* e, const double* u, int32_t n) { return (e && u && n > 0) ? e->impl.set_uniforms(u, n) : TJM_ERR_ARG; }
+int tjm_engine_tdvp(tjm_engine* e, int32_t set) { return (e && set >= 0 && set < 2) ? e->impl.tdvp(set) : TJM_ERR_ARG; }
+int tjm_engine_dissipate(tjm_engine* e, int32_t set, double dt) { return (e && set >= 0 && set < 2) ? e->impl.dissipate(set, dt) : TJM_ERR_ARG; }
+int tjm_engine_stochastic(tjm_engine* e, int32_t set, double dt, int32_t* jumped, double* dp) {
+  return (e && set >= 0 && set < 2) ? e->impl.stochastic(set, dt, jumped, dp) : TJM_ERR_ARG;
+}
+int tjm_engine_site_moments(tjm_engine* e, int32_t set, double* M) { return (e && M) ? e->impl.site_moments(set, M) : TJM_ERR_ARG; }
+int tjm_engine_bond_dims(tjm_engine* e, int32_t set, int32_t* chi) { return (e && chi) ? e->impl.bond_dims(set, chi) : TJM_ERR_ARG; }
+int tjm_engine_site0_normsq(tjm_engine* e, int32_t set, double* out) { return (e && out) ? e->impl.site_normsq0(set, out) : TJM_ERR_ARG; }
+int tjm_engine_stats(const tjm_engine* e, int64_t* o) {
+  if (!e || !o) return TJM_ERR_ARG;
+  o[0] = e->impl.stat_matvecs; o[1] = e->impl.stat_krylov_calls; o[2] = e->impl.stat_svds; o[3] = e->impl.stat_svd_sweeps;
+  o[4] = e->impl.stat_site_updates;
+  return TJM_OK;
+}
+
+int tjm_zgemm_batched(const tjm_gemm_desc* t, void* stream) {
+  if (!t) return TJM_ERR_ARG;
+  GemmDesc g;
+  std::memset(&g, 0, sizeof(g));
+  g.A = static_cast<const cplx*>(t->A); g.B = static_cast<const cplx*>(t->B); g.C = static_cast<cplx*>(t->C);
+  g.M = t->M; g.N = t->N; g.K = t->K;
+  g.a_rs = t->a_rs; g.a_cs = t->a_cs; g.b_rs = t->b_rs; g.b_cs = t->b_cs; g.c_rs = t->c_rs;
+  g.nks = t->nks; g.a_ks = t->a_ks; g.b_ks = t->b_ks;
+  g.nb0 = t->nb0; g.nb1 = t->nb1; g.nb2 = t->nb2;
+  g.a_b0 = t->a_b0; g.a_b1 = t->a_b1; g.a_b2 = t->a_b2;
+  g.b_b0 = t->b_b0; g.b_b1 = t->b_b1; g.b_b2 = t->b_b2;
+  g.c_b0 = t->c_b0; g.c_b1 = t->c_b1; g.c_b2 = t->c_b2;
+  g.conjA = t->conjA; g.conjB = t->conjB;
+  return launch_gemm(g, static_cast<hipStream_t>(stream));
+}
+
+size_t tjm_svd_workspace_bytes(int32_t max_dim, int32_t B) { return svd_workspace_bytes(max_dim, B) + (size_t)B * 64; }
+
+int tjm_svd_split(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t capR, int32_t capM, void* left, void* right,
+                  int32_t distribution, int32_t trunc_mode, double threshold, int32_t max_bond, int32_t min_keep, int32_t* chi_lrm,
+                  double* spectrum, int32_t spec_ld, void* work, size_t work_bytes, int32_t* sweeps_out, void* stream_) {
+  if (!theta || !left || !right || !chi_lrm || !work) return TJM_ERR_ARG;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int m = d * capL, n = d * capR;
+  const int mx = m > n ? m : n;
+  if (work_bytes < tjm_svd_workspace_bytes(mx, B)) return TJM_ERR_WORKSPACE;
+  const int p = (mx + 15) / 16 * 16;
+  char* w = static_cast<char*>(work);
+  auto take = [&](size_t nbytes) { char* q = w; w += (nbytes + 255) / 256 * 256; return q; };
+  SvdWorkspace sw;
+  sw.y_b0 = (long)p * 2 * p;
+  sw.Y = reinterpret_cast<cplx*>(take((size_t)B * sw.y_b0 * sizeof(cplx)));
+  sw.norms = reinterpret_cast<double*>(take((size_t)B * p * sizeof(double)));
+  sw.perm = reinterpret_cast<int*>(take((size_t)B * p * sizeof(int)));
+  sw.fro2 = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
+  sw.nrot = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  sw.done = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  sw.n_active = reinterpret_cast<int*>(take(256));
+  static int* pinned = nullptr;
+  if (!pinned) TJM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pinned), 256, hipHostMallocDefault));
+  sw.h_pinned = pinned;
+  SvdSplitDesc s;
+  s.theta = static_cast<const cplx*>(theta); s.theta_b0 = (long)m * n; s.ld_theta = n; s.m = m; s.n = n; s.d = d;
+  s.capL = capL; s.capR = capR; s.capM = capM;
+  s.left = static_cast<cplx*>(left); s.right = static_cast<cplx*>(right);
+  s.left_b0 = (long)d * capL * capM; s.right_b0 = (long)d * capM * capR;
+  s.distribution = distribution; s.trunc_mode = trunc_mode; s.threshold = threshold; s.max_bond = max_bond; s.min_keep = min_keep;
+  s.chiL = chi_lrm; s.chiR = chi_lrm + 1; s.chiM = chi_lrm + 2; s.chi_stride = 3;
+  s.spectrum = spectrum; s.spec_ld = spec_ld; s.nb0 = B; s.ids = nullptr;
+  int sweeps = 0;
+  const int rc = svd_split(s, sw, stream, &sweeps);
+  if (sweeps_out) *sweeps_out = sweeps;
+  return rc;
+}
+
+int tjm_tridiag_expm(const double* alpha, const double* beta, int32_t k, double dt, double* out, void* stream) {
+  return launch_tridiag_expm_test(alpha, beta, k, dt, out, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// Batched TJM engine: B trajectories advance the same site in lock-step on one GPU.
+// Host-side control (this class) issues the kernels of tjm_gemm / tjm_kernels / tjm_svd on one
+// HIP stream; all tensors live in a caller-provided device workspace.
+#pragma once
+#include <vector>
+
+#include "tjm_kernels.h"
+
+namespace tjm {
+
+struct NoiseProc {
+  int nsites;          // 1 or 2
+  int site0, site1;
+  double gamma;
+  int pauli;           // unit-phase Pauli (L^dag L = 1)
+  cplx mat[16];        // 1-site: d x d ; adjacent 2-site: d^2 x d^2
+  cplx f0[4], f1[4];   // long-range factors
+  int has_factors;
+};
+
+// One set of MPS tensors for the whole batch (the trajectory state phi, or the measurement copy psi).
+struct StateSet {
+  std::vector<cplx*> A;  // per site: [B][d][cap[i]][cap[i+1]]
+  int* chi = nullptr;    // device [B][L+1] actual bond dimensions
+};
+
+class Engine {
+ public:
+  int L = 0, d = 2, chi_max = 0, B = 0, mmax = 25;
+  std::vector<int> cap, Dm;
+  int Dmax = 1;
+  hipStream_t stream = nullptr;
+  // numerical parameters
+  double dt = 0.1, svd_threshold = 1e-6, krylov_tol = 1e-4;
+  int trunc_mode = 0, max_bond = 0, tdvp_mode = 2, tdvp_sweeps = 1;
+  // statistics
+  long stat_matvecs = 0, stat_krylov_calls = 0, stat_svds = 0, stat_svd_sweeps = 0, stat_site_updates = 0;
+
+  int create(int L, int d, int chi_max, int B, const int* mpo_bond);
+  size_t workspace_bytes() const;
+  int bind(void* ws, size_t bytes, hipStream_t s);
+  int set_mpo(const double* host_tensors);   // packed (o,p,l,r) complex128 per site
+  int set_noise(const std::vector<NoiseProc>& procs);
+  int load_state(int set, const double* host_tensors, const int* host_bonds);  // broadcast one MPS to all slots
+  int copy_state(int dst, int src);
+  int export_state(int set, int b, double* host_out, int* host_bonds);         // padded tensors of slot b
+  int set_uniforms(const double* host_u, int n_per_traj);
+  int reset_cursor();
+
+  int tdvp(int set);
+  int dissipate(int set, double dt_);
+  int stochastic(int set, double dt_, int* host_jumped /*B or null*/, double* host_dp /*B or null*/);
+  int site_moments(int set, double* host_M /*[B][L][d][d] complex*/);
+  int bond_dims(int set, int* host_chi /*[B][L+1]*/);
+  int site_normsq0(int set, double* host_out);
+
+  // exposed for kernel-level parity tests
+  int krylov_site(cplx* x_in_v0, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0,
+                  int Dr, const cplx* Wm, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2,
+                  int n3, long o0, long o1, long o2, int nb0, const int* ids);
+  int heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv,
+                 long r_b0, int Dr, const cplx* Wm, cplx* y, long y_b0, int nb0, const int* ids, const int* active);
+
+  StateSet sets[2];
+  // work areas (public for tests)
+  cplx *T1 = nullptr, *T2 = nullptr, *V = nullptr, *theta = nullptr;
+  long v_b0 = 0, v_ld = 0, t_b0 = 0, theta_b0 = 0;
+  SvdWorkspace svdw{};
+  KrylovState ks{};
+
+ private:
+  bool bound_ = false;
+  std::vector<long> a_b0_, l_b0_, r_b0_;
+  std::vector<cplx*> Lenv_, Renv_;
+  std::vector<cplx*> W_;         // per-site MPO as matrix [(o,l),(p,r)] : matvec / right-env form
+  std::vector<cplx*> WenvL_;     // [(p,r),(o,l)] : left-env form
+  std::vector<cplx*> W2_;        // merged two-site [(o o', l),(p p', r)]
+  std::vector<std::vector<cplx>> Whost_;
+  double *part1_ = nullptr, *part2_ = nullptr;
+  int* nloc_ = nullptr;
+  double* scal_ = nullptr;       // [B] scratch scalars
+  double* normsq_ = nullptr;     // [B]
+  int* ids_ = nullptr;           // [B] compacted trajectory list
+  int* opidx_ = nullptr;         // [B]
+  int* jsite_ = nullptr;         // [B]
+  cplx* ops_ = nullptr;          // operator table (device)
+  cplx* E_ = nullptr;            // [B][chi][chi] moment environment (x2 ping-pong)
+  cplx* E2_ = nullptr;
+  cplx* M_ = nullptr;            // [L][B][d][d]
+  int n_uniform_ = 0;
+  std::vector<int> cursor_;      // host-side cursor per trajectory
+  std::vector<double> uni_host_;
+  int* h_pinned_ = nullptr;
+  std::vector<NoiseProc> noise_;
+  std::vector<std::vector<int>> one_by_site_, two_by_right_;
+  size_t ws_bytes_ = 0;
+
+  int gemm(const GemmDesc& g) { return launch_gemm(g, stream); }
+  int merge_tensor_layout(StateSet& S, int i, cplx* out, long out_b0, const int* ids, int nb0);
+  int merge_matrix_layout(StateSet& S, int i, const int* ids, int nb0);
+  int env_left(StateSet& S, int i);    // Lenv[i+1] from Lenv[i], A_i
+  int env_right(StateSet& S, int i);   // Renv[i-1] from Renv[i], A_i
+  int two_site_update(StateSet& S, int i, double dt_, int dist);
+  int one_site_update(StateSet& S, int i, double dt_);
+  int sweep_2site(StateSet& S, double scale);
+  int split(StateSet& S, int i, int dist, int mode, double thr, int maxb, int min_keep, const int* ids, int nb0);
+  int set_nloc(StateSet& S, int bl, int br, int P);
+  int svd_shift_right(StateSet& S, int i, const int* ids, int nb0);
+  int svd_shift_left(StateSet& S, int i, const int* ids, int nb0);
+};
+
+}  // namespace tjm

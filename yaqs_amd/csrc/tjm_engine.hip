@@ -1,0 +1,839 @@
+// Engine: host-side control of the batched TJM sweep (see tjm_engine.h).
+//
+// Reference call stack restated here (all paths relative to /root/reference/src/mqt/yaqs):
+//   tdvp()            core/methods/tdvp/tdvp.py:69-111 -> integrators.py:161-291 (sweep_2site)
+//   dissipate()       core/methods/dissipation.py:50-183
+//   stochastic()      core/methods/stochastic_process.py:190-292
+//   site_moments()    replaces the QR centre walk of mps.py:1178-1234 (evaluate_observables) by
+//                     left "density" environments; same expectation values, no gauge moves.
+#include "tjm_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace tjm {
+
+namespace {
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+inline int round16(int x) { return (x + 15) / 16 * 16; }
+
+// dense expm for tiny matrices (<= 4x4) by scaling and squaring + Taylor
+void small_expm(const cplx* in, int n, cplx* out) {
+  double nrm = 0.0;
+  for (int i = 0; i < n * n; ++i) nrm = std::max(nrm, std::hypot(in[i].x, in[i].y));
+  int s = 0;
+  while (nrm > 0.25) { nrm *= 0.5; ++s; }
+  const double sc = std::ldexp(1.0, -s);
+  cplx a[16], term[16], res[16], tmp[16];
+  for (int i = 0; i < n * n; ++i) {
+    a[i] = cscale(in[i], sc);
+    term[i] = cplx{(i / n == i % n) ? 1.0 : 0.0, 0.0};
+    res[i] = term[i];
+  }
+  for (int k = 1; k <= 24; ++k) {
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) {
+        cplx acc{0.0, 0.0};
+        for (int l = 0; l < n; ++l) cfma(acc, term[i * n + l], a[l * n + j]);
+        tmp[i * n + j] = cscale(acc, 1.0 / k);
+      }
+    for (int i = 0; i < n * n; ++i) { term[i] = tmp[i]; res[i] = cadd(res[i], term[i]); }
+  }
+  for (int q = 0; q < s; ++q) {
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) {
+        cplx acc{0.0, 0.0};
+        for (int l = 0; l < n; ++l) cfma(acc, res[i * n + l], res[l * n + j]);
+        tmp[i * n + j] = acc;
+      }
+    for (int i = 0; i < n * n; ++i) res[i] = tmp[i];
+  }
+  for (int i = 0; i < n * n; ++i) out[i] = res[i];
+}
+}  // namespace
+
+int Engine::create(int L_, int d_, int chi_, int B_, const int* mpo_bond) {
+  if (L_ < 2 || d_ != 2 || chi_ < 1 || B_ < 1) return TJM_ERR_ARG;  // qubit chains only for now
+  L = L_; d = d_; chi_max = chi_; B = B_;
+  cap.assign(L + 1, 1);
+  long left = 1;
+  for (int i = 1; i < L; ++i) { left = std::min<long>(left * d, chi_max); cap[i] = (int)left; }
+  long right = 1;
+  for (int i = L - 1; i > 0; --i) { right = std::min<long>(right * d, chi_max); cap[i] = std::min<int>(cap[i], (int)right); }
+  Dm.assign(mpo_bond, mpo_bond + L + 1);
+  Dmax = *std::max_element(Dm.begin(), Dm.end());
+  if (Dm[0] != 1 || Dm[L] != 1) return TJM_ERR_ARG;
+  a_b0_.resize(L); l_b0_.resize(L); r_b0_.resize(L);
+  for (int i = 0; i < L; ++i) {
+    a_b0_[i] = (long)d * cap[i] * cap[i + 1];
+    l_b0_[i] = (long)cap[i] * Dm[i] * cap[i];
+    r_b0_[i] = (long)cap[i + 1] * Dm[i + 1] * cap[i + 1];
+  }
+  return TJM_OK;
+}
+
+size_t Engine::workspace_bytes() const {
+  const int cm = *std::max_element(cap.begin(), cap.end());
+  size_t tot = 0;
+  for (int s = 0; s < 2; ++s) {
+    for (int i = 0; i < L; ++i) tot += align_up((size_t)B * a_b0_[i] * sizeof(cplx));
+    tot += align_up((size_t)B * (L + 1) * sizeof(int));
+  }
+  for (int i = 0; i < L; ++i) tot += align_up((size_t)B * l_b0_[i] * sizeof(cplx)) + align_up((size_t)B * r_b0_[i] * sizeof(cplx));
+  const size_t tb = (size_t)d * d * cm * Dmax * cm;
+  tot += 2 * align_up((size_t)B * tb * sizeof(cplx));
+  const size_t nloc = (size_t)d * d * cm * cm;
+  tot += align_up((size_t)B * (mmax + 1) * nloc * sizeof(cplx));
+  const int p = round16(d * cm);
+  tot += align_up((size_t)B * (size_t)(d * cm) * (d * cm) * sizeof(cplx));
+  tot += align_up((size_t)B * p * 2 * p * sizeof(cplx));               // Y
+  tot += align_up((size_t)B * p * sizeof(double)) + align_up((size_t)B * p * sizeof(int));
+  tot += 8 * align_up((size_t)B * sizeof(double) * 4);
+  tot += 2 * align_up((size_t)B * TJM_MAX_PART * sizeof(double));
+  tot += 3 * align_up((size_t)B * mmax * sizeof(cplx));
+  tot += 2 * align_up((size_t)B * cm * cm * sizeof(cplx));              // E ping-pong
+  tot += align_up((size_t)L * B * d * d * sizeof(cplx));                // M
+  // MPO matrices + operator table
+  tot += (size_t)(3 * L) * align_up((size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx));
+  tot += align_up((size_t)(L + 64) * 16 * sizeof(cplx));
+  tot += 1 << 16;
+  return tot;
+}
+
+int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
+  if (bytes < workspace_bytes()) return TJM_ERR_WORKSPACE;
+  stream = s;
+  char* p = static_cast<char*>(ws);
+  auto take = [&](size_t n) { char* q = p; p += align_up(n); return q; };
+  const int cm = *std::max_element(cap.begin(), cap.end());
+  for (int st = 0; st < 2; ++st) {
+    sets[st].A.resize(L);
+    for (int i = 0; i < L; ++i) sets[st].A[i] = reinterpret_cast<cplx*>(take((size_t)B * a_b0_[i] * sizeof(cplx)));
+    sets[st].chi = reinterpret_cast<int*>(take((size_t)B * (L + 1) * sizeof(int)));
+  }
+  Lenv_.resize(L); Renv_.resize(L);
+  for (int i = 0; i < L; ++i) {
+    Lenv_[i] = reinterpret_cast<cplx*>(take((size_t)B * l_b0_[i] * sizeof(cplx)));
+    Renv_[i] = reinterpret_cast<cplx*>(take((size_t)B * r_b0_[i] * sizeof(cplx)));
+  }
+  t_b0 = (long)d * d * cm * Dmax * cm;
+  T1 = reinterpret_cast<cplx*>(take((size_t)B * t_b0 * sizeof(cplx)));
+  T2 = reinterpret_cast<cplx*>(take((size_t)B * t_b0 * sizeof(cplx)));
+  v_ld = (long)d * d * cm * cm;
+  v_b0 = v_ld * (mmax + 1);
+  V = reinterpret_cast<cplx*>(take((size_t)B * v_b0 * sizeof(cplx)));
+  theta_b0 = (long)(d * cm) * (d * cm);
+  theta = reinterpret_cast<cplx*>(take((size_t)B * theta_b0 * sizeof(cplx)));
+  const int pp = round16(d * cm);
+  svdw.y_b0 = (long)pp * 2 * pp;
+  svdw.Y = reinterpret_cast<cplx*>(take((size_t)B * svdw.y_b0 * sizeof(cplx)));
+  svdw.norms = reinterpret_cast<double*>(take((size_t)B * pp * sizeof(double)));
+  svdw.perm = reinterpret_cast<int*>(take((size_t)B * pp * sizeof(int)));
+  svdw.fro2 = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
+  svdw.nrot = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  svdw.done = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  svdw.n_active = reinterpret_cast<int*>(take(256));
+  part1_ = reinterpret_cast<double*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));
+  part2_ = reinterpret_cast<double*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));
+  ks.mmax = mmax;
+  ks.alpha = reinterpret_cast<double*>(take((size_t)B * mmax * sizeof(double)));
+  ks.beta = reinterpret_cast<double*>(take((size_t)B * mmax * sizeof(double)));
+  ks.coef = reinterpret_cast<cplx*>(take((size_t)B * mmax * sizeof(cplx)));
+  ks.vnorm = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
+  ks.scale = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
+  ks.status = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  ks.kfinal = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  ks.n_active = reinterpret_cast<int*>(take(256));
+  nloc_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  scal_ = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
+  normsq_ = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
+  ids_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  opidx_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  jsite_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  E_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
+  E2_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
+  M_ = reinterpret_cast<cplx*>(take((size_t)L * B * d * d * sizeof(cplx)));
+  const size_t wsz = (size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx);
+  W_.resize(L); WenvL_.resize(L); W2_.resize(L);
+  for (int i = 0; i < L; ++i) {
+    W_[i] = reinterpret_cast<cplx*>(take(wsz));
+    WenvL_[i] = reinterpret_cast<cplx*>(take(wsz));
+    W2_[i] = reinterpret_cast<cplx*>(take(wsz));
+  }
+  ops_ = reinterpret_cast<cplx*>(take((size_t)(L + 64) * 16 * sizeof(cplx)));
+  if ((size_t)(p - static_cast<char*>(ws)) > bytes) return TJM_ERR_WORKSPACE;
+  if (!h_pinned_) TJM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 256, hipHostMallocDefault));
+  svdw.h_pinned = h_pinned_;
+  ws_bytes_ = bytes;
+  bound_ = true;
+  return TJM_OK;
+}
+
+int Engine::set_mpo(const double* host) {
+  if (!bound_) return TJM_ERR_STATE;
+  Whost_.assign(L, {});
+  const cplx* src = reinterpret_cast<const cplx*>(host);
+  for (int i = 0; i < L; ++i) {
+    const int Dl = Dm[i], Dr = Dm[i + 1];
+    Whost_[i].assign(src, src + (size_t)d * d * Dl * Dr);  // (o,p,l,r)
+    src += (size_t)d * d * Dl * Dr;
+  }
+  auto W4 = [&](int i, int o, int p, int l, int r) { return Whost_[i][(((size_t)o * d + p) * Dm[i] + l) * Dm[i + 1] + r]; };
+  for (int i = 0; i < L; ++i) {
+    const int Dl = Dm[i], Dr = Dm[i + 1];
+    std::vector<cplx> mv((size_t)d * Dl * d * Dr), el((size_t)d * Dr * d * Dl);
+    for (int o = 0; o < d; ++o) for (int p = 0; p < d; ++p) for (int l = 0; l < Dl; ++l) for (int r = 0; r < Dr; ++r) {
+      mv[(size_t)(o * Dl + l) * (d * Dr) + (p * Dr + r)] = W4(i, o, p, l, r);
+      el[(size_t)(p * Dr + r) * (d * Dl) + (o * Dl + l)] = W4(i, o, p, l, r);
+    }
+    TJM_HIP_CHECK(hipMemcpyAsync(W_[i], mv.data(), mv.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
+    TJM_HIP_CHECK(hipMemcpyAsync(WenvL_[i], el.data(), el.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
+    TJM_HIP_CHECK(hipStreamSynchronize(stream));
+    if (i + 1 < L) {
+      const int Dr2 = Dm[i + 2], P = d * d;
+      std::vector<cplx> m2((size_t)P * Dl * P * Dr2, cplx{0.0, 0.0});
+      for (int o = 0; o < d; ++o) for (int o2 = 0; o2 < d; ++o2) for (int p = 0; p < d; ++p) for (int p2 = 0; p2 < d; ++p2)
+        for (int l = 0; l < Dl; ++l) for (int r = 0; r < Dr2; ++r) {
+          cplx acc{0.0, 0.0};
+          for (int m = 0; m < Dr; ++m) cfma(acc, W4(i, o, p, l, m), W4(i + 1, o2, p2, m, r));
+          m2[(size_t)((o * d + o2) * Dl + l) * (P * Dr2) + ((p * d + p2) * Dr2 + r)] = acc;
+        }
+      TJM_HIP_CHECK(hipMemcpyAsync(W2_[i], m2.data(), m2.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
+      TJM_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+  }
+  return TJM_OK;
+}
+
+int Engine::set_noise(const std::vector<NoiseProc>& procs) {
+  noise_ = procs;
+  one_by_site_.assign(L, {});
+  two_by_right_.assign(L, {});
+  for (size_t k = 0; k < noise_.size(); ++k) {
+    const NoiseProc& p = noise_[k];
+    if (p.nsites == 1) {
+      if (p.site0 < 0 || p.site0 >= L) return TJM_ERR_ARG;
+      one_by_site_[p.site0].push_back((int)k);
+    } else if (p.nsites == 2) {
+      if (p.site0 < 0 || p.site1 >= L || p.site1 <= p.site0) return TJM_ERR_ARG;
+      two_by_right_[p.site1].push_back((int)k);
+    } else {
+      return TJM_ERR_ARG;
+    }
+  }
+  return TJM_OK;
+}
+
+int Engine::load_state(int set, const double* host, const int* bonds) {
+  if (!bound_ || set < 0 || set > 1) return TJM_ERR_STATE;
+  StateSet& S = sets[set];
+  const cplx* src = reinterpret_cast<const cplx*>(host);
+  std::vector<int> chi((size_t)B * (L + 1));
+  for (int b = 0; b < B; ++b) for (int k = 0; k <= L; ++k) chi[(size_t)b * (L + 1) + k] = bonds[k];
+  for (int k = 0; k <= L; ++k) if (bonds[k] > cap[k] || bonds[k] < 1) return TJM_ERR_ARG;
+  TJM_HIP_CHECK(hipMemcpyAsync(S.chi, chi.data(), chi.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+  for (int i = 0; i < L; ++i) {
+    const int cl = bonds[i], cr = bonds[i + 1];
+    std::vector<cplx> pad((size_t)a_b0_[i], cplx{0.0, 0.0});
+    for (int p = 0; p < d; ++p) for (int a = 0; a < cl; ++a) for (int c = 0; c < cr; ++c)
+      pad[((size_t)p * cap[i] + a) * cap[i + 1] + c] = src[((size_t)p * cl + a) * cr + c];
+    src += (size_t)d * cl * cr;
+    // first slot from host, the others by device copies
+    TJM_HIP_CHECK(hipMemcpyAsync(S.A[i], pad.data(), pad.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
+    TJM_HIP_CHECK(hipStreamSynchronize(stream));
+    long done = 1;
+    while (done < B) {
+      const long n = std::min<long>(done, B - done);
+      TJM_HIP_CHECK(hipMemcpyAsync(S.A[i] + done * a_b0_[i], S.A[i], (size_t)n * a_b0_[i] * sizeof(cplx), hipMemcpyDeviceToDevice, stream));
+      done += n;
+    }
+  }
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+int Engine::copy_state(int dst, int src) {
+  if (!bound_ || dst == src) return TJM_ERR_ARG;
+  for (int i = 0; i < L; ++i)
+    TJM_HIP_CHECK(hipMemcpyAsync(sets[dst].A[i], sets[src].A[i], (size_t)B * a_b0_[i] * sizeof(cplx), hipMemcpyDeviceToDevice, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(sets[dst].chi, sets[src].chi, (size_t)B * (L + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  return TJM_OK;
+}
+
+int Engine::export_state(int set, int b, double* out, int* bonds) {
+  if (!bound_ || b < 0 || b >= B) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  TJM_HIP_CHECK(hipMemcpyAsync(bonds, S.chi + (size_t)b * (L + 1), (L + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+  cplx* dst = reinterpret_cast<cplx*>(out);
+  for (int i = 0; i < L; ++i) {
+    TJM_HIP_CHECK(hipMemcpyAsync(dst, S.A[i] + (size_t)b * a_b0_[i], (size_t)a_b0_[i] * sizeof(cplx), hipMemcpyDeviceToHost, stream));
+    dst += a_b0_[i];
+  }
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+int Engine::set_uniforms(const double* host_u, int n_per_traj) {
+  uni_host_.assign(host_u, host_u + (size_t)B * n_per_traj);
+  n_uniform_ = n_per_traj;
+  cursor_.assign(B, 0);
+  return TJM_OK;
+}
+
+int Engine::reset_cursor() {
+  cursor_.assign(B, 0);
+  return TJM_OK;
+}
+
+int Engine::bond_dims(int set, int* host_chi) {
+  TJM_HIP_CHECK(hipMemcpyAsync(host_chi, sets[set].chi, (size_t)B * (L + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// contractions
+// ------------------------------------------------------------------------------------------
+static GemmDesc blank_gemm() {
+  GemmDesc g;
+  std::memset(&g, 0, sizeof(g));
+  g.nks = 1; g.nb0 = 1; g.nb1 = 1; g.nb2 = 1;
+  return g;
+}
+
+int Engine::merge_tensor_layout(StateSet& S, int i, cplx* out, long out_b0, const int* ids, int nb0) {
+  const int ca = cap[i], cmid = cap[i + 1], cc = cap[i + 2];
+  GemmDesc g = blank_gemm();
+  g.A = S.A[i]; g.B = S.A[i + 1]; g.C = out;
+  g.M = ca; g.K = cmid; g.N = cc;
+  g.a_rs = cmid; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = cc;
+  g.nb0 = nb0; g.nb1 = d; g.nb2 = d;
+  g.a_b0 = a_b0_[i]; g.a_b1 = (long)ca * cmid; g.a_b2 = 0;
+  g.b_b0 = a_b0_[i + 1]; g.b_b1 = 0; g.b_b2 = (long)cmid * cc;
+  g.c_b0 = out_b0; g.c_b1 = (long)d * ca * cc; g.c_b2 = (long)ca * cc;
+  g.ids = ids;
+  return gemm(g);
+}
+
+int Engine::merge_matrix_layout(StateSet& S, int i, const int* ids, int nb0) {
+  const int ca = cap[i], cmid = cap[i + 1], cc = cap[i + 2];
+  GemmDesc g = blank_gemm();
+  g.A = S.A[i]; g.B = S.A[i + 1]; g.C = theta;
+  g.M = d * ca; g.K = cmid; g.N = cc;
+  g.a_rs = cmid; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = (long)d * cc;
+  g.nb0 = nb0; g.nb1 = d;
+  g.a_b0 = a_b0_[i]; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cmid * cc;
+  g.c_b0 = theta_b0; g.c_b1 = cc;
+  g.ids = ids;
+  return gemm(g);
+}
+
+int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv,
+                       long r_b0, int Dr, const cplx* Wm, cplx* y, long y_b0, int nb0, const int* ids, const int* active) {
+  int rc;
+  {  // T1[(p,a),(r,B)] = x[(p,a),b] R[b,(r,B)]
+    GemmDesc g = blank_gemm();
+    g.A = x; g.B = Renv; g.C = T1;
+    g.M = P * ca; g.K = cb; g.N = Dr * cb;
+    g.a_rs = cb; g.a_cs = 1; g.b_rs = (long)Dr * cb; g.b_cs = 1; g.c_rs = (long)Dr * cb;
+    g.nb0 = nb0; g.a_b0 = x_b0; g.b_b0 = r_b0; g.c_b0 = t_b0;
+    g.ids = ids; g.active = active;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  {  // T2[o][a][l][B] = sum_{p,r} W[(o,l),(p,r)] T1[p][a][r][B]
+    MpoApplyDesc m;
+    m.in = T1; m.out = T2; m.Wm = Wm; m.P = P; m.din = Dr; m.dout = Dl; m.na = ca; m.nB = cb;
+    m.in_sp = (long)ca * Dr * cb; m.in_sb = cb; m.in_sa = (long)Dr * cb;
+    m.out_sp = (long)ca * Dl * cb; m.out_sb = cb; m.out_sa = (long)Dl * cb;
+    m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = nb0; m.ids = ids; m.active = active;
+    if ((rc = launch_mpo_apply(m, stream)) != TJM_OK) return rc;
+  }
+  {  // y[o][A][B] = sum_{(a,l)} L[(a,l)][A] T2[o][(a,l)][B]
+    GemmDesc g = blank_gemm();
+    g.A = Lenv; g.B = T2; g.C = y;
+    g.M = ca; g.K = ca * Dl; g.N = cb;
+    g.a_rs = 1; g.a_cs = ca; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb;
+    g.nb0 = nb0; g.nb1 = P;
+    g.a_b0 = l_b0; g.b_b0 = t_b0; g.b_b1 = (long)ca * Dl * cb; g.c_b0 = y_b0; g.c_b1 = (long)ca * cb;
+    g.ids = ids; g.active = active;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  return TJM_OK;
+}
+
+int Engine::env_left(StateSet& S, int i) {
+  const int ca = cap[i], cb = cap[i + 1], Dl = Dm[i], Dr = Dm[i + 1];
+  int rc;
+  {  // T1[(a,l),(o,B)] = L[(a,l),A] conj(A_i[o][A][B])
+    GemmDesc g = blank_gemm();
+    g.A = Lenv_[i]; g.B = S.A[i]; g.C = T1;
+    g.M = ca * Dl; g.K = ca; g.N = cb;
+    g.a_rs = ca; g.a_cs = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = (long)d * cb; g.conjB = 1;
+    g.nb0 = B; g.nb1 = d;
+    g.a_b0 = l_b0_[i]; g.b_b0 = a_b0_[i]; g.b_b1 = (long)ca * cb; g.c_b0 = t_b0; g.c_b1 = cb;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  {  // T2[p][a][r][B] = sum_{o,l} W[o,p,l,r] T1[a][l][o][B]
+    MpoApplyDesc m;
+    m.in = T1; m.out = T2; m.Wm = WenvL_[i]; m.P = d; m.din = Dl; m.dout = Dr; m.na = ca; m.nB = cb;
+    m.in_sp = cb; m.in_sb = (long)d * cb; m.in_sa = (long)Dl * d * cb;
+    m.out_sp = (long)ca * Dr * cb; m.out_sb = cb; m.out_sa = (long)Dr * cb;
+    m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = B; m.ids = nullptr; m.active = nullptr;
+    if ((rc = launch_mpo_apply(m, stream)) != TJM_OK) return rc;
+  }
+  {  // L'[b,(r,B)] = sum_{(p,a)} A_i[(p,a),b] T2[(p,a),(r,B)]
+    GemmDesc g = blank_gemm();
+    g.A = S.A[i]; g.B = T2; g.C = Lenv_[i + 1];
+    g.M = cb; g.K = d * ca; g.N = Dr * cb;
+    g.a_rs = 1; g.a_cs = cb; g.b_rs = (long)Dr * cb; g.b_cs = 1; g.c_rs = (long)Dr * cb;
+    g.nb0 = B; g.a_b0 = a_b0_[i]; g.b_b0 = t_b0; g.c_b0 = l_b0_[i + 1];
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  return TJM_OK;
+}
+
+int Engine::env_right(StateSet& S, int i) {
+  // Renv_[i-1] (bond cap[i], Dm[i]) from Renv_[i] and A_i
+  const int ca = cap[i], cb = cap[i + 1], Dl = Dm[i], Dr = Dm[i + 1];
+  int rc;
+  {  // T1[(p,a),(r,B)] = A_i[(p,a),b] R[b,(r,B)]
+    GemmDesc g = blank_gemm();
+    g.A = S.A[i]; g.B = Renv_[i]; g.C = T1;
+    g.M = d * ca; g.K = cb; g.N = Dr * cb;
+    g.a_rs = cb; g.a_cs = 1; g.b_rs = (long)Dr * cb; g.b_cs = 1; g.c_rs = (long)Dr * cb;
+    g.nb0 = B; g.a_b0 = a_b0_[i]; g.b_b0 = r_b0_[i]; g.c_b0 = t_b0;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  {  // T2[a][l][o][B] = sum_{p,r} W[o,p,l,r] T1[p][a][r][B]
+    MpoApplyDesc m;
+    m.in = T1; m.out = T2; m.Wm = W_[i]; m.P = d; m.din = Dr; m.dout = Dl; m.na = ca; m.nB = cb;
+    m.in_sp = (long)ca * Dr * cb; m.in_sb = cb; m.in_sa = (long)Dr * cb;
+    m.out_sp = cb; m.out_sb = (long)d * cb; m.out_sa = (long)Dl * d * cb;
+    m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = B; m.ids = nullptr; m.active = nullptr;
+    if ((rc = launch_mpo_apply(m, stream)) != TJM_OK) return rc;
+  }
+  {  // R'[(a,l),A] = sum_o sum_B T2[(a,l),(o,B)] conj(A_i[o][A][B])
+    GemmDesc g = blank_gemm();
+    g.A = T2; g.B = S.A[i]; g.C = Renv_[i - 1];
+    g.M = ca * Dl; g.K = cb; g.N = ca;
+    g.a_rs = (long)d * cb; g.a_cs = 1; g.b_rs = 1; g.b_cs = cb; g.c_rs = ca; g.conjB = 1;
+    g.nks = d; g.a_ks = cb; g.b_ks = (long)ca * cb;
+    g.nb0 = B; g.a_b0 = t_b0; g.b_b0 = a_b0_[i]; g.c_b0 = r_b0_[i - 1];
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  return TJM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Krylov exponential of a site tensor held in V[:, 0]
+// ------------------------------------------------------------------------------------------
+int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0,
+                        int Dr, const cplx* Wm, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2,
+                        int n3, long o0, long o1, long o2, int nb0, const int* ids) {
+  const int n = P * ca * cb;
+  int rc, nblk = 1;
+  ++stat_krylov_calls;
+  TJM_HIP_CHECK(hipMemsetAsync(ks.n_active, 0, sizeof(int), stream));
+  if ((rc = launch_normsq_partial(V, v_b0, n, part2_, nb0, ids, nullptr, stream, &nblk)) != TJM_OK) return rc;
+  if ((rc = launch_lanczos_init(ks, part2_, nblk, nb0, ids, stream)) != TJM_OK) return rc;
+  if ((rc = launch_scale(V, v_b0, n, ks.scale, nb0, ids, ks.status, stream)) != TJM_OK) return rc;
+  for (int j = 0; j < mmax; ++j) {
+    cplx* vj = V + (long)j * v_ld;
+    cplx* w = V + (long)(j + 1) * v_ld;
+    cplx* vjm1 = V + (long)(j > 0 ? j - 1 : 0) * v_ld;
+    if ((rc = heff_apply(vj, v_b0, P, ca, cb, Lenv, l_b0, Dl, Renv, r_b0, Dr, Wm, w, v_b0, nb0, ids, ks.status)) != TJM_OK) return rc;
+    ++stat_matvecs;
+    if ((rc = launch_dot_partial(vj, w, v_b0, v_b0, n, part1_, nb0, ids, ks.status, stream, &nblk)) != TJM_OK) return rc;
+    if ((rc = launch_lanczos_axpy(w, vj, vjm1, v_b0, n, part1_, part2_, nblk, ks.beta, mmax, j, nb0, ids, ks.status, stream)) != TJM_OK) return rc;
+    TJM_HIP_CHECK(hipMemsetAsync(ks.n_active, 0, sizeof(int), stream));
+    if ((rc = launch_lanczos_finalize(ks, part1_, part2_, nblk, j, dt_, krylov_tol, nloc_dev, nb0, ids, stream)) != TJM_OK) return rc;
+    if (j + 1 < mmax)
+      if ((rc = launch_scale(w, v_b0, n, ks.scale, nb0, ids, ks.status, stream)) != TJM_OK) return rc;
+    TJM_HIP_CHECK(hipMemcpyAsync(h_pinned_, ks.n_active, sizeof(int), hipMemcpyDeviceToHost, stream));
+    TJM_HIP_CHECK(hipStreamSynchronize(stream));
+    if (*h_pinned_ == 0) break;
+  }
+  return launch_krylov_combine(V, v_b0, v_ld, ks, out, out_b0, n0, n1, n2, n3, o0, o1, o2, nb0, ids, stream);
+}
+
+// nloc[b] = P * chi[b][bl] * chi[b][br]   (actual local dimension; matrix_exponential.py:94 uses vec.size)
+__global__ void nloc_kernel(const int* chi, int stride, int bl, int br, int P, int* nloc, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) nloc[b] = P * chi[(long)b * stride + bl] * chi[(long)b * stride + br];
+}
+
+int Engine::set_nloc(StateSet& S, int bl, int br, int P) {
+  hipLaunchKernelGGL(nloc_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, S.chi, L + 1, bl, br, P, nloc_, B);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+int Engine::split(StateSet& S, int i, int dist, int mode, double thr, int maxb, int min_keep, const int* ids, int nb0) {
+  SvdSplitDesc s;
+  s.theta = theta; s.theta_b0 = theta_b0; s.ld_theta = d * cap[i + 2];
+  s.m = d * cap[i]; s.n = d * cap[i + 2]; s.d = d;
+  s.capL = cap[i]; s.capR = cap[i + 2]; s.capM = cap[i + 1];
+  s.left = S.A[i]; s.right = S.A[i + 1]; s.left_b0 = a_b0_[i]; s.right_b0 = a_b0_[i + 1];
+  s.distribution = dist; s.trunc_mode = mode; s.threshold = thr; s.max_bond = maxb; s.min_keep = min_keep;
+  s.chiL = S.chi + i; s.chiR = S.chi + i + 2; s.chiM = S.chi + i + 1; s.chi_stride = L + 1;
+  s.spectrum = nullptr; s.spec_ld = 0; s.nb0 = nb0; s.ids = ids;
+  int sweeps = 0;
+  const int rc = svd_split(s, svdw, stream, &sweeps);
+  ++stat_svds;
+  stat_svd_sweeps += sweeps;
+  return rc;
+}
+
+int Engine::two_site_update(StateSet& S, int i, double dt_, int dist) {
+  const int ca = cap[i], cc = cap[i + 2], P = d * d;
+  int rc;
+  if ((rc = merge_tensor_layout(S, i, V, v_b0, nullptr, B)) != TJM_OK) return rc;
+  if ((rc = set_nloc(S, i, i + 2, P)) != TJM_OK) return rc;
+  // result in matrix layout theta[(s,a),(t,c)] from tensor layout [s][t][a][c]
+  if ((rc = krylov_site(nullptr, P, ca, cc, Lenv_[i], l_b0_[i], Dm[i], Renv_[i + 1], r_b0_[i + 1], Dm[i + 2], W2_[i], dt_, nloc_,
+                        theta, theta_b0, d, d, ca, cc, (long)ca * d * cc, cc, (long)d * cc, B, nullptr)) != TJM_OK) return rc;
+  const int mk = (max_bond > 0) ? std::min(2, max_bond) : 2;
+  if ((rc = split(S, i, dist, trunc_mode, svd_threshold, max_bond, mk, nullptr, B)) != TJM_OK) return rc;
+  ++stat_site_updates;
+  return TJM_OK;
+}
+
+int Engine::one_site_update(StateSet& S, int i, double dt_) {
+  const int ca = cap[i], cb = cap[i + 1];
+  int rc;
+  TJM_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)v_b0 * sizeof(cplx), S.A[i], (size_t)a_b0_[i] * sizeof(cplx), (size_t)a_b0_[i] * sizeof(cplx), B,
+                                 hipMemcpyDeviceToDevice, stream));
+  if ((rc = set_nloc(S, i, i + 1, d)) != TJM_OK) return rc;
+  return krylov_site(nullptr, d, ca, cb, Lenv_[i], l_b0_[i], Dm[i], Renv_[i], r_b0_[i], Dm[i + 1], W_[i], dt_, nloc_, S.A[i], a_b0_[i], 1,
+                     d, ca, cb, 0, (long)ca * cb, cb, B, nullptr);
+}
+
+int Engine::sweep_2site(StateSet& S, double scale) {
+  int rc;
+  const double sdt = dt * scale;
+  for (int i = 0; i < L - 2; ++i) {
+    if ((rc = two_site_update(S, i, 0.5 * sdt, 0)) != TJM_OK) return rc;
+    if ((rc = env_left(S, i)) != TJM_OK) return rc;
+    if ((rc = one_site_update(S, i + 1, -0.5 * sdt)) != TJM_OK) return rc;
+  }
+  {
+    const int i = L - 2;
+    if ((rc = two_site_update(S, i, sdt, 1)) != TJM_OK) return rc;
+    if ((rc = env_right(S, i + 1)) != TJM_OK) return rc;
+  }
+  for (int i = L - 3; i >= 0; --i) {
+    if ((rc = one_site_update(S, i + 1, -0.5 * sdt)) != TJM_OK) return rc;
+    if ((rc = two_site_update(S, i, 0.5 * sdt, 1)) != TJM_OK) return rc;
+    if ((rc = env_right(S, i + 1)) != TJM_OK) return rc;
+  }
+  return TJM_OK;
+}
+
+int Engine::tdvp(int set) {
+  if (!bound_) return TJM_ERR_STATE;
+  if (tdvp_mode != 2) return TJM_ERR_NOT_IMPLEMENTED;
+  StateSet& S = sets[set];
+  int rc;
+  // right environments (primitives.py:139-174), left boundary (integrators.py:186-193)
+  if ((rc = launch_identity_env(Renv_[L - 1], r_b0_[L - 1], cap[L], Dm[L], B, stream)) != TJM_OK) return rc;
+  for (int i = L - 1; i >= 1; --i)
+    if ((rc = env_right(S, i)) != TJM_OK) return rc;
+  if ((rc = launch_identity_env(Lenv_[0], l_b0_[0], cap[0], Dm[0], B, stream)) != TJM_OK) return rc;
+  for (int s = 0; s < tdvp_sweeps; ++s)
+    if ((rc = sweep_2site(S, 1.0 / tdvp_sweeps)) != TJM_OK) return rc;
+  return TJM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// SVD centre shifts (mps.py:747-788): two-site merge + split, discarded_weight 1e-12, no cap
+// ------------------------------------------------------------------------------------------
+int Engine::svd_shift_right(StateSet& S, int i, const int* ids, int nb0) {
+  int rc;
+  if ((rc = merge_matrix_layout(S, i, ids, nb0)) != TJM_OK) return rc;
+  return split(S, i, 0, 0, 1e-12, 0, 1, ids, nb0);
+}
+
+int Engine::svd_shift_left(StateSet& S, int i, const int* ids, int nb0) {
+  // centre i -> i-1: split theta(i-1, i) with the singular values absorbed to the left
+  int rc;
+  if ((rc = merge_matrix_layout(S, i - 1, ids, nb0)) != TJM_OK) return rc;
+  return split(S, i - 1, 1, 0, 1e-12, 0, 1, ids, nb0);
+}
+
+// x *= s (uniform scalar over the batch)
+__global__ void fill_kernel(double* p, double v, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) p[t] = v;
+}
+__global__ void rsqrt_kernel(const double* in, double* out, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = (in[t] > 0.0) ? 1.0 / sqrt(in[t]) : 0.0;
+}
+
+int Engine::dissipate(int set, double dt_) {
+  if (!bound_) return TJM_ERR_STATE;
+  StateSet& S = sets[set];
+  int rc;
+  bool any = false;
+  for (const auto& p : noise_) any = any || (p.gamma != 0.0);
+  if (!any) {  // dissipation.py:79-86: QR at site 0 with R discarded = renormalise
+    if ((rc = launch_normsq(S.A[0], a_b0_[0], a_b0_[0], normsq_, B, nullptr, stream)) != TJM_OK) return rc;
+    hipLaunchKernelGGL(rsqrt_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, normsq_, scal_, B);
+    return launch_scale(S.A[0], a_b0_[0], a_b0_[0], scal_, B, nullptr, nullptr, stream);
+  }
+  for (int i = 0; i < L - 1; ++i)
+    if ((rc = svd_shift_right(S, i, nullptr, B)) != TJM_OK) return rc;
+  for (int i = L - 1; i >= 0; --i) {
+    double expo = 0.0;
+    bool need_matrix = false;
+    cplx gen[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    for (int k : one_by_site_[i]) {
+      const NoiseProc& p = noise_[k];
+      if (p.pauli) {
+        gen[0].x += p.gamma; gen[3].x += p.gamma;
+      } else {
+        need_matrix = true;
+        for (int a = 0; a < d; ++a) for (int c = 0; c < d; ++c) {
+          cplx acc{0.0, 0.0};
+          for (int r = 0; r < d; ++r) cfma(acc, cconj(p.mat[r * d + a]), p.mat[r * d + c]);
+          gen[a * d + c] = cadd(gen[a * d + c], cscale(acc, p.gamma));
+        }
+      }
+    }
+    if (!one_by_site_[i].empty() && !need_matrix) expo += gen[0].x;
+    if (i != 0) {
+      for (int k : two_by_right_[i]) {
+        const NoiseProc& p = noise_[k];
+        if (!p.pauli) return TJM_ERR_NOT_IMPLEMENTED;  // non-Pauli two-site dissipators: next round
+        expo += p.gamma;
+      }
+    }
+    if (need_matrix) {
+      cplx arg[4], m[4];
+      for (int q = 0; q < 4; ++q) arg[q] = cscale(gen[q], -0.5 * dt_);
+      small_expm(arg, d, m);
+      TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)i * 16, m, sizeof(m), hipMemcpyHostToDevice, stream));
+      TJM_HIP_CHECK(hipStreamSynchronize(stream));
+      if ((rc = launch_apply_local(S.A[i], a_b0_[i], d, (long)cap[i] * cap[i + 1], ops_ + (size_t)i * 16, nullptr, B, nullptr, stream)) != TJM_OK) return rc;
+    }
+    if (expo != 0.0) {
+      hipLaunchKernelGGL(fill_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, scal_, std::exp(-0.5 * dt_ * expo), B);
+      if ((rc = launch_scale(S.A[i], a_b0_[i], a_b0_[i], scal_, B, nullptr, nullptr, stream)) != TJM_OK) return rc;
+    }
+    if (i != 0)
+      if ((rc = svd_shift_left(S, i, nullptr, B)) != TJM_OK) return rc;
+  }
+  return TJM_OK;
+}
+
+int Engine::site_normsq0(int set, double* host_out) {
+  StateSet& S = sets[set];
+  int rc;
+  if ((rc = launch_normsq(S.A[0], a_b0_[0], a_b0_[0], normsq_, B, nullptr, stream)) != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipMemcpyAsync(host_out, normsq_, B * sizeof(double), hipMemcpyDeviceToHost, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+int Engine::site_moments(int set, double* host_M) {
+  if (!bound_) return TJM_ERR_STATE;
+  StateSet& S = sets[set];
+  int rc;
+  cplx one{1.0, 0.0};
+  // E_0 = [[1]] for every trajectory
+  std::vector<cplx> ones((size_t)B, one);
+  TJM_HIP_CHECK(hipMemcpyAsync(E_, ones.data(), ones.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  cplx* E = E_;
+  cplx* En = E2_;
+  for (int i = 0; i < L; ++i) {
+    const int ca = cap[i], cb = cap[i + 1];
+    {  // T[p][a][b] = sum_a' E[a][a'] A_i[p][a'][b]
+      GemmDesc g = blank_gemm();
+      g.A = E; g.B = S.A[i]; g.C = T1;
+      g.M = ca; g.K = ca; g.N = cb;
+      g.a_rs = ca; g.a_cs = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb;
+      g.nb0 = B; g.nb1 = d;
+      g.a_b0 = (long)ca * ca; g.b_b0 = a_b0_[i]; g.b_b1 = (long)ca * cb; g.c_b0 = t_b0; g.c_b1 = (long)ca * cb;
+      if ((rc = gemm(g)) != TJM_OK) return rc;
+    }
+    if ((rc = launch_phys_overlap(S.A[i], T1, a_b0_[i], t_b0, d, (long)ca * cb, M_ + (size_t)i * B * d * d, B, nullptr, stream)) != TJM_OK) return rc;
+    if (i + 1 < L) {  // E'[b][b'] = sum_{(p,a)} conj(A_i[(p,a),b]) T[(p,a),b']
+      GemmDesc g = blank_gemm();
+      g.A = S.A[i]; g.B = T1; g.C = En;
+      g.M = cb; g.K = d * ca; g.N = cb;
+      g.a_rs = 1; g.a_cs = cb; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb; g.conjA = 1;
+      g.nb0 = B; g.a_b0 = a_b0_[i]; g.b_b0 = t_b0; g.c_b0 = (long)cb * cb;
+      if ((rc = gemm(g)) != TJM_OK) return rc;
+      std::swap(E, En);
+    }
+  }
+  TJM_HIP_CHECK(hipMemcpyAsync(host_M, M_, (size_t)L * B * d * d * sizeof(cplx), hipMemcpyDeviceToHost, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+// x_b <- O_b x_b at a per-trajectory site
+__global__ __launch_bounds__(256) void apply_local_multi_kernel(cplx* const* site_ptr, const long* site_b0, const long* site_rest,
+                                                               int d, const cplx* ops, const int* op_index, const int* site,
+                                                               const int* ids) {
+  const int b = ids[blockIdx.y];
+  const int s = site[b];
+  const int oi = op_index[b];
+  if (oi < 0 || s < 0) return;
+  const cplx* O = ops + (long)oi * d * d;
+  cplx* xb = site_ptr[s] + (long)b * site_b0[s];
+  const long rest = site_rest[s];
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rest; r += (long)gridDim.x * blockDim.x) {
+    cplx v[4], y[4];
+    for (int q = 0; q < d; ++q) v[q] = xb[(long)q * rest + r];
+    for (int p = 0; p < d; ++p) {
+      cplx acc{0.0, 0.0};
+      for (int q = 0; q < d; ++q) cfma(acc, O[p * d + q], v[q]);
+      y[p] = acc;
+    }
+    for (int p = 0; p < d; ++p) xb[(long)p * rest + r] = y[p];
+  }
+}
+
+int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
+  if (!bound_) return TJM_ERR_STATE;
+  StateSet& S = sets[set];
+  int rc;
+  std::vector<double> nsq(B);
+  if ((rc = site_normsq0(set, nsq.data())) != TJM_OK) return rc;
+  const bool have_noise = !noise_.empty();
+  std::vector<int> jumped;
+  std::vector<double> scale(B, 1.0);
+  std::vector<double> u_choice(B, 0.0);
+  for (int b = 0; b < B; ++b) {
+    const double dp = 1.0 - nsq[b];
+    if (host_dp) host_dp[b] = dp;
+    bool jump = false;
+    if (have_noise) {
+      if (cursor_[b] >= n_uniform_) return TJM_ERR_STATE;
+      const double u = uni_host_[(size_t)b * n_uniform_ + cursor_[b]++];
+      jump = !(u >= dp);  // stochastic_process.py:226
+    }
+    if (jump) {
+      if (cursor_[b] >= n_uniform_) return TJM_ERR_STATE;
+      u_choice[b] = uni_host_[(size_t)b * n_uniform_ + cursor_[b]++];
+      jumped.push_back(b);
+    } else {
+      scale[b] = (nsq[b] > 0.0) ? 1.0 / std::sqrt(nsq[b]) : 0.0;
+    }
+    if (host_jumped) host_jumped[b] = jump ? 1 : 0;
+  }
+  // no-jump branch: QR at site 0 with R discarded (mps.py:736-746)
+  TJM_HIP_CHECK(hipMemcpyAsync(scal_, scale.data(), B * sizeof(double), hipMemcpyHostToDevice, stream));
+  if ((rc = launch_scale(S.A[0], a_b0_[0], a_b0_[0], scal_, B, nullptr, nullptr, stream)) != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  if (jumped.empty()) return TJM_OK;
+
+  // ---- channel weights in site-sweep order (stochastic_process.py:139-176)
+  struct Cand { int proc; };
+  std::vector<int> order;
+  for (int site = 0; site < L; ++site) {
+    for (size_t k = 0; k < noise_.size(); ++k)
+      if (noise_[k].nsites == 1 && noise_[k].site0 == site) order.push_back((int)k);
+    if (site < L - 1)
+      for (size_t k = 0; k < noise_.size(); ++k)
+        if (noise_[k].nsites == 2 && noise_[k].site0 == site) order.push_back((int)k);
+  }
+  bool need_moments = false;
+  for (int k : order) {
+    const NoiseProc& p = noise_[k];
+    if (p.nsites == 1 && !p.pauli) need_moments = true;
+    if (p.nsites == 2 && !p.pauli) return TJM_ERR_NOT_IMPLEMENTED;
+    if (p.nsites == 2 && p.pauli && p.site1 == p.site0 + 1) return TJM_ERR_NOT_IMPLEMENTED;  // adjacent: merged split path
+  }
+  std::vector<cplx> Mh;
+  if (need_moments) {
+    Mh.resize((size_t)L * B * d * d);
+    if ((rc = site_moments(set, reinterpret_cast<double*>(Mh.data()))) != TJM_OK) return rc;
+  }
+  // operator table: per process one (or two, for long-range factors) d x d matrices
+  std::vector<cplx> optab;
+  std::vector<int> op_first(noise_.size());
+  for (size_t k = 0; k < noise_.size(); ++k) {
+    op_first[k] = (int)(optab.size() / (d * d));
+    const NoiseProc& p = noise_[k];
+    if (p.nsites == 1) optab.insert(optab.end(), p.mat, p.mat + d * d);
+    else { optab.insert(optab.end(), p.f0, p.f0 + d * d); optab.insert(optab.end(), p.f1, p.f1 + d * d); }
+  }
+  if (optab.size() > (size_t)(L + 64) * 16) return TJM_ERR_WORKSPACE;
+  TJM_HIP_CHECK(hipMemcpyAsync(ops_, optab.data(), optab.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
+
+  std::vector<int> opi(B, -1), opi2(B, -1), js(B, -1), js2(B, -1);
+  bool any_second = false;
+  std::vector<double> w(order.size());
+  for (int b : jumped) {
+    double tot = 0.0;
+    for (size_t c = 0; c < order.size(); ++c) {
+      const NoiseProc& p = noise_[order[c]];
+      double nrm;
+      if (p.pauli) {
+        nrm = nsq[b];  // unitary jump operator: ||L psi||^2 = ||psi||^2
+      } else {
+        // ||L psi||^2 = sum_{p,q} (L^dag L)[p][q] M[p][q]
+        const cplx* M = &Mh[((size_t)p.site0 * B + b) * d * d];
+        double acc = 0.0;
+        for (int a = 0; a < d; ++a) for (int c2 = 0; c2 < d; ++c2) {
+          cplx ll{0.0, 0.0};
+          for (int r = 0; r < d; ++r) cfma(ll, cconj(p.mat[r * d + a]), p.mat[r * d + c2]);
+          acc += ll.x * M[a * d + c2].x - ll.y * M[a * d + c2].y;
+        }
+        nrm = acc;
+      }
+      w[c] = dt_ * p.gamma * nrm;
+      tot += w[c];
+    }
+    if (!(tot > 0.0) || !std::isfinite(tot)) return TJM_ERR_NUMERIC;  // stochastic_process.py:178-186
+    // rng.choice(n, p): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, side="right")
+    std::vector<double> cdf(order.size());
+    double run = 0.0;
+    for (size_t c = 0; c < order.size(); ++c) { run += w[c] / tot; cdf[c] = run; }
+    const double last = cdf.back();
+    size_t choice = order.size() - 1;
+    for (size_t c = 0; c < order.size(); ++c) if (u_choice[b] < cdf[c] / last) { choice = c; break; }
+    const NoiseProc& p = noise_[order[choice]];
+    js[b] = p.site0;
+    opi[b] = op_first[order[choice]];
+    if (p.nsites == 2) { js2[b] = p.site1; opi2[b] = op_first[order[choice]] + 1; any_second = true; }
+  }
+  // device tables for the per-trajectory site application
+  std::vector<cplx*> sp(L);
+  std::vector<long> sb(L), sr(L);
+  for (int i = 0; i < L; ++i) { sp[i] = S.A[i]; sb[i] = a_b0_[i]; sr[i] = (long)cap[i] * cap[i + 1]; }
+  // reuse the tail of T2 as scratch for the small tables
+  char* scratch = reinterpret_cast<char*>(T2);
+  cplx** d_sp = reinterpret_cast<cplx**>(scratch);
+  long* d_sb = reinterpret_cast<long*>(scratch + align_up(L * sizeof(cplx*)));
+  long* d_sr = reinterpret_cast<long*>(scratch + 2 * align_up(L * sizeof(cplx*)));
+  TJM_HIP_CHECK(hipMemcpyAsync(d_sp, sp.data(), L * sizeof(cplx*), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(d_sb, sb.data(), L * sizeof(long), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(d_sr, sr.data(), L * sizeof(long), hipMemcpyHostToDevice, stream));
+  const int nj = (int)jumped.size();
+  TJM_HIP_CHECK(hipMemcpyAsync(ids_, jumped.data(), nj * sizeof(int), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(opidx_, opi.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(jsite_, js.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(apply_local_multi_kernel, dim3(64, nj), dim3(256), 0, stream, d_sp, d_sb, d_sr, d, ops_, opidx_, jsite_, ids_);
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  if (any_second) {
+    TJM_HIP_CHECK(hipMemcpyAsync(opidx_, opi2.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
+    TJM_HIP_CHECK(hipMemcpyAsync(jsite_, js2.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(apply_local_multi_kernel, dim3(64, nj), dim3(256), 0, stream, d_sp, d_sb, d_sr, d, ops_, opidx_, jsite_, ids_);
+    TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  // ---- normalize("B", "SVD") on the jumped trajectories (mps.py:815-839): SVD sweep right -> left, then drop R at site 0
+  for (int i = L - 1; i >= 1; --i)
+    if ((rc = svd_shift_left(S, i, ids_, nj)) != TJM_OK) return rc;
+  if ((rc = launch_normsq(S.A[0], a_b0_[0], a_b0_[0], normsq_, nj, ids_, stream)) != TJM_OK) return rc;
+  hipLaunchKernelGGL(rsqrt_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, normsq_, scal_, B);
+  if ((rc = launch_scale(S.A[0], a_b0_[0], a_b0_[0], scal_, nj, ids_, nullptr, stream)) != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+}  // namespace tjm

@@ -1,0 +1,167 @@
+// Strided batched complex128 GEMM on the gfx950 fp64 matrix cores.
+//
+// One kernel serves every bond x bond x phys contraction of the TDVP sweep (merge_two_site,
+// the three tensordots of project_site / project_bond, the environment updates and the
+// centre-shift absorptions; reference: core/methods/tdvp/primitives.py:77-226,
+// core/methods/decompositions.py:87-102).  Layout permutations of the reference's
+// np.tensordot / transpose chains are absorbed into operand strides, so no tensor is ever
+// transposed in memory.
+//
+// Tiling: 256 threads = 4 wavefronts (2x2), block tile 64x64x16, every wave owns a 32x32
+// sub-tile = 2x2 MFMA tiles of v_mfma_f64_16x16x4_f64.  A complex product is four real
+// MFMAs into four accumulators (ArBr, AiBi, ArBi, AiBr); conjugation of either operand is a
+// sign choice in the epilogue.  Operands are staged through LDS as separate re/im planes,
+// k-major with a row pitch of 80 doubles so that the two k-groups of a ds_read_b64 half-wave
+// land in disjoint banks.  Global loads for tile k+1 are issued before the MFMAs of tile k.
+#include "tjm_common.h"
+
+namespace tjm {
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int PITCH = 80;  // doubles per k-row in LDS (64 + 16: second k-group -> banks 32..63)
+
+template <bool A_MCONTIG, bool B_NCONTIG>
+__global__ __launch_bounds__(256) void zgemm_kernel(GemmDesc g) {
+  __shared__ double sAr[BK * PITCH];
+  __shared__ double sAi[BK * PITCH];
+  __shared__ double sBr[BK * PITCH];
+  __shared__ double sBi[BK * PITCH];
+
+  int z = blockIdx.z;
+  const int b2 = z % g.nb2;
+  z /= g.nb2;
+  const int b1 = z % g.nb1;
+  int b0 = z / g.nb1;
+  if (g.ids) b0 = g.ids[b0];
+  if (g.active && g.active[b0] == 0) return;
+
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const cplx* __restrict__ Ab = g.A + (long)b0 * g.a_b0 + (long)b1 * g.a_b1 + (long)b2 * g.a_b2;
+  const cplx* __restrict__ Bb = g.B + (long)b0 * g.b_b0 + (long)b1 * g.b_b1 + (long)b2 * g.b_b2;
+  cplx* __restrict__ Cb = g.C + (long)b0 * g.c_b0 + (long)b1 * g.c_b1 + (long)b2 * g.c_b2;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+
+  // per-thread staging coordinates: 4 elements of A (64x16) and 4 of B (16x64)
+  int am[4], ak[4], bk[4], bn[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int idx = tid + e * 256;
+    if (A_MCONTIG) { am[e] = idx & 63; ak[e] = idx >> 6; }
+    else           { ak[e] = idx & 15; am[e] = idx >> 4; }
+    if (B_NCONTIG) { bn[e] = idx & 63; bk[e] = idx >> 6; }
+    else           { bk[e] = idx & 15; bn[e] = idx >> 4; }
+  }
+
+  d4 accP[2][2], accQ[2][2], accS1[2][2], accS2[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      accP[i][j] = d4{0, 0, 0, 0}; accQ[i][j] = d4{0, 0, 0, 0};
+      accS1[i][j] = d4{0, 0, 0, 0}; accS2[i][j] = d4{0, 0, 0, 0};
+    }
+
+  const int ktiles = (g.K + BK - 1) / BK;
+  const int total = ktiles * g.nks;
+  cplx ra[4], rb[4];
+
+  auto load_tile = [&](int it) {
+    const int ks = it / ktiles;
+    const int k0 = (it - ks * ktiles) * BK;
+    const cplx* Ap = Ab + (long)ks * g.a_ks;
+    const cplx* Bp = Bb + (long)ks * g.b_ks;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int m = m0 + am[e], k = k0 + ak[e];
+      ra[e] = (m < g.M && k < g.K) ? Ap[(long)m * g.a_rs + (long)k * g.a_cs] : cplx{0.0, 0.0};
+      int kk = k0 + bk[e], n = n0 + bn[e];
+      rb[e] = (kk < g.K && n < g.N) ? Bp[(long)kk * g.b_rs + (long)n * g.b_cs] : cplx{0.0, 0.0};
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sAr[ak[e] * PITCH + am[e]] = ra[e].x;
+      sAi[ak[e] * PITCH + am[e]] = ra[e].y;
+      sBr[bk[e] * PITCH + bn[e]] = rb[e].x;
+      sBi[bk[e] * PITCH + bn[e]] = rb[e].y;
+    }
+  };
+
+  load_tile(0);
+  const int li = lane & 15, lk = lane >> 4;
+  for (int it = 0; it < total; ++it) {
+    __syncthreads();  // previous tile's reads are done
+    store_tile();
+    __syncthreads();
+    if (it + 1 < total) load_tile(it + 1);  // in flight during the MFMAs below
+#pragma unroll
+    for (int s = 0; s < BK / 4; ++s) {
+      const int krow = (4 * s + lk) * PITCH;
+      double ar[2], ai[2], br[2], bi[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ar[i] = sAr[krow + wm + 16 * i + li];
+        ai[i] = sAi[krow + wm + 16 * i + li];
+        br[i] = sBr[krow + wn + 16 * i + li];
+        bi[i] = sBi[krow + wn + 16 * i + li];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          accP[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], br[j], accP[i][j], 0, 0, 0);
+          accQ[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i], bi[j], accQ[i][j], 0, 0, 0);
+          accS1[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], bi[j], accS1[i][j], 0, 0, 0);
+          accS2[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i], br[j], accS2[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // epilogue: Cr = P -/+ Q, Ci = +/-S1 +/- S2 depending on the conjugation flags
+  const double sq = (g.conjA != g.conjB) ? 1.0 : -1.0;
+  const double s1 = g.conjB ? -1.0 : 1.0;
+  const double s2 = g.conjA ? -1.0 : 1.0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m = m0 + wm + 16 * i + lk + 4 * r;
+        int n = n0 + wn + 16 * j + li;
+        if (m < g.M && n < g.N) {
+          cplx v;
+          v.x = accP[i][j][r] + sq * accQ[i][j][r];
+          v.y = s1 * accS1[i][j][r] + s2 * accS2[i][j][r];
+          Cb[(long)m * g.c_rs + n] = v;
+        }
+      }
+}
+
+}  // namespace
+
+int launch_gemm(const GemmDesc& g, hipStream_t stream) {
+  if (g.M <= 0 || g.N <= 0 || g.nb0 <= 0 || g.nb1 <= 0 || g.nb2 <= 0) return TJM_OK;
+  if (g.K <= 0 || g.nks <= 0) return TJM_ERR_ARG;
+  dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), 1, g.nb0 * g.nb1 * g.nb2);
+  dim3 block(256);
+  const bool am = (g.a_rs == 1 && g.a_cs != 1);
+  const bool bn = (g.b_cs == 1);
+  if (am && bn) hipLaunchKernelGGL((zgemm_kernel<true, true>), grid, block, 0, stream, g);
+  else if (am && !bn) hipLaunchKernelGGL((zgemm_kernel<true, false>), grid, block, 0, stream, g);
+  else if (!am && bn) hipLaunchKernelGGL((zgemm_kernel<false, true>), grid, block, 0, stream, g);
+  else hipLaunchKernelGGL((zgemm_kernel<false, false>), grid, block, 0, stream, g);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+}  // namespace tjm

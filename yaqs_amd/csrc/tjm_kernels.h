@@ -1,0 +1,100 @@
+// Launch wrappers for the helper kernels (tjm_kernels.hip) and the Jacobi SVD (tjm_svd.hip).
+#pragma once
+#include "tjm_common.h"
+
+namespace tjm {
+
+constexpr int TJM_MAX_PART = 64;  // partial sums per trajectory in two-stage reductions
+
+struct MpoApplyDesc {
+  const cplx* in;
+  cplx* out;
+  const cplx* Wm;  // [(po, bo)][(pi, bi)] row-major, (P*dout) x (P*din)
+  int P, din, dout;
+  int na, nB;
+  long in_sp, in_sb, in_sa;
+  long out_sp, out_sb, out_sa;
+  long in_b0, out_b0;
+  int nb0;
+  const int* ids;
+  const int* active;
+};
+int launch_mpo_apply(const MpoApplyDesc& d, hipStream_t stream);
+
+// Per-trajectory Krylov bookkeeping (device arrays, indexed by trajectory slot).
+struct KrylovState {
+  double* alpha;   // [B][mmax]
+  double* beta;    // [B][mmax]
+  cplx* coef;      // [B][mmax]
+  double* vnorm;   // [B]
+  double* scale;   // [B]  1/beta_j (or 1/|v|)
+  int* status;     // [B]  1 = still iterating, 0 = finished
+  int* kfinal;     // [B]
+  int* n_active;   // [1]
+  int mmax;
+};
+
+int launch_normsq_partial(const cplx* x, long x_b0, int n, double* part, int nb0, const int* ids, const int* active,
+                          hipStream_t s, int* nblk_out);
+int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n, double* part, int nb0, const int* ids,
+                       const int* active, hipStream_t s, int* nblk_out);
+int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, int n, const double* part1, double* part2,
+                        int nblk, const double* beta, int beta_ld, int j, int nb0, const int* ids, const int* active,
+                        hipStream_t s);
+int launch_scale(cplx* x, long x_b0, long n, const double* scale, int nb0, const int* ids, const int* active, hipStream_t s);
+int launch_lanczos_init(const KrylovState& ks, const double* part, int nblk, int nb0, const int* ids, hipStream_t s);
+int launch_lanczos_finalize(const KrylovState& ks, const double* part1, const double* part2, int nblk, int j, double dt,
+                            double tol, const int* nloc, int nb0, const int* ids, hipStream_t s);
+int launch_krylov_combine(const cplx* V, long v_b0, long v_ld, const KrylovState& ks, cplx* out, long out_b0, int n0, int n1,
+                          int n2, int n3, long o0, long o1, long o2, int nb0, const int* ids, hipStream_t s);
+int launch_tridiag_expm_test(const double* alpha, const double* beta, int k, double dt, double* out, hipStream_t s);
+int launch_normsq(const cplx* x, long x_b0, long n, double* out, int nb0, const int* ids, hipStream_t s);
+int launch_apply_local(cplx* x, long x_b0, int d, long rest, const cplx* ops, const int* op_index, int nb0, const int* ids,
+                       hipStream_t s);
+int launch_identity_env(cplx* E, long e_b0, int n, int D, int nb0, hipStream_t s);
+int launch_phys_overlap(const cplx* x, const cplx* y, long x_b0, long y_b0, int d, long rest, cplx* M, int nb0, const int* ids,
+                        hipStream_t s);
+
+// ---- batched one-sided block-Jacobi SVD (tjm_svd.hip) ---------------------------------------
+// Splits theta[b] (m x n, row-major, row pitch ld_theta) = U S V^H, truncates per the
+// reference's rule and writes the two site tensors.
+struct SvdSplitDesc {
+  const cplx* theta;   // [B] m x n matrices, rows (s, a), cols (t, c)
+  long theta_b0;
+  int ld_theta;
+  int m, n;            // padded matrix extents (m = d*capL, n = d*capR)
+  int d;               // physical dimension (rows = d x capL, cols = d x capR)
+  int capL, capR;      // padded left / right bond extents
+  int capM;            // padded middle bond extent of the output tensors
+  cplx* left;          // [B][d][capL][capM]
+  cplx* right;         // [B][d][capM][capR]
+  long left_b0, right_b0;
+  int distribution;    // 0 = "right" (left isometric), 1 = "left" (right isometric)
+  int trunc_mode;      // 0 discarded_weight, 1 relative, 2 hard_cutoff, 3 relative_discarded_weight
+  double threshold;
+  int max_bond;        // <= 0: none
+  int min_keep;
+  const int* chiL;     // actual left bond per trajectory, element stride chi_stride
+  const int* chiR;
+  int* chiM;           // out: new middle bond
+  int chi_stride;
+  double* spectrum;    // optional out [B][spec_ld] singular values (descending), may be null
+  int spec_ld;
+  int nb0;
+  const int* ids;
+};
+struct SvdWorkspace {
+  cplx* Y;        // [B][ncols_pad][rtot]  column-major stacked [X; W]
+  long y_b0;
+  double* norms;  // [B][ncols_pad]
+  double* fro2;   // [B] squared Frobenius norm of theta (noise floor for the rotations)
+  int* perm;      // [B][ncols_pad]
+  int* nrot;      // [B]
+  int* done;      // [B]
+  int* n_active;  // [1]
+  int* h_pinned;  // host pinned int for the active counter
+};
+size_t svd_workspace_bytes(int max_dim, int B);
+int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* sweeps_out);
+
+}  // namespace tjm

@@ -1,0 +1,502 @@
+// HBM-bound helper kernels of the TJM sweep: MPO application between the two GEMMs of
+// H_eff / environment updates, the fused Lanczos vector operations, the per-trajectory
+// Krylov bookkeeping (exp(-i dt T_k) e_1, adaptive stop), the basis combine, and the small
+// per-site kernels (norms, scalings, local operators, jump decisions).
+//
+// Reference: core/methods/matrix_exponential.py:33-173 (expm_krylov),
+// core/methods/tdvp/primitives.py:77-226, core/methods/stochastic_process.py:190-292.
+#include "tjm_kernels.h"
+
+namespace tjm {
+
+// ------------------------------------------------------------------------------------------
+// MPO apply:  out[po][bo][a][B] = sum_{pi,bi} Wm[(po,bo),(pi,bi)] * in[pi][bi][a][B]
+// (strides per index are free, B is contiguous on both sides).  One thread per (a, B).
+// ------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void mpo_apply_kernel(MpoApplyDesc d) {
+  extern __shared__ double smem[];
+  cplx* sW = reinterpret_cast<cplx*>(smem);
+  int b0 = blockIdx.y;
+  if (d.ids) b0 = d.ids[b0];
+  if (d.active && d.active[b0] == 0) return;
+  const int nin = P * d.din, nout = P * d.dout;
+  for (int i = threadIdx.x; i < nin * nout; i += blockDim.x) sW[i] = d.Wm[i];
+  __syncthreads();
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)d.na * d.nB) return;
+  const int a = idx / d.nB, Bc = idx % d.nB;
+  const cplx* __restrict__ in = d.in + (long)b0 * d.in_b0 + (long)a * d.in_sa + Bc;
+  cplx* __restrict__ out = d.out + (long)b0 * d.out_b0 + (long)a * d.out_sa + Bc;
+  for (int bo = 0; bo < d.dout; ++bo) {
+    cplx acc[P];
+#pragma unroll
+    for (int po = 0; po < P; ++po) acc[po] = cplx{0.0, 0.0};
+    for (int bi = 0; bi < d.din; ++bi) {
+      cplx x[P];
+#pragma unroll
+      for (int pi = 0; pi < P; ++pi) x[pi] = in[(long)pi * d.in_sp + (long)bi * d.in_sb];
+#pragma unroll
+      for (int po = 0; po < P; ++po)
+#pragma unroll
+        for (int pi = 0; pi < P; ++pi) cfma(acc[po], sW[(po * d.dout + bo) * nin + pi * d.din + bi], x[pi]);
+    }
+#pragma unroll
+    for (int po = 0; po < P; ++po) out[(long)po * d.out_sp + (long)bo * d.out_sb] = acc[po];
+  }
+}
+
+int launch_mpo_apply(const MpoApplyDesc& d, hipStream_t stream) {
+  const long n = (long)d.na * d.nB;
+  if (n <= 0 || d.nb0 <= 0) return TJM_OK;
+  dim3 grid((unsigned)((n + 255) / 256), d.nb0);
+  size_t sh = sizeof(cplx) * (size_t)(d.P * d.din) * (d.P * d.dout);
+  if (d.P == 2) hipLaunchKernelGGL(mpo_apply_kernel<2>, grid, dim3(256), sh, stream, d);
+  else if (d.P == 4) hipLaunchKernelGGL(mpo_apply_kernel<4>, grid, dim3(256), sh, stream, d);
+  else if (d.P == 1) hipLaunchKernelGGL(mpo_apply_kernel<1>, grid, dim3(256), sh, stream, d);
+  else return TJM_ERR_NOT_IMPLEMENTED;
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// block reduction helper (256 threads, result valid in every thread)
+// ------------------------------------------------------------------------------------------
+__device__ inline double block_sum(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int w = 0; w < nw; ++w) t += sh[w];
+  return t;
+}
+
+// part[b][blk] = sum over this block's chunk of |x|^2          (x = vector j of trajectory b)
+__global__ __launch_bounds__(256) void normsq_partial_kernel(const cplx* __restrict__ x, long x_b0, int n, double* part,
+                                                            int nblk, const int* ids, const int* active) {
+  __shared__ double sh[4];
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  if (active && active[b] == 0) return;
+  const cplx* xb = x + (long)b * x_b0;
+  double acc = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nblk * blockDim.x) {
+    cplx v = xb[i];
+    acc = fma(v.x, v.x, acc);
+    acc = fma(v.y, v.y, acc);
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = acc;
+}
+
+// part[b][blk] = Re <v, w> over the chunk
+__global__ __launch_bounds__(256) void dot_partial_kernel(const cplx* __restrict__ v, const cplx* __restrict__ w, long v_b0,
+                                                         long w_b0, int n, double* part, int nblk, const int* ids,
+                                                         const int* active) {
+  __shared__ double sh[4];
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  if (active && active[b] == 0) return;
+  const cplx* vb = v + (long)b * v_b0;
+  const cplx* wb = w + (long)b * w_b0;
+  double acc = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nblk * blockDim.x) {
+    cplx a = vb[i], c = wb[i];
+    acc = fma(a.x, c.x, acc);
+    acc = fma(a.y, c.y, acc);
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) part[(long)b * nblk + blockIdx.x] = acc;
+}
+
+// w -= alpha v_j + beta_{j-1} v_{j-1};  part2[b][blk] = sum |w|^2.  alpha = sum(part1[b][:]).
+__global__ __launch_bounds__(256) void lanczos_axpy_kernel(cplx* __restrict__ w, const cplx* __restrict__ vj,
+                                                          const cplx* __restrict__ vjm1, long v_b0, int n,
+                                                          const double* part1, double* part2, int nblk,
+                                                          const double* beta, int beta_ld, int j, const int* ids,
+                                                          const int* active) {
+  __shared__ double sh[4];
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  if (active && active[b] == 0) return;
+  double alpha = 0.0;
+  for (int i = 0; i < nblk; ++i) alpha += part1[(long)b * nblk + i];
+  const double bprev = (j > 0) ? beta[(long)b * beta_ld + j - 1] : 0.0;
+  cplx* wb = w + (long)b * v_b0;
+  const cplx* vb = vj + (long)b * v_b0;
+  const cplx* ub = vjm1 + (long)b * v_b0;
+  double acc = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nblk * blockDim.x) {
+    cplx x = wb[i], a = vb[i];
+    x.x = fma(-alpha, a.x, x.x);
+    x.y = fma(-alpha, a.y, x.y);
+    if (j > 0) {
+      cplx u = ub[i];
+      x.x = fma(-bprev, u.x, x.x);
+      x.y = fma(-bprev, u.y, x.y);
+    }
+    wb[i] = x;
+    acc = fma(x.x, x.x, acc);
+    acc = fma(x.y, x.y, acc);
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) part2[(long)b * nblk + blockIdx.x] = acc;
+}
+
+// x *= scale[b]
+__global__ __launch_bounds__(256) void scale_kernel(cplx* __restrict__ x, long x_b0, long n, const double* scale, const int* ids,
+                                                   const int* active) {
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  if (active && active[b] == 0) return;
+  const double s = scale[b];
+  cplx* xb = x + (long)b * x_b0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    cplx v = xb[i];
+    v.x *= s;
+    v.y *= s;
+    xb[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// phi = exp(-i dt T_k) e_1 for the real symmetric tridiagonal T_k (k <= 64), one wavefront.
+// Shift by the Gershgorin centre, split the remaining phase radius rho into s = ceil(rho)
+// sub-steps and apply a degree-22 Taylor polynomial per sub-step (|arg| <= 1): unitary to
+// ~1e-16 per sub-step, no eigen-decomposition.  The reference diagonalises T_k with LAPACK
+// (matrix_exponential.py:147-163); both evaluate the same analytic function.
+// Lane i holds entry i.  Returns phi_i in (pr, pi).
+// ------------------------------------------------------------------------------------------
+__device__ inline void tridiag_expm_e1(const double* alpha, const double* beta, int k, double dt, int lane, double& pr,
+                                       double& pi, int ov_idx = -1, double ov_val = 0.0) {
+  // alpha[ov_idx] may have been written by this very wavefront an instant ago: take it from a register
+  const double a = (lane < k) ? ((lane == ov_idx) ? ov_val : alpha[lane]) : 0.0;
+  const double bu = (lane < k - 1) ? beta[lane] : 0.0;                 // couples lane <-> lane+1
+  const double bl = (lane >= 1 && lane < k) ? beta[lane - 1] : 0.0;    // couples lane <-> lane-1
+  double lo = (lane < k) ? a - fabs(bu) - fabs(bl) : 1e300;
+  double hi = (lane < k) ? a + fabs(bu) + fabs(bl) : -1e300;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, o, 64));
+    hi = fmax(hi, __shfl_xor(hi, o, 64));
+  }
+  const double mu = 0.5 * (lo + hi);
+  const double rho = fabs(dt) * 0.5 * (hi - lo);
+  int nsub = (int)ceil(rho);
+  if (nsub < 1) nsub = 1;
+  const double h = dt / nsub;
+  const double as = a - mu;
+  double xr = (lane == 0) ? 1.0 : 0.0, xi = 0.0;
+  for (int s = 0; s < nsub; ++s) {
+    double tr = xr, ti = xi, sr = xr, si = xi;
+    for (int n = 1; n <= 22; ++n) {
+      // t <- (-i h / n) * T t
+      double ur = __shfl_up(tr, 1, 64), ui = __shfl_up(ti, 1, 64);
+      double dr = __shfl_down(tr, 1, 64), di = __shfl_down(ti, 1, 64);
+      if (lane == 0) { ur = 0.0; ui = 0.0; }
+      double yr = as * tr + bl * ur + bu * dr;
+      double yi = as * ti + bl * ui + bu * di;
+      const double c = h / n;
+      tr = c * yi;   // (-i)(yr + i yi) = yi - i yr
+      ti = -c * yr;
+      sr += tr;
+      si += ti;
+    }
+    xr = sr;
+    xi = si;
+  }
+  // global phase exp(-i dt mu)
+  double sn, cs;
+  sincos(-dt * mu, &sn, &cs);
+  pr = xr * cs - xi * sn;
+  pi = xr * sn + xi * cs;
+  if (lane >= k) { pr = 0.0; pi = 0.0; }
+}
+
+__global__ __launch_bounds__(64) void tridiag_expm_test_kernel(const double* alpha, const double* beta, int k, double dt,
+                                                              double* out) {
+  double pr, pi;
+  tridiag_expm_e1(alpha, beta, k, dt, threadIdx.x, pr, pi);
+  if ((int)threadIdx.x < k) { out[2 * threadIdx.x] = pr; out[2 * threadIdx.x + 1] = pi; }
+}
+
+int launch_tridiag_expm_test(const double* alpha, const double* beta, int k, double dt, double* out, hipStream_t s) {
+  if (k < 1 || k > 64) return TJM_ERR_ARG;
+  hipLaunchKernelGGL(tridiag_expm_test_kernel, dim3(1), dim3(64), 0, s, alpha, beta, k, dt, out);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// Lanczos start: vnorm = sqrt(sum part), status, first scale
+__global__ __launch_bounds__(64) void lanczos_init_kernel(KrylovState ks, const double* part, int nblk, int nb, const int* ids) {
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  if (threadIdx.x != 0) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += part[(long)b * nblk + i];
+  const double nrm = sqrt(s);
+  ks.vnorm[b] = nrm;
+  if (nrm == 0.0) {
+    ks.status[b] = 0;  // finished: result is the zero vector
+    ks.kfinal[b] = 1;
+    ks.coef[(long)b * ks.mmax] = cplx{0.0, 0.0};
+    ks.scale[b] = 0.0;
+  } else {
+    ks.status[b] = 1;
+    ks.kfinal[b] = 0;
+    ks.scale[b] = 1.0 / nrm;
+    atomicAdd(ks.n_active, 1);
+  }
+}
+
+// One wavefront per trajectory: store alpha_j / beta_j, breakdown and adaptive-stop tests
+// (matrix_exponential.py:100-163), coefficient vector on exit.
+__global__ __launch_bounds__(64) void lanczos_finalize_kernel(KrylovState ks, const double* part1, const double* part2, int nblk,
+                                                             int j, double dt, double tol, const int* nloc, const int* ids) {
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  if (ks.status[b] == 0) return;
+  const int lane = threadIdx.x;
+  const int m = ks.mmax;
+  double* al = ks.alpha + (long)b * m;
+  double* be = ks.beta + (long)b * m;
+  double a = 0.0, s2 = 0.0;
+  for (int i = 0; i < nblk; ++i) {
+    a += part1[(long)b * nblk + i];
+    s2 += part2[(long)b * nblk + i];
+  }
+  const double bj = sqrt(s2);
+  if (lane == 0) {
+    al[j] = a;
+    if (j < m - 1) be[j] = bj;
+  }
+  const double eps_cut = 100.0 * (double)nloc[b] * 2.220446049250313e-16;
+  bool done = false;
+  const int k = j + 1;
+  double pr = 0.0, pi = 0.0;
+  if (j < m - 1 && bj < eps_cut) {
+    tridiag_expm_e1(al, be, k, dt, lane, pr, pi, j, a);
+    done = true;
+  } else if (j >= 1 || j == m - 1) {
+    tridiag_expm_e1(al, be, k, dt, lane, pr, pi, j, a);
+    if (j == m - 1) {
+      done = true;
+    } else {
+      const double lr = __shfl(pr, k - 1, 64), li = __shfl(pi, k - 1, 64);
+      done = (bj * sqrt(lr * lr + li * li) < tol);
+    }
+  }
+  if (done) {
+    const double nrm = ks.vnorm[b];
+    if (lane < k) ks.coef[(long)b * m + lane] = cplx{pr * nrm, pi * nrm};
+    if (lane == 0) {
+      ks.status[b] = 0;
+      ks.kfinal[b] = k;
+    }
+  } else if (lane == 0) {
+    ks.scale[b] = 1.0 / bj;
+    atomicAdd(ks.n_active, 1);
+  }
+}
+
+// out = sum_{j<kfinal} coef_j V_j, with a 4-level output index permutation.
+__global__ __launch_bounds__(256) void krylov_combine_kernel(const cplx* __restrict__ V, long v_b0, long v_ld, KrylovState ks,
+                                                            cplx* __restrict__ out, long out_b0, int n1, int n2, int n3, long o0,
+                                                            long o1, long o2, long n, const int* ids) {
+  __shared__ cplx sc[64];
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  const int k = ks.kfinal[b];
+  if (threadIdx.x < k) sc[threadIdx.x] = ks.coef[(long)b * ks.mmax + threadIdx.x];
+  __syncthreads();
+  const cplx* Vb = V + (long)b * v_b0;
+  cplx* ob = out + (long)b * out_b0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    cplx acc{0.0, 0.0};
+    for (int j = 0; j < k; ++j) cfma(acc, sc[j], Vb[(long)j * v_ld + e]);
+    long i3 = e % n3, r = e / n3;
+    long i2 = r % n2;
+    r /= n2;
+    long i1 = r % n1, i0 = r / n1;
+    ob[i0 * o0 + i1 * o1 + i2 * o2 + i3] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+static inline int nblk_for(long n) {
+  long nb = (n + 1023) / 1024;
+  if (nb < 1) nb = 1;
+  if (nb > TJM_MAX_PART) nb = TJM_MAX_PART;
+  return (int)nb;
+}
+
+int launch_normsq_partial(const cplx* x, long x_b0, int n, double* part, int nb0, const int* ids, const int* active,
+                          hipStream_t s, int* nblk_out) {
+  const int nblk = nblk_for(n);
+  *nblk_out = nblk;
+  hipLaunchKernelGGL(normsq_partial_kernel, dim3(nblk, nb0), dim3(256), 0, s, x, x_b0, n, part, nblk, ids, active);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n, double* part, int nb0, const int* ids,
+                       const int* active, hipStream_t s, int* nblk_out) {
+  const int nblk = nblk_for(n);
+  *nblk_out = nblk;
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(nblk, nb0), dim3(256), 0, s, v, w, v_b0, w_b0, n, part, nblk, ids, active);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, int n, const double* part1, double* part2,
+                        int nblk, const double* beta, int beta_ld, int j, int nb0, const int* ids, const int* active,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(lanczos_axpy_kernel, dim3(nblk, nb0), dim3(256), 0, s, w, vj, vjm1, v_b0, n, part1, part2, nblk, beta,
+                     beta_ld, j, ids, active);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+int launch_scale(cplx* x, long x_b0, long n, const double* scale, int nb0, const int* ids, const int* active, hipStream_t s) {
+  int gx = (int)((n + 1023) / 1024);
+  if (gx < 1) gx = 1;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(scale_kernel, dim3(gx, nb0), dim3(256), 0, s, x, x_b0, n, scale, ids, active);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+int launch_lanczos_init(const KrylovState& ks, const double* part, int nblk, int nb0, const int* ids, hipStream_t s) {
+  hipLaunchKernelGGL(lanczos_init_kernel, dim3(nb0), dim3(64), 0, s, ks, part, nblk, nb0, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+int launch_lanczos_finalize(const KrylovState& ks, const double* part1, const double* part2, int nblk, int j, double dt,
+                            double tol, const int* nloc, int nb0, const int* ids, hipStream_t s) {
+  hipLaunchKernelGGL(lanczos_finalize_kernel, dim3(nb0), dim3(64), 0, s, ks, part1, part2, nblk, j, dt, tol, nloc, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+int launch_krylov_combine(const cplx* V, long v_b0, long v_ld, const KrylovState& ks, cplx* out, long out_b0, int n0, int n1,
+                          int n2, int n3, long o0, long o1, long o2, int nb0, const int* ids, hipStream_t s) {
+  const long n = (long)n0 * n1 * n2 * n3;
+  int gx = (int)((n + 1023) / 1024);
+  if (gx < 1) gx = 1;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(krylov_combine_kernel, dim3(gx, nb0), dim3(256), 0, s, V, v_b0, v_ld, ks, out, out_b0, n1, n2, n3, o0, o1,
+                     o2, n, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// small per-site kernels
+// ------------------------------------------------------------------------------------------
+// out[b] = sum |x_b|^2   (one block per trajectory)
+__global__ __launch_bounds__(256) void normsq_kernel(const cplx* __restrict__ x, long x_b0, long n, double* out, const int* ids) {
+  __shared__ double sh[4];
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  const cplx* xb = x + (long)b * x_b0;
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    cplx v = xb[i];
+    acc = fma(v.x, v.x, acc);
+    acc = fma(v.y, v.y, acc);
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) out[b] = acc;
+}
+
+int launch_normsq(const cplx* x, long x_b0, long n, double* out, int nb0, const int* ids, hipStream_t s) {
+  hipLaunchKernelGGL(normsq_kernel, dim3(nb0), dim3(256), 0, s, x, x_b0, n, out, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// x[p][r] <- sum_q O_b[p][q] x[q][r]   (physical-leg operator, per-trajectory operator index)
+// ops: table of d x d matrices; op_index[b] < 0 => identity (skip)
+__global__ __launch_bounds__(256) void apply_local_kernel(cplx* __restrict__ x, long x_b0, int d, long rest, const cplx* ops,
+                                                         const int* op_index, const int* ids) {
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  const int oi = op_index ? op_index[b] : 0;
+  if (oi < 0) return;
+  const cplx* O = ops + (long)oi * d * d;
+  cplx* xb = x + (long)b * x_b0;
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rest; r += (long)gridDim.x * blockDim.x) {
+    cplx v[4], y[4];
+    for (int q = 0; q < d; ++q) v[q] = xb[(long)q * rest + r];
+    for (int p = 0; p < d; ++p) {
+      cplx acc{0.0, 0.0};
+      for (int q = 0; q < d; ++q) cfma(acc, O[p * d + q], v[q]);
+      y[p] = acc;
+    }
+    for (int p = 0; p < d; ++p) xb[(long)p * rest + r] = y[p];
+  }
+}
+
+int launch_apply_local(cplx* x, long x_b0, int d, long rest, const cplx* ops, const int* op_index, int nb0, const int* ids,
+                       hipStream_t s) {
+  if (d > 4) return TJM_ERR_NOT_IMPLEMENTED;
+  int gx = (int)((rest + 255) / 256);
+  if (gx > 128) gx = 128;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(apply_local_kernel, dim3(gx, nb0), dim3(256), 0, s, x, x_b0, d, rest, ops, op_index, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// E[b][i][a][i] = 1 for i < n (boundary environment, primitives.py:161-168)
+__global__ void identity_env_kernel(cplx* E, long e_b0, int n, int D, int nb0) {
+  int b = blockIdx.x;
+  for (int t = threadIdx.x; t < n * D * n; t += blockDim.x) {
+    int i = t / (D * n), r = t % (D * n), k = r % n;
+    E[(long)b * e_b0 + t] = cplx{(i == k) ? 1.0 : 0.0, 0.0};
+  }
+}
+
+int launch_identity_env(cplx* E, long e_b0, int n, int D, int nb0, hipStream_t s) {
+  hipLaunchKernelGGL(identity_env_kernel, dim3(nb0), dim3(64), 0, s, E, e_b0, n, D, nb0);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// M[b][p][q] = <x_p | y_q> = sum_r conj(x[p][r]) y[q][r]   (d x d physical overlap matrix)
+__global__ __launch_bounds__(256) void phys_overlap_kernel(const cplx* __restrict__ x, const cplx* __restrict__ y, long x_b0,
+                                                          long y_b0, int d, long rest, cplx* M, const int* ids) {
+  __shared__ double sh[4];
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  const cplx* xb = x + (long)b * x_b0;
+  const cplx* yb = y + (long)b * y_b0;
+  for (int p = 0; p < d; ++p)
+    for (int q = 0; q < d; ++q) {
+      double ar = 0.0, ai = 0.0;
+      for (long r = threadIdx.x; r < rest; r += blockDim.x) {
+        cplx a = xb[(long)p * rest + r], c = yb[(long)q * rest + r];
+        ar += a.x * c.x + a.y * c.y;
+        ai += a.x * c.y - a.y * c.x;
+      }
+      ar = block_sum(ar, sh);
+      ai = block_sum(ai, sh);
+      if (threadIdx.x == 0) M[((long)b * d + p) * d + q] = cplx{ar, ai};
+    }
+}
+
+int launch_phys_overlap(const cplx* x, const cplx* y, long x_b0, long y_b0, int d, long rest, cplx* M, int nb0, const int* ids,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(phys_overlap_kernel, dim3(nb0), dim3(256), 0, s, x, y, x_b0, y_b0, d, rest, M, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+}  // namespace tjm

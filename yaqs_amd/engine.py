@@ -1,0 +1,156 @@
+"""Python handle on the batched HIP engine (one GPU, B trajectories in lock-step).
+
+PyTorch is used for device storage only: the workspace is one uint8 tensor whose
+``data_ptr`` is handed to the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+
+TRUNC_MODES = {"discarded_weight": 0, "relative": 1, "hard_cutoff": 2, "relative_discarded_weight": 3}
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+class BatchEngine:
+    def __init__(self, length: int, chi_max: int, batch: int, mpo: Sequence[np.ndarray], device: str = "cuda:0", d: int = 2):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise _lib.TjmError("yaqs_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
+        self.torch = torch
+        self.lib = _lib.load()
+        self.L, self.d, self.chi_max, self.B = int(length), int(d), int(chi_max), int(batch)
+        self.device = torch.device(device)
+        bonds = [int(mpo[0].shape[2])] + [int(w.shape[3]) for w in mpo]
+        self.mpo_bonds = _i32(bonds)
+        h = C.c_void_p()
+        _lib.check(self.lib.tjm_engine_create(C.byref(h), self.L, self.d, self.chi_max, self.B, self.mpo_bonds.ctypes.data), "create")
+        self.h = h
+        nbytes = self.lib.tjm_engine_workspace_bytes(self.h)
+        self.workspace_bytes = int(nbytes)
+        with torch.cuda.device(self.device):
+            self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            self.stream = torch.cuda.current_stream(self.device)
+        _lib.check(self.lib.tjm_engine_bind(self.h, self.ws.data_ptr(), nbytes, C.c_void_p(self.stream.cuda_stream)), "bind")
+        packed = np.concatenate([np.ascontiguousarray(w, dtype=np.complex128).reshape(-1) for w in mpo])
+        _lib.check(self.lib.tjm_engine_set_mpo(self.h, packed.ctypes.data), "set_mpo")
+        caps = np.zeros(self.L + 1, dtype=np.int32)
+        self.lib.tjm_engine_bond_caps(self.h, caps.ctypes.data)
+        self.caps = caps
+        self.padded_elems = int(self.lib.tjm_engine_padded_state_elems(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tjm_engine_destroy(self.h)
+            self.h = None
+            self.ws = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration ---------------------------------------------------------------
+    def set_params(self, *, dt, svd_threshold, trunc_mode="discarded_weight", max_bond_dim=None, krylov_tol=1e-4, tdvp_mode="2site",
+                   tdvp_sweeps=1):
+        if tdvp_mode != "2site":
+            raise NotImplementedError(f"tdvp_mode {tdvp_mode!r} is not built yet in the HIP path")
+        _lib.check(self.lib.tjm_engine_set_params(self.h, float(dt), float(svd_threshold), TRUNC_MODES[trunc_mode],
+                                                  -1 if max_bond_dim is None else int(max_bond_dim), float(krylov_tol), 2, int(tdvp_sweeps)),
+                   "set_params")
+
+    def set_noise(self, processes, is_pauli_flags):
+        n = len(processes)
+        nsites = np.zeros(max(n, 1), dtype=np.int32)
+        sites = np.zeros(2 * max(n, 1), dtype=np.int32)
+        gamma = np.zeros(max(n, 1))
+        pauli = np.zeros(max(n, 1), dtype=np.int32)
+        mats = np.zeros((max(n, 1), 16), dtype=np.complex128)
+        facs = np.zeros((max(n, 1), 8), dtype=np.complex128)
+        hasf = np.zeros(max(n, 1), dtype=np.int32)
+        for k, p in enumerate(processes):
+            s = list(p["sites"])
+            nsites[k] = len(s)
+            sites[2 * k] = s[0]
+            sites[2 * k + 1] = s[1] if len(s) > 1 else s[0]
+            gamma[k] = p["strength"]
+            pauli[k] = int(bool(is_pauli_flags[k]))
+            if "matrix" in p:
+                m = np.asarray(p["matrix"], dtype=np.complex128).reshape(-1)
+                mats[k, : m.size] = m
+            if "factors" in p:
+                facs[k, :4] = np.asarray(p["factors"][0], dtype=np.complex128).reshape(-1)
+                facs[k, 4:] = np.asarray(p["factors"][1], dtype=np.complex128).reshape(-1)
+                hasf[k] = 1
+        _lib.check(self.lib.tjm_engine_set_noise(self.h, n, nsites.ctypes.data, sites.ctypes.data, gamma.ctypes.data, pauli.ctypes.data,
+                                                 mats.ctypes.data, facs.ctypes.data, hasf.ctypes.data), "set_noise")
+
+    def load_state(self, tensors: Sequence[np.ndarray], set_index: int = 0):
+        bonds = _i32([tensors[0].shape[1]] + [t.shape[2] for t in tensors])
+        packed = np.concatenate([np.ascontiguousarray(t, dtype=np.complex128).reshape(-1) for t in tensors])
+        _lib.check(self.lib.tjm_engine_load_state(self.h, set_index, packed.ctypes.data, bonds.ctypes.data), "load_state")
+
+    def copy_state(self, dst: int, src: int):
+        _lib.check(self.lib.tjm_engine_copy_state(self.h, dst, src), "copy_state")
+
+    def export_state(self, b: int, set_index: int = 0) -> list[np.ndarray]:
+        buf = np.zeros(self.padded_elems, dtype=np.complex128)
+        bonds = np.zeros(self.L + 1, dtype=np.int32)
+        _lib.check(self.lib.tjm_engine_export_state(self.h, set_index, b, buf.ctypes.data, bonds.ctypes.data), "export_state")
+        out, off = [], 0
+        for i in range(self.L):
+            cl, cr = int(self.caps[i]), int(self.caps[i + 1])
+            t = buf[off: off + self.d * cl * cr].reshape(self.d, cl, cr)
+            off += self.d * cl * cr
+            out.append(t[:, : bonds[i], : bonds[i + 1]].copy())
+        return out
+
+    def set_uniforms(self, u: np.ndarray):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        assert u.shape[0] == self.B
+        _lib.check(self.lib.tjm_engine_set_uniforms(self.h, u.ctypes.data, u.shape[1]), "set_uniforms")
+
+    # -- the path --------------------------------------------------------------------
+    def tdvp(self, set_index: int = 0):
+        _lib.check(self.lib.tjm_engine_tdvp(self.h, set_index), "tdvp")
+
+    def dissipate(self, dt: float, set_index: int = 0):
+        _lib.check(self.lib.tjm_engine_dissipate(self.h, set_index, float(dt)), "dissipate")
+
+    def stochastic(self, dt: float, set_index: int = 0):
+        jumped = np.zeros(self.B, dtype=np.int32)
+        dp = np.zeros(self.B)
+        _lib.check(self.lib.tjm_engine_stochastic(self.h, set_index, float(dt), jumped.ctypes.data, dp.ctypes.data), "stochastic")
+        return jumped, dp
+
+    def site_moments(self, set_index: int = 0) -> np.ndarray:
+        m = np.zeros((self.L, self.B, self.d, self.d), dtype=np.complex128)
+        _lib.check(self.lib.tjm_engine_site_moments(self.h, set_index, m.ctypes.data), "site_moments")
+        return m
+
+    def bond_dims(self, set_index: int = 0) -> np.ndarray:
+        chi = np.zeros((self.B, self.L + 1), dtype=np.int32)
+        _lib.check(self.lib.tjm_engine_bond_dims(self.h, set_index, chi.ctypes.data), "bond_dims")
+        return chi
+
+    def site0_normsq(self, set_index: int = 0) -> np.ndarray:
+        out = np.zeros(self.B)
+        _lib.check(self.lib.tjm_engine_site0_normsq(self.h, set_index, out.ctypes.data), "site0_normsq")
+        return out
+
+    def stats(self) -> dict:
+        s = np.zeros(5, dtype=np.int64)
+        self.lib.tjm_engine_stats(self.h, s.ctypes.data)
+        return dict(matvecs=int(s[0]), krylov_calls=int(s[1]), svds=int(s[2]), svd_sweeps=int(s[3]), site_updates=int(s[4]))
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)

@@ -1,0 +1,238 @@
+"""Batched TJM trajectory drivers on the HIP engine and the ``Simulator`` front end.
+
+Restates the control flow of the reference drivers for a whole batch of trajectories
+advancing in lock-step (paths relative to /root/reference/src/mqt/yaqs):
+
+* ``analog_tjm_1`` / ``analog_tjm_2``        analog/analog_tjm.py:206-462
+* RNG streams                                 core/random_utils.py:15-69
+* ``Simulator.run`` (MPS analog branch)       simulator.py:1173-1312, 1444-1679
+* trajectory sharding replaces                core/parallel_utils.py:331-390
+"""
+from __future__ import annotations
+
+import os
+from typing import Sequence
+
+import numpy as np
+
+from .api import AnalogSimParams, MPO, MPS, NoiseModel, Result, is_pauli
+from .engine import BatchEngine
+
+TAG_TRAJ = 0x5452414A
+TAG_SAMPLE = 0x53414D50
+
+
+def trajectory_uniforms(seed: int | None, traj: int, n: int) -> np.ndarray:
+    """First ``n`` doubles of ``make_trajectory_rng(traj, base_seed=seed)`` (random_utils.py:20-37)."""
+    rng = np.random.default_rng() if seed is None else np.random.default_rng(np.random.SeedSequence([seed, traj, TAG_TRAJ]))
+    return rng.random(n)
+
+
+def sample_uniforms(seed: int | None, traj: int, timestep: int, n: int = 2) -> np.ndarray:
+    """First doubles of ``make_sample_rng`` (random_utils.py:40-69)."""
+    rng = np.random.default_rng() if seed is None else np.random.default_rng(np.random.SeedSequence([seed, traj, timestep, TAG_SAMPLE]))
+    return rng.random(n)
+
+
+def _diagnostics_from_bonds(chi: np.ndarray, d: int) -> np.ndarray:
+    """record_diagnostics (mps.py:549-602) from the bond table chi[B, L+1] -> [B, 3]."""
+    inner = chi[:, 1:-1].astype(np.float64)
+    cost = np.sum(inner ** 3, axis=1)
+    max_bond = np.maximum(d, np.max(chi[:, 1:], axis=1)).astype(np.float64)
+    total = np.sum(inner, axis=1)
+    return np.stack([cost, max_bond, total], axis=1)
+
+
+class TrajectoryBatch:
+    """Runs trajectories ``traj_indices`` (one per engine slot) through one TJM driver."""
+
+    def __init__(self, engine: BatchEngine, params: AnalogSimParams, noise: NoiseModel | None):
+        self.e = engine
+        self.p = params
+        self.noise = noise if (noise is not None and noise.processes) else None
+        if params.tdvp_mode != "2site":
+            raise NotImplementedError(f"tdvp_mode {params.tdvp_mode!r} is not built yet in the HIP path")
+        for obs in params.observables:
+            if isinstance(obs.sites, (list, tuple)) and len(obs.sites) != 1:
+                raise NotImplementedError("two-site observables are not built yet in the HIP path")
+        engine.set_params(dt=params.dt, svd_threshold=params.svd_threshold, trunc_mode=params.trunc_mode,
+                          max_bond_dim=params.max_bond_dim, krylov_tol=params.krylov_tol, tdvp_mode=params.tdvp_mode,
+                          tdvp_sweeps=params.tdvp_sweeps)
+        procs = self.noise.processes if self.noise is not None else []
+        engine.set_noise(procs, [is_pauli(q) for q in procs])
+        self.sorted_obs = params.sorted_observables
+        self.dp_log: list[np.ndarray] = []
+        self.jump_log: list[np.ndarray] = []
+
+    # ---- measurement ----------------------------------------------------------------
+    def _measure(self, set_index: int, results: np.ndarray, diagnostics: np.ndarray, col: int) -> None:
+        e = self.e
+        M = e.site_moments(set_index)  # [L, B, d, d]
+        for row, obs in enumerate(self.sorted_obs):
+            site = obs.first_site
+            O = np.asarray(obs.gate.matrix, dtype=np.complex128)
+            val = np.einsum("pq,bpq->b", O, M[site])
+            if np.any(val.imag >= 1e-13):
+                raise AssertionError(f"Measurement should be real, got max imag {val.imag.max():.3e}")  # mps.py:1233
+            results[:, row, col] = val.real
+        diagnostics[:, :, col] = _diagnostics_from_bonds(e.bond_dims(set_index), e.d)
+
+    def _stochastic(self, set_index: int, dt: float, u: np.ndarray, pos: np.ndarray | None) -> None:
+        """One stochastic_process call; ``u[b, pos[b]:pos[b]+2]`` are the candidate draws."""
+        e = self.e
+        if self.noise is None:
+            e.set_uniforms(np.zeros((e.B, 2)))
+            e.stochastic(dt, set_index)
+            return
+        if pos is None:
+            cand = u[:, :2]
+        else:
+            cand = np.stack([u[np.arange(e.B), pos], u[np.arange(e.B), pos + 1]], axis=1)
+        e.set_uniforms(cand)
+        jumped, dp = e.stochastic(dt, set_index)
+        self.dp_log.append(dp.copy())
+        self.jump_log.append(jumped.copy())
+        if pos is not None:
+            pos += 1 + jumped
+
+    # ---- drivers --------------------------------------------------------------------
+    def run(self, traj_indices: Sequence[int], initial: MPS):
+        e, p = self.e, self.p
+        assert len(traj_indices) == e.B
+        n_t = len(p.times)
+        cols = n_t if p.sample_timesteps else 1
+        results = np.zeros((e.B, len(self.sorted_obs), cols))
+        diagnostics = np.zeros((e.B, 3, cols))
+        e.load_state(initial.tensors, 0)
+        n_draw = 2 * n_t + 2
+        u = np.stack([trajectory_uniforms(p.random_seed, int(t), n_draw) for t in traj_indices])
+        pos = np.zeros(e.B, dtype=np.int64)
+        if p.order == 2:
+            self._run_order2(traj_indices, results, diagnostics, u, pos)
+        else:
+            self._run_order1(results, diagnostics, u, pos)
+        return results, diagnostics
+
+    def _run_order1(self, results, diagnostics, u, pos):
+        """analog_tjm_1 (analog_tjm.py:369-462)."""
+        e, p = self.e, self.p
+        n_t = len(p.times)
+        if p.sample_timesteps:
+            self._measure(0, results, diagnostics, 0)
+        for j in range(1, n_t):
+            e.tdvp(0)
+            if self.noise is not None:
+                e.dissipate(p.dt, 0)
+                self._stochastic(0, p.dt, u, pos)
+            if p.sample_timesteps or j == n_t - 1:
+                self._measure(0, results, diagnostics, j if p.sample_timesteps else 0)
+        if not p.sample_timesteps and n_t <= 1:
+            self._measure(0, results, diagnostics, 0)
+
+    def _run_order2(self, traj_indices, results, diagnostics, u, pos):
+        """analog_tjm_2 (analog_tjm.py:206-366), standalone form."""
+        e, p = self.e, self.p
+        n_t = len(p.times)
+
+        def record(j):
+            return True if p.sample_timesteps else j == n_t - 1
+
+        def sample(j):
+            if not record(j):
+                return
+            e.copy_state(1, 0)  # psi = deepcopy(phi)
+            e.tdvp(1)
+            e.dissipate(p.dt / 2, 1)
+            us = np.stack([sample_uniforms(p.random_seed, int(t), j) for t in traj_indices])
+            self._stochastic(1, p.dt, us, None)
+            self._measure(1, results, diagnostics, j if p.sample_timesteps else 0)
+
+        if n_t == 1:
+            if record(0):
+                self._measure(0, results, diagnostics, 0)
+            return
+        if record(0):
+            self._measure(0, results, diagnostics, 0)
+        e.dissipate(p.dt / 2, 0)
+        self._stochastic(0, p.dt, u, pos)
+        sample(1)
+        for j in range(2, n_t):
+            e.tdvp(0)
+            e.dissipate(p.dt, 0)
+            self._stochastic(0, p.dt, u, pos)
+            sample(j)
+
+
+class Simulator:
+    """``Simulator().run(state, hamiltonian, sim_params, noise_model) -> Result`` (simulator.py:1173-1312).
+
+    ``batch`` trajectories are resident on the GPU at a time; with ``torch.distributed``
+    initialised, trajectory indices are sharded contiguously over ranks and the observable /
+    diagnostic sums are combined with one all-reduce.
+    """
+
+    def __init__(self, batch: int | None = None, device: str | None = None, show_progress: bool = False):
+        self.batch = batch
+        self.device = device
+        self.show_progress = show_progress
+
+    def run(self, initial_state: MPS, hamiltonian: MPO, sim_params: AnalogSimParams, noise_model: NoiseModel | None = None) -> Result:
+        import torch
+
+        if hamiltonian.length != initial_state.length:
+            raise ValueError("State and Hamiltonian must have the same number of sites")  # tdvp.py:91-93
+        rank, world = 0, 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        device = self.device or f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
+        noisy = noise_model is not None and any(q["strength"] != 0 for q in noise_model.processes)
+        num_traj = sim_params.num_traj if noisy else 1  # simulator.py:1549-1559
+        lo, hi = shard_range(num_traj, rank, world)
+        mine = list(range(lo, hi))
+        chi = sim_params.max_bond_dim or max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors)
+        chi = max(chi, max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors))
+        cols = len(sim_params.times) if sim_params.sample_timesteps else 1
+        n_obs = len(sim_params.observables)
+        res_all = np.zeros((len(mine), n_obs, cols))
+        diag_all = np.zeros((len(mine), 3, cols))
+        B = min(self.batch or 64, max(len(mine), 1))
+        done = 0
+        engine = None
+        while done < len(mine):
+            chunk = mine[done: done + B]
+            if engine is None or engine.B != len(chunk):
+                if engine is not None:
+                    engine.close()
+                engine = BatchEngine(initial_state.length, chi, len(chunk), hamiltonian.tensors, device=device)
+            tb = TrajectoryBatch(engine, sim_params, noise_model if noisy else None)
+            r, dg = tb.run(chunk, initial_state)
+            res_all[done: done + len(chunk)] = r
+            diag_all[done: done + len(chunk)] = dg
+            done += len(chunk)
+        if engine is not None:
+            engine.close()
+        if world > 1:
+            res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, lo, device)
+        return Result(sim_params, res_all, diag_all)
+
+
+def shard_range(num_traj: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous trajectory-index range of ``rank``."""
+    return (num_traj * rank) // world, (num_traj * (rank + 1)) // world
+
+
+def gather_trajectories(res: np.ndarray, diag: np.ndarray, num_traj: int, lo: int, device):
+    """Place this rank's rows into the global buffers and all-reduce(sum) them over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    full_r = np.zeros((num_traj,) + res.shape[1:])
+    full_d = np.zeros((num_traj,) + diag.shape[1:])
+    full_r[lo: lo + res.shape[0]] = res
+    full_d[lo: lo + diag.shape[0]] = diag
+    dev = torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
+    tr = torch.from_numpy(full_r).to(dev)
+    td = torch.from_numpy(full_d).to(dev)
+    dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+    dist.all_reduce(td, op=dist.ReduceOp.SUM)
+    return tr.cpu().numpy(), td.cpu().numpy()
