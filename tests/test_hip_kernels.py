@@ -136,7 +136,8 @@ def test_svd_split_matches_oracle(lib, capL, capR, dist):
     theta[2] *= 1e-3
     chiL = np.full(B, capL, dtype=np.int32)
     chiR = np.full(B, capR, dtype=np.int32)
-    thr, maxb, mk = 1e-6, max(1, capM - 1), 2 if capM >= 2 else 1
+    thr, maxb = 1e-6, max(1, capM - 1)
+    mk = min(2, maxb)
     left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, capL, capR, capM, dist, 0, thr, maxb, mk, chiL, chiR)
     for b in range(B):
         merged = theta[b].reshape(d, capL, d, capR).transpose(0, 2, 1, 3).reshape(d * d, capL, capR)

@@ -289,6 +289,24 @@ class MPS:
                 raise ValueError("Invalid state string")
             self.tensors.append(v.reshape(2, 1, 1))
 
+    def normalize(self, form: str = "B") -> None:
+        """Right-canonical form with centre 0 and norm 1 (``MPS.normalize("B")``, mps.py:815-839).
+
+        One-off host preparation of the input state (the reference does this in
+        ``State.ensure_encoded``, state.py:278-297, above the trajectory path).
+        """
+        if form != "B":
+            raise ValueError("only form 'B' is prepared on the host")
+        t = self.tensors
+        for i in range(self.length - 1, 0, -1):
+            d, cl, cr = t[i].shape
+            m = t[i].transpose(1, 0, 2).reshape(cl, d * cr)          # (chi_l, d*chi_r)
+            q, r = np.linalg.qr(m.conj().T)                           # m^H = q r  ->  m = r^H q^H
+            k = q.shape[1]
+            t[i] = q.conj().T.reshape(k, d, cr).transpose(1, 0, 2)
+            t[i - 1] = np.einsum("sab,bk->sak", t[i - 1], r.conj().T)
+        t[0] = t[0] / np.linalg.norm(t[0])
+
     @staticmethod
     def bond_caps(length: int, target: int, d: int = 2) -> list[int]:
         caps = [1] * (length + 1)
