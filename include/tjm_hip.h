@@ -107,6 +107,13 @@ int tjm_svd_split(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t
 /* exp(-i dt T_k) e_1 of the Lanczos tridiagonal (matrix_exponential.py:147-163); device pointers. */
 int tjm_tridiag_expm(const double* alpha, const double* beta, int32_t k, double dt, double* out_k_complex, void* hip_stream);
 
+/* ---- measurement ---------------------------------------------------------------------- *
+ * Brackets every `every`-th launch of the dominant kernel (the Jacobi block-pair kernel of the SVD split)
+ * with HIP events on the launch stream; 0 switches it off.  read(): summed duration [ms], summed
+ * algorithmic bytes (2 x 16 columns x rows x 16 B per block-pair visit of a live trajectory), sample count. */
+int tjm_profile_cross_kernel(int32_t every);
+int tjm_profile_cross_kernel_read(double* total_ms, double* total_bytes, int64_t* samples);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,4 +199,4 @@ def test_svd_split_chi128_rank_deficient(lib):
         assert np.allclose(spec[b, :cap], s_ref[:cap], atol=1e-12)
         rec = left[b].reshape(d * cap, cap) @ right[b].transpose(1, 0, 2).reshape(cap, d * cap)
         assert np.allclose(rec, theta[b], atol=1e-12)
-    assert sweeps < 25
+    assert sweeps < 40

@@ -22,8 +22,12 @@ e.set_noise(nm.processes, [is_pauli(p) for p in nm.processes])
 e.load_state(st.tensors)
 rng = np.random.default_rng(0)
 for s in range(steps):
+    s0 = e.stats()
     t0 = time.time(); e.tdvp(); e.synchronize(); t1 = time.time()
+    s1 = e.stats()
     e.dissipate(0.1); e.synchronize(); t2 = time.time()
+    s2 = e.stats()
+    print("   tdvp svds", s1["svds"]-s0["svds"], "sweeps", s1["svd_sweeps"]-s0["svd_sweeps"], "| diss svds", s2["svds"]-s1["svds"], "sweeps", s2["svd_sweeps"]-s1["svd_sweeps"])
     e.set_uniforms(rng.random((B, 2)))
     j, dp = e.stochastic(0.1); e.synchronize(); t3 = time.time()
     print(f"step {s}: tdvp {t1-t0:.3f}s diss {t2-t1:.3f}s stoch {t3-t2:.3f}s  jumps {j.sum()}/{B} dp {dp[:3]}", e.stats(), flush=True)

@@ -70,6 +70,8 @@ EXPORTS = {
     "tjm_svd_workspace_bytes": (C.c_size_t, [I, I]),
     "tjm_svd_split": (C.c_int, [V, I, I, I, I, I, V, V, I, I, D, I, I, V, V, I, V, C.c_size_t, V, V]),
     "tjm_tridiag_expm": (C.c_int, [V, V, I, D, V, V]),
+    "tjm_profile_cross_kernel": (C.c_int, [I]),
+    "tjm_profile_cross_kernel_read": (C.c_int, [V, V, V]),
 }
 
 _lib = None

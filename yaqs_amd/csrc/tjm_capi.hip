@@ -140,7 +140,7 @@ int tjm_svd_split(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t
   char* w = static_cast<char*>(work);
   auto take = [&](size_t nbytes) { char* q = w; w += (nbytes + 255) / 256 * 256; return q; };
   SvdWorkspace sw;
-  sw.y_b0 = (long)p * 2 * p;
+  sw.y_b0 = (long)p * ((2 * p + 63) / 64 * 64);
   sw.Y = reinterpret_cast<cplx*>(take((size_t)B * sw.y_b0 * sizeof(cplx)));
   sw.norms = reinterpret_cast<double*>(take((size_t)B * p * sizeof(double)));
   sw.perm = reinterpret_cast<int*>(take((size_t)B * p * sizeof(int)));
@@ -163,6 +163,19 @@ int tjm_svd_split(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t
   const int rc = svd_split(s, sw, stream, &sweeps);
   if (sweeps_out) *sweeps_out = sweeps;
   return rc;
+}
+
+int tjm_profile_cross_kernel(int32_t every) {
+  profile_enable(every);
+  return TJM_OK;
+}
+
+int tjm_profile_cross_kernel_read(double* total_ms, double* total_bytes, int64_t* samples) {
+  if (!total_ms || !total_bytes || !samples) return TJM_ERR_ARG;
+  long n = 0;
+  profile_get(total_ms, total_bytes, &n);
+  *samples = n;
+  return TJM_OK;
 }
 
 int tjm_tridiag_expm(const double* alpha, const double* beta, int32_t k, double dt, double* out, void* stream) {

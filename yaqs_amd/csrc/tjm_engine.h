@@ -107,6 +107,10 @@ class Engine {
   int set_nloc(StateSet& S, int bl, int br, int P);
   int svd_shift_right(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left(StateSet& S, int i, const int* ids, int nb0);
+  int svd_shift_left_rc(StateSet& S, int i, const int* ids, int nb0);
+  int svd_shift_left_2site(StateSet& S, int i, const int* ids, int nb0);
+  int copy_back(cplx* dst, long dst_b0, const cplx* src, long src_b0, long n, const int* ids, int nb0);
+  std::vector<int> unitary_jump_;
 };
 
 }  // namespace tjm

@@ -87,7 +87,7 @@ size_t Engine::workspace_bytes() const {
   tot += align_up((size_t)B * (mmax + 1) * nloc * sizeof(cplx));
   const int p = round16(d * cm);
   tot += align_up((size_t)B * (size_t)(d * cm) * (d * cm) * sizeof(cplx));
-  tot += align_up((size_t)B * p * 2 * p * sizeof(cplx));               // Y
+  tot += align_up((size_t)B * p * ((2 * p + 63) / 64 * 64) * sizeof(cplx));  // Y
   tot += align_up((size_t)B * p * sizeof(double)) + align_up((size_t)B * p * sizeof(int));
   tot += 8 * align_up((size_t)B * sizeof(double) * 4);
   tot += 2 * align_up((size_t)B * TJM_MAX_PART * sizeof(double));
@@ -126,7 +126,7 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   theta_b0 = (long)(d * cm) * (d * cm);
   theta = reinterpret_cast<cplx*>(take((size_t)B * theta_b0 * sizeof(cplx)));
   const int pp = round16(d * cm);
-  svdw.y_b0 = (long)pp * 2 * pp;
+  svdw.y_b0 = (long)pp * ((2 * pp + 63) / 64 * 64);
   svdw.Y = reinterpret_cast<cplx*>(take((size_t)B * svdw.y_b0 * sizeof(cplx)));
   svdw.norms = reinterpret_cast<double*>(take((size_t)B * pp * sizeof(double)));
   svdw.perm = reinterpret_cast<int*>(take((size_t)B * pp * sizeof(int)));
@@ -548,17 +548,137 @@ int Engine::tdvp(int set) {
 // ------------------------------------------------------------------------------------------
 // SVD centre shifts (mps.py:747-788): two-site merge + split, discarded_weight 1e-12, no cap
 // ------------------------------------------------------------------------------------------
+// Centre shift i -> i+1 when A_{i+1} is right-isometric: theta = A_i A_{i+1} has the singular values of the
+// matrix A_i[(s,a), b], so the 256 x 256 two-site SVD reduces to a (d chi_l) x chi_r one:
+//   A_i = U S V^H  ->  A_i <- U ,  A_{i+1} <- (S V^H) A_{i+1}        (same truncation rule, same state)
 int Engine::svd_shift_right(StateSet& S, int i, const int* ids, int nb0) {
+  const int ca = cap[i], cb = cap[i + 1], cc = cap[i + 2];
   int rc;
-  if ((rc = merge_matrix_layout(S, i, ids, nb0)) != TJM_OK) return rc;
-  return split(S, i, 0, 0, 1e-12, 0, 1, ids, nb0);
+  JacobiSource src;
+  src.src = S.A[i]; src.src_b0 = a_b0_[i]; src.rx = d * ca; src.ncols = cb; src.conj = 0;
+  src.r_n0 = ca; src.s_r1 = (long)ca * cb; src.s_r0 = cb; src.c_n0 = cb; src.s_c1 = 0; src.s_c0 = 1;
+  src.nb0 = nb0; src.ids = ids;
+  TruncSpec tr;
+  tr.trunc_mode = 0; tr.threshold = 1e-12; tr.max_bond = 0; tr.min_keep = 1;
+  tr.chiA = S.chi + i; tr.mulA = d; tr.chiB = S.chi + i + 1; tr.mulB = 1; tr.chiOut = S.chi + i + 1; tr.chi_stride = L + 1;
+  tr.spectrum = nullptr; tr.spec_ld = 0;
+  JacobiShape sh;
+  int sweeps = 0;
+  if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps)) != TJM_OK) return rc;
+  ++stat_svds; stat_svd_sweeps += sweeps;
+  ExtractDesc xu;  // A_i[(s,a)][k] = X_final / sigma
+  xu.out = S.A[i]; xu.out_b0 = a_b0_[i]; xu.n_k = cb; xu.o_k = 1; xu.n_r1 = 1; xu.n_r0 = d * ca; xu.o_r1 = 0; xu.o_r0 = cb;
+  xu.row_off = 0; xu.conj = 0; xu.scale_mode = 2;
+  if ((rc = svd_extract(xu, svdw, sh, S.chi + i + 1, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
+  ExtractDesc xg;  // G[k][j] = sigma_k conj(V[j][k])
+  xg.out = theta; xg.out_b0 = theta_b0; xg.n_k = cb; xg.o_k = cb; xg.n_r1 = 1; xg.n_r0 = cb; xg.o_r1 = 0; xg.o_r0 = 1;
+  xg.row_off = sh.rx_top; xg.conj = 1; xg.scale_mode = 1;
+  if ((rc = svd_extract(xg, svdw, sh, S.chi + i + 1, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
+  GemmDesc g = blank_gemm();  // T1[t][k][c] = G[k][j] A_{i+1}[t][j][c]
+  g.A = theta; g.B = S.A[i + 1]; g.C = T1;
+  g.M = cb; g.K = cb; g.N = cc;
+  g.a_rs = cb; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = cc;
+  g.nb0 = nb0; g.nb1 = d; g.a_b0 = theta_b0; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cb * cc; g.c_b0 = a_b0_[i + 1]; g.c_b1 = (long)cb * cc;
+  g.ids = ids;
+  // product goes to a packed temp (stride a_b0) and is copied back
+  g.C = T1; g.c_b0 = t_b0;
+  if ((rc = gemm(g)) != TJM_OK) return rc;
+  return copy_back(S.A[i + 1], a_b0_[i + 1], T1, t_b0, a_b0_[i + 1], ids, nb0);
 }
 
+// Centre shift i -> i-1 when A_{i-1} is left-isometric (mirror image of svd_shift_right):
+//   A_i[a,(t,c)] = U S V^H  ->  A_i <- V^H ,  A_{i-1} <- A_{i-1} (U S)
 int Engine::svd_shift_left(StateSet& S, int i, const int* ids, int nb0) {
-  // centre i -> i-1: split theta(i-1, i) with the singular values absorbed to the left
+  const int cz = cap[i - 1], ca = cap[i], cb = cap[i + 1];
+  int rc;
+  JacobiSource src;  // X = M^H : rows (t,c), columns a
+  src.src = S.A[i]; src.src_b0 = a_b0_[i]; src.rx = d * cb; src.ncols = ca; src.conj = 1;
+  src.r_n0 = cb; src.s_r1 = (long)ca * cb; src.s_r0 = 1; src.c_n0 = ca; src.s_c1 = 0; src.s_c0 = cb;
+  src.nb0 = nb0; src.ids = ids;
+  TruncSpec tr;
+  tr.trunc_mode = 0; tr.threshold = 1e-12; tr.max_bond = 0; tr.min_keep = 1;
+  tr.chiA = S.chi + i; tr.mulA = 1; tr.chiB = S.chi + i + 1; tr.mulB = d; tr.chiOut = S.chi + i; tr.chi_stride = L + 1;
+  tr.spectrum = nullptr; tr.spec_ld = 0;
+  JacobiShape sh;
+  int sweeps = 0;
+  if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps)) != TJM_OK) return rc;
+  ++stat_svds; stat_svd_sweeps += sweeps;
+  ExtractDesc xv;  // A_i[t][k][c] = conj(X_final[(t,c)][k]) / sigma
+  xv.out = S.A[i]; xv.out_b0 = a_b0_[i]; xv.n_k = ca; xv.o_k = cb; xv.n_r1 = d; xv.n_r0 = cb; xv.o_r1 = (long)ca * cb; xv.o_r0 = 1;
+  xv.row_off = 0; xv.conj = 1; xv.scale_mode = 2;
+  if ((rc = svd_extract(xv, svdw, sh, S.chi + i, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
+  ExtractDesc xg;  // G[a][k] = U[a][k] sigma_k
+  xg.out = theta; xg.out_b0 = theta_b0; xg.n_k = ca; xg.o_k = 1; xg.n_r1 = 1; xg.n_r0 = ca; xg.o_r1 = 0; xg.o_r0 = ca;
+  xg.row_off = sh.rx_top; xg.conj = 0; xg.scale_mode = 1;
+  if ((rc = svd_extract(xg, svdw, sh, S.chi + i, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
+  GemmDesc g = blank_gemm();  // T1[s][z][k] = A_{i-1}[s][z][a] G[a][k]
+  g.A = S.A[i - 1]; g.B = theta; g.C = T1;
+  g.M = d * cz; g.K = ca; g.N = ca;
+  g.a_rs = ca; g.a_cs = 1; g.b_rs = ca; g.b_cs = 1; g.c_rs = ca;
+  g.nb0 = nb0; g.a_b0 = a_b0_[i - 1]; g.b_b0 = theta_b0; g.c_b0 = t_b0;
+  g.ids = ids;
+  if ((rc = gemm(g)) != TJM_OK) return rc;
+  return copy_back(S.A[i - 1], a_b0_[i - 1], T1, t_b0, a_b0_[i - 1], ids, nb0);
+}
+
+// Gauge sweep step of normalize("B", "SVD") (mps.py:815-839) on a right-canonical tail: theta = A_{i-1} A_i with
+// A_i right-isometric has the singular values of A_{i-1}[(s,z), a]:
+//   A_{i-1} = U S V^H  ->  A_{i-1} <- U S (= A_{i-1} V, no division) ,  A_i <- V^H A_i
+int Engine::svd_shift_left_rc(StateSet& S, int i, const int* ids, int nb0) {
+  const int cz = cap[i - 1], ca = cap[i], cb = cap[i + 1];
+  int rc;
+  JacobiSource src;  // X = A_{i-1} as (d cz) x ca
+  src.src = S.A[i - 1]; src.src_b0 = a_b0_[i - 1]; src.rx = d * cz; src.ncols = ca; src.conj = 0;
+  src.r_n0 = cz; src.s_r1 = (long)cz * ca; src.s_r0 = ca; src.c_n0 = ca; src.s_c1 = 0; src.s_c0 = 1;
+  src.nb0 = nb0; src.ids = ids;
+  TruncSpec tr;
+  tr.trunc_mode = 0; tr.threshold = 1e-12; tr.max_bond = 0; tr.min_keep = 1;
+  tr.chiA = S.chi + i - 1; tr.mulA = d; tr.chiB = S.chi + i; tr.mulB = 1; tr.chiOut = S.chi + i; tr.chi_stride = L + 1;
+  tr.spectrum = nullptr; tr.spec_ld = 0;
+  JacobiShape sh;
+  int sweeps = 0;
+  if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps)) != TJM_OK) return rc;
+  ++stat_svds; stat_svd_sweeps += sweeps;
+  ExtractDesc xu;  // A_{i-1}[(s,z)][k] = X_final
+  xu.out = S.A[i - 1]; xu.out_b0 = a_b0_[i - 1]; xu.n_k = ca; xu.o_k = 1; xu.n_r1 = 1; xu.n_r0 = d * cz; xu.o_r1 = 0; xu.o_r0 = ca;
+  xu.row_off = 0; xu.conj = 0; xu.scale_mode = 0;
+  if ((rc = svd_extract(xu, svdw, sh, S.chi + i, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
+  ExtractDesc xg;  // Vh[k][a] = conj(V[a][k])
+  xg.out = theta; xg.out_b0 = theta_b0; xg.n_k = ca; xg.o_k = ca; xg.n_r1 = 1; xg.n_r0 = ca; xg.o_r1 = 0; xg.o_r0 = 1;
+  xg.row_off = sh.rx_top; xg.conj = 1; xg.scale_mode = 0;
+  if ((rc = svd_extract(xg, svdw, sh, S.chi + i, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
+  GemmDesc g = blank_gemm();  // T1[t][k][c] = Vh[k][a] A_i[t][a][c]
+  g.A = theta; g.B = S.A[i]; g.C = T1;
+  g.M = ca; g.K = ca; g.N = cb;
+  g.a_rs = ca; g.a_cs = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb;
+  g.nb0 = nb0; g.nb1 = d; g.a_b0 = theta_b0; g.b_b0 = a_b0_[i]; g.b_b1 = (long)ca * cb; g.c_b0 = t_b0; g.c_b1 = (long)ca * cb;
+  g.ids = ids;
+  if ((rc = gemm(g)) != TJM_OK) return rc;
+  return copy_back(S.A[i], a_b0_[i], T1, t_b0, a_b0_[i], ids, nb0);
+}
+
+// General centre shift i -> i-1 by the two-site SVD (mps.py:771-788), any gauge.
+int Engine::svd_shift_left_2site(StateSet& S, int i, const int* ids, int nb0) {
   int rc;
   if ((rc = merge_matrix_layout(S, i - 1, ids, nb0)) != TJM_OK) return rc;
   return split(S, i - 1, 1, 0, 1e-12, 0, 1, ids, nb0);
+}
+
+__global__ __launch_bounds__(256) void copy_back_kernel(cplx* __restrict__ dst, long dst_b0, const cplx* __restrict__ src, long src_b0, long n,
+                                                       const int* ids) {
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+    dst[(long)b * dst_b0 + e] = src[(long)b * src_b0 + e];
+}
+
+int Engine::copy_back(cplx* dst, long dst_b0, const cplx* src, long src_b0, long n, const int* ids, int nb0) {
+  int gx = (int)((n + 1023) / 1024);
+  if (gx < 1) gx = 1;
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(copy_back_kernel, dim3(gx, nb0), dim3(256), 0, stream, dst, dst_b0, src, src_b0, n, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
 }
 
 // x *= s (uniform scalar over the batch)
@@ -766,6 +886,7 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
   TJM_HIP_CHECK(hipMemcpyAsync(ops_, optab.data(), optab.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
 
   std::vector<int> opi(B, -1), opi2(B, -1), js(B, -1), js2(B, -1);
+  unitary_jump_.assign(B, 0);
   bool any_second = false;
   std::vector<double> w(order.size());
   for (int b : jumped) {
@@ -800,6 +921,7 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
     const NoiseProc& p = noise_[order[choice]];
     js[b] = p.site0;
     opi[b] = op_first[order[choice]];
+    unitary_jump_[b] = p.pauli ? 1 : 0;
     if (p.nsites == 2) { js2[b] = p.site1; opi2[b] = op_first[order[choice]] + 1; any_second = true; }
   }
   // device tables for the per-trajectory site application
@@ -826,9 +948,33 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
     hipLaunchKernelGGL(apply_local_multi_kernel, dim3(64, nj), dim3(256), 0, stream, d_sp, d_sb, d_sr, d, ops_, opidx_, jsite_, ids_);
     TJM_HIP_CHECK(hipStreamSynchronize(stream));
   }
-  // ---- normalize("B", "SVD") on the jumped trajectories (mps.py:815-839): SVD sweep right -> left, then drop R at site 0
-  for (int i = L - 1; i >= 1; --i)
-    if ((rc = svd_shift_left(S, i, ids_, nj)) != TJM_OK) return rc;
+  // ---- normalize("B", "SVD") on the jumped trajectories (mps.py:815-839): SVD sweep right -> left, then drop R at site 0.
+  // While the tensor right of the bond is still right-isometric (always for unitary jump operators, otherwise right of
+  // the jump site) the two-site SVD equals the one-tensor SVD of svd_shift_left_rc; elsewhere the two-site path runs.
+  {
+    std::vector<int> lst_short, lst_full;
+    int* ids_full = opidx_;  // the operator-index table is no longer needed: reuse it as the second id list
+    for (int i = L - 1; i >= 1; --i) {
+      lst_short.clear();
+      lst_full.clear();
+      for (int b : jumped) {
+        const bool unitary = unitary_jump_[b];
+        const int jlast = (js2[b] >= 0) ? js2[b] : js[b];
+        if (unitary || i > jlast) lst_short.push_back(b);
+        else lst_full.push_back(b);
+      }
+      if (!lst_short.empty()) {
+        TJM_HIP_CHECK(hipMemcpyAsync(ids_, lst_short.data(), lst_short.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        if ((rc = svd_shift_left_rc(S, i, ids_, (int)lst_short.size())) != TJM_OK) return rc;
+      }
+      if (!lst_full.empty()) {
+        TJM_HIP_CHECK(hipMemcpyAsync(ids_full, lst_full.data(), lst_full.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        if ((rc = svd_shift_left_2site(S, i, ids_full, (int)lst_full.size())) != TJM_OK) return rc;
+      }
+      TJM_HIP_CHECK(hipStreamSynchronize(stream));  // host vectors are reused next iteration
+    }
+    TJM_HIP_CHECK(hipMemcpyAsync(ids_, jumped.data(), nj * sizeof(int), hipMemcpyHostToDevice, stream));
+  }
   if ((rc = launch_normsq(S.A[0], a_b0_[0], a_b0_[0], normsq_, nj, ids_, stream)) != TJM_OK) return rc;
   hipLaunchKernelGGL(rsqrt_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, normsq_, scal_, B);
   if ((rc = launch_scale(S.A[0], a_b0_[0], a_b0_[0], scal_, nj, ids_, nullptr, stream)) != TJM_OK) return rc;

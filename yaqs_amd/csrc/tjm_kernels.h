@@ -94,7 +94,49 @@ struct SvdWorkspace {
   int* n_active;  // [1]
   int* h_pinned;  // host pinned int for the active counter
 };
+// Generic one-sided Jacobi problem: X[r][c] (rx x ncols) read through two-level strided indices
+//   r = r1 * r_n0 + r0 ,  c = c1 * c_n0 + c0 ,  X[r][c] = op(src[b*src_b0 + r1*s_r1 + r0*s_r0 + c1*s_c1 + c0*s_c0])
+struct JacobiSource {
+  const cplx* src;
+  long src_b0;
+  int rx, ncols;
+  int r_n0, c_n0;
+  long s_r1, s_r0, s_c1, s_c0;
+  int conj;
+  int nb0;
+  const int* ids;
+};
+// Truncation rule (core/linalg/svd_utils.py:22-104); number of singular values = min(mulA*chiA, mulB*chiB)
+struct TruncSpec {
+  int trunc_mode;
+  double threshold;
+  int max_bond, min_keep;
+  const int* chiA; int mulA;
+  const int* chiB; int mulB;
+  int* chiOut;
+  int chi_stride;
+  double* spectrum;
+  int spec_ld;
+};
+struct JacobiShape { int ncols_pad, rx_top, rtot; };
+// out[b][k*o_k + r1*o_r1 + r0*o_r0] = scale_k * op(Ycol[perm[k]][row_off + r1*n_r0 + r0]) for k < keep, 0 for keep <= k < n_k
+// scale_mode: 0 none, 1 multiply by sigma_k, 2 divide by sigma_k
+struct ExtractDesc {
+  cplx* out;
+  long out_b0;
+  int n_k; long o_k;
+  int n_r1, n_r0; long o_r1, o_r0;
+  int row_off;
+  int conj;
+  int scale_mode;
+};
 size_t svd_workspace_bytes(int max_dim, int B);
+void profile_enable(int every);
+void profile_get(double* total_ms, double* total_bytes, long* samples);
+int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspace& w, hipStream_t s, JacobiShape* shape_out,
+                 int* sweeps_out);
+int svd_extract(const ExtractDesc& x, const SvdWorkspace& w, const JacobiShape& sh, const int* chi_keep, int chi_stride, int nb0,
+                const int* ids, hipStream_t s);
 int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* sweeps_out);
 
 }  // namespace tjm

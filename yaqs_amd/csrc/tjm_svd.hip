@@ -1,38 +1,43 @@
-// Batched truncated SVD split of the two-site tensor: one-sided block-Jacobi (Hestenes) on
-// the fp64 matrix cores, with the reference's truncation rule applied on the device.
+// Batched truncated SVD for the TJM sweep: register-resident one-sided Jacobi (Hestenes) with
+// the reference's truncation rule applied on the device.
 //
 // Replaces decompositions.py:105-185 (split_two_site: scipy zgesdd + linalg.truncate,
-// core/linalg/svd_utils.py:22-104) for a whole batch of trajectories at once.
+// core/linalg/svd_utils.py:22-104) and the SVD centre shifts of mps.py:747-788 for a whole
+// batch of trajectories at once.
 //
-// Method.  For "right" distribution (left tensor isometric) the kernel orthogonalises the
-// columns of X = theta^H, for "left" distribution the columns of X = theta, by plane
-// rotations accumulated in W (X W = Q Sigma).  The isometric output is always read from the
-// accumulated unitary W and the sigma-weighted output from the rotated X, so no division by
-// a singular value ever happens (a zero singular value kept by min_keep = 2 is harmless).
-// Columns are processed as block pairs of 2 x 8 columns: the stacked tile [X; W] (16 columns)
-// is staged in LDS, its 16 x 16 Gram matrix is formed with v_mfma_f64_16x16x4_f64, the Gram
-// matrix is (nearly) diagonalised by a small cyclic Jacobi in one wavefront, and the
-// resulting 16 x 16 unitary is applied to all rows of the tile with MFMAs again.  Block pairs
-// of one round-robin round are independent, so one launch handles (pairs x trajectories)
-// workgroups.  Trajectories whose sweep performed no rotation are flagged done and skipped.
+// Method.  The columns of X (rx x ncols) are orthogonalised by plane rotations accumulated in
+// W (X W = Q Sigma, W unitary).  The stacked matrix Y = [X; W] is stored column-major in HBM /
+// Infinity Cache (2 MiB per trajectory at d*chi = 256).  Columns are grouped in blocks of 8:
+//   * jacobi_cross_kernel: one workgroup (8 wavefronts) per block pair (I, J) of a round-robin
+//     round.  Wavefront w keeps column w of block I and one column of block J in registers
+//     (lane l holds rows l, l+64, ...), computes <y_I, y_J> over the X rows with a wavefront
+//     reduction, rotates both columns in registers, then the J columns move one wavefront on
+//     through LDS.  8 steps visit the 64 cross pairs of the block pair; each column is read
+//     from and written to memory once per visit, with 1 KiB coalesced accesses.
+//   * jacobi_diag_kernel: the 28 pairs inside each block, LDS-resident, once per sweep.
+// A sweep is 1 diag launch + (nblk - 1) cross launches over (block pairs x trajectories)
+// workgroups; trajectories whose sweep performed no rotation are flagged done and skipped.
+// The isometric output is always read from W and the sigma-weighted output from the rotated
+// X for the two-site split, so that path never divides by a singular value.
+#include <utility>
+#include <vector>
+
 #include "tjm_kernels.h"
 
 namespace tjm {
 
 namespace {
 
-constexpr int NB = 8;       // columns per block
-constexpr int TC = 2 * NB;  // columns per tile
+constexpr int NB = 8;        // columns per block
+constexpr int MAXRK = 8;     // row groups of 64 per column held in registers (rtot <= 512)
 
 struct JacobiArgs {
   cplx* Y;
   long y_b0;
-  int rtot;     // rows of the stacked tile (multiple of 16)
-  int rx;       // rows of X (top part, multiple of 16)
+  int rtot;     // rows of the stacked column (multiple of 64)
+  int rx;       // rows of X (top part)
   int nblk;     // number of column blocks (even)
   int round;    // round-robin round
-  int cs;       // LDS column pitch in doubles
-  int max_inner;
   double tol2;  // squared relative tolerance
   const double* fro2;
   int* nrot;
@@ -53,256 +58,249 @@ __device__ inline void pair_of(int nblk, int round, int p, int& I, int& J) {
   if (I > J) { int t = I; I = J; J = t; }
 }
 
-// cyclic Jacobi on the 16x16 Hermitian matrix in LDS (sA), accumulating W (sW); wave 0 only.
-// Wave-synchronous: a single wavefront executes in lock-step; wave barriers order LDS traffic.
-__device__ inline int inner_jacobi(cplx* sA, cplx* sW, double* sRot, int lane, int max_inner, double tol2, double floor2) {
-  // sW = identity
-  for (int t = lane; t < TC * TC; t += 64) sW[t] = cplx{(t / TC == t % TC) ? 1.0 : 0.0, 0.0};
-  __builtin_amdgcn_wave_barrier();
-  int first_count = 0;
-  for (int sweep = 0; sweep < max_inner; ++sweep) {
-    int sweep_count = 0;
-    for (int step = 0; step < TC - 1; ++step) {
-      // lanes 0..7: rotation for pair (p, q) of this step
-      if (lane < TC / 2) {
-        int p, q;
-        pair_of(TC, step, lane, p, q);
-        const double app = sA[p * TC + p].x, aqq = sA[q * TC + q].x;
-        const cplx apq = sA[p * TC + q];
-        const double mag2 = apq.x * apq.x + apq.y * apq.y;
-        double c = 1.0, sr = 0.0, si = 0.0;
-        int rot = 0;
-        const double big = fmax(app, aqq);
-        // rotate only if the pair is non-orthogonal at the 1e-14 level, the rotation angle is above
-        // 1e-15 and the two columns are not both at the rounding-noise floor of the matrix
-        if (mag2 > tol2 * app * aqq && mag2 > 1e-30 * big * big && app * aqq > floor2 && mag2 > 1e-300) {
-          const double mag = sqrt(mag2);
-          const double tau = (aqq - app) / (2.0 * mag);
-          const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          c = 1.0 / sqrt(1.0 + t * t);
-          const double s = t * c;
-          sr = s * apq.x / mag;  // s * e^{i phi}
-          si = s * apq.y / mag;
-          rot = 1;
-        }
-        sRot[lane * 4 + 0] = c;
-        sRot[lane * 4 + 1] = sr;
-        sRot[lane * 4 + 2] = si;
-        sRot[lane * 4 + 3] = (double)rot;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // lane -> column `col` (l & 15) and rows (l>>4) + 4t.  partner/role from the pairing.
-      const int col = lane & 15;
-      int myp = 0, pp = 0, qq = 0;
-      for (int k = 0; k < TC / 2; ++k) {
-        int p, q;
-        pair_of(TC, step, k, p, q);
-        if (p == col || q == col) { myp = k; pp = p; qq = q; }
-      }
-      const double c = sRot[myp * 4 + 0], sr = sRot[myp * 4 + 1], si = sRot[myp * 4 + 2];
-      sweep_count += (lane < TC / 2) ? (int)sRot[lane * 4 + 3] : 0;
-      const bool is_p = (col == pp);
-      // ---- column phase on A and W:  y_p' = c y_p - conj(s) y_q ;  y_q' = s y_p + c y_q
-      cplx na[4], nw[4];
+__device__ inline double wave_sum(double v) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = (lane >> 4) + 4 * t;
-        const cplx ap = sA[r * TC + pp], aq = sA[r * TC + qq];
-        const cplx wp = sW[r * TC + pp], wq = sW[r * TC + qq];
-        if (is_p) {
-          na[t] = cplx{c * ap.x - (sr * aq.x + si * aq.y), c * ap.y - (sr * aq.y - si * aq.x)};
-          nw[t] = cplx{c * wp.x - (sr * wq.x + si * wq.y), c * wp.y - (sr * wq.y - si * wq.x)};
-        } else {
-          na[t] = cplx{(sr * ap.x - si * ap.y) + c * aq.x, (sr * ap.y + si * ap.x) + c * aq.y};
-          nw[t] = cplx{(sr * wp.x - si * wp.y) + c * wq.x, (sr * wp.y + si * wp.x) + c * wq.y};
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = (lane >> 4) + 4 * t;
-        sA[r * TC + col] = na[t];
-        sW[r * TC + col] = nw[t];
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // ---- row phase on A: row index `col` now plays the row role
-      //   a_p' = c a_p - s a_q ; a_q' = conj(s) a_p + c a_q      (rows of J^H A)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int cc = (lane >> 4) + 4 * t;
-        const cplx ap = sA[pp * TC + cc], aq = sA[qq * TC + cc];
-        if (is_p) na[t] = cplx{c * ap.x - (sr * aq.x - si * aq.y), c * ap.y - (sr * aq.y + si * aq.x)};
-        else      na[t] = cplx{(sr * ap.x + si * ap.y) + c * aq.x, (sr * ap.y - si * ap.x) + c * aq.y};
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int cc = (lane >> 4) + 4 * t;
-        cplx v = na[t];
-        if (sRot[myp * 4 + 3] != 0.0) {
-          if ((col == pp && cc == qq) || (col == qq && cc == pp)) v = cplx{0.0, 0.0};
-          if (cc == col) v.y = 0.0;
-        }
-        sA[col * TC + cc] = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-    // total rotations of this sweep (lanes 0..7 hold counts)
-    int tot = sweep_count;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-    if (sweep == 0) first_count = tot;
-    if (tot == 0) break;
-  }
-  return first_count;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
 }
 
-__global__ __launch_bounds__(256) void jacobi_round_kernel(JacobiArgs g) {
+// Decide and build the rotation for the column pair with norms (a, d) and inner product g.
+// Returns true when a rotation is applied; (c, sr + i si) as in
+//   y_p' = c y_p - conj(s) y_q ,  y_q' = s y_p + c y_q ,  a' = a - t|g| ,  d' = d + t|g|.
+__device__ inline bool make_rotation(double a, double d, double gx, double gy, double tol2, double nfloor, double& c, double& sr,
+                                     double& si, double& tg) {
+  const double mag2 = gx * gx + gy * gy;
+  const double big = fmax(a, d);
+  // rotate only if the pair is non-orthogonal at the tolerance level, the rotation angle is above 1e-15 and
+  // neither column sits at the rounding-noise floor of the matrix (sigma < 1e-13 ||X||_F: such columns are
+  // numerically null, carry no weight, and would otherwise be rotated against rounding noise for ever)
+  if (!(mag2 > tol2 * a * d && mag2 > 1e-30 * big * big && a > nfloor && d > nfloor && mag2 > 1e-300)) return false;
+  const double mag = sqrt(mag2);
+  const double tau = (d - a) / (2.0 * mag);
+  const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+  c = 1.0 / sqrt(1.0 + t * t);
+  const double s = t * c;
+  sr = s * gx / mag;
+  si = s * gy / mag;
+  tg = t * mag;
+  return true;
+}
+
+__device__ inline void rotate_pair(cplx& p, cplx& q, double c, double sr, double si) {
+  const cplx np{c * p.x - (sr * q.x + si * q.y), c * p.y - (sr * q.y - si * q.x)};
+  const cplx nq{(sr * p.x - si * p.y) + c * q.x, (sr * p.y + si * p.x) + c * q.y};
+  p = np;
+  q = nq;
+}
+
+// ---- cross pairs of one block pair -----------------------------------------------------------
+__global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
   extern __shared__ double smem[];
   int b = blockIdx.y;
   if (g.ids) b = g.ids[b];
   if (g.done[b]) return;
-  const int cs = g.cs;
-  double* sRe = smem;
-  double* sIm = sRe + TC * cs;
-  cplx* sA = reinterpret_cast<cplx*>(sIm + TC * cs);
-  cplx* sW = sA + TC * TC;
-  double* sRot = reinterpret_cast<double*>(sW + TC * TC);
-  int* sFlag = reinterpret_cast<int*>(sRot + 64);
+  const int rtot = g.rtot, rx = g.rx;
+  const int nrk = rtot >> 6;
+  cplx* slots = reinterpret_cast<cplx*>(smem);                  // [8][rtot]
+  double* sN = reinterpret_cast<double*>(slots + NB * rtot);    // [8]
+  int* sCnt = reinterpret_cast<int*>(sN + NB);                  // [8]
 
   int I, J;
   pair_of(g.nblk, g.round, blockIdx.x, I, J);
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rtot = g.rtot;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  cplx* colI = Yb + (long)(I * NB + w) * rtot;
+  cplx* colJ = Yb + (long)(J * NB + w) * rtot;
 
-  // ---- stage the 16 columns in LDS (planar re / im)
-  for (int c = 0; c < TC; ++c) {
-    const int gc = (c < NB) ? (I * NB + c) : (J * NB + (c - NB));
-    const cplx* colp = Yb + (long)gc * rtot;
-    for (int r = tid; r < rtot; r += 256) {
-      cplx v = colp[r];
-      sRe[c * cs + r] = v.x;
-      sIm[c * cs + r] = v.y;
+  cplx yI[MAXRK], yJ[MAXRK];
+#pragma unroll
+  for (int k = 0; k < MAXRK; ++k) {
+    if (k < nrk) {
+      yI[k] = colI[lane + 64 * k];
+      yJ[k] = colJ[lane + 64 * k];
+    } else {
+      yI[k] = cplx{0.0, 0.0};
+      yJ[k] = cplx{0.0, 0.0};
     }
   }
-  for (int t = tid; t < TC * TC; t += 256) sA[t] = cplx{0.0, 0.0};
-  __syncthreads();
-
-  // ---- Gram matrix of the X part with MFMA: G = X^H X (16 x 16)
-  {
-    d4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
-    const int c = lane & 15, rk = lane >> 4;
-    const int nsteps = g.rx / 4;
-    for (int s = wave; s < nsteps; s += 4) {
-      const double xr = sRe[c * cs + 4 * s + rk];
-      const double xi = sIm[c * cs + 4 * s + rk];
-      P = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xr, P, 0, 0, 0);
-      Q = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xi, Q, 0, 0, 0);
-      S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, xi, S1, 0, 0, 0);
-      S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, xr, S2, 0, 0, 0);
-    }
-    // deterministic reduction over the four waves
-    for (int w = 0; w < 4; ++w) {
-      if (wave == w) {
+  double nI = 0.0, nJ = 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = (lane >> 4) + 4 * r, j = lane & 15;
-          cplx v = sA[i * TC + j];
-          v.x += P[r] + Q[r];
-          v.y += S1[r] - S2[r];
-          sA[i * TC + j] = v;
-        }
+  for (int k = 0; k < MAXRK; ++k) {
+    if (k < nrk && lane + 64 * k < rx) {
+      nI = fma(yI[k].x, yI[k].x, fma(yI[k].y, yI[k].y, nI));
+      nJ = fma(yJ[k].x, yJ[k].x, fma(yJ[k].y, yJ[k].y, nJ));
+    }
+  }
+  nI = wave_sum(nI);
+  nJ = wave_sum(nJ);
+  const double floor2 = 1e-26 * g.fro2[b];
+  int cnt = 0;
+  for (int s = 0; s < NB; ++s) {
+    double gx = 0.0, gy = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXRK; ++k) {
+      if (k < nrk && lane + 64 * k < rx) {
+        gx = fma(yI[k].x, yJ[k].x, fma(yI[k].y, yJ[k].y, gx));   // conj(yI) * yJ
+        gy = fma(yI[k].x, yJ[k].y, fma(-yI[k].y, yJ[k].x, gy));
       }
+    }
+    gx = wave_sum(gx);
+    gy = wave_sum(gy);
+    double c, sr, si, tg;
+    if (make_rotation(nI, nJ, gx, gy, g.tol2, floor2, c, sr, si, tg)) {
+#pragma unroll
+      for (int k = 0; k < MAXRK; ++k)
+        if (k < nrk) rotate_pair(yI[k], yJ[k], c, sr, si);
+      nI -= tg;
+      nJ += tg;
+      ++cnt;
+    }
+    if (s + 1 < NB) {
+      // hand the J column to the previous wavefront: wave w next needs the column held by wave w+1
+#pragma unroll
+      for (int k = 0; k < MAXRK; ++k)
+        if (k < nrk) slots[w * rtot + lane + 64 * k] = yJ[k];
+      if (lane == 0) sN[w] = nJ;
+      __syncthreads();
+      const int src = (w + 1) & (NB - 1);
+#pragma unroll
+      for (int k = 0; k < MAXRK; ++k)
+        if (k < nrk) yJ[k] = slots[src * rtot + lane + 64 * k];
+      nJ = sN[src];
       __syncthreads();
     }
   }
-
-  // ---- diagonalise the Gram matrix (wave 0), count significant rotations
-  if (wave == 0) {
-    const int cnt = inner_jacobi(sA, sW, sRot, lane, g.max_inner, g.tol2, 1e-60 * g.fro2[b] * g.fro2[b]);
-    if (lane == 0) {
-      sFlag[0] = cnt;
-      if (cnt > 0) atomicAdd(&g.nrot[b], cnt);
-    }
-  }
+  if (lane == 0) sCnt[w] = cnt;
   __syncthreads();
-  if (sFlag[0] == 0) return;  // tile already orthogonal: nothing to update or store
-
-  // ---- apply the 16x16 unitary to every row of the tile:  Y' = Y * W
-  {
-    const int j = lane & 15, kq = lane >> 4;
-    double wr[4], wi[4];
+  int total = 0;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const cplx v = sW[(4 * kk + kq) * TC + j];
-      wr[kk] = v.x;
-      wi[kk] = v.y;
-    }
-    const int nchunks = rtot / 16;
-    for (int ch = wave; ch < nchunks; ch += 4) {
-      const int r0 = ch * 16;
-      double yr[4], yi[4];
+  for (int q = 0; q < NB; ++q) total += sCnt[q];
+  if (total == 0) return;  // nothing rotated: memory is already up to date
+  // after 7 hand-overs wave w holds J column (w + 7) mod 8
+  cplx* outJ = Yb + (long)(J * NB + ((w + NB - 1) & (NB - 1))) * rtot;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        yr[kk] = sRe[(4 * kk + kq) * cs + r0 + j];  // A operand: row = l & 15, old column = 4kk + (l >> 4)
-        yi[kk] = sIm[(4 * kk + kq) * cs + r0 + j];
-      }
-      d4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        P = __builtin_amdgcn_mfma_f64_16x16x4f64(yr[kk], wr[kk], P, 0, 0, 0);
-        Q = __builtin_amdgcn_mfma_f64_16x16x4f64(yi[kk], wi[kk], Q, 0, 0, 0);
-        S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(yr[kk], wi[kk], S1, 0, 0, 0);
-        S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(yi[kk], wr[kk], S2, 0, 0, 0);
-      }
-      // D layout: row = (l >> 4) + 4 r, new column = l & 15.  The chunk's rows belong to this wave only.
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = r0 + kq + 4 * r;
-        sRe[j * cs + row] = P[r] - Q[r];
-        sIm[j * cs + row] = S1[r] + S2[r];
-      }
+  for (int k = 0; k < MAXRK; ++k) {
+    if (k < nrk) {
+      colI[lane + 64 * k] = yI[k];
+      outJ[lane + 64 * k] = yJ[k];
     }
   }
-  __syncthreads();
-
-  // ---- write the tile back
-  for (int c = 0; c < TC; ++c) {
-    const int gc = (c < NB) ? (I * NB + c) : (J * NB + (c - NB));
-    cplx* colp = Yb + (long)gc * rtot;
-    for (int r = tid; r < rtot; r += 256) colp[r] = cplx{sRe[c * cs + r], sIm[c * cs + r]};
-  }
+  if (tid == 0) atomicAdd(&g.nrot[b], total);
 }
 
-// Y[c][r] from theta.  dist 0: X = theta^H (columns = theta rows), dist 1: X = theta.
-__global__ __launch_bounds__(256) void svd_load_kernel(const cplx* __restrict__ theta, long theta_b0, int ld, int m, int n, int dist,
-                                                      cplx* __restrict__ Y, long y_b0, int ncols_pad, int rx, int rtot,
-                                                      const int* ids) {
+// ---- pairs inside one block (LDS resident) -----------------------------------------------------
+__global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
+  extern __shared__ double smem[];
   int b = blockIdx.y;
-  if (ids) b = ids[b];
-  const cplx* th = theta + (long)b * theta_b0;
+  if (g.ids) b = g.ids[b];
+  if (g.done[b]) return;
+  const int rtot = g.rtot, rx = g.rx;
+  const int nrk = rtot >> 6;
+  cplx* tile = reinterpret_cast<cplx*>(smem);                  // [8][rtot]
+  double* sN = reinterpret_cast<double*>(tile + NB * rtot);    // [8]
+  int* sCnt = reinterpret_cast<int*>(sN + NB);                 // [4]
+  cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0 + (long)blockIdx.x * NB * rtot;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int c = w; c < NB; c += 4) {
+    double n = 0.0;
+    for (int k = 0; k < nrk; ++k) {
+      const cplx v = Yb[(long)c * rtot + lane + 64 * k];
+      tile[c * rtot + lane + 64 * k] = v;
+      if (lane + 64 * k < rx) n = fma(v.x, v.x, fma(v.y, v.y, n));
+    }
+    n = wave_sum(n);
+    if (lane == 0) sN[c] = n;
+  }
+  __syncthreads();
+  const double floor2 = 1e-26 * g.fro2[b];
+  int cnt = 0;
+  for (int s = 0; s < NB - 1; ++s) {
+    int p, q;
+    pair_of(NB, s, w, p, q);
+    cplx yp[MAXRK], yq[MAXRK];
+    double gx = 0.0, gy = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXRK; ++k) {
+      if (k < nrk) {
+        yp[k] = tile[p * rtot + lane + 64 * k];
+        yq[k] = tile[q * rtot + lane + 64 * k];
+        if (lane + 64 * k < rx) {
+          gx = fma(yp[k].x, yq[k].x, fma(yp[k].y, yq[k].y, gx));
+          gy = fma(yp[k].x, yq[k].y, fma(-yp[k].y, yq[k].x, gy));
+        }
+      }
+    }
+    gx = wave_sum(gx);
+    gy = wave_sum(gy);
+    double c, sr, si, tg;
+    const double a = sN[p], d = sN[q];
+    if (make_rotation(a, d, gx, gy, g.tol2, floor2, c, sr, si, tg)) {
+#pragma unroll
+      for (int k = 0; k < MAXRK; ++k) {
+        if (k < nrk) {
+          rotate_pair(yp[k], yq[k], c, sr, si);
+          tile[p * rtot + lane + 64 * k] = yp[k];
+          tile[q * rtot + lane + 64 * k] = yq[k];
+        }
+      }
+      if (lane == 0) { sN[p] = a - tg; sN[q] = d + tg; }
+      ++cnt;
+    }
+    __syncthreads();
+  }
+  if (lane == 0) sCnt[w] = cnt;
+  __syncthreads();
+  const int total = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
+  if (total == 0) return;
+  for (int c = w; c < NB; c += 4)
+    for (int k = 0; k < nrk; ++k) Yb[(long)c * rtot + lane + 64 * k] = tile[c * rtot + lane + 64 * k];
+  if (tid == 0) atomicAdd(&g.nrot[b], total);
+}
+
+// Y[c][r]:  rows [0, rx) = X (from the strided source, optionally conjugated), rows [rx, rx + ncols_pad) = identity
+__global__ __launch_bounds__(256) void jacobi_load_kernel(JacobiSource src, cplx* __restrict__ Y, long y_b0, int ncols_pad, int rx_top,
+                                                         int rtot) {
+  int b = blockIdx.y;
+  if (src.ids) b = src.ids[b];
+  const cplx* sp = src.src + (long)b * src.src_b0;
   cplx* Yb = Y + (long)b * y_b0;
   const long total = (long)ncols_pad * rtot;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int c = (int)(e / rtot), r = (int)(e % rtot);
     cplx v{0.0, 0.0};
-    if (r < rx) {
-      if (dist == 0) {
-        if (c < m && r < n) { v = th[(long)c * ld + r]; v.y = -v.y; }
-      } else {
-        if (r < m && c < n) v = th[(long)r * ld + c];
+    if (r < rx_top) {
+      if (r < src.rx && c < src.ncols) {
+        // two-level row / column indices let a (phys, bond) pair be flattened without a transpose
+        const int r1 = r / src.r_n0, r0 = r % src.r_n0;
+        const int c1 = c / src.c_n0, c0 = c % src.c_n0;
+        v = sp[(long)r1 * src.s_r1 + (long)r0 * src.s_r0 + (long)c1 * src.s_c1 + (long)c0 * src.s_c0];
+        if (src.conj) v.y = -v.y;
       }
-    } else if (r - rx == c) {
+    } else if (r - rx_top == c) {
       v.x = 1.0;
     }
     Yb[e] = v;
   }
+}
+
+// squared Frobenius norm of the source (noise floor of the rotations)
+__global__ __launch_bounds__(256) void jacobi_fro_kernel(const cplx* __restrict__ Y, long y_b0, int ncols_pad, int rx_top, int rtot,
+                                                        double* fro2, const int* ids) {
+  __shared__ double sh[4];
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  const cplx* Yb = Y + (long)b * y_b0;
+  double acc = 0.0;
+  const long total = (long)ncols_pad * rx_top;
+  for (long e = threadIdx.x; e < total; e += blockDim.x) {
+    const long c = e / rx_top, r = e % rx_top;
+    const cplx v = Yb[c * rtot + r];
+    acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) fro2[b] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
 __global__ void svd_sweep_check_kernel(int* nrot, int* done, int* n_active, int nb0, const int* ids) {
@@ -325,11 +323,11 @@ __global__ void svd_reset_kernel(int* nrot, int* done, int nb0, const int* ids) 
 }
 
 // Column norms of the X part, descending rank sort, truncation (svd_utils.py:22-104).
-__global__ __launch_bounds__(256) void svd_finish_kernel(SvdSplitDesc d, SvdWorkspace w, int ncols_pad, int rx, int rtot) {
+__global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspace w, int ncols_pad, int rx, int rtot, const int* ids) {
   __shared__ double sN[512];
   __shared__ int sPerm[512];
   int b = blockIdx.x;
-  if (d.ids) b = d.ids[b];
+  if (ids) b = ids[b];
   const cplx* Yb = w.Y + (long)b * w.y_b0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = wave; c < ncols_pad; c += 4) {
@@ -340,8 +338,7 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(SvdSplitDesc d, SvdWork
       acc = fma(v.x, v.x, acc);
       acc = fma(v.y, v.y, acc);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    acc = wave_sum(acc);
     if (lane == 0) sN[c] = acc;
   }
   __syncthreads();
@@ -363,8 +360,8 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(SvdSplitDesc d, SvdWork
   }
   __syncthreads();
   if (tid == 0) {
-    const int m_act = d.d * d.chiL[(long)b * d.chi_stride];
-    const int n_act = d.d * d.chiR[(long)b * d.chi_stride];
+    const int m_act = d.mulA * d.chiA[(long)b * d.chi_stride];
+    const int n_act = d.mulB * d.chiB[(long)b * d.chi_stride];
     int nsv = m_act < n_act ? m_act : n_act;
     if (nsv > ncols_pad) nsv = ncols_pad;
     int keep = 0;
@@ -407,131 +404,219 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(SvdSplitDesc d, SvdWork
       if (keep < d.min_keep) keep = d.min_keep;
       if (keep > nsv) keep = nsv;
     }
-    d.chiM[(long)b * d.chi_stride] = keep;
+    d.chiOut[(long)b * d.chi_stride] = keep;
   }
   if (d.spectrum) {
     for (int k = tid; k < d.spec_ld; k += 256) d.spectrum[(long)b * d.spec_ld + k] = (k < ncols_pad) ? sqrt(sN[sPerm[k]]) : 0.0;
   }
 }
 
-// left[b][s][a][k], right[b][t][k][c] from the rotated tile (zero beyond `keep`).
-__global__ __launch_bounds__(256) void svd_write_kernel(SvdSplitDesc d, SvdWorkspace w, int ncols_pad, int rx, int rtot) {
+// out[b][k*o_k + r1*o_r1 + r0*o_r0] = scale_k * op(Y[perm[k]][row_off + r1*n_r0 + r0])  for k < keep, else 0
+__global__ __launch_bounds__(256) void svd_extract_kernel(ExtractDesc x, SvdWorkspace w, int ncols_pad, int rtot, const int* chi_keep,
+                                                         int chi_stride, const int* ids) {
   int b = blockIdx.y;
-  if (d.ids) b = d.ids[b];
+  if (ids) b = ids[b];
   const cplx* Yb = w.Y + (long)b * w.y_b0;
   const int* perm = w.perm + (long)b * ncols_pad;
-  const int keep = d.chiM[(long)b * d.chi_stride];
-  const long nl = (long)d.d * d.capL * d.capM, nr = (long)d.d * d.capM * d.capR;
-  cplx* L = d.left + (long)b * d.left_b0;
-  cplx* R = d.right + (long)b * d.right_b0;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nl + nr; e += (long)gridDim.x * blockDim.x) {
-    if (e < nl) {
-      const int k = (int)(e % d.capM);
-      const int row = (int)(e / d.capM);  // (s, a) -> s * capL + a
-      cplx v{0.0, 0.0};
-      if (k < keep) {
-        const long col = perm[k];
-        v = (d.distribution == 0) ? Yb[col * rtot + rx + row] : Yb[col * rtot + row];
-      }
-      L[e] = v;
-    } else {
-      const long f = e - nl;
-      const int c = (int)(f % d.capR);
-      const int k = (int)((f / d.capR) % d.capM);
-      const int t = (int)(f / ((long)d.capR * d.capM));
-      cplx v{0.0, 0.0};
-      if (k < keep) {
-        const long col = perm[k];
-        const int row = t * d.capR + c;
-        v = (d.distribution == 0) ? Yb[col * rtot + row] : Yb[col * rtot + rx + row];
-        v.y = -v.y;
-      }
-      R[f] = v;
+  const double* sig = w.norms + (long)b * ncols_pad;
+  const int keep = chi_keep[(long)b * chi_stride];
+  cplx* out = x.out + (long)b * x.out_b0;
+  const long nrows = (long)x.n_r1 * x.n_r0;
+  const long total = nrows * x.n_k;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    // iterate with the row index fastest: contiguous reads of a Y column
+    const int k = (int)(e / nrows);
+    const long r = e % nrows;
+    const int r1 = (int)(r / x.n_r0), r0 = (int)(r % x.n_r0);
+    cplx v{0.0, 0.0};
+    if (k < keep) {
+      v = Yb[(long)perm[k] * rtot + x.row_off + r];
+      if (x.conj) v.y = -v.y;
+      if (x.scale_mode == 1) { v.x *= sig[k]; v.y *= sig[k]; }
+      else if (x.scale_mode == 2) { const double inv = (sig[k] > 0.0) ? 1.0 / sig[k] : 0.0; v.x *= inv; v.y *= inv; }
     }
+    out[(long)k * x.o_k + (long)r1 * x.o_r1 + (long)r0 * x.o_r0] = v;
   }
 }
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Optional live timing of the dominant kernel (jacobi_cross_kernel) with HIP events on the launch stream.
+struct CrossProfile {
+  int every = 0;  // 0 = off, otherwise every N-th launch is bracketed by events
+  long counter = 0;
+  std::vector<hipEvent_t> pool;
+  std::vector<std::pair<int, double>> pending;  // (event pair index, bytes)
+  size_t used = 0;
+  double total_ms = 0.0, total_bytes = 0.0;
+  long samples = 0;
+};
+CrossProfile g_prof;
+
+void prof_collect() {
+  for (auto& p : g_prof.pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof.pool[2 * p.first], g_prof.pool[2 * p.first + 1]) == hipSuccess) {
+      g_prof.total_ms += ms;
+      g_prof.total_bytes += p.second;
+      ++g_prof.samples;
+    }
+  }
+  g_prof.pending.clear();
+  g_prof.used = 0;
+}
+
 }  // namespace
+
+void profile_enable(int every) {
+  g_prof.every = every;
+  g_prof.counter = 0;
+  g_prof.total_ms = 0.0;
+  g_prof.total_bytes = 0.0;
+  g_prof.samples = 0;
+}
+
+void profile_get(double* total_ms, double* total_bytes, long* samples) {
+  *total_ms = g_prof.total_ms;
+  *total_bytes = g_prof.total_bytes;
+  *samples = g_prof.samples;
+}
 
 size_t svd_workspace_bytes(int max_dim, int B) {
   const int p = round_up(max_dim, 16);
-  size_t y = (size_t)B * p * (2 * p) * sizeof(cplx);
-  size_t small = (size_t)B * p * (sizeof(double) + sizeof(int)) + (size_t)B * 2 * sizeof(int) + 64;
-  return y + small + 1024;
+  size_t y = (size_t)B * p * round_up(2 * p, 64) * sizeof(cplx);
+  size_t small = (size_t)B * p * (sizeof(double) + sizeof(int)) + (size_t)B * 4 * sizeof(int) + 64;
+  return y + small + 4096;
 }
 
-int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* sweeps_out) {
-  if (d.nb0 <= 0) return TJM_OK;
-  const int ncols = d.distribution == 0 ? d.m : d.n;
-  const int rxr = d.distribution == 0 ? d.n : d.m;
-  const int ncols_pad = round_up(ncols, 16);
-  const int rx = round_up(rxr, 16);
-  const int rtot = rx + ncols_pad;
-  if (rtot > 512 || ncols_pad > 512) return TJM_ERR_NOT_IMPLEMENTED;  // LDS-resident tile: d*chi <= 256
+int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspace& w, hipStream_t s, JacobiShape* shape_out,
+                 int* sweeps_out) {
+  if (src.nb0 <= 0) return TJM_OK;
+  const int ncols_pad = round_up(src.ncols, 16);
+  const int rx_top = round_up(src.rx, 16);
+  const int rtot = round_up(rx_top + ncols_pad, 64);
+  if (rtot > 64 * MAXRK) return TJM_ERR_NOT_IMPLEMENTED;  // register-resident columns: rx + ncols <= 512
   if ((long)ncols_pad * rtot > w.y_b0) return TJM_ERR_WORKSPACE;
-  const int cs = rtot + 2;
-  const size_t lds = (size_t)2 * TC * cs * sizeof(double) + 2 * TC * TC * sizeof(cplx) + 64 * sizeof(double) + 16;
   static bool attr_set = false;
   if (!attr_set) {
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_round_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
-  const int tb = (d.nb0 + 255) / 256;
-  hipLaunchKernelGGL(svd_reset_kernel, dim3(tb), dim3(256), 0, s, w.nrot, w.done, d.nb0, d.ids);
-  if (d.ld_theta != d.n) return TJM_ERR_ARG;
-  {
-    int rc = launch_normsq(d.theta, d.theta_b0, (long)d.m * d.n, w.fro2, d.nb0, d.ids, s);
-    if (rc != TJM_OK) return rc;
-  }
+  const size_t lds = (size_t)NB * rtot * sizeof(cplx) + NB * sizeof(double) + 16 * sizeof(int);
+  const int tb = (src.nb0 + 255) / 256;
+  hipLaunchKernelGGL(svd_reset_kernel, dim3(tb), dim3(256), 0, s, w.nrot, w.done, src.nb0, src.ids);
   {
     const long total = (long)ncols_pad * rtot;
     int gx = (int)((total + 1023) / 1024);
     if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(svd_load_kernel, dim3(gx, d.nb0), dim3(256), 0, s, d.theta, d.theta_b0, d.ld_theta, d.m, d.n,
-                       d.distribution, w.Y, w.y_b0, ncols_pad, rx, rtot, d.ids);
+    hipLaunchKernelGGL(jacobi_load_kernel, dim3(gx, src.nb0), dim3(256), 0, s, src, w.Y, w.y_b0, ncols_pad, rx_top, rtot);
+    hipLaunchKernelGGL(jacobi_fro_kernel, dim3(src.nb0), dim3(256), 0, s, w.Y, w.y_b0, ncols_pad, rx_top, rtot, w.fro2, src.ids);
   }
   JacobiArgs g;
   g.Y = w.Y;
   g.y_b0 = w.y_b0;
   g.rtot = rtot;
-  g.rx = rx;
+  g.rx = rx_top;
   g.nblk = ncols_pad / NB;
-  g.cs = cs;
-  g.max_inner = 3;
-  g.tol2 = 1e-28;  // relative off-diagonal tolerance 1e-14
-  g.nrot = w.nrot;
+  g.tol2 = 1e-26;  // relative off-diagonal tolerance 1e-13
   g.fro2 = w.fro2;
+  g.nrot = w.nrot;
   g.done = w.done;
-  g.ids = d.ids;
+  g.ids = src.ids;
+  g.round = 0;
   const int nrounds = g.nblk - 1;
   const int npairs = g.nblk / 2;
-  const int max_sweeps = 30;
+  const int max_sweeps = 40;
   int sweep = 0;
-  for (; sweep < max_sweeps; ++sweep) {
+  int n_live = src.nb0;
+  bool converged = false;
+  for (; sweep < max_sweeps && !converged; ++sweep) {
+    hipLaunchKernelGGL(jacobi_diag_kernel, dim3(g.nblk, src.nb0), dim3(256), lds, s, g);
     for (int r = 0; r < nrounds; ++r) {
       g.round = r;
-      hipLaunchKernelGGL(jacobi_round_kernel, dim3(npairs, d.nb0), dim3(256), lds, s, g);
+      const bool timed = g_prof.every > 0 && (g_prof.counter++ % g_prof.every == 0);
+      int slot = -1;
+      if (timed) {
+        slot = (int)g_prof.used++;
+        while (g_prof.pool.size() < 2 * g_prof.used) {
+          hipEvent_t ev;
+          TJM_HIP_CHECK(hipEventCreate(&ev));
+          g_prof.pool.push_back(ev);
+        }
+        TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot], s));
+      }
+      hipLaunchKernelGGL(jacobi_cross_kernel, dim3(npairs, src.nb0), dim3(512), lds, s, g);
+      if (timed) {
+        TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot + 1], s));
+        // algorithmic bytes: every column of the stacked [X; W] tile of a still-iterating trajectory is read once and written once
+        g_prof.pending.emplace_back(slot, (double)npairs * n_live * 2.0 * (2 * NB) * rtot * sizeof(cplx));
+      }
     }
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, sizeof(int), s));
-    hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tb), dim3(256), 0, s, w.nrot, w.done, w.n_active, d.nb0, d.ids);
+    hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tb), dim3(256), 0, s, w.nrot, w.done, w.n_active, src.nb0, src.ids);
     TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
     TJM_HIP_CHECK(hipStreamSynchronize(s));
-    if (*w.h_pinned == 0) { ++sweep; break; }
+    converged = (*w.h_pinned == 0);
+    n_live = *w.h_pinned;
+    if (g_prof.every > 0) prof_collect();
   }
   if (sweeps_out) *sweeps_out = sweep;
-  hipLaunchKernelGGL(svd_finish_kernel, dim3(d.nb0), dim3(256), 0, s, d, w, ncols_pad, rx, rtot);
-  {
-    const long total = (long)d.d * d.capL * d.capM + (long)d.d * d.capM * d.capR;
-    int gx = (int)((total + 1023) / 1024);
-    if (gx > 256) gx = 256;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(svd_write_kernel, dim3(gx, d.nb0), dim3(256), 0, s, d, w, ncols_pad, rx, rtot);
-  }
+  hipLaunchKernelGGL(svd_finish_kernel, dim3(src.nb0), dim3(256), 0, s, tr, w, ncols_pad, rx_top, rtot, src.ids);
   TJM_HIP_CHECK(hipGetLastError());
-  return (sweep >= max_sweeps && *w.h_pinned != 0) ? TJM_ERR_NUMERIC : TJM_OK;
+  if (shape_out) {
+    shape_out->ncols_pad = ncols_pad;
+    shape_out->rx_top = rx_top;
+    shape_out->rtot = rtot;
+  }
+  return converged ? TJM_OK : TJM_ERR_NUMERIC;
+}
+
+int svd_extract(const ExtractDesc& x, const SvdWorkspace& w, const JacobiShape& sh, const int* chi_keep, int chi_stride, int nb0,
+                const int* ids, hipStream_t s) {
+  const long total = (long)x.n_r1 * x.n_r0 * x.n_k;
+  if (total <= 0 || nb0 <= 0) return TJM_OK;
+  int gx = (int)((total + 1023) / 1024);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(svd_extract_kernel, dim3(gx, nb0), dim3(256), 0, s, x, w, sh.ncols_pad, sh.rtot, chi_keep, chi_stride, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// Two-site split: theta (m x n, rows (s,a), cols (t,c)) -> left[d][capL][capM], right[d][capM][capR].
+int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* sweeps_out) {
+  if (d.nb0 <= 0) return TJM_OK;
+  JacobiSource src;
+  src.src = d.theta; src.src_b0 = d.theta_b0; src.conj = (d.distribution == 0);
+  if (d.distribution == 0) {  // X = theta^H : rows = theta columns, columns = theta rows
+    src.rx = d.n; src.ncols = d.m;
+    src.r_n0 = d.n; src.s_r1 = 0; src.s_r0 = 1;
+    src.c_n0 = d.m; src.s_c1 = 0; src.s_c0 = d.ld_theta;
+  } else {                    // X = theta
+    src.rx = d.m; src.ncols = d.n;
+    src.r_n0 = d.m; src.s_r1 = 0; src.s_r0 = d.ld_theta;
+    src.c_n0 = d.n; src.s_c1 = 0; src.s_c0 = 1;
+  }
+  src.nb0 = d.nb0; src.ids = d.ids;
+  TruncSpec tr;
+  tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
+  tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
+  tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
+  JacobiShape sh;
+  int rc = jacobi_solve(src, tr, w, s, &sh, sweeps_out);
+  if (rc != TJM_OK) return rc;
+  // left[(s,a)][k]: rows (s,a) of the isometric factor U (dist 0: W part) or of U S (dist 1: X part)
+  ExtractDesc xl;
+  xl.out = d.left; xl.out_b0 = d.left_b0; xl.n_k = d.capM; xl.o_k = 1;
+  xl.n_r1 = 1; xl.n_r0 = d.d * d.capL; xl.o_r1 = 0; xl.o_r0 = d.capM;
+  xl.row_off = (d.distribution == 0) ? sh.rx_top : 0; xl.conj = 0; xl.scale_mode = 0;
+  if ((rc = svd_extract(xl, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  // right[t][k][c] = conj of rows (t,c): S V^H (dist 0: X part) or V^H (dist 1: W part)
+  ExtractDesc xr;
+  xr.out = d.right; xr.out_b0 = d.right_b0; xr.n_k = d.capM; xr.o_k = d.capR;
+  xr.n_r1 = d.d; xr.n_r0 = d.capR; xr.o_r1 = (long)d.capM * d.capR; xr.o_r0 = 1;
+  xr.row_off = (d.distribution == 0) ? 0 : sh.rx_top; xr.conj = 1; xr.scale_mode = 0;
+  return svd_extract(xr, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s);
 }
 
 }  // namespace tjm
