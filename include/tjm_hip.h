@@ -104,6 +104,13 @@ int tjm_svd_split(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t
                   int32_t distribution, int32_t trunc_mode, double threshold, int32_t max_bond, int32_t min_keep,
                   int32_t* chi_lrm, double* spectrum, int32_t spec_ld, void* work, size_t work_bytes, int32_t* sweeps_out,
                   void* hip_stream);
+/* Same split with the Householder-QR preconditioner the engine uses for d*cap >= 64 (theta = Q R, Jacobi on R^H,
+ * isometric factor Q W); work must hold tjm_svd_qr_workspace_bytes. */
+size_t tjm_svd_qr_workspace_bytes(int32_t max_dim, int32_t B);
+int tjm_svd_split_qr(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t capR, int32_t capM, void* left, void* right,
+                     int32_t distribution, int32_t trunc_mode, double threshold, int32_t max_bond, int32_t min_keep,
+                     int32_t* chi_lrm, double* spectrum, int32_t spec_ld, void* work, size_t work_bytes, int32_t* sweeps_out,
+                     void* hip_stream);
 /* exp(-i dt T_k) e_1 of the Lanczos tridiagonal (matrix_exponential.py:147-163); device pointers. */
 int tjm_tridiag_expm(const double* alpha, const double* beta, int32_t k, double dt, double* out_k_complex, void* hip_stream);
 

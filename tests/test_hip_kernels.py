@@ -104,7 +104,7 @@ def test_tridiag_expm_matches_dense(lib, k, dt, scale):
     assert np.allclose(got, ref, atol=5e-13)
 
 
-def svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, min_keep, chiL, chiR):
+def svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, min_keep, chiL, chiR, qr=False):
     from yaqs_amd._lib import check
 
     B = theta.shape[0]
@@ -114,17 +114,19 @@ def svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, mi
     chi = dev(np.stack([chiL, chiR, np.zeros(B, dtype=np.int32)], axis=1).astype(np.int32))
     spec_ld = d * max(capL, capR)
     spec = torch.zeros((B, spec_ld), dtype=torch.float64, device="cuda:0")
-    nbytes = lib.tjm_svd_workspace_bytes(d * max(capL, capR), B)
+    nbytes = (lib.tjm_svd_qr_workspace_bytes if qr else lib.tjm_svd_workspace_bytes)(d * max(capL, capR), B)
+    fn = lib.tjm_svd_split_qr if qr else lib.tjm_svd_split
     work = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
     sweeps = C.c_int32(0)
-    check(lib.tjm_svd_split(th.data_ptr(), B, d, capL, capR, capM, left.data_ptr(), right.data_ptr(), dist, mode, thr, max_bond, min_keep,
+    check(fn(th.data_ptr(), B, d, capL, capR, capM, left.data_ptr(), right.data_ptr(), dist, mode, thr, max_bond, min_keep,
                             chi.data_ptr(), spec.data_ptr(), spec_ld, work.data_ptr(), nbytes, C.byref(sweeps), None), "svd_split")
     torch.cuda.synchronize()
     return left.cpu().numpy(), right.cpu().numpy(), chi.cpu().numpy()[:, 2], spec.cpu().numpy(), sweeps.value
 
 
-@pytest.mark.parametrize("capL,capR,dist", [(4, 4, 0), (4, 4, 1), (8, 3, 0), (3, 8, 1), (16, 16, 0), (32, 32, 1), (1, 2, 0), (2, 1, 1)])
-def test_svd_split_matches_oracle(lib, capL, capR, dist):
+@pytest.mark.parametrize("qr", [False, True])
+@pytest.mark.parametrize("capL,capR,dist", [(4, 4, 0), (4, 4, 1), (8, 3, 0), (3, 8, 1), (16, 16, 0), (32, 32, 1), (1, 2, 0), (2, 1, 1), (32, 48, 0), (40, 32, 1)])
+def test_svd_split_matches_oracle(lib, capL, capR, dist, qr):
     from oracle import tjm_oracle as o
 
     rng = np.random.default_rng(capL * 10 + capR + dist)
@@ -138,7 +140,7 @@ def test_svd_split_matches_oracle(lib, capL, capR, dist):
     chiR = np.full(B, capR, dtype=np.int32)
     thr, maxb = 1e-6, max(1, capM - 1)
     mk = min(2, maxb)
-    left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, capL, capR, capM, dist, 0, thr, maxb, mk, chiL, chiR)
+    left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, capL, capR, capM, dist, 0, thr, maxb, mk, chiL, chiR, qr=qr)
     for b in range(B):
         merged = theta[b].reshape(d, capL, d, capR).transpose(0, 2, 1, 3).reshape(d * d, capL, capR)
         l_ref, r_ref, s_ref = o.split_two_site(merged, [d, d], svd_distribution="right" if dist == 0 else "left", trunc_mode="discarded_weight",
@@ -184,7 +186,8 @@ def test_svd_split_ragged_bonds_and_modes(lib):
             assert np.allclose(got, o.merge_two_site(l_ref, r_ref), atol=1e-11), (name, b)
 
 
-def test_svd_split_chi128_rank_deficient(lib):
+@pytest.mark.parametrize("qr", [False, True])
+def test_svd_split_chi128_rank_deficient(lib, qr):
     """Full-size case of the headline config: 256 x 256 theta of rank 128 (a centre-shift merge)."""
     rng = np.random.default_rng(11)
     d, cap, B = 2, 128, 2
@@ -192,7 +195,8 @@ def test_svd_split_chi128_rank_deficient(lib):
     q = np.linalg.qr(crand(rng, B, d * cap, cap))[0].conj().transpose(0, 2, 1)  # right-isometric (cap x d*cap)
     theta = a @ q
     chi = np.full(B, cap, dtype=np.int32)
-    left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, cap, cap, cap, 0, 0, 1e-12, 0, 1, chi, chi)
+    left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, cap, cap, cap, 0, 0, 1e-12, 0, 1, chi, chi, qr=qr)
+    print('sweeps', sweeps, 'qr', qr)
     for b in range(B):
         s_ref = np.linalg.svd(theta[b], compute_uv=False)
         assert keep[b] == cap
@@ -200,3 +204,38 @@ def test_svd_split_chi128_rank_deficient(lib):
         rec = left[b].reshape(d * cap, cap) @ right[b].transpose(1, 0, 2).reshape(cap, d * cap)
         assert np.allclose(rec, theta[b], atol=1e-12)
     assert sweeps < 40
+
+
+@pytest.mark.parametrize("dist", [0, 1])
+def test_svd_split_qr_graded_full_size(lib, dist):
+    """256 x 256 theta with a spectrum graded over 8 decades (the time-evolved two-site tensor regime)."""
+    rng = np.random.default_rng(21 + dist)
+    d, cap, B = 2, 128, 2
+    n = d * cap
+    theta = np.zeros((B, n, n), dtype=np.complex128)
+    svs = []
+    for b in range(B):
+        u = np.linalg.qr(crand(rng, n, n))[0]
+        v = np.linalg.qr(crand(rng, n, n))[0]
+        s = np.concatenate([np.linspace(1.0, 0.05, cap), 10.0 ** rng.uniform(-8, -2, cap)])
+        s = np.sort(s)[::-1]
+        svs.append(s)
+        theta[b] = (u * s) @ v.conj().T
+    chi = np.full(B, cap, dtype=np.int32)
+    out = {}
+    for qr in (False, True):
+        left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, cap, cap, cap, dist, 0, 1e-12, cap, 2, chi, chi, qr=qr)
+        out[qr] = sweeps
+        for b in range(B):
+            assert keep[b] == cap
+            assert np.allclose(spec[b, :n], svs[b], atol=1e-12)
+            L_ = left[b].reshape(n, cap)
+            R_ = right[b].transpose(1, 0, 2).reshape(cap, n)
+            best = (u_ := None)
+            ref_u, ref_s, ref_vh = np.linalg.svd(theta[b])
+            trunc = (ref_u[:, :cap] * ref_s[:cap]) @ ref_vh[:cap]
+            assert np.allclose(L_ @ R_, trunc, atol=1e-10)
+            iso = L_ if dist == 0 else R_.conj().T
+            assert np.allclose(iso.conj().T @ iso, np.eye(cap), atol=1e-12)
+    print("sweeps plain", out[False], "qr", out[True])
+    assert out[True] < out[False]

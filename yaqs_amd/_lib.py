@@ -69,6 +69,8 @@ EXPORTS = {
     "tjm_zgemm_batched": (C.c_int, [C.POINTER(GemmDesc), V]),
     "tjm_svd_workspace_bytes": (C.c_size_t, [I, I]),
     "tjm_svd_split": (C.c_int, [V, I, I, I, I, I, V, V, I, I, D, I, I, V, V, I, V, C.c_size_t, V, V]),
+    "tjm_svd_qr_workspace_bytes": (C.c_size_t, [I, I]),
+    "tjm_svd_split_qr": (C.c_int, [V, I, I, I, I, I, V, V, I, I, D, I, I, V, V, I, V, C.c_size_t, V, V]),
     "tjm_tridiag_expm": (C.c_int, [V, V, I, D, V, V]),
     "tjm_profile_cross_kernel": (C.c_int, [I]),
     "tjm_profile_cross_kernel_read": (C.c_int, [V, V, V]),

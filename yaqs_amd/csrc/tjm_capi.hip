@@ -126,16 +126,17 @@ int tjm_zgemm_batched(const tjm_gemm_desc* t, void* stream) {
   return launch_gemm(g, static_cast<hipStream_t>(stream));
 }
 
-size_t tjm_svd_workspace_bytes(int32_t max_dim, int32_t B) { return svd_workspace_bytes(max_dim, B) + (size_t)B * 64; }
+size_t tjm_svd_workspace_bytes(int32_t max_dim, int32_t B) { return svd_workspace_bytes(max_dim, B) + (size_t)B * 64 + 4096; }
 
-int tjm_svd_split(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t capR, int32_t capM, void* left, void* right,
-                  int32_t distribution, int32_t trunc_mode, double threshold, int32_t max_bond, int32_t min_keep, int32_t* chi_lrm,
-                  double* spectrum, int32_t spec_ld, void* work, size_t work_bytes, int32_t* sweeps_out, void* stream_) {
+static int svd_split_impl(bool use_qr, const void* theta, int32_t B, int32_t d, int32_t capL, int32_t capR, int32_t capM, void* left, void* right,
+                          int32_t distribution, int32_t trunc_mode, double threshold, int32_t max_bond, int32_t min_keep, int32_t* chi_lrm,
+                          double* spectrum, int32_t spec_ld, void* work, size_t work_bytes, int32_t* sweeps_out, void* stream_) {
   if (!theta || !left || !right || !chi_lrm || !work) return TJM_ERR_ARG;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int m = d * capL, n = d * capR;
   const int mx = m > n ? m : n;
-  if (work_bytes < tjm_svd_workspace_bytes(mx, B)) return TJM_ERR_WORKSPACE;
+  const size_t need = use_qr ? tjm_svd_qr_workspace_bytes(mx, B) : tjm_svd_workspace_bytes(mx, B);
+  if (work_bytes < need) return TJM_ERR_WORKSPACE;
   const int p = (mx + 15) / 16 * 16;
   char* w = static_cast<char*>(work);
   auto take = [&](size_t nbytes) { char* q = w; w += (nbytes + 255) / 256 * 256; return q; };
@@ -145,12 +146,27 @@ int tjm_svd_split(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t
   sw.norms = reinterpret_cast<double*>(take((size_t)B * p * sizeof(double)));
   sw.perm = reinterpret_cast<int*>(take((size_t)B * p * sizeof(int)));
   sw.fro2 = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
+  sw.stamps = reinterpret_cast<int*>(take((size_t)B * 1152 * sizeof(int)));
   sw.nrot = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   sw.done = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   sw.n_active = reinterpret_cast<int*>(take(256));
   static int* pinned = nullptr;
   if (!pinned) TJM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pinned), 256, hipHostMallocDefault));
   sw.h_pinned = pinned;
+  QrWorkspace qw;
+  std::memset(&qw, 0, sizeof(qw));
+  if (use_qr) {
+    const int npan = mx / 16 + 1;
+    qw.z_b0 = (long)mx * mx;
+    qw.Z = reinterpret_cast<cplx*>(take((size_t)B * qw.z_b0 * sizeof(cplx)));
+    qw.v_b0 = (long)npan * 16 * mx;
+    qw.V = reinterpret_cast<cplx*>(take((size_t)B * qw.v_b0 * sizeof(cplx)));
+    qw.t_b0 = (long)npan * 256;
+    qw.T = reinterpret_cast<cplx*>(take((size_t)B * qw.t_b0 * sizeof(cplx)));
+    qw.w_ld = mx;
+    qw.W1 = reinterpret_cast<cplx*>(take((size_t)B * 16 * mx * sizeof(cplx)));
+    qw.W2 = reinterpret_cast<cplx*>(take((size_t)B * 16 * mx * sizeof(cplx)));
+  }
   SvdSplitDesc s;
   s.theta = static_cast<const cplx*>(theta); s.theta_b0 = (long)m * n; s.ld_theta = n; s.m = m; s.n = n; s.d = d;
   s.capL = capL; s.capR = capR; s.capM = capM;
@@ -160,9 +176,27 @@ int tjm_svd_split(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t
   s.chiL = chi_lrm; s.chiR = chi_lrm + 1; s.chiM = chi_lrm + 2; s.chi_stride = 3;
   s.spectrum = spectrum; s.spec_ld = spec_ld; s.nb0 = B; s.ids = nullptr;
   int sweeps = 0;
-  const int rc = svd_split(s, sw, stream, &sweeps);
+  const int rc = use_qr ? svd_split_qr(s, sw, qw, stream, &sweeps) : svd_split(s, sw, stream, &sweeps);
   if (sweeps_out) *sweeps_out = sweeps;
   return rc;
+}
+
+size_t tjm_svd_qr_workspace_bytes(int32_t max_dim, int32_t B) {
+  return tjm_svd_workspace_bytes(max_dim, B) + qr_workspace_bytes(max_dim, B) + 16384;
+}
+
+int tjm_svd_split(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t capR, int32_t capM, void* left, void* right,
+                  int32_t distribution, int32_t trunc_mode, double threshold, int32_t max_bond, int32_t min_keep, int32_t* chi_lrm,
+                  double* spectrum, int32_t spec_ld, void* work, size_t work_bytes, int32_t* sweeps_out, void* stream_) {
+  return svd_split_impl(false, theta, B, d, capL, capR, capM, left, right, distribution, trunc_mode, threshold, max_bond, min_keep, chi_lrm,
+                        spectrum, spec_ld, work, work_bytes, sweeps_out, stream_);
+}
+
+int tjm_svd_split_qr(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t capR, int32_t capM, void* left, void* right,
+                     int32_t distribution, int32_t trunc_mode, double threshold, int32_t max_bond, int32_t min_keep, int32_t* chi_lrm,
+                     double* spectrum, int32_t spec_ld, void* work, size_t work_bytes, int32_t* sweeps_out, void* stream_) {
+  return svd_split_impl(true, theta, B, d, capL, capR, capM, left, right, distribution, trunc_mode, threshold, max_bond, min_keep, chi_lrm,
+                        spectrum, spec_ld, work, work_bytes, sweeps_out, stream_);
 }
 
 int tjm_profile_cross_kernel(int32_t every) {

@@ -59,6 +59,7 @@ struct GemmDesc {
   int nb0, nb1, nb2;
   long a_b0, a_b1, a_b2, b_b0, b_b1, b_b2, c_b0, c_b1, c_b2;
   int conjA, conjB;
+  int accumulate;     // 0: C = A*B ; +1: C += A*B ; -1: C -= A*B
   const int* ids;     // optional trajectory remap for b0 (device pointer) or nullptr
   const int* active;  // optional per-trajectory mask (device, indexed by remapped id); 0 => skip
 };

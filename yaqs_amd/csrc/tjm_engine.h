@@ -66,6 +66,7 @@ class Engine {
   cplx *T1 = nullptr, *T2 = nullptr, *V = nullptr, *theta = nullptr;
   long v_b0 = 0, v_ld = 0, t_b0 = 0, theta_b0 = 0;
   SvdWorkspace svdw{};
+  QrWorkspace qrw{};
   KrylovState ks{};
 
  private:

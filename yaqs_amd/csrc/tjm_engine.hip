@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace tjm {
@@ -90,6 +91,8 @@ size_t Engine::workspace_bytes() const {
   tot += align_up((size_t)B * p * ((2 * p + 63) / 64 * 64) * sizeof(cplx));  // Y
   tot += align_up((size_t)B * p * sizeof(double)) + align_up((size_t)B * p * sizeof(int));
   tot += 8 * align_up((size_t)B * sizeof(double) * 4);
+  tot += align_up((size_t)B * 1152 * sizeof(int));
+  tot += align_up(qr_workspace_bytes(d * cm, B)) + 4096;
   tot += 2 * align_up((size_t)B * TJM_MAX_PART * sizeof(double));
   tot += 3 * align_up((size_t)B * mmax * sizeof(cplx));
   tot += 2 * align_up((size_t)B * cm * cm * sizeof(cplx));              // E ping-pong
@@ -131,9 +134,23 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   svdw.norms = reinterpret_cast<double*>(take((size_t)B * pp * sizeof(double)));
   svdw.perm = reinterpret_cast<int*>(take((size_t)B * pp * sizeof(int)));
   svdw.fro2 = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
+  svdw.stamps = reinterpret_cast<int*>(take((size_t)B * 1152 * sizeof(int)));
   svdw.nrot = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   svdw.done = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   svdw.n_active = reinterpret_cast<int*>(take(256));
+  {
+    const int md = d * cm;
+    const int npan = md / 16 + 1;
+    qrw.z_b0 = (long)md * md;
+    qrw.Z = reinterpret_cast<cplx*>(take((size_t)B * qrw.z_b0 * sizeof(cplx)));
+    qrw.v_b0 = (long)npan * 16 * md;
+    qrw.V = reinterpret_cast<cplx*>(take((size_t)B * qrw.v_b0 * sizeof(cplx)));
+    qrw.t_b0 = (long)npan * 256;
+    qrw.T = reinterpret_cast<cplx*>(take((size_t)B * qrw.t_b0 * sizeof(cplx)));
+    qrw.w_ld = md;
+    qrw.W1 = reinterpret_cast<cplx*>(take((size_t)B * 16 * md * sizeof(cplx)));
+    qrw.W2 = reinterpret_cast<cplx*>(take((size_t)B * 16 * md * sizeof(cplx)));
+  }
   part1_ = reinterpret_cast<double*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));
   part2_ = reinterpret_cast<double*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));
   ks.mmax = mmax;
@@ -479,7 +496,9 @@ int Engine::split(StateSet& S, int i, int dist, int mode, double thr, int maxb, 
   s.chiL = S.chi + i; s.chiR = S.chi + i + 2; s.chiM = S.chi + i + 1; s.chi_stride = L + 1;
   s.spectrum = nullptr; s.spec_ld = 0; s.nb0 = nb0; s.ids = ids;
   int sweeps = 0;
-  const int rc = svd_split(s, svdw, stream, &sweeps);
+  static const bool no_qr = getenv("TJM_NO_QR") != nullptr;
+  const bool use_qr = !no_qr && ids == nullptr && std::min(s.m, s.n) >= 64 && s.m % 16 == 0 && s.n % 16 == 0;
+  const int rc = use_qr ? svd_split_qr(s, svdw, qrw, stream, &sweeps) : svd_split(s, svdw, stream, &sweeps);
   ++stat_svds;
   stat_svd_sweeps += sweeps;
   return rc;
@@ -555,7 +574,7 @@ int Engine::svd_shift_right(StateSet& S, int i, const int* ids, int nb0) {
   const int ca = cap[i], cb = cap[i + 1], cc = cap[i + 2];
   int rc;
   JacobiSource src;
-  src.src = S.A[i]; src.src_b0 = a_b0_[i]; src.rx = d * ca; src.ncols = cb; src.conj = 0;
+  src.src = S.A[i]; src.src_b0 = a_b0_[i]; src.rx = d * ca; src.ncols = cb; src.conj = 0; src.tri = 0;
   src.r_n0 = ca; src.s_r1 = (long)ca * cb; src.s_r0 = cb; src.c_n0 = cb; src.s_c1 = 0; src.s_c0 = 1;
   src.nb0 = nb0; src.ids = ids;
   TruncSpec tr;
@@ -592,7 +611,7 @@ int Engine::svd_shift_left(StateSet& S, int i, const int* ids, int nb0) {
   const int cz = cap[i - 1], ca = cap[i], cb = cap[i + 1];
   int rc;
   JacobiSource src;  // X = M^H : rows (t,c), columns a
-  src.src = S.A[i]; src.src_b0 = a_b0_[i]; src.rx = d * cb; src.ncols = ca; src.conj = 1;
+  src.src = S.A[i]; src.src_b0 = a_b0_[i]; src.rx = d * cb; src.ncols = ca; src.conj = 1; src.tri = 0;
   src.r_n0 = cb; src.s_r1 = (long)ca * cb; src.s_r0 = 1; src.c_n0 = ca; src.s_c1 = 0; src.s_c0 = cb;
   src.nb0 = nb0; src.ids = ids;
   TruncSpec tr;
@@ -628,7 +647,7 @@ int Engine::svd_shift_left_rc(StateSet& S, int i, const int* ids, int nb0) {
   const int cz = cap[i - 1], ca = cap[i], cb = cap[i + 1];
   int rc;
   JacobiSource src;  // X = A_{i-1} as (d cz) x ca
-  src.src = S.A[i - 1]; src.src_b0 = a_b0_[i - 1]; src.rx = d * cz; src.ncols = ca; src.conj = 0;
+  src.src = S.A[i - 1]; src.src_b0 = a_b0_[i - 1]; src.rx = d * cz; src.ncols = ca; src.conj = 0; src.tri = 0;
   src.r_n0 = cz; src.s_r1 = (long)cz * ca; src.s_r0 = ca; src.c_n0 = ca; src.s_c1 = 0; src.s_c0 = 1;
   src.nb0 = nb0; src.ids = ids;
   TruncSpec tr;

@@ -142,6 +142,11 @@ __global__ __launch_bounds__(256) void zgemm_kernel(GemmDesc g) {
           cplx v;
           v.x = accP[i][j][r] + sq * accQ[i][j][r];
           v.y = s1 * accS1[i][j][r] + s2 * accS2[i][j][r];
+          if (g.accumulate != 0) {
+            const cplx old = Cb[(long)m * g.c_rs + n];
+            v.x = (g.accumulate > 0) ? old.x + v.x : old.x - v.x;
+            v.y = (g.accumulate > 0) ? old.y + v.y : old.y - v.y;
+          }
           Cb[(long)m * g.c_rs + n] = v;
         }
       }

@@ -89,6 +89,7 @@ struct SvdWorkspace {
   double* norms;  // [B][ncols_pad]
   double* fro2;   // [B] squared Frobenius norm of theta (noise floor for the rotations)
   int* perm;      // [B][ncols_pad]
+  int* stamps;    // [B][1152] visit-pruning stamps of the Jacobi sweeps
   int* nrot;      // [B]
   int* done;      // [B]
   int* n_active;  // [1]
@@ -103,6 +104,7 @@ struct JacobiSource {
   int r_n0, c_n0;
   long s_r1, s_r0, s_c1, s_c0;
   int conj;
+  int tri;  // 1: the source is triangular, keep X[r][c] only for c <= r
   int nb0;
   const int* ids;
 };
@@ -138,5 +140,25 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
 int svd_extract(const ExtractDesc& x, const SvdWorkspace& w, const JacobiShape& sh, const int* chi_keep, int chi_stride, int nb0,
                 const int* ids, hipStream_t s);
 int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* sweeps_out);
+
+// ---- blocked Householder QR preconditioner of the two-site split (tjm_qr.hip) -----------------
+struct QrWorkspace {
+  cplx* Z;   // [B][zr*zc] column-major work matrix (factor in place, later the isometric factor Q W)
+  long z_b0;
+  cplx* V;   // [B][panels][16][zr] reflector blocks with explicit zeros / unit diagonal
+  long v_b0;
+  cplx* T;   // [B][panels][16][16]
+  long t_b0;
+  cplx* W1;  // [B][16][w_ld]
+  cplx* W2;
+  int w_ld;
+};
+size_t qr_workspace_bytes(int max_dim, int B);
+int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s);
+int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hipStream_t s);
+int qr_apply_q(const QrWorkspace& q, int zr, int zc, cplx* C, long c_b0, int nc, int nb0, const int* ids, hipStream_t s);
+int qr_scatter(const cplx* in, long in_b0, int ld, const ExtractDesc& x, const int* chi_keep, int chi_stride, int nb0, const int* ids,
+               hipStream_t s);
+int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out);
 
 }  // namespace tjm

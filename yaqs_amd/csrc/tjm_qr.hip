@@ -1,0 +1,409 @@
+// Batched blocked Householder QR (compact WY) used to precondition the Jacobi SVD of the two-site split.
+//
+// Why: one-sided Jacobi on theta (or theta^H) of a time-evolved two-site tensor needs 16-19 sweeps because the
+// singular spectrum is graded over many decades and both singular bases are dense.  After Z = Q R the Jacobi
+// iteration on R^H starts from nearly orthogonal, norm-ordered columns and converges in about half the sweeps
+// (Drmac-Veselic preconditioning).  The isometric factor is recovered exactly as Q * W (Q: product of Householder
+// reflectors, W: accumulated plane rotations), so no division by a singular value appears anywhere.
+//
+// Structure: panels of 16 columns.  qr_panel_kernel factors one panel in LDS (one workgroup per trajectory),
+// builds the triangular T of the compact WY form and writes the reflector block V with explicit zeros / unit
+// diagonal; the trailing update and the application of Q are three launches of the batched MFMA zgemm each.
+#include <cstring>
+
+#include "tjm_kernels.h"
+
+namespace tjm {
+
+namespace {
+
+constexpr int PW = 16;  // panel width
+
+__device__ inline double block_sum256(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__device__ inline cplx wave_csum(cplx v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v.x += __shfl_xor(v.x, o, 64);
+    v.y += __shfl_xor(v.y, o, 64);
+  }
+  return v;
+}
+
+template <int CTRL>
+__device__ inline double dpp_pull(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double lane_value(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// wavefront all-reduce: DPP butterfly inside rows of 16 lanes, then the four row totals via v_readlane
+__device__ inline double wsum(double v) {
+  v += dpp_pull<0xB1>(v);
+  v += dpp_pull<0x4E>(v);
+  v += dpp_pull<0x141>(v);
+  v += dpp_pull<0x140>(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+
+// Factor panel columns [k0, k0 + pw) of A (column-major, zr x zc, leading dimension zr), rows k0 .. zr-1.
+// ONE wavefront per trajectory with the panel in LDS: a single wavefront runs in lock-step, so the 16 sequential
+// Householder steps need wavefront reductions only (no workgroup barrier), and the loops stay rolled (small code).
+__global__ __launch_bounds__(64) void qr_panel_kernel(cplx* __restrict__ A, long a_b0, int zr, int k0, int pw, cplx* __restrict__ Vb,
+                                                     long v_b0, cplx* __restrict__ Tb, long t_b0, int panel, const int* ids) {
+  extern __shared__ double smem[];
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  const int lane = threadIdx.x;
+  const int mp = zr - k0;  // panel rows, local row r = global row - k0
+  cplx* P = reinterpret_cast<cplx*>(smem);  // [PW][mp]
+  cplx* sG = P + PW * mp;                   // [PW][PW]
+  cplx* sT = sG + PW * PW;                  // [PW][PW]
+  cplx* sTau = sT + PW * PW;                // [PW]
+  double* sBeta = reinterpret_cast<double*>(sTau + PW);
+  cplx* Ab = A + (long)b * a_b0;
+  for (int c = 0; c < pw; ++c)
+    for (int r = lane; r < mp; r += 64) P[c * mp + r] = Ab[(long)(k0 + c) * zr + k0 + r];
+  for (int t = lane; t < PW * PW; t += 64) { sG[t] = cplx{0.0, 0.0}; sT[t] = cplx{0.0, 0.0}; }
+  if (lane < PW) { sTau[lane] = cplx{0.0, 0.0}; sBeta[lane] = 0.0; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int j = 0; j < pw; ++j) {
+    // ---- zlarfg on column j, rows j .. mp-1
+    cplx* pj = P + j * mp;
+    double acc = 0.0;
+    for (int r = j + 1 + lane; r < mp; r += 64) {
+      const cplx v = pj[r];
+      acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+    }
+    const double xn2 = wsum(acc);
+    const cplx alpha = (j < mp) ? pj[j] : cplx{0.0, 0.0};
+    cplx tau{0.0, 0.0}, scale{0.0, 0.0};
+    double bt = alpha.x;
+    if (j < mp && (xn2 > 0.0 || alpha.y != 0.0)) {
+      const double an = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xn2);
+      bt = (alpha.x >= 0.0) ? -an : an;
+      tau = cplx{(bt - alpha.x) / bt, -alpha.y / bt};
+      const cplx dnm{alpha.x - bt, alpha.y};
+      const double d2 = dnm.x * dnm.x + dnm.y * dnm.y;
+      scale = cplx{dnm.x / d2, -dnm.y / d2};
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int r = j + 1 + lane; r < mp; r += 64) pj[r] = cmul(pj[r], scale);
+    if (lane == 0) {
+      if (j < mp) pj[j] = cplx{1.0, 0.0};
+      sTau[j] = tau;
+      sBeta[j] = bt;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- H^H = I - conj(tau) v v^H on the remaining panel columns
+    if (tau.x != 0.0 || tau.y != 0.0) {
+      // all dot products v^H a_c (c > j) first, reduced together (the reductions pipeline), then the rank-1 update
+      cplx w[PW];
+#pragma unroll
+      for (int c = 0; c < PW; ++c) w[c] = cplx{0.0, 0.0};
+      for (int r = j + lane; r < mp; r += 64) {
+        const cplx vv = cconj(pj[r]);
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+          if (c > j && c < pw) cfma(w[c], vv, P[c * mp + r]);
+      }
+#pragma unroll
+      for (int c = 0; c < PW; ++c) {
+        w[c].x = wsum(w[c].x);
+        w[c].y = wsum(w[c].y);
+        w[c] = cmul(cconj(tau), w[c]);
+      }
+      for (int r = j + lane; r < mp; r += 64) {
+        const cplx vv = pj[r];
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+          if (c > j && c < pw) {
+            cplx x = P[c * mp + r];
+            x.x -= w[c].x * vv.x - w[c].y * vv.y;
+            x.y -= w[c].x * vv.y + w[c].y * vv.x;
+            P[c * mp + r] = x;
+          }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- G[l][j] = V_l^H V_j (l < j); column c holds v_c below row c, 1 on it (R entries above are not part of V)
+  for (int j = 1; j < pw; ++j) {
+    cplx w[PW];
+#pragma unroll
+    for (int l = 0; l < PW; ++l) w[l] = cplx{0.0, 0.0};
+    for (int r = j + lane; r < mp; r += 64) {
+      const cplx vj = P[j * mp + r];
+#pragma unroll
+      for (int l = 0; l < PW; ++l)
+        if (l < j) cfma(w[l], cconj(P[l * mp + r]), vj);
+    }
+#pragma unroll
+    for (int l = 0; l < PW; ++l) {
+      w[l].x = wsum(w[l].x);
+      w[l].y = wsum(w[l].y);
+      if (lane == 0 && l < j) sG[l * PW + j] = w[l];
+    }
+  }
+  if (lane < pw) sT[lane * PW + lane] = sTau[lane];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ---- T (zlarft forward / columnwise); lane i builds row i of column j
+  for (int j = 1; j < pw; ++j) {
+    const cplx tj = sT[j * PW + j];
+    if (lane < j) {
+      cplx accv{0.0, 0.0};
+      for (int l = lane; l < j; ++l) cfma(accv, sT[lane * PW + l], sG[l * PW + j]);
+      sT[lane * PW + j] = cplx{-(tj.x * accv.x - tj.y * accv.y), -(tj.x * accv.y + tj.y * accv.x)};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- write back: R part / reflectors into A, explicit V block (zeros above, unit diagonal), T
+  cplx* Vp = Vb + (long)b * v_b0 + (long)panel * PW * zr;
+  for (int c = 0; c < PW; ++c) {
+    for (int r = lane; r < mp; r += 64) {
+      cplx v{0.0, 0.0};
+      if (c < pw) {
+        cplx a = P[c * mp + r];
+        if (r == c) a = cplx{sBeta[c], 0.0};
+        Ab[(long)(k0 + c) * zr + k0 + r] = a;
+        if (r == c) v = cplx{1.0, 0.0};
+        else if (r > c) v = P[c * mp + r];
+      }
+      Vp[(long)c * zr + k0 + r] = v;
+    }
+    for (int gr = lane; gr < k0; gr += 64) Vp[(long)c * zr + gr] = cplx{0.0, 0.0};
+  }
+  cplx* Tp = Tb + (long)b * t_b0 + (long)panel * PW * PW;
+  for (int t = lane; t < PW * PW; t += 64) Tp[t] = sT[t];
+}
+
+// Fused block reflector on a chunk of 16 columns of C (column-major, leading dimension zr), fp64 MFMA:
+//   C_chunk <- C_chunk - V op(T) (V^H C_chunk),   op = T^H (factorisation) or T (Q * C)
+__global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restrict__ Vb, long v_b0, const cplx* __restrict__ Tb, long t_b0, int panel,
+                                                            int zr, int t_herm, cplx* __restrict__ C, long c_b0, int col0, int nc,
+                                                            const int* ids) {
+  __shared__ cplx sW1[PW * PW];   // (i, c)
+  __shared__ cplx sW2[PW * PW];
+  __shared__ cplx sTm[PW * PW];
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = col0 + blockIdx.x * PW;
+  const int ncw = (nc - blockIdx.x * PW < PW) ? nc - blockIdx.x * PW : PW;
+  const cplx* __restrict__ Vp = Vb + (long)b * v_b0 + (long)panel * PW * zr;
+  const cplx* Tp = Tb + (long)b * t_b0 + (long)panel * PW * PW;
+  cplx* Cb = C + (long)b * c_b0;
+  sTm[tid] = Tp[tid];
+  sW1[tid] = cplx{0.0, 0.0};
+  __syncthreads();
+  const int li = lane & 15, lk = lane >> 4;
+  {  // W1[i][c] = sum_r conj(V[i][r]) C[c][r]   (K = rows, split over the four wavefronts)
+    d4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
+    const int nsteps = zr >> 2;
+    const bool cvalid = li < ncw;
+    for (int s = wave; s < nsteps; s += 4) {
+      const int r = 4 * s + lk;
+      const cplx v = Vp[(long)li * zr + r];
+      const cplx x = cvalid ? Cb[(long)(c0 + li) * zr + r] : cplx{0.0, 0.0};
+      P = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.x, P, 0, 0, 0);
+      Q = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, x.y, Q, 0, 0, 0);
+      S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.y, S1, 0, 0, 0);
+      S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, x.x, S2, 0, 0, 0);
+    }
+    for (int w = 0; w < 4; ++w) {  // deterministic reduction over the wavefronts
+      if (wave == w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = lk + 4 * q, c = li;
+          cplx a = sW1[i * PW + c];
+          a.x += P[q] + Q[q];
+          a.y += S1[q] - S2[q];
+          sW1[i * PW + c] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  {  // W2 = op(T) W1
+    const int i = tid >> 4, c = tid & 15;
+    cplx acc{0.0, 0.0};
+    for (int l = 0; l < PW; ++l) {
+      const cplx t = t_herm ? cconj(sTm[l * PW + i]) : sTm[i * PW + l];
+      cfma(acc, t, sW1[l * PW + c]);
+    }
+    sW2[i * PW + c] = acc;
+  }
+  __syncthreads();
+  {  // C[c][r] -= sum_i V[i][r] W2[i][c] : D[row][c] = sum_i A[row][i] B[i][c]
+    double wr[4], wi[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const cplx t = sW2[(4 * kk + lk) * PW + li];
+      wr[kk] = t.x;
+      wi[kk] = t.y;
+    }
+    const int nchunks = zr >> 4;
+    for (int ch = wave; ch < nchunks; ch += 4) {
+      const int r0 = ch * 16;
+      d4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const cplx v = Vp[(long)(4 * kk + lk) * zr + r0 + li];  // A[row = li][i = 4kk + lk]
+        P = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, wr[kk], P, 0, 0, 0);
+        Q = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, wi[kk], Q, 0, 0, 0);
+        S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, wi[kk], S1, 0, 0, 0);
+        S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, wr[kk], S2, 0, 0, 0);
+      }
+      if (li < ncw) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const long idx = (long)(c0 + li) * zr + r0 + lk + 4 * q;  // D: row = lk + 4q, column = li
+          cplx x = Cb[idx];
+          x.x -= P[q] - Q[q];
+          x.y -= S1[q] + S2[q];
+          Cb[idx] = x;
+        }
+      }
+    }
+  }
+}
+
+// out(col-major zr x zc) from theta (row-major m x n): dist 0 -> Z = theta ; dist 1 -> Z = theta^H
+__global__ __launch_bounds__(256) void qr_prepare_kernel(const cplx* __restrict__ theta, long th_b0, int m, int n, int dist, cplx* __restrict__ Z,
+                                                        long z_b0, const int* ids) {
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  const cplx* th = theta + (long)b * th_b0;
+  cplx* Zb = Z + (long)b * z_b0;
+  const long total = (long)m * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    if (dist == 0) {
+      // Z(r, c) = theta[r][c], column-major: index c * m + r ; iterate e over (c, r) with r fastest
+      const long c = e / m, r = e % m;
+      Zb[e] = th[r * n + c];
+    } else {
+      // Z = theta^H (n x m), column-major: Z(j, i) at i * n + j = conj(theta[i][j]) : same memory order as theta
+      cplx v = th[e];
+      v.y = -v.y;
+      Zb[e] = v;
+    }
+  }
+}
+
+// out[k*o_k + r1*o_r1 + r0*o_r0] = op(in[k*ld + r1*n_r0 + r0])  for k < n_k (zero beyond keep)
+__global__ __launch_bounds__(256) void qr_scatter_kernel(const cplx* __restrict__ in, long in_b0, int ld, ExtractDesc x, const int* chi_keep,
+                                                        int chi_stride, const int* ids) {
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  const cplx* ib = in + (long)b * in_b0;
+  cplx* out = x.out + (long)b * x.out_b0;
+  const int keep = chi_keep[(long)b * chi_stride];
+  const long nrows = (long)x.n_r1 * x.n_r0;
+  const long total = nrows * x.n_k;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / nrows);
+    const long r = e % nrows;
+    const int r1 = (int)(r / x.n_r0), r0 = (int)(r % x.n_r0);
+    cplx v{0.0, 0.0};
+    if (k < keep) {
+      v = ib[(long)k * ld + r];
+      if (x.conj) v.y = -v.y;
+    }
+    out[(long)k * x.o_k + (long)r1 * x.o_r1 + (long)r0 * x.o_r0] = v;
+  }
+}
+
+GemmDesc blank() {
+  GemmDesc g;
+  memset(&g, 0, sizeof(g));
+  g.nks = 1; g.nb0 = 1; g.nb1 = 1; g.nb2 = 1;
+  return g;
+}
+
+// C (col-major zr x nc at C + col0 * zr) <- C - V_p op(T_p) V_p^H C     (op = T^H for the factorisation, T for Q * C)
+int apply_block_reflector(const QrWorkspace& q, int zr, int panel, bool t_herm, cplx* C, long c_b0, int col0, int nc, int nb0, const int* ids,
+                          hipStream_t s) {
+  if (nc <= 0) return TJM_OK;
+  hipLaunchKernelGGL(qr_block_apply_kernel, dim3((nc + PW - 1) / PW, nb0), dim3(256), 0, s, q.V, q.v_b0, q.T, q.t_b0, panel, zr, t_herm ? 1 : 0, C,
+                     c_b0, col0, nc, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+}  // namespace
+
+size_t qr_workspace_bytes(int max_dim, int B) {
+  const size_t mat = (size_t)max_dim * max_dim * sizeof(cplx);
+  const size_t vb = (size_t)(max_dim / PW + 1) * PW * max_dim * sizeof(cplx);
+  return (size_t)B * (mat + vb + (size_t)(max_dim / PW + 1) * PW * PW * sizeof(cplx) + 2 * (size_t)PW * max_dim * sizeof(cplx)) + 16384;
+}
+
+int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s) {
+  const long total = (long)m * n;
+  int gx = (int)((total + 1023) / 1024);
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(qr_prepare_kernel, dim3(gx, nb0), dim3(256), 0, s, theta, th_b0, m, n, dist, q.Z, q.z_b0, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// Z (zr x zc, column-major in q.Z) = Q R in place: R in the upper triangle, reflector blocks in q.V / q.T.
+int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hipStream_t s) {
+  const int kmax = zr < zc ? zr : zc;
+  static bool attr_set = false;
+  if (!attr_set) {
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  int rc;
+  int panel = 0;
+  for (int k0 = 0; k0 < kmax; k0 += PW, ++panel) {
+    const int pw = (kmax - k0 < PW) ? kmax - k0 : PW;
+    const size_t lds = (size_t)(PW * (zr - k0) + 2 * PW * PW + PW) * sizeof(cplx) + PW * sizeof(double) + 64;
+    if (zr % 16 != 0) return TJM_ERR_NOT_IMPLEMENTED;
+    hipLaunchKernelGGL(qr_panel_kernel, dim3(nb0), dim3(64), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
+    TJM_HIP_CHECK(hipGetLastError());
+    const int col0 = k0 + pw;
+    if ((rc = apply_block_reflector(q, zr, panel, true, q.Z, q.z_b0, col0, zc - col0, nb0, ids, s)) != TJM_OK) return rc;
+  }
+  return TJM_OK;
+}
+
+// C (zr x nc, column-major, leading dimension zr) <- Q C
+int qr_apply_q(const QrWorkspace& q, int zr, int zc, cplx* C, long c_b0, int nc, int nb0, const int* ids, hipStream_t s) {
+  const int kmax = zr < zc ? zr : zc;
+  const int npanels = (kmax + PW - 1) / PW;
+  int rc;
+  for (int p = npanels - 1; p >= 0; --p)
+    if ((rc = apply_block_reflector(q, zr, p, false, C, c_b0, 0, nc, nb0, ids, s)) != TJM_OK) return rc;
+  return TJM_OK;
+}
+
+int qr_scatter(const cplx* in, long in_b0, int ld, const ExtractDesc& x, const int* chi_keep, int chi_stride, int nb0, const int* ids,
+               hipStream_t s) {
+  const long total = (long)x.n_r1 * x.n_r0 * x.n_k;
+  if (total <= 0) return TJM_OK;
+  int gx = (int)((total + 1023) / 1024);
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(qr_scatter_kernel, dim3(gx, nb0), dim3(256), 0, s, in, in_b0, ld, x, chi_keep, chi_stride, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+}  // namespace tjm

@@ -19,6 +19,7 @@
 // workgroups; trajectories whose sweep performed no rotation are flagged done and skipped.
 // The isometric output is always read from W and the sigma-weighted output from the rotated
 // X for the two-site split, so that path never divides by a singular value.
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -30,6 +31,8 @@ namespace {
 
 constexpr int NB = 8;        // columns per block
 constexpr int MAXRK = 8;     // row groups of 64 per column held in registers (rtot <= 512)
+constexpr int MAXBLK = 32;   // column blocks per matrix (ncols <= 256)
+constexpr int STAMP_STRIDE = 3 * MAXBLK + MAXBLK * MAXBLK;
 
 struct JacobiArgs {
   cplx* Y;
@@ -43,6 +46,8 @@ struct JacobiArgs {
   int* nrot;
   const int* done;
   const int* ids;
+  int* stamps;  // [B][STAMP_STRIDE]: mod[32] | verd[32] | nz[32] | ver[32*32]   (visit pruning)
+  int clock;    // launch counter, strictly increasing inside one solve
 };
 
 __device__ inline void pair_of(int nblk, int round, int p, int& I, int& J) {
@@ -58,10 +63,41 @@ __device__ inline void pair_of(int nblk, int round, int p, int& I, int& J) {
   if (I > J) { int t = I; I = J; J = t; }
 }
 
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- wavefront all-reduce without LDS traffic: four DPP butterfly stages inside each row of 16 lanes
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row totals are read with v_readlane.
+template <int CTRL>
+__device__ inline double dpp_pull(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ inline double row_total(double v) {
+  v += dpp_pull<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_pull<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_pull<0x141>(v);  // row_half_mirror
+  v += dpp_pull<0x140>(v);  // row_mirror
   return v;
+}
+
+__device__ inline double lane_value(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ inline double wave_sum(double v) {
+  v = row_total(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+
+// fp64 reciprocal square root: hardware estimate + two Newton steps (full double precision)
+__device__ inline double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
 }
 
 // Decide and build the rotation for the column pair with norms (a, d) and inner product g.
@@ -69,28 +105,38 @@ __device__ inline double wave_sum(double v) {
 //   y_p' = c y_p - conj(s) y_q ,  y_q' = s y_p + c y_q ,  a' = a - t|g| ,  d' = d + t|g|.
 __device__ inline bool make_rotation(double a, double d, double gx, double gy, double tol2, double nfloor, double& c, double& sr,
                                      double& si, double& tg) {
-  const double mag2 = gx * gx + gy * gy;
+  const double mag2 = fma(gx, gx, gy * gy);
   const double big = fmax(a, d);
   // rotate only if the pair is non-orthogonal at the tolerance level, the rotation angle is above 1e-15 and
   // neither column sits at the rounding-noise floor of the matrix (sigma < 1e-13 ||X||_F: such columns are
   // numerically null, carry no weight, and would otherwise be rotated against rounding noise for ever)
   if (!(mag2 > tol2 * a * d && mag2 > 1e-30 * big * big && a > nfloor && d > nfloor && mag2 > 1e-300)) return false;
-  const double mag = sqrt(mag2);
-  const double tau = (d - a) / (2.0 * mag);
-  const double t = ((tau >= 0.0) ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-  c = 1.0 / sqrt(1.0 + t * t);
+  const double inv_mag = fast_rsqrt(mag2);
+  const double mag = mag2 * inv_mag;
+  const double tau = 0.5 * (d - a) * inv_mag;
+  const double h2 = fma(tau, tau, 1.0);
+  const double hyp = h2 * fast_rsqrt(h2);                       // sqrt(1 + tau^2)
+  const double den = fabs(tau) + hyp;                           // >= 1
+  double t = __builtin_amdgcn_rcp(den);
+  t = t * fma(-den, t, 2.0);
+  t = t * fma(-den, t, 2.0);
+  t = (tau >= 0.0) ? t : -t;
+  c = fast_rsqrt(fma(t, t, 1.0));
   const double s = t * c;
-  sr = s * gx / mag;
-  si = s * gy / mag;
+  sr = s * gx * inv_mag;
+  si = s * gy * inv_mag;
   tg = t * mag;
   return true;
 }
 
 __device__ inline void rotate_pair(cplx& p, cplx& q, double c, double sr, double si) {
-  const cplx np{c * p.x - (sr * q.x + si * q.y), c * p.y - (sr * q.y - si * q.x)};
-  const cplx nq{(sr * p.x - si * p.y) + c * q.x, (sr * p.y + si * p.x) + c * q.y};
-  p = np;
-  q = nq;
+  // y_p' = c y_p - conj(s) y_q ; y_q' = s y_p + c y_q
+  const double npx = fma(-si, q.y, fma(-sr, q.x, c * p.x));
+  const double npy = fma(si, q.x, fma(-sr, q.y, c * p.y));
+  const double nqx = fma(c, q.x, fma(-si, p.y, sr * p.x));
+  const double nqy = fma(c, q.y, fma(si, p.x, sr * p.y));
+  p = cplx{npx, npy};
+  q = cplx{nqx, nqy};
 }
 
 // ---- cross pairs of one block pair -----------------------------------------------------------
@@ -107,6 +153,14 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
 
   int I, J;
   pair_of(g.nblk, g.round, blockIdx.x, I, J);
+  // visit pruning: a block with only zero columns never rotates; a pair found orthogonal stays so until one of
+  // its blocks is modified again
+  int* st = g.stamps + (long)b * STAMP_STRIDE;
+  if (!st[2 * MAXBLK + I] || !st[2 * MAXBLK + J]) return;
+  {
+    const int ver = st[3 * MAXBLK + I * MAXBLK + J];
+    if (ver > st[I] && ver > st[J]) return;
+  }
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   cplx* colI = Yb + (long)(I * NB + w) * rtot;
@@ -175,7 +229,11 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
   int total = 0;
 #pragma unroll
   for (int q = 0; q < NB; ++q) total += sCnt[q];
-  if (total == 0) return;  // nothing rotated: memory is already up to date
+  if (total == 0) {  // nothing rotated: memory is already up to date, remember the pair as verified
+    if (tid == 0) st[3 * MAXBLK + I * MAXBLK + J] = g.clock;
+    return;
+  }
+  if (tid == 0) { st[I] = g.clock; st[J] = g.clock; }
   // after 7 hand-overs wave w holds J column (w + 7) mod 8
   cplx* outJ = Yb + (long)(J * NB + ((w + NB - 1) & (NB - 1))) * rtot;
 #pragma unroll
@@ -199,6 +257,10 @@ __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
   cplx* tile = reinterpret_cast<cplx*>(smem);                  // [8][rtot]
   double* sN = reinterpret_cast<double*>(tile + NB * rtot);    // [8]
   int* sCnt = reinterpret_cast<int*>(sN + NB);                 // [4]
+  int* st = g.stamps + (long)b * STAMP_STRIDE;
+  const int I = blockIdx.x;
+  if (!st[2 * MAXBLK + I]) return;
+  if (st[MAXBLK + I] > st[I]) return;
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0 + (long)blockIdx.x * NB * rtot;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int c = w; c < NB; c += 4) {
@@ -251,7 +313,11 @@ __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
   if (lane == 0) sCnt[w] = cnt;
   __syncthreads();
   const int total = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
-  if (total == 0) return;
+  if (total == 0) {
+    if (tid == 0) st[MAXBLK + I] = g.clock;
+    return;
+  }
+  if (tid == 0) st[I] = g.clock;
   for (int c = w; c < NB; c += 4)
     for (int k = 0; k < nrk; ++k) Yb[(long)c * rtot + lane + 64 * k] = tile[c * rtot + lane + 64 * k];
   if (tid == 0) atomicAdd(&g.nrot[b], total);
@@ -269,7 +335,7 @@ __global__ __launch_bounds__(256) void jacobi_load_kernel(JacobiSource src, cplx
     const int c = (int)(e / rtot), r = (int)(e % rtot);
     cplx v{0.0, 0.0};
     if (r < rx_top) {
-      if (r < src.rx && c < src.ncols) {
+      if (r < src.rx && c < src.ncols && !(src.tri && c > r)) {
         // two-level row / column indices let a (phys, bond) pair be flattened without a transpose
         const int r1 = r / src.r_n0, r0 = r % src.r_n0;
         const int c1 = c / src.c_n0, c0 = c % src.c_n0;
@@ -303,6 +369,28 @@ __global__ __launch_bounds__(256) void jacobi_fro_kernel(const cplx* __restrict_
   if (threadIdx.x == 0) fro2[b] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// stamps: mod = 1, verified = 0, nz[I] = block I has a non-zero X column
+__global__ __launch_bounds__(256) void jacobi_stamp_init_kernel(const cplx* __restrict__ Y, long y_b0, int nblk, int rx_top, int rtot, int* stamps,
+                                                               const int* ids) {
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  int* st = stamps + (long)b * STAMP_STRIDE;
+  for (int t = threadIdx.x; t < STAMP_STRIDE; t += blockDim.x) st[t] = (t < MAXBLK) ? 1 : 0;
+  __syncthreads();
+  const cplx* Yb = Y + (long)b * y_b0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int I = wave; I < nblk; I += 4) {
+    int nz = 0;
+    for (int c = 0; c < NB; ++c)
+      for (int r = lane; r < rx_top; r += 64) {
+        const cplx v = Yb[(long)(I * NB + c) * rtot + r];
+        nz |= (v.x != 0.0 || v.y != 0.0) ? 1 : 0;
+      }
+    nz = __any(nz);
+    if (lane == 0) st[2 * MAXBLK + I] = nz;
+  }
+}
+
 __global__ void svd_sweep_check_kernel(int* nrot, int* done, int* n_active, int nb0, const int* ids) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nb0) return;
@@ -310,6 +398,7 @@ __global__ void svd_sweep_check_kernel(int* nrot, int* done, int* n_active, int 
   if (!done[b]) {
     if (nrot[b] == 0) done[b] = 1;
     else atomicAdd(n_active, 1);
+    atomicAdd(n_active + 1, nrot[b]);
   }
   nrot[b] = 0;
 }
@@ -452,6 +541,7 @@ struct CrossProfile {
   long samples = 0;
 };
 CrossProfile g_prof;
+const bool g_debug = getenv("TJM_DEBUG_SVD") != nullptr;
 
 void prof_collect() {
   for (auto& p : g_prof.pending) {
@@ -485,7 +575,7 @@ void profile_get(double* total_ms, double* total_bytes, long* samples) {
 size_t svd_workspace_bytes(int max_dim, int B) {
   const int p = round_up(max_dim, 16);
   size_t y = (size_t)B * p * round_up(2 * p, 64) * sizeof(cplx);
-  size_t small = (size_t)B * p * (sizeof(double) + sizeof(int)) + (size_t)B * 4 * sizeof(int) + 64;
+  size_t small = (size_t)B * p * (sizeof(double) + sizeof(int)) + (size_t)B * 4 * sizeof(int) + (size_t)B * STAMP_STRIDE * sizeof(int) + 64;
   return y + small + 4096;
 }
 
@@ -512,6 +602,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(jacobi_load_kernel, dim3(gx, src.nb0), dim3(256), 0, s, src, w.Y, w.y_b0, ncols_pad, rx_top, rtot);
     hipLaunchKernelGGL(jacobi_fro_kernel, dim3(src.nb0), dim3(256), 0, s, w.Y, w.y_b0, ncols_pad, rx_top, rtot, w.fro2, src.ids);
+    hipLaunchKernelGGL(jacobi_stamp_init_kernel, dim3(src.nb0), dim3(256), 0, s, w.Y, w.y_b0, ncols_pad / NB, rx_top, rtot, w.stamps, src.ids);
   }
   JacobiArgs g;
   g.Y = w.Y;
@@ -525,6 +616,9 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   g.done = w.done;
   g.ids = src.ids;
   g.round = 0;
+  g.stamps = w.stamps;
+  g.clock = 1;
+  if (g.nblk > MAXBLK) return TJM_ERR_NOT_IMPLEMENTED;
   const int nrounds = g.nblk - 1;
   const int npairs = g.nblk / 2;
   const int max_sweeps = 40;
@@ -532,9 +626,11 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   int n_live = src.nb0;
   bool converged = false;
   for (; sweep < max_sweeps && !converged; ++sweep) {
+    ++g.clock;
     hipLaunchKernelGGL(jacobi_diag_kernel, dim3(g.nblk, src.nb0), dim3(256), lds, s, g);
     for (int r = 0; r < nrounds; ++r) {
       g.round = r;
+      ++g.clock;
       const bool timed = g_prof.every > 0 && (g_prof.counter++ % g_prof.every == 0);
       int slot = -1;
       if (timed) {
@@ -553,11 +649,12 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
         g_prof.pending.emplace_back(slot, (double)npairs * n_live * 2.0 * (2 * NB) * rtot * sizeof(cplx));
       }
     }
-    TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, sizeof(int), s));
+    TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 2 * sizeof(int), s));
     hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tb), dim3(256), 0, s, w.nrot, w.done, w.n_active, src.nb0, src.ids);
-    TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+    TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     TJM_HIP_CHECK(hipStreamSynchronize(s));
     converged = (*w.h_pinned == 0);
+    if (g_debug && src.ncols >= 128) fprintf(stderr, "[svd] ncols %d rx %d sweep %d live %d rotations %d\n", src.ncols, src.rx, sweep, w.h_pinned[0], w.h_pinned[1]);
     n_live = *w.h_pinned;
     if (g_prof.every > 0) prof_collect();
   }
@@ -587,7 +684,7 @@ int svd_extract(const ExtractDesc& x, const SvdWorkspace& w, const JacobiShape& 
 int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* sweeps_out) {
   if (d.nb0 <= 0) return TJM_OK;
   JacobiSource src;
-  src.src = d.theta; src.src_b0 = d.theta_b0; src.conj = (d.distribution == 0);
+  src.src = d.theta; src.src_b0 = d.theta_b0; src.conj = (d.distribution == 0); src.tri = 0;
   if (d.distribution == 0) {  // X = theta^H : rows = theta columns, columns = theta rows
     src.rx = d.n; src.ncols = d.m;
     src.r_n0 = d.n; src.s_r1 = 0; src.s_r0 = 1;
@@ -617,6 +714,55 @@ int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* 
   xr.n_r1 = d.d; xr.n_r0 = d.capR; xr.o_r1 = (long)d.capM * d.capR; xr.o_r0 = 1;
   xr.row_off = (d.distribution == 0) ? 0 : sh.rx_top; xr.conj = 1; xr.scale_mode = 0;
   return svd_extract(xr, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s);
+}
+
+
+// Two-site split with QR preconditioning: Z = theta (dist 0) or theta^H (dist 1) = Q R, Jacobi on R^H with accumulated W,
+// isometric factor = Q W, weighted factor = rotated R^H.  Same outputs as svd_split.
+int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out) {
+  if (d.nb0 <= 0) return TJM_OK;
+  if (d.ids) return svd_split(d, w, s, sweeps_out);  // index-list batches take the plain path
+  if (d.ld_theta != d.n) return TJM_ERR_ARG;
+  const int zr = (d.distribution == 0) ? d.m : d.n;
+  const int zc = (d.distribution == 0) ? d.n : d.m;
+  if (zr % 16 != 0 || zr < 16) return svd_split(d, w, s, sweeps_out);  // the MFMA block reflector works on 16-row chunks
+  const int kmax = zr < zc ? zr : zc;
+  int rc;
+  if ((rc = qr_prepare(d.theta, d.theta_b0, d.m, d.n, d.distribution, q, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  if ((rc = qr_factor(q, zr, zc, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  JacobiSource src;  // X = R^H : X[r][c] = conj(R[c][r]) , R[i][j] = Z[j * zr + i] for i <= j
+  src.src = q.Z; src.src_b0 = q.z_b0; src.rx = zc; src.ncols = kmax; src.conj = 1; src.tri = 1;
+  src.r_n0 = zc; src.s_r1 = 0; src.s_r0 = zr; src.c_n0 = kmax; src.s_c1 = 0; src.s_c0 = 1;
+  src.nb0 = d.nb0; src.ids = d.ids;
+  TruncSpec tr;
+  tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
+  tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
+  tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
+  JacobiShape sh;
+  if ((rc = jacobi_solve(src, tr, w, s, &sh, sweeps_out)) != TJM_OK) return rc;
+  // isometric factor Q W: W (sorted, first capM columns) into Z, rows beyond the W block are zero
+  TJM_HIP_CHECK(hipMemsetAsync(q.Z, 0, (size_t)q.z_b0 * sizeof(cplx) * (size_t)d.nb0, s));
+  ExtractDesc xw;
+  xw.out = q.Z; xw.out_b0 = q.z_b0; xw.n_k = d.capM; xw.o_k = zr; xw.n_r1 = 1; xw.n_r0 = (zr < sh.ncols_pad) ? zr : sh.ncols_pad;
+  xw.o_r1 = 0; xw.o_r0 = 1; xw.row_off = sh.rx_top; xw.conj = 0; xw.scale_mode = 0;
+  if ((rc = svd_extract(xw, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  if ((rc = qr_apply_q(q, zr, zc, q.Z, q.z_b0, d.capM, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  ExtractDesc xi, xx;
+  if (d.distribution == 0) {
+    // left[(s,a)][k] = (Q W)[(s,a)][k] ; right[t][k][c] = conj(Xfinal[(t,c)][k])
+    xi.out = d.left; xi.out_b0 = d.left_b0; xi.n_k = d.capM; xi.o_k = 1; xi.n_r1 = 1; xi.n_r0 = d.d * d.capL; xi.o_r1 = 0; xi.o_r0 = d.capM;
+    xi.row_off = 0; xi.conj = 0; xi.scale_mode = 0;
+    xx.out = d.right; xx.out_b0 = d.right_b0; xx.n_k = d.capM; xx.o_k = d.capR; xx.n_r1 = d.d; xx.n_r0 = d.capR;
+    xx.o_r1 = (long)d.capM * d.capR; xx.o_r0 = 1; xx.row_off = 0; xx.conj = 1; xx.scale_mode = 0;
+  } else {
+    // right[t][k][c] = conj((Q W)[(t,c)][k]) ; left[(s,a)][k] = Xfinal[(s,a)][k]
+    xi.out = d.right; xi.out_b0 = d.right_b0; xi.n_k = d.capM; xi.o_k = d.capR; xi.n_r1 = d.d; xi.n_r0 = d.capR;
+    xi.o_r1 = (long)d.capM * d.capR; xi.o_r0 = 1; xi.row_off = 0; xi.conj = 1; xi.scale_mode = 0;
+    xx.out = d.left; xx.out_b0 = d.left_b0; xx.n_k = d.capM; xx.o_k = 1; xx.n_r1 = 1; xx.n_r0 = d.d * d.capL; xx.o_r1 = 0; xx.o_r0 = d.capM;
+    xx.row_off = 0; xx.conj = 0; xx.scale_mode = 0;
+  }
+  if ((rc = qr_scatter(q.Z, q.z_b0, zr, xi, d.chiM, d.chi_stride, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  return svd_extract(xx, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s);
 }
 
 }  // namespace tjm
