@@ -89,6 +89,7 @@ struct SvdWorkspace {
   double* norms;  // [B][ncols_pad]
   double* fro2;   // [B] squared Frobenius norm of theta (noise floor for the rotations)
   int* perm;      // [B][ncols_pad]
+  double* rec;    // [B][8][256][4] rotation record (split X / W Jacobi), may be null
   int* stamps;    // [B][1152] visit-pruning stamps of the Jacobi sweeps
   int* nrot;      // [B]
   int* done;      // [B]
@@ -132,6 +133,7 @@ struct ExtractDesc {
   int conj;
   int scale_mode;
 };
+long svd_y_elems(int max_dim);  // complex elements of the stacked Jacobi matrix per trajectory
 size_t svd_workspace_bytes(int max_dim, int B);
 void profile_enable(int every);
 void profile_get(double* total_ms, double* total_bytes, long* samples);

@@ -46,6 +46,8 @@ struct JacobiArgs {
   int* nrot;
   const int* done;
   const int* ids;
+  int mode;     // 0: round-robin pair of the round ; 1: sibling pair (2p, 2p+1) of 8-column blocks
+  double* rec;  // [B][npairs][256][4] rotation record of the split X / W scheme (c, sr, si, flag)
   int* stamps;  // [B][STAMP_STRIDE]: mod[32] | verd[32] | nz[32] | ver[32*32]   (visit pruning)
   int clock;    // launch counter, strictly increasing inside one solve
 };
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
   int* sCnt = reinterpret_cast<int*>(sN + NB);                  // [8]
 
   int I, J;
-  pair_of(g.nblk, g.round, blockIdx.x, I, J);
+  if (g.mode == 1) { I = 2 * blockIdx.x; J = I + 1; }
+  else pair_of(g.nblk, g.round, blockIdx.x, I, J);
   // visit pruning: a block with only zero columns never rotates; a pair found orthogonal stays so until one of
   // its blocks is modified again
   int* st = g.stamps + (long)b * STAMP_STRIDE;
@@ -244,6 +247,303 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
     }
   }
   if (tid == 0) atomicAdd(&g.nrot[b], total);
+}
+
+// ---- cross pairs of a pair of 16-column blocks ---------------------------------------------------
+// Same scheme with twice the tile: every wavefront keeps TWO columns of block I and TWO of block J, so each LDS
+// hand-over (and its two barriers) is followed by four rotations, the two independent ones back to back, and a
+// column is read from / written to memory once per 256 rotations of the tile instead of once per 64.
+__global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
+  extern __shared__ double smem[];
+  int b = blockIdx.y;
+  if (g.ids) b = g.ids[b];
+  if (g.done[b]) return;
+  const int rtot = g.rtot, rx = g.rx;
+  const int nrk = rtot >> 6;
+  cplx* slots = reinterpret_cast<cplx*>(smem);                      // [8][2][rtot]
+  double* sN = reinterpret_cast<double*>(slots + 2 * NB * rtot);    // [8][2]
+  int* sCnt = reinterpret_cast<int*>(sN + 2 * NB);                  // [8]
+  int I, J;
+  pair_of(g.nblk / 2, g.round, blockIdx.x, I, J);                   // indices of 16-column blocks
+  int* st = g.stamps + (long)b * STAMP_STRIDE;
+  {
+    const int nzI = st[2 * MAXBLK + 2 * I] | st[2 * MAXBLK + 2 * I + 1];
+    const int nzJ = st[2 * MAXBLK + 2 * J] | st[2 * MAXBLK + 2 * J + 1];
+    if (!nzI || !nzJ) return;
+    const int ver = st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J];
+    const int m1 = max(max(st[2 * I], st[2 * I + 1]), max(st[2 * J], st[2 * J + 1]));
+    if (ver > m1) return;
+  }
+  cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  cplx yI[2][MAXRK], yJ[2][MAXRK];
+  double nI[2] = {0.0, 0.0}, nJ[2] = {0.0, 0.0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const cplx* cI = Yb + (long)(I * 16 + 2 * w + h) * rtot;
+    const cplx* cJ = Yb + (long)(J * 16 + 2 * w + h) * rtot;
+#pragma unroll
+    for (int k = 0; k < MAXRK; ++k) {
+      if (k < nrk) {
+        yI[h][k] = cI[lane + 64 * k];
+        yJ[h][k] = cJ[lane + 64 * k];
+      } else {
+        yI[h][k] = cplx{0.0, 0.0};
+        yJ[h][k] = cplx{0.0, 0.0};
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int k = 0; k < MAXRK; ++k) {
+      if (k < nrk && lane + 64 * k < rx) {
+        nI[h] = fma(yI[h][k].x, yI[h][k].x, fma(yI[h][k].y, yI[h][k].y, nI[h]));
+        nJ[h] = fma(yJ[h][k].x, yJ[h][k].x, fma(yJ[h][k].y, yJ[h][k].y, nJ[h]));
+      }
+    }
+  }
+  nI[0] = wave_sum(nI[0]); nI[1] = wave_sum(nI[1]);
+  nJ[0] = wave_sum(nJ[0]); nJ[1] = wave_sum(nJ[1]);
+  const double floor2 = 1e-26 * g.fro2[b];
+  int cnt = 0;
+  for (int s = 0; s < NB; ++s) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      // sub 0: (I0,J0) and (I1,J1) ; sub 1: (I0,J1) and (I1,J0) -- the two pairs of a sub-step are independent
+      double gx[2] = {0.0, 0.0}, gy[2] = {0.0, 0.0};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int hj = h ^ sub;
+#pragma unroll
+        for (int k = 0; k < MAXRK; ++k) {
+          if (k < nrk && lane + 64 * k < rx) {
+            gx[h] = fma(yI[h][k].x, yJ[hj][k].x, fma(yI[h][k].y, yJ[hj][k].y, gx[h]));
+            gy[h] = fma(yI[h][k].x, yJ[hj][k].y, fma(-yI[h][k].y, yJ[hj][k].x, gy[h]));
+          }
+        }
+      }
+      gx[0] = wave_sum(gx[0]); gy[0] = wave_sum(gy[0]);
+      gx[1] = wave_sum(gx[1]); gy[1] = wave_sum(gy[1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int hj = h ^ sub;
+        double c, sr, si, tg;
+        if (make_rotation(nI[h], nJ[hj], gx[h], gy[h], g.tol2, floor2, c, sr, si, tg)) {
+#pragma unroll
+          for (int k = 0; k < MAXRK; ++k)
+            if (k < nrk) rotate_pair(yI[h][k], yJ[hj][k], c, sr, si);
+          nI[h] -= tg;
+          nJ[hj] += tg;
+          ++cnt;
+        }
+      }
+    }
+    if (s + 1 < NB) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < MAXRK; ++k)
+          if (k < nrk) slots[(w * 2 + h) * rtot + lane + 64 * k] = yJ[h][k];
+      if (lane < 2) sN[w * 2 + lane] = (lane == 0) ? nJ[0] : nJ[1];
+      __syncthreads();
+      const int src = (w + 1) & (NB - 1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < MAXRK; ++k)
+          if (k < nrk) yJ[h][k] = slots[(src * 2 + h) * rtot + lane + 64 * k];
+      nJ[0] = sN[src * 2];
+      nJ[1] = sN[src * 2 + 1];
+      __syncthreads();
+    }
+  }
+  if (lane == 0) sCnt[w] = cnt;
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int q = 0; q < NB; ++q) total += sCnt[q];
+  if (total == 0) {
+    if (tid == 0) st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J] = g.clock;
+    return;
+  }
+  if (tid == 0) { st[2 * I] = g.clock; st[2 * I + 1] = g.clock; st[2 * J] = g.clock; st[2 * J + 1] = g.clock; }
+  const int wj = (w + NB - 1) & (NB - 1);  // after 7 hand-overs wave w holds the J column pair of wave w-1
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    cplx* oI = Yb + (long)(I * 16 + 2 * w + h) * rtot;
+    cplx* oJ = Yb + (long)(J * 16 + 2 * wj + h) * rtot;
+#pragma unroll
+    for (int k = 0; k < MAXRK; ++k) {
+      if (k < nrk) {
+        oI[lane + 64 * k] = yI[h][k];
+        oJ[lane + 64 * k] = yJ[h][k];
+      }
+    }
+  }
+  if (tid == 0) atomicAdd(&g.nrot[b], total);
+}
+
+// ---- split scheme: rotate the X rows and RECORD the rotations, replay them on the W rows ------------
+// The dot products only involve the X rows; the accumulated unitary W just follows.  Splitting the tile at the
+// X / W boundary halves the registers and LDS of the latency-bound kernel (2 workgroups per CU) and turns the W
+// half into a pure FMA stream: one lane per row, all 32 columns of the tile in registers, 256 rotations with
+// wave-uniform parameters and compile-time column indices.
+constexpr int XRK = 4;  // row groups of 64 of the X part (rx_top == 256)
+constexpr int REC_PER_VISIT = 2 * NB * 2 * NB;  // 8 steps x 2 sub-steps x 8 wavefronts x 2 pairs = 256 rotations
+
+__global__ __launch_bounds__(512, 4) void jacobi_cross16x_kernel(JacobiArgs g) {
+  extern __shared__ double smem[];
+  int b = blockIdx.y;
+  if (g.ids) b = g.ids[b];
+  double* rec = g.rec + ((long)b * gridDim.x + blockIdx.x) * (REC_PER_VISIT * 4);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (g.done[b]) { if (tid == 0) rec[3] = 0.0; return; }
+  const int rtot = g.rtot;
+  const int xr = 64 * XRK;
+  cplx* slots = reinterpret_cast<cplx*>(smem);                    // [8][2][xr]
+  double* sN = reinterpret_cast<double*>(slots + 2 * NB * xr);    // [8][2]
+  int* sCnt = reinterpret_cast<int*>(sN + 2 * NB);                // [8]
+  int I, J;
+  pair_of(g.nblk / 2, g.round, blockIdx.x, I, J);
+  int* st = g.stamps + (long)b * STAMP_STRIDE;
+  {
+    const int nzI = st[2 * MAXBLK + 2 * I] | st[2 * MAXBLK + 2 * I + 1];
+    const int nzJ = st[2 * MAXBLK + 2 * J] | st[2 * MAXBLK + 2 * J + 1];
+    const int ver = st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J];
+    const int m1 = max(max(st[2 * I], st[2 * I + 1]), max(st[2 * J], st[2 * J + 1]));
+    if (!nzI || !nzJ || ver > m1) { if (tid == 0) rec[3] = 0.0; return; }
+  }
+  cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
+  cplx yI[2][XRK], yJ[2][XRK];
+  double nI[2] = {0.0, 0.0}, nJ[2] = {0.0, 0.0};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const cplx* cI = Yb + (long)(I * 16 + 2 * w + h) * rtot;
+    const cplx* cJ = Yb + (long)(J * 16 + 2 * w + h) * rtot;
+#pragma unroll
+    for (int k = 0; k < XRK; ++k) {
+      yI[h][k] = cI[lane + 64 * k];
+      yJ[h][k] = cJ[lane + 64 * k];
+      nI[h] = fma(yI[h][k].x, yI[h][k].x, fma(yI[h][k].y, yI[h][k].y, nI[h]));
+      nJ[h] = fma(yJ[h][k].x, yJ[h][k].x, fma(yJ[h][k].y, yJ[h][k].y, nJ[h]));
+    }
+  }
+  nI[0] = wave_sum(nI[0]); nI[1] = wave_sum(nI[1]);
+  nJ[0] = wave_sum(nJ[0]); nJ[1] = wave_sum(nJ[1]);
+  const double floor2 = 1e-26 * g.fro2[b];
+  int cnt = 0;
+  for (int s = 0; s < NB; ++s) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      double gx[2] = {0.0, 0.0}, gy[2] = {0.0, 0.0};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int hj = h ^ sub;
+#pragma unroll
+        for (int k = 0; k < XRK; ++k) {
+          gx[h] = fma(yI[h][k].x, yJ[hj][k].x, fma(yI[h][k].y, yJ[hj][k].y, gx[h]));
+          gy[h] = fma(yI[h][k].x, yJ[hj][k].y, fma(-yI[h][k].y, yJ[hj][k].x, gy[h]));
+        }
+      }
+      gx[0] = wave_sum(gx[0]); gy[0] = wave_sum(gy[0]);
+      gx[1] = wave_sum(gx[1]); gy[1] = wave_sum(gy[1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int hj = h ^ sub;
+        double c = 1.0, sr = 0.0, si = 0.0, tg;
+        if (make_rotation(nI[h], nJ[hj], gx[h], gy[h], g.tol2, floor2, c, sr, si, tg)) {
+#pragma unroll
+          for (int k = 0; k < XRK; ++k) rotate_pair(yI[h][k], yJ[hj][k], c, sr, si);
+          nI[h] -= tg;
+          nJ[hj] += tg;
+          ++cnt;
+        } else {
+          c = 1.0; sr = 0.0; si = 0.0;
+        }
+        if (lane == 0) {
+          double* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + h) * 4);
+          r4[0] = c; r4[1] = sr; r4[2] = si;
+        }
+      }
+    }
+    if (s + 1 < NB) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < XRK; ++k) slots[(w * 2 + h) * xr + lane + 64 * k] = yJ[h][k];
+      if (lane < 2) sN[w * 2 + lane] = (lane == 0) ? nJ[0] : nJ[1];
+      __syncthreads();
+      const int src = (w + 1) & (NB - 1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < XRK; ++k) yJ[h][k] = slots[(src * 2 + h) * xr + lane + 64 * k];
+      nJ[0] = sN[src * 2];
+      nJ[1] = sN[src * 2 + 1];
+      __syncthreads();
+    }
+  }
+  if (lane == 0) sCnt[w] = cnt;
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int q = 0; q < NB; ++q) total += sCnt[q];
+  if (tid == 0) rec[3] = (total > 0) ? 1.0 : 0.0;  // flag slot of the first record: does the W half have work
+  if (total == 0) {
+    if (tid == 0) st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J] = g.clock;
+    return;
+  }
+  if (tid == 0) { st[2 * I] = g.clock; st[2 * I + 1] = g.clock; st[2 * J] = g.clock; st[2 * J + 1] = g.clock; }
+  const int wj = (w + NB - 1) & (NB - 1);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    cplx* oI = Yb + (long)(I * 16 + 2 * w + h) * rtot;
+    cplx* oJ = Yb + (long)(J * 16 + 2 * wj + h) * rtot;
+#pragma unroll
+    for (int k = 0; k < XRK; ++k) {
+      oI[lane + 64 * k] = yI[h][k];
+      oJ[lane + 64 * k] = yJ[h][k];
+    }
+  }
+  if (tid == 0) atomicAdd(&g.nrot[b], total);
+}
+
+// Replay of the recorded rotations on the W rows of the same tile: lane = one row, 32 columns in registers.
+__global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int wrow0) {
+  int b = blockIdx.z;
+  if (g.ids) b = g.ids[b];
+  const double* __restrict__ rec = g.rec + ((long)b * gridDim.x + blockIdx.x) * (REC_PER_VISIT * 4);
+  if (rec[3] == 0.0) return;
+  int I, J;
+  pair_of(g.nblk / 2, g.round, blockIdx.x, I, J);
+  const int rtot = g.rtot;
+  const int row = wrow0 + blockIdx.y * 64 + threadIdx.x;
+  cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0 + row;
+  cplx yI[16], yJ[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    yI[c] = Yb[(long)(I * 16 + c) * rtot];
+    yJ[c] = Yb[(long)(J * 16 + c) * rtot];
+  }
+#pragma unroll
+  for (int s = 0; s < NB; ++s)
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int w = 0; w < NB; ++w)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + h) * 4);
+          const double c = r4[0], sr = r4[1], si = r4[2];
+          // wavefront w rotated its I column 2w+h with the J column that started in wavefront (w+s) mod 8
+          rotate_pair(yI[2 * w + h], yJ[2 * ((w + s) & (NB - 1)) + (h ^ sub)], c, sr, si);
+        }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    Yb[(long)(I * 16 + c) * rtot] = yI[c];
+    Yb[(long)(J * 16 + c) * rtot] = yJ[c];
+  }
 }
 
 // ---- pairs inside one block (LDS resident) -----------------------------------------------------
@@ -572,17 +872,25 @@ void profile_get(double* total_ms, double* total_bytes, long* samples) {
   *samples = g_prof.samples;
 }
 
+long svd_y_elems(int max_dim) {
+  const int p32 = round_up(max_dim, 32);
+  return (long)p32 * round_up(round_up(max_dim, 16) + p32, 64);
+}
+
 size_t svd_workspace_bytes(int max_dim, int B) {
-  const int p = round_up(max_dim, 16);
-  size_t y = (size_t)B * p * round_up(2 * p, 64) * sizeof(cplx);
-  size_t small = (size_t)B * p * (sizeof(double) + sizeof(int)) + (size_t)B * 4 * sizeof(int) + (size_t)B * STAMP_STRIDE * sizeof(int) + 64;
+  const int p = round_up(max_dim, 32);
+  size_t y = (size_t)B * svd_y_elems(max_dim) * sizeof(cplx);
+  size_t small = (size_t)B * 8 * 256 * 4 * sizeof(double) + (size_t)B * p * (sizeof(double) + sizeof(int)) + (size_t)B * 4 * sizeof(int) + (size_t)B * STAMP_STRIDE * sizeof(int) + 64;
   return y + small + 4096;
 }
 
 int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspace& w, hipStream_t s, JacobiShape* shape_out,
                  int* sweeps_out) {
   if (src.nb0 <= 0) return TJM_OK;
-  const int ncols_pad = round_up(src.ncols, 16);
+  static const bool no16 = getenv("TJM_NO_TILE16") != nullptr;
+  int ncols_pad = round_up(src.ncols, 16);
+  const bool tile16 = !no16 && ncols_pad >= 32 && round_up(round_up(src.rx, 16) + round_up(src.ncols, 32), 64) <= 64 * MAXRK;
+  if (tile16) ncols_pad = round_up(src.ncols, 32);
   const int rx_top = round_up(src.rx, 16);
   const int rtot = round_up(rx_top + ncols_pad, 64);
   if (rtot > 64 * MAXRK) return TJM_ERR_NOT_IMPLEMENTED;  // register-resident columns: rx + ncols <= 512
@@ -591,6 +899,8 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   if (!attr_set) {
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     attr_set = true;
   }
   const size_t lds = (size_t)NB * rtot * sizeof(cplx) + NB * sizeof(double) + 16 * sizeof(int);
@@ -618,16 +928,30 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   g.round = 0;
   g.stamps = w.stamps;
   g.clock = 1;
+  g.mode = 0;
   if (g.nblk > MAXBLK) return TJM_ERR_NOT_IMPLEMENTED;
-  const int nrounds = g.nblk - 1;
-  const int npairs = g.nblk / 2;
+  const int nrounds = tile16 ? (g.nblk / 2 - 1) : (g.nblk - 1);
+  const int npairs = tile16 ? g.nblk / 4 : g.nblk / 2;
+  const size_t lds16 = (size_t)2 * NB * rtot * sizeof(cplx) + 2 * NB * sizeof(double) + 16 * sizeof(int);
+  static const bool no_split = getenv("TJM_NO_SPLIT") != nullptr;
+  const bool split16 = tile16 && !no_split && rx_top == 64 * XRK && ncols_pad % 64 == 0 && w.rec != nullptr && src.nb0 <= 65535;
+  const size_t lds16x = (size_t)2 * NB * 64 * XRK * sizeof(cplx) + 2 * NB * sizeof(double) + 16 * sizeof(int);
+  g.rec = w.rec;
+  const double tile_bytes = (tile16 ? 4.0 : 2.0) * NB * rtot * sizeof(cplx) * 2.0;  // columns of the tile, read + written
   const int max_sweeps = 40;
   int sweep = 0;
   int n_live = src.nb0;
   bool converged = false;
   for (; sweep < max_sweeps && !converged; ++sweep) {
     ++g.clock;
+    g.mode = 0;
     hipLaunchKernelGGL(jacobi_diag_kernel, dim3(g.nblk, src.nb0), dim3(256), lds, s, g);
+    if (tile16) {  // pairs between the two 8-column halves of every 16-column block
+      ++g.clock;
+      g.mode = 1;
+      hipLaunchKernelGGL(jacobi_cross_kernel, dim3(g.nblk / 2, src.nb0), dim3(512), lds, s, g);
+      g.mode = 0;
+    }
     for (int r = 0; r < nrounds; ++r) {
       g.round = r;
       ++g.clock;
@@ -642,11 +966,15 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
         }
         TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot], s));
       }
-      hipLaunchKernelGGL(jacobi_cross_kernel, dim3(npairs, src.nb0), dim3(512), lds, s, g);
+      if (split16) {
+        hipLaunchKernelGGL(jacobi_cross16x_kernel, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
+        hipLaunchKernelGGL(jacobi_cross16w_kernel, dim3(npairs, ncols_pad / 64, src.nb0), dim3(64), 0, s, g, rx_top);
+      } else if (tile16) hipLaunchKernelGGL(jacobi_cross16_kernel, dim3(npairs, src.nb0), dim3(512), lds16, s, g);
+      else hipLaunchKernelGGL(jacobi_cross_kernel, dim3(npairs, src.nb0), dim3(512), lds, s, g);
       if (timed) {
         TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot + 1], s));
         // algorithmic bytes: every column of the stacked [X; W] tile of a still-iterating trajectory is read once and written once
-        g_prof.pending.emplace_back(slot, (double)npairs * n_live * 2.0 * (2 * NB) * rtot * sizeof(cplx));
+        g_prof.pending.emplace_back(slot, (double)npairs * n_live * tile_bytes);
       }
     }
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 2 * sizeof(int), s));
