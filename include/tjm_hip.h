@@ -46,7 +46,7 @@ size_t tjm_engine_workspace_bytes(const tjm_engine* e);
 int tjm_engine_bind(tjm_engine* e, void* dev_workspace, size_t bytes, void* hip_stream);
 /* AnalogSimParams knobs of the path (simulation_parameters.py:520-613).
  * trunc_mode: 0 discarded_weight, 1 relative, 2 hard_cutoff, 3 relative_discarded_weight.
- * max_bond <= 0: no cap.  tdvp_mode: 2 = "2site". */
+ * max_bond <= 0: no cap.  tdvp_mode: 2 = "2site", 1 = "1site" (integrators.py:44-158). */
 int tjm_engine_set_params(tjm_engine* e, double dt, double svd_threshold, int32_t trunc_mode, int32_t max_bond,
                           double krylov_tol, int32_t tdvp_mode, int32_t tdvp_sweeps);
 /* host pointer: per site the tensor (phys_out, phys_in, chi_l, chi_r) C-contiguous, sites concatenated. */
@@ -67,8 +67,8 @@ int tjm_engine_export_state(tjm_engine* e, int32_t set, int32_t b, double* host_
 /* host uniforms [B][n_per_traj]: the per-trajectory PCG64 double streams of core/random_utils.py:20-69 */
 int tjm_engine_set_uniforms(tjm_engine* e, const double* host_u, int32_t n_per_traj);
 
-/* apply_unitary_evolution -> tdvp -> sweep_2site (analog/evolution.py:24-51, tdvp/tdvp.py:69-111,
- * tdvp/integrators.py:161-291) on every trajectory of the set. */
+/* apply_unitary_evolution -> tdvp -> sweep_2site | sweep_1site (analog/evolution.py:24-51, tdvp/tdvp.py:69-111,
+ * tdvp/integrators.py:44-291) on every trajectory of the set. */
 int tjm_engine_tdvp(tjm_engine* e, int32_t set);
 /* apply_dissipation (core/methods/dissipation.py:50-183). */
 int tjm_engine_dissipate(tjm_engine* e, int32_t set, double dt);

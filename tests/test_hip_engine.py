@@ -48,12 +48,10 @@ def test_one_tdvp_call_matches_reference_fixture():
     for key in g["cases"]:
         key = str(key)
         L, chi, mode, sweeps = key.split("_")
-        if mode != "2site":
-            continue
         L, chi, sweeps = int(L[1:]), int(chi[3:]), int(sweeps[1:])
         mpo = tensors(g, key + "_mpo")
         e = make_engine(L, chi, 3, mpo)
-        e.set_params(dt=0.1, svd_threshold=1e-9, max_bond_dim=chi, krylov_tol=1e-12, tdvp_sweeps=sweeps)
+        e.set_params(dt=0.1, svd_threshold=1e-9, max_bond_dim=chi, krylov_tol=1e-12, tdvp_sweeps=sweeps, tdvp_mode=mode)
         e.load_state(tensors(g, key + "_in"))
         e.tdvp()
         for b in (0, 2):
@@ -194,3 +192,27 @@ def test_simulator_front_end_runs_in_chunks():
         r, _, _ = o.run_trajectory(t, o.MPSState.product(L, "zeros"), on, op, o.ising_mpo(L, 1.0, 0.5))
         assert np.allclose(res.trajectories[0][t], r[idx[0]], atol=1e-8)
         assert np.allclose(res.trajectories[1][t], r[idx[1]], atol=1e-8)
+
+
+def test_one_site_tdvp_trajectories_match_oracle():
+    """Config-4-like path (tdvp_mode="1site", frozen bonds) on a D=5 Heisenberg MPO with dephasing, against the oracle."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, X as Xg, Z as Zg
+
+    L, chi = 6, 8
+    rng = np.random.default_rng(9)
+    st = o.MPSState.haar(L, chi, rng)
+    st.normalize("B")
+    init = [t.copy() for t in st.tensors]
+    mpo = MPO.heisenberg(L, 1.0, 1.0, 0.5, 0.2)
+    noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.05} for i in range(L)])
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 2)], elapsed_time=0.3, dt=0.05, max_bond_dim=chi,
+                        svd_threshold=1e-12, krylov_tol=1e-12, order=1, sample_timesteps=True, random_seed=11, tdvp_mode="1site")
+    r, d, tb = _run(L, init, noise, p, mpo.tensors, list(range(4)))
+    op = o.Params(observables=[o.Obs(Z, s) for s in range(L)] + [o.Obs(X, 2)], elapsed_time=0.3, dt=0.05, max_bond_dim=chi, svd_threshold=1e-12,
+                  krylov_tol=1e-12, order=1, sample_timesteps=True, random_seed=11, tdvp_mode="1site")
+    on = [o.make_process("pauli_z", [i], 0.05) for i in range(L)]
+    omp = o.heisenberg_mpo(L, 1.0, 1.0, 0.5, 0.2)
+    for t in range(4):
+        ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, omp)
+        assert np.allclose(r[t], ro, atol=1e-8), t
+        assert np.array_equal(d[t], do), t

@@ -161,7 +161,8 @@ def test_svd_split_matches_oracle(lib, capL, capR, dist, qr):
             assert np.allclose(iso @ iso.conj().T, np.eye(k), atol=1e-12)
 
 
-def test_svd_split_ragged_bonds_and_modes(lib):
+@pytest.mark.parametrize("qr", [False, True])
+def test_svd_split_ragged_bonds_and_modes(lib, qr):
     from oracle import tjm_oracle as o
 
     rng = np.random.default_rng(3)
@@ -175,7 +176,7 @@ def test_svd_split_ragged_bonds_and_modes(lib):
         full[:, : chiL[b], :, : chiR[b]] = t
         theta[b] = full.reshape(d * capL, d * capR)
     for mode, name, thr in [(0, "discarded_weight", 0.3), (1, "relative", 0.4), (2, "hard_cutoff", 1.5), (3, "relative_discarded_weight", 0.05)]:
-        left, right, keep, spec, _ = svd_split_gpu(lib, theta, d, capL, capR, capM, 0, mode, thr, 8, 1, chiL, chiR)
+        left, right, keep, spec, _ = svd_split_gpu(lib, theta, d, capL, capR, capM, 0, mode, thr, 8, 1, chiL, chiR, qr=qr)
         for b in range(B):
             t = theta[b].reshape(d, capL, d, capR)[:, : chiL[b], :, : chiR[b]]
             merged = t.transpose(0, 2, 1, 3).reshape(d * d, chiL[b], chiR[b])
@@ -184,6 +185,10 @@ def test_svd_split_ragged_bonds_and_modes(lib):
             assert keep[b] == k, (name, b, keep[b], k)
             got = o.merge_two_site(left[b][:, : chiL[b], :k], right[b][:, :k, : chiR[b]])
             assert np.allclose(got, o.merge_two_site(l_ref, r_ref), atol=1e-11), (name, b)
+            # zero padding stays exactly zero and the active block of the isometric factor is isometric on its own
+            assert np.all(left[b][:, chiL[b]:, :] == 0) and np.all(right[b][:, :, chiR[b]:] == 0), (name, b)
+            iso = left[b][:, : chiL[b], :k].reshape(d * chiL[b], k)
+            assert np.allclose(iso.conj().T @ iso, np.eye(k), atol=1e-12), (name, b)
 
 
 @pytest.mark.parametrize("qr", [False, True])

@@ -2,6 +2,7 @@
 // Host-side control (this class) issues the kernels of tjm_gemm / tjm_kernels / tjm_svd on one
 // HIP stream; all tensors live in a caller-provided device workspace.
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "tjm_kernels.h"
@@ -88,6 +89,7 @@ class Engine {
   cplx* E_ = nullptr;            // [B][chi][chi] moment environment (x2 ping-pong)
   cplx* E2_ = nullptr;
   cplx* M_ = nullptr;            // [L][B][d][d]
+  cplx* Cm_ = nullptr;           // [B][cap][cap] bond matrix of the one-site sweep
   int n_uniform_ = 0;
   std::vector<int> cursor_;      // host-side cursor per trajectory
   std::vector<double> uni_host_;
@@ -106,6 +108,12 @@ class Engine {
   int sweep_2site(StateSet& S, double scale);
   int split(StateSet& S, int i, int dist, int mode, double thr, int maxb, int min_keep, const int* ids, int nb0);
   int set_nloc(StateSet& S, int bl, int br, int P);
+  using ApplyFn = std::function<int(const cplx* x, cplx* y, const int* active)>;
+  int krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2, int n3,
+                  long o0, long o1, long o2, int nb0, const int* ids);
+  int bond_apply(const cplx* x, int cu, int cv, const cplx* Lenv, long l_b0, const cplx* Renv, long r_b0, int D, cplx* y, const int* active);
+  int sweep_1site(StateSet& S, double scale);
+  int qr_site(StateSet& S, int i, bool right);   // A_i = Q C (right) or A_i = C^T Q (left); C into Cm_
   int svd_shift_right(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left_rc(StateSet& S, int i, const int* ids, int nb0);

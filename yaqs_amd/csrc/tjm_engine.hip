@@ -95,7 +95,7 @@ size_t Engine::workspace_bytes() const {
   tot += align_up(qr_workspace_bytes(d * cm, B)) + 4096;
   tot += 2 * align_up((size_t)B * TJM_MAX_PART * sizeof(double));
   tot += 3 * align_up((size_t)B * mmax * sizeof(cplx));
-  tot += 2 * align_up((size_t)B * cm * cm * sizeof(cplx));              // E ping-pong
+  tot += 3 * align_up((size_t)B * cm * cm * sizeof(cplx));              // E ping-pong + bond matrix
   tot += align_up((size_t)L * B * d * d * sizeof(cplx));                // M
   // MPO matrices + operator table
   tot += (size_t)(3 * L) * align_up((size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx));
@@ -172,6 +172,7 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   E_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
   E2_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
   M_ = reinterpret_cast<cplx*>(take((size_t)L * B * d * d * sizeof(cplx)));
+  Cm_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
   const size_t wsz = (size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx);
   W_.resize(L); WenvL_.resize(L); W2_.resize(L);
   for (int i = 0; i < L; ++i) {
@@ -446,10 +447,8 @@ int Engine::env_right(StateSet& S, int i) {
 // ------------------------------------------------------------------------------------------
 // Krylov exponential of a site tensor held in V[:, 0]
 // ------------------------------------------------------------------------------------------
-int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0,
-                        int Dr, const cplx* Wm, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2,
-                        int n3, long o0, long o1, long o2, int nb0, const int* ids) {
-  const int n = P * ca * cb;
+int Engine::krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2, int n3,
+                        long o0, long o1, long o2, int nb0, const int* ids) {
   int rc, nblk = 1;
   ++stat_krylov_calls;
   TJM_HIP_CHECK(hipMemsetAsync(ks.n_active, 0, sizeof(int), stream));
@@ -460,7 +459,7 @@ int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Len
     cplx* vj = V + (long)j * v_ld;
     cplx* w = V + (long)(j + 1) * v_ld;
     cplx* vjm1 = V + (long)(j > 0 ? j - 1 : 0) * v_ld;
-    if ((rc = heff_apply(vj, v_b0, P, ca, cb, Lenv, l_b0, Dl, Renv, r_b0, Dr, Wm, w, v_b0, nb0, ids, ks.status)) != TJM_OK) return rc;
+    if ((rc = apply(vj, w, ks.status)) != TJM_OK) return rc;
     ++stat_matvecs;
     if ((rc = launch_dot_partial(vj, w, v_b0, v_b0, n, part1_, nb0, ids, ks.status, stream, &nblk)) != TJM_OK) return rc;
     if ((rc = launch_lanczos_axpy(w, vj, vjm1, v_b0, n, part1_, part2_, nblk, ks.beta, mmax, j, nb0, ids, ks.status, stream)) != TJM_OK) return rc;
@@ -473,6 +472,38 @@ int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Len
     if (*h_pinned_ == 0) break;
   }
   return launch_krylov_combine(V, v_b0, v_ld, ks, out, out_b0, n0, n1, n2, n3, o0, o1, o2, nb0, ids, stream);
+}
+
+int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0,
+                        int Dr, const cplx* Wm, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2,
+                        int n3, long o0, long o1, long o2, int nb0, const int* ids) {
+  ApplyFn f = [&](const cplx* x, cplx* y, const int* active) {
+    return heff_apply(x, v_b0, P, ca, cb, Lenv, l_b0, Dl, Renv, r_b0, Dr, Wm, y, v_b0, nb0, ids, active);
+  };
+  return krylov_core(f, P * ca * cb, dt_, nloc_dev, out, out_b0, n0, n1, n2, n3, o0, o1, o2, nb0, ids);
+}
+
+// project_bond (primitives.py:207-226): y[p][w] = sum L[u][a][p] C[u][v] R[v][a][w]
+int Engine::bond_apply(const cplx* x, int cu, int cv, const cplx* Lenv, long l_b0, const cplx* Renv, long r_b0, int D, cplx* y,
+                       const int* active) {
+  int rc;
+  {  // T[u][(a,w)] = C[u][v] R[v][(a,w)]
+    GemmDesc g = blank_gemm();
+    g.A = x; g.B = Renv; g.C = T1;
+    g.M = cu; g.K = cv; g.N = D * cv;
+    g.a_rs = cv; g.a_cs = 1; g.b_rs = (long)D * cv; g.b_cs = 1; g.c_rs = (long)D * cv;
+    g.nb0 = B; g.a_b0 = v_b0; g.b_b0 = r_b0; g.c_b0 = t_b0; g.active = active;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  {  // y[p][w] = sum_{(u,a)} L[(u,a)][p] T[(u,a)][w]
+    GemmDesc g = blank_gemm();
+    g.A = Lenv; g.B = T1; g.C = y;
+    g.M = cu; g.K = cu * D; g.N = cv;
+    g.a_rs = 1; g.a_cs = cu; g.b_rs = cv; g.b_cs = 1; g.c_rs = cv;
+    g.nb0 = B; g.a_b0 = l_b0; g.b_b0 = t_b0; g.c_b0 = v_b0; g.active = active;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  return TJM_OK;
 }
 
 // nloc[b] = P * chi[b][bl] * chi[b][br]   (actual local dimension; matrix_exponential.py:94 uses vec.size)
@@ -498,7 +529,7 @@ int Engine::split(StateSet& S, int i, int dist, int mode, double thr, int maxb, 
   s.spectrum = nullptr; s.spec_ld = 0; s.nb0 = nb0; s.ids = ids;
   int sweeps = 0;
   static const bool no_qr = getenv("TJM_NO_QR") != nullptr;
-  const bool use_qr = !no_qr && ids == nullptr && std::min(s.m, s.n) >= 64 && s.m % 16 == 0 && s.n % 16 == 0;
+  const bool use_qr = !no_qr && ids == nullptr && std::min(s.m, s.n) >= 64;
   const int rc = use_qr ? svd_split_qr(s, svdw, qrw, stream, &sweeps) : svd_split(s, svdw, stream, &sweeps);
   ++stat_svds;
   stat_svd_sweeps += sweeps;
@@ -550,11 +581,165 @@ int Engine::sweep_2site(StateSet& S, double scale) {
   return TJM_OK;
 }
 
+// ---- helpers of the one-site sweep ---------------------------------------------------------------------------
+// Z (column-major, bond-major rows) from a site tensor.  right: rows (a, p), columns b ; left: rows (b, p), columns a
+__global__ __launch_bounds__(256) void site_to_z_kernel(const cplx* __restrict__ A, long a_b0, int d, int ca, int cb, int right, cplx* __restrict__ Z,
+                                                       long z_b0) {
+  const int b = blockIdx.y;
+  const cplx* Ab = A + (long)b * a_b0;
+  cplx* Zb = Z + (long)b * z_b0;
+  const long total = (long)d * ca * cb;
+  const int zr = right ? d * ca : d * cb;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(e / zr), rp = (int)(e % zr);
+    const int bond = rp / d, p = rp % d;
+    Zb[e] = right ? Ab[((long)p * ca + bond) * cb + col] : Ab[((long)p * ca + col) * cb + bond];
+  }
+}
+
+// Cm from the R factor (upper triangle of Z).  right: Cm[j][c] = R[j][c] ; left: Cm[c][j] = R[j][c]   (ld = cdim)
+__global__ __launch_bounds__(256) void r_to_bond_kernel(const cplx* __restrict__ Z, long z_b0, int zr, int zc, int right, cplx* __restrict__ Cm,
+                                                       long c_b0, int cdim) {
+  const int b = blockIdx.y;
+  const cplx* Zb = Z + (long)b * z_b0;
+  cplx* Cb = Cm + (long)b * c_b0;
+  const long total = (long)cdim * cdim;
+  const int kmax = zr < zc ? zr : zc;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(e / cdim), c = (int)(e % cdim);
+    const int j = right ? r : c, col = right ? c : r;
+    cplx v{0.0, 0.0};
+    if (j < kmax && col < zc && j <= col) v = Zb[(long)col * zr + j];
+    Cb[e] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void z_identity_kernel(cplx* __restrict__ Z, long z_b0, int zr, int nc) {
+  const int b = blockIdx.y;
+  cplx* Zb = Z + (long)b * z_b0;
+  const long total = (long)zr * nc;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    Zb[e] = cplx{(e / zr == e % zr) ? 1.0 : 0.0, 0.0};
+}
+
+// new bond dimension after the thin QR (np.linalg.qr reduced: k = min(rows, cols)), and vec.size of the bond problem
+__global__ void qr_bond_dims_kernel(int* chi, int stride, int i, int d, int right, int* nloc, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int* c = chi + (long)b * stride;
+  if (right) {
+    const int k = min(d * c[i], c[i + 1]);
+    nloc[b] = k * c[i + 1];
+    c[i + 1] = k;
+  } else {
+    const int k = min(d * c[i + 1], c[i]);
+    nloc[b] = c[i] * k;
+    c[i] = k;
+  }
+}
+
+// A_i = Q C with Q left-isometric (right = true, integrators.py:98-101) or A_i = C^T Q with Q right-isometric
+// (right = false, integrators.py:128-136).  Householder QR; the bond matrix lands in Cm_ ([u][v] order of project_bond).
+int Engine::qr_site(StateSet& S, int i, bool right) {
+  const int ca = cap[i], cb = cap[i + 1];
+  const int zr = right ? d * ca : d * cb;
+  const int zc = right ? cb : ca;
+  const int kmax = std::min(zr, zc);
+  const int cdim = right ? cb : ca;
+  int rc;
+  const long total = (long)d * ca * cb;
+  int gx = (int)((total + 1023) / 1024);
+  if (gx < 1) gx = 1;
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(site_to_z_kernel, dim3(gx, B), dim3(256), 0, stream, S.A[i], a_b0_[i], d, ca, cb, right ? 1 : 0, qrw.Z, qrw.z_b0);
+  if ((rc = qr_factor(qrw, zr, zc, B, nullptr, stream)) != TJM_OK) return rc;
+  {
+    int g2 = (int)(((long)cdim * cdim + 1023) / 1024);
+    if (g2 < 1) g2 = 1;
+    hipLaunchKernelGGL(r_to_bond_kernel, dim3(g2, B), dim3(256), 0, stream, qrw.Z, qrw.z_b0, zr, zc, right ? 1 : 0, Cm_, (long)cdim * cdim, cdim);
+  }
+  hipLaunchKernelGGL(qr_bond_dims_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, S.chi, L + 1, i, d, right ? 1 : 0, nloc_, B);
+  {
+    int g3 = (int)(((long)zr * kmax + 1023) / 1024);
+    if (g3 < 1) g3 = 1;
+    if (g3 > 128) g3 = 128;
+    hipLaunchKernelGGL(z_identity_kernel, dim3(g3, B), dim3(256), 0, stream, qrw.Z, qrw.z_b0, zr, kmax);
+  }
+  if ((rc = qr_apply_q(qrw, zr, zc, qrw.Z, qrw.z_b0, kmax, B, nullptr, stream)) != TJM_OK) return rc;
+  ExtractDesc x;
+  x.out = S.A[i]; x.out_b0 = a_b0_[i]; x.row_off = 0; x.conj = 0; x.scale_mode = 0;
+  if (right) {  // A_i[p][a][k] = Q[(a,p)][k]
+    x.n_k = cb; x.o_k = 1; x.n_r1 = ca; x.n_r0 = d; x.o_r1 = cb; x.o_r0 = (long)ca * cb;
+    rc = qr_scatter(qrw.Z, qrw.z_b0, zr, x, S.chi + i + 1, L + 1, B, nullptr, stream);
+  } else {      // A_i[p][k][r] = Q[(r,p)][k]
+    x.n_k = ca; x.o_k = cb; x.n_r1 = cb; x.n_r0 = d; x.o_r1 = 1; x.o_r0 = (long)ca * cb;
+    rc = qr_scatter(qrw.Z, qrw.z_b0, zr, x, S.chi + i, L + 1, B, nullptr, stream);
+  }
+  TJM_HIP_CHECK(hipGetLastError());
+  return rc;
+}
+
+// One symmetric 1TDVP sweep (integrators.py:44-158); bond dimensions are frozen apart from the thin-QR rule.
+int Engine::sweep_1site(StateSet& S, double scale) {
+  int rc;
+  const double sdt = dt * scale;
+  if ((rc = launch_identity_env(Renv_[L - 1], r_b0_[L - 1], cap[L], Dm[L], B, stream)) != TJM_OK) return rc;
+  for (int i = L - 1; i >= 1; --i)
+    if ((rc = env_right(S, i)) != TJM_OK) return rc;
+  if ((rc = launch_identity_env(Lenv_[0], l_b0_[0], cap[0], Dm[0], B, stream)) != TJM_OK) return rc;
+  for (int i = 0; i < L - 1; ++i) {
+    const int cb = cap[i + 1], cc = cap[i + 2];
+    if ((rc = one_site_update(S, i, 0.5 * sdt)) != TJM_OK) return rc;
+    if ((rc = qr_site(S, i, true)) != TJM_OK) return rc;
+    if ((rc = env_left(S, i)) != TJM_OK) return rc;
+    // bond matrix C[u][v] (cb x cb padded) evolves backwards under project_bond(L_{i+1}, R_i)
+    TJM_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)v_b0 * sizeof(cplx), Cm_, (size_t)cb * cb * sizeof(cplx), (size_t)cb * cb * sizeof(cplx), B,
+                                   hipMemcpyDeviceToDevice, stream));
+    ApplyFn f = [&](const cplx* x, cplx* y, const int* active) {
+      return bond_apply(x, cb, cb, Lenv_[i + 1], l_b0_[i + 1], Renv_[i], r_b0_[i], Dm[i + 1], y, active);
+    };
+    if ((rc = krylov_core(f, cb * cb, -0.5 * sdt, nloc_, Cm_, (long)cb * cb, 1, 1, cb, cb, 0, 0, cb, B, nullptr)) != TJM_OK) return rc;
+    GemmDesc g = blank_gemm();  // T1[p][l][r] = C[l][x] A_{i+1}[p][x][r]
+    g.A = Cm_; g.B = S.A[i + 1]; g.C = T1;
+    g.M = cb; g.K = cb; g.N = cc;
+    g.a_rs = cb; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = cc;
+    g.nb0 = B; g.nb1 = d; g.a_b0 = (long)cb * cb; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cb * cc; g.c_b0 = t_b0; g.c_b1 = (long)cb * cc;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+    if ((rc = copy_back(S.A[i + 1], a_b0_[i + 1], T1, t_b0, a_b0_[i + 1], nullptr, B)) != TJM_OK) return rc;
+  }
+  if ((rc = one_site_update(S, L - 1, sdt)) != TJM_OK) return rc;
+  for (int i = L - 1; i >= 1; --i) {
+    const int cz = cap[i - 1], ca = cap[i];
+    if ((rc = qr_site(S, i, false)) != TJM_OK) return rc;
+    if ((rc = env_right(S, i)) != TJM_OK) return rc;
+    TJM_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)v_b0 * sizeof(cplx), Cm_, (size_t)ca * ca * sizeof(cplx), (size_t)ca * ca * sizeof(cplx), B,
+                                   hipMemcpyDeviceToDevice, stream));
+    ApplyFn f = [&](const cplx* x, cplx* y, const int* active) {
+      return bond_apply(x, ca, ca, Lenv_[i], l_b0_[i], Renv_[i - 1], r_b0_[i - 1], Dm[i], y, active);
+    };
+    if ((rc = krylov_core(f, ca * ca, -0.5 * sdt, nloc_, Cm_, (long)ca * ca, 1, 1, ca, ca, 0, 0, ca, B, nullptr)) != TJM_OK) return rc;
+    GemmDesc g = blank_gemm();  // T1[(p,l)][r] = A_{i-1}[(p,l)][x] C^T[x][r]
+    g.A = S.A[i - 1]; g.B = Cm_; g.C = T1;
+    g.M = d * cz; g.K = ca; g.N = ca;
+    g.a_rs = ca; g.a_cs = 1; g.b_rs = ca; g.b_cs = 1; g.c_rs = ca;
+    g.nb0 = B; g.a_b0 = a_b0_[i - 1]; g.b_b0 = (long)ca * ca; g.c_b0 = t_b0;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+    if ((rc = copy_back(S.A[i - 1], a_b0_[i - 1], T1, t_b0, a_b0_[i - 1], nullptr, B)) != TJM_OK) return rc;
+    if ((rc = one_site_update(S, i - 1, 0.5 * sdt)) != TJM_OK) return rc;
+  }
+  return TJM_OK;
+}
+
 int Engine::tdvp(int set) {
   if (!bound_) return TJM_ERR_STATE;
-  if (tdvp_mode != 2) return TJM_ERR_NOT_IMPLEMENTED;
+  if (tdvp_mode != 2 && tdvp_mode != 1) return TJM_ERR_NOT_IMPLEMENTED;
   StateSet& S = sets[set];
   int rc;
+  if (tdvp_mode == 1) {
+    for (int sw = 0; sw < tdvp_sweeps; ++sw)
+      if ((rc = sweep_1site(S, 1.0 / tdvp_sweeps)) != TJM_OK) return rc;
+    return TJM_OK;
+  }
   // right environments (primitives.py:139-174), left boundary (integrators.py:186-193)
   if ((rc = launch_identity_env(Renv_[L - 1], r_b0_[L - 1], cap[L], Dm[L], B, stream)) != TJM_OK) return rc;
   for (int i = L - 1; i >= 1; --i)

@@ -156,7 +156,7 @@ struct QrWorkspace {
   int w_ld;
 };
 size_t qr_workspace_bytes(int max_dim, int B);
-int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s);
+int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s);
 int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hipStream_t s);
 int qr_apply_q(const QrWorkspace& q, int zr, int zc, cplx* C, long c_b0, int nc, int nb0, const int* ids, hipStream_t s);
 int qr_scatter(const cplx* in, long in_b0, int ld, const ExtractDesc& x, const int* chi_keep, int chi_stride, int nb0, const int* ids,

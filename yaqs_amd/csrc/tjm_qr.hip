@@ -215,12 +215,12 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
   const int li = lane & 15, lk = lane >> 4;
   {  // W1[i][c] = sum_r conj(V[i][r]) C[c][r]   (K = rows, split over the four wavefronts)
     d4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
-    const int nsteps = zr >> 2;
+    const int nsteps = (zr + 3) >> 2;
     const bool cvalid = li < ncw;
     for (int s = wave; s < nsteps; s += 4) {
       const int r = 4 * s + lk;
-      const cplx v = Vp[(long)li * zr + r];
-      const cplx x = cvalid ? Cb[(long)(c0 + li) * zr + r] : cplx{0.0, 0.0};
+      const cplx v = (r < zr) ? Vp[(long)li * zr + r] : cplx{0.0, 0.0};
+      const cplx x = (cvalid && r < zr) ? Cb[(long)(c0 + li) * zr + r] : cplx{0.0, 0.0};
       P = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.x, P, 0, 0, 0);
       Q = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, x.y, Q, 0, 0, 0);
       S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.y, S1, 0, 0, 0);
@@ -258,13 +258,13 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
       wr[kk] = t.x;
       wi[kk] = t.y;
     }
-    const int nchunks = zr >> 4;
+    const int nchunks = (zr + 15) >> 4;
     for (int ch = wave; ch < nchunks; ch += 4) {
       const int r0 = ch * 16;
       d4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const cplx v = Vp[(long)(4 * kk + lk) * zr + r0 + li];  // A[row = li][i = 4kk + lk]
+        const cplx v = (r0 + li < zr) ? Vp[(long)(4 * kk + lk) * zr + r0 + li] : cplx{0.0, 0.0};  // A[row = li][i = 4kk + lk]
         P = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, wr[kk], P, 0, 0, 0);
         Q = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, wi[kk], Q, 0, 0, 0);
         S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, wi[kk], S1, 0, 0, 0);
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
       if (li < ncw) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          if (r0 + lk + 4 * q >= zr) continue;
           const long idx = (long)(c0 + li) * zr + r0 + lk + 4 * q;  // D: row = lk + 4q, column = li
           cplx x = Cb[idx];
           x.x -= P[q] - Q[q];
@@ -284,22 +285,28 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
   }
 }
 
-// out(col-major zr x zc) from theta (row-major m x n): dist 0 -> Z = theta ; dist 1 -> Z = theta^H
-__global__ __launch_bounds__(256) void qr_prepare_kernel(const cplx* __restrict__ theta, long th_b0, int m, int n, int dist, cplx* __restrict__ Z,
+// Z (column-major zr x zc) from theta (row-major m x n, rows (s,a), columns (t,c)):
+//   dist 0 -> Z = theta   with rows re-ordered bond-major:  r' = a * d + s
+//   dist 1 -> Z = theta^H with rows re-ordered bond-major:  r' = c * d + t
+// Bond-major rows make the zero padding (bond index >= actual bond dimension) a SUFFIX of the row range, so every
+// Householder reflector stays inside the active rows and the padded rows of Q stay exactly untouched.
+__global__ __launch_bounds__(256) void qr_prepare_kernel(const cplx* __restrict__ theta, long th_b0, int m, int n, int dist, int d, cplx* __restrict__ Z,
                                                         long z_b0, const int* ids) {
   int b = blockIdx.y;
   if (ids) b = ids[b];
   const cplx* th = theta + (long)b * th_b0;
   cplx* Zb = Z + (long)b * z_b0;
   const long total = (long)m * n;
+  const int capL = m / d, capR = n / d;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     if (dist == 0) {
-      // Z(r, c) = theta[r][c], column-major: index c * m + r ; iterate e over (c, r) with r fastest
-      const long c = e / m, r = e % m;
-      Zb[e] = th[r * n + c];
+      const long c = e / m, rp = e % m;            // Z(rp, c), rp = a * d + s
+      const int a = (int)(rp / d), sph = (int)(rp % d);
+      Zb[e] = th[((long)sph * capL + a) * n + c];
     } else {
-      // Z = theta^H (n x m), column-major: Z(j, i) at i * n + j = conj(theta[i][j]) : same memory order as theta
-      cplx v = th[e];
+      const long i = e / n, rp = e % n;            // Z(rp, i) = conj(theta[i][(t,c)]), rp = c * d + t
+      const int cc = (int)(rp / d), t = (int)(rp % d);
+      cplx v = th[i * n + (long)t * capR + cc];
       v.y = -v.y;
       Zb[e] = v;
     }
@@ -354,11 +361,11 @@ size_t qr_workspace_bytes(int max_dim, int B) {
   return (size_t)B * (mat + vb + (size_t)(max_dim / PW + 1) * PW * PW * sizeof(cplx) + 2 * (size_t)PW * max_dim * sizeof(cplx)) + 16384;
 }
 
-int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s) {
+int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s) {
   const long total = (long)m * n;
   int gx = (int)((total + 1023) / 1024);
   if (gx > 128) gx = 128;
-  hipLaunchKernelGGL(qr_prepare_kernel, dim3(gx, nb0), dim3(256), 0, s, theta, th_b0, m, n, dist, q.Z, q.z_b0, ids);
+  hipLaunchKernelGGL(qr_prepare_kernel, dim3(gx, nb0), dim3(256), 0, s, theta, th_b0, m, n, dist, d, q.Z, q.z_b0, ids);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
@@ -376,7 +383,6 @@ int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hip
   for (int k0 = 0; k0 < kmax; k0 += PW, ++panel) {
     const int pw = (kmax - k0 < PW) ? kmax - k0 : PW;
     const size_t lds = (size_t)(PW * (zr - k0) + 2 * PW * PW + PW) * sizeof(cplx) + PW * sizeof(double) + 64;
-    if (zr % 16 != 0) return TJM_ERR_NOT_IMPLEMENTED;
     hipLaunchKernelGGL(qr_panel_kernel, dim3(nb0), dim3(64), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
     TJM_HIP_CHECK(hipGetLastError());
     const int col0 = k0 + pw;

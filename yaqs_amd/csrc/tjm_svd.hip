@@ -1053,10 +1053,9 @@ int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace
   if (d.ld_theta != d.n) return TJM_ERR_ARG;
   const int zr = (d.distribution == 0) ? d.m : d.n;
   const int zc = (d.distribution == 0) ? d.n : d.m;
-  if (zr % 16 != 0 || zr < 16) return svd_split(d, w, s, sweeps_out);  // the MFMA block reflector works on 16-row chunks
   const int kmax = zr < zc ? zr : zc;
   int rc;
-  if ((rc = qr_prepare(d.theta, d.theta_b0, d.m, d.n, d.distribution, q, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  if ((rc = qr_prepare(d.theta, d.theta_b0, d.m, d.n, d.distribution, d.d, q, d.nb0, d.ids, s)) != TJM_OK) return rc;
   if ((rc = qr_factor(q, zr, zc, d.nb0, d.ids, s)) != TJM_OK) return rc;
   JacobiSource src;  // X = R^H : X[r][c] = conj(R[c][r]) , R[i][j] = Z[j * zr + i] for i <= j
   src.src = q.Z; src.src_b0 = q.z_b0; src.rx = zc; src.ncols = kmax; src.conj = 1; src.tri = 1;
@@ -1078,14 +1077,16 @@ int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace
   ExtractDesc xi, xx;
   if (d.distribution == 0) {
     // left[(s,a)][k] = (Q W)[(s,a)][k] ; right[t][k][c] = conj(Xfinal[(t,c)][k])
-    xi.out = d.left; xi.out_b0 = d.left_b0; xi.n_k = d.capM; xi.o_k = 1; xi.n_r1 = 1; xi.n_r0 = d.d * d.capL; xi.o_r1 = 0; xi.o_r0 = d.capM;
+    xi.out = d.left; xi.out_b0 = d.left_b0; xi.n_k = d.capM; xi.o_k = 1; xi.n_r1 = d.capL; xi.n_r0 = d.d; xi.o_r1 = d.capM;
+    xi.o_r0 = (long)d.capL * d.capM;  // rows of Q W are bond-major (a, s)
     xi.row_off = 0; xi.conj = 0; xi.scale_mode = 0;
     xx.out = d.right; xx.out_b0 = d.right_b0; xx.n_k = d.capM; xx.o_k = d.capR; xx.n_r1 = d.d; xx.n_r0 = d.capR;
     xx.o_r1 = (long)d.capM * d.capR; xx.o_r0 = 1; xx.row_off = 0; xx.conj = 1; xx.scale_mode = 0;
   } else {
     // right[t][k][c] = conj((Q W)[(t,c)][k]) ; left[(s,a)][k] = Xfinal[(s,a)][k]
-    xi.out = d.right; xi.out_b0 = d.right_b0; xi.n_k = d.capM; xi.o_k = d.capR; xi.n_r1 = d.d; xi.n_r0 = d.capR;
-    xi.o_r1 = (long)d.capM * d.capR; xi.o_r0 = 1; xi.row_off = 0; xi.conj = 1; xi.scale_mode = 0;
+    xi.out = d.right; xi.out_b0 = d.right_b0; xi.n_k = d.capM; xi.o_k = d.capR; xi.n_r1 = d.capR; xi.n_r0 = d.d;
+    xi.o_r1 = 1; xi.o_r0 = (long)d.capM * d.capR;  // rows of Q W are bond-major (c, t)
+    xi.row_off = 0; xi.conj = 1; xi.scale_mode = 0;
     xx.out = d.left; xx.out_b0 = d.left_b0; xx.n_k = d.capM; xx.o_k = 1; xx.n_r1 = 1; xx.n_r0 = d.d * d.capL; xx.o_r1 = 0; xx.o_r0 = d.capM;
     xx.row_off = 0; xx.conj = 0; xx.scale_mode = 0;
   }

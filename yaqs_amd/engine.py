@@ -62,10 +62,11 @@ class BatchEngine:
     # -- configuration ---------------------------------------------------------------
     def set_params(self, *, dt, svd_threshold, trunc_mode="discarded_weight", max_bond_dim=None, krylov_tol=1e-4, tdvp_mode="2site",
                    tdvp_sweeps=1):
-        if tdvp_mode != "2site":
+        if tdvp_mode not in ("1site", "2site"):
             raise NotImplementedError(f"tdvp_mode {tdvp_mode!r} is not built yet in the HIP path")
         _lib.check(self.lib.tjm_engine_set_params(self.h, float(dt), float(svd_threshold), TRUNC_MODES[trunc_mode],
-                                                  -1 if max_bond_dim is None else int(max_bond_dim), float(krylov_tol), 2, int(tdvp_sweeps)),
+                                                  -1 if max_bond_dim is None else int(max_bond_dim), float(krylov_tol),
+                                                  1 if tdvp_mode == "1site" else 2, int(tdvp_sweeps)),
                    "set_params")
 
     def set_noise(self, processes, is_pauli_flags):

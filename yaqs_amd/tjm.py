@@ -50,7 +50,7 @@ class TrajectoryBatch:
         self.e = engine
         self.p = params
         self.noise = noise if (noise is not None and noise.processes) else None
-        if params.tdvp_mode != "2site":
+        if params.tdvp_mode not in ("1site", "2site"):
             raise NotImplementedError(f"tdvp_mode {params.tdvp_mode!r} is not built yet in the HIP path")
         for obs in params.observables:
             if isinstance(obs.sites, (list, tuple)) and len(obs.sites) != 1:
