@@ -78,6 +78,9 @@ int tjm_engine_stochastic(tjm_engine* e, int32_t set, double dt, int32_t* jumped
  * <O_site> = sum_pq O[p][q] M[p][q].  Replaces MPS.evaluate_observables / local_expect
  * (mps.py:961-1047, 1178-1234) for one-site observables. */
 int tjm_engine_site_moments(tjm_engine* e, int32_t set, double* host_M);
+/* Same plus the nearest-neighbour two-site moments M2[site][b][(s,t)][(s',t')] for two-site observables
+ * (mps.py:999-1047) and adjacent two-site jump weights (stochastic_process.py:53-83). */
+int tjm_engine_site_moments2(tjm_engine* e, int32_t set, double* host_M, double* host_M2);
 int tjm_engine_bond_dims(tjm_engine* e, int32_t set, int32_t* host_chi); /* [B][L+1]; record_diagnostics mps.py:549-602 */
 int tjm_engine_site0_normsq(tjm_engine* e, int32_t set, double* host_out); /* MPS.norm(0), mps.py:1539-1565 */
 /* counters: matvecs, krylov calls, svds, svd sweeps, two-site updates */

@@ -62,10 +62,14 @@ def test_one_tdvp_call_matches_reference_fixture():
 
 
 def _noise_sets(L):
+    kx = np.kron(X, X)
     return {
         "pauli": [o.make_process(n, [i], 0.1 + 0.01 * i) for i in range(L) for n in ("pauli_z", "pauli_x")],
         "lowering": [o.make_process("lowering", [i], 0.2) for i in range(L)],
         "mixed": [o.make_process(n, [i], 0.1) for i in range(L) for n in ("lowering", "pauli_z")],
+        "twosite": [o.make_process("pauli_z", [i], 0.05) for i in range(L)]
+        + [o.make_process("crosstalk_xx", [i, i + 1], 0.07, matrix=kx) for i in range(L - 1)]
+        + [o.make_process("longrange_crosstalk_zz", [0, 3], 0.03, factors=(Z, Z))],
     }
 
 
@@ -100,9 +104,9 @@ def test_dissipation_and_jump_step_match_reference_fixture():
 
 
 def test_unsupported_noise_raises_not_implemented():
+    # non-Pauli long-range processes raise NotImplementedError in the reference too (dissipation.py:136-138)
     L = 6
-    kx = np.kron(X, X)
-    procs = [o.make_process("crosstalk_xx", [i, i + 1], 0.07, matrix=kx * 2.0) for i in range(L - 1)]
+    procs = [o.make_process("lr", [0, 3], 0.07, factors=(2.0 * X, X))]
     e = make_engine(L, 4, 1, o.ising_mpo(L, 1.0, 0.5))
     e.set_params(dt=0.1, svd_threshold=1e-10, max_bond_dim=4)
     e.set_noise(procs, [False] * len(procs))
@@ -214,5 +218,35 @@ def test_one_site_tdvp_trajectories_match_oracle():
     omp = o.heisenberg_mpo(L, 1.0, 1.0, 0.5, 0.2)
     for t in range(4):
         ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, omp)
+        assert np.allclose(r[t], ro, atol=1e-8), t
+        assert np.array_equal(d[t], do), t
+
+
+def test_adjacent_two_site_noise_and_two_site_observables_match_oracle():
+    """Non-Pauli adjacent two-site processes (merged expm / jump + truncated split) and nearest-neighbour observables."""
+    from yaqs_amd.api import AnalogSimParams, MPO, NoiseModel, Observable, Z as Zg
+
+    L, chi = 6, 8
+    low = o.JUMP_OPS["lowering"]
+    two = np.kron(low, Z) + 0.3 * np.kron(X, low)          # non-Pauli, non-product two-site operator
+    zz = np.kron(Z, Z)
+    xz = np.kron(X, Z)
+    procs = [{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)] + \
+            [{"name": "custom2", "sites": [i, i + 1], "strength": 0.4, "matrix": two} for i in range(0, L - 1, 2)] + \
+            [{"name": "crosstalk_zy", "sites": [1, 2], "strength": 0.2}]
+    noise = NoiseModel(procs)
+    obs = [Observable(Zg(), 0), Observable(zz, [2, 3]), Observable(xz, [0, 1]), Observable(Zg(), 5), Observable(zz, [4, 5])]
+    p = AnalogSimParams(observables=obs, elapsed_time=0.4, dt=0.1, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-12, order=2,
+                        sample_timesteps=True, random_seed=3)
+    init = o.MPSState.product(L, "x+").tensors
+    mpo = MPO.ising(L, 1.0, 0.5)
+    r, d, tb = _run(L, init, noise, p, mpo.tensors, list(range(6)))
+    assert np.array(tb.jump_log).sum() > 0  # the jump branch (incl. adjacent pairs) is exercised
+    oobs = [o.Obs(Z, 0), o.Obs(zz, [2, 3]), o.Obs(xz, [0, 1]), o.Obs(Z, 5), o.Obs(zz, [4, 5])]
+    op = o.Params(observables=oobs, elapsed_time=0.4, dt=0.1, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-12, order=2,
+                  sample_timesteps=True, random_seed=3)
+    on = [o.make_process(q["name"], q["sites"], q["strength"], matrix=q.get("matrix"), factors=q.get("factors")) for q in noise.processes]
+    for t in range(6):
+        ro, do, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), on, op, o.ising_mpo(L, 1.0, 0.5))
         assert np.allclose(r[t], ro, atol=1e-8), t
         assert np.array_equal(d[t], do), t

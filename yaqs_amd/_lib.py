@@ -63,6 +63,7 @@ EXPORTS = {
     "tjm_engine_dissipate": (C.c_int, [V, I, D]),
     "tjm_engine_stochastic": (C.c_int, [V, I, D, V, V]),
     "tjm_engine_site_moments": (C.c_int, [V, I, V]),
+    "tjm_engine_site_moments2": (C.c_int, [V, I, V, V]),
     "tjm_engine_bond_dims": (C.c_int, [V, I, V]),
     "tjm_engine_site0_normsq": (C.c_int, [V, I, V]),
     "tjm_engine_stats": (C.c_int, [V, V]),

@@ -101,6 +101,9 @@ int tjm_engine_stochastic(tjm_engine* e, int32_t set, double dt, int32_t* jumped
   return (e && set >= 0 && set < 2) ? e->impl.stochastic(set, dt, jumped, dp) : TJM_ERR_ARG;
 }
 int tjm_engine_site_moments(tjm_engine* e, int32_t set, double* M) { return (e && M) ? e->impl.site_moments(set, M) : TJM_ERR_ARG; }
+int tjm_engine_site_moments2(tjm_engine* e, int32_t set, double* M, double* M2) {
+  return (e && M && M2) ? e->impl.site_moments(set, M, M2) : TJM_ERR_ARG;
+}
 int tjm_engine_bond_dims(tjm_engine* e, int32_t set, int32_t* chi) { return (e && chi) ? e->impl.bond_dims(set, chi) : TJM_ERR_ARG; }
 int tjm_engine_site0_normsq(tjm_engine* e, int32_t set, double* out) { return (e && out) ? e->impl.site_normsq0(set, out) : TJM_ERR_ARG; }
 int tjm_engine_stats(const tjm_engine* e, int64_t* o) {

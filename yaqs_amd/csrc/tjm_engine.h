@@ -51,7 +51,7 @@ class Engine {
   int tdvp(int set);
   int dissipate(int set, double dt_);
   int stochastic(int set, double dt_, int* host_jumped /*B or null*/, double* host_dp /*B or null*/);
-  int site_moments(int set, double* host_M /*[B][L][d][d] complex*/);
+  int site_moments(int set, double* host_M /*[L][B][d][d] complex*/, double* host_M2 = nullptr /*[L-1][B][d^2][d^2] or null*/);
   int bond_dims(int set, int* host_chi /*[B][L+1]*/);
   int site_normsq0(int set, double* host_out);
 
@@ -90,6 +90,7 @@ class Engine {
   cplx* E2_ = nullptr;
   cplx* M_ = nullptr;            // [L][B][d][d]
   cplx* Cm_ = nullptr;           // [B][cap][cap] bond matrix of the one-site sweep
+  cplx* M2_ = nullptr;           // [L-1][B][d^2][d^2] two-site moments
   int n_uniform_ = 0;
   std::vector<int> cursor_;      // host-side cursor per trajectory
   std::vector<double> uni_host_;
@@ -114,6 +115,7 @@ class Engine {
   int bond_apply(const cplx* x, int cu, int cv, const cplx* Lenv, long l_b0, const cplx* Renv, long r_b0, int D, cplx* y, const int* active);
   int sweep_1site(StateSet& S, double scale);
   int qr_site(StateSet& S, int i, bool right);   // A_i = Q C (right) or A_i = C^T Q (left); C into Cm_
+  int two_site_op(StateSet& S, int i, const cplx* dev_ops, const int* op_index, const int* ids, int nb0);
   int svd_shift_right(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left_rc(StateSet& S, int i, const int* ids, int nb0);

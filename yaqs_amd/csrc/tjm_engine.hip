@@ -97,6 +97,7 @@ size_t Engine::workspace_bytes() const {
   tot += 3 * align_up((size_t)B * mmax * sizeof(cplx));
   tot += 3 * align_up((size_t)B * cm * cm * sizeof(cplx));              // E ping-pong + bond matrix
   tot += align_up((size_t)L * B * d * d * sizeof(cplx));                // M
+  tot += align_up((size_t)L * B * d * d * d * d * sizeof(cplx));        // M2
   // MPO matrices + operator table
   tot += (size_t)(3 * L) * align_up((size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx));
   tot += align_up((size_t)(L + 64) * 16 * sizeof(cplx));
@@ -173,6 +174,7 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   E2_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
   M_ = reinterpret_cast<cplx*>(take((size_t)L * B * d * d * sizeof(cplx)));
   Cm_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
+  M2_ = reinterpret_cast<cplx*>(take((size_t)L * B * d * d * d * d * sizeof(cplx)));
   const size_t wsz = (size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx);
   W_.resize(L); WenvL_.resize(L); W2_.resize(L);
   for (int i = 0; i < L; ++i) {
@@ -927,12 +929,30 @@ int Engine::dissipate(int set, double dt_) {
       }
     }
     if (!one_by_site_[i].empty() && !need_matrix) expo += gen[0].x;
+    bool need_matrix2 = false;
+    cplx gen2[16];
+    for (int q = 0; q < 16; ++q) gen2[q] = cplx{0.0, 0.0};
     if (i != 0) {
+      double adj_pauli = 0.0;
       for (int k : two_by_right_[i]) {
         const NoiseProc& p = noise_[k];
-        if (!p.pauli) return TJM_ERR_NOT_IMPLEMENTED;  // non-Pauli two-site dissipators: next round
-        expo += p.gamma;
+        const bool longrange = (p.site1 - p.site0) > 1;
+        if (longrange) {
+          if (!p.pauli) return TJM_ERR_NOT_IMPLEMENTED;  // dissipation.py:136-138
+          expo += p.gamma;
+        } else if (p.pauli) {
+          adj_pauli += p.gamma;
+          for (int q = 0; q < 4; ++q) gen2[q * 4 + q].x += p.gamma;
+        } else {
+          need_matrix2 = true;
+          for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) {
+            cplx acc{0.0, 0.0};
+            for (int r = 0; r < 4; ++r) cfma(acc, cconj(p.mat[r * 4 + a]), p.mat[r * 4 + c]);
+            gen2[a * 4 + c] = cadd(gen2[a * 4 + c], cscale(acc, p.gamma));
+          }
+        }
       }
+      if (!need_matrix2) expo += adj_pauli;  // all adjacent processes Pauli: scalar (dissipation.py:156-157)
     }
     if (need_matrix) {
       cplx arg[4], m[4];
@@ -945,6 +965,14 @@ int Engine::dissipate(int set, double dt_) {
     if (expo != 0.0) {
       hipLaunchKernelGGL(fill_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, scal_, std::exp(-0.5 * dt_ * expo), B);
       if ((rc = launch_scale(S.A[i], a_b0_[i], a_b0_[i], scal_, B, nullptr, nullptr, stream)) != TJM_OK) return rc;
+    }
+    if (need_matrix2) {  // merged pair (i-1, i): expm(-dt/2 sum gamma L^dag L), truncated split to the right
+      cplx arg[16], m2[16];
+      for (int q = 0; q < 16; ++q) arg[q] = cscale(gen2[q], -0.5 * dt_);
+      small_expm(arg, 4, m2);
+      TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)L * 16, m2, sizeof(m2), hipMemcpyHostToDevice, stream));
+      TJM_HIP_CHECK(hipStreamSynchronize(stream));
+      if ((rc = two_site_op(S, i - 1, ops_ + (size_t)L * 16, nullptr, nullptr, B)) != TJM_OK) return rc;
     }
     if (i != 0)
       if ((rc = svd_shift_left(S, i, nullptr, B)) != TJM_OK) return rc;
@@ -961,7 +989,7 @@ int Engine::site_normsq0(int set, double* host_out) {
   return TJM_OK;
 }
 
-int Engine::site_moments(int set, double* host_M) {
+int Engine::site_moments(int set, double* host_M, double* host_M2) {
   if (!bound_) return TJM_ERR_STATE;
   StateSet& S = sets[set];
   int rc;
@@ -984,6 +1012,21 @@ int Engine::site_moments(int set, double* host_M) {
       if ((rc = gemm(g)) != TJM_OK) return rc;
     }
     if ((rc = launch_phys_overlap(S.A[i], T1, a_b0_[i], t_b0, d, (long)ca * cb, M_ + (size_t)i * B * d * d, B, nullptr, stream)) != TJM_OK) return rc;
+    if (host_M2 && i + 1 < L) {
+      // two-site moments M2[(s,t),(s',t')] = <theta_st | E | theta_s't'>: theta = A_i A_{i+1} into V[0], E theta = T A_{i+1} into V[1]
+      const int cc = cap[i + 2];
+      if ((rc = merge_tensor_layout(S, i, V, v_b0, nullptr, B)) != TJM_OK) return rc;
+      GemmDesc g = blank_gemm();
+      g.A = T1; g.B = S.A[i + 1]; g.C = V + v_ld;
+      g.M = ca; g.K = cb; g.N = cc;
+      g.a_rs = cb; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = cc;
+      g.nb0 = B; g.nb1 = d; g.nb2 = d;
+      g.a_b0 = t_b0; g.a_b1 = (long)ca * cb; g.b_b0 = a_b0_[i + 1]; g.b_b2 = (long)cb * cc;
+      g.c_b0 = v_b0; g.c_b1 = (long)d * ca * cc; g.c_b2 = (long)ca * cc;
+      if ((rc = gemm(g)) != TJM_OK) return rc;
+      if ((rc = launch_phys_overlap(V, V + v_ld, v_b0, v_b0, d * d, (long)ca * cc, M2_ + (size_t)i * B * d * d * d * d, B, nullptr, stream)) != TJM_OK)
+        return rc;
+    }
     if (i + 1 < L) {  // E'[b][b'] = sum_{(p,a)} conj(A_i[(p,a),b]) T[(p,a),b']
       GemmDesc g = blank_gemm();
       g.A = S.A[i]; g.B = T1; g.C = En;
@@ -995,8 +1038,51 @@ int Engine::site_moments(int set, double* host_M) {
     }
   }
   TJM_HIP_CHECK(hipMemcpyAsync(host_M, M_, (size_t)L * B * d * d * sizeof(cplx), hipMemcpyDeviceToHost, stream));
+  if (host_M2)
+    TJM_HIP_CHECK(hipMemcpyAsync(host_M2, M2_, (size_t)(L - 1) * B * d * d * d * d * sizeof(cplx), hipMemcpyDeviceToHost, stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
   return TJM_OK;
+}
+
+// theta[(s,a),(t,c)] <- sum_{s',t'} O_b[(s,t),(s',t')] theta[(s',a),(t',c)]   (two-site operator on the merged pair)
+__global__ __launch_bounds__(256) void apply_phys2_kernel(cplx* __restrict__ theta, long th_b0, int d, int ca, int cc, const cplx* ops,
+                                                         const int* op_index, const int* ids) {
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  const int oi = op_index ? op_index[b] : 0;
+  if (oi < 0) return;
+  const int P = d * d;
+  const cplx* O = ops + (long)oi * P * P;
+  cplx* tb = theta + (long)b * th_b0;
+  const long n = (long)d * cc;
+  const long total = (long)ca * cc;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(e / cc), c = (int)(e % cc);
+    cplx v[16], y[16];
+    for (int sp = 0; sp < d; ++sp)
+      for (int tp = 0; tp < d; ++tp) v[sp * d + tp] = tb[((long)sp * ca + a) * n + (long)tp * cc + c];
+    for (int q = 0; q < P; ++q) {
+      cplx acc{0.0, 0.0};
+      for (int r = 0; r < P; ++r) cfma(acc, O[q * P + r], v[r]);
+      y[q] = acc;
+    }
+    for (int sp = 0; sp < d; ++sp)
+      for (int tp = 0; tp < d; ++tp) tb[((long)sp * ca + a) * n + (long)tp * cc + c] = y[sp * d + tp];
+  }
+}
+
+// merge (i, i+1), apply a d^2 x d^2 operator, split "right" with the run's truncation (dissipation.py:158-171,
+// stochastic_process.py:268-288): centre ends on site i+1.
+int Engine::two_site_op(StateSet& S, int i, const cplx* dev_ops, const int* op_index, const int* ids, int nb0) {
+  int rc;
+  if ((rc = merge_matrix_layout(S, i, ids, nb0)) != TJM_OK) return rc;
+  const long total = (long)cap[i] * cap[i + 2];
+  int gx = (int)((total + 255) / 256);
+  if (gx > 128) gx = 128;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(apply_phys2_kernel, dim3(gx, nb0), dim3(256), 0, stream, theta, theta_b0, d, cap[i], cap[i + 2], dev_ops, op_index, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return split(S, i, 0, trunc_mode, svd_threshold, max_bond, 1, ids, nb0);
 }
 
 // x_b <- O_b x_b at a per-trajectory site
@@ -1066,17 +1152,21 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
       for (size_t k = 0; k < noise_.size(); ++k)
         if (noise_[k].nsites == 2 && noise_[k].site0 == site) order.push_back((int)k);
   }
-  bool need_moments = false;
+  bool need_moments = false, need_moments2 = false;
   for (int k : order) {
     const NoiseProc& p = noise_[k];
     if (p.nsites == 1 && !p.pauli) need_moments = true;
-    if (p.nsites == 2 && !p.pauli) return TJM_ERR_NOT_IMPLEMENTED;
-    if (p.nsites == 2 && p.pauli && p.site1 == p.site0 + 1) return TJM_ERR_NOT_IMPLEMENTED;  // adjacent: merged split path
+    if (p.nsites == 2 && !p.pauli) {
+      if (p.site1 != p.site0 + 1) return TJM_ERR_NOT_IMPLEMENTED;  // stochastic_process.py:171-176
+      need_moments2 = true;
+    }
   }
-  std::vector<cplx> Mh;
-  if (need_moments) {
+  std::vector<cplx> Mh, Mh2;
+  if (need_moments || need_moments2) {
     Mh.resize((size_t)L * B * d * d);
-    if ((rc = site_moments(set, reinterpret_cast<double*>(Mh.data()))) != TJM_OK) return rc;
+    if (need_moments2) Mh2.resize((size_t)(L - 1) * B * d * d * d * d);
+    if ((rc = site_moments(set, reinterpret_cast<double*>(Mh.data()), need_moments2 ? reinterpret_cast<double*>(Mh2.data()) : nullptr)) != TJM_OK)
+      return rc;
   }
   // operator table: per process one (or two, for long-range factors) d x d matrices
   std::vector<cplx> optab;
@@ -1087,10 +1177,24 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
     if (p.nsites == 1) optab.insert(optab.end(), p.mat, p.mat + d * d);
     else { optab.insert(optab.end(), p.f0, p.f0 + d * d); optab.insert(optab.end(), p.f1, p.f1 + d * d); }
   }
+  // adjacent two-site operators (d^2 x d^2) live in a second table behind the one-site ones
+  std::vector<cplx> optab2;
+  std::vector<int> op2_index(noise_.size(), -1);
+  for (size_t k = 0; k < noise_.size(); ++k) {
+    const NoiseProc& p = noise_[k];
+    if (p.nsites == 2 && p.site1 == p.site0 + 1) {
+      op2_index[k] = (int)(optab2.size() / 16);
+      optab2.insert(optab2.end(), p.mat, p.mat + 16);
+    }
+  }
+  const size_t tab2_off = ((optab.size() + 15) / 16) * 16;
+  if (tab2_off + optab2.size() > (size_t)(L + 64) * 16) return TJM_ERR_WORKSPACE;
+  if (!optab2.empty()) TJM_HIP_CHECK(hipMemcpyAsync(ops_ + tab2_off, optab2.data(), optab2.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
   if (optab.size() > (size_t)(L + 64) * 16) return TJM_ERR_WORKSPACE;
   TJM_HIP_CHECK(hipMemcpyAsync(ops_, optab.data(), optab.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
 
-  std::vector<int> opi(B, -1), opi2(B, -1), js(B, -1), js2(B, -1);
+  std::vector<int> opi(B, -1), opi2(B, -1), js(B, -1), js2(B, -1), adj_site(B, -1), adj_op(B, -1);
+  bool any_adjacent = false;
   unitary_jump_.assign(B, 0);
   bool any_second = false;
   std::vector<double> w(order.size());
@@ -1101,6 +1205,16 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
       double nrm;
       if (p.pauli) {
         nrm = nsq[b];  // unitary jump operator: ||L psi||^2 = ||psi||^2
+      } else if (p.nsites == 2) {
+        // adjacent non-Pauli: Frobenius weight of the untruncated L theta (stochastic_process.py:53-83)
+        const cplx* M2 = &Mh2[((size_t)p.site0 * B + b) * 16];
+        double acc = 0.0;
+        for (int a = 0; a < 4; ++a) for (int c2 = 0; c2 < 4; ++c2) {
+          cplx ll{0.0, 0.0};
+          for (int r = 0; r < 4; ++r) cfma(ll, cconj(p.mat[r * 4 + a]), p.mat[r * 4 + c2]);
+          acc += ll.x * M2[a * 4 + c2].x - ll.y * M2[a * 4 + c2].y;
+        }
+        nrm = acc;
       } else {
         // ||L psi||^2 = sum_{p,q} (L^dag L)[p][q] M[p][q]
         const cplx* M = &Mh[((size_t)p.site0 * B + b) * d * d];
@@ -1125,8 +1239,17 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
     for (size_t c = 0; c < order.size(); ++c) if (u_choice[b] < cdf[c] / last) { choice = c; break; }
     const NoiseProc& p = noise_[order[choice]];
     js[b] = p.site0;
-    opi[b] = op_first[order[choice]];
     unitary_jump_[b] = p.pauli ? 1 : 0;
+    if (p.nsites == 2 && p.site1 == p.site0 + 1) {
+      // adjacent pair: merged application + truncated split, never the one-tensor shortcut at or left of the pair
+      adj_site[b] = p.site0;
+      adj_op[b] = op2_index[order[choice]];
+      js2[b] = p.site1;
+      unitary_jump_[b] = 0;
+      any_adjacent = true;
+      continue;
+    }
+    opi[b] = op_first[order[choice]];
     if (p.nsites == 2) { js2[b] = p.site1; opi2[b] = op_first[order[choice]] + 1; any_second = true; }
   }
   // device tables for the per-trajectory site application
@@ -1152,6 +1275,21 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
     TJM_HIP_CHECK(hipMemcpyAsync(jsite_, js2.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(apply_local_multi_kernel, dim3(64, nj), dim3(256), 0, stream, d_sp, d_sb, d_sr, d, ops_, opidx_, jsite_, ids_);
     TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  if (any_adjacent) {
+    // adjacent two-site jumps: group the trajectories by pair position
+    for (int site = 0; site + 1 < L; ++site) {
+      std::vector<int> lst;
+      std::vector<int> opsel(B, -1);
+      for (int b : jumped)
+        if (adj_site[b] == site) { lst.push_back(b); opsel[b] = adj_op[b]; }
+      if (lst.empty()) continue;
+      TJM_HIP_CHECK(hipMemcpyAsync(ids_, lst.data(), lst.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+      TJM_HIP_CHECK(hipMemcpyAsync(opidx_, opsel.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
+      if ((rc = two_site_op(S, site, ops_ + tab2_off, opidx_, ids_, (int)lst.size())) != TJM_OK) return rc;
+      TJM_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    TJM_HIP_CHECK(hipMemcpyAsync(ids_, jumped.data(), nj * sizeof(int), hipMemcpyHostToDevice, stream));
   }
   // ---- normalize("B", "SVD") on the jumped trajectories (mps.py:815-839): SVD sweep right -> left, then drop R at site 0.
   // While the tensor right of the bond is still right-isometric (always for unitary jump operators, otherwise right of

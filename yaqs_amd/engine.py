@@ -138,6 +138,12 @@ class BatchEngine:
         _lib.check(self.lib.tjm_engine_site_moments(self.h, set_index, m.ctypes.data), "site_moments")
         return m
 
+    def site_moments2(self, set_index: int = 0):
+        m = np.zeros((self.L, self.B, self.d, self.d), dtype=np.complex128)
+        m2 = np.zeros((self.L - 1, self.B, self.d * self.d, self.d * self.d), dtype=np.complex128)
+        _lib.check(self.lib.tjm_engine_site_moments2(self.h, set_index, m.ctypes.data, m2.ctypes.data), "site_moments2")
+        return m, m2
+
     def bond_dims(self, set_index: int = 0) -> np.ndarray:
         chi = np.zeros((self.B, self.L + 1), dtype=np.int32)
         _lib.check(self.lib.tjm_engine_bond_dims(self.h, set_index, chi.ctypes.data), "bond_dims")

@@ -52,9 +52,12 @@ class TrajectoryBatch:
         self.noise = noise if (noise is not None and noise.processes) else None
         if params.tdvp_mode not in ("1site", "2site"):
             raise NotImplementedError(f"tdvp_mode {params.tdvp_mode!r} is not built yet in the HIP path")
+        self.two_site_obs = False
         for obs in params.observables:
-            if isinstance(obs.sites, (list, tuple)) and len(obs.sites) != 1:
-                raise NotImplementedError("two-site observables are not built yet in the HIP path")
+            if isinstance(obs.sites, (list, tuple)) and len(obs.sites) == 2:
+                if obs.sites[1] != obs.sites[0] + 1:
+                    raise ValueError("Only nearest-neighbor observables are currently implemented.")  # mps.py:1012-1014
+                self.two_site_obs = True
         engine.set_params(dt=params.dt, svd_threshold=params.svd_threshold, trunc_mode=params.trunc_mode,
                           max_bond_dim=params.max_bond_dim, krylov_tol=params.krylov_tol, tdvp_mode=params.tdvp_mode,
                           tdvp_sweeps=params.tdvp_sweeps)
@@ -67,11 +70,17 @@ class TrajectoryBatch:
     # ---- measurement ----------------------------------------------------------------
     def _measure(self, set_index: int, results: np.ndarray, diagnostics: np.ndarray, col: int) -> None:
         e = self.e
-        M = e.site_moments(set_index)  # [L, B, d, d]
+        if self.two_site_obs:
+            M, M2 = e.site_moments2(set_index)
+        else:
+            M, M2 = e.site_moments(set_index), None  # [L, B, d, d]
         for row, obs in enumerate(self.sorted_obs):
             site = obs.first_site
             O = np.asarray(obs.gate.matrix, dtype=np.complex128)
-            val = np.einsum("pq,bpq->b", O, M[site])
+            if isinstance(obs.sites, (list, tuple)) and len(obs.sites) == 2:
+                val = np.einsum("pq,bpq->b", O, M2[site])   # <theta| O |theta> on the merged pair (mps.py:999-1047)
+            else:
+                val = np.einsum("pq,bpq->b", O, M[site])
             if np.any(val.imag >= 1e-13):
                 raise AssertionError(f"Measurement should be real, got max imag {val.imag.max():.3e}")  # mps.py:1233
             results[:, row, col] = val.real
