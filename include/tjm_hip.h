@@ -72,6 +72,19 @@ int tjm_engine_set_uniforms(tjm_engine* e, const double* host_u, int32_t n_per_t
 int tjm_engine_tdvp(tjm_engine* e, int32_t set);
 /* apply_dissipation (core/methods/dissipation.py:50-183). */
 int tjm_engine_dissipate(tjm_engine* e, int32_t set, double dt);
+/* ---- digital (circuit) path: TEBD gates with per-gate local noise (digital/digital_tjm.py:636-749) ---- */
+/* apply_dissipation started from a known centre (after a TEBD split the centre sits on the gate's right site). */
+int tjm_engine_dissipate_from(tjm_engine* e, int32_t set, double dt, int32_t center);
+/* create_local_noise_model (digital_tjm.py:187-204): restrict dissipation / jumps to the listed process indices;
+ * n < 0 re-activates every process. */
+int tjm_engine_set_noise_filter(tjm_engine* e, int32_t n, const int32_t* idx);
+/* MPS.normalize("B", "QR") from a known centre (mps.py:815-839). */
+int tjm_engine_normalize_qr(tjm_engine* e, int32_t set, int32_t center);
+/* _apply_single_qubit_gate (digital_tjm.py:304-309); host 2x2 complex128 row-major. */
+int tjm_engine_apply_single(tjm_engine* e, int32_t set, int32_t site, const double* host_mat);
+/* apply_two_qubit_gate_tebd (digital_tjm.py:455-533) for a nearest-neighbour gate on (left, left+1) of a state with
+ * centre 0; host U[(out_l,out_r),(in_l,in_r)] 4x4 complex128 row-major (mpo_utils.py:104-159 index order). */
+int tjm_engine_tebd_gate(tjm_engine* e, int32_t set, int32_t left, const double* host_u);
 /* stochastic_process (core/methods/stochastic_process.py:190-292); jumped[B], dp[B] optional host outputs. */
 int tjm_engine_stochastic(tjm_engine* e, int32_t set, double dt, int32_t* jumped, double* dp);
 /* Physical-leg moment matrices M[site][b][p][q] = <psi| |p><q|_site |psi> (host, complex128);

@@ -250,3 +250,38 @@ def test_adjacent_two_site_noise_and_two_site_observables_match_oracle():
         ro, do, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), on, op, o.ising_mpo(L, 1.0, 0.5))
         assert np.allclose(r[t], ro, atol=1e-8), t
         assert np.array_equal(d[t], do), t
+
+
+def test_digital_tebd_trajectories_match_reference_fixture():
+    """Circuit path (TEBD gates + per-gate local noise, digital_tjm.py:636-749) against outputs of the reference itself."""
+    from yaqs_amd.api import DigitalSimParams, MPS, NoiseModel, Observable, X as Xg, Z as Zg, ising_trotter_layers
+    from yaqs_amd.tjm import DigitalBatch
+
+    g = load("digital")
+    L, steps = 8, 5
+    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 3)]
+    mpo = o.ising_mpo(L, 1.0, 0.5)  # the engine wants an MPO shape; the circuit path never applies it
+    init = MPS(L, state="zeros")
+
+    def run(noise, params, layers, trajs, chi):
+        e = make_engine(L, chi, len(trajs), mpo)
+        db = DigitalBatch(e, params, noise)
+        r, d = db.run(trajs, init, layers)
+        e.close()
+        return r, d, db
+
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.01} for i in range(L) for n in ("pauli_x", "pauli_y", "pauli_z")])
+    p = DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-9, random_seed=3)
+    r, d, _ = run(noise, p, ising_trotter_layers(L, 1.0, 0.5, 0.1, steps), list(range(6)), 16)
+    assert np.allclose(r[:, :, 0], g["noisy_results"][:, :, 0], atol=1e-8)
+    assert np.array_equal(d, g["noisy_diag"])
+    p = DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-9, random_seed=3, sample_layers=True, num_mid_measurements=steps)
+    r, d, _ = run(None, p, ising_trotter_layers(L, 1.0, 0.5, 0.1, steps, sample_each=True), [0, 1], 16)
+    assert np.allclose(r[0], g["noiseless_results"][0], atol=1e-8)
+    assert np.array_equal(d[0], g["noiseless_diag"][0])
+    noise2 = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
+    p = DigitalSimParams(observables=obs, max_bond_dim=4, svd_threshold=1e-6, random_seed=7)
+    r, d, db = run(noise2, p, ising_trotter_layers(L, 1.0, 0.5, 0.1, 3), list(range(6)), 4)
+    assert np.array(db.jump_log).sum() > 0
+    assert np.allclose(r[:, :, 0], g["strong_results"][:, :, 0], atol=1e-8)
+    assert np.array_equal(d, g["strong_diag"])

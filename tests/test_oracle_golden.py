@@ -247,3 +247,29 @@ def test_closed_and_dephasing_configs():
         assert np.allclose(r, g["c2_results"][i], atol=1e-9), i
         assert np.array_equal(dg, g["c2_diag"][i]), i
     assert sorted_rows[0] == 0 and sorted_rows[8] == 1  # Z0 -> row 0, X0 -> row 1 (site-sorted, stable)
+
+
+def test_digital_tebd_trajectories_match_reference():
+    g = load("digital")
+    assert np.allclose(o.rx_matrix(-0.1), g["rx_matrix"], atol=1e-15)
+    assert np.allclose(o.rzz_tensor(-0.2), g["rzz_tensor"], atol=1e-15)
+    L, steps = 8, 5
+    obs = [o.Obs(Z, s) for s in range(L)] + [o.Obs(X, 3)]
+    init = o.MPSState.product(L, "zeros")
+    noise = [o.make_process(n, [i], 0.01) for i in range(L) for n in ("pauli_x", "pauli_y", "pauli_z")]
+    p = o.DigitalParams(observables=obs, max_bond_dim=16, svd_threshold=1e-9, random_seed=3)
+    layers = o.ising_trotter_layers(L, 1.0, 0.5, 0.1, steps)
+    for i in range(6):
+        r, dg, _ = o.digital_tjm(i, init, noise, p, layers)
+        assert np.allclose(r, g["noisy_results"][i], atol=1e-9), i
+        assert np.array_equal(dg, g["noisy_diag"][i]), i
+    p = o.DigitalParams(observables=obs, max_bond_dim=16, svd_threshold=1e-9, random_seed=3, sample_layers=True, num_mid_measurements=steps)
+    r, dg, _ = o.digital_tjm(0, init, None, p, o.ising_trotter_layers(L, 1.0, 0.5, 0.1, steps, sample_each=True))
+    assert np.allclose(r, g["noiseless_results"][0], atol=1e-9)
+    assert np.array_equal(dg, g["noiseless_diag"][0])
+    noise2 = [o.make_process(n, [i], 0.1) for i in range(L) for n in ("lowering", "pauli_z")]
+    p = o.DigitalParams(observables=obs, max_bond_dim=4, svd_threshold=1e-6, random_seed=7)
+    for i in range(6):
+        r, dg, _ = o.digital_tjm(i, init, noise2, p, o.ising_trotter_layers(L, 1.0, 0.5, 0.1, 3))
+        assert np.allclose(r, g["strong_results"][i], atol=1e-9), i
+        assert np.array_equal(dg, g["strong_diag"][i]), i

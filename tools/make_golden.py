@@ -333,7 +333,60 @@ def gen_traj():
     save("trajectories", **out)
 
 
+
+
+# ------------------------------------------------------------------ 7. digital TEBD trajectories
+def gen_digital():
+    dtm = ref("digital.digital_tjm")
+    L, steps = 8, 5
+    J, g, dt = 1.0, 0.5, 0.1
+
+    def layer(sample):
+        singles = []
+        for q in range(L):
+            gt = gl.GateLibrary.rx([-2 * dt * g]); gt.set_sites(q); singles.append(gt)
+        even, odd = [], []
+        for q in range(0, L - 1, 2):
+            gt = gl.GateLibrary.rzz([-2 * dt * J]); gt.set_sites(q, q + 1); even.append(gt)
+        for q in range(1, L - 1, 2):
+            gt = gl.GateLibrary.rzz([-2 * dt * J]); gt.set_sites(q, q + 1); odd.append(gt)
+        return dtm._CompiledCircuitLayer(tuple(singles), tuple(even), tuple(odd), 1 if sample else 0)
+
+    out = {}
+    g0 = gl.GateLibrary.rx([-2 * dt * g]); g0.set_sites(0)
+    g1 = gl.GateLibrary.rzz([-2 * dt * J]); g1.set_sites(0, 1)
+    out["rx_matrix"] = np.asarray(g0.tensor)
+    out["rzz_tensor"] = np.asarray(g1.tensor)
+    st = MPS(L, state="zeros")
+    st.normalize("B")
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.01} for i in range(L) for n in ("pauli_x", "pauli_y", "pauli_z")])
+    obs = [sp.Observable(gl.Z(), s) for s in range(L)] + [sp.Observable(gl.X(), 3)]
+    for name, nm, sample in (("noisy", noise, False), ("noiseless", None, True)):
+        cc = dtm._CompiledCircuit(tuple(layer(sample) for _ in range(steps)), steps if sample else 0)
+        p = sp.DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-9, random_seed=3, sample_layers=sample,
+                                num_mid_measurements=steps if sample else 0)
+        res, diag = [], []
+        for i in range(6 if nm is not None else 1):
+            r, dg, _, _ = dtm.digital_tjm((i, st, nm, p, None), compiled_circuit=cc)
+            res.append(np.asarray(r, dtype=np.float64))
+            diag.append(dg)
+        out[name + "_results"] = np.array(res)
+        out[name + "_diag"] = np.array(diag)
+    # strong noise with non-Pauli channel and truncation: lowering + dephasing, chi 4
+    noise2 = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
+    cc = dtm._CompiledCircuit(tuple(layer(False) for _ in range(3)), 0)
+    p = sp.DigitalSimParams(observables=obs, max_bond_dim=4, svd_threshold=1e-6, random_seed=7)
+    res, diag = [], []
+    for i in range(6):
+        r, dg, _, _ = dtm.digital_tjm((i, st, noise2, p, None), compiled_circuit=cc)
+        res.append(np.asarray(r, dtype=np.float64))
+        diag.append(dg)
+    out["strong_results"] = np.array(res)
+    out["strong_diag"] = np.array(diag)
+    save("digital", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "truncate", "kernels", "tdvp", "noise", "traj"]
+    which = sys.argv[1:] or ["rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital"]
     for w in which:
         globals()["gen_" + w]()

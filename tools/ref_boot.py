@@ -54,6 +54,42 @@ def boot():
     sys.modules["mqt.yaqs.core.methods.lanczos_numba"] = None
 
 
+class _StubFinder:
+    """Auto-stub qiskit.* / cma so the digital driver module imports (its DAG front end is never called)."""
+
+    PREFIXES = ("qiskit", "cma", "qiskit_qasm3_import")
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname.split(".")[0] in self.PREFIXES:
+            import importlib.machinery
+
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = types.ModuleType(spec.name)
+        m.__path__ = []
+
+        def _getattr(name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return type(name, (), {})
+
+        m.__getattr__ = _getattr
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def boot_digital():
+    boot()
+    if not any(isinstance(f, _StubFinder) for f in sys.meta_path):
+        sys.meta_path.insert(0, _StubFinder())
+
+
 def ref(name: str):
     boot()
+    if name.startswith("digital"):
+        boot_digital()
     return importlib.import_module("mqt.yaqs." + name)

@@ -61,6 +61,11 @@ EXPORTS = {
     "tjm_engine_set_uniforms": (C.c_int, [V, V, I]),
     "tjm_engine_tdvp": (C.c_int, [V, I]),
     "tjm_engine_dissipate": (C.c_int, [V, I, D]),
+    "tjm_engine_dissipate_from": (C.c_int, [V, I, D, I]),
+    "tjm_engine_set_noise_filter": (C.c_int, [V, I, V]),
+    "tjm_engine_normalize_qr": (C.c_int, [V, I, I]),
+    "tjm_engine_apply_single": (C.c_int, [V, I, I, V]),
+    "tjm_engine_tebd_gate": (C.c_int, [V, I, I, V]),
     "tjm_engine_stochastic": (C.c_int, [V, I, D, V, V]),
     "tjm_engine_site_moments": (C.c_int, [V, I, V]),
     "tjm_engine_site_moments2": (C.c_int, [V, I, V, V]),

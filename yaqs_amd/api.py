@@ -148,6 +148,79 @@ class AnalogSimParams:
         return tuple(out)
 
 
+class DigitalSimParams:
+    """Truncation / sampling knobs of the circuit path (simulation_parameters.py:616-745); ``dt`` is fixed to 1."""
+
+    def __init__(self, observables=None, num_traj: int | None = None, max_bond_dim=_USE_PRESET, trunc_mode: str = "discarded_weight",
+                 svd_threshold: float | None = None, *, preset: str = "balanced", sample_layers: bool = False, num_mid_measurements: int = 0,
+                 get_state: bool = False, random_seed: int | None = None):
+        if preset not in SIMULATION_PRESETS:
+            raise ValueError(f"Unknown preset {preset!r}")
+        if trunc_mode not in _TRUNC:
+            raise ValueError(f"Unknown truncation mode: {trunc_mode!r}")
+        pv = SIMULATION_PRESETS[preset]
+        self.observables = [] if observables is None else list(observables)
+        self.num_traj = num_traj if num_traj is not None else pv["num_traj"]
+        self.max_bond_dim = pv["max_bond_dim"] if max_bond_dim is _USE_PRESET else max_bond_dim
+        self.trunc_mode = trunc_mode
+        self.svd_threshold = svd_threshold if svd_threshold is not None else pv["svd_threshold"]
+        self.sample_layers = sample_layers
+        self.num_mid_measurements = num_mid_measurements
+        self.get_state = get_state
+        self.random_seed = random_seed
+        self.dt = 1.0  # simulation_parameters.py:667
+
+    def _ordering(self):
+        return sorted(range(len(self.observables)), key=lambda i: (self.observables[i].first_site, i))
+
+    @property
+    def sorted_observables(self):
+        return [self.observables[i] for i in self._ordering()]
+
+    @property
+    def observable_sorted_indices(self):
+        out = [0] * len(self.observables)
+        for row, user in enumerate(self._ordering()):
+            out[user] = row
+        return tuple(out)
+
+
+@dataclass
+class GateLayer:
+    """One pre-compiled execution layer (the build's replacement of the qiskit DAG front end; digital_tjm.py:49-68).
+
+    ``singles``: [(site, 2x2 matrix)]; ``even`` / ``odd``: [(left_site, U[out_l, out_r, in_l, in_r])] nearest-neighbour gates on
+    (left_site, left_site + 1) in the index order of mpo_utils.py:104-159; ``sample_points``: measurement barriers after the layer.
+    """
+
+    singles: list
+    even: list
+    odd: list
+    sample_points: int = 0
+
+
+def rx_matrix(theta: float) -> np.ndarray:
+    """gate_library.py:949-978."""
+    c, s_ = np.cos(theta / 2), np.sin(theta / 2)
+    return np.array([[c, -1j * s_], [-1j * s_, c]], dtype=C128)
+
+
+def rzz_tensor(theta: float) -> np.ndarray:
+    """gate_library.py:1612-1646 as U[out_l, out_r, in_l, in_r]."""
+    return np.diag(np.exp(-0.5j * theta * np.array([1, -1, -1, 1]))).astype(C128).reshape(2, 2, 2, 2)
+
+
+def ising_trotter_layers(length: int, J: float, g: float, dt: float, steps: int, sample_each: bool = False) -> list:
+    """Gate sequence of ``create_ising_circuit`` (circuit_library.py:28-79)."""
+    out = []
+    for _ in range(steps):
+        singles = [(q, rx_matrix(-2.0 * dt * g)) for q in range(length)]
+        even = [(q, rzz_tensor(-2.0 * dt * J)) for q in range(0, length - 1, 2)]
+        odd = [(q, rzz_tensor(-2.0 * dt * J)) for q in range(1, length - 1, 2)]
+        out.append(GateLayer(singles, even, odd, 1 if sample_each else 0))
+    return out
+
+
 # ------------------------------------------------------------------ noise
 _LIB_OPS = {
     "pauli_x": _X, "pauli_y": _Y, "pauli_z": _Z,

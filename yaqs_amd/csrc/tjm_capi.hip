@@ -97,6 +97,19 @@ int tjm_engine_export_state(tjm_engine* e, int32_t set, int32_t b, double* out, 
 int tjm_engine_set_uniforms(tjm_engine* e, const double* u, int32_t n) { return (e && u && n > 0) ? e->impl.set_uniforms(u, n) : TJM_ERR_ARG; }
 int tjm_engine_tdvp(tjm_engine* e, int32_t set) { return (e && set >= 0 && set < 2) ? e->impl.tdvp(set) : TJM_ERR_ARG; }
 int tjm_engine_dissipate(tjm_engine* e, int32_t set, double dt) { return (e && set >= 0 && set < 2) ? e->impl.dissipate(set, dt) : TJM_ERR_ARG; }
+int tjm_engine_dissipate_from(tjm_engine* e, int32_t set, double dt, int32_t center) {
+  return (e && set >= 0 && set < 2) ? e->impl.dissipate(set, dt, center) : TJM_ERR_ARG;
+}
+int tjm_engine_set_noise_filter(tjm_engine* e, int32_t n, const int32_t* idx) { return e ? e->impl.set_noise_filter(n, idx) : TJM_ERR_ARG; }
+int tjm_engine_normalize_qr(tjm_engine* e, int32_t set, int32_t center) {
+  return (e && set >= 0 && set < 2) ? e->impl.normalize_qr(set, center) : TJM_ERR_ARG;
+}
+int tjm_engine_apply_single(tjm_engine* e, int32_t set, int32_t site, const double* mat) {
+  return (e && mat && set >= 0 && set < 2) ? e->impl.apply_single(set, site, mat) : TJM_ERR_ARG;
+}
+int tjm_engine_tebd_gate(tjm_engine* e, int32_t set, int32_t left, const double* u) {
+  return (e && u && set >= 0 && set < 2) ? e->impl.tebd_gate(set, left, u) : TJM_ERR_ARG;
+}
 int tjm_engine_stochastic(tjm_engine* e, int32_t set, double dt, int32_t* jumped, double* dp) {
   return (e && set >= 0 && set < 2) ? e->impl.stochastic(set, dt, jumped, dp) : TJM_ERR_ARG;
 }

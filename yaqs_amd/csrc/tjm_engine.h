@@ -49,7 +49,11 @@ class Engine {
   int reset_cursor();
 
   int tdvp(int set);
-  int dissipate(int set, double dt_);
+  int dissipate(int set, double dt_, int start_center = 0);
+  int set_noise_filter(int n, const int* idx);   // n < 0: all processes active
+  int normalize_qr(int set, int center);
+  int apply_single(int set, int site, const double* host_mat);
+  int tebd_gate(int set, int left, const double* host_u);
   int stochastic(int set, double dt_, int* host_jumped /*B or null*/, double* host_dp /*B or null*/);
   int site_moments(int set, double* host_M /*[L][B][d][d] complex*/, double* host_M2 = nullptr /*[L-1][B][d^2][d^2] or null*/);
   int bond_dims(int set, int* host_chi /*[B][L+1]*/);
@@ -115,7 +119,10 @@ class Engine {
   int bond_apply(const cplx* x, int cu, int cv, const cplx* Lenv, long l_b0, const cplx* Renv, long r_b0, int D, cplx* y, const int* active);
   int sweep_1site(StateSet& S, double scale);
   int qr_site(StateSet& S, int i, bool right);   // A_i = Q C (right) or A_i = C^T Q (left); C into Cm_
-  int two_site_op(StateSet& S, int i, const cplx* dev_ops, const int* op_index, const int* ids, int nb0);
+  int two_site_op(StateSet& S, int i, const cplx* dev_ops, const int* op_index, const int* ids, int nb0, int min_keep);
+  int qr_shift_right(StateSet& S, int i);
+  int qr_shift_left(StateSet& S, int i);
+  std::vector<char> proc_on_;
   int svd_shift_right(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left_rc(StateSet& S, int i, const int* ids, int nb0);

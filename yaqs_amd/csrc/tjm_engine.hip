@@ -229,6 +229,7 @@ int Engine::set_mpo(const double* host) {
 
 int Engine::set_noise(const std::vector<NoiseProc>& procs) {
   noise_ = procs;
+  proc_on_.assign(procs.size(), 1);
   one_by_site_.assign(L, {});
   two_by_right_.assign(L, {});
   for (size_t k = 0; k < noise_.size(); ++k) {
@@ -898,24 +899,97 @@ __global__ void rsqrt_kernel(const double* in, double* out, int n) {
   if (t < n) out[t] = (in[t] > 0.0) ? 1.0 / sqrt(in[t]) : 0.0;
 }
 
-int Engine::dissipate(int set, double dt_) {
+int Engine::set_noise_filter(int n, const int* idx) {
+  if (n < 0) { proc_on_.assign(noise_.size(), 1); return TJM_OK; }
+  proc_on_.assign(noise_.size(), 0);
+  for (int k = 0; k < n; ++k) {
+    if (idx[k] < 0 || idx[k] >= (int)noise_.size()) return TJM_ERR_ARG;
+    proc_on_[idx[k]] = 1;
+  }
+  return TJM_OK;
+}
+
+// QR centre shifts (mps.py:719-746 / 771-788 with decomposition="QR"): exact gauge moves, no truncation
+int Engine::qr_shift_right(StateSet& S, int i) {
+  const int cb = cap[i + 1], cc = cap[i + 2];
+  int rc;
+  if ((rc = qr_site(S, i, true)) != TJM_OK) return rc;
+  GemmDesc g = blank_gemm();  // T1[p][l][r] = C[l][x] A_{i+1}[p][x][r]
+  g.A = Cm_; g.B = S.A[i + 1]; g.C = T1;
+  g.M = cb; g.K = cb; g.N = cc;
+  g.a_rs = cb; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = cc;
+  g.nb0 = B; g.nb1 = d; g.a_b0 = (long)cb * cb; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cb * cc; g.c_b0 = t_b0; g.c_b1 = (long)cb * cc;
+  if ((rc = gemm(g)) != TJM_OK) return rc;
+  return copy_back(S.A[i + 1], a_b0_[i + 1], T1, t_b0, a_b0_[i + 1], nullptr, B);
+}
+
+int Engine::qr_shift_left(StateSet& S, int i) {
+  const int cz = cap[i - 1], ca = cap[i];
+  int rc;
+  if ((rc = qr_site(S, i, false)) != TJM_OK) return rc;
+  GemmDesc g = blank_gemm();  // T1[(p,l)][r] = A_{i-1}[(p,l)][x] C^T[x][r]
+  g.A = S.A[i - 1]; g.B = Cm_; g.C = T1;
+  g.M = d * cz; g.K = ca; g.N = ca;
+  g.a_rs = ca; g.a_cs = 1; g.b_rs = ca; g.b_cs = 1; g.c_rs = ca;
+  g.nb0 = B; g.a_b0 = a_b0_[i - 1]; g.b_b0 = (long)ca * ca; g.c_b0 = t_b0;
+  if ((rc = gemm(g)) != TJM_OK) return rc;
+  return copy_back(S.A[i - 1], a_b0_[i - 1], T1, t_b0, a_b0_[i - 1], nullptr, B);
+}
+
+// normalize("B", "QR") from a known centre (mps.py:815-839): QR shifts down to site 0, then drop R (unit norm)
+int Engine::normalize_qr(int set, int center) {
+  if (!bound_ || center < 0 || center >= L) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  int rc;
+  for (int i = center; i >= 1; --i)
+    if ((rc = qr_shift_left(S, i)) != TJM_OK) return rc;
+  if ((rc = launch_normsq(S.A[0], a_b0_[0], a_b0_[0], normsq_, B, nullptr, stream)) != TJM_OK) return rc;
+  hipLaunchKernelGGL(rsqrt_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, normsq_, scal_, B);
+  return launch_scale(S.A[0], a_b0_[0], a_b0_[0], scal_, B, nullptr, nullptr, stream);
+}
+
+// _apply_single_qubit_gate (digital_tjm.py:304-309): a unitary on the physical leg keeps the gauge
+int Engine::apply_single(int set, int site, const double* host_mat) {
+  if (!bound_ || site < 0 || site >= L) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 2) * 16, host_mat, (size_t)d * d * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return launch_apply_local(S.A[site], a_b0_[site], d, (long)cap[site] * cap[site + 1], ops_ + (size_t)(L + 2) * 16, nullptr, B, nullptr, stream);
+}
+
+// apply_two_qubit_gate_tebd (digital_tjm.py:455-533) for a nearest-neighbour gate on (left, left+1), from a state with
+// centre 0: QR shifts put the centre on the pair, then merge, gate, truncated split to the right (min_keep = min(2, chi)).
+int Engine::tebd_gate(int set, int left, const double* host_u) {
+  if (!bound_ || left < 0 || left + 1 >= L) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  int rc;
+  for (int i = 0; i < left; ++i)
+    if ((rc = qr_shift_right(S, i)) != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 4) * 16, host_u, 16 * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  const int mk = (max_bond > 0) ? std::min(2, max_bond) : 2;
+  return two_site_op(S, left, ops_ + (size_t)(L + 4) * 16, nullptr, nullptr, B, mk);
+}
+
+int Engine::dissipate(int set, double dt_, int start_center) {
   if (!bound_) return TJM_ERR_STATE;
+  if (start_center < 0 || start_center >= L) return TJM_ERR_ARG;
   StateSet& S = sets[set];
   int rc;
   bool any = false;
-  for (const auto& p : noise_) any = any || (p.gamma != 0.0);
-  if (!any) {  // dissipation.py:79-86: QR at site 0 with R discarded = renormalise
-    if ((rc = launch_normsq(S.A[0], a_b0_[0], a_b0_[0], normsq_, B, nullptr, stream)) != TJM_OK) return rc;
-    hipLaunchKernelGGL(rsqrt_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, normsq_, scal_, B);
-    return launch_scale(S.A[0], a_b0_[0], a_b0_[0], scal_, B, nullptr, nullptr, stream);
-  }
-  for (int i = 0; i < L - 1; ++i)
+  for (size_t k = 0; k < noise_.size(); ++k) any = any || (proc_on_[k] && noise_[k].gamma != 0.0);
+  if (!any)  // dissipation.py:79-86: centre to 0 by QR, then QR at site 0 with R discarded = renormalise
+    return normalize_qr(set, start_center);
+  for (int i = start_center; i < L - 1; ++i)
     if ((rc = svd_shift_right(S, i, nullptr, B)) != TJM_OK) return rc;
   for (int i = L - 1; i >= 0; --i) {
     double expo = 0.0;
     bool need_matrix = false;
     cplx gen[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    bool any_one = false;
     for (int k : one_by_site_[i]) {
+      if (!proc_on_[k]) continue;
+      any_one = true;
       const NoiseProc& p = noise_[k];
       if (p.pauli) {
         gen[0].x += p.gamma; gen[3].x += p.gamma;
@@ -928,13 +1002,14 @@ int Engine::dissipate(int set, double dt_) {
         }
       }
     }
-    if (!one_by_site_[i].empty() && !need_matrix) expo += gen[0].x;
+    if (any_one && !need_matrix) expo += gen[0].x;
     bool need_matrix2 = false;
     cplx gen2[16];
     for (int q = 0; q < 16; ++q) gen2[q] = cplx{0.0, 0.0};
     if (i != 0) {
       double adj_pauli = 0.0;
       for (int k : two_by_right_[i]) {
+        if (!proc_on_[k]) continue;
         const NoiseProc& p = noise_[k];
         const bool longrange = (p.site1 - p.site0) > 1;
         if (longrange) {
@@ -972,7 +1047,7 @@ int Engine::dissipate(int set, double dt_) {
       small_expm(arg, 4, m2);
       TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)L * 16, m2, sizeof(m2), hipMemcpyHostToDevice, stream));
       TJM_HIP_CHECK(hipStreamSynchronize(stream));
-      if ((rc = two_site_op(S, i - 1, ops_ + (size_t)L * 16, nullptr, nullptr, B)) != TJM_OK) return rc;
+      if ((rc = two_site_op(S, i - 1, ops_ + (size_t)L * 16, nullptr, nullptr, B, 1)) != TJM_OK) return rc;
     }
     if (i != 0)
       if ((rc = svd_shift_left(S, i, nullptr, B)) != TJM_OK) return rc;
@@ -1073,7 +1148,7 @@ __global__ __launch_bounds__(256) void apply_phys2_kernel(cplx* __restrict__ the
 
 // merge (i, i+1), apply a d^2 x d^2 operator, split "right" with the run's truncation (dissipation.py:158-171,
 // stochastic_process.py:268-288): centre ends on site i+1.
-int Engine::two_site_op(StateSet& S, int i, const cplx* dev_ops, const int* op_index, const int* ids, int nb0) {
+int Engine::two_site_op(StateSet& S, int i, const cplx* dev_ops, const int* op_index, const int* ids, int nb0, int min_keep) {
   int rc;
   if ((rc = merge_matrix_layout(S, i, ids, nb0)) != TJM_OK) return rc;
   const long total = (long)cap[i] * cap[i + 2];
@@ -1082,7 +1157,7 @@ int Engine::two_site_op(StateSet& S, int i, const cplx* dev_ops, const int* op_i
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(apply_phys2_kernel, dim3(gx, nb0), dim3(256), 0, stream, theta, theta_b0, d, cap[i], cap[i + 2], dev_ops, op_index, ids);
   TJM_HIP_CHECK(hipGetLastError());
-  return split(S, i, 0, trunc_mode, svd_threshold, max_bond, 1, ids, nb0);
+  return split(S, i, 0, trunc_mode, svd_threshold, max_bond, min_keep, ids, nb0);
 }
 
 // x_b <- O_b x_b at a per-trajectory site
@@ -1147,10 +1222,10 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
   std::vector<int> order;
   for (int site = 0; site < L; ++site) {
     for (size_t k = 0; k < noise_.size(); ++k)
-      if (noise_[k].nsites == 1 && noise_[k].site0 == site) order.push_back((int)k);
+      if (proc_on_[k] && noise_[k].nsites == 1 && noise_[k].site0 == site) order.push_back((int)k);
     if (site < L - 1)
       for (size_t k = 0; k < noise_.size(); ++k)
-        if (noise_[k].nsites == 2 && noise_[k].site0 == site) order.push_back((int)k);
+        if (proc_on_[k] && noise_[k].nsites == 2 && noise_[k].site0 == site) order.push_back((int)k);
   }
   bool need_moments = false, need_moments2 = false;
   for (int k : order) {
@@ -1286,7 +1361,7 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
       if (lst.empty()) continue;
       TJM_HIP_CHECK(hipMemcpyAsync(ids_, lst.data(), lst.size() * sizeof(int), hipMemcpyHostToDevice, stream));
       TJM_HIP_CHECK(hipMemcpyAsync(opidx_, opsel.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
-      if ((rc = two_site_op(S, site, ops_ + tab2_off, opidx_, ids_, (int)lst.size())) != TJM_OK) return rc;
+      if ((rc = two_site_op(S, site, ops_ + tab2_off, opidx_, ids_, (int)lst.size(), 1)) != TJM_OK) return rc;
       TJM_HIP_CHECK(hipStreamSynchronize(stream));
     }
     TJM_HIP_CHECK(hipMemcpyAsync(ids_, jumped.data(), nj * sizeof(int), hipMemcpyHostToDevice, stream));

@@ -127,6 +127,27 @@ class BatchEngine:
     def dissipate(self, dt: float, set_index: int = 0):
         _lib.check(self.lib.tjm_engine_dissipate(self.h, set_index, float(dt)), "dissipate")
 
+    def dissipate_from(self, dt: float, center: int, set_index: int = 0):
+        _lib.check(self.lib.tjm_engine_dissipate_from(self.h, set_index, float(dt), int(center)), "dissipate_from")
+
+    def set_noise_filter(self, indices=None):
+        if indices is None:
+            _lib.check(self.lib.tjm_engine_set_noise_filter(self.h, -1, None), "set_noise_filter")
+        else:
+            idx = _i32(indices)
+            _lib.check(self.lib.tjm_engine_set_noise_filter(self.h, len(idx), idx.ctypes.data), "set_noise_filter")
+
+    def normalize_qr(self, center: int, set_index: int = 0):
+        _lib.check(self.lib.tjm_engine_normalize_qr(self.h, set_index, int(center)), "normalize_qr")
+
+    def apply_single(self, site: int, matrix: np.ndarray, set_index: int = 0):
+        m = np.ascontiguousarray(matrix, dtype=np.complex128)
+        _lib.check(self.lib.tjm_engine_apply_single(self.h, set_index, int(site), m.ctypes.data), "apply_single")
+
+    def tebd_gate(self, left: int, u4: np.ndarray, set_index: int = 0):
+        u = np.ascontiguousarray(np.asarray(u4, dtype=np.complex128).reshape(4, 4))
+        _lib.check(self.lib.tjm_engine_tebd_gate(self.h, set_index, int(left), u.ctypes.data), "tebd_gate")
+
     def stochastic(self, dt: float, set_index: int = 0):
         jumped = np.zeros(self.B, dtype=np.int32)
         dp = np.zeros(self.B)

@@ -172,6 +172,68 @@ class TrajectoryBatch:
             sample(j)
 
 
+class DigitalBatch:
+    """``digital_tjm`` (digital/digital_tjm.py:636-749) for a batch of trajectories: pre-compiled gate layers of
+    single-qubit gates and nearest-neighbour two-qubit gates (TEBD), local noise after every two-qubit gate with dt = 1."""
+
+    def __init__(self, engine: BatchEngine, params, noise: NoiseModel | None):
+        self.e = engine
+        self.p = params
+        self.noise = noise if (noise is not None and noise.processes) else None
+        self.noisy = self.noise is not None and any(q["strength"] != 0 for q in self.noise.processes)
+        engine.set_params(dt=1.0, svd_threshold=params.svd_threshold, trunc_mode=params.trunc_mode, max_bond_dim=params.max_bond_dim,
+                          krylov_tol=1e-4)
+        procs = self.noise.processes if self.noise is not None else []
+        engine.set_noise(procs, [is_pauli(q) for q in procs])
+        self.procs = procs
+        self.sorted_obs = params.sorted_observables
+        self.two_site_obs = any(isinstance(o.sites, (list, tuple)) and len(o.sites) == 2 for o in params.observables)
+        self.jump_log: list[np.ndarray] = []
+
+    _measure = TrajectoryBatch._measure
+
+    def run(self, traj_indices: Sequence[int], initial: MPS, layers):
+        e, p = self.e, self.p
+        assert len(traj_indices) == e.B
+        n_gates = sum(len(l.even) + len(l.odd) for l in layers)
+        mid = p.num_mid_measurements if p.sample_layers else 0
+        cols = (mid + 2) if p.sample_layers else 1
+        results = np.zeros((e.B, len(self.sorted_obs), cols))
+        diagnostics = np.zeros((e.B, 3, cols))
+        e.load_state(initial.tensors, 0)
+        if p.sample_layers:
+            self._measure(0, results, diagnostics, 0)
+        u = np.stack([trajectory_uniforms(p.random_seed, int(t), 2 * n_gates + 2) for t in traj_indices])
+        pos = np.zeros(e.B, dtype=np.int64)
+        rows = np.arange(e.B)
+        col = 0
+        for layer in layers:
+            for site, m in layer.singles:
+                e.apply_single(site, m)
+            for group in (layer.even, layer.odd):
+                for left, u4 in group:
+                    e.tebd_gate(left, u4)
+                    if not self.noisy:
+                        e.normalize_qr(left + 1)
+                        continue
+                    local = [k for k, q in enumerate(self.procs) if set(q["sites"]).issubset({left, left + 1})]  # digital_tjm.py:187-204
+                    e.set_noise_filter(local)
+                    e.dissipate_from(1.0, left + 1)
+                    e.set_uniforms(np.stack([u[rows, pos], u[rows, pos + 1]], axis=1))
+                    jumped, _ = e.stochastic(1.0)
+                    if not local:
+                        jumped[:] = 0  # an empty local model can only renormalise (stochastic_process.py:236-243)
+                    self.jump_log.append(jumped.copy())
+                    pos += 1 + jumped
+            if p.sample_layers:
+                for _ in range(layer.sample_points):
+                    col += 1
+                    self._measure(0, results, diagnostics, col)
+        e.set_noise_filter(None)
+        self._measure(0, results, diagnostics, cols - 1)
+        return results, diagnostics
+
+
 class Simulator:
     """``Simulator().run(state, hamiltonian, sim_params, noise_model) -> Result`` (simulator.py:1173-1312).
 
