@@ -526,6 +526,15 @@ __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int w
     yI[c] = Yb[(long)(I * 16 + c) * rtot];
     yJ[c] = Yb[(long)(J * 16 + c) * rtot];
   }
+  // the 256 rotation records (c, sr, si) are spread over the lanes (4 records per lane) and broadcast with v_readlane
+  double pc[4], psr[4], psi[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double* r4 = rec + (long)(threadIdx.x + 64 * q) * 4;
+    pc[q] = r4[0];
+    psr[q] = r4[1];
+    psi[q] = r4[2];
+  }
 #pragma unroll
   for (int s = 0; s < NB; ++s)
 #pragma unroll
@@ -534,8 +543,10 @@ __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int w
       for (int w = 0; w < NB; ++w)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const double* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + h) * 4);
-          const double c = r4[0], sr = r4[1], si = r4[2];
+          const int ridx = ((s * 2 + sub) * NB + w) * 2 + h;   // compile-time constant after unrolling
+          const double c = lane_value(pc[ridx >> 6], ridx & 63);
+          const double sr = lane_value(psr[ridx >> 6], ridx & 63);
+          const double si = lane_value(psi[ridx >> 6], ridx & 63);
           // wavefront w rotated its I column 2w+h with the J column that started in wavefront (w+s) mod 8
           rotate_pair(yI[2 * w + h], yJ[2 * ((w + s) & (NB - 1)) + (h ^ sub)], c, sr, si);
         }
