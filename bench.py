@@ -73,6 +73,22 @@ def cpu_baseline(L, chi, tol):
     }
 
 
+def pmc_traffic(L, chi, B):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    separate FETCH_SIZE and WRITE_SIZE runs of this script, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    PMC counters cannot be read from inside the timed run, so the number is only reported for the configuration it was
+    collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except OSError:
+        return None, "no PMC summary committed"
+    if (rec.get("L"), rec.get("chi"), rec.get("batch")) != (L, chi, B):
+        return None, "PMC summary was collected on a different configuration"
+    return rec["traffic_bytes_per_launch"], rec["note"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +175,7 @@ def main():
         value = total_traj * K / STEPS_PER_TRAJ / elapsed
         site_updates = total_traj * K * (2 * L - 3) / elapsed
         achieved = (nbytes.value / 1e9) / (ms.value / 1e3) if ms.value > 0 else None
+        traffic, traffic_note = pmc_traffic(L, chi, B)
         out = {
             "metric": "trajectories/sec",
             "value": value,
@@ -184,12 +201,13 @@ def main():
             "mean_Z_site0": float(zsum[0] / total_traj),
             "roofline": {
                 "bound": "hbm",
-                "kernel": "jacobi_cross_kernel (block-pair step of the batched one-sided Jacobi SVD)",
+                "kernel": "jacobi_cross16x_kernel (X-rows block-pair step of the batched one-sided Jacobi SVD)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "avg_launch_us": (1e3 * ms.value / ns.value) if ns.value else None,
                 "launches_sampled": int(ns.value),
             },

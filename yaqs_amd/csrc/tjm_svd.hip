@@ -948,7 +948,6 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   const bool split16 = tile16 && !no_split && rx_top == 64 * XRK && ncols_pad % 64 == 0 && w.rec != nullptr && src.nb0 <= 65535;
   const size_t lds16x = (size_t)2 * NB * 64 * XRK * sizeof(cplx) + 2 * NB * sizeof(double) + 16 * sizeof(int);
   g.rec = w.rec;
-  const double tile_bytes = (tile16 ? 4.0 : 2.0) * NB * rtot * sizeof(cplx) * 2.0;  // columns of the tile, read + written
   const int max_sweeps = 40;
   int sweep = 0;
   int n_live = src.nb0;
@@ -966,7 +965,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     for (int r = 0; r < nrounds; ++r) {
       g.round = r;
       ++g.clock;
-      const bool timed = g_prof.every > 0 && (g_prof.counter++ % g_prof.every == 0);
+      const bool timed = g_prof.every > 0 && split16 && (g_prof.counter++ % g_prof.every == 0);  // only the dominant (split X) kernel is sampled
       int slot = -1;
       if (timed) {
         slot = (int)g_prof.used++;
@@ -979,14 +978,13 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
       }
       if (split16) {
         hipLaunchKernelGGL(jacobi_cross16x_kernel, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
+        if (timed) {  // the timed kernel is the X-rows kernel alone: its tile is the X part of the 32 columns, read + written once
+          TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot + 1], s));
+          g_prof.pending.emplace_back(slot, (double)npairs * n_live * 4.0 * NB * rx_top * sizeof(cplx) * 2.0);
+        }
         hipLaunchKernelGGL(jacobi_cross16w_kernel, dim3(npairs, ncols_pad / 64, src.nb0), dim3(64), 0, s, g, rx_top);
       } else if (tile16) hipLaunchKernelGGL(jacobi_cross16_kernel, dim3(npairs, src.nb0), dim3(512), lds16, s, g);
       else hipLaunchKernelGGL(jacobi_cross_kernel, dim3(npairs, src.nb0), dim3(512), lds, s, g);
-      if (timed) {
-        TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot + 1], s));
-        // algorithmic bytes: every column of the stacked [X; W] tile of a still-iterating trajectory is read once and written once
-        g_prof.pending.emplace_back(slot, (double)npairs * n_live * tile_bytes);
-      }
     }
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 2 * sizeof(int), s));
     hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tb), dim3(256), 0, s, w.nrot, w.done, w.n_active, src.nb0, src.ids);
