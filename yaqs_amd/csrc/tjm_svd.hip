@@ -94,6 +94,31 @@ __device__ inline double wave_sum(double v) {
   return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
+// sum over lanes l ^ 16 and l ^ 32 with the gfx950 row / half-wave swap instructions (pure VALU, no LDS crossbar)
+__device__ inline double xor16_sum(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ inline double xor32_sum(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+
+// Four wavefront sums for the price of two: a halving butterfly.  On return lane l holds the total of p[l & 3].
+__device__ inline double wave_sum4(double p0, double p1, double p2, double p3, int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2;
+  const double x01 = (b0 ? p1 : p0) + dpp_pull<0xB1>(b0 ? p0 : p1);
+  const double x23 = (b0 ? p3 : p2) + dpp_pull<0xB1>(b0 ? p2 : p3);
+  double y = (b1 ? x23 : x01) + dpp_pull<0x4E>(b1 ? x01 : x23);
+  y += dpp_pull<0x124>(y);  // row_ror:4
+  y += dpp_pull<0x128>(y);  // row_ror:8
+  return xor32_sum(xor16_sum(y));
+}
+
 // fp64 reciprocal square root: hardware estimate + two Newton steps (full double precision)
 __device__ inline double fast_rsqrt(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -129,6 +154,30 @@ __device__ inline bool make_rotation(double a, double d, double gx, double gy, d
   si = s * gy * inv_mag;
   tg = t * mag;
   return true;
+}
+
+// The same decision and rotation, evaluated per lane for wave_sum4 output: lane classes (0,1) carry (Re g, Im g) of
+// the first pair, classes (2,3) of the second.  own = this lane's component of g; (a, d) the norms of its pair.
+// Returns c, sv = s * own / |g| (Re s on even lanes, Im s on odd lanes) and tg; (1, 0, 0) when no rotation applies.
+__device__ inline void make_rotation_lanes(double a, double d, double own, double tol2, double nfloor, double& c, double& sv, double& tg) {
+  const double sq = own * own;
+  const double mag2 = sq + dpp_pull<0xB1>(sq);  // identical in both lanes of the pair (addition commutes)
+  const double big = fmax(a, d);
+  const bool rot = mag2 > tol2 * a * d && mag2 > 1e-30 * big * big && a > nfloor && d > nfloor && mag2 > 1e-300;
+  const double inv_mag = fast_rsqrt(mag2);
+  const double mag = mag2 * inv_mag;
+  const double tau = 0.5 * (d - a) * inv_mag;
+  const double h2 = fma(tau, tau, 1.0);
+  const double hyp = h2 * fast_rsqrt(h2);
+  const double den = fabs(tau) + hyp;
+  double t = __builtin_amdgcn_rcp(den);
+  t = t * fma(-den, t, 2.0);
+  t = t * fma(-den, t, 2.0);
+  t = (tau >= 0.0) ? t : -t;
+  const double cc = fast_rsqrt(fma(t, t, 1.0));
+  c = rot ? cc : 1.0;
+  sv = rot ? t * cc * own * inv_mag : 0.0;
+  tg = rot ? t * mag : 0.0;
 }
 
 __device__ inline void rotate_pair(cplx& p, cplx& q, double c, double sr, double si) {
@@ -446,24 +495,27 @@ __global__ __launch_bounds__(512, 4) void jacobi_cross16x_kernel(JacobiArgs g) {
           gy[h] = fma(yI[h][k].x, yJ[hj][k].y, fma(-yI[h][k].y, yJ[hj][k].x, gy[h]));
         }
       }
-      gx[0] = wave_sum(gx[0]); gy[0] = wave_sum(gy[0]);
-      gx[1] = wave_sum(gx[1]); gy[1] = wave_sum(gy[1]);
+      // both inner products reduced together; both rotations computed side by side in lanes 0..3
+      const double gsum = wave_sum4(gx[0], gy[0], gx[1], gy[1], lane);
+      const bool second = lane & 2;
+      double cv, sv, tv;
+      make_rotation_lanes(second ? nI[1] : nI[0], second ? nJ[1 ^ sub] : nJ[sub], gsum, g.tol2, floor2, cv, sv, tv);
+      if (lane < 4) {
+        double* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + (lane >> 1)) * 4);
+        if (lane & 1) r4[2] = sv;
+        else { r4[0] = cv; r4[1] = sv; }
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int hj = h ^ sub;
-        double c = 1.0, sr = 0.0, si = 0.0, tg;
-        if (make_rotation(nI[h], nJ[hj], gx[h], gy[h], g.tol2, floor2, c, sr, si, tg)) {
+        const double sr = lane_value(sv, 2 * h), si = lane_value(sv, 2 * h + 1);
+        if (sr != 0.0 || si != 0.0) {
+          const double c = lane_value(cv, 2 * h), tg = lane_value(tv, 2 * h);
 #pragma unroll
           for (int k = 0; k < XRK; ++k) rotate_pair(yI[h][k], yJ[hj][k], c, sr, si);
           nI[h] -= tg;
           nJ[hj] += tg;
           ++cnt;
-        } else {
-          c = 1.0; sr = 0.0; si = 0.0;
-        }
-        if (lane == 0) {
-          double* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + h) * 4);
-          r4[0] = c; r4[1] = sr; r4[2] = si;
         }
       }
     }
