@@ -9,6 +9,7 @@
 // Structure: panels of 16 columns.  qr_panel_kernel factors one panel in LDS (one workgroup per trajectory),
 // builds the triangular T of the compact WY form and writes the reflector block V with explicit zeros / unit
 // diagonal; the trailing update and the application of Q are three launches of the batched MFMA zgemm each.
+#include <cstdlib>
 #include <cstring>
 
 #include "tjm_kernels.h"
@@ -191,6 +192,182 @@ __global__ __launch_bounds__(64) void qr_panel_kernel(cplx* __restrict__ A, long
   }
   cplx* Tp = Tb + (long)b * t_b0 + (long)panel * PW * PW;
   for (int t = lane; t < PW * PW; t += 64) Tp[t] = sT[t];
+}
+
+// Row-resident panel factorisation: 256 threads, thread t keeps rows t, t + 256, ... of the 16 panel columns in
+// registers.  One step needs ONE workgroup reduction: with a_j the not yet scaled column j, every inner product of the
+// step follows from raw sums over the rows below j,
+//   xn2 = sum |a_j|^2,   d_l = sum conj(v_l) a_j  (l < j, for T),   e_c = sum conj(a_j) a_c  (c > j, for the update),
+// because v_j = scale * a_j below the diagonal: v_j^H a_c = conj(scale) e_c + a_c[j],  v_l^H v_j = scale d_l + conj(v_l[j]).
+// The 31 partial sums are transposed through LDS ([value][thread]), 8 threads add 32 entries each per value, a DPP
+// butterfly joins them.  Row j of the panel (alpha, a_c[j], v_l[j]) is broadcast through LDS by its owner.
+constexpr int NRED = 2 * PW;          // slot 0: xn2, slots 1..15: Re, 17..31: Im of the 15 complex sums (slot 16 unused)
+constexpr int RED_PITCH = 256 + 1;
+
+template <int RPT>
+__global__ __launch_bounds__(256) void qr_panel_rows_kernel(cplx* __restrict__ A, long a_b0, int zr, int k0, int pw, cplx* __restrict__ Vb,
+                                                           long v_b0, cplx* __restrict__ Tb, long t_b0, int panel, const int* ids) {
+  extern __shared__ double smem[];
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  const int tid = threadIdx.x;
+  const int mp = zr - k0;
+  double* sPart = smem;                                           // [NRED][RED_PITCH]
+  double* sRed = sPart + NRED * RED_PITCH;                        // [2][NRED]
+  cplx* sRow = reinterpret_cast<cplx*>(sRed + 2 * NRED);          // [2][PW]
+  cplx* sG = sRow + 2 * PW;                                       // [PW][PW]
+  cplx* sT = sG + PW * PW;                                        // [PW][PW]
+  cplx* sTau = sT + PW * PW;                                      // [PW]
+  double* sBeta = reinterpret_cast<double*>(sTau + PW);           // [PW]
+  cplx* Ab = A + (long)b * a_b0;
+
+  cplx P[PW][RPT];
+#pragma unroll
+  for (int c = 0; c < PW; ++c)
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + 256 * q;
+      P[c][q] = (c < pw && r < mp) ? Ab[(long)(k0 + c) * zr + k0 + r] : cplx{0.0, 0.0};
+    }
+  for (int t = tid; t < PW * PW; t += 256) { sG[t] = cplx{0.0, 0.0}; sT[t] = cplx{0.0, 0.0}; }
+  if (tid < PW) { sTau[tid] = cplx{0.0, 0.0}; sBeta[tid] = 0.0; }
+
+#pragma unroll
+  for (int j = 0; j < PW; ++j) {
+    if (j < pw && j < mp) {   // uniform
+      const int buf = j & 1;
+      // ---- partial sums over this thread's rows below j
+      double part[NRED];
+#pragma unroll
+      for (int v = 0; v < NRED; ++v) part[v] = 0.0;
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        const int r = tid + 256 * q;
+        if (r > j && r < mp) {
+          const cplx aj = P[j][q];
+          part[0] = fma(aj.x, aj.x, fma(aj.y, aj.y, part[0]));
+#pragma unroll
+          for (int c = 0; c < PW; ++c) {
+            if (c == j) continue;
+            const cplx x = P[c][q];
+            const int slot = (c < j) ? c + 1 : c;   // 1..15
+            if (c < j) {  // conj(v_l) * a_j
+              part[slot] = fma(x.x, aj.x, fma(x.y, aj.y, part[slot]));
+              part[slot + PW] = fma(x.x, aj.y, fma(-x.y, aj.x, part[slot + PW]));
+            } else {      // conj(a_j) * a_c
+              part[slot] = fma(aj.x, x.x, fma(aj.y, x.y, part[slot]));
+              part[slot + PW] = fma(aj.x, x.y, fma(-aj.y, x.x, part[slot + PW]));
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < NRED; ++v) sPart[v * RED_PITCH + tid] = part[v];
+      if (tid == (j & 255)) {
+#pragma unroll
+        for (int c = 0; c < PW; ++c) sRow[buf * PW + c] = P[c][(RPT > 1) ? (j >> 8) : 0];
+      }
+      __syncthreads();
+      {
+        const int v = tid >> 3, seg = tid & 7;
+        const double* src = sPart + v * RED_PITCH + seg * 32;
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc += src[(i + 4 * seg) & 31];
+        acc += dpp_pull<0xB1>(acc);
+        acc += dpp_pull<0x4E>(acc);
+        acc += dpp_pull<0x141>(acc);
+        if (seg == 0) sRed[buf * NRED + v] = acc;
+      }
+      __syncthreads();
+      // ---- zlarfg (every thread, redundantly)
+      const double xn2 = sRed[buf * NRED];
+      const cplx alpha = sRow[buf * PW + j];
+      cplx tau{0.0, 0.0}, scale{0.0, 0.0};
+      double bt = alpha.x;
+      if (xn2 > 0.0 || alpha.y != 0.0) {
+        const double an = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xn2);
+        bt = (alpha.x >= 0.0) ? -an : an;
+        tau = cplx{(bt - alpha.x) / bt, -alpha.y / bt};
+        const cplx dnm{alpha.x - bt, alpha.y};
+        const double d2 = dnm.x * dnm.x + dnm.y * dnm.y;
+        scale = cplx{dnm.x / d2, -dnm.y / d2};
+      }
+      if (tid == 0) { sTau[j] = tau; sBeta[j] = bt; }
+      if (tid < j) {  // Gram entry for T: v_l^H v_j = scale * d_l + conj(v_l[j])
+        const cplx dl{sRed[buf * NRED + tid + 1], sRed[buf * NRED + tid + 1 + PW]};
+        const cplx vlj = sRow[buf * PW + tid];
+        cplx gv = cmul(scale, dl);
+        gv.x += vlj.x;
+        gv.y -= vlj.y;
+        sG[tid * PW + j] = gv;
+      }
+      // ---- v_j, then H^H = I - conj(tau) v v^H on the remaining panel columns
+      cplx wv[PW];
+#pragma unroll
+      for (int c = 0; c < PW; ++c) {
+        if (c > j) {
+          const cplx e{sRed[buf * NRED + c], sRed[buf * NRED + c + PW]};
+          const cplx acj = sRow[buf * PW + c];
+          cplx t = cmul(cconj(scale), e);
+          t.x += acj.x;
+          t.y += acj.y;
+          wv[c] = cmul(cconj(tau), t);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < RPT; ++q) {
+        const int r = tid + 256 * q;
+        if (r >= j && r < mp) {
+          const cplx vv = (r == j) ? cplx{1.0, 0.0} : cmul(P[j][q], scale);
+          P[j][q] = vv;
+#pragma unroll
+          for (int c = 0; c < PW; ++c) {
+            if (c > j) {
+              P[c][q].x -= wv[c].x * vv.x - wv[c].y * vv.y;
+              P[c][q].y -= wv[c].x * vv.y + wv[c].y * vv.x;
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < pw) sT[tid * PW + tid] = sTau[tid];
+  __syncthreads();
+  // ---- T (zlarft forward / columnwise); thread i builds row i of column j
+  for (int j = 1; j < pw; ++j) {
+    const cplx tj = sT[j * PW + j];
+    if (tid < j) {
+      cplx accv{0.0, 0.0};
+      for (int l = tid; l < j; ++l) cfma(accv, sT[tid * PW + l], sG[l * PW + j]);
+      sT[tid * PW + j] = cplx{-(tj.x * accv.x - tj.y * accv.y), -(tj.x * accv.y + tj.y * accv.x)};
+    }
+    __syncthreads();
+  }
+  // ---- write back: R part / reflectors into A, explicit V block (zeros above, unit diagonal), T
+  cplx* Vp = Vb + (long)b * v_b0 + (long)panel * PW * zr;
+#pragma unroll
+  for (int c = 0; c < PW; ++c) {
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+      const int r = tid + 256 * q;
+      if (r < mp) {
+        cplx v{0.0, 0.0};
+        if (c < pw) {
+          cplx a = P[c][q];
+          if (r == c) a = cplx{sBeta[c], 0.0};
+          Ab[(long)(k0 + c) * zr + k0 + r] = a;
+          if (r == c) v = cplx{1.0, 0.0};
+          else if (r > c) v = P[c][q];
+        }
+        Vp[(long)c * zr + k0 + r] = v;
+      }
+    }
+    for (int gr = tid; gr < k0; gr += 256) Vp[(long)c * zr + gr] = cplx{0.0, 0.0};
+  }
+  cplx* Tp = Tb + (long)b * t_b0 + (long)panel * PW * PW;
+  for (int t = tid; t < PW * PW; t += 256) Tp[t] = sT[t];
 }
 
 // Fused block reflector on a chunk of 16 columns of C (column-major, leading dimension zr), fp64 MFMA:
@@ -376,14 +553,26 @@ int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hip
   static bool attr_set = false;
   if (!attr_set) {
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
+  static const bool no_rows = getenv("TJM_QR_LDS_PANEL") != nullptr;
   int rc;
   int panel = 0;
   for (int k0 = 0; k0 < kmax; k0 += PW, ++panel) {
     const int pw = (kmax - k0 < PW) ? kmax - k0 : PW;
-    const size_t lds = (size_t)(PW * (zr - k0) + 2 * PW * PW + PW) * sizeof(cplx) + PW * sizeof(double) + 64;
-    hipLaunchKernelGGL(qr_panel_kernel, dim3(nb0), dim3(64), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
+    const int mp = zr - k0;
+    if (mp <= 512 && !no_rows) {  // rows of the panel in registers, 1 or 2 per thread
+      const size_t lds = (size_t)(NRED * RED_PITCH + 2 * NRED + PW) * sizeof(double) + (size_t)(2 * PW + 2 * PW * PW + PW) * sizeof(cplx);
+      if (mp <= 256)
+        hipLaunchKernelGGL(qr_panel_rows_kernel<1>, dim3(nb0), dim3(256), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
+      else
+        hipLaunchKernelGGL(qr_panel_rows_kernel<2>, dim3(nb0), dim3(256), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
+    } else {
+      const size_t lds = (size_t)(PW * (zr - k0) + 2 * PW * PW + PW) * sizeof(cplx) + PW * sizeof(double) + 64;
+      hipLaunchKernelGGL(qr_panel_kernel, dim3(nb0), dim3(64), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
+    }
     TJM_HIP_CHECK(hipGetLastError());
     const int col0 = k0 + pw;
     if ((rc = apply_block_reflector(q, zr, panel, true, q.Z, q.z_b0, col0, zc - col0, nb0, ids, s)) != TJM_OK) return rc;
