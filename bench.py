@@ -46,9 +46,9 @@ def build_inputs(L, chi):
     return mpo, st, noise
 
 
-def cpu_baseline(L, chi, tol):
-    """The CPU oracle (a NumPy/SciPy port of the reference path) on one host core, bounded sample:
-    ONE order-1 TJM step of ONE trajectory of the same workload, extrapolated to 10 steps per trajectory."""
+def _cpu_step(args):
+    """One order-1 TJM step of one trajectory on the CPU oracle; returns its own wall time."""
+    L, chi, tol, traj = args
     from oracle import tjm_oracle as o
 
     rng = np.random.default_rng(1)
@@ -60,16 +60,36 @@ def cpu_baseline(L, chi, tol):
     t0 = time.perf_counter()
     o.tdvp(st, mpo, p)
     o.apply_dissipation(st, noise, 0.1, p)
-    st = o.stochastic_process(st, noise, 0.1, p, o.trajectory_rng(42, 0))
-    dt = time.perf_counter() - t0
+    st = o.stochastic_process(st, noise, 0.1, p, o.trajectory_rng(42, traj))
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(L, chi, tol, procs):
+    """The CPU oracle (a NumPy/SciPy port of the reference path), run the way the reference runs: `procs` forked
+    single-BLAS-thread workers, one trajectory each (core/parallel_utils.py:331-390).  Bounded sample: ONE order-1 TJM
+    step per worker, extrapolated to 10 steps per trajectory.  Must run before anything touches the GPU (fork)."""
+    import multiprocessing as mp
+
+    ncpu = len(os.sched_getaffinity(0))
+    procs = max(1, min(procs, ncpu))
+    t0 = time.perf_counter()
+    if procs == 1:
+        per = [_cpu_step((L, chi, tol, 0))]
+    else:
+        with mp.get_context("fork").Pool(procs) as pool:
+            per = pool.map(_cpu_step, [(L, chi, tol, t) for t in range(procs)], chunksize=1)
+    wall = time.perf_counter() - t0
+    slowest = max(per)
     return {
-        "value": 1.0 / (STEPS_PER_TRAJ * dt),
+        "value": procs / (STEPS_PER_TRAJ * slowest),
         "unit": "trajectories/sec",
-        "cores": 1,
+        "cores": procs,
         "kind": "port",
-        "sample": f"1 TJM step (2-site TDVP + dissipation + jump) of 1 trajectory at L={L}, chi={chi}: {dt:.1f} s on 1 core, "
-                  f"x{STEPS_PER_TRAJ} steps per trajectory; host has {len(os.sched_getaffinity(0))} cores",
-        "seconds_per_step": dt,
+        "sample": f"1 TJM step (2-site TDVP + dissipation + jump) of 1 trajectory per worker at L={L}, chi={chi}, {procs} forked "
+                  f"single-thread workers side by side: slowest {slowest:.1f} s, fastest {min(per):.1f} s (wall {wall:.1f} s incl. set-up), "
+                  f"x{STEPS_PER_TRAJ} steps per trajectory; host has {ncpu} cores",
+        "seconds_per_step": slowest,
+        "per_core_value": 1.0 / (STEPS_PER_TRAJ * slowest),
     }
 
 
@@ -94,12 +114,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="trajectories resident per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="trajectories resident per GPU")
     ap.add_argument("--length", type=int, default=64)
     ap.add_argument("--chi", type=int, default=128)
     ap.add_argument("--krylov-tol", type=float, default=1e-4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-procs", type=int, default=32, help="forked single-thread CPU workers of the cpu_baseline leg (capped at the core count)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu_ref = None
+    if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu_ref = cpu_baseline(args.length, args.chi, args.krylov_tol, args.cpu_procs)  # before torch / HIP are initialised
 
     import torch
     import torch.distributed as dist
@@ -109,9 +137,6 @@ def main():
     from yaqs_amd.engine import BatchEngine
     from yaqs_amd.tjm import trajectory_uniforms
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -212,8 +237,8 @@ def main():
                 "launches_sampled": int(ns.value),
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(L, chi, args.krylov_tol)
+        if cpu_ref is not None:
+            out["cpu_baseline"] = cpu_ref
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -132,6 +132,8 @@ struct ExtractDesc {
   int row_off;
   int conj;
   int scale_mode;
+  const int* row_map = nullptr;  // optional: matrix row r goes to output row row_map[b * row_map_ld + r]
+  int row_map_ld = 0;
 };
 long svd_y_elems(int max_dim);  // complex elements of the stacked Jacobi matrix per trajectory
 size_t svd_workspace_bytes(int max_dim, int B);
@@ -151,9 +153,10 @@ struct QrWorkspace {
   long v_b0;
   cplx* T;   // [B][panels][16][16]
   long t_b0;
-  cplx* W1;  // [B][16][w_ld]
+  cplx* W1;  // [B][16][w_ld] scratch; its head holds the column order of the sorted QR (int[B][w_ld])
   cplx* W2;
   int w_ld;
+  int* colperm() const { return reinterpret_cast<int*>(W1); }
 };
 size_t qr_workspace_bytes(int max_dim, int B);
 int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s);

@@ -467,23 +467,67 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
 //   dist 1 -> Z = theta^H with rows re-ordered bond-major:  r' = c * d + t
 // Bond-major rows make the zero padding (bond index >= actual bond dimension) a SUFFIX of the row range, so every
 // Householder reflector stays inside the active rows and the padded rows of Q stay exactly untouched.
+// Order of the columns of Z by decreasing norm: cperm[j] = source column that becomes column j.  One workgroup per
+// trajectory; the rank of a column is the number of columns that precede it (ties broken by index: deterministic).
+__global__ __launch_bounds__(256) void qr_colsort_kernel(const cplx* __restrict__ theta, long th_b0, int m, int n, int dist, int* __restrict__ cperm,
+                                                        int ld, const int* ids) {
+  __shared__ double sn[512];
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  const cplx* th = theta + (long)b * th_b0;
+  const int tid = threadIdx.x;
+  const int zc = (dist == 0) ? n : m;
+  if (dist == 0) {  // column c of theta
+    for (int c = tid; c < zc; c += 256) {
+      double acc = 0.0;
+      for (int r = 0; r < m; ++r) {
+        const cplx v = th[(long)r * n + c];
+        acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+      }
+      sn[c] = acc;
+    }
+  } else {          // row i of theta, one wavefront per row
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int i = wave; i < zc; i += 4) {
+      double acc = 0.0;
+      for (int k = lane; k < n; k += 64) {
+        const cplx v = th[(long)i * n + k];
+        acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+      }
+      acc = wsum(acc);
+      if (lane == 0) sn[i] = acc;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < zc; c += 256) {
+    const double mine = sn[c];
+    int rank = 0;
+    for (int o = 0; o < zc; ++o) {
+      const double other = sn[o];
+      rank += (other > mine || (other == mine && o < c)) ? 1 : 0;
+    }
+    cperm[(long)b * ld + rank] = c;
+  }
+}
+
 __global__ __launch_bounds__(256) void qr_prepare_kernel(const cplx* __restrict__ theta, long th_b0, int m, int n, int dist, int d, cplx* __restrict__ Z,
-                                                        long z_b0, const int* ids) {
+                                                        long z_b0, const int* __restrict__ cperm, int perm_ld, const int* ids) {
   int b = blockIdx.y;
   if (ids) b = ids[b];
   const cplx* th = theta + (long)b * th_b0;
   cplx* Zb = Z + (long)b * z_b0;
+  const int* cp = cperm + (long)b * perm_ld;
   const long total = (long)m * n;
   const int capL = m / d, capR = n / d;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     if (dist == 0) {
       const long c = e / m, rp = e % m;            // Z(rp, c), rp = a * d + s
       const int a = (int)(rp / d), sph = (int)(rp % d);
-      Zb[e] = th[((long)sph * capL + a) * n + c];
+      Zb[e] = th[((long)sph * capL + a) * n + cp[c]];
     } else {
       const long i = e / n, rp = e % n;            // Z(rp, i) = conj(theta[i][(t,c)]), rp = c * d + t
       const int cc = (int)(rp / d), t = (int)(rp % d);
-      cplx v = th[i * n + (long)t * capR + cc];
+      cplx v = th[(long)cp[i] * n + (long)t * capR + cc];
       v.y = -v.y;
       Zb[e] = v;
     }
@@ -542,7 +586,9 @@ int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, con
   const long total = (long)m * n;
   int gx = (int)((total + 1023) / 1024);
   if (gx > 128) gx = 128;
-  hipLaunchKernelGGL(qr_prepare_kernel, dim3(gx, nb0), dim3(256), 0, s, theta, th_b0, m, n, dist, d, q.Z, q.z_b0, ids);
+  if ((dist == 0 ? n : m) > 512 || (dist == 0 ? n : m) > q.w_ld) return TJM_ERR_NOT_IMPLEMENTED;
+  hipLaunchKernelGGL(qr_colsort_kernel, dim3(nb0), dim3(256), 0, s, theta, th_b0, m, n, dist, q.colperm(), q.w_ld, ids);
+  hipLaunchKernelGGL(qr_prepare_kernel, dim3(gx, nb0), dim3(256), 0, s, theta, th_b0, m, n, dist, d, q.Z, q.z_b0, q.colperm(), q.w_ld, ids);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
