@@ -173,16 +173,8 @@ static int svd_split_impl(bool use_qr, const void* theta, int32_t B, int32_t d, 
   QrWorkspace qw;
   std::memset(&qw, 0, sizeof(qw));
   if (use_qr) {
-    const int npan = mx / 16 + 1;
-    qw.z_b0 = (long)mx * mx;
-    qw.Z = reinterpret_cast<cplx*>(take((size_t)B * qw.z_b0 * sizeof(cplx)));
-    qw.v_b0 = (long)npan * 16 * mx;
-    qw.V = reinterpret_cast<cplx*>(take((size_t)B * qw.v_b0 * sizeof(cplx)));
-    qw.t_b0 = (long)npan * 256;
-    qw.T = reinterpret_cast<cplx*>(take((size_t)B * qw.t_b0 * sizeof(cplx)));
-    qw.w_ld = mx;
-    qw.W1 = reinterpret_cast<cplx*>(take((size_t)B * 16 * mx * sizeof(cplx)));
-    qw.W2 = reinterpret_cast<cplx*>(take((size_t)B * 16 * mx * sizeof(cplx)));
+    char* qbase = take(qr_workspace_bytes(mx, B));
+    qr_carve(qw, qbase, mx, B);
   }
   SvdSplitDesc s;
   s.theta = static_cast<const cplx*>(theta); s.theta_b0 = (long)m * n; s.ld_theta = n; s.m = m; s.n = n; s.d = d;

@@ -142,16 +142,8 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   svdw.n_active = reinterpret_cast<int*>(take(256));
   {
     const int md = d * cm;
-    const int npan = md / 16 + 1;
-    qrw.z_b0 = (long)md * md;
-    qrw.Z = reinterpret_cast<cplx*>(take((size_t)B * qrw.z_b0 * sizeof(cplx)));
-    qrw.v_b0 = (long)npan * 16 * md;
-    qrw.V = reinterpret_cast<cplx*>(take((size_t)B * qrw.v_b0 * sizeof(cplx)));
-    qrw.t_b0 = (long)npan * 256;
-    qrw.T = reinterpret_cast<cplx*>(take((size_t)B * qrw.t_b0 * sizeof(cplx)));
-    qrw.w_ld = md;
-    qrw.W1 = reinterpret_cast<cplx*>(take((size_t)B * 16 * md * sizeof(cplx)));
-    qrw.W2 = reinterpret_cast<cplx*>(take((size_t)B * 16 * md * sizeof(cplx)));
+    char* qbase = take(qr_workspace_bytes(md, B));
+    qr_carve(qrw, qbase, md, B);
   }
   part1_ = reinterpret_cast<double*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));
   part2_ = reinterpret_cast<double*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));

@@ -156,8 +156,14 @@ struct QrWorkspace {
   cplx* W1;  // [B][16][w_ld] scratch; its head holds the column order of the sorted QR (int[B][w_ld])
   cplx* W2;
   int w_ld;
+  cplx* Z2 = nullptr;  // second factorisation (R^H = Q1 R1) of the doubly preconditioned split: same shapes as Z / V / T
+  cplx* V2 = nullptr;
+  cplx* T2 = nullptr;
   int* colperm() const { return reinterpret_cast<int*>(W1); }
+  QrWorkspace second() const { QrWorkspace q = *this; q.Z = Z2; q.V = V2; q.T = T2; return q; }
 };
+size_t qr_carve(QrWorkspace& q, char* base, int max_dim, int B);  // lays the buffers out behind base, returns the bytes used
+int qr_adjoint_triangle(const QrWorkspace& q, int n, int nb0, const int* ids, hipStream_t s);  // Z2 = R^H of the factored Z
 size_t qr_workspace_bytes(int max_dim, int B);
 int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s);
 int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hipStream_t s);

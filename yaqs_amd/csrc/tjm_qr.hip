@@ -547,7 +547,8 @@ __global__ __launch_bounds__(256) void qr_scatter_kernel(const cplx* __restrict_
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int k = (int)(e / nrows);
     const long r = e % nrows;
-    const int r1 = (int)(r / x.n_r0), r0 = (int)(r % x.n_r0);
+    const long ro = x.row_map ? x.row_map[(long)b * x.row_map_ld + r] : r;
+    const int r1 = (int)(ro / x.n_r0), r0 = (int)(ro % x.n_r0);
     cplx v{0.0, 0.0};
     if (k < keep) {
       v = ib[(long)k * ld + r];
@@ -576,10 +577,54 @@ int apply_block_reflector(const QrWorkspace& q, int zr, int panel, bool t_herm, 
 
 }  // namespace
 
+namespace {
+// Z2 (n x n, column-major) = R^H where R is the upper triangle of the factored Z (leading dimension n)
+__global__ __launch_bounds__(256) void qr_adjoint_triangle_kernel(const cplx* __restrict__ Z, long z_b0, cplx* __restrict__ Z2, int n, const int* ids) {
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  const cplx* Zb = Z + (long)b * z_b0;
+  cplx* Ob = Z2 + (long)b * z_b0;
+  const long total = (long)n * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e / n), r = (int)(e % n);  // R^H[r][c] = conj(R[c][r]) , R[c][r] = Z[r * n + c] for c <= r
+    cplx v{0.0, 0.0};
+    if (r >= c) { v = Zb[(long)r * n + c]; v.y = -v.y; }
+    Ob[e] = v;
+  }
+}
+}  // namespace
+
+int qr_adjoint_triangle(const QrWorkspace& q, int n, int nb0, const int* ids, hipStream_t s) {
+  const long total = (long)n * n;
+  int gx = (int)((total + 1023) / 1024);
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(qr_adjoint_triangle_kernel, dim3(gx, nb0), dim3(256), 0, s, q.Z, q.z_b0, q.Z2, n, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+size_t qr_carve(QrWorkspace& q, char* base, int max_dim, int B) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; };
+  const int npan = max_dim / PW + 1;
+  q.z_b0 = (long)max_dim * max_dim;
+  q.v_b0 = (long)npan * PW * max_dim;
+  q.t_b0 = (long)npan * PW * PW;
+  q.w_ld = max_dim;
+  q.Z = reinterpret_cast<cplx*>(take((size_t)B * q.z_b0 * sizeof(cplx)));
+  q.V = reinterpret_cast<cplx*>(take((size_t)B * q.v_b0 * sizeof(cplx)));
+  q.T = reinterpret_cast<cplx*>(take((size_t)B * q.t_b0 * sizeof(cplx)));
+  q.W1 = reinterpret_cast<cplx*>(take((size_t)B * PW * max_dim * sizeof(cplx)));
+  q.W2 = nullptr;
+  q.Z2 = reinterpret_cast<cplx*>(take((size_t)B * q.z_b0 * sizeof(cplx)));
+  q.V2 = reinterpret_cast<cplx*>(take((size_t)B * q.v_b0 * sizeof(cplx)));
+  q.T2 = reinterpret_cast<cplx*>(take((size_t)B * q.t_b0 * sizeof(cplx)));
+  return off;
+}
+
 size_t qr_workspace_bytes(int max_dim, int B) {
-  const size_t mat = (size_t)max_dim * max_dim * sizeof(cplx);
-  const size_t vb = (size_t)(max_dim / PW + 1) * PW * max_dim * sizeof(cplx);
-  return (size_t)B * (mat + vb + (size_t)(max_dim / PW + 1) * PW * PW * sizeof(cplx) + 2 * (size_t)PW * max_dim * sizeof(cplx)) + 16384;
+  QrWorkspace q;
+  return qr_carve(q, nullptr, max_dim, B) + 4096;
 }
 
 int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s) {
