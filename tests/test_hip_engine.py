@@ -285,3 +285,28 @@ def test_digital_tebd_trajectories_match_reference_fixture():
     assert np.array(db.jump_log).sum() > 0
     assert np.allclose(r[:, :, 0], g["strong_results"][:, :, 0], atol=1e-8)
     assert np.array_equal(d, g["strong_diag"])
+
+
+def test_chi256_heisenberg_lowering_step_matches_oracle():
+    """Config-3-like step in fp64 at the largest supported bond: Heisenberg D=5 MPO, `lowering` (non-Pauli) noise on every
+    site, chi = 256, so the two-site split is 512 x 512 (split X / W Jacobi with 8 row groups, doubly QR-preconditioned)
+    and the dissipation / jump shifts are 512 x 256."""
+    from yaqs_amd.api import AnalogSimParams, NoiseModel, Observable, Z as Zg
+
+    L, chi = 18, 256
+    rng = np.random.default_rng(7)
+    st = o.MPSState.haar(L, chi, rng)
+    st.normalize("B")
+    init = [t.copy() for t in st.tensors]
+    mpo = o.heisenberg_mpo(L, 1.0, 1.0, 0.5, 0.0)
+    noise = NoiseModel([{"name": "lowering", "sites": [i], "strength": 0.05} for i in range(L)])
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=0.05, dt=0.05, max_bond_dim=chi, svd_threshold=1e-12,
+                        krylov_tol=1e-10, order=1, sample_timesteps=True, random_seed=42)
+    r, d, tb = _run(L, init, noise, p, mpo, [0, 1])
+    on = [o.make_process("lowering", [i], 0.05) for i in range(L)]
+    op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], elapsed_time=0.05, dt=0.05, max_bond_dim=chi, svd_threshold=1e-12, krylov_tol=1e-10,
+                  random_seed=42, sample_timesteps=True)
+    for t in range(2):
+        rr, dd, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, mpo)
+        assert np.allclose(r[t], rr, atol=1e-8), np.abs(r[t] - rr).max()
+        assert np.array_equal(d[t], dd)

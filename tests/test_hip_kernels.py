@@ -244,3 +244,57 @@ def test_svd_split_qr_graded_full_size(lib, dist):
             assert np.allclose(iso.conj().T @ iso, np.eye(cap), atol=1e-12)
     print("sweeps plain", out[False], "qr", out[True])
     assert out[True] < out[False]
+
+
+@pytest.mark.parametrize("qr,dist", [(False, 0), (True, 0), (True, 1)])
+def test_svd_split_chi256_full_size(lib, qr, dist):
+    """d*chi = 512: the largest two-site split the register-resident Jacobi holds (16 row groups per stacked column,
+    8 per X column in the split scheme); graded spectrum, truncation to chi = 256."""
+    rng = np.random.default_rng(31 + dist)
+    d, cap, B = 2, 256, 2
+    n = d * cap
+    theta = np.zeros((B, n, n), dtype=np.complex128)
+    svs = []
+    for b in range(B):
+        u = np.linalg.qr(crand(rng, n, n))[0]
+        v = np.linalg.qr(crand(rng, n, n))[0]
+        s = np.sort(np.concatenate([np.linspace(1.0, 0.05, cap), 10.0 ** rng.uniform(-7, -2, cap)]))[::-1]
+        svs.append(s)
+        theta[b] = (u * s) @ v.conj().T
+    chi = np.full(B, cap, dtype=np.int32)
+    left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, cap, cap, cap, dist, 0, 1e-12, cap, 2, chi, chi, qr=qr)
+    print("sweeps", sweeps, "qr", qr)
+    for b in range(B):
+        assert keep[b] == cap
+        assert np.allclose(spec[b, :n], svs[b], atol=1e-12)
+        L_ = left[b].reshape(n, cap)
+        R_ = right[b].transpose(1, 0, 2).reshape(cap, n)
+        ref_u, ref_s, ref_vh = np.linalg.svd(theta[b])
+        trunc = (ref_u[:, :cap] * ref_s[:cap]) @ ref_vh[:cap]
+        assert np.allclose(L_ @ R_, trunc, atol=1e-10)
+        iso = L_ if dist == 0 else R_.conj().T
+        assert np.allclose(iso.conj().T @ iso, np.eye(cap), atol=1e-12)
+    assert sweeps < 40
+
+
+@pytest.mark.parametrize("capL,capR", [(256, 128), (128, 256), (200, 200), (256, 64)])
+def test_svd_split_large_rectangular_and_odd_sizes(lib, capL, capR):
+    """Shapes next to the bond cap and bond dimensions that are not powers of two (generic 8-column path at > 512 rows)."""
+    rng = np.random.default_rng(capL + capR)
+    d, B = 2, 2
+    m, n = d * capL, d * capR
+    capM = min(m, n, 256)
+    theta = crand(rng, B, m, n) / np.sqrt(m * n)
+    chiL = np.full(B, capL, dtype=np.int32)
+    chiR = np.full(B, capR, dtype=np.int32)
+    for qr in (False, True):
+        left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, capL, capR, capM, 0, 0, 1e-12, capM, 2, chiL, chiR, qr=qr)
+        for b in range(B):
+            ref_u, ref_s, ref_vh = np.linalg.svd(theta[b], full_matrices=False)
+            assert keep[b] == capM
+            assert np.allclose(spec[b, : len(ref_s)], ref_s, atol=1e-12)
+            L_ = left[b].reshape(m, capM)
+            R_ = right[b].transpose(1, 0, 2).reshape(capM, n)
+            trunc = (ref_u[:, :capM] * ref_s[:capM]) @ ref_vh[:capM]
+            assert np.allclose(L_ @ R_, trunc, atol=1e-11)
+            assert np.allclose(L_.conj().T @ L_, np.eye(capM), atol=1e-12)

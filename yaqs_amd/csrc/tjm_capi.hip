@@ -153,20 +153,13 @@ static int svd_split_impl(bool use_qr, const void* theta, int32_t B, int32_t d, 
   const int mx = m > n ? m : n;
   const size_t need = use_qr ? tjm_svd_qr_workspace_bytes(mx, B) : tjm_svd_workspace_bytes(mx, B);
   if (work_bytes < need) return TJM_ERR_WORKSPACE;
-  const int p = (mx + 31) / 32 * 32;
   char* w = static_cast<char*>(work);
   auto take = [&](size_t nbytes) { char* q = w; w += (nbytes + 255) / 256 * 256; return q; };
   SvdWorkspace sw;
-  sw.y_b0 = svd_y_elems(mx);
-  sw.Y = reinterpret_cast<cplx*>(take((size_t)B * sw.y_b0 * sizeof(cplx)));
-  sw.norms = reinterpret_cast<double*>(take((size_t)B * p * sizeof(double)));
-  sw.perm = reinterpret_cast<int*>(take((size_t)B * p * sizeof(int)));
-  sw.fro2 = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
-  sw.rec = reinterpret_cast<double*>(take((size_t)B * 8 * 256 * 4 * sizeof(double)));
-  sw.stamps = reinterpret_cast<int*>(take((size_t)B * 1152 * sizeof(int)));
-  sw.nrot = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
-  sw.done = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
-  sw.n_active = reinterpret_cast<int*>(take(256));
+  {
+    char* sbase = take(svd_workspace_bytes(mx, B));
+    svd_carve(sw, sbase, mx, B);
+  }
   static int* pinned = nullptr;
   if (!pinned) TJM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pinned), 256, hipHostMallocDefault));
   sw.h_pinned = pinned;

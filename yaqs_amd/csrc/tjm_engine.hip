@@ -86,12 +86,9 @@ size_t Engine::workspace_bytes() const {
   tot += 2 * align_up((size_t)B * tb * sizeof(cplx));
   const size_t nloc = (size_t)d * d * cm * cm;
   tot += align_up((size_t)B * (mmax + 1) * nloc * sizeof(cplx));
-  const int p = (d * cm + 31) / 32 * 32;
   tot += align_up((size_t)B * (size_t)(d * cm) * (d * cm) * sizeof(cplx));
-  tot += align_up((size_t)B * svd_y_elems(d * cm) * sizeof(cplx));  // Y
-  tot += align_up((size_t)B * p * sizeof(double)) + align_up((size_t)B * p * sizeof(int));
-  tot += 8 * align_up((size_t)B * sizeof(double) * 4);
-  tot += align_up((size_t)B * 1152 * sizeof(int)) + align_up((size_t)B * 8 * 256 * 4 * sizeof(double));
+  tot += align_up(svd_workspace_bytes(d * cm, B));
+  tot += 8 * align_up((size_t)B * sizeof(double) * 4);  // small per-trajectory scalars and index lists
   tot += align_up(qr_workspace_bytes(d * cm, B)) + 4096;
   tot += 2 * align_up((size_t)B * TJM_MAX_PART * sizeof(double));
   tot += 3 * align_up((size_t)B * mmax * sizeof(cplx));
@@ -129,17 +126,10 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   V = reinterpret_cast<cplx*>(take((size_t)B * v_b0 * sizeof(cplx)));
   theta_b0 = (long)(d * cm) * (d * cm);
   theta = reinterpret_cast<cplx*>(take((size_t)B * theta_b0 * sizeof(cplx)));
-  const int pp = (d * cm + 31) / 32 * 32;
-  svdw.y_b0 = svd_y_elems(d * cm);
-  svdw.Y = reinterpret_cast<cplx*>(take((size_t)B * svdw.y_b0 * sizeof(cplx)));
-  svdw.norms = reinterpret_cast<double*>(take((size_t)B * pp * sizeof(double)));
-  svdw.perm = reinterpret_cast<int*>(take((size_t)B * pp * sizeof(int)));
-  svdw.fro2 = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
-  svdw.rec = reinterpret_cast<double*>(take((size_t)B * 8 * 256 * 4 * sizeof(double)));
-  svdw.stamps = reinterpret_cast<int*>(take((size_t)B * 1152 * sizeof(int)));
-  svdw.nrot = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
-  svdw.done = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
-  svdw.n_active = reinterpret_cast<int*>(take(256));
+  {
+    char* sbase = take(svd_workspace_bytes(d * cm, B));
+    svd_carve(svdw, sbase, d * cm, B);
+  }
   {
     const int md = d * cm;
     char* qbase = take(qr_workspace_bytes(md, B));

@@ -137,6 +137,7 @@ struct ExtractDesc {
 };
 long svd_y_elems(int max_dim);  // complex elements of the stacked Jacobi matrix per trajectory
 size_t svd_workspace_bytes(int max_dim, int B);
+size_t svd_carve(SvdWorkspace& w, char* base, int max_dim, int B);  // lays the buffers out behind base, returns the bytes used
 void profile_enable(int every);
 void profile_get(double* total_ms, double* total_bytes, long* samples);
 int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspace& w, hipStream_t s, JacobiShape* shape_out,

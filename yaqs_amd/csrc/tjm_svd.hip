@@ -30,8 +30,8 @@ namespace tjm {
 namespace {
 
 constexpr int NB = 8;        // columns per block
-constexpr int MAXRK = 8;     // row groups of 64 per column held in registers (rtot <= 512)
-constexpr int MAXBLK = 32;   // column blocks per matrix (ncols <= 256)
+constexpr int MAXRK = 16;    // row groups of 64 per column held in registers (rtot <= 1024); kernels are instantiated for 8 and 16
+constexpr int MAXBLK = 64;   // column blocks per matrix (ncols <= 512)
 constexpr int STAMP_STRIDE = 3 * MAXBLK + MAXBLK * MAXBLK;
 
 struct JacobiArgs {
@@ -47,8 +47,8 @@ struct JacobiArgs {
   const int* done;
   const int* ids;
   int mode;     // 0: round-robin pair of the round ; 1: sibling pair (2p, 2p+1) of 8-column blocks
-  double* rec;  // [B][npairs][256][4] rotation record of the split X / W scheme (c, sr, si, flag)
-  int* stamps;  // [B][STAMP_STRIDE]: mod[32] | verd[32] | nz[32] | ver[32*32]   (visit pruning)
+  double* rec;  // [B][MAXBLK/4][256][4] rotation record of the split X / W scheme (c, sr, si, flag)
+  int* stamps;  // [B][STAMP_STRIDE]: mod[MAXBLK] | verd[MAXBLK] | nz[MAXBLK] | ver[MAXBLK*MAXBLK]   (visit pruning)
   int clock;    // launch counter, strictly increasing inside one solve
 };
 
@@ -191,6 +191,7 @@ __device__ inline void rotate_pair(cplx& p, cplx& q, double c, double sr, double
 }
 
 // ---- cross pairs of one block pair -----------------------------------------------------------
+template <int RK>
 __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
   extern __shared__ double smem[];
   int b = blockIdx.y;
@@ -218,9 +219,9 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
   cplx* colI = Yb + (long)(I * NB + w) * rtot;
   cplx* colJ = Yb + (long)(J * NB + w) * rtot;
 
-  cplx yI[MAXRK], yJ[MAXRK];
+  cplx yI[RK], yJ[RK];
 #pragma unroll
-  for (int k = 0; k < MAXRK; ++k) {
+  for (int k = 0; k < RK; ++k) {
     if (k < nrk) {
       yI[k] = colI[lane + 64 * k];
       yJ[k] = colJ[lane + 64 * k];
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
   }
   double nI = 0.0, nJ = 0.0;
 #pragma unroll
-  for (int k = 0; k < MAXRK; ++k) {
+  for (int k = 0; k < RK; ++k) {
     if (k < nrk && lane + 64 * k < rx) {
       nI = fma(yI[k].x, yI[k].x, fma(yI[k].y, yI[k].y, nI));
       nJ = fma(yJ[k].x, yJ[k].x, fma(yJ[k].y, yJ[k].y, nJ));
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
   for (int s = 0; s < NB; ++s) {
     double gx = 0.0, gy = 0.0;
 #pragma unroll
-    for (int k = 0; k < MAXRK; ++k) {
+    for (int k = 0; k < RK; ++k) {
       if (k < nrk && lane + 64 * k < rx) {
         gx = fma(yI[k].x, yJ[k].x, fma(yI[k].y, yJ[k].y, gx));   // conj(yI) * yJ
         gy = fma(yI[k].x, yJ[k].y, fma(-yI[k].y, yJ[k].x, gy));
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
     double c, sr, si, tg;
     if (make_rotation(nI, nJ, gx, gy, g.tol2, floor2, c, sr, si, tg)) {
 #pragma unroll
-      for (int k = 0; k < MAXRK; ++k)
+      for (int k = 0; k < RK; ++k)
         if (k < nrk) rotate_pair(yI[k], yJ[k], c, sr, si);
       nI -= tg;
       nJ += tg;
@@ -264,13 +265,13 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
     if (s + 1 < NB) {
       // hand the J column to the previous wavefront: wave w next needs the column held by wave w+1
 #pragma unroll
-      for (int k = 0; k < MAXRK; ++k)
+      for (int k = 0; k < RK; ++k)
         if (k < nrk) slots[w * rtot + lane + 64 * k] = yJ[k];
       if (lane == 0) sN[w] = nJ;
       __syncthreads();
       const int src = (w + 1) & (NB - 1);
 #pragma unroll
-      for (int k = 0; k < MAXRK; ++k)
+      for (int k = 0; k < RK; ++k)
         if (k < nrk) yJ[k] = slots[src * rtot + lane + 64 * k];
       nJ = sN[src];
       __syncthreads();
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
   // after 7 hand-overs wave w holds J column (w + 7) mod 8
   cplx* outJ = Yb + (long)(J * NB + ((w + NB - 1) & (NB - 1))) * rtot;
 #pragma unroll
-  for (int k = 0; k < MAXRK; ++k) {
+  for (int k = 0; k < RK; ++k) {
     if (k < nrk) {
       colI[lane + 64 * k] = yI[k];
       outJ[lane + 64 * k] = yJ[k];
@@ -302,6 +303,7 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
 // Same scheme with twice the tile: every wavefront keeps TWO columns of block I and TWO of block J, so each LDS
 // hand-over (and its two barriers) is followed by four rotations, the two independent ones back to back, and a
 // column is read from / written to memory once per 256 rotations of the tile instead of once per 64.
+template <int RK>
 __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
   extern __shared__ double smem[];
   int b = blockIdx.y;
@@ -325,14 +327,14 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
   }
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  cplx yI[2][MAXRK], yJ[2][MAXRK];
+  cplx yI[2][RK], yJ[2][RK];
   double nI[2] = {0.0, 0.0}, nJ[2] = {0.0, 0.0};
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const cplx* cI = Yb + (long)(I * 16 + 2 * w + h) * rtot;
     const cplx* cJ = Yb + (long)(J * 16 + 2 * w + h) * rtot;
 #pragma unroll
-    for (int k = 0; k < MAXRK; ++k) {
+    for (int k = 0; k < RK; ++k) {
       if (k < nrk) {
         yI[h][k] = cI[lane + 64 * k];
         yJ[h][k] = cJ[lane + 64 * k];
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
-    for (int k = 0; k < MAXRK; ++k) {
+    for (int k = 0; k < RK; ++k) {
       if (k < nrk && lane + 64 * k < rx) {
         nI[h] = fma(yI[h][k].x, yI[h][k].x, fma(yI[h][k].y, yI[h][k].y, nI[h]));
         nJ[h] = fma(yJ[h][k].x, yJ[h][k].x, fma(yJ[h][k].y, yJ[h][k].y, nJ[h]));
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
       for (int h = 0; h < 2; ++h) {
         const int hj = h ^ sub;
 #pragma unroll
-        for (int k = 0; k < MAXRK; ++k) {
+        for (int k = 0; k < RK; ++k) {
           if (k < nrk && lane + 64 * k < rx) {
             gx[h] = fma(yI[h][k].x, yJ[hj][k].x, fma(yI[h][k].y, yJ[hj][k].y, gx[h]));
             gy[h] = fma(yI[h][k].x, yJ[hj][k].y, fma(-yI[h][k].y, yJ[hj][k].x, gy[h]));
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
         double c, sr, si, tg;
         if (make_rotation(nI[h], nJ[hj], gx[h], gy[h], g.tol2, floor2, c, sr, si, tg)) {
 #pragma unroll
-          for (int k = 0; k < MAXRK; ++k)
+          for (int k = 0; k < RK; ++k)
             if (k < nrk) rotate_pair(yI[h][k], yJ[hj][k], c, sr, si);
           nI[h] -= tg;
           nJ[hj] += tg;
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int k = 0; k < MAXRK; ++k)
+        for (int k = 0; k < RK; ++k)
           if (k < nrk) slots[(w * 2 + h) * rtot + lane + 64 * k] = yJ[h][k];
       if (lane < 2) sN[w * 2 + lane] = (lane == 0) ? nJ[0] : nJ[1];
       __syncthreads();
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int k = 0; k < MAXRK; ++k)
+        for (int k = 0; k < RK; ++k)
           if (k < nrk) yJ[h][k] = slots[(src * 2 + h) * rtot + lane + 64 * k];
       nJ[0] = sN[src * 2];
       nJ[1] = sN[src * 2 + 1];
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
     cplx* oI = Yb + (long)(I * 16 + 2 * w + h) * rtot;
     cplx* oJ = Yb + (long)(J * 16 + 2 * wj + h) * rtot;
 #pragma unroll
-    for (int k = 0; k < MAXRK; ++k) {
+    for (int k = 0; k < RK; ++k) {
       if (k < nrk) {
         oI[lane + 64 * k] = yI[h][k];
         oJ[lane + 64 * k] = yJ[h][k];
@@ -438,10 +440,11 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
 // X / W boundary halves the registers and LDS of the latency-bound kernel (2 workgroups per CU) and turns the W
 // half into a pure FMA stream: one lane per row, all 32 columns of the tile in registers, 256 rotations with
 // wave-uniform parameters and compile-time column indices.
-constexpr int XRK = 4;  // row groups of 64 of the X part (rx_top == 256)
 constexpr int REC_PER_VISIT = 2 * NB * 2 * NB;  // 8 steps x 2 sub-steps x 8 wavefronts x 2 pairs = 256 rotations
 
-__global__ __launch_bounds__(512, 4) void jacobi_cross16x_kernel(JacobiArgs g) {
+// XRK = row groups of 64 of the X part: 4 (rx_top == 256, d*chi = 256) or 8 (rx_top == 512)
+template <int XRK>
+__global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kernel(JacobiArgs g) {
   extern __shared__ double smem[];
   int b = blockIdx.y;
   if (g.ids) b = g.ids[b];
@@ -610,6 +613,7 @@ __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int w
 }
 
 // ---- pairs inside one block (LDS resident) -----------------------------------------------------
+template <int RK>
 __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
   extern __shared__ double smem[];
   int b = blockIdx.y;
@@ -642,10 +646,10 @@ __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
   for (int s = 0; s < NB - 1; ++s) {
     int p, q;
     pair_of(NB, s, w, p, q);
-    cplx yp[MAXRK], yq[MAXRK];
+    cplx yp[RK], yq[RK];
     double gx = 0.0, gy = 0.0;
 #pragma unroll
-    for (int k = 0; k < MAXRK; ++k) {
+    for (int k = 0; k < RK; ++k) {
       if (k < nrk) {
         yp[k] = tile[p * rtot + lane + 64 * k];
         yq[k] = tile[q * rtot + lane + 64 * k];
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
     const double a = sN[p], d = sN[q];
     if (make_rotation(a, d, gx, gy, g.tol2, floor2, c, sr, si, tg)) {
 #pragma unroll
-      for (int k = 0; k < MAXRK; ++k) {
+      for (int k = 0; k < RK; ++k) {
         if (k < nrk) {
           rotate_pair(yp[k], yq[k], c, sr, si);
           tile[p * rtot + lane + 64 * k] = yp[k];
@@ -941,30 +945,56 @@ long svd_y_elems(int max_dim) {
   return (long)p32 * round_up(round_up(max_dim, 16) + p32, 64);
 }
 
-size_t svd_workspace_bytes(int max_dim, int B) {
+// One layout of the Jacobi workspace for every user (engine, stand-alone ABI calls): buffers behind base, returns bytes used.
+size_t svd_carve(SvdWorkspace& w, char* base, int max_dim, int B) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) / 256 * 256; return p; };
   const int p = round_up(max_dim, 32);
-  size_t y = (size_t)B * svd_y_elems(max_dim) * sizeof(cplx);
-  size_t small = (size_t)B * 8 * 256 * 4 * sizeof(double) + (size_t)B * p * (sizeof(double) + sizeof(int)) + (size_t)B * 4 * sizeof(int) + (size_t)B * STAMP_STRIDE * sizeof(int) + 64;
-  return y + small + 4096;
+  w.y_b0 = svd_y_elems(max_dim);
+  w.Y = reinterpret_cast<cplx*>(take((size_t)B * w.y_b0 * sizeof(cplx)));
+  w.norms = reinterpret_cast<double*>(take((size_t)B * p * sizeof(double)));
+  w.perm = reinterpret_cast<int*>(take((size_t)B * p * sizeof(int)));
+  w.fro2 = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
+  w.rec = reinterpret_cast<double*>(take((size_t)B * (MAXBLK / 4) * REC_PER_VISIT * 4 * sizeof(double)));
+  w.stamps = reinterpret_cast<int*>(take((size_t)B * STAMP_STRIDE * sizeof(int)));
+  w.nrot = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  w.done = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  w.n_active = reinterpret_cast<int*>(take(256));
+  return off;
+}
+
+size_t svd_workspace_bytes(int max_dim, int B) {
+  SvdWorkspace w;
+  return svd_carve(w, nullptr, max_dim, B) + 4096;
 }
 
 int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspace& w, hipStream_t s, JacobiShape* shape_out,
                  int* sweeps_out) {
   if (src.nb0 <= 0) return TJM_OK;
   static const bool no16 = getenv("TJM_NO_TILE16") != nullptr;
-  int ncols_pad = round_up(src.ncols, 16);
-  const bool tile16 = !no16 && ncols_pad >= 32 && round_up(round_up(src.rx, 16) + round_up(src.ncols, 32), 64) <= 64 * MAXRK;
-  if (tile16) ncols_pad = round_up(src.ncols, 32);
+  static const bool no_split = getenv("TJM_NO_SPLIT") != nullptr;
   const int rx_top = round_up(src.rx, 16);
+  const int ncols32 = round_up(src.ncols, 32);
+  // split X / W scheme: 16-column blocks, X rows exactly 256 or 512 (one register layout each), W rows in groups of 64
+  const bool split16 = !no16 && !no_split && ncols32 >= 32 && (rx_top == 256 || rx_top == 512) && ncols32 % 64 == 0 && w.rec != nullptr &&
+                       src.nb0 <= 65535 && round_up(rx_top + ncols32, 64) <= 64 * MAXRK;
+  // fused 16-column blocks for the smaller matrices (two stacked columns per wavefront fit registers and LDS up to 512 rows)
+  const bool tile16 = split16 || (!no16 && ncols32 >= 32 && round_up(rx_top + ncols32, 64) <= 512);
+  const int ncols_pad = tile16 ? ncols32 : round_up(src.ncols, 16);
   const int rtot = round_up(rx_top + ncols_pad, 64);
-  if (rtot > 64 * MAXRK) return TJM_ERR_NOT_IMPLEMENTED;  // register-resident columns: rx + ncols <= 512
+  if (rtot > 64 * MAXRK) return TJM_ERR_NOT_IMPLEMENTED;  // register-resident columns: rx + ncols <= 1024
   if ((long)ncols_pad * rtot > w.y_b0) return TJM_ERR_WORKSPACE;
+  const bool big = rtot > 512;  // 16 row groups per column instead of 8
   static bool attr_set = false;
   if (!attr_set) {
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    const int big_lds = 136 * 1024;
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_diag_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_diag_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
     attr_set = true;
   }
   const size_t lds = (size_t)NB * rtot * sizeof(cplx) + NB * sizeof(double) + 16 * sizeof(int);
@@ -997,9 +1027,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   const int nrounds = tile16 ? (g.nblk / 2 - 1) : (g.nblk - 1);
   const int npairs = tile16 ? g.nblk / 4 : g.nblk / 2;
   const size_t lds16 = (size_t)2 * NB * rtot * sizeof(cplx) + 2 * NB * sizeof(double) + 16 * sizeof(int);
-  static const bool no_split = getenv("TJM_NO_SPLIT") != nullptr;
-  const bool split16 = tile16 && !no_split && rx_top == 64 * XRK && ncols_pad % 64 == 0 && w.rec != nullptr && src.nb0 <= 65535;
-  const size_t lds16x = (size_t)2 * NB * 64 * XRK * sizeof(cplx) + 2 * NB * sizeof(double) + 16 * sizeof(int);
+  const size_t lds16x = (size_t)2 * NB * rx_top * sizeof(cplx) + 2 * NB * sizeof(double) + 16 * sizeof(int);
   g.rec = w.rec;
   const int max_sweeps = 40;
   int sweep = 0;
@@ -1008,11 +1036,13 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   for (; sweep < max_sweeps && !converged; ++sweep) {
     ++g.clock;
     g.mode = 0;
-    hipLaunchKernelGGL(jacobi_diag_kernel, dim3(g.nblk, src.nb0), dim3(256), lds, s, g);
+    if (big) hipLaunchKernelGGL(jacobi_diag_kernel<16>, dim3(g.nblk, src.nb0), dim3(256), lds, s, g);
+    else hipLaunchKernelGGL(jacobi_diag_kernel<8>, dim3(g.nblk, src.nb0), dim3(256), lds, s, g);
     if (tile16) {  // pairs between the two 8-column halves of every 16-column block
       ++g.clock;
       g.mode = 1;
-      hipLaunchKernelGGL(jacobi_cross_kernel, dim3(g.nblk / 2, src.nb0), dim3(512), lds, s, g);
+      if (big) hipLaunchKernelGGL(jacobi_cross_kernel<16>, dim3(g.nblk / 2, src.nb0), dim3(512), lds, s, g);
+      else hipLaunchKernelGGL(jacobi_cross_kernel<8>, dim3(g.nblk / 2, src.nb0), dim3(512), lds, s, g);
       g.mode = 0;
     }
     for (int r = 0; r < nrounds; ++r) {
@@ -1030,14 +1060,16 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
         TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot], s));
       }
       if (split16) {
-        hipLaunchKernelGGL(jacobi_cross16x_kernel, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
+        if (rx_top == 256) hipLaunchKernelGGL(jacobi_cross16x_kernel<4>, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
+        else hipLaunchKernelGGL(jacobi_cross16x_kernel<8>, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
         if (timed) {  // the timed kernel is the X-rows kernel alone: its tile is the X part of the 32 columns, read + written once
           TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot + 1], s));
           g_prof.pending.emplace_back(slot, (double)npairs * n_live * 4.0 * NB * rx_top * sizeof(cplx) * 2.0);
         }
         hipLaunchKernelGGL(jacobi_cross16w_kernel, dim3(npairs, ncols_pad / 64, src.nb0), dim3(64), 0, s, g, rx_top);
-      } else if (tile16) hipLaunchKernelGGL(jacobi_cross16_kernel, dim3(npairs, src.nb0), dim3(512), lds16, s, g);
-      else hipLaunchKernelGGL(jacobi_cross_kernel, dim3(npairs, src.nb0), dim3(512), lds, s, g);
+      } else if (tile16) hipLaunchKernelGGL(jacobi_cross16_kernel<8>, dim3(npairs, src.nb0), dim3(512), lds16, s, g);
+      else if (big) hipLaunchKernelGGL(jacobi_cross_kernel<16>, dim3(npairs, src.nb0), dim3(512), lds, s, g);
+      else hipLaunchKernelGGL(jacobi_cross_kernel<8>, dim3(npairs, src.nb0), dim3(512), lds, s, g);
     }
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 2 * sizeof(int), s));
     hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tb), dim3(256), 0, s, w.nrot, w.done, w.n_active, src.nb0, src.ids);
