@@ -28,6 +28,7 @@ extern "C" {
 #define TJM_ERR_NOT_IMPLEMENTED (-4) /* maps to NotImplementedError (dissipation.py:136-138) */
 #define TJM_ERR_NUMERIC (-5)         /* maps to ValueError (stochastic_process.py:178-186)   */
 #define TJM_ERR_STATE (-6)
+#define TJM_ERR_ASSERT (-7)          /* maps to AssertionError: imaginary expectation value (mps.py:1233) */
 
 /* ---- library ------------------------------------------------------------------------ */
 int tjm_version(void);
@@ -98,6 +99,30 @@ int tjm_engine_bond_dims(tjm_engine* e, int32_t set, int32_t* host_chi); /* [B][
 int tjm_engine_site0_normsq(tjm_engine* e, int32_t set, double* host_out); /* MPS.norm(0), mps.py:1539-1565 */
 /* counters: matvecs, krylov calls, svds, svd sweeps, two-site updates */
 int tjm_engine_stats(const tjm_engine* e, int64_t* out5);
+
+/* ---- whole trajectories in one call -------------------------------------------------- *
+ * The body of the backend contract: analog_tjm_1 / analog_tjm_2 (analog/analog_tjm.py:206-462) for the B resident
+ * trajectories, after set_params / set_mpo / set_noise / load_state.  Observables are given in the reference's
+ * site-sorted order (simulation_parameters.py:419-456); a two-site observable acts on (site, site+1) (mps.py:999-1047). */
+typedef struct {
+  int32_t order;            /* 1: analog_tjm_1, 2: analog_tjm_2 */
+  int32_t n_times;          /* len(sim_params.times) = number of steps + 1 */
+  int32_t sample_timesteps; /* 1: one column per time point, 0: final time only */
+  int32_t has_noise;        /* 0: noise_model is None */
+  int32_t has_seed;         /* 0: random_seed is None (fresh OS entropy, random_utils.py:33-35) */
+  uint64_t seed;            /* sim_params.random_seed */
+  int32_t n_obs;
+  const int32_t* obs_nsites; /* [n_obs] 1 or 2 */
+  const int32_t* obs_site;   /* [n_obs] first site */
+  const double* obs_matrix;  /* [n_obs][32]: row-major complex 2x2 (first 8 doubles) or 4x4 */
+} tjm_run_config;
+/* traj[B]: trajectory indices (seeds of the per-trajectory streams); results[B][n_obs][T], diagnostics[B][3][T] with
+ * T = n_times if sample_timesteps else 1 (host, float64).  Returns TJM_ERR_ASSERT for an imaginary expectation
+ * value (AssertionError in mps.py:1233) and TJM_ERR_NUMERIC for zero / non-finite jump weights. */
+int tjm_engine_run(tjm_engine* e, const tjm_run_config* cfg, const int64_t* traj, double* results, double* diagnostics);
+/* The reference's host random streams, bit-compatible with NumPy (core/random_utils.py:20-69):
+ * timestep < 0: make_trajectory_rng(traj, base_seed=seed).random(n); otherwise make_sample_rng(traj, timestep, seed). */
+int tjm_rng_uniforms(int32_t has_seed, uint64_t seed, uint64_t traj, int64_t timestep, int32_t n, double* out);
 
 /* ---- single kernels, exported for parity tests -------------------------------------- */
 typedef struct {

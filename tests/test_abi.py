@@ -6,7 +6,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import GOLDEN, ROOT
 
 
 def header_symbols():
@@ -89,3 +89,32 @@ def test_trajectory_uniform_streams_match_oracle():
     assert np.array_equal(sample_uniforms(42, 3, 5), o.sample_rng(42, 3, 5).random(2))
     parts = [shard_range(1024, r, 8) for r in range(8)]
     assert parts[0][0] == 0 and parts[-1][1] == 1024 and all(parts[i][1] == parts[i + 1][0] for i in range(7))
+
+
+def test_c_rng_streams_match_reference_fixture_bit_exactly():
+    """tjm_rng_uniforms (host code of the C ABI, no GPU involved) reproduces make_trajectory_rng / make_sample_rng of
+    core/random_utils.py:20-69 bit for bit: SeedSequence([seed, traj, TAG]) -> PCG64 -> random()."""
+    import ctypes as C
+
+    from yaqs_amd import _lib
+
+    lib = _lib.load()
+    g = np.load(os.path.join(GOLDEN, "rng_streams.npz"))
+    out = np.zeros(8)
+    for i, seed in enumerate(g["seeds"]):
+        for j, traj in enumerate(g["trajs"]):
+            _lib.check(lib.tjm_rng_uniforms(1, int(seed), int(traj), -1, 8, out.ctypes.data))
+            assert np.array_equal(out, g["traj"][i, j]), (seed, traj)
+            for k, step in enumerate(g["steps"]):
+                _lib.check(lib.tjm_rng_uniforms(1, int(seed), int(traj), int(step), 8, out.ctypes.data))
+                assert np.array_equal(out, g["sample"][i, j, k]), (seed, traj, step)
+    # a seed beyond 32 bits splits into two entropy words exactly as NumPy does
+    big = 2**40 + 12345
+    ref = np.random.default_rng(np.random.SeedSequence([big, 7, 0x5452414A])).random(8)
+    _lib.check(lib.tjm_rng_uniforms(1, big, 7, -1, 8, out.ctypes.data))
+    assert np.array_equal(out, ref)
+    # unseeded: two calls differ
+    a, b = np.zeros(4), np.zeros(4)
+    lib.tjm_rng_uniforms(0, 0, 0, -1, 4, a.ctypes.data)
+    lib.tjm_rng_uniforms(0, 0, 0, -1, 4, b.ctypes.data)
+    assert not np.array_equal(a, b) and np.all((a >= 0) & (a < 1))

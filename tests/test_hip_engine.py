@@ -116,13 +116,13 @@ def test_unsupported_noise_raises_not_implemented():
     e.close()
 
 
-def _run(L, init, noise, params, mpo, trajs, batch=None):
+def _run(L, init, noise, params, mpo, trajs, batch=None, native=False):
     from yaqs_amd.api import MPS
     from yaqs_amd.tjm import TrajectoryBatch
 
     e = make_engine(L, params.max_bond_dim, len(trajs), mpo)
     tb = TrajectoryBatch(e, params, noise)
-    r, d = tb.run(trajs, MPS(L, tensors=init))
+    r, d = tb.run(trajs, MPS(L, tensors=init), native=native)
     e.close()
     return r, d, tb
 
@@ -150,6 +150,10 @@ def test_trajectories_match_reference_fixture_and_pinned_golden():
                 assert np.allclose(dps[:, i], ref_dp, atol=1e-8), (key, i)
             assert np.allclose(r, g[key + "_results"], atol=1e-8), key
             assert np.array_equal(d, g[key + "_diag"]), key
+            # the one-call C driver (tjm_engine_run: schedule, RNG streams and measurement inside the library)
+            rn, dn, _ = _run(L, init, noise, p, mpo, list(range(10)), native=True)
+            assert np.allclose(rn, g[key + "_results"], atol=1e-8), key
+            assert np.array_equal(dn, g[key + "_diag"]), key
             if order == 2 and not sample:
                 assert np.allclose(r.mean(axis=0).ravel(), g["pinned_expected_z"], atol=1e-8)  # tests/test_simulator.py:191-197
 
@@ -164,6 +168,8 @@ def test_closed_and_dephasing_configs_match_reference_fixture():
         p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(10)], elapsed_time=1.0, dt=0.1, max_bond_dim=16, svd_threshold=1e-9,
                             krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=42)
         r, d, _ = _run(10, init, None, p, mpo, [0, 1])
+        rn, dn, _ = _run(10, init, None, p, mpo, [0, 1], native=True)
+        assert np.allclose(rn, r, atol=1e-12) and np.array_equal(dn, d)
         assert np.allclose(r[0], g[f"c1_order{order}_results"], atol=1e-9)
         assert np.allclose(r[1], r[0], atol=1e-12)  # a closed system is deterministic
         assert np.array_equal(d[0], g[f"c1_order{order}_diag"])
@@ -242,6 +248,8 @@ def test_adjacent_two_site_noise_and_two_site_observables_match_oracle():
     mpo = MPO.ising(L, 1.0, 0.5)
     r, d, tb = _run(L, init, noise, p, mpo.tensors, list(range(6)))
     assert np.array(tb.jump_log).sum() > 0  # the jump branch (incl. adjacent pairs) is exercised
+    rn, dn, _ = _run(L, init, noise, p, mpo.tensors, list(range(6)), native=True)  # two-site observables through the C driver
+    assert np.allclose(rn, r, atol=1e-11) and np.array_equal(dn, d)
     oobs = [o.Obs(Z, 0), o.Obs(zz, [2, 3]), o.Obs(xz, [0, 1]), o.Obs(Z, 5), o.Obs(zz, [4, 5])]
     op = o.Params(observables=oobs, elapsed_time=0.4, dt=0.1, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-12, order=2,
                   sample_timesteps=True, random_seed=3)

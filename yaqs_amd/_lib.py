@@ -18,6 +18,7 @@ ERRORS = {
     -4: NotImplementedError,
     -5: ValueError,
     -6: RuntimeError,
+    -7: AssertionError,
 }
 
 
@@ -37,6 +38,13 @@ class GemmDesc(C.Structure):
         ("c_b0", C.c_int64), ("c_b1", C.c_int64), ("c_b2", C.c_int64),
         ("conjA", C.c_int32), ("conjB", C.c_int32),
     ]
+
+
+class RunConfig(C.Structure):
+    """tjm_run_config of include/tjm_hip.h."""
+    _fields_ = [("order", C.c_int32), ("n_times", C.c_int32), ("sample_timesteps", C.c_int32), ("has_noise", C.c_int32),
+                ("has_seed", C.c_int32), ("seed", C.c_uint64), ("n_obs", C.c_int32), ("obs_nsites", C.c_void_p),
+                ("obs_site", C.c_void_p), ("obs_matrix", C.c_void_p)]
 
 
 V = C.c_void_p
@@ -72,6 +80,8 @@ EXPORTS = {
     "tjm_engine_bond_dims": (C.c_int, [V, I, V]),
     "tjm_engine_site0_normsq": (C.c_int, [V, I, V]),
     "tjm_engine_stats": (C.c_int, [V, V]),
+    "tjm_engine_run": (C.c_int, [V, C.POINTER(RunConfig), V, V, V]),
+    "tjm_rng_uniforms": (C.c_int, [I, C.c_uint64, C.c_uint64, C.c_int64, I, V]),
     "tjm_zgemm_batched": (C.c_int, [C.POINTER(GemmDesc), V]),
     "tjm_svd_workspace_bytes": (C.c_size_t, [I, I]),
     "tjm_svd_split": (C.c_int, [V, I, I, I, I, I, V, V, I, I, D, I, I, V, V, I, V, C.c_size_t, V, V]),

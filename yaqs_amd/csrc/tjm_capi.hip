@@ -24,6 +24,7 @@ const char* tjm_error_string(int code) {
     case TJM_ERR_NOT_IMPLEMENTED: return "not implemented";
     case TJM_ERR_NUMERIC: return "numerical failure";
     case TJM_ERR_STATE: return "engine state error";
+    case TJM_ERR_ASSERT: return "measurement should be real";
     default: return "unknown";
   }
 }
@@ -119,6 +120,17 @@ int tjm_engine_site_moments2(tjm_engine* e, int32_t set, double* M, double* M2) 
 }
 int tjm_engine_bond_dims(tjm_engine* e, int32_t set, int32_t* chi) { return (e && chi) ? e->impl.bond_dims(set, chi) : TJM_ERR_ARG; }
 int tjm_engine_site0_normsq(tjm_engine* e, int32_t set, double* out) { return (e && out) ? e->impl.site_normsq0(set, out) : TJM_ERR_ARG; }
+int tjm_engine_run(tjm_engine* e, const tjm_run_config* cfg, const int64_t* traj, double* results, double* diagnostics) {
+  if (!e) return TJM_ERR_ARG;
+  return run_batch(e->impl, cfg, traj, results, diagnostics);
+}
+
+int tjm_rng_uniforms(int32_t has_seed, uint64_t seed, uint64_t traj, int64_t timestep, int32_t n, double* out) {
+  if (!out || n < 0) return TJM_ERR_ARG;
+  rng_uniforms(has_seed, seed, traj, timestep, n, out);
+  return TJM_OK;
+}
+
 int tjm_engine_stats(const tjm_engine* e, int64_t* o) {
   if (!e || !o) return TJM_ERR_ARG;
   o[0] = e->impl.stat_matvecs; o[1] = e->impl.stat_krylov_calls; o[2] = e->impl.stat_svds; o[3] = e->impl.stat_svd_sweeps;

@@ -5,6 +5,7 @@
 #include <functional>
 #include <vector>
 
+#include "../../include/tjm_hip.h"
 #include "tjm_kernels.h"
 
 namespace tjm {
@@ -130,5 +131,9 @@ class Engine {
   int copy_back(cplx* dst, long dst_b0, const cplx* src, long src_b0, long n, const int* ids, int nb0);
   std::vector<int> unitary_jump_;
 };
+
+// tjm_run.hip
+void rng_uniforms(int has_seed, uint64_t seed, uint64_t traj, int64_t timestep, int n, double* out);
+int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* results, double* diagnostics);
 
 }  // namespace tjm

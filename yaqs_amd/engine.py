@@ -175,6 +175,28 @@ class BatchEngine:
         _lib.check(self.lib.tjm_engine_site0_normsq(self.h, set_index, out.ctypes.data), "site0_normsq")
         return out
 
+    def run(self, *, order: int, n_times: int, sample_timesteps: bool, has_noise: bool, seed, traj_indices, observables):
+        """Whole trajectories in one C call (tjm_engine_run).  observables: [(first_site, matrix 2x2 | 4x4)] in site-sorted order."""
+        n_obs = len(observables)
+        nsites = np.zeros(max(n_obs, 1), dtype=np.int32)
+        site = np.zeros(max(n_obs, 1), dtype=np.int32)
+        mats = np.zeros((max(n_obs, 1), 16), dtype=np.complex128)
+        for k, (s0, m) in enumerate(observables):
+            m = np.asarray(m, dtype=np.complex128)
+            nsites[k] = 2 if m.size == 16 else 1
+            site[k] = s0
+            mats[k, : m.size] = m.reshape(-1)
+        cfg = _lib.RunConfig(order=int(order), n_times=int(n_times), sample_timesteps=int(bool(sample_timesteps)), has_noise=int(bool(has_noise)),
+                             has_seed=int(seed is not None), seed=int(seed or 0), n_obs=n_obs, obs_nsites=nsites.ctypes.data,
+                             obs_site=site.ctypes.data, obs_matrix=mats.ctypes.data)
+        traj = np.ascontiguousarray(np.asarray(traj_indices, dtype=np.int64))
+        assert traj.shape == (self.B,)
+        cols = n_times if sample_timesteps else 1
+        results = np.zeros((self.B, n_obs, cols))
+        diagnostics = np.zeros((self.B, 3, cols))
+        _lib.check(self.lib.tjm_engine_run(self.h, C.byref(cfg), traj.ctypes.data, results.ctypes.data, diagnostics.ctypes.data), "run")
+        return results, diagnostics
+
     def stats(self) -> dict:
         s = np.zeros(5, dtype=np.int64)
         self.lib.tjm_engine_stats(self.h, s.ctypes.data)

@@ -105,10 +105,17 @@ class TrajectoryBatch:
             pos += 1 + jumped
 
     # ---- drivers --------------------------------------------------------------------
-    def run(self, traj_indices: Sequence[int], initial: MPS):
+    def run(self, traj_indices: Sequence[int], initial: MPS, native: bool = False):
+        """``native=True`` hands the whole schedule to the C driver (``tjm_engine_run``): same results, no per-step host
+        logic and no dp / jump logs.  The Python schedule below is the readable mirror of analog_tjm.py used by the tests."""
         e, p = self.e, self.p
         assert len(traj_indices) == e.B
         n_t = len(p.times)
+        if native:
+            e.load_state(initial.tensors, 0)
+            obs = [(o_.first_site, np.asarray(o_.gate.matrix, dtype=np.complex128)) for o_ in self.sorted_obs]
+            return e.run(order=p.order, n_times=n_t, sample_timesteps=p.sample_timesteps, has_noise=self.noise is not None,
+                         seed=p.random_seed, traj_indices=traj_indices, observables=obs)
         cols = n_t if p.sample_timesteps else 1
         results = np.zeros((e.B, len(self.sorted_obs), cols))
         diagnostics = np.zeros((e.B, 3, cols))
@@ -242,10 +249,11 @@ class Simulator:
     diagnostic sums are combined with one all-reduce.
     """
 
-    def __init__(self, batch: int | None = None, device: str | None = None, show_progress: bool = False):
+    def __init__(self, batch: int | None = None, device: str | None = None, show_progress: bool = False, native: bool = True):
         self.batch = batch
         self.device = device
         self.show_progress = show_progress
+        self.native = native  # True: the C driver tjm_engine_run runs the schedule; False: the Python mirror of it
 
     def run(self, initial_state: MPS, hamiltonian: MPO, sim_params: AnalogSimParams, noise_model: NoiseModel | None = None) -> Result:
         import torch
@@ -276,7 +284,7 @@ class Simulator:
                     engine.close()
                 engine = BatchEngine(initial_state.length, chi, len(chunk), hamiltonian.tensors, device=device)
             tb = TrajectoryBatch(engine, sim_params, noise_model if noisy else None)
-            r, dg = tb.run(chunk, initial_state)
+            r, dg = tb.run(chunk, initial_state, native=self.native)
             res_all[done: done + len(chunk)] = r
             diag_all[done: done + len(chunk)] = dg
             done += len(chunk)
