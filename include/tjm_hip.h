@@ -86,6 +86,9 @@ int tjm_engine_apply_single(tjm_engine* e, int32_t set, int32_t site, const doub
 /* apply_two_qubit_gate_tebd (digital_tjm.py:455-533) for a nearest-neighbour gate on (left, left+1) of a state with
  * centre 0; host U[(out_l,out_r),(in_l,in_r)] 4x4 complex128 row-major (mpo_utils.py:104-159 index order). */
 int tjm_engine_tebd_gate(tjm_engine* e, int32_t set, int32_t left, const double* host_u);
+/* The same gate from a state whose orthogonality centre is at `center` (chains of gates without noise in between, e.g. the
+ * adjacent SWAPs that route a long-range gate, digital_tjm.py:476-499).  The centre ends on left + 1. */
+int tjm_engine_tebd_gate_at(tjm_engine* e, int32_t set, int32_t left, int32_t center, const double* host_u);
 /* stochastic_process (core/methods/stochastic_process.py:190-292); jumped[B], dp[B] optional host outputs. */
 int tjm_engine_stochastic(tjm_engine* e, int32_t set, double dt, int32_t* jumped, double* dp);
 /* Physical-leg moment matrices M[site][b][p][q] = <psi| |p><q|_site |psi> (host, complex128);

@@ -293,6 +293,22 @@ def test_digital_tebd_trajectories_match_reference_fixture():
     assert np.array(db.jump_log).sum() > 0
     assert np.allclose(r[:, :, 0], g["strong_results"][:, :, 0], atol=1e-8)
     assert np.array_equal(d, g["strong_diag"])
+    # long-range gates in both site orders, routed with adjacent SWAPs (digital_tjm.py:476-499); local noise on the gate's own
+    # sites only, including a long-range two-site Pauli channel and a non-Pauli one-site channel
+    from yaqs_amd.api import GateLayer, rx_matrix
+
+    cx, rzz = g["lr_cx_matrix"], g["lr_rzz_matrix"]
+    lr_layers = [GateLayer([(q, rx_matrix(0.3 + 0.1 * q)) for q in range(L)], [(1, 5, cx), (6, 2, rzz)], [(4, 3, cx), (7, 0, cx)], 0)
+                 for _ in range(2)]
+    noise3 = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)] +
+                        [{"name": "crosstalk_zz", "sites": [1, 5], "strength": 0.1}, {"name": "lowering", "sites": [6], "strength": 0.2}])
+    p = DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-10, random_seed=11)
+    r, d, _ = run(None, p, lr_layers, [0], 16)
+    assert np.allclose(r[0], g["lr_noiseless_results"][0], atol=1e-8)
+    assert np.array_equal(d[0], g["lr_noiseless_diag"][0])
+    r, d, db = run(noise3, p, lr_layers, list(range(6)), 16)
+    assert np.allclose(r, g["lr_noisy_results"], atol=1e-8)
+    assert np.array_equal(d, g["lr_noisy_diag"])
 
 
 def test_chi256_heisenberg_lowering_step_matches_oracle():

@@ -273,3 +273,30 @@ def test_digital_tebd_trajectories_match_reference():
         r, dg, _ = o.digital_tjm(i, init, noise2, p, o.ising_trotter_layers(L, 1.0, 0.5, 0.1, 3))
         assert np.allclose(r, g["strong_results"][i], atol=1e-9), i
         assert np.array_equal(dg, g["strong_diag"][i]), i
+
+
+def _long_range_layers(g, L):
+    cx, rzz = g["lr_cx_matrix"], g["lr_rzz_matrix"]
+    layers = []
+    for _ in range(2):
+        singles = [(q, o.rx_matrix(0.3 + 0.1 * q)) for q in range(L)]
+        layers.append(o.GateLayer(singles, [(1, 5, cx), (6, 2, rzz)], [(4, 3, cx), (7, 0, cx)], 0))
+    return layers
+
+
+def test_digital_long_range_gates_match_reference():
+    """SWAP-routed long-range gates in both site orders (digital_tjm.py:476-499) with local one- and two-site noise."""
+    g = load("digital")
+    L = 8
+    obs = [o.Obs(Z, s) for s in range(L)] + [o.Obs(X, 3)]
+    init = o.MPSState.product(L, "zeros")
+    noise = [o.make_process("pauli_x", [i], 0.05) for i in range(L)] + [o.make_process("crosstalk_zz", [1, 5], 0.1, factors=(Z, Z)),
+                                                                         o.make_process("lowering", [6], 0.2)]
+    p = o.DigitalParams(observables=obs, max_bond_dim=16, svd_threshold=1e-10, random_seed=11)
+    r, dg, _ = o.digital_tjm(0, init, None, p, _long_range_layers(g, L))
+    assert np.allclose(r, g["lr_noiseless_results"][0], atol=1e-9)
+    assert np.array_equal(dg, g["lr_noiseless_diag"][0])
+    for i in range(6):
+        r, dg, _ = o.digital_tjm(i, init, noise, p, _long_range_layers(g, L))
+        assert np.allclose(r, g["lr_noisy_results"][i], atol=1e-9), i
+        assert np.array_equal(dg, g["lr_noisy_diag"][i]), i

@@ -383,6 +383,31 @@ def gen_digital():
         diag.append(dg)
     out["strong_results"] = np.array(res)
     out["strong_diag"] = np.array(diag)
+    # long-range gates (SWAP-routed TEBD, digital_tjm.py:476-499) in both site orders, with one- and two-site local noise
+    def lr_layer():
+        singles = []
+        for q in range(L):
+            gt = gl.GateLibrary.rx([0.3 + 0.1 * q]); gt.set_sites(q); singles.append(gt)
+        a = gl.GateLibrary.cx(); a.set_sites(1, 5)
+        b = gl.GateLibrary.rzz([0.7]); b.set_sites(6, 2)
+        c = gl.GateLibrary.cx(); c.set_sites(4, 3)
+        d_ = gl.GateLibrary.cx(); d_.set_sites(7, 0)
+        return dtm._CompiledCircuitLayer(tuple(singles), (a, b), (c, d_), 0)
+
+    out["lr_cx_matrix"] = np.asarray(gl.GateLibrary.cx().matrix)
+    out["lr_rzz_matrix"] = np.asarray(gl.GateLibrary.rzz([0.7]).matrix)
+    noise3 = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)] +
+                        [{"name": "crosstalk_zz", "sites": [1, 5], "strength": 0.1}, {"name": "lowering", "sites": [6], "strength": 0.2}])
+    cc = dtm._CompiledCircuit(tuple(lr_layer() for _ in range(2)), 0)
+    p = sp.DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-10, random_seed=11)
+    for name, nm, ntraj in (("lr_noisy", noise3, 6), ("lr_noiseless", None, 1)):
+        res, diag = [], []
+        for i in range(ntraj):
+            r, dg, _, _ = dtm.digital_tjm((i, st, nm, p, None), compiled_circuit=cc)
+            res.append(np.asarray(r, dtype=np.float64))
+            diag.append(dg)
+        out[name + "_results"] = np.array(res)
+        out[name + "_diag"] = np.array(diag)
     save("digital", **out)
 
 

@@ -111,6 +111,9 @@ int tjm_engine_apply_single(tjm_engine* e, int32_t set, int32_t site, const doub
 int tjm_engine_tebd_gate(tjm_engine* e, int32_t set, int32_t left, const double* u) {
   return (e && u && set >= 0 && set < 2) ? e->impl.tebd_gate(set, left, u) : TJM_ERR_ARG;
 }
+int tjm_engine_tebd_gate_at(tjm_engine* e, int32_t set, int32_t left, int32_t center, const double* u) {
+  return (e && u && set >= 0 && set < 2) ? e->impl.tebd_gate(set, left, u, center) : TJM_ERR_ARG;
+}
 int tjm_engine_stochastic(tjm_engine* e, int32_t set, double dt, int32_t* jumped, double* dp) {
   return (e && set >= 0 && set < 2) ? e->impl.stochastic(set, dt, jumped, dp) : TJM_ERR_ARG;
 }

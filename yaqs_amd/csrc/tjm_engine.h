@@ -54,7 +54,7 @@ class Engine {
   int set_noise_filter(int n, const int* idx);   // n < 0: all processes active
   int normalize_qr(int set, int center);
   int apply_single(int set, int site, const double* host_mat);
-  int tebd_gate(int set, int left, const double* host_u);
+  int tebd_gate(int set, int left, const double* host_u, int center = 0);
   int stochastic(int set, double dt_, int* host_jumped /*B or null*/, double* host_dp /*B or null*/);
   int site_moments(int set, double* host_M /*[L][B][d][d] complex*/, double* host_M2 = nullptr /*[L-1][B][d^2][d^2] or null*/);
   int bond_dims(int set, int* host_chi /*[B][L+1]*/);

@@ -940,13 +940,20 @@ int Engine::apply_single(int set, int site, const double* host_mat) {
 }
 
 // apply_two_qubit_gate_tebd (digital_tjm.py:455-533) for a nearest-neighbour gate on (left, left+1), from a state with
-// centre 0: QR shifts put the centre on the pair, then merge, gate, truncated split to the right (min_keep = min(2, chi)).
-int Engine::tebd_gate(int set, int left, const double* host_u) {
-  if (!bound_ || left < 0 || left + 1 >= L) return TJM_ERR_ARG;
+// centre `center`: QR shifts put the centre on the pair, then merge, gate, truncated split to the right (min_keep = min(2, chi));
+// the centre ends on left + 1.
+int Engine::tebd_gate(int set, int left, const double* host_u, int center) {
+  if (!bound_ || left < 0 || left + 1 >= L || center < 0 || center >= L) return TJM_ERR_ARG;
   StateSet& S = sets[set];
   int rc;
-  for (int i = 0; i < left; ++i)
-    if ((rc = qr_shift_right(S, i)) != TJM_OK) return rc;
+  // shift_center_to(left) unless the centre already sits on the pair (digital_tjm.py:503-506); QR shifts only move the gauge
+  if (center < left) {
+    for (int i = center; i < left; ++i)
+      if ((rc = qr_shift_right(S, i)) != TJM_OK) return rc;
+  } else if (center > left + 1) {
+    for (int i = center; i > left; --i)
+      if ((rc = qr_shift_left(S, i)) != TJM_OK) return rc;
+  }
   TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 4) * 16, host_u, 16 * sizeof(cplx), hipMemcpyHostToDevice, stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
   const int mk = (max_bond > 0) ? std::min(2, max_bond) : 2;

@@ -144,9 +144,9 @@ class BatchEngine:
         m = np.ascontiguousarray(matrix, dtype=np.complex128)
         _lib.check(self.lib.tjm_engine_apply_single(self.h, set_index, int(site), m.ctypes.data), "apply_single")
 
-    def tebd_gate(self, left: int, u4: np.ndarray, set_index: int = 0):
+    def tebd_gate(self, left: int, u4: np.ndarray, set_index: int = 0, center: int = 0):
         u = np.ascontiguousarray(np.asarray(u4, dtype=np.complex128).reshape(4, 4))
-        _lib.check(self.lib.tjm_engine_tebd_gate(self.h, set_index, int(left), u.ctypes.data), "tebd_gate")
+        _lib.check(self.lib.tjm_engine_tebd_gate_at(self.h, set_index, int(left), int(center), u.ctypes.data), "tebd_gate")
 
     def stochastic(self, dt: float, set_index: int = 0):
         jumped = np.zeros(self.B, dtype=np.int32)

@@ -199,6 +199,34 @@ class DigitalBatch:
 
     _measure = TrajectoryBatch._measure
 
+    _SWAP = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=np.complex128).reshape(2, 2, 2, 2)
+
+    def _apply_two_qubit(self, entry):
+        """``apply_two_qubit_gate_tebd`` (digital_tjm.py:455-533).  ``entry`` is ``(left, U[out_l,out_r,in_l,in_r])`` for a gate on
+        (left, left+1), or ``(site0, site1, 4x4 matrix)`` with the matrix indexed ``2*q_site0 + q_site1`` as ``BaseGate.matrix``;
+        non-adjacent sites are routed with adjacent SWAPs.  Returns the gate's sites and the centre position afterwards."""
+        e = self.e
+        if len(entry) == 2:
+            left, u4 = entry
+            e.tebd_gate(left, u4)
+            return {left, left + 1}, left + 1
+        s0, s1, mat = entry
+        if s0 == s1:
+            raise ValueError("a two-qubit gate needs two different sites")
+        t = np.asarray(mat, dtype=np.complex128).reshape(2, 2, 2, 2)
+        u_lr = t if s0 < s1 else t.transpose(1, 0, 3, 2)  # resolve_lr_tensor (mpo_utils.py:127-159)
+        left, right = min(s0, s1), max(s0, s1)
+        center = 0
+        for i in range(right - 1, left, -1):  # bring the right qubit next to the left one
+            e.tebd_gate(i, self._SWAP, center=center)
+            center = i + 1
+        e.tebd_gate(left, u_lr, center=center)
+        center = left + 1
+        for i in range(left + 1, right):      # and back
+            e.tebd_gate(i, self._SWAP, center=center)
+            center = i + 1
+        return {s0, s1}, center
+
     def run(self, traj_indices: Sequence[int], initial: MPS, layers):
         e, p = self.e, self.p
         assert len(traj_indices) == e.B
@@ -218,14 +246,14 @@ class DigitalBatch:
             for site, m in layer.singles:
                 e.apply_single(site, m)
             for group in (layer.even, layer.odd):
-                for left, u4 in group:
-                    e.tebd_gate(left, u4)
+                for entry in group:
+                    sites, center = self._apply_two_qubit(entry)
                     if not self.noisy:
-                        e.normalize_qr(left + 1)
+                        e.normalize_qr(center)
                         continue
-                    local = [k for k, q in enumerate(self.procs) if set(q["sites"]).issubset({left, left + 1})]  # digital_tjm.py:187-204
+                    local = [k for k, q in enumerate(self.procs) if set(q["sites"]).issubset(sites)]  # digital_tjm.py:187-204
                     e.set_noise_filter(local)
-                    e.dissipate_from(1.0, left + 1)
+                    e.dissipate_from(1.0, center)
                     e.set_uniforms(np.stack([u[rows, pos], u[rows, pos + 1]], axis=1))
                     jumped, _ = e.stochastic(1.0)
                     if not local:
