@@ -101,6 +101,11 @@ int tjm_engine_site_moments2(tjm_engine* e, int32_t set, double* host_M, double*
 int tjm_engine_bond_dims(tjm_engine* e, int32_t set, int32_t* host_chi); /* [B][L+1]; record_diagnostics mps.py:549-602 */
 int tjm_engine_site0_normsq(tjm_engine* e, int32_t set, double* host_out); /* MPS.norm(0), mps.py:1539-1565 */
 /* counters: matvecs, krylov calls, svds, svd sweeps, two-site updates */
+/* MPS.measure_shots / measure_single_shot (mps.py:1282-1417) for every resident trajectory, from a normalised state with
+ * centre 0: `shots` projective samples of all L sites.  rotation: the 2x2 basis change of mps.py:1306-1311 (row-major
+ * complex; identity for "Z"); uniforms[B][shots][L] (host): the draw of rng.choice at each site; bits[B][shots][L] (host):
+ * outcomes, site 0 first (the reference packs them as sum(bit_i << i)). */
+int tjm_engine_sample_shots(tjm_engine* e, int32_t set, int32_t shots, const double* rotation, const double* uniforms, uint8_t* bits);
 int tjm_engine_stats(const tjm_engine* e, int64_t* out5);
 
 /* ---- whole trajectories in one call -------------------------------------------------- *

@@ -300,3 +300,12 @@ def test_digital_long_range_gates_match_reference():
         r, dg, _ = o.digital_tjm(i, init, noise, p, _long_range_layers(g, L))
         assert np.allclose(r, g["lr_noisy_results"][i], atol=1e-9), i
         assert np.array_equal(dg, g["lr_noisy_diag"][i]), i
+
+
+def test_measure_single_shot_matches_reference():
+    """Projective sampling of all sites (mps.py:1282-1350) with the recorded draws, in the Z, X and Y bases."""
+    g = load("shots")
+    st = o.MPSState([g[f"t{i}"] for i in range(6)], 0)
+    for bi, basis in enumerate("ZXY"):
+        for k in range(40):
+            assert o.measure_single_shot(st, g["uniforms"][bi, k], basis) == g["codes"][bi, k], (basis, k)

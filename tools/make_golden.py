@@ -411,7 +411,40 @@ def gen_digital():
     save("digital", **out)
 
 
+def gen_shots():
+    """MPS.measure_single_shot (mps.py:1282-1350) with scripted draws: rng.choice(n, p) replaced by its definition
+    (searchsorted on the normalised cumulative sum) so that the fixture records the uniforms."""
+
+    class ScriptRng:
+        def __init__(self, u):
+            self.u = list(u)
+
+        def choice(self, n, p):
+            u = self.u.pop(0)
+            cdf = np.cumsum(p)
+            cdf /= cdf[-1]
+            return int(np.searchsorted(cdf, u, side="right"))
+
+    rng = np.random.default_rng(17)
+    L, chi = 6, 8
+    tensors = []
+    for i in range(L):
+        cl, cr = min(2 ** i, 2 ** (L - i), chi), min(2 ** (i + 1), 2 ** (L - i - 1), chi)
+        tensors.append(rng.normal(size=(2, cl, cr)) + 1j * rng.normal(size=(2, cl, cr)))
+    m = MPS(L, tensors=[t.copy() for t in tensors])
+    m.normalize("B")
+    out = {f"t{i}": m.tensors[i] for i in range(L)}
+    u = rng.random((3, 40, L))
+    codes = np.zeros((3, 40), dtype=np.int64)
+    for bi, basis in enumerate("ZXY"):
+        for k in range(40):
+            codes[bi, k] = m.measure_single_shot(basis, rng=ScriptRng(u[bi, k]))
+    out["uniforms"] = u
+    out["codes"] = codes
+    save("shots", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital"]
+    which = sys.argv[1:] or ["rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots"]
     for w in which:
         globals()["gen_" + w]()

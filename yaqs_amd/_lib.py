@@ -80,6 +80,7 @@ EXPORTS = {
     "tjm_engine_site_moments2": (C.c_int, [V, I, V, V]),
     "tjm_engine_bond_dims": (C.c_int, [V, I, V]),
     "tjm_engine_site0_normsq": (C.c_int, [V, I, V]),
+    "tjm_engine_sample_shots": (C.c_int, [V, I, I, V, V, V]),
     "tjm_engine_stats": (C.c_int, [V, V]),
     "tjm_engine_run": (C.c_int, [V, C.POINTER(RunConfig), V, V, V]),
     "tjm_rng_uniforms": (C.c_int, [I, C.c_uint64, C.c_uint64, C.c_int64, I, V]),

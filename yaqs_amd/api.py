@@ -153,13 +153,16 @@ class DigitalSimParams:
 
     def __init__(self, observables=None, num_traj: int | None = None, max_bond_dim=_USE_PRESET, trunc_mode: str = "discarded_weight",
                  svd_threshold: float | None = None, *, preset: str = "balanced", sample_layers: bool = False, num_mid_measurements: int = 0,
-                 get_state: bool = False, random_seed: int | None = None):
+                 get_state: bool = False, random_seed: int | None = None, shots: int | None = None):
         if preset not in SIMULATION_PRESETS:
             raise ValueError(f"Unknown preset {preset!r}")
         if trunc_mode not in _TRUNC:
             raise ValueError(f"Unknown truncation mode: {trunc_mode!r}")
+        if shots is not None and shots < 1:
+            raise ValueError("shots must be a positive integer when set")
         pv = SIMULATION_PRESETS[preset]
         self.observables = [] if observables is None else list(observables)
+        self.shots = shots
         self.num_traj = num_traj if num_traj is not None else pv["num_traj"]
         self.max_bond_dim = pv["max_bond_dim"] if max_bond_dim is _USE_PRESET else max_bond_dim
         self.trunc_mode = trunc_mode
@@ -460,3 +463,23 @@ class Result:
         d = np.mean(diagnostics, axis=0)
         self.runtime_cost, self.max_bond, self.total_bond = d[0], d[1], d[2]
         self.trajectory_diagnostics = diagnostics
+
+
+class CircuitResult:
+    """Outcome of ``Simulator.run_circuit``: averaged observables / diagnostics as in ``Result`` plus the aggregated
+    measurement histogram ``counts`` {basis-state integer: occurrences} when ``shots`` is set (result.py:155-189)."""
+
+    def __init__(self, sim_params: DigitalSimParams, results_sorted, diagnostics, counts):
+        self.sim_params = sim_params
+        self.observables = list(sim_params.observables)
+        self.counts = counts
+        if results_sorted is not None and len(self.observables):
+            idx = sim_params.observable_sorted_indices
+            self.trajectories = [results_sorted[:, idx[u], :] for u in range(len(self.observables))]
+            self.expectation_values = [np.mean(t, axis=0) for t in self.trajectories]
+        else:
+            self.trajectories, self.expectation_values = [], []
+        if diagnostics is not None:
+            d = np.mean(diagnostics, axis=0)
+            self.runtime_cost, self.max_bond, self.total_bond = d[0], d[1], d[2]
+            self.trajectory_diagnostics = diagnostics

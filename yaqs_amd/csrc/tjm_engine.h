@@ -59,6 +59,7 @@ class Engine {
   int site_moments(int set, double* host_M /*[L][B][d][d] complex*/, double* host_M2 = nullptr /*[L-1][B][d^2][d^2] or null*/);
   int bond_dims(int set, int* host_chi /*[B][L+1]*/);
   int site_normsq0(int set, double* host_out);
+  int sample_shots(int set, int shots, const double* host_rot, const double* host_u /*[B][shots][L]*/, unsigned char* host_bits /*[B][shots][L]*/);
 
   // exposed for kernel-level parity tests
   int krylov_site(cplx* x_in_v0, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0,

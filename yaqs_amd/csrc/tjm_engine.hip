@@ -1053,6 +1053,98 @@ int Engine::site_normsq0(int set, double* host_out) {
   return TJM_OK;
 }
 
+// ---- projective sampling of all sites (MPS.measure_single_shot / measure_shots, mps.py:1282-1417) -----------------------
+// The reference walks the centre through the chain and projects site by site; from a state with centre 0 the projected
+// left part is a row vector, so S shots of one trajectory are the rows of a matrix: per site two GEMMs
+// T[sigma] = Vec (S x ca) A_i[sigma] (ca x cb), then per shot p(sigma') = || sum_sigma rot[sigma'][sigma] T[sigma][s] ||^2,
+// rng.choice (searchsorted of the cumulative sum, one uniform) and Vec'[s] = rotated row / sqrt(p).
+__global__ __launch_bounds__(256) void shot_select_kernel(const cplx* __restrict__ T, long t_b0, long t_sig, int cb, int ldt, cplx rot00, cplx rot01,
+                                                         cplx rot10, cplx rot11, const double* __restrict__ u, int u_b0, int u_s, int site,
+                                                         cplx* __restrict__ vec, long v_b0, int ldv, unsigned char* __restrict__ bits, long bits_b0,
+                                                         int L, int shots) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int sidx = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wavefront per shot
+  if (sidx >= shots) return;
+  const cplx* t0 = T + (long)b * t_b0 + (long)sidx * ldt;
+  const cplx* t1 = t0 + t_sig;
+  double p0 = 0.0, p1 = 0.0;
+  for (int c = lane; c < cb; c += 64) {
+    const cplx a = t0[c], q = t1[c];
+    const cplx r0 = cadd(cmul(rot00, a), cmul(rot01, q));
+    const cplx r1 = cadd(cmul(rot10, a), cmul(rot11, q));
+    p0 = fma(r0.x, r0.x, fma(r0.y, r0.y, p0));
+    p1 = fma(r1.x, r1.x, fma(r1.y, r1.y, p1));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    p0 += __shfl_xor(p0, o, 64);
+    p1 += __shfl_xor(p1, o, 64);
+  }
+  // probabilities / sum, cdf = cumsum / cdf[-1], searchsorted(cdf, u, side="right")
+  const double tot = p0 + p1;
+  const double q0 = p0 / tot, q1 = p1 / tot;
+  const double last = q0 + q1;
+  const double uu = u[(long)b * u_b0 + (long)sidx * u_s + site];
+  const int pick = (uu < q0 / last) ? 0 : 1;
+  const double inv = 1.0 / sqrt(pick ? q1 * tot : q0 * tot);
+  cplx* vo = vec + (long)b * v_b0 + (long)sidx * ldv;
+  for (int c = lane; c < cb; c += 64) {
+    const cplx a = t0[c], q = t1[c];
+    const cplx r = pick ? cadd(cmul(rot10, a), cmul(rot11, q)) : cadd(cmul(rot00, a), cmul(rot01, q));
+    vo[c] = cplx{r.x * inv, r.y * inv};
+  }
+  if (lane == 0) bits[(long)b * bits_b0 + (long)sidx * L + site] = (unsigned char)pick;
+}
+
+__global__ void shot_init_kernel(cplx* vec, long v_b0, int ldv, int shots) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < shots) vec[(long)blockIdx.y * v_b0 + (long)s * ldv] = cplx{1.0, 0.0};
+}
+
+int Engine::sample_shots(int set, int shots, const double* host_rot, const double* host_u, unsigned char* host_bits) {
+  if (!bound_) return TJM_ERR_STATE;
+  if (shots <= 0 || !host_rot || !host_u || !host_bits || d != 2) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  const int cm = *std::max_element(cap.begin(), cap.end());
+  // buffers inside the Krylov basis area: Vec [S][cm] and T [d][S][cm] per trajectory, uniforms and bits behind them
+  const long per_shot = (long)(1 + d) * cm + (L * (long)sizeof(double) + L + 15) / 16 + 1;
+  const long s_max = v_b0 / per_shot;
+  if (s_max < 1) return TJM_ERR_WORKSPACE;
+  const cplx* rot = reinterpret_cast<const cplx*>(host_rot);
+  int rc;
+  for (int s0 = 0; s0 < shots; s0 += (int)s_max) {
+    const int ns = (int)std::min<long>(s_max, shots - s0);
+    cplx* vec = V;                                  // [B] stride v_b0: Vec at 0
+    cplx* T = V + (long)ns * cm;                    // T[sigma][s][cm]
+    double* du = reinterpret_cast<double*>(V + (long)(1 + d) * ns * cm);
+    unsigned char* dbits = reinterpret_cast<unsigned char*>(du + (long)ns * L);
+    const long vb = v_b0;                           // trajectory stride in complex elements
+    for (int b = 0; b < B; ++b)
+      TJM_HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(du) + (size_t)b * vb * sizeof(cplx), host_u + ((size_t)b * shots + s0) * L,
+                                   (size_t)ns * L * sizeof(double), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(shot_init_kernel, dim3((ns + 255) / 256, B), dim3(256), 0, stream, vec, vb, cm, ns);
+    for (int i = 0; i < L; ++i) {
+      const int ca = cap[i], cb = cap[i + 1];
+      GemmDesc g = blank_gemm();  // T[sigma][s][c] = sum_a Vec[s][a] A_i[sigma][a][c]
+      g.A = vec; g.B = S.A[i]; g.C = T;
+      g.M = ns; g.K = ca; g.N = cb;
+      g.a_rs = cm; g.a_cs = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = cm;
+      g.nb0 = B; g.nb1 = d;
+      g.a_b0 = vb; g.b_b0 = a_b0_[i]; g.b_b1 = (long)ca * cb; g.c_b0 = vb; g.c_b1 = (long)ns * cm;
+      if ((rc = gemm(g)) != TJM_OK) return rc;
+      hipLaunchKernelGGL(shot_select_kernel, dim3((ns + 3) / 4, B), dim3(256), 0, stream, T, vb, (long)ns * cm, cb, cm, rot[0], rot[1], rot[2], rot[3],
+                         du, (int)(vb * 2), L, i, vec, vb, cm, dbits, vb * (long)sizeof(cplx), L, ns);
+    }
+    TJM_HIP_CHECK(hipGetLastError());
+    for (int b = 0; b < B; ++b)
+      TJM_HIP_CHECK(hipMemcpyAsync(host_bits + ((size_t)b * shots + s0) * L, dbits + (size_t)b * vb * sizeof(cplx), (size_t)ns * L,
+                                   hipMemcpyDeviceToHost, stream));
+    TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return TJM_OK;
+}
+
 int Engine::site_moments(int set, double* host_M, double* host_M2) {
   if (!bound_) return TJM_ERR_STATE;
   StateSet& S = sets[set];

@@ -197,6 +197,24 @@ class BatchEngine:
         _lib.check(self.lib.tjm_engine_run(self.h, C.byref(cfg), traj.ctypes.data, results.ctypes.data, diagnostics.ctypes.data), "run")
         return results, diagnostics
 
+    BASIS_ROTATION = {
+        "Z": np.eye(2, dtype=np.complex128),
+        "X": np.array([[1, 1], [1, -1]], dtype=np.complex128) / np.sqrt(2),
+        "Y": np.array([[1, -1j], [1, 1j]], dtype=np.complex128) / np.sqrt(2),
+    }
+
+    def sample_shots(self, uniforms: np.ndarray, basis: str = "Z", set_index: int = 0) -> np.ndarray:
+        """measure_shots (mps.py:1282-1417): uniforms[B, shots, L] -> bits[B, shots, L] (uint8), site 0 first."""
+        basis = basis.upper()
+        if basis not in self.BASIS_ROTATION:
+            raise ValueError(f"Invalid basis: {basis}. Expected 'X', 'Y', or 'Z'.")  # mps.py:1313-1315
+        u = np.ascontiguousarray(uniforms, dtype=np.float64)
+        assert u.ndim == 3 and u.shape[0] == self.B and u.shape[2] == self.L
+        rot = np.ascontiguousarray(self.BASIS_ROTATION[basis])
+        bits = np.zeros(u.shape, dtype=np.uint8)
+        _lib.check(self.lib.tjm_engine_sample_shots(self.h, set_index, u.shape[1], rot.ctypes.data, u.ctypes.data, bits.ctypes.data), "sample_shots")
+        return bits
+
     def stats(self) -> dict:
         s = np.zeros(5, dtype=np.int64)
         self.lib.tjm_engine_stats(self.h, s.ctypes.data)

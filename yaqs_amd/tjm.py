@@ -20,6 +20,7 @@ from .engine import BatchEngine
 
 TAG_TRAJ = 0x5452414A
 TAG_SAMPLE = 0x53414D50
+TAG_SHOT = 0x53484F54
 
 
 def trajectory_uniforms(seed: int | None, traj: int, n: int) -> np.ndarray:
@@ -227,7 +228,7 @@ class DigitalBatch:
             center = i + 1
         return {s0, s1}, center
 
-    def run(self, traj_indices: Sequence[int], initial: MPS, layers):
+    def run(self, traj_indices: Sequence[int], initial: MPS, layers, shots_per_traj=None, basis: str = "Z"):
         e, p = self.e, self.p
         assert len(traj_indices) == e.B
         n_gates = sum(len(l.even) + len(l.odd) for l in layers)
@@ -266,7 +267,30 @@ class DigitalBatch:
                     self._measure(0, results, diagnostics, col)
         e.set_noise_filter(None)
         self._measure(0, results, diagnostics, cols - 1)
+        self.counts = None
+        if shots_per_traj is not None:
+            self.counts = self._sample(traj_indices, np.asarray(shots_per_traj, dtype=np.int64), basis)
         return results, diagnostics
+
+    def _sample(self, traj_indices, shots_per_traj, basis):
+        """measure_shots on the final states (mps.py:1352-1417); trajectory b keeps its first shots_per_traj[b] samples.
+        The reference draws from an unseeded generator; with a seed the draws come from SeedSequence([seed, traj, TAG_SHOT])."""
+        e, p = self.e, self.p
+        n = int(shots_per_traj.max()) if len(shots_per_traj) else 0
+        counts: dict[int, int] = {}
+        if n <= 0:
+            return counts
+        u = np.zeros((e.B, n, e.L))
+        for b, t in enumerate(traj_indices):
+            rng = np.random.default_rng() if p.random_seed is None else np.random.default_rng(np.random.SeedSequence([p.random_seed, int(t), TAG_SHOT]))
+            u[b] = rng.random((n, e.L))
+        bits = e.sample_shots(u, basis)
+        weights = (1 << np.arange(e.L, dtype=object))
+        for b in range(e.B):
+            for s_ in range(int(shots_per_traj[b])):
+                code = int(np.dot(bits[b, s_].astype(object), weights))  # sum(bit_i << i), arbitrary length
+                counts[code] = counts.get(code, 0) + 1
+        return counts
 
 
 class Simulator:
@@ -321,6 +345,68 @@ class Simulator:
         if world > 1:
             res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, lo, device)
         return Result(sim_params, res_all, diag_all)
+
+    def run_circuit(self, initial_state: MPS, layers, sim_params, noise_model: NoiseModel | None = None, basis: str = "Z"):
+        """Circuit runs (simulator.py:1681-1830 with gate layers instead of a qiskit circuit): observables, diagnostics and, with
+        ``sim_params.shots``, the measurement histogram.  Single rank; trajectories in chunks of ``batch``."""
+        from .api import CircuitResult
+
+        noisy = noise_model is not None and any(q["strength"] != 0 for q in noise_model.processes)
+        num_traj, per_call, distribution = plan_digital_shots(sim_params, noisy)
+        device = self.device or f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
+        chi = sim_params.max_bond_dim or 2 ** (initial_state.length // 2)
+        chi = max(chi, max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors))
+        mid = sim_params.num_mid_measurements if sim_params.sample_layers else 0
+        cols = (mid + 2) if sim_params.sample_layers else 1
+        res_all = np.zeros((num_traj, len(sim_params.observables), cols))
+        diag_all = np.zeros((num_traj, 3, cols))
+        counts: dict[int, int] = {}
+        wants_shots = sim_params.shots is not None
+        identity_mpo = [np.eye(2, dtype=np.complex128).reshape(2, 2, 1, 1)] * initial_state.length  # the circuit path never applies it
+        B = min(self.batch or 64, num_traj)
+        done, engine = 0, None
+        while done < num_traj:
+            chunk = list(range(done, min(done + B, num_traj)))
+            if engine is None or engine.B != len(chunk):
+                if engine is not None:
+                    engine.close()
+                engine = BatchEngine(initial_state.length, chi, len(chunk), identity_mpo, device=device)
+            db = DigitalBatch(engine, sim_params, noise_model if noisy else None)
+            spt = [shots_for_trajectory(t, per_call, distribution) for t in chunk] if wants_shots else None
+            r, dg = db.run(chunk, initial_state, layers, shots_per_traj=spt, basis=basis)
+            res_all[done: done + len(chunk)] = r
+            diag_all[done: done + len(chunk)] = dg
+            if db.counts:
+                for k, v in db.counts.items():
+                    counts[k] = counts.get(k, 0) + v
+            done += len(chunk)
+        if engine is not None:
+            engine.close()
+        return CircuitResult(sim_params, res_all, diag_all, counts if wants_shots else None)
+
+
+def plan_digital_shots(sim_params, noisy: bool):
+    """``_plan_digital_shots`` (simulator.py:1001-1050): (effective_num_traj, per_call_shots | None, (total, n_traj) | None)."""
+    wants_obs = bool(sim_params.observables)
+    wants_shots = sim_params.shots is not None
+    if wants_shots and not wants_obs:
+        return (sim_params.shots, 1, None) if noisy else (1, sim_params.shots, None)
+    if wants_obs:
+        n = sim_params.num_traj if noisy else 1
+        if wants_shots:
+            return (n, None, (sim_params.shots, n)) if noisy else (n, sim_params.shots, None)
+        return n, None, None
+    return 1, None, None
+
+
+def shots_for_trajectory(traj: int, per_call, distribution) -> int:
+    """``_per_call_shots`` (digital_tjm.py:750-766)."""
+    if per_call is not None:
+        return int(per_call)
+    if distribution is not None:
+        base, rem = divmod(int(distribution[0]), int(distribution[1]))
+        return base + (1 if traj < rem else 0)
+    return 0
 
 
 def shard_range(num_traj: int, rank: int, world: int) -> tuple[int, int]:
