@@ -101,6 +101,12 @@ int tjm_engine_site_moments2(tjm_engine* e, int32_t set, double* host_M, double*
 int tjm_engine_bond_dims(tjm_engine* e, int32_t set, int32_t* host_chi); /* [B][L+1]; record_diagnostics mps.py:549-602 */
 int tjm_engine_site0_normsq(tjm_engine* e, int32_t set, double* host_out); /* MPS.norm(0), mps.py:1539-1565 */
 /* counters: matvecs, krylov calls, svds, svd sweeps, two-site updates */
+/* Singular values (descending) of theta = A_site A_{site+1} reshaped (d chi_l) x (d chi_r): the spectrum behind
+ * MPS.get_entropy and MPS.get_schmidt_spectrum (mps.py:604-678).  spectrum[B][n_out] (host), zero-filled past min(m, n). */
+int tjm_engine_bond_spectrum(tjm_engine* e, int32_t set, int32_t site, double* spectrum, int32_t n_out);
+/* MPS.project_onto_bitstring (mps.py:1495-1537): probability of the computational-basis outcome bits[L] (site 0 first)
+ * for every resident trajectory; prob[B] (host). */
+int tjm_engine_bitstring_probability(tjm_engine* e, int32_t set, const uint8_t* bits, double* prob);
 /* MPS.measure_shots / measure_single_shot (mps.py:1282-1417) for every resident trajectory, from a normalised state with
  * centre 0: `shots` projective samples of all L sites.  rotation: the 2x2 basis change of mps.py:1306-1311 (row-major
  * complex; identity for "Z"); uniforms[B][shots][L] (host): the draw of rng.choice at each site; bits[B][shots][L] (host):

@@ -399,3 +399,49 @@ def test_run_circuit_with_shots_matches_dense_probabilities():
     p = DigitalSimParams(observables=[Observable(Zg(), 2)], num_traj=8, max_bond_dim=8, svd_threshold=1e-12, random_seed=1, shots=20)
     res = Simulator(batch=8).run_circuit(MPS(L, state="zeros"), layers, p, noise)
     assert sum(res.counts.values()) == 20 and res.trajectories[0].shape == (8, 1)
+
+
+def test_entropy_schmidt_spectrum_and_pvm_observables():
+    """Meta-observables of evaluate_observables (mps.py:1200-1218) through the engine, against the reference fixture and, along
+    a noisy trajectory, against the oracle."""
+    from yaqs_amd.api import AnalogSimParams, Entropy, MPS, NoiseModel, Observable, PVM, SchmidtSpectrum, Z as Zg
+    from yaqs_amd.tjm import TrajectoryBatch
+
+    g = load("shots")
+    L = 6
+    tens = [g[f"t{i}"] for i in range(L)]
+    e = make_engine(L, 8, 2, o.ising_mpo(L, 1.0, 0.5))
+    e.load_state(tens)
+    for i in range(L - 1):
+        spec = e.bond_spectrum(i)
+        ref = g["schmidt"][i]
+        ref = ref[~np.isnan(ref)]
+        assert np.allclose(spec[0, : len(ref)], ref, atol=1e-12) and np.allclose(spec[1], spec[0], atol=1e-14)
+    for b, ref in zip(g["pvm_strings"], g["pvm"]):
+        assert np.allclose(e.bitstring_probability(str(b)), ref, atol=1e-13)
+    e.close()
+    obs = [Observable(Entropy(), [2, 3]), Observable(Zg(), 1), Observable(SchmidtSpectrum(), [1, 2]), Observable(PVM("010101"), 0)]
+    p = AnalogSimParams(observables=obs, elapsed_time=0.3, dt=0.1, max_bond_dim=8, svd_threshold=1e-10, krylov_tol=1e-10, order=1,
+                        sample_timesteps=True, random_seed=9)
+    noise = NoiseModel([{"name": "lowering", "sites": [i], "strength": 0.2} for i in range(L)])
+    e = make_engine(L, 8, 3, o.ising_mpo(L, 1.0, 0.5))
+    tb = TrajectoryBatch(e, p, noise)
+    r, d = tb.run([0, 1, 2], MPS(L, tensors=tens), native=True)  # falls back to the host schedule for meta-observables
+    e.close()
+    on = [o.make_process("lowering", [i], 0.2) for i in range(L)]
+    rows = {u: row for u, row in enumerate(p.observable_sorted_indices)}
+    for t in range(3):
+        # replay the trajectory in the oracle and evaluate the same quantities on its states
+        st = o.MPSState([x.copy() for x in tens], 0)
+        op = o.Params(observables=[o.Obs(Z, 1)], elapsed_time=0.3, dt=0.1, max_bond_dim=8, svd_threshold=1e-10, krylov_tol=1e-10,
+                      random_seed=9, sample_timesteps=True)
+        rng = o.trajectory_rng(9, t)
+        for j in range(4):
+            if j > 0:
+                o.tdvp(st, o.ising_mpo(L, 1.0, 0.5), op)
+                o.apply_dissipation(st, on, 0.1, op)
+                st = o.stochastic_process(st, on, 0.1, op, rng)
+            assert abs(r[t, rows[0], j] - o.get_entropy(st, [2, 3])) < 1e-8
+            assert abs(r[t, rows[3], j] - o.project_onto_bitstring(st, "010101")) < 1e-9
+            ref = o.get_schmidt_spectrum(st, [1, 2])
+            assert np.allclose(tb.schmidt[(rows[2], j)][t], ref, atol=1e-9, equal_nan=True)

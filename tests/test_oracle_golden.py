@@ -309,3 +309,14 @@ def test_measure_single_shot_matches_reference():
     for bi, basis in enumerate("ZXY"):
         for k in range(40):
             assert o.measure_single_shot(st, g["uniforms"][bi, k], basis) == g["codes"][bi, k], (basis, k)
+
+
+def test_entropy_schmidt_and_bitstring_projection_match_reference():
+    """MPS.get_entropy / get_schmidt_spectrum / project_onto_bitstring (mps.py:604-678, 1495-1537)."""
+    g = load("shots")
+    st = o.MPSState([g[f"t{i}"] for i in range(6)], 0)
+    for i in range(5):
+        assert abs(o.get_entropy(st, [i, i + 1]) - g["entropy"][i]) < 1e-12
+        assert np.allclose(o.get_schmidt_spectrum(st, [i, i + 1]), g["schmidt"][i], atol=1e-13, equal_nan=True)
+    for b, ref in zip(g["pvm_strings"], g["pvm"]):
+        assert abs(o.project_onto_bitstring(st, str(b)) - ref) < 1e-14

@@ -441,6 +441,12 @@ def gen_shots():
             codes[bi, k] = m.measure_single_shot(basis, rng=ScriptRng(u[bi, k]))
     out["uniforms"] = u
     out["codes"] = codes
+    # entropy / Schmidt spectrum / bitstring projection on the same state (mps.py:604-678, 1495-1537)
+    out["entropy"] = np.array([m.get_entropy([i, i + 1]) for i in range(L - 1)])
+    out["schmidt"] = np.array([m.get_schmidt_spectrum([i, i + 1]) for i in range(L - 1)])
+    strings = ["000000", "101010", "111111", "010011"]
+    out["pvm_strings"] = np.array(strings)
+    out["pvm"] = np.array([complex(m.project_onto_bitstring(b)).real for b in strings])
     save("shots", **out)
 
 

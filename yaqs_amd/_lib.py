@@ -80,6 +80,8 @@ EXPORTS = {
     "tjm_engine_site_moments2": (C.c_int, [V, I, V, V]),
     "tjm_engine_bond_dims": (C.c_int, [V, I, V]),
     "tjm_engine_site0_normsq": (C.c_int, [V, I, V]),
+    "tjm_engine_bond_spectrum": (C.c_int, [V, I, I, V, I]),
+    "tjm_engine_bitstring_probability": (C.c_int, [V, I, V, V]),
     "tjm_engine_sample_shots": (C.c_int, [V, I, I, V, V, V]),
     "tjm_engine_stats": (C.c_int, [V, V]),
     "tjm_engine_run": (C.c_int, [V, C.POINTER(RunConfig), V, V, V]),

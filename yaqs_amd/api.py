@@ -57,6 +57,26 @@ def Id() -> BaseGate:
     return BaseGate("id", _I.copy())
 
 
+def Entropy() -> BaseGate:
+    """Meta-observable: entanglement entropy across the cut (i, i+1) (gate_library.py:1873-1900, mps.py:604-641)."""
+    return BaseGate("entropy", _I.copy(), interaction=2)
+
+
+def SchmidtSpectrum() -> BaseGate:
+    """Meta-observable: singular values across the cut (i, i+1), padded to 500 with NaN (gate_library.py:1903-1930, mps.py:643-678)."""
+    return BaseGate("schmidt_spectrum", _I.copy(), interaction=2)
+
+
+def PVM(bitstring: str) -> BaseGate:
+    """Projection onto a computational-basis string, site 0 first (gate_library.py:1796-1811, mps.py:1495-1537)."""
+    g = BaseGate("pvm", _I.copy())
+    g.bitstring = bitstring
+    return g
+
+
+META_OBSERVABLES = ("entropy", "schmidt_spectrum", "pvm")
+
+
 class Observable:
     """``Observable(gate, sites)`` (simulation_parameters.py:330-416); one-site local observables."""
 

@@ -123,6 +123,14 @@ int tjm_engine_site_moments2(tjm_engine* e, int32_t set, double* M, double* M2) 
 }
 int tjm_engine_bond_dims(tjm_engine* e, int32_t set, int32_t* chi) { return (e && chi) ? e->impl.bond_dims(set, chi) : TJM_ERR_ARG; }
 int tjm_engine_site0_normsq(tjm_engine* e, int32_t set, double* out) { return (e && out) ? e->impl.site_normsq0(set, out) : TJM_ERR_ARG; }
+int tjm_engine_bond_spectrum(tjm_engine* e, int32_t set, int32_t site, double* spectrum, int32_t n_out) {
+  return (e && set >= 0 && set < 2) ? e->impl.bond_spectrum(set, site, spectrum, n_out) : TJM_ERR_ARG;
+}
+
+int tjm_engine_bitstring_probability(tjm_engine* e, int32_t set, const uint8_t* bits, double* prob) {
+  return (e && set >= 0 && set < 2) ? e->impl.bitstring_probability(set, bits, prob) : TJM_ERR_ARG;
+}
+
 int tjm_engine_sample_shots(tjm_engine* e, int32_t set, int32_t shots, const double* rotation, const double* uniforms, uint8_t* bits) {
   return (e && set >= 0 && set < 2) ? e->impl.sample_shots(set, shots, rotation, uniforms, bits) : TJM_ERR_ARG;
 }

@@ -59,6 +59,8 @@ class Engine {
   int site_moments(int set, double* host_M /*[L][B][d][d] complex*/, double* host_M2 = nullptr /*[L-1][B][d^2][d^2] or null*/);
   int bond_dims(int set, int* host_chi /*[B][L+1]*/);
   int site_normsq0(int set, double* host_out);
+  int bond_spectrum(int set, int i, double* host_spec /*[B][n_out]*/, int n_out);
+  int bitstring_probability(int set, const unsigned char* bits /*[L]*/, double* host_prob /*[B]*/);
   int sample_shots(int set, int shots, const double* host_rot, const double* host_u /*[B][shots][L]*/, unsigned char* host_bits /*[B][shots][L]*/);
 
   // exposed for kernel-level parity tests

@@ -1145,6 +1145,68 @@ int Engine::sample_shots(int set, int shots, const double* host_rot, const doubl
   return TJM_OK;
 }
 
+// Singular values of theta = A_i A_{i+1} as a (d cap_i) x (d cap_{i+2}) matrix, descending: the quantity behind
+// MPS.get_entropy / get_schmidt_spectrum (mps.py:604-678), which the reference evaluates on the tensors as they stand.
+int Engine::bond_spectrum(int set, int i, double* host_spec, int n_out) {
+  if (!bound_) return TJM_ERR_STATE;
+  if (i < 0 || i + 1 >= L || !host_spec || n_out < 1) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  int rc;
+  if ((rc = merge_matrix_layout(S, i, nullptr, B)) != TJM_OK) return rc;
+  const int m = d * cap[i], n = d * cap[i + 2];
+  const int nsv = std::min(m, n);
+  double* dspec = reinterpret_cast<double*>(T2);
+  int* dchi = reinterpret_cast<int*>(reinterpret_cast<char*>(T2) + align_up((size_t)B * nsv * sizeof(double)));
+  TJM_HIP_CHECK(hipMemcpyAsync(dchi, S.chi, (size_t)B * (L + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  SvdSplitDesc sd;
+  sd.theta = theta; sd.theta_b0 = theta_b0; sd.ld_theta = n;
+  sd.m = m; sd.n = n; sd.d = d;
+  sd.capL = cap[i]; sd.capR = cap[i + 2]; sd.capM = 1;
+  sd.left = T1; sd.right = T1 + t_b0 / 2; sd.left_b0 = t_b0; sd.right_b0 = t_b0;
+  sd.distribution = 0; sd.trunc_mode = 2; sd.threshold = 0.0; sd.max_bond = 0; sd.min_keep = 1;
+  sd.chiL = dchi + i; sd.chiR = dchi + i + 2; sd.chiM = dchi + i + 1; sd.chi_stride = L + 1;
+  sd.spectrum = dspec; sd.spec_ld = nsv; sd.nb0 = B; sd.ids = nullptr;
+  int sweeps = 0;
+  if ((rc = svd_split(sd, svdw, stream, &sweeps)) != TJM_OK) return rc;
+  std::vector<double> h((size_t)B * nsv);
+  TJM_HIP_CHECK(hipMemcpyAsync(h.data(), dspec, h.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < n_out; ++k) host_spec[(size_t)b * n_out + k] = (k < nsv) ? h[(size_t)b * nsv + k] : 0.0;
+  return TJM_OK;
+}
+
+// MPS.project_onto_bitstring (mps.py:1495-1537): |<bits|psi>|^2 as the squared norm of the product of the selected slices
+int Engine::bitstring_probability(int set, const unsigned char* bits, double* host_prob) {
+  if (!bound_) return TJM_ERR_STATE;
+  if (!bits || !host_prob) return TJM_ERR_ARG;
+  for (int i = 0; i < L; ++i) if (bits[i] >= d) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  int rc;
+  std::vector<cplx> ones((size_t)B, cplx{1.0, 0.0});
+  TJM_HIP_CHECK(hipMemcpyAsync(E_, ones.data(), ones.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  cplx* v = E_;
+  cplx* vn = E2_;
+  long vs = 1;  // trajectory stride of the current row vector
+  for (int i = 0; i < L; ++i) {
+    const int ca = cap[i], cb = cap[i + 1];
+    GemmDesc g = blank_gemm();  // vn[c] = sum_a v[a] A_i[bits_i][a][c]
+    g.A = v; g.B = S.A[i] + (long)bits[i] * ca * cb; g.C = vn;
+    g.M = 1; g.K = ca; g.N = cb;
+    g.a_rs = ca; g.a_cs = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb;
+    g.nb0 = B; g.a_b0 = vs; g.b_b0 = a_b0_[i]; g.c_b0 = cb;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+    std::swap(v, vn);
+    vs = cb;
+  }
+  std::vector<cplx> h(B);
+  TJM_HIP_CHECK(hipMemcpyAsync(h.data(), v, (size_t)B * sizeof(cplx), hipMemcpyDeviceToHost, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  for (int b = 0; b < B; ++b) host_prob[b] = h[b].x * h[b].x + h[b].y * h[b].y;
+  return TJM_OK;
+}
+
 int Engine::site_moments(int set, double* host_M, double* host_M2) {
   if (!bound_) return TJM_ERR_STATE;
   StateSet& S = sets[set];

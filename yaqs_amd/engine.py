@@ -197,6 +197,21 @@ class BatchEngine:
         _lib.check(self.lib.tjm_engine_run(self.h, C.byref(cfg), traj.ctypes.data, results.ctypes.data, diagnostics.ctypes.data), "run")
         return results, diagnostics
 
+    def bond_spectrum(self, site: int, set_index: int = 0) -> np.ndarray:
+        """Singular values of A_site A_{site+1} as a (d chi_l) x (d chi_r) matrix -> [B, min(m, n)] (mps.py:604-678)."""
+        n = int(self.d * min(self.caps[site], self.caps[site + 2]))
+        out = np.zeros((self.B, n))
+        _lib.check(self.lib.tjm_engine_bond_spectrum(self.h, set_index, int(site), out.ctypes.data, n), "bond_spectrum")
+        return out
+
+    def bitstring_probability(self, bitstring: str, set_index: int = 0) -> np.ndarray:
+        """project_onto_bitstring (mps.py:1495-1537): site 0 is the first character."""
+        assert len(bitstring) == self.L, "Bitstring length must match number of sites"
+        bits = np.array([int(c) for c in bitstring], dtype=np.uint8)
+        out = np.zeros(self.B)
+        _lib.check(self.lib.tjm_engine_bitstring_probability(self.h, set_index, bits.ctypes.data, out.ctypes.data), "bitstring_probability")
+        return out
+
     BASIS_ROTATION = {
         "Z": np.eye(2, dtype=np.complex128),
         "X": np.array([[1, 1], [1, -1]], dtype=np.complex128) / np.sqrt(2),

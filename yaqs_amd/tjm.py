@@ -15,7 +15,7 @@ from typing import Sequence
 
 import numpy as np
 
-from .api import AnalogSimParams, MPO, MPS, NoiseModel, Result, is_pauli
+from .api import META_OBSERVABLES, AnalogSimParams, MPO, MPS, NoiseModel, Result, is_pauli
 from .engine import BatchEngine
 
 TAG_TRAJ = 0x5452414A
@@ -54,7 +54,11 @@ class TrajectoryBatch:
         if params.tdvp_mode not in ("1site", "2site"):
             raise NotImplementedError(f"tdvp_mode {params.tdvp_mode!r} is not built yet in the HIP path")
         self.two_site_obs = False
+        self.schmidt: dict = {}  # (sorted row, column) -> [B, 500] Schmidt spectra
+        self.meta_obs = any(obs.gate.name in META_OBSERVABLES for obs in params.observables)
         for obs in params.observables:
+            if obs.gate.name in META_OBSERVABLES:
+                continue
             if isinstance(obs.sites, (list, tuple)) and len(obs.sites) == 2:
                 if obs.sites[1] != obs.sites[0] + 1:
                     raise ValueError("Only nearest-neighbor observables are currently implemented.")  # mps.py:1012-1014
@@ -77,6 +81,33 @@ class TrajectoryBatch:
             M, M2 = e.site_moments(set_index), None  # [L, B, d, d]
         for row, obs in enumerate(self.sorted_obs):
             site = obs.first_site
+            if obs.gate.name in ("entropy", "schmidt_spectrum"):  # mps.py:1200-1213
+                assert isinstance(obs.sites, (list, tuple)) and len(obs.sites) == 2, "Given metric requires 2 sites to act on."
+                lo, hi = min(obs.sites), max(obs.sites)
+                assert hi - lo == 1, "Entropy and Schmidt cuts must be nearest neighbor."
+                spec = e.bond_spectrum(lo, set_index)
+                chi = e.bond_dims(set_index)
+                if obs.gate.name == "entropy":
+                    s2 = spec ** 2
+                    norm = s2.sum(axis=1, keepdims=True)
+                    pr = np.divide(s2, norm, out=np.zeros_like(s2), where=norm > 0)
+                    ent = -np.sum(pr * np.log(pr + np.finfo(np.float64).tiny), axis=1)
+                    ent[chi[:, lo + 1] == 1] = 0.0
+                    results[:, row, col] = ent
+                else:
+                    padded = np.full((e.B, 500), np.nan)
+                    for b in range(e.B):
+                        nb_ = int(e.d * min(chi[b, lo], chi[b, lo + 2]))
+                        if chi[b, lo + 1] == 1:
+                            padded[b, 0] = 1.0
+                        else:
+                            padded[b, : min(500, nb_)] = spec[b, : min(500, nb_)]
+                    self.schmidt[(row, col)] = padded
+                    results[:, row, col] = np.nan  # the vector lives in self.schmidt[(row, col)]
+                continue
+            if obs.gate.name == "pvm":
+                results[:, row, col] = e.bitstring_probability(obs.gate.bitstring, set_index)
+                continue
             O = np.asarray(obs.gate.matrix, dtype=np.complex128)
             if isinstance(obs.sites, (list, tuple)) and len(obs.sites) == 2:
                 val = np.einsum("pq,bpq->b", O, M2[site])   # <theta| O |theta> on the merged pair (mps.py:999-1047)
@@ -112,7 +143,7 @@ class TrajectoryBatch:
         e, p = self.e, self.p
         assert len(traj_indices) == e.B
         n_t = len(p.times)
-        if native:
+        if native and not self.meta_obs:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
             e.load_state(initial.tensors, 0)
             obs = [(o_.first_site, np.asarray(o_.gate.matrix, dtype=np.complex128)) for o_ in self.sorted_obs]
             return e.run(order=p.order, n_times=n_t, sample_timesteps=p.sample_timesteps, has_noise=self.noise is not None,
@@ -195,7 +226,9 @@ class DigitalBatch:
         engine.set_noise(procs, [is_pauli(q) for q in procs])
         self.procs = procs
         self.sorted_obs = params.sorted_observables
-        self.two_site_obs = any(isinstance(o.sites, (list, tuple)) and len(o.sites) == 2 for o in params.observables)
+        self.two_site_obs = any(isinstance(o.sites, (list, tuple)) and len(o.sites) == 2 and o.gate.name not in META_OBSERVABLES
+                                for o in params.observables)
+        self.schmidt: dict = {}
         self.jump_log: list[np.ndarray] = []
 
     _measure = TrajectoryBatch._measure
