@@ -107,6 +107,13 @@ int tjm_engine_bond_spectrum(tjm_engine* e, int32_t set, int32_t site, double* s
 /* MPS.project_onto_bitstring (mps.py:1495-1537): probability of the computational-basis outcome bits[L] (site 0 first)
  * for every resident trajectory; prob[B] (host). */
 int tjm_engine_bitstring_probability(tjm_engine* e, int32_t set, const uint8_t* bits, double* prob);
+/* Scheduled two-site jump (core/methods/scheduled_jumps.py:88-106): a d^2 x d^2 operator (row-major, index
+ * d*sigma_left + sigma_right) on the merged pair (left, left+1), then split_two_site("right") with the engine's truncation
+ * settings and `min_keep`; the gauge is not touched beforehand.  One-site scheduled jumps use tjm_engine_apply_single. */
+int tjm_engine_apply_pair(tjm_engine* e, int32_t set, int32_t left, const double* host_u, int32_t min_keep);
+/* QR sweep from `center` down to site 0 without normalising (set_canonical_form / the sweep of normalize("B"),
+ * mps.py:790-839); with center = L-1 it works from any gauge.  tjm_engine_site0_normsq then returns the squared norm. */
+int tjm_engine_canonicalize_qr(tjm_engine* e, int32_t set, int32_t center);
 /* MPS.measure_shots / measure_single_shot (mps.py:1282-1417) for every resident trajectory, from a normalised state with
  * centre 0: `shots` projective samples of all L sites.  rotation: the 2x2 basis change of mps.py:1306-1311 (row-major
  * complex; identity for "Z"); uniforms[B][shots][L] (host): the draw of rng.choice at each site; bits[B][shots][L] (host):

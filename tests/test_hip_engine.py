@@ -445,3 +445,27 @@ def test_entropy_schmidt_spectrum_and_pvm_observables():
             assert abs(r[t, rows[3], j] - o.project_onto_bitstring(st, "010101")) < 1e-9
             ref = o.get_schmidt_spectrum(st, [1, 2])
             assert np.allclose(tb.schmidt[(rows[2], j)][t], ref, atol=1e-9, equal_nan=True)
+
+
+def test_scheduled_jumps_match_reference_fixture():
+    """NoiseModel.scheduled_jumps through the engine (one-site at t = 0 and mid-run, adjacent two-site) against the reference."""
+    from yaqs_amd.api import AnalogSimParams, MPS, NoiseModel, Observable, X as Xg, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    g = load("scheduled")
+    L = 6
+    sched = [{"time": 0.0, "sites": [2], "name": "pauli_x"}, {"time": 0.2, "sites": [4], "name": "lowering"},
+             {"time": 0.3, "sites": [1, 2], "name": "custom", "matrix": g["two"]}]
+    noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.2} for i in range(L)], scheduled_jumps=sched)
+    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 0)]
+    p = AnalogSimParams(observables=obs, elapsed_time=0.5, dt=0.1, max_bond_dim=8, svd_threshold=1e-10, krylov_tol=1e-10, order=1,
+                        sample_timesteps=True, random_seed=21)
+    r, d, _ = _run(L, o.MPSState.product(L, "x+").tensors, noise, p, [g[f"mpo{i}"] for i in range(L)], [0, 1, 2, 3])
+    assert np.allclose(r, g["results"], atol=1e-8)
+    assert np.array_equal(d, g["diag"])
+    p2 = AnalogSimParams(observables=obs, elapsed_time=0.5, dt=0.1, max_bond_dim=8, order=2, random_seed=21)
+    with pytest.raises(ValueError):
+        _run(L, o.MPSState.product(L, "x+").tensors, noise, p2, [g[f"mpo{i}"] for i in range(L)], [0])
+    bad = NoiseModel([], scheduled_jumps=[{"time": 0.1, "sites": [0], "name": "lowering"}, {"time": 0.1, "sites": [0], "name": "lowering"}])
+    with pytest.raises(ValueError):  # sigma^- twice annihilates the state
+        _run(L, o.MPSState.product(L, "zeros").tensors, bad, p, [g[f"mpo{i}"] for i in range(L)], [0])

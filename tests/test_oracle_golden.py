@@ -320,3 +320,24 @@ def test_entropy_schmidt_and_bitstring_projection_match_reference():
         assert np.allclose(o.get_schmidt_spectrum(st, [i, i + 1]), g["schmidt"][i], atol=1e-13, equal_nan=True)
     for b, ref in zip(g["pvm_strings"], g["pvm"]):
         assert abs(o.project_onto_bitstring(st, str(b)) - ref) < 1e-14
+
+
+def _scheduled_setup(g):
+    L = 6
+    mpo = [g[f"mpo{i}"] for i in range(L)]
+    sched = [{"time": 0.0, "sites": [2], "matrix": X}, {"time": 0.2, "sites": [4], "matrix": o.JUMP_OPS["lowering"]},
+             {"time": 0.3, "sites": [1, 2], "matrix": g["two"]}]
+    noise = [o.make_process("pauli_z", [i], 0.2) for i in range(L)]
+    p = o.Params(observables=[o.Obs(Z, s) for s in range(L)] + [o.Obs(X, 0)], elapsed_time=0.5, dt=0.1, max_bond_dim=8, svd_threshold=1e-10,
+                 krylov_tol=1e-10, order=1, sample_timesteps=True, random_seed=21)
+    return L, mpo, sched, noise, p
+
+
+def test_scheduled_jumps_match_reference():
+    """analog_tjm_1 with deterministic jumps replacing the stochastic step at their times (scheduled_jumps.py:51-119)."""
+    g = load("scheduled")
+    L, mpo, sched, noise, p = _scheduled_setup(g)
+    for t in range(4):
+        r, dg, _ = o.analog_tjm_1(t, o.MPSState.product(L, "x+"), noise, p, mpo, scheduled=sched)
+        assert np.allclose(r, g["results"][t], atol=1e-9), t
+        assert np.array_equal(dg, g["diag"][t]), t

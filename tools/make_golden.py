@@ -450,7 +450,32 @@ def gen_shots():
     save("shots", **out)
 
 
+def gen_scheduled():
+    """analog_tjm_1 with NoiseModel.scheduled_jumps (scheduled_jumps.py:51-119): one-site jumps at t = 0 and mid-run, an adjacent
+    two-site jump, on top of stochastic dephasing."""
+    atjm = ref("analog.analog_tjm")
+    L = 6
+    H = MPO.ising(L, 1.0, 0.5)
+    st = MPS(L, state="x+")
+    two = np.kron(np.array([[0, 1], [0, 0]]), np.array([[1, 0], [0, -1]])).astype(complex)
+    sched = [{"time": 0.0, "sites": [2], "name": "pauli_x"}, {"time": 0.2, "sites": [4], "name": "lowering"},
+             {"time": 0.3, "sites": [1, 2], "name": "custom", "matrix": two}]
+    noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.2} for i in range(L)], scheduled_jumps=sched)
+    obs = [sp.Observable(gl.Z(), s) for s in range(L)] + [sp.Observable(gl.X(), 0)]
+    p = sp.AnalogSimParams(observables=obs, elapsed_time=0.5, dt=0.1, max_bond_dim=8, svd_threshold=1e-10, krylov_tol=1e-10, order=1,
+                           sample_timesteps=True, random_seed=21)
+    res, diag = [], []
+    for i in range(4):
+        r, dg, _ = atjm.analog_tjm_1((i, st, noise, p, H))
+        res.append(np.asarray(r, dtype=np.float64))
+        diag.append(dg)
+    out = {"results": np.array(res), "diag": np.array(diag), "two": two}
+    for i, w in enumerate(H.tensors):
+        out[f"mpo{i}"] = w
+    save("scheduled", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots"]
+    which = sys.argv[1:] or ["rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled"]
     for w in which:
         globals()["gen_" + w]()

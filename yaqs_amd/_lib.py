@@ -75,6 +75,8 @@ EXPORTS = {
     "tjm_engine_apply_single": (C.c_int, [V, I, I, V]),
     "tjm_engine_tebd_gate": (C.c_int, [V, I, I, V]),
     "tjm_engine_tebd_gate_at": (C.c_int, [V, I, I, I, V]),
+    "tjm_engine_apply_pair": (C.c_int, [V, I, I, V, I]),
+    "tjm_engine_canonicalize_qr": (C.c_int, [V, I, I]),
     "tjm_engine_stochastic": (C.c_int, [V, I, D, V, V]),
     "tjm_engine_site_moments": (C.c_int, [V, I, V]),
     "tjm_engine_site_moments2": (C.c_int, [V, I, V, V]),

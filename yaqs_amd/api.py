@@ -283,8 +283,14 @@ def is_pauli(proc: dict[str, Any]) -> bool:
 class NoiseModel:
     """``NoiseModel(processes)`` (noise_model.py:227-490): list of {name, sites, strength[, matrix|factors]}."""
 
-    def __init__(self, processes: Sequence[dict[str, Any]] | None = None):
+    def __init__(self, processes: Sequence[dict[str, Any]] | None = None, scheduled_jumps: Sequence[dict[str, Any]] | None = None):
         self.processes: list[dict[str, Any]] = []
+        self.scheduled_jumps: list[dict[str, Any]] = []
+        if scheduled_jumps is not None:
+            if not isinstance(scheduled_jumps, (list, tuple)):
+                raise TypeError("scheduled_jumps must be a list or tuple of dictionaries.")
+            for jump in scheduled_jumps:
+                self.scheduled_jumps.append(self._normalize_scheduled_jump(jump))
         if processes is None:
             return
         if not isinstance(processes, (list, tuple)):
@@ -333,6 +339,44 @@ class NoiseModel:
                 raise ValueError("Noise processes must act on one or two sites.")
             p["sites"] = sites
             self.processes.append(p)
+
+
+    @staticmethod
+    def _normalize_scheduled_jump(jump) -> dict[str, Any]:
+        """noise_model.py:298-338: {time, sites, name[, matrix]}; two-site jumps act on adjacent sites in ascending order."""
+        for key in ("time", "sites", "name"):
+            if key not in jump:
+                raise ValueError(f"Each scheduled jump must have a '{key}' key.")
+        if "factors" in jump:
+            raise ValueError("Scheduled jumps do not accept 'factors'; use 'matrix' for custom operators.")
+        j = dict(jump)
+        j["time"] = float(j["time"])
+        if not np.isfinite(j["time"]):
+            raise ValueError("Scheduled jump time must be finite.")
+        sites = [int(s_) for s_ in (j["sites"] if isinstance(j["sites"], (list, tuple)) else [j["sites"]])]
+        swapped = False
+        if len(sites) == 2:
+            swapped = sites[0] > sites[1]
+            sites = sorted(sites)
+            if sites[1] - sites[0] != 1:
+                raise ValueError(f"Scheduled jump acts on non-adjacent sites {sites}. Only nearest-neighbor scheduled jumps are supported.")
+            if swapped and "matrix" in j:
+                raise ValueError("Custom full scheduled-jump matrices require ascending site order.")
+        elif len(sites) != 1:
+            raise ValueError("Scheduled jumps must act on one or two sites.")
+        j["sites"] = sites
+        if "matrix" in j:
+            j["matrix"] = np.asarray(j["matrix"], dtype=C128)
+        else:
+            m = re.fullmatch(r"(?:longrange_)?crosstalk_([xyz])([xyz])", str(j["name"]))
+            if m:
+                a, b = (m.group(2), m.group(1)) if swapped else (m.group(1), m.group(2))
+                j["matrix"] = np.kron(PAULI_MAP[a], PAULI_MAP[b])
+            elif j["name"] in _LIB_OPS:
+                j["matrix"] = _LIB_OPS[j["name"]].copy()
+            else:
+                raise ValueError(f"Unknown noise operator {j['name']!r}")
+        return j
 
 
 # ------------------------------------------------------------------ states / operators

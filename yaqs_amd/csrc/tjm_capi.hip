@@ -111,6 +111,12 @@ int tjm_engine_apply_single(tjm_engine* e, int32_t set, int32_t site, const doub
 int tjm_engine_tebd_gate(tjm_engine* e, int32_t set, int32_t left, const double* u) {
   return (e && u && set >= 0 && set < 2) ? e->impl.tebd_gate(set, left, u) : TJM_ERR_ARG;
 }
+int tjm_engine_apply_pair(tjm_engine* e, int32_t set, int32_t left, const double* u, int32_t min_keep) {
+  return (e && u && set >= 0 && set < 2) ? e->impl.apply_pair(set, left, u, min_keep) : TJM_ERR_ARG;
+}
+int tjm_engine_canonicalize_qr(tjm_engine* e, int32_t set, int32_t center) {
+  return (e && set >= 0 && set < 2) ? e->impl.canonicalize_qr(set, center) : TJM_ERR_ARG;
+}
 int tjm_engine_tebd_gate_at(tjm_engine* e, int32_t set, int32_t left, int32_t center, const double* u) {
   return (e && u && set >= 0 && set < 2) ? e->impl.tebd_gate(set, left, u, center) : TJM_ERR_ARG;
 }

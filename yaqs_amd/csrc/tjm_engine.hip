@@ -960,6 +960,27 @@ int Engine::tebd_gate(int set, int left, const double* host_u, int center) {
   return two_site_op(S, left, ops_ + (size_t)(L + 4) * 16, nullptr, nullptr, B, mk);
 }
 
+// A d^2 x d^2 operator on the merged pair (left, left+1) followed by the truncated split to the right, in whatever gauge the
+// state is in (scheduled two-site jumps, scheduled_jumps.py:88-106: sim_params truncation, min_keep 1).
+int Engine::apply_pair(int set, int left, const double* host_u, int min_keep) {
+  if (!bound_ || left < 0 || left + 1 >= L || !host_u || min_keep < 1) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 4) * 16, host_u, 16 * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return two_site_op(S, left, ops_ + (size_t)(L + 4) * 16, nullptr, nullptr, B, min_keep);
+}
+
+// QR sweep from `center` down to site 0 without the final normalisation: with center = L-1 it right-canonicalises a state in
+// any gauge (the sweep of normalize("B") / set_canonical_form, mps.py:790-839); ||A_0||^2 is then the squared norm of the state.
+int Engine::canonicalize_qr(int set, int center) {
+  if (!bound_ || center < 0 || center >= L) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  int rc;
+  for (int i = center; i >= 1; --i)
+    if ((rc = qr_shift_left(S, i)) != TJM_OK) return rc;
+  return TJM_OK;
+}
+
 int Engine::dissipate(int set, double dt_, int start_center) {
   if (!bound_) return TJM_ERR_STATE;
   if (start_center < 0 || start_center >= L) return TJM_ERR_ARG;

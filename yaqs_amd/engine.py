@@ -148,6 +148,13 @@ class BatchEngine:
         u = np.ascontiguousarray(np.asarray(u4, dtype=np.complex128).reshape(4, 4))
         _lib.check(self.lib.tjm_engine_tebd_gate_at(self.h, set_index, int(left), int(center), u.ctypes.data), "tebd_gate")
 
+    def apply_pair(self, left: int, matrix: np.ndarray, min_keep: int = 1, set_index: int = 0):
+        m = np.ascontiguousarray(np.asarray(matrix, dtype=np.complex128).reshape(4, 4))
+        _lib.check(self.lib.tjm_engine_apply_pair(self.h, set_index, int(left), m.ctypes.data, int(min_keep)), "apply_pair")
+
+    def canonicalize_qr(self, center: int, set_index: int = 0):
+        _lib.check(self.lib.tjm_engine_canonicalize_qr(self.h, set_index, int(center)), "canonicalize_qr")
+
     def stochastic(self, dt: float, set_index: int = 0):
         jumped = np.zeros(self.B, dtype=np.int32)
         dp = np.zeros(self.B)

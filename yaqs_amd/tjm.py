@@ -50,7 +50,7 @@ class TrajectoryBatch:
     def __init__(self, engine: BatchEngine, params: AnalogSimParams, noise: NoiseModel | None):
         self.e = engine
         self.p = params
-        self.noise = noise if (noise is not None and noise.processes) else None
+        self.noise = noise if (noise is not None and (noise.processes or getattr(noise, "scheduled_jumps", None))) else None
         if params.tdvp_mode not in ("1site", "2site"):
             raise NotImplementedError(f"tdvp_mode {params.tdvp_mode!r} is not built yet in the HIP path")
         self.two_site_obs = False
@@ -143,7 +143,14 @@ class TrajectoryBatch:
         e, p = self.e, self.p
         assert len(traj_indices) == e.B
         n_t = len(p.times)
-        if native and not self.meta_obs:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
+        has_sched = self.noise is not None and bool(getattr(self.noise, "scheduled_jumps", None))
+        if has_sched and p.order != 1:
+            raise ValueError(f"scheduled_jumps are only supported for AnalogSimParams(order=1); got order={p.order}.")  # noise_model.py:758-765
+        if has_sched:
+            for j in self.noise.scheduled_jumps:
+                if not np.any(np.isclose(p.times, j["time"], atol=p.dt * 1e-3, rtol=0.0)):
+                    raise ValueError(f"Scheduled jump time {j['time']} is not on the simulation time grid.")  # noise_model.py:768-775
+        if native and not self.meta_obs and not has_sched:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
             e.load_state(initial.tensors, 0)
             obs = [(o_.first_site, np.asarray(o_.gate.matrix, dtype=np.complex128)) for o_ in self.sorted_obs]
             return e.run(order=p.order, n_times=n_t, sample_timesteps=p.sample_timesteps, has_noise=self.noise is not None,
@@ -161,17 +168,43 @@ class TrajectoryBatch:
             self._run_order1(results, diagnostics, u, pos)
         return results, diagnostics
 
+    # ---- scheduled jumps (core/methods/scheduled_jumps.py:28-119) ----------------------
+    def _scheduled_at(self, time: float) -> list:
+        if self.noise is None or not getattr(self.noise, "scheduled_jumps", None):
+            return []
+        return [j for j in self.noise.scheduled_jumps if np.isclose(j["time"], time, atol=self.p.dt * 1e-3, rtol=0.0)]
+
+    def _apply_scheduled(self, jumps) -> None:
+        e, p = self.e, self.p
+        for j in jumps:
+            if len(j["sites"]) == 1:
+                e.apply_single(j["sites"][0], j["matrix"])
+            else:
+                e.apply_pair(j["sites"][0], j["matrix"], min_keep=1)
+        e.canonicalize_qr(e.L - 1)                     # state.norm() needs no gauge; here it is ||A_0||^2 after the QR sweep
+        nsq = e.site0_normsq()
+        if not np.all(np.isfinite(nsq)) or np.any(nsq <= 0.0):
+            raise ValueError("Scheduled jump produced a zero or non-finite squared norm. The jump operator annihilates the current state.")
+        e.normalize_qr(0)                              # normalize("B")
+
     def _run_order1(self, results, diagnostics, u, pos):
         """analog_tjm_1 (analog_tjm.py:369-462)."""
         e, p = self.e, self.p
         n_t = len(p.times)
+        first = self._scheduled_at(p.times[0])
+        if first:
+            self._apply_scheduled(first)
         if p.sample_timesteps:
             self._measure(0, results, diagnostics, 0)
         for j in range(1, n_t):
             e.tdvp(0)
             if self.noise is not None:
                 e.dissipate(p.dt, 0)
-                self._stochastic(0, p.dt, u, pos)
+                due = self._scheduled_at(p.times[j])
+                if due:
+                    self._apply_scheduled(due)
+                else:
+                    self._stochastic(0, p.dt, u, pos)
             if p.sample_timesteps or j == n_t - 1:
                 self._measure(0, results, diagnostics, j if p.sample_timesteps else 0)
         if not p.sample_timesteps and n_t <= 1:
@@ -368,7 +401,7 @@ class Simulator:
                 if engine is not None:
                     engine.close()
                 engine = BatchEngine(initial_state.length, chi, len(chunk), hamiltonian.tensors, device=device)
-            tb = TrajectoryBatch(engine, sim_params, noise_model if noisy else None)
+            tb = TrajectoryBatch(engine, sim_params, noise_model)  # the backend sees the model as given (simulator.py:1549-1559)
             r, dg = tb.run(chunk, initial_state, native=self.native)
             res_all[done: done + len(chunk)] = r
             diag_all[done: done + len(chunk)] = dg
