@@ -301,10 +301,16 @@ class NoiseModel:
                     raise ValueError(f"Each process must have a '{key}' key.")
             p = dict(original)
             sites = [int(s) for s in p["sites"]]
-            g = float(p["strength"])
-            if not np.isfinite(g) or g < 0:
-                raise ValueError("Noise strengths must be finite and nonnegative.")
-            p["strength"] = g
+            if isinstance(p["strength"], dict):  # static disorder: {"distribution", "mean", "std"}, resolved by sample()
+                spec = p["strength"]
+                if spec.get("distribution") not in ("normal", "lognormal", "truncated_normal"):
+                    raise ValueError(f"Unsupported distribution type: {spec.get('distribution')}")
+                p["strength"] = {"distribution": spec["distribution"], "mean": float(spec["mean"]), "std": float(spec["std"])}
+            else:
+                g = float(p["strength"])
+                if not np.isfinite(g) or g < 0:
+                    raise ValueError("Noise strengths must be finite and nonnegative.")
+                p["strength"] = g
             if len(sites) == 1:
                 if "matrix" in p:
                     p["matrix"] = np.asarray(p["matrix"], dtype=C128)
@@ -340,6 +346,43 @@ class NoiseModel:
             p["sites"] = sites
             self.processes.append(p)
 
+
+    def sample(self, rng=None) -> "NoiseModel":
+        """One realisation of static disorder (noise_model.py:492-559): distribution-valued strengths become floats, drawn in
+        process order from ``rng`` (``make_disorder_rng``: SeedSequence([seed, 0x4449534F]), random_utils.py:72-87)."""
+        import copy
+
+        generator = np.random.default_rng(rng)
+        new = object.__new__(NoiseModel)
+        new.processes = []
+        new.scheduled_jumps = copy.deepcopy(self.scheduled_jumps)
+        for proc in self.processes:
+            q = copy.deepcopy(proc)
+            sv = proc["strength"]
+            if isinstance(sv, dict):
+                kind, mean, std = sv["distribution"], sv["mean"], sv["std"]
+                if kind == "normal":
+                    val = max(0.0, float(generator.normal(loc=mean, scale=std)))
+                elif kind == "lognormal":
+                    val = float(generator.lognormal(mean=mean, sigma=std))
+                elif kind == "truncated_normal":
+                    if abs(std) <= 1e-8:
+                        val = float(max(0.0, mean))
+                    else:
+                        from scipy.stats import truncnorm
+
+                        val = float(truncnorm.rvs((0.0 - mean) / std, np.inf, loc=mean, scale=std, random_state=generator))
+                else:
+                    raise ValueError(f"Unsupported distribution type: {kind}")
+                if not np.isfinite(val) or val < 0:
+                    raise ValueError("sampled process strength must be finite and nonnegative.")
+                q["strength"] = val
+            new.processes.append(q)
+        return new
+
+    @property
+    def has_disorder(self) -> bool:
+        return any(isinstance(q["strength"], dict) for q in self.processes)
 
     @staticmethod
     def _normalize_scheduled_jump(jump) -> dict[str, Any]:

@@ -21,6 +21,7 @@ from .engine import BatchEngine
 TAG_TRAJ = 0x5452414A
 TAG_SAMPLE = 0x53414D50
 TAG_SHOT = 0x53484F54
+TAG_DISORDER = 0x4449534F
 
 
 def trajectory_uniforms(seed: int | None, traj: int, n: int) -> np.ndarray:
@@ -33,6 +34,11 @@ def sample_uniforms(seed: int | None, traj: int, timestep: int, n: int = 2) -> n
     """First doubles of ``make_sample_rng`` (random_utils.py:40-69)."""
     rng = np.random.default_rng() if seed is None else np.random.default_rng(np.random.SeedSequence([seed, traj, timestep, TAG_SAMPLE]))
     return rng.random(n)
+
+
+def disorder_rng(seed: int | None) -> np.random.Generator:
+    """``make_disorder_rng`` (random_utils.py:72-87)."""
+    return np.random.default_rng() if seed is None else np.random.default_rng(np.random.SeedSequence([seed, TAG_DISORDER]))
 
 
 def _diagnostics_from_bonds(chi: np.ndarray, d: int) -> np.ndarray:
@@ -378,6 +384,8 @@ class Simulator:
 
         if hamiltonian.length != initial_state.length:
             raise ValueError("State and Hamiltonian must have the same number of sites")  # tdvp.py:91-93
+        if noise_model is not None:  # one realisation of static disorder per run (simulator.py:1269-1271)
+            noise_model = noise_model.sample(rng=disorder_rng(sim_params.random_seed))
         rank, world = 0, 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
@@ -417,6 +425,8 @@ class Simulator:
         ``sim_params.shots``, the measurement histogram.  Single rank; trajectories in chunks of ``batch``."""
         from .api import CircuitResult
 
+        if noise_model is not None:
+            noise_model = noise_model.sample(rng=disorder_rng(sim_params.random_seed))
         noisy = noise_model is not None and any(q["strength"] != 0 for q in noise_model.processes)
         num_traj, per_call, distribution = plan_digital_shots(sim_params, noisy)
         device = self.device or f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
