@@ -140,8 +140,9 @@ size_t svd_workspace_bytes(int max_dim, int B);
 size_t svd_carve(SvdWorkspace& w, char* base, int max_dim, int B);  // lays the buffers out behind base, returns the bytes used
 void profile_enable(int every);
 void profile_get(double* total_ms, double* total_bytes, long* samples);
+// accumulate = false: rotate X only (no W rows, no rotation record); the caller rebuilds the other factor from X
 int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspace& w, hipStream_t s, JacobiShape* shape_out,
-                 int* sweeps_out);
+                 int* sweeps_out, bool accumulate = true);
 int svd_extract(const ExtractDesc& x, const SvdWorkspace& w, const JacobiShape& sh, const int* chi_keep, int chi_stride, int nb0,
                 const int* ids, hipStream_t s);
 int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* sweeps_out);
@@ -164,6 +165,12 @@ struct QrWorkspace {
   QrWorkspace second() const { QrWorkspace q = *this; q.Z = Z2; q.V = V2; q.T = T2; return q; }
 };
 size_t qr_carve(QrWorkspace& q, char* base, int max_dim, int B);  // lays the buffers out behind base, returns the bytes used
+// helpers of the accumulation-free split (tjm_svd.hip: svd_split_qr2)
+int qr_gather_scaled(const cplx* G, long g_b0, int rows, int ncols, int d, const double* sigma, int sig_ld, const int* keep, int keep_stride,
+                     cplx* Z, long z_b0, int nb0, hipStream_t s);  // Z[k][bond*d+p] = G[(p,bond)][k] / sigma_k (0 beyond keep)
+int qr_identity(cplx* C, long c_b0, int rows, int ncols, int nb0, hipStream_t s);
+int qr_r_times_sigma(const cplx* Z, long z_b0, int zr, int ncols, const double* sigma, int sig_ld, const int* keep, int keep_stride, cplx* Rs,
+                     long rs_b0, int nb0, hipStream_t s);  // Rs[k][j] = R[k][j] sigma_j for k <= j < keep, else 0 (row-major ncols x ncols)
 int qr_adjoint_triangle(const QrWorkspace& q, int n, int nb0, const int* ids, hipStream_t s);  // Z2 = R^H of the factored Z
 size_t qr_workspace_bytes(int max_dim, int B);
 int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s);

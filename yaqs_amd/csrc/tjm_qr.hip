@@ -594,6 +594,91 @@ __global__ __launch_bounds__(256) void qr_adjoint_triangle_kernel(const cplx* __
 }
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void qr_gather_scaled_kernel(const cplx* __restrict__ G, long g_b0, int rows, int ncols, int d,
+                                                              const double* __restrict__ sigma, int sig_ld, const int* __restrict__ keep,
+                                                              int keep_stride, cplx* __restrict__ Z, long z_b0) {
+  const int b = blockIdx.y;
+  const cplx* Gb = G + (long)b * g_b0;
+  cplx* Zb = Z + (long)b * z_b0;
+  const int kp = keep[(long)b * keep_stride];
+  const int cap = rows / d;
+  const long total = (long)rows * ncols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / rows), rp = (int)(e % rows);  // destination: column k, bond-major row rp = bond * d + p
+    const int bond = rp / d, ph = rp % d;
+    cplx v{0.0, 0.0};
+    if (k < kp) {
+      const double sg = sigma[(long)b * sig_ld + k];
+      if (sg > 0.0) {
+        const double inv = 1.0 / sg;
+        v = Gb[((long)ph * cap + bond) * ncols + k];
+        v.x *= inv;
+        v.y *= inv;
+      }
+    }
+    Zb[e] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void qr_identity_kernel(cplx* __restrict__ C, long c_b0, int rows, int ncols) {
+  cplx* Cb = C + (long)blockIdx.y * c_b0;
+  const long total = (long)rows * ncols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
+    Cb[e] = cplx{(e / rows == e % rows) ? 1.0 : 0.0, 0.0};
+}
+
+__global__ __launch_bounds__(256) void qr_r_times_sigma_kernel(const cplx* __restrict__ Z, long z_b0, int zr, int ncols, const double* __restrict__ sigma,
+                                                              int sig_ld, const int* __restrict__ keep, int keep_stride, cplx* __restrict__ Rs,
+                                                              long rs_b0) {
+  const int b = blockIdx.y;
+  const cplx* Zb = Z + (long)b * z_b0;
+  cplx* Rb = Rs + (long)b * rs_b0;
+  const int kp = keep[(long)b * keep_stride];
+  const long total = (long)ncols * ncols;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e / ncols), j = (int)(e % ncols);
+    cplx v{0.0, 0.0};
+    if (k <= j && j < kp && k < zr) {
+      const double sg = sigma[(long)b * sig_ld + j];
+      v = Zb[(long)j * zr + k];
+      v.x *= sg;
+      v.y *= sg;
+    }
+    Rb[e] = v;
+  }
+}
+}  // namespace
+
+int qr_gather_scaled(const cplx* G, long g_b0, int rows, int ncols, int d, const double* sigma, int sig_ld, const int* keep, int keep_stride,
+                     cplx* Z, long z_b0, int nb0, hipStream_t s) {
+  const long total = (long)rows * ncols;
+  int gx = (int)((total + 1023) / 1024);
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(qr_gather_scaled_kernel, dim3(gx, nb0), dim3(256), 0, s, G, g_b0, rows, ncols, d, sigma, sig_ld, keep, keep_stride, Z, z_b0);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+int qr_identity(cplx* C, long c_b0, int rows, int ncols, int nb0, hipStream_t s) {
+  const long total = (long)rows * ncols;
+  int gx = (int)((total + 1023) / 1024);
+  if (gx > 128) gx = 128;
+  hipLaunchKernelGGL(qr_identity_kernel, dim3(gx, nb0), dim3(256), 0, s, C, c_b0, rows, ncols);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+int qr_r_times_sigma(const cplx* Z, long z_b0, int zr, int ncols, const double* sigma, int sig_ld, const int* keep, int keep_stride, cplx* Rs,
+                     long rs_b0, int nb0, hipStream_t s) {
+  const long total = (long)ncols * ncols;
+  int gx = (int)((total + 1023) / 1024);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(qr_r_times_sigma_kernel, dim3(gx, nb0), dim3(256), 0, s, Z, z_b0, zr, ncols, sigma, sig_ld, keep, keep_stride, Rs, rs_b0);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
 int qr_adjoint_triangle(const QrWorkspace& q, int n, int nb0, const int* ids, hipStream_t s) {
   const long total = (long)n * n;
   int gx = (int)((total + 1023) / 1024);

@@ -20,6 +20,7 @@
 // The isometric output is always read from W and the sigma-weighted output from the rotated
 // X for the two-site split, so that path never divides by a singular value.
 #include <cstdlib>
+#include <cstring>
 #include <utility>
 #include <vector>
 
@@ -448,9 +449,10 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
   extern __shared__ double smem[];
   int b = blockIdx.y;
   if (g.ids) b = g.ids[b];
-  double* rec = g.rec + ((long)b * gridDim.x + blockIdx.x) * (REC_PER_VISIT * 4);
+  const bool record = g.rec != nullptr;  // without accumulation nothing replays the rotations
+  double* rec = record ? g.rec + ((long)b * gridDim.x + blockIdx.x) * (REC_PER_VISIT * 4) : nullptr;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (g.done[b]) { if (tid == 0) rec[3] = 0.0; return; }
+  if (g.done[b]) { if (tid == 0 && record) rec[3] = 0.0; return; }
   const int rtot = g.rtot;
   const int xr = 64 * XRK;
   cplx* slots = reinterpret_cast<cplx*>(smem);                    // [8][2][xr]
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
     const int nzJ = st[2 * MAXBLK + 2 * J] | st[2 * MAXBLK + 2 * J + 1];
     const int ver = st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J];
     const int m1 = max(max(st[2 * I], st[2 * I + 1]), max(st[2 * J], st[2 * J + 1]));
-    if (!nzI || !nzJ || ver > m1) { if (tid == 0) rec[3] = 0.0; return; }
+    if (!nzI || !nzJ || ver > m1) { if (tid == 0 && record) rec[3] = 0.0; return; }
   }
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
   cplx yI[2][XRK], yJ[2][XRK];
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
       const bool second = lane & 2;
       double cv, sv, tv;
       make_rotation_lanes(second ? nI[1] : nI[0], second ? nJ[1 ^ sub] : nJ[sub], gsum, g.tol2, floor2, cv, sv, tv);
-      if (lane < 4) {
+      if (record && lane < 4) {
         double* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + (lane >> 1)) * 4);
         if (lane & 1) r4[2] = sv;
         else { r4[0] = cv; r4[1] = sv; }
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
   int total = 0;
 #pragma unroll
   for (int q = 0; q < NB; ++q) total += sCnt[q];
-  if (tid == 0) rec[3] = (total > 0) ? 1.0 : 0.0;  // flag slot of the first record: does the W half have work
+  if (tid == 0 && record) rec[3] = (total > 0) ? 1.0 : 0.0;  // flag slot of the first record: does the W half have work
   if (total == 0) {
     if (tid == 0) st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J] = g.clock;
     return;
@@ -969,19 +971,20 @@ size_t svd_workspace_bytes(int max_dim, int B) {
 }
 
 int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspace& w, hipStream_t s, JacobiShape* shape_out,
-                 int* sweeps_out) {
+                 int* sweeps_out, bool accumulate) {
   if (src.nb0 <= 0) return TJM_OK;
   static const bool no16 = getenv("TJM_NO_TILE16") != nullptr;
   static const bool no_split = getenv("TJM_NO_SPLIT") != nullptr;
   const int rx_top = round_up(src.rx, 16);
   const int ncols32 = round_up(src.ncols, 32);
   // split X / W scheme: 16-column blocks, X rows exactly 256 or 512 (one register layout each), W rows in groups of 64
-  const bool split16 = !no16 && !no_split && ncols32 >= 32 && (rx_top == 256 || rx_top == 512) && ncols32 % 64 == 0 && w.rec != nullptr &&
-                       src.nb0 <= 65535 && round_up(rx_top + ncols32, 64) <= 64 * MAXRK;
+  const int wrows32 = accumulate ? ncols32 : 0;  // rows of the accumulated unitary stacked under X
+  const bool split16 = !no16 && !no_split && ncols32 >= 32 && (rx_top == 256 || rx_top == 512) && ncols32 % 64 == 0 &&
+                       (w.rec != nullptr || !accumulate) && src.nb0 <= 65535 && round_up(rx_top + wrows32, 64) <= 64 * MAXRK;
   // fused 16-column blocks for the smaller matrices (two stacked columns per wavefront fit registers and LDS up to 512 rows)
-  const bool tile16 = split16 || (!no16 && ncols32 >= 32 && round_up(rx_top + ncols32, 64) <= 512);
+  const bool tile16 = split16 || (!no16 && ncols32 >= 32 && round_up(rx_top + wrows32, 64) <= 512);
   const int ncols_pad = tile16 ? ncols32 : round_up(src.ncols, 16);
-  const int rtot = round_up(rx_top + ncols_pad, 64);
+  const int rtot = round_up(rx_top + (accumulate ? ncols_pad : 0), 64);
   if (rtot > 64 * MAXRK) return TJM_ERR_NOT_IMPLEMENTED;  // register-resident columns: rx + ncols <= 1024
   if ((long)ncols_pad * rtot > w.y_b0) return TJM_ERR_WORKSPACE;
   const bool big = rtot > 512;  // 16 row groups per column instead of 8
@@ -1028,7 +1031,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   const int npairs = tile16 ? g.nblk / 4 : g.nblk / 2;
   const size_t lds16 = (size_t)2 * NB * rtot * sizeof(cplx) + 2 * NB * sizeof(double) + 16 * sizeof(int);
   const size_t lds16x = (size_t)2 * NB * rx_top * sizeof(cplx) + 2 * NB * sizeof(double) + 16 * sizeof(int);
-  g.rec = w.rec;
+  g.rec = accumulate ? w.rec : nullptr;
   const int max_sweeps = 40;
   int sweep = 0;
   int n_live = src.nb0;
@@ -1066,7 +1069,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
           TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot + 1], s));
           g_prof.pending.emplace_back(slot, (double)npairs * n_live * 4.0 * NB * rx_top * sizeof(cplx) * 2.0);
         }
-        hipLaunchKernelGGL(jacobi_cross16w_kernel, dim3(npairs, ncols_pad / 64, src.nb0), dim3(64), 0, s, g, rx_top);
+        if (accumulate) hipLaunchKernelGGL(jacobi_cross16w_kernel, dim3(npairs, ncols_pad / 64, src.nb0), dim3(64), 0, s, g, rx_top);
       } else if (tile16) hipLaunchKernelGGL(jacobi_cross16_kernel<8>, dim3(npairs, src.nb0), dim3(512), lds16, s, g);
       else if (big) hipLaunchKernelGGL(jacobi_cross_kernel<16>, dim3(npairs, src.nb0), dim3(512), lds, s, g);
       else hipLaunchKernelGGL(jacobi_cross_kernel<8>, dim3(npairs, src.nb0), dim3(512), lds, s, g);
@@ -1164,6 +1167,69 @@ static int svd_split_qr2(const SvdSplitDesc& d, const SvdWorkspace& w, const QrW
   tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
   tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
   JacobiShape sh;
+  static const bool accumulate_w = getenv("TJM_ACCUMULATE_W") != nullptr;
+  if (!accumulate_w && d.capM <= N && (long)N * d.capM + (long)d.capM * d.capM <= w.y_b0) {
+    // ---- accumulation-free variant: rotate X only (half the Jacobi traffic, no replay kernel).  With Y = X W the left
+    // singular vectors of Z are Uhat = Q Y Sigma^-1, and the isometric factor follows from the input itself,
+    //   G = op(theta) Uhat Sigma^-1   (op = identity for dist 0, adjoint for dist 1),
+    // whose columns are orthonormal up to eps * sigma_max / sigma_k.  A Householder QR G = Qu Ru restores an exactly
+    // isometric factor Qu, and Ru (identity up to that error) goes into the weighted factor, so the product is unchanged:
+    //   dist 0: theta ~ Qu (Ru Sigma Uhat^H),   dist 1: theta ~ (Uhat Sigma Ru^H) Qu^H.
+    if ((rc = jacobi_solve(src, tr, w, s, &sh, sweeps_out, false)) != TJM_OK) return rc;
+    const int cm = d.capM;
+    ExtractDesc xy;  // Uhat-to-be: normalised kept columns of Y into Z (N x capM, column-major)
+    xy.out = q.Z; xy.out_b0 = q.z_b0; xy.n_k = cm; xy.o_k = N; xy.n_r1 = 1; xy.n_r0 = N;
+    xy.o_r1 = 0; xy.o_r0 = 1; xy.row_off = 0; xy.conj = 0; xy.scale_mode = 2;
+    if ((rc = svd_extract(xy, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s)) != TJM_OK) return rc;
+    if ((rc = qr_apply_q(q, N, N, q.Z, q.z_b0, cm, d.nb0, d.ids, s)) != TJM_OK) return rc;  // Uhat, rows bond-major
+    cplx* G = w.Y;                  // [N][capM] row-major, natural row order; Y itself is no longer needed
+    cplx* Rs = w.Y + (long)N * cm;  // [capM][capM] row-major
+    {
+      GemmDesc g;
+      memset(&g, 0, sizeof(g));
+      g.nb0 = d.nb0; g.nb1 = 1; g.nb2 = 1;
+      g.B = q.Z; g.C = G;
+      g.N = cm; g.b_cs = N; g.c_rs = cm;
+      g.b_b0 = q.z_b0; g.c_b0 = w.y_b0; g.a_b0 = d.theta_b0;
+      g.A = d.theta;
+      if (d.distribution == 0) {
+        // G[(s,a)][k] = sum_{(c,t)} theta[(s,a)][(t,c)] Uhat[c*d+t][k]
+        g.M = d.m; g.a_rs = d.ld_theta;
+        g.nks = d.d; g.K = d.capR; g.a_ks = d.capR; g.a_cs = 1; g.b_ks = 1; g.b_rs = d.d;
+      } else {
+        // G[(t,c)][k] = sum_{(a,s)} conj(theta[(s,a)][(t,c)]) Uhat[a*d+s][k]
+        g.M = d.n; g.a_rs = 1; g.conjA = 1;
+        g.nks = d.d; g.K = d.capL; g.a_ks = (long)d.capL * d.ld_theta; g.a_cs = d.ld_theta; g.b_ks = 1; g.b_rs = d.d;
+      }
+      if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
+    }
+    if ((rc = qr_gather_scaled(G, w.y_b0, N, cm, d.d, w.norms, sh.ncols_pad, d.chiM, d.chi_stride, q2.Z, q2.z_b0, d.nb0, s)) != TJM_OK) return rc;
+    if ((rc = qr_factor(q2, N, cm, d.nb0, d.ids, s)) != TJM_OK) return rc;
+    if ((rc = qr_r_times_sigma(q2.Z, q2.z_b0, N, cm, w.norms, sh.ncols_pad, d.chiM, d.chi_stride, Rs, w.y_b0, d.nb0, s)) != TJM_OK) return rc;
+    if ((rc = qr_identity(G, w.y_b0, N, cm, d.nb0, s)) != TJM_OK) return rc;                       // thin Qu = Q2 [I; 0]
+    if ((rc = qr_apply_q(q2, N, cm, G, w.y_b0, cm, d.nb0, d.ids, s)) != TJM_OK) return rc;
+    ExtractDesc xi;
+    GemmDesc g;
+    memset(&g, 0, sizeof(g));
+    g.nks = 1; g.nb0 = d.nb0; g.nb1 = d.d; g.nb2 = 1; g.K = cm;
+    if (d.distribution == 0) {
+      // left[(s,a)][k] = Qu[a*d+s][k] ; right[t][k][c] = sum_j Rs[k][j] conj(Uhat[c*d+t][j])
+      xi.out = d.left; xi.out_b0 = d.left_b0; xi.n_k = cm; xi.o_k = 1; xi.n_r1 = d.capL; xi.n_r0 = d.d; xi.o_r1 = cm;
+      xi.o_r0 = (long)d.capL * cm; xi.row_off = 0; xi.conj = 0; xi.scale_mode = 0;
+      g.A = Rs; g.a_rs = cm; g.a_cs = 1; g.a_b0 = w.y_b0; g.M = cm;
+      g.B = q.Z; g.b_rs = N; g.b_cs = d.d; g.b_b0 = q.z_b0; g.b_b1 = 1; g.conjB = 1; g.N = d.capR;
+      g.C = d.right; g.c_rs = d.capR; g.c_b0 = d.right_b0; g.c_b1 = (long)cm * d.capR;
+    } else {
+      // right[t][k][c] = conj(Qu[c*d+t][k]) ; left[s][a][k] = sum_j Uhat[a*d+s][j] conj(Rs[k][j])
+      xi.out = d.right; xi.out_b0 = d.right_b0; xi.n_k = cm; xi.o_k = d.capR; xi.n_r1 = d.capR; xi.n_r0 = d.d;
+      xi.o_r1 = 1; xi.o_r0 = (long)cm * d.capR; xi.row_off = 0; xi.conj = 1; xi.scale_mode = 0;
+      g.A = q.Z; g.a_rs = d.d; g.a_cs = N; g.a_b0 = q.z_b0; g.a_b1 = 1; g.M = d.capL;
+      g.B = Rs; g.b_rs = 1; g.b_cs = cm; g.b_b0 = w.y_b0; g.conjB = 1; g.N = cm;
+      g.C = d.left; g.c_rs = cm; g.c_b0 = d.left_b0; g.c_b1 = (long)d.capL * cm;
+    }
+    if ((rc = qr_scatter(G, w.y_b0, N, xi, d.chiM, d.chi_stride, d.nb0, d.ids, s)) != TJM_OK) return rc;
+    return launch_gemm(g, s);
+  }
   if ((rc = jacobi_solve(src, tr, w, s, &sh, sweeps_out)) != TJM_OK) return rc;
   // isometric factor Q1 W
   TJM_HIP_CHECK(hipMemsetAsync(q2.Z, 0, (size_t)q2.z_b0 * sizeof(cplx) * (size_t)d.nb0, s));
