@@ -390,18 +390,30 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
   sW1[tid] = cplx{0.0, 0.0};
   __syncthreads();
   const int li = lane & 15, lk = lane >> 4;
-  {  // W1[i][c] = sum_r conj(V[i][r]) C[c][r]   (K = rows, split over the four wavefronts)
+  const int row0 = panel * PW;  // the reflector block is zero above its first row: start there
+  {  // W1[i][c] = sum_r conj(V[i][r]) C[c][r]   (K = rows in chunks of 16, split over the four wavefronts).  The order of the
+     // K index is free, so lane (li, lk) takes the four CONSECUTIVE rows base + 4 lk + q: 64-byte runs instead of 16-byte ones.
     d4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
-    const int nsteps = (zr + 3) >> 2;
+    const int nsteps = (zr - row0 + 15) >> 4;
     const bool cvalid = li < ncw;
+    const cplx* vcol = Vp + (long)li * zr;
+    const cplx* ccol = Cb + (long)(c0 + li) * zr;
     for (int s = wave; s < nsteps; s += 4) {
-      const int r = 4 * s + lk;
-      const cplx v = (r < zr) ? Vp[(long)li * zr + r] : cplx{0.0, 0.0};
-      const cplx x = (cvalid && r < zr) ? Cb[(long)(c0 + li) * zr + r] : cplx{0.0, 0.0};
-      P = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.x, P, 0, 0, 0);
-      Q = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, x.y, Q, 0, 0, 0);
-      S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, x.y, S1, 0, 0, 0);
-      S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, x.x, S2, 0, 0, 0);
+      const int rb = row0 + 16 * s + 4 * lk;
+      cplx v[4], x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = rb + q;
+        v[q] = (r < zr) ? vcol[r] : cplx{0.0, 0.0};
+        x[q] = (cvalid && r < zr) ? ccol[r] : cplx{0.0, 0.0};
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        P = __builtin_amdgcn_mfma_f64_16x16x4f64(v[q].x, x[q].x, P, 0, 0, 0);
+        Q = __builtin_amdgcn_mfma_f64_16x16x4f64(v[q].y, x[q].y, Q, 0, 0, 0);
+        S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[q].x, x[q].y, S1, 0, 0, 0);
+        S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[q].y, x[q].x, S2, 0, 0, 0);
+      }
     }
     for (int w = 0; w < 4; ++w) {  // deterministic reduction over the wavefronts
       if (wave == w) {
@@ -427,31 +439,33 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
     sW2[i * PW + c] = acc;
   }
   __syncthreads();
-  {  // C[c][r] -= sum_i V[i][r] W2[i][c] : D[row][c] = sum_i A[row][i] B[i][c]
+  {  // C[c][r] -= sum_i W2[i][c] V[i][r], computed transposed: D[c][row] = sum_i A[c][i] B[i][row] with A = W2^T, B = V^T, so that
+     // the 16 lanes of a row group read and write 16 consecutive rows of one column (256-byte runs)
     double wr[4], wi[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const cplx t = sW2[(4 * kk + lk) * PW + li];
+      const cplx t = sW2[(4 * kk + lk) * PW + li];  // A[c = li][i = 4kk + lk]
       wr[kk] = t.x;
       wi[kk] = t.y;
     }
-    const int nchunks = (zr + 15) >> 4;
+    const int nchunks = (zr - row0 + 15) >> 4;
     for (int ch = wave; ch < nchunks; ch += 4) {
-      const int r0 = ch * 16;
+      const int r0 = row0 + ch * 16;
       d4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const cplx v = (r0 + li < zr) ? Vp[(long)(4 * kk + lk) * zr + r0 + li] : cplx{0.0, 0.0};  // A[row = li][i = 4kk + lk]
-        P = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, wr[kk], P, 0, 0, 0);
-        Q = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, wi[kk], Q, 0, 0, 0);
-        S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.x, wi[kk], S1, 0, 0, 0);
-        S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v.y, wr[kk], S2, 0, 0, 0);
+        const cplx v = (r0 + li < zr) ? Vp[(long)(4 * kk + lk) * zr + r0 + li] : cplx{0.0, 0.0};  // B[i = 4kk + lk][row = li]
+        P = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[kk], v.x, P, 0, 0, 0);
+        Q = __builtin_amdgcn_mfma_f64_16x16x4f64(wi[kk], v.y, Q, 0, 0, 0);
+        S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wi[kk], v.x, S1, 0, 0, 0);
+        S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[kk], v.y, S2, 0, 0, 0);
       }
-      if (li < ncw) {
+      if (r0 + li < zr) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          if (r0 + lk + 4 * q >= zr) continue;
-          const long idx = (long)(c0 + li) * zr + r0 + lk + 4 * q;  // D: row = lk + 4q, column = li
+          const int c = lk + 4 * q;  // D: row (= column of C) lk + 4q, column (= row of C) li
+          if (c >= ncw) continue;
+          const long idx = (long)(c0 + c) * zr + r0 + li;
           cplx x = Cb[idx];
           x.x -= P[q] - Q[q];
           x.y -= S1[q] + S2[q];
