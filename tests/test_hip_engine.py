@@ -469,3 +469,23 @@ def test_scheduled_jumps_match_reference_fixture():
     bad = NoiseModel([], scheduled_jumps=[{"time": 0.1, "sites": [0], "name": "lowering"}, {"time": 0.1, "sites": [0], "name": "lowering"}])
     with pytest.raises(ValueError):  # sigma^- twice annihilates the state
         _run(L, o.MPSState.product(L, "zeros").tensors, bad, p, [g[f"mpo{i}"] for i in range(L)], [0])
+
+
+def test_get_state_returns_the_final_mps_of_a_closed_run():
+    """get_state (simulator.py:1438, 1555-1557): the final physical state of a noise-free run; noisy runs refuse it."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    L = 6
+    for order in (1, 2):
+        p = AnalogSimParams(observables=[Observable(Zg(), 0)], elapsed_time=0.3, dt=0.1, max_bond_dim=8, svd_threshold=1e-12, krylov_tol=1e-12,
+                            order=order, get_state=True, sample_timesteps=False)
+        res = Simulator().run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p)
+        op = o.Params(observables=[o.Obs(Z, 0)], elapsed_time=0.3, dt=0.1, max_bond_dim=8, svd_threshold=1e-12, krylov_tol=1e-12, order=order,
+                      get_state=True, sample_timesteps=False)
+        _, _, ref = o.run_trajectory(0, o.MPSState.product(L, "x+"), None, op, o.ising_mpo(L, 1.0, 0.5))
+        got = vec_of(res.output_state.tensors)
+        want = ref.to_vec()
+        assert np.allclose(phase_align(want, got), want, atol=1e-9), order
+    with pytest.raises(ValueError):
+        Simulator().run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p, NoiseModel([{"name": "pauli_z", "sites": [0], "strength": 0.1}]))

@@ -391,6 +391,8 @@ class Simulator:
             rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
         device = self.device or f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
         noisy = noise_model is not None and any(q["strength"] != 0 for q in noise_model.processes)
+        if noisy and sim_params.get_state:
+            raise ValueError("Cannot return state in noisy analog simulation due to stochastics.")  # simulator.py:1555-1557
         num_traj = sim_params.num_traj if noisy else 1  # simulator.py:1549-1559
         lo, hi = shard_range(num_traj, rank, world)
         mine = list(range(lo, hi))
@@ -414,11 +416,19 @@ class Simulator:
             res_all[done: done + len(chunk)] = r
             diag_all[done: done + len(chunk)] = dg
             done += len(chunk)
+        final = None
+        if sim_params.get_state and engine is not None and 0 in mine:
+            # the physical state at the last time: the trajectory state (order 1) or the last sampled copy psi (order 2,
+            # analog_tjm.py:331-366); closed-system runs have one trajectory, slot 0 of the first chunk
+            use_psi = sim_params.order == 2 and len(sim_params.times) > 1
+            final = MPS(initial_state.length, tensors=engine.export_state(0, 1 if use_psi else 0))
         if engine is not None:
             engine.close()
         if world > 1:
             res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, lo, device)
-        return Result(sim_params, res_all, diag_all)
+        out = Result(sim_params, res_all, diag_all)
+        out.output_state = final
+        return out
 
     def run_circuit(self, initial_state: MPS, layers, sim_params, noise_model: NoiseModel | None = None, basis: str = "Z"):
         """Circuit runs (simulator.py:1681-1830 with gate layers instead of a qiskit circuit): observables, diagnostics and, with
