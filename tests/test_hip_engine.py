@@ -489,3 +489,25 @@ def test_get_state_returns_the_final_mps_of_a_closed_run():
         assert np.allclose(phase_align(want, got), want, atol=1e-9), order
     with pytest.raises(ValueError):
         Simulator().run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p, NoiseModel([{"name": "pauli_z", "sites": [0], "strength": 0.1}]))
+
+
+def test_piecewise_hamiltonian_matches_reference_fixture():
+    """A tuple of MPOs, one per interval, through TrajectoryBatch.set_intervals (engine re-loads the MPO between steps)."""
+    from yaqs_amd.api import AnalogSimParams, MPS, NoiseModel, Observable, X as Xg, Z as Zg
+    from yaqs_amd.tjm import TrajectoryBatch
+
+    g = load("piecewise")
+    L, n = 6, 4
+    hams = [[g[f"h{k}_mpo{i}"] for i in range(L)] for k in range(n)]
+    noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.1} for i in range(L)])
+    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 2)]
+    for order in (1, 2):
+        p = AnalogSimParams(observables=obs, elapsed_time=0.1 * n, dt=0.1, max_bond_dim=8, svd_threshold=1e-10, krylov_tol=1e-10, order=order,
+                            sample_timesteps=True, random_seed=5)
+        e = make_engine(L, 8, 3, hams[0])
+        tb = TrajectoryBatch(e, p, noise)
+        tb.set_intervals(hams)
+        r, d = tb.run([0, 1, 2], MPS(L, state="x+"), native=True)  # the host schedule takes over for piecewise drives
+        e.close()
+        assert np.allclose(r, g[f"order{order}_results"], atol=1e-8), order
+        assert np.array_equal(d, g[f"order{order}_diag"]), order

@@ -341,3 +341,25 @@ def test_scheduled_jumps_match_reference():
         r, dg, _ = o.analog_tjm_1(t, o.MPSState.product(L, "x+"), noise, p, mpo, scheduled=sched)
         assert np.allclose(r, g["results"][t], atol=1e-9), t
         assert np.array_equal(dg, g["diag"][t]), t
+
+
+def _piecewise_setup(g):
+    L, n = 6, 4
+    hams = tuple([g[f"h{k}_mpo{i}"] for i in range(L)] for k in range(n))
+    noise = [o.make_process("pauli_z", [i], 0.1) for i in range(L)]
+    obs = [o.Obs(Z, s) for s in range(L)] + [o.Obs(X, 2)]
+    return L, n, hams, noise, obs
+
+
+def test_piecewise_hamiltonian_matches_reference():
+    """One MPO per time interval (analog_tjm.py:43-49): interval j-1 for step j (order 1); j-2 for the step and j-1 for the
+    sample of order 2 (analog_tjm.py:351-360)."""
+    g = load("piecewise")
+    L, n, hams, noise, obs = _piecewise_setup(g)
+    for order in (1, 2):
+        p = o.Params(observables=obs, elapsed_time=0.1 * n, dt=0.1, max_bond_dim=8, svd_threshold=1e-10, krylov_tol=1e-10, order=order,
+                     sample_timesteps=True, random_seed=5)
+        for t in range(3):
+            r, dg, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), noise, p, hams)
+            assert np.allclose(r, g[f"order{order}_results"][t], atol=1e-9), (order, t)
+            assert np.array_equal(dg, g[f"order{order}_diag"][t]), (order, t)

@@ -475,7 +475,34 @@ def gen_scheduled():
     save("scheduled", **out)
 
 
+def gen_piecewise():
+    """Piecewise-constant Hamiltonian: a tuple of MPOs, one per time interval (analog_tjm.py:43-49, 351-360), order 1 and 2."""
+    atjm = ref("analog.analog_tjm")
+    L, n = 6, 4
+    gs = [0.3, 0.9, -0.4, 0.6]
+    hams = tuple(MPO.ising(L, 1.0, g) for g in gs)
+    st = MPS(L, state="x+")
+    noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.1} for i in range(L)])
+    obs = [sp.Observable(gl.Z(), s) for s in range(L)] + [sp.Observable(gl.X(), 2)]
+    out = {"g": np.array(gs)}
+    for k, h in enumerate(hams):
+        for i, w in enumerate(h.tensors):
+            out[f"h{k}_mpo{i}"] = w
+    for order in (1, 2):
+        p = sp.AnalogSimParams(observables=obs, elapsed_time=0.1 * n, dt=0.1, max_bond_dim=8, svd_threshold=1e-10, krylov_tol=1e-10, order=order,
+                               sample_timesteps=True, random_seed=5)
+        fn = atjm.analog_tjm_1 if order == 1 else atjm.analog_tjm_2
+        res, diag = [], []
+        for i in range(3):
+            r, dg, _ = fn((i, st, noise, p, hams))
+            res.append(np.asarray(r, dtype=np.float64))
+            diag.append(dg)
+        out[f"order{order}_results"] = np.array(res)
+        out[f"order{order}_diag"] = np.array(diag)
+    save("piecewise", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled"]
+    which = sys.argv[1:] or ["rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
     for w in which:
         globals()["gen_" + w]()

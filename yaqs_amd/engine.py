@@ -47,6 +47,14 @@ class BatchEngine:
         self.caps = caps
         self.padded_elems = int(self.lib.tjm_engine_padded_state_elems(self.h))
 
+    def set_mpo(self, mpo: Sequence[np.ndarray]):
+        """Replace the Hamiltonian (piecewise-constant drives, analog_tjm.py:43-49); bond dimensions must match the engine's."""
+        bonds = _i32([int(mpo[0].shape[2])] + [int(w.shape[3]) for w in mpo])
+        if len(mpo) != self.L or not np.array_equal(bonds, self.mpo_bonds):
+            raise NotImplementedError("piecewise Hamiltonians must share the MPO bond dimensions the engine was created with")
+        packed = np.concatenate([np.ascontiguousarray(w, dtype=np.complex128).reshape(-1) for w in mpo])
+        _lib.check(self.lib.tjm_engine_set_mpo(self.h, packed.ctypes.data), "set_mpo")
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.tjm_engine_destroy(self.h)

@@ -77,6 +77,22 @@ class TrajectoryBatch:
         self.sorted_obs = params.sorted_observables
         self.dp_log: list[np.ndarray] = []
         self.jump_log: list[np.ndarray] = []
+        self.intervals = None  # piecewise-constant Hamiltonian: one MPO tensor list per time interval
+        self._interval_loaded = None
+
+    def set_intervals(self, mpos) -> None:
+        """``hamiltonian`` given as a tuple of MPOs, one per interval of the time grid (analog_tjm.py:43-49)."""
+        mpos = [m.tensors if hasattr(m, "tensors") else m for m in mpos]
+        if len(mpos) != len(self.p.times) - 1:
+            raise ValueError("a piecewise Hamiltonian needs one MPO per time interval")
+        self.intervals = mpos
+        self._interval_loaded = None
+
+    def _tdvp(self, set_index: int, interval: int) -> None:
+        if self.intervals is not None and self._interval_loaded != interval:
+            self.e.set_mpo(self.intervals[interval])
+            self._interval_loaded = interval
+        self.e.tdvp(set_index)
 
     # ---- measurement ----------------------------------------------------------------
     def _measure(self, set_index: int, results: np.ndarray, diagnostics: np.ndarray, col: int) -> None:
@@ -156,7 +172,7 @@ class TrajectoryBatch:
             for j in self.noise.scheduled_jumps:
                 if not np.any(np.isclose(p.times, j["time"], atol=p.dt * 1e-3, rtol=0.0)):
                     raise ValueError(f"Scheduled jump time {j['time']} is not on the simulation time grid.")  # noise_model.py:768-775
-        if native and not self.meta_obs and not has_sched:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
+        if native and not self.meta_obs and not has_sched and self.intervals is None:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
             e.load_state(initial.tensors, 0)
             obs = [(o_.first_site, np.asarray(o_.gate.matrix, dtype=np.complex128)) for o_ in self.sorted_obs]
             return e.run(order=p.order, n_times=n_t, sample_timesteps=p.sample_timesteps, has_noise=self.noise is not None,
@@ -203,7 +219,7 @@ class TrajectoryBatch:
         if p.sample_timesteps:
             self._measure(0, results, diagnostics, 0)
         for j in range(1, n_t):
-            e.tdvp(0)
+            self._tdvp(0, j - 1)
             if self.noise is not None:
                 e.dissipate(p.dt, 0)
                 due = self._scheduled_at(p.times[j])
@@ -228,7 +244,7 @@ class TrajectoryBatch:
             if not record(j):
                 return
             e.copy_state(1, 0)  # psi = deepcopy(phi)
-            e.tdvp(1)
+            self._tdvp(1, j - 1)  # capture_sample(phi, j, interval j - 1), analog_tjm.py:347, 360
             e.dissipate(p.dt / 2, 1)
             us = np.stack([sample_uniforms(p.random_seed, int(t), j) for t in traj_indices])
             self._stochastic(1, p.dt, us, None)
@@ -244,7 +260,7 @@ class TrajectoryBatch:
         self._stochastic(0, p.dt, u, pos)
         sample(1)
         for j in range(2, n_t):
-            e.tdvp(0)
+            self._tdvp(0, j - 2)  # step_through with interval j - 2, analog_tjm.py:351-358
             e.dissipate(p.dt, 0)
             self._stochastic(0, p.dt, u, pos)
             sample(j)
@@ -382,6 +398,12 @@ class Simulator:
     def run(self, initial_state: MPS, hamiltonian: MPO, sim_params: AnalogSimParams, noise_model: NoiseModel | None = None) -> Result:
         import torch
 
+        pieces = None
+        if isinstance(hamiltonian, (tuple, list)):  # piecewise-constant drive: one MPO per interval
+            pieces = list(hamiltonian)
+            if not pieces:
+                raise ValueError("a piecewise Hamiltonian needs at least one MPO")
+            hamiltonian = pieces[0]
         if hamiltonian.length != initial_state.length:
             raise ValueError("State and Hamiltonian must have the same number of sites")  # tdvp.py:91-93
         if noise_model is not None:  # one realisation of static disorder per run (simulator.py:1269-1271)
@@ -412,6 +434,8 @@ class Simulator:
                     engine.close()
                 engine = BatchEngine(initial_state.length, chi, len(chunk), hamiltonian.tensors, device=device)
             tb = TrajectoryBatch(engine, sim_params, noise_model)  # the backend sees the model as given (simulator.py:1549-1559)
+            if pieces is not None:
+                tb.set_intervals(pieces)
             r, dg = tb.run(chunk, initial_state, native=self.native)
             res_all[done: done + len(chunk)] = r
             diag_all[done: done + len(chunk)] = dg
