@@ -298,3 +298,40 @@ def test_svd_split_large_rectangular_and_odd_sizes(lib, capL, capR):
             trunc = (ref_u[:, :capM] * ref_s[:capM]) @ ref_vh[:capM]
             assert np.allclose(L_ @ R_, trunc, atol=1e-11)
             assert np.allclose(L_.conj().T @ L_, np.eye(capM), atol=1e-12)
+
+
+@pytest.mark.parametrize("dist", [0, 1])
+def test_svd_split_qr_rank_deficient_and_ragged_square(lib, dist):
+    """Square theta through the accumulation-free doubly preconditioned path: kept ZERO singular values (threshold 0 keeps
+    everything up to max_bond, the rank is smaller) and ragged zero-padded bonds.  The isometric factor must stay exactly
+    isometric (orthonormal completion by the QR), padding exactly zero, and the product must reproduce theta."""
+    rng = np.random.default_rng(77 + dist)
+    d, cap, B = 2, 32, 4
+    n = d * cap
+    chiL = np.array([32, 32, 11, 20], dtype=np.int32)
+    chiR = np.array([32, 32, 17, 5], dtype=np.int32)
+    theta = np.zeros((B, n, n), dtype=np.complex128)
+    theta[0] = crand(rng, n, 10) @ crand(rng, 10, n)          # rank 10, keep 32
+    theta[1] = crand(rng, n, n)                                # full rank
+    for b in (2, 3):
+        t = crand(rng, d, chiL[b], d, chiR[b])
+        full = np.zeros((d, cap, d, cap), dtype=np.complex128)
+        full[:, : chiL[b], :, : chiR[b]] = t
+        theta[b] = full.reshape(n, n)
+    capM = 32
+    left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, cap, cap, capM, dist, 0, 0.0, capM, 2, chiL, chiR, qr=True)
+    for b in range(B):
+        k = keep[b]
+        nsv = min(d * chiL[b], d * chiR[b])
+        assert k == min(capM, nsv), (b, k)
+        s_ref = np.linalg.svd(theta[b], compute_uv=False)
+        assert np.allclose(spec[b, :n], s_ref, atol=1e-12 * s_ref[0])
+        L_ = left[b].reshape(n, capM)
+        R_ = right[b].transpose(1, 0, 2).reshape(capM, n)
+        u, s, vh = np.linalg.svd(theta[b])
+        trunc = (u[:, :k] * s[:k]) @ vh[:k]
+        assert np.allclose(L_ @ R_, trunc, atol=1e-11 * s_ref[0]), b
+        iso = L_[:, :k] if dist == 0 else R_[:k].conj().T
+        assert np.allclose(iso.conj().T @ iso, np.eye(k), atol=1e-12), b
+        assert np.all(left[b][:, chiL[b]:, :] == 0) and np.all(right[b][:, :, chiR[b]:] == 0), b
+        assert np.all(left[b][:, :, k:] == 0) and np.all(right[b][:, k:, :] == 0), b
