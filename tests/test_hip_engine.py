@@ -511,3 +511,40 @@ def test_piecewise_hamiltonian_matches_reference_fixture():
         e.close()
         assert np.allclose(r, g[f"order{order}_results"], atol=1e-8), order
         assert np.array_equal(d, g[f"order{order}_diag"]), order
+
+
+def test_config4_like_one_site_tdvp_long_range_mpo_padded_state():
+    """Config 4 of SURVEY section 8d in small: exponential-sum long-range Ising MPO (D = 4) built on the host, "x+" padded with zeros
+    to a fixed chi (tangent space of the padded isometries), tdvp_mode = "1site", dephasing; the same MPO tensors go to the oracle.
+    The MPO is checked against the dense Hamiltonian it stands for."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
+
+    L, chi = 10, 32
+    mpo = MPO.long_range_ising(L, [1.0, 0.25], [0.35, 0.7], 0.5)
+    st = MPS(L, state="x+", pad=chi)
+    assert max(t.shape[2] for t in st.tensors) == chi and st.tensors[4].shape == (2, 16, 32)
+    # the MPO is the Hamiltonian it claims to be
+    def embed(i, op):  # site 0 is the fastest index (mps.py:1633-1658)
+        return np.kron(np.eye(2 ** (L - 1 - i)), np.kron(op, np.eye(2 ** i)))
+
+    H = o.mpo_to_matrix(mpo.tensors)
+    ref = np.zeros_like(H)
+    zs = [embed(i, Z) for i in range(L)]
+    for i in range(L):
+        ref -= 0.5 * embed(i, X)
+        for j in range(i + 1, L):
+            ref -= (1.0 * 0.35 ** (j - i - 1) + 0.25 * 0.7 ** (j - i - 1)) * (zs[i] @ zs[j])
+    assert np.allclose(H, ref, atol=1e-12)
+    obs = [Observable(Zg(), s) for s in range(L)]
+    noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.05} for i in range(L)])
+    p = AnalogSimParams(observables=obs, elapsed_time=0.15, dt=0.05, max_bond_dim=chi, svd_threshold=1e-12, krylov_tol=1e-10, order=1,
+                        sample_timesteps=True, random_seed=42, tdvp_mode="1site")
+    init = [t.copy() for t in st.tensors]
+    r, d, _ = _run(L, init, noise, p, mpo.tensors, [0, 1])
+    op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], elapsed_time=0.15, dt=0.05, max_bond_dim=chi, svd_threshold=1e-12, krylov_tol=1e-10,
+                  order=1, sample_timesteps=True, random_seed=42, tdvp_mode="1site")
+    on = [o.make_process("pauli_z", [i], 0.05) for i in range(L)]
+    for t in range(2):
+        ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, mpo.tensors)
+        assert np.allclose(r[t], ro, atol=1e-8), np.abs(r[t] - ro).max()
+        assert np.array_equal(d[t], do)

@@ -471,6 +471,21 @@ class MPS:
             else:
                 raise ValueError("Invalid state string")
             self.tensors.append(v.reshape(2, 1, 1))
+        if pad is not None:
+            self.pad_bond_dimension(pad)
+
+    def pad_bond_dimension(self, target_dim: int) -> None:
+        """Zero-pad every internal bond k to ``min(target_dim, 2**min(k, L-k))`` and re-canonicalise (mps.py:409-452): the start
+        of fixed-chi runs such as one-site TDVP, whose tangent space is spanned by the padded isometries."""
+        caps = self.bond_caps(self.length, target_dim)
+        for i, t in enumerate(self.tensors):
+            d, cl, cr = t.shape
+            if cl > caps[i] or cr > caps[i + 1]:
+                raise ValueError("Target bond dim must be at least current bond dim.")
+            new = np.zeros((d, caps[i], caps[i + 1]), dtype=C128)
+            new[:, :cl, :cr] = t
+            self.tensors[i] = new
+        self.normalize("B")
 
     def normalize(self, form: str = "B") -> None:
         """Right-canonical form with centre 0 and norm 1 (``MPS.normalize("B")``, mps.py:815-839).
@@ -513,6 +528,22 @@ class MPO:
     @property
     def length(self) -> int:
         return len(self.tensors)
+
+    @classmethod
+    def long_range_ising(cls, length: int, coeffs, decays, g: float) -> "MPO":
+        """H = -sum_{i<j} f(j-i) Z_i Z_j - g sum_i X_i with f(r) = sum_k coeffs[k] * decays[k]**(r-1): the exponential-sum
+        form of a power-law coupling as a finite-state-machine MPO of bond dimension K + 2."""
+        K = len(coeffs)
+        D = K + 2
+        w = np.zeros((D, D, 2, 2), dtype=C128)
+        w[0, 0] = _I
+        w[D - 1, D - 1] = _I
+        w[0, D - 1] = -g * _X
+        for k in range(K):
+            w[0, 1 + k] = -coeffs[k] * _Z
+            w[1 + k, 1 + k] = decays[k] * _I
+            w[1 + k, D - 1] = _Z
+        return cls._fsm(length, w)
 
     @classmethod
     def _fsm(cls, length: int, w: np.ndarray) -> "MPO":
