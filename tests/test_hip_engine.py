@@ -548,3 +548,17 @@ def test_config4_like_one_site_tdvp_long_range_mpo_padded_state():
         ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, mpo.tensors)
         assert np.allclose(r[t], ro, atol=1e-8), np.abs(r[t] - ro).max()
         assert np.array_equal(d[t], do)
+
+
+def test_entry_points_work_in_a_fresh_interpreter():
+    """build() then smoke() in one fresh process, the way the driver calls them: the library is loaded before anything else has
+    touched the GPU and must still share PyTorch's HIP runtime (a second runtime instance sees no device)."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=ROOT, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "smoke ok" in out.stdout

@@ -111,6 +111,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C yaqs_amd/csrc).  yaqs_amd has no CPU fallback."
         )
+    # PyTorch ships its own libamdhip64; load it FIRST so that this library binds to the same HIP runtime instance.  Loaded the
+    # other way round, the process holds two runtimes and the second one reports "no ROCm-capable device is detected".
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)
