@@ -562,3 +562,31 @@ def test_entry_points_work_in_a_fresh_interpreter():
                          timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "smoke ok" in out.stdout
+
+
+@pytest.mark.parametrize("L", [1, 2, 3])
+@pytest.mark.parametrize("order", [1, 2])
+def test_tiny_chains_and_zero_duration(L, order):
+    """Edge cases of the drivers: one-, two- and three-site chains (tdvp.py:96-100 falls back to 1TDVP on one site), a
+    zero-duration run (analog_tjm.py:313-321), zero noise strength, a trajectory count that is not a multiple of the batch."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, X as Xg, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    obs = [Observable(Zg(), L - 1), Observable(Xg(), 0)]
+    oobs = [o.Obs(Z, L - 1), o.Obs(X, 0)]
+    mpo_o = o.ising_mpo(L, 1.0, 0.7)
+    for elapsed, gamma, ntraj in ((0.3, 0.3, 5), (0.0, 0.3, 3), (0.2, 0.0, 4)):
+        p = AnalogSimParams(observables=obs, elapsed_time=elapsed, dt=0.1, num_traj=ntraj, max_bond_dim=4, svd_threshold=1e-10, krylov_tol=1e-10,
+                            order=order, random_seed=13)
+        noise = NoiseModel([{"name": "lowering", "sites": [i], "strength": gamma} for i in range(L)])
+        res = Simulator(batch=2).run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.7), p, noise)
+        op = o.Params(observables=oobs, elapsed_time=elapsed, dt=0.1, max_bond_dim=4, svd_threshold=1e-10, krylov_tol=1e-10, order=order,
+                      random_seed=13)
+        on = [o.make_process("lowering", [i], gamma) for i in range(L)]
+        idx = op.observable_sorted_indices
+        n_eff = ntraj if gamma > 0 else 1
+        assert res.trajectories[0].shape[0] == n_eff
+        for t in range(n_eff):
+            r, _, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), on, op, mpo_o)
+            for u in range(2):
+                assert np.allclose(res.trajectories[u][t], r[idx[u]], atol=1e-8), (L, order, elapsed, gamma, t, u)

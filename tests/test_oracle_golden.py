@@ -363,3 +363,17 @@ def test_piecewise_hamiltonian_matches_reference():
             r, dg, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), noise, p, hams)
             assert np.allclose(r, g[f"order{order}_results"][t], atol=1e-9), (order, t)
             assert np.array_equal(dg, g[f"order{order}_diag"][t]), (order, t)
+
+
+def test_one_and_two_site_chains_match_reference():
+    """L = 1 takes the 1TDVP fallback (tdvp.py:96-98); L = 2 has a single bond."""
+    g = load("tiny")
+    for L in (1, 2):
+        mpo = [g[f"L{L}_mpo{i}"] for i in range(L)]
+        noise = [o.make_process("lowering", [i], 0.3) for i in range(L)]
+        for order in (1, 2):
+            p = o.Params(observables=[o.Obs(Z, L - 1), o.Obs(X, 0)], elapsed_time=0.3, dt=0.1, max_bond_dim=4, svd_threshold=1e-10,
+                         krylov_tol=1e-10, order=order, sample_timesteps=True, random_seed=13)
+            for t in range(5):
+                r, _, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), noise, p, mpo)
+                assert np.allclose(r, g[f"L{L}_order{order}"][t], atol=1e-9), (L, order, t)

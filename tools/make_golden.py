@@ -502,7 +502,30 @@ def gen_piecewise():
     save("piecewise", **out)
 
 
+def gen_tiny():
+    """One- and two-site chains (tdvp.py:96-100: a single site falls back to 1TDVP), order 1 and 2, amplitude damping."""
+    atjm = ref("analog.analog_tjm")
+    out = {}
+    for L in (1, 2):
+        H = MPO.ising(L, 1.0, 0.7)
+        st = MPS(L, state="x+")
+        noise = NoiseModel([{"name": "lowering", "sites": [i], "strength": 0.3} for i in range(L)])
+        obs = [sp.Observable(gl.Z(), L - 1), sp.Observable(gl.X(), 0)]
+        for i, w in enumerate(H.tensors):
+            out[f"L{L}_mpo{i}"] = w
+        for order in (1, 2):
+            p = sp.AnalogSimParams(observables=obs, elapsed_time=0.3, dt=0.1, max_bond_dim=4, svd_threshold=1e-10, krylov_tol=1e-10, order=order,
+                                   sample_timesteps=True, random_seed=13)
+            fn = atjm.analog_tjm_1 if order == 1 else atjm.analog_tjm_2
+            res = []
+            for i in range(5):
+                r, _, _ = fn((i, st, noise, p, H))
+                res.append(np.asarray(r, dtype=np.float64))
+            out[f"L{L}_order{order}"] = np.array(res)
+    save("tiny", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
+    which = sys.argv[1:] or ["tiny", "rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
     for w in which:
         globals()["gen_" + w]()

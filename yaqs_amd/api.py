@@ -551,7 +551,9 @@ class MPO:
         bulk = w.transpose(2, 3, 0, 1)
         t = []
         for i in range(length):
-            if i == 0:
+            if length == 1:
+                t.append(bulk[:, :, 0:1, D - 1:D].copy())
+            elif i == 0:
                 t.append(bulk[:, :, 0:1, :].copy())
             elif i == length - 1:
                 t.append(bulk[:, :, :, D - 1:D].copy())

@@ -55,7 +55,7 @@ void small_expm(const cplx* in, int n, cplx* out) {
 }  // namespace
 
 int Engine::create(int L_, int d_, int chi_, int B_, const int* mpo_bond) {
-  if (L_ < 2 || d_ != 2 || chi_ < 1 || B_ < 1) return TJM_ERR_ARG;  // qubit chains only for now
+  if (L_ < 1 || d_ != 2 || chi_ < 1 || B_ < 1) return TJM_ERR_ARG;  // qubit chains only for now
   L = L_; d = d_; chi_max = chi_; B = B_;
   cap.assign(L + 1, 1);
   long left = 1;
@@ -720,7 +720,7 @@ int Engine::tdvp(int set) {
   if (tdvp_mode != 2 && tdvp_mode != 1) return TJM_ERR_NOT_IMPLEMENTED;
   StateSet& S = sets[set];
   int rc;
-  if (tdvp_mode == 1) {
+  if (tdvp_mode == 1 || L == 1) {  // a one-site chain falls back to 1TDVP (tdvp.py:96-98)
     for (int sw = 0; sw < tdvp_sweeps; ++sw)
       if ((rc = sweep_1site(S, 1.0 / tdvp_sweeps)) != TJM_OK) return rc;
     return TJM_OK;
