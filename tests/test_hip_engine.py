@@ -590,3 +590,25 @@ def test_tiny_chains_and_zero_duration(L, order):
             r, _, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), on, op, mpo_o)
             for u in range(2):
                 assert np.allclose(res.trajectories[u][t], r[idx[u]], atol=1e-8), (L, order, elapsed, gamma, t, u)
+
+
+def test_unbounded_bond_dimension_is_exact_or_refused():
+    """max_bond_dim=None (the "exact" preset): the engine gets the exact maximum Schmidt rank as capacity and reproduces dense
+    evolution; on chains where that exceeds the supported size the run is refused, never silently truncated."""
+    import scipy.linalg
+
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, Observable, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    L = 8
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=0.5, dt=0.05, max_bond_dim=None, svd_threshold=1e-14,
+                        krylov_tol=1e-12, order=2, sample_timesteps=False)
+    res = Simulator().run(MPS(L, state="x+"), MPO.heisenberg(L, 1.0, 0.8, 0.5, 0.3), p)
+    H = o.mpo_to_matrix(o.heisenberg_mpo(L, 1.0, 0.8, 0.5, 0.3))
+    psi0 = o.MPSState.product(L, "x+").to_vec()
+    psi = scipy.linalg.expm(-1j * 0.5 * H) @ psi0
+    for s in range(L):
+        zs = np.kron(np.eye(2 ** (L - 1 - s)), np.kron(Z, np.eye(2 ** s)))
+        assert abs(res.expectation_values[s][0] - np.vdot(psi, zs @ psi).real) < 2e-5  # second-order splitting error of dt = 0.05
+    with pytest.raises(NotImplementedError):
+        Simulator().run(MPS(40, state="x+"), MPO.ising(40, 1.0, 0.5), AnalogSimParams(observables=[Observable(Zg(), 0)], max_bond_dim=None))

@@ -418,8 +418,7 @@ class Simulator:
         num_traj = sim_params.num_traj if noisy else 1  # simulator.py:1549-1559
         lo, hi = shard_range(num_traj, rank, world)
         mine = list(range(lo, hi))
-        chi = sim_params.max_bond_dim or max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors)
-        chi = max(chi, max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors))
+        chi = engine_bond_cap(sim_params, initial_state)
         cols = len(sim_params.times) if sim_params.sample_timesteps else 1
         n_obs = len(sim_params.observables)
         res_all = np.zeros((len(mine), n_obs, cols))
@@ -464,8 +463,7 @@ class Simulator:
         noisy = noise_model is not None and any(q["strength"] != 0 for q in noise_model.processes)
         num_traj, per_call, distribution = plan_digital_shots(sim_params, noisy)
         device = self.device or f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
-        chi = sim_params.max_bond_dim or 2 ** (initial_state.length // 2)
-        chi = max(chi, max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors))
+        chi = engine_bond_cap(sim_params, initial_state)
         mid = sim_params.num_mid_measurements if sim_params.sample_layers else 0
         cols = (mid + 2) if sim_params.sample_layers else 1
         res_all = np.zeros((num_traj, len(sim_params.observables), cols))
@@ -493,6 +491,24 @@ class Simulator:
         if engine is not None:
             engine.close()
         return CircuitResult(sim_params, res_all, diag_all, counts if wants_shots else None)
+
+
+MAX_CHI = 256  # largest bond the register-resident Jacobi SVD holds (d * chi <= 512)
+
+
+def engine_bond_cap(sim_params, initial_state) -> int:
+    """Static bond capacity of the engine.  With ``max_bond_dim=None`` (no cap, the "exact" preset) the capacity is the exact
+    maximum Schmidt rank 2**(L//2); beyond the supported size this raises instead of silently truncating."""
+    have = max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors)
+    want = sim_params.max_bond_dim
+    if want is None:
+        want = 2 ** (initial_state.length // 2)
+        if want > MAX_CHI:
+            raise NotImplementedError(f"max_bond_dim=None on {initial_state.length} sites needs bonds up to {want}; the HIP path holds chi <= {MAX_CHI}")
+    chi = max(int(want), have)
+    if chi > MAX_CHI:
+        raise NotImplementedError(f"bond dimension {chi} exceeds the supported chi <= {MAX_CHI}")
+    return chi
 
 
 def plan_digital_shots(sim_params, noisy: bool):
