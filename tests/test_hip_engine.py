@@ -612,3 +612,26 @@ def test_unbounded_bond_dimension_is_exact_or_refused():
         assert abs(res.expectation_values[s][0] - np.vdot(psi, zs @ psi).real) < 2e-5  # second-order splitting error of dt = 0.05
     with pytest.raises(NotImplementedError):
         Simulator().run(MPS(40, state="x+"), MPO.ising(40, 1.0, 0.5), AnalogSimParams(observables=[Observable(Zg(), 0)], max_bond_dim=None))
+
+
+def test_simulator_normalises_the_initial_state_like_the_reference():
+    """Simulator.run brings the given MPS to B-normal form on a copy (state.py:278-297): a left-canonical, unnormalised Haar state
+    gives the same results as handing over its normalised form, and the caller's tensors stay untouched."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, Observable, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    L, chi = 6, 8
+    raw = MPS(L, state="haar-random", pad=chi, rng=np.random.default_rng(3))
+    raw.tensors[2] = 1.7 * raw.tensors[2]
+    keep = [t.copy() for t in raw.tensors]
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=0.2, dt=0.1, max_bond_dim=chi, svd_threshold=1e-12,
+                        krylov_tol=1e-12, order=1, sample_timesteps=True)
+    a = Simulator().run(raw, MPO.ising(L, 1.0, 0.5), p)
+    assert all(np.array_equal(x, y) for x, y in zip(keep, raw.tensors))
+    st = o.MPSState([t.copy() for t in keep], None)
+    st.normalize("B")
+    op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], elapsed_time=0.2, dt=0.1, max_bond_dim=chi, svd_threshold=1e-12, krylov_tol=1e-12,
+                  order=1, sample_timesteps=True)
+    r, _, _ = o.run_trajectory(0, st, None, op, o.ising_mpo(L, 1.0, 0.5))
+    for s in range(L):
+        assert np.allclose(a.trajectories[s][0], r[s], atol=1e-9)

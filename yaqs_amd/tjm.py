@@ -408,6 +408,7 @@ class Simulator:
             raise ValueError("State and Hamiltonian must have the same number of sites")  # tdvp.py:91-93
         if noise_model is not None:  # one realisation of static disorder per run (simulator.py:1269-1271)
             noise_model = noise_model.sample(rng=disorder_rng(sim_params.random_seed))
+        initial_state = _encoded(initial_state)
         rank, world = 0, 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
@@ -460,6 +461,7 @@ class Simulator:
 
         if noise_model is not None:
             noise_model = noise_model.sample(rng=disorder_rng(sim_params.random_seed))
+        initial_state = _encoded(initial_state)
         noisy = noise_model is not None and any(q["strength"] != 0 for q in noise_model.processes)
         num_traj, per_call, distribution = plan_digital_shots(sim_params, noisy)
         device = self.device or f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
@@ -491,6 +493,13 @@ class Simulator:
         if engine is not None:
             engine.close()
         return CircuitResult(sim_params, res_all, diag_all, counts if wants_shots else None)
+
+
+def _encoded(state: MPS) -> MPS:
+    """``State._encode("mps")`` (state.py:278-297): the run works on a copy brought to B-normal form (centre 0, unit norm)."""
+    out = MPS(state.length, tensors=[np.array(t, dtype=np.complex128, copy=True) for t in state.tensors])
+    out.normalize("B")
+    return out
 
 
 MAX_CHI = 256  # largest bond the register-resident Jacobi SVD holds (d * chi <= 512)
