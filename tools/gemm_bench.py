@@ -1,0 +1,42 @@
+"""Micro-benchmark of the batched complex GEMM at the shapes of the two-site H_eff apply (diagnostic tool).
+
+    python tools/gemm_bench.py [B] [reps]
+"""
+import ctypes as C
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from yaqs_amd import _lib  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+lib = _lib.load()
+shapes = {
+    "x*R  (A k-contig, B n-contig)": dict(M=512, N=384, K=128, a_rs=128, a_cs=1, b_rs=384, b_cs=1),
+    "L*T  (A m-contig, B n-contig)": dict(M=384, N=512, K=384, a_rs=1, a_cs=384, b_rs=512, b_cs=1),
+}
+for name, sh in shapes.items():
+    M, N, K = sh["M"], sh["N"], sh["K"]
+    A = torch.randn(B, M * K, 2, dtype=torch.float64, device="cuda")
+    Bm = torch.randn(B, K * N, 2, dtype=torch.float64, device="cuda")
+    Cm = torch.zeros(B, M * N, 2, dtype=torch.float64, device="cuda")
+    g = _lib.GemmDesc()
+    g.A, g.B, g.C = A.data_ptr(), Bm.data_ptr(), Cm.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.a_rs, g.a_cs, g.b_rs, g.b_cs, g.c_rs = sh["a_rs"], sh["a_cs"], sh["b_rs"], sh["b_cs"], N
+    g.nks, g.nb0, g.nb1, g.nb2 = 1, B, 1, 1
+    g.a_b0, g.b_b0, g.c_b0 = M * K, K * N, M * N
+    for _ in range(3):
+        lib.tjm_zgemm_batched(C.byref(g), None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lib.tjm_zgemm_batched(C.byref(g), None)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    flop = 8.0 * M * N * K * B
+    print(f"{name}: {dt * 1e3:.3f} ms  {flop / dt / 1e12:.1f} TFLOP/s  ({100 * flop / dt / 78.6e12:.0f} % of the fp64 MFMA peak)")

@@ -12,7 +12,8 @@
 // MFMAs into four accumulators (ArBr, AiBi, ArBi, AiBr); conjugation of either operand is a
 // sign choice in the epilogue.  Operands are staged through LDS as separate re/im planes,
 // k-major with a row pitch of 80 doubles so that the two k-groups of a ds_read_b64 half-wave
-// land in disjoint banks.  Global loads for tile k+1 are issued before the MFMAs of tile k.
+// land in disjoint banks.  Global loads for tile k+1 are issued before the MFMAs of tile k.  The register budget is held to
+// 256 (128 accumulator + 128 others) so that two workgroups share a CU and one's barriers hide behind the other's MFMAs.
 #include "tjm_common.h"
 
 namespace tjm {
@@ -23,7 +24,7 @@ constexpr int BM = 64, BN = 64, BK = 16;
 constexpr int PITCH = 80;  // doubles per k-row in LDS (64 + 16: second k-group -> banks 32..63)
 
 template <bool A_MCONTIG, bool B_NCONTIG>
-__global__ __launch_bounds__(256) void zgemm_kernel(GemmDesc g) {
+__global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
   __shared__ double sAr[BK * PITCH];
   __shared__ double sAi[BK * PITCH];
   __shared__ double sBr[BK * PITCH];
@@ -86,13 +87,20 @@ __global__ __launch_bounds__(256) void zgemm_kernel(GemmDesc g) {
       rb[e] = (kk < g.K && n < g.N) ? Bp[(long)kk * g.b_rs + (long)n * g.b_cs] : cplx{0.0, 0.0};
     }
   };
+  // k-contiguous operands are fetched with 16 consecutive k per 16 lanes (256-byte runs); stored k-major that would put the
+  // 16 lanes on two bank pairs (pitch 80: bank = 16 (k & 1) + column), an 8-way conflict.  XOR-ing the column with
+  // 4 ((k >> 1) & 3) spreads them over 8 bank pairs and stays inside the 16-column group every MFMA operand read covers, so the
+  // reads remain conflict-free.
+  auto swz = [](int k) { return 4 * ((k >> 1) & 3); };
   auto store_tile = [&]() {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      sAr[ak[e] * PITCH + am[e]] = ra[e].x;
-      sAi[ak[e] * PITCH + am[e]] = ra[e].y;
-      sBr[bk[e] * PITCH + bn[e]] = rb[e].x;
-      sBi[bk[e] * PITCH + bn[e]] = rb[e].y;
+      const int ca = A_MCONTIG ? am[e] : (am[e] ^ swz(ak[e]));
+      const int cb = B_NCONTIG ? bn[e] : (bn[e] ^ swz(bk[e]));
+      sAr[ak[e] * PITCH + ca] = ra[e].x;
+      sAi[ak[e] * PITCH + ca] = ra[e].y;
+      sBr[bk[e] * PITCH + cb] = rb[e].x;
+      sBi[bk[e] * PITCH + cb] = rb[e].y;
     }
   };
 
@@ -106,13 +114,15 @@ __global__ __launch_bounds__(256) void zgemm_kernel(GemmDesc g) {
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
       const int krow = (4 * s + lk) * PITCH;
+      const int la = A_MCONTIG ? li : (li ^ swz(4 * s + lk));
+      const int lb = B_NCONTIG ? li : (li ^ swz(4 * s + lk));
       double ar[2], ai[2], br[2], bi[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ar[i] = sAr[krow + wm + 16 * i + li];
-        ai[i] = sAi[krow + wm + 16 * i + li];
-        br[i] = sBr[krow + wn + 16 * i + li];
-        bi[i] = sBi[krow + wn + 16 * i + li];
+        ar[i] = sAr[krow + wm + 16 * i + la];
+        ai[i] = sAi[krow + wm + 16 * i + la];
+        br[i] = sBr[krow + wn + 16 * i + lb];
+        bi[i] = sBi[krow + wn + 16 * i + lb];
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
