@@ -9,11 +9,11 @@
 //
 // Tiling: 256 threads = 4 wavefronts (2x2), block tile 64x64x16, every wave owns a 32x32
 // sub-tile = 2x2 MFMA tiles of v_mfma_f64_16x16x4_f64.  A complex product is four real
-// MFMAs into four accumulators (ArBr, AiBi, ArBi, AiBr); conjugation of either operand is a
-// sign choice in the epilogue.  Operands are staged through LDS as separate re/im planes,
+// MFMAs into TWO accumulators (Re += ArBr, Re += (-Ai)Bi, Im += ArBi, Im += AiBr); conjugation of either operand is a
+// sign applied when its tile is stored to LDS.  Operands are staged through LDS as separate re/im planes,
 // k-major with a row pitch of 80 doubles so that the two k-groups of a ds_read_b64 half-wave
 // land in disjoint banks.  Global loads for tile k+1 are issued before the MFMAs of tile k.  The register budget is held to
-// 256 (128 accumulator + 128 others) so that two workgroups share a CU and one's barriers hide behind the other's MFMAs.
+// 170 (64 accumulator registers + the rest) so that three workgroups share a CU and one's barriers hide behind the others' MFMAs.
 #include "tjm_common.h"
 
 namespace tjm {
@@ -24,7 +24,7 @@ constexpr int BM = 64, BN = 64, BK = 16;
 constexpr int PITCH = 80;  // doubles per k-row in LDS (64 + 16: second k-group -> banks 32..63)
 
 template <bool A_MCONTIG, bool B_NCONTIG>
-__global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
+__global__ __launch_bounds__(256, 3) void zgemm_kernel(GemmDesc g) {
   __shared__ double sAr[BK * PITCH];
   __shared__ double sAi[BK * PITCH];
   __shared__ double sBr[BK * PITCH];
@@ -61,14 +61,17 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
     else           { bk[e] = idx & 15; bn[e] = idx >> 4; }
   }
 
-  d4 accP[2][2], accQ[2][2], accS1[2][2], accS2[2][2];
+  // two accumulators per MFMA tile: Re = Ar Br + (-Ai') Bi' and Im = Ar Bi' + Ai' Br, where the primes carry the conjugation
+  // signs (applied once, when the tile is stored to LDS) and the negation is a sign-bit flip of the register operand
+  d4 accRe[2][2], accIm[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      accP[i][j] = d4{0, 0, 0, 0}; accQ[i][j] = d4{0, 0, 0, 0};
-      accS1[i][j] = d4{0, 0, 0, 0}; accS2[i][j] = d4{0, 0, 0, 0};
+      accRe[i][j] = d4{0, 0, 0, 0};
+      accIm[i][j] = d4{0, 0, 0, 0};
     }
+  const double sgnA = g.conjA ? -1.0 : 1.0, sgnB = g.conjB ? -1.0 : 1.0;
 
   const int ktiles = (g.K + BK - 1) / BK;
   const int total = ktiles * g.nks;
@@ -98,9 +101,9 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
       const int ca = A_MCONTIG ? am[e] : (am[e] ^ swz(ak[e]));
       const int cb = B_NCONTIG ? bn[e] : (bn[e] ^ swz(bk[e]));
       sAr[ak[e] * PITCH + ca] = ra[e].x;
-      sAi[ak[e] * PITCH + ca] = ra[e].y;
+      sAi[ak[e] * PITCH + ca] = sgnA * ra[e].y;
       sBr[bk[e] * PITCH + cb] = rb[e].x;
-      sBi[bk[e] * PITCH + cb] = rb[e].y;
+      sBi[bk[e] * PITCH + cb] = sgnB * rb[e].y;
     }
   };
 
@@ -124,22 +127,28 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
         br[i] = sBr[krow + wn + 16 * i + lb];
         bi[i] = sBi[krow + wn + 16 * i + lb];
       }
+      // first the four real-part and four imaginary-part products, then the second term of each: every accumulator is
+      // touched again only after seven other MFMAs, so there is no back-to-back dependency
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          accP[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], br[j], accP[i][j], 0, 0, 0);
-          accQ[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i], bi[j], accQ[i][j], 0, 0, 0);
-          accS1[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], bi[j], accS1[i][j], 0, 0, 0);
-          accS2[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i], br[j], accS2[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < 2; ++j) accRe[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], br[j], accRe[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accIm[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], bi[j], accIm[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accRe[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai[i], bi[j], accRe[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accIm[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i], br[j], accIm[i][j], 0, 0, 0);
     }
   }
 
-  // epilogue: Cr = P -/+ Q, Ci = +/-S1 +/- S2 depending on the conjugation flags
-  const double sq = (g.conjA != g.conjB) ? 1.0 : -1.0;
-  const double s1 = g.conjB ? -1.0 : 1.0;
-  const double s2 = g.conjA ? -1.0 : 1.0;
+  // epilogue
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -150,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
         int n = n0 + wn + 16 * j + li;
         if (m < g.M && n < g.N) {
           cplx v;
-          v.x = accP[i][j][r] + sq * accQ[i][j][r];
-          v.y = s1 * accS1[i][j][r] + s2 * accS2[i][j][r];
+          v.x = accRe[i][j][r];
+          v.y = accIm[i][j][r];
           if (g.accumulate != 0) {
             const cplx old = Cb[(long)m * g.c_rs + n];
             v.x = (g.accumulate > 0) ? old.x + v.x : old.x - v.x;
