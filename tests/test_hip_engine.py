@@ -635,3 +635,58 @@ def test_simulator_normalises_the_initial_state_like_the_reference():
     r, _, _ = o.run_trajectory(0, st, None, op, o.ising_mpo(L, 1.0, 0.5))
     for s in range(L):
         assert np.allclose(a.trajectories[s][0], r[s], atol=1e-9)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("TJM_FUZZ_CASES", "32"))))
+def test_randomised_configurations_match_oracle(case):
+    """Differential test on seeded random set-ups: chain length, bond cap, truncation mode and threshold, TDVP mode and substeps,
+    driver order, initial state, and a noise model mixing Pauli / non-Pauli one-site, adjacent two-site (Pauli and custom) and
+    long-range Pauli channels.  Every trajectory must agree with the oracle to 1e-8 and reproduce its bond dimensions."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, X as Xg, Y as Yg, Z as Zg
+
+    rng = np.random.default_rng(1000 + case)
+    L = int(rng.integers(2, 8))
+    chi = int(rng.choice([2, 4, 8]))
+    order = int(rng.choice([1, 2]))
+    mode = str(rng.choice(["2site", "2site", "1site"]))
+    sweeps = int(rng.choice([1, 1, 2]))
+    trunc = str(rng.choice(["discarded_weight", "relative", "hard_cutoff", "relative_discarded_weight"]))
+    thr = float(10.0 ** rng.uniform(-12, -5))
+    state = str(rng.choice(["zeros", "x+", "y-", "Neel", "haar"]))
+    one_site = ["lowering", "raising", "pauli_x", "pauli_y", "pauli_z"]
+    procs = []
+    for i in range(L):
+        for name in rng.choice(one_site, size=int(rng.integers(0, 3)), replace=False):
+            procs.append({"name": str(name), "sites": [i], "strength": float(rng.uniform(0.02, 0.4))})
+    if L >= 3 and rng.random() < 0.7:
+        i = int(rng.integers(0, L - 1))
+        procs.append({"name": "crosstalk_xz", "sites": [i, i + 1], "strength": float(rng.uniform(0.05, 0.3))})
+    if L >= 3 and rng.random() < 0.5:
+        i = int(rng.integers(0, L - 1))
+        m = np.kron(o.JUMP_OPS["lowering"], np.array([[1, 0], [0, -1]])) + 0.3 * np.kron(np.eye(2), o.JUMP_OPS["raising"])
+        procs.append({"name": "custom", "sites": [i, i + 1], "strength": float(rng.uniform(0.05, 0.3)), "matrix": m})
+    if L >= 4 and rng.random() < 0.5:
+        procs.append({"name": "crosstalk_zy", "sites": [0, L - 1], "strength": float(rng.uniform(0.05, 0.3))})
+    if not procs:
+        procs.append({"name": "pauli_z", "sites": [0], "strength": 0.2})
+    noise = NoiseModel(procs)
+    if state == "haar":
+        st = o.MPSState.haar(L, chi, np.random.default_rng(case))
+        st.normalize("B")
+        init = [t.copy() for t in st.tensors]
+    else:
+        init = MPS(L, state=state).tensors
+    gates = {"x": (Xg, X), "y": (Yg, o.PAULI["y"]), "z": (Zg, Z)}
+    picks = [(str(rng.choice(list(gates))), int(rng.integers(0, L))) for _ in range(4)]
+    obs = [Observable(gates[g_][0](), s) for g_, s in picks]
+    oobs = [o.Obs(gates[g_][1], s) for g_, s in picks]
+    kw = dict(elapsed_time=0.3, dt=0.1, max_bond_dim=chi, svd_threshold=thr, trunc_mode=trunc, krylov_tol=1e-11, order=order,
+              sample_timesteps=bool(rng.integers(0, 2)), random_seed=int(rng.integers(0, 10 ** 6)), tdvp_mode=mode, tdvp_sweeps=sweeps)
+    mpo = MPO.heisenberg(L, 1.0, 0.7, 0.4, 0.25) if rng.random() < 0.5 else MPO.ising(L, 1.0, 0.6)
+    r, d, _ = _run(L, init, noise, AnalogSimParams(observables=obs, **kw), mpo.tensors, [0, 1, 2], native=bool(rng.integers(0, 2)))
+    op = o.Params(observables=oobs, **kw)
+    on = [o.make_process(q["name"], q["sites"], q["strength"], matrix=q.get("matrix"), factors=q.get("factors")) for q in noise.processes]
+    for t in range(3):
+        ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, [w.copy() for w in mpo.tensors])
+        assert np.allclose(r[t], ro, atol=1e-8), (case, t, np.abs(r[t] - ro).max(), kw, [q["name"] for q in procs])
+        assert np.array_equal(d[t], do), (case, t)

@@ -569,8 +569,8 @@ int Engine::sweep_2site(StateSet& S, double scale) {
 // ---- helpers of the one-site sweep ---------------------------------------------------------------------------
 // Z (column-major, bond-major rows) from a site tensor.  right: rows (a, p), columns b ; left: rows (b, p), columns a
 __global__ __launch_bounds__(256) void site_to_z_kernel(const cplx* __restrict__ A, long a_b0, int d, int ca, int cb, int right, cplx* __restrict__ Z,
-                                                       long z_b0) {
-  const int b = blockIdx.y;
+                                                       long z_b0, const int* ids) {
+  const int b = ids ? ids[blockIdx.y] : blockIdx.y;
   const cplx* Ab = A + (long)b * a_b0;
   cplx* Zb = Z + (long)b * z_b0;
   const long total = (long)d * ca * cb;
@@ -584,8 +584,8 @@ __global__ __launch_bounds__(256) void site_to_z_kernel(const cplx* __restrict__
 
 // Cm from the R factor (upper triangle of Z).  right: Cm[j][c] = R[j][c] ; left: Cm[c][j] = R[j][c]   (ld = cdim)
 __global__ __launch_bounds__(256) void r_to_bond_kernel(const cplx* __restrict__ Z, long z_b0, int zr, int zc, int right, cplx* __restrict__ Cm,
-                                                       long c_b0, int cdim) {
-  const int b = blockIdx.y;
+                                                       long c_b0, int cdim, const int* ids) {
+  const int b = ids ? ids[blockIdx.y] : blockIdx.y;
   const cplx* Zb = Z + (long)b * z_b0;
   cplx* Cb = Cm + (long)b * c_b0;
   const long total = (long)cdim * cdim;
@@ -599,8 +599,8 @@ __global__ __launch_bounds__(256) void r_to_bond_kernel(const cplx* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void z_identity_kernel(cplx* __restrict__ Z, long z_b0, int zr, int nc) {
-  const int b = blockIdx.y;
+__global__ __launch_bounds__(256) void z_identity_kernel(cplx* __restrict__ Z, long z_b0, int zr, int nc, const int* ids) {
+  const int b = ids ? ids[blockIdx.y] : blockIdx.y;
   cplx* Zb = Z + (long)b * z_b0;
   const long total = (long)zr * nc;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
@@ -608,9 +608,10 @@ __global__ __launch_bounds__(256) void z_identity_kernel(cplx* __restrict__ Z, l
 }
 
 // new bond dimension after the thin QR (np.linalg.qr reduced: k = min(rows, cols)), and vec.size of the bond problem
-__global__ void qr_bond_dims_kernel(int* chi, int stride, int i, int d, int right, int* nloc, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+__global__ void qr_bond_dims_kernel(int* chi, int stride, int i, int d, int right, int* nloc, int nb0, const int* ids) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb0) return;
+  const int b = ids ? ids[t] : t;
   int* c = chi + (long)b * stride;
   if (right) {
     const int k = min(d * c[i], c[i + 1]);
@@ -625,7 +626,8 @@ __global__ void qr_bond_dims_kernel(int* chi, int stride, int i, int d, int righ
 
 // A_i = Q C with Q left-isometric (right = true, integrators.py:98-101) or A_i = C^T Q with Q right-isometric
 // (right = false, integrators.py:128-136).  Householder QR; the bond matrix lands in Cm_ ([u][v] order of project_bond).
-int Engine::qr_site(StateSet& S, int i, bool right) {
+int Engine::qr_site(StateSet& S, int i, bool right, const int* ids, int nb0) {
+  if (nb0 < 0) nb0 = B;
   const int ca = cap[i], cb = cap[i + 1];
   const int zr = right ? d * ca : d * cb;
   const int zc = right ? cb : ca;
@@ -636,29 +638,29 @@ int Engine::qr_site(StateSet& S, int i, bool right) {
   int gx = (int)((total + 1023) / 1024);
   if (gx < 1) gx = 1;
   if (gx > 128) gx = 128;
-  hipLaunchKernelGGL(site_to_z_kernel, dim3(gx, B), dim3(256), 0, stream, S.A[i], a_b0_[i], d, ca, cb, right ? 1 : 0, qrw.Z, qrw.z_b0);
-  if ((rc = qr_factor(qrw, zr, zc, B, nullptr, stream)) != TJM_OK) return rc;
+  hipLaunchKernelGGL(site_to_z_kernel, dim3(gx, nb0), dim3(256), 0, stream, S.A[i], a_b0_[i], d, ca, cb, right ? 1 : 0, qrw.Z, qrw.z_b0, ids);
+  if ((rc = qr_factor(qrw, zr, zc, nb0, ids, stream)) != TJM_OK) return rc;
   {
     int g2 = (int)(((long)cdim * cdim + 1023) / 1024);
     if (g2 < 1) g2 = 1;
-    hipLaunchKernelGGL(r_to_bond_kernel, dim3(g2, B), dim3(256), 0, stream, qrw.Z, qrw.z_b0, zr, zc, right ? 1 : 0, Cm_, (long)cdim * cdim, cdim);
+    hipLaunchKernelGGL(r_to_bond_kernel, dim3(g2, nb0), dim3(256), 0, stream, qrw.Z, qrw.z_b0, zr, zc, right ? 1 : 0, Cm_, (long)cdim * cdim, cdim, ids);
   }
-  hipLaunchKernelGGL(qr_bond_dims_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, S.chi, L + 1, i, d, right ? 1 : 0, nloc_, B);
+  hipLaunchKernelGGL(qr_bond_dims_kernel, dim3((nb0 + 255) / 256), dim3(256), 0, stream, S.chi, L + 1, i, d, right ? 1 : 0, nloc_, nb0, ids);
   {
     int g3 = (int)(((long)zr * kmax + 1023) / 1024);
     if (g3 < 1) g3 = 1;
     if (g3 > 128) g3 = 128;
-    hipLaunchKernelGGL(z_identity_kernel, dim3(g3, B), dim3(256), 0, stream, qrw.Z, qrw.z_b0, zr, kmax);
+    hipLaunchKernelGGL(z_identity_kernel, dim3(g3, nb0), dim3(256), 0, stream, qrw.Z, qrw.z_b0, zr, kmax, ids);
   }
-  if ((rc = qr_apply_q(qrw, zr, zc, qrw.Z, qrw.z_b0, kmax, B, nullptr, stream)) != TJM_OK) return rc;
+  if ((rc = qr_apply_q(qrw, zr, zc, qrw.Z, qrw.z_b0, kmax, nb0, ids, stream)) != TJM_OK) return rc;
   ExtractDesc x;
   x.out = S.A[i]; x.out_b0 = a_b0_[i]; x.row_off = 0; x.conj = 0; x.scale_mode = 0;
   if (right) {  // A_i[p][a][k] = Q[(a,p)][k]
     x.n_k = cb; x.o_k = 1; x.n_r1 = ca; x.n_r0 = d; x.o_r1 = cb; x.o_r0 = (long)ca * cb;
-    rc = qr_scatter(qrw.Z, qrw.z_b0, zr, x, S.chi + i + 1, L + 1, B, nullptr, stream);
+    rc = qr_scatter(qrw.Z, qrw.z_b0, zr, x, S.chi + i + 1, L + 1, nb0, ids, stream);
   } else {      // A_i[p][k][r] = Q[(r,p)][k]
     x.n_k = ca; x.o_k = cb; x.n_r1 = cb; x.n_r0 = d; x.o_r1 = 1; x.o_r0 = (long)ca * cb;
-    rc = qr_scatter(qrw.Z, qrw.z_b0, zr, x, S.chi + i, L + 1, B, nullptr, stream);
+    rc = qr_scatter(qrw.Z, qrw.z_b0, zr, x, S.chi + i, L + 1, nb0, ids, stream);
   }
   TJM_HIP_CHECK(hipGetLastError());
   return rc;
@@ -892,17 +894,19 @@ int Engine::set_noise_filter(int n, const int* idx) {
 }
 
 // QR centre shifts (mps.py:719-746 / 771-788 with decomposition="QR"): exact gauge moves, no truncation
-int Engine::qr_shift_right(StateSet& S, int i) {
+int Engine::qr_shift_right(StateSet& S, int i, const int* ids, int nb0) {
+  if (nb0 < 0) nb0 = B;
   const int cb = cap[i + 1], cc = cap[i + 2];
   int rc;
-  if ((rc = qr_site(S, i, true)) != TJM_OK) return rc;
+  if ((rc = qr_site(S, i, true, ids, nb0)) != TJM_OK) return rc;
   GemmDesc g = blank_gemm();  // T1[p][l][r] = C[l][x] A_{i+1}[p][x][r]
   g.A = Cm_; g.B = S.A[i + 1]; g.C = T1;
   g.M = cb; g.K = cb; g.N = cc;
   g.a_rs = cb; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = cc;
-  g.nb0 = B; g.nb1 = d; g.a_b0 = (long)cb * cb; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cb * cc; g.c_b0 = t_b0; g.c_b1 = (long)cb * cc;
+  g.nb0 = nb0; g.nb1 = d; g.a_b0 = (long)cb * cb; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cb * cc; g.c_b0 = t_b0; g.c_b1 = (long)cb * cc;
+  g.ids = ids;
   if ((rc = gemm(g)) != TJM_OK) return rc;
-  return copy_back(S.A[i + 1], a_b0_[i + 1], T1, t_b0, a_b0_[i + 1], nullptr, B);
+  return copy_back(S.A[i + 1], a_b0_[i + 1], T1, t_b0, a_b0_[i + 1], ids, nb0);
 }
 
 int Engine::qr_shift_left(StateSet& S, int i) {
@@ -1505,6 +1509,11 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
   TJM_HIP_CHECK(hipMemcpyAsync(d_sr, sr.data(), L * sizeof(long), hipMemcpyHostToDevice, stream));
   const int nj = (int)jumped.size();
   TJM_HIP_CHECK(hipMemcpyAsync(ids_, jumped.data(), nj * sizeof(int), hipMemcpyHostToDevice, stream));
+  // create_probability_distribution (stochastic_process.py:139-176) walks the orthogonality centre 0 -> L-1 by QR on the state
+  // itself, so the jump operator meets a LEFT-canonical chain with the centre on the last site.  The weights above do not
+  // depend on the gauge, but the truncations of the renormalising sweep below do: reproduce the gauge move.
+  for (int i = 0; i + 1 < L; ++i)
+    if ((rc = qr_shift_right(S, i, ids_, nj)) != TJM_OK) return rc;
   TJM_HIP_CHECK(hipMemcpyAsync(opidx_, opi.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
   TJM_HIP_CHECK(hipMemcpyAsync(jsite_, js.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL(apply_local_multi_kernel, dim3(64, nj), dim3(256), 0, stream, d_sp, d_sb, d_sr, d, ops_, opidx_, jsite_, ids_);
@@ -1530,24 +1539,27 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
     }
     TJM_HIP_CHECK(hipMemcpyAsync(ids_, jumped.data(), nj * sizeof(int), hipMemcpyHostToDevice, stream));
   }
-  // ---- normalize("B", "SVD") on the jumped trajectories (mps.py:815-839): SVD sweep right -> left, then drop R at site 0.
-  // While the tensor right of the bond is still right-isometric (always for unitary jump operators, otherwise right of
-  // the jump site) the two-site SVD equals the one-tensor SVD of svd_shift_left_rc; elsewhere the two-site path runs.
+  // ---- normalize("B", "SVD") on the jumped trajectories (mps.py:815-839): two-site SVD sweep right -> left (discarded weight
+  // 1e-12, no cap), then drop R at site 0.  The chain is left-canonical with the centre at L-1 except for the tensor the jump
+  // made non-isometric.  Where the left tensor of the pair (i-1, i) is left-isometric, theta = A_{i-1} C_i has the singular
+  // values of the centre tensor C_i alone (svd_shift_left); only the pair whose left tensor is the broken one needs the
+  // two-site SVD.  Broken: the site of a non-unitary one-site jump; the right site of an adjacent pair (its split leaves
+  // U on the left site and S V^H on the right one); nothing for Pauli jumps.
   {
+    std::vector<int> broken(B, -1);
+    for (int b : jumped) {
+      if (adj_site[b] >= 0) broken[b] = adj_site[b] + 1;
+      else if (!unitary_jump_[b]) broken[b] = js[b];
+    }
     std::vector<int> lst_short, lst_full;
     int* ids_full = opidx_;  // the operator-index table is no longer needed: reuse it as the second id list
     for (int i = L - 1; i >= 1; --i) {
       lst_short.clear();
       lst_full.clear();
-      for (int b : jumped) {
-        const bool unitary = unitary_jump_[b];
-        const int jlast = (js2[b] >= 0) ? js2[b] : js[b];
-        if (unitary || i > jlast) lst_short.push_back(b);
-        else lst_full.push_back(b);
-      }
+      for (int b : jumped) (broken[b] == i - 1 ? lst_full : lst_short).push_back(b);
       if (!lst_short.empty()) {
         TJM_HIP_CHECK(hipMemcpyAsync(ids_, lst_short.data(), lst_short.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        if ((rc = svd_shift_left_rc(S, i, ids_, (int)lst_short.size())) != TJM_OK) return rc;
+        if ((rc = svd_shift_left(S, i, ids_, (int)lst_short.size())) != TJM_OK) return rc;
       }
       if (!lst_full.empty()) {
         TJM_HIP_CHECK(hipMemcpyAsync(ids_full, lst_full.data(), lst_full.size() * sizeof(int), hipMemcpyHostToDevice, stream));
