@@ -690,3 +690,63 @@ def test_randomised_configurations_match_oracle(case):
         ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, [w.copy() for w in mpo.tensors])
         assert np.allclose(r[t], ro, atol=1e-8), (case, t, np.abs(r[t] - ro).max(), kw, [q["name"] for q in procs])
         assert np.array_equal(d[t], do), (case, t)
+
+
+@pytest.mark.parametrize("case", range(int(os.environ.get("TJM_FUZZ_CASES", "16"))))
+def test_randomised_circuits_match_oracle(case):
+    """Differential test of the circuit path on seeded random circuits: random one-qubit unitaries, random two-qubit unitaries on
+    adjacent and distant pairs in both site orders, local noise with Pauli / non-Pauli / adjacent two-site / long-range channels,
+    optional mid-circuit sampling points."""
+    from yaqs_amd.api import DigitalSimParams, GateLayer, MPS, NoiseModel, Observable, X as Xg, Z as Zg
+    from yaqs_amd.tjm import DigitalBatch
+
+    rng = np.random.default_rng(7000 + case)
+    L = int(rng.integers(3, 8))
+    chi = int(rng.choice([2, 4, 8]))
+    n_layers = int(rng.integers(1, 4))
+    sample = bool(rng.integers(0, 2))
+
+    def haar(n):
+        q, r = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+        return q * (np.diag(r) / np.abs(np.diag(r)))
+
+    layers, olayers = [], []
+    for _ in range(n_layers):
+        singles = [(int(q), haar(2)) for q in rng.choice(L, size=int(rng.integers(0, L + 1)), replace=False)]
+        groups = []
+        for _g in range(2):
+            grp = []
+            sites = list(rng.permutation(L))
+            while len(sites) >= 2 and rng.random() < 0.7:
+                a, b = int(sites.pop()), int(sites.pop())
+                grp.append((a, b, haar(4)))
+            groups.append(grp)
+        sp_ = int(rng.integers(0, 2)) if sample else 0
+        layers.append(GateLayer(singles, groups[0], groups[1], sp_))
+        olayers.append(o.GateLayer(singles, groups[0], groups[1], sp_))
+    mid = sum(l.sample_points for l in layers)
+    procs = []
+    for i in range(L):
+        for name in rng.choice(["lowering", "pauli_x", "pauli_y", "pauli_z", "raising"], size=int(rng.integers(0, 3)), replace=False):
+            procs.append({"name": str(name), "sites": [i], "strength": float(rng.uniform(0.01, 0.3))})
+    if rng.random() < 0.6:
+        i = int(rng.integers(0, L - 1))
+        procs.append({"name": "crosstalk_zx", "sites": [i, i + 1], "strength": float(rng.uniform(0.05, 0.3))})
+    if L >= 4 and rng.random() < 0.6:
+        procs.append({"name": "crosstalk_yy", "sites": [0, L - 1], "strength": float(rng.uniform(0.05, 0.3))})
+    noise = NoiseModel(procs) if procs and rng.random() < 0.85 else None
+    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), int(rng.integers(0, L)))]
+    oobs = [o.Obs(Z, s) for s in range(L)] + [o.Obs(X, obs[-1].sites)]
+    kw = dict(max_bond_dim=chi, svd_threshold=float(10.0 ** rng.uniform(-12, -6)), random_seed=int(rng.integers(0, 10 ** 6)), sample_layers=sample,
+              num_mid_measurements=mid if sample else 0)
+    e = make_engine(L, chi, 3, o.ising_mpo(L, 1.0, 0.5))
+    db = DigitalBatch(e, DigitalSimParams(observables=obs, **kw), noise)
+    r, d = db.run([0, 1, 2], MPS(L, state="zeros"), layers)
+    e.close()
+    on = None if noise is None else [o.make_process(q["name"], q["sites"], q["strength"], matrix=q.get("matrix"), factors=q.get("factors"))
+                                     for q in noise.processes]
+    op = o.DigitalParams(observables=oobs, **kw)
+    for t in range(3):
+        ro, do, _ = o.digital_tjm(t, o.MPSState.product(L, "zeros"), on, op, olayers)
+        assert np.allclose(r[t], ro, atol=1e-8), (case, t, np.abs(r[t] - ro).max())
+        assert np.array_equal(d[t], do), (case, t)
