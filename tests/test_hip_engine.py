@@ -750,3 +750,25 @@ def test_randomised_circuits_match_oracle(case):
         ro, do, _ = o.digital_tjm(t, o.MPSState.product(L, "zeros"), on, op, olayers)
         assert np.allclose(r[t], ro, atol=1e-8), (case, t, np.abs(r[t] - ro).max())
         assert np.array_equal(d[t], do), (case, t)
+
+
+@pytest.mark.parametrize("L,chi", [(12, 32), (14, 64), (16, 128)])
+def test_medium_bond_dimensions_match_oracle(L, chi):
+    """chi = 32 / 64 / 128: the two-site split is 64 / 128 / 256 square, so the doubly QR-preconditioned, accumulation-free path runs
+    with the fused 16-column kernels (64, 128) and the split X kernel (256); chi-saturated Haar state, amplitude damping plus dephasing."""
+    from yaqs_amd.api import AnalogSimParams, MPO, NoiseModel, Observable, Z as Zg
+
+    rng = np.random.default_rng(L * 100 + chi)
+    st = o.MPSState.haar(L, chi, rng)
+    st.normalize("B")
+    init = [t.copy() for t in st.tensors]
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.08} for i in range(L) for n in ("lowering", "pauli_z")])
+    kw = dict(elapsed_time=0.2, dt=0.1, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-10, order=1, sample_timesteps=True, random_seed=77)
+    mpo = MPO.ising(L, 1.0, 0.5)
+    r, d, _ = _run(L, init, noise, AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], **kw), mpo.tensors, [0, 1])
+    on = [o.make_process(n, [i], 0.08) for i in range(L) for n in ("lowering", "pauli_z")]
+    op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], **kw)
+    for t in range(2):
+        ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, mpo.tensors)
+        assert np.allclose(r[t], ro, atol=1e-8), (t, np.abs(r[t] - ro).max())
+        assert np.array_equal(d[t], do), t
