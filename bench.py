@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="trajectories resident per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="trajectories resident per GPU")
     ap.add_argument("--length", type=int, default=64)
     ap.add_argument("--chi", type=int, default=128)
     ap.add_argument("--krylov-tol", type=float, default=1e-4)
