@@ -131,7 +131,6 @@ class Engine {
   std::vector<char> proc_on_;
   int svd_shift_right(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left(StateSet& S, int i, const int* ids, int nb0);
-  int svd_shift_left_rc(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left_2site(StateSet& S, int i, const int* ids, int nb0);
   int copy_back(cplx* dst, long dst_b0, const cplx* src, long src_b0, long n, const int* ids, int nb0);
   std::vector<int> unitary_jump_;

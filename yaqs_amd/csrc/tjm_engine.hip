@@ -813,42 +813,6 @@ int Engine::svd_shift_left(StateSet& S, int i, const int* ids, int nb0) {
   return copy_back(S.A[i - 1], a_b0_[i - 1], T1, t_b0, a_b0_[i - 1], ids, nb0);
 }
 
-// Gauge sweep step of normalize("B", "SVD") (mps.py:815-839) on a right-canonical tail: theta = A_{i-1} A_i with
-// A_i right-isometric has the singular values of A_{i-1}[(s,z), a]:
-//   A_{i-1} = U S V^H  ->  A_{i-1} <- U S (= A_{i-1} V, no division) ,  A_i <- V^H A_i
-int Engine::svd_shift_left_rc(StateSet& S, int i, const int* ids, int nb0) {
-  const int cz = cap[i - 1], ca = cap[i], cb = cap[i + 1];
-  int rc;
-  JacobiSource src;  // X = A_{i-1} as (d cz) x ca
-  src.src = S.A[i - 1]; src.src_b0 = a_b0_[i - 1]; src.rx = d * cz; src.ncols = ca; src.conj = 0; src.tri = 0;
-  src.r_n0 = cz; src.s_r1 = (long)cz * ca; src.s_r0 = ca; src.c_n0 = ca; src.s_c1 = 0; src.s_c0 = 1;
-  src.nb0 = nb0; src.ids = ids;
-  TruncSpec tr;
-  tr.trunc_mode = 0; tr.threshold = 1e-12; tr.max_bond = 0; tr.min_keep = 1;
-  tr.chiA = S.chi + i - 1; tr.mulA = d; tr.chiB = S.chi + i; tr.mulB = 1; tr.chiOut = S.chi + i; tr.chi_stride = L + 1;
-  tr.spectrum = nullptr; tr.spec_ld = 0;
-  JacobiShape sh;
-  int sweeps = 0;
-  if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps)) != TJM_OK) return rc;
-  ++stat_svds; stat_svd_sweeps += sweeps;
-  ExtractDesc xu;  // A_{i-1}[(s,z)][k] = X_final
-  xu.out = S.A[i - 1]; xu.out_b0 = a_b0_[i - 1]; xu.n_k = ca; xu.o_k = 1; xu.n_r1 = 1; xu.n_r0 = d * cz; xu.o_r1 = 0; xu.o_r0 = ca;
-  xu.row_off = 0; xu.conj = 0; xu.scale_mode = 0;
-  if ((rc = svd_extract(xu, svdw, sh, S.chi + i, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
-  ExtractDesc xg;  // Vh[k][a] = conj(V[a][k])
-  xg.out = theta; xg.out_b0 = theta_b0; xg.n_k = ca; xg.o_k = ca; xg.n_r1 = 1; xg.n_r0 = ca; xg.o_r1 = 0; xg.o_r0 = 1;
-  xg.row_off = sh.rx_top; xg.conj = 1; xg.scale_mode = 0;
-  if ((rc = svd_extract(xg, svdw, sh, S.chi + i, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
-  GemmDesc g = blank_gemm();  // T1[t][k][c] = Vh[k][a] A_i[t][a][c]
-  g.A = theta; g.B = S.A[i]; g.C = T1;
-  g.M = ca; g.K = ca; g.N = cb;
-  g.a_rs = ca; g.a_cs = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb;
-  g.nb0 = nb0; g.nb1 = d; g.a_b0 = theta_b0; g.b_b0 = a_b0_[i]; g.b_b1 = (long)ca * cb; g.c_b0 = t_b0; g.c_b1 = (long)ca * cb;
-  g.ids = ids;
-  if ((rc = gemm(g)) != TJM_OK) return rc;
-  return copy_back(S.A[i], a_b0_[i], T1, t_b0, a_b0_[i], ids, nb0);
-}
-
 // General centre shift i -> i-1 by the two-site SVD (mps.py:771-788), any gauge.
 int Engine::svd_shift_left_2site(StateSet& S, int i, const int* ids, int nb0) {
   int rc;
