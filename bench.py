@@ -32,39 +32,52 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-STEPS_PER_TRAJ = 10
+STEPS_PER_TRAJ = 10  # elapsed_time = 1.0 at dt = 0.1 (the headline configuration); main() rescales it for another --dt
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_inputs(L, chi):
-    from yaqs_amd.api import MPO, MPS, NoiseModel
+WORKLOADS = {
+    # name: (description, MPO builder, noise process name, gamma)   -- SURVEY section 8d
+    "tfim": ("dissipative TFIM (J=1, g=0.5, D=3 MPO), pauli_z gamma=0.1 on every site", lambda api, L: api.MPO.ising(L, 1.0, 0.5), "pauli_z", 0.1),
+    "xxz": ("XXZ chain (Jx=Jy=1, Jz=0.5, D=5 MPO), lowering gamma=0.05 on every site", lambda api, L: api.MPO.heisenberg(L, 1.0, 1.0, 0.5, 0.0),
+            "lowering", 0.05),
+    "lr-ising": ("long-range Ising (two-exponential fit of 1/r^3, D=4 MPO) with g=0.5, pauli_z gamma=0.05 on every site",
+                 lambda api, L: api.MPO.long_range_ising(L, [0.8792, 0.1208], [0.0717, 0.5136], 0.5), "pauli_z", 0.05),
+}
 
-    mpo = MPO.ising(L, 1.0, 0.5)
-    st = MPS(L, state="haar-random", pad=chi, rng=np.random.default_rng(1))
+
+def build_inputs(L, chi, workload="tfim"):
+    from yaqs_amd import api
+
+    _, make_mpo, proc, gamma = WORKLOADS[workload]
+    mpo = make_mpo(api, L)
+    st = api.MPS(L, state="haar-random", pad=chi, rng=np.random.default_rng(1))
     st.normalize("B")
-    noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.1} for i in range(L)])
+    noise = api.NoiseModel([{"name": proc, "sites": [i], "strength": gamma} for i in range(L)])
     return mpo, st, noise
 
 
 def _cpu_step(args):
     """One order-1 TJM step of one trajectory on the CPU oracle; returns its own wall time."""
-    L, chi, tol, traj = args
+    L, chi, tol, traj, workload, tdvp_mode, dt = args
     from oracle import tjm_oracle as o
+    from yaqs_amd import api  # host-side builders only (no GPU): the same MPO tensors as the GPU leg
 
+    _, make_mpo, proc, gamma = WORKLOADS[workload]
     rng = np.random.default_rng(1)
     st = o.MPSState.haar(L, chi, rng)
     st.normalize("B")
-    mpo = o.ising_mpo(L, 1.0, 0.5)
-    noise = [o.make_process("pauli_z", [i], 0.1) for i in range(L)]
-    p = o.Params(dt=0.1, max_bond_dim=chi, svd_threshold=1e-12, krylov_tol=tol, random_seed=42)
+    mpo = [np.asarray(w) for w in make_mpo(api, L).tensors]
+    noise = [o.make_process(proc, [i], gamma) for i in range(L)]
+    p = o.Params(dt=dt, max_bond_dim=chi, svd_threshold=1e-12, krylov_tol=tol, random_seed=42, tdvp_mode=tdvp_mode)
     t0 = time.perf_counter()
     o.tdvp(st, mpo, p)
-    o.apply_dissipation(st, noise, 0.1, p)
-    st = o.stochastic_process(st, noise, 0.1, p, o.trajectory_rng(42, traj))
+    o.apply_dissipation(st, noise, dt, p)
+    st = o.stochastic_process(st, noise, dt, p, o.trajectory_rng(42, traj))
     return time.perf_counter() - t0
 
 
-def cpu_baseline(L, chi, tol, procs):
+def cpu_baseline(L, chi, tol, procs, workload="tfim", tdvp_mode="2site", dt=0.1):
     """The CPU oracle (a NumPy/SciPy port of the reference path), run the way the reference runs: `procs` forked
     single-BLAS-thread workers, one trajectory each (core/parallel_utils.py:331-390).  Bounded sample: ONE order-1 TJM
     step per worker, extrapolated to 10 steps per trajectory.  Must run before anything touches the GPU (fork)."""
@@ -74,10 +87,10 @@ def cpu_baseline(L, chi, tol, procs):
     procs = max(1, min(procs, ncpu))
     t0 = time.perf_counter()
     if procs == 1:
-        per = [_cpu_step((L, chi, tol, 0))]
+        per = [_cpu_step((L, chi, tol, 0, workload, tdvp_mode, dt))]
     else:
         with mp.get_context("fork").Pool(procs) as pool:
-            per = pool.map(_cpu_step, [(L, chi, tol, t) for t in range(procs)], chunksize=1)
+            per = pool.map(_cpu_step, [(L, chi, tol, t, workload, tdvp_mode, dt) for t in range(procs)], chunksize=1)
     wall = time.perf_counter() - t0
     slowest = max(per)
     return {
@@ -85,7 +98,7 @@ def cpu_baseline(L, chi, tol, procs):
         "unit": "trajectories/sec",
         "cores": procs,
         "kind": "port",
-        "sample": f"1 TJM step (2-site TDVP + dissipation + jump) of 1 trajectory per worker at L={L}, chi={chi}, {procs} forked "
+        "sample": f"1 TJM step ({tdvp_mode} TDVP + dissipation + jump, workload {workload}) of 1 trajectory per worker at L={L}, chi={chi}, {procs} forked "
                   f"single-thread workers side by side: slowest {slowest:.1f} s, fastest {min(per):.1f} s (wall {wall:.1f} s incl. set-up), "
                   f"x{STEPS_PER_TRAJ} steps per trajectory; host has {ncpu} cores",
         "seconds_per_step": slowest,
@@ -118,16 +131,21 @@ def main():
     ap.add_argument("--length", type=int, default=64)
     ap.add_argument("--chi", type=int, default=128)
     ap.add_argument("--krylov-tol", type=float, default=1e-4)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="tfim", help="tfim is BASELINE.json's headline configuration")
+    ap.add_argument("--tdvp-mode", choices=["2site", "1site"], default="2site")
+    ap.add_argument("--dt", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=32, help="forked single-thread CPU workers of the cpu_baseline leg (capped at the core count)")
     args = ap.parse_args()
+    global STEPS_PER_TRAJ
+    STEPS_PER_TRAJ = max(1, int(round(1.0 / args.dt)))  # a trajectory runs to elapsed_time = 1.0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     cpu_ref = None
     if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu_ref = cpu_baseline(args.length, args.chi, args.krylov_tol, args.cpu_procs)  # before torch / HIP are initialised
+        cpu_ref = cpu_baseline(args.length, args.chi, args.krylov_tol, args.cpu_procs, args.workload, args.tdvp_mode, args.dt)  # before torch / HIP
 
     import torch
     import torch.distributed as dist
@@ -145,9 +163,10 @@ def main():
     device = f"cuda:{local}"
 
     L, chi, B, K, W = args.length, args.chi, args.batch, args.steps, args.warmup
-    mpo, st, noise = build_inputs(L, chi)
+    mpo, st, noise = build_inputs(L, chi, args.workload)
+    dt = args.dt
     eng = BatchEngine(L, chi, B, mpo.tensors, device=device)
-    eng.set_params(dt=0.1, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=args.krylov_tol)
+    eng.set_params(dt=dt, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=args.krylov_tol, tdvp_mode=args.tdvp_mode)
     eng.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
     eng.load_state(st.tensors)
     traj = [rank * B + b for b in range(B)]
@@ -157,9 +176,9 @@ def main():
 
     def step():
         eng.tdvp()
-        eng.dissipate(0.1)
+        eng.dissipate(dt)
         eng.set_uniforms(np.stack([u[np.arange(B), pos], u[np.arange(B), pos + 1]], axis=1))
-        jumped, _ = eng.stochastic(0.1)
+        jumped, _ = eng.stochastic(dt)
         pos[:] += 1 + jumped
 
     def barrier():
@@ -215,8 +234,8 @@ def main():
             "dtype": "c128 (f64 arithmetic)",
             "data": "synthetic",
             "config": {
-                "workload": f"{L}-site dissipative TFIM (J=1, g=0.5, D=3 MPO), pauli_z gamma=0.1 on every site, chi={chi}, dt=0.1, "
-                            f"order-1 TJM, 2-site TDVP, svd_threshold=1e-12, krylov_tol={args.krylov_tol:g}, Haar chi-saturated initial MPS",
+                "workload": f"{L}-site {WORKLOADS[args.workload][0]}, chi={chi}, dt={dt:g}, "
+                            f"order-1 TJM, {args.tdvp_mode} TDVP, svd_threshold=1e-12, krylov_tol={args.krylov_tol:g}, Haar chi-saturated initial MPS",
                 "trajectories_in_flight_per_gpu": B,
                 "steps_per_trajectory": STEPS_PER_TRAJ,
                 "parallelism": f"trajectory-sharded x{world}",
