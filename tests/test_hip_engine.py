@@ -302,13 +302,15 @@ def test_digital_tebd_trajectories_match_reference_fixture():
                  for _ in range(2)]
     noise3 = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)] +
                         [{"name": "crosstalk_zz", "sites": [1, 5], "strength": 0.1}, {"name": "lowering", "sites": [6], "strength": 0.2}])
-    p = DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-10, random_seed=11)
-    r, d, _ = run(None, p, lr_layers, [0], 16)
+    p = DigitalSimParams(observables=obs, max_bond_dim=4, svd_threshold=1e-8, random_seed=11, gate_mode="swaps")
+    r, d, _ = run(None, p, lr_layers, [0], 4)
     assert np.allclose(r[0], g["lr_noiseless_results"][0], atol=1e-8)
     assert np.array_equal(d[0], g["lr_noiseless_diag"][0])
-    r, d, db = run(noise3, p, lr_layers, list(range(6)), 16)
+    r, d, db = run(noise3, p, lr_layers, list(range(6)), 4)
     assert np.allclose(r, g["lr_noisy_results"], atol=1e-8)
     assert np.array_equal(d, g["lr_noisy_diag"])
+    with pytest.raises(NotImplementedError):  # the default gate_mode="mpo" sends distant pairs through the gate-MPO product
+        run(None, DigitalSimParams(observables=obs, max_bond_dim=4, svd_threshold=1e-8, random_seed=11), lr_layers, [0], 4)
 
 
 def test_chi256_heisenberg_lowering_step_matches_oracle():
@@ -740,7 +742,7 @@ def test_randomised_circuits_match_oracle(case):
     kw = dict(max_bond_dim=chi, svd_threshold=float(10.0 ** rng.uniform(-12, -6)), random_seed=int(rng.integers(0, 10 ** 6)), sample_layers=sample,
               num_mid_measurements=mid if sample else 0)
     e = make_engine(L, chi, 3, o.ising_mpo(L, 1.0, 0.5))
-    db = DigitalBatch(e, DigitalSimParams(observables=obs, **kw), noise)
+    db = DigitalBatch(e, DigitalSimParams(observables=obs, gate_mode="swaps", **kw), noise)
     r, d = db.run([0, 1, 2], MPS(L, state="zeros"), layers)
     e.close()
     on = None if noise is None else [o.make_process(q["name"], q["sites"], q["strength"], matrix=q.get("matrix"), factors=q.get("factors"))

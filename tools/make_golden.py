@@ -399,7 +399,9 @@ def gen_digital():
     noise3 = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)] +
                         [{"name": "crosstalk_zz", "sites": [1, 5], "strength": 0.1}, {"name": "lowering", "sites": [6], "strength": 0.2}])
     cc = dtm._CompiledCircuit(tuple(lr_layer() for _ in range(2)), 0)
-    p = sp.DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-10, random_seed=11)
+    # gate_mode="swaps" is the routed-TEBD mode (digital_tjm.py:604-605); chi = 4 makes the truncations of the SWAP chain bite,
+    # so the fixture distinguishes it from the default gate-MPO route
+    p = sp.DigitalSimParams(observables=obs, max_bond_dim=4, svd_threshold=1e-8, random_seed=11, gate_mode="swaps")
     for name, nm, ntraj in (("lr_noisy", noise3, 6), ("lr_noiseless", None, 1)):
         res, diag = [], []
         for i in range(ntraj):

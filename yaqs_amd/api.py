@@ -173,11 +173,14 @@ class DigitalSimParams:
 
     def __init__(self, observables=None, num_traj: int | None = None, max_bond_dim=_USE_PRESET, trunc_mode: str = "discarded_weight",
                  svd_threshold: float | None = None, *, preset: str = "balanced", sample_layers: bool = False, num_mid_measurements: int = 0,
-                 get_state: bool = False, random_seed: int | None = None, shots: int | None = None):
+                 get_state: bool = False, random_seed: int | None = None, shots: int | None = None, gate_mode: str = "mpo"):
         if preset not in SIMULATION_PRESETS:
             raise ValueError(f"Unknown preset {preset!r}")
         if trunc_mode not in _TRUNC:
             raise ValueError(f"Unknown truncation mode: {trunc_mode!r}")
+        if gate_mode not in ("swaps", "tdvp", "full-tdvp", "mpo"):
+            raise ValueError(f"gate_mode must be one of ('swaps', 'tdvp', 'full-tdvp', 'mpo'), got {gate_mode!r}.")  # simulation_parameters.py:175-190
+        self.gate_mode = gate_mode  # nearest-neighbour gates are TEBD in every mode; "swaps" also routes distant pairs with TEBD
         if shots is not None and shots < 1:
             raise ValueError("shots must be a positive integer when set")
         pv = SIMULATION_PRESETS[preset]

@@ -305,6 +305,10 @@ class DigitalBatch:
         t = np.asarray(mat, dtype=np.complex128).reshape(2, 2, 2, 2)
         u_lr = t if s0 < s1 else t.transpose(1, 0, 3, 2)  # resolve_lr_tensor (mpo_utils.py:127-159)
         left, right = min(s0, s1), max(s0, s1)
+        if right - left > 1 and getattr(self.p, "gate_mode", "mpo") != "swaps":
+            # digital_tjm.py:592-620: every other mode sends a distant pair through the gate-MPO product (or a TDVP window), whose
+            # intermediate bonds are up to four times max_bond_dim; only the SWAP-routed TEBD route is built here
+            raise NotImplementedError(f"long-range gate on sites ({s0}, {s1}) needs gate_mode='swaps' (got {self.p.gate_mode!r})")
         center = 0
         for i in range(right - 1, left, -1):  # bring the right qubit next to the left one
             e.tebd_gate(i, self._SWAP, center=center)
