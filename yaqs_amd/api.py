@@ -116,7 +116,12 @@ class AnalogSimParams:
     def __init__(self, observables=None, elapsed_time: float = 0.1, dt: float = 0.1, num_traj: int | None = None,
                  max_bond_dim=_USE_PRESET, trunc_mode: str = "discarded_weight", svd_threshold: float | None = None,
                  krylov_tol: float | None = None, order: int = 1, *, preset: str = "balanced", sample_timesteps: bool = True,
-                 get_state: bool = False, random_seed: int | None = None, tdvp_sweeps: int = 1, tdvp_mode: str = "2site"):
+                 get_state: bool = False, random_seed: int | None = None, tdvp_sweeps: int = 1, tdvp_mode: str = "2site",
+                 evolution_mode: str = "tdvp"):
+        mode = str(getattr(evolution_mode, "value", evolution_mode)).lower()
+        if mode not in ("tdvp", "bug"):
+            raise ValueError(f"evolution_mode must be one of ('tdvp', 'bug'), got {evolution_mode!r}.")  # simulation_parameters.py:338-357
+        self.evolution_mode = mode
         if preset not in SIMULATION_PRESETS:
             raise ValueError(f"Unknown preset {preset!r}")
         pv = SIMULATION_PRESETS[preset]

@@ -59,6 +59,9 @@ class TrajectoryBatch:
         self.noise = noise if (noise is not None and (noise.processes or getattr(noise, "scheduled_jumps", None))) else None
         if params.tdvp_mode not in ("1site", "2site"):
             raise NotImplementedError(f"tdvp_mode {params.tdvp_mode!r} is not built yet in the HIP path")
+        if getattr(params, "evolution_mode", "tdvp") != "tdvp":
+            # bug.py:213-257: two augmented half-sweeps let every bond grow to 4 * max_bond_dim before the compression
+            raise NotImplementedError("evolution_mode='bug' (Basis-Update and Galerkin) is not built yet in the HIP path")
         self.two_site_obs = False
         self.schmidt: dict = {}  # (sorted row, column) -> [B, 500] Schmidt spectra
         self.meta_obs = any(obs.gate.name in META_OBSERVABLES for obs in params.observables)
