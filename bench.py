@@ -155,7 +155,8 @@ def main():
     from yaqs_amd.engine import BatchEngine
     from yaqs_amd.tjm import trajectory_uniforms
 
-    if args.gpus > 1 or world > 1:
+    use_dist = args.gpus > 1 or world > 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
@@ -259,7 +260,7 @@ def main():
         if cpu_ref is not None:
             out["cpu_baseline"] = cpu_ref
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
