@@ -137,6 +137,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, default=32, help="forked single-thread CPU workers of the cpu_baseline leg (capped at the core count)")
     args = ap.parse_args()
+    # stdout carries exactly one JSON line: everything else a library prints there (RCCL writes its version banner to
+    # stdout when the communicator is created) is sent to stderr by pointing fd 1 at fd 2 for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     global STEPS_PER_TRAJ
     STEPS_PER_TRAJ = max(1, int(round(1.0 / args.dt)))  # a trajectory runs to elapsed_time = 1.0
 
@@ -259,7 +264,8 @@ def main():
         }
         if cpu_ref is not None:
             out["cpu_baseline"] = cpu_ref
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
