@@ -335,3 +335,25 @@ def test_svd_split_qr_rank_deficient_and_ragged_square(lib, dist):
         assert np.allclose(iso.conj().T @ iso, np.eye(k), atol=1e-12), b
         assert np.all(left[b][:, chiL[b]:, :] == 0) and np.all(right[b][:, :, chiR[b]:] == 0), b
         assert np.all(left[b][:, :, k:] == 0) and np.all(right[b][:, k:, :] == 0), b
+
+
+@pytest.mark.parametrize("svs,mode,thr,expected", [
+    ([1.0, 0.5, 0.1, 0.0100001], 0, 1e-4, 4), ([1.0, 0.5, 0.01, 0.001], 0, 1e-4, 3), ([1.0, 0.2, 0.2, 0.2], 0, 0.2 ** 2 * 3, 1),
+    ([1.0, 0.6, 0.4, 0.1], 1, 0.5, 2), ([1.0, 0.99, 0.98], 1, 0.95, 3), ([1.0, 0.55, 0.3], 1, 0.5, 2)])
+def test_truncation_known_answers_of_the_reference(lib, svs, mode, thr, expected):
+    """The keep counts of the reference's own known-answer tests (tests/core/methods/tdvp/test_sweep_utils.py:136-222:
+    discarded_weight and relative modes, min_keep = 2 as split_tdvp passes it) through the GPU split."""
+    rng = np.random.default_rng(11)
+    d, capL, capR = 2, 3, 3
+    m, n = d * capL, d * capR
+    s = np.zeros(min(m, n))
+    s[: len(svs)] = svs
+    u = np.linalg.qr(crand(rng, m, m))[0]
+    v = np.linalg.qr(crand(rng, n, n))[0]
+    theta = ((u[:, : len(s)] * s) @ v[:, : len(s)].conj().T)[None]
+    chi = np.array([3], dtype=np.int32)
+    for qr in (False, True):
+        left, right, keep, spec, _ = svd_split_gpu(lib, theta, d, capL, capR, min(m, n), 0, mode, thr, 0, 2, chi, chi, qr=qr)
+        boundary = mode == 0 and abs(np.sum(np.square(svs[expected:])) - thr) < 64 * np.finfo(float).eps
+        assert keep[0] == max(expected, 2) or (boundary and abs(keep[0] - expected) <= 1), (keep, expected)
+        assert np.allclose(spec[0, : len(svs)], svs, atol=1e-13)
