@@ -863,6 +863,12 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspa
       if (keep > nsv) keep = nsv;
     }
     d.chiOut[(long)b * d.chi_stride] = keep;
+    // kept columns at the rounding-noise floor were never rotated: their normalised columns are not orthogonal to the rest,
+    // so the caller must not take them as singular vectors (n_active[2] != 0 selects the re-orthonormalising path)
+    if (keep > 0 && w.n_active != nullptr) {
+      const double s0 = sqrt(sN[sPerm[0]]);
+      if (sqrt(sN[sPerm[keep - 1]]) <= 1e-11 * s0) atomicOr(w.n_active + 2, 1);
+    }
   }
   if (d.spectrum) {
     for (int k = tid; k < d.spec_ld; k += 256) d.spectrum[(long)b * d.spec_ld + k] = (k < ncols_pad) ? sqrt(sN[sPerm[k]]) : 0.0;
@@ -1084,6 +1090,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     if (g_prof.every > 0) prof_collect();
   }
   if (sweeps_out) *sweeps_out = sweep;
+  TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 2, 0, sizeof(int), s));
   hipLaunchKernelGGL(svd_finish_kernel, dim3(src.nb0), dim3(256), 0, s, tr, w, ncols_pad, rx_top, rtot, src.ids);
   TJM_HIP_CHECK(hipGetLastError());
   if (shape_out) {
@@ -1149,8 +1156,76 @@ int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* 
 // Z = theta^H (dist 0) / theta (dist 1), columns sorted, Z = Q R; R^H = Q1 R1; Jacobi on X = R1^H, X W = Y.  Then
 //   Z = (Q Y) (Q1 W)^H :  isometric factor = Q1 W (rows in the sorted column order of Z), weighted factor = (Q Y).
 // R1^H is closer to diagonal than R^H and the iteration needs about a fifth fewer sweeps again.
+// Direct variant (default): the factorisation is taken in the orientation in which the ISOMETRIC factor is the left singular
+// basis of the factored matrix, Z = theta (dist 0) / theta^H (dist 1), Z = Q R, R^H = Q1 R1, X = R1^H, Y = X W:
+//   Z = (Q Ytilde) Sigma (Q1 W)^H ,  Ytilde = Y Sigma^-1 .
+// One-sided Jacobi delivers the normalised columns of Y orthonormal to the convergence tolerance and with high relative
+// accuracy, so Q Ytilde (reflectors times an orthonormal set) is the isometric factor without W, and the weighted factor
+// is the exact projection of the input on it, isoᴴ theta resp. theta iso — one MFMA GEMM.  When a kept singular value sits
+// at the noise floor (rank-deficient input with min_keep / threshold 0) its column was never rotated; the routine reports
+// that through *needs_completion and the caller falls back to the re-orthonormalising variant below.
+static int svd_split_qr2_direct(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out,
+                                bool* needs_completion) {
+  const int N = d.m;
+  const int cm = d.capM;
+  const QrWorkspace q2 = q.second();
+  int rc;
+  if ((rc = qr_prepare(d.theta, d.theta_b0, d.m, d.n, d.distribution, d.d, q, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  if ((rc = qr_factor(q, N, N, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  if ((rc = qr_adjoint_triangle(q, N, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  if ((rc = qr_factor(q2, N, N, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  JacobiSource src;  // X = R1^H
+  src.src = q2.Z; src.src_b0 = q2.z_b0; src.rx = N; src.ncols = N; src.conj = 1; src.tri = 1;
+  src.r_n0 = N; src.s_r1 = 0; src.s_r0 = N; src.c_n0 = N; src.s_c1 = 0; src.s_c0 = 1;
+  src.nb0 = d.nb0; src.ids = d.ids;
+  TruncSpec tr;
+  tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
+  tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
+  tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
+  JacobiShape sh;
+  if ((rc = jacobi_solve(src, tr, w, s, &sh, sweeps_out, false)) != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+  TJM_HIP_CHECK(hipStreamSynchronize(s));
+  *needs_completion = (*w.h_pinned != 0);
+  if (*needs_completion) return TJM_OK;
+  ExtractDesc xy;  // Ytilde: normalised kept columns of Y into Z (N x capM, column-major)
+  xy.out = q.Z; xy.out_b0 = q.z_b0; xy.n_k = cm; xy.o_k = N; xy.n_r1 = 1; xy.n_r0 = N;
+  xy.o_r1 = 0; xy.o_r0 = 1; xy.row_off = 0; xy.conj = 0; xy.scale_mode = 2;
+  if ((rc = svd_extract(xy, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  if ((rc = qr_apply_q(q, N, N, q.Z, q.z_b0, cm, d.nb0, d.ids, s)) != TJM_OK) return rc;  // iso = Q Ytilde, rows bond-major
+  ExtractDesc xi;
+  GemmDesc g;
+  memset(&g, 0, sizeof(g));
+  g.nb0 = d.nb0; g.nb2 = 1; g.nks = d.d;
+  if (d.distribution == 0) {
+    // left[(s,a)][k] = iso[a*d+s][k] ; right[t][k][c] = sum_{(a,s)} conj(iso[a*d+s][k]) theta[(s,a)][(t,c)]
+    xi.out = d.left; xi.out_b0 = d.left_b0; xi.n_k = cm; xi.o_k = 1; xi.n_r1 = d.capL; xi.n_r0 = d.d; xi.o_r1 = cm;
+    xi.o_r0 = (long)d.capL * cm; xi.row_off = 0; xi.conj = 0; xi.scale_mode = 0;
+    g.nb1 = d.d;
+    g.A = q.Z; g.a_rs = N; g.a_ks = 1; g.a_cs = d.d; g.a_b0 = q.z_b0; g.conjA = 1; g.M = cm; g.K = d.capL;
+    g.B = d.theta; g.b_ks = (long)d.capL * d.ld_theta; g.b_rs = d.ld_theta; g.b_cs = 1; g.b_b0 = d.theta_b0; g.b_b1 = d.capR; g.N = d.capR;
+    g.C = d.right; g.c_rs = d.capR; g.c_b0 = d.right_b0; g.c_b1 = (long)cm * d.capR;
+  } else {
+    // right[t][k][c] = conj(iso[c*d+t][k]) ; left[(s,a)][k] = sum_{(t,c)} theta[(s,a)][(t,c)] iso[c*d+t][k]
+    xi.out = d.right; xi.out_b0 = d.right_b0; xi.n_k = cm; xi.o_k = d.capR; xi.n_r1 = d.capR; xi.n_r0 = d.d;
+    xi.o_r1 = 1; xi.o_r0 = (long)cm * d.capR; xi.row_off = 0; xi.conj = 1; xi.scale_mode = 0;
+    g.nb1 = 1;
+    g.A = d.theta; g.a_rs = d.ld_theta; g.a_ks = d.capR; g.a_cs = 1; g.a_b0 = d.theta_b0; g.M = d.m; g.K = d.capR;
+    g.B = q.Z; g.b_ks = 1; g.b_rs = d.d; g.b_cs = N; g.b_b0 = q.z_b0; g.N = cm;
+    g.C = d.left; g.c_rs = cm; g.c_b0 = d.left_b0;
+  }
+  if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;  // reads theta and iso before the scatter below overwrites nothing they need
+  return qr_scatter(q.Z, q.z_b0, N, xi, d.chiM, d.chi_stride, d.nb0, d.ids, s);
+}
+
 static int svd_split_qr2(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out) {
   const int N = d.m;
+  static const bool reorth = getenv("TJM_REORTH_SPLIT") != nullptr;
+  if (!reorth && getenv("TJM_ACCUMULATE_W") == nullptr && d.capM <= N) {
+    bool needs_completion = false;
+    const int rc0 = svd_split_qr2_direct(d, w, q, s, sweeps_out, &needs_completion);
+    if (rc0 != TJM_OK || !needs_completion) return rc0;
+  }
   const int fdist = 1 - d.distribution;
   const QrWorkspace q2 = q.second();
   int rc;
