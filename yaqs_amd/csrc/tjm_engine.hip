@@ -756,24 +756,30 @@ int Engine::svd_shift_right(StateSet& S, int i, const int* ids, int nb0) {
   tr.spectrum = nullptr; tr.spec_ld = 0;
   JacobiShape sh;
   int sweeps = 0;
-  if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps)) != TJM_OK) return rc;
+  // only X is rotated: U is the set of normalised rotated columns, and S V^H = U^H A_i comes from one GEMM on the input
+  if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps, false)) != TJM_OK) return rc;
   ++stat_svds; stat_svd_sweeps += sweeps;
-  ExtractDesc xu;  // A_i[(s,a)][k] = X_final / sigma
-  xu.out = S.A[i]; xu.out_b0 = a_b0_[i]; xu.n_k = cb; xu.o_k = 1; xu.n_r1 = 1; xu.n_r0 = d * ca; xu.o_r1 = 0; xu.o_r0 = cb;
+  ExtractDesc xu;  // U[(s,a)][k] = X_final / sigma  (zero beyond keep), first into the temp: A_i is still needed
+  xu.out = theta; xu.out_b0 = theta_b0; xu.n_k = cb; xu.o_k = 1; xu.n_r1 = 1; xu.n_r0 = d * ca; xu.o_r1 = 0; xu.o_r0 = cb;
   xu.row_off = 0; xu.conj = 0; xu.scale_mode = 2;
   if ((rc = svd_extract(xu, svdw, sh, S.chi + i + 1, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
-  ExtractDesc xg;  // G[k][j] = sigma_k conj(V[j][k])
-  xg.out = theta; xg.out_b0 = theta_b0; xg.n_k = cb; xg.o_k = cb; xg.n_r1 = 1; xg.n_r0 = cb; xg.o_r1 = 0; xg.o_r0 = 1;
-  xg.row_off = sh.rx_top; xg.conj = 1; xg.scale_mode = 1;
-  if ((rc = svd_extract(xg, svdw, sh, S.chi + i + 1, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
+  {
+    GemmDesc g = blank_gemm();  // G[k][j] = sum_{(s,a)} conj(U[(s,a)][k]) A_i[(s,a)][j]  (= sigma_k conj(V[j][k]))
+    g.A = theta; g.B = S.A[i]; g.C = T2;
+    g.M = cb; g.K = d * ca; g.N = cb;
+    g.a_rs = 1; g.a_cs = cb; g.conjA = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb;
+    g.nb0 = nb0; g.a_b0 = theta_b0; g.b_b0 = a_b0_[i]; g.c_b0 = t_b0;
+    g.ids = ids;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  xu.out = S.A[i]; xu.out_b0 = a_b0_[i];
+  if ((rc = svd_extract(xu, svdw, sh, S.chi + i + 1, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
   GemmDesc g = blank_gemm();  // T1[t][k][c] = G[k][j] A_{i+1}[t][j][c]
-  g.A = theta; g.B = S.A[i + 1]; g.C = T1;
+  g.A = T2; g.B = S.A[i + 1]; g.C = T1;
   g.M = cb; g.K = cb; g.N = cc;
   g.a_rs = cb; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = cc;
-  g.nb0 = nb0; g.nb1 = d; g.a_b0 = theta_b0; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cb * cc; g.c_b0 = a_b0_[i + 1]; g.c_b1 = (long)cb * cc;
+  g.nb0 = nb0; g.nb1 = d; g.a_b0 = t_b0; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cb * cc; g.c_b0 = t_b0; g.c_b1 = (long)cb * cc;
   g.ids = ids;
-  // product goes to a packed temp (stride a_b0) and is copied back
-  g.C = T1; g.c_b0 = t_b0;
   if ((rc = gemm(g)) != TJM_OK) return rc;
   return copy_back(S.A[i + 1], a_b0_[i + 1], T1, t_b0, a_b0_[i + 1], ids, nb0);
 }
@@ -793,21 +799,31 @@ int Engine::svd_shift_left(StateSet& S, int i, const int* ids, int nb0) {
   tr.spectrum = nullptr; tr.spec_ld = 0;
   JacobiShape sh;
   int sweeps = 0;
-  if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps)) != TJM_OK) return rc;
+  // only X = M^H is rotated: its normalised columns are the right singular vectors V of M, and U S = M V is one GEMM
+  if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps, false)) != TJM_OK) return rc;
   ++stat_svds; stat_svd_sweeps += sweeps;
+  ExtractDesc xt;  // Vt[(t,c)][k] = X_final / sigma into the temp (row-major, d*cb x ca)
+  xt.out = theta; xt.out_b0 = theta_b0; xt.n_k = ca; xt.o_k = 1; xt.n_r1 = 1; xt.n_r0 = d * cb; xt.o_r1 = 0; xt.o_r0 = ca;
+  xt.row_off = 0; xt.conj = 0; xt.scale_mode = 2;
+  if ((rc = svd_extract(xt, svdw, sh, S.chi + i, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
+  {
+    GemmDesc g = blank_gemm();  // G[a][k] = sum_{(t,c)} A_i[t][a][c] Vt[(t,c)][k]  (= U[a][k] sigma_k)
+    g.A = S.A[i]; g.B = theta; g.C = T2;
+    g.M = ca; g.K = cb; g.N = ca; g.nks = d;
+    g.a_rs = cb; g.a_cs = 1; g.a_ks = (long)ca * cb; g.b_rs = ca; g.b_cs = 1; g.b_ks = (long)cb * ca; g.c_rs = ca;
+    g.nb0 = nb0; g.a_b0 = a_b0_[i]; g.b_b0 = theta_b0; g.c_b0 = t_b0;
+    g.ids = ids;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
   ExtractDesc xv;  // A_i[t][k][c] = conj(X_final[(t,c)][k]) / sigma
   xv.out = S.A[i]; xv.out_b0 = a_b0_[i]; xv.n_k = ca; xv.o_k = cb; xv.n_r1 = d; xv.n_r0 = cb; xv.o_r1 = (long)ca * cb; xv.o_r0 = 1;
   xv.row_off = 0; xv.conj = 1; xv.scale_mode = 2;
   if ((rc = svd_extract(xv, svdw, sh, S.chi + i, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
-  ExtractDesc xg;  // G[a][k] = U[a][k] sigma_k
-  xg.out = theta; xg.out_b0 = theta_b0; xg.n_k = ca; xg.o_k = 1; xg.n_r1 = 1; xg.n_r0 = ca; xg.o_r1 = 0; xg.o_r0 = ca;
-  xg.row_off = sh.rx_top; xg.conj = 0; xg.scale_mode = 1;
-  if ((rc = svd_extract(xg, svdw, sh, S.chi + i, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
   GemmDesc g = blank_gemm();  // T1[s][z][k] = A_{i-1}[s][z][a] G[a][k]
-  g.A = S.A[i - 1]; g.B = theta; g.C = T1;
+  g.A = S.A[i - 1]; g.B = T2; g.C = T1;
   g.M = d * cz; g.K = ca; g.N = ca;
   g.a_rs = ca; g.a_cs = 1; g.b_rs = ca; g.b_cs = 1; g.c_rs = ca;
-  g.nb0 = nb0; g.a_b0 = a_b0_[i - 1]; g.b_b0 = theta_b0; g.c_b0 = t_b0;
+  g.nb0 = nb0; g.a_b0 = a_b0_[i - 1]; g.b_b0 = t_b0; g.c_b0 = t_b0;
   g.ids = ids;
   if ((rc = gemm(g)) != TJM_OK) return rc;
   return copy_back(S.A[i - 1], a_b0_[i - 1], T1, t_b0, a_b0_[i - 1], ids, nb0);
