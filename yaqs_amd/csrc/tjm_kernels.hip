@@ -28,6 +28,33 @@ __global__ __launch_bounds__(256) void mpo_apply_kernel(MpoApplyDesc d) {
   const int a = idx / d.nB, Bc = idx % d.nB;
   const cplx* __restrict__ in = d.in + (long)b0 * d.in_b0 + (long)a * d.in_sa + Bc;
   cplx* __restrict__ out = d.out + (long)b0 * d.out_b0 + (long)a * d.out_sa + Bc;
+  constexpr int MAXD = 6;  // MPO bond dimensions held in registers (Ising 3, Heisenberg 5, exponential-sum models K + 2)
+  if (d.din <= MAXD) {
+    // every input element is loaded once and kept in registers for all dout outputs
+    cplx x[P][MAXD];
+#pragma unroll
+    for (int pi = 0; pi < P; ++pi)
+#pragma unroll
+      for (int bi = 0; bi < MAXD; ++bi)
+        x[pi][bi] = (bi < d.din) ? in[(long)pi * d.in_sp + (long)bi * d.in_sb] : cplx{0.0, 0.0};
+    for (int bo = 0; bo < d.dout; ++bo) {
+      cplx acc[P];
+#pragma unroll
+      for (int po = 0; po < P; ++po) acc[po] = cplx{0.0, 0.0};
+#pragma unroll
+      for (int bi = 0; bi < MAXD; ++bi) {
+        if (bi < d.din) {
+#pragma unroll
+          for (int po = 0; po < P; ++po)
+#pragma unroll
+            for (int pi = 0; pi < P; ++pi) cfma(acc[po], sW[(po * d.dout + bo) * nin + pi * d.din + bi], x[pi][bi]);
+        }
+      }
+#pragma unroll
+      for (int po = 0; po < P; ++po) out[(long)po * d.out_sp + (long)bo * d.out_sb] = acc[po];
+    }
+    return;
+  }
   for (int bo = 0; bo < d.dout; ++bo) {
     cplx acc[P];
 #pragma unroll
