@@ -357,3 +357,30 @@ def test_truncation_known_answers_of_the_reference(lib, svs, mode, thr, expected
         boundary = mode == 0 and abs(np.sum(np.square(svs[expected:])) - thr) < 64 * np.finfo(float).eps
         assert keep[0] == max(expected, 2) or (boundary and abs(keep[0] - expected) <= 1), (keep, expected)
         assert np.allclose(spec[0, : len(svs)], svs, atol=1e-13)
+
+
+@pytest.mark.parametrize("dist", [0, 1])
+def test_svd_split_steeply_graded_spectrum_keeps_small_values_accurately(lib, dist):
+    """Singular values over ten decades, all kept (threshold far below the smallest): the direct variant takes the isometric
+    factor from normalised rotated columns, so this checks the relative accuracy of the small ones and the isometry."""
+    rng = np.random.default_rng(91 + dist)
+    d, cap, B = 2, 64, 2
+    n = d * cap
+    theta = np.zeros((B, n, n), dtype=np.complex128)
+    svs = 10.0 ** (-10.0 * np.arange(n) / (n - 1))
+    for b in range(B):
+        u = np.linalg.qr(crand(rng, n, n))[0]
+        v = np.linalg.qr(crand(rng, n, n))[0]
+        theta[b] = (u * svs) @ v.conj().T
+    chi = np.full(B, cap, dtype=np.int32)
+    capM = n
+    left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, cap, cap, capM, dist, 0, 1e-26, 0, 2, chi, chi, qr=True)
+    for b in range(B):
+        assert keep[b] == n
+        assert np.allclose(spec[b, :n] / svs, 1.0, atol=2e-6)  # small values: absolute accuracy eps * sigma_max
+        assert np.allclose(spec[b, :40] / svs[:40], 1.0, atol=1e-10)
+        L_ = left[b].reshape(n, capM)
+        R_ = right[b].transpose(1, 0, 2).reshape(capM, n)
+        assert np.allclose(L_ @ R_, theta[b], atol=1e-13)
+        iso = L_ if dist == 0 else R_.conj().T
+        assert np.allclose(iso.conj().T @ iso, np.eye(n), atol=1e-11)

@@ -134,11 +134,11 @@ __device__ inline double fast_rsqrt(double x) {
 __device__ inline bool make_rotation(double a, double d, double gx, double gy, double tol2, double nfloor, double& c, double& sr,
                                      double& si, double& tg) {
   const double mag2 = fma(gx, gx, gy * gy);
-  const double big = fmax(a, d);
-  // rotate only if the pair is non-orthogonal at the tolerance level, the rotation angle is above 1e-15 and
-  // neither column sits at the rounding-noise floor of the matrix (sigma < 1e-13 ||X||_F: such columns are
+  // rotate only if the pair is non-orthogonal at the tolerance level and neither column sits at the rounding-noise floor of the
+  // matrix.  (No lower bound on the angle: a rotation far below 1 ulp of the large column still carries the correction that makes
+  // a column ten decades smaller orthogonal to it.) (sigma < 1e-13 ||X||_F: such columns are
   // numerically null, carry no weight, and would otherwise be rotated against rounding noise for ever)
-  if (!(mag2 > tol2 * a * d && mag2 > 1e-30 * big * big && a > nfloor && d > nfloor && mag2 > 1e-300)) return false;
+  if (!(mag2 > tol2 * a * d && a > nfloor && d > nfloor && mag2 > 1e-300)) return false;
   const double inv_mag = fast_rsqrt(mag2);
   const double mag = mag2 * inv_mag;
   const double tau = 0.5 * (d - a) * inv_mag;
@@ -163,8 +163,7 @@ __device__ inline bool make_rotation(double a, double d, double gx, double gy, d
 __device__ inline void make_rotation_lanes(double a, double d, double own, double tol2, double nfloor, double& c, double& sv, double& tg) {
   const double sq = own * own;
   const double mag2 = sq + dpp_pull<0xB1>(sq);  // identical in both lanes of the pair (addition commutes)
-  const double big = fmax(a, d);
-  const bool rot = mag2 > tol2 * a * d && mag2 > 1e-30 * big * big && a > nfloor && d > nfloor && mag2 > 1e-300;
+  const bool rot = mag2 > tol2 * a * d && a > nfloor && d > nfloor && mag2 > 1e-300;
   const double inv_mag = fast_rsqrt(mag2);
   const double mag = mag2 * inv_mag;
   const double tau = 0.5 * (d - a) * inv_mag;
