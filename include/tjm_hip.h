@@ -29,6 +29,7 @@ extern "C" {
 #define TJM_ERR_NUMERIC (-5)         /* maps to ValueError (stochastic_process.py:178-186)   */
 #define TJM_ERR_STATE (-6)
 #define TJM_ERR_ASSERT (-7)          /* maps to AssertionError: imaginary expectation value (mps.py:1233) */
+#define TJM_ERR_CAPACITY (-8)        /* a truncation wanted more singular values than the engine's chi_max holds: re-run larger */
 
 /* ---- library ------------------------------------------------------------------------ */
 int tjm_version(void);
@@ -47,9 +48,15 @@ size_t tjm_engine_workspace_bytes(const tjm_engine* e);
 int tjm_engine_bind(tjm_engine* e, void* dev_workspace, size_t bytes, void* hip_stream);
 /* AnalogSimParams knobs of the path (simulation_parameters.py:520-613).
  * trunc_mode: 0 discarded_weight, 1 relative, 2 hard_cutoff, 3 relative_discarded_weight.
- * max_bond <= 0: no cap.  tdvp_mode: 2 = "2site", 1 = "1site" (integrators.py:44-158). */
+ * max_bond <= 0: no cap.  tdvp_mode: 2 = "2site", 1 = "1site" (integrators.py:44-158).
+ * max_bond may exceed chi_max (the reference's presets ask for 4096 or no cap at all while the bonds of most runs stay far
+ * smaller): the engine then works within chi_max and REPORTS the first truncation that needed more, see below. */
 int tjm_engine_set_params(tjm_engine* e, double dt, double svd_threshold, int32_t trunc_mode, int32_t max_bond,
                           double krylov_tol, int32_t tdvp_mode, int32_t tdvp_sweeps);
+/* *flag = 1 when, since the last clear, a truncation (svd_utils.py:22-104) kept fewer values than its rule and max_bond ask for
+ * because the new bond only stores chi_max; the states are then not the reference's and the caller re-runs the trajectories
+ * on a larger engine.  tjm_engine_run checks after every time step and returns TJM_ERR_CAPACITY. */
+int tjm_engine_capacity_overflow(tjm_engine* e, int32_t* flag, int32_t clear);
 /* host pointer: per site the tensor (phys_out, phys_in, chi_l, chi_r) C-contiguous, sites concatenated. */
 int tjm_engine_set_mpo(tjm_engine* e, const double* host_mpo);
 /* NoiseModel.processes (noise_model.py:227-243), one entry per process:
@@ -139,7 +146,8 @@ typedef struct {
 } tjm_run_config;
 /* traj[B]: trajectory indices (seeds of the per-trajectory streams); results[B][n_obs][T], diagnostics[B][3][T] with
  * T = n_times if sample_timesteps else 1 (host, float64).  Returns TJM_ERR_ASSERT for an imaginary expectation
- * value (AssertionError in mps.py:1233) and TJM_ERR_NUMERIC for zero / non-finite jump weights. */
+ * value (AssertionError in mps.py:1233), TJM_ERR_NUMERIC for zero / non-finite jump weights and TJM_ERR_CAPACITY as soon as
+ * a time step needed a bond beyond chi_max. */
 int tjm_engine_run(tjm_engine* e, const tjm_run_config* cfg, const int64_t* traj, double* results, double* diagnostics);
 /* The reference's host random streams, bit-compatible with NumPy (core/random_utils.py:20-69):
  * timestep < 0: make_trajectory_rng(traj, base_seed=seed).random(n); otherwise make_sample_rng(traj, timestep, seed). */

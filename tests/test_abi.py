@@ -42,7 +42,7 @@ def test_engine_argument_validation_without_gpu():
     # params validation happens on the host
     assert lib.tjm_engine_set_params(h, -1.0, 1e-6, 0, 8, 1e-4, 2, 1) == -1
     assert lib.tjm_engine_set_params(h, 0.1, 1e-6, 7, 8, 1e-4, 2, 1) == -1
-    assert lib.tjm_engine_set_params(h, 0.1, 1e-6, 0, 16, 1e-4, 2, 1) == -1  # cap above chi_max
+    assert lib.tjm_engine_set_params(h, 0.1, 1e-6, 0, 16, 1e-4, 2, 1) == 0  # a cap above chi_max is legal: clipped truncations are reported
     assert lib.tjm_engine_set_params(h, 0.1, 1e-6, 0, 8, 1e-4, 2, 1) == 0
     # operations before bind() are refused, not executed
     assert lib.tjm_engine_tdvp(h, 0) == -6

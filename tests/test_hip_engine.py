@@ -594,9 +594,8 @@ def test_tiny_chains_and_zero_duration(L, order):
                 assert np.allclose(res.trajectories[u][t], r[idx[u]], atol=1e-8), (L, order, elapsed, gamma, t, u)
 
 
-def test_unbounded_bond_dimension_is_exact_or_refused():
-    """max_bond_dim=None (the "exact" preset): the engine gets the exact maximum Schmidt rank as capacity and reproduces dense
-    evolution; on chains where that exceeds the supported size the run is refused, never silently truncated."""
+def test_unbounded_bond_dimension_is_exact():
+    """max_bond_dim=None (the "exact" preset): no truncation by a cap anywhere; the result reproduces dense evolution."""
     import scipy.linalg
 
     from yaqs_amd.api import AnalogSimParams, MPO, MPS, Observable, Z as Zg
@@ -612,8 +611,112 @@ def test_unbounded_bond_dimension_is_exact_or_refused():
     for s in range(L):
         zs = np.kron(np.eye(2 ** (L - 1 - s)), np.kron(Z, np.eye(2 ** s)))
         assert abs(res.expectation_values[s][0] - np.vdot(psi, zs @ psi).real) < 2e-5  # second-order splitting error of dt = 0.05
-    with pytest.raises(NotImplementedError):
-        Simulator().run(MPS(40, state="x+"), MPO.ising(40, 1.0, 0.5), AnalogSimParams(observables=[Observable(Zg(), 0)], max_bond_dim=None))
+
+
+def _recording_engine(monkeypatch):
+    """Records the storage capacity of every engine the Simulator builds."""
+    import yaqs_amd.tjm as tjm_mod
+
+    built = []
+
+    class Recording(tjm_mod.BatchEngine):
+        def __init__(self, length, chi_max, batch, mpo, **kw):
+            built.append(int(chi_max))
+            super().__init__(length, chi_max, batch, mpo, **kw)
+
+    monkeypatch.setattr(tjm_mod, "BatchEngine", Recording)
+    return built
+
+
+@pytest.mark.parametrize("max_bond", [None, 4096, 24])
+def test_storage_capacity_grows_on_demand(monkeypatch, max_bond):
+    """The reference's presets ask for max_bond_dim = 4096 or None while the bonds stay small: the engine starts with a small
+    static capacity and the chunk is repeated with twice the capacity whenever a truncation was clipped by it.  The final pass is
+    the reference's run: per-trajectory observables and bond diagnostics equal the oracle's with the same max_bond_dim."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, X as Xg, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    built = _recording_engine(monkeypatch)
+    L, ntraj = 12, 3
+    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 3)]
+    oobs = [o.Obs(Z, s) for s in range(L)] + [o.Obs(X, 3)]
+    kw = dict(elapsed_time=1.2, dt=0.1, max_bond_dim=max_bond, svd_threshold=1e-10, krylov_tol=1e-11, order=1, random_seed=5)
+    p = AnalogSimParams(observables=obs, num_traj=ntraj, sample_timesteps=True, **kw)
+    noise = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)])
+    res = Simulator(batch=ntraj).run(MPS(L, state="Neel"), MPO.heisenberg(L, 1.0, 0.9, 0.7, 0.2), p, noise)
+    op = o.Params(observables=oobs, sample_timesteps=True, **kw)
+    on = [o.make_process("pauli_x", [i], 0.05) for i in range(L)]
+    idx = op.observable_sorted_indices
+    biggest = 0
+    for t in range(ntraj):
+        r, dg, _ = o.run_trajectory(t, o.MPSState.product(L, "Neel"), on, op, o.heisenberg_mpo(L, 1.0, 0.9, 0.7, 0.2))
+        for u in range(len(obs)):
+            assert np.allclose(res.trajectories[u][t], r[idx[u]], atol=1e-8), (t, u)
+        biggest = max(biggest, int(np.max(dg[1])))
+    assert biggest > 16, "the case must outgrow the first capacity to mean anything"
+    assert built[0] == 16 and built == sorted(built) and len(built) >= 2, built
+    assert built[-1] >= min(biggest, 64) and built[-1] <= 64  # 2**(L//2) bounds every bond of a 12-site chain
+    if max_bond == 24:
+        assert built[-1] == 24 and biggest == 24
+
+
+def test_capacity_overflow_is_reported_by_the_engine_and_the_driver():
+    """A two-site truncation that wants more values than the new bond stores sets the engine's flag (and only such a one), and
+    tjm_engine_run stops after that time step with TJM_ERR_CAPACITY instead of finishing a run that is not the reference's."""
+    from yaqs_amd._lib import CapacityError
+    from yaqs_amd.api import MPO, MPS
+    from yaqs_amd.engine import BatchEngine
+
+    L = 8
+    mpo = MPO.heisenberg(L, 1.0, 0.9, 0.7, 0.2).tensors
+    init = MPS(L, state="Neel")
+    init.normalize("B")
+    e = BatchEngine(L, 4, 2, mpo)
+    try:
+        e.set_params(dt=0.1, svd_threshold=1e-12, max_bond_dim=64, krylov_tol=1e-10)
+        e.set_noise([], [])
+        e.load_state(init.tensors, 0)
+        assert not e.capacity_overflow()
+        e.tdvp(0)  # bonds 1 -> at most 4 with threshold 1e-12: nothing is clipped in the first step
+        first = e.capacity_overflow()
+        for _ in range(6):
+            e.tdvp(0)
+        assert e.capacity_overflow() and np.max(e.bond_dims(0)) == 4
+        assert e.capacity_overflow(clear=True) and not e.capacity_overflow()
+        e.load_state(init.tensors, 0)
+        with pytest.raises(CapacityError):
+            e.run(order=1, n_times=12, sample_timesteps=False, has_noise=False, seed=1, traj_indices=[0, 1],
+                  observables=[(0, np.diag([1.0, -1.0]))])
+        # with max_bond_dim = capacity the clip IS the requested truncation: no flag
+        e.set_params(dt=0.1, svd_threshold=1e-12, max_bond_dim=4, krylov_tol=1e-10)
+        e.load_state(init.tensors, 0)
+        e.capacity_overflow(clear=True)
+        for _ in range(6):
+            e.tdvp(0)
+        assert not e.capacity_overflow()
+        assert first in (False, True)
+    finally:
+        e.close()
+
+
+def test_default_presets_run_on_long_chains(monkeypatch):
+    """The "accurate" (4096) and "exact" (None) presets on a 40-site chain: refused before (static capacity), now served within
+    the capacity the run really needs and equal to the oracle."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, Observable, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    built = _recording_engine(monkeypatch)
+    L = 40
+    for max_bond in (None, 4096):
+        p = AnalogSimParams(observables=[Observable(Zg(), s) for s in (0, 17, 39)], elapsed_time=0.3, dt=0.1, max_bond_dim=max_bond,
+                            svd_threshold=1e-9, krylov_tol=1e-10, sample_timesteps=False)
+        res = Simulator().run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p)
+        op = o.Params(observables=[o.Obs(Z, s) for s in (0, 17, 39)], elapsed_time=0.3, dt=0.1, max_bond_dim=max_bond, svd_threshold=1e-9,
+                      krylov_tol=1e-10, sample_timesteps=False)
+        r, _, _ = o.run_trajectory(0, o.MPSState.product(L, "x+"), [], op, o.ising_mpo(L, 1.0, 0.5))
+        for u in range(3):
+            assert abs(res.expectation_values[u][0] - r[op.observable_sorted_indices[u]][0]) < 1e-8
+    assert max(built) <= 32, built
 
 
 def test_simulator_normalises_the_initial_state_like_the_reference():

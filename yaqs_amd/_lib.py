@@ -26,6 +26,13 @@ class TjmError(RuntimeError):
     pass
 
 
+class CapacityError(TjmError):
+    """A truncation asked for a bond beyond the engine's chi_max (TJM_ERR_CAPACITY): re-run on a larger engine."""
+
+
+ERRORS[-8] = CapacityError
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
@@ -59,6 +66,7 @@ EXPORTS = {
     "tjm_engine_workspace_bytes": (C.c_size_t, [V]),
     "tjm_engine_bind": (C.c_int, [V, V, C.c_size_t, V]),
     "tjm_engine_set_params": (C.c_int, [V, D, D, I, I, D, I, I]),
+    "tjm_engine_capacity_overflow": (C.c_int, [V, V, I]),
     "tjm_engine_set_mpo": (C.c_int, [V, V]),
     "tjm_engine_set_noise": (C.c_int, [V, I, V, V, V, V, V, V, V]),
     "tjm_engine_load_state": (C.c_int, [V, I, V, V]),

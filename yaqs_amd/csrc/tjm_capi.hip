@@ -25,6 +25,7 @@ const char* tjm_error_string(int code) {
     case TJM_ERR_NUMERIC: return "numerical failure";
     case TJM_ERR_STATE: return "engine state error";
     case TJM_ERR_ASSERT: return "measurement should be real";
+    case TJM_ERR_CAPACITY: return "a truncation needs a bond beyond the engine's capacity";
     default: return "unknown";
   }
 }
@@ -51,10 +52,17 @@ int tjm_engine_bind(tjm_engine* e, void* ws, size_t bytes, void* stream) {
 int tjm_engine_set_params(tjm_engine* e, double dt, double svd_threshold, int32_t trunc_mode, int32_t max_bond, double krylov_tol,
                           int32_t tdvp_mode, int32_t tdvp_sweeps) {
   if (!e || !(dt > 0) || trunc_mode < 0 || trunc_mode > 3 || tdvp_sweeps < 1) return TJM_ERR_ARG;
-  if (max_bond > 0 && max_bond > e->impl.chi_max) return TJM_ERR_ARG;
   e->impl.dt = dt; e->impl.svd_threshold = svd_threshold; e->impl.trunc_mode = trunc_mode; e->impl.max_bond = max_bond;
   e->impl.krylov_tol = krylov_tol; e->impl.tdvp_mode = tdvp_mode; e->impl.tdvp_sweeps = tdvp_sweeps;
   return TJM_OK;
+}
+
+int tjm_engine_capacity_overflow(tjm_engine* e, int32_t* flag, int32_t clear) {
+  if (!e || !flag) return TJM_ERR_ARG;
+  int f = 0;
+  const int rc = e->impl.capacity_overflow(&f, clear != 0);
+  *flag = f;
+  return rc;
 }
 
 int tjm_engine_set_mpo(tjm_engine* e, const double* host_mpo) { return (e && host_mpo) ? e->impl.set_mpo(host_mpo) : TJM_ERR_ARG; }

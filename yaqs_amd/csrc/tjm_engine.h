@@ -48,6 +48,7 @@ class Engine {
   int export_state(int set, int b, double* host_out, int* host_bonds);         // padded tensors of slot b
   int set_uniforms(const double* host_u, int n_per_traj);
   int reset_cursor();
+  int capacity_overflow(int* host_flag, bool clear);
 
   int tdvp(int set);
   int dissipate(int set, double dt_, int start_center = 0);
@@ -95,6 +96,7 @@ class Engine {
   int* ids_ = nullptr;           // [B] compacted trajectory list
   int* opidx_ = nullptr;         // [B]
   int* jsite_ = nullptr;         // [B]
+  int* overflow_ = nullptr;      // sticky flag: a truncation was clipped by the storage capacity
   cplx* ops_ = nullptr;          // operator table (device)
   cplx* E_ = nullptr;            // [B][chi][chi] moment environment (x2 ping-pong)
   cplx* E2_ = nullptr;

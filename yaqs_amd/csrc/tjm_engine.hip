@@ -152,6 +152,8 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   ids_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   opidx_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   jsite_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
+  overflow_ = reinterpret_cast<int*>(take(256));
+  TJM_HIP_CHECK(hipMemsetAsync(overflow_, 0, sizeof(int), s));
   E_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
   E2_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
   M_ = reinterpret_cast<cplx*>(take((size_t)L * B * d * d * sizeof(cplx)));
@@ -497,6 +499,17 @@ __global__ void nloc_kernel(const int* chi, int stride, int bl, int br, int P, i
   if (b < B) nloc[b] = P * chi[(long)b * stride + bl] * chi[(long)b * stride + br];
 }
 
+// Has any truncation since the last clear asked for more singular values than the storage of its bond holds?  The states are then
+// those of a run with max_bond_dim = chi_max rather than the requested one; the caller re-runs with a larger engine.
+int Engine::capacity_overflow(int* host_flag, bool clear) {
+  if (!bound_) return TJM_ERR_STATE;
+  TJM_HIP_CHECK(hipMemcpyAsync(h_pinned_ + 8, overflow_, sizeof(int), hipMemcpyDeviceToHost, stream));
+  if (clear) TJM_HIP_CHECK(hipMemsetAsync(overflow_, 0, sizeof(int), stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  *host_flag = h_pinned_[8];
+  return TJM_OK;
+}
+
 int Engine::set_nloc(StateSet& S, int bl, int br, int P) {
   hipLaunchKernelGGL(nloc_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, S.chi, L + 1, bl, br, P, nloc_, B);
   TJM_HIP_CHECK(hipGetLastError());
@@ -512,6 +525,7 @@ int Engine::split(StateSet& S, int i, int dist, int mode, double thr, int maxb, 
   s.distribution = dist; s.trunc_mode = mode; s.threshold = thr; s.max_bond = maxb; s.min_keep = min_keep;
   s.chiL = S.chi + i; s.chiR = S.chi + i + 2; s.chiM = S.chi + i + 1; s.chi_stride = L + 1;
   s.spectrum = nullptr; s.spec_ld = 0; s.nb0 = nb0; s.ids = ids;
+  s.overflow = overflow_;
   int sweeps = 0;
   static const bool no_qr = getenv("TJM_NO_QR") != nullptr;
   const bool use_qr = !no_qr && ids == nullptr && std::min(s.m, s.n) >= 64;

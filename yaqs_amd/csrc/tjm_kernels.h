@@ -74,6 +74,7 @@ struct SvdSplitDesc {
   double threshold;
   int max_bond;        // <= 0: none
   int min_keep;
+  int* overflow = nullptr;  // device flag: set when the truncation rule wanted more than capM values (may be null)
   const int* chiL;     // actual left bond per trajectory, element stride chi_stride
   const int* chiR;
   int* chiM;           // out: new middle bond
@@ -114,6 +115,8 @@ struct TruncSpec {
   int trunc_mode;
   double threshold;
   int max_bond, min_keep;
+  int cap = 0;               // storage extent of the new bond (0: unbounded); a wish beyond it is clipped and reported
+  int* overflow = nullptr;   // device flag, set when the clip changed the result
   const int* chiA; int mulA;
   const int* chiB; int mulB;
   int* chiOut;

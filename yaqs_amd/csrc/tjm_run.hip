@@ -186,7 +186,13 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
   for (int b = 0; b < B; ++b) rng_uniforms(c->has_seed, c->seed, (uint64_t)traj[b], -1, n_draw, &u[(size_t)b * n_draw]);
   std::vector<int> pos(B, 0), jumped(B, 0);
   std::vector<double> cand((size_t)B * 2);
-  int rc;
+  int rc, clipped = 0;
+  if ((rc = e.capacity_overflow(&clipped, true)) != TJM_OK) return rc;  // start from a clean flag
+  // after every time step: a truncation clipped by the engine's storage makes the rest of the run pointless
+  auto capacity_ok = [&]() -> int {
+    if ((rc = e.capacity_overflow(&clipped, false)) != TJM_OK) return rc;
+    return clipped ? TJM_ERR_CAPACITY : TJM_OK;
+  };
   auto record = [&](int j) { return c->sample_timesteps ? true : j == n_t - 1; };
   auto col_of = [&](int j) { return c->sample_timesteps ? j : 0; };
   auto stochastic_main = [&](int set) -> int {
@@ -214,6 +220,7 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
         if ((rc = e.dissipate(0, dt)) != TJM_OK) return rc;
         if ((rc = stochastic_main(0)) != TJM_OK) return rc;
       }
+      if ((rc = capacity_ok()) != TJM_OK) return rc;
       if (record(j))
         if ((rc = measure(r, 0, col_of(j))) != TJM_OK) return rc;
     }
@@ -231,6 +238,7 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
     else std::fill(cand.begin(), cand.end(), 0.0);
     if ((rc = e.set_uniforms(cand.data(), 2)) != TJM_OK) return rc;
     if ((rc = e.stochastic(1, dt, nullptr, nullptr)) != TJM_OK) return rc;
+    if ((rc = capacity_ok()) != TJM_OK) return rc;
     return measure(r, 1, col_of(j));
   };
   if (record(0))
@@ -243,6 +251,7 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
     if ((rc = e.tdvp(0)) != TJM_OK) return rc;
     if ((rc = e.dissipate(0, dt)) != TJM_OK) return rc;
     if ((rc = stochastic_main(0)) != TJM_OK) return rc;
+    if ((rc = capacity_ok()) != TJM_OK) return rc;
     if ((rc = sample(j)) != TJM_OK) return rc;
   }
   return TJM_OK;

@@ -860,6 +860,10 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspa
       if (d.max_bond > 0 && keep > d.max_bond) keep = d.max_bond;
       if (keep < d.min_keep) keep = d.min_keep;
       if (keep > nsv) keep = nsv;
+      if (d.cap > 0 && keep > d.cap) {  // the engine's storage is smaller than what the truncation rule asks for
+        keep = d.cap;
+        if (d.overflow) atomicOr(d.overflow, 1);
+      }
     }
     d.chiOut[(long)b * d.chi_stride] = keep;
     // kept columns at the rounding-noise floor were never rotated: their normalised columns are not orthogonal to the rest,
@@ -1128,6 +1132,7 @@ int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* 
   src.nb0 = d.nb0; src.ids = d.ids;
   TruncSpec tr;
   tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
+  tr.cap = d.capM; tr.overflow = d.overflow;
   tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
   tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
   JacobiShape sh;
@@ -1179,6 +1184,7 @@ static int svd_split_qr2_direct(const SvdSplitDesc& d, const SvdWorkspace& w, co
   src.nb0 = d.nb0; src.ids = d.ids;
   TruncSpec tr;
   tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
+  tr.cap = d.capM; tr.overflow = d.overflow;
   tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
   tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
   JacobiShape sh;
@@ -1238,6 +1244,7 @@ static int svd_split_qr2(const SvdSplitDesc& d, const SvdWorkspace& w, const QrW
   src.nb0 = d.nb0; src.ids = d.ids;
   TruncSpec tr;
   tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
+  tr.cap = d.capM; tr.overflow = d.overflow;
   tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
   tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
   JacobiShape sh;
@@ -1356,6 +1363,7 @@ int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace
   src.nb0 = d.nb0; src.ids = d.ids;
   TruncSpec tr;
   tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
+  tr.cap = d.capM; tr.overflow = d.overflow;
   tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
   tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
   JacobiShape sh;

@@ -212,6 +212,12 @@ class BatchEngine:
         _lib.check(self.lib.tjm_engine_run(self.h, C.byref(cfg), traj.ctypes.data, results.ctypes.data, diagnostics.ctypes.data), "run")
         return results, diagnostics
 
+    def capacity_overflow(self, clear: bool = False) -> bool:
+        """True when a truncation since the last clear was clipped by the storage capacity ``chi_max`` of this engine."""
+        flag = C.c_int32(0)
+        _lib.check(self.lib.tjm_engine_capacity_overflow(self.h, C.byref(flag), int(clear)), "capacity_overflow")
+        return bool(flag.value)
+
     def bond_spectrum(self, site: int, set_index: int = 0) -> np.ndarray:
         """Singular values of A_site A_{site+1} as a (d chi_l) x (d chi_r) matrix -> [B, min(m, n)] (mps.py:604-678)."""
         n = int(self.d * min(self.caps[site], self.caps[site + 2]))

@@ -16,6 +16,7 @@ from typing import Sequence
 import numpy as np
 
 from .api import META_OBSERVABLES, AnalogSimParams, MPO, MPS, NoiseModel, Result, is_pauli
+from ._lib import CapacityError
 from .engine import BatchEngine
 
 TAG_TRAJ = 0x5452414A
@@ -184,6 +185,7 @@ class TrajectoryBatch:
         results = np.zeros((e.B, len(self.sorted_obs), cols))
         diagnostics = np.zeros((e.B, 3, cols))
         e.load_state(initial.tensors, 0)
+        e.capacity_overflow(clear=True)
         n_draw = 2 * n_t + 2
         u = np.stack([trajectory_uniforms(p.random_seed, int(t), n_draw) for t in traj_indices])
         pos = np.zeros(e.B, dtype=np.int64)
@@ -191,6 +193,7 @@ class TrajectoryBatch:
             self._run_order2(traj_indices, results, diagnostics, u, pos)
         else:
             self._run_order1(results, diagnostics, u, pos)
+        _require_capacity(e)
         return results, diagnostics
 
     # ---- scheduled jumps (core/methods/scheduled_jumps.py:28-119) ----------------------
@@ -332,6 +335,7 @@ class DigitalBatch:
         results = np.zeros((e.B, len(self.sorted_obs), cols))
         diagnostics = np.zeros((e.B, 3, cols))
         e.load_state(initial.tensors, 0)
+        e.capacity_overflow(clear=True)
         if p.sample_layers:
             self._measure(0, results, diagnostics, 0)
         u = np.stack([trajectory_uniforms(p.random_seed, int(t), 2 * n_gates + 2) for t in traj_indices])
@@ -356,6 +360,7 @@ class DigitalBatch:
                         jumped[:] = 0  # an empty local model can only renormalise (stochastic_process.py:236-243)
                     self.jump_log.append(jumped.copy())
                     pos += 1 + jumped
+            _require_capacity(e)
             if p.sample_layers:
                 for _ in range(layer.sample_points):
                     col += 1
@@ -426,7 +431,7 @@ class Simulator:
         num_traj = sim_params.num_traj if noisy else 1  # simulator.py:1549-1559
         lo, hi = shard_range(num_traj, rank, world)
         mine = list(range(lo, hi))
-        chi = engine_bond_cap(sim_params, initial_state)
+        chi, chi_top = engine_bond_caps(sim_params, initial_state)
         cols = len(sim_params.times) if sim_params.sample_timesteps else 1
         n_obs = len(sim_params.observables)
         res_all = np.zeros((len(mine), n_obs, cols))
@@ -436,14 +441,18 @@ class Simulator:
         engine = None
         while done < len(mine):
             chunk = mine[done: done + B]
-            if engine is None or engine.B != len(chunk):
+            if engine is None or engine.B != len(chunk) or engine.chi_max != chi:
                 if engine is not None:
                     engine.close()
                 engine = BatchEngine(initial_state.length, chi, len(chunk), hamiltonian.tensors, device=device)
             tb = TrajectoryBatch(engine, sim_params, noise_model)  # the backend sees the model as given (simulator.py:1549-1559)
             if pieces is not None:
                 tb.set_intervals(pieces)
-            r, dg = tb.run(chunk, initial_state, native=self.native)
+            try:
+                r, dg = tb.run(chunk, initial_state, native=self.native)
+            except CapacityError:
+                chi = grown_capacity(chi, chi_top)  # trajectories are pure functions of (seed, index): run the chunk again
+                continue
             res_all[done: done + len(chunk)] = r
             diag_all[done: done + len(chunk)] = dg
             done += len(chunk)
@@ -472,7 +481,7 @@ class Simulator:
         noisy = noise_model is not None and any(q["strength"] != 0 for q in noise_model.processes)
         num_traj, per_call, distribution = plan_digital_shots(sim_params, noisy)
         device = self.device or f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
-        chi = engine_bond_cap(sim_params, initial_state)
+        chi, chi_top = engine_bond_caps(sim_params, initial_state)
         mid = sim_params.num_mid_measurements if sim_params.sample_layers else 0
         cols = (mid + 2) if sim_params.sample_layers else 1
         res_all = np.zeros((num_traj, len(sim_params.observables), cols))
@@ -484,13 +493,17 @@ class Simulator:
         done, engine = 0, None
         while done < num_traj:
             chunk = list(range(done, min(done + B, num_traj)))
-            if engine is None or engine.B != len(chunk):
+            if engine is None or engine.B != len(chunk) or engine.chi_max != chi:
                 if engine is not None:
                     engine.close()
                 engine = BatchEngine(initial_state.length, chi, len(chunk), identity_mpo, device=device)
             db = DigitalBatch(engine, sim_params, noise_model if noisy else None)
             spt = [shots_for_trajectory(t, per_call, distribution) for t in chunk] if wants_shots else None
-            r, dg = db.run(chunk, initial_state, layers, shots_per_traj=spt, basis=basis)
+            try:
+                r, dg = db.run(chunk, initial_state, layers, shots_per_traj=spt, basis=basis)
+            except CapacityError:
+                chi = grown_capacity(chi, chi_top)
+                continue
             res_all[done: done + len(chunk)] = r
             diag_all[done: done + len(chunk)] = dg
             if db.counts:
@@ -509,22 +522,52 @@ def _encoded(state: MPS) -> MPS:
     return out
 
 
-MAX_CHI = 256  # largest bond the register-resident Jacobi SVD holds (d * chi <= 512)
+MAX_CHI = 256   # largest bond the register-resident Jacobi SVD holds (d * chi <= 512)
+START_CHI = 16  # first storage capacity tried when the requested cap is larger
+
+
+def engine_bond_caps(sim_params, initial_state) -> tuple[int, int]:
+    """``(first, top)`` storage capacities of the engine.
+
+    The reference's bonds are dynamic and its presets ask for ``max_bond_dim`` = 128, 4096 or no cap at all
+    (simulation_parameters.py:46-51) while the bonds of most runs stay far below that.  The engine's storage is static, so a
+    run starts with a small capacity and is repeated with twice the capacity whenever a truncation was clipped by it
+    (``CapacityError``): the final pass is one in which ``max_bond_dim`` and the threshold alone decided every truncation,
+    exactly as in the reference.  Work grows with chi**3, so the discarded passes cost at most 1/7 of the last one.
+    ``top`` is the largest capacity that can ever be needed: ``max_bond_dim``, the exact Schmidt-rank bound ``2**(L//2)`` and
+    the bonds of the initial state.
+    """
+    have = max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors)
+    exact = 2 ** min(initial_state.length // 2, 30)
+    want = exact if sim_params.max_bond_dim is None else min(int(sim_params.max_bond_dim), exact)
+    top = max(want, have)
+    if have > MAX_CHI:
+        raise NotImplementedError(f"bond dimension {have} of the initial state exceeds the supported chi <= {MAX_CHI}")
+    if getattr(sim_params, "tdvp_mode", "2site") == "1site":
+        return have, have  # one-site TDVP never changes a bond (integrators.py:44-158)
+    return max(have, min(top, START_CHI)), top
+
+
+def grown_capacity(chi: int, top: int) -> int:
+    if chi >= top:
+        raise RuntimeError("a truncation was clipped although the engine holds max_bond_dim")  # cannot happen: svd_finish_kernel
+    new = min(2 * chi, top)
+    if new > MAX_CHI:
+        raise NotImplementedError(f"the run needs bonds beyond {chi}; the HIP path holds chi <= {MAX_CHI}")
+    return new
 
 
 def engine_bond_cap(sim_params, initial_state) -> int:
-    """Static bond capacity of the engine.  With ``max_bond_dim=None`` (no cap, the "exact" preset) the capacity is the exact
-    maximum Schmidt rank 2**(L//2); beyond the supported size this raises instead of silently truncating."""
-    have = max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors)
-    want = sim_params.max_bond_dim
-    if want is None:
-        want = 2 ** (initial_state.length // 2)
-        if want > MAX_CHI:
-            raise NotImplementedError(f"max_bond_dim=None on {initial_state.length} sites needs bonds up to {want}; the HIP path holds chi <= {MAX_CHI}")
-    chi = max(int(want), have)
-    if chi > MAX_CHI:
-        raise NotImplementedError(f"bond dimension {chi} exceeds the supported chi <= {MAX_CHI}")
-    return chi
+    """Largest capacity a run can need (``engine_bond_caps(...)[1]``), refused when beyond the supported size."""
+    top = engine_bond_caps(sim_params, initial_state)[1]
+    if top > MAX_CHI:
+        raise NotImplementedError(f"bond dimension {top} exceeds the supported chi <= {MAX_CHI}")
+    return top
+
+
+def _require_capacity(engine) -> None:
+    if engine.capacity_overflow():
+        raise CapacityError(f"a truncation needed a bond beyond the engine's capacity chi = {engine.chi_max}")
 
 
 def plan_digital_shots(sim_params, noisy: bool):
