@@ -143,3 +143,20 @@ def test_static_disorder_sampling_matches_reference_draws():
     assert not got.has_disorder and nm.has_disorder  # the template is untouched
     with pytest.raises(ValueError):
         NoiseModel([{"name": "pauli_z", "sites": [0], "strength": {"distribution": "cauchy", "mean": 0, "std": 1}}])
+
+
+def test_simulation_presets_are_the_reference_table():
+    """simulation_parameters.py:46-51: the four presets, value by value; explicit arguments override them (:520-613)."""
+    from yaqs_amd.api import AnalogSimParams, SIMULATION_PRESETS
+
+    assert SIMULATION_PRESETS == {
+        "fast": {"svd_threshold": 1e-3, "max_bond_dim": 16, "num_traj": 128, "krylov_tol": 1e-3},
+        "balanced": {"svd_threshold": 1e-6, "max_bond_dim": 128, "num_traj": 256, "krylov_tol": 1e-4},
+        "accurate": {"svd_threshold": 1e-9, "max_bond_dim": 4096, "num_traj": 1024, "krylov_tol": 1e-6},
+        "exact": {"svd_threshold": 1e-13, "max_bond_dim": None, "num_traj": 1024, "krylov_tol": 1e-12},
+    }
+    p = AnalogSimParams(observables=[])
+    assert (p.max_bond_dim, p.svd_threshold, p.num_traj, p.krylov_tol) == (128, 1e-6, 256, 1e-4)
+    q = AnalogSimParams(observables=[], preset="exact", max_bond_dim=7)
+    assert (q.max_bond_dim, q.svd_threshold) == (7, 1e-13)
+    assert AnalogSimParams(observables=[], preset="accurate", max_bond_dim=None).max_bond_dim is None

@@ -654,7 +654,7 @@ def test_storage_capacity_grows_on_demand(monkeypatch, max_bond):
             assert np.allclose(res.trajectories[u][t], r[idx[u]], atol=1e-8), (t, u)
         biggest = max(biggest, int(np.max(dg[1])))
     assert biggest > 16, "the case must outgrow the first capacity to mean anything"
-    assert built[0] == 16 and built == sorted(built) and len(built) >= 2, built
+    assert built[0] == 8 and built == sorted(built) and len(built) >= 2, built
     assert built[-1] >= min(biggest, 64) and built[-1] <= 64  # 2**(L//2) bounds every bond of a 12-site chain
     if max_bond == 24:
         assert built[-1] == 24 and biggest == 24

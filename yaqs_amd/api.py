@@ -101,10 +101,10 @@ class Observable:
 # ------------------------------------------------------------------ parameters
 SIMULATION_PRESETS = {
     # simulation_parameters.py:46-51
-    "fast": dict(svd_threshold=1e-4, max_bond_dim=64, num_traj=64, krylov_tol=1e-3),
+    "fast": dict(svd_threshold=1e-3, max_bond_dim=16, num_traj=128, krylov_tol=1e-3),
     "balanced": dict(svd_threshold=1e-6, max_bond_dim=128, num_traj=256, krylov_tol=1e-4),
-    "accurate": dict(svd_threshold=1e-9, max_bond_dim=256, num_traj=1024, krylov_tol=1e-6),
-    "exact": dict(svd_threshold=1e-12, max_bond_dim=None, num_traj=1024, krylov_tol=1e-12),
+    "accurate": dict(svd_threshold=1e-9, max_bond_dim=4096, num_traj=1024, krylov_tol=1e-6),
+    "exact": dict(svd_threshold=1e-13, max_bond_dim=None, num_traj=1024, krylov_tol=1e-12),
 }
 _USE_PRESET = object()
 _TRUNC = ("discarded_weight", "relative", "hard_cutoff", "relative_discarded_weight")

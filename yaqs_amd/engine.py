@@ -47,6 +47,18 @@ class BatchEngine:
         self.caps = caps
         self.padded_elems = int(self.lib.tjm_engine_padded_state_elems(self.h))
 
+    @staticmethod
+    def workspace_bytes_for(length: int, chi_max: int, batch: int, mpo: Sequence[np.ndarray], d: int = 2) -> int:
+        """Device bytes an engine of this shape binds (no GPU needed): used to size the batch to the free HBM."""
+        lib = _lib.load()
+        bonds = _i32([int(mpo[0].shape[2])] + [int(w.shape[3]) for w in mpo])
+        h = C.c_void_p()
+        _lib.check(lib.tjm_engine_create(C.byref(h), int(length), int(d), int(chi_max), int(batch), bonds.ctypes.data), "create")
+        try:
+            return int(lib.tjm_engine_workspace_bytes(h))
+        finally:
+            lib.tjm_engine_destroy(h)
+
     def set_mpo(self, mpo: Sequence[np.ndarray]):
         """Replace the Hamiltonian (piecewise-constant drives, analog_tjm.py:43-49); bond dimensions must match the engine's."""
         bonds = _i32([int(mpo[0].shape[2])] + [int(w.shape[3]) for w in mpo])
@@ -60,6 +72,7 @@ class BatchEngine:
             self.lib.tjm_engine_destroy(self.h)
             self.h = None
             self.ws = None
+            self.torch.cuda.empty_cache()  # hand the workspace back to the device: the next engine may be larger
 
     def __del__(self):
         try:

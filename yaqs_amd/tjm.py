@@ -407,6 +407,18 @@ class Simulator:
         self.show_progress = show_progress
         self.native = native  # True: the C driver tjm_engine_run runs the schedule; False: the Python mirror of it
 
+    def _batch_for(self, remaining: int, length: int, chi: int, mpo, device) -> int:
+        """Trajectories resident at once.  ``batch=None``: as many as fit in 60 % of the free HBM (at most ``AUTO_BATCH_MAX``) - small
+        bonds are launch-latency-bound, so throughput grows with the batch until the chip is full; an explicit ``batch`` is kept."""
+        if self.batch is not None:
+            return max(1, min(int(self.batch), remaining))
+        import torch
+
+        per_traj = BatchEngine.workspace_bytes_for(length, chi, 64, mpo) / 64.0
+        free, _total = torch.cuda.mem_get_info(torch.device(device))
+        fit = int(0.6 * free / per_traj)
+        return max(1, min(remaining, AUTO_BATCH_MAX, fit))
+
     def run(self, initial_state: MPS, hamiltonian: MPO, sim_params: AnalogSimParams, noise_model: NoiseModel | None = None) -> Result:
         import torch
 
@@ -436,10 +448,10 @@ class Simulator:
         n_obs = len(sim_params.observables)
         res_all = np.zeros((len(mine), n_obs, cols))
         diag_all = np.zeros((len(mine), 3, cols))
-        B = min(self.batch or 64, max(len(mine), 1))
         done = 0
         engine = None
         while done < len(mine):
+            B = self._batch_for(len(mine) - done, initial_state.length, chi, hamiltonian.tensors, device)
             chunk = mine[done: done + B]
             if engine is None or engine.B != len(chunk) or engine.chi_max != chi:
                 if engine is not None:
@@ -489,9 +501,9 @@ class Simulator:
         counts: dict[int, int] = {}
         wants_shots = sim_params.shots is not None
         identity_mpo = [np.eye(2, dtype=np.complex128).reshape(2, 2, 1, 1)] * initial_state.length  # the circuit path never applies it
-        B = min(self.batch or 64, num_traj)
         done, engine = 0, None
         while done < num_traj:
+            B = self._batch_for(num_traj - done, initial_state.length, chi, identity_mpo, device)
             chunk = list(range(done, min(done + B, num_traj)))
             if engine is None or engine.B != len(chunk) or engine.chi_max != chi:
                 if engine is not None:
@@ -523,7 +535,8 @@ def _encoded(state: MPS) -> MPS:
 
 
 MAX_CHI = 256   # largest bond the register-resident Jacobi SVD holds (d * chi <= 512)
-START_CHI = 16  # first storage capacity tried when the requested cap is larger
+START_CHI = 8   # first storage capacity tried when the requested cap is larger
+AUTO_BATCH_MAX = 4096  # trajectories in flight when Simulator(batch=None) sizes the batch itself
 
 
 def engine_bond_caps(sim_params, initial_state) -> tuple[int, int]:
