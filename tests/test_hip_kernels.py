@@ -53,6 +53,22 @@ def test_gemm_nn_batched(lib, M, N, K, conjA, conjB):
     assert np.allclose(Cc.cpu().numpy(), ref, atol=1e-11 * K)
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 24, 8), (17, 200, 33), (130, 9, 4), (16, 16, 512), (1, 1, 1), (31, 31, 127)])
+def test_gemm_small_tile_path(lib, M, N, K):
+    """Products with M <= 32 or N <= 32 and K <= 512 run on the one-tile-per-wavefront kernel (small bonds): strided and
+    conjugated operands and the K-split sum against numpy."""
+    rng = np.random.default_rng(M * 131 + N * 7 + K)
+    nb, O = 5, 2
+    a, b = crand(rng, nb, O, K, M), crand(rng, nb, O, N, K)  # A stored [K][M] (m contiguous), B stored [N][K] (k contiguous)
+    A, B = dev(a), dev(b)
+    nks = O if K * O <= 512 else 1
+    Cc = torch.zeros((nb, M, N), dtype=torch.complex128, device="cuda:0")
+    run_gemm(lib, A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, a_rs=1, a_cs=M, b_rs=1, b_cs=K, c_rs=N,
+             nks=nks, a_ks=K * M, b_ks=N * K, nb0=nb, a_b0=O * K * M, b_b0=O * N * K, c_b0=M * N, conjA=1, conjB=1)
+    want = np.einsum("bokm,bonk->bmn", a[:, :nks].conj(), b[:, :nks].conj())
+    assert np.allclose(Cc.cpu().numpy(), want, atol=1e-11 * max(K, 8))
+
+
 def test_gemm_transposed_operands_ksplit_and_inner_batches(lib):
     rng = np.random.default_rng(7)
     # C[b][o] = A^T B_o  (A stored [K][M]), inner batch over o

@@ -1,5 +1,5 @@
 """Times Simulator.run on a low-entanglement run with the reference's default ("balanced") preset: static capacity = max_bond_dim
-versus the capacity grown on demand.  Usage: python tools/capacity_probe.py [L] [num_traj] [batch]"""
+versus the capacity grown on demand.  Usage: python tools/capacity_probe.py [L] [num_traj] [batch|0] [mode]"""
 import sys
 import time
 
@@ -11,11 +11,14 @@ from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z  #
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 ntraj = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-batch = int(sys.argv[3]) if len(sys.argv) > 3 else None  # None: sized to the free HBM
+batch = (int(sys.argv[3]) or None) if len(sys.argv) > 3 else None  # None: sized to the free HBM
 p = AnalogSimParams(observables=[Observable(Z(), s) for s in range(L)], elapsed_time=1.0, dt=0.1, num_traj=ntraj, random_seed=3, sample_timesteps=False)
 noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.1} for i in range(L)])
 out = {}
-for label, start in (("on-demand", tjm.START_CHI), ("static", 4096)):
+modes = (("on-demand", tjm.START_CHI), ("static", 4096))
+if len(sys.argv) > 4:  # e.g. "on-demand": one mode only (profiling runs)
+    modes = tuple(m for m in modes if m[0] == sys.argv[4])
+for label, start in modes:
     tjm.START_CHI = start
     built = []
     orig = tjm.BatchEngine
@@ -32,4 +35,5 @@ for label, start in (("on-demand", tjm.START_CHI), ("static", 4096)):
     tjm.BatchEngine = orig
     out[label] = np.array([e[0] for e in res.expectation_values])
     print(f"{label:10s} capacities {built}  max bond {int(np.max(res.max_bond))}  {dt:.2f} s  ({ntraj / dt:.2f} trajectories/s)", flush=True)
-print("max |difference| of the ensemble means:", float(np.max(np.abs(out["on-demand"] - out["static"]))))
+if len(out) == 2:
+    print("max |difference| of the ensemble means:", float(np.max(np.abs(out["on-demand"] - out["static"]))))

@@ -171,11 +171,83 @@ __global__ __launch_bounds__(256, 3) void zgemm_kernel(GemmDesc g) {
       }
 }
 
+// Small bonds (chi <= 8, or the narrow products of the centre shifts): a 64 x 64 block tile would be mostly padding and
+// spend its time on barriers.  Here every wavefront owns one 16 x 16 output tile of one batch entry and feeds the MFMA
+// straight from global memory - the operands of such a product are a few KiB and stay in L2 - with the next k-group's loads
+// in flight during the four MFMAs of the current one.  No LDS, no barriers, four independent tiles per workgroup.
+__global__ __launch_bounds__(256) void zgemm_small_kernel(GemmDesc g, int tiles_m, int tiles_n, long total_tiles) {
+  const int lane = threadIdx.x & 63;
+  const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= total_tiles) return;
+  const int per = tiles_m * tiles_n;
+  int z = (int)(t / per);
+  const int tt = (int)(t - (long)z * per);
+  const int m0 = (tt / tiles_n) * 16, n0 = (tt % tiles_n) * 16;
+  const int b2 = z % g.nb2;
+  z /= g.nb2;
+  const int b1 = z % g.nb1;
+  int b0 = z / g.nb1;
+  if (g.ids) b0 = g.ids[b0];
+  if (g.active && g.active[b0] == 0) return;
+  const cplx* __restrict__ Ab = g.A + (long)b0 * g.a_b0 + (long)b1 * g.a_b1 + (long)b2 * g.a_b2;
+  const cplx* __restrict__ Bb = g.B + (long)b0 * g.b_b0 + (long)b1 * g.b_b1 + (long)b2 * g.b_b2;
+  cplx* __restrict__ Cb = g.C + (long)b0 * g.c_b0 + (long)b1 * g.c_b1 + (long)b2 * g.c_b2;
+  const int li = lane & 15, lk = lane >> 4;
+  const int m = m0 + li, n = n0 + li;
+  const bool mok = m < g.M, nok = n < g.N;
+  const double sgnA = g.conjA ? -1.0 : 1.0, sgnB = g.conjB ? -1.0 : 1.0;
+  const int ksteps = (g.K + 3) / 4;
+  const int total = ksteps * g.nks;
+  auto fetch = [&](int it, cplx& a, cplx& b) {
+    const int ks = it / ksteps;
+    const int k = (it - ks * ksteps) * 4 + lk;
+    const bool kok = k < g.K;
+    a = (mok && kok) ? Ab[(long)ks * g.a_ks + (long)m * g.a_rs + (long)k * g.a_cs] : cplx{0.0, 0.0};
+    b = (nok && kok) ? Bb[(long)ks * g.b_ks + (long)k * g.b_rs + (long)n * g.b_cs] : cplx{0.0, 0.0};
+  };
+  d4 accRe = d4{0, 0, 0, 0}, accIm = d4{0, 0, 0, 0};
+  cplx a, b, an, bn;
+  fetch(0, a, b);
+  for (int it = 0; it < total; ++it) {
+    if (it + 1 < total) fetch(it + 1, an, bn);
+    const double ai = sgnA * a.y, bi = sgnB * b.y;
+    accRe = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, accRe, 0, 0, 0);
+    accIm = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bi, accIm, 0, 0, 0);
+    accRe = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, accRe, 0, 0, 0);
+    accIm = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, b.x, accIm, 0, 0, 0);
+    a = an;
+    b = bn;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int mm = m0 + lk + 4 * r;
+    if (mm < g.M && nok) {
+      cplx v;
+      v.x = accRe[r];
+      v.y = accIm[r];
+      if (g.accumulate != 0) {
+        const cplx old = Cb[(long)mm * g.c_rs + n];
+        v.x = (g.accumulate > 0) ? old.x + v.x : old.x - v.x;
+        v.y = (g.accumulate > 0) ? old.y + v.y : old.y - v.y;
+      }
+      Cb[(long)mm * g.c_rs + n] = v;
+    }
+  }
+}
+
 }  // namespace
 
 int launch_gemm(const GemmDesc& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.nb0 <= 0 || g.nb1 <= 0 || g.nb2 <= 0) return TJM_OK;
   if (g.K <= 0 || g.nks <= 0) return TJM_ERR_ARG;
+  static const bool no_small = getenv("TJM_NO_SMALL_GEMM") != nullptr;
+  if (!no_small && (g.M <= 32 || g.N <= 32) && (long)g.K * g.nks <= 512) {  // long sums keep the LDS-tiled kernel's four-wave k loop
+    const int tiles_m = (g.M + 15) / 16, tiles_n = (g.N + 15) / 16;
+    const long total_tiles = (long)tiles_m * tiles_n * g.nb0 * g.nb1 * g.nb2;
+    hipLaunchKernelGGL(zgemm_small_kernel, dim3((unsigned)((total_tiles + 3) / 4)), dim3(256), 0, stream, g, tiles_m, tiles_n, total_tiles);
+    TJM_HIP_CHECK(hipGetLastError());
+    return TJM_OK;
+  }
   dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), 1, g.nb0 * g.nb1 * g.nb2);
   dim3 block(256);
   const bool am = (g.a_rs == 1 && g.a_cs != 1);
