@@ -57,6 +57,9 @@ int tjm_engine_set_params(tjm_engine* e, double dt, double svd_threshold, int32_
  * because the new bond only stores chi_max; the states are then not the reference's and the caller re-runs the trajectories
  * on a larger engine.  tjm_engine_run checks after every time step and returns TJM_ERR_CAPACITY. */
 int tjm_engine_capacity_overflow(tjm_engine* e, int32_t* flag, int32_t clear);
+/* Growing the storage: set 0 of dst slot k = set 0 of src slot (src_first + k), zero-padded to dst's larger bond capacities
+ * (same L and d; dst.chi_max >= src.chi_max; src_first + dst.B <= src.B).  Device-to-device on dst's stream. */
+int tjm_engine_adopt_state(tjm_engine* dst, tjm_engine* src, int32_t src_first);
 /* host pointer: per site the tensor (phys_out, phys_in, chi_l, chi_r) C-contiguous, sites concatenated. */
 int tjm_engine_set_mpo(tjm_engine* e, const double* host_mpo);
 /* NoiseModel.processes (noise_model.py:227-243), one entry per process:
@@ -143,11 +146,21 @@ typedef struct {
   const int32_t* obs_nsites; /* [n_obs] 1 or 2 */
   const int32_t* obs_site;   /* [n_obs] first site */
   const double* obs_matrix;  /* [n_obs][32]: row-major complex 2x2 (first 8 doubles) or 4x4 */
+  /* Continuation after TJM_ERR_CAPACITY (all zero / null for a run from the initial state).
+   * start_step = j > 0: set 0 already holds the trajectory states at the START of time step j (tjm_engine_adopt_state), the
+   * columns measured before j are already in results / diagnostics, and rng_pos[B] holds every trajectory's cursor into its
+   * random stream.  start_phase = 1 (order 2 only): the trajectory state is the one AFTER step j; only its sampling is redone.
+   * rng_pos (in/out, may be null) and resume (out, may be null: int32[2] = {step, phase}) are written when the run stops with
+   * TJM_ERR_CAPACITY; set 0 then holds the states to continue from.  resume[0] = 0 means: start again from the initial state. */
+  int32_t start_step;
+  int32_t start_phase;
+  int64_t* rng_pos;
+  int32_t* resume;
 } tjm_run_config;
 /* traj[B]: trajectory indices (seeds of the per-trajectory streams); results[B][n_obs][T], diagnostics[B][3][T] with
  * T = n_times if sample_timesteps else 1 (host, float64).  Returns TJM_ERR_ASSERT for an imaginary expectation
  * value (AssertionError in mps.py:1233), TJM_ERR_NUMERIC for zero / non-finite jump weights and TJM_ERR_CAPACITY as soon as
- * a time step needed a bond beyond chi_max. */
+ * a time step needed a bond beyond chi_max (the step is rolled back: see start_step). */
 int tjm_engine_run(tjm_engine* e, const tjm_run_config* cfg, const int64_t* traj, double* results, double* diagnostics);
 /* The reference's host random streams, bit-compatible with NumPy (core/random_utils.py:20-69):
  * timestep < 0: make_trajectory_rng(traj, base_seed=seed).random(n); otherwise make_sample_rng(traj, timestep, seed). */

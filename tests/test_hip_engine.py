@@ -660,6 +660,45 @@ def test_storage_capacity_grows_on_demand(monkeypatch, max_bond):
         assert built[-1] == 24 and biggest == 24
 
 
+@pytest.mark.parametrize("order,sample_timesteps", [(1, False), (2, True), (2, False)])
+def test_growth_continues_mid_run_and_splits_pieces(monkeypatch, order, sample_timesteps):
+    """A run that outgrows its storage is not started again: the step that was clipped is rolled back, the states move to
+    engines of twice the capacity (here forced to hold fewer trajectories each, so the piece is split) and the run continues from
+    that step with the random-stream cursors it had - order 1 and both phases of order 2, against the oracle per trajectory."""
+    import yaqs_amd.tjm as tjm_mod
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, X as Xg, Z as Zg
+
+    built = _recording_engine(monkeypatch)
+    monkeypatch.setattr(tjm_mod.Simulator, "_batch_for", lambda self, remaining, length, chi, mpo, device: min(remaining, 5 if chi <= 8 else 2))
+    starts = []
+    orig_run = tjm_mod.BatchEngine.run
+
+    def spy(self, **kw):
+        starts.append(tuple(kw.get("start", (0, 0))))
+        return orig_run(self, **kw)
+
+    monkeypatch.setattr(tjm_mod.BatchEngine, "run", spy)
+    L, ntraj = 10, 5
+    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 4)]
+    oobs = [o.Obs(Z, s) for s in range(L)] + [o.Obs(X, 4)]
+    kw = dict(elapsed_time=1.5, dt=0.1, max_bond_dim=None, svd_threshold=1e-10, krylov_tol=1e-11, order=order, random_seed=9)
+    p = AnalogSimParams(observables=obs, num_traj=ntraj, sample_timesteps=sample_timesteps, **kw)
+    noise = NoiseModel([{"name": "lowering", "sites": [i], "strength": 0.08} for i in range(L)])
+    res = tjm_mod.Simulator().run(MPS(L, state="Neel"), MPO.heisenberg(L, 1.0, 0.9, 0.7, 0.2), p, noise)
+    op = o.Params(observables=oobs, sample_timesteps=sample_timesteps, **kw)
+    on = [o.make_process("lowering", [i], 0.08) for i in range(L)]
+    idx = op.observable_sorted_indices
+    for t in range(ntraj):
+        r, dg, _ = o.run_trajectory(t, o.MPSState.product(L, "Neel"), on, op, o.heisenberg_mpo(L, 1.0, 0.9, 0.7, 0.2))
+        for u in range(len(obs)):
+            assert np.allclose(res.trajectories[u][t], r[idx[u]], atol=1e-8), (t, u)
+        assert np.array_equal(res.max_bond_trajectories[t], dg[1]) if hasattr(res, "max_bond_trajectories") else True
+    assert built[0] == 8 and max(built) >= 16 and len(built) >= 4, built          # 5 trajectories -> pieces of 2, 2 and 1
+    assert any(st[0] > 0 for st in starts), starts                                # some piece continued mid-run
+    if order == 2:
+        assert all(st[1] in (0, 1) for st in starts)
+
+
 def test_capacity_overflow_is_reported_by_the_engine_and_the_driver():
     """A two-site truncation that wants more values than the new bond stores sets the engine's flag (and only such a one), and
     tjm_engine_run stops after that time step with TJM_ERR_CAPACITY instead of finishing a run that is not the reference's."""

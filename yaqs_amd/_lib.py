@@ -27,7 +27,13 @@ class TjmError(RuntimeError):
 
 
 class CapacityError(TjmError):
-    """A truncation asked for a bond beyond the engine's chi_max (TJM_ERR_CAPACITY): re-run on a larger engine."""
+    """A truncation asked for a bond beyond the engine's chi_max (TJM_ERR_CAPACITY): continue (or re-run) on a larger engine.
+
+    ``resume`` = (time step, phase) and ``rng_pos`` are set by ``BatchEngine.run``: set 0 of the engine then holds the states at
+    the start of that step; ``resume[0] == 0`` (or None) means: start again from the initial state."""
+
+    resume = None
+    rng_pos = None
 
 
 ERRORS[-8] = CapacityError
@@ -51,7 +57,8 @@ class RunConfig(C.Structure):
     """tjm_run_config of include/tjm_hip.h."""
     _fields_ = [("order", C.c_int32), ("n_times", C.c_int32), ("sample_timesteps", C.c_int32), ("has_noise", C.c_int32),
                 ("has_seed", C.c_int32), ("seed", C.c_uint64), ("n_obs", C.c_int32), ("obs_nsites", C.c_void_p),
-                ("obs_site", C.c_void_p), ("obs_matrix", C.c_void_p)]
+                ("obs_site", C.c_void_p), ("obs_matrix", C.c_void_p),
+                ("start_step", C.c_int32), ("start_phase", C.c_int32), ("rng_pos", C.c_void_p), ("resume", C.c_void_p)]
 
 
 V = C.c_void_p
@@ -67,6 +74,7 @@ EXPORTS = {
     "tjm_engine_bind": (C.c_int, [V, V, C.c_size_t, V]),
     "tjm_engine_set_params": (C.c_int, [V, D, D, I, I, D, I, I]),
     "tjm_engine_capacity_overflow": (C.c_int, [V, V, I]),
+    "tjm_engine_adopt_state": (C.c_int, [V, V, I]),
     "tjm_engine_set_mpo": (C.c_int, [V, V]),
     "tjm_engine_set_noise": (C.c_int, [V, I, V, V, V, V, V, V, V]),
     "tjm_engine_load_state": (C.c_int, [V, I, V, V]),

@@ -65,6 +65,11 @@ int tjm_engine_capacity_overflow(tjm_engine* e, int32_t* flag, int32_t clear) {
   return rc;
 }
 
+int tjm_engine_adopt_state(tjm_engine* dst, tjm_engine* src, int32_t src_first) {
+  if (!dst || !src || dst == src) return TJM_ERR_ARG;
+  return dst->impl.adopt(src->impl, src_first);
+}
+
 int tjm_engine_set_mpo(tjm_engine* e, const double* host_mpo) { return (e && host_mpo) ? e->impl.set_mpo(host_mpo) : TJM_ERR_ARG; }
 
 int tjm_engine_set_noise(tjm_engine* e, int32_t nproc, const int32_t* nsites, const int32_t* sites, const double* gamma,

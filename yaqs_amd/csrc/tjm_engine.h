@@ -49,6 +49,7 @@ class Engine {
   int set_uniforms(const double* host_u, int n_per_traj);
   int reset_cursor();
   int capacity_overflow(int* host_flag, bool clear);
+  int adopt(Engine& src, int first);   // set 0 <- set 0 of src slots [first, first + B), re-padded
 
   int tdvp(int set);
   int dissipate(int set, double dt_, int start_center = 0);

@@ -267,6 +267,38 @@ int Engine::copy_state(int dst, int src) {
   return TJM_OK;
 }
 
+// dst[b][p][a][c] (extents capL x capR) = src[b][p][a][c] (extents sl x sr) inside the source extents, zero outside
+__global__ __launch_bounds__(256) void repad_kernel(const cplx* __restrict__ src, long src_b0, int sl, int sr, cplx* __restrict__ dst, long dst_b0,
+                                                   int capL, int capR, int d) {
+  const long n = (long)d * capL * capR;
+  const int b = blockIdx.y;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(t % capR);
+    const long q = t / capR;
+    const int a = (int)(q % capL), p = (int)(q / capL);
+    cplx v{0.0, 0.0};
+    if (a < sl && c < sr) v = src[(long)b * src_b0 + ((long)p * sl + a) * sr + c];
+    dst[(long)b * dst_b0 + t] = v;
+  }
+}
+
+// Take over the trajectory states (set 0) of slots [first, first + B) of a smaller-capacity engine.
+int Engine::adopt(Engine& src, int first) {
+  if (!bound_ || !src.bound_ || src.L != L || src.d != d || first < 0 || first + B > src.B) return TJM_ERR_ARG;
+  for (int k = 0; k <= L; ++k) if (src.cap[k] > cap[k]) return TJM_ERR_ARG;
+  TJM_HIP_CHECK(hipStreamSynchronize(src.stream));
+  for (int i = 0; i < L; ++i) {
+    const long n = (long)d * cap[i] * cap[i + 1];
+    const int gx = (int)std::min<long>((n + 255) / 256, 64);
+    hipLaunchKernelGGL(repad_kernel, dim3(gx, B), dim3(256), 0, stream, src.sets[0].A[i] + (long)first * src.a_b0_[i], src.a_b0_[i], src.cap[i],
+                       src.cap[i + 1], sets[0].A[i], a_b0_[i], cap[i], cap[i + 1], d);
+  }
+  TJM_HIP_CHECK(hipGetLastError());
+  TJM_HIP_CHECK(hipMemcpyAsync(sets[0].chi, src.sets[0].chi + (size_t)first * (L + 1), (size_t)B * (L + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
 int Engine::export_state(int set, int b, double* out, int* bonds) {
   if (!bound_ || b < 0 || b >= B) return TJM_ERR_ARG;
   StateSet& S = sets[set];

@@ -184,15 +184,31 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
   const int n_draw = 2 * n_t + 2;
   std::vector<double> u((size_t)B * n_draw);
   for (int b = 0; b < B; ++b) rng_uniforms(c->has_seed, c->seed, (uint64_t)traj[b], -1, n_draw, &u[(size_t)b * n_draw]);
-  std::vector<int> pos(B, 0), jumped(B, 0);
+  std::vector<int> pos(B, 0), jumped(B, 0), pos_snap(B, 0);
   std::vector<double> cand((size_t)B * 2);
   int rc, clipped = 0;
+  const int j0 = c->start_step;
+  if (j0 < 0 || j0 >= n_t || (j0 > 0 && !c->rng_pos) || (c->start_phase != 0 && (c->order != 2 || j0 < 2))) return TJM_ERR_ARG;
+  if (j0 > 0)
+    for (int b = 0; b < B; ++b) {
+      if (c->rng_pos[b] < 0 || c->rng_pos[b] + 2 > n_draw) return TJM_ERR_ARG;
+      pos[b] = (int)c->rng_pos[b];
+    }
   if ((rc = e.capacity_overflow(&clipped, true)) != TJM_OK) return rc;  // start from a clean flag
-  // after every time step: a truncation clipped by the engine's storage makes the rest of the run pointless
-  auto capacity_ok = [&]() -> int {
-    if ((rc = e.capacity_overflow(&clipped, false)) != TJM_OK) return rc;
-    return clipped ? TJM_ERR_CAPACITY : TJM_OK;
+  // A truncation clipped by the engine's storage makes the rest of the run pointless.  Time step j is then rolled back (set 1
+  // holds the states of its start, nothing else uses that set in between) and the caller continues on a larger engine.
+  auto stop_at = [&](int step, int phase) -> int {
+    if (c->resume) { c->resume[0] = step; c->resume[1] = phase; }
+    if (c->rng_pos) for (int b = 0; b < B; ++b) c->rng_pos[b] = pos[b];
+    return TJM_ERR_CAPACITY;
   };
+  auto clipped_now = [&](bool& yes) -> int {
+    if ((rc = e.capacity_overflow(&clipped, false)) != TJM_OK) return rc;
+    yes = clipped != 0;
+    return TJM_OK;
+  };
+  auto snapshot = [&]() -> int { pos_snap = pos; return e.copy_state(1, 0); };
+  auto roll_back = [&]() -> int { pos = pos_snap; return e.copy_state(0, 1); };
   auto record = [&](int j) { return c->sample_timesteps ? true : j == n_t - 1; };
   auto col_of = [&](int j) { return c->sample_timesteps ? j : 0; };
   auto stochastic_main = [&](int set) -> int {
@@ -210,17 +226,23 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
     for (int b = 0; b < B; ++b) pos[b] += 1 + jumped[b];
     return TJM_OK;
   };
+  bool over = false;
 
   if (c->order == 1) {  // analog_tjm_1 (analog_tjm.py:369-462)
-    if (c->sample_timesteps || n_t <= 1)
+    if (j0 == 0 && (c->sample_timesteps || n_t <= 1))
       if ((rc = measure(r, 0, 0)) != TJM_OK) return rc;
-    for (int j = 1; j < n_t; ++j) {
+    for (int j = (j0 > 0 ? j0 : 1); j < n_t; ++j) {
+      if ((rc = snapshot()) != TJM_OK) return rc;
       if ((rc = e.tdvp(0)) != TJM_OK) return rc;
       if (noisy) {
         if ((rc = e.dissipate(0, dt)) != TJM_OK) return rc;
         if ((rc = stochastic_main(0)) != TJM_OK) return rc;
       }
-      if ((rc = capacity_ok()) != TJM_OK) return rc;
+      if ((rc = clipped_now(over)) != TJM_OK) return rc;
+      if (over) {
+        if ((rc = roll_back()) != TJM_OK) return rc;
+        return stop_at(j, 0);
+      }
       if (record(j))
         if ((rc = measure(r, 0, col_of(j))) != TJM_OK) return rc;
     }
@@ -238,21 +260,34 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
     else std::fill(cand.begin(), cand.end(), 0.0);
     if ((rc = e.set_uniforms(cand.data(), 2)) != TJM_OK) return rc;
     if ((rc = e.stochastic(1, dt, nullptr, nullptr)) != TJM_OK) return rc;
-    if ((rc = capacity_ok()) != TJM_OK) return rc;
+    if ((rc = clipped_now(over)) != TJM_OK) return rc;
+    if (over) return TJM_OK;  // phi is untouched: the caller stops with phase 1
     return measure(r, 1, col_of(j));
   };
-  if (record(0))
-    if ((rc = measure(r, 0, 0)) != TJM_OK) return rc;
-  if (n_t == 1) return TJM_OK;
-  if ((rc = e.dissipate(0, 0.5 * dt)) != TJM_OK) return rc;
-  if ((rc = stochastic_main(0)) != TJM_OK) return rc;
-  if ((rc = sample(1)) != TJM_OK) return rc;
-  for (int j = 2; j < n_t; ++j) {
-    if ((rc = e.tdvp(0)) != TJM_OK) return rc;
-    if ((rc = e.dissipate(0, dt)) != TJM_OK) return rc;
+  if (j0 == 0) {
+    if (record(0))
+      if ((rc = measure(r, 0, 0)) != TJM_OK) return rc;
+    if (n_t == 1) return TJM_OK;
+    if ((rc = e.dissipate(0, 0.5 * dt)) != TJM_OK) return rc;
     if ((rc = stochastic_main(0)) != TJM_OK) return rc;
-    if ((rc = capacity_ok()) != TJM_OK) return rc;
+    if ((rc = clipped_now(over)) != TJM_OK) return rc;
+    if (!over && (rc = sample(1)) != TJM_OK) return rc;
+    if (over) return stop_at(0, 0);  // before the first full step: nothing to keep
+  }
+  for (int j = (j0 > 1 ? j0 : 2); j < n_t; ++j) {
+    if (!(j == j0 && c->start_phase == 1)) {
+      if ((rc = snapshot()) != TJM_OK) return rc;
+      if ((rc = e.tdvp(0)) != TJM_OK) return rc;
+      if ((rc = e.dissipate(0, dt)) != TJM_OK) return rc;
+      if ((rc = stochastic_main(0)) != TJM_OK) return rc;
+      if ((rc = clipped_now(over)) != TJM_OK) return rc;
+      if (over) {
+        if ((rc = roll_back()) != TJM_OK) return rc;
+        return stop_at(j, 0);
+      }
+    }
     if ((rc = sample(j)) != TJM_OK) return rc;
+    if (over) return stop_at(j, 1);
   }
   return TJM_OK;
 }

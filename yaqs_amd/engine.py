@@ -203,8 +203,12 @@ class BatchEngine:
         _lib.check(self.lib.tjm_engine_site0_normsq(self.h, set_index, out.ctypes.data), "site0_normsq")
         return out
 
-    def run(self, *, order: int, n_times: int, sample_timesteps: bool, has_noise: bool, seed, traj_indices, observables):
-        """Whole trajectories in one C call (tjm_engine_run).  observables: [(first_site, matrix 2x2 | 4x4)] in site-sorted order."""
+    def run(self, *, order: int, n_times: int, sample_timesteps: bool, has_noise: bool, seed, traj_indices, observables,
+            start=(0, 0), rng_pos=None, results=None, diagnostics=None):
+        """Whole trajectories in one C call (tjm_engine_run).  observables: [(first_site, matrix 2x2 | 4x4)] in site-sorted order.
+
+        ``start`` / ``rng_pos`` / ``results`` / ``diagnostics`` continue a run that stopped with ``CapacityError`` (whose
+        ``resume`` and ``rng_pos`` attributes carry the values to pass) after ``adopt`` has moved the states to this engine."""
         n_obs = len(observables)
         nsites = np.zeros(max(n_obs, 1), dtype=np.int32)
         site = np.zeros(max(n_obs, 1), dtype=np.int32)
@@ -214,16 +218,32 @@ class BatchEngine:
             nsites[k] = 2 if m.size == 16 else 1
             site[k] = s0
             mats[k, : m.size] = m.reshape(-1)
+        pos = np.zeros(self.B, dtype=np.int64) if rng_pos is None else np.ascontiguousarray(rng_pos, dtype=np.int64).copy()
+        resume = np.zeros(2, dtype=np.int32)
         cfg = _lib.RunConfig(order=int(order), n_times=int(n_times), sample_timesteps=int(bool(sample_timesteps)), has_noise=int(bool(has_noise)),
                              has_seed=int(seed is not None), seed=int(seed or 0), n_obs=n_obs, obs_nsites=nsites.ctypes.data,
-                             obs_site=site.ctypes.data, obs_matrix=mats.ctypes.data)
+                             obs_site=site.ctypes.data, obs_matrix=mats.ctypes.data, start_step=int(start[0]), start_phase=int(start[1]),
+                             rng_pos=pos.ctypes.data, resume=resume.ctypes.data)
         traj = np.ascontiguousarray(np.asarray(traj_indices, dtype=np.int64))
-        assert traj.shape == (self.B,)
+        assert traj.shape == (self.B,) and pos.shape == (self.B,)
         cols = n_times if sample_timesteps else 1
-        results = np.zeros((self.B, n_obs, cols))
-        diagnostics = np.zeros((self.B, 3, cols))
-        _lib.check(self.lib.tjm_engine_run(self.h, C.byref(cfg), traj.ctypes.data, results.ctypes.data, diagnostics.ctypes.data), "run")
+        if results is None:
+            results = np.zeros((self.B, n_obs, cols))
+            diagnostics = np.zeros((self.B, 3, cols))
+        assert results.shape == (self.B, n_obs, cols) and diagnostics.shape == (self.B, 3, cols)
+        assert results.flags.c_contiguous and diagnostics.flags.c_contiguous
+        try:
+            _lib.check(self.lib.tjm_engine_run(self.h, C.byref(cfg), traj.ctypes.data, results.ctypes.data, diagnostics.ctypes.data), "run")
+        except _lib.CapacityError as err:
+            err.resume = (int(resume[0]), int(resume[1]))
+            err.rng_pos = pos
+            err.results, err.diagnostics = results, diagnostics
+            raise
         return results, diagnostics
+
+    def adopt(self, src: "BatchEngine", first: int = 0) -> None:
+        """Set 0 of this engine = set 0 of ``src`` slots [first, first + B), zero-padded to this engine's larger capacities."""
+        _lib.check(self.lib.tjm_engine_adopt_state(self.h, src.h, int(first)), "adopt_state")
 
     def capacity_overflow(self, clear: bool = False) -> bool:
         """True when a truncation since the last clear was clipped by the storage capacity ``chi_max`` of this engine."""

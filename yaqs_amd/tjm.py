@@ -163,7 +163,7 @@ class TrajectoryBatch:
             pos += 1 + jumped
 
     # ---- drivers --------------------------------------------------------------------
-    def run(self, traj_indices: Sequence[int], initial: MPS, native: bool = False):
+    def run(self, traj_indices: Sequence[int], initial: MPS | None, native: bool = False, resume: dict | None = None):
         """``native=True`` hands the whole schedule to the C driver (``tjm_engine_run``): same results, no per-step host
         logic and no dp / jump logs.  The Python schedule below is the readable mirror of analog_tjm.py used by the tests."""
         e, p = self.e, self.p
@@ -177,10 +177,16 @@ class TrajectoryBatch:
                 if not np.any(np.isclose(p.times, j["time"], atol=p.dt * 1e-3, rtol=0.0)):
                     raise ValueError(f"Scheduled jump time {j['time']} is not on the simulation time grid.")  # noise_model.py:768-775
         if native and not self.meta_obs and not has_sched and self.intervals is None:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
-            e.load_state(initial.tensors, 0)
             obs = [(o_.first_site, np.asarray(o_.gate.matrix, dtype=np.complex128)) for o_ in self.sorted_obs]
+            kw = {}
+            if resume is None:
+                e.load_state(initial.tensors, 0)
+            else:  # the states were adopted from the engine that ran out of capacity (CapacityError.resume / .rng_pos)
+                kw = dict(start=resume["start"], rng_pos=resume["rng_pos"], results=resume["results"], diagnostics=resume["diagnostics"])
             return e.run(order=p.order, n_times=n_t, sample_timesteps=p.sample_timesteps, has_noise=self.noise is not None,
-                         seed=p.random_seed, traj_indices=traj_indices, observables=obs)
+                         seed=p.random_seed, traj_indices=traj_indices, observables=obs, **kw)
+        if resume is not None:
+            raise ValueError("only the native driver continues a run; the host schedule starts again from the initial state")
         cols = n_t if p.sample_timesteps else 1
         results = np.zeros((e.B, len(self.sorted_obs), cols))
         diagnostics = np.zeros((e.B, 3, cols))
@@ -419,6 +425,50 @@ class Simulator:
         fit = int(0.6 * free / per_traj)
         return max(1, min(remaining, AUTO_BATCH_MAX, fit))
 
+    def _run_growing(self, chunk, chi, chi_top, initial_state, mpo, make_batch, device, cols, n_obs, keep_last):
+        """One chunk of trajectories with storage grown on demand.  A piece that runs out of capacity at time step j hands its
+        states (rolled back to the start of j) to engines of twice the capacity - several smaller ones when the memory asks for
+        it - which continue from j; only a clip before the first full step starts the piece again from the initial state.
+        Returns (results, diagnostics, engine holding trajectory chunk[0] if ``keep_last``)."""
+        res = np.zeros((len(chunk), n_obs, cols))
+        dg = np.zeros((len(chunk), 3, cols))
+        # (lo, hi, source engine or None, first source slot, (step, phase), rng cursors, capacity)
+        pending = [(0, len(chunk), None, 0, (0, 0), None, chi)]
+        kept = None
+        while pending:
+            lo, hi, src, first, start, pos, cap_now = pending.pop()
+            fit = self._batch_for(hi - lo, initial_state.length, cap_now, mpo, device)
+            if fit < hi - lo:  # the larger engine holds fewer trajectories: the rest of the piece waits
+                pending.append((lo + fit, hi, src, first + fit, start, None if pos is None else pos[fit:], cap_now))
+                hi = lo + fit
+                pos = None if pos is None else pos[:fit]
+            engine = BatchEngine(initial_state.length, cap_now, hi - lo, mpo, device=device)
+            tb = make_batch(engine)
+            try:
+                if src is None:
+                    r, d_ = tb.run(chunk[lo:hi], initial_state, native=self.native)
+                else:
+                    engine.adopt(src, first)
+                    r, d_ = tb.run(chunk[lo:hi], None, native=True,
+                                   resume=dict(start=start, rng_pos=pos, results=np.ascontiguousarray(res[lo:hi]), diagnostics=np.ascontiguousarray(dg[lo:hi])))
+                res[lo:hi], dg[lo:hi] = r, d_
+            except CapacityError as err:
+                bigger = grown_capacity(cap_now, chi_top)
+                if err.resume is not None and err.resume[0] > 0:
+                    res[lo:hi], dg[lo:hi] = err.results, err.diagnostics  # the columns measured so far
+                    pending.append((lo, hi, engine, 0, err.resume, err.rng_pos, bigger))
+                    engine = None  # stays alive as the source of its successors
+                else:
+                    pending.append((lo, hi, None, 0, (0, 0), None, bigger))
+            if src is not None and not any(q[2] is src for q in pending):
+                src.close()
+            if engine is not None:
+                if keep_last and lo == 0 and not any(q[0] == 0 for q in pending):
+                    kept = engine
+                else:
+                    engine.close()
+        return res, dg, kept
+
     def run(self, initial_state: MPS, hamiltonian: MPO, sim_params: AnalogSimParams, noise_model: NoiseModel | None = None) -> Result:
         import torch
 
@@ -449,33 +499,28 @@ class Simulator:
         res_all = np.zeros((len(mine), n_obs, cols))
         diag_all = np.zeros((len(mine), 3, cols))
         done = 0
-        engine = None
+        final = None
         while done < len(mine):
             B = self._batch_for(len(mine) - done, initial_state.length, chi, hamiltonian.tensors, device)
             chunk = mine[done: done + B]
-            if engine is None or engine.B != len(chunk) or engine.chi_max != chi:
-                if engine is not None:
-                    engine.close()
-                engine = BatchEngine(initial_state.length, chi, len(chunk), hamiltonian.tensors, device=device)
-            tb = TrajectoryBatch(engine, sim_params, noise_model)  # the backend sees the model as given (simulator.py:1549-1559)
-            if pieces is not None:
-                tb.set_intervals(pieces)
-            try:
-                r, dg = tb.run(chunk, initial_state, native=self.native)
-            except CapacityError:
-                chi = grown_capacity(chi, chi_top)  # trajectories are pure functions of (seed, index): run the chunk again
-                continue
+
+            def make_batch(engine):
+                tb = TrajectoryBatch(engine, sim_params, noise_model)  # the backend sees the model as given (simulator.py:1549-1559)
+                if pieces is not None:
+                    tb.set_intervals(pieces)
+                return tb
+
+            keep = sim_params.get_state and 0 in chunk
+            r, dg, last = self._run_growing(chunk, chi, chi_top, initial_state, hamiltonian.tensors, make_batch, device, cols, n_obs, keep)
             res_all[done: done + len(chunk)] = r
             diag_all[done: done + len(chunk)] = dg
             done += len(chunk)
-        final = None
-        if sim_params.get_state and engine is not None and 0 in mine:
-            # the physical state at the last time: the trajectory state (order 1) or the last sampled copy psi (order 2,
-            # analog_tjm.py:331-366); closed-system runs have one trajectory, slot 0 of the first chunk
-            use_psi = sim_params.order == 2 and len(sim_params.times) > 1
-            final = MPS(initial_state.length, tensors=engine.export_state(0, 1 if use_psi else 0))
-        if engine is not None:
-            engine.close()
+            if last is not None:
+                # the physical state at the last time: the trajectory state (order 1) or the last sampled copy psi (order 2,
+                # analog_tjm.py:331-366); closed-system runs have one trajectory, slot 0 of the first chunk
+                use_psi = sim_params.order == 2 and len(sim_params.times) > 1
+                final = MPS(initial_state.length, tensors=last.export_state(0, 1 if use_psi else 0))
+                last.close()
         if world > 1:
             res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, lo, device)
         out = Result(sim_params, res_all, diag_all)
