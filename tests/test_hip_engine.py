@@ -699,6 +699,49 @@ def test_growth_continues_mid_run_and_splits_pieces(monkeypatch, order, sample_t
         assert all(st[1] in (0, 1) for st in starts)
 
 
+def test_circuit_growth_continues_at_the_clipped_layer(monkeypatch):
+    """run_circuit with storage grown on demand: the layer whose truncation was clipped is rolled back and repeated on engines of
+    twice the capacity (split into smaller batches here), mid-circuit sampling columns and the jump streams carry over; per
+    trajectory equal to the oracle, shot counts complete."""
+    import yaqs_amd.tjm as tjm_mod
+    from yaqs_amd.api import DigitalSimParams, GateLayer, MPS, NoiseModel, Observable, X as Xg, Z as Zg
+
+    built = _recording_engine(monkeypatch)
+    monkeypatch.setattr(tjm_mod.Simulator, "_batch_for", lambda self, remaining, length, chi, mpo, device: min(remaining, 4 if chi <= 8 else 3))
+    rng = np.random.default_rng(99)
+
+    def haar(n):
+        q, r = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+        return q * (np.diag(r) / np.abs(np.diag(r)))
+
+    L, ntraj, n_layers = 10, 4, 6
+    layers, olayers = [], []
+    for k in range(n_layers):
+        singles = [(q, haar(2)) for q in range(L)]
+        even = [(q, q + 1, haar(4)) for q in range(0, L - 1, 2)]
+        odd = [(q, q + 1, haar(4)) for q in range(1, L - 1, 2)]
+        layers.append(GateLayer(singles, even, odd, 1 if k in (1, 3) else 0))
+        olayers.append(o.GateLayer(singles, even, odd, 1 if k in (1, 3) else 0))
+    procs = [{"name": name, "sites": [i], "strength": 0.05} for i in range(L) for name in ("pauli_x", "lowering")]
+    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 2)]
+    oobs = [o.Obs(Z, s) for s in range(L)] + [o.Obs(X, 2)]
+    kw = dict(max_bond_dim=None, svd_threshold=1e-9, random_seed=21, sample_layers=True, num_mid_measurements=2)
+    res = tjm_mod.Simulator().run_circuit(MPS(L, state="zeros"), layers, DigitalSimParams(observables=obs, num_traj=ntraj, shots=40, **kw),
+                                          NoiseModel(procs))
+    on = [o.make_process(q["name"], q["sites"], q["strength"]) for q in procs]
+    op = o.DigitalParams(observables=oobs, **kw)
+    order_ = sorted(range(len(oobs)), key=lambda i: (oobs[i].first_site, i))  # user index -> row of the site-sorted buffer
+    idx = [order_.index(u) for u in range(len(oobs))]
+    biggest = 0
+    for t in range(ntraj):
+        ro, do, _ = o.digital_tjm(t, o.MPSState.product(L, "zeros"), on, op, olayers)
+        for u in range(len(obs)):
+            assert np.allclose(res.trajectories[u][t], ro[idx[u]], atol=1e-8), (t, u)
+        biggest = max(biggest, int(np.max(do[1])))
+    assert biggest > 8 and built[0] == 8 and max(built) >= 16, (biggest, built)
+    assert sum(res.counts.values()) == 40
+
+
 def test_capacity_overflow_is_reported_by_the_engine_and_the_driver():
     """A two-site truncation that wants more values than the new bond stores sets the engine's flag (and only such a one), and
     tjm_engine_run stops after that time step with TJM_ERR_CAPACITY instead of finishing a run that is not the reference's."""

@@ -332,23 +332,33 @@ class DigitalBatch:
             center = i + 1
         return {s0, s1}, center
 
-    def run(self, traj_indices: Sequence[int], initial: MPS, layers, shots_per_traj=None, basis: str = "Z"):
+    def run(self, traj_indices: Sequence[int], initial: MPS | None, layers, shots_per_traj=None, basis: str = "Z", resume: dict | None = None):
+        """``resume`` continues a run that stopped with ``CapacityError`` at the start of layer ``resume["start"][0] - 1`` after the
+        states were adopted from the smaller engine (same contract as ``TrajectoryBatch.run``)."""
         e, p = self.e, self.p
         assert len(traj_indices) == e.B
         n_gates = sum(len(l.even) + len(l.odd) for l in layers)
         mid = p.num_mid_measurements if p.sample_layers else 0
         cols = (mid + 2) if p.sample_layers else 1
-        results = np.zeros((e.B, len(self.sorted_obs), cols))
-        diagnostics = np.zeros((e.B, 3, cols))
-        e.load_state(initial.tensors, 0)
         e.capacity_overflow(clear=True)
-        if p.sample_layers:
-            self._measure(0, results, diagnostics, 0)
+        if resume is None:
+            results = np.zeros((e.B, len(self.sorted_obs), cols))
+            diagnostics = np.zeros((e.B, 3, cols))
+            e.load_state(initial.tensors, 0)
+            if p.sample_layers:
+                self._measure(0, results, diagnostics, 0)
+            pos = np.zeros(e.B, dtype=np.int64)
+            col, first_layer = 0, 0
+        else:
+            results, diagnostics = resume["results"], resume["diagnostics"]
+            pos = np.asarray(resume["rng_pos"], dtype=np.int64).copy()
+            col, first_layer = int(resume["extra"]["col"]), int(resume["start"][0]) - 1
         u = np.stack([trajectory_uniforms(p.random_seed, int(t), 2 * n_gates + 2) for t in traj_indices])
-        pos = np.zeros(e.B, dtype=np.int64)
         rows = np.arange(e.B)
-        col = 0
-        for layer in layers:
+        for li in range(first_layer, len(layers)):
+            layer = layers[li]
+            e.copy_state(1, 0)  # the layer is rolled back if one of its truncations is clipped by the storage
+            pos_at_start, jumps_at_start = pos.copy(), len(self.jump_log)
             for site, m in layer.singles:
                 e.apply_single(site, m)
             for group in (layer.even, layer.odd):
@@ -366,7 +376,13 @@ class DigitalBatch:
                         jumped[:] = 0  # an empty local model can only renormalise (stochastic_process.py:236-243)
                     self.jump_log.append(jumped.copy())
                     pos += 1 + jumped
-            _require_capacity(e)
+            if e.capacity_overflow():
+                e.copy_state(0, 1)
+                e.set_noise_filter(None)
+                del self.jump_log[jumps_at_start:]
+                err = CapacityError(f"layer {li} needs a bond beyond the engine's capacity chi = {e.chi_max}")
+                err.resume, err.rng_pos, err.results, err.diagnostics, err.extra = (li + 1, 0), pos_at_start, results, diagnostics, {"col": col}
+                raise err
             if p.sample_layers:
                 for _ in range(layer.sample_points):
                     col += 1
@@ -425,41 +441,40 @@ class Simulator:
         fit = int(0.6 * free / per_traj)
         return max(1, min(remaining, AUTO_BATCH_MAX, fit))
 
-    def _run_growing(self, chunk, chi, chi_top, initial_state, mpo, make_batch, device, cols, n_obs, keep_last):
-        """One chunk of trajectories with storage grown on demand.  A piece that runs out of capacity at time step j hands its
-        states (rolled back to the start of j) to engines of twice the capacity - several smaller ones when the memory asks for
-        it - which continue from j; only a clip before the first full step starts the piece again from the initial state.
+    def _run_growing(self, chunk, chi, chi_top, length, mpo, make_batch, run_piece, device, cols, n_obs, keep_last=False):
+        """One chunk of trajectories with storage grown on demand.  A piece that runs out of capacity at time step (gate layer) j
+        hands its states, rolled back to the start of j, to engines of twice the capacity - several smaller ones when the memory
+        asks for it - which continue from j; only a clip before the first full step starts the piece again from the initial state.
+        ``run_piece(batch, lo, hi, resume)`` runs trajectories chunk[lo:hi] on ``batch`` (made by ``make_batch(engine)``).
         Returns (results, diagnostics, engine holding trajectory chunk[0] if ``keep_last``)."""
         res = np.zeros((len(chunk), n_obs, cols))
         dg = np.zeros((len(chunk), 3, cols))
-        # (lo, hi, source engine or None, first source slot, (step, phase), rng cursors, capacity)
-        pending = [(0, len(chunk), None, 0, (0, 0), None, chi)]
+        # (lo, hi, source engine or None, first source slot, (step, phase), rng cursors, extra, capacity)
+        pending = [(0, len(chunk), None, 0, (0, 0), None, None, chi)]
         kept = None
         while pending:
-            lo, hi, src, first, start, pos, cap_now = pending.pop()
-            fit = self._batch_for(hi - lo, initial_state.length, cap_now, mpo, device)
+            lo, hi, src, first, start, pos, extra, cap_now = pending.pop()
+            fit = self._batch_for(hi - lo, length, cap_now, mpo, device)
             if fit < hi - lo:  # the larger engine holds fewer trajectories: the rest of the piece waits
-                pending.append((lo + fit, hi, src, first + fit, start, None if pos is None else pos[fit:], cap_now))
+                pending.append((lo + fit, hi, src, first + fit, start, None if pos is None else pos[fit:], extra, cap_now))
                 hi = lo + fit
                 pos = None if pos is None else pos[:fit]
-            engine = BatchEngine(initial_state.length, cap_now, hi - lo, mpo, device=device)
-            tb = make_batch(engine)
+            engine = BatchEngine(length, cap_now, hi - lo, mpo, device=device)
+            batch = make_batch(engine)
             try:
-                if src is None:
-                    r, d_ = tb.run(chunk[lo:hi], initial_state, native=self.native)
-                else:
+                resume = None
+                if src is not None:
                     engine.adopt(src, first)
-                    r, d_ = tb.run(chunk[lo:hi], None, native=True,
-                                   resume=dict(start=start, rng_pos=pos, results=np.ascontiguousarray(res[lo:hi]), diagnostics=np.ascontiguousarray(dg[lo:hi])))
-                res[lo:hi], dg[lo:hi] = r, d_
+                    resume = dict(start=start, rng_pos=pos, extra=extra, results=np.ascontiguousarray(res[lo:hi]), diagnostics=np.ascontiguousarray(dg[lo:hi]))
+                res[lo:hi], dg[lo:hi] = run_piece(batch, lo, hi, resume)
             except CapacityError as err:
                 bigger = grown_capacity(cap_now, chi_top)
                 if err.resume is not None and err.resume[0] > 0:
                     res[lo:hi], dg[lo:hi] = err.results, err.diagnostics  # the columns measured so far
-                    pending.append((lo, hi, engine, 0, err.resume, err.rng_pos, bigger))
+                    pending.append((lo, hi, engine, 0, err.resume, err.rng_pos, getattr(err, "extra", None), bigger))
                     engine = None  # stays alive as the source of its successors
                 else:
-                    pending.append((lo, hi, None, 0, (0, 0), None, bigger))
+                    pending.append((lo, hi, None, 0, (0, 0), None, None, bigger))
             if src is not None and not any(q[2] is src for q in pending):
                 src.close()
             if engine is not None:
@@ -510,8 +525,14 @@ class Simulator:
                     tb.set_intervals(pieces)
                 return tb
 
+            def run_piece(tb, lo_, hi_, resume, chunk=chunk):
+                if resume is None:
+                    return tb.run(chunk[lo_:hi_], initial_state, native=self.native)
+                return tb.run(chunk[lo_:hi_], None, native=True, resume=resume)
+
             keep = sim_params.get_state and 0 in chunk
-            r, dg, last = self._run_growing(chunk, chi, chi_top, initial_state, hamiltonian.tensors, make_batch, device, cols, n_obs, keep)
+            r, dg, last = self._run_growing(chunk, chi, chi_top, initial_state.length, hamiltonian.tensors, make_batch, run_piece, device, cols,
+                                            n_obs, keep)
             res_all[done: done + len(chunk)] = r
             diag_all[done: done + len(chunk)] = dg
             done += len(chunk)
@@ -546,29 +567,23 @@ class Simulator:
         counts: dict[int, int] = {}
         wants_shots = sim_params.shots is not None
         identity_mpo = [np.eye(2, dtype=np.complex128).reshape(2, 2, 1, 1)] * initial_state.length  # the circuit path never applies it
-        done, engine = 0, None
+        done = 0
         while done < num_traj:
             B = self._batch_for(num_traj - done, initial_state.length, chi, identity_mpo, device)
             chunk = list(range(done, min(done + B, num_traj)))
-            if engine is None or engine.B != len(chunk) or engine.chi_max != chi:
-                if engine is not None:
-                    engine.close()
-                engine = BatchEngine(initial_state.length, chi, len(chunk), identity_mpo, device=device)
-            db = DigitalBatch(engine, sim_params, noise_model if noisy else None)
             spt = [shots_for_trajectory(t, per_call, distribution) for t in chunk] if wants_shots else None
-            try:
-                r, dg = db.run(chunk, initial_state, layers, shots_per_traj=spt, basis=basis)
-            except CapacityError:
-                chi = grown_capacity(chi, chi_top)
-                continue
+
+            def run_piece(db, lo_, hi_, resume, chunk=chunk, spt=spt):
+                out = db.run(chunk[lo_:hi_], initial_state, layers, shots_per_traj=None if spt is None else spt[lo_:hi_], basis=basis, resume=resume)
+                for k, v in (db.counts or {}).items():
+                    counts[k] = counts.get(k, 0) + v
+                return out
+
+            r, dg, _ = self._run_growing(chunk, chi, chi_top, initial_state.length, identity_mpo, lambda eng: DigitalBatch(eng, sim_params, noise_model if noisy else None),
+                                         run_piece, device, cols, len(sim_params.observables))
             res_all[done: done + len(chunk)] = r
             diag_all[done: done + len(chunk)] = dg
-            if db.counts:
-                for k, v in db.counts.items():
-                    counts[k] = counts.get(k, 0) + v
             done += len(chunk)
-        if engine is not None:
-            engine.close()
         return CircuitResult(sim_params, res_all, diag_all, counts if wants_shots else None)
 
 
