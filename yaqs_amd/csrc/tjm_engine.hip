@@ -153,7 +153,7 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   opidx_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   jsite_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   overflow_ = reinterpret_cast<int*>(take(256));
-  TJM_HIP_CHECK(hipMemsetAsync(overflow_, 0, sizeof(int), s));
+  TJM_HIP_CHECK(hipMemsetAsync(overflow_, 0, 2 * sizeof(int), s));
   E_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
   E2_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
   M_ = reinterpret_cast<cplx*>(take((size_t)L * B * d * d * sizeof(cplx)));
@@ -535,10 +535,11 @@ __global__ void nloc_kernel(const int* chi, int stride, int bl, int br, int P, i
 // those of a run with max_bond_dim = chi_max rather than the requested one; the caller re-runs with a larger engine.
 int Engine::capacity_overflow(int* host_flag, bool clear) {
   if (!bound_) return TJM_ERR_STATE;
-  TJM_HIP_CHECK(hipMemcpyAsync(h_pinned_ + 8, overflow_, sizeof(int), hipMemcpyDeviceToHost, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(h_pinned_ + 8, overflow_, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
   if (clear) TJM_HIP_CHECK(hipMemsetAsync(overflow_, 0, sizeof(int), stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
   *host_flag = h_pinned_[8];
+  if (h_pinned_[9] != 0) return TJM_ERR_NUMERIC;  // a fused small-bond factorisation did not converge (sticky)
   return TJM_OK;
 }
 
@@ -792,6 +793,15 @@ int Engine::tdvp(int set) {
 int Engine::svd_shift_right(StateSet& S, int i, const int* ids, int nb0) {
   const int ca = cap[i], cb = cap[i + 1], cc = cap[i + 2];
   int rc;
+  if (svd_shift_small_fits(d, ca, cb, false)) {  // small bonds: factorisation, truncation and absorption in one kernel
+    SmallShiftDesc q;
+    q.site = S.A[i]; q.site_b0 = a_b0_[i]; q.nb = S.A[i + 1]; q.nb_b0 = a_b0_[i + 1];
+    q.d = d; q.ca = ca; q.cb = cb; q.cn = cc;
+    q.chi = S.chi + i; q.chi_stride = L + 1; q.threshold = 1e-12; q.min_keep = 1;
+    q.ids = ids; q.nb0 = nb0; q.flags = overflow_;
+    ++stat_svds;
+    return launch_svd_shift_small(q, false, stream);
+  }
   JacobiSource src;
   src.src = S.A[i]; src.src_b0 = a_b0_[i]; src.rx = d * ca; src.ncols = cb; src.conj = 0; src.tri = 0;
   src.r_n0 = ca; src.s_r1 = (long)ca * cb; src.s_r0 = cb; src.c_n0 = cb; src.s_c1 = 0; src.s_c0 = 1;
@@ -835,6 +845,15 @@ int Engine::svd_shift_right(StateSet& S, int i, const int* ids, int nb0) {
 int Engine::svd_shift_left(StateSet& S, int i, const int* ids, int nb0) {
   const int cz = cap[i - 1], ca = cap[i], cb = cap[i + 1];
   int rc;
+  if (svd_shift_small_fits(d, ca, cb, true)) {
+    SmallShiftDesc q;
+    q.site = S.A[i]; q.site_b0 = a_b0_[i]; q.nb = S.A[i - 1]; q.nb_b0 = a_b0_[i - 1];
+    q.d = d; q.ca = ca; q.cb = cb; q.cn = cz;
+    q.chi = S.chi + i; q.chi_stride = L + 1; q.threshold = 1e-12; q.min_keep = 1;
+    q.ids = ids; q.nb0 = nb0; q.flags = overflow_;
+    ++stat_svds;
+    return launch_svd_shift_small(q, true, stream);
+  }
   JacobiSource src;  // X = M^H : rows (t,c), columns a
   src.src = S.A[i]; src.src_b0 = a_b0_[i]; src.rx = d * cb; src.ncols = ca; src.conj = 1; src.tri = 0;
   src.r_n0 = cb; src.s_r1 = (long)ca * cb; src.s_r0 = 1; src.c_n0 = ca; src.s_c1 = 0; src.s_c0 = cb;

@@ -125,6 +125,19 @@ struct TruncSpec {
   int spec_ld;
 };
 struct JacobiShape { int ncols_pad, rx_top, rtot; };
+// Centre shift of one site with small bonds, everything in one kernel (svd_shift_small_kernel): the site tensor [d][ca][cb] is
+// factorised, the isometric factor replaces it and the weighted factor is multiplied into the neighbour.
+struct SmallShiftDesc {
+  cplx* site; long site_b0;   // A_i  [d][ca][cb]
+  cplx* nb;   long nb_b0;     // right shift: A_{i+1} [d][cb][cn];  left shift: A_{i-1} [d][cn][ca]
+  int d, ca, cb, cn;
+  int* chi; int chi_stride;   // chi[b * stride + 0] = left bond of the site, [+1] = right bond
+  double threshold; int min_keep;
+  const int* ids; int nb0;
+  int* flags;                 // flags[1] |= 1 when the Jacobi iteration did not converge
+};
+int launch_svd_shift_small(const SmallShiftDesc& p, bool left, hipStream_t s);
+bool svd_shift_small_fits(int d, int ca, int cb, bool left);
 // out[b][k*o_k + r1*o_r1 + r0*o_r0] = scale_k * op(Ycol[perm[k]][row_off + r1*n_r0 + r0]) for k < keep, 0 for keep <= k < n_k
 // scale_mode: 0 none, 1 multiply by sigma_k, 2 divide by sigma_k
 struct ExtractDesc {

@@ -779,6 +779,178 @@ __global__ void svd_reset_kernel(int* nrot, int* done, int nb0, const int* ids) 
   done[b] = 0;
 }
 
+// ---- small bonds: the whole centre shift in one kernel -------------------------------------------
+// One wavefront per trajectory, lane = row of the matrix being orthogonalised (at most 64 rows, 16 columns), columns in LDS.
+// Right shift: X = A_i as (d ca) x cb;  left shift: X = A_i^H as (d cb) x ca.  One-sided Jacobi over the ACTUAL columns
+// (the bond dimension of this trajectory, not the padded capacity), cyclic by rows, the rotation rule of the large kernels;
+// then norms, rank sort and the discarded-weight truncation of svd_finish_kernel; the isometric factor is the set of
+// normalised columns, the weighted factor is its overlap with the input (accumulation-free, as in the large path) and goes
+// straight into the neighbouring tensor.  Replaces ~12 launches and one host synchronisation per sweep.
+constexpr int SMALL_MAXN = 16;
+
+template <bool LEFT>
+__global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p) {
+  __shared__ cplx Y[SMALL_MAXN][64];
+  __shared__ cplx G[SMALL_MAXN][SMALL_MAXN];
+  __shared__ double sNorm[SMALL_MAXN];
+  __shared__ int sPerm[SMALL_MAXN];
+  __shared__ int sKeep;
+  int b = blockIdx.x;
+  if (p.ids) b = p.ids[b];
+  const int lane = threadIdx.x;
+  const int d = p.d, ca = p.ca, cb = p.cb;
+  cplx* __restrict__ A = p.site + (long)b * p.site_b0;
+  int* chi = p.chi + (long)b * p.chi_stride;
+  const int chiL = chi[0], chiR = chi[1];
+  const int R = LEFT ? d * cb : d * ca;       // rows of X (padded extents: rows beyond the actual bond are zero)
+  const int n = LEFT ? chiL : chiR;           // actual columns
+  const int ncap = LEFT ? ca : cb;            // padded columns
+  int nsv = LEFT ? min(chiL, d * chiR) : min(d * chiL, chiR);
+  if (nsv > n) nsv = n;
+  // element (row r, column j) of X inside the site tensor
+  auto site_index = [&](int r, int j) -> long {
+    if (LEFT) { const int t = r / cb, c = r - t * cb; return ((long)t * ca + j) * cb + c; }
+    return (long)r * cb + j;
+  };
+  double fro = 0.0;
+  for (int j = 0; j < n; ++j) {
+    cplx v{0.0, 0.0};
+    if (lane < R) {
+      v = A[site_index(lane, j)];
+      if (LEFT) v.y = -v.y;
+    }
+    Y[j][lane] = v;
+    fro = fma(v.x, v.x, fma(v.y, v.y, fro));
+  }
+  fro = wave_sum(fro);
+  const double floor2 = 1e-26 * fro;
+  __syncthreads();
+  bool converged = n < 2;
+  for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
+    int cnt = 0;
+    for (int pc = 0; pc + 1 < n; ++pc)
+      for (int qc = pc + 1; qc < n; ++qc) {
+        cplx yp = Y[pc][lane], yq = Y[qc][lane];
+        const double a = wave_sum(fma(yp.x, yp.x, yp.y * yp.y));
+        const double dd = wave_sum(fma(yq.x, yq.x, yq.y * yq.y));
+        const double gx = wave_sum(fma(yp.x, yq.x, yp.y * yq.y));
+        const double gy = wave_sum(fma(yp.x, yq.y, -yp.y * yq.x));
+        double c, sr, si, tg;
+        if (make_rotation(a, dd, gx, gy, 1e-26, floor2, c, sr, si, tg)) {
+          rotate_pair(yp, yq, c, sr, si);
+          Y[pc][lane] = yp;
+          Y[qc][lane] = yq;
+          ++cnt;
+        }
+        __syncthreads();
+      }
+    converged = cnt == 0;
+  }
+  if (!converged && lane == 0 && p.flags) atomicOr(p.flags + 1, 1);
+  // norms, descending rank sort (ties by index), truncation
+  for (int j = 0; j < n; ++j) {
+    const cplx v = Y[j][lane];
+    const double s2 = wave_sum(fma(v.x, v.x, v.y * v.y));
+    if (lane == 0) sNorm[j] = s2;
+  }
+  __syncthreads();
+  if (lane < n) {
+    const double v = sNorm[lane];
+    int rank = 0;
+    for (int o = 0; o < n; ++o) {
+      const double u = sNorm[o];
+      rank += (u > v || (u == v && o < lane)) ? 1 : 0;
+    }
+    sPerm[rank] = lane;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int keep = 0;
+    if (nsv > 0) {
+      keep = nsv;
+      double discard = 0.0;
+      for (int idx = 0; idx < nsv; ++idx) {
+        const double s = sqrt(sNorm[sPerm[nsv - 1 - idx]]);
+        discard += s * s;
+        if (discard >= p.threshold) {
+          keep = nsv - idx;
+          if (keep < p.min_keep) keep = p.min_keep;
+          break;
+        }
+      }
+      if (keep < p.min_keep) keep = p.min_keep;
+      if (keep > nsv) keep = nsv;
+    }
+    sKeep = keep;
+    chi[LEFT ? 0 : 1] = keep;
+  }
+  __syncthreads();
+  const int keep = sKeep;
+  // weighted factor from the untouched input:  right: G[k][j] = sum_r conj(U[r][k]) X0[r][j]   (= S V^H)
+  //                                            left:  G[j][k] = sum_r conj(X0[r][j]) V[r][k]   (= U S), stored as G[k][j] too
+  for (int e = lane; e < keep * n; e += 64) {
+    const int k = e / n, j = e - k * n;
+    const int col = sPerm[k];
+    const double inv = 1.0 / sqrt(sNorm[col]);
+    double ax = 0.0, ay = 0.0;
+    for (int r = 0; r < R; ++r) {
+      const cplx u = Y[col][r];
+      cplx x = A[site_index(r, j)];
+      if (LEFT) x.y = -x.y;
+      if (LEFT) {  // conj(x) * u
+        ax = fma(x.x, u.x, fma(x.y, u.y, ax));
+        ay = fma(x.x, u.y, fma(-x.y, u.x, ay));
+      } else {     // conj(u) * x
+        ax = fma(u.x, x.x, fma(u.y, x.y, ax));
+        ay = fma(u.x, x.y, fma(-u.y, x.x, ay));
+      }
+    }
+    G[k][j] = cplx{ax * inv, ay * inv};
+  }
+  __syncthreads();
+  // isometric factor into the site tensor (zero beyond keep, all padded columns written)
+  if (lane < R) {
+    for (int k = 0; k < ncap; ++k) {
+      cplx v{0.0, 0.0};
+      if (k < keep) {
+        const int col = sPerm[k];
+        const double inv = 1.0 / sqrt(sNorm[col]);
+        v = Y[col][lane];
+        v.x *= inv;
+        v.y *= LEFT ? -inv : inv;
+      }
+      A[site_index(lane, k)] = v;
+    }
+  }
+  // neighbour: right shift  N[t][k][c] = sum_j G[k][j] N[t][j][c]   (rows j of the bond being replaced)
+  //            left shift   N[s][z][k] = sum_j N[s][z][j] G[k][j]   (columns j)
+  cplx* __restrict__ Nb = p.nb + (long)b * p.nb_b0;
+  const int cn = p.cn;
+  const int lines = d * cn;  // independent lines of the neighbour, each of ncap entries along the bond
+  for (int line = lane; line < lines; line += 64) {
+    cplx old[SMALL_MAXN];
+    long base, stride;
+    if (LEFT) { base = (long)line * ca; stride = 1; }                                         // line = (s, z)
+    else { const int t = line / cn, c = line - t * cn; base = (long)t * cb * cn + c; stride = cn; }  // line = (t, c)
+#pragma unroll
+    for (int j = 0; j < SMALL_MAXN; ++j) old[j] = (j < n) ? Nb[base + j * stride] : cplx{0.0, 0.0};
+    for (int k = 0; k < ncap; ++k) {
+      double ax = 0.0, ay = 0.0;
+      if (k < keep) {
+#pragma unroll
+        for (int j = 0; j < SMALL_MAXN; ++j) {
+          if (j < n) {
+            const cplx g = G[k][j];
+            ax = fma(g.x, old[j].x, fma(-g.y, old[j].y, ax));
+            ay = fma(g.x, old[j].y, fma(g.y, old[j].x, ay));
+          }
+        }
+      }
+      Nb[base + k * stride] = cplx{ax, ay};
+    }
+  }
+}
+
 // Column norms of the X part, descending rank sort, truncation (svd_utils.py:22-104).
 __global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspace w, int ncols_pad, int rx, int rtot, const int* ids) {
   __shared__ double sN[512];
@@ -936,6 +1108,22 @@ void prof_collect() {
 }
 
 }  // namespace
+
+bool svd_shift_small_fits(int d, int ca, int cb, bool left) {
+  static const bool off = getenv("TJM_NO_SMALL_SHIFT") != nullptr;
+  if (off) return false;
+  const int rows = left ? d * cb : d * ca, cols = left ? ca : cb;
+  return rows <= 64 && cols <= SMALL_MAXN;
+}
+
+int launch_svd_shift_small(const SmallShiftDesc& p, bool left, hipStream_t s) {
+  if (p.nb0 <= 0) return TJM_OK;
+  if (left) hipLaunchKernelGGL(svd_shift_small_kernel<true>, dim3(p.nb0), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(svd_shift_small_kernel<false>, dim3(p.nb0), dim3(64), 0, s, p);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
 
 void profile_enable(int every) {
   g_prof.every = every;

@@ -596,7 +596,7 @@ def _encoded(state: MPS) -> MPS:
 
 MAX_CHI = 256   # largest bond the register-resident Jacobi SVD holds (d * chi <= 512)
 START_CHI = 8   # first storage capacity tried when the requested cap is larger
-AUTO_BATCH_MAX = 4096  # trajectories in flight when Simulator(batch=None) sizes the batch itself
+AUTO_BATCH_MAX = 16384  # trajectories in flight when Simulator(batch=None) sizes the batch itself
 
 
 def engine_bond_caps(sim_params, initial_state) -> tuple[int, int]:
