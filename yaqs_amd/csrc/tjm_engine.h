@@ -127,7 +127,8 @@ class Engine {
                   long o0, long o1, long o2, int nb0, const int* ids);
   int bond_apply(const cplx* x, int cu, int cv, const cplx* Lenv, long l_b0, const cplx* Renv, long r_b0, int D, cplx* y, const int* active);
   int sweep_1site(StateSet& S, double scale);
-  int qr_site(StateSet& S, int i, bool right, const int* ids = nullptr, int nb0 = -1);   // A_i = Q C (right) or A_i = C^T Q (left); C into Cm_
+  int qr_site(StateSet& S, int i, bool right, const int* ids = nullptr, int nb0 = -1, bool absorb = false);  // absorb: also multiply C into the neighbour (small bonds only)
+    // A_i = Q C (right) or A_i = C^T Q (left); C into Cm_
   int two_site_op(StateSet& S, int i, const cplx* dev_ops, const int* op_index, const int* ids, int nb0, int min_keep);
   int qr_shift_right(StateSet& S, int i, const int* ids = nullptr, int nb0 = -1);
   int qr_shift_left(StateSet& S, int i);

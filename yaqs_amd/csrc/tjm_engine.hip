@@ -673,9 +673,20 @@ __global__ void qr_bond_dims_kernel(int* chi, int stride, int i, int d, int righ
 
 // A_i = Q C with Q left-isometric (right = true, integrators.py:98-101) or A_i = C^T Q with Q right-isometric
 // (right = false, integrators.py:128-136).  Householder QR; the bond matrix lands in Cm_ ([u][v] order of project_bond).
-int Engine::qr_site(StateSet& S, int i, bool right, const int* ids, int nb0) {
+int Engine::qr_site(StateSet& S, int i, bool right, const int* ids, int nb0, bool absorb) {
   if (nb0 < 0) nb0 = B;
   const int ca = cap[i], cb = cap[i + 1];
+  if (svd_shift_small_fits(d, ca, cb, !right)) {  // small bonds: factorisation, bond matrix, bond rule (and the shift) in one kernel
+    SmallQrDesc q;
+    q.site = S.A[i]; q.site_b0 = a_b0_[i]; q.bond = Cm_; q.nb = nullptr; q.nb_b0 = 0; q.cn = 0;
+    if (absorb) {
+      const int j = right ? i + 1 : i - 1;
+      q.nb = S.A[j]; q.nb_b0 = a_b0_[j]; q.cn = right ? cap[i + 2] : cap[i - 1];
+    }
+    q.d = d; q.ca = ca; q.cb = cb;
+    q.chi = S.chi + i; q.chi_stride = L + 1; q.nloc = nloc_; q.ids = ids; q.nb0 = nb0;
+    return launch_qr_site_small(q, right, stream);
+  }
   const int zr = right ? d * ca : d * cb;
   const int zc = right ? cb : ca;
   const int kmax = std::min(zr, zc);
@@ -943,6 +954,7 @@ int Engine::qr_shift_right(StateSet& S, int i, const int* ids, int nb0) {
   if (nb0 < 0) nb0 = B;
   const int cb = cap[i + 1], cc = cap[i + 2];
   int rc;
+  if (svd_shift_small_fits(d, cap[i], cb, false)) return qr_site(S, i, true, ids, nb0, true);
   if ((rc = qr_site(S, i, true, ids, nb0)) != TJM_OK) return rc;
   GemmDesc g = blank_gemm();  // T1[p][l][r] = C[l][x] A_{i+1}[p][x][r]
   g.A = Cm_; g.B = S.A[i + 1]; g.C = T1;
@@ -957,6 +969,7 @@ int Engine::qr_shift_right(StateSet& S, int i, const int* ids, int nb0) {
 int Engine::qr_shift_left(StateSet& S, int i) {
   const int cz = cap[i - 1], ca = cap[i];
   int rc;
+  if (svd_shift_small_fits(d, ca, cap[i + 1], true)) return qr_site(S, i, false, nullptr, B, true);
   if ((rc = qr_site(S, i, false)) != TJM_OK) return rc;
   GemmDesc g = blank_gemm();  // T1[(p,l)][r] = A_{i-1}[(p,l)][x] C^T[x][r]
   g.A = S.A[i - 1]; g.B = Cm_; g.C = T1;

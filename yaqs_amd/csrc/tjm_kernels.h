@@ -137,6 +137,18 @@ struct SmallShiftDesc {
   int* flags;                 // flags[1] |= 1 when the Jacobi iteration did not converge
 };
 int launch_svd_shift_small(const SmallShiftDesc& p, bool left, hipStream_t s);
+// Householder QR of one site with small bonds in one kernel (qr_site_small_kernel): A_i <- Q, R into the padded bond matrix
+// `bond` ([cap][cap], may be null) and, when `nb` is given, multiplied into the neighbour (the QR centre shift).
+struct SmallQrDesc {
+  cplx* site; long site_b0;   // A_i [d][ca][cb]
+  cplx* bond;                 // [B][cap][cap] with cap = cb (right) or ca (left); right: C[k][j] = R[k][j], left: C[j][k] = R[k][j]
+  cplx* nb;   long nb_b0;     // right: A_{i+1} [d][cb][cn]; left: A_{i-1} [d][cn][ca]
+  int d, ca, cb, cn;
+  int* chi; int chi_stride;   // chi[0] = left bond of the site, chi[1] = right bond
+  int* nloc;                  // [B] size of the bond problem (may be null)
+  const int* ids; int nb0;
+};
+int launch_qr_site_small(const SmallQrDesc& p, bool right, hipStream_t s);
 bool svd_shift_small_fits(int d, int ca, int cb, bool left);
 // out[b][k*o_k + r1*o_r1 + r0*o_r0] = scale_k * op(Ycol[perm[k]][row_off + r1*n_r0 + r0]) for k < keep, 0 for keep <= k < n_k
 // scale_mode: 0 none, 1 multiply by sigma_k, 2 divide by sigma_k

@@ -779,6 +779,8 @@ __global__ void svd_reset_kernel(int* nrot, int* done, int nb0, const int* ids) 
   done[b] = 0;
 }
 
+constexpr int SMALL_MAXN = 16;
+
 // ---- small bonds: the whole centre shift in one kernel -------------------------------------------
 // One wavefront per trajectory, lane = row of the matrix being orthogonalised (at most 64 rows, 16 columns), columns in LDS.
 // Right shift: X = A_i as (d ca) x cb;  left shift: X = A_i^H as (d cb) x ca.  One-sided Jacobi over the ACTUAL columns
@@ -786,7 +788,36 @@ __global__ void svd_reset_kernel(int* nrot, int* done, int nb0, const int* ids) 
 // then norms, rank sort and the discarded-weight truncation of svd_finish_kernel; the isometric factor is the set of
 // normalised columns, the weighted factor is its overlap with the input (accumulation-free, as in the large path) and goes
 // straight into the neighbouring tensor.  Replaces ~12 launches and one host synchronisation per sweep.
-constexpr int SMALL_MAXN = 16;
+// Neighbour update shared by the fused small-bond kernels.  G[k][j] (k < keep new, j < n old) is the weighted factor.
+//   right shift (LEFT = false):  N[t][k][c] = sum_j G[k][j] N[t][j][c]   neighbour A_{i+1} [d][cb][cn], bond = its rows
+//   left shift  (LEFT = true):   N[s][z][k] = sum_j N[s][z][j] G[k][j]   neighbour A_{i-1} [d][cn][ca], bond = its columns
+template <bool LEFT>
+__device__ inline void small_absorb(cplx* __restrict__ Nb, const cplx (*G)[SMALL_MAXN], int d, int ca, int cb, int cn, int n, int keep, int ncap,
+                                    int lane) {
+  const int lines = d * cn;  // independent lines of the neighbour, each of ncap entries along the bond
+  for (int line = lane; line < lines; line += 64) {
+    cplx old[SMALL_MAXN];
+    long base, stride;
+    if (LEFT) { base = (long)line * ca; stride = 1; }                                                // line = (s, z)
+    else { const int t = line / cn, c = line - t * cn; base = (long)t * cb * cn + c; stride = cn; }  // line = (t, c)
+#pragma unroll
+    for (int j = 0; j < SMALL_MAXN; ++j) old[j] = (j < n) ? Nb[base + j * stride] : cplx{0.0, 0.0};
+    for (int k = 0; k < ncap; ++k) {
+      double ax = 0.0, ay = 0.0;
+      if (k < keep) {
+#pragma unroll
+        for (int j = 0; j < SMALL_MAXN; ++j) {
+          if (j < n) {
+            const cplx g = G[k][j];
+            ax = fma(g.x, old[j].x, fma(-g.y, old[j].y, ax));
+            ay = fma(g.x, old[j].y, fma(g.y, old[j].x, ay));
+          }
+        }
+      }
+      Nb[base + k * stride] = cplx{ax, ay};
+    }
+  }
+}
 
 template <bool LEFT>
 __global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p) {
@@ -922,33 +953,104 @@ __global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p) {
       A[site_index(lane, k)] = v;
     }
   }
-  // neighbour: right shift  N[t][k][c] = sum_j G[k][j] N[t][j][c]   (rows j of the bond being replaced)
-  //            left shift   N[s][z][k] = sum_j N[s][z][j] G[k][j]   (columns j)
-  cplx* __restrict__ Nb = p.nb + (long)b * p.nb_b0;
-  const int cn = p.cn;
-  const int lines = d * cn;  // independent lines of the neighbour, each of ncap entries along the bond
-  for (int line = lane; line < lines; line += 64) {
-    cplx old[SMALL_MAXN];
-    long base, stride;
-    if (LEFT) { base = (long)line * ca; stride = 1; }                                         // line = (s, z)
-    else { const int t = line / cn, c = line - t * cn; base = (long)t * cb * cn + c; stride = cn; }  // line = (t, c)
-#pragma unroll
-    for (int j = 0; j < SMALL_MAXN; ++j) old[j] = (j < n) ? Nb[base + j * stride] : cplx{0.0, 0.0};
-    for (int k = 0; k < ncap; ++k) {
-      double ax = 0.0, ay = 0.0;
-      if (k < keep) {
-#pragma unroll
-        for (int j = 0; j < SMALL_MAXN; ++j) {
-          if (j < n) {
-            const cplx g = G[k][j];
-            ax = fma(g.x, old[j].x, fma(-g.y, old[j].y, ax));
-            ay = fma(g.x, old[j].y, fma(g.y, old[j].x, ay));
-          }
-        }
+  small_absorb<LEFT>(p.nb + (long)b * p.nb_b0, G, d, ca, cb, p.cn, n, keep, ncap, lane);
+}
+
+// ---- small bonds: Householder QR of one site in one kernel ---------------------------------------
+// qr_site for d*cap <= 64 rows and cap <= 16 columns: rows in bond-major order (bond, p) so that the actual rows are the leading
+// lanes and padded rows stay exactly zero; reflectors v_k = x - alpha e_k (alpha = -e^{i arg x_k} |x|, H_k Hermitian) kept in
+// place below the diagonal; R into the bond matrix Cm (and, for the shifts, straight into the neighbour); Q = H_0 ... H_{k-1}
+// applied to unit vectors.  Thin-QR bond rule k = min(rows, columns) of np.linalg.qr as in qr_bond_dims_kernel.
+template <bool RIGHT>
+__global__ __launch_bounds__(64) void qr_site_small_kernel(SmallQrDesc p) {
+  __shared__ cplx Z[SMALL_MAXN][64];
+  __shared__ cplx G[SMALL_MAXN][SMALL_MAXN];
+  __shared__ cplx sDiag[SMALL_MAXN];
+  __shared__ double sBeta[SMALL_MAXN];
+  int b = blockIdx.x;
+  if (p.ids) b = p.ids[b];
+  const int lane = threadIdx.x;
+  const int d = p.d, ca = p.ca, cb = p.cb;
+  cplx* __restrict__ A = p.site + (long)b * p.site_b0;
+  int* chi = p.chi + (long)b * p.chi_stride;
+  const int chiL = chi[0], chiR = chi[1];
+  const int R = RIGHT ? d * ca : d * cb;
+  const int rows_act = RIGHT ? d * chiL : d * chiR;
+  const int n = RIGHT ? chiR : chiL;
+  const int ncap = RIGHT ? cb : ca;
+  const int kn = min(rows_act, n);
+  const int bond = lane / d, ph = lane - bond * d;
+  auto site_index = [&](int col) -> long { return RIGHT ? ((long)ph * ca + bond) * cb + col : ((long)ph * ca + col) * cb + bond; };
+  for (int j = 0; j < n; ++j) Z[j][lane] = (lane < rows_act) ? A[site_index(j)] : cplx{0.0, 0.0};
+  for (int e = lane; e < SMALL_MAXN * SMALL_MAXN; e += 64) G[e / SMALL_MAXN][e % SMALL_MAXN] = cplx{0.0, 0.0};
+  __syncthreads();
+  for (int k = 0; k < kn; ++k) {
+    const bool in = lane >= k && lane < rows_act;
+    cplx x = in ? Z[k][lane] : cplx{0.0, 0.0};
+    const double nx2 = wave_sum(fma(x.x, x.x, x.y * x.y));
+    if (nx2 == 0.0) {  // nothing below the diagonal and a zero pivot: H_k = 1
+      if (lane == 0) { sDiag[k] = cplx{0.0, 0.0}; sBeta[k] = 0.0; }
+      __syncthreads();
+      continue;
+    }
+    const cplx xk = Z[k][k];
+    const double nx = sqrt(nx2), ak = sqrt(fma(xk.x, xk.x, xk.y * xk.y));
+    const double px = ak > 0.0 ? xk.x / ak : 1.0, py = ak > 0.0 ? xk.y / ak : 0.0;
+    const cplx alpha{-px * nx, -py * nx};
+    const double beta = 1.0 / (nx * (nx + ak));  // 2 / |v|^2
+    if (lane == k) { x.x -= alpha.x; x.y -= alpha.y; }
+    __syncthreads();  // every lane has read Z[k][k]
+    if (in) Z[k][lane] = x;
+    if (lane == 0) { sDiag[k] = alpha; sBeta[k] = beta; }
+    for (int j = k + 1; j < n; ++j) {
+      cplx y = in ? Z[j][lane] : cplx{0.0, 0.0};
+      const double wr = beta * wave_sum(fma(x.x, y.x, x.y * y.y));   // beta * conj(v) . y
+      const double wi = beta * wave_sum(fma(x.x, y.y, -x.y * y.x));
+      if (in) {
+        y.x -= wr * x.x - wi * x.y;
+        y.y -= wr * x.y + wi * x.x;
+        Z[j][lane] = y;
       }
-      Nb[base + k * stride] = cplx{ax, ay};
+    }
+    __syncthreads();
+  }
+  // R (kn x n, upper trapezoidal): G[k][j], and the padded bond matrix
+  for (int e = lane; e < kn * n; e += 64) {
+    const int k = e / n, j = e - k * n;
+    if (j >= k) G[k][j] = (j == k) ? sDiag[k] : Z[j][k];
+  }
+  __syncthreads();
+  if (p.bond) {
+    cplx* Cb = p.bond + (long)b * ncap * ncap;
+    for (int e = lane; e < ncap * ncap; e += 64) {
+      const int r = e / ncap, c = e - r * ncap;
+      const int k = RIGHT ? r : c, j = RIGHT ? c : r;
+      Cb[e] = (k < kn && j < n) ? G[k][j] : cplx{0.0, 0.0};
     }
   }
+  if (lane == 0) {
+    if (p.nloc) p.nloc[b] = RIGHT ? kn * chiR : chiL * kn;
+    chi[RIGHT ? 1 : 0] = kn;
+  }
+  // Q columns: H_0 ... H_c e_c
+  for (int c = 0; c < ncap; ++c) {
+    cplx q{0.0, 0.0};
+    if (c < kn) {
+      if (lane == c) q.x = 1.0;
+      for (int k = c; k >= 0; --k) {
+        const double beta = sBeta[k];
+        if (beta == 0.0) continue;
+        const bool in = lane >= k && lane < rows_act;
+        const cplx v = in ? Z[k][lane] : cplx{0.0, 0.0};
+        const double wr = beta * wave_sum(fma(v.x, q.x, v.y * q.y));
+        const double wi = beta * wave_sum(fma(v.x, q.y, -v.y * q.x));
+        q.x -= wr * v.x - wi * v.y;
+        q.y -= wr * v.y + wi * v.x;
+      }
+    }
+    if (lane < R) A[site_index(c)] = q;
+  }
+  if (p.nb) small_absorb<!RIGHT>(p.nb + (long)b * p.nb_b0, G, d, ca, cb, p.cn, n, kn, ncap, lane);
 }
 
 // Column norms of the X part, descending rank sort, truncation (svd_utils.py:22-104).
@@ -1114,6 +1216,14 @@ bool svd_shift_small_fits(int d, int ca, int cb, bool left) {
   if (off) return false;
   const int rows = left ? d * cb : d * ca, cols = left ? ca : cb;
   return rows <= 64 && cols <= SMALL_MAXN;
+}
+
+int launch_qr_site_small(const SmallQrDesc& p, bool right, hipStream_t s) {
+  if (p.nb0 <= 0) return TJM_OK;
+  if (right) hipLaunchKernelGGL(qr_site_small_kernel<true>, dim3(p.nb0), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(qr_site_small_kernel<false>, dim3(p.nb0), dim3(64), 0, s, p);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
 }
 
 int launch_svd_shift_small(const SmallShiftDesc& p, bool left, hipStream_t s) {
