@@ -742,6 +742,22 @@ def test_circuit_growth_continues_at_the_clipped_layer(monkeypatch):
     assert sum(res.counts.values()) == 40
 
 
+def test_general_kernels_still_serve_small_bonds():
+    """Bonds up to 16 take the fused one-kernel centre shifts and site QR; with TJM_NO_SMALL_SHIFT the same cases run on the
+    general Jacobi / Householder path (the switch is read once per process, hence the child interpreter)."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, TJM_NO_SMALL_SHIFT="1", TJM_FUZZ_CASES="10")
+    out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_hip_engine.py", "-m", "gpu", "-x", "-q", "-k",
+                          "randomised_configurations or randomised_circuits or tiny_chains"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
 def test_capacity_overflow_is_reported_by_the_engine_and_the_driver():
     """A two-site truncation that wants more values than the new bond stores sets the engine's flag (and only such a one), and
     tjm_engine_run stops after that time step with TJM_ERR_CAPACITY instead of finishing a run that is not the reference's."""
