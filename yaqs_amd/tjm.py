@@ -621,13 +621,16 @@ def engine_bond_caps(sim_params, initial_state) -> tuple[int, int]:
     return max(have, min(top, START_CHI)), top
 
 
+CAPACITY_LADDER = (8, 16, 24, 32, 48, 64, 96, 128, 192, 256)  # steps of x1.5 / x1.33: work grows with chi**3, a re-padding copy is cheap
+
+
 def grown_capacity(chi: int, top: int) -> int:
     if chi >= top:
         raise RuntimeError("a truncation was clipped although the engine holds max_bond_dim")  # cannot happen: svd_finish_kernel
-    new = min(2 * chi, top)
-    if new > MAX_CHI:
+    if chi >= MAX_CHI:
         raise NotImplementedError(f"the run needs bonds beyond {chi}; the HIP path holds chi <= {MAX_CHI}")
-    return new
+    ladder = CAPACITY_LADDER if os.environ.get("TJM_CAPACITY_DOUBLING") is None else (8, 16, 32, 64, 128, 256)
+    return min(next(c for c in ladder if c > chi), top)
 
 
 def engine_bond_cap(sim_params, initial_state) -> int:
