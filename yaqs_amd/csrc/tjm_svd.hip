@@ -788,6 +788,81 @@ constexpr int SMALL_MAXN = 16;
 // then norms, rank sort and the discarded-weight truncation of svd_finish_kernel; the isometric factor is the set of
 // normalised columns, the weighted factor is its overlap with the input (accumulation-free, as in the large path) and goes
 // straight into the neighbouring tensor.  Replaces ~12 launches and one host synchronisation per sweep.
+// Cyclic-by-rows one-sided Jacobi on the n columns Y[j][0..63] held in LDS by ONE wavefront (lane = row), with the rotation rule of
+// the large kernels.  Returns false when 40 sweeps did not converge.
+__device__ inline bool small_jacobi(cplx (*Y)[64], int n, int lane, double floor2) {
+  bool converged = n < 2;
+  for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
+    int cnt = 0;
+    for (int pc = 0; pc + 1 < n; ++pc)
+      for (int qc = pc + 1; qc < n; ++qc) {
+        cplx yp = Y[pc][lane], yq = Y[qc][lane];
+        const double a = wave_sum(fma(yp.x, yp.x, yp.y * yp.y));
+        const double dd = wave_sum(fma(yq.x, yq.x, yq.y * yq.y));
+        const double gx = wave_sum(fma(yp.x, yq.x, yp.y * yq.y));
+        const double gy = wave_sum(fma(yp.x, yq.y, -yp.y * yq.x));
+        double c, sr, si, tg;
+        if (make_rotation(a, dd, gx, gy, 1e-26, floor2, c, sr, si, tg)) {
+          rotate_pair(yp, yq, c, sr, si);
+          Y[pc][lane] = yp;
+          Y[qc][lane] = yq;
+          ++cnt;
+        }
+        __syncthreads();
+      }
+    converged = cnt == 0;
+  }
+  return converged;
+}
+
+// Number of singular values to keep (svd_utils.py:22-104); sv(k) = k-th largest value, nsv = how many exist.
+template <class SV>
+__device__ inline int truncation_keep(const TruncSpec& d, int nsv, SV sv) {
+  int keep = 0;
+  if (nsv <= 0) return 0;
+  if (d.trunc_mode == 2) {  // hard_cutoff
+    for (int k = 0; k < nsv; ++k) keep += (sv(k) > d.threshold) ? 1 : 0;
+  } else if (d.trunc_mode == 1) {  // relative
+    const double smax = sv(0);
+    if (smax > 0.0)
+      for (int k = 0; k < nsv; ++k) keep += ((sv(k) / smax) >= d.threshold) ? 1 : 0;
+  } else if (d.trunc_mode == 0) {  // discarded_weight
+    keep = nsv;
+    double discard = 0.0;
+    for (int idx = 0; idx < nsv; ++idx) {
+      const double s = sv(nsv - 1 - idx);
+      discard += s * s;
+      if (discard >= d.threshold) {
+        keep = nsv - idx;
+        if (keep < d.min_keep) keep = d.min_keep;
+        break;
+      }
+    }
+  } else {  // relative_discarded_weight
+    const double smax = sv(0);
+    if (smax > 0.0) {
+      double total = 0.0;
+      for (int k = 0; k < nsv; ++k) { const double q = sv(k) / smax; total += q * q; }
+      keep = nsv;
+      double discard = 0.0;
+      for (int idx = 0; idx < nsv; ++idx) {
+        const double q = sv(nsv - 1 - idx) / smax;
+        const double cand = discard + q * q;
+        if (cand / total <= d.threshold) { discard = cand; keep = nsv - idx - 1; }
+        else break;
+      }
+    }
+  }
+  if (d.max_bond > 0 && keep > d.max_bond) keep = d.max_bond;
+  if (keep < d.min_keep) keep = d.min_keep;
+  if (keep > nsv) keep = nsv;
+  if (d.cap > 0 && keep > d.cap) {  // the engine's storage is smaller than what the truncation rule asks for
+    keep = d.cap;
+    if (d.overflow) atomicOr(d.overflow, 1);
+  }
+  return keep;
+}
+
 // Neighbour update shared by the fused small-bond kernels.  G[k][j] (k < keep new, j < n old) is the weighted factor.
 //   right shift (LEFT = false):  N[t][k][c] = sum_j G[k][j] N[t][j][c]   neighbour A_{i+1} [d][cb][cn], bond = its rows
 //   left shift  (LEFT = true):   N[s][z][k] = sum_j N[s][z][j] G[k][j]   neighbour A_{i-1} [d][cn][ca], bond = its columns
@@ -856,27 +931,7 @@ __global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p) {
   fro = wave_sum(fro);
   const double floor2 = 1e-26 * fro;
   __syncthreads();
-  bool converged = n < 2;
-  for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
-    int cnt = 0;
-    for (int pc = 0; pc + 1 < n; ++pc)
-      for (int qc = pc + 1; qc < n; ++qc) {
-        cplx yp = Y[pc][lane], yq = Y[qc][lane];
-        const double a = wave_sum(fma(yp.x, yp.x, yp.y * yp.y));
-        const double dd = wave_sum(fma(yq.x, yq.x, yq.y * yq.y));
-        const double gx = wave_sum(fma(yp.x, yq.x, yp.y * yq.y));
-        const double gy = wave_sum(fma(yp.x, yq.y, -yp.y * yq.x));
-        double c, sr, si, tg;
-        if (make_rotation(a, dd, gx, gy, 1e-26, floor2, c, sr, si, tg)) {
-          rotate_pair(yp, yq, c, sr, si);
-          Y[pc][lane] = yp;
-          Y[qc][lane] = yq;
-          ++cnt;
-        }
-        __syncthreads();
-      }
-    converged = cnt == 0;
-  }
+  const bool converged = small_jacobi(Y, n, lane, floor2);
   if (!converged && lane == 0 && p.flags) atomicOr(p.flags + 1, 1);
   // norms, descending rank sort (ties by index), truncation
   for (int j = 0; j < n; ++j) {
@@ -954,6 +1009,131 @@ __global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p) {
     }
   }
   small_absorb<LEFT>(p.nb + (long)b * p.nb_b0, G, d, ca, cb, p.cn, n, keep, ncap, lane);
+}
+
+// ---- small bonds: the two-site split in one kernel ------------------------------------------------
+// theta (d capL x d capR, at most 64 rows on the isometric side and MAXN actual columns on the other) -> left, right with the
+// truncation rule of svd_finish_kernel.  distribution 0: X = theta, U = normalised rotated columns, right = U^H theta;
+// distribution 1: X = theta^H, V likewise, left = theta V.  Columns are the ACTUAL ones (t, c < chi) of this trajectory.
+// A kept singular value at the rounding floor (<= 1e-11 sigma_0: its column was never rotated) raises flags[2]; the caller then
+// repeats the batch on the general path, which completes such columns to an orthonormal set.
+template <int MAXN>
+__global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, TruncSpec tr, int* flags) {
+  __shared__ cplx Y[MAXN][64];
+  __shared__ cplx G[MAXN][MAXN];
+  __shared__ double sNorm[MAXN];
+  __shared__ int sPerm[MAXN];
+  __shared__ int sKeep;
+  int b = blockIdx.x;
+  if (p.ids) b = p.ids[b];
+  const int lane = threadIdx.x;
+  const int d = p.d, capL = p.capL, capR = p.capR, capM = p.capM;
+  const bool d0 = p.distribution == 0;
+  const cplx* __restrict__ T = p.theta + (long)b * p.theta_b0;
+  const int chiL = p.chiL[(long)b * p.chi_stride], chiR = p.chiR[(long)b * p.chi_stride];
+  const int R = d0 ? d * capL : d * capR;            // rows of X (padded extent)
+  const int chiC = d0 ? chiR : chiL;                 // actual bond on the column side
+  const int capC = d0 ? capR : capL;
+  const int n = d * chiC;                            // actual columns
+  const int nsv = min(d * chiL, d * chiR);
+  auto padded_col = [&](int j) { const int t = j / chiC; return t * capC + (j - t * chiC); };
+  auto theta_at = [&](int r, int j) -> cplx {        // X[r][j]
+    if (d0) return T[(long)r * p.ld_theta + padded_col(j)];
+    cplx v = T[(long)padded_col(j) * p.ld_theta + r];
+    v.y = -v.y;
+    return v;
+  };
+  double fro = 0.0;
+  for (int j = 0; j < n; ++j) {
+    const cplx v = (lane < R) ? theta_at(lane, j) : cplx{0.0, 0.0};
+    Y[j][lane] = v;
+    fro = fma(v.x, v.x, fma(v.y, v.y, fro));
+  }
+  fro = wave_sum(fro);
+  __syncthreads();
+  const bool converged = small_jacobi(Y, n, lane, 1e-26 * fro);
+  if (!converged && lane == 0) atomicOr(flags + 3, 1);
+  for (int j = 0; j < n; ++j) {
+    const cplx v = Y[j][lane];
+    const double s2 = wave_sum(fma(v.x, v.x, v.y * v.y));
+    if (lane == 0) sNorm[j] = s2;
+  }
+  __syncthreads();
+  if (lane < n) {
+    const double v = sNorm[lane];
+    int rank = 0;
+    for (int o = 0; o < n; ++o) {
+      const double u = sNorm[o];
+      rank += (u > v || (u == v && o < lane)) ? 1 : 0;
+    }
+    sPerm[rank] = lane;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    const int keep = truncation_keep(tr, min(nsv, n), [&](int k) { return sqrt(sNorm[sPerm[k]]); });
+    sKeep = keep;
+    tr.chiOut[(long)b * tr.chi_stride] = keep;
+    if (keep > 0 && sqrt(sNorm[sPerm[keep - 1]]) <= 1e-11 * sqrt(sNorm[sPerm[0]])) atomicOr(flags + 2, 1);
+  }
+  if (tr.spectrum)
+    for (int k = lane; k < tr.spec_ld; k += 64) tr.spectrum[(long)b * tr.spec_ld + k] = (k < n) ? sqrt(sNorm[sPerm[k]]) : 0.0;
+  __syncthreads();
+  const int keep = sKeep;
+  // weighted factor G[k][j] = sum_r conj(Q[r][k]) X0[r][j]  (d0: S V^H)   or   sum_r conj(X0[r][j]) Q[r][k]  (d1: U S), Q = Y / sigma
+  for (int e = lane; e < keep * n; e += 64) {
+    const int k = e / n, j = e - k * n;
+    const int col = sPerm[k];
+    const double inv = 1.0 / sqrt(sNorm[col]);
+    double ax = 0.0, ay = 0.0;
+    for (int r = 0; r < R; ++r) {
+      const cplx u = Y[col][r];
+      const cplx x = theta_at(r, j);
+      if (d0) {  // conj(u) * x
+        ax = fma(u.x, x.x, fma(u.y, x.y, ax));
+        ay = fma(u.x, x.y, fma(-u.y, x.x, ay));
+      } else {   // conj(x) * u
+        ax = fma(x.x, u.x, fma(x.y, u.y, ax));
+        ay = fma(x.x, u.y, fma(-x.y, u.x, ay));
+      }
+    }
+    G[k][j] = cplx{ax * inv, ay * inv};
+  }
+  __syncthreads();
+  cplx* __restrict__ Lt = p.left + (long)b * p.left_b0;     // [d][capL][capM]
+  cplx* __restrict__ Rt = p.right + (long)b * p.right_b0;   // [d][capM][capR]
+  // isometric side: one row of X per lane
+  if (lane < R) {
+    for (int k = 0; k < capM; ++k) {
+      cplx v{0.0, 0.0};
+      if (k < keep) {
+        const int col = sPerm[k];
+        const double inv = 1.0 / sqrt(sNorm[col]);
+        v = Y[col][lane];
+        v.x *= inv;
+        v.y *= d0 ? inv : -inv;
+      }
+      if (d0) Lt[(long)lane * capM + k] = v;                                        // left[(s,a)][k] = U
+      else { const int t = lane / capR, c = lane - t * capR; Rt[((long)t * capM + k) * capR + c] = v; }  // right[t][k][c] = conj(V)
+    }
+  }
+  // weighted side: every padded entry, zero outside the actual block
+  const long total = (long)d * capC * capM;
+  for (long e = lane; e < total; e += 64) {
+    cplx v{0.0, 0.0};
+    if (d0) {  // right[t][k][c]
+      const int c = (int)(e % capR);
+      const long q = e / capR;
+      const int k = (int)(q % capM), t = (int)(q / capM);
+      if (k < keep && c < chiR) v = G[k][t * chiR + c];
+      Rt[e] = v;
+    } else {   // left[s][a][k]
+      const int k = (int)(e % capM);
+      const long q = e / capM;
+      const int a = (int)(q % capL), s_ = (int)(q / capL);
+      if (k < keep && a < chiL) v = G[k][s_ * chiL + a];
+      Lt[e] = v;
+    }
+  }
 }
 
 // ---- small bonds: Householder QR of one site in one kernel ---------------------------------------
@@ -1095,50 +1275,7 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspa
     const int n_act = d.mulB * d.chiB[(long)b * d.chi_stride];
     int nsv = m_act < n_act ? m_act : n_act;
     if (nsv > ncols_pad) nsv = ncols_pad;
-    int keep = 0;
-    if (nsv > 0) {
-      auto sv = [&](int k) { return sqrt(sN[sPerm[k]]); };
-      if (d.trunc_mode == 2) {  // hard_cutoff
-        for (int k = 0; k < nsv; ++k) keep += (sv(k) > d.threshold) ? 1 : 0;
-      } else if (d.trunc_mode == 1) {  // relative
-        const double smax = sv(0);
-        if (smax > 0.0)
-          for (int k = 0; k < nsv; ++k) keep += ((sv(k) / smax) >= d.threshold) ? 1 : 0;
-      } else if (d.trunc_mode == 0) {  // discarded_weight
-        keep = nsv;
-        double discard = 0.0;
-        for (int idx = 0; idx < nsv; ++idx) {
-          const double s = sv(nsv - 1 - idx);
-          discard += s * s;
-          if (discard >= d.threshold) {
-            keep = nsv - idx;
-            if (keep < d.min_keep) keep = d.min_keep;
-            break;
-          }
-        }
-      } else {  // relative_discarded_weight
-        const double smax = sv(0);
-        if (smax > 0.0) {
-          double total = 0.0;
-          for (int k = 0; k < nsv; ++k) { const double q = sv(k) / smax; total += q * q; }
-          keep = nsv;
-          double discard = 0.0;
-          for (int idx = 0; idx < nsv; ++idx) {
-            const double q = sv(nsv - 1 - idx) / smax;
-            const double cand = discard + q * q;
-            if (cand / total <= d.threshold) { discard = cand; keep = nsv - idx - 1; }
-            else break;
-          }
-        }
-      }
-      if (d.max_bond > 0 && keep > d.max_bond) keep = d.max_bond;
-      if (keep < d.min_keep) keep = d.min_keep;
-      if (keep > nsv) keep = nsv;
-      if (d.cap > 0 && keep > d.cap) {  // the engine's storage is smaller than what the truncation rule asks for
-        keep = d.cap;
-        if (d.overflow) atomicOr(d.overflow, 1);
-      }
-    }
+    const int keep = truncation_keep(d, nsv, [&](int k) { return sqrt(sN[sPerm[k]]); });
     d.chiOut[(long)b * d.chi_stride] = keep;
     // kept columns at the rounding-noise floor were never rotated: their normalised columns are not orthogonal to the rest,
     // so the caller must not take them as singular vectors (n_active[2] != 0 selects the re-orthonormalising path)
@@ -1416,6 +1553,26 @@ int svd_extract(const ExtractDesc& x, const SvdWorkspace& w, const JacobiShape& 
 // Two-site split: theta (m x n, rows (s,a), cols (t,c)) -> left[d][capL][capM], right[d][capM][capR].
 int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* sweeps_out) {
   if (d.nb0 <= 0) return TJM_OK;
+  {  // small bonds: everything in one kernel, unless a kept singular value sits at the rounding floor
+    static const bool off = getenv("TJM_NO_SMALL_SHIFT") != nullptr;
+    const int rows = d.distribution == 0 ? d.m : d.n, cols = d.distribution == 0 ? d.n : d.m;
+    if (!off && rows <= 64 && cols <= 32 && d.m == d.d * d.capL && d.n == d.d * d.capR && w.n_active != nullptr) {
+      TruncSpec tr;
+      tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
+      tr.cap = d.capM; tr.overflow = d.overflow;
+      tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
+      tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
+      TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 2, 0, 2 * sizeof(int), s));
+      if (cols <= 16) hipLaunchKernelGGL(svd_split_small_kernel<16>, dim3(d.nb0), dim3(64), 0, s, d, tr, w.n_active);
+      else hipLaunchKernelGGL(svd_split_small_kernel<32>, dim3(d.nb0), dim3(64), 0, s, d, tr, w.n_active);
+      TJM_HIP_CHECK(hipGetLastError());
+      TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+      TJM_HIP_CHECK(hipStreamSynchronize(s));
+      if (sweeps_out) *sweeps_out = 0;
+      if (w.h_pinned[0] == 0 && w.h_pinned[1] == 0) return TJM_OK;
+      // otherwise fall through: the general path handles rank-deficient kept sets (theta is untouched, the outputs are rewritten)
+    }
+  }
   JacobiSource src;
   src.src = d.theta; src.src_b0 = d.theta_b0; src.conj = (d.distribution == 0); src.tri = 0;
   if (d.distribution == 0) {  // X = theta^H : rows = theta columns, columns = theta rows
