@@ -613,6 +613,100 @@ __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int w
   }
 }
 
+// ---- medium bonds: the whole Jacobi iteration of one matrix inside one workgroup ---------------------
+// At most 64 columns of at most 128 stacked rows (128 KiB of LDS): eight wavefronts take the disjoint pairs of every round of the
+// circle ordering side by side, all sweeps run inside the launch (norms refreshed from the tile at the start of each sweep), and
+// the host reads one convergence flag at the end instead of synchronising after every sweep.  Same rotation rule and noise floor as
+// the tiled kernels; zero columns are skipped.
+template <int RK>
+__global__ __launch_bounds__(512) void jacobi_lds_kernel(JacobiArgs g, int ncols, int max_sweeps, int* n_unconverged) {
+  extern __shared__ double smem[];
+  int b = blockIdx.x;
+  if (g.ids) b = g.ids[b];
+  const int rtot = g.rtot, rx = g.rx;
+  cplx* tile = reinterpret_cast<cplx*>(smem);                     // [ncols][rtot]
+  double* sN = reinterpret_cast<double*>(tile + (long)ncols * rtot);  // [ncols]
+  int* sCnt = reinterpret_cast<int*>(sN + ncols);                 // [8]
+  cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int c = w; c < ncols; c += 8)
+#pragma unroll
+    for (int k = 0; k < RK; ++k)
+      if (lane + 64 * k < rtot) tile[c * rtot + lane + 64 * k] = Yb[(long)c * rtot + lane + 64 * k];
+  __syncthreads();
+  bool converged = false;
+  double floor2 = 0.0;
+  for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
+    for (int c = w; c < ncols; c += 8) {  // column norms of the X part from the tile (no drift from the running updates)
+      double n = 0.0;
+#pragma unroll
+      for (int k = 0; k < RK; ++k)
+        if (lane + 64 * k < rx) {
+          const cplx v = tile[c * rtot + lane + 64 * k];
+          n = fma(v.x, v.x, fma(v.y, v.y, n));
+        }
+      n = wave_sum(n);
+      if (lane == 0) sN[c] = n;
+    }
+    __syncthreads();
+    if (sweep == 0) {
+      double f = 0.0;
+      for (int c = 0; c < ncols; ++c) f += sN[c];
+      floor2 = 1e-26 * f;
+    }
+    int cnt = 0;
+    for (int s = 0; s < ncols - 1; ++s) {
+      for (int pi = w; pi < ncols / 2; pi += 8) {
+        int p, q;
+        pair_of(ncols, s, pi, p, q);
+        const double a = sN[p], dd = sN[q];
+        if (a == 0.0 || dd == 0.0) continue;  // padding columns
+        cplx yp[RK], yq[RK];
+        double gx = 0.0, gy = 0.0;
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+          if (lane + 64 * k < rtot) {
+            yp[k] = tile[p * rtot + lane + 64 * k];
+            yq[k] = tile[q * rtot + lane + 64 * k];
+            if (lane + 64 * k < rx) {
+              gx = fma(yp[k].x, yq[k].x, fma(yp[k].y, yq[k].y, gx));
+              gy = fma(yp[k].x, yq[k].y, fma(-yp[k].y, yq[k].x, gy));
+            }
+          }
+        }
+        gx = wave_sum(gx);
+        gy = wave_sum(gy);
+        double c, sr, si, tg;
+        if (make_rotation(a, dd, gx, gy, g.tol2, floor2, c, sr, si, tg)) {
+#pragma unroll
+          for (int k = 0; k < RK; ++k) {
+            if (lane + 64 * k < rtot) {
+              rotate_pair(yp[k], yq[k], c, sr, si);
+              tile[p * rtot + lane + 64 * k] = yp[k];
+              tile[q * rtot + lane + 64 * k] = yq[k];
+            }
+          }
+          if (lane == 0) { sN[p] = a - tg; sN[q] = dd + tg; }
+          ++cnt;
+        }
+      }
+      __syncthreads();
+    }
+    if (lane == 0) sCnt[w] = cnt;
+    __syncthreads();
+    int total = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) total += sCnt[q];
+    converged = total == 0;
+    __syncthreads();
+  }
+  for (int c = w; c < ncols; c += 8)
+#pragma unroll
+    for (int k = 0; k < RK; ++k)
+      if (lane + 64 * k < rtot) Yb[(long)c * rtot + lane + 64 * k] = tile[c * rtot + lane + 64 * k];
+  if (!converged && tid == 0) atomicAdd(n_unconverged, 1);
+}
+
 // ---- pairs inside one block (LDS resident) -----------------------------------------------------
 template <int RK>
 __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
@@ -1432,6 +1526,33 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   if (rtot > 64 * MAXRK) return TJM_ERR_NOT_IMPLEMENTED;  // register-resident columns: rx + ncols <= 1024
   if ((long)ncols_pad * rtot > w.y_b0) return TJM_ERR_WORKSPACE;
   const bool big = rtot > 512;  // 16 row groups per column instead of 8
+  static const bool no_lds = getenv("TJM_NO_LDS_JACOBI") != nullptr;
+  if (!no_lds && ncols_pad <= 64 && rtot <= 128) {  // the whole problem fits one workgroup's LDS: all sweeps in one launch
+    static bool lds_attr = false;
+    if (!lds_attr) {
+      TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_lds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+      TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_lds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+      lds_attr = true;
+    }
+    const long total = (long)ncols_pad * rtot;
+    int gx = (int)((total + 1023) / 1024);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(jacobi_load_kernel, dim3(gx, src.nb0), dim3(256), 0, s, src, w.Y, w.y_b0, ncols_pad, rx_top, rtot);
+    JacobiArgs g;
+    g.Y = w.Y; g.y_b0 = w.y_b0; g.rtot = rtot; g.rx = rx_top; g.nblk = ncols_pad / NB; g.tol2 = 1e-26; g.fro2 = nullptr; g.nrot = nullptr;
+    g.done = nullptr; g.ids = src.ids; g.round = 0; g.stamps = nullptr; g.clock = 0; g.mode = 0; g.rec = nullptr;
+    TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 3 * sizeof(int), s));
+    const size_t lds_bytes = (size_t)ncols_pad * rtot * sizeof(cplx) + (size_t)ncols_pad * sizeof(double) + 16 * sizeof(int);
+    if (rtot <= 64) hipLaunchKernelGGL(jacobi_lds_kernel<1>, dim3(src.nb0), dim3(512), lds_bytes, s, g, ncols_pad, 40, w.n_active);
+    else hipLaunchKernelGGL(jacobi_lds_kernel<2>, dim3(src.nb0), dim3(512), lds_bytes, s, g, ncols_pad, 40, w.n_active);
+    hipLaunchKernelGGL(svd_finish_kernel, dim3(src.nb0), dim3(256), 0, s, tr, w, ncols_pad, rx_top, rtot, src.ids);
+    TJM_HIP_CHECK(hipGetLastError());
+    TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+    TJM_HIP_CHECK(hipStreamSynchronize(s));
+    if (sweeps_out) *sweeps_out = 0;
+    if (shape_out) { shape_out->ncols_pad = ncols_pad; shape_out->rx_top = rx_top; shape_out->rtot = rtot; }
+    return (*w.h_pinned == 0) ? TJM_OK : TJM_ERR_NUMERIC;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     const int big_lds = 136 * 1024;
@@ -1556,15 +1677,14 @@ int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* 
   {  // small bonds: everything in one kernel, unless a kept singular value sits at the rounding floor
     static const bool off = getenv("TJM_NO_SMALL_SHIFT") != nullptr;
     const int rows = d.distribution == 0 ? d.m : d.n, cols = d.distribution == 0 ? d.n : d.m;
-    if (!off && rows <= 64 && cols <= 32 && d.m == d.d * d.capL && d.n == d.d * d.capR && w.n_active != nullptr) {
+    if (!off && rows <= 64 && cols <= 16 && d.m == d.d * d.capL && d.n == d.d * d.capR && w.n_active != nullptr) {  // wider: the LDS-resident kernel
       TruncSpec tr;
       tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
       tr.cap = d.capM; tr.overflow = d.overflow;
       tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
       tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
       TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 2, 0, 2 * sizeof(int), s));
-      if (cols <= 16) hipLaunchKernelGGL(svd_split_small_kernel<16>, dim3(d.nb0), dim3(64), 0, s, d, tr, w.n_active);
-      else hipLaunchKernelGGL(svd_split_small_kernel<32>, dim3(d.nb0), dim3(64), 0, s, d, tr, w.n_active);
+      hipLaunchKernelGGL(svd_split_small_kernel<16>, dim3(d.nb0), dim3(64), 0, s, d, tr, w.n_active);
       TJM_HIP_CHECK(hipGetLastError());
       TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
       TJM_HIP_CHECK(hipStreamSynchronize(s));
