@@ -614,22 +614,22 @@ __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int w
 }
 
 // ---- medium bonds: the whole Jacobi iteration of one matrix inside one workgroup ---------------------
-// At most 64 columns of at most 128 stacked rows (128 KiB of LDS): eight wavefronts take the disjoint pairs of every round of the
+// At most 64 columns of at most 128 stacked rows (128 KiB of LDS): sixteen wavefronts take the disjoint pairs of every round of the
 // circle ordering side by side, all sweeps run inside the launch (norms refreshed from the tile at the start of each sweep), and
 // the host reads one convergence flag at the end instead of synchronising after every sweep.  Same rotation rule and noise floor as
 // the tiled kernels; zero columns are skipped.
 template <int RK>
-__global__ __launch_bounds__(512) void jacobi_lds_kernel(JacobiArgs g, int ncols, int max_sweeps, int* n_unconverged) {
+__global__ __launch_bounds__(1024) void jacobi_lds_kernel(JacobiArgs g, int ncols, int max_sweeps, int* n_unconverged) {
   extern __shared__ double smem[];
   int b = blockIdx.x;
   if (g.ids) b = g.ids[b];
   const int rtot = g.rtot, rx = g.rx;
   cplx* tile = reinterpret_cast<cplx*>(smem);                     // [ncols][rtot]
   double* sN = reinterpret_cast<double*>(tile + (long)ncols * rtot);  // [ncols]
-  int* sCnt = reinterpret_cast<int*>(sN + ncols);                 // [8]
+  int* sCnt = reinterpret_cast<int*>(sN + ncols);                 // [16]
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int c = w; c < ncols; c += 8)
+  for (int c = w; c < ncols; c += 16)
 #pragma unroll
     for (int k = 0; k < RK; ++k)
       if (lane + 64 * k < rtot) tile[c * rtot + lane + 64 * k] = Yb[(long)c * rtot + lane + 64 * k];
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(JacobiArgs g, int ncols
   bool converged = false;
   double floor2 = 0.0;
   for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
-    for (int c = w; c < ncols; c += 8) {  // column norms of the X part from the tile (no drift from the running updates)
+    for (int c = w; c < ncols; c += 16) {  // column norms of the X part from the tile (no drift from the running updates)
       double n = 0.0;
 #pragma unroll
       for (int k = 0; k < RK; ++k)
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(JacobiArgs g, int ncols
     }
     int cnt = 0;
     for (int s = 0; s < ncols - 1; ++s) {
-      for (int pi = w; pi < ncols / 2; pi += 8) {
+      for (int pi = w; pi < ncols / 2; pi += 16) {
         int p, q;
         pair_of(ncols, s, pi, p, q);
         const double a = sN[p], dd = sN[q];
@@ -696,11 +696,11 @@ __global__ __launch_bounds__(512) void jacobi_lds_kernel(JacobiArgs g, int ncols
     __syncthreads();
     int total = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) total += sCnt[q];
+    for (int q = 0; q < 16; ++q) total += sCnt[q];
     converged = total == 0;
     __syncthreads();
   }
-  for (int c = w; c < ncols; c += 8)
+  for (int c = w; c < ncols; c += 16)
 #pragma unroll
     for (int k = 0; k < RK; ++k)
       if (lane + 64 * k < rtot) Yb[(long)c * rtot + lane + 64 * k] = tile[c * rtot + lane + 64 * k];
@@ -1542,9 +1542,9 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     g.Y = w.Y; g.y_b0 = w.y_b0; g.rtot = rtot; g.rx = rx_top; g.nblk = ncols_pad / NB; g.tol2 = 1e-26; g.fro2 = nullptr; g.nrot = nullptr;
     g.done = nullptr; g.ids = src.ids; g.round = 0; g.stamps = nullptr; g.clock = 0; g.mode = 0; g.rec = nullptr;
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 3 * sizeof(int), s));
-    const size_t lds_bytes = (size_t)ncols_pad * rtot * sizeof(cplx) + (size_t)ncols_pad * sizeof(double) + 16 * sizeof(int);
-    if (rtot <= 64) hipLaunchKernelGGL(jacobi_lds_kernel<1>, dim3(src.nb0), dim3(512), lds_bytes, s, g, ncols_pad, 40, w.n_active);
-    else hipLaunchKernelGGL(jacobi_lds_kernel<2>, dim3(src.nb0), dim3(512), lds_bytes, s, g, ncols_pad, 40, w.n_active);
+    const size_t lds_bytes = (size_t)ncols_pad * rtot * sizeof(cplx) + (size_t)ncols_pad * sizeof(double) + 32 * sizeof(int);
+    if (rtot <= 64) hipLaunchKernelGGL(jacobi_lds_kernel<1>, dim3(src.nb0), dim3(1024), lds_bytes, s, g, ncols_pad, 40, w.n_active);
+    else hipLaunchKernelGGL(jacobi_lds_kernel<2>, dim3(src.nb0), dim3(1024), lds_bytes, s, g, ncols_pad, 40, w.n_active);
     hipLaunchKernelGGL(svd_finish_kernel, dim3(src.nb0), dim3(256), 0, s, tr, w, ncols_pad, rx_top, rtot, src.ids);
     TJM_HIP_CHECK(hipGetLastError());
     TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
