@@ -743,14 +743,15 @@ def test_circuit_growth_continues_at_the_clipped_layer(monkeypatch):
 
 
 def test_general_kernels_still_serve_small_bonds():
-    """Bonds up to 16 take the fused one-kernel centre shifts and site QR; with TJM_NO_SMALL_SHIFT the same cases run on the
-    general Jacobi / Householder path (the switch is read once per process, hence the child interpreter)."""
+    """Small bonds take the fused one-kernel centre shifts, site QR, two-site split and Krylov exponential and the LDS-resident
+    Jacobi; with the switches below the same cases run on the general GEMM / Jacobi / Householder path (the switches are read once
+    per process, hence the child interpreter)."""
     import subprocess
     import sys
 
     from conftest import ROOT
 
-    env = dict(os.environ, TJM_NO_SMALL_SHIFT="1", TJM_FUZZ_CASES="10")
+    env = dict(os.environ, TJM_NO_SMALL_SHIFT="1", TJM_NO_SMALL_KRYLOV="1", TJM_NO_LDS_JACOBI="1", TJM_FUZZ_CASES="10")
     out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_hip_engine.py", "-m", "gpu", "-x", "-q", "-k",
                           "randomised_configurations or randomised_circuits or tiny_chains"], cwd=ROOT, env=env, capture_output=True, text=True,
                          timeout=1500)

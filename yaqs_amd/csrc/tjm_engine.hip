@@ -496,6 +496,16 @@ int Engine::krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc
 int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0,
                         int Dr, const cplx* Wm, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2,
                         int n3, long o0, long o1, long o2, int nb0, const int* ids) {
+  if (krylov_small_fits(P, ca, cb, Dl, Dr, mmax)) {  // small bonds: contraction, recurrence, adaptive stop and combination in one kernel
+    SmallKrylovDesc q;
+    q.V = V; q.v_b0 = v_b0; q.v_ld = v_ld; q.P = P; q.ca = ca; q.cb = cb;
+    q.Lenv = Lenv; q.l_b0 = l_b0; q.Dl = Dl; q.Renv = Renv; q.r_b0 = r_b0; q.Dr = Dr; q.Wm = Wm;
+    q.dt = dt_; q.tol = krylov_tol; q.nloc = nloc_dev; q.mmax = mmax;
+    q.out = out; q.out_b0 = out_b0; q.n1 = n1; q.n2 = n2; q.n3 = n3; q.o0 = o0; q.o1 = o1; q.o2 = o2;
+    q.ids = ids; q.nb0 = nb0; q.matvecs = nullptr;
+    ++stat_krylov_calls;
+    return launch_krylov_site_small(q, stream);
+  }
   ApplyFn f = [&](const cplx* x, cplx* y, const int* active) {
     return heff_apply(x, v_b0, P, ca, cb, Lenv, l_b0, Dl, Renv, r_b0, Dr, Wm, y, v_b0, nb0, ids, active);
   };

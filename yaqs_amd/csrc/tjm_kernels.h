@@ -34,6 +34,26 @@ struct KrylovState {
   int mmax;
 };
 
+// expm_krylov (matrix_exponential.py:60-163) of one site / two-site block with small bonds, everything in one kernel
+// (krylov_site_small_kernel): V[0] holds the input, the Krylov vectors are written behind it, the result goes to `out` through the
+// 4-level index permutation of krylov_combine_kernel.
+struct SmallKrylovDesc {
+  cplx* V; long v_b0, v_ld;
+  int P, ca, cb;              // physical extent (d or d^2) and padded bond extents of the block
+  const cplx* Lenv; long l_b0; int Dl;   // L[(a,l)][A]
+  const cplx* Renv; long r_b0; int Dr;   // R[b][(r,B)]
+  const cplx* Wm;             // [(o,l)][(p,r)] row-major
+  double dt, tol;
+  const int* nloc;            // actual local dimension per trajectory (breakdown threshold)
+  int mmax;
+  cplx* out; long out_b0;
+  int n1, n2, n3; long o0, o1, o2;
+  const int* ids; int nb0;
+  unsigned long long* matvecs;   // device counter (statistics), may be null
+};
+bool krylov_small_fits(int P, int ca, int cb, int Dl, int Dr, int mmax);
+int launch_krylov_site_small(const SmallKrylovDesc& p, hipStream_t s);
+
 int launch_normsq_partial(const cplx* x, long x_b0, int n, double* part, int nb0, const int* ids, const int* active,
                           hipStream_t s, int* nblk_out);
 int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n, double* part, int nb0, const int* ids,

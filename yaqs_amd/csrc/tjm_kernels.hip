@@ -258,6 +258,183 @@ int launch_tridiag_expm_test(const double* alpha, const double* beta, int k, dou
   return TJM_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Small bonds: the whole expm_krylov of one block in one kernel.  One workgroup per trajectory; the block (<= 256 entries), both
+// environment slices, the MPO matrix and the two intermediates of the three-stage contraction live in LDS; the recurrence, the
+// breakdown / adaptive-stop tests of lanczos_finalize_kernel and the final combination follow in the same launch.  Replaces
+// about ten launches and one host synchronisation per Lanczos iteration.
+// ------------------------------------------------------------------------------------------
+constexpr int KS_MAXN = 256;   // P * ca * cb
+constexpr int KS_MAXT = 1536;  // P * ca * D * cb with D <= 6
+constexpr int KS_MAXE = 384;   // ca * D * ca
+constexpr int KS_MAXW = 576;   // (P D)^2
+
+__global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc p) {
+  extern __shared__ double ks_smem[];
+  __shared__ cplx sCoef[64];
+  __shared__ double sAl[64], sBe[64], sh[4];
+  __shared__ int sDone, sK;
+  int b = blockIdx.x;
+  if (p.ids) b = p.ids[b];
+  const int tid = threadIdx.x;
+  const int P = p.P, ca = p.ca, cb = p.cb, Dl = p.Dl, Dr = p.Dr, m = p.mmax;
+  const int N = P * ca * cb, nT1 = P * ca * Dr * cb, nT2 = P * ca * Dl * cb;
+  cplx* sX = reinterpret_cast<cplx*>(ks_smem);
+  cplx* sY = sX + N;
+  cplx* sPrev = sY + N;
+  cplx* sT1 = sPrev + N;
+  cplx* sT2 = sT1 + nT1;
+  cplx* sL = sT2 + nT2;
+  cplx* sR = sL + ca * Dl * ca;
+  cplx* sW = sR + cb * Dr * cb;
+  cplx* __restrict__ Vb = p.V + (long)b * p.v_b0;
+  for (int e = tid; e < ca * Dl * ca; e += 256) sL[e] = p.Lenv[(long)b * p.l_b0 + e];
+  for (int e = tid; e < cb * Dr * cb; e += 256) sR[e] = p.Renv[(long)b * p.r_b0 + e];
+  for (int e = tid; e < P * Dl * P * Dr; e += 256) sW[e] = p.Wm[e];
+  double acc = 0.0;
+  for (int e = tid; e < N; e += 256) {
+    const cplx v = Vb[e];
+    sX[e] = v;
+    acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+  }
+  const double nrm = sqrt(block_sum(acc, sh));
+  cplx* __restrict__ ob = p.out + (long)b * p.out_b0;
+  auto out_index = [&](int e) -> long {
+    long i3 = e % p.n3, r = e / p.n3;
+    long i2 = r % p.n2;
+    r /= p.n2;
+    long i1 = r % p.n1, i0 = r / p.n1;
+    return i0 * p.o0 + i1 * p.o1 + i2 * p.o2 + i3;
+  };
+  if (nrm == 0.0) {  // the result is the zero vector
+    for (int e = tid; e < N; e += 256) ob[out_index(e)] = cplx{0.0, 0.0};
+    return;
+  }
+  const double inv0 = 1.0 / nrm;
+  for (int e = tid; e < N; e += 256) {
+    cplx v = sX[e];
+    v.x *= inv0; v.y *= inv0;
+    sX[e] = v;
+    Vb[e] = v;
+  }
+  const double eps_cut = 100.0 * (double)p.nloc[b] * 2.220446049250313e-16;
+  double bprev = 0.0;
+  int kfinal = 0;
+  __syncthreads();
+  for (int j = 0; j < m; ++j) {
+    // T1[(p,a),(r,B)] = sum_b x[(p,a),b] R[b,(r,B)]
+    for (int e = tid; e < nT1; e += 256) {
+      const int Bc = e % cb, r = (e / cb) % Dr, pa = e / (cb * Dr);
+      cplx t{0.0, 0.0};
+      for (int q = 0; q < cb; ++q) cfma(t, sX[pa * cb + q], sR[(q * Dr + r) * cb + Bc]);
+      sT1[e] = t;
+    }
+    __syncthreads();
+    // T2[o][a][l][B] = sum_{p,r} W[(o,l),(p,r)] T1[p][a][r][B]
+    for (int e = tid; e < nT2; e += 256) {
+      const int Bc = e % cb, l = (e / cb) % Dl, a = (e / (cb * Dl)) % ca, o = e / (cb * Dl * ca);
+      cplx t{0.0, 0.0};
+      for (int pp = 0; pp < P; ++pp)
+        for (int r = 0; r < Dr; ++r) cfma(t, sW[(o * Dl + l) * (P * Dr) + pp * Dr + r], sT1[((pp * ca + a) * Dr + r) * cb + Bc]);
+      sT2[e] = t;
+    }
+    __syncthreads();
+    // y[o][A][B] = sum_{(a,l)} L[(a,l)][A] T2[o][(a,l)][B] ;  alpha = Re <x, y>
+    double dot = 0.0;
+    for (int e = tid; e < N; e += 256) {
+      const int Bc = e % cb, A = (e / cb) % ca, o = e / (cb * ca);
+      cplx t{0.0, 0.0};
+      for (int al = 0; al < ca * Dl; ++al) cfma(t, sL[al * ca + A], sT2[(o * ca * Dl + al) * cb + Bc]);
+      sY[e] = t;
+      const cplx x = sX[e];
+      dot = fma(x.x, t.x, fma(x.y, t.y, dot));
+    }
+    const double alpha = block_sum(dot, sh);
+    // w = y - alpha x - beta_{j-1} x_{j-1}
+    double s2 = 0.0;
+    for (int e = tid; e < N; e += 256) {
+      cplx w = sY[e];
+      const cplx x = sX[e];
+      w.x = fma(-alpha, x.x, w.x);
+      w.y = fma(-alpha, x.y, w.y);
+      if (j > 0) {
+        const cplx u = sPrev[e];
+        w.x = fma(-bprev, u.x, w.x);
+        w.y = fma(-bprev, u.y, w.y);
+      }
+      sY[e] = w;
+      s2 = fma(w.x, w.x, fma(w.y, w.y, s2));
+    }
+    const double bj = sqrt(block_sum(s2, sh));
+    if (tid == 0) {
+      sAl[j] = alpha;
+      if (j < m - 1) sBe[j] = bj;
+      sDone = 0;
+    }
+    __syncthreads();
+    const int k = j + 1;
+    if (tid < 64) {  // breakdown and adaptive stop (lanczos_finalize_kernel)
+      double pr = 0.0, pi = 0.0;
+      bool done = false;
+      if (j < m - 1 && bj < eps_cut) {
+        tridiag_expm_e1(sAl, sBe, k, p.dt, tid, pr, pi);
+        done = true;
+      } else if (j >= 1 || j == m - 1) {
+        tridiag_expm_e1(sAl, sBe, k, p.dt, tid, pr, pi);
+        if (j == m - 1) done = true;
+        else {
+          const double lr = __shfl(pr, k - 1, 64), li = __shfl(pi, k - 1, 64);
+          done = (bj * sqrt(lr * lr + li * li) < p.tol);
+        }
+      }
+      if (done) {
+        if (tid < k) sCoef[tid] = cplx{pr * nrm, pi * nrm};
+        if (tid == 0) { sDone = 1; sK = k; }
+      }
+    }
+    __syncthreads();
+    if (sDone) { kfinal = sK; break; }
+    const double invb = 1.0 / bj;
+    for (int e = tid; e < N; e += 256) {
+      cplx w = sY[e];
+      w.x *= invb; w.y *= invb;
+      sPrev[e] = sX[e];
+      sX[e] = w;
+      Vb[(long)(j + 1) * p.v_ld + e] = w;
+    }
+    bprev = bj;
+    __syncthreads();
+  }
+  if (tid == 0 && p.matvecs) atomicAdd(p.matvecs, (unsigned long long)kfinal);
+  // out = sum_{j < kfinal} coef_j V_j
+  for (int e = tid; e < N; e += 256) {
+    cplx t{0.0, 0.0};
+    for (int j = 0; j < kfinal; ++j) cfma(t, sCoef[j], Vb[(long)j * p.v_ld + e]);
+    ob[out_index(e)] = t;
+  }
+}
+
+bool krylov_small_fits(int P, int ca, int cb, int Dl, int Dr, int mmax) {
+  static const bool off = getenv("TJM_NO_SMALL_KRYLOV") != nullptr;
+  if (off || mmax > 63) return false;
+  const int D = Dl > Dr ? Dl : Dr;
+  return P * ca * cb <= KS_MAXN && P * ca * D * cb <= KS_MAXT && ca * Dl * ca <= KS_MAXE && cb * Dr * cb <= KS_MAXE && P * Dl * P * Dr <= KS_MAXW;
+}
+
+int launch_krylov_site_small(const SmallKrylovDesc& p, hipStream_t s) {
+  if (p.nb0 <= 0) return TJM_OK;
+  static bool attr = false;
+  if (!attr) {
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(krylov_site_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    attr = true;
+  }
+  const size_t n = (size_t)3 * p.P * p.ca * p.cb + (size_t)p.P * p.ca * p.cb * (p.Dl + p.Dr) + (size_t)p.ca * p.Dl * p.ca + (size_t)p.cb * p.Dr * p.cb +
+                   (size_t)p.P * p.Dl * p.P * p.Dr;
+  hipLaunchKernelGGL(krylov_site_small_kernel, dim3(p.nb0), dim3(256), n * sizeof(cplx), s, p);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
 // Lanczos start: vnorm = sqrt(sum part), status, first scale
 __global__ __launch_bounds__(64) void lanczos_init_kernel(KrylovState ks, const double* part, int nblk, int nb, const int* ids) {
   int b = blockIdx.x;
