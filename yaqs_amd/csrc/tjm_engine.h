@@ -70,7 +70,7 @@ class Engine {
   // exposed for kernel-level parity tests
   int krylov_site(cplx* x_in_v0, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0,
                   int Dr, const cplx* Wm, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2,
-                  int n3, long o0, long o1, long o2, int nb0, const int* ids);
+                  int n3, long o0, long o1, long o2, int nb0, const int* ids, const int* chi_l = nullptr, const int* chi_r = nullptr);
   int heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv,
                  long r_b0, int Dr, const cplx* Wm, cplx* y, long y_b0, int nb0, const int* ids, const int* active);
 

@@ -495,7 +495,7 @@ int Engine::krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc
 
 int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0,
                         int Dr, const cplx* Wm, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2,
-                        int n3, long o0, long o1, long o2, int nb0, const int* ids) {
+                        int n3, long o0, long o1, long o2, int nb0, const int* ids, const int* chi_l, const int* chi_r) {
   if (krylov_small_fits(P, ca, cb, Dl, Dr, mmax)) {  // small bonds: contraction, recurrence, adaptive stop and combination in one kernel
     SmallKrylovDesc q;
     q.V = V; q.v_b0 = v_b0; q.v_ld = v_ld; q.P = P; q.ca = ca; q.cb = cb;
@@ -503,6 +503,7 @@ int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Len
     q.dt = dt_; q.tol = krylov_tol; q.nloc = nloc_dev; q.mmax = mmax;
     q.out = out; q.out_b0 = out_b0; q.n1 = n1; q.n2 = n2; q.n3 = n3; q.o0 = o0; q.o1 = o1; q.o2 = o2;
     q.ids = ids; q.nb0 = nb0; q.matvecs = nullptr;
+    q.chi_l = chi_l; q.chi_r = chi_r; q.chi_stride = L + 1;
     ++stat_krylov_calls;
     return launch_krylov_site_small(q, stream);
   }
@@ -585,7 +586,7 @@ int Engine::two_site_update(StateSet& S, int i, double dt_, int dist) {
   if ((rc = set_nloc(S, i, i + 2, P)) != TJM_OK) return rc;
   // result in matrix layout theta[(s,a),(t,c)] from tensor layout [s][t][a][c]
   if ((rc = krylov_site(nullptr, P, ca, cc, Lenv_[i], l_b0_[i], Dm[i], Renv_[i + 1], r_b0_[i + 1], Dm[i + 2], W2_[i], dt_, nloc_,
-                        theta, theta_b0, d, d, ca, cc, (long)ca * d * cc, cc, (long)d * cc, B, nullptr)) != TJM_OK) return rc;
+                        theta, theta_b0, d, d, ca, cc, (long)ca * d * cc, cc, (long)d * cc, B, nullptr, S.chi + i, S.chi + i + 2)) != TJM_OK) return rc;
   const int mk = (max_bond > 0) ? std::min(2, max_bond) : 2;
   if ((rc = split(S, i, dist, trunc_mode, svd_threshold, max_bond, mk, nullptr, B)) != TJM_OK) return rc;
   ++stat_site_updates;
@@ -599,7 +600,7 @@ int Engine::one_site_update(StateSet& S, int i, double dt_) {
                                  hipMemcpyDeviceToDevice, stream));
   if ((rc = set_nloc(S, i, i + 1, d)) != TJM_OK) return rc;
   return krylov_site(nullptr, d, ca, cb, Lenv_[i], l_b0_[i], Dm[i], Renv_[i], r_b0_[i], Dm[i + 1], W_[i], dt_, nloc_, S.A[i], a_b0_[i], 1,
-                     d, ca, cb, 0, (long)ca * cb, cb, B, nullptr);
+                     d, ca, cb, 0, (long)ca * cb, cb, B, nullptr, S.chi + i, S.chi + i + 1);
 }
 
 int Engine::sweep_2site(StateSet& S, double scale) {

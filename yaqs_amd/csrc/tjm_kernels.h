@@ -50,6 +50,7 @@ struct SmallKrylovDesc {
   int n1, n2, n3; long o0, o1, o2;
   const int* ids; int nb0;
   unsigned long long* matvecs;   // device counter (statistics), may be null
+  const int* chi_l; const int* chi_r; int chi_stride;   // actual bonds of the block per trajectory (null: the padded extents)
 };
 bool krylov_small_fits(int P, int ca, int cb, int Dl, int Dr, int mmax);
 int launch_krylov_site_small(const SmallKrylovDesc& p, hipStream_t s);

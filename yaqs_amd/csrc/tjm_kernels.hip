@@ -318,25 +318,30 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
     Vb[e] = v;
   }
   const double eps_cut = 100.0 * (double)p.nloc[b] * 2.220446049250313e-16;
+  const int na = p.chi_l ? min(p.chi_l[(long)b * p.chi_stride], ca) : ca;
+  const int nb = p.chi_r ? min(p.chi_r[(long)b * p.chi_stride], cb) : cb;
   double bprev = 0.0;
   int kfinal = 0;
   __syncthreads();
   for (int j = 0; j < m; ++j) {
+    // Every loop runs over the ACTUAL bonds (na, nb) of this trajectory: entries beyond them are exactly zero in x, and the
+    // intermediates are only read at the positions that were written.
     // T1[(p,a),(r,B)] = sum_b x[(p,a),b] R[b,(r,B)]
-    for (int e = tid; e < nT1; e += 256) {
-      const int Bc = e % cb, r = (e / cb) % Dr, pa = e / (cb * Dr);
+    for (int e = tid; e < P * na * Dr * nb; e += 256) {
+      const int Bc = e % nb, r = (e / nb) % Dr, a = (e / (nb * Dr)) % na, pp = e / (nb * Dr * na);
+      const int pa = pp * ca + a;
       cplx t{0.0, 0.0};
-      for (int q = 0; q < cb; ++q) cfma(t, sX[pa * cb + q], sR[(q * Dr + r) * cb + Bc]);
-      sT1[e] = t;
+      for (int q = 0; q < nb; ++q) cfma(t, sX[pa * cb + q], sR[(q * Dr + r) * cb + Bc]);
+      sT1[(pa * Dr + r) * cb + Bc] = t;
     }
     __syncthreads();
     // T2[o][a][l][B] = sum_{p,r} W[(o,l),(p,r)] T1[p][a][r][B]
-    for (int e = tid; e < nT2; e += 256) {
-      const int Bc = e % cb, l = (e / cb) % Dl, a = (e / (cb * Dl)) % ca, o = e / (cb * Dl * ca);
+    for (int e = tid; e < P * na * Dl * nb; e += 256) {
+      const int Bc = e % nb, l = (e / nb) % Dl, a = (e / (nb * Dl)) % na, o = e / (nb * Dl * na);
       cplx t{0.0, 0.0};
       for (int pp = 0; pp < P; ++pp)
         for (int r = 0; r < Dr; ++r) cfma(t, sW[(o * Dl + l) * (P * Dr) + pp * Dr + r], sT1[((pp * ca + a) * Dr + r) * cb + Bc]);
-      sT2[e] = t;
+      sT2[((o * ca + a) * Dl + l) * cb + Bc] = t;
     }
     __syncthreads();
     // y[o][A][B] = sum_{(a,l)} L[(a,l)][A] T2[o][(a,l)][B] ;  alpha = Re <x, y>
@@ -344,7 +349,9 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
     for (int e = tid; e < N; e += 256) {
       const int Bc = e % cb, A = (e / cb) % ca, o = e / (cb * ca);
       cplx t{0.0, 0.0};
-      for (int al = 0; al < ca * Dl; ++al) cfma(t, sL[al * ca + A], sT2[(o * ca * Dl + al) * cb + Bc]);
+      if (A < na && Bc < nb)
+        for (int a = 0; a < na; ++a)
+          for (int l = 0; l < Dl; ++l) cfma(t, sL[(a * Dl + l) * ca + A], sT2[((o * ca + a) * Dl + l) * cb + Bc]);
       sY[e] = t;
       const cplx x = sX[e];
       dot = fma(x.x, t.x, fma(x.y, t.y, dot));
