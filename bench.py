@@ -125,9 +125,9 @@ def pmc_traffic(L, chi, B):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=512, help="trajectories resident per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="trajectories resident per GPU (the headline configuration has 1024 trajectories)")
     ap.add_argument("--length", type=int, default=64)
     ap.add_argument("--chi", type=int, default=128)
     ap.add_argument("--krylov-tol", type=float, default=1e-4)
