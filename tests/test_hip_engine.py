@@ -956,7 +956,7 @@ def test_randomised_circuits_match_oracle(case):
         assert np.array_equal(d[t], do), (case, t)
 
 
-@pytest.mark.parametrize("L,chi", [(12, 32), (14, 64), (16, 128), (12, 24), (14, 48), (16, 96)])
+@pytest.mark.parametrize("L,chi", [(12, 32), (14, 64), (16, 128), (12, 24), (14, 48), (16, 96), (10, 16), (10, 12)])
 def test_medium_bond_dimensions_match_oracle(L, chi):
     """chi = 32 / 64 / 128: the two-site split is 64 / 128 / 256 square, so the doubly QR-preconditioned, accumulation-free path runs
     with the fused 16-column kernels (64, 128) and the split X kernel (256); chi-saturated Haar state, amplitude damping plus dephasing."""

@@ -496,7 +496,7 @@ int Engine::krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc
 int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0,
                         int Dr, const cplx* Wm, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2,
                         int n3, long o0, long o1, long o2, int nb0, const int* ids, const int* chi_l, const int* chi_r) {
-  if (krylov_small_fits(P, ca, cb, Dl, Dr, mmax)) {  // small bonds: contraction, recurrence, adaptive stop and combination in one kernel
+  if (krylov_small_fits(P, ca, cb, Dl, Dr, mmax, nb0)) {  // small bonds: contraction, recurrence, adaptive stop and combination in one kernel
     SmallKrylovDesc q;
     q.V = V; q.v_b0 = v_b0; q.v_ld = v_ld; q.P = P; q.ca = ca; q.cb = cb;
     q.Lenv = Lenv; q.l_b0 = l_b0; q.Dl = Dl; q.Renv = Renv; q.r_b0 = r_b0; q.Dr = Dr; q.Wm = Wm;

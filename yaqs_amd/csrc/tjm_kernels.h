@@ -52,7 +52,7 @@ struct SmallKrylovDesc {
   unsigned long long* matvecs;   // device counter (statistics), may be null
   const int* chi_l; const int* chi_r; int chi_stride;   // actual bonds of the block per trajectory (null: the padded extents)
 };
-bool krylov_small_fits(int P, int ca, int cb, int Dl, int Dr, int mmax);
+bool krylov_small_fits(int P, int ca, int cb, int Dl, int Dr, int mmax, int nb0);
 int launch_krylov_site_small(const SmallKrylovDesc& p, hipStream_t s);
 
 int launch_normsq_partial(const cplx* x, long x_b0, int n, double* part, int nb0, const int* ids, const int* active,

@@ -264,10 +264,15 @@ int launch_tridiag_expm_test(const double* alpha, const double* beta, int k, dou
 // breakdown / adaptive-stop tests of lanczos_finalize_kernel and the final combination follow in the same launch.  Replaces
 // about ten launches and one host synchronisation per Lanczos iteration.
 // ------------------------------------------------------------------------------------------
-constexpr int KS_MAXN = 256;   // P * ca * cb
-constexpr int KS_MAXT = 1536;  // P * ca * D * cb with D <= 6
-constexpr int KS_MAXE = 384;   // ca * D * ca
-constexpr int KS_MAXW = 576;   // (P D)^2
+constexpr int KS_MAXN = 1024;          // P * ca * cb: capacity 16 for a two-site block
+constexpr size_t KS_MAX_LDS = 150 * 1024;  // bytes of dynamic LDS (one workgroup per CU at the upper end)
+constexpr int KS_THROUGHPUT_N = 256;   // up to this block size the kernel also wins with thousands of trajectories in flight
+constexpr int KS_LATENCY_BATCH = 1024; // larger blocks: only while the batch leaves the GEMM path launch-bound
+
+static size_t krylov_small_lds(int P, int ca, int cb, int Dl, int Dr) {
+  const size_t n = (size_t)P * ca * cb + (size_t)P * ca * cb * (Dl + Dr) + (size_t)ca * Dl * ca + (size_t)cb * Dr * cb + (size_t)P * Dl * P * Dr;
+  return n * sizeof(cplx);
+}
 
 __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc p) {
   extern __shared__ double ks_smem[];
@@ -280,9 +285,8 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
   const int P = p.P, ca = p.ca, cb = p.cb, Dl = p.Dl, Dr = p.Dr, m = p.mmax;
   const int N = P * ca * cb, nT1 = P * ca * Dr * cb, nT2 = P * ca * Dl * cb;
   cplx* sX = reinterpret_cast<cplx*>(ks_smem);
-  cplx* sY = sX + N;
-  cplx* sPrev = sY + N;
-  cplx* sT1 = sPrev + N;
+  cplx* sT1 = sX + N;
+  cplx* sY = sT1;  // the product vector overwrites the first intermediate, which is dead by then (nT1 >= N)
   cplx* sT2 = sT1 + nT1;
   cplx* sL = sT2 + nT2;
   cplx* sR = sL + ca * Dl * ca;
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
       w.x = fma(-alpha, x.x, w.x);
       w.y = fma(-alpha, x.y, w.y);
       if (j > 0) {
-        const cplx u = sPrev[e];
+        const cplx u = Vb[(long)(j - 1) * p.v_ld + e];
         w.x = fma(-bprev, u.x, w.x);
         w.y = fma(-bprev, u.y, w.y);
       }
@@ -405,7 +409,6 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
     for (int e = tid; e < N; e += 256) {
       cplx w = sY[e];
       w.x *= invb; w.y *= invb;
-      sPrev[e] = sX[e];
       sX[e] = w;
       Vb[(long)(j + 1) * p.v_ld + e] = w;
     }
@@ -421,23 +424,22 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
   }
 }
 
-bool krylov_small_fits(int P, int ca, int cb, int Dl, int Dr, int mmax) {
+bool krylov_small_fits(int P, int ca, int cb, int Dl, int Dr, int mmax, int nb0) {
   static const bool off = getenv("TJM_NO_SMALL_KRYLOV") != nullptr;
   if (off || mmax > 63) return false;
-  const int D = Dl > Dr ? Dl : Dr;
-  return P * ca * cb <= KS_MAXN && P * ca * D * cb <= KS_MAXT && ca * Dl * ca <= KS_MAXE && cb * Dr * cb <= KS_MAXE && P * Dl * P * Dr <= KS_MAXW;
+  const int N = P * ca * cb;
+  if (N > KS_MAXN || krylov_small_lds(P, ca, cb, Dl, Dr) > KS_MAX_LDS) return false;
+  return N <= KS_THROUGHPUT_N || nb0 <= KS_LATENCY_BATCH;
 }
 
 int launch_krylov_site_small(const SmallKrylovDesc& p, hipStream_t s) {
   if (p.nb0 <= 0) return TJM_OK;
   static bool attr = false;
   if (!attr) {
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(krylov_site_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(krylov_site_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_MAX_LDS));
     attr = true;
   }
-  const size_t n = (size_t)3 * p.P * p.ca * p.cb + (size_t)p.P * p.ca * p.cb * (p.Dl + p.Dr) + (size_t)p.ca * p.Dl * p.ca + (size_t)p.cb * p.Dr * p.cb +
-                   (size_t)p.P * p.Dl * p.P * p.Dr;
-  hipLaunchKernelGGL(krylov_site_small_kernel, dim3(p.nb0), dim3(256), n * sizeof(cplx), s, p);
+  hipLaunchKernelGGL(krylov_site_small_kernel, dim3(p.nb0), dim3(256), krylov_small_lds(p.P, p.ca, p.cb, p.Dl, p.Dr), s, p);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
