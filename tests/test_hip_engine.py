@@ -841,7 +841,7 @@ def test_simulator_normalises_the_initial_state_like_the_reference():
         assert np.allclose(a.trajectories[s][0], r[s], atol=1e-9)
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("TJM_FUZZ_CASES", "32"))))
+@pytest.mark.parametrize("case", range(int(os.environ.get("TJM_FUZZ_CASES", "120"))))
 def test_randomised_configurations_match_oracle(case):
     """Differential test on seeded random set-ups: chain length, bond cap, truncation mode and threshold, TDVP mode and substeps,
     driver order, initial state, and a noise model mixing Pauli / non-Pauli one-site, adjacent two-site (Pauli and custom) and
@@ -896,7 +896,7 @@ def test_randomised_configurations_match_oracle(case):
         assert np.array_equal(d[t], do), (case, t)
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("TJM_FUZZ_CASES", "16"))))
+@pytest.mark.parametrize("case", range(int(os.environ.get("TJM_FUZZ_CASES", "80"))))
 def test_randomised_circuits_match_oracle(case):
     """Differential test of the circuit path on seeded random circuits: random one-qubit unitaries, random two-qubit unitaries on
     adjacent and distant pairs in both site orders, local noise with Pauli / non-Pauli / adjacent two-site / long-range channels,
