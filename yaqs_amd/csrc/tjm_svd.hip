@@ -1517,7 +1517,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   const int ncols32 = round_up(src.ncols, 32);
   // split X / W scheme: 16-column blocks, X rows exactly 256 or 512 (one register layout each), W rows in groups of 64
   const int wrows32 = accumulate ? ncols32 : 0;  // rows of the accumulated unitary stacked under X
-  const bool split16 = !no16 && !no_split && ncols32 >= 32 && (rx_top == 256 || rx_top == 512) && ncols32 % 64 == 0 &&
+  const bool split16 = !no16 && !no_split && ncols32 >= 32 && (rx_top == 128 || rx_top == 256 || rx_top == 512) && ncols32 % 64 == 0 && (rx_top >= 256 || !accumulate) &&
                        (w.rec != nullptr || !accumulate) && src.nb0 <= 65535 && round_up(rx_top + wrows32, 64) <= 64 * MAXRK;
   // fused 16-column blocks for the smaller matrices (two stacked columns per wavefront fit registers and LDS up to 512 rows)
   const bool tile16 = split16 || (!no16 && ncols32 >= 32 && round_up(rx_top + wrows32, 64) <= 512);
@@ -1628,7 +1628,8 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
         TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot], s));
       }
       if (split16) {
-        if (rx_top == 256) hipLaunchKernelGGL(jacobi_cross16x_kernel<4>, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
+        if (rx_top == 128) hipLaunchKernelGGL(jacobi_cross16x_kernel<2>, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
+        else if (rx_top == 256) hipLaunchKernelGGL(jacobi_cross16x_kernel<4>, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
         else hipLaunchKernelGGL(jacobi_cross16x_kernel<8>, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
         if (timed) {  // the timed kernel is the X-rows kernel alone: its tile is the X part of the 32 columns, read + written once
           TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot + 1], s));
