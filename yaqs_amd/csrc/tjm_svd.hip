@@ -1513,11 +1513,13 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   if (src.nb0 <= 0) return TJM_OK;
   static const bool no16 = getenv("TJM_NO_TILE16") != nullptr;
   static const bool no_split = getenv("TJM_NO_SPLIT") != nullptr;
-  const int rx_top = round_up(src.rx, 16);
+  // without the accumulated unitary the X rows are padded to whole 64-row groups (zero rows cost nothing in the dot products and
+  // let the split X kernel serve every height up to 512)
+  const int rx_top = accumulate ? round_up(src.rx, 16) : round_up(src.rx, 64);
   const int ncols32 = round_up(src.ncols, 32);
   // split X / W scheme: 16-column blocks, X rows exactly 256 or 512 (one register layout each), W rows in groups of 64
   const int wrows32 = accumulate ? ncols32 : 0;  // rows of the accumulated unitary stacked under X
-  const bool split16 = !no16 && !no_split && ncols32 >= 32 && (rx_top == 128 || rx_top == 256 || rx_top == 512) && ncols32 % 64 == 0 && (rx_top >= 256 || !accumulate) &&
+  const bool split16 = !no16 && !no_split && ncols32 >= 32 && ((!accumulate && rx_top <= 512) || ((rx_top == 256 || rx_top == 512) && ncols32 % 64 == 0)) &&
                        (w.rec != nullptr || !accumulate) && src.nb0 <= 65535 && round_up(rx_top + wrows32, 64) <= 64 * MAXRK;
   // fused 16-column blocks for the smaller matrices (two stacked columns per wavefront fit registers and LDS up to 512 rows)
   const bool tile16 = split16 || (!no16 && ncols32 >= 32 && round_up(rx_top + wrows32, 64) <= 512);
@@ -1562,6 +1564,9 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_diag_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
     attr_set = true;
   }
@@ -1628,9 +1633,17 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
         TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot], s));
       }
       if (split16) {
-        if (rx_top == 128) hipLaunchKernelGGL(jacobi_cross16x_kernel<2>, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
-        else if (rx_top == 256) hipLaunchKernelGGL(jacobi_cross16x_kernel<4>, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
-        else hipLaunchKernelGGL(jacobi_cross16x_kernel<8>, dim3(npairs, src.nb0), dim3(512), lds16x, s, g);
+        const dim3 gridx(npairs, src.nb0), blockx(512);
+        switch (rx_top / 64) {  // row groups of 64 held in registers
+          case 1: hipLaunchKernelGGL(jacobi_cross16x_kernel<1>, gridx, blockx, lds16x, s, g); break;
+          case 2: hipLaunchKernelGGL(jacobi_cross16x_kernel<2>, gridx, blockx, lds16x, s, g); break;
+          case 3: hipLaunchKernelGGL(jacobi_cross16x_kernel<3>, gridx, blockx, lds16x, s, g); break;
+          case 4: hipLaunchKernelGGL(jacobi_cross16x_kernel<4>, gridx, blockx, lds16x, s, g); break;
+          case 5: hipLaunchKernelGGL(jacobi_cross16x_kernel<5>, gridx, blockx, lds16x, s, g); break;
+          case 6: hipLaunchKernelGGL(jacobi_cross16x_kernel<6>, gridx, blockx, lds16x, s, g); break;
+          case 7: hipLaunchKernelGGL(jacobi_cross16x_kernel<7>, gridx, blockx, lds16x, s, g); break;
+          default: hipLaunchKernelGGL(jacobi_cross16x_kernel<8>, gridx, blockx, lds16x, s, g); break;
+        }
         if (timed) {  // the timed kernel is the X-rows kernel alone: its tile is the X part of the 32 columns, read + written once
           TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot + 1], s));
           g_prof.pending.emplace_back(slot, (double)npairs * n_live * 4.0 * NB * rx_top * sizeof(cplx) * 2.0);
