@@ -98,6 +98,10 @@ class Engine {
   int* opidx_ = nullptr;         // [B]
   int* jsite_ = nullptr;         // [B]
   int* overflow_ = nullptr;      // sticky flag: a truncation was clipped by the storage capacity
+  SmallSiteRef* site_refs_[2] = {nullptr, nullptr};   // device tables of the fused small-bond sweeps
+  SmallSweepStep* sweep_steps_ = nullptr;
+  bool sweep_ok_ = false;
+  int run_sweep(int set, const std::vector<SmallSweepStep>& steps, const int* ids, int nb0);
   cplx* ops_ = nullptr;          // operator table (device)
   cplx* E_ = nullptr;            // [B][chi][chi] moment environment (x2 ping-pong)
   cplx* E2_ = nullptr;

@@ -98,6 +98,7 @@ size_t Engine::workspace_bytes() const {
   // MPO matrices + operator table
   tot += (size_t)(3 * L) * align_up((size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx));
   tot += align_up((size_t)(L + 64) * 16 * sizeof(cplx));
+  tot += align_up((size_t)2 * L * sizeof(SmallSiteRef)) + align_up((size_t)(4 * L + 8) * sizeof(SmallSweepStep));  // fused sweeps
   tot += 1 << 16;
   return tot;
 }
@@ -153,6 +154,8 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   opidx_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   jsite_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   overflow_ = reinterpret_cast<int*>(take(256));
+  for (int st = 0; st < 2; ++st) site_refs_[st] = reinterpret_cast<SmallSiteRef*>(take((size_t)L * sizeof(SmallSiteRef)));
+  sweep_steps_ = reinterpret_cast<SmallSweepStep*>(take((size_t)(4 * L + 8) * sizeof(SmallSweepStep)));
   TJM_HIP_CHECK(hipMemsetAsync(overflow_, 0, 2 * sizeof(int), s));
   E_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
   E2_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
@@ -172,7 +175,31 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   svdw.h_pinned = h_pinned_;
   ws_bytes_ = bytes;
   bound_ = true;
+  // fused small-bond sweeps: every site must fit the one-wavefront kernels in both directions
+  static const bool no_sweeps = getenv("TJM_NO_SWEEP_FUSION") != nullptr;
+  sweep_ok_ = !no_sweeps && d == 2 && L >= 2;
+  for (int i = 0; i < L && sweep_ok_; ++i)
+    sweep_ok_ = svd_shift_small_fits(d, cap[i], cap[i + 1], false) && svd_shift_small_fits(d, cap[i], cap[i + 1], true);
+  for (int st = 0; st < 2; ++st) {
+    std::vector<SmallSiteRef> refs(L);
+    for (int i = 0; i < L; ++i) refs[i] = SmallSiteRef{sets[st].A[i], a_b0_[i], cap[i], cap[i + 1]};
+    TJM_HIP_CHECK(hipMemcpyAsync(site_refs_[st], refs.data(), refs.size() * sizeof(SmallSiteRef), hipMemcpyHostToDevice, stream));
+  }
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
   return TJM_OK;
+}
+
+// One launch for a list of small-bond centre shifts (with optional one-site factors) on set `set`.
+int Engine::run_sweep(int set, const std::vector<SmallSweepStep>& steps, const int* ids, int nb0) {
+  if (steps.empty() || nb0 <= 0) return TJM_OK;
+  if ((int)steps.size() > 4 * L + 8) return TJM_ERR_ARG;
+  TJM_HIP_CHECK(hipMemcpyAsync(sweep_steps_, steps.data(), steps.size() * sizeof(SmallSweepStep), hipMemcpyHostToDevice, stream));
+  SmallSweepDesc q;
+  q.sites = site_refs_[set]; q.steps = sweep_steps_; q.nsteps = (int)steps.size(); q.d = d;
+  q.chi = sets[set].chi; q.chi_stride = L + 1; q.threshold = 1e-12; q.min_keep = 1;
+  q.ids = ids; q.nb0 = nb0; q.flags = overflow_;
+  stat_svds += (long)steps.size();
+  return launch_small_sweep(q, stream);
 }
 
 int Engine::set_mpo(const double* host) {
@@ -1063,6 +1090,63 @@ int Engine::dissipate(int set, double dt_, int start_center) {
   for (size_t k = 0; k < noise_.size(); ++k) any = any || (proc_on_[k] && noise_[k].gamma != 0.0);
   if (!any)  // dissipation.py:79-86: centre to 0 by QR, then QR at site 0 with R discarded = renormalise
     return normalize_qr(set, start_center);
+  if (sweep_ok_) {  // small bonds: the whole sweep in one launch, unless an adjacent non-Pauli pair needs its merged two-site factor
+    std::vector<SmallSweepStep> steps;
+    bool fits = true;
+    for (int i = start_center; i < L - 1; ++i) {
+      SmallSweepStep st{};
+      st.site = i; st.kind = 1; st.op = 0;
+      steps.push_back(st);
+    }
+    for (int i = L - 1; i >= 0 && fits; --i) {
+      double expo = 0.0;
+      bool need_matrix = false, any_one = false;
+      cplx gen[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+      for (int k : one_by_site_[i]) {
+        if (!proc_on_[k]) continue;
+        any_one = true;
+        const NoiseProc& p = noise_[k];
+        if (p.pauli) {
+          gen[0].x += p.gamma; gen[3].x += p.gamma;
+        } else {
+          need_matrix = true;
+          for (int a = 0; a < d; ++a) for (int c = 0; c < d; ++c) {
+            cplx acc{0.0, 0.0};
+            for (int r = 0; r < d; ++r) cfma(acc, cconj(p.mat[r * d + a]), p.mat[r * d + c]);
+            gen[a * d + c] = cadd(gen[a * d + c], cscale(acc, p.gamma));
+          }
+        }
+      }
+      if (any_one && !need_matrix) expo += gen[0].x;
+      if (i != 0)
+        for (int k : two_by_right_[i]) {
+          if (!proc_on_[k]) continue;
+          const NoiseProc& p = noise_[k];
+          if ((p.site1 - p.site0) > 1) {
+            if (!p.pauli) return TJM_ERR_NOT_IMPLEMENTED;  // dissipation.py:136-138
+            expo += p.gamma;
+          } else if (p.pauli) {
+            expo += p.gamma;  // all adjacent processes of this pair must be Pauli for the scalar form (checked below)
+          } else {
+            fits = false;  // merged two-site factor with a truncated split: general path
+          }
+        }
+      if (!fits) break;
+      if (need_matrix) {  // the matrix step first, then the scalar on the same site, then the shift (same order as below)
+        SmallSweepStep sm{};
+        sm.site = i; sm.kind = 0; sm.op = 1;
+        cplx arg[4];
+        for (int q = 0; q < 4; ++q) arg[q] = cscale(gen[q], -0.5 * dt_);
+        small_expm(arg, d, sm.m);
+        steps.push_back(sm);
+      }
+      SmallSweepStep st{};
+      st.site = i; st.kind = (i != 0) ? 2 : 0;
+      if (expo != 0.0) { st.op = 2; st.scal = std::exp(-0.5 * dt_ * expo); }
+      if (st.kind != 0 || st.op != 0) steps.push_back(st);
+    }
+    if (fits) return run_sweep(set, steps, nullptr, B);
+  }
   for (int i = start_center; i < L - 1; ++i)
     if ((rc = svd_shift_right(S, i, nullptr, B)) != TJM_OK) return rc;
   for (int i = L - 1; i >= 0; --i) {

@@ -170,6 +170,21 @@ struct SmallQrDesc {
   const int* ids; int nb0;
 };
 int launch_qr_site_small(const SmallQrDesc& p, bool right, hipStream_t s);
+// A whole sweep of small-bond centre shifts in one kernel (small_sweep_kernel): per step an optional one-site factor on the
+// physical index of `site` (op 1: 2x2 matrix m, op 2: real scalar) followed by a shift of the centre away from `site`
+// (kind 1: SVD to the right, 2: SVD to the left, 3: QR to the right, 4: QR to the left, 0: none).
+struct SmallSiteRef { cplx* A; long b0; int ca, cb; };
+struct SmallSweepStep { int site, kind, op; double scal; cplx m[4]; };
+struct SmallSweepDesc {
+  const SmallSiteRef* sites;     // device [L]
+  const SmallSweepStep* steps;   // device [nsteps]
+  int nsteps, d;
+  int* chi; int chi_stride;      // chi[b * stride + k] = bond k
+  double threshold; int min_keep;
+  const int* ids; int nb0;
+  int* flags;
+};
+int launch_small_sweep(const SmallSweepDesc& p, hipStream_t s);
 bool svd_shift_small_fits(int d, int ca, int cb, bool left);
 // out[b][k*o_k + r1*o_r1 + r0*o_r0] = scale_k * op(Ycol[perm[k]][row_off + r1*n_r0 + r0]) for k < keep, 0 for keep <= k < n_k
 // scale_mode: 0 none, 1 multiply by sigma_k, 2 divide by sigma_k

@@ -988,16 +988,24 @@ __device__ inline void small_absorb(cplx* __restrict__ Nb, const cplx (*G)[SMALL
   }
 }
 
+// LDS of one wavefront of the fused small-bond kernels
+struct SmallLds {
+  cplx Y[SMALL_MAXN][64];
+  cplx G[SMALL_MAXN][SMALL_MAXN];
+  cplx diag[SMALL_MAXN];
+  double norm[SMALL_MAXN];
+  double beta[SMALL_MAXN];
+  int perm[SMALL_MAXN];
+  int keep;
+};
+
 template <bool LEFT>
-__global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p) {
-  __shared__ cplx Y[SMALL_MAXN][64];
-  __shared__ cplx G[SMALL_MAXN][SMALL_MAXN];
-  __shared__ double sNorm[SMALL_MAXN];
-  __shared__ int sPerm[SMALL_MAXN];
-  __shared__ int sKeep;
-  int b = blockIdx.x;
-  if (p.ids) b = p.ids[b];
-  const int lane = threadIdx.x;
+__device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int lane, SmallLds& sm) {
+  cplx (*Y)[64] = sm.Y;
+  cplx (*G)[SMALL_MAXN] = sm.G;
+  double* sNorm = sm.norm;
+  int* sPerm = sm.perm;
+  int& sKeep = sm.keep;
   const int d = p.d, ca = p.ca, cb = p.cb;
   cplx* __restrict__ A = p.site + (long)b * p.site_b0;
   int* chi = p.chi + (long)b * p.chi_stride;
@@ -1103,6 +1111,14 @@ __global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p) {
     }
   }
   small_absorb<LEFT>(p.nb + (long)b * p.nb_b0, G, d, ca, cb, p.cn, n, keep, ncap, lane);
+}
+
+template <bool LEFT>
+__global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p) {
+  __shared__ SmallLds sm;
+  int b = blockIdx.x;
+  if (p.ids) b = p.ids[b];
+  svd_shift_small_body<LEFT>(p, b, threadIdx.x, sm);
 }
 
 // ---- small bonds: the two-site split in one kernel ------------------------------------------------
@@ -1236,14 +1252,11 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
 // place below the diagonal; R into the bond matrix Cm (and, for the shifts, straight into the neighbour); Q = H_0 ... H_{k-1}
 // applied to unit vectors.  Thin-QR bond rule k = min(rows, columns) of np.linalg.qr as in qr_bond_dims_kernel.
 template <bool RIGHT>
-__global__ __launch_bounds__(64) void qr_site_small_kernel(SmallQrDesc p) {
-  __shared__ cplx Z[SMALL_MAXN][64];
-  __shared__ cplx G[SMALL_MAXN][SMALL_MAXN];
-  __shared__ cplx sDiag[SMALL_MAXN];
-  __shared__ double sBeta[SMALL_MAXN];
-  int b = blockIdx.x;
-  if (p.ids) b = p.ids[b];
-  const int lane = threadIdx.x;
+__device__ inline void qr_site_small_body(const SmallQrDesc& p, int b, int lane, SmallLds& sm) {
+  cplx (*Z)[64] = sm.Y;
+  cplx (*G)[SMALL_MAXN] = sm.G;
+  cplx* sDiag = sm.diag;
+  double* sBeta = sm.beta;
   const int d = p.d, ca = p.ca, cb = p.cb;
   cplx* __restrict__ A = p.site + (long)b * p.site_b0;
   int* chi = p.chi + (long)b * p.chi_stride;
@@ -1325,6 +1338,69 @@ __global__ __launch_bounds__(64) void qr_site_small_kernel(SmallQrDesc p) {
     if (lane < R) A[site_index(c)] = q;
   }
   if (p.nb) small_absorb<!RIGHT>(p.nb + (long)b * p.nb_b0, G, d, ca, cb, p.cn, n, kn, ncap, lane);
+}
+
+template <bool RIGHT>
+__global__ __launch_bounds__(64) void qr_site_small_kernel(SmallQrDesc p) {
+  __shared__ SmallLds sm;
+  int b = blockIdx.x;
+  if (p.ids) b = p.ids[b];
+  qr_site_small_body<RIGHT>(p, b, threadIdx.x, sm);
+}
+
+// ---- small bonds: a whole sweep of centre shifts in one kernel -------------------------------------
+// The chain direction is sequential but every trajectory is independent: one wavefront walks its trajectory through the list of
+// steps (local one-site factor of the dissipator, then an SVD or QR shift of the centre), so a dissipation sweep, the QR walk
+// before a jump and the renormalising sweep after it are one launch each instead of one per site.
+__global__ __launch_bounds__(64) void small_sweep_kernel(SmallSweepDesc p) {
+  __shared__ SmallLds sm;
+  int b = blockIdx.x;
+  if (p.ids) b = p.ids[b];
+  const int lane = threadIdx.x;
+  for (int t = 0; t < p.nsteps; ++t) {
+    const SmallSweepStep st = p.steps[t];
+    const SmallSiteRef site = p.sites[st.site];
+    if (st.op != 0) {  // A[s'] = sum_s m[s'][s] A[s]  (d = 2), or a plain scalar
+      cplx* A = site.A + (long)b * site.b0;
+      const long plane = (long)site.ca * site.cb;
+      for (long e = lane; e < plane; e += 64) {
+        const cplx x0 = A[e], x1 = A[plane + e];
+        cplx y0{0.0, 0.0}, y1{0.0, 0.0};
+        if (st.op == 1) {
+          cfma(y0, st.m[0], x0); cfma(y0, st.m[1], x1);
+          cfma(y1, st.m[2], x0); cfma(y1, st.m[3], x1);
+        } else {
+          y0 = cplx{st.scal * x0.x, st.scal * x0.y};
+          y1 = cplx{st.scal * x1.x, st.scal * x1.y};
+        }
+        A[e] = y0;
+        A[plane + e] = y1;
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    if (st.kind == 0) continue;
+    const bool towards_right = (st.kind == 1 || st.kind == 3);
+    const SmallSiteRef nb = p.sites[towards_right ? st.site + 1 : st.site - 1];
+    if (st.kind <= 2) {
+      SmallShiftDesc q;
+      q.site = site.A; q.site_b0 = site.b0; q.nb = nb.A; q.nb_b0 = nb.b0;
+      q.d = p.d; q.ca = site.ca; q.cb = site.cb; q.cn = towards_right ? nb.cb : nb.ca;
+      q.chi = p.chi + st.site; q.chi_stride = p.chi_stride; q.threshold = p.threshold; q.min_keep = p.min_keep;
+      q.ids = nullptr; q.nb0 = 0; q.flags = p.flags;
+      if (towards_right) svd_shift_small_body<false>(q, b, lane, sm);
+      else svd_shift_small_body<true>(q, b, lane, sm);
+    } else {
+      SmallQrDesc q;
+      q.site = site.A; q.site_b0 = site.b0; q.bond = nullptr; q.nb = nb.A; q.nb_b0 = nb.b0;
+      q.d = p.d; q.ca = site.ca; q.cb = site.cb; q.cn = towards_right ? nb.cb : nb.ca;
+      q.chi = p.chi + st.site; q.chi_stride = p.chi_stride; q.nloc = nullptr; q.ids = nullptr; q.nb0 = 0;
+      if (towards_right) qr_site_small_body<true>(q, b, lane, sm);
+      else qr_site_small_body<false>(q, b, lane, sm);
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
 }
 
 // Column norms of the X part, descending rank sort, truncation (svd_utils.py:22-104).
@@ -1453,6 +1529,13 @@ int launch_qr_site_small(const SmallQrDesc& p, bool right, hipStream_t s) {
   if (p.nb0 <= 0) return TJM_OK;
   if (right) hipLaunchKernelGGL(qr_site_small_kernel<true>, dim3(p.nb0), dim3(64), 0, s, p);
   else hipLaunchKernelGGL(qr_site_small_kernel<false>, dim3(p.nb0), dim3(64), 0, s, p);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+int launch_small_sweep(const SmallSweepDesc& p, hipStream_t s) {
+  if (p.nb0 <= 0 || p.nsteps <= 0) return TJM_OK;
+  hipLaunchKernelGGL(small_sweep_kernel, dim3(p.nb0), dim3(64), 0, s, p);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
