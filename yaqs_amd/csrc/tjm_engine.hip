@@ -1023,8 +1023,18 @@ int Engine::normalize_qr(int set, int center) {
   if (!bound_ || center < 0 || center >= L) return TJM_ERR_ARG;
   StateSet& S = sets[set];
   int rc;
-  for (int i = center; i >= 1; --i)
-    if ((rc = qr_shift_left(S, i)) != TJM_OK) return rc;
+  if (sweep_ok_ && center >= 1) {
+    std::vector<SmallSweepStep> steps;
+    for (int i = center; i >= 1; --i) {
+      SmallSweepStep st{};
+      st.site = i; st.kind = 4; st.op = 0;
+      steps.push_back(st);
+    }
+    if ((rc = run_sweep(set, steps, nullptr, B)) != TJM_OK) return rc;
+  } else {
+    for (int i = center; i >= 1; --i)
+      if ((rc = qr_shift_left(S, i)) != TJM_OK) return rc;
+  }
   if ((rc = launch_normsq(S.A[0], a_b0_[0], a_b0_[0], normsq_, B, nullptr, stream)) != TJM_OK) return rc;
   hipLaunchKernelGGL(rsqrt_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, normsq_, scal_, B);
   return launch_scale(S.A[0], a_b0_[0], a_b0_[0], scal_, B, nullptr, nullptr, stream);
@@ -1665,8 +1675,18 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
   // create_probability_distribution (stochastic_process.py:139-176) walks the orthogonality centre 0 -> L-1 by QR on the state
   // itself, so the jump operator meets a LEFT-canonical chain with the centre on the last site.  The weights above do not
   // depend on the gauge, but the truncations of the renormalising sweep below do: reproduce the gauge move.
-  for (int i = 0; i + 1 < L; ++i)
-    if ((rc = qr_shift_right(S, i, ids_, nj)) != TJM_OK) return rc;
+  if (sweep_ok_) {  // small bonds: the whole walk in one launch
+    std::vector<SmallSweepStep> steps;
+    for (int i = 0; i + 1 < L; ++i) {
+      SmallSweepStep st{};
+      st.site = i; st.kind = 3; st.op = 0;
+      steps.push_back(st);
+    }
+    if ((rc = run_sweep(set, steps, ids_, nj)) != TJM_OK) return rc;
+  } else {
+    for (int i = 0; i + 1 < L; ++i)
+      if ((rc = qr_shift_right(S, i, ids_, nj)) != TJM_OK) return rc;
+  }
   TJM_HIP_CHECK(hipMemcpyAsync(opidx_, opi.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
   TJM_HIP_CHECK(hipMemcpyAsync(jsite_, js.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL(apply_local_multi_kernel, dim3(64, nj), dim3(256), 0, stream, d_sp, d_sb, d_sr, d, ops_, opidx_, jsite_, ids_);
@@ -1706,6 +1726,17 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
     }
     std::vector<int> lst_short, lst_full;
     int* ids_full = opidx_;  // the operator-index table is no longer needed: reuse it as the second id list
+    bool any_broken = false;
+    for (int b : jumped) any_broken = any_broken || broken[b] >= 0;
+    if (sweep_ok_ && !any_broken) {  // small bonds, unitary jumps only: every pair is a plain centre shift - one launch
+      std::vector<SmallSweepStep> steps;
+      for (int i = L - 1; i >= 1; --i) {
+        SmallSweepStep st{};
+        st.site = i; st.kind = 2; st.op = 0;
+        steps.push_back(st);
+      }
+      if ((rc = run_sweep(set, steps, ids_, nj)) != TJM_OK) return rc;
+    } else
     for (int i = L - 1; i >= 1; --i) {
       lst_short.clear();
       lst_full.clear();
