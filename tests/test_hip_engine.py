@@ -751,7 +751,7 @@ def test_general_kernels_still_serve_small_bonds():
 
     from conftest import ROOT
 
-    env = dict(os.environ, TJM_NO_SMALL_SHIFT="1", TJM_NO_SMALL_KRYLOV="1", TJM_NO_LDS_JACOBI="1", TJM_FUZZ_CASES="10")
+    env = dict(os.environ, TJM_NO_SMALL_SHIFT="1", TJM_NO_SMALL_KRYLOV="1", TJM_NO_LDS_JACOBI="1", TJM_NO_SWEEP_FUSION="1", TJM_FUZZ_CASES="10")
     out = subprocess.run([sys.executable, "-m", "pytest", "tests/test_hip_engine.py", "-m", "gpu", "-x", "-q", "-k",
                           "randomised_configurations or randomised_circuits or tiny_chains"], cwd=ROOT, env=env, capture_output=True, text=True,
                          timeout=1500)

@@ -102,6 +102,7 @@ class Engine {
   SmallSweepStep* sweep_steps_ = nullptr;
   bool sweep_ok_ = false;
   int run_sweep(int set, const std::vector<SmallSweepStep>& steps, const int* ids, int nb0);
+  int qr_walk(int set, int from, int to);
   cplx* ops_ = nullptr;          // operator table (device)
   cplx* E_ = nullptr;            // [B][chi][chi] moment environment (x2 ping-pong)
   cplx* E2_ = nullptr;

@@ -1049,6 +1049,29 @@ int Engine::apply_single(int set, int site, const double* host_mat) {
   return launch_apply_local(S.A[site], a_b0_[site], d, (long)cap[site] * cap[site + 1], ops_ + (size_t)(L + 2) * 16, nullptr, B, nullptr, stream);
 }
 
+// QR shifts of the centre from site `from` to site `to` (either direction) on the whole batch: one launch at small bonds.
+int Engine::qr_walk(int set, int from, int to) {
+  StateSet& S = sets[set];
+  int rc;
+  if (from == to) return TJM_OK;
+  if (sweep_ok_) {
+    std::vector<SmallSweepStep> steps;
+    if (from < to)
+      for (int i = from; i < to; ++i) { SmallSweepStep st{}; st.site = i; st.kind = 3; steps.push_back(st); }
+    else
+      for (int i = from; i > to; --i) { SmallSweepStep st{}; st.site = i; st.kind = 4; steps.push_back(st); }
+    return run_sweep(set, steps, nullptr, B);
+  }
+  if (from < to) {
+    for (int i = from; i < to; ++i)
+      if ((rc = qr_shift_right(S, i)) != TJM_OK) return rc;
+  } else {
+    for (int i = from; i > to; --i)
+      if ((rc = qr_shift_left(S, i)) != TJM_OK) return rc;
+  }
+  return TJM_OK;
+}
+
 // apply_two_qubit_gate_tebd (digital_tjm.py:455-533) for a nearest-neighbour gate on (left, left+1), from a state with
 // centre `center`: QR shifts put the centre on the pair, then merge, gate, truncated split to the right (min_keep = min(2, chi));
 // the centre ends on left + 1.
@@ -1057,13 +1080,8 @@ int Engine::tebd_gate(int set, int left, const double* host_u, int center) {
   StateSet& S = sets[set];
   int rc;
   // shift_center_to(left) unless the centre already sits on the pair (digital_tjm.py:503-506); QR shifts only move the gauge
-  if (center < left) {
-    for (int i = center; i < left; ++i)
-      if ((rc = qr_shift_right(S, i)) != TJM_OK) return rc;
-  } else if (center > left + 1) {
-    for (int i = center; i > left; --i)
-      if ((rc = qr_shift_left(S, i)) != TJM_OK) return rc;
-  }
+  if (center < left || center > left + 1)
+    if ((rc = qr_walk(set, center, left)) != TJM_OK) return rc;
   TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 4) * 16, host_u, 16 * sizeof(cplx), hipMemcpyHostToDevice, stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
   const int mk = (max_bond > 0) ? std::min(2, max_bond) : 2;
@@ -1084,11 +1102,7 @@ int Engine::apply_pair(int set, int left, const double* host_u, int min_keep) {
 // any gauge (the sweep of normalize("B") / set_canonical_form, mps.py:790-839); ||A_0||^2 is then the squared norm of the state.
 int Engine::canonicalize_qr(int set, int center) {
   if (!bound_ || center < 0 || center >= L) return TJM_ERR_ARG;
-  StateSet& S = sets[set];
-  int rc;
-  for (int i = center; i >= 1; --i)
-    if ((rc = qr_shift_left(S, i)) != TJM_OK) return rc;
-  return TJM_OK;
+  return qr_walk(set, center, 0);
 }
 
 int Engine::dissipate(int set, double dt_, int start_center) {
