@@ -9,6 +9,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, ".")
+import torch  # noqa: E402,F401  (loaded before the timed region)
+
 import yaqs_amd.tjm as tjm  # noqa: E402
 from yaqs_amd.api import DigitalSimParams, MPS, NoiseModel, Observable, Z, ising_trotter_layers  # noqa: E402
 

@@ -32,6 +32,8 @@ if args.check:  # before torch / HIP are loaded
     cpu = [o.run_trajectory(t, o.MPSState.product(L, "x+"), on, op, o.ising_mpo(L, 1.0, 0.5)) for t in range(args.check)]
     cpu_s = (time.perf_counter() - t0) / args.check
 
+import torch  # noqa: E402,F401  (loaded before the timed region)
+
 import yaqs_amd.tjm as tjm  # noqa: E402
 from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z  # noqa: E402
 
