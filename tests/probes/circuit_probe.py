@@ -1,7 +1,7 @@
 """Config-5-like circuit run: 20 Trotter layers of the 64-site Ising circuit, depolarising noise (pauli_x/y/z,
 gamma = 0.001 each on every site, applied after each two-qubit gate on that gate's sites), max_bond_dim = 512, svd_threshold 1e-9,
 fp64.  With a 4th argument N the first N trajectories also run through the oracle on one host core each (timed, compared).
-Usage: python tools/circuit_probe.py [L] [num_traj] [layers] [check]"""
+Usage: python tests/probes/circuit_probe.py [L] [num_traj] [layers] [check]"""
 import json
 import sys
 import time

@@ -2,7 +2,7 @@
 site, max_bond_dim 128, dt = 0.1, 10 steps, svd_threshold 1e-12, krylov_tol 1e-4, order 1, final-time sampling - bonds grow from 1,
 so this exercises the capacity-on-demand path end to end.  With --check N the first N trajectories are also run through the
 oracle on the host (single core each, timed) and compared.
-Usage: python tools/physics_probe.py [num_traj] [--check N] [--threshold 1e-12] [--steps 10]"""
+Usage: python tests/probes/physics_probe.py [num_traj] [--check N] [--threshold 1e-12] [--steps 10]"""
 import argparse
 import json
 import sys
