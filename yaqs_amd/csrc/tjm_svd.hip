@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
 // wave-uniform parameters and compile-time column indices.
 constexpr int REC_PER_VISIT = 2 * NB * 2 * NB;  // 8 steps x 2 sub-steps x 8 wavefronts x 2 pairs = 256 rotations
 
-// XRK = row groups of 64 of the X part: 4 (rx_top == 256, d*chi = 256) or 8 (rx_top == 512)
+// XRK = row groups of 64 of the X part held in registers: 1 ... 8 (rx_top = 64 XRK; 4 at d*chi = 256)
 template <int XRK>
 __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kernel(JacobiArgs g) {
   extern __shared__ double smem[];
@@ -1600,7 +1600,8 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   // let the split X kernel serve every height up to 512)
   const int rx_top = accumulate ? round_up(src.rx, 16) : round_up(src.rx, 64);
   const int ncols32 = round_up(src.ncols, 32);
-  // split X / W scheme: 16-column blocks, X rows exactly 256 or 512 (one register layout each), W rows in groups of 64
+  // split X / W scheme: 16-column blocks; X rows in whole groups of 64 up to 512 (with the accumulated unitary: exactly 256 or 512
+  // and W rows in groups of 64)
   const int wrows32 = accumulate ? ncols32 : 0;  // rows of the accumulated unitary stacked under X
   const bool split16 = !no16 && !no_split && ncols32 >= 32 && ((!accumulate && rx_top <= 512) || ((rx_top == 256 || rx_top == 512) && ncols32 % 64 == 0)) &&
                        (w.rec != nullptr || !accumulate) && src.nb0 <= 65535 && round_up(rx_top + wrows32, 64) <= 64 * MAXRK;
