@@ -18,7 +18,7 @@ def _free_port():
 def _worker(rank, world, port, out_dir):
     import torch.distributed as dist
 
-    from yaqs_amd.tjm import gather_trajectories, shard_range
+    from yaqs_amd.tjm import gather_counts, gather_trajectories, shard_range
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -29,6 +29,11 @@ def _worker(rank, world, port, out_dir):
     res = np.stack([np.full((n_obs, T), float(t)) + np.arange(T) for t in range(lo, hi)]) if hi > lo else np.zeros((0, n_obs, T))
     diag = np.stack([np.full((3, T), 10.0 * t) for t in range(lo, hi)]) if hi > lo else np.zeros((0, 3, T))
     full_r, full_d = gather_trajectories(res, diag, num_traj, lo, "cpu")
+    # measurement histograms of the circuit path: basis states are L-bit Python integers, ranks hold different (possibly no) keys
+    mine = {0: {5: 2, (1 << 70) + 3: 1}, 1: {5: 4, 9: 7}}[rank]
+    total = gather_counts(mine, "cpu")
+    assert total == {5: 6, (1 << 70) + 3: 1, 9: 7}, total
+    assert gather_counts({}, "cpu") == {}
     np.save(os.path.join(out_dir, f"r{rank}.npy"), full_r)
     np.save(os.path.join(out_dir, f"d{rank}.npy"), full_d)
     dist.destroy_process_group()
@@ -43,3 +48,48 @@ def test_sharded_trajectories_allreduce_gloo(tmp_path):
     for rank in range(world):
         assert np.array_equal(np.load(tmp_path / f"r{rank}.npy"), expect_r)
         assert np.array_equal(np.load(tmp_path / f"d{rank}.npy"), expect_d)
+
+
+def _gpu_worker(rank, world, port, out_dir):
+    """Two gloo ranks on the one GPU of the test box: the sharding, the all-reduce of the rows and the histogram gather of
+    Simulator.run / run_circuit end to end (the collectives run on CPU tensors under gloo, the trajectories on the GPU)."""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res, cres = _sharded_case()
+    np.save(os.path.join(out_dir, f"a{rank}.npy"), np.stack(res.trajectories))
+    np.save(os.path.join(out_dir, f"c{rank}.npy"), np.stack(cres.trajectories))
+    np.save(os.path.join(out_dir, f"k{rank}.npy"), np.array(sorted(cres.counts.items()), dtype=np.int64))
+    dist.destroy_process_group()
+
+
+def _sharded_case():
+    from yaqs_amd.api import AnalogSimParams, DigitalSimParams, MPO, MPS, NoiseModel, Observable, Z, ising_trotter_layers
+    from yaqs_amd.tjm import Simulator
+
+    L = 6
+    noise = NoiseModel([{"name": "lowering", "sites": [i], "strength": 0.2} for i in range(L)])
+    obs = [Observable(Z(), s) for s in range(L)]
+    p = AnalogSimParams(observables=obs, elapsed_time=0.3, dt=0.1, num_traj=7, max_bond_dim=8, svd_threshold=1e-10, random_seed=4)
+    sim = Simulator(device="cuda:0")
+    res = sim.run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p, noise)
+    dp = DigitalSimParams(observables=obs, num_traj=5, shots=35, max_bond_dim=8, svd_threshold=1e-10, random_seed=4)
+    cres = sim.run_circuit(MPS(L, state="zeros"), ising_trotter_layers(L, 1.0, 0.5, 0.1, 3), dp, noise)
+    return res, cres
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_trajectories_on_the_gpu(tmp_path):
+    world = 2
+    mp.spawn(_gpu_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res, cres = _sharded_case()  # the same runs in one process
+    for rank in range(world):
+        assert np.allclose(np.load(tmp_path / f"a{rank}.npy"), np.stack(res.trajectories), atol=1e-12)
+        assert np.allclose(np.load(tmp_path / f"c{rank}.npy"), np.stack(cres.trajectories), atol=1e-12)
+        assert np.array_equal(np.load(tmp_path / f"k{rank}.npy"), np.array(sorted(cres.counts.items()), dtype=np.int64))
+    assert sum(cres.counts.values()) == 35

@@ -550,7 +550,11 @@ class Simulator:
 
     def run_circuit(self, initial_state: MPS, layers, sim_params, noise_model: NoiseModel | None = None, basis: str = "Z"):
         """Circuit runs (simulator.py:1681-1830 with gate layers instead of a qiskit circuit): observables, diagnostics and, with
-        ``sim_params.shots``, the measurement histogram.  Single rank; trajectories in chunks of ``batch``."""
+        ``sim_params.shots``, the measurement histogram.  Trajectories in chunks of ``batch``; with ``torch.distributed``
+        initialised they are sharded contiguously over the ranks, and the per-trajectory rows and the histogram are combined at the
+        end."""
+        import torch
+
         from .api import CircuitResult
 
         if noise_model is not None:
@@ -567,10 +571,16 @@ class Simulator:
         counts: dict[int, int] = {}
         wants_shots = sim_params.shots is not None
         identity_mpo = [np.eye(2, dtype=np.complex128).reshape(2, 2, 1, 1)] * initial_state.length  # the circuit path never applies it
+        rank, world = 0, 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        first, last = shard_range(num_traj, rank, world)
+        res_all = res_all[: last - first]
+        diag_all = diag_all[: last - first]
         done = 0
-        while done < num_traj:
-            B = self._batch_for(num_traj - done, initial_state.length, chi, identity_mpo, device)
-            chunk = list(range(done, min(done + B, num_traj)))
+        while done < last - first:
+            B = self._batch_for(last - first - done, initial_state.length, chi, identity_mpo, device)
+            chunk = list(range(first + done, first + min(done + B, last - first)))
             spt = [shots_for_trajectory(t, per_call, distribution) for t in chunk] if wants_shots else None
 
             def run_piece(db, lo_, hi_, resume, chunk=chunk, spt=spt):
@@ -584,6 +594,10 @@ class Simulator:
             res_all[done: done + len(chunk)] = r
             diag_all[done: done + len(chunk)] = dg
             done += len(chunk)
+        if world > 1:
+            res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, first, device)
+            if wants_shots:
+                counts = gather_counts(counts, device)
         return CircuitResult(sim_params, res_all, diag_all, counts if wants_shots else None)
 
 
@@ -673,6 +687,25 @@ def shots_for_trajectory(traj: int, per_call, distribution) -> int:
 def shard_range(num_traj: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous trajectory-index range of ``rank``."""
     return (num_traj * rank) // world, (num_traj * (rank + 1)) // world
+
+
+def gather_counts(counts: dict, device) -> dict:
+    """Sum of the per-rank measurement histograms {basis state: occurrences}.  The keys are Python integers of L bits (more than 64
+    on long chains), so the tables travel as objects."""
+    import contextlib
+
+    import torch
+    import torch.distributed as dist
+
+    parts = [None] * dist.get_world_size()
+    ctx = torch.cuda.device(torch.device(device)) if dist.get_backend() == "nccl" else contextlib.nullcontext()
+    with ctx:  # the object collectives of the nccl backend stage through the current device
+        dist.all_gather_object(parts, dict(counts))
+    total: dict[int, int] = {}
+    for part in parts:
+        for key, val in part.items():
+            total[int(key)] = total.get(int(key), 0) + int(val)
+    return total
 
 
 def gather_trajectories(res: np.ndarray, diag: np.ndarray, num_traj: int, lo: int, device):
