@@ -160,3 +160,78 @@ def test_simulation_presets_are_the_reference_table():
     q = AnalogSimParams(observables=[], preset="exact", max_bond_dim=7)
     assert (q.max_bond_dim, q.svd_threshold) == (7, 1e-13)
     assert AnalogSimParams(observables=[], preset="accurate", max_bond_dim=None).max_bond_dim is None
+
+
+def test_capacity_ladder_and_bounds():
+    """Host logic of the storage capacity (yaqs_amd/tjm.py): first capacity, the largest one a run can need, the ladder."""
+    from yaqs_amd.api import AnalogSimParams, MPS
+    from yaqs_amd.tjm import CAPACITY_LADDER, MAX_CHI, engine_bond_caps, grown_capacity
+
+    p = AnalogSimParams(observables=[], max_bond_dim=4096)
+    assert engine_bond_caps(p, MPS(40, state="x+")) == (8, 4096)
+    assert engine_bond_caps(p, MPS(6, state="x+")) == (8, 8)            # 2**(L//2) bounds every bond of a short chain
+    assert engine_bond_caps(AnalogSimParams(observables=[], max_bond_dim=None), MPS(12, state="x+")) == (8, 64)
+    assert engine_bond_caps(AnalogSimParams(observables=[], max_bond_dim=4), MPS(12, state="x+")) == (4, 4)
+    assert engine_bond_caps(AnalogSimParams(observables=[], max_bond_dim=64, tdvp_mode="1site"), MPS(12, state="x+", pad=32))[0] == 32
+    chi, seen = 8, [8]
+    while chi < 200:
+        chi = grown_capacity(chi, 200)
+        seen.append(chi)
+    assert seen == [c for c in CAPACITY_LADDER if c < 200] + [200]
+    with pytest.raises(NotImplementedError):
+        grown_capacity(MAX_CHI, 4096)
+    with pytest.raises(RuntimeError):
+        grown_capacity(16, 16)
+
+
+def test_growing_run_bookkeeping_without_a_gpu(monkeypatch):
+    """Simulator._run_growing with stand-in engines: a piece that runs out of capacity at step j hands its rows, cursors and
+    measured columns to larger engines, is split when those hold fewer trajectories, and every source engine is closed once its
+    last successor has taken over."""
+    import yaqs_amd.tjm as tjm_mod
+    from yaqs_amd._lib import CapacityError
+
+    log = {"built": [], "closed": [], "adopted": []}
+
+    class FakeEngine:
+        def __init__(self, length, chi_max, batch, mpo, device=None):
+            self.chi_max, self.B, self.rows = chi_max, batch, None
+            log["built"].append((chi_max, batch))
+
+        def adopt(self, src, first):
+            self.rows = src.rows[first: first + self.B]
+            log["adopted"].append((src.chi_max, self.chi_max, first, self.B))
+
+        def close(self):
+            log["closed"].append((self.chi_max, self.B))
+
+    monkeypatch.setattr(tjm_mod, "BatchEngine", FakeEngine)
+    monkeypatch.setattr(tjm_mod.Simulator, "_batch_for", lambda self, remaining, length, chi, mpo, device: min(remaining, {8: 6, 16: 4, 24: 2}[chi]))
+    n_steps = 6
+    need = {0: 8, 1: 8, 2: 16, 3: 16, 4: 24, 5: 24}  # capacity that time step j needs
+
+    def run_piece(engine, lo, hi, resume):
+        rows = list(range(lo, hi))
+        engine.rows = rows
+        start = 0 if resume is None else resume["start"][0]
+        res = np.zeros((hi - lo, 1, n_steps)) if resume is None else resume["results"]
+        dg = np.zeros((hi - lo, 3, n_steps)) if resume is None else resume["diagnostics"]
+        pos = np.zeros(hi - lo, dtype=np.int64) if resume is None else np.asarray(resume["rng_pos"]).copy()
+        if resume is not None:
+            assert list(pos) == [start * (t + 1) for t in rows]  # the cursors travelled with their trajectories
+        for j in range(start, n_steps):
+            if need[j] > engine.chi_max:
+                err = CapacityError("clipped")
+                err.resume, err.rng_pos, err.results, err.diagnostics = ((j, 0) if j > 0 else (0, 0)), pos, res, dg
+                raise err
+            res[:, 0, j] = [100 * t + j for t in rows]
+            pos += np.array([t + 1 for t in rows])
+        return res, dg
+
+    sim = tjm_mod.Simulator()
+    res, dg, kept = sim._run_growing(list(range(6)), 8, 64, 10, None, lambda e: e, run_piece, "cpu", n_steps, 1)
+    assert kept is None
+    assert np.array_equal(res[:, 0, :], np.array([[100 * t + j for j in range(n_steps)] for t in range(6)]))
+    assert log["built"][0] == (8, 6) and sorted(c for c, _ in log["built"]) == [8, 16, 16, 24, 24, 24]
+    assert sorted(log["closed"]) == sorted(log["built"])           # nothing leaks
+    assert all(a[0] < a[1] for a in log["adopted"]) and len(log["adopted"]) == 5
