@@ -759,6 +759,53 @@ def test_general_kernels_still_serve_small_bonds():
     assert " passed" in out.stdout
 
 
+def _channel_switch_points(noise, chi, u2):
+    """One forced jump per trajectory from |00> (dissipation with dt = 1, then a jump test with u1 = 0) with the channel draw u2:
+    returns <Z_0> after the jump, from which the chosen channel can be read."""
+    from yaqs_amd.api import MPO, MPS, is_pauli
+
+    L = 2
+    st = MPS(L, state="zeros")
+    e = make_engine(L, chi, len(u2), MPO.ising(L, 1.0, 0.5).tensors)
+    try:
+        e.set_params(dt=1.0, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=1e-10)
+        e.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
+        e.load_state(st.tensors, 0)
+        e.dissipate(1.0)
+        e.set_uniforms(np.stack([np.zeros(len(u2)), np.asarray(u2)], axis=1))
+        jumped, dp = e.stochastic(1.0)
+        assert np.all(jumped == 1) and np.all(dp > 0.5)
+        m = e.site_moments(0)
+        return np.real(m[0, :, 0, 0] - m[0, :, 1, 1])
+    finally:
+        e.close()
+
+
+def test_channel_weights_of_the_reference_known_answer_tests():
+    """tests/core/methods/test_stochastic_process.py:264-297 of the reference, through the engine: X on site 0 and 2 I on the pair
+    (0, 1) at equal rates from |00> have weights ||X|0>||^2 : ||2 I |00>||^2 = 1 : 4, i.e. [0.2, 0.8]; rng.choice switches channel
+    where the draw crosses the cumulative weight (searchsorted, side = "right").  The xx / Bell-creation pair has [0.5, 0.5] - the
+    weight of an adjacent non-Pauli channel is the Frobenius norm of the UNTRUNCATED block."""
+    from yaqs_amd.api import NoiseModel
+
+    u2 = np.array([0.0, 0.1, 0.19, 0.1999999, 0.2000001, 0.21, 0.5, 0.8, 0.999])
+    noise = NoiseModel([{"name": "pauli_x", "sites": [0], "strength": 1.0},
+                        {"name": "scaled_i", "sites": [0, 1], "strength": 1.0, "matrix": 2.0 * np.eye(4, dtype=np.complex128)}])
+    z0 = _channel_switch_points(noise, 2, u2)
+    assert np.allclose(z0, np.where(u2 < 0.2, -1.0, 1.0), atol=1e-10), z0  # X flips qubit 0, 2 I leaves |00>
+    xx = np.kron(np.array([[0, 1], [1, 0]]), np.array([[0, 1], [1, 0]])).astype(np.complex128)
+    bell = np.zeros((4, 4), dtype=np.complex128)
+    bell[:, 0] = [1 / np.sqrt(2), 0, 0, 1 / np.sqrt(2)]
+    bell[:, 1] = [0, 1, 0, 0]
+    bell[:, 2] = [0, 0, 1, 0]
+    bell[:, 3] = [1 / np.sqrt(2), 0, 0, -1 / np.sqrt(2)]
+    noise = NoiseModel([{"name": "xx", "sites": [0, 1], "strength": 1.0, "matrix": xx},
+                        {"name": "bell", "sites": [0, 1], "strength": 1.0, "matrix": bell}])
+    u2 = np.array([0.0, 0.3, 0.4999999, 0.5000001, 0.7, 0.999])
+    z0 = _channel_switch_points(noise, 2, u2)
+    assert np.allclose(z0, np.where(u2 < 0.5, -1.0, 0.0), atol=1e-10), z0  # xx |00> = |11>;  Bell state: <Z_0> = 0
+
+
 def test_capacity_overflow_is_reported_by_the_engine_and_the_driver():
     """A two-site truncation that wants more values than the new bond stores sets the engine's flag (and only such a one), and
     tjm_engine_run stops after that time step with TJM_ERR_CAPACITY instead of finishing a run that is not the reference's."""
