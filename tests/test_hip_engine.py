@@ -806,6 +806,44 @@ def test_channel_weights_of_the_reference_known_answer_tests():
     assert np.allclose(z0, np.where(u2 < 0.5, -1.0, 0.0), atol=1e-10), z0  # xx |00> = |11>;  Bell state: <Z_0> = 0
 
 
+@pytest.mark.parametrize("entangled", [False, True])
+def test_jump_probability_after_dissipation_matches_the_dense_master_equation_step(entangled):
+    """tests/analog/test_analog_tjm.py:257-279 of the reference: for lowering noise on every site (H = 0) the norm lost in the
+    dissipative sweep, dp = 1 - ||psi||^2, is the jump probability of one dense quantum-jump step, 1 - ||exp(-dt/2 sum gamma
+    L^dag L) psi||^2 - from the product state |1...1> and from an entangled state (one TDVP step of the Ising chain).  The
+    reference allows 5e-4; the one-site dissipators commute, so the two agree to rounding."""
+    import scipy.linalg
+
+    from yaqs_amd.api import MPO, MPS, NoiseModel, is_pauli
+
+    L, dt, gamma = 5, 0.05, 1.0
+    st = o.MPSState.product(L, "ones")
+    if entangled:
+        o.tdvp(st, o.ising_mpo(L, 1.0, 0.5), o.Params(elapsed_time=0.0, dt=dt, max_bond_dim=64, svd_threshold=1e-10))
+    psi = st.to_vec()
+    psi = psi / np.linalg.norm(psi)
+    lower = np.array([[0, 1], [0, 0]], dtype=np.complex128)
+    local = scipy.linalg.expm(-0.5 * dt * gamma * lower.conj().T @ lower)
+    prop = np.array([[1.0]])
+    for _ in range(L):
+        prop = np.kron(prop, local)
+    p_dense = 1.0 - np.linalg.norm(prop @ psi) ** 2
+    noise = NoiseModel([{"name": "lowering", "sites": [i], "strength": gamma} for i in range(L)])
+    tensors = [t.copy() for t in st.tensors]
+    e = make_engine(L, 8, 2, MPO.ising(L, 1.0, 0.5).tensors)
+    try:
+        e.set_params(dt=dt, svd_threshold=1e-10, max_bond_dim=8, krylov_tol=1e-10)
+        e.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
+        e.load_state(MPS(L, tensors=tensors).tensors, 0)
+        e.dissipate(dt)
+        e.set_uniforms(np.ones((2, 2)))  # u = 1 >= dp: no jump, dp is only read
+        jumped, dp = e.stochastic(dt)
+    finally:
+        e.close()
+    assert not jumped.any()
+    assert p_dense > 0.1 and np.allclose(dp, p_dense, rtol=0.0, atol=1e-10), (dp, p_dense)
+
+
 def test_capacity_overflow_is_reported_by_the_engine_and_the_driver():
     """A two-site truncation that wants more values than the new bond stores sets the engine's flag (and only such a one), and
     tjm_engine_run stops after that time step with TJM_ERR_CAPACITY instead of finishing a run that is not the reference's."""
