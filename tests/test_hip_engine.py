@@ -844,6 +844,47 @@ def test_jump_probability_after_dissipation_matches_the_dense_master_equation_st
     assert p_dense > 0.1 and np.allclose(dp, p_dense, rtol=0.0, atol=1e-10), (dp, p_dense)
 
 
+@pytest.mark.parametrize("adjacent", [False, True])
+def test_noncommuting_channels_use_one_exponential_of_the_summed_generator(adjacent):
+    """tests/core/methods/test_dissipation.py:212-295 of the reference, through the engine: two channels on the same site (or the
+    same adjacent pair) whose L^dag L do not commute are applied as ONE expm(-dt/2 sum gamma L^dag L), independent of their order
+    in the noise model; the dissipated two-site state equals the dense result."""
+    import scipy.linalg
+
+    from yaqs_amd.api import MPO, MPS, NoiseModel, is_pauli
+
+    lowering = np.array([[0, 1], [0, 0]], dtype=np.complex128)
+    mixed = np.array([[0, 1], [1, 1]], dtype=np.complex128)
+    eye = np.eye(2, dtype=np.complex128)
+    la, lb = (np.kron(lowering, eye), np.kron(mixed, eye)) if adjacent else (lowering, mixed)
+    a, b = la.conj().T @ la, lb.conj().T @ lb
+    assert not np.allclose(a @ b, b @ a)
+    gamma_a, gamma_b, dt = 0.4, 0.3, 0.2
+    sites = [0, 1] if adjacent else [0]
+    fwd = [{"name": "a", "sites": sites, "strength": gamma_a, "matrix": la}, {"name": "b", "sites": sites, "strength": gamma_b, "matrix": lb}]
+    amp = np.array([1 / np.sqrt(2), 1 / np.sqrt(2)], dtype=np.complex128)
+    t0 = amp.reshape(2, 1, 1)
+    t1 = (amp if adjacent else np.array([1.0, 0.0], dtype=np.complex128)).reshape(2, 1, 1)
+    vec = np.kron(amp, t1.reshape(2))
+    gen = gamma_a * a + gamma_b * b
+    expected = (scipy.linalg.expm(-0.5 * dt * gen) @ vec) if adjacent else np.kron(scipy.linalg.expm(-0.5 * dt * gen) @ amp, t1.reshape(2))
+    got = []
+    for procs in (fwd, fwd[::-1]):
+        noise = NoiseModel(procs)
+        e = make_engine(2, 4, 1, MPO.ising(2, 1.0, 0.5).tensors)
+        try:
+            e.set_params(dt=dt, svd_threshold=1e-14, max_bond_dim=4, krylov_tol=1e-10)
+            e.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
+            e.load_state(MPS(2, tensors=[t0.copy(), t1.copy()]).tensors, 0)
+            e.dissipate(dt)
+            ts = e.export_state(0, 0)
+        finally:
+            e.close()
+        got.append(np.einsum("alr,brc->ab", ts[0], ts[1]).reshape(-1))
+    assert np.allclose(got[0], got[1], atol=1e-12)
+    assert np.allclose(got[0], expected, atol=1e-10), (got[0], expected)
+
+
 def test_capacity_overflow_is_reported_by_the_engine_and_the_driver():
     """A two-site truncation that wants more values than the new bond stores sets the engine's flag (and only such a one), and
     tjm_engine_run stops after that time step with TJM_ERR_CAPACITY instead of finishing a run that is not the reference's."""
