@@ -375,6 +375,41 @@ def test_truncation_known_answers_of_the_reference(lib, svs, mode, thr, expected
         assert np.allclose(spec[0, : len(svs)], svs, atol=1e-13)
 
 
+@pytest.mark.parametrize("svs,mode,thr,max_bond,min_keep,expected", [
+    ([10.0, 3.0, 1.0, 0.5], 0, 10.0, 0, 1, 2),             # discarded_weight: 0.25 + 1 < 10 <= 0.25 + 1 + 9
+    ([2.0, 1.0, 0.4], 1, 0.45, 0, 1, 2),                   # relative: 0.5 >= 0.45 > 0.2
+    ([5.0, 2.0, 0.5, 0.1], 2, 0.2, 0, 1, 3),               # hard_cutoff: s > 0.2
+    ([5.0, 2.0, 0.5, 0.1], 2, 0.2, 2, 1, 2),               # ... capped by max_bond_dim
+    ([10.0, 1.0, 0.1, 0.01], 3, 1e-3, 0, 1, 2),            # relative_discarded_weight: (0.01 + 0.0001) / 101.0101 <= 1e-3 < 1.0101 / 101.0101
+    ([10.0, 1.0, 0.1, 0.01], 3, 0.02, 0, 1, 1),
+    ([4.0, 2.0, 0.5, 0.1], 3, 0.05, 0, 1, 2),              # (0.25 + 0.01) / 20.26 <= 0.05 < 4.26 / 20.26
+])
+def test_truncation_modes_hand_computed_cases_of_the_reference(lib, svs, mode, thr, max_bond, min_keep, expected):
+    """tests/core/linalg/test_svd_utils.py:20-80 of the reference (all four truncation modes, max_bond_dim, min_keep) through the
+    GPU split: the spectrum is planted in a random two-site block; one-kernel and general paths.  (The reference's threshold-0 case
+    needs exactly zero trailing values, which no factorisation of a matrix returns; it stays an oracle-level test.)"""
+    rng = np.random.default_rng(23)
+    d, capL, capR = 2, 3, 3
+    m, n = d * capL, d * capR
+    s = np.zeros(min(m, n))
+    s[: len(svs)] = svs
+    u = np.linalg.qr(crand(rng, m, m))[0]
+    v = np.linalg.qr(crand(rng, n, n))[0]
+    theta = ((u[:, : len(s)] * s) @ v[:, : len(s)].conj().T)[None]
+    chi = np.array([3], dtype=np.int32)
+    for qr in (False, True):
+        _, _, keep, spec, _ = svd_split_gpu(lib, theta, d, capL, capR, min(m, n), 0, mode, thr, max_bond, min_keep, chi, chi, qr=qr)
+        assert keep[0] == expected, (keep, expected, qr)
+        assert np.allclose(spec[0, : len(svs)], svs, atol=1e-12)
+    # relative_discarded_weight is scale invariant (test_svd_utils.py:62-69).  The reference scales the bare spectrum by 1e+-200; the
+    # GPU path factorises a matrix, whose squared column norms and their products must stay representable: overall scales within
+    # about 1e+-70 (the states of the path are normalised).
+    for scale in (3.7, 1e40, 1e-40):
+        if mode == 3:
+            _, _, keep, _, _ = svd_split_gpu(lib, theta * scale, d, capL, capR, min(m, n), 0, mode, thr, max_bond, min_keep, chi, chi, qr=False)
+            assert keep[0] == expected, (scale, keep)
+
+
 @pytest.mark.parametrize("dist", [0, 1])
 def test_svd_split_steeply_graded_spectrum_keeps_small_values_accurately(lib, dist):
     """Singular values over ten decades, all kept (threshold far below the smallest): the direct variant takes the isometric
