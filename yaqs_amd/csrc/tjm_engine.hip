@@ -198,6 +198,7 @@ int Engine::run_sweep(int set, const std::vector<SmallSweepStep>& steps, const i
   q.sites = site_refs_[set]; q.steps = sweep_steps_; q.nsteps = (int)steps.size(); q.d = d;
   q.chi = sets[set].chi; q.chi_stride = L + 1; q.threshold = 1e-12; q.min_keep = 1;
   q.ids = ids; q.nb0 = nb0; q.flags = overflow_;
+  q.pitch = small_sweep_pitch(d * *std::max_element(cap.begin(), cap.end()));
   stat_svds += (long)steps.size();
   return launch_small_sweep(q, stream);
 }

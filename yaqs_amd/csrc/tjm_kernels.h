@@ -183,7 +183,9 @@ struct SmallSweepDesc {
   double threshold; int min_keep;
   const int* ids; int nb0;
   int* flags;
+  int pitch;                     // rows of the LDS columns: small_sweep_pitch(largest d * cap of the chain)
 };
+int small_sweep_pitch(int rows);
 int launch_small_sweep(const SmallSweepDesc& p, hipStream_t s);
 bool svd_shift_small_fits(int d, int ca, int cb, bool left);
 // out[b][k*o_k + r1*o_r1 + r0*o_r0] = scale_k * op(Ycol[perm[k]][row_off + r1*n_r0 + r0]) for k < keep, 0 for keep <= k < n_k

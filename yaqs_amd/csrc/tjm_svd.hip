@@ -882,15 +882,16 @@ constexpr int SMALL_MAXN = 16;
 // then norms, rank sort and the discarded-weight truncation of svd_finish_kernel; the isometric factor is the set of
 // normalised columns, the weighted factor is its overlap with the input (accumulation-free, as in the large path) and goes
 // straight into the neighbouring tensor.  Replaces ~12 launches and one host synchronisation per sweep.
-// Cyclic-by-rows one-sided Jacobi on the n columns Y[j][0..63] held in LDS by ONE wavefront (lane = row), with the rotation rule of
+// Cyclic-by-rows one-sided Jacobi on the n columns Y[j * pitch + 0 .. pitch) held in LDS by ONE wavefront (lane = row), with the rotation rule of
 // the large kernels.  Returns false when 40 sweeps did not converge.
-__device__ inline bool small_jacobi(cplx (*Y)[64], int n, int lane, double floor2) {
+__device__ inline bool small_jacobi(cplx* Y, int pitch, int n, int lane, double floor2) {
   bool converged = n < 2;
+  const bool mine = lane < pitch;  // rows beyond the pitch do not exist (and would be zero)
   for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
     int cnt = 0;
     for (int pc = 0; pc + 1 < n; ++pc)
       for (int qc = pc + 1; qc < n; ++qc) {
-        cplx yp = Y[pc][lane], yq = Y[qc][lane];
+        cplx yp = mine ? Y[pc * pitch + lane] : cplx{0.0, 0.0}, yq = mine ? Y[qc * pitch + lane] : cplx{0.0, 0.0};
         const double a = wave_sum(fma(yp.x, yp.x, yp.y * yp.y));
         const double dd = wave_sum(fma(yq.x, yq.x, yq.y * yq.y));
         const double gx = wave_sum(fma(yp.x, yq.x, yp.y * yq.y));
@@ -898,8 +899,10 @@ __device__ inline bool small_jacobi(cplx (*Y)[64], int n, int lane, double floor
         double c, sr, si, tg;
         if (make_rotation(a, dd, gx, gy, 1e-26, floor2, c, sr, si, tg)) {
           rotate_pair(yp, yq, c, sr, si);
-          Y[pc][lane] = yp;
-          Y[qc][lane] = yq;
+          if (mine) {
+            Y[pc * pitch + lane] = yp;
+            Y[qc * pitch + lane] = yq;
+          }
           ++cnt;
         }
         __syncthreads();
@@ -990,7 +993,8 @@ __device__ inline void small_absorb(cplx* __restrict__ Nb, const cplx (*G)[SMALL
 
 // LDS of one wavefront of the fused small-bond kernels
 struct SmallLds {
-  cplx Y[SMALL_MAXN][64];
+  cplx* Y;     // [SMALL_MAXN][pitch] in dynamic LDS; pitch = 16, 32 or 64 rows (the smaller, the more wavefronts per CU)
+  int pitch;
   cplx G[SMALL_MAXN][SMALL_MAXN];
   cplx diag[SMALL_MAXN];
   double norm[SMALL_MAXN];
@@ -1001,7 +1005,8 @@ struct SmallLds {
 
 template <bool LEFT>
 __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int lane, SmallLds& sm) {
-  cplx (*Y)[64] = sm.Y;
+  cplx* Y = sm.Y;
+  const int pitch = sm.pitch;
   cplx (*G)[SMALL_MAXN] = sm.G;
   double* sNorm = sm.norm;
   int* sPerm = sm.perm;
@@ -1027,17 +1032,17 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
       v = A[site_index(lane, j)];
       if (LEFT) v.y = -v.y;
     }
-    Y[j][lane] = v;
+    if (lane < pitch) Y[j * pitch + lane] = v;
     fro = fma(v.x, v.x, fma(v.y, v.y, fro));
   }
   fro = wave_sum(fro);
   const double floor2 = 1e-26 * fro;
   __syncthreads();
-  const bool converged = small_jacobi(Y, n, lane, floor2);
+  const bool converged = small_jacobi(Y, pitch, n, lane, floor2);
   if (!converged && lane == 0 && p.flags) atomicOr(p.flags + 1, 1);
   // norms, descending rank sort (ties by index), truncation
   for (int j = 0; j < n; ++j) {
-    const cplx v = Y[j][lane];
+    const cplx v = (lane < pitch) ? Y[j * pitch + lane] : cplx{0.0, 0.0};
     const double s2 = wave_sum(fma(v.x, v.x, v.y * v.y));
     if (lane == 0) sNorm[j] = s2;
   }
@@ -1082,7 +1087,7 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
     const double inv = 1.0 / sqrt(sNorm[col]);
     double ax = 0.0, ay = 0.0;
     for (int r = 0; r < R; ++r) {
-      const cplx u = Y[col][r];
+      const cplx u = Y[col * pitch + r];
       cplx x = A[site_index(r, j)];
       if (LEFT) x.y = -x.y;
       if (LEFT) {  // conj(x) * u
@@ -1103,7 +1108,7 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
       if (k < keep) {
         const int col = sPerm[k];
         const double inv = 1.0 / sqrt(sNorm[col]);
-        v = Y[col][lane];
+        v = Y[col * pitch + lane];
         v.x *= inv;
         v.y *= LEFT ? -inv : inv;
       }
@@ -1113,9 +1118,13 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
   small_absorb<LEFT>(p.nb + (long)b * p.nb_b0, G, d, ca, cb, p.cn, n, keep, ncap, lane);
 }
 
+extern __shared__ double small_dyn_lds[];
+
 template <bool LEFT>
-__global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p) {
+__global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p, int pitch) {
   __shared__ SmallLds sm;
+  if (threadIdx.x == 0) { sm.Y = reinterpret_cast<cplx*>(small_dyn_lds); sm.pitch = pitch; }
+  __syncthreads();
   int b = blockIdx.x;
   if (p.ids) b = p.ids[b];
   svd_shift_small_body<LEFT>(p, b, threadIdx.x, sm);
@@ -1161,7 +1170,7 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
   }
   fro = wave_sum(fro);
   __syncthreads();
-  const bool converged = small_jacobi(Y, n, lane, 1e-26 * fro);
+  const bool converged = small_jacobi(&Y[0][0], 64, n, lane, 1e-26 * fro);
   if (!converged && lane == 0) atomicOr(flags + 3, 1);
   for (int j = 0; j < n; ++j) {
     const cplx v = Y[j][lane];
@@ -1253,7 +1262,8 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
 // applied to unit vectors.  Thin-QR bond rule k = min(rows, columns) of np.linalg.qr as in qr_bond_dims_kernel.
 template <bool RIGHT>
 __device__ inline void qr_site_small_body(const SmallQrDesc& p, int b, int lane, SmallLds& sm) {
-  cplx (*Z)[64] = sm.Y;
+  cplx* Z = sm.Y;
+  const int pitch = sm.pitch;
   cplx (*G)[SMALL_MAXN] = sm.G;
   cplx* sDiag = sm.diag;
   double* sBeta = sm.beta;
@@ -1268,35 +1278,36 @@ __device__ inline void qr_site_small_body(const SmallQrDesc& p, int b, int lane,
   const int kn = min(rows_act, n);
   const int bond = lane / d, ph = lane - bond * d;
   auto site_index = [&](int col) -> long { return RIGHT ? ((long)ph * ca + bond) * cb + col : ((long)ph * ca + col) * cb + bond; };
-  for (int j = 0; j < n; ++j) Z[j][lane] = (lane < rows_act) ? A[site_index(j)] : cplx{0.0, 0.0};
+  for (int j = 0; j < n; ++j)
+    if (lane < pitch) Z[j * pitch + lane] = (lane < rows_act) ? A[site_index(j)] : cplx{0.0, 0.0};
   for (int e = lane; e < SMALL_MAXN * SMALL_MAXN; e += 64) G[e / SMALL_MAXN][e % SMALL_MAXN] = cplx{0.0, 0.0};
   __syncthreads();
   for (int k = 0; k < kn; ++k) {
     const bool in = lane >= k && lane < rows_act;
-    cplx x = in ? Z[k][lane] : cplx{0.0, 0.0};
+    cplx x = in ? Z[k * pitch + lane] : cplx{0.0, 0.0};
     const double nx2 = wave_sum(fma(x.x, x.x, x.y * x.y));
     if (nx2 == 0.0) {  // nothing below the diagonal and a zero pivot: H_k = 1
       if (lane == 0) { sDiag[k] = cplx{0.0, 0.0}; sBeta[k] = 0.0; }
       __syncthreads();
       continue;
     }
-    const cplx xk = Z[k][k];
+    const cplx xk = Z[k * pitch + k];
     const double nx = sqrt(nx2), ak = sqrt(fma(xk.x, xk.x, xk.y * xk.y));
     const double px = ak > 0.0 ? xk.x / ak : 1.0, py = ak > 0.0 ? xk.y / ak : 0.0;
     const cplx alpha{-px * nx, -py * nx};
     const double beta = 1.0 / (nx * (nx + ak));  // 2 / |v|^2
     if (lane == k) { x.x -= alpha.x; x.y -= alpha.y; }
     __syncthreads();  // every lane has read Z[k][k]
-    if (in) Z[k][lane] = x;
+    if (in) Z[k * pitch + lane] = x;
     if (lane == 0) { sDiag[k] = alpha; sBeta[k] = beta; }
     for (int j = k + 1; j < n; ++j) {
-      cplx y = in ? Z[j][lane] : cplx{0.0, 0.0};
+      cplx y = in ? Z[j * pitch + lane] : cplx{0.0, 0.0};
       const double wr = beta * wave_sum(fma(x.x, y.x, x.y * y.y));   // beta * conj(v) . y
       const double wi = beta * wave_sum(fma(x.x, y.y, -x.y * y.x));
       if (in) {
         y.x -= wr * x.x - wi * x.y;
         y.y -= wr * x.y + wi * x.x;
-        Z[j][lane] = y;
+        Z[j * pitch + lane] = y;
       }
     }
     __syncthreads();
@@ -1304,7 +1315,7 @@ __device__ inline void qr_site_small_body(const SmallQrDesc& p, int b, int lane,
   // R (kn x n, upper trapezoidal): G[k][j], and the padded bond matrix
   for (int e = lane; e < kn * n; e += 64) {
     const int k = e / n, j = e - k * n;
-    if (j >= k) G[k][j] = (j == k) ? sDiag[k] : Z[j][k];
+    if (j >= k) G[k][j] = (j == k) ? sDiag[k] : Z[j * pitch + k];
   }
   __syncthreads();
   if (p.bond) {
@@ -1328,7 +1339,7 @@ __device__ inline void qr_site_small_body(const SmallQrDesc& p, int b, int lane,
         const double beta = sBeta[k];
         if (beta == 0.0) continue;
         const bool in = lane >= k && lane < rows_act;
-        const cplx v = in ? Z[k][lane] : cplx{0.0, 0.0};
+        const cplx v = in ? Z[k * pitch + lane] : cplx{0.0, 0.0};
         const double wr = beta * wave_sum(fma(v.x, q.x, v.y * q.y));
         const double wi = beta * wave_sum(fma(v.x, q.y, -v.y * q.x));
         q.x -= wr * v.x - wi * v.y;
@@ -1341,8 +1352,10 @@ __device__ inline void qr_site_small_body(const SmallQrDesc& p, int b, int lane,
 }
 
 template <bool RIGHT>
-__global__ __launch_bounds__(64) void qr_site_small_kernel(SmallQrDesc p) {
+__global__ __launch_bounds__(64) void qr_site_small_kernel(SmallQrDesc p, int pitch) {
   __shared__ SmallLds sm;
+  if (threadIdx.x == 0) { sm.Y = reinterpret_cast<cplx*>(small_dyn_lds); sm.pitch = pitch; }
+  __syncthreads();
   int b = blockIdx.x;
   if (p.ids) b = p.ids[b];
   qr_site_small_body<RIGHT>(p, b, threadIdx.x, sm);
@@ -1354,6 +1367,8 @@ __global__ __launch_bounds__(64) void qr_site_small_kernel(SmallQrDesc p) {
 // before a jump and the renormalising sweep after it are one launch each instead of one per site.
 __global__ __launch_bounds__(64) void small_sweep_kernel(SmallSweepDesc p) {
   __shared__ SmallLds sm;
+  if (threadIdx.x == 0) { sm.Y = reinterpret_cast<cplx*>(small_dyn_lds); sm.pitch = p.pitch; }
+  __syncthreads();
   int b = blockIdx.x;
   if (p.ids) b = p.ids[b];
   const int lane = threadIdx.x;
@@ -1525,25 +1540,34 @@ bool svd_shift_small_fits(int d, int ca, int cb, bool left) {
   return rows <= 64 && cols <= SMALL_MAXN;
 }
 
+// rows of the LDS columns of the one-wavefront kernels: the smallest of 16, 32, 64 that holds `rows`
+static int small_pitch(int rows) { return rows <= 16 ? 16 : (rows <= 32 ? 32 : 64); }
+
+int small_sweep_pitch(int rows) { return small_pitch(rows); }
+
 int launch_qr_site_small(const SmallQrDesc& p, bool right, hipStream_t s) {
   if (p.nb0 <= 0) return TJM_OK;
-  if (right) hipLaunchKernelGGL(qr_site_small_kernel<true>, dim3(p.nb0), dim3(64), 0, s, p);
-  else hipLaunchKernelGGL(qr_site_small_kernel<false>, dim3(p.nb0), dim3(64), 0, s, p);
+  const int pitch = small_pitch(right ? p.d * p.ca : p.d * p.cb);
+  const size_t lds = (size_t)SMALL_MAXN * pitch * sizeof(cplx);
+  if (right) hipLaunchKernelGGL(qr_site_small_kernel<true>, dim3(p.nb0), dim3(64), lds, s, p, pitch);
+  else hipLaunchKernelGGL(qr_site_small_kernel<false>, dim3(p.nb0), dim3(64), lds, s, p, pitch);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
 
 int launch_small_sweep(const SmallSweepDesc& p, hipStream_t s) {
   if (p.nb0 <= 0 || p.nsteps <= 0) return TJM_OK;
-  hipLaunchKernelGGL(small_sweep_kernel, dim3(p.nb0), dim3(64), 0, s, p);
+  hipLaunchKernelGGL(small_sweep_kernel, dim3(p.nb0), dim3(64), (size_t)SMALL_MAXN * p.pitch * sizeof(cplx), s, p);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
 
 int launch_svd_shift_small(const SmallShiftDesc& p, bool left, hipStream_t s) {
   if (p.nb0 <= 0) return TJM_OK;
-  if (left) hipLaunchKernelGGL(svd_shift_small_kernel<true>, dim3(p.nb0), dim3(64), 0, s, p);
-  else hipLaunchKernelGGL(svd_shift_small_kernel<false>, dim3(p.nb0), dim3(64), 0, s, p);
+  const int pitch = small_pitch(left ? p.d * p.cb : p.d * p.ca);
+  const size_t lds = (size_t)SMALL_MAXN * pitch * sizeof(cplx);
+  if (left) hipLaunchKernelGGL(svd_shift_small_kernel<true>, dim3(p.nb0), dim3(64), lds, s, p, pitch);
+  else hipLaunchKernelGGL(svd_shift_small_kernel<false>, dim3(p.nb0), dim3(64), lds, s, p, pitch);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
