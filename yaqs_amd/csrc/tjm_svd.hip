@@ -1137,8 +1137,8 @@ __global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p, i
 // A kept singular value at the rounding floor (<= 1e-11 sigma_0: its column was never rotated) raises flags[2]; the caller then
 // repeats the batch on the general path, which completes such columns to an orthonormal set.
 template <int MAXN>
-__global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, TruncSpec tr, int* flags) {
-  __shared__ cplx Y[MAXN][64];
+__global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, TruncSpec tr, int* flags, int pitch) {
+  cplx* Y = reinterpret_cast<cplx*>(small_dyn_lds);  // [MAXN][pitch]
   __shared__ cplx G[MAXN][MAXN];
   __shared__ double sNorm[MAXN];
   __shared__ int sPerm[MAXN];
@@ -1165,15 +1165,15 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
   double fro = 0.0;
   for (int j = 0; j < n; ++j) {
     const cplx v = (lane < R) ? theta_at(lane, j) : cplx{0.0, 0.0};
-    Y[j][lane] = v;
+    if (lane < pitch) Y[j * pitch + lane] = v;
     fro = fma(v.x, v.x, fma(v.y, v.y, fro));
   }
   fro = wave_sum(fro);
   __syncthreads();
-  const bool converged = small_jacobi(&Y[0][0], 64, n, lane, 1e-26 * fro);
+  const bool converged = small_jacobi(Y, pitch, n, lane, 1e-26 * fro);
   if (!converged && lane == 0) atomicOr(flags + 3, 1);
   for (int j = 0; j < n; ++j) {
-    const cplx v = Y[j][lane];
+    const cplx v = (lane < pitch) ? Y[j * pitch + lane] : cplx{0.0, 0.0};
     const double s2 = wave_sum(fma(v.x, v.x, v.y * v.y));
     if (lane == 0) sNorm[j] = s2;
   }
@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
     const double inv = 1.0 / sqrt(sNorm[col]);
     double ax = 0.0, ay = 0.0;
     for (int r = 0; r < R; ++r) {
-      const cplx u = Y[col][r];
+      const cplx u = Y[col * pitch + r];
       const cplx x = theta_at(r, j);
       if (d0) {  // conj(u) * x
         ax = fma(u.x, x.x, fma(u.y, x.y, ax));
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
       if (k < keep) {
         const int col = sPerm[k];
         const double inv = 1.0 / sqrt(sNorm[col]);
-        v = Y[col][lane];
+        v = Y[col * pitch + lane];
         v.x *= inv;
         v.y *= d0 ? inv : -inv;
       }
@@ -1806,7 +1806,8 @@ int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* 
       tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
       tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
       TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 2, 0, 2 * sizeof(int), s));
-      hipLaunchKernelGGL(svd_split_small_kernel<16>, dim3(d.nb0), dim3(64), 0, s, d, tr, w.n_active);
+      const int pitch = small_pitch(rows);
+      hipLaunchKernelGGL(svd_split_small_kernel<16>, dim3(d.nb0), dim3(64), (size_t)16 * pitch * sizeof(cplx), s, d, tr, w.n_active, pitch);
       TJM_HIP_CHECK(hipGetLastError());
       TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
       TJM_HIP_CHECK(hipStreamSynchronize(s));
