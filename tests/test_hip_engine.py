@@ -660,8 +660,9 @@ def test_storage_capacity_grows_on_demand(monkeypatch, max_bond):
         assert built[-1] == 24 and biggest == 24
 
 
+@pytest.mark.parametrize("native", [True, False])
 @pytest.mark.parametrize("order,sample_timesteps", [(1, False), (2, True), (2, False)])
-def test_growth_continues_mid_run_and_splits_pieces(monkeypatch, order, sample_timesteps):
+def test_growth_continues_mid_run_and_splits_pieces(monkeypatch, order, sample_timesteps, native):
     """A run that outgrows its storage is not started again: the step that was clipped is rolled back, the states move to
     engines of twice the capacity (here forced to hold fewer trajectories each, so the piece is split) and the run continues from
     that step with the random-stream cursors it had - order 1 and both phases of order 2, against the oracle per trajectory."""
@@ -684,7 +685,16 @@ def test_growth_continues_mid_run_and_splits_pieces(monkeypatch, order, sample_t
     kw = dict(elapsed_time=1.5, dt=0.1, max_bond_dim=None, svd_threshold=1e-10, krylov_tol=1e-11, order=order, random_seed=9)
     p = AnalogSimParams(observables=obs, num_traj=ntraj, sample_timesteps=sample_timesteps, **kw)
     noise = NoiseModel([{"name": "lowering", "sites": [i], "strength": 0.08} for i in range(L)])
-    res = tjm_mod.Simulator().run(MPS(L, state="Neel"), MPO.heisenberg(L, 1.0, 0.9, 0.7, 0.2), p, noise)
+    resumed = []
+    orig_host = tjm_mod.TrajectoryBatch.run
+
+    def spy_host(self, traj, initial, native=False, resume=None):
+        if resume is not None:
+            resumed.append(tuple(resume["start"]))
+        return orig_host(self, traj, initial, native=native, resume=resume)
+
+    monkeypatch.setattr(tjm_mod.TrajectoryBatch, "run", spy_host)
+    res = tjm_mod.Simulator(native=native).run(MPS(L, state="Neel"), MPO.heisenberg(L, 1.0, 0.9, 0.7, 0.2), p, noise)
     op = o.Params(observables=oobs, sample_timesteps=sample_timesteps, **kw)
     on = [o.make_process("lowering", [i], 0.08) for i in range(L)]
     idx = op.observable_sorted_indices
@@ -694,9 +704,11 @@ def test_growth_continues_mid_run_and_splits_pieces(monkeypatch, order, sample_t
             assert np.allclose(res.trajectories[u][t], r[idx[u]], atol=1e-8), (t, u)
         assert np.array_equal(res.max_bond_trajectories[t], dg[1]) if hasattr(res, "max_bond_trajectories") else True
     assert built[0] == 8 and max(built) >= 16 and len(built) >= 4, built          # 5 trajectories -> pieces of 2, 2 and 1
-    assert any(st[0] > 0 for st in starts), starts                                # some piece continued mid-run
+    assert any(st[0] > 0 for st in resumed), resumed                              # some piece continued mid-run (either driver)
+    if native:
+        assert any(st[0] > 0 for st in starts), starts
     if order == 2:
-        assert all(st[1] in (0, 1) for st in starts)
+        assert all(st[1] in (0, 1) for st in resumed)
 
 
 def test_circuit_growth_continues_at_the_clipped_layer(monkeypatch):

@@ -185,22 +185,48 @@ class TrajectoryBatch:
                 kw = dict(start=resume["start"], rng_pos=resume["rng_pos"], results=resume["results"], diagnostics=resume["diagnostics"])
             return e.run(order=p.order, n_times=n_t, sample_timesteps=p.sample_timesteps, has_noise=self.noise is not None,
                          seed=p.random_seed, traj_indices=traj_indices, observables=obs, **kw)
-        if resume is not None:
-            raise ValueError("only the native driver continues a run; the host schedule starts again from the initial state")
         cols = n_t if p.sample_timesteps else 1
-        results = np.zeros((e.B, len(self.sorted_obs), cols))
-        diagnostics = np.zeros((e.B, 3, cols))
-        e.load_state(initial.tensors, 0)
-        e.capacity_overflow(clear=True)
         n_draw = 2 * n_t + 2
         u = np.stack([trajectory_uniforms(p.random_seed, int(t), n_draw) for t in traj_indices])
-        pos = np.zeros(e.B, dtype=np.int64)
+        e.capacity_overflow(clear=True)
+        if resume is None:
+            results = np.zeros((e.B, len(self.sorted_obs), cols))
+            diagnostics = np.zeros((e.B, 3, cols))
+            e.load_state(initial.tensors, 0)
+            pos = np.zeros(e.B, dtype=np.int64)
+            start = (0, 0)
+        else:  # continue on this (larger) engine at the time step that ran out of capacity on the previous one
+            results, diagnostics = resume["results"], resume["diagnostics"]
+            pos = np.asarray(resume["rng_pos"], dtype=np.int64).copy()
+            start = tuple(resume["start"])
+        self._out = (results, diagnostics)
         if p.order == 2:
-            self._run_order2(traj_indices, results, diagnostics, u, pos)
+            self._run_order2(traj_indices, results, diagnostics, u, pos, start)
         else:
-            self._run_order1(results, diagnostics, u, pos)
-        _require_capacity(e)
+            self._run_order1(results, diagnostics, u, pos, start)
         return results, diagnostics
+
+    # ---- storage capacity: per-step rollback of the host schedule (mirror of run_batch in tjm_run.hip) ----
+    def _snapshot(self, pos):
+        """Start of a time step: the trajectory states go to the measurement-copy set (idle then), the cursors and log lengths aside."""
+        self.e.copy_state(1, 0)
+        return pos.copy(), len(self.dp_log), len(self.jump_log), set(self.schmidt)
+
+    def _clipped(self, step: int, phase: int, pos, snap=None) -> None:
+        """After a step (phase 0) or its sampling (phase 1): on a clipped truncation roll back and hand over to a larger engine."""
+        if not self.e.capacity_overflow():
+            return
+        if snap is not None:
+            self.e.copy_state(0, 1)
+            pos[:] = snap[0]
+            del self.dp_log[snap[1]:]
+            del self.jump_log[snap[2]:]
+            for key in set(self.schmidt) - snap[3]:
+                del self.schmidt[key]
+        err = CapacityError(f"time step {step} needs a bond beyond the engine's capacity chi = {self.e.chi_max}")
+        err.resume, err.rng_pos = (step, phase), pos.copy()
+        err.results, err.diagnostics = self._out
+        raise err
 
     # ---- scheduled jumps (core/methods/scheduled_jumps.py:28-119) ----------------------
     def _scheduled_at(self, time: float) -> list:
@@ -221,16 +247,19 @@ class TrajectoryBatch:
             raise ValueError("Scheduled jump produced a zero or non-finite squared norm. The jump operator annihilates the current state.")
         e.normalize_qr(0)                              # normalize("B")
 
-    def _run_order1(self, results, diagnostics, u, pos):
+    def _run_order1(self, results, diagnostics, u, pos, start=(0, 0)):
         """analog_tjm_1 (analog_tjm.py:369-462)."""
         e, p = self.e, self.p
         n_t = len(p.times)
-        first = self._scheduled_at(p.times[0])
-        if first:
-            self._apply_scheduled(first)
-        if p.sample_timesteps:
-            self._measure(0, results, diagnostics, 0)
-        for j in range(1, n_t):
+        if start[0] == 0:
+            first = self._scheduled_at(p.times[0])
+            if first:
+                self._apply_scheduled(first)
+                self._clipped(0, 0, pos)
+            if p.sample_timesteps:
+                self._measure(0, results, diagnostics, 0)
+        for j in range(max(1, start[0]), n_t):
+            snap = self._snapshot(pos)
             self._tdvp(0, j - 1)
             if self.noise is not None:
                 e.dissipate(p.dt, 0)
@@ -239,12 +268,13 @@ class TrajectoryBatch:
                     self._apply_scheduled(due)
                 else:
                     self._stochastic(0, p.dt, u, pos)
+            self._clipped(j, 0, pos, snap)
             if p.sample_timesteps or j == n_t - 1:
                 self._measure(0, results, diagnostics, j if p.sample_timesteps else 0)
         if not p.sample_timesteps and n_t <= 1:
             self._measure(0, results, diagnostics, 0)
 
-    def _run_order2(self, traj_indices, results, diagnostics, u, pos):
+    def _run_order2(self, traj_indices, results, diagnostics, u, pos, start=(0, 0)):
         """analog_tjm_2 (analog_tjm.py:206-366), standalone form."""
         e, p = self.e, self.p
         n_t = len(p.times)
@@ -259,22 +289,34 @@ class TrajectoryBatch:
             self._tdvp(1, j - 1)  # capture_sample(phi, j, interval j - 1), analog_tjm.py:347, 360
             e.dissipate(p.dt / 2, 1)
             us = np.stack([sample_uniforms(p.random_seed, int(t), j) for t in traj_indices])
+            n_dp, n_jump, keys = len(self.dp_log), len(self.jump_log), set(self.schmidt)
             self._stochastic(1, p.dt, us, None)
+            if e.capacity_overflow():  # phi is untouched: only the sampling of step j is repeated on the larger engine
+                del self.dp_log[n_dp:]
+                del self.jump_log[n_jump:]
+                for key in set(self.schmidt) - keys:
+                    del self.schmidt[key]
+                self._clipped(j if j >= 2 else 0, 1 if j >= 2 else 0, pos)
             self._measure(1, results, diagnostics, j if p.sample_timesteps else 0)
 
         if n_t == 1:
             if record(0):
                 self._measure(0, results, diagnostics, 0)
             return
-        if record(0):
-            self._measure(0, results, diagnostics, 0)
-        e.dissipate(p.dt / 2, 0)
-        self._stochastic(0, p.dt, u, pos)
-        sample(1)
-        for j in range(2, n_t):
-            self._tdvp(0, j - 2)  # step_through with interval j - 2, analog_tjm.py:351-358
-            e.dissipate(p.dt, 0)
+        if start[0] == 0:
+            if record(0):
+                self._measure(0, results, diagnostics, 0)
+            e.dissipate(p.dt / 2, 0)
             self._stochastic(0, p.dt, u, pos)
+            self._clipped(0, 0, pos)  # before the first full step: nothing to keep
+            sample(1)
+        for j in range(max(2, start[0]), n_t):
+            if not (j == start[0] and start[1] == 1):
+                snap = self._snapshot(pos)
+                self._tdvp(0, j - 2)  # step_through with interval j - 2, analog_tjm.py:351-358
+                e.dissipate(p.dt, 0)
+                self._stochastic(0, p.dt, u, pos)
+                self._clipped(j, 0, pos, snap)
             sample(j)
 
 
@@ -526,9 +568,7 @@ class Simulator:
                 return tb
 
             def run_piece(tb, lo_, hi_, resume, chunk=chunk):
-                if resume is None:
-                    return tb.run(chunk[lo_:hi_], initial_state, native=self.native)
-                return tb.run(chunk[lo_:hi_], None, native=True, resume=resume)
+                return tb.run(chunk[lo_:hi_], initial_state if resume is None else None, native=self.native, resume=resume)
 
             keep = sim_params.get_state and 0 in chunk
             r, dg, last = self._run_growing(chunk, chi, chi_top, initial_state.length, hamiltonian.tensors, make_batch, run_piece, device, cols,
