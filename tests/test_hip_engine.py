@@ -711,6 +711,23 @@ def test_growth_continues_mid_run_and_splits_pieces(monkeypatch, order, sample_t
         assert all(st[1] in (0, 1) for st in resumed)
 
 
+def test_run_dispatches_on_the_parameter_type_like_the_reference():
+    """Simulator.run(state, operator, sim_params, noise) is the one entry point of the reference (simulator.py:1173-1312): with
+    DigitalSimParams the operator is the circuit (here: gate layers) and the call is the circuit run."""
+    from yaqs_amd.api import DigitalSimParams, MPS, NoiseModel, Observable, Z as Zg, ising_trotter_layers
+    from yaqs_amd.tjm import Simulator
+
+    L = 5
+    layers = ising_trotter_layers(L, 1.0, 0.5, 0.1, 2)
+    noise = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)])
+    p = DigitalSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=3, max_bond_dim=8, svd_threshold=1e-10, random_seed=2)
+    a = Simulator().run(MPS(L, state="zeros"), layers, p, noise)
+    b = Simulator().run_circuit(MPS(L, state="zeros"), layers, p, noise)
+    assert np.array_equal(np.stack(a.trajectories), np.stack(b.trajectories))
+    with pytest.raises(NotImplementedError):
+        Simulator().run(MPS(L, state="zeros"), layers, p, noise, num_traj=5)
+
+
 def test_circuit_growth_continues_at_the_clipped_layer(monkeypatch):
     """run_circuit with storage grown on demand: the layer whose truncation was clipped is rolled back and repeated on engines of
     twice the capacity (split into smaller batches here), mid-circuit sampling columns and the jump streams carry over; per

@@ -526,8 +526,19 @@ class Simulator:
                     engine.close()
         return res, dg, kept
 
-    def run(self, initial_state: MPS, hamiltonian: MPO, sim_params: AnalogSimParams, noise_model: NoiseModel | None = None) -> Result:
+    def run(self, initial_state: MPS, hamiltonian: MPO, sim_params: AnalogSimParams, noise_model: NoiseModel | None = None, *,
+            observables=None, num_traj=None, random_seed=None, get_state: bool = False) -> Result:
+        """Same entry point as the reference for both paths (simulator.py:1173-1312): ``DigitalSimParams`` with a list of gate
+        layers as operator goes to ``run_circuit``.  The keyword arguments belong to simulation programs (pair lists), which
+        are the reference's control plane and not part of this path."""
         import torch
+
+        from .api import DigitalSimParams
+
+        if observables is not None or num_traj is not None or random_seed is not None or get_state:
+            raise NotImplementedError("program-wide arguments belong to SimulationProgram runs, which are outside the hot path built here")
+        if isinstance(sim_params, DigitalSimParams):
+            return self.run_circuit(initial_state, hamiltonian, sim_params, noise_model)
 
         pieces = None
         if isinstance(hamiltonian, (tuple, list)):  # piecewise-constant drive: one MPO per interval
