@@ -711,6 +711,54 @@ def test_growth_continues_mid_run_and_splits_pieces(monkeypatch, order, sample_t
         assert all(st[1] in (0, 1) for st in resumed)
 
 
+def test_the_reference_own_analog_test_reads_the_same():
+    """tests/test_simulator.py:159-207 of the reference, line by line with this package's names in place of ``mqt.yaqs``: same
+    objects, same call, the reference's five pinned <Z> values (its own tolerance)."""
+    from yaqs_amd.api import AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    length = 5
+    initial_state = State(length, initial="zeros")
+    H = Hamiltonian.ising(length, J=1, g=0.5)
+    sim_params = AnalogSimParams(
+        observables=[Observable(Zg(), site) for site in range(length)],
+        elapsed_time=1,
+        dt=0.1,
+        num_traj=10,
+        max_bond_dim=4,
+        svd_threshold=1e-6,
+        order=2,
+        sample_timesteps=False,
+        random_seed=42,
+    )
+    gamma = 0.1
+    noise_model = NoiseModel([{"name": name, "sites": [i], "strength": gamma} for i in range(length) for name in ["lowering", "pauli_z"]])
+    result = Simulator(show_progress=False).run(initial_state, H, sim_params, noise_model)
+    expected_z = [0.748947146695782, 0.8720515025769692, 0.8652609567462763, 0.8673233347433466, 0.6872036335377433]
+    for i in range(len(result.observables)):
+        assert result.expectation_values[i] is not None
+        assert len(result.trajectories[i]) == sim_params.num_traj
+        assert len(result.expectation_values[i]) == 1
+        assert np.isclose(np.real(result.expectation_values[i][0]), expected_z[i], atol=2e-4)
+        assert np.isclose(np.real(result.expectation_values[i][0]), expected_z[i], atol=1e-8)  # in fact to rounding
+
+
+def test_piecewise_hamiltonian_through_the_reference_style_factory():
+    """Hamiltonian.piecewise([(H, duration), ...]) (hamiltonian.py:179-230) equals the tuple-of-MPOs form."""
+    from yaqs_amd.api import AnalogSimParams, Hamiltonian, MPO, Observable, State, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    L = 5
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=0.5, dt=0.1, max_bond_dim=8, svd_threshold=1e-10,
+                        krylov_tol=1e-10, sample_timesteps=False)
+    a, b = Hamiltonian.ising(L, 1.0, 0.5), Hamiltonian.ising(L, 1.0, 1.3)
+    r1 = Simulator().run(State(L, initial="zeros"), Hamiltonian.piecewise([(a, 0.2), (b, 0.3)]), p)
+    r2 = Simulator().run(State(L, initial="zeros"), (a, a, b, b, b), p)
+    assert np.allclose(np.stack(r1.expectation_values), np.stack(r2.expectation_values), atol=1e-12)
+    with pytest.raises(ValueError):
+        Simulator().run(State(L, initial="zeros"), Hamiltonian.piecewise([(a, 0.25), (b, 0.25)]), p)
+
+
 def test_run_dispatches_on_the_parameter_type_like_the_reference():
     """Simulator.run(state, operator, sim_params, noise) is the one entry point of the reference (simulator.py:1173-1312): with
     DigitalSimParams the operator is the circuit (here: gate layers) and the call is the circuit run."""

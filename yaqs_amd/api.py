@@ -631,3 +631,74 @@ class CircuitResult:
             d = np.mean(diagnostics, axis=0)
             self.runtime_cost, self.max_bond, self.total_bond = d[0], d[1], d[2]
             self.trajectory_diagnostics = diagnostics
+
+
+# ------------------------------------------------------------------ front-end wrappers of the reference's newer API
+class State(MPS):
+    """``State(length, initial="zeros", pad=..., tensors=...)`` (core/data_structures/state.py:50-140), MPS representation only:
+    the TJM path works on matrix product states, the ``vector`` / ``density_matrix`` representations belong to the reference's
+    other solvers."""
+
+    def __init__(self, length: int | None = None, *, initial: str = "zeros", representation: str | None = None,
+                 physical_dimensions=None, tensors=None, vector=None, density_matrix=None, pad: int | None = None,
+                 basis_string: str | None = None, seed: int | None = None):
+        if length is not None and length <= 0:
+            raise ValueError("length must be a positive integer.")  # state.py:88-90
+        if vector is not None or density_matrix is not None or representation not in (None, "mps"):
+            raise NotImplementedError("only representation='mps' is part of the TJM path built here")
+        if physical_dimensions not in (None, 2) and list(np.atleast_1d(physical_dimensions)) != [2] * (length or len(tensors or [])):
+            raise NotImplementedError("physical dimensions other than 2 are not built yet in the HIP path")
+        if basis_string is not None or initial == "basis":
+            raise NotImplementedError("initial='basis' is not built yet; pass tensors=")
+        if tensors is not None:
+            if len(tensors) == 0:
+                raise ValueError("tensors must be a non-empty list of MPS cores.")
+            if length is not None and length != len(tensors):
+                raise ValueError(f"length={length} does not match len(tensors)={len(tensors)}.")
+            super().__init__(len(tensors), tensors=list(tensors))
+        else:
+            if length is None:
+                raise ValueError("length is required for a preset state.")
+            rng = np.random.default_rng(seed) if seed is not None else None
+            super().__init__(length, state=initial, pad=pad, rng=rng)
+        self.initial, self.representation = initial, "mps"
+
+
+class Hamiltonian(MPO):
+    """``Hamiltonian.ising(...)`` / ``.heisenberg(...)`` / ``.from_mpo(...)`` / ``.piecewise(...)``
+    (core/data_structures/hamiltonian.py:36-330); the factories are those of ``MPO``."""
+
+    @classmethod
+    def from_mpo(cls, mpo: MPO) -> "Hamiltonian":
+        out = cls.__new__(cls)
+        out.__dict__.update(mpo.__dict__)
+        return out
+
+    @staticmethod
+    def piecewise(pieces):
+        """``[(Hamiltonian, duration), ...]`` -> the tuple of per-interval MPOs ``Simulator.run`` takes (hamiltonian.py:179-230); the
+        durations are checked against the time grid there."""
+        out = []
+        for ham, duration in pieces:
+            if not duration > 0:
+                raise ValueError("piece durations must be positive")
+            out.append((ham, float(duration)))
+        return PiecewiseHamiltonian(out)
+
+
+class PiecewiseHamiltonian:
+    def __init__(self, pieces):
+        self.pieces = pieces
+        self.length = pieces[0][0].length
+
+    def per_interval(self, dt: float, n_intervals: int):
+        """One MPO per interval of the dt grid; durations must be integer multiples of dt and add up to the run."""
+        out = []
+        for ham, duration in self.pieces:
+            k = duration / dt
+            if abs(k - round(k)) > 1e-9 or round(k) < 1:
+                raise ValueError("piece durations must be positive integer multiples of dt")
+            out.extend([ham] * int(round(k)))
+        if len(out) != n_intervals:
+            raise ValueError("piece durations must sum to elapsed_time")
+        return out

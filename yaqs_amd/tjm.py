@@ -541,6 +541,8 @@ class Simulator:
             return self.run_circuit(initial_state, hamiltonian, sim_params, noise_model)
 
         pieces = None
+        if hasattr(hamiltonian, "per_interval"):  # Hamiltonian.piecewise([(H, duration), ...])
+            hamiltonian = hamiltonian.per_interval(sim_params.dt, len(sim_params.times) - 1)
         if isinstance(hamiltonian, (tuple, list)):  # piecewise-constant drive: one MPO per interval
             pieces = list(hamiltonian)
             if not pieces:
