@@ -743,6 +743,32 @@ def test_the_reference_own_analog_test_reads_the_same():
         assert np.isclose(np.real(result.expectation_values[i][0]), expected_z[i], atol=1e-8)  # in fact to rounding
 
 
+@pytest.mark.parametrize("case", ["test_two_site_correlator_left_boundary", "test_two_site_correlator_center", "test_two_site_correlator_right_boundary"])
+def test_the_reference_two_site_correlator_series(case):
+    """tests/test_simulator.py:858-1188 of the reference with this package's names: closed 4-site Ising chain from |0000>, default
+    preset, <XX>, <YY>, <ZZ> of a neighbouring pair at 21 time points against the reference's pinned series (its tolerance 1e-3;
+    vectors extracted as data by tools/extract_reference_test_vectors.py)."""
+    import json
+
+    from yaqs_amd.api import XX, YY, ZZ, AnalogSimParams, Hamiltonian, Observable, State
+    from yaqs_amd.tjm import Simulator
+
+    g = json.load(open(os.path.join(GOLDEN, "reference_two_site_correlators.json")))[case]
+    H_0 = Hamiltonian.ising(g["L"], g["J"], g["g"])
+    state = State(g["L"], initial="zeros")
+    sim_params = AnalogSimParams(
+        observables=[Observable(XX(), g["sites"]), Observable(YY(), g["sites"]), Observable(ZZ(), g["sites"])],
+        elapsed_time=g["elapsed_time"],
+        dt=g["dt"],
+        max_bond_dim=g["max_bond_dim"],
+        sample_timesteps=True,
+    )
+    result = Simulator(show_progress=False).run(state, H_0, sim_params)
+    for k, name in enumerate(("xx", "yy", "zz")):
+        assert result.expectation_values[k] is not None
+        np.testing.assert_allclose(result.expectation_values[k], np.array(g[name]), atol=1e-3)
+
+
 def test_piecewise_hamiltonian_through_the_reference_style_factory():
     """Hamiltonian.piecewise([(H, duration), ...]) (hamiltonian.py:179-230) equals the tuple-of-MPOs form."""
     from yaqs_amd.api import AnalogSimParams, Hamiltonian, MPO, Observable, State, Z as Zg

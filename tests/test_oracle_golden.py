@@ -377,3 +377,20 @@ def test_one_and_two_site_chains_match_reference():
             for t in range(5):
                 r, _, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), noise, p, mpo)
                 assert np.allclose(r, g[f"L{L}_order{order}"][t], atol=1e-9), (L, order, t)
+
+
+@pytest.mark.parametrize("case", ["test_two_site_correlator_left_boundary", "test_two_site_correlator_center", "test_two_site_correlator_right_boundary"])
+def test_oracle_reproduces_the_reference_two_site_correlator_series(case):
+    """The pinned <XX>, <YY>, <ZZ> series of the reference's own tests (tests/test_simulator.py:858-1188; extracted as data by
+    tools/extract_reference_test_vectors.py): closed 4-site Ising chain, default preset, 21 time points, the reference's tolerance."""
+    import json
+
+    g = json.load(open(os.path.join(GOLDEN, "reference_two_site_correlators.json")))[case]
+    x, y, z = o.PAULI["x"], o.PAULI["y"], o.PAULI["z"]
+    obs = [o.Obs(np.kron(m, m), list(g["sites"])) for m in (x, y, z)]
+    p = o.Params(observables=obs, elapsed_time=g["elapsed_time"], dt=g["dt"], max_bond_dim=g["max_bond_dim"], svd_threshold=1e-6, krylov_tol=1e-4,
+                 order=1, sample_timesteps=True)
+    res, _, _ = o.run_trajectory(0, o.MPSState.product(g["L"], "zeros"), [], p, o.ising_mpo(g["L"], g["J"], g["g"]))
+    idx = p.observable_sorted_indices
+    for k, name in enumerate(("xx", "yy", "zz")):
+        assert np.allclose(res[idx[k]], np.array(g[name]), atol=1e-3), name

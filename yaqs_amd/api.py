@@ -57,6 +57,21 @@ def Id() -> BaseGate:
     return BaseGate("id", _I.copy())
 
 
+def XX() -> BaseGate:
+    """Two-site correlator X (x) X (gate_library.py:1674-1698)."""
+    return BaseGate("xx", np.kron(_X, _X), interaction=2)
+
+
+def YY() -> BaseGate:
+    """Two-site correlator Y (x) Y (gate_library.py:1700-1724)."""
+    return BaseGate("yy", np.kron(_Y, _Y), interaction=2)
+
+
+def ZZ() -> BaseGate:
+    """Two-site correlator Z (x) Z (gate_library.py:1726-1750)."""
+    return BaseGate("zz", np.kron(_Z, _Z), interaction=2)
+
+
 def Entropy() -> BaseGate:
     """Meta-observable: entanglement entropy across the cut (i, i+1) (gate_library.py:1873-1900, mps.py:604-641)."""
     return BaseGate("entropy", _I.copy(), interaction=2)
