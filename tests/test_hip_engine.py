@@ -769,6 +769,32 @@ def test_the_reference_two_site_correlator_series(case):
         np.testing.assert_allclose(result.expectation_values[k], np.array(g[name]), atol=1e-3)
 
 
+def test_the_reference_observable_order_test_reads_the_same():
+    """tests/test_simulator.py:1292-1324 of the reference with this package's names (the qiskit Statevector expectation replaced by
+    the same dense formula): user order of the observables on Result, values against the dense final state."""
+    from yaqs_amd.api import AnalogSimParams, Hamiltonian, Observable, State, X as Xg, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    state = State(2, initial="zeros")
+    H = Hamiltonian.ising(2, J=1.0, g=0.7)
+    requested = [Observable(Zg(), 1), Observable(Xg(), 0), Observable(Zg(), 0)]
+    sim_params = AnalogSimParams(observables=requested, elapsed_time=0.1, dt=0.1, num_traj=1, get_state=True, sample_timesteps=False, preset="exact")
+    result = Simulator(parallel=False, show_progress=False).run(state, H, sim_params)
+    assert result.output_state is not None
+    vec = result.output_state.mps.to_vec()
+    n = int(np.log2(vec.size))
+    assert len(result.observables) == len(requested)
+    for i, (got_obs, req_obs) in enumerate(zip(result.observables, requested)):
+        assert got_obs.gate.name == req_obs.gate.name
+        assert got_obs.sites == req_obs.sites
+        site = got_obs.sites[0] if isinstance(got_obs.sites, list) else got_obs.sites
+        op = np.kron(np.kron(np.eye(2 ** site), got_obs.gate.matrix), np.eye(2 ** (n - 1 - site)))
+        expected = float(np.real(np.vdot(vec, op @ vec)))
+        got = float(np.real(result.expectation_values[i][-1]))
+        assert got == pytest.approx(expected, abs=1e-10)
+        assert result.output_state.mps.expect(got_obs) == pytest.approx(expected, abs=1e-10)
+
+
 def test_piecewise_hamiltonian_through_the_reference_style_factory():
     """Hamiltonian.piecewise([(H, duration), ...]) (hamiltonian.py:179-230) equals the tuple-of-MPOs form."""
     from yaqs_amd.api import AnalogSimParams, Hamiltonian, MPO, Observable, State, Z as Zg

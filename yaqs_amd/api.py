@@ -497,6 +497,29 @@ class MPS:
         if pad is not None:
             self.pad_bond_dimension(pad)
 
+    @property
+    def mps(self) -> "MPS":
+        """``result.output_state.mps`` of the reference (state.py): the MPS behind a State - here the object itself."""
+        return self
+
+    def to_vec(self) -> np.ndarray:
+        """Dense state vector, site 0 as the most significant index (mps.py:1049-1073); small chains only."""
+        if self.length > 20:
+            raise ValueError("to_vec is meant for small chains")
+        v = np.ones((1, 1), dtype=C128)
+        for t in self.tensors:  # (sigma, l, r)
+            v = np.einsum("xl,slr->xsr", v, t).reshape(-1, t.shape[2])
+        return v.reshape(-1)
+
+    def expect(self, observable) -> float:
+        """<psi| O |psi> of a one-site or nearest-neighbour two-site observable (mps.py:961-1047), dense evaluation for small chains."""
+        psi = self.to_vec()
+        sites = observable.sites if isinstance(observable.sites, (list, tuple)) else [observable.sites]
+        m = np.asarray(observable.gate.matrix, dtype=C128)
+        first, span = int(sites[0]), len(sites)
+        op = np.kron(np.kron(np.eye(2 ** first), m), np.eye(2 ** (self.length - first - span)))
+        return float(np.real(np.vdot(psi, op @ psi)))
+
     def pad_bond_dimension(self, target_dim: int) -> None:
         """Zero-pad every internal bond k to ``min(target_dim, 2**min(k, L-k))`` and re-canonicalise (mps.py:409-452): the start
         of fixed-chi runs such as one-site TDVP, whose tangent space is spanned by the padded isometries."""

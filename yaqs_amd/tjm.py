@@ -465,7 +465,11 @@ class Simulator:
     diagnostic sums are combined with one all-reduce.
     """
 
-    def __init__(self, batch: int | None = None, device: str | None = None, show_progress: bool = False, native: bool = True):
+    def __init__(self, batch: int | None = None, device: str | None = None, show_progress: bool = False, native: bool = True,
+                 parallel: bool = True, max_workers: int | None = None):
+        # parallel / max_workers configure the reference's process pool (simulator.py:60-130); here the trajectories of a run are
+        # batched on the GPU instead, so the arguments are accepted for source compatibility and have no effect on the results
+        self.parallel, self.max_workers = parallel, max_workers
         self.batch = batch
         self.device = device
         self.show_progress = show_progress
