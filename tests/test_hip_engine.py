@@ -788,11 +788,48 @@ def test_the_reference_observable_order_test_reads_the_same():
         assert got_obs.gate.name == req_obs.gate.name
         assert got_obs.sites == req_obs.sites
         site = got_obs.sites[0] if isinstance(got_obs.sites, list) else got_obs.sites
-        op = np.kron(np.kron(np.eye(2 ** site), got_obs.gate.matrix), np.eye(2 ** (n - 1 - site)))
+        op = np.kron(np.kron(np.eye(2 ** (n - 1 - site)), got_obs.gate.matrix), np.eye(2 ** site))  # site 0 = least significant (qiskit label order)
         expected = float(np.real(np.vdot(vec, op @ vec)))
         got = float(np.real(result.expectation_values[i][-1]))
         assert got == pytest.approx(expected, abs=1e-10)
         assert result.output_state.mps.expect(got_obs) == pytest.approx(expected, abs=1e-10)
+    # a two-site observable without exchange symmetry pins the (s_i, s_{i+1}) index order of the measured value and of MPS.expect;
+    # Hamiltonian(matrix=...) (hamiltonian.py:49-120) must be the same operator as the MPO it was made from
+    from yaqs_amd.api import BaseGate
+
+    xz = Observable(BaseGate("xz", np.kron(Xg().matrix, Zg().matrix), interaction=2), [0, 1])
+    p2 = AnalogSimParams(observables=[xz], elapsed_time=0.3, dt=0.1, num_traj=1, get_state=True, sample_timesteps=False, preset="exact")
+    H3 = Hamiltonian.heisenberg(3, 1.0, 0.8, 0.5, 0.3)
+    r2 = Simulator(show_progress=False).run(State(3, initial="x+"), H3, p2)
+    assert float(r2.expectation_values[0][-1]) == pytest.approx(r2.output_state.mps.expect(xz), abs=1e-10)
+    dense = Hamiltonian(matrix=o.mpo_to_matrix(H3.tensors))
+    r3 = Simulator(show_progress=False).run(State(3, initial="x+"), dense, p2)
+    assert float(r3.expectation_values[0][-1]) == pytest.approx(float(r2.expectation_values[0][-1]), abs=1e-9)
+
+
+def test_the_reference_scheduled_jump_at_t0_tests_read_the_same():
+    """tests/test_simulator.py:1802-1850 of the reference with this package's names: an order-1 scheduled X jump at t = 0 on a
+    single qubit with H = 0 is applied before the initial sample; also with elapsed_time = 0 and final-time sampling."""
+    from yaqs_amd.api import AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    hamiltonian = Hamiltonian(matrix=np.zeros((2, 2), dtype=complex))
+    noise = NoiseModel(scheduled_jumps=[{"time": 0.0, "sites": [0], "name": "x"}])
+    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=0.3, num_traj=1, order=1, get_state=True)
+    result = Simulator(show_progress=False).run(State(1, initial="zeros"), hamiltonian, sim_params, noise)
+    z = np.asarray(result.expectation_values[0], dtype=float)
+    np.testing.assert_allclose(z, -1.0, atol=1e-10)
+    assert result.output_state is not None
+    final_z = float(result.output_state.mps.expect(Observable(Zg(), 0)))
+    assert final_z == pytest.approx(-1.0)
+    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=0.0, num_traj=1, order=1, sample_timesteps=False,
+                                 get_state=True)
+    result = Simulator(show_progress=False).run(State(1, initial="zeros"), hamiltonian, sim_params, noise)
+    z = float(np.asarray(result.expectation_values[0], dtype=complex).reshape(-1)[0].real)
+    assert result.output_state is not None
+    final_z = float(result.output_state.mps.expect(Observable(Zg(), 0)))
+    assert z == pytest.approx(-1.0)
+    assert final_z == pytest.approx(-1.0)
 
 
 def test_piecewise_hamiltonian_through_the_reference_style_factory():

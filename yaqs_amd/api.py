@@ -503,22 +503,27 @@ class MPS:
         return self
 
     def to_vec(self) -> np.ndarray:
-        """Dense state vector, site 0 as the most significant index (mps.py:1049-1073); small chains only."""
+        """Dense state vector with site 0 as the fastest (least significant) index, the reference's convention (mps.py:1633-1658:
+        the network is flipped before the contraction); small chains only."""
         if self.length > 20:
             raise ValueError("to_vec is meant for small chains")
-        v = np.ones((1, 1), dtype=C128)
-        for t in self.tensors:  # (sigma, l, r)
-            v = np.einsum("xl,slr->xsr", v, t).reshape(-1, t.shape[2])
+        v = np.ones((1, 1), dtype=C128)  # (physical indices of the sites so far, right bond)
+        for t in self.tensors:  # (sigma, l, r): the new site becomes the MOST significant index so far
+            v = np.einsum("xl,slr->sxr", v, t).reshape(-1, t.shape[2])
         return v.reshape(-1)
 
     def expect(self, observable) -> float:
-        """<psi| O |psi> of a one-site or nearest-neighbour two-site observable (mps.py:961-1047), dense evaluation for small chains."""
-        psi = self.to_vec()
+        """<psi| O |psi> of a one-site or nearest-neighbour two-site observable (mps.py:961-1047), dense evaluation for small chains;
+        a two-site matrix is indexed (s_i, s_{i+1}) with site i the major index."""
+        L = self.length
+        psi = self.to_vec().reshape([2] * L)  # axes (s_{L-1}, ..., s_0)
         sites = observable.sites if isinstance(observable.sites, (list, tuple)) else [observable.sites]
         m = np.asarray(observable.gate.matrix, dtype=C128)
-        first, span = int(sites[0]), len(sites)
-        op = np.kron(np.kron(np.eye(2 ** first), m), np.eye(2 ** (self.length - first - span)))
-        return float(np.real(np.vdot(psi, op @ psi)))
+        axes = [L - 1 - int(q) for q in sites]
+        k = len(axes)
+        out = np.tensordot(m.reshape([2] * (2 * k)), psi, axes=(list(range(k, 2 * k)), axes))
+        out = np.moveaxis(out, list(range(k)), axes)
+        return float(np.real(np.vdot(psi, out)))
 
     def pad_bond_dimension(self, target_dim: int) -> None:
         """Zero-pad every internal bond k to ``min(target_dim, 2**min(k, L-k))`` and re-canonicalise (mps.py:409-452): the start
@@ -705,6 +710,29 @@ class State(MPS):
 class Hamiltonian(MPO):
     """``Hamiltonian.ising(...)`` / ``.heisenberg(...)`` / ``.from_mpo(...)`` / ``.piecewise(...)``
     (core/data_structures/hamiltonian.py:36-330); the factories are those of ``MPO``."""
+
+    def __init__(self, tensors=None, *, matrix=None):
+        """``Hamiltonian(matrix=H)`` (hamiltonian.py:49-120): a dense operator on L qubits in the convention of ``to_vec`` (site 0 the
+        least significant index), as an exact MPO by successive SVDs (small chains)."""
+        if matrix is None:
+            super().__init__(tensors)
+            return
+        H = np.asarray(matrix, dtype=C128)
+        L = int(round(np.log2(H.shape[0])))
+        if H.ndim != 2 or H.shape[0] != H.shape[1] or 2 ** L != H.shape[0] or L < 1 or L > 10:
+            raise ValueError("matrix must be a square operator on 1 to 10 qubits")
+        # T[(o_0 i_0), (o_1 i_1), ...] then split site by site
+        T = H.reshape([2] * (2 * L)).transpose([k for s_ in range(L) for k in (L - 1 - s_, 2 * L - 1 - s_)]).reshape([4] * L)
+        out, left = [], 1
+        rest = T.reshape(left * 4, -1)
+        for s_ in range(L - 1):
+            u, sv, vh = np.linalg.svd(rest, full_matrices=False)
+            keep = max(1, int(np.sum(sv > 1e-14 * max(sv[0], 1e-300))))
+            out.append(u[:, :keep].reshape(left, 2, 2, keep).transpose(1, 2, 0, 3))
+            rest = (sv[:keep, None] * vh[:keep]).reshape(keep * 4, -1)
+            left = keep
+        out.append(rest.reshape(left, 2, 2, 1).transpose(1, 2, 0, 3))
+        super().__init__(out)
 
     @classmethod
     def from_mpo(cls, mpo: MPO) -> "Hamiltonian":
