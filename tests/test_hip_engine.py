@@ -832,6 +832,37 @@ def test_the_reference_scheduled_jump_at_t0_tests_read_the_same():
     assert final_z == pytest.approx(-1.0)
 
 
+def test_the_reference_scheduled_jump_tests_read_the_same():
+    """tests/test_simulator.py:1327-1408 of the reference with this package's names: a scheduled X flip of a single qubit at
+    t = 0.5 and a scheduled XX jump of two qubits at t = 0.2, vacuum Hamiltonian."""
+    from yaqs_amd.api import ZZ, AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    L, T, dt, jump_time = 1, 1.0, 0.1, 0.5
+    state = State(L, initial="zeros")
+    noise_model = NoiseModel(scheduled_jumps=[{"time": jump_time, "sites": [0], "name": "x"}])
+    sim_params = AnalogSimParams(elapsed_time=T, dt=dt, num_traj=1, observables=[Observable(Zg(), sites=0)])
+    hamiltonian = Hamiltonian.ising(L, 0.0, 0.0)
+    result = Simulator(show_progress=False).run(state, hamiltonian, sim_params, noise_model=noise_model)
+    results = result.expectation_values[0]
+    assert results is not None
+    np.testing.assert_allclose(results[:5], 1.0, atol=1e-10)
+    np.testing.assert_allclose(results[5:], -1.0, atol=1e-10)
+
+    L, T, dt, jump_time = 2, 0.4, 0.1, 0.2
+    noise_model = NoiseModel(scheduled_jumps=[{"time": jump_time, "sites": [0, 1], "name": "crosstalk_xx"}])
+    hamiltonian = Hamiltonian.ising(L, 0.0, 0.0)
+    sim_params = AnalogSimParams(elapsed_time=T, dt=dt, num_traj=1, observables=[Observable(ZZ(), sites=[0, 1])])
+    result = Simulator(show_progress=False).run(State(L, initial="zeros"), hamiltonian, sim_params, noise_model=noise_model)
+    assert result.expectation_values[0] is not None
+    np.testing.assert_allclose(result.expectation_values[0], 1.0, atol=1e-10)  # ZZ is blind to the double flip
+    sim_params = AnalogSimParams(observables=[Observable(Zg(), sites=0)], elapsed_time=T, dt=dt, num_traj=1)
+    result = Simulator(show_progress=False).run(State(L, initial="zeros"), hamiltonian, sim_params, noise_model=noise_model)
+    results = result.expectation_values[0]
+    np.testing.assert_allclose(results[:2], 1.0, atol=1e-10)
+    np.testing.assert_allclose(results[2:], -1.0, atol=1e-10)
+
+
 def test_piecewise_hamiltonian_through_the_reference_style_factory():
     """Hamiltonian.piecewise([(H, duration), ...]) (hamiltonian.py:179-230) equals the tuple-of-MPOs form."""
     from yaqs_amd.api import AnalogSimParams, Hamiltonian, MPO, Observable, State, Z as Zg
