@@ -863,6 +863,38 @@ def test_the_reference_scheduled_jump_tests_read_the_same():
     np.testing.assert_allclose(results[2:], -1.0, atol=1e-10)
 
 
+@pytest.mark.parametrize(("elapsed_time", "sample_timesteps"), [(0.0, True), (0.0, False), (0.1, False)])
+def test_the_reference_order_2_short_run_tests_read_the_same(elapsed_time, sample_timesteps):
+    """tests/test_simulator.py:1845-1929 of the reference with this package's names: order-2 runs with elapsed_time in {0, dt}, and a
+    zero-duration final-only run that must not apply the initial half-step of noise."""
+    from yaqs_amd.api import AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    hamiltonian = Hamiltonian.ising(2, J=1.0, g=0.5)
+    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=elapsed_time, num_traj=1, order=2,
+                                 sample_timesteps=sample_timesteps, get_state=True, random_seed=0)
+    result = Simulator(show_progress=False).run(State(2, initial="zeros"), hamiltonian, sim_params)
+    z = np.asarray(result.expectation_values[0], dtype=complex).reshape(-1)
+    assert result.output_state is not None
+    assert np.isfinite(z.real).all()
+    assert np.all(np.abs(z.real) > 0.5)
+    if elapsed_time == pytest.approx(0.1) and not sample_timesteps:
+        sampled = Simulator(show_progress=False).run(
+            State(2, initial="zeros"), hamiltonian,
+            AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=0.1, num_traj=1, order=2, sample_timesteps=True, get_state=True,
+                            random_seed=0))
+        z_sampled_final = float(np.asarray(sampled.expectation_values[0], dtype=complex).reshape(-1)[-1].real)
+        assert float(z.real[0]) == pytest.approx(z_sampled_final, abs=1e-10)
+    if elapsed_time == 0.0:
+        h0 = Hamiltonian(matrix=np.zeros((2, 2), dtype=complex))
+        noise = NoiseModel([{"name": "lowering", "sites": [0], "strength": 1.0}])
+        run = Simulator(show_progress=False).run(
+            State(1, initial="x+"), h0,
+            AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=0.0, num_traj=1, order=2, sample_timesteps=sample_timesteps,
+                            random_seed=0), noise)
+        assert float(np.asarray(run.expectation_values[0], dtype=complex).reshape(-1)[0].real) == pytest.approx(0.0, abs=1e-10)
+
+
 def test_piecewise_hamiltonian_through_the_reference_style_factory():
     """Hamiltonian.piecewise([(H, duration), ...]) (hamiltonian.py:179-230) equals the tuple-of-MPOs form."""
     from yaqs_amd.api import AnalogSimParams, Hamiltonian, MPO, Observable, State, Z as Zg
