@@ -895,6 +895,36 @@ def test_the_reference_order_2_short_run_tests_read_the_same(elapsed_time, sampl
         assert float(np.asarray(run.expectation_values[0], dtype=complex).reshape(-1)[0].real) == pytest.approx(0.0, abs=1e-10)
 
 
+def test_the_reference_piecewise_hamiltonian_tests_read_the_same():
+    """tests/test_simulator.py:2086-2150 of the reference with this package's names: one piecewise analog run equals two sequential
+    static runs (one-qubit X drives, one-site TDVP, the final state of the first run feeding the second); durations off the dt grid
+    are rejected."""
+    from yaqs_amd.api import AnalogSimParams, Hamiltonian, Observable, State
+    from yaqs_amd.tjm import Simulator
+
+    def _x_drive(amplitude):
+        return Hamiltonian.pauli(length=1, one_body=[(amplitude, "X")])
+
+    first, second = _x_drive(1.0), _x_drive(2.0)
+    sim = Simulator(parallel=False, show_progress=False)
+    first_params = AnalogSimParams(observables=[Observable("z", 0)], elapsed_time=0.1, dt=0.1, order=1, tdvp_mode="1site", get_state=True,
+                                   sample_timesteps=False)
+    first_result = sim.run(State(1, initial="zeros"), first, first_params)
+    assert first_result.output_state is not None
+    second_params = AnalogSimParams(observables=[Observable("z", 0)], elapsed_time=0.1, dt=0.1, order=1, tdvp_mode="1site", sample_timesteps=False)
+    sequential = sim.run(first_result.output_state, second, second_params)
+    piecewise = Hamiltonian.piecewise([(first, 0.1), (second, 0.1)])
+    combined = sim.run(State(1, initial="zeros"), piecewise,
+                       AnalogSimParams(observables=[Observable("z", 0)], elapsed_time=0.2, dt=0.1, order=1, tdvp_mode="1site", sample_timesteps=False))
+    np.testing.assert_allclose(np.asarray(combined.expectation_values[0], dtype=np.complex128),
+                               np.asarray(sequential.expectation_values[0], dtype=np.complex128), atol=1e-10)
+    # the exact value: |0> under exp(-i 0.1 X) then exp(-i 0.2 X): <Z> = cos(2 * 0.3)
+    assert float(combined.expectation_values[0][-1]) == pytest.approx(np.cos(0.6), abs=1e-9)
+    params = AnalogSimParams(observables=[Observable("z", 0)], elapsed_time=0.2, dt=0.1, order=1, tdvp_mode="1site")
+    with pytest.raises(ValueError, match="integer multiple"):
+        sim.run(State(1, initial="zeros"), Hamiltonian.piecewise([(first, 0.15), (second, 0.05)]), params)
+
+
 def test_piecewise_hamiltonian_through_the_reference_style_factory():
     """Hamiltonian.piecewise([(H, duration), ...]) (hamiltonian.py:179-230) equals the tuple-of-MPOs form."""
     from yaqs_amd.api import AnalogSimParams, Hamiltonian, MPO, Observable, State, Z as Zg

@@ -97,7 +97,7 @@ class Observable:
 
     def __init__(self, gate: BaseGate | str | np.ndarray, sites: int | list[int] | None = None):
         if isinstance(gate, str):
-            table = {"x": X, "y": Y, "z": Z, "id": Id}
+            table = {"x": X, "y": Y, "z": Z, "id": Id, "xx": XX, "yy": YY, "zz": ZZ}
             if gate.lower() not in table:
                 raise ValueError(f"Unknown observable {gate!r}")
             gate = table[gate.lower()]()
@@ -613,6 +613,32 @@ class MPO:
         return cls(t)
 
     @classmethod
+    def pauli(cls, *, length: int, two_body=None, one_body=None, bc: str = "open", **_unused) -> "MPO":
+        """H = sum_bonds c A_i B_{i+1} + sum_i c A_i from ``(coeff, op_i, op_j)`` / ``(coeff, op)`` terms (mpo.py:247-325), as an exact
+        finite-state-machine MPO of bond dimension 2 + len(two_body) (the reference compresses a Pauli sum; the operator is the same)."""
+        if bc != "open":
+            raise NotImplementedError("periodic boundary conditions are not built into the finite-state-machine MPO")
+        ops = {"I": _I, "X": _X, "Y": _Y, "Z": _Z}
+
+        def op(x):
+            x = str(x).upper()
+            if x not in ops:
+                raise ValueError(f"Invalid operator {x!r}; expected one of {sorted(ops)}.")
+            return ops[x]
+
+        two_body, one_body = list(two_body or []), list(one_body or [])
+        D = 2 + len(two_body)
+        w = np.zeros((D, D, 2, 2), dtype=C128)
+        w[0, 0] = _I
+        w[D - 1, D - 1] = _I
+        for k, (c, a, b) in enumerate(two_body):
+            w[0, 1 + k] = c * op(a)
+            w[1 + k, D - 1] = op(b)
+        for c, a in one_body:
+            w[0, D - 1] = w[0, D - 1] + c * op(a)
+        return cls._fsm(length, w)
+
+    @classmethod
     def ising(cls, length: int, J: float, g: float) -> "MPO":
         """H = -J sum Z_i Z_{i+1} - g sum X_i (sign convention of mpo.py:326-363)."""
         w = np.zeros((3, 3, 2, 2), dtype=C128)
@@ -763,7 +789,7 @@ class PiecewiseHamiltonian:
         for ham, duration in self.pieces:
             k = duration / dt
             if abs(k - round(k)) > 1e-9 or round(k) < 1:
-                raise ValueError("piece durations must be positive integer multiples of dt")
+                raise ValueError("every piece duration must be a positive integer multiple of dt")
             out.extend([ham] * int(round(k)))
         if len(out) != n_intervals:
             raise ValueError("piece durations must sum to elapsed_time")
