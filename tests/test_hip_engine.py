@@ -895,6 +895,32 @@ def test_the_reference_order_2_short_run_tests_read_the_same(elapsed_time, sampl
         assert float(np.asarray(run.expectation_values[0], dtype=complex).reshape(-1)[0].real) == pytest.approx(0.0, abs=1e-10)
 
 
+def test_the_reference_get_state_and_long_range_tests_read_the_same():
+    """tests/test_simulator.py:262-299 (the final state vector of a closed two-site run, orders 1 and 2, against the reference's
+    pinned vector) and :2068-2083 (the documented long-range crosstalk channel runs on the analog MPS path), with this package's names."""
+    from yaqs_amd.api import AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, X as Xg, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    for order in [1, 2]:
+        length = 2
+        initial_state = State(length, initial="zeros")
+        H = Hamiltonian.ising(length, J=1, g=0.5)
+        sim_params = AnalogSimParams(observables=[Observable(Xg(), length // 2)], elapsed_time=1, dt=0.1, num_traj=1, max_bond_dim=4,
+                                     svd_threshold=1e-6, order=order, get_state=True, sample_timesteps=False)
+        result = Simulator(show_progress=False).run(initial_state, H, sim_params)
+        assert result.output_state is not None
+        assert isinstance(result.output_state, State)
+        sv = result.output_state.mps.to_vec()
+        expected = [3.48123000e-01 + 0.76996349j, 0.00000000e00 + 0.349228j, 0.00000000e00 + 0.349228j, -1.92179306e-01 - 0.07150749j]
+        fidelity = np.abs(np.vdot(sv, expected)) ** 2
+        np.testing.assert_allclose(1, fidelity)
+    hamiltonian = Hamiltonian.ising(3, J=1.0, g=0.5)
+    noise = NoiseModel([{"name": "longrange_crosstalk_xy", "sites": [0, 2], "strength": 0.05}])
+    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=0.2, num_traj=2, random_seed=0)
+    result = Simulator(show_progress=False).run(State(3), hamiltonian, sim_params, noise)
+    assert result.expectation_values[0].shape[0] >= 1
+
+
 def test_the_reference_piecewise_hamiltonian_tests_read_the_same():
     """tests/test_simulator.py:2086-2150 of the reference with this package's names: one piecewise analog run equals two sequential
     static runs (one-qubit X drives, one-site TDVP, the final state of the first run feeding the second); durations off the dt grid

@@ -597,7 +597,9 @@ class Simulator:
                 # the physical state at the last time: the trajectory state (order 1) or the last sampled copy psi (order 2,
                 # analog_tjm.py:331-366); closed-system runs have one trajectory, slot 0 of the first chunk
                 use_psi = sim_params.order == 2 and len(sim_params.times) > 1
-                final = MPS(initial_state.length, tensors=last.export_state(0, 1 if use_psi else 0))
+                from .api import State
+
+                final = State(tensors=last.export_state(0, 1 if use_psi else 0))  # result.output_state is a State (result.py:155-189)
                 last.close()
         if world > 1:
             res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, lo, device)
