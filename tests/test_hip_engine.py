@@ -921,6 +921,56 @@ def test_the_reference_get_state_and_long_range_tests_read_the_same():
     assert result.expectation_values[0].shape[0] >= 1
 
 
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("sample_timesteps", [True, False])
+def test_the_reference_analog_tjm_shape_test_reads_the_same(order, sample_timesteps):
+    """tests/analog/test_analog_tjm.py:134-163 of the reference with this package's names: per-observable trajectories have one column
+    without intermediate sampling and len(times) columns with it."""
+    from yaqs_amd.api import AnalogSimParams, Hamiltonian, Observable, State, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    length = 5
+    state = State(length, initial="zeros")
+    hamiltonian = Hamiltonian.ising(length, J=1.0, g=0.5)
+    observables = [Observable(Zg(), site) for site in range(length)]
+    sim_params = AnalogSimParams(observables=observables, elapsed_time=0.2, dt=0.2, num_traj=1, max_bond_dim=2, order=order,
+                                 sample_timesteps=sample_timesteps)
+    result = Simulator(parallel=False, show_progress=False).run(state, hamiltonian, sim_params)
+    expected_cols = len(sim_params.times) if sample_timesteps else 1
+    assert result.expectation_values is not None
+    assert result.trajectories is not None
+    for traj in result.trajectories:
+        assert traj.shape == (sim_params.num_traj, expected_cols)
+
+
+@pytest.mark.parametrize("two_site_process", ["crosstalk_xx", "lowering_two"])
+def test_the_reference_two_site_jump_smoke_test_reads_the_same(two_site_process):
+    """tests/analog/test_analog_tjm.py:166-195 of the reference with this package's names: one-site plus one adjacent two-site jump
+    process (a Pauli pair and the non-Pauli ``lowering_two``), 20 trajectories, order 2."""
+    from yaqs_amd.api import AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    length = 2
+    hamiltonian = Hamiltonian.ising(length, 1.0, 0.5)
+    state = State(length, initial="zeros")
+    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], elapsed_time=0.1, dt=0.1, num_traj=20, max_bond_dim=8, order=2,
+                                 sample_timesteps=False, random_seed=42)
+    noise = NoiseModel([{"name": "pauli_x", "sites": [0], "strength": 0.02}, {"name": two_site_process, "sites": [0, 1], "strength": 0.01}])
+    result = Simulator(parallel=False, show_progress=False).run(state, hamiltonian, sim_params, noise)
+    results = result.expectation_values[0]
+    assert results is not None
+    z_mean = np.real(results)
+    assert np.isfinite(z_mean).all()
+    assert np.all(np.abs(z_mean) <= 1.0 + 1e-6)
+    # beyond the smoke test: the same run through the oracle, trajectory by trajectory
+    op = o.Params(observables=[o.Obs(Z, 0)], elapsed_time=0.1, dt=0.1, max_bond_dim=8, svd_threshold=1e-6, krylov_tol=1e-4, order=2,
+                  sample_timesteps=False, random_seed=42)
+    on = [o.make_process(q["name"], q["sites"], q["strength"], matrix=q.get("matrix"), factors=q.get("factors")) for q in noise.processes]
+    for t in range(20):
+        r, _, _ = o.run_trajectory(t, o.MPSState.product(length, "zeros"), on, op, o.ising_mpo(length, 1.0, 0.5))
+        assert np.allclose(result.trajectories[0][t], r[0], atol=1e-8), t
+
+
 def test_the_reference_piecewise_hamiltonian_tests_read_the_same():
     """tests/test_simulator.py:2086-2150 of the reference with this package's names: one piecewise analog run equals two sequential
     static runs (one-qubit X drives, one-site TDVP, the final state of the first run feeding the second); durations off the dt grid

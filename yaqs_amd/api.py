@@ -353,6 +353,9 @@ class NoiseModel:
                     elif m:
                         a, b = (m.group(2), m.group(1)) if swapped else (m.group(1), m.group(2))
                         p["matrix"] = np.kron(PAULI_MAP[a], PAULI_MAP[b])
+                    elif str(p["name"]) in ("raising_two", "lowering_two"):  # noise_library.py:88-106: kron of the one-site operators
+                        one = _LIB_OPS[str(p["name"])[:-4]]
+                        p["matrix"] = np.kron(one, one)
                     else:
                         raise ValueError(f"Unknown two-site noise operator {p['name']!r}")
                 else:
