@@ -235,3 +235,111 @@ def test_growing_run_bookkeeping_without_a_gpu(monkeypatch):
     assert log["built"][0] == (8, 6) and sorted(c for c, _ in log["built"]) == [8, 16, 16, 24, 24, 24]
     assert sorted(log["closed"]) == sorted(log["built"])           # nothing leaks
     assert all(a[0] < a[1] for a in log["adopted"]) and len(log["adopted"]) == 5
+
+
+def test_noise_model_normalisation_and_error_behaviour():
+    """Host logic of the data format on the boundary (noise_model.py:227-490, 668-790), behaviour by behaviour as the reference's own
+    tests document it (tests/core/data_structures/test_noise_model.py): site order with the operators following their sites, library
+    lookups, every construction error with its type and wording, run-context validation."""
+    from yaqs_amd.api import AnalogSimParams, NoiseModel, Observable, Z, is_pauli, validate_noise_model_for_run
+
+    X2, Y2, Z2 = (NoiseModel.get_operator(n) for n in ("x", "y", "z"))
+    # normalisation
+    p = NoiseModel([{"name": "custom_longrange_xy", "sites": [3, 1], "strength": 0.3, "factors": (X2, Y2)}]).processes[0]
+    assert p["sites"] == [1, 3] and np.allclose(p["factors"][0], Y2) and np.allclose(p["factors"][1], X2) and "matrix" not in p
+    p = NoiseModel([{"name": "longrange_crosstalk_xy", "sites": [0, 2], "strength": 0.3}]).processes[0]
+    assert np.allclose(p["factors"][0], X2) and np.allclose(p["factors"][1], Y2) and "matrix" not in p
+    p = NoiseModel([{"name": "crosstalk_xy", "sites": (1, 0), "strength": 0.1}]).processes[0]
+    assert p["sites"] == [0, 1] and np.allclose(p["matrix"], np.kron(Y2, X2))
+    custom = np.diag([1.0, 2.0, 3.0, 4.0]).astype(complex)
+    assert np.allclose(NoiseModel([{"name": "crosstalk_xy", "sites": [0, 1], "strength": 0.1, "matrix": custom}]).processes[0]["matrix"], custom)
+    assert NoiseModel([{"name": "raising_two", "sites": [0, 1], "strength": 0.1}]).processes[0]["matrix"].shape == (4, 4)
+    assert np.allclose(NoiseModel.get_operator("crosstalk_xy"), np.kron(X2, Y2))
+    op = NoiseModel.get_operator("pauli_x")
+    op[0, 0] = 99.0
+    assert NoiseModel.get_operator("pauli_x")[0, 0] == 0.0
+    almost_x = X2.copy()
+    almost_x[0, 1] += 5e-6
+    assert is_pauli(NoiseModel([{"name": "almost_x", "sites": [0], "strength": 0.1, "matrix": almost_x}]).processes[0]) is False
+    jumps = NoiseModel(scheduled_jumps=[{"time": 0.0, "sites": [0, 1], "name": "crosstalk_xx"}]).scheduled_jumps
+    assert jumps[0]["sites"] == [0, 1] and np.allclose(jumps[0]["matrix"], np.kron(X2, X2))
+    # construction errors: (exception, fragment of the message, keyword arguments)
+    lr = {"name": "custom", "sites": [0, 2], "strength": 0.1}
+    cases = [
+        (ValueError, "factors", dict(processes=[{"name": "foo_bar", "sites": [0, 2], "strength": 0.1}])),
+        (ValueError, "must contain 'distribution' key", dict(processes=[{"name": "pauli_x", "sites": [0], "strength": {"mean": 0.5, "std": 0.1}}])),
+        (ValueError, "nonnegative", dict(processes=[{"name": "pauli_x", "sites": [0], "strength": -0.1}])),
+        (ValueError, "finite", dict(processes=[{"name": "pauli_x", "sites": [0], "strength": np.nan}])),
+        (TypeError, "booleans", dict(processes=[{"name": "pauli_x", "sites": [True], "strength": 0.1}])),
+        (TypeError, "booleans", dict(processes=[{"name": "pauli_x", "sites": [0], "strength": True}])),
+        (ValueError, "distinct", dict(processes=[{"name": "pauli_x", "sites": [1, 1], "strength": 0.1}])),
+        (ValueError, "exactly 1 or 2", dict(processes=[{"name": "pauli_x", "sites": [], "strength": 0.1}])),
+        (ValueError, "ascending site order", dict(processes=[{"name": "custom", "sites": [1, 0], "strength": 0.1, "matrix": np.kron(X2, Z2)}])),
+        (ValueError, "Unknown noise operator", dict(processes=[{"name": "not_an_operator", "sites": [0], "strength": 0.1}])),
+        (ValueError, "std must be nonnegative", dict(processes=[{"name": "pauli_x", "sites": [0], "strength": {"distribution": "normal", "mean": 0.1, "std": -0.1}}])),
+        (ValueError, "Unknown distribution keys", dict(processes=[{"name": "pauli_x", "sites": [0], "strength": {"distribution": "normal", "mean": 0.1, "stdev": 0.1}}])),
+        (ValueError, "non-adjacent", dict(scheduled_jumps=[{"time": 0.0, "sites": [0, 2], "name": "x"}])),
+        (TypeError, "booleans", dict(scheduled_jumps=[{"time": True, "sites": [0], "name": "x"}])),
+        (ValueError, "both 'matrix' and 'factors'", dict(processes=[dict(lr, matrix=np.eye(4, dtype=complex), factors=(X2, Y2))])),
+        (ValueError, "not None", dict(processes=[dict(lr, factors=None)])),
+        (ValueError, "do not accept 'factors'", dict(scheduled_jumps=[{"time": 0.0, "sites": [0], "name": "x", "factors": None}])),
+        (TypeError, "dictionary", dict(processes=["not-a-dict"])),
+        (TypeError, "list or tuple", dict(processes={"name": "pauli_x", "sites": [0], "strength": 0.1})),
+        (TypeError, "list or tuple", dict(scheduled_jumps={"time": 0.0, "sites": [0], "name": "x"})),
+        (TypeError, "must be a string", dict(processes=[{"name": 1, "sites": [0], "strength": 0.1}])),
+        (ValueError, "nonempty", dict(processes=[{"name": "", "sites": [0], "strength": 0.1}])),
+        (TypeError, "list or tuple of integers", dict(processes=[{"name": "pauli_x", "sites": 0, "strength": 0.1}])),
+        (ValueError, "nonnegative", dict(processes=[{"name": "pauli_x", "sites": [-1], "strength": 0.1}])),
+        (TypeError, "numeric array", dict(processes=[{"name": "custom", "sites": [0], "strength": 0.1, "matrix": object()}])),
+        (ValueError, "square", dict(processes=[{"name": "custom", "sites": [0], "strength": 0.1, "matrix": np.ones((2, 3))}])),
+        (ValueError, "finite", dict(processes=[{"name": "custom", "sites": [0], "strength": 0.1, "matrix": np.array([[np.nan, 0], [0, 1]])}])),
+        (ValueError, "One-site processes do not accept", dict(processes=[{"name": "custom", "sites": [0], "strength": 0.1, "factors": (X2, Y2)}])),
+        (ValueError, "use 'matrix', not 'factors'", dict(processes=[{"name": "custom", "sites": [0, 1], "strength": 0.1, "factors": (X2, Y2)}])),
+        (ValueError, "require 'factors'", dict(processes=[dict(lr, matrix=np.eye(4, dtype=complex))])),
+        (ValueError, "exactly two", dict(processes=[dict(lr, factors=(X2,))])),
+        (ValueError, "'time' key", dict(scheduled_jumps=[{"sites": [0], "name": "x"}])),
+        (ValueError, "ascending site order", dict(scheduled_jumps=[{"time": 0.0, "sites": [1, 0], "name": "custom", "matrix": np.kron(X2, Z2)}])),
+        (ValueError, "finite", dict(scheduled_jumps=[{"time": np.nan, "sites": [0], "name": "x"}])),
+    ]
+    for exc, fragment, kw in cases:
+        with pytest.raises(exc, match=fragment):
+            NoiseModel(**kw)
+    nm = NoiseModel([{"name": "pauli_x", "sites": [0], "strength": 0.1}])
+    nm.processes[0]["strength"] = {"distribution": "bogus", "mean": 0.0, "std": 0.1}
+    with pytest.raises(ValueError, match="Unsupported distribution type"):
+        nm.sample(rng=0)
+    # run-context validation
+    sp = AnalogSimParams(observables=[Observable(Z(), 0)], dt=0.1, elapsed_time=0.2, order=1, get_state=True)
+    validate_noise_model_for_run(NoiseModel([{"name": "pauli_x", "sites": [0], "strength": 0.1}]), length=2, physical_dimensions=2, representation="mps", sim_params=sp)
+    lowering = np.array([[0, 1], [0, 0]], dtype=complex)
+    sched = NoiseModel(scheduled_jumps=[{"time": 0.0, "sites": [0], "name": "x"}])
+    run_cases = [
+        ("out of range", NoiseModel([{"name": "pauli_x", "sites": [3], "strength": 0.1}]), dict(length=2)),
+        ("matrix shape", NoiseModel([{"name": "custom", "sites": [0], "strength": 0.1, "matrix": np.eye(3, dtype=complex)}]), dict(length=2)),
+        ("factor on site", NoiseModel([dict(lr, factors=(np.eye(3, dtype=complex), Y2))]), dict(length=3)),
+        ("Digital TJM does not support non-adjacent", NoiseModel([{"name": "longrange_crosstalk_xy", "sites": [0, 2], "strength": 0.1}]), dict(length=3, is_digital=True)),
+        ("non-Pauli long-range", NoiseModel([dict(lr, factors=(lowering, Y2))]), dict(length=3)),
+        ("AnalogSimParams are required", sched, dict(length=2, sim_params=None)),
+        ("only supported for single-State analog MPS", sched, dict(length=2, is_digital=True, sim_params=sp)),
+        ("only supported for single-State analog MPS", sched, dict(length=2, representation="vector", sim_params=sp)),
+        ("order=1", sched, dict(length=2, sim_params=AnalogSimParams(observables=[Observable(Z(), 0)], dt=0.1, elapsed_time=0.2, order=2, get_state=True))),
+        ("not on the simulation time grid", NoiseModel(scheduled_jumps=[{"time": 0.05, "sites": [0], "name": "x"}]), dict(length=2, sim_params=sp)),
+    ]
+    for fragment, model, kw in run_cases:
+        kw.setdefault("representation", "mps")
+        with pytest.raises(ValueError, match=fragment):
+            validate_noise_model_for_run(model, **kw)
+    validate_noise_model_for_run(sched, length=2, representation="mps", sim_params=sp)
+
+
+def test_normal_strength_below_zero_is_clamped_with_a_warning(caplog):
+    """noise_model.py:521-533: a normal draw below zero becomes 0 and is reported."""
+    import logging
+
+    from yaqs_amd.api import NoiseModel
+
+    nm = NoiseModel([{"name": "pauli_x", "sites": [0], "strength": {"distribution": "normal", "mean": -5.0, "std": 0.1}}])
+    with caplog.at_level(logging.WARNING):
+        out = nm.sample(rng=np.random.default_rng(1))
+    assert "was negative and clamped to 0.0" in caplog.text
+    assert out.processes[0]["strength"] == 0.0

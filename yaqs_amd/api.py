@@ -303,8 +303,24 @@ def is_pauli(proc: dict[str, Any]) -> bool:
     return False
 
 
+_DISTRIBUTIONS = ("normal", "lognormal", "truncated_normal")
+_TWO_SITE_LIBRARY = ("raising_two", "lowering_two")
+_log = __import__("logging").getLogger(__name__)
+
+
+def _is_bool(x) -> bool:
+    return isinstance(x, (bool, np.bool_))
+
+
+def _crosstalk_letters(name):
+    m = re.fullmatch(r"(?:longrange_)?crosstalk_([xyz])([xyz])", str(name))
+    return (m.group(1), m.group(2)) if m else None
+
+
 class NoiseModel:
-    """``NoiseModel(processes)`` (noise_model.py:227-490): list of {name, sites, strength[, matrix|factors]}."""
+    """``NoiseModel(processes, scheduled_jumps)`` (noise_model.py:227-490): list of {name, sites, strength[, matrix | factors]} and
+    of {time, sites, name[, matrix]}.  Construction normalises and validates: sites ascending (operators reordered with them),
+    library operators attached as ``matrix`` (one site, adjacent pair) or ``factors`` (distant pair), the documented errors."""
 
     def __init__(self, processes: Sequence[dict[str, Any]] | None = None, scheduled_jumps: Sequence[dict[str, Any]] | None = None):
         self.processes: list[dict[str, Any]] = []
@@ -319,59 +335,154 @@ class NoiseModel:
         if not isinstance(processes, (list, tuple)):
             raise TypeError("processes must be a list or tuple of dictionaries.")
         for original in processes:
-            for key in ("name", "sites", "strength"):
-                if key not in original:
-                    raise ValueError(f"Each process must have a '{key}' key.")
-            p = dict(original)
-            sites = [int(s) for s in p["sites"]]
-            if isinstance(p["strength"], dict):  # static disorder: {"distribution", "mean", "std"}, resolved by sample()
-                spec = p["strength"]
-                if spec.get("distribution") not in ("normal", "lognormal", "truncated_normal"):
-                    raise ValueError(f"Unsupported distribution type: {spec.get('distribution')}")
-                p["strength"] = {"distribution": spec["distribution"], "mean": float(spec["mean"]), "std": float(spec["std"])}
-            else:
-                g = float(p["strength"])
-                if not np.isfinite(g) or g < 0:
-                    raise ValueError("Noise strengths must be finite and nonnegative.")
-                p["strength"] = g
-            if len(sites) == 1:
-                if "matrix" in p:
-                    p["matrix"] = np.asarray(p["matrix"], dtype=C128)
-                else:
-                    if p["name"] not in _LIB_OPS:
-                        raise ValueError(f"Unknown noise operator {p['name']!r}")
-                    p["matrix"] = _LIB_OPS[p["name"]].copy()
-            elif len(sites) == 2:
-                swapped = sites[0] > sites[1]
-                sites = sorted(sites)
-                m = re.fullmatch(r"(?:longrange_)?crosstalk_([xyz])([xyz])", str(p["name"]))
-                if abs(sites[1] - sites[0]) == 1:
-                    if "matrix" in p:
-                        if swapped:
-                            raise ValueError("Custom full two-site matrices require ascending site order.")
-                        p["matrix"] = np.asarray(p["matrix"], dtype=C128)
-                    elif m:
-                        a, b = (m.group(2), m.group(1)) if swapped else (m.group(1), m.group(2))
-                        p["matrix"] = np.kron(PAULI_MAP[a], PAULI_MAP[b])
-                    elif str(p["name"]) in ("raising_two", "lowering_two"):  # noise_library.py:88-106: kron of the one-site operators
-                        one = _LIB_OPS[str(p["name"])[:-4]]
-                        p["matrix"] = np.kron(one, one)
-                    else:
-                        raise ValueError(f"Unknown two-site noise operator {p['name']!r}")
-                else:
-                    if "factors" in p:
-                        f = p["factors"]
-                        p["factors"] = (np.asarray(f[0], dtype=C128), np.asarray(f[1], dtype=C128))
-                    elif m:
-                        a, b = (m.group(2), m.group(1)) if swapped else (m.group(1), m.group(2))
-                        p["factors"] = (PAULI_MAP[a].copy(), PAULI_MAP[b].copy())
-                    else:
-                        raise ValueError("Long-range two-site processes need 'factors' or a crosstalk name.")
-            else:
-                raise ValueError("Noise processes must act on one or two sites.")
-            p["sites"] = sites
-            self.processes.append(p)
+            self.processes.append(self._normalize_process(original))
 
+    # ---- library ----------------------------------------------------------------------
+    @staticmethod
+    def get_operator(name: str) -> np.ndarray:
+        """An owned copy of a library operator by name (noise_model.py:262-296): one-site names, ``raising_two`` / ``lowering_two``
+        and ``[longrange_]crosstalk_ab`` as the Kronecker product of its two Pauli letters."""
+        if not isinstance(name, str):
+            raise TypeError("Noise operator name must be a string.")
+        if name in _LIB_OPS:
+            return _LIB_OPS[name].copy()
+        if name in _TWO_SITE_LIBRARY:
+            one = _LIB_OPS[name[:-4]]
+            return np.kron(one, one)
+        letters = _crosstalk_letters(name)
+        if letters:
+            return np.kron(PAULI_MAP[letters[0]], PAULI_MAP[letters[1]])
+        raise ValueError(f"Unknown noise operator {name!r}; supported: {sorted(_LIB_OPS) + list(_TWO_SITE_LIBRARY)} and crosstalk_ab with a, b in x, y, z.")
+
+    # ---- validation helpers -------------------------------------------------------------
+    @staticmethod
+    def _sites_of(entry, what: str) -> tuple[list[int], bool]:
+        raw = entry["sites"]
+        if not isinstance(raw, (list, tuple)):
+            raise TypeError(f"{what} 'sites' must be a list or tuple of integers.")
+        if any(_is_bool(q) for q in raw):
+            raise TypeError(f"{what} 'sites' must be integers, not booleans.")
+        if any(not isinstance(q, (int, np.integer)) for q in raw):
+            raise TypeError(f"{what} 'sites' must be a list or tuple of integers.")
+        sites = [int(q) for q in raw]
+        if len(sites) not in (1, 2):
+            raise ValueError(f"{what} must act on exactly 1 or 2 sites.")
+        if any(q < 0 for q in sites):
+            raise ValueError(f"{what} site indices must be nonnegative.")
+        if len(set(sites)) != len(sites):
+            raise ValueError(f"{what} sites must be distinct.")
+        swapped = len(sites) == 2 and sites[0] > sites[1]
+        return sorted(sites), swapped
+
+    @staticmethod
+    def _name_of(entry, what: str) -> str:
+        name = entry["name"]
+        if not isinstance(name, str):
+            raise TypeError(f"{what} 'name' must be a string.")
+        if not name:
+            raise ValueError(f"{what} 'name' must be nonempty.")
+        return name
+
+    @staticmethod
+    def _matrix_of(value, what: str) -> np.ndarray:
+        try:
+            m = np.asarray(value, dtype=C128)
+        except (TypeError, ValueError) as err:
+            raise TypeError(f"{what} must be a numeric array.") from err
+        if m.ndim != 2 or m.shape[0] != m.shape[1]:
+            raise ValueError(f"{what} must be a square matrix.")
+        if not np.all(np.isfinite(m)):
+            raise ValueError(f"{what} must have finite entries.")
+        return m
+
+    @staticmethod
+    def _strength_of(value):
+        if isinstance(value, dict):  # static disorder: {"distribution", "mean", "std"}, resolved by sample()
+            if "distribution" not in value:
+                raise ValueError("Noise strength dict must contain 'distribution' key.")
+            unknown = set(value) - {"distribution", "mean", "std"}
+            if unknown:
+                raise ValueError(f"Unknown distribution keys: {sorted(unknown)}")
+            if value["distribution"] not in _DISTRIBUTIONS:
+                raise ValueError(f"Unsupported distribution type: {value['distribution']}")
+            for key in ("mean", "std"):
+                if key not in value:
+                    raise ValueError(f"Noise strength distribution needs a '{key}' value.")
+                if _is_bool(value[key]) or not np.isfinite(float(value[key])):
+                    raise ValueError(f"Noise strength distribution {key} must be a finite number.")
+            if float(value["std"]) < 0:
+                raise ValueError("Noise strength distribution std must be nonnegative.")
+            return {"distribution": value["distribution"], "mean": float(value["mean"]), "std": float(value["std"])}
+        if _is_bool(value):
+            raise TypeError("Noise strengths must be numbers, not booleans.")
+        g = float(value)
+        if not np.isfinite(g):
+            raise ValueError("Noise strengths must be finite.")
+        if g < 0:
+            raise ValueError("Noise strengths must be nonnegative.")
+        return g
+
+    def _normalize_process(self, original) -> dict[str, Any]:
+        if not isinstance(original, dict):
+            raise TypeError("Each noise process must be a dictionary.")
+        for key in ("name", "sites", "strength"):
+            if key not in original:
+                raise ValueError(f"Each process must have a '{key}' key.")
+        p = dict(original)
+        name = self._name_of(p, "Noise process")
+        sites, swapped = self._sites_of(p, "Noise process")
+        p["strength"] = self._strength_of(p["strength"])
+        if "matrix" in p and "factors" in p:
+            raise ValueError("A noise process cannot specify both 'matrix' and 'factors'.")
+        if "factors" in p and p["factors"] is None:
+            raise ValueError("'factors' must be a pair of matrices, not None.")
+        if len(sites) == 1:
+            if "factors" in p:
+                raise ValueError("One-site processes do not accept 'factors'; use 'matrix'.")
+            p["matrix"] = self._matrix_of(p["matrix"], "A process 'matrix'") if "matrix" in p else self._library_one_site(name)
+        elif sites[1] - sites[0] == 1:
+            if "factors" in p:
+                raise ValueError("Adjacent two-site processes use 'matrix', not 'factors'.")
+            if "matrix" in p:
+                if swapped:
+                    raise ValueError("Custom full two-site matrices require ascending site order.")
+                p["matrix"] = self._matrix_of(p["matrix"], "A process 'matrix'")
+            else:
+                p["matrix"] = self._library_pair(name, swapped)
+        else:
+            if "matrix" in p:
+                raise ValueError("Non-adjacent two-site processes require 'factors' (one operator per site), not a full 'matrix'.")
+            if "factors" in p:
+                f = p["factors"]
+                if not isinstance(f, (list, tuple)) or len(f) != 2:
+                    raise ValueError("'factors' must hold exactly two matrices.")
+                pair = (self._matrix_of(f[0], "A process factor"), self._matrix_of(f[1], "A process factor"))
+                p["factors"] = (pair[1], pair[0]) if swapped else pair  # the operators follow their sites
+            else:
+                letters = _crosstalk_letters(name)
+                if not letters:
+                    raise ValueError(f"Long-range process {name!r} needs 'factors' or a crosstalk_ab name.")
+                a, b = (letters[1], letters[0]) if swapped else letters
+                p["factors"] = (PAULI_MAP[a].copy(), PAULI_MAP[b].copy())
+        p["sites"] = sites
+        return p
+
+    @staticmethod
+    def _library_one_site(name: str) -> np.ndarray:
+        if name not in _LIB_OPS:
+            raise ValueError(f"Unknown noise operator {name!r}; supported one-site operators: {sorted(_LIB_OPS)}.")
+        return _LIB_OPS[name].copy()
+
+    @staticmethod
+    def _library_pair(name: str, swapped: bool) -> np.ndarray:
+        letters = _crosstalk_letters(name)
+        if letters:
+            a, b = (letters[1], letters[0]) if swapped else letters
+            return np.kron(PAULI_MAP[a], PAULI_MAP[b])
+        if name in _TWO_SITE_LIBRARY:  # noise_library.py:88-106: symmetric under the exchange of the two sites
+            one = _LIB_OPS[name[:-4]]
+            return np.kron(one, one)
+        raise ValueError(f"Unknown noise operator {name!r} for an adjacent pair; use crosstalk_ab, raising_two, lowering_two or 'matrix'.")
 
     def sample(self, rng=None) -> "NoiseModel":
         """One realisation of static disorder (noise_model.py:492-559): distribution-valued strengths become floats, drawn in
@@ -388,7 +499,10 @@ class NoiseModel:
             if isinstance(sv, dict):
                 kind, mean, std = sv["distribution"], sv["mean"], sv["std"]
                 if kind == "normal":
-                    val = max(0.0, float(generator.normal(loc=mean, scale=std)))
+                    val = float(generator.normal(loc=mean, scale=std))
+                    if val < 0.0:
+                        _log.warning("Sampled strength %.6g of process %r was negative and clamped to 0.0", val, proc.get("name"))
+                        val = 0.0
                 elif kind == "lognormal":
                     val = float(generator.lognormal(mean=mean, sigma=std))
                 elif kind == "truncated_normal":
@@ -410,42 +524,73 @@ class NoiseModel:
     def has_disorder(self) -> bool:
         return any(isinstance(q["strength"], dict) for q in self.processes)
 
-    @staticmethod
-    def _normalize_scheduled_jump(jump) -> dict[str, Any]:
+    def _normalize_scheduled_jump(self, jump) -> dict[str, Any]:
         """noise_model.py:298-338: {time, sites, name[, matrix]}; two-site jumps act on adjacent sites in ascending order."""
+        if not isinstance(jump, dict):
+            raise TypeError("Each scheduled jump must be a dictionary.")
         for key in ("time", "sites", "name"):
             if key not in jump:
                 raise ValueError(f"Each scheduled jump must have a '{key}' key.")
         if "factors" in jump:
             raise ValueError("Scheduled jumps do not accept 'factors'; use 'matrix' for custom operators.")
         j = dict(jump)
+        if _is_bool(j["time"]):
+            raise TypeError("Scheduled jump times must be numbers, not booleans.")
         j["time"] = float(j["time"])
         if not np.isfinite(j["time"]):
             raise ValueError("Scheduled jump time must be finite.")
-        sites = [int(s_) for s_ in (j["sites"] if isinstance(j["sites"], (list, tuple)) else [j["sites"]])]
-        swapped = False
-        if len(sites) == 2:
-            swapped = sites[0] > sites[1]
-            sites = sorted(sites)
-            if sites[1] - sites[0] != 1:
-                raise ValueError(f"Scheduled jump acts on non-adjacent sites {sites}. Only nearest-neighbor scheduled jumps are supported.")
-            if swapped and "matrix" in j:
-                raise ValueError("Custom full scheduled-jump matrices require ascending site order.")
-        elif len(sites) != 1:
-            raise ValueError("Scheduled jumps must act on one or two sites.")
-        j["sites"] = sites
+        name = self._name_of(j, "Scheduled jump")
+        sites, swapped = self._sites_of(j, "Scheduled jump")
+        if len(sites) == 2 and sites[1] - sites[0] != 1:
+            raise ValueError(f"Scheduled jump acts on non-adjacent sites {sites}. Only nearest-neighbor scheduled jumps are supported.")
         if "matrix" in j:
-            j["matrix"] = np.asarray(j["matrix"], dtype=C128)
+            if swapped:
+                raise ValueError("Custom full scheduled-jump matrices require ascending site order.")
+            j["matrix"] = self._matrix_of(j["matrix"], "A scheduled jump 'matrix'")
+        elif len(sites) == 1:
+            j["matrix"] = self._library_one_site(name)
         else:
-            m = re.fullmatch(r"(?:longrange_)?crosstalk_([xyz])([xyz])", str(j["name"]))
-            if m:
-                a, b = (m.group(2), m.group(1)) if swapped else (m.group(1), m.group(2))
-                j["matrix"] = np.kron(PAULI_MAP[a], PAULI_MAP[b])
-            elif j["name"] in _LIB_OPS:
-                j["matrix"] = _LIB_OPS[j["name"]].copy()
-            else:
-                raise ValueError(f"Unknown noise operator {j['name']!r}")
+            j["matrix"] = self._library_pair(name, swapped)
+        j["sites"] = sites
         return j
+
+
+def validate_noise_model_for_run(noise_model, *, length: int, physical_dimensions=2, representation: str = "mps", is_digital: bool = False,
+                                 is_ensemble: bool = False, sim_params=None) -> None:
+    """Run-context checks of a noise model (noise_model.py:668-790): site range, operator shapes, what the digital and the analog
+    MPS paths support, and where scheduled jumps are allowed."""
+    if noise_model is None:
+        return
+    dims = [int(physical_dimensions)] * length if np.isscalar(physical_dimensions) else [int(q) for q in physical_dimensions]
+    for proc in noise_model.processes:
+        sites = proc["sites"]
+        if any(q >= length for q in sites):
+            raise ValueError(f"Noise process {proc['name']!r} acts on site(s) {sites} out of range for {length} sites.")
+        if "matrix" in proc:
+            want = int(np.prod([dims[q] for q in sites]))
+            if np.shape(proc["matrix"]) != (want, want):
+                raise ValueError(f"Noise process {proc['name']!r}: matrix shape {np.shape(proc['matrix'])} does not match ({want}, {want}).")
+        if "factors" in proc:
+            for q, f in zip(sites, proc["factors"]):
+                if np.shape(f) != (dims[q], dims[q]):
+                    raise ValueError(f"Noise process {proc['name']!r}: factor on site {q} has shape {np.shape(f)}, expected ({dims[q]}, {dims[q]}).")
+        if len(sites) == 2 and sites[1] - sites[0] > 1:
+            if is_digital:
+                raise ValueError("Digital TJM does not support non-adjacent two-site noise processes.")
+            if representation == "mps" and not is_ensemble and not is_pauli(proc):
+                raise ValueError("Analog MPS TJM does not support non-Pauli long-range processes (dissipation.py:136-138).")
+    if noise_model.scheduled_jumps:
+        if is_digital or is_ensemble or representation != "mps":
+            raise ValueError("scheduled_jumps are only supported for single-State analog MPS runs.")
+        if sim_params is None or not hasattr(sim_params, "times") or not hasattr(sim_params, "order"):
+            raise ValueError("AnalogSimParams are required to validate scheduled_jumps.")
+        if sim_params.order != 1:
+            raise ValueError(f"scheduled_jumps are only supported for AnalogSimParams(order=1); got order={sim_params.order}.")
+        for jump in noise_model.scheduled_jumps:
+            if any(q >= length for q in jump["sites"]):
+                raise ValueError(f"Scheduled jump acts on site(s) {jump['sites']} out of range for {length} sites.")
+            if not np.any(np.isclose(sim_params.times, jump["time"], atol=sim_params.dt * 1e-3, rtol=0.0)):
+                raise ValueError(f"Scheduled jump time {jump['time']} is not on the simulation time grid.")
 
 
 # ------------------------------------------------------------------ states / operators

@@ -605,6 +605,7 @@ class Simulator:
             res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, lo, device)
         out = Result(sim_params, res_all, diag_all)
         out.output_state = final
+        out.noise_model = noise_model  # the sampled realisation the trajectories ran with (result.py:155-189)
         return out
 
     def run_circuit(self, initial_state: MPS, layers, sim_params, noise_model: NoiseModel | None = None, basis: str = "Z"):
@@ -657,7 +658,9 @@ class Simulator:
             res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, first, device)
             if wants_shots:
                 counts = gather_counts(counts, device)
-        return CircuitResult(sim_params, res_all, diag_all, counts if wants_shots else None)
+        out = CircuitResult(sim_params, res_all, diag_all, counts if wants_shots else None)
+        out.noise_model = noise_model
+        return out
 
 
 def _encoded(state: MPS) -> MPS:
