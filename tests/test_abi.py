@@ -343,3 +343,98 @@ def test_normal_strength_below_zero_is_clamped_with_a_warning(caplog):
         out = nm.sample(rng=np.random.default_rng(1))
     assert "was negative and clamped to 0.0" in caplog.text
     assert out.processes[0]["strength"] == 0.0
+
+
+def test_simulation_parameter_classes_validate_like_the_reference():
+    """Host logic of AnalogSimParams / DigitalSimParams / Observable (simulation_parameters.py:100-745), behaviour by behaviour as the
+    reference's tests document it (tests/core/data_structures/test_simulation_parameters.py): the time grid and its rounding dust,
+    presets and overrides, every validation error with type and wording, observable construction from names / matrices / bitstrings,
+    the site-sorted worker order with PVMs last."""
+    from yaqs_amd.api import (SIMULATION_PRESETS, AnalogSimParams, DigitalSimParams, EvolutionMode, Observable, PVM, SchmidtSpectrum, X, Y, Z,
+                              _validate_tdvp_sweeps)
+
+    obs = [Observable(X(), 0)]
+    p = AnalogSimParams(observables=obs, elapsed_time=1.0, dt=0.2, num_traj=50)
+    assert np.allclose(p.times, [0.0, 0.2, 0.4, 0.6, 0.8, 1.0]) and p.sample_timesteps is True and p.num_traj == 50 and p.order == 1
+    assert np.allclose(AnalogSimParams(observables=obs, elapsed_time=0.0, dt=0.1).times, [0.0])
+    for elapsed, dt in ((100.1, 0.1), (1.0, 1.0 / 9015), (1.23456789, 1e-8)):  # float64 rounding dust is not a fraction of a step
+        assert AnalogSimParams(observables=obs, elapsed_time=elapsed, dt=dt).times[-1] == elapsed
+    for elapsed, dt in ((0.15, 0.1), (0.25, 0.1), (5e-13, 1e-12), (1.5e-12, 1e-12), (1.0, 1e9)):
+        with pytest.raises(ValueError, match="integer multiple"):
+            AnalogSimParams(observables=obs, elapsed_time=elapsed, dt=dt)
+    for elapsed, dt, fragment in ((-0.1, 0.1, "non-negative"), (0.1, 0.0, "positive"), (0.1, -0.1, "positive"), (float("nan"), 0.1, "finite"),
+                                  (0.1, float("inf"), "finite"), (1e308, 1e-308, "elapsed_time / dt must be finite")):
+        with pytest.raises(ValueError, match=fragment):
+            AnalogSimParams(observables=obs, elapsed_time=elapsed, dt=dt)
+    for elapsed, dt in ((True, 0.1), (0.1, False), ("0.1", 0.1), (0.1, None)):
+        with pytest.raises(TypeError, match="real number"):
+            AnalogSimParams(observables=obs, elapsed_time=elapsed, dt=dt)
+    for cls, kw in ((AnalogSimParams, {}), (DigitalSimParams, {"get_state": True}), (DigitalSimParams, {"shots": 100})):
+        for preset, expected in SIMULATION_PRESETS.items():
+            q = cls(preset=preset, **kw)
+            assert (q.preset, q.svd_threshold, q.max_bond_dim, q.krylov_tol) == (preset, expected["svd_threshold"], expected["max_bond_dim"], expected["krylov_tol"])
+        q = cls(preset="fast", svd_threshold=1e-8, max_bond_dim=512, krylov_tol=1e-12, **kw)
+        assert (q.svd_threshold, q.max_bond_dim, q.krylov_tol) == (1e-8, 512, 1e-12)
+        assert cls(preset="balanced", max_bond_dim=None, **kw).max_bond_dim is None
+        assert (cls(**kw).tdvp_mode, cls(**kw).tdvp_sweeps) == ("2site", 1)
+        for bad in ("invalid", None):
+            with pytest.raises(ValueError, match="preset must be one of"):
+                cls(preset=bad, **kw)
+        for bad in ("nope", ["discarded_weight"], 1, None):
+            with pytest.raises(ValueError, match="trunc_mode"):
+                cls(trunc_mode=bad, **kw)
+        with pytest.raises(ValueError, match="tdvp_mode"):
+            cls(tdvp_mode="invalid", **kw)
+        for bad in (0, -1):
+            with pytest.raises(ValueError, match="tdvp_sweeps"):
+                cls(tdvp_sweeps=bad, **kw)
+        with pytest.raises(TypeError, match="random_seed must be int or None"):
+            cls(random_seed="not-a-seed", **kw)
+        with pytest.raises(ValueError, match="random_seed must be non-negative"):
+            cls(random_seed=-1, **kw)
+        for bad in (0.0, -1.0, float("inf"), float("nan")):
+            with pytest.raises(ValueError, match="krylov_tol must be a finite positive float"):
+                cls(krylov_tol=bad, **kw)
+        for bad in (-1.0, float("inf"), float("nan")):
+            with pytest.raises(ValueError, match="svd_threshold must be a finite non-negative float"):
+                cls(svd_threshold=bad, **kw)
+        assert cls(svd_threshold=0.0, **kw).svd_threshold == 0.0
+    for bad in (1.5, True):
+        with pytest.raises(TypeError, match="tdvp_sweeps"):
+            _validate_tdvp_sweeps(bad)
+    assert AnalogSimParams(evolution_mode="bug").evolution_mode is EvolutionMode.BUG
+    with pytest.raises(ValueError, match="evolution_mode"):
+        AnalogSimParams(evolution_mode="not-a-mode")
+    assert DigitalSimParams(shots=1).gate_mode == "mpo" and DigitalSimParams(get_state=True, gate_mode="full-tdvp").gate_mode == "full-tdvp"
+    with pytest.raises(ValueError, match="gate_mode"):
+        DigitalSimParams(get_state=True, gate_mode="invalid")
+    for bad in (0, -1):
+        with pytest.raises(ValueError, match="shots must be a positive int"):
+            DigitalSimParams(shots=bad)
+    with pytest.raises(TypeError, match=r"keyword-only|takes 1 positional"):
+        DigitalSimParams([Observable("z", 0)])
+    d = DigitalSimParams()
+    assert d.observables == [] and d.shots is None and not d.get_state
+    # observables
+    assert Observable("entropy", sites=[3, 4]).gate.name == "entropy" and Observable("schmidt_spectrum", sites=[3, 4]).sites == [3, 4]
+    pvm = Observable("10101", sites=None)
+    assert pvm.gate.name == "pvm" and pvm.gate.bitstring == "10101" and np.allclose(pvm.gate.matrix, np.eye(2))
+    assert Observable("pvm").gate.bitstring == "pvm"
+    local = Observable(np.diag([1.0, -1.0]), 0)
+    assert local.gate.name == "local" and local.gate.interaction == 1
+    for bad in (np.ones(3), np.ones((2, 3))):
+        with pytest.raises(ValueError, match="Local operator matrix"):
+            Observable(bad, 0)
+    with pytest.raises(TypeError, match="unexpected keyword argument 'positions'"):
+        Observable("z", 0, positions=[0.0, 1.0])
+    with pytest.raises(TypeError, match="only supported for named observables"):
+        Observable(np.eye(2), 0, positions=[0.0, 1.0])
+    # worker order: by first site, ties by user order, PVMs last; derived from the current list
+    z3, x2, y1, ssp = Observable(Z(), sites=3), Observable(X(), sites=2), Observable(Y(), sites=1), Observable(SchmidtSpectrum(), sites=[1, 2])
+    dp = DigitalSimParams(observables=[z3, x2, y1, ssp], num_traj=7, max_bond_dim=128, get_state=True, sample_layers=True, num_mid_measurements=2)
+    assert dp.sorted_observables == [y1, ssp, x2, z3] and dp.observable_sorted_indices == (3, 2, 0, 1)
+    dp.observables.append(Observable(Z(), sites=0))
+    assert dp.observable_sorted_indices == (4, 3, 1, 2, 0)
+    with pytest.raises(AssertionError):
+        DigitalSimParams(observables=[Observable(PVM("101"), sites=None), Observable(Z(), sites=0)])
+    DigitalSimParams(observables=[Observable(PVM("0"), sites=None), Observable(PVM("1"), sites=None)])

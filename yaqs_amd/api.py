@@ -93,23 +93,39 @@ META_OBSERVABLES = ("entropy", "schmidt_spectrum", "pvm")
 
 
 class Observable:
-    """``Observable(gate, sites)`` (simulation_parameters.py:330-416); one-site local observables."""
+    """``Observable(gate, sites)`` (simulation_parameters.py:330-416): a gate instance, a gate name (``"x"``, ``"zz"``, ``"entropy"``,
+    ``"schmidt_spectrum"``), a local operator matrix, or - any other string - a computational-basis projector (PVM) on that bitstring."""
 
-    def __init__(self, gate: BaseGate | str | np.ndarray, sites: int | list[int] | None = None):
+    def __init__(self, gate: BaseGate | str | np.ndarray, sites: int | list[int] | None = None, **parameters):
         if isinstance(gate, str):
-            table = {"x": X, "y": Y, "z": Z, "id": Id, "xx": XX, "yy": YY, "zz": ZZ}
-            if gate.lower() not in table:
-                raise ValueError(f"Unknown observable {gate!r}")
-            gate = table[gate.lower()]()
+            table = {"x": X, "y": Y, "z": Z, "id": Id, "xx": XX, "yy": YY, "zz": ZZ, "entropy": Entropy, "schmidt_spectrum": SchmidtSpectrum}
+            if gate == "position":
+                raise NotImplementedError("the 'position' observable lives on sites of physical dimension > 2, which the HIP path does not build")
+            if parameters:
+                if gate.lower() in table:
+                    raise TypeError(f"Observable {gate!r} got an unexpected keyword argument {next(iter(parameters))!r}")
+                if gate == "pvm" or set(gate) <= {"0", "1"}:
+                    raise TypeError("'pvm' does not accept observable parameters")
+                raise TypeError(f"Unknown observable {gate!r}")
+            gate = table[gate.lower()]() if gate.lower() in table else PVM(gate)  # simulation_parameters.py:392-401: fall back to a PVM
         elif isinstance(gate, np.ndarray):
-            gate = BaseGate("local", np.asarray(gate, dtype=C128), interaction=1 if gate.shape == (2, 2) else 2)
+            if parameters:
+                raise TypeError("Observable parameters are only supported for named observables")
+            m = np.asarray(gate, dtype=C128)
+            if m.ndim != 2 or m.shape[0] != m.shape[1]:
+                raise ValueError("Local operator matrix must be a square two-dimensional array")
+            gate = BaseGate("local", m, interaction=2 if m.shape == (4, 4) else 1)
+        elif parameters:
+            raise TypeError("Observable parameters are only supported for named observables")
         self.gate = gate
-        assert sites is not None
         self.sites = sites
-        self.gate.set_sites(sites)
+        if sites is not None:
+            self.gate.set_sites(sites)
 
     @property
     def first_site(self) -> int:
+        if self.sites is None:  # PVMs act on the whole chain; they sort behind the local observables
+            return 0
         return self.sites[0] if isinstance(self.sites, (list, tuple)) else int(self.sites)
 
 
@@ -123,112 +139,149 @@ SIMULATION_PRESETS = {
 }
 _USE_PRESET = object()
 _TRUNC = ("discarded_weight", "relative", "hard_cutoff", "relative_discarded_weight")
+_TDVP_MODES = ("1site", "2site", "dynamic")
+_GATE_MODES = ("swaps", "tdvp", "full-tdvp", "mpo")
 
 
-class AnalogSimParams:
+class EvolutionMode(str, __import__("enum").Enum):
+    """simulation_parameters.py:300-336."""
+
+    TDVP = "tdvp"
+    BUG = "bug"
+
+
+def _real_number(value, what: str) -> float:
+    if isinstance(value, (bool, np.bool_)) or not isinstance(value, (int, float, np.integer, np.floating)):
+        raise TypeError(f"{what} must be a real number, got {type(value).__name__}.")
+    return float(value)
+
+
+def _validate_time_grid(elapsed_time, dt) -> tuple[float, float, int]:
+    """simulation_parameters.py:100-170: dt finite and positive, elapsed_time finite and non-negative, their ratio an integer up to
+    float64 rounding dust (a few ulps of the larger of elapsed_time and dt), never a genuine fraction of a step."""
+    elapsed_time, dt = _real_number(elapsed_time, "elapsed_time"), _real_number(dt, "dt")
+    if not np.isfinite(elapsed_time) or not np.isfinite(dt):
+        raise ValueError("elapsed_time and dt must be finite.")
+    if elapsed_time < 0:
+        raise ValueError("elapsed_time must be non-negative.")
+    if dt <= 0:
+        raise ValueError("dt must be positive.")
+    with np.errstate(over="ignore"):
+        ratio = elapsed_time / dt
+    if not np.isfinite(ratio):
+        raise ValueError("elapsed_time / dt must be finite.")
+    n_steps = int(round(ratio))
+    slack = 8 * np.finfo(np.float64).eps * max(abs(elapsed_time), dt * max(n_steps, 1))
+    if abs(n_steps * dt - elapsed_time) > slack or (n_steps == 0 and elapsed_time != 0.0):
+        raise ValueError("elapsed_time must be an integer multiple of dt.")
+    return elapsed_time, dt, n_steps
+
+
+def _validate_tdvp_sweeps(value) -> int:
+    if isinstance(value, (bool, np.bool_)) or not isinstance(value, (int, np.integer)):
+        raise TypeError("tdvp_sweeps must be an int.")
+    if value < 1:
+        raise ValueError("tdvp_sweeps must be at least 1.")
+    return int(value)
+
+
+def _common_knobs(self, *, preset, num_traj, max_bond_dim, trunc_mode, svd_threshold, krylov_tol, random_seed, tdvp_sweeps, tdvp_mode) -> None:
+    """Validation shared by AnalogSimParams and DigitalSimParams (simulation_parameters.py:216-300)."""
+    if not isinstance(preset, str) or preset not in SIMULATION_PRESETS:
+        raise ValueError(f"preset must be one of {tuple(SIMULATION_PRESETS)}, got {preset!r}.")
+    pv = SIMULATION_PRESETS[preset]
+    if not isinstance(trunc_mode, str) or trunc_mode not in _TRUNC:
+        raise ValueError(f"trunc_mode must be one of {_TRUNC}, got {trunc_mode!r}.")
+    if not isinstance(tdvp_mode, str) or tdvp_mode not in _TDVP_MODES:
+        raise ValueError(f"tdvp_mode must be one of {_TDVP_MODES}, got {tdvp_mode!r}.")
+    if random_seed is not None:
+        if isinstance(random_seed, (bool, np.bool_)) or not isinstance(random_seed, (int, np.integer)):
+            raise TypeError("random_seed must be int or None.")
+        if random_seed < 0:
+            raise ValueError("random_seed must be non-negative.")
+    if max_bond_dim is not _USE_PRESET and max_bond_dim is not None and (isinstance(max_bond_dim, bool) or not isinstance(max_bond_dim, (int, np.integer))):
+        raise TypeError(f"max_bond_dim must be int, None, or omitted, got {type(max_bond_dim).__name__}.")
+    self.preset = preset
+    self.num_traj = num_traj if num_traj is not None else pv["num_traj"]
+    self.max_bond_dim = pv["max_bond_dim"] if max_bond_dim is _USE_PRESET else max_bond_dim
+    self.trunc_mode = trunc_mode
+    self.svd_threshold = float(svd_threshold if svd_threshold is not None else pv["svd_threshold"])
+    if not np.isfinite(self.svd_threshold) or self.svd_threshold < 0.0:
+        raise ValueError(f"svd_threshold must be a finite non-negative float, got {svd_threshold!r}.")
+    self.krylov_tol = float(krylov_tol if krylov_tol is not None else pv["krylov_tol"])
+    if not np.isfinite(self.krylov_tol) or self.krylov_tol <= 0.0:
+        raise ValueError(f"krylov_tol must be a finite positive float, got {krylov_tol!r}.")
+    self.random_seed = None if random_seed is None else int(random_seed)
+    self.tdvp_sweeps = _validate_tdvp_sweeps(tdvp_sweeps)
+    self.tdvp_mode = tdvp_mode
+
+
+class _ObservableOrdering:
+    """Site-sorted worker order of the observables, PVMs last (simulation_parameters.py:419-475); derived on every access."""
+
+    def _ordering(self):
+        local = [i for i, ob in enumerate(self.observables) if ob.gate.name != "pvm"]
+        pvms = [i for i, ob in enumerate(self.observables) if ob.gate.name == "pvm"]
+        return sorted(local, key=lambda i: (self.observables[i].first_site, i)) + pvms
+
+    @property
+    def sorted_observables(self):
+        return [self.observables[i] for i in self._ordering()]
+
+    @property
+    def observable_sorted_indices(self):
+        out = [0] * len(self.observables)
+        for row, user in enumerate(self._ordering()):
+            out[user] = row
+        return tuple(out)
+
+
+class AnalogSimParams(_ObservableOrdering):
     """Numerical knobs of the analog TJM path (simulation_parameters.py:520-613)."""
 
     def __init__(self, observables=None, elapsed_time: float = 0.1, dt: float = 0.1, num_traj: int | None = None,
                  max_bond_dim=_USE_PRESET, trunc_mode: str = "discarded_weight", svd_threshold: float | None = None,
                  krylov_tol: float | None = None, order: int = 1, *, preset: str = "balanced", sample_timesteps: bool = True,
                  get_state: bool = False, random_seed: int | None = None, tdvp_sweeps: int = 1, tdvp_mode: str = "2site",
-                 evolution_mode: str = "tdvp"):
-        mode = str(getattr(evolution_mode, "value", evolution_mode)).lower()
-        if mode not in ("tdvp", "bug"):
-            raise ValueError(f"evolution_mode must be one of ('tdvp', 'bug'), got {evolution_mode!r}.")  # simulation_parameters.py:338-357
-        self.evolution_mode = mode
-        if preset not in SIMULATION_PRESETS:
-            raise ValueError(f"Unknown preset {preset!r}")
-        pv = SIMULATION_PRESETS[preset]
-        if not (np.isfinite(dt) and dt > 0):
-            raise ValueError("dt must be finite and > 0")
-        if not (np.isfinite(elapsed_time) and elapsed_time >= 0):
-            raise ValueError("elapsed_time must be finite and >= 0")
-        n_steps = int(round(elapsed_time / dt))
-        if abs(n_steps * dt - elapsed_time) > 1e-9 * max(1.0, abs(elapsed_time)):
-            raise ValueError("elapsed_time must be an integer multiple of dt")
-        if trunc_mode not in _TRUNC:
-            raise ValueError(f"Unknown truncation mode: {trunc_mode!r}")
-        if tdvp_sweeps < 1:
-            raise ValueError("tdvp_sweeps must be >= 1")
-        if tdvp_mode not in ("1site", "2site", "dynamic"):
-            raise ValueError(f"Unknown tdvp_mode {tdvp_mode!r}")
-        self.preset = preset
+                 evolution_mode="tdvp"):
+        try:
+            self.evolution_mode = evolution_mode if isinstance(evolution_mode, EvolutionMode) else EvolutionMode(evolution_mode)
+        except ValueError:
+            raise ValueError(f"evolution_mode must be one of {tuple(m.value for m in EvolutionMode)}, got {evolution_mode!r}.") from None
+        self.elapsed_time, self.dt, n_steps = _validate_time_grid(elapsed_time, dt)
+        _common_knobs(self, preset=preset, num_traj=num_traj, max_bond_dim=max_bond_dim, trunc_mode=trunc_mode, svd_threshold=svd_threshold,
+                      krylov_tol=krylov_tol, random_seed=random_seed, tdvp_sweeps=tdvp_sweeps, tdvp_mode=tdvp_mode)
         self.observables = [] if observables is None else list(observables)
-        self.elapsed_time = float(elapsed_time)
-        self.dt = float(dt)
         self.times = self.dt * np.arange(n_steps + 1, dtype=np.float64)
         if n_steps > 0:
             self.times[-1] = self.elapsed_time
         self.sample_timesteps = sample_timesteps
-        self.num_traj = num_traj if num_traj is not None else pv["num_traj"]
-        self.max_bond_dim = pv["max_bond_dim"] if max_bond_dim is _USE_PRESET else max_bond_dim
-        self.trunc_mode = trunc_mode
-        self.svd_threshold = svd_threshold if svd_threshold is not None else pv["svd_threshold"]
-        self.krylov_tol = krylov_tol if krylov_tol is not None else pv["krylov_tol"]
         self.order = order
         self.get_state = get_state
-        self.random_seed = random_seed
-        self.tdvp_sweeps = tdvp_sweeps
-        self.tdvp_mode = tdvp_mode
-
-    def _ordering(self):
-        idx = sorted(range(len(self.observables)), key=lambda i: (self.observables[i].first_site, i))
-        return idx
-
-    @property
-    def sorted_observables(self):
-        return [self.observables[i] for i in self._ordering()]
-
-    @property
-    def observable_sorted_indices(self):
-        out = [0] * len(self.observables)
-        for row, user in enumerate(self._ordering()):
-            out[user] = row
-        return tuple(out)
 
 
-class DigitalSimParams:
-    """Truncation / sampling knobs of the circuit path (simulation_parameters.py:616-745); ``dt`` is fixed to 1."""
+class DigitalSimParams(_ObservableOrdering):
+    """Truncation / sampling knobs of the circuit path (simulation_parameters.py:616-745); keyword-only; ``dt`` is fixed to 1."""
 
-    def __init__(self, observables=None, num_traj: int | None = None, max_bond_dim=_USE_PRESET, trunc_mode: str = "discarded_weight",
-                 svd_threshold: float | None = None, *, preset: str = "balanced", sample_layers: bool = False, num_mid_measurements: int = 0,
-                 get_state: bool = False, random_seed: int | None = None, shots: int | None = None, gate_mode: str = "mpo"):
-        if preset not in SIMULATION_PRESETS:
-            raise ValueError(f"Unknown preset {preset!r}")
-        if trunc_mode not in _TRUNC:
-            raise ValueError(f"Unknown truncation mode: {trunc_mode!r}")
-        if gate_mode not in ("swaps", "tdvp", "full-tdvp", "mpo"):
-            raise ValueError(f"gate_mode must be one of ('swaps', 'tdvp', 'full-tdvp', 'mpo'), got {gate_mode!r}.")  # simulation_parameters.py:175-190
+    def __init__(self, *, observables=None, shots: int | None = None, num_traj: int | None = None, max_bond_dim=_USE_PRESET,
+                 trunc_mode: str = "discarded_weight", svd_threshold: float | None = None, krylov_tol: float | None = None,
+                 preset: str = "balanced", get_state: bool = False, sample_layers: bool = False, num_mid_measurements: int = 0,
+                 random_seed: int | None = None, gate_mode: str = "mpo", tdvp_sweeps: int = 1, tdvp_mode: str = "2site"):
+        if not isinstance(gate_mode, str) or gate_mode not in _GATE_MODES:
+            raise ValueError(f"gate_mode must be one of {_GATE_MODES}, got {gate_mode!r}.")  # simulation_parameters.py:175-190
         self.gate_mode = gate_mode  # nearest-neighbour gates are TEBD in every mode; "swaps" also routes distant pairs with TEBD
-        if shots is not None and shots < 1:
-            raise ValueError("shots must be a positive integer when set")
-        pv = SIMULATION_PRESETS[preset]
+        if shots is not None and (isinstance(shots, bool) or not isinstance(shots, (int, np.integer)) or shots < 1):
+            raise ValueError("shots must be a positive int or None.")
+        _common_knobs(self, preset=preset, num_traj=num_traj, max_bond_dim=max_bond_dim, trunc_mode=trunc_mode, svd_threshold=svd_threshold,
+                      krylov_tol=krylov_tol, random_seed=random_seed, tdvp_sweeps=tdvp_sweeps, tdvp_mode=tdvp_mode)
         self.observables = [] if observables is None else list(observables)
+        n_pvm = sum(ob.gate.name == "pvm" for ob in self.observables)
+        assert n_pvm in (0, len(self.observables)), "PVM observables cannot be mixed with other observables"  # simulation_parameters.py:700-712
         self.shots = shots
-        self.num_traj = num_traj if num_traj is not None else pv["num_traj"]
-        self.max_bond_dim = pv["max_bond_dim"] if max_bond_dim is _USE_PRESET else max_bond_dim
-        self.trunc_mode = trunc_mode
-        self.svd_threshold = svd_threshold if svd_threshold is not None else pv["svd_threshold"]
         self.sample_layers = sample_layers
         self.num_mid_measurements = num_mid_measurements
         self.get_state = get_state
-        self.random_seed = random_seed
         self.dt = 1.0  # simulation_parameters.py:667
-
-    def _ordering(self):
-        return sorted(range(len(self.observables)), key=lambda i: (self.observables[i].first_site, i))
-
-    @property
-    def sorted_observables(self):
-        return [self.observables[i] for i in self._ordering()]
-
-    @property
-    def observable_sorted_indices(self):
-        out = [0] * len(self.observables)
-        for row, user in enumerate(self._ordering()):
-            out[user] = row
-        return tuple(out)
 
 
 @dataclass
