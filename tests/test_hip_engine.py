@@ -971,6 +971,56 @@ def test_the_reference_two_site_jump_smoke_test_reads_the_same(two_site_process)
         assert np.allclose(result.trajectories[0][t], r[0], atol=1e-8), t
 
 
+def test_the_reference_result_tests_read_the_same():
+    """tests/core/data_structures/test_result.py:41-166 of the reference with this package's names (the qiskit circuit replaced by the
+    gate layers of the same Ising circuit): what a Result holds after an analog run, after a shots-only and an observables-only
+    circuit run, the sampled noise model, untouched sim_params / observables, a pickle round trip."""
+    import pickle
+
+    from yaqs_amd import AnalogSimParams, DigitalSimParams, Hamiltonian, NoiseModel, Observable, Result, Simulator, State
+    from yaqs_amd.api import Z as Zg, ising_trotter_layers
+
+    length = 2
+    H = Hamiltonian.ising(length, J=1.0, g=0.5)
+    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], elapsed_time=0.1, dt=0.1, num_traj=1, get_state=True, sample_timesteps=False)
+    result = Simulator(parallel=False, show_progress=False).run(State(length, initial="zeros"), H, sim_params)
+    assert isinstance(result, Result)
+    assert result.sim_params is sim_params
+    assert result.observables is not sim_params.observables
+    assert len(result.observables) == 1 and len(result.expectation_values) == 1 and len(result.trajectories) == 1
+    assert result.output_state is not None
+    assert result.noise_model is None and result.counts is None
+    assert result.multi_time_times is None and result.multi_time_results is None
+    assert result.runtime_cost is not None and result.max_bond is not None and result.total_bond is not None
+    assert result.times is not None and len(result.runtime_cost) == len(result.times)
+
+    circuit = ising_trotter_layers(2, 1, 0.5, 0.1, 1)
+    shot_params = DigitalSimParams(shots=16, max_bond_dim=4)
+    shot_result = Simulator(parallel=False, show_progress=False).run(State(2, initial="zeros"), circuit, shot_params)
+    assert shot_result.counts is not None and sum(shot_result.counts.values()) == shot_params.shots
+    assert shot_result.runtime_cost is None and shot_result.max_bond is None and shot_result.total_bond is None
+    obs_params = DigitalSimParams(observables=[Observable(Zg(), 0)], num_traj=1, max_bond_dim=4)
+    obs_result = Simulator(parallel=False, show_progress=False).run(State(2, initial="zeros"), circuit, obs_params)
+    assert obs_result.counts is None
+    assert obs_result.runtime_cost is not None and obs_result.max_bond is not None and obs_result.total_bond is not None
+
+    noise_model = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 1e-3} for i in range(2)])
+    noisy_params = DigitalSimParams(shots=4, max_bond_dim=4, random_seed=0)
+    noisy = Simulator(parallel=False, show_progress=False).run(State(2, initial="zeros"), circuit, noisy_params, noise_model)
+    assert noisy.noise_model is not None
+    assert not hasattr(noisy_params, "noise_model")
+
+    user_obs = Observable(Zg(), 0)
+    many = AnalogSimParams(observables=[user_obs], elapsed_time=0.1, dt=0.1, num_traj=1000, get_state=True, sample_timesteps=False)
+    res = Simulator(parallel=False, show_progress=False).run(State(length, initial="zeros"), H, many)
+    assert many.num_traj == 1000 and not hasattr(user_obs, "results")
+    assert res.expectation_values[0] is not None and res.observables[0] is not user_obs
+
+    restored = pickle.loads(pickle.dumps(result))
+    assert isinstance(restored, Result) and isinstance(restored.sim_params, AnalogSimParams) and len(restored.observables) == 1
+    np.testing.assert_allclose(np.asarray(restored.expectation_values[0]), np.asarray(result.expectation_values[0]))
+
+
 def test_the_reference_piecewise_hamiltonian_tests_read_the_same():
     """tests/test_simulator.py:2086-2150 of the reference with this package's names: one piecewise analog run equals two sequential
     static runs (one-qubit X drives, one-site TDVP, the final state of the first run feeding the second); durations off the dt grid

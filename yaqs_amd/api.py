@@ -868,39 +868,37 @@ class MPO:
 
 # ------------------------------------------------------------------ result
 class Result:
-    """Averaged observables and diagnostics (result.py:34-189)."""
+    """Outcome of a run (result.py:34-189): ``sim_params`` (the caller's object, untouched), copies of the observables in the user's
+    order, per-trajectory rows and their means, averaged diagnostics, the final state / sampled noise model / measurement histogram
+    when the run produced them, ``None`` otherwise."""
 
-    def __init__(self, sim_params: AnalogSimParams, results_sorted: np.ndarray, diagnostics: np.ndarray):
+    def __init__(self, sim_params, results_sorted, diagnostics, counts=None):
+        import copy
+
         # results_sorted: [num_traj, n_obs_sorted, T]; diagnostics: [num_traj, 3, T]
         self.sim_params = sim_params
-        self.observables = list(sim_params.observables)
-        self.times = sim_params.times if sim_params.sample_timesteps else sim_params.times[-1:]
-        idx = sim_params.observable_sorted_indices
-        self.trajectories = [results_sorted[:, idx[u], :] for u in range(len(self.observables))]
-        self.expectation_values = [np.mean(t, axis=0) for t in self.trajectories]
-        d = np.mean(diagnostics, axis=0)
-        self.runtime_cost, self.max_bond, self.total_bond = d[0], d[1], d[2]
-        self.trajectory_diagnostics = diagnostics
-
-
-class CircuitResult:
-    """Outcome of ``Simulator.run_circuit``: averaged observables / diagnostics as in ``Result`` plus the aggregated
-    measurement histogram ``counts`` {basis-state integer: occurrences} when ``shots`` is set (result.py:155-189)."""
-
-    def __init__(self, sim_params: DigitalSimParams, results_sorted, diagnostics, counts):
-        self.sim_params = sim_params
-        self.observables = list(sim_params.observables)
+        self.observables = [copy.copy(ob) for ob in sim_params.observables]
+        self.output_state = None
+        self.noise_model = None
         self.counts = counts
+        self.multi_time_times = None    # correlator outputs of the reference's other solvers
+        self.multi_time_results = None
+        self.times = None
+        if hasattr(sim_params, "times"):
+            self.times = sim_params.times if sim_params.sample_timesteps else sim_params.times[-1:]
+        self.trajectories, self.expectation_values = [], []
         if results_sorted is not None and len(self.observables):
             idx = sim_params.observable_sorted_indices
             self.trajectories = [results_sorted[:, idx[u], :] for u in range(len(self.observables))]
             self.expectation_values = [np.mean(t, axis=0) for t in self.trajectories]
-        else:
-            self.trajectories, self.expectation_values = [], []
-        if diagnostics is not None:
+        self.runtime_cost = self.max_bond = self.total_bond = None
+        self.trajectory_diagnostics = diagnostics  # per-trajectory rows (this package's addition), also for shots-only runs
+        if diagnostics is not None and (len(self.observables) or counts is None):  # a shots-only run reports no averaged diagnostics
             d = np.mean(diagnostics, axis=0)
             self.runtime_cost, self.max_bond, self.total_bond = d[0], d[1], d[2]
-            self.trajectory_diagnostics = diagnostics
+
+
+CircuitResult = Result  # circuit runs return the same object, with ``counts`` when ``shots`` is set (result.py:155-189)
 
 
 # ------------------------------------------------------------------ front-end wrappers of the reference's newer API

@@ -658,7 +658,8 @@ class Simulator:
             res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, first, device)
             if wants_shots:
                 counts = gather_counts(counts, device)
-        out = CircuitResult(sim_params, res_all, diag_all, counts if wants_shots else None)
+        has_obs = len(sim_params.observables) > 0  # a shots-only run reports no diagnostics (result.py:155-189)
+        out = CircuitResult(sim_params, res_all if has_obs else None, diag_all, counts if wants_shots else None)
         out.noise_model = noise_model
         return out
 
