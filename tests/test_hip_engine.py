@@ -971,6 +971,24 @@ def test_the_reference_two_site_jump_smoke_test_reads_the_same(two_site_process)
         assert np.allclose(result.trajectories[0][t], r[0], atol=1e-8), t
 
 
+def test_reruns_are_bit_identical_and_independent_of_the_batching():
+    """tests/core/test_random_utils.py:72-100 and tests/test_simulator.py:87-117 of the reference (bit-identical reruns, parallel equals
+    serial): here the pool is the batch axis - the same seed gives the same bits on a rerun, and a trajectory's numbers do not depend on
+    how many others share its launches or on the chunk it lands in."""
+    from yaqs_amd import AnalogSimParams, Hamiltonian, NoiseModel, Observable, Simulator, State
+    from yaqs_amd.api import Z as Zg
+
+    L = 6
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=0.5, dt=0.1, num_traj=11, max_bond_dim=8, svd_threshold=1e-10,
+                        order=2, random_seed=42)
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
+    H = Hamiltonian.ising(L, J=1.0, g=0.5)
+    runs = [np.stack(Simulator(batch=b, show_progress=False).run(State(L, initial="x+"), H, p, noise).trajectories) for b in (11, 11, 3, 7, 1)]
+    assert np.array_equal(runs[0], runs[1])                      # rerun: atol = 0
+    for other in runs[2:]:
+        assert np.array_equal(runs[0], other)                    # 11 at once, chunks of 3 / 7, one by one: the same bits
+
+
 def test_the_reference_result_tests_read_the_same():
     """tests/core/data_structures/test_result.py:41-166 of the reference with this package's names (the qiskit circuit replaced by the
     gate layers of the same Ising circuit): what a Result holds after an analog run, after a shots-only and an observables-only
