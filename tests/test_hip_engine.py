@@ -971,6 +971,44 @@ def test_the_reference_two_site_jump_smoke_test_reads_the_same(two_site_process)
         assert np.allclose(result.trajectories[0][t], r[0], atol=1e-8), t
 
 
+def test_ensemble_mean_converges_to_the_lindblad_solution():
+    """The physics the method exists for (cf. tests/analog/test_analog_tjm.py:323-379 of the reference, TJM against a dense solver
+    within 0.03): the mean over 16384 trajectories of a 4-site dissipative Ising chain (amplitude damping and dephasing on every site)
+    against the exact solution of the Lindblad master equation, exp(t Liouvillian) applied to the vectorised density matrix."""
+    import scipy.linalg
+
+    from yaqs_amd import AnalogSimParams, Hamiltonian, NoiseModel, Observable, Simulator, State
+    from yaqs_amd.api import Z as Zg
+
+    L, T, gamma, n = 4, 1.0, 0.1, 16384
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=T, dt=0.05, num_traj=n, max_bond_dim=16, svd_threshold=1e-10,
+                        order=2, random_seed=7, sample_timesteps=False)
+    noise = NoiseModel([{"name": name, "sites": [i], "strength": gamma} for i in range(L) for name in ("lowering", "pauli_z")])
+    res = Simulator(show_progress=False).run(State(L, initial="x+"), Hamiltonian.ising(L, J=1.0, g=0.5), p, noise)
+    got = np.array([res.expectation_values[s][-1] for s in range(L)])
+    # dense Lindblad: d rho / dt = -i [H, rho] + sum_k gamma (L_k rho L_k^dag - {L_k^dag L_k, rho} / 2), site 0 = least significant index
+    dim = 2 ** L
+    H = o.mpo_to_matrix(o.ising_mpo(L, 1.0, 0.5))
+    lower = np.array([[0, 1], [0, 0]], dtype=complex)
+
+    def embed(m, s):
+        return np.kron(np.eye(2 ** (L - 1 - s)), np.kron(m, np.eye(2 ** s)))
+
+    jumps = [embed(m, s) for s in range(L) for m in (lower, Z)]
+    eye = np.eye(dim)
+    liouv = -1j * (np.kron(eye, H) - np.kron(H.T, eye))  # column-stacking vec: vec(A rho B) = (B^T kron A) vec(rho)
+    for Lk in jumps:
+        LdL = Lk.conj().T @ Lk
+        liouv += gamma * (np.kron(Lk.conj(), Lk) - 0.5 * np.kron(eye, LdL) - 0.5 * np.kron(LdL.T, eye))
+    psi = o.MPSState.product(L, "x+").to_vec()
+    rho = (scipy.linalg.expm(T * liouv) @ np.outer(psi, psi.conj()).reshape(-1, order="F")).reshape(dim, dim, order="F")
+    exact = np.array([np.real(np.trace(rho @ embed(Z, s))) for s in range(L)])
+    assert abs(np.trace(rho) - 1.0) < 1e-10
+    spread = np.array([np.std(res.trajectories[s][:, -1]) for s in range(L)]) / np.sqrt(n)
+    assert np.all(np.abs(got - exact) < 5 * spread + 2e-3), (got, exact, spread)  # 5 sigma of the mean + the O(dt^2) splitting error
+    assert np.max(np.abs(exact)) > 0.05  # the dynamics is not trivial
+
+
 def test_reruns_are_bit_identical_and_independent_of_the_batching():
     """tests/core/test_random_utils.py:72-100 and tests/test_simulator.py:87-117 of the reference (bit-identical reruns, parallel equals
     serial): here the pool is the batch axis - the same seed gives the same bits on a rerun, and a trajectory's numbers do not depend on
