@@ -1138,6 +1138,14 @@ def test_run_dispatches_on_the_parameter_type_like_the_reference():
     assert np.array_equal(np.stack(a.trajectories), np.stack(b.trajectories))
     with pytest.raises(NotImplementedError):
         Simulator().run(MPS(L, state="zeros"), layers, p, noise, num_traj=5)
+    with pytest.raises(ValueError, match="qubit counts do not match"):  # tests/test_simulator.py:838-855
+        Simulator().run(MPS(L - 1, state="zeros"), layers, p, noise)
+    with pytest.raises(NotImplementedError):
+        Simulator().run([MPS(L, state="zeros")], layers, p, noise)
+    with pytest.raises(NotImplementedError):
+        Simulator().run(MPS(L, state="zeros"), "OPENQASM 2.0;", p, noise)
+    with pytest.raises(TypeError):
+        Simulator().run("not a state", layers, p, noise)
 
 
 def test_circuit_growth_continues_at_the_clipped_layer(monkeypatch):

@@ -541,7 +541,20 @@ class Simulator:
 
         if observables is not None or num_traj is not None or random_seed is not None or get_state:
             raise NotImplementedError("program-wide arguments belong to SimulationProgram runs, which are outside the hot path built here")
+        if isinstance(initial_state, (list, tuple)):
+            raise NotImplementedError("a list of initial states (deterministic unitary ensemble, simulator.py:1190-1196) is outside the TJM path built here")
+        if not hasattr(initial_state, "tensors"):
+            raise TypeError("initial_state must be a State (MPS representation).")  # simulator.py:1465-1476
+        if isinstance(hamiltonian, (str, os.PathLike)):
+            raise NotImplementedError("QASM circuits go through the reference's qiskit front end; pass gate layers (yaqs_amd.api.GateLayer)")
+        if sim_params is None:
+            raise NotImplementedError("SimulationProgram / pair-list runs are the reference's control plane, outside the path built here")
         if isinstance(sim_params, DigitalSimParams):
+            if not isinstance(hamiltonian, (list, tuple)) or not all(hasattr(layer, "singles") for layer in hamiltonian):
+                raise TypeError("a circuit run needs a list of gate layers as operator.")  # simulator.py:1537-1544
+            top = max([q for layer in hamiltonian for q, _ in layer.singles] + [e[0] + 1 if len(e) == 2 else max(e[0], e[1]) for layer in hamiltonian for e in list(layer.even) + list(layer.odd)] + [0])
+            if top >= initial_state.length:
+                raise ValueError("State and circuit qubit counts do not match.")  # simulator.py:1738-1741
             return self.run_circuit(initial_state, hamiltonian, sim_params, noise_model)
 
         pieces = None
