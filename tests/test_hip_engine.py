@@ -1334,6 +1334,49 @@ def test_noncommuting_channels_use_one_exponential_of_the_summed_generator(adjac
     assert np.allclose(got[0], expected, atol=1e-10), (got[0], expected)
 
 
+@pytest.mark.parametrize("case", range(int(os.environ.get("TJM_FUZZ_GROWTH_CASES", "12"))))
+def test_randomised_front_end_runs_with_growing_storage_match_oracle(case, monkeypatch):
+    """Differential test of the whole front end on seeded random set-ups that outgrow their first storage capacity: random chain
+    length, model, noise, order, sampling mode, truncation settings and max_bond_dim in {None, 4096, a binding cap}, forced piece
+    splitting in half of the cases; per trajectory against the oracle, bond diagnostics included."""
+    import yaqs_amd.tjm as tjm_mod
+    from yaqs_amd import AnalogSimParams, Hamiltonian, NoiseModel, Observable, Simulator, State
+    from yaqs_amd.api import X as Xg, Z as Zg
+
+    rng = np.random.default_rng(9100 + case)
+    L = int(rng.integers(8, 12))
+    heis = bool(rng.integers(0, 2))
+    order = int(rng.integers(1, 3))
+    sample_timesteps = bool(rng.integers(0, 2))
+    max_bond = [None, 4096, int(rng.integers(9, 20))][int(rng.integers(0, 3))]
+    steps = int(rng.integers(8, 15))
+    ntraj = int(rng.integers(2, 5))
+    gamma = float(rng.uniform(0.02, 0.15))
+    name = str(rng.choice(["lowering", "pauli_x", "pauli_z", "raising"]))
+    if rng.integers(0, 2):
+        monkeypatch.setattr(tjm_mod.Simulator, "_batch_for", lambda self, remaining, length, chi, mpo, device: min(remaining, 4 if chi <= 8 else 2))
+    built = _recording_engine(monkeypatch)
+    kw = dict(elapsed_time=0.1 * steps, dt=0.1, max_bond_dim=max_bond, svd_threshold=float(10.0 ** rng.uniform(-11, -8)), krylov_tol=1e-10, order=order,
+              random_seed=int(rng.integers(0, 10 ** 6)))
+    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), int(rng.integers(0, L)))]
+    oobs = [o.Obs(Z, s) for s in range(L)] + [o.Obs(X, obs[-1].sites)]
+    H = Hamiltonian.heisenberg(L, 1.0, 0.9, 0.7, 0.2) if heis else Hamiltonian.ising(L, 1.0, 0.8)
+    Ho = o.heisenberg_mpo(L, 1.0, 0.9, 0.7, 0.2) if heis else o.ising_mpo(L, 1.0, 0.8)
+    init = str(rng.choice(["Neel", "x+", "wall"]))
+    p = AnalogSimParams(observables=obs, num_traj=ntraj, sample_timesteps=sample_timesteps, **kw)
+    noise = NoiseModel([{"name": name, "sites": [i], "strength": gamma} for i in range(L)])
+    res = Simulator(show_progress=False).run(State(L, initial=init), H, p, noise)
+    op = o.Params(observables=oobs, sample_timesteps=sample_timesteps, **kw)
+    on = [o.make_process(name, [i], gamma) for i in range(L)]
+    idx = op.observable_sorted_indices
+    for t in range(ntraj):
+        r, dg, _ = o.run_trajectory(t, o.MPSState.product(L, init), on, op, Ho)
+        for u in range(len(obs)):
+            assert np.allclose(res.trajectories[u][t], r[idx[u]], atol=1e-8), (case, t, u)
+        assert np.array_equal(res.trajectory_diagnostics[t], dg), (case, t)
+    assert built[0] == 8 and max(built) <= 64, built  # every run starts small; 2**(L//2) bounds what it can ever need
+
+
 def test_capacity_overflow_is_reported_by_the_engine_and_the_driver():
     """A two-site truncation that wants more values than the new bond stores sets the engine's flag (and only such a one), and
     tjm_engine_run stops after that time step with TJM_ERR_CAPACITY instead of finishing a run that is not the reference's."""
