@@ -237,7 +237,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "c128 (f64 arithmetic)",
+            "dtype": "f64",  # arithmetic type; the tensors are complex128 (interleaved re, im)
             "data": "synthetic",
             "config": {
                 "workload": f"{L}-site {WORKLOADS[args.workload][0]}, chi={chi}, dt={dt:g}, "
@@ -245,6 +245,7 @@ def main():
                 "trajectories_in_flight_per_gpu": B,
                 "steps_per_trajectory": STEPS_PER_TRAJ,
                 "parallelism": f"trajectory-sharded x{world}",
+                "storage": "complex128",
             },
             "site_updates_per_sec": site_updates,
             "counters_per_step": {k_: (stats1[k_] - stats0[k_]) / K for k_ in stats1},
