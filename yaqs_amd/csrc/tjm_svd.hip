@@ -892,10 +892,10 @@ __device__ inline bool small_jacobi(cplx* Y, int pitch, int n, int lane, double 
     for (int pc = 0; pc + 1 < n; ++pc)
       for (int qc = pc + 1; qc < n; ++qc) {
         cplx yp = mine ? Y[pc * pitch + lane] : cplx{0.0, 0.0}, yq = mine ? Y[qc * pitch + lane] : cplx{0.0, 0.0};
-        const double a = wave_sum(fma(yp.x, yp.x, yp.y * yp.y));
-        const double dd = wave_sum(fma(yq.x, yq.x, yq.y * yq.y));
-        const double gx = wave_sum(fma(yp.x, yq.x, yp.y * yq.y));
-        const double gy = wave_sum(fma(yp.x, yq.y, -yp.y * yq.x));
+        // the four sums of the pair (two norms, the inner product) in ONE packed butterfly; lanes 0..3 hold the totals
+        const double packed = wave_sum4(fma(yp.x, yp.x, yp.y * yp.y), fma(yq.x, yq.x, yq.y * yq.y), fma(yp.x, yq.x, yp.y * yq.y),
+                                        fma(yp.x, yq.y, -yp.y * yq.x), lane);
+        const double a = lane_value(packed, 0), dd = lane_value(packed, 1), gx = lane_value(packed, 2), gy = lane_value(packed, 3);
         double c, sr, si, tg;
         if (make_rotation(a, dd, gx, gy, 1e-26, floor2, c, sr, si, tg)) {
           rotate_pair(yp, yq, c, sr, si);
