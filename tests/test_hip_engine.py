@@ -1617,3 +1617,25 @@ def test_error_behaviour_matches_reference_types():
                       "factors": (np.array([[0, 1], [0, 0]], dtype=complex), np.array([[1, 0], [0, -1]], dtype=complex))}])
     with pytest.raises(NotImplementedError):
         Simulator().run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p2, lr)
+
+
+def test_run_from_a_basis_state_matches_oracle():
+    """A noisy run started from ``State(initial="basis", basis_string=...)`` against the oracle started from the same product state:
+    the same per-trajectory observables with the same seeds."""
+    from yaqs_amd.api import AnalogSimParams, MPO, NoiseModel, Observable, State, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    L, bits = 6, "010011"
+    noise = [{"name": "lowering", "sites": [s], "strength": 0.2} for s in range(L)]
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=0.4, dt=0.1, num_traj=3, max_bond_dim=8, svd_threshold=1e-12,
+                        krylov_tol=1e-12, order=2, sample_timesteps=True, random_seed=11)
+    a = Simulator().run(State(L, initial="basis", basis_string=bits), MPO.ising(L, 1.0, 0.7), p, NoiseModel(noise))
+    assert np.allclose([a.trajectories[s][0][0] for s in range(L)], [1 - 2 * int(c) for c in bits], atol=1e-12)
+    on = [o.make_process(q["name"], q["sites"], q["strength"]) for q in noise]
+    op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], elapsed_time=0.4, dt=0.1, max_bond_dim=8, svd_threshold=1e-12,
+                  krylov_tol=1e-12, order=2, sample_timesteps=True, random_seed=11)
+    for t in range(3):
+        v = [np.eye(2)[int(c)].reshape(2, 1, 1).astype(complex) for c in bits]
+        r, _, _ = o.run_trajectory(t, o.MPSState(v, 0), on, op, o.ising_mpo(L, 1.0, 0.7))
+        for s in range(L):
+            assert np.allclose(a.trajectories[s][t], r[s], atol=1e-8), (t, s)

@@ -651,7 +651,7 @@ class MPS:
     """Tensor list with index order (sigma, chi_left, chi_right) (mps.py:58)."""
 
     def __init__(self, length: int, tensors: list[np.ndarray] | None = None, state: str = "zeros", pad: int | None = None,
-                 rng: np.random.Generator | None = None):
+                 rng: np.random.Generator | None = None, basis_string: str | None = None):
         self.length = length
         self.physical_dimensions = [2] * length
         if tensors is not None:
@@ -692,6 +692,14 @@ class MPS:
                 v[0 if i % 2 else 1] = 1
             elif state == "wall":
                 v[0 if i < length // 2 else 1] = 1
+            elif state == "random":  # (r, 1 - r) per site, normalised afterwards (mps.py:266-269, 294-295)
+                r = (rng if rng is not None else np.random.default_rng()).random()
+                v[:] = (r, 1 - r)
+                v /= np.linalg.norm(v)
+            elif state == "basis":   # one character per site, site 0 first (mps.py:395-408)
+                if basis_string is None or len(basis_string) != length or set(basis_string) - {"0", "1"}:
+                    raise ValueError("state='basis' needs basis_string of one '0' / '1' per site")
+                v[int(basis_string[i])] = 1
             else:
                 raise ValueError("Invalid state string")
             self.tensors.append(v.reshape(2, 1, 1))
@@ -916,8 +924,8 @@ class State(MPS):
             raise NotImplementedError("only representation='mps' is part of the TJM path built here")
         if physical_dimensions not in (None, 2) and list(np.atleast_1d(physical_dimensions)) != [2] * (length or len(tensors or [])):
             raise NotImplementedError("physical dimensions other than 2 are not built yet in the HIP path")
-        if basis_string is not None or initial == "basis":
-            raise NotImplementedError("initial='basis' is not built yet; pass tensors=")
+        if tensors is not None and (basis_string is not None or pad is not None or seed is not None or initial != "zeros"):
+            raise ValueError("initial / pad / basis_string / seed describe a preset state; omit them with tensors=")  # state_utils.py:39-76
         if tensors is not None:
             if len(tensors) == 0:
                 raise ValueError("tensors must be a non-empty list of MPS cores.")
@@ -928,8 +936,8 @@ class State(MPS):
             if length is None:
                 raise ValueError("length is required for a preset state.")
             rng = np.random.default_rng(seed) if seed is not None else None
-            super().__init__(length, state=initial, pad=pad, rng=rng)
-        self.initial, self.representation = initial, "mps"
+            super().__init__(length, state=initial, pad=pad, rng=rng, basis_string=basis_string)
+        self.initial, self.representation, self.basis_string = initial, "mps", basis_string
 
 
 class Hamiltonian(MPO):
