@@ -462,3 +462,42 @@ def test_preset_states_basis_and_random():
     for kw in (dict(initial="x+"), dict(pad=2), dict(basis_string="00"), dict(seed=1)):
         with pytest.raises(ValueError, match="preset"):
             State(tensors=m.tensors[:2], **kw)
+
+
+def _dense_of(mpo):
+    """Dense matrix of an MPO, site 0 the most significant index (test helper)."""
+    acc = np.ones((1, 1, 1), dtype=complex)  # (out, in, bond)
+    for t in mpo.tensors:
+        acc = np.einsum("oib,pqbc->opiqc", acc, t).reshape(acc.shape[0] * 2, acc.shape[1] * 2, t.shape[3])
+    return acc[:, :, 0]
+
+
+def _embed(L, ops):
+    out = np.ones((1, 1), dtype=complex)
+    for s in range(L):
+        out = np.kron(out, ops.get(s, np.eye(2)))
+    return out
+
+
+def test_periodic_boundary_conditions_close_the_chain():
+    """``bc="periodic"`` adds the bond (L-1, 0) with the first operator of each two-body term on site L-1 (mpo.py:304-308): checked
+    against explicit Kronecker sums for ising, heisenberg and a non-symmetric pauli term, for L = 2 (the bond counted twice) to 5."""
+    from yaqs_amd.api import MPO, Hamiltonian
+
+    X, Y, Z = (np.array(m, dtype=complex) for m in ([[0, 1], [1, 0]], [[0, -1j], [1j, 0]], [[1, 0], [0, -1]]))
+    for L in (2, 3, 5):
+        bonds = [(i, (i + 1) % L) for i in range(L)]
+        want = sum(-1.3 * _embed(L, {i: Z}) @ _embed(L, {j: Z}) for i, j in bonds) + sum(-0.4 * _embed(L, {i: X}) for i in range(L))
+        assert np.allclose(_dense_of(MPO.ising(L, 1.3, 0.4, bc="periodic")), want, atol=1e-14)
+        want = sum(-(0.5 * _embed(L, {i: X}) @ _embed(L, {j: X}) + 0.7 * _embed(L, {i: Y}) @ _embed(L, {j: Y}) + 1.1 * _embed(L, {i: Z}) @ _embed(L, {j: Z}))
+                   for i, j in bonds) + sum(-0.2 * _embed(L, {i: Z}) for i in range(L))
+        assert np.allclose(_dense_of(Hamiltonian.heisenberg(L, 0.5, 0.7, 1.1, 0.2, bc="periodic")), want, atol=1e-14)
+        want = sum(0.9 * _embed(L, {i: X}) @ _embed(L, {j: Z}) for i, j in bonds) + sum(0.3 * _embed(L, {i: Y}) for i in range(L))
+        got = MPO.pauli(length=L, two_body=[(0.9, "X", "Z")], one_body=[(0.3, "Y")], bc="periodic")
+        assert np.allclose(_dense_of(got), want, atol=1e-14)
+        assert all(t.shape[:2] == (2, 2) for t in got.tensors) and got.tensors[0].shape[2] == 1 and got.tensors[-1].shape[3] == 1
+    assert np.allclose(_dense_of(MPO.ising(4, 1.3, 0.4)), _dense_of(MPO.ising(4, 1.3, 0.4, bc="open")))
+    with pytest.raises(ValueError, match="bc must be"):
+        MPO.ising(4, 1.0, 1.0, bc="twisted")
+    with pytest.raises(ValueError, match="at least two sites"):
+        MPO.ising(1, 1.0, 1.0, bc="periodic")

@@ -805,8 +805,35 @@ class MPO:
             w[1 + k, D - 1] = _Z
         return cls._fsm(length, w)
 
+    @staticmethod
+    def _check_bc(bc: str, length: int) -> bool:
+        if bc not in ("open", "periodic"):
+            raise ValueError("bc must be 'open' or 'periodic'.")  # mpo.py:288-290
+        if bc == "periodic" and length < 2:
+            raise ValueError("periodic boundary conditions need at least two sites")
+        return bc == "periodic"
+
     @classmethod
-    def _fsm(cls, length: int, w: np.ndarray) -> "MPO":
+    def _fsm(cls, length: int, w: np.ndarray, wrap=None) -> "MPO":
+        """Site tensors of the automaton ``w[from, to]`` (state 0 = nothing placed yet, state D-1 = term complete).  ``wrap`` lists the
+        closing bonds (A, B) of a periodic chain, the terms A_{L-1} B_0 (mpo.py:304-308): each gets one more state that site 0 enters
+        with B, the bulk carries with the identity and the last site leaves with A."""
+        if wrap:
+            D0, n = w.shape[0], len(wrap)
+            big = np.zeros((D0 + n, D0 + n, 2, 2), dtype=C128)
+            big[:D0 - 1, :D0 - 1] = w[:D0 - 1, :D0 - 1]
+            big[:D0 - 1, -1] = w[:D0 - 1, -1]
+            big[-1, -1] = w[-1, -1]
+            first, last = big.copy(), big.copy()
+            for k, (a_op, b_op) in enumerate(wrap):
+                big[D0 - 1 + k, D0 - 1 + k] = _I
+                first[0, D0 - 1 + k] = b_op
+                last[D0 - 1 + k, -1] = a_op
+            D = D0 + n
+            t = [first.transpose(2, 3, 0, 1)[:, :, 0:1, :].copy()]
+            t += [big.transpose(2, 3, 0, 1).copy() for _ in range(length - 2)]
+            t.append(last.transpose(2, 3, 0, 1)[:, :, :, D - 1:D].copy())
+            return cls(t)
         D = w.shape[0]
         bulk = w.transpose(2, 3, 0, 1)
         t = []
@@ -825,8 +852,7 @@ class MPO:
     def pauli(cls, *, length: int, two_body=None, one_body=None, bc: str = "open", **_unused) -> "MPO":
         """H = sum_bonds c A_i B_{i+1} + sum_i c A_i from ``(coeff, op_i, op_j)`` / ``(coeff, op)`` terms (mpo.py:247-325), as an exact
         finite-state-machine MPO of bond dimension 2 + len(two_body) (the reference compresses a Pauli sum; the operator is the same)."""
-        if bc != "open":
-            raise NotImplementedError("periodic boundary conditions are not built into the finite-state-machine MPO")
+        periodic = cls._check_bc(bc, length)
         ops = {"I": _I, "X": _X, "Y": _Y, "Z": _Z}
 
         def op(x):
@@ -845,22 +871,24 @@ class MPO:
             w[1 + k, D - 1] = op(b)
         for c, a in one_body:
             w[0, D - 1] = w[0, D - 1] + c * op(a)
-        return cls._fsm(length, w)
+        return cls._fsm(length, w, [(c * op(a), op(b)) for c, a, b in two_body] if periodic else None)
 
     @classmethod
-    def ising(cls, length: int, J: float, g: float) -> "MPO":
-        """H = -J sum Z_i Z_{i+1} - g sum X_i (sign convention of mpo.py:326-363)."""
+    def ising(cls, length: int, J: float, g: float, bc: str = "open") -> "MPO":
+        """H = -J sum Z_i Z_{i+1} - g sum X_i (sign convention of mpo.py:326-363); ``bc="periodic"`` adds the bond (L-1, 0)."""
+        periodic = cls._check_bc(bc, length)
         w = np.zeros((3, 3, 2, 2), dtype=C128)
         w[0, 0] = _I
         w[0, 1] = -J * _Z
         w[0, 2] = -g * _X
         w[1, 2] = _Z
         w[2, 2] = _I
-        return cls._fsm(length, w)
+        return cls._fsm(length, w, [(-J * _Z, _Z)] if periodic else None)
 
     @classmethod
-    def heisenberg(cls, length: int, Jx: float, Jy: float, Jz: float, h: float = 0.0) -> "MPO":
-        """H = -sum (Jx XX + Jy YY + Jz ZZ) - h sum Z (mpo.py:365-406)."""
+    def heisenberg(cls, length: int, Jx: float, Jy: float, Jz: float, h: float = 0.0, bc: str = "open") -> "MPO":
+        """H = -sum (Jx XX + Jy YY + Jz ZZ) - h sum Z (mpo.py:365-406); ``bc="periodic"`` adds the bond (L-1, 0)."""
+        periodic = cls._check_bc(bc, length)
         w = np.zeros((5, 5, 2, 2), dtype=C128)
         w[0, 0] = _I
         w[0, 1] = -Jx * _X
@@ -871,7 +899,7 @@ class MPO:
         w[2, 4] = _Y
         w[3, 4] = _Z
         w[4, 4] = _I
-        return cls._fsm(length, w)
+        return cls._fsm(length, w, [(-Jx * _X, _X), (-Jy * _Y, _Y), (-Jz * _Z, _Z)] if periodic else None)
 
 
 # ------------------------------------------------------------------ result
