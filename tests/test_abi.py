@@ -501,3 +501,52 @@ def test_periodic_boundary_conditions_close_the_chain():
         MPO.ising(4, 1.0, 1.0, bc="twisted")
     with pytest.raises(ValueError, match="at least two sites"):
         MPO.ising(1, 1.0, 1.0, bc="periodic")
+
+
+def test_pauli_sum_hamiltonians_and_dense_converters():
+    """``MPO().from_pauli_sum(terms=..., length=...)`` (mpo.py:1171-1318) against explicit Kronecker sums, including long-range and
+    three-body strings, complex coefficients and the identity term; the bond dimensions are the operator Schmidt ranks (3 for the Ising
+    chain); ``to_matrix`` has site 0 as the most significant index, ``to_matrix_mps_order`` acts on ``MPS.to_vec`` vectors; malformed
+    terms raise ValueError; ``identity`` and ``custom`` as in the reference."""
+    from yaqs_amd.api import MPO, MPS, Observable, Z as Zg, X as Xg
+
+    pa = {"I": np.eye(2, dtype=complex), "X": np.array([[0, 1], [1, 0]], dtype=complex), "Y": np.array([[0, -1j], [1j, 0]]),
+          "Z": np.diag([1.0, -1.0]).astype(complex)}
+    L = 5
+    terms = [(-1.0, f"Z{i} Z{i + 1}") for i in range(L - 1)] + [(-0.5, f"X{i}") for i in range(L)]
+    ising = MPO()
+    ising.from_pauli_sum(terms=terms, length=L)
+    assert [t.shape[3] for t in ising.tensors] == [3, 3, 3, 3, 1] and ising.length == L
+    assert np.allclose(ising.to_matrix(), MPO.ising(L, 1.0, 0.5).to_matrix(), atol=1e-13)
+    more = terms + [(0.3 + 0.1j, "Y0 X2 Z4"), (0.7, "x1 z4"), (2.0, "")]
+    m = MPO()
+    m.from_pauli_sum(terms=more, length=L)
+    want = sum(c * _embed(L, {int(t[1:]): pa[t[0].upper()] for t in spec.split()}) for c, spec in more)
+    assert np.allclose(m.to_matrix(), want, atol=1e-12)
+    assert np.allclose(_dense_of(m), m.to_matrix())
+    # the two dense layouts: a haar state's <Z_0>, <X_3> through to_vec and the LSB-ordered matrix
+    psi = MPS(L, state="haar-random", pad=4, rng=np.random.default_rng(0))
+    vec = psi.to_vec()
+    for label, gate, site in (("Z", Zg(), 0), ("X", Xg(), 3)):
+        one = MPO()
+        one.from_pauli_sum(terms=[(1.0, f"{label}{site}")], length=L)
+        got = np.real(vec.conj() @ one.to_matrix_mps_order() @ vec)
+        assert abs(got - psi.expect(Observable(gate, site))) < 1e-13
+        assert np.allclose(one.to_matrix(), _embed(L, {site: pa[label]}))
+    capped = MPO()
+    capped.from_pauli_sum(terms=more, length=L, max_bond_dim=2)
+    assert max(t.shape[3] for t in capped.tensors) == 2
+    empty = MPO()
+    empty.from_pauli_sum(terms=[], length=3)
+    assert np.allclose(empty.to_matrix(), 0)
+    for bad, msg in (([(1.0, "Q0")], "Invalid term"), ([(1.0, "X9")], "out of bounds"), ([(1.0, "X0 Z0")], "twice"), ([(1.0, "X")], "Invalid term")):
+        with pytest.raises(ValueError, match=msg):
+            MPO().from_pauli_sum(terms=bad, length=L)
+    with pytest.raises(ValueError, match="positive"):
+        MPO().from_pauli_sum(terms=terms, length=0)
+    assert np.allclose(MPO.identity(3).to_matrix(), np.eye(8))
+    c = MPO()
+    c.custom([t.transpose(2, 3, 0, 1) for t in ising.tensors])
+    assert np.allclose(c.to_matrix(), ising.to_matrix())
+    c.custom(ising.tensors, transpose=False)
+    assert np.allclose(c.to_matrix(), ising.to_matrix())

@@ -1677,3 +1677,30 @@ def test_periodic_chain_matches_oracle_and_dense_evolution():
     assert np.allclose(got, want, atol=2e-3), np.abs(got - want).max()
     b = Simulator().run(start, MPO.ising(L, J, gf), p)
     assert np.abs(got - np.array([b.expectation_values[s][-1] for s in range(L)])).max() > 1e-2  # the closing bond matters
+
+
+def test_pauli_sum_hamiltonian_run_matches_oracle():
+    """A noisy run under ``MPO().from_pauli_sum(...)`` with a next-nearest-neighbour and a three-site string (site-dependent MPO bond
+    dimensions): per-trajectory observables against the oracle fed with the same MPO tensors."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, X as Xg, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    L = 6
+    terms = ([(-1.0, f"Z{i} Z{i + 1}") for i in range(L - 1)] + [(-0.6, f"X{i}") for i in range(L)] + [(0.4, f"X{i} X{i + 2}") for i in range(L - 2)]
+             + [(0.25, "Y0 Z2 Y3")])
+    mpo = MPO()
+    mpo.from_pauli_sum(terms=terms, length=L)
+    assert len({t.shape[3] for t in mpo.tensors[:-1]}) > 1
+    noise = [{"name": "pauli_x", "sites": [s], "strength": 0.15} for s in range(L)]
+    obs = [Observable(Zg(), s) for s in range(3)] + [Observable(Xg(), 2)] + [Observable(Zg(), s) for s in range(3, L)]  # in worker order
+    p = AnalogSimParams(observables=obs, elapsed_time=0.4, dt=0.1, num_traj=3, max_bond_dim=8, svd_threshold=1e-12, krylov_tol=1e-12, order=2,
+                        sample_timesteps=True, random_seed=3)
+    start = MPS(L, state="Neel")
+    a = Simulator().run(start, mpo, p, NoiseModel(noise))
+    on = [o.make_process(q["name"], q["sites"], q["strength"]) for q in noise]
+    op = o.Params(observables=[o.Obs(Z, s) for s in range(3)] + [o.Obs(X, 2)] + [o.Obs(Z, s) for s in range(3, L)], elapsed_time=0.4, dt=0.1,
+                  max_bond_dim=8, svd_threshold=1e-12, krylov_tol=1e-12, order=2, sample_timesteps=True, random_seed=3)
+    for t in range(3):
+        r, _, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in start.tensors], 0), on, op, [w.copy() for w in mpo.tensors])
+        for u in range(len(obs)):
+            assert np.allclose(a.trajectories[u][t], r[u], atol=1e-8), (t, u)

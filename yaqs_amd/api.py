@@ -790,6 +790,93 @@ class MPO:
         return len(self.tensors)
 
     @classmethod
+    def identity(cls, length: int, physical_dimension: int = 2) -> "MPO":
+        """Identity operator with bond dimension 1 (mpo.py:1015-1028)."""
+        if physical_dimension != 2:
+            raise NotImplementedError("physical dimensions other than 2 are not built yet in the HIP path")
+        return cls([_I.reshape(2, 2, 1, 1).copy() for _ in range(length)])
+
+    def custom(self, tensors, *, transpose: bool = True) -> None:
+        """Adopt site tensors; ``transpose=True`` takes them as (chi_left, chi_right, phys_out, phys_in) (mpo.py:1146-1169)."""
+        ts = [np.asarray(t, dtype=C128) for t in tensors]
+        if transpose:
+            ts = [t.transpose(2, 3, 0, 1) for t in ts]
+        ok = all(t.ndim == 4 for t in ts) and ts[0].shape[2] == 1 and ts[-1].shape[3] == 1
+        assert ok and all(a.shape[3] == b.shape[2] for a, b in zip(ts, ts[1:])), "MPO initialized wrong"
+        self.tensors = ts
+
+    def to_matrix(self) -> np.ndarray:
+        """Dense operator with site 0 the MOST significant index (mpo.py:1755-1781)."""
+        acc = np.ones((1, 1, 1), dtype=C128)
+        for t in self.tensors:
+            acc = np.einsum("oib,pqbc->opiqc", acc, t).reshape(acc.shape[0] * t.shape[0], acc.shape[1] * t.shape[1], t.shape[3])
+        return acc[:, :, 0]
+
+    def to_matrix_mps_order(self) -> np.ndarray:
+        """Dense operator acting on ``MPS.to_vec`` vectors: site 0 the LEAST significant index (mpo.py:1783-1794)."""
+        acc = np.ones((1, 1, 1), dtype=C128)
+        for t in self.tensors:
+            acc = np.einsum("pqbc,oib->poqic", t, acc).reshape(acc.shape[0] * t.shape[0], acc.shape[1] * t.shape[1], t.shape[3])
+        return acc[:, :, 0]
+
+    def from_pauli_sum(self, *, terms, length: int, physical_dimension: int = 2, tol: float = 1e-12, max_bond_dim: int | None = None,
+                       n_sweeps: int = 2) -> None:
+        """H = sum_k c_k P_k from ``(coeff, "X0 Z3 ...")`` terms, ``""`` being the identity (mpo.py:1171-1318).  The reference assembles a
+        finite-state machine and compresses it; here every term is one channel of a direct sum that is compressed exactly while it is
+        built: a left-to-right sweep of SVDs over (left basis x site, channels), then one right-to-left SVD sweep on the left-canonical
+        result, both cut at ``tol`` relative to the largest singular value (and at ``max_bond_dim`` when given).  The operator is the
+        same; the bond dimensions are the operator Schmidt ranks.  ``n_sweeps`` is accepted for signature parity."""
+        if length <= 0:
+            raise ValueError("L must be positive.")
+        if physical_dimension != 2:
+            raise ValueError("Only physical_dimension=2 is supported.")
+        ops = {"I": _I, "X": _X, "Y": _Y, "Z": _Z}
+        coef, table = [], []
+        for c, spec in terms:
+            row = {}
+            for tok in str(spec).split():
+                label, idx = tok[:1].upper(), tok[1:]
+                if label not in ops or not idx.isdigit():
+                    raise ValueError(f"Invalid term {spec!r}: expected tokens like 'X0' with an operator in {sorted(ops)}.")
+                site = int(idx)
+                if site >= length:
+                    raise ValueError(f"Site index {site} out of bounds for length {length}.")
+                if site in row:
+                    raise ValueError(f"Invalid term {spec!r}: site {site} appears twice.")
+                row[site] = label
+            coef.append(complex(c))
+            table.append(row)
+        n = len(coef)
+        if n == 0:
+            self.tensors = [np.zeros((2, 2, 1, 1), dtype=C128) for _ in range(length)]
+            return
+
+        def rank(sv):
+            k = int(np.sum(sv > tol * sv[0])) if sv.size and sv[0] > 0 else 0
+            return max(1, k if max_bond_dim is None else min(k, int(max_bond_dim)))
+
+        carry = np.asarray(coef, dtype=C128).reshape(1, n)  # (left basis, channel)
+        left = []
+        for i in range(length):
+            site_ops = np.stack([ops[row.get(i, "I")] for row in table])  # (channel, out, in)
+            m = np.einsum("kt,tpq->kpqt", carry, site_ops)
+            k = carry.shape[0]
+            if i == length - 1:
+                left.append(m.sum(axis=3).reshape(k, 2, 2, 1))
+                break
+            u, sv, vh = np.linalg.svd(m.reshape(k * 4, n), full_matrices=False)
+            r = rank(sv)
+            left.append(u[:, :r].reshape(k, 2, 2, r))
+            carry = sv[:r, None] * vh[:r]
+        for i in range(length - 1, 0, -1):  # (l, out, in, r) tensors, left-canonical up to site i
+            l, r_ = left[i].shape[0], left[i].shape[3]
+            u, sv, vh = np.linalg.svd(left[i].reshape(l, 4 * r_), full_matrices=False)
+            r = rank(sv)
+            left[i] = vh[:r].reshape(r, 2, 2, r_)
+            left[i - 1] = np.einsum("kpqm,mr->kpqr", left[i - 1], u[:, :r] * sv[:r])
+        self.tensors = [t.transpose(1, 2, 0, 3).copy() for t in left]
+
+    @classmethod
     def long_range_ising(cls, length: int, coeffs, decays, g: float) -> "MPO":
         """H = -sum_{i<j} f(j-i) Z_i Z_j - g sum_i X_i with f(r) = sum_k coeffs[k] * decays[k]**(r-1): the exponential-sum
         form of a power-law coupling as a finite-state-machine MPO of bond dimension K + 2."""
