@@ -550,3 +550,34 @@ def test_pauli_sum_hamiltonians_and_dense_converters():
     assert np.allclose(c.to_matrix(), ising.to_matrix())
     c.custom(ising.tensors, transpose=False)
     assert np.allclose(c.to_matrix(), ising.to_matrix())
+
+
+def test_mps_inspection_helpers():
+    """Host-side helpers of the reference's MPS that users call on ``result.output_state`` (mps.py:514-678, 901-959, 1539-1630),
+    checked against dense linear algebra on a Haar state brought to a known canonical form."""
+    from yaqs_amd.api import MPS
+
+    L = 6
+    psi = MPS(L, state="haar-random", pad=8, rng=np.random.default_rng(5))  # left-orthonormal sites, norm 1
+    assert psi.bond_dimensions() == [2, 4, 8, 4, 2] and psi.get_total_bond() == 20 and psi.get_cost() == 2 ** 3 * 2 + 4 ** 3 * 2 + 8 ** 3
+    assert psi.get_max_bond() == 8 and MPS(3, state="zeros").get_max_bond() == 2
+    psi.check_if_valid_mps()
+    assert abs(psi.norm() - 1) < 1e-13 and abs(psi.norm(L - 1) - 1) < 1e-13
+    assert psi.check_canonical_form() == [L - 1]
+    assert MPS(4, state="x+").check_canonical_form() == [0, 1, 2, 3]
+    broken = MPS(L, tensors=[1.5 * t for t in psi.tensors])
+    assert broken.check_canonical_form() == []
+    other = MPS(L, state="haar-random", pad=4, rng=np.random.default_rng(6))
+    assert abs(psi.scalar_product(other) - np.vdot(psi.to_vec(), other.to_vec())) < 1e-13
+    assert abs(psi.scalar_product(other, 0) - np.vdot(psi.tensors[0], other.tensors[0])) < 1e-15
+    # the centre is on the last site: the block (L-2, L-1) carries the Schmidt values of that cut
+    vec = psi.to_vec().reshape(2, 2 ** (L - 1))  # (s_{L-1}, rest): site L-1 is the most significant index
+    sv = np.linalg.svd(vec, compute_uv=False)
+    spec = psi.get_schmidt_spectrum([L - 2, L - 1])
+    assert spec.shape == (500,) and np.allclose(spec[:2], sv, atol=1e-13) and np.all(np.isnan(spec[2:]))
+    pr = sv ** 2
+    assert abs(psi.get_entropy([L - 2, L - 1]) - (-np.sum(pr * np.log(pr)))) < 1e-12
+    prod = MPS(3, state="zeros")
+    assert prod.get_entropy([0, 1]) == 0.0 and prod.get_schmidt_spectrum([0, 1])[0] == 1.0 and np.all(np.isnan(prod.get_schmidt_spectrum([0, 1])[1:]))
+    with pytest.raises(AssertionError):
+        psi.get_entropy([0, 2])

@@ -1704,3 +1704,27 @@ def test_pauli_sum_hamiltonian_run_matches_oracle():
         r, _, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in start.tensors], 0), on, op, [w.copy() for w in mpo.tensors])
         for u in range(len(obs)):
             assert np.allclose(a.trajectories[u][t], r[u], atol=1e-8), (t, u)
+
+
+def test_output_state_answers_the_inspection_helpers():
+    """``result.output_state`` of a closed run: unit norm, a valid canonical form, bond dimensions and entropies consistent with the
+    dense vector, and <Z_s> of the returned state equal to the reported final expectation values."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, Observable, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    L = 6
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=0.5, dt=0.1, max_bond_dim=8, svd_threshold=1e-12,
+                        krylov_tol=1e-12, order=2, sample_timesteps=False, get_state=True)
+    res = Simulator().run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p)
+    out = res.output_state
+    out.check_if_valid_mps()
+    assert abs(out.norm() - 1) < 1e-10 and len(out.check_canonical_form()) >= 1
+    assert out.get_total_bond() == sum(out.bond_dimensions()) and max(out.bond_dimensions()) <= 8
+    for s in range(L):
+        assert abs(out.expect(Observable(Zg(), s)) - res.expectation_values[s][-1]) < 1e-9
+    c = out.check_canonical_form()[0]
+    i = min(max(c, 0), L - 2) if c < L - 1 else L - 2
+    vec = out.to_vec().reshape(2 ** (L - 1 - i), 2 ** (i + 1))  # rows: sites above the cut (site L-1 most significant)
+    pr = np.linalg.svd(vec, compute_uv=False) ** 2
+    pr = pr[pr > 1e-300]
+    assert abs(out.get_entropy([i, i + 1]) - (-np.sum(pr * np.log(pr)))) < 1e-9

@@ -721,6 +721,82 @@ class MPS:
             v = np.einsum("xl,slr->sxr", v, t).reshape(-1, t.shape[2])
         return v.reshape(-1)
 
+    # -- inspection helpers of the reference's MPS (host side, numpy over the site tensors) -----------------------------------------
+    def bond_dimensions(self) -> list[int]:
+        """Internal bond dimensions, left to right (mps.py:514-520)."""
+        return [int(t.shape[2]) for t in self.tensors[:-1]]
+
+    def get_max_bond(self) -> int:
+        """max over sites of max(shape[0], shape[2]) exactly as mps.py:549-565 writes it (the physical dimension takes part, so a
+        product state reports 2)."""
+        return max(max(int(t.shape[0]), int(t.shape[2])) for t in self.tensors)
+
+    def get_total_bond(self) -> int:
+        """Sum of the left bonds of sites 1 .. L-1 (mps.py:567-578)."""
+        return sum(int(t.shape[1]) for t in self.tensors[1:])
+
+    def get_cost(self) -> int:
+        """Sum of the cubed left bonds of sites 1 .. L-1 (mps.py:580-591)."""
+        return sum(int(t.shape[1]) ** 3 for t in self.tensors[1:])
+
+    def _bond_singular_values(self, sites, what: str):
+        assert len(sites) == 2, f"{what} is defined on a bond (two adjacent sites)."
+        i, j = sites
+        assert i + 1 == j, f"{what} is only defined for nearest-neighbor cut."
+        a, b = self.tensors[i], self.tensors[j]
+        if a.shape[2] == 1:
+            return None
+        theta = np.tensordot(a, b, axes=(2, 1)).reshape(a.shape[0] * a.shape[1], b.shape[0] * b.shape[2])
+        return np.linalg.svd(theta, compute_uv=False)
+
+    def get_entropy(self, sites) -> np.float64:
+        """Von Neumann entropy (natural log) of the normalised squared singular values of the two-site block (i, i+1) as it stands
+        (mps.py:604-642): the entanglement entropy of the cut when the orthogonality centre is on one of the two sites."""
+        sv = self._bond_singular_values(sites, "Entropy")
+        if sv is None or not np.sum(sv ** 2) > 0:
+            return np.float64(0.0)
+        pr = sv ** 2 / np.sum(sv ** 2)
+        return np.float64(-np.sum(pr * np.log(pr + np.finfo(np.float64).tiny)))
+
+    def get_schmidt_spectrum(self, sites) -> np.ndarray:
+        """Singular values of the two-site block (i, i+1), NaN-padded to 500 entries (mps.py:644-678)."""
+        sv = self._bond_singular_values(sites, "Schmidt spectrum")
+        out = np.full(500, np.nan)
+        if sv is None:
+            out[0] = 1.0
+        else:
+            out[:min(500, len(sv))] = sv[:500]
+        return out
+
+    def scalar_product(self, other: "MPS", sites: int | None = None) -> np.complex128:
+        """<self|other> over the whole chain, or the local contraction of one site's tensors (mps.py:901-959)."""
+        if sites is not None:
+            i = int(sites[0]) if isinstance(sites, (list, tuple)) else int(sites)
+            if isinstance(sites, (list, tuple)) and len(sites) != 1:
+                raise ValueError("Invalid `sites` argument.")
+            return np.complex128(np.vdot(self.tensors[i], other.tensors[i]))
+        env = np.ones((1, 1), dtype=C128)  # (bra bond, ket bond)
+        for a, b in zip(self.tensors, other.tensors):
+            env = np.einsum("xy,pxa,pyb->ab", env, a.conj(), b)
+        return np.complex128(env[0, 0])
+
+    def norm(self, site: int | None = None) -> np.float64:
+        """<psi|psi>, or the squared Frobenius norm of one site tensor (the norm when the centre sits there) (mps.py:1539-1565)."""
+        return np.float64(np.real(self.scalar_product(self, site)))
+
+    def check_if_valid_mps(self) -> None:
+        """Neighbouring bonds must agree (mps.py:1567-1579)."""
+        for a, b in zip(self.tensors, self.tensors[1:]):
+            assert a.shape[2] == b.shape[1]
+
+    def check_canonical_form(self) -> list[int]:
+        """Every site that can serve as orthogonality centre: all sites left of it left-orthonormal, all sites right of it
+        right-orthonormal - what the code of mps.py:1598-1630 returns (several sites for e.g. a normalised product state, an empty list
+        when there is none)."""
+        lefts = [np.allclose(np.einsum("pxa,pxb->ab", t.conj(), t), np.eye(t.shape[2])) for t in self.tensors]
+        rights = [np.allclose(np.einsum("pax,pbx->ab", t.conj(), t), np.eye(t.shape[1])) for t in self.tensors]
+        return [i for i in range(self.length) if all(lefts[:i]) and all(rights[i + 1:])]
+
     def expect(self, observable) -> float:
         """<psi| O |psi> of a one-site or nearest-neighbour two-site observable (mps.py:961-1047), dense evaluation for small chains;
         a two-site matrix is indexed (s_i, s_{i+1}) with site i the major index."""
