@@ -581,3 +581,25 @@ def test_mps_inspection_helpers():
     assert prod.get_entropy([0, 1]) == 0.0 and prod.get_schmidt_spectrum([0, 1])[0] == 1.0 and np.all(np.isnan(prod.get_schmidt_spectrum([0, 1])[1:]))
     with pytest.raises(AssertionError):
         psi.get_entropy([0, 2])
+
+
+def test_host_side_shot_measurement():
+    """``MPS.measure_shots`` / ``measure_single_shot`` (mps.py:1282-1382): outcome = sum(bit_i << i); basis states are deterministic
+    in Z, x+ is deterministic in X, y+ in Y; a GHZ-like state gives only the two extreme outcomes with frequencies near 1/2."""
+    from yaqs_amd.api import MPS
+
+    rng = np.random.default_rng(0)
+    assert MPS(5, state="basis", basis_string="10110").measure_shots(50, rng=rng) == {0b01101: 50}
+    assert MPS(4, state="x+").measure_shots(20, basis="X", rng=rng) == {0: 20}
+    assert MPS(4, state="x-").measure_shots(20, basis="x", rng=rng) == {15: 20}
+    assert MPS(3, state="y+").measure_shots(20, basis="Y", rng=rng) == {0: 20}
+    assert MPS(3, state="y-").measure_single_shot("Y", rng) == 7
+    z = MPS(3, state="x+").measure_shots(4000, rng=rng)
+    assert set(z) == set(range(8)) and all(abs(v / 4000 - 0.125) < 0.03 for v in z.values())
+    a = np.zeros((2, 1, 2), dtype=complex); a[0, 0, 0] = a[1, 0, 1] = 2 ** -0.5
+    m = np.zeros((2, 2, 2), dtype=complex); m[0, 0, 0] = m[1, 1, 1] = 1
+    b = np.zeros((2, 2, 1), dtype=complex); b[0, 0, 0] = b[1, 1, 0] = 1
+    ghz = MPS(4, tensors=[a, m, m, b]).measure_shots(2000, rng=rng)
+    assert set(ghz) == {0, 15} and abs(ghz[0] / 2000 - 0.5) < 0.05
+    with pytest.raises(ValueError, match="Invalid basis"):
+        MPS(2, state="zeros").measure_shots(1, basis="W")

@@ -797,6 +797,35 @@ class MPS:
         rights = [np.allclose(np.einsum("pax,pbx->ab", t.conj(), t), np.eye(t.shape[1])) for t in self.tensors]
         return [i for i in range(self.length) if all(lefts[:i]) and all(rights[i + 1:])]
 
+    _MEASUREMENT_ROTATION = {"Z": np.eye(2, dtype=C128), "X": np.array([[1, 1], [1, -1]], dtype=C128) / np.sqrt(2),
+                             "Y": np.array([[1, -1j], [1, 1j]], dtype=C128) / np.sqrt(2)}
+
+    def _outcome_probabilities(self, basis: str) -> np.ndarray:
+        basis = str(basis).upper()
+        if basis not in self._MEASUREMENT_ROTATION:
+            raise ValueError(f"Invalid basis: {basis}. Expected 'X', 'Y', or 'Z'.")  # mps.py:1306-1314
+        if self.length > 24:
+            raise ValueError("host-side sampling enumerates the 2^L outcomes; use DigitalSimParams(shots=...) for long chains")
+        rot = self._MEASUREMENT_ROTATION[basis]
+        pr = np.abs(MPS(self.length, tensors=[np.einsum("ab,bcd->acd", rot, t) for t in self.tensors]).to_vec()) ** 2
+        return pr / pr.sum()
+
+    def measure_single_shot(self, basis: str = "Z", rng: np.random.Generator | None = None) -> int:
+        """One projective measurement of every site in the X, Y or Z basis; the outcome is sum(bit_i << i), site 0 the least
+        significant bit (mps.py:1282-1345).  Host-side helper for small chains: the outcome is drawn from the exact distribution
+        of the 2^L results instead of site by site, so a seeded generator gives the same statistics but not the same draws as the
+        reference; ensembles of shots on the GPU are ``DigitalSimParams(shots=...)`` (``tjm_engine_sample_shots``)."""
+        rng = rng if rng is not None else np.random.default_rng()
+        pr = self._outcome_probabilities(basis)
+        return int(rng.choice(pr.size, p=pr))
+
+    def measure_shots(self, shots: int, basis: str = "Z", rng: np.random.Generator | None = None) -> dict[int, int]:
+        """Histogram {outcome: count} of ``shots`` independent measurements (mps.py:1351-1382)."""
+        rng = rng if rng is not None else np.random.default_rng()
+        pr = self._outcome_probabilities(basis)
+        draws, counts = np.unique(rng.choice(pr.size, size=int(shots), p=pr), return_counts=True)
+        return {int(k): int(v) for k, v in zip(draws, counts)}
+
     def expect(self, observable) -> float:
         """<psi| O |psi> of a one-site or nearest-neighbour two-site observable (mps.py:961-1047), dense evaluation for small chains;
         a two-site matrix is indexed (s_i, s_{i+1}) with site i the major index."""
