@@ -4,14 +4,17 @@
     python bench.py --gpus N --steps K --warmup W
 
 A *step* is one order-1 TJM time step (two-site TDVP sweep -> dissipation -> stochastic jump,
-analog/analog_tjm.py:438-447 in the reference) of one batch of trajectories resident on the GPU.
+analog/analog_tjm.py:438-447 in the reference) of the trajectories resident on the GPU(s).
 A trajectory is 10 such steps plus one measurement of <Z_i> on every site (final-time sampling), so
-trajectories/sec = trajectories_in_flight * K / 10 / elapsed.  Inputs (MPO, initial MPS, noise table,
+trajectories/sec = trajectories * K / 10 / elapsed.  Inputs (MPO, initial MPS, noise table,
 uniforms) are resident in HBM / host memory before the timed region starts.
 
-With --gpus N > 1 the script is launched by torch.distributed.run, one rank per GPU: trajectory indices
-are sharded contiguously over ranks (weak scaling: every rank runs --batch trajectories), there is no
-exchange during evolution and one RCCL all-reduce combines the observable sums at the end.
+Multi-GPU: one process per GPU over RCCL.  Started under torch.distributed.run the script is one rank (RANK / LOCAL_RANK /
+WORLD_SIZE from the environment); started directly with --gpus N > 1 it launches its N ranks itself (fresh child processes,
+before anything touches the GPU) and relays rank 0's JSON line.  Trajectory indices are sharded contiguously over the ranks,
+there is no exchange during evolution and one all-reduce combines the observable sums at the end.  Default for N > 1 is
+STRONG scaling on BASELINE.json's ensemble (--trajectories 1024 in total, 1024 / N resident per GPU); --scaling weak keeps
+--batch trajectories per GPU.
 """
 from __future__ import annotations
 
@@ -23,7 +26,9 @@ for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
 import argparse
 import ctypes as C
 import json
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -33,7 +38,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 STEPS_PER_TRAJ = 10  # elapsed_time = 1.0 at dt = 0.1 (the headline configuration); main() rescales it for another --dt
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak = fp64 matrix (MFMA) peak: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz
 
 
 WORKLOADS = {
@@ -57,6 +63,9 @@ def build_inputs(L, chi, workload="tfim"):
     return mpo, st, noise
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (a NumPy/SciPy port of the reference path) on the GPU box's host cores
+# ------------------------------------------------------------------------------------------------------------------------
 def _cpu_step(args):
     """One order-1 TJM step of one trajectory on the CPU oracle; returns its own wall time."""
     L, chi, tol, traj, workload, tdvp_mode, dt = args
@@ -77,49 +86,143 @@ def _cpu_step(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(L, chi, tol, procs, workload="tfim", tdvp_mode="2site", dt=0.1):
-    """The CPU oracle (a NumPy/SciPy port of the reference path), run the way the reference runs: `procs` forked
-    single-BLAS-thread workers, one trajectory each (core/parallel_utils.py:331-390).  Bounded sample: ONE order-1 TJM
-    step per worker, extrapolated to 10 steps per trajectory.  Must run before anything touches the GPU (fork)."""
+_SLAB = {}  # inputs of the site-update sample, built once in the parent and inherited by the forked workers
+
+
+def _slab_prepare(L, chi, tol, workload, dt):
+    """Tensors and environments of ONE bulk site-update at the chain centre (SURVEY section 8d's unit of work)."""
+    from oracle import tjm_oracle as o
+    from yaqs_amd import api
+
+    _, make_mpo, _, _ = WORKLOADS[workload]
+    st = o.MPSState.haar(L, chi, np.random.default_rng(1))
+    st.normalize("B")
+    mpo = [np.asarray(w) for w in make_mpo(api, L).tensors]
+    i = L // 2 - 1
+    t = st.tensors
+    # the sample only needs environments of the right shapes and an isometric gauge around the pair
+    rb = o.right_environments(t, mpo)
+    lb = o.identity_env(t[0].shape[1], mpo[0].shape[2])
+    for k in range(i):
+        lb = o.update_left_environment(t[k], t[k], mpo[k], lb)
+    _SLAB.update(a=t[i], b=t[i + 1], w0=mpo[i], w1=mpo[i + 1], lb=lb, rb1=rb[i + 1],
+                 p=o.Params(dt=dt, max_bond_dim=chi, svd_threshold=1e-12, krylov_tol=tol), dt=dt, tol=tol)
+
+
+def _slab_run(n_updates):
+    """n bulk site-updates (merge, two-site Krylov, truncated split, environment update, backward one-site Krylov) on the
+    prepared tensors; returns seconds per site-update."""
+    from oracle import tjm_oracle as o
+
+    s = _SLAB
+    t0 = time.perf_counter()
+    for _ in range(n_updates):
+        theta = o.merge_two_site(s["a"], s["b"])
+        w2 = o.merge_mpo_tensors(s["w0"], s["w1"])
+        theta = o.update_site(s["lb"], s["rb1"], w2, theta, 0.5 * s["dt"], s["tol"])
+        a, b = o._split_tdvp(theta, s["p"], "right")
+        lb1 = o.update_left_environment(a, a, s["w0"], s["lb"])
+        o.update_site(lb1, s["rb1"], s["w1"], b, -0.5 * s["dt"], s["tol"])
+    return (time.perf_counter() - t0) / n_updates
+
+
+def cpu_baseline(L, chi, tol, procs_list, workload="tfim", tdvp_mode="2site", dt=0.1):
+    """The CPU oracle run the way the reference runs: P forked single-BLAS-thread workers, one trajectory each
+    (core/parallel_utils.py:331-390).  Bounded sample.  Rows:
+      * P = 1 and every P of ``procs_list`` that fits the time budget: ONE full order-1 TJM step per worker (slowest worker counts),
+        extrapolated to 10 steps per trajectory;
+      * every P including P = all cores: a SLAB sample - 3 bulk site-updates at the chain centre per worker, all workers side by
+        side - from which the per-worker slow-down under contention is read and applied to the uncontended full-step time
+        (a full step with every core busy takes minutes: measured once, 316-411 s at 256 workers).
+    Must run before anything touches the GPU (fork)."""
     import multiprocessing as mp
 
     ncpu = len(os.sched_getaffinity(0))
-    procs = max(1, min(procs, ncpu))
-    t0 = time.perf_counter()
-    if procs == 1:
-        per = [_cpu_step((L, chi, tol, 0, workload, tdvp_mode, dt))]
-    else:
-        with mp.get_context("fork").Pool(procs) as pool:
-            per = pool.map(_cpu_step, [(L, chi, tol, t, workload, tdvp_mode, dt) for t in range(procs)], chunksize=1)
-    wall = time.perf_counter() - t0
-    slowest = max(per)
+    ctx = mp.get_context("fork")
+    rows = []
+    t_all = time.perf_counter()
+    # --- uncontended: one worker, the whole step
+    t1 = _cpu_step((L, chi, tol, 0, workload, tdvp_mode, dt))
+    rows.append({"cores": 1, "value": 1.0 / (STEPS_PER_TRAJ * t1), "seconds_per_step": t1, "how": "full step, one worker alone on the host"})
+    # --- full step with P workers side by side
+    for P in procs_list:
+        P = min(P, ncpu)
+        if P <= 1 or any(r["cores"] == P and r["how"].startswith("full") for r in rows):
+            continue
+        with ctx.Pool(P) as pool:
+            per = pool.map(_cpu_step, [(L, chi, tol, t, workload, tdvp_mode, dt) for t in range(P)], chunksize=1)
+        rows.append({"cores": P, "value": P / (STEPS_PER_TRAJ * max(per)), "seconds_per_step": max(per), "fastest_worker_s": min(per),
+                     "how": f"full step, {P} workers side by side (slowest worker)"})
+    # --- slab sample: contention factor for every P up to all cores
+    slab = []
+    if tdvp_mode == "2site":
+        _slab_prepare(L, chi, tol, workload, dt)
+        base = _slab_run(3)
+        ladder = sorted({p for p in (8, 16, 32, 64, 128, ncpu) if 1 < p <= ncpu})
+        for P in ladder:
+            with ctx.Pool(P) as pool:
+                per = pool.map(_slab_run, [3] * P, chunksize=1)
+            factor = max(per) / base
+            slab.append({"cores": P, "seconds_per_site_update": max(per), "slowdown_vs_one_worker": factor})
+            rows.append({"cores": P, "value": P / (STEPS_PER_TRAJ * t1 * factor), "seconds_per_step": t1 * factor,
+                         "how": f"extrapolated: uncontended full step x slow-down of the 3-site-update slab sample at {P} workers"})
+        _SLAB.clear()
+    best = max(rows, key=lambda r: r["value"])
+    measured_best = max((r for r in rows if r["how"].startswith("full")), key=lambda r: r["value"])
     return {
-        "value": procs / (STEPS_PER_TRAJ * slowest),
+        "value": best["value"],
         "unit": "trajectories/sec",
-        "cores": procs,
+        "cores": best["cores"],
         "kind": "port",
-        "sample": f"1 TJM step ({tdvp_mode} TDVP + dissipation + jump, workload {workload}) of 1 trajectory per worker at L={L}, chi={chi}, {procs} forked "
-                  f"single-thread workers side by side: slowest {slowest:.1f} s, fastest {min(per):.1f} s (wall {wall:.1f} s incl. set-up), "
-                  f"x{STEPS_PER_TRAJ} steps per trajectory; host has {ncpu} cores",
-        "seconds_per_step": slowest,
-        "per_core_value": 1.0 / (STEPS_PER_TRAJ * slowest),
+        "sample": f"oracle (NumPy/SciPy port of the reference path), forked single-BLAS-thread workers, one trajectory each, workload {workload}, "
+                  f"L={L}, chi={chi}, {tdvp_mode} TDVP: 1 full TJM step per worker at P=1 and P in {list(procs_list)}, x{STEPS_PER_TRAJ} steps per "
+                  f"trajectory; plus a 3-site-update slab sample at P up to all {ncpu} cores giving the contention slow-down; "
+                  f"value = best whole-host row ({best['how']}); CPU leg took {time.perf_counter() - t_all:.0f} s",
+        "host_cores": ncpu,
+        "per_core_value": rows[0]["value"],  # one worker with the host to itself
+        "best_measured_full_step": {k: measured_best[k] for k in ("cores", "value", "seconds_per_step")},
+        "rows": rows,
+        "slab_sample": {"seconds_per_site_update_one_worker": base, "by_workers": slab} if slab else None,
     }
 
 
 def pmc_traffic(L, chi, B):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r0*_pmc_traffic.json:
     separate FETCH_SIZE and WRITE_SIZE runs of this script, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
     PMC counters cannot be read from inside the timed run, so the number is only reported for the configuration it was
     collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-    except OSError:
-        return None, "no PMC summary committed"
-    if (rec.get("L"), rec.get("chi"), rec.get("batch")) != (L, chi, B):
-        return None, "PMC summary was collected on a different configuration"
-    return rec["traffic_bytes_per_launch"], rec["note"]
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f)
+        except OSError:
+            continue
+        if (rec.get("L"), rec.get("chi")) != (L, chi):
+            continue
+        return rec["traffic_bytes_per_launch"], f"{name}: {rec['note']} (collected with {rec.get('batch')} trajectories in flight)"
+    return None, "no PMC summary committed for this configuration"
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torch.distributed.run starts its own ranks
+# ------------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv):
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -127,7 +230,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="trajectories resident per GPU (the headline configuration has 1024 trajectories)")
+    ap.add_argument("--trajectories", type=int, default=1024, help="ensemble of BASELINE.json's headline configuration (strong scaling splits it over the GPUs)")
+    ap.add_argument("--batch", type=int, default=None, help="trajectories resident per GPU (default: --trajectories / N for strong scaling, --trajectories for weak)")
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto", help="auto: strong for N > 1")
+    ap.add_argument("--engines", type=int, default=1, help="engines (host thread + HIP stream each) sharing one GPU's trajectories")
     ap.add_argument("--length", type=int, default=64)
     ap.add_argument("--chi", type=int, default=128)
     ap.add_argument("--krylov-tol", type=float, default=1e-4)
@@ -135,8 +241,12 @@ def main():
     ap.add_argument("--tdvp-mode", choices=["2site", "1site"], default="2site")
     ap.add_argument("--dt", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-procs", type=int, default=32, help="forked single-thread CPU workers of the cpu_baseline leg (capped at the core count)")
+    ap.add_argument("--cpu-procs", type=int, nargs="*", default=[32], help="worker counts of the full-step CPU rows besides P = 1")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # nothing has touched the GPU in this process
+
     # stdout carries exactly one JSON line: everything else a library prints there (RCCL writes its version banner to
     # stdout when the communicator is created) is sent to stderr by pointing fd 1 at fd 2 for the duration of the run
     sys.stdout.flush()
@@ -148,8 +258,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running on {world} rank(s)", file=sys.stderr)
     cpu_ref = None
-    if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         cpu_ref = cpu_baseline(args.length, args.chi, args.krylov_tol, args.cpu_procs, args.workload, args.tdvp_mode, args.dt)  # before torch / HIP
 
     import torch
@@ -160,32 +272,82 @@ def main():
     from yaqs_amd.engine import BatchEngine
     from yaqs_amd.tjm import trajectory_uniforms
 
-    use_dist = args.gpus > 1 or world > 1
-    if use_dist:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        world = dist.get_world_size()  # n_gpus below is what RCCL saw
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
 
-    L, chi, B, K, W = args.length, args.chi, args.batch, args.steps, args.warmup
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
+    if args.batch is not None:
+        B = args.batch
+        if scaling == "strong":
+            B = args.batch // world
+    else:
+        B = args.trajectories // world if scaling == "strong" else args.trajectories
+    if B < 1:
+        raise SystemExit("fewer than one trajectory per GPU")
+    E = max(1, min(args.engines, B))
+    L, chi, K, W = args.length, args.chi, args.steps, args.warmup
     mpo, st, noise = build_inputs(L, chi, args.workload)
     dt = args.dt
-    eng = BatchEngine(L, chi, B, mpo.tensors, device=device)
-    eng.set_params(dt=dt, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=args.krylov_tol, tdvp_mode=args.tdvp_mode)
-    eng.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
-    eng.load_state(st.tensors)
-    traj = [rank * B + b for b in range(B)]
-    u = np.stack([trajectory_uniforms(42, t, 2 * (K + W) + 4) for t in traj])
-    pos = np.zeros(B, dtype=np.int64)
+    sizes = [B // E + (1 if k < B % E else 0) for k in range(E)]
+    first = rank * B
+    engines, trajs = [], []
+    for k, nb in enumerate(sizes):
+        eng = BatchEngine(L, chi, nb, mpo.tensors, device=device, stream=torch.cuda.Stream(device=device) if E > 1 else None)
+        eng.set_params(dt=dt, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=args.krylov_tol, tdvp_mode=args.tdvp_mode)
+        eng.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
+        eng.load_state(st.tensors)
+        engines.append(eng)
+        trajs.append(list(range(first, first + nb)))
+        first += nb
     lib = _lib.load()
 
-    def step():
-        eng.tdvp()
-        eng.dissipate(dt)
-        eng.set_uniforms(np.stack([u[np.arange(B), pos], u[np.arange(B), pos + 1]], axis=1))
-        jumped, _ = eng.stochastic(dt)
-        pos[:] += 1 + jumped
+    class Drive:
+        """One host thread per engine: the steps of its trajectories, the measurement at the end of every trajectory."""
+
+        def __init__(self, eng, traj):
+            self.eng, self.nb = eng, eng.B
+            self.u = np.stack([trajectory_uniforms(42, t, 2 * (K + W) + 4) for t in traj])
+            self.pos = np.zeros(self.nb, dtype=np.int64)
+            self.zsum = np.zeros(L)
+            self.err = None
+
+        def step(self):
+            e, ar = self.eng, np.arange(self.nb)
+            e.tdvp()
+            e.dissipate(dt)
+            e.set_uniforms(np.stack([self.u[ar, self.pos], self.u[ar, self.pos + 1]], axis=1))
+            jumped, _ = e.stochastic(dt)
+            self.pos[:] += 1 + jumped
+
+        def run(self, n, measure):
+            try:
+                for k in range(n):
+                    self.step()
+                    if measure and ((k + 1) % STEPS_PER_TRAJ == 0 or k == n - 1):
+                        M = self.eng.site_moments()
+                        self.zsum += np.einsum("lb->l", (M[:, :, 0, 0] - M[:, :, 1, 1]).real)
+            except BaseException as exc:  # surfaced by run_all
+                self.err = exc
+
+    drives = [Drive(e, t) for e, t in zip(engines, trajs)]
+
+    def run_all(n, measure):
+        if len(drives) == 1:
+            drives[0].run(n, measure)
+        else:
+            th = [threading.Thread(target=d.run, args=(n, measure)) for d in drives]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        for d in drives:
+            if d.err is not None:
+                raise d.err
 
     def barrier():
         torch.cuda.synchronize()
@@ -193,18 +355,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(W):
-        step()
-    stats0 = eng.stats()
-    lib.tjm_profile_cross_kernel(8)  # bracket every 8th launch of the dominant kernel with HIP events
+    run_all(W, False)
+    stats0 = [e.stats() for e in engines]
+    for e in engines:
+        e.profile(True)
+    lib.tjm_profile_cross_kernel(8 if E == 1 else 0)  # bracket every 8th launch of the dominant kernel with HIP events (one engine only)
     barrier()
     t0 = time.perf_counter()
-    zsum = np.zeros(L)
-    for k in range(K):
-        step()
-        if (k + 1) % STEPS_PER_TRAJ == 0 or k == K - 1:
-            M = eng.site_moments()
-            zsum += np.einsum("lb->l", (M[:, :, 0, 0] - M[:, :, 1, 1]).real)
+    run_all(K, True)
+    zsum = sum(d.zsum for d in drives)
     if world > 1:
         tz = torch.from_numpy(zsum).to(device)
         dist.all_reduce(tz, op=dist.ReduceOp.SUM)  # the only collective of the path (RCCL over xGMI)
@@ -215,7 +374,8 @@ def main():
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-    stats1 = eng.stats()
+    stats1 = [e.stats() for e in engines]
+    prof = [e.profile_read() for e in engines]
     ms, nbytes, ns = C.c_double(0), C.c_double(0), C.c_int64(0)
     lib.tjm_profile_cross_kernel_read(C.byref(ms), C.byref(nbytes), C.byref(ns))
     lib.tjm_profile_cross_kernel(0)
@@ -224,8 +384,26 @@ def main():
         total_traj = B * world
         value = total_traj * K / STEPS_PER_TRAJ / elapsed
         site_updates = total_traj * K * (2 * L - 3) / elapsed
-        achieved = (nbytes.value / 1e9) / (ms.value / 1e3) if ms.value > 0 else None
+        # ---- algorithmic work of this rank's timed region (SURVEY section 8d formulas; cMAC = 8 real flops) -----------------
+        d_, D = 2, max(int(w.shape[3]) for w in mpo.tensors)
+        n = d_ * chi
+        F_mv2 = 8.0 * (2 * d_ ** 2 * D * chi ** 3 + d_ ** 4 * D ** 2 * chi ** 2)
+        F_mv1 = 8.0 * (2 * d_ * D * chi ** 3 + d_ ** 2 * D ** 2 * chi ** 2)
+        F_svd = 88.0 * n ** 3   # nominal zgesdd count of the reference's (d chi) x (d chi) SVD, for every split AND every centre shift
+        cnt = {k_: sum(s1[k_] - s0[k_] for s0, s1 in zip(stats0, stats1)) for k_ in stats1[0]}
+        # counters count batched calls; each call covers the engine's nb trajectories
+        wsum = lambda key: sum((s1[key] - s0[key]) * e.B for s0, s1, e in zip(stats0, stats1, engines))  # noqa: E731
+        flops_svd = F_svd * sum(s1["svd_matrices"] - s0["svd_matrices"] for s0, s1 in zip(stats0, stats1))
+        flops_kry = F_mv2 * wsum("matvecs_two_site") + F_mv1 * (wsum("matvecs") - wsum("matvecs_two_site"))
+        flops_env = F_mv1 * wsum("env_updates")
+        cls_ms = {c: sum(p[c]["ms"] for p in prof) for c in ("svd", "krylov", "env")}
+        # with several engines the classes overlap in time on the device: fractions are then of the engines' summed stream time
+        tf = lambda fl, msv: (fl / 1e12) / (msv / 1e3) if msv > 0 else None  # noqa: E731
+        svd_tf, kry_tf, env_tf = tf(flops_svd, cls_ms["svd"]), tf(flops_kry, cls_ms["krylov"]), tf(flops_env, cls_ms["env"])
+        step_tf = (flops_svd + flops_kry + flops_env) / 1e12 / elapsed
+        busy = sum(cls_ms.values()) / 1e3
         traffic, traffic_note = pmc_traffic(L, chi, B)
+        cross_gbs = (nbytes.value / 1e9) / (ms.value / 1e3) if ms.value > 0 else None
         out = {
             "metric": "trajectories/sec",
             "value": value,
@@ -235,39 +413,64 @@ def main():
             "warmup": W,
             "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",  # arithmetic type; the tensors are complex128 (interleaved re, im)
             "data": "synthetic",
             "config": {
                 "workload": f"{L}-site {WORKLOADS[args.workload][0]}, chi={chi}, dt={dt:g}, "
                             f"order-1 TJM, {args.tdvp_mode} TDVP, svd_threshold=1e-12, krylov_tol={args.krylov_tol:g}, Haar chi-saturated initial MPS",
+                "trajectories": total_traj,
                 "trajectories_in_flight_per_gpu": B,
+                "engines_per_gpu": E,
                 "steps_per_trajectory": STEPS_PER_TRAJ,
                 "parallelism": f"trajectory-sharded x{world}",
                 "storage": "complex128",
             },
             "site_updates_per_sec": site_updates,
-            "counters_per_step": {k_: (stats1[k_] - stats0[k_]) / K for k_ in stats1},
+            "counters_per_step": {k_: v / K / E for k_, v in cnt.items()},
             "mean_Z_site0": float(zsum[0] / total_traj),
+            # Dominant kernel class: the SVD family (Jacobi + QR kernels; fp64 VALU-issue-bound, not HBM-bound).  Unit of a "launch" =
+            # one batched SVD (a two-site split or an SVD centre shift of every resident trajectory); algorithmic work = SURVEY 8d's
+            # nominal 88 n^3 real flops per (d chi) x (d chi) SVD; duration = HIP events on the engine's stream around every such SVD.
             "roofline": {
-                "bound": "hbm",
-                "kernel": "jacobi_cross16x_kernel (X-rows block-pair step of the batched one-sided Jacobi SVD)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "bound": "fp64-valu",
+                "kernel": "SVD family: jacobi_cross16x_kernel (dominant) + jacobi_* + qr_* + svd_finish/extract, per batched SVD",
+                "achieved": svd_tf,
+                "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": (svd_tf / FP64_PEAK_TFLOPS) if svd_tf else None,
                 "traffic": traffic,
                 "traffic_note": traffic_note,
-                "avg_launch_us": (1e3 * ms.value / ns.value) if ns.value else None,
-                "launches_sampled": int(ns.value),
+                "algorithmic_flops_per_svd": F_svd,
+                "svds_per_step": cnt["svds"] / K / E,
+                "avg_batched_svd_ms": cls_ms["svd"] / max(1, sum(p["svd"]["regions"] for p in prof)),
+                "dominant_kernel": {
+                    "name": "jacobi_cross16x_kernel",
+                    "avg_launch_us": (1e3 * ms.value / ns.value) if ns.value else None,
+                    "launches_sampled": int(ns.value),
+                    "tile_bytes_GBps": cross_gbs,  # bytes of the 32-column tiles it reads and writes once per launch / duration
+                    "tile_bytes_frac_of_hbm_peak": (cross_gbs / HBM_PEAK_GBS) if cross_gbs else None,
+                },
+                "classes": {
+                    "svd": {"bound": "fp64-valu", "achieved_TFLOPs": svd_tf, "frac": (svd_tf / FP64_PEAK_TFLOPS) if svd_tf else None,
+                            "share_of_stream_time": cls_ms["svd"] / 1e3 / busy if busy else None},
+                    "krylov": {"bound": "mfma-f64", "achieved_TFLOPs": kry_tf, "frac": (kry_tf / FP64_PEAK_TFLOPS) if kry_tf else None,
+                               "share_of_stream_time": cls_ms["krylov"] / 1e3 / busy if busy else None,
+                               "note": "H_eff applies (2 MFMA GEMMs + MPO stage) with the Lanczos vector kernels (HBM-bound) inside the region"},
+                    "env": {"bound": "mfma-f64", "achieved_TFLOPs": env_tf, "frac": (env_tf / FP64_PEAK_TFLOPS) if env_tf else None,
+                            "share_of_stream_time": cls_ms["env"] / 1e3 / busy if busy else None},
+                    "whole_step": {"achieved_TFLOPs": step_tf, "frac": step_tf / FP64_PEAK_TFLOPS,
+                                   "timed_classes_over_wall": busy / elapsed if elapsed > 0 else None},
+                },
             },
         }
         if cpu_ref is not None:
             out["cpu_baseline"] = cpu_ref
+            out["speedup_vs_cpu"] = {"vs_best_whole_host_row": value / cpu_ref["value"], "vs_one_core": value / cpu_ref["per_core_value"]}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    if use_dist:
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -130,6 +130,15 @@ int tjm_engine_canonicalize_qr(tjm_engine* e, int32_t set, int32_t center);
  * outcomes, site 0 first (the reference packs them as sum(bit_i << i)). */
 int tjm_engine_sample_shots(tjm_engine* e, int32_t set, int32_t shots, const double* rotation, const double* uniforms, uint8_t* bits);
 int tjm_engine_stats(const tjm_engine* e, int64_t* out5);
+/* the same five counters followed by: two-site H_eff applies (a subset of matvecs), environment updates, centre shifts served by
+ * the certified QR path, matrices factorised (batched SVD calls x trajectories in the call); writes min(n, 9) values */
+int tjm_engine_stats_ex(const tjm_engine* e, int64_t* out, int32_t n);
+/* Live device time per kernel class of a step, bracketed with HIP events on the engine's stream (the source of bench.py's
+ * roofline object): class 0 = SVD family (split_two_site and the SVD centre shifts: QR, Jacobi, truncation, their GEMMs),
+ * 1 = Krylov exponentials (project_site / project_bond applies, Lanczos vector kernels), 2 = environment updates.
+ * read(): summed milliseconds and region counts since enable. */
+int tjm_engine_profile(tjm_engine* e, int32_t enable);
+int tjm_engine_profile_read(tjm_engine* e, double* ms3, int64_t* regions3);
 
 /* ---- whole trajectories in one call -------------------------------------------------- *
  * The body of the backend contract: analog_tjm_1 / analog_tjm_2 (analog/analog_tjm.py:206-462) for the B resident

@@ -1615,8 +1615,16 @@ def test_error_behaviour_matches_reference_types():
     p2 = AnalogSimParams(observables=[Observable(Zg(), 0)], elapsed_time=0.1, dt=0.1, max_bond_dim=4)
     lr = NoiseModel([{"name": "custom", "sites": [0, 3], "strength": 0.2,
                       "factors": (np.array([[0, 1], [0, 0]], dtype=complex), np.array([[1, 0], [0, -1]], dtype=complex))}])
-    with pytest.raises(NotImplementedError):
+    # the front end refuses it in the run-context validation (noise_model.py:668-742 -> ValueError), the backend itself with the
+    # reference's NotImplementedError (dissipation.py:136-138)
+    with pytest.raises(ValueError, match="non-Pauli long-range"):
         Simulator().run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p2, lr)
+    from yaqs_amd.tjm import TrajectoryBatch
+
+    eng = make_engine(L, 4, 1, MPO.ising(L, 1.0, 0.5).tensors)
+    with pytest.raises(NotImplementedError):
+        TrajectoryBatch(eng, p2, lr).run([0], MPS(L, state="x+"))
+    eng.close()
 
 
 def test_run_from_a_basis_state_matches_oracle():
@@ -1728,3 +1736,73 @@ def test_output_state_answers_the_inspection_helpers():
     pr = np.linalg.svd(vec, compute_uv=False) ** 2
     pr = pr[pr > 1e-300]
     assert abs(out.get_entropy([i, i + 1]) - (-np.sum(pr * np.log(pr)))) < 1e-9
+
+
+def test_schmidt_spectrum_through_the_front_end():
+    """Simulator.run with a schmidt_spectrum observable: trajectories[u] holds the 500-entry vectors per trajectory and time point,
+    expectation_values[u] their concatenation over the trajectories (mps.py:1211, result.py:127-139) - not NaN means."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    L = 6
+    noise = NoiseModel([{"name": "lowering", "sites": [s], "strength": 0.1} for s in range(L)])
+    obs = [Observable(Zg(), 0), Observable("schmidt_spectrum", [2, 3]), Observable("entropy", [2, 3])]
+    kw = dict(elapsed_time=0.3, dt=0.1, num_traj=3, max_bond_dim=8, svd_threshold=1e-12, krylov_tol=1e-12, order=1, sample_timesteps=True, random_seed=5)
+    res = Simulator(batch=2).run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), AnalogSimParams(observables=obs, **kw), noise)
+    spec = res.trajectories[1]
+    assert spec.shape == (3, 4, 500)
+    assert res.expectation_values[1].shape == (3 * 4 * 500,)
+    # entropy row (a scalar) and the spectrum must agree with each other at every time point: S = -sum p log p, p = s^2 / sum s^2
+    for t in range(3):
+        for j in range(4):
+            sv = spec[t, j][~np.isnan(spec[t, j])]
+            pr = sv ** 2 / np.sum(sv ** 2)
+            ent = -np.sum(pr * np.log(pr + np.finfo(float).tiny))
+            assert abs(ent - res.trajectories[2][t, j]) < 1e-10
+    assert np.isfinite(res.expectation_values[0]).all() and np.isfinite(res.expectation_values[2]).all()
+
+
+def test_one_site_tdvp_run_with_a_pair_channel_grows_its_storage():
+    """tdvp_mode='1site' freezes the bonds of the sweep, but an adjacent non-Pauli two-site channel goes through a merged truncated
+    split that can enlarge them: the storage ladder must serve that instead of refusing."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    L = 4
+    noise = NoiseModel([{"name": "lowering_two", "sites": [1, 2], "strength": 0.4}, {"name": "pauli_x", "sites": [0], "strength": 0.2}])
+    kw = dict(elapsed_time=0.3, dt=0.1, max_bond_dim=4, svd_threshold=1e-12, krylov_tol=1e-12, order=1, sample_timesteps=True, random_seed=3,
+              tdvp_mode="1site")
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=4, **kw)
+    res = Simulator().run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p, noise)
+    on = [o.make_process(q["name"], q["sites"], q["strength"], matrix=q.get("matrix")) for q in noise.processes]
+    op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], **kw)
+    for t in range(4):
+        r, _, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), on, op, o.ising_mpo(L, 1.0, 0.5))
+        for s_ in range(L):
+            assert np.allclose(res.trajectories[s_][t], r[s_], atol=1e-8), (t, s_)
+
+
+def test_engine_runs_on_the_device_that_owns_its_workspace():
+    """Every C entry point selects the engine's device itself: an engine whose workspace lives on the last visible
+    device must work while another device is current.  With one GPU the guard is exercised with that device."""
+    from yaqs_amd.engine import BatchEngine
+
+    n = torch.cuda.device_count()
+    dev = f"cuda:{n - 1}"
+    torch.cuda.set_device(0)
+    L = 6
+    mpo = o.ising_mpo(L, 1.0, 0.5)
+    e = BatchEngine(L, 8, 2, mpo, device=dev, stream=torch.cuda.Stream(device=dev))
+    e.set_params(dt=0.1, svd_threshold=1e-10, max_bond_dim=8, krylov_tol=1e-12)
+    e.set_noise([], [])
+    st = o.MPSState.product(L, "x+")
+    e.load_state(st.tensors)
+    e.tdvp()
+    M = e.site_moments()
+    ref = o.MPSState.product(L, "x+")
+    o.tdvp(ref, mpo, o.Params(dt=0.1, max_bond_dim=8, svd_threshold=1e-10, krylov_tol=1e-12))
+    for s_ in range(L):
+        z = (M[s_, 0, 0, 0] - M[s_, 0, 1, 1]).real
+        assert abs(z - ref.local_expect(Z, [s_]).real) < 1e-9
+    assert torch.cuda.current_device() == 0
+    e.close()

@@ -527,7 +527,87 @@ def gen_tiny():
     save("tiny", **out)
 
 
+# ------------------------------------------------------------------ 12. BASELINE.json configurations at their stated sizes
+def _fullsize_inputs(L, chi, seed=1):
+    """The chi-saturated Haar state of bench.py / SURVEY section 8d, built by the package's own host-side builder (no GPU), so the
+    GPU test regenerates the identical input from the seed; handed to the reference as MPS(tensors=...)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from yaqs_amd import api
+
+    st = api.MPS(L, state="haar-random", pad=chi, rng=np.random.default_rng(seed))
+    st.normalize("B")
+    return api, [np.array(t, dtype=np.complex128) for t in st.tensors]
+
+
+def _one_step(name, L, chi, mpo_tensors, proc, gamma, dt, tdvp_mode, tensors, trajs, out, krylov_tol=1e-10):
+    import time
+
+    H = MPO()  # tensors in the reference's (phys_out, phys_in, chi_l, chi_r) order already
+    H.tensors = [np.asarray(w, dtype=np.complex128) for w in mpo_tensors]
+    H.length = L
+    H.physical_dimension = 2
+    noise = NoiseModel([{"name": proc, "sites": [i], "strength": gamma} for i in range(L)])
+    obs = [sp.Observable(gl.Z(), s) for s in range(L)]
+    p = sp.AnalogSimParams(observables=obs, elapsed_time=dt, dt=dt, max_bond_dim=chi, svd_threshold=1e-12, krylov_tol=krylov_tol, order=1,
+                           sample_timesteps=False, random_seed=42, tdvp_mode=tdvp_mode, get_state=True)
+    dps = []
+    orig = stoch.calculate_stochastic_factor
+
+    def spy(state):
+        v = orig(state)
+        dps.append(float(v))
+        return v
+
+    stoch.calculate_stochastic_factor = spy
+    res, dplog, bonds, diag, ulog = [], [], [], [], []
+    try:
+        for t in trajs:
+            dps.clear()
+            t0 = time.time()
+            st = MPS(L, tensors=[x.copy() for x in tensors])
+            r, dg, final = tjm.analog_tjm_1((t, st, noise, p, H))
+            print(f"  {name}: trajectory {t} took {time.time() - t0:.1f} s, dp {dps}", flush=True)
+            res.append(np.asarray(r, dtype=np.float64)[:, 0])
+            diag.append(np.asarray(dg, dtype=np.float64)[:, 0])
+            dplog.append(dps[0])
+            bonds.append([final.tensors[0].shape[1]] + [x.shape[2] for x in final.tensors])
+            ulog.append(rutil.make_trajectory_rng(t, base_seed=42).random())
+    finally:
+        stoch.calculate_stochastic_factor = orig
+    out[name + "_traj"] = np.array(trajs)
+    out[name + "_z"] = np.array(res)
+    out[name + "_diag"] = np.array(diag)
+    out[name + "_dp"] = np.array(dplog)
+    out[name + "_bonds"] = np.array(bonds)
+    out[name + "_u0"] = np.array(ulog)
+
+
+def gen_fullsize(which=("cfg2", "cfg4", "cfg3")):
+    """One order-1 TJM step of the reference at BASELINE.json's sizes (krylov_tol 1e-10): per-site <Z>, dp, final bond dimensions,
+    diagnostics.  cfg2: L=64 chi=128 dissipative TFIM; cfg4: L=32 chi=256 long-range Ising, one-site TDVP; cfg3: L=128 chi=256 XXZ
+    with amplitude damping.  The inputs are regenerated from seeds by the test (nothing large is stored)."""
+    path = os.path.join(OUT, "fullsize.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    if "cfg2" in which:
+        api, tensors = _fullsize_inputs(64, 128)
+        # trajectory 0 does not jump (u = 0.858 >= dp), trajectory 3 does (first uniform 0.0858...): chosen from the stream table
+        us = [rutil.make_trajectory_rng(t, base_seed=42).random() for t in range(16)]
+        jumper = next(t for t in range(16) if us[t] < 0.3)
+        _one_step("cfg2", 64, 128, api.MPO.ising(64, 1.0, 0.5).tensors, "pauli_z", 0.1, 0.1, "2site", tensors, [0, jumper], out)
+    if "cfg4" in which:
+        api, tensors = _fullsize_inputs(32, 256)
+        mpo = api.MPO.long_range_ising(32, [0.8792, 0.1208], [0.0717, 0.5136], 0.5)
+        _one_step("cfg4", 32, 256, mpo.tensors, "pauli_z", 0.05, 0.05, "1site", tensors, [0], out)
+    if "cfg3" in which:
+        api, tensors = _fullsize_inputs(128, 256)
+        _one_step("cfg3", 128, 256, api.MPO.heisenberg(128, 1.0, 1.0, 0.5, 0.0).tensors, "lowering", 0.05, 0.05, "2site", tensors, [0], out)
+    save("fullsize", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tiny", "rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
     for w in which:
-        globals()["gen_" + w]()
+        if w.startswith("fullsize:"):
+            gen_fullsize(tuple(w.split(":")[1].split(",")))
+        else:
+            globals()["gen_" + w]()

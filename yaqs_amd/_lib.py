@@ -102,6 +102,9 @@ EXPORTS = {
     "tjm_engine_bitstring_probability": (C.c_int, [V, I, V, V]),
     "tjm_engine_sample_shots": (C.c_int, [V, I, I, V, V, V]),
     "tjm_engine_stats": (C.c_int, [V, V]),
+    "tjm_engine_stats_ex": (C.c_int, [V, V, I]),
+    "tjm_engine_profile": (C.c_int, [V, I]),
+    "tjm_engine_profile_read": (C.c_int, [V, V, V]),
     "tjm_engine_run": (C.c_int, [V, C.POINTER(RunConfig), V, V, V]),
     "tjm_rng_uniforms": (C.c_int, [I, C.c_uint64, C.c_uint64, C.c_int64, I, V]),
     "tjm_zgemm_batched": (C.c_int, [C.POINTER(GemmDesc), V]),

@@ -1100,7 +1100,7 @@ class Result:
     order, per-trajectory rows and their means, averaged diagnostics, the final state / sampled noise model / measurement histogram
     when the run produced them, ``None`` otherwise."""
 
-    def __init__(self, sim_params, results_sorted, diagnostics, counts=None):
+    def __init__(self, sim_params, results_sorted, diagnostics, counts=None, schmidt=None):
         import copy
 
         # results_sorted: [num_traj, n_obs_sorted, T]; diagnostics: [num_traj, 3, T]
@@ -1119,6 +1119,18 @@ class Result:
             idx = sim_params.observable_sorted_indices
             self.trajectories = [results_sorted[:, idx[u], :] for u in range(len(self.observables))]
             self.expectation_values = [np.mean(t, axis=0) for t in self.trajectories]
+            for u, ob in enumerate(self.observables):
+                if ob.gate.name != "schmidt_spectrum":
+                    continue
+                # the reference keeps the 500-entry vectors in the results buffer and concatenates them over the trajectories
+                # (mps.py:1211, result.py:127-139): trajectories[u] is [num_traj, T, 500], NaN-padded past the spectrum
+                n_traj, cols = results_sorted.shape[0], results_sorted.shape[2]
+                spec = np.full((n_traj, cols, 500), np.nan)
+                for (t, row, col), vec in (schmidt or {}).items():
+                    if row == idx[u]:
+                        spec[t, col] = vec
+                self.trajectories[u] = spec
+                self.expectation_values[u] = np.concatenate([spec[t].ravel() for t in range(n_traj)]) if n_traj else np.zeros(0)
         self.runtime_cost = self.max_bond = self.total_bond = None
         self.trajectory_diagnostics = diagnostics  # per-trajectory rows (this package's addition), also for shots-only runs
         if diagnostics is not None and (len(self.observables) or counts is None):  # a shots-only run reports no averaged diagnostics

@@ -11,6 +11,28 @@ struct tjm_engine {
   Engine impl;
 };
 
+namespace {
+// Every entry point that touches the device runs on the device that owns the engine's workspace, whatever device the calling
+// thread has current (one process may drive several GPUs, and a torchrun rank >= 1 starts with device 0 current).
+struct DeviceGuard {
+  int prev = -1, want = -1;
+  explicit DeviceGuard(int device) : want(device) {
+    if (want < 0) return;
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+    if (prev != want && hipSetDevice(want) != hipSuccess) prev = -1;
+  }
+  ~DeviceGuard() {
+    if (want >= 0 && prev >= 0 && prev != want) (void)hipSetDevice(prev);
+  }
+};
+int device_of(const void* dev_ptr) {
+  hipPointerAttribute_t a;
+  if (!dev_ptr || hipPointerGetAttributes(&a, dev_ptr) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return a.device;
+}
+}  // namespace
+#define TJM_ON_DEVICE(e) DeviceGuard tjm_guard_((e) ? (e)->impl.device_id : -1)
+
 extern "C" {
 
 int tjm_version(void) { return 100; }
@@ -40,12 +62,17 @@ int tjm_engine_create(tjm_engine** out, int32_t L, int32_t d, int32_t chi_max, i
   return TJM_OK;
 }
 
-void tjm_engine_destroy(tjm_engine* e) { delete e; }
+void tjm_engine_destroy(tjm_engine* e) {
+  TJM_ON_DEVICE(e);
+  delete e;
+}
 
 size_t tjm_engine_workspace_bytes(const tjm_engine* e) { return e ? e->impl.workspace_bytes() : 0; }
 
 int tjm_engine_bind(tjm_engine* e, void* ws, size_t bytes, void* stream) {
   if (!e || !ws) return TJM_ERR_ARG;
+  e->impl.device_id = device_of(ws);
+  TJM_ON_DEVICE(e);
   return e->impl.bind(ws, bytes, static_cast<hipStream_t>(stream));
 }
 
@@ -60,17 +87,19 @@ int tjm_engine_set_params(tjm_engine* e, double dt, double svd_threshold, int32_
 int tjm_engine_capacity_overflow(tjm_engine* e, int32_t* flag, int32_t clear) {
   if (!e || !flag) return TJM_ERR_ARG;
   int f = 0;
+  TJM_ON_DEVICE(e);
   const int rc = e->impl.capacity_overflow(&f, clear != 0);
   *flag = f;
   return rc;
 }
 
 int tjm_engine_adopt_state(tjm_engine* dst, tjm_engine* src, int32_t src_first) {
-  if (!dst || !src || dst == src) return TJM_ERR_ARG;
+  if (!dst || !src || dst == src || dst->impl.device_id != src->impl.device_id) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(dst);
   return dst->impl.adopt(src->impl, src_first);
 }
 
-int tjm_engine_set_mpo(tjm_engine* e, const double* host_mpo) { return (e && host_mpo) ? e->impl.set_mpo(host_mpo) : TJM_ERR_ARG; }
+int tjm_engine_set_mpo(tjm_engine* e, const double* host_mpo) { TJM_ON_DEVICE(e); return (e && host_mpo) ? e->impl.set_mpo(host_mpo) : TJM_ERR_ARG; }
 
 int tjm_engine_set_noise(tjm_engine* e, int32_t nproc, const int32_t* nsites, const int32_t* sites, const double* gamma,
                          const int32_t* pauli, const double* mats, const double* factors, const int32_t* has_factors) {
@@ -88,13 +117,15 @@ int tjm_engine_set_noise(tjm_engine* e, int32_t nproc, const int32_t* nsites, co
     }
     if (p.nsites == 2 && p.site1 - p.site0 > 1 && !p.has_factors) return TJM_ERR_ARG;
   }
+  TJM_ON_DEVICE(e);
   return e->impl.set_noise(v);
 }
 
 int tjm_engine_load_state(tjm_engine* e, int32_t set, const double* t, const int32_t* bonds) {
+  TJM_ON_DEVICE(e);
   return (e && t && bonds) ? e->impl.load_state(set, t, bonds) : TJM_ERR_ARG;
 }
-int tjm_engine_copy_state(tjm_engine* e, int32_t dst, int32_t src) { return e ? e->impl.copy_state(dst, src) : TJM_ERR_ARG; }
+int tjm_engine_copy_state(tjm_engine* e, int32_t dst, int32_t src) { TJM_ON_DEVICE(e); return e ? e->impl.copy_state(dst, src) : TJM_ERR_ARG; }
 
 size_t tjm_engine_padded_state_elems(const tjm_engine* e) {
   size_t n = 0;
@@ -106,56 +137,70 @@ int tjm_engine_bond_caps(const tjm_engine* e, int32_t* caps) {
   return TJM_OK;
 }
 int tjm_engine_export_state(tjm_engine* e, int32_t set, int32_t b, double* out, int32_t* bonds) {
+  TJM_ON_DEVICE(e);
   return (e && out && bonds && set >= 0 && set < 2) ? e->impl.export_state(set, b, out, bonds) : TJM_ERR_ARG;
 }
-int tjm_engine_set_uniforms(tjm_engine* e, const double* u, int32_t n) { return (e && u && n > 0) ? e->impl.set_uniforms(u, n) : TJM_ERR_ARG; }
-int tjm_engine_tdvp(tjm_engine* e, int32_t set) { return (e && set >= 0 && set < 2) ? e->impl.tdvp(set) : TJM_ERR_ARG; }
-int tjm_engine_dissipate(tjm_engine* e, int32_t set, double dt) { return (e && set >= 0 && set < 2) ? e->impl.dissipate(set, dt) : TJM_ERR_ARG; }
+int tjm_engine_set_uniforms(tjm_engine* e, const double* u, int32_t n) { TJM_ON_DEVICE(e); return (e && u && n > 0) ? e->impl.set_uniforms(u, n) : TJM_ERR_ARG; }
+int tjm_engine_tdvp(tjm_engine* e, int32_t set) { TJM_ON_DEVICE(e); return (e && set >= 0 && set < 2) ? e->impl.tdvp(set) : TJM_ERR_ARG; }
+int tjm_engine_dissipate(tjm_engine* e, int32_t set, double dt) { TJM_ON_DEVICE(e); return (e && set >= 0 && set < 2) ? e->impl.dissipate(set, dt) : TJM_ERR_ARG; }
 int tjm_engine_dissipate_from(tjm_engine* e, int32_t set, double dt, int32_t center) {
+  TJM_ON_DEVICE(e);
   return (e && set >= 0 && set < 2) ? e->impl.dissipate(set, dt, center) : TJM_ERR_ARG;
 }
-int tjm_engine_set_noise_filter(tjm_engine* e, int32_t n, const int32_t* idx) { return e ? e->impl.set_noise_filter(n, idx) : TJM_ERR_ARG; }
+int tjm_engine_set_noise_filter(tjm_engine* e, int32_t n, const int32_t* idx) { TJM_ON_DEVICE(e); return e ? e->impl.set_noise_filter(n, idx) : TJM_ERR_ARG; }
 int tjm_engine_normalize_qr(tjm_engine* e, int32_t set, int32_t center) {
+  TJM_ON_DEVICE(e);
   return (e && set >= 0 && set < 2) ? e->impl.normalize_qr(set, center) : TJM_ERR_ARG;
 }
 int tjm_engine_apply_single(tjm_engine* e, int32_t set, int32_t site, const double* mat) {
+  TJM_ON_DEVICE(e);
   return (e && mat && set >= 0 && set < 2) ? e->impl.apply_single(set, site, mat) : TJM_ERR_ARG;
 }
 int tjm_engine_tebd_gate(tjm_engine* e, int32_t set, int32_t left, const double* u) {
+  TJM_ON_DEVICE(e);
   return (e && u && set >= 0 && set < 2) ? e->impl.tebd_gate(set, left, u) : TJM_ERR_ARG;
 }
 int tjm_engine_apply_pair(tjm_engine* e, int32_t set, int32_t left, const double* u, int32_t min_keep) {
+  TJM_ON_DEVICE(e);
   return (e && u && set >= 0 && set < 2) ? e->impl.apply_pair(set, left, u, min_keep) : TJM_ERR_ARG;
 }
 int tjm_engine_canonicalize_qr(tjm_engine* e, int32_t set, int32_t center) {
+  TJM_ON_DEVICE(e);
   return (e && set >= 0 && set < 2) ? e->impl.canonicalize_qr(set, center) : TJM_ERR_ARG;
 }
 int tjm_engine_tebd_gate_at(tjm_engine* e, int32_t set, int32_t left, int32_t center, const double* u) {
+  TJM_ON_DEVICE(e);
   return (e && u && set >= 0 && set < 2) ? e->impl.tebd_gate(set, left, u, center) : TJM_ERR_ARG;
 }
 int tjm_engine_stochastic(tjm_engine* e, int32_t set, double dt, int32_t* jumped, double* dp) {
+  TJM_ON_DEVICE(e);
   return (e && set >= 0 && set < 2) ? e->impl.stochastic(set, dt, jumped, dp) : TJM_ERR_ARG;
 }
-int tjm_engine_site_moments(tjm_engine* e, int32_t set, double* M) { return (e && M) ? e->impl.site_moments(set, M) : TJM_ERR_ARG; }
+int tjm_engine_site_moments(tjm_engine* e, int32_t set, double* M) { TJM_ON_DEVICE(e); return (e && M) ? e->impl.site_moments(set, M) : TJM_ERR_ARG; }
 int tjm_engine_site_moments2(tjm_engine* e, int32_t set, double* M, double* M2) {
+  TJM_ON_DEVICE(e);
   return (e && M && M2) ? e->impl.site_moments(set, M, M2) : TJM_ERR_ARG;
 }
-int tjm_engine_bond_dims(tjm_engine* e, int32_t set, int32_t* chi) { return (e && chi) ? e->impl.bond_dims(set, chi) : TJM_ERR_ARG; }
-int tjm_engine_site0_normsq(tjm_engine* e, int32_t set, double* out) { return (e && out) ? e->impl.site_normsq0(set, out) : TJM_ERR_ARG; }
+int tjm_engine_bond_dims(tjm_engine* e, int32_t set, int32_t* chi) { TJM_ON_DEVICE(e); return (e && chi) ? e->impl.bond_dims(set, chi) : TJM_ERR_ARG; }
+int tjm_engine_site0_normsq(tjm_engine* e, int32_t set, double* out) { TJM_ON_DEVICE(e); return (e && out) ? e->impl.site_normsq0(set, out) : TJM_ERR_ARG; }
 int tjm_engine_bond_spectrum(tjm_engine* e, int32_t set, int32_t site, double* spectrum, int32_t n_out) {
+  TJM_ON_DEVICE(e);
   return (e && set >= 0 && set < 2) ? e->impl.bond_spectrum(set, site, spectrum, n_out) : TJM_ERR_ARG;
 }
 
 int tjm_engine_bitstring_probability(tjm_engine* e, int32_t set, const uint8_t* bits, double* prob) {
+  TJM_ON_DEVICE(e);
   return (e && set >= 0 && set < 2) ? e->impl.bitstring_probability(set, bits, prob) : TJM_ERR_ARG;
 }
 
 int tjm_engine_sample_shots(tjm_engine* e, int32_t set, int32_t shots, const double* rotation, const double* uniforms, uint8_t* bits) {
+  TJM_ON_DEVICE(e);
   return (e && set >= 0 && set < 2) ? e->impl.sample_shots(set, shots, rotation, uniforms, bits) : TJM_ERR_ARG;
 }
 
 int tjm_engine_run(tjm_engine* e, const tjm_run_config* cfg, const int64_t* traj, double* results, double* diagnostics) {
   if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
   return run_batch(e->impl, cfg, traj, results, diagnostics);
 }
 
@@ -172,6 +217,31 @@ int tjm_engine_stats(const tjm_engine* e, int64_t* o) {
   return TJM_OK;
 }
 
+int tjm_engine_stats_ex(const tjm_engine* e, int64_t* o, int32_t n) {
+  if (!e || !o || n < 0) return TJM_ERR_ARG;
+  const int64_t v[9] = {e->impl.stat_matvecs, e->impl.stat_krylov_calls, e->impl.stat_svds, e->impl.stat_svd_sweeps,
+                        e->impl.stat_site_updates, e->impl.stat_matvecs2, e->impl.stat_env_updates, e->impl.stat_cert_shifts,
+                        e->impl.stat_svd_mats};
+  for (int k = 0; k < n && k < 9; ++k) o[k] = v[k];
+  return TJM_OK;
+}
+
+int tjm_engine_profile(tjm_engine* e, int32_t enable) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  e->impl.profile_enable(enable != 0);
+  return TJM_OK;
+}
+
+int tjm_engine_profile_read(tjm_engine* e, double* ms3, int64_t* regions3) {
+  if (!e || !ms3 || !regions3) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  long n[Engine::PROF_NCLASS];
+  const int rc = e->impl.profile_read(ms3, n);
+  for (int c = 0; c < Engine::PROF_NCLASS; ++c) regions3[c] = n[c];
+  return rc;
+}
+
 int tjm_zgemm_batched(const tjm_gemm_desc* t, void* stream) {
   if (!t) return TJM_ERR_ARG;
   GemmDesc g;
@@ -185,6 +255,7 @@ int tjm_zgemm_batched(const tjm_gemm_desc* t, void* stream) {
   g.b_b0 = t->b_b0; g.b_b1 = t->b_b1; g.b_b2 = t->b_b2;
   g.c_b0 = t->c_b0; g.c_b1 = t->c_b1; g.c_b2 = t->c_b2;
   g.conjA = t->conjA; g.conjB = t->conjB;
+  DeviceGuard guard(device_of(t->C));
   return launch_gemm(g, static_cast<hipStream_t>(stream));
 }
 
@@ -194,6 +265,7 @@ static int svd_split_impl(bool use_qr, const void* theta, int32_t B, int32_t d, 
                           int32_t distribution, int32_t trunc_mode, double threshold, int32_t max_bond, int32_t min_keep, int32_t* chi_lrm,
                           double* spectrum, int32_t spec_ld, void* work, size_t work_bytes, int32_t* sweeps_out, void* stream_) {
   if (!theta || !left || !right || !chi_lrm || !work) return TJM_ERR_ARG;
+  DeviceGuard guard(device_of(work));
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int m = d * capL, n = d * capR;
   const int mx = m > n ? m : n;
@@ -261,6 +333,7 @@ int tjm_profile_cross_kernel_read(double* total_ms, double* total_bytes, int64_t
 }
 
 int tjm_tridiag_expm(const double* alpha, const double* beta, int32_t k, double dt, double* out, void* stream) {
+  DeviceGuard guard(device_of(out));
   return launch_tridiag_expm_test(alpha, beta, k, dt, out, static_cast<hipStream_t>(stream));
 }
 

@@ -32,11 +32,25 @@ class Engine {
   std::vector<int> cap, Dm;
   int Dmax = 1;
   hipStream_t stream = nullptr;
+  int device_id = -1;  // device that owns the workspace (set at bind from the workspace pointer)
   // numerical parameters
   double dt = 0.1, svd_threshold = 1e-6, krylov_tol = 1e-4;
   int trunc_mode = 0, max_bond = 0, tdvp_mode = 2, tdvp_sweeps = 1;
   // statistics
   long stat_matvecs = 0, stat_krylov_calls = 0, stat_svds = 0, stat_svd_sweeps = 0, stat_site_updates = 0;
+  long stat_matvecs2 = 0, stat_env_updates = 0, stat_cert_shifts = 0, stat_svd_mats = 0;  // two-site H_eff applies (subset of matvecs), environment updates, certified shifts
+
+  // Live timing of the kernel classes of a step with HIP events on the engine's stream (bench.py's roofline object):
+  // class 0 = SVD family (two-site splits and SVD centre shifts: QR + Jacobi + finish + their GEMMs), 1 = Krylov exponentials
+  // (H_eff applies, MPO stage, Lanczos vector kernels), 2 = environment updates and merges.
+  enum { PROF_SVD = 0, PROF_KRYLOV = 1, PROF_ENV = 2, PROF_NCLASS = 3 };
+  void profile_enable(bool on);
+  int profile_read(double* ms /*[PROF_NCLASS]*/, long* regions /*[PROF_NCLASS]*/);
+  struct Region {
+    Engine& e; int idx;
+    Region(Engine& eng, int cls);
+    ~Region();
+  };
 
   int create(int L, int d, int chi_max, int B, const int* mpo_bond);
   size_t workspace_bytes() const;
@@ -74,6 +88,32 @@ class Engine {
   int heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv,
                  long r_b0, int Dr, const cplx* Wm, cplx* y, long y_b0, int nb0, const int* ids, const int* active);
 
+  struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> pool;       // pairs (begin, end)
+    std::vector<int> cls;               // class of pair k
+    size_t used = 0;
+    double ms[PROF_NCLASS] = {0, 0, 0};
+    long n[PROF_NCLASS] = {0, 0, 0};
+    int depth = 0;
+  } prof_;
+  void prof_collect();
+
+  // environment updates on explicit tensors (also the kernel-level parity exports of the C ABI)
+  int env_left_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int Dr, const cplx* Lin, long lin_b0, const cplx* WenvL, cplx* Lout,
+                  long lout_b0, int nb);
+  int env_right_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int Dr, const cplx* Rin, long rin_b0, const cplx* Wm, cplx* Rout,
+                   long rout_b0, int nb);
+  // kernel-level parity exports (tjm_capi.hip): operands are device arrays of nb <= B slots, W is a host MPO tensor (o,p,l,r)
+  int x_heff_apply(int nsites, int ca, int cb, int Dl, int Dr, const cplx* x, const cplx* Lenv, const cplx* Renv, const double* host_w, cplx* y, int nb);
+  int x_env_update(int left, int ca, int cb, int Dl, int Dr, const cplx* A, const cplx* env, const double* host_w, cplx* out, int nb);
+  int x_project_bond(int cu, int cv, int D, const cplx* C, const cplx* Lenv, const cplx* Renv, cplx* y, int nb);
+  int x_lanczos_expm(int nsites, int ca, int cb, int Dl, int Dr, const cplx* x, const cplx* Lenv, const cplx* Renv, const double* host_w, double dt_,
+                     double tol, cplx* y, int nb, long* matvecs);
+  int x_center_shift(int set, int site, int direction, int use_svd);
+  int x_jump_weights(int set, double dt_, int* host_order /*[nproc]*/, double* host_w /*[B][nproc]*/, int* n_out);
+  int upload_w(const double* host_w, int P, int Dl, int Dr, cplx** mv, cplx** envl);
+
   StateSet sets[2];
   // work areas (public for tests)
   cplx *T1 = nullptr, *T2 = nullptr, *V = nullptr, *theta = nullptr;
@@ -84,6 +124,7 @@ class Engine {
 
  private:
   bool bound_ = false;
+  int krylov_P_ = 0;             // physical dimension of the block the running Krylov exponential acts on (0: bond matrix)
   std::vector<long> a_b0_, l_b0_, r_b0_;
   std::vector<cplx*> Lenv_, Renv_;
   std::vector<cplx*> W_;         // per-site MPO as matrix [(o,l),(p,r)] : matvec / right-env form

@@ -54,6 +54,52 @@ void small_expm(const cplx* in, int n, cplx* out) {
 }
 }  // namespace
 
+// ---- live class timing -------------------------------------------------------------------------------------------------
+void Engine::profile_enable(bool on) {
+  prof_collect();
+  prof_.on = on;
+  if (on) for (int c = 0; c < PROF_NCLASS; ++c) { prof_.ms[c] = 0.0; prof_.n[c] = 0; }
+}
+
+void Engine::prof_collect() {
+  if (prof_.used == 0) return;
+  (void)hipStreamSynchronize(stream);
+  for (size_t k = 0; k < prof_.used; ++k) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, prof_.pool[2 * k], prof_.pool[2 * k + 1]) == hipSuccess) {
+      prof_.ms[prof_.cls[k]] += ms;
+      ++prof_.n[prof_.cls[k]];
+    }
+  }
+  prof_.used = 0;
+}
+
+int Engine::profile_read(double* ms, long* regions) {
+  prof_collect();
+  for (int c = 0; c < PROF_NCLASS; ++c) { ms[c] = prof_.ms[c]; regions[c] = prof_.n[c]; }
+  return TJM_OK;
+}
+
+Engine::Region::Region(Engine& eng, int cls) : e(eng), idx(-1) {
+  if (!e.prof_.on || e.prof_.depth++ > 0) return;  // nested regions count for the outer class
+  if (e.prof_.used >= 8192) e.prof_collect();
+  idx = (int)e.prof_.used++;
+  while (e.prof_.pool.size() < 2 * e.prof_.used) {
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) { idx = -1; --e.prof_.used; return; }
+    e.prof_.pool.push_back(ev);
+  }
+  if (e.prof_.cls.size() < e.prof_.used) e.prof_.cls.resize(e.prof_.used);
+  e.prof_.cls[idx] = cls;
+  (void)hipEventRecord(e.prof_.pool[2 * idx], e.stream);
+}
+
+Engine::Region::~Region() {
+  if (!e.prof_.on) return;
+  --e.prof_.depth;
+  if (idx >= 0) (void)hipEventRecord(e.prof_.pool[2 * idx + 1], e.stream);
+}
+
 int Engine::create(int L_, int d_, int chi_, int B_, const int* mpo_bond) {
   if (L_ < 1 || d_ != 2 || chi_ < 1 || B_ < 1) return TJM_ERR_ARG;  // qubit chains only for now
   L = L_; d = d_; chi_max = chi_; B = B_;
@@ -200,6 +246,7 @@ int Engine::run_sweep(int set, const std::vector<SmallSweepStep>& steps, const i
   q.ids = ids; q.nb0 = nb0; q.flags = overflow_;
   q.pitch = small_sweep_pitch(d * *std::max_element(cap.begin(), cap.end()));
   stat_svds += (long)steps.size();
+  stat_svd_mats += (long)steps.size() * nb0;
   return launch_small_sweep(q, stream);
 }
 
@@ -429,31 +476,38 @@ int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cp
 }
 
 int Engine::env_left(StateSet& S, int i) {
-  const int ca = cap[i], cb = cap[i + 1], Dl = Dm[i], Dr = Dm[i + 1];
+  return env_left_at(S.A[i], a_b0_[i], cap[i], cap[i + 1], Dm[i], Dm[i + 1], Lenv_[i], l_b0_[i], WenvL_[i], Lenv_[i + 1], l_b0_[i + 1], B);
+}
+
+// update_left_environment (primitives.py:77-107) on explicit tensors: A [nb][d][ca][cb], Lin [nb][ca][Dl][ca] -> Lout [nb][cb][Dr][cb]
+int Engine::env_left_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int Dr, const cplx* Lin, long lin_b0, const cplx* WenvL, cplx* Lout,
+                        long lout_b0, int nb) {
   int rc;
+  Region prof(*this, PROF_ENV);
+  ++stat_env_updates;
   {  // T1[(a,l),(o,B)] = L[(a,l),A] conj(A_i[o][A][B])
     GemmDesc g = blank_gemm();
-    g.A = Lenv_[i]; g.B = S.A[i]; g.C = T1;
+    g.A = Lin; g.B = A; g.C = T1;
     g.M = ca * Dl; g.K = ca; g.N = cb;
     g.a_rs = ca; g.a_cs = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = (long)d * cb; g.conjB = 1;
-    g.nb0 = B; g.nb1 = d;
-    g.a_b0 = l_b0_[i]; g.b_b0 = a_b0_[i]; g.b_b1 = (long)ca * cb; g.c_b0 = t_b0; g.c_b1 = cb;
+    g.nb0 = nb; g.nb1 = d;
+    g.a_b0 = lin_b0; g.b_b0 = a_b0; g.b_b1 = (long)ca * cb; g.c_b0 = t_b0; g.c_b1 = cb;
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   {  // T2[p][a][r][B] = sum_{o,l} W[o,p,l,r] T1[a][l][o][B]
     MpoApplyDesc m;
-    m.in = T1; m.out = T2; m.Wm = WenvL_[i]; m.P = d; m.din = Dl; m.dout = Dr; m.na = ca; m.nB = cb;
+    m.in = T1; m.out = T2; m.Wm = WenvL; m.P = d; m.din = Dl; m.dout = Dr; m.na = ca; m.nB = cb;
     m.in_sp = cb; m.in_sb = (long)d * cb; m.in_sa = (long)Dl * d * cb;
     m.out_sp = (long)ca * Dr * cb; m.out_sb = cb; m.out_sa = (long)Dr * cb;
-    m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = B; m.ids = nullptr; m.active = nullptr;
+    m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = nb; m.ids = nullptr; m.active = nullptr;
     if ((rc = launch_mpo_apply(m, stream)) != TJM_OK) return rc;
   }
   {  // L'[b,(r,B)] = sum_{(p,a)} A_i[(p,a),b] T2[(p,a),(r,B)]
     GemmDesc g = blank_gemm();
-    g.A = S.A[i]; g.B = T2; g.C = Lenv_[i + 1];
+    g.A = A; g.B = T2; g.C = Lout;
     g.M = cb; g.K = d * ca; g.N = Dr * cb;
     g.a_rs = 1; g.a_cs = cb; g.b_rs = (long)Dr * cb; g.b_cs = 1; g.c_rs = (long)Dr * cb;
-    g.nb0 = B; g.a_b0 = a_b0_[i]; g.b_b0 = t_b0; g.c_b0 = l_b0_[i + 1];
+    g.nb0 = nb; g.a_b0 = a_b0; g.b_b0 = t_b0; g.c_b0 = lout_b0;
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   return TJM_OK;
@@ -461,31 +515,38 @@ int Engine::env_left(StateSet& S, int i) {
 
 int Engine::env_right(StateSet& S, int i) {
   // Renv_[i-1] (bond cap[i], Dm[i]) from Renv_[i] and A_i
-  const int ca = cap[i], cb = cap[i + 1], Dl = Dm[i], Dr = Dm[i + 1];
+  return env_right_at(S.A[i], a_b0_[i], cap[i], cap[i + 1], Dm[i], Dm[i + 1], Renv_[i], r_b0_[i], W_[i], Renv_[i - 1], r_b0_[i - 1], B);
+}
+
+// update_right_environment (primitives.py:110-136) on explicit tensors: A [nb][d][ca][cb], Rin [nb][cb][Dr][cb] -> Rout [nb][ca][Dl][ca]
+int Engine::env_right_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int Dr, const cplx* Rin, long rin_b0, const cplx* Wm, cplx* Rout,
+                         long rout_b0, int nb) {
   int rc;
+  Region prof(*this, PROF_ENV);
+  ++stat_env_updates;
   {  // T1[(p,a),(r,B)] = A_i[(p,a),b] R[b,(r,B)]
     GemmDesc g = blank_gemm();
-    g.A = S.A[i]; g.B = Renv_[i]; g.C = T1;
+    g.A = A; g.B = Rin; g.C = T1;
     g.M = d * ca; g.K = cb; g.N = Dr * cb;
     g.a_rs = cb; g.a_cs = 1; g.b_rs = (long)Dr * cb; g.b_cs = 1; g.c_rs = (long)Dr * cb;
-    g.nb0 = B; g.a_b0 = a_b0_[i]; g.b_b0 = r_b0_[i]; g.c_b0 = t_b0;
+    g.nb0 = nb; g.a_b0 = a_b0; g.b_b0 = rin_b0; g.c_b0 = t_b0;
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   {  // T2[a][l][o][B] = sum_{p,r} W[o,p,l,r] T1[p][a][r][B]
     MpoApplyDesc m;
-    m.in = T1; m.out = T2; m.Wm = W_[i]; m.P = d; m.din = Dr; m.dout = Dl; m.na = ca; m.nB = cb;
+    m.in = T1; m.out = T2; m.Wm = Wm; m.P = d; m.din = Dr; m.dout = Dl; m.na = ca; m.nB = cb;
     m.in_sp = (long)ca * Dr * cb; m.in_sb = cb; m.in_sa = (long)Dr * cb;
     m.out_sp = cb; m.out_sb = (long)d * cb; m.out_sa = (long)Dl * d * cb;
-    m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = B; m.ids = nullptr; m.active = nullptr;
+    m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = nb; m.ids = nullptr; m.active = nullptr;
     if ((rc = launch_mpo_apply(m, stream)) != TJM_OK) return rc;
   }
   {  // R'[(a,l),A] = sum_o sum_B T2[(a,l),(o,B)] conj(A_i[o][A][B])
     GemmDesc g = blank_gemm();
-    g.A = T2; g.B = S.A[i]; g.C = Renv_[i - 1];
+    g.A = T2; g.B = A; g.C = Rout;
     g.M = ca * Dl; g.K = cb; g.N = ca;
     g.a_rs = (long)d * cb; g.a_cs = 1; g.b_rs = 1; g.b_cs = cb; g.c_rs = ca; g.conjB = 1;
     g.nks = d; g.a_ks = cb; g.b_ks = (long)ca * cb;
-    g.nb0 = B; g.a_b0 = t_b0; g.b_b0 = a_b0_[i]; g.c_b0 = r_b0_[i - 1];
+    g.nb0 = nb; g.a_b0 = t_b0; g.b_b0 = a_b0; g.c_b0 = rout_b0;
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   return TJM_OK;
@@ -497,6 +558,7 @@ int Engine::env_right(StateSet& S, int i) {
 int Engine::krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2, int n3,
                         long o0, long o1, long o2, int nb0, const int* ids) {
   int rc, nblk = 1;
+  Region prof(*this, PROF_KRYLOV);
   ++stat_krylov_calls;
   TJM_HIP_CHECK(hipMemsetAsync(ks.n_active, 0, sizeof(int), stream));
   if ((rc = launch_normsq_partial(V, v_b0, n, part2_, nb0, ids, nullptr, stream, &nblk)) != TJM_OK) return rc;
@@ -508,6 +570,7 @@ int Engine::krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc
     cplx* vjm1 = V + (long)(j > 0 ? j - 1 : 0) * v_ld;
     if ((rc = apply(vj, w, ks.status)) != TJM_OK) return rc;
     ++stat_matvecs;
+    if (krylov_P_ == d * d) ++stat_matvecs2;
     if ((rc = launch_dot_partial(vj, w, v_b0, v_b0, n, part1_, nb0, ids, ks.status, stream, &nblk)) != TJM_OK) return rc;
     if ((rc = launch_lanczos_axpy(w, vj, vjm1, v_b0, n, part1_, part2_, nblk, ks.beta, mmax, j, nb0, ids, ks.status, stream)) != TJM_OK) return rc;
     TJM_HIP_CHECK(hipMemsetAsync(ks.n_active, 0, sizeof(int), stream));
@@ -538,7 +601,10 @@ int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Len
   ApplyFn f = [&](const cplx* x, cplx* y, const int* active) {
     return heff_apply(x, v_b0, P, ca, cb, Lenv, l_b0, Dl, Renv, r_b0, Dr, Wm, y, v_b0, nb0, ids, active);
   };
-  return krylov_core(f, P * ca * cb, dt_, nloc_dev, out, out_b0, n0, n1, n2, n3, o0, o1, o2, nb0, ids);
+  krylov_P_ = P;
+  const int rc = krylov_core(f, P * ca * cb, dt_, nloc_dev, out, out_b0, n0, n1, n2, n3, o0, o1, o2, nb0, ids);
+  krylov_P_ = 0;
+  return rc;
 }
 
 // project_bond (primitives.py:207-226): y[p][w] = sum L[u][a][p] C[u][v] R[v][a][w]
@@ -599,10 +665,12 @@ int Engine::split(StateSet& S, int i, int dist, int mode, double thr, int maxb, 
   s.spectrum = nullptr; s.spec_ld = 0; s.nb0 = nb0; s.ids = ids;
   s.overflow = overflow_;
   int sweeps = 0;
+  Region prof(*this, PROF_SVD);
   static const bool no_qr = getenv("TJM_NO_QR") != nullptr;
   const bool use_qr = !no_qr && ids == nullptr && std::min(s.m, s.n) >= 64;
   const int rc = use_qr ? svd_split_qr(s, svdw, qrw, stream, &sweeps) : svd_split(s, svdw, stream, &sweeps);
   ++stat_svds;
+  stat_svd_mats += nb0;
   stat_svd_sweeps += sweeps;
   return rc;
 }
@@ -843,13 +911,14 @@ int Engine::tdvp(int set) {
 int Engine::svd_shift_right(StateSet& S, int i, const int* ids, int nb0) {
   const int ca = cap[i], cb = cap[i + 1], cc = cap[i + 2];
   int rc;
+  Region prof(*this, PROF_SVD);
   if (svd_shift_small_fits(d, ca, cb, false)) {  // small bonds: factorisation, truncation and absorption in one kernel
     SmallShiftDesc q;
     q.site = S.A[i]; q.site_b0 = a_b0_[i]; q.nb = S.A[i + 1]; q.nb_b0 = a_b0_[i + 1];
     q.d = d; q.ca = ca; q.cb = cb; q.cn = cc;
     q.chi = S.chi + i; q.chi_stride = L + 1; q.threshold = 1e-12; q.min_keep = 1;
     q.ids = ids; q.nb0 = nb0; q.flags = overflow_;
-    ++stat_svds;
+    ++stat_svds; stat_svd_mats += nb0;
     return launch_svd_shift_small(q, false, stream);
   }
   JacobiSource src;
@@ -864,7 +933,7 @@ int Engine::svd_shift_right(StateSet& S, int i, const int* ids, int nb0) {
   int sweeps = 0;
   // only X is rotated: U is the set of normalised rotated columns, and S V^H = U^H A_i comes from one GEMM on the input
   if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps, false)) != TJM_OK) return rc;
-  ++stat_svds; stat_svd_sweeps += sweeps;
+  ++stat_svds; stat_svd_mats += nb0; stat_svd_sweeps += sweeps;
   ExtractDesc xu;  // U[(s,a)][k] = X_final / sigma  (zero beyond keep), first into the temp: A_i is still needed
   xu.out = theta; xu.out_b0 = theta_b0; xu.n_k = cb; xu.o_k = 1; xu.n_r1 = 1; xu.n_r0 = d * ca; xu.o_r1 = 0; xu.o_r0 = cb;
   xu.row_off = 0; xu.conj = 0; xu.scale_mode = 2;
@@ -895,13 +964,14 @@ int Engine::svd_shift_right(StateSet& S, int i, const int* ids, int nb0) {
 int Engine::svd_shift_left(StateSet& S, int i, const int* ids, int nb0) {
   const int cz = cap[i - 1], ca = cap[i], cb = cap[i + 1];
   int rc;
+  Region prof(*this, PROF_SVD);
   if (svd_shift_small_fits(d, ca, cb, true)) {
     SmallShiftDesc q;
     q.site = S.A[i]; q.site_b0 = a_b0_[i]; q.nb = S.A[i - 1]; q.nb_b0 = a_b0_[i - 1];
     q.d = d; q.ca = ca; q.cb = cb; q.cn = cz;
     q.chi = S.chi + i; q.chi_stride = L + 1; q.threshold = 1e-12; q.min_keep = 1;
     q.ids = ids; q.nb0 = nb0; q.flags = overflow_;
-    ++stat_svds;
+    ++stat_svds; stat_svd_mats += nb0;
     return launch_svd_shift_small(q, true, stream);
   }
   JacobiSource src;  // X = M^H : rows (t,c), columns a
@@ -916,7 +986,7 @@ int Engine::svd_shift_left(StateSet& S, int i, const int* ids, int nb0) {
   int sweeps = 0;
   // only X = M^H is rotated: its normalised columns are the right singular vectors V of M, and U S = M V is one GEMM
   if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps, false)) != TJM_OK) return rc;
-  ++stat_svds; stat_svd_sweeps += sweeps;
+  ++stat_svds; stat_svd_mats += nb0; stat_svd_sweeps += sweeps;
   ExtractDesc xt;  // Vt[(t,c)][k] = X_final / sigma into the temp (row-major, d*cb x ca)
   xt.out = theta; xt.out_b0 = theta_b0; xt.n_k = ca; xt.o_k = 1; xt.n_r1 = 1; xt.n_r0 = d * cb; xt.o_r1 = 0; xt.o_r0 = ca;
   xt.row_off = 0; xt.conj = 0; xt.scale_mode = 2;

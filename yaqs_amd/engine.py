@@ -20,7 +20,7 @@ def _i32(a) -> np.ndarray:
 
 
 class BatchEngine:
-    def __init__(self, length: int, chi_max: int, batch: int, mpo: Sequence[np.ndarray], device: str = "cuda:0", d: int = 2):
+    def __init__(self, length: int, chi_max: int, batch: int, mpo: Sequence[np.ndarray], device: str = "cuda:0", d: int = 2, stream=None):
         import torch
 
         if not torch.cuda.is_available():
@@ -37,8 +37,12 @@ class BatchEngine:
         nbytes = self.lib.tjm_engine_workspace_bytes(self.h)
         self.workspace_bytes = int(nbytes)
         with torch.cuda.device(self.device):
-            self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
-            self.stream = torch.cuda.current_stream(self.device)
+            # every engine launches on ONE stream; engines on different streams overlap on the device (the SVD kernels are
+            # VALU-bound, the contractions MFMA-bound: the two pipes of a CU run side by side)
+            self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(self.stream):
+                self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)  # zero fill ordered before the engine's work
+            self.stream.synchronize()
         _lib.check(self.lib.tjm_engine_bind(self.h, self.ws.data_ptr(), nbytes, C.c_void_p(self.stream.cuda_stream)), "bind")
         packed = np.concatenate([np.ascontiguousarray(w, dtype=np.complex128).reshape(-1) for w in mpo])
         _lib.check(self.lib.tjm_engine_set_mpo(self.h, packed.ctypes.data), "set_mpo")
@@ -285,9 +289,20 @@ class BatchEngine:
         return bits
 
     def stats(self) -> dict:
-        s = np.zeros(5, dtype=np.int64)
-        self.lib.tjm_engine_stats(self.h, s.ctypes.data)
-        return dict(matvecs=int(s[0]), krylov_calls=int(s[1]), svds=int(s[2]), svd_sweeps=int(s[3]), site_updates=int(s[4]))
+        s = np.zeros(9, dtype=np.int64)
+        self.lib.tjm_engine_stats_ex(self.h, s.ctypes.data, 9)
+        return dict(matvecs=int(s[0]), krylov_calls=int(s[1]), svds=int(s[2]), svd_sweeps=int(s[3]), site_updates=int(s[4]),
+                    matvecs_two_site=int(s[5]), env_updates=int(s[6]), certified_shifts=int(s[7]), svd_matrices=int(s[8]))
+
+    def profile(self, enable: bool = True):
+        """Bracket the kernel classes of every step with HIP events on the engine's stream (tjm_engine_profile)."""
+        _lib.check(self.lib.tjm_engine_profile(self.h, int(bool(enable))), "profile")
+
+    def profile_read(self) -> dict:
+        ms = np.zeros(3)
+        n = np.zeros(3, dtype=np.int64)
+        _lib.check(self.lib.tjm_engine_profile_read(self.h, ms.ctypes.data, n.ctypes.data), "profile_read")
+        return {k: {"ms": float(ms[i]), "regions": int(n[i])} for i, k in enumerate(("svd", "krylov", "env"))}
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)

@@ -15,7 +15,7 @@ from typing import Sequence
 
 import numpy as np
 
-from .api import META_OBSERVABLES, AnalogSimParams, MPO, MPS, NoiseModel, Result, is_pauli
+from .api import META_OBSERVABLES, AnalogSimParams, MPO, MPS, NoiseModel, Result, is_pauli, validate_noise_model_for_run
 from ._lib import CapacityError
 from .engine import BatchEngine
 
@@ -567,6 +567,7 @@ class Simulator:
             hamiltonian = pieces[0]
         if hamiltonian.length != initial_state.length:
             raise ValueError("State and Hamiltonian must have the same number of sites")  # tdvp.py:91-93
+        validate_noise_model_for_run(noise_model, length=initial_state.length, is_digital=False, sim_params=sim_params)  # simulator.py:1488-1516
         if noise_model is not None:  # one realisation of static disorder per run (simulator.py:1269-1271)
             noise_model = noise_model.sample(rng=disorder_rng(sim_params.random_seed))
         initial_state = _encoded(initial_state)
@@ -580,13 +581,14 @@ class Simulator:
         num_traj = sim_params.num_traj if noisy else 1  # simulator.py:1549-1559
         lo, hi = shard_range(num_traj, rank, world)
         mine = list(range(lo, hi))
-        chi, chi_top = engine_bond_caps(sim_params, initial_state)
+        chi, chi_top = engine_bond_caps(sim_params, initial_state, can_grow=_noise_can_grow_bonds(noise_model))
         cols = len(sim_params.times) if sim_params.sample_timesteps else 1
         n_obs = len(sim_params.observables)
         res_all = np.zeros((len(mine), n_obs, cols))
         diag_all = np.zeros((len(mine), 3, cols))
         done = 0
         final = None
+        schmidt: dict = {}  # (global trajectory index, sorted row, column) -> 500-entry Schmidt spectrum
         while done < len(mine):
             B = self._batch_for(len(mine) - done, initial_state.length, chi, hamiltonian.tensors, device)
             chunk = mine[done: done + B]
@@ -598,7 +600,12 @@ class Simulator:
                 return tb
 
             def run_piece(tb, lo_, hi_, resume, chunk=chunk):
-                return tb.run(chunk[lo_:hi_], initial_state if resume is None else None, native=self.native, resume=resume)
+                try:
+                    return tb.run(chunk[lo_:hi_], initial_state if resume is None else None, native=self.native, resume=resume)
+                finally:  # also on a capacity hand-over: the columns measured before the clipped step stay valid
+                    for (row, col), arr in tb.schmidt.items():
+                        for b_, t_ in enumerate(chunk[lo_:hi_]):
+                            schmidt[(t_, row, col)] = arr[b_]
 
             keep = sim_params.get_state and 0 in chunk
             r, dg, last = self._run_growing(chunk, chi, chi_top, initial_state.length, hamiltonian.tensors, make_batch, run_piece, device, cols,
@@ -616,7 +623,9 @@ class Simulator:
                 last.close()
         if world > 1:
             res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, lo, device)
-        out = Result(sim_params, res_all, diag_all)
+            if any(ob.gate.name == "schmidt_spectrum" for ob in sim_params.observables):
+                schmidt = gather_counts_like(schmidt, device)
+        out = Result(sim_params, res_all, diag_all, schmidt=schmidt)
         out.output_state = final
         out.noise_model = noise_model  # the sampled realisation the trajectories ran with (result.py:155-189)
         return out
@@ -630,18 +639,20 @@ class Simulator:
 
         from .api import CircuitResult
 
+        validate_noise_model_for_run(noise_model, length=initial_state.length, is_digital=True, sim_params=sim_params)  # simulator.py:1867-1873
         if noise_model is not None:
             noise_model = noise_model.sample(rng=disorder_rng(sim_params.random_seed))
         initial_state = _encoded(initial_state)
         noisy = noise_model is not None and any(q["strength"] != 0 for q in noise_model.processes)
         num_traj, per_call, distribution = plan_digital_shots(sim_params, noisy)
         device = self.device or f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
-        chi, chi_top = engine_bond_caps(sim_params, initial_state)
+        chi, chi_top = engine_bond_caps(sim_params, initial_state, can_grow=True)  # every TEBD gate is a truncated split
         mid = sim_params.num_mid_measurements if sim_params.sample_layers else 0
         cols = (mid + 2) if sim_params.sample_layers else 1
         res_all = np.zeros((num_traj, len(sim_params.observables), cols))
         diag_all = np.zeros((num_traj, 3, cols))
         counts: dict[int, int] = {}
+        schmidt: dict = {}
         wants_shots = sim_params.shots is not None
         identity_mpo = [np.eye(2, dtype=np.complex128).reshape(2, 2, 1, 1)] * initial_state.length  # the circuit path never applies it
         rank, world = 0, 1
@@ -657,7 +668,12 @@ class Simulator:
             spt = [shots_for_trajectory(t, per_call, distribution) for t in chunk] if wants_shots else None
 
             def run_piece(db, lo_, hi_, resume, chunk=chunk, spt=spt):
-                out = db.run(chunk[lo_:hi_], initial_state, layers, shots_per_traj=None if spt is None else spt[lo_:hi_], basis=basis, resume=resume)
+                try:
+                    out = db.run(chunk[lo_:hi_], initial_state, layers, shots_per_traj=None if spt is None else spt[lo_:hi_], basis=basis, resume=resume)
+                finally:
+                    for (row, col), arr in db.schmidt.items():
+                        for b_, t_ in enumerate(chunk[lo_:hi_]):
+                            schmidt[(t_, row, col)] = arr[b_]
                 for k, v in (db.counts or {}).items():
                     counts[k] = counts.get(k, 0) + v
                 return out
@@ -671,8 +687,10 @@ class Simulator:
             res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, first, device)
             if wants_shots:
                 counts = gather_counts(counts, device)
+            if any(ob.gate.name == "schmidt_spectrum" for ob in sim_params.observables):
+                schmidt = gather_counts_like(schmidt, device)
         has_obs = len(sim_params.observables) > 0  # a shots-only run reports no diagnostics (result.py:155-189)
-        out = CircuitResult(sim_params, res_all if has_obs else None, diag_all, counts if wants_shots else None)
+        out = CircuitResult(sim_params, res_all if has_obs else None, diag_all, counts if wants_shots else None, schmidt=schmidt)
         out.noise_model = noise_model
         return out
 
@@ -689,7 +707,7 @@ START_CHI = 8   # first storage capacity tried when the requested cap is larger
 AUTO_BATCH_MAX = 16384  # trajectories in flight when Simulator(batch=None) sizes the batch itself
 
 
-def engine_bond_caps(sim_params, initial_state) -> tuple[int, int]:
+def engine_bond_caps(sim_params, initial_state, can_grow: bool = False) -> tuple[int, int]:
     """``(first, top)`` storage capacities of the engine.
 
     The reference's bonds are dynamic and its presets ask for ``max_bond_dim`` = 128, 4096 or no cap at all
@@ -698,7 +716,9 @@ def engine_bond_caps(sim_params, initial_state) -> tuple[int, int]:
     (``CapacityError``): the final pass is one in which ``max_bond_dim`` and the threshold alone decided every truncation,
     exactly as in the reference.  Work grows with chi**3, so the discarded passes cost at most 1/7 of the last one.
     ``top`` is the largest capacity that can ever be needed: ``max_bond_dim``, the exact Schmidt-rank bound ``2**(L//2)`` and
-    the bonds of the initial state.
+    the bonds of the initial state.  ``can_grow``: something besides the TDVP sweep can enlarge a bond (an adjacent non-Pauli
+    two-site process or a scheduled pair jump goes through a merged, truncated split; so does every TEBD gate), so a one-site
+    TDVP run is not confined to the bonds of its initial state.
     """
     have = max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors)
     exact = 2 ** min(initial_state.length // 2, 30)
@@ -706,7 +726,7 @@ def engine_bond_caps(sim_params, initial_state) -> tuple[int, int]:
     top = max(want, have)
     if have > MAX_CHI:
         raise NotImplementedError(f"bond dimension {have} of the initial state exceeds the supported chi <= {MAX_CHI}")
-    if getattr(sim_params, "tdvp_mode", "2site") == "1site":
+    if getattr(sim_params, "tdvp_mode", "2site") == "1site" and not can_grow:
         return have, have  # one-site TDVP never changes a bond (integrators.py:44-158)
     return max(have, min(top, START_CHI)), top
 
@@ -763,6 +783,34 @@ def shots_for_trajectory(traj: int, per_call, distribution) -> int:
 def shard_range(num_traj: int, rank: int, world: int) -> tuple[int, int]:
     """Contiguous trajectory-index range of ``rank``."""
     return (num_traj * rank) // world, (num_traj * (rank + 1)) // world
+
+
+def _noise_can_grow_bonds(noise_model) -> bool:
+    """True when a process of the model is applied through a merged two-site split (dissipation.py:158-171,
+    stochastic_process.py:268-288, scheduled_jumps.py:88-106): adjacent non-Pauli pairs and scheduled pair jumps."""
+    if noise_model is None:
+        return False
+    for q in noise_model.processes:
+        if len(q["sites"]) == 2 and abs(q["sites"][1] - q["sites"][0]) == 1 and not is_pauli(q):
+            return True
+    return any(len(j["sites"]) == 2 for j in (getattr(noise_model, "scheduled_jumps", None) or []))
+
+
+def gather_counts_like(table: dict, device) -> dict:
+    """Union of per-rank dictionaries with disjoint keys (the Schmidt spectra of each rank's trajectories)."""
+    import contextlib
+
+    import torch
+    import torch.distributed as dist
+
+    parts = [None] * dist.get_world_size()
+    ctx = torch.cuda.device(torch.device(device)) if dist.get_backend() == "nccl" else contextlib.nullcontext()
+    with ctx:
+        dist.all_gather_object(parts, dict(table))
+    out: dict = {}
+    for part in parts:
+        out.update(part)
+    return out
 
 
 def gather_counts(counts: dict, device) -> dict:
