@@ -203,6 +203,31 @@ int tjm_svd_split_qr(const void* theta, int32_t B, int32_t d, int32_t capL, int3
                      int32_t distribution, int32_t trunc_mode, double threshold, int32_t max_bond, int32_t min_keep,
                      int32_t* chi_lrm, double* spectrum, int32_t spec_ld, void* work, size_t work_bytes, int32_t* sweeps_out,
                      void* hip_stream);
+/* The contractions of the sweep on explicit tensors.  Every operand is a device array of nb slots (nb must equal the engine's B),
+ * contiguous per slot, within the engine's bond capacities; host_w is ONE host MPO tensor in the reference's (phys_out, phys_in,
+ * chi_l, chi_r) order (mpo.py:45-50), for nsites = 2 the merged tensor of merge_mpo_tensors (primitives.py:54-74).
+ *   tjm_heff_apply   project_site (core/methods/tdvp/primitives.py:180-204): x, y [P][ca][cb] (P = d or d^2),
+ *                    Lenv [ca][Dl][ca], Renv [cb][Dr][cb]
+ *   tjm_env_update   update_left_environment (left = 1, primitives.py:77-107): A [d][ca][cb], env [ca][Dl][ca] -> out [cb][Dr][cb];
+ *                    update_right_environment (left = 0, primitives.py:110-136): env [cb][Dr][cb] -> out [ca][Dl][ca]; bra = ket = A
+ *   tjm_project_bond project_bond (primitives.py:207-226): C, y [cu][cv], Lenv [cu][D][cu], Renv [cv][D][cv]
+ *   tjm_lanczos_expm update_site = expm_krylov o project_site (primitives.py:484-520, matrix_exponential.py:33-173):
+ *                    y = exp(-i dt H_eff) x with the reference's adaptive stop at `tol`; matvecs (optional) = Lanczos steps issued */
+int tjm_heff_apply(tjm_engine* e, int32_t nsites, int32_t ca, int32_t cb, int32_t Dl, int32_t Dr, const void* x, const void* Lenv, const void* Renv,
+                   const double* host_w, void* y, int32_t nb);
+int tjm_env_update(tjm_engine* e, int32_t left, int32_t ca, int32_t cb, int32_t Dl, int32_t Dr, const void* A, const void* env, const double* host_w,
+                   void* out, int32_t nb);
+int tjm_project_bond(tjm_engine* e, int32_t cu, int32_t cv, int32_t D, const void* C, const void* Lenv, const void* Renv, void* y, int32_t nb);
+int tjm_lanczos_expm(tjm_engine* e, int32_t nsites, int32_t ca, int32_t cb, int32_t Dl, int32_t Dr, const void* x, const void* Lenv, const void* Renv,
+                     const double* host_w, double dt, double tol, void* y, int32_t nb, int64_t* matvecs);
+/* One orthogonality-centre shift of the loaded state, shift_orthogonality_center_right / _left (mps.py:719-788): direction = +1
+ * moves the centre from `site` to site + 1, -1 to site - 1; use_svd = 0: QR (exact gauge move), 1: SVD with the shift's own
+ * truncation (discarded weight 1e-12, no cap). */
+int tjm_engine_center_shift(tjm_engine* e, int32_t set, int32_t site, int32_t direction, int32_t use_svd);
+/* create_probability_distribution (stochastic_process.py:139-187) of a state with centre 0: order[k] = index of the k-th channel
+ * in the reference's sweep order, weights[B][n] = dt * gamma * ||L psi||^2 (unnormalised); *n_out = number of channels.
+ * TJM_ERR_NUMERIC for a zero / non-finite total (stochastic_process.py:178-186). */
+int tjm_engine_jump_weights(tjm_engine* e, int32_t set, double dt, int32_t* order, double* weights, int32_t* n_out);
 /* exp(-i dt T_k) e_1 of the Lanczos tridiagonal (matrix_exponential.py:147-163); device pointers. */
 int tjm_tridiag_expm(const double* alpha, const double* beta, int32_t k, double dt, double* out_k_complex, void* hip_stream);
 

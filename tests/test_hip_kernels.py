@@ -435,3 +435,194 @@ def test_svd_split_steeply_graded_spectrum_keeps_small_values_accurately(lib, di
         assert np.allclose(L_ @ R_, theta[b], atol=1e-13)
         iso = L_ if dist == 0 else R_.conj().T
         assert np.allclose(iso.conj().T @ iso, np.eye(n), atol=1e-11)
+
+
+# ---- kernel-level exports of the sweep against the REFERENCE's own outputs (tests/golden/kernels.npz, tools/make_golden.py) ----
+def _kernel_engine(B=2):
+    from oracle import tjm_oracle as o  # checker only: MPO builder for an engine of Dmax = 3, capacities up to 8
+    from yaqs_amd.engine import BatchEngine
+
+    return BatchEngine(8, 8, B, o.ising_mpo(8, 1.0, 0.5))
+
+
+_KEEP = []  # device operands stay referenced until the test module is done (a temporary's memory would be reused mid-call)
+
+
+def _slots(a, B=2):
+    """Slot 0 = the fixture operand, slot 1 = a scaled copy (checks the batch strides)."""
+    t = dev(np.stack([a * (1.0 + 0.5 * k) for k in range(B)]))
+    _KEEP.append(t)
+    return t
+
+
+def _same(a, B=2):
+    t = dev(np.stack([a] * B))
+    _KEEP.append(t)
+    return t
+
+
+def test_project_site_env_updates_and_project_bond_match_reference_outputs(lib):
+    """tjm_heff_apply / tjm_env_update / tjm_project_bond on the reference's operands (primitives.py:77-226), tolerance 1e-11."""
+    from conftest import GOLDEN
+    from yaqs_amd._lib import check
+
+    g = np.load(os.path.join(GOLDEN, "kernels.npz"))
+    e = _kernel_engine()
+    H = lambda a: np.ascontiguousarray(a, dtype=np.complex128)  # noqa: E731
+    # two-site project_site: x = merge (4, 5, 4), L (5, 3, 5), R (4, 3, 4), merged MPO (4, 4, 3, 3)
+    x, L, R, W2 = g["merge"], g["L"], g["R"], H(g["merge_mpo"])
+    y = torch.zeros((2,) + x.shape, dtype=torch.complex128, device="cuda:0")
+    check(lib.tjm_heff_apply(e.h, 2, 5, 4, 3, 3, _slots(x).data_ptr(), _same(L).data_ptr(), _same(R).data_ptr(),
+                             W2.ctypes.data, y.data_ptr(), 2), "heff2")
+    got = y.cpu().numpy()
+    assert np.allclose(got[0], g["project_site_2"], atol=1e-11) and np.allclose(got[1], 1.5 * g["project_site_2"], atol=1e-11)
+    # one-site project_site: x = A (2, 5, 6), L (5, 3, 5), R1 (6, 3, 6), W1 (2, 2, 3, 3)
+    a, R1, W1 = g["A"], g["R1"], H(g["W1"])
+    y = torch.zeros((2,) + a.shape, dtype=torch.complex128, device="cuda:0")
+    check(lib.tjm_heff_apply(e.h, 1, 5, 6, 3, 3, _slots(a).data_ptr(), _same(L).data_ptr(), _same(R1).data_ptr(),
+                             W1.ctypes.data, y.data_ptr(), 2), "heff1")
+    got = y.cpu().numpy()
+    assert np.allclose(got[0], g["project_site_1"], atol=1e-11) and np.allclose(got[1], 1.5 * g["project_site_1"], atol=1e-11)
+    # environments: left from (A, W1, L) -> (6, 3, 6); right from (B, W2, R) -> (6, 3, 6); quadratic in the site tensor
+    out = torch.zeros((2, 6, 3, 6), dtype=torch.complex128, device="cuda:0")
+    check(lib.tjm_env_update(e.h, 1, 5, 6, 3, 3, _slots(a).data_ptr(), _same(L).data_ptr(), W1.ctypes.data, out.data_ptr(), 2), "envL")
+    got = out.cpu().numpy()
+    assert np.allclose(got[0], g["env_left"], atol=1e-11) and np.allclose(got[1], 2.25 * g["env_left"], atol=1e-11)
+    b, Wb = g["B"], H(g["W2"])
+    out = torch.zeros((2, 6, 3, 6), dtype=torch.complex128, device="cuda:0")
+    check(lib.tjm_env_update(e.h, 0, 6, 4, 3, 3, _slots(b).data_ptr(), _same(R).data_ptr(), Wb.ctypes.data, out.data_ptr(), 2), "envR")
+    got = out.cpu().numpy()
+    assert np.allclose(got[0], g["env_right"], atol=1e-11) and np.allclose(got[1], 2.25 * g["env_right"], atol=1e-11)
+    # project_bond: C (5, 4), LB (5, 3, 5), R (4, 3, 4)
+    c, LB = g["C"], g["LB"]
+    y = torch.zeros((2, 5, 4), dtype=torch.complex128, device="cuda:0")
+    check(lib.tjm_project_bond(e.h, 5, 4, 3, _slots(c).data_ptr(), _same(LB).data_ptr(), _same(R).data_ptr(), y.data_ptr(), 2),
+          "project_bond")
+    got = y.cpu().numpy()
+    assert np.allclose(got[0], g["project_bond"], atol=1e-11) and np.allclose(got[1], 1.5 * g["project_bond"], atol=1e-11)
+    e.close()
+
+
+def test_lanczos_expm_matches_reference_outputs(lib):
+    """tjm_lanczos_expm = update_site (expm_krylov o project_site) on the reference's two-site block of a 6-site chain at both
+    tolerances of the fixture (the fused small-bond kernel serves blocks of this size)."""
+    from conftest import GOLDEN
+    from oracle import tjm_oracle as o  # checker only: merge of the fixture's tensors
+    from yaqs_amd._lib import check
+
+    g = np.load(os.path.join(GOLDEN, "kernels.npz"))
+    e = _kernel_engine()
+    th = o.merge_two_site(g["mps0"], g["mps1"])           # (4, 1, 4)
+    w2 = np.ascontiguousarray(o.merge_mpo_tensors(g["mpo0"], g["mpo1"]), dtype=np.complex128)  # (4, 4, 1, 3)
+    l0 = np.ones((1, 1, 1), dtype=np.complex128)
+    rb = g["renv1"]                                        # (4, 3, 4)
+    for tol in (1e-4, 1e-12):
+        y = torch.zeros((2, 4, 1, 4), dtype=torch.complex128, device="cuda:0")
+        check(lib.tjm_lanczos_expm(e.h, 2, 1, 4, 1, 3, _slots(th).data_ptr(), _same(l0).data_ptr(), _same(rb).data_ptr(),
+                                   w2.ctypes.data, 0.05, tol, y.data_ptr(), 2, None), "lanczos")
+        got = y.cpu().numpy()
+        ref = g[f"krylov_site2_tol{tol:g}"]
+        assert np.allclose(got[0], ref, atol=1e-11), (tol, np.abs(got[0] - ref).max())
+        assert np.allclose(got[1], 1.5 * ref, atol=1e-11)
+    e.close()
+
+
+@pytest.mark.parametrize("nsites", [1, 2])
+def test_lanczos_expm_general_path_matches_oracle(lib, nsites):
+    """The same export at bond 24 (block of 1152 / 2304 entries: MFMA GEMMs + Lanczos vector kernels, one host check per iteration)
+    against the oracle's update_site (pinned to the reference by the fixture above), with the adaptive stop at 1e-4 and 1e-12."""
+    from oracle import tjm_oracle as o  # checker only
+    from yaqs_amd._lib import check
+    from yaqs_amd.engine import BatchEngine
+
+    rng = np.random.default_rng(11 + nsites)
+    ca = cb = 24
+    D, P = 3, 2 ** nsites
+    mpo = o.ising_mpo(8, 1.0, 0.5)
+    w = mpo[3] if nsites == 1 else o.merge_mpo_tensors(mpo[3], mpo[4])
+    herm = lambda m: m + m.conj().transpose(2, 1, 0)  # noqa: E731  (environments of a Hermitian MPO are Hermitian in their outer legs)
+    Lenv, Renv = herm(crand(rng, ca, D, ca)), herm(crand(rng, cb, D, cb))
+    x = crand(rng, P, ca, cb)
+    x /= np.linalg.norm(x)
+    e = BatchEngine(12, 32, 2, o.ising_mpo(12, 1.0, 0.5))
+    wh = np.ascontiguousarray(w, dtype=np.complex128)
+    for tol in (1e-4, 1e-12):
+        y = torch.zeros((2, P, ca, cb), dtype=torch.complex128, device="cuda:0")
+        mv = C.c_int64(0)
+        check(lib.tjm_lanczos_expm(e.h, nsites, ca, cb, D, D, _slots(x).data_ptr(), _same(Lenv).data_ptr(),
+                                   _same(Renv).data_ptr(), wh.ctypes.data, 0.02, tol, y.data_ptr(), 2, C.byref(mv)), "lanczos")
+        ref = o.update_site(Lenv, Renv, w, x, 0.02, tol)
+        got = y.cpu().numpy()
+        assert mv.value >= 2
+        assert np.allclose(got[0], ref, atol=1e-10), (tol, np.abs(got[0] - ref).max())
+        assert np.allclose(got[1], 1.5 * ref, atol=1e-10)
+    e.close()
+
+
+def test_center_shifts_are_gauge_moves_with_isometric_factors(lib):
+    """tjm_engine_center_shift (shift_orthogonality_center_right / _left, mps.py:719-788), QR and SVD flavour: the state vector is
+    unchanged, the tensor left behind is an isometry, the bond obeys the thin-QR rule; at bonds that take the general Householder /
+    Jacobi kernels (capacity 32) and at small ones (fused one-wavefront kernels)."""
+    from oracle import tjm_oracle as o  # checker only
+    from yaqs_amd._lib import check
+    from yaqs_amd.engine import BatchEngine
+
+    for L, chi in ((8, 4), (12, 32)):
+        rng = np.random.default_rng(L)
+        st = o.MPSState.haar(L, chi, rng)
+        st.normalize("B")
+        v0 = st.to_vec() if L <= 12 else None
+        e = BatchEngine(L, chi, 2, o.ising_mpo(L, 1.0, 0.5))
+        e.set_params(dt=0.1, svd_threshold=1e-12, max_bond_dim=chi)
+        for use_svd in (0, 1):
+            e.load_state(st.tensors)
+            for i in range(L - 1):
+                check(lib.tjm_engine_center_shift(e.h, 0, i, 1, use_svd), "shift right")
+                t = e.export_state(1)[i]
+                m = t.reshape(-1, t.shape[2])
+                assert np.allclose(m.conj().T @ m, np.eye(m.shape[1]), atol=1e-12), (L, use_svd, i)
+            out = e.export_state(0)
+            assert np.allclose(abs(np.vdot(o.MPSState(out, L - 1).to_vec(), v0)), 1.0, atol=1e-11)
+            for i in range(L - 1, 0, -1):
+                check(lib.tjm_engine_center_shift(e.h, 0, i, -1, use_svd), "shift left")
+                t = e.export_state(0)[i]
+                m = t.transpose(1, 0, 2).reshape(t.shape[1], -1)
+                assert np.allclose(m @ m.conj().T, np.eye(m.shape[0]), atol=1e-12), (L, use_svd, i)
+            out = e.export_state(1)
+            assert np.allclose(abs(np.vdot(o.MPSState(out, 0).to_vec(), v0)), 1.0, atol=1e-11)
+            assert [t.shape[2] for t in out] == [t.shape[2] for t in st.tensors]
+        e.close()
+
+
+def test_jump_weights_match_the_oracle_distribution(lib):
+    """tjm_engine_jump_weights = create_probability_distribution (stochastic_process.py:139-187): channel order and normalised
+    probabilities for one-site Pauli / non-Pauli, adjacent two-site non-Pauli and long-range Pauli processes."""
+    from oracle import tjm_oracle as o  # checker only
+    from yaqs_amd._lib import check
+    from yaqs_amd.api import is_pauli
+    from yaqs_amd.engine import BatchEngine
+
+    L, chi = 6, 8
+    X, Zm = o.PAULI["x"], o.PAULI["z"]
+    low = np.array([[0, 1], [0, 0]], dtype=np.complex128)
+    procs = [o.make_process("lowering", [2], 0.3), o.make_process("pauli_z", [0], 0.2), o.make_process("pauli_x", [2], 0.1),
+             o.make_process("pair", [3, 4], 0.25, matrix=np.kron(low, low)), o.make_process("lr", [1, 5], 0.15, factors=(X, Zm)),
+             o.make_process("raising", [5], 0.05)]
+    rng = np.random.default_rng(4)
+    st = o.MPSState.haar(L, chi, rng)
+    st.normalize("B")
+    for t in st.tensors[:1]:
+        t *= 0.9  # an unnormalised centre, as after dissipation
+    e = BatchEngine(L, chi, 2, o.ising_mpo(L, 1.0, 0.5))
+    e.set_params(dt=0.1, svd_threshold=1e-12, max_bond_dim=chi)
+    e.set_noise(procs, [is_pauli(q) for q in procs])
+    e.load_state(st.tensors)
+    order = np.zeros(len(procs), dtype=np.int32)
+    w = np.zeros((2, len(procs)))
+    n = C.c_int32(0)
+    check(lib.tjm_engine_jump_weights(e.h, 0, 0.1, order.ctypes.data, w.ctypes.data, C.byref(n)), "jump_weights")
+    assert n.value == len(procs)
+    chosen, probs = o.jump_distribution(o.MPSState([x.copy() for x in st.tensors], 0), procs, 0.1, o.Params(dt=0.1, max_bond_dim=chi, svd_threshold=1e-12))
+    assert [procs[k]["name"] for k in order] == [c["name"] for c in chosen]
+    assert np.allclose(w[0] / w[0].sum(), probs, atol=1e-12) and np.allclose(w[1], w[0], atol=1e-14)
+    e.close()

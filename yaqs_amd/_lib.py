@@ -103,6 +103,12 @@ EXPORTS = {
     "tjm_engine_sample_shots": (C.c_int, [V, I, I, V, V, V]),
     "tjm_engine_stats": (C.c_int, [V, V]),
     "tjm_engine_stats_ex": (C.c_int, [V, V, I]),
+    "tjm_heff_apply": (C.c_int, [V, I, I, I, I, I, V, V, V, V, V, I]),
+    "tjm_env_update": (C.c_int, [V, I, I, I, I, I, V, V, V, V, I]),
+    "tjm_project_bond": (C.c_int, [V, I, I, I, V, V, V, V, I]),
+    "tjm_lanczos_expm": (C.c_int, [V, I, I, I, I, I, V, V, V, V, D, D, V, I, V]),
+    "tjm_engine_center_shift": (C.c_int, [V, I, I, I, I]),
+    "tjm_engine_jump_weights": (C.c_int, [V, I, D, V, V, V]),
     "tjm_engine_profile": (C.c_int, [V, I]),
     "tjm_engine_profile_read": (C.c_int, [V, V, V]),
     "tjm_engine_run": (C.c_int, [V, C.POINTER(RunConfig), V, V, V]),

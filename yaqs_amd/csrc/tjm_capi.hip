@@ -226,6 +226,54 @@ int tjm_engine_stats_ex(const tjm_engine* e, int64_t* o, int32_t n) {
   return TJM_OK;
 }
 
+int tjm_heff_apply(tjm_engine* e, int32_t nsites, int32_t ca, int32_t cb, int32_t Dl, int32_t Dr, const void* x, const void* Lenv, const void* Renv,
+                   const double* host_w, void* y, int32_t nb) {
+  if (!e || !x || !Lenv || !Renv || !host_w || !y) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.x_heff_apply(nsites, ca, cb, Dl, Dr, static_cast<const cplx*>(x), static_cast<const cplx*>(Lenv), static_cast<const cplx*>(Renv), host_w,
+                              static_cast<cplx*>(y), nb);
+}
+
+int tjm_env_update(tjm_engine* e, int32_t left, int32_t ca, int32_t cb, int32_t Dl, int32_t Dr, const void* A, const void* env, const double* host_w,
+                   void* out, int32_t nb) {
+  if (!e || !A || !env || !host_w || !out) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.x_env_update(left, ca, cb, Dl, Dr, static_cast<const cplx*>(A), static_cast<const cplx*>(env), host_w, static_cast<cplx*>(out), nb);
+}
+
+int tjm_project_bond(tjm_engine* e, int32_t cu, int32_t cv, int32_t D, const void* C, const void* Lenv, const void* Renv, void* y, int32_t nb) {
+  if (!e || !C || !Lenv || !Renv || !y) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.x_project_bond(cu, cv, D, static_cast<const cplx*>(C), static_cast<const cplx*>(Lenv), static_cast<const cplx*>(Renv),
+                                static_cast<cplx*>(y), nb);
+}
+
+int tjm_lanczos_expm(tjm_engine* e, int32_t nsites, int32_t ca, int32_t cb, int32_t Dl, int32_t Dr, const void* x, const void* Lenv, const void* Renv,
+                     const double* host_w, double dt, double tol, void* y, int32_t nb, int64_t* matvecs) {
+  if (!e || !x || !Lenv || !Renv || !host_w || !y) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  long mv = 0;
+  const int rc = e->impl.x_lanczos_expm(nsites, ca, cb, Dl, Dr, static_cast<const cplx*>(x), static_cast<const cplx*>(Lenv),
+                                        static_cast<const cplx*>(Renv), host_w, dt, tol, static_cast<cplx*>(y), nb, &mv);
+  if (matvecs) *matvecs = mv;
+  return rc;
+}
+
+int tjm_engine_center_shift(tjm_engine* e, int32_t set, int32_t site, int32_t direction, int32_t use_svd) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.x_center_shift(set, site, direction, use_svd);
+}
+
+int tjm_engine_jump_weights(tjm_engine* e, int32_t set, double dt, int32_t* order, double* weights, int32_t* n_out) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  int n = 0;
+  const int rc = e->impl.x_jump_weights(set, dt, order, weights, &n);
+  if (n_out) *n_out = n;
+  return rc;
+}
+
 int tjm_engine_profile(tjm_engine* e, int32_t enable) {
   if (!e) return TJM_ERR_ARG;
   TJM_ON_DEVICE(e);

@@ -113,6 +113,8 @@ class Engine {
   int x_center_shift(int set, int site, int direction, int use_svd);
   int x_jump_weights(int set, double dt_, int* host_order /*[nproc]*/, double* host_w /*[B][nproc]*/, int* n_out);
   int upload_w(const double* host_w, int P, int Dl, int Dr, cplx** mv, cplx** envl);
+  int jump_weights(int set, double dt_, const std::vector<double>& nsq, const std::vector<int>& which, std::vector<int>& order,
+                   std::vector<double>& w);
 
   StateSet sets[2];
   // work areas (public for tests)
@@ -145,6 +147,7 @@ class Engine {
   int run_sweep(int set, const std::vector<SmallSweepStep>& steps, const int* ids, int nb0);
   int qr_walk(int set, int from, int to);
   cplx* ops_ = nullptr;          // operator table (device)
+  cplx* Wx_[2] = {nullptr, nullptr};  // MPO matrices of the kernel-level exports
   cplx* E_ = nullptr;            // [B][chi][chi] moment environment (x2 ping-pong)
   cplx* E2_ = nullptr;
   cplx* M_ = nullptr;            // [L][B][d][d]

@@ -144,6 +144,7 @@ size_t Engine::workspace_bytes() const {
   // MPO matrices + operator table
   tot += (size_t)(3 * L) * align_up((size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx));
   tot += align_up((size_t)(L + 64) * 16 * sizeof(cplx));
+  tot += 2 * align_up((size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx));  // MPO matrices of the kernel-level exports
   tot += align_up((size_t)2 * L * sizeof(SmallSiteRef)) + align_up((size_t)(4 * L + 8) * sizeof(SmallSweepStep));  // fused sweeps
   tot += 1 << 16;
   return tot;
@@ -216,6 +217,8 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
     W2_[i] = reinterpret_cast<cplx*>(take(wsz));
   }
   ops_ = reinterpret_cast<cplx*>(take((size_t)(L + 64) * 16 * sizeof(cplx)));
+  Wx_[0] = reinterpret_cast<cplx*>(take(wsz));
+  Wx_[1] = reinterpret_cast<cplx*>(take(wsz));
   if ((size_t)(p - static_cast<char*>(ws)) > bytes) return TJM_ERR_WORKSPACE;
   if (!h_pinned_) TJM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 256, hipHostMallocDefault));
   svdw.h_pinned = h_pinned_;
@@ -1599,6 +1602,71 @@ __global__ __launch_bounds__(256) void apply_local_multi_kernel(cplx* const* sit
   }
 }
 
+// Jump weights dt * gamma_m * ||L_m psi||^2 of create_probability_distribution (stochastic_process.py:139-176) for the listed
+// trajectories, in the reference's order: site sweep, one-site processes before the two-site ones starting at that site.
+// nsq[B] = squared norms (||A_0||^2, centre 0).  w is [which.size()][order.size()].
+int Engine::jump_weights(int set, double dt_, const std::vector<double>& nsq, const std::vector<int>& which, std::vector<int>& order,
+                         std::vector<double>& w) {
+  int rc;
+  order.clear();
+  for (int site = 0; site < L; ++site) {
+    for (size_t k = 0; k < noise_.size(); ++k)
+      if (proc_on_[k] && noise_[k].nsites == 1 && noise_[k].site0 == site) order.push_back((int)k);
+    if (site < L - 1)
+      for (size_t k = 0; k < noise_.size(); ++k)
+        if (proc_on_[k] && noise_[k].nsites == 2 && noise_[k].site0 == site) order.push_back((int)k);
+  }
+  bool need_moments = false, need_moments2 = false;
+  for (int k : order) {
+    const NoiseProc& p = noise_[k];
+    if (p.nsites == 1 && !p.pauli) need_moments = true;
+    if (p.nsites == 2 && !p.pauli) {
+      if (p.site1 != p.site0 + 1) return TJM_ERR_NOT_IMPLEMENTED;  // stochastic_process.py:171-176
+      need_moments2 = true;
+    }
+  }
+  std::vector<cplx> Mh, Mh2;
+  if (need_moments || need_moments2) {
+    Mh.resize((size_t)L * B * d * d);
+    if (need_moments2) Mh2.resize((size_t)(L - 1) * B * d * d * d * d);
+    if ((rc = site_moments(set, reinterpret_cast<double*>(Mh.data()), need_moments2 ? reinterpret_cast<double*>(Mh2.data()) : nullptr)) != TJM_OK)
+      return rc;
+  }
+  w.assign(which.size() * order.size(), 0.0);
+  for (size_t jb = 0; jb < which.size(); ++jb) {
+    const int b = which[jb];
+    for (size_t c = 0; c < order.size(); ++c) {
+      const NoiseProc& p = noise_[order[c]];
+      double nrm;
+      if (p.pauli) {
+        nrm = nsq[b];  // unitary jump operator: ||L psi||^2 = ||psi||^2
+      } else if (p.nsites == 2) {
+        // adjacent non-Pauli: Frobenius weight of the untruncated L theta (stochastic_process.py:53-83)
+        const cplx* M2 = &Mh2[((size_t)p.site0 * B + b) * 16];
+        double acc = 0.0;
+        for (int a = 0; a < 4; ++a) for (int c2 = 0; c2 < 4; ++c2) {
+          cplx ll{0.0, 0.0};
+          for (int r = 0; r < 4; ++r) cfma(ll, cconj(p.mat[r * 4 + a]), p.mat[r * 4 + c2]);
+          acc += ll.x * M2[a * 4 + c2].x - ll.y * M2[a * 4 + c2].y;
+        }
+        nrm = acc;
+      } else {
+        // ||L psi||^2 = sum_{p,q} (L^dag L)[p][q] M[p][q]
+        const cplx* M = &Mh[((size_t)p.site0 * B + b) * d * d];
+        double acc = 0.0;
+        for (int a = 0; a < d; ++a) for (int c2 = 0; c2 < d; ++c2) {
+          cplx ll{0.0, 0.0};
+          for (int r = 0; r < d; ++r) cfma(ll, cconj(p.mat[r * d + a]), p.mat[r * d + c2]);
+          acc += ll.x * M[a * d + c2].x - ll.y * M[a * d + c2].y;
+        }
+        nrm = acc;
+      }
+      w[jb * order.size() + c] = dt_ * p.gamma * nrm;
+    }
+  }
+  return TJM_OK;
+}
+
 int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
   if (!bound_) return TJM_ERR_STATE;
   StateSet& S = sets[set];
@@ -1634,31 +1702,9 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
   if (jumped.empty()) return TJM_OK;
 
   // ---- channel weights in site-sweep order (stochastic_process.py:139-176)
-  struct Cand { int proc; };
   std::vector<int> order;
-  for (int site = 0; site < L; ++site) {
-    for (size_t k = 0; k < noise_.size(); ++k)
-      if (proc_on_[k] && noise_[k].nsites == 1 && noise_[k].site0 == site) order.push_back((int)k);
-    if (site < L - 1)
-      for (size_t k = 0; k < noise_.size(); ++k)
-        if (proc_on_[k] && noise_[k].nsites == 2 && noise_[k].site0 == site) order.push_back((int)k);
-  }
-  bool need_moments = false, need_moments2 = false;
-  for (int k : order) {
-    const NoiseProc& p = noise_[k];
-    if (p.nsites == 1 && !p.pauli) need_moments = true;
-    if (p.nsites == 2 && !p.pauli) {
-      if (p.site1 != p.site0 + 1) return TJM_ERR_NOT_IMPLEMENTED;  // stochastic_process.py:171-176
-      need_moments2 = true;
-    }
-  }
-  std::vector<cplx> Mh, Mh2;
-  if (need_moments || need_moments2) {
-    Mh.resize((size_t)L * B * d * d);
-    if (need_moments2) Mh2.resize((size_t)(L - 1) * B * d * d * d * d);
-    if ((rc = site_moments(set, reinterpret_cast<double*>(Mh.data()), need_moments2 ? reinterpret_cast<double*>(Mh2.data()) : nullptr)) != TJM_OK)
-      return rc;
-  }
+  std::vector<double> wall;
+  if ((rc = jump_weights(set, dt_, nsq, jumped, order, wall)) != TJM_OK) return rc;
   // operator table: per process one (or two, for long-range factors) d x d matrices
   std::vector<cplx> optab;
   std::vector<int> op_first(noise_.size());
@@ -1689,37 +1735,10 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
   unitary_jump_.assign(B, 0);
   bool any_second = false;
   std::vector<double> w(order.size());
-  for (int b : jumped) {
+  for (size_t jb = 0; jb < jumped.size(); ++jb) {
+    const int b = jumped[jb];
     double tot = 0.0;
-    for (size_t c = 0; c < order.size(); ++c) {
-      const NoiseProc& p = noise_[order[c]];
-      double nrm;
-      if (p.pauli) {
-        nrm = nsq[b];  // unitary jump operator: ||L psi||^2 = ||psi||^2
-      } else if (p.nsites == 2) {
-        // adjacent non-Pauli: Frobenius weight of the untruncated L theta (stochastic_process.py:53-83)
-        const cplx* M2 = &Mh2[((size_t)p.site0 * B + b) * 16];
-        double acc = 0.0;
-        for (int a = 0; a < 4; ++a) for (int c2 = 0; c2 < 4; ++c2) {
-          cplx ll{0.0, 0.0};
-          for (int r = 0; r < 4; ++r) cfma(ll, cconj(p.mat[r * 4 + a]), p.mat[r * 4 + c2]);
-          acc += ll.x * M2[a * 4 + c2].x - ll.y * M2[a * 4 + c2].y;
-        }
-        nrm = acc;
-      } else {
-        // ||L psi||^2 = sum_{p,q} (L^dag L)[p][q] M[p][q]
-        const cplx* M = &Mh[((size_t)p.site0 * B + b) * d * d];
-        double acc = 0.0;
-        for (int a = 0; a < d; ++a) for (int c2 = 0; c2 < d; ++c2) {
-          cplx ll{0.0, 0.0};
-          for (int r = 0; r < d; ++r) cfma(ll, cconj(p.mat[r * d + a]), p.mat[r * d + c2]);
-          acc += ll.x * M[a * d + c2].x - ll.y * M[a * d + c2].y;
-        }
-        nrm = acc;
-      }
-      w[c] = dt_ * p.gamma * nrm;
-      tot += w[c];
-    }
+    for (size_t c = 0; c < order.size(); ++c) { w[c] = wall[jb * order.size() + c]; tot += w[c]; }
     if (!(tot > 0.0) || !std::isfinite(tot)) return TJM_ERR_NUMERIC;  // stochastic_process.py:178-186
     // rng.choice(n, p): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, side="right")
     std::vector<double> cdf(order.size());
@@ -1842,6 +1861,132 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
   hipLaunchKernelGGL(rsqrt_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, normsq_, scal_, B);
   if ((rc = launch_scale(S.A[0], a_b0_[0], a_b0_[0], scal_, nj, ids_, nullptr, stream)) != TJM_OK) return rc;
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel-level parity exports: the single contractions of the sweep on explicit device tensors.
+// All operands hold nb == B slots, contiguous per slot; W is a host MPO tensor in the reference's (o, p, l, r) order.
+// ------------------------------------------------------------------------------------------
+int Engine::upload_w(const double* host_w, int P, int Dl, int Dr, cplx** mv, cplx** envl) {
+  if (!bound_ || !host_w || P < 1 || P > d * d || Dl < 1 || Dr < 1 || Dl > Dmax || Dr > Dmax) return TJM_ERR_ARG;
+  const cplx* w = reinterpret_cast<const cplx*>(host_w);
+  std::vector<cplx> a((size_t)P * Dl * P * Dr), b((size_t)P * Dr * P * Dl);
+  for (int o = 0; o < P; ++o) for (int p = 0; p < P; ++p) for (int l = 0; l < Dl; ++l) for (int r = 0; r < Dr; ++r) {
+    const cplx v = w[(((size_t)o * P + p) * Dl + l) * Dr + r];
+    a[(size_t)(o * Dl + l) * (P * Dr) + (p * Dr + r)] = v;
+    b[(size_t)(p * Dr + r) * (P * Dl) + (o * Dl + l)] = v;
+  }
+  TJM_HIP_CHECK(hipMemcpyAsync(Wx_[0], a.data(), a.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(Wx_[1], b.data(), b.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  *mv = Wx_[0];
+  *envl = Wx_[1];
+  return TJM_OK;
+}
+
+// project_site (primitives.py:180-204): y = L (W (x R)); x, y [B][P][ca][cb], L [B][ca][Dl][ca], R [B][cb][Dr][cb]
+int Engine::x_heff_apply(int nsites, int ca, int cb, int Dl, int Dr, const cplx* x, const cplx* Lenv, const cplx* Renv, const double* host_w, cplx* y,
+                         int nb) {
+  const int cm = *std::max_element(cap.begin(), cap.end());
+  if (nb != B || (nsites != 1 && nsites != 2) || ca < 1 || cb < 1 || ca > cm || cb > cm) return TJM_ERR_ARG;
+  const int P = nsites == 1 ? d : d * d;
+  cplx *mv, *el;
+  int rc;
+  if ((rc = upload_w(host_w, P, Dl, Dr, &mv, &el)) != TJM_OK) return rc;
+  const long xb = (long)P * ca * cb;
+  if ((rc = heff_apply(x, xb, P, ca, cb, Lenv, (long)ca * Dl * ca, Dl, Renv, (long)cb * Dr * cb, Dr, mv, y, xb, nb, nullptr, nullptr)) != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+// update_left_environment / update_right_environment (primitives.py:77-136) with bra = ket = A [B][d][ca][cb]
+int Engine::x_env_update(int left, int ca, int cb, int Dl, int Dr, const cplx* A, const cplx* env, const double* host_w, cplx* out, int nb) {
+  const int cm = *std::max_element(cap.begin(), cap.end());
+  if (nb != B || ca < 1 || cb < 1 || ca > cm || cb > cm) return TJM_ERR_ARG;
+  cplx *mv, *el;
+  int rc;
+  if ((rc = upload_w(host_w, d, Dl, Dr, &mv, &el)) != TJM_OK) return rc;
+  const long ab = (long)d * ca * cb;
+  if (left) rc = env_left_at(A, ab, ca, cb, Dl, Dr, env, (long)ca * Dl * ca, el, out, (long)cb * Dr * cb, nb);
+  else rc = env_right_at(A, ab, ca, cb, Dl, Dr, env, (long)cb * Dr * cb, mv, out, (long)ca * Dl * ca, nb);
+  if (rc != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+// project_bond (primitives.py:207-226): y[p][w] = sum L[u][a][p] C[u][v] R[v][a][w]; C, y [B][cu][cv], L [B][cu][D][cu], R [B][cv][D][cv]
+int Engine::x_project_bond(int cu, int cv, int D, const cplx* C, const cplx* Lenv, const cplx* Renv, cplx* y, int nb) {
+  const int cm = *std::max_element(cap.begin(), cap.end());
+  if (nb != B || cu < 1 || cv < 1 || cu > cm || cv > cm || D < 1 || D > Dmax) return TJM_ERR_ARG;
+  int rc;
+  const size_t row = (size_t)cu * cv * sizeof(cplx);
+  TJM_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)v_b0 * sizeof(cplx), C, row, row, B, hipMemcpyDeviceToDevice, stream));
+  if ((rc = bond_apply(V, cu, cv, Lenv, (long)cu * D * cu, Renv, (long)cv * D * cv, D, V + v_ld, nullptr)) != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipMemcpy2DAsync(y, row, V + v_ld, (size_t)v_b0 * sizeof(cplx), row, B, hipMemcpyDeviceToDevice, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+// update_site = expm_krylov(project_site) (primitives.py:484-520, matrix_exponential.py:33-173): y = exp(-i dt H_eff) x
+int Engine::x_lanczos_expm(int nsites, int ca, int cb, int Dl, int Dr, const cplx* x, const cplx* Lenv, const cplx* Renv, const double* host_w,
+                           double dt_, double tol, cplx* y, int nb, long* matvecs) {
+  const int cm = *std::max_element(cap.begin(), cap.end());
+  if (nb != B || (nsites != 1 && nsites != 2) || ca < 1 || cb < 1 || ca > cm || cb > cm) return TJM_ERR_ARG;
+  const int P = nsites == 1 ? d : d * d;
+  cplx *mv, *el;
+  int rc;
+  if ((rc = upload_w(host_w, P, Dl, Dr, &mv, &el)) != TJM_OK) return rc;
+  const long n = (long)P * ca * cb;
+  TJM_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)v_b0 * sizeof(cplx), x, (size_t)n * sizeof(cplx), (size_t)n * sizeof(cplx), B, hipMemcpyDeviceToDevice, stream));
+  std::vector<int> nl(B, (int)n);
+  TJM_HIP_CHECK(hipMemcpyAsync(nloc_, nl.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  const double keep_tol = krylov_tol;
+  const long mv0 = stat_matvecs;
+  krylov_tol = tol;
+  rc = krylov_site(nullptr, P, ca, cb, Lenv, (long)ca * Dl * ca, Dl, Renv, (long)cb * Dr * cb, Dr, mv, dt_, nloc_, y, n, 1, P, ca, cb, 0,
+                   (long)ca * cb, cb, B, nullptr, nullptr, nullptr);
+  krylov_tol = keep_tol;
+  if (matvecs) *matvecs = stat_matvecs - mv0;
+  if (rc != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+// One orthogonality-centre shift of the loaded state (mps.py:719-788): direction +1 moves the centre site -> site + 1,
+// -1 moves it site -> site - 1; use_svd selects the truncating SVD shift (discarded weight 1e-12, no cap) instead of QR.
+int Engine::x_center_shift(int set, int site, int direction, int use_svd) {
+  if (!bound_ || set < 0 || set > 1 || site < 0 || site >= L) return TJM_ERR_ARG;
+  if ((direction == 1 && site + 1 >= L) || (direction == -1 && site < 1) || (direction != 1 && direction != -1)) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  int rc;
+  if (direction == 1) rc = use_svd ? svd_shift_right(S, site, nullptr, B) : qr_shift_right(S, site);
+  else rc = use_svd ? svd_shift_left(S, site, nullptr, B) : qr_shift_left(S, site);
+  if (rc != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+// create_probability_distribution (stochastic_process.py:139-187) for every resident trajectory of a state with centre 0:
+// host_order[k] = index of the k-th process in the reference's order, host_w[b][k] = its unnormalised weight dt * gamma * ||L psi||^2
+int Engine::x_jump_weights(int set, double dt_, int* host_order, double* host_w, int* n_out) {
+  if (!bound_ || set < 0 || set > 1 || !host_order || !host_w || !n_out) return TJM_ERR_ARG;
+  std::vector<double> nsq(B);
+  int rc;
+  if ((rc = site_normsq0(set, nsq.data())) != TJM_OK) return rc;
+  std::vector<int> all(B), order;
+  for (int b = 0; b < B; ++b) all[b] = b;
+  std::vector<double> w;
+  if ((rc = jump_weights(set, dt_, nsq, all, order, w)) != TJM_OK) return rc;
+  *n_out = (int)order.size();
+  for (size_t k = 0; k < order.size(); ++k) host_order[k] = order[k];
+  for (size_t k = 0; k < w.size(); ++k) host_w[k] = w[k];
+  for (int b = 0; b < B; ++b) {
+    double tot = 0.0;
+    for (size_t k = 0; k < order.size(); ++k) tot += w[(size_t)b * order.size() + k];
+    if (!order.empty() && (!(tot > 0.0) || !std::isfinite(tot))) return TJM_ERR_NUMERIC;  // stochastic_process.py:178-186
+  }
   return TJM_OK;
 }
 
