@@ -626,3 +626,36 @@ def test_jump_weights_match_the_oracle_distribution(lib):
     assert [procs[k]["name"] for k in order] == [c["name"] for c in chosen]
     assert np.allclose(w[0] / w[0].sum(), probs, atol=1e-12) and np.allclose(w[1], w[0], atol=1e-14)
     e.close()
+
+
+# ---- bonds up to 512 (BASELINE config 5's max_bond_dim): matrices of up to 1024 x 1024 --------------------------------------
+@pytest.mark.parametrize("capL,capR,dist", [(512, 512, 0), (512, 512, 1), (256, 512, 0), (512, 256, 1)])
+def test_svd_split_up_to_1024_matches_oracle(lib, capL, capR, dist):
+    """split_two_site (decompositions.py:105-185) of a (2 capL) x (2 capR) theta with a spectrum graded over ten decades against the
+    oracle: keep, singular values, the reconstructed truncated theta, exact isometry - square 1024 x 1024 and the rectangular
+    512 x 1024 / 1024 x 512 shapes of the chain positions where the outer bonds differ (embedded in the square factorisation)."""
+    from oracle import tjm_oracle as o
+
+    rng = np.random.default_rng(capL + 2 * capR + dist)
+    d, B = 2, 1
+    m, n = d * capL, d * capR
+    k0 = min(m, n)
+    u = np.linalg.qr(crand(rng, m, k0))[0]
+    v = np.linalg.qr(crand(rng, n, k0))[0]
+    sv = 10.0 ** (-10.0 * np.arange(k0) / k0) * (1.0 + 0.1 * rng.random(k0))
+    theta = ((u * sv) @ v.conj().T)[None]
+    capM = 512
+    chiL, chiR = np.full(B, capL, dtype=np.int32), np.full(B, capR, dtype=np.int32)
+    thr, maxb = 1e-14, 400
+    left, right, keep, spec, sweeps = svd_split_gpu(lib, theta, d, capL, capR, capM, dist, 0, thr, maxb, 2, chiL, chiR, qr=True)
+    merged = theta[0].reshape(d, capL, d, capR).transpose(0, 2, 1, 3).reshape(d * d, capL, capR)
+    l_ref, r_ref, s_ref = o.split_two_site(merged, [d, d], svd_distribution="right" if dist == 0 else "left", trunc_mode="discarded_weight",
+                                            threshold=thr, max_bond_dim=maxb, min_keep=2, return_spectrum=True)
+    k = l_ref.shape[2]
+    assert keep[0] == k, (keep[0], k)
+    assert np.allclose(spec[0, :k], s_ref[:k], rtol=1e-10, atol=1e-14)
+    got = o.merge_two_site(left[0][:, :, :k], right[0][:, :k, :])
+    assert np.allclose(got, o.merge_two_site(l_ref, r_ref), atol=1e-11)
+    assert np.all(left[0][:, :, k:] == 0) and np.all(right[0][:, k:, :] == 0)
+    iso = left[0][:, :, :k].reshape(m, k) if dist == 0 else right[0][:, :k, :].transpose(1, 0, 2).reshape(k, n).conj().T
+    assert np.allclose(iso.conj().T @ iso, np.eye(k), atol=1e-12)

@@ -670,7 +670,9 @@ int Engine::split(StateSet& S, int i, int dist, int mode, double thr, int maxb, 
   int sweeps = 0;
   Region prof(*this, PROF_SVD);
   static const bool no_qr = getenv("TJM_NO_QR") != nullptr;
-  const bool use_qr = !no_qr && ids == nullptr && std::min(s.m, s.n) >= 64;
+  static const bool force_large = getenv("TJM_FORCE_LARGE_SPLIT") != nullptr;
+  const bool large = std::max(s.m, s.n) > 512 || (force_large && std::min(s.m, s.n) >= 32);  // bonds beyond 256: only the QR-preconditioned X-only variant holds the columns
+  const bool use_qr = large || (!no_qr && ids == nullptr && std::min(s.m, s.n) >= 64);
   const int rc = use_qr ? svd_split_qr(s, svdw, qrw, stream, &sweeps) : svd_split(s, svdw, stream, &sweeps);
   ++stat_svds;
   stat_svd_mats += nb0;
@@ -1443,7 +1445,7 @@ int Engine::bond_spectrum(int set, int i, double* host_spec, int n_out) {
   sd.chiL = dchi + i; sd.chiR = dchi + i + 2; sd.chiM = dchi + i + 1; sd.chi_stride = L + 1;
   sd.spectrum = dspec; sd.spec_ld = nsv; sd.nb0 = B; sd.ids = nullptr;
   int sweeps = 0;
-  if ((rc = svd_split(sd, svdw, stream, &sweeps)) != TJM_OK) return rc;
+  if ((rc = (std::max(m, n) > 512 ? svd_split_qr(sd, svdw, qrw, stream, &sweeps) : svd_split(sd, svdw, stream, &sweeps))) != TJM_OK) return rc;
   std::vector<double> h((size_t)B * nsv);
   TJM_HIP_CHECK(hipMemcpyAsync(h.data(), dspec, h.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));

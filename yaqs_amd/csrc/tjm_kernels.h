@@ -234,12 +234,15 @@ size_t qr_carve(QrWorkspace& q, char* base, int max_dim, int B);  // lays the bu
 // helpers of the accumulation-free split (tjm_svd.hip: svd_split_qr2)
 int qr_gather_scaled(const cplx* G, long g_b0, int rows, int ncols, int d, const double* sigma, int sig_ld, const int* keep, int keep_stride,
                      cplx* Z, long z_b0, int nb0, hipStream_t s);  // Z[k][bond*d+p] = G[(p,bond)][k] / sigma_k (0 beyond keep)
-int qr_identity(cplx* C, long c_b0, int rows, int ncols, int nb0, hipStream_t s);
+int qr_identity(cplx* C, long c_b0, int rows, int ncols, int nb0, hipStream_t s, const int* ids = nullptr, const int* keep = nullptr,
+                int keep_stride = 0);
 int qr_r_times_sigma(const cplx* Z, long z_b0, int zr, int ncols, const double* sigma, int sig_ld, const int* keep, int keep_stride, cplx* Rs,
                      long rs_b0, int nb0, hipStream_t s);  // Rs[k][j] = R[k][j] sigma_j for k <= j < keep, else 0 (row-major ncols x ncols)
 int qr_adjoint_triangle(const QrWorkspace& q, int n, int nb0, const int* ids, hipStream_t s);  // Z2 = R^H of the factored Z
 size_t qr_workspace_bytes(int max_dim, int B);
-int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s);
+// square > 0: embed the rectangular matrix in a square one of that size (zero rows / columns behind the data)
+int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s,
+               int square = 0);
 int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hipStream_t s);
 int qr_apply_q(const QrWorkspace& q, int zr, int zc, cplx* C, long c_b0, int nc, int nb0, const int* ids, hipStream_t s);
 int qr_scatter(const cplx* in, long in_b0, int ld, const ExtractDesc& x, const int* chi_keep, int chi_stride, int nb0, const int* ids,

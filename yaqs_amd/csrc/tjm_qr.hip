@@ -202,16 +202,19 @@ __global__ __launch_bounds__(64) void qr_panel_kernel(cplx* __restrict__ A, long
 // The 31 partial sums are transposed through LDS ([value][thread]), 8 threads add 32 entries each per value, a DPP
 // butterfly joins them.  Row j of the panel (alpha, a_c[j], v_l[j]) is broadcast through LDS by its owner.
 constexpr int NRED = 2 * PW;          // slot 0: xn2, slots 1..15: Re, 17..31: Im of the 15 complex sums (slot 16 unused)
-constexpr int RED_PITCH = 256 + 1;
 
-template <int RPT>
-__global__ __launch_bounds__(256) void qr_panel_rows_kernel(cplx* __restrict__ A, long a_b0, int zr, int k0, int pw, cplx* __restrict__ Vb,
+// NT = 256 threads for panels of up to 512 rows; NT = 512 (RPT = 2) for up to 1024 rows (bonds up to 512): the 32 sums are then
+// joined by 16 threads each
+template <int RPT, int NT = 256>
+__global__ __launch_bounds__(NT) void qr_panel_rows_kernel(cplx* __restrict__ A, long a_b0, int zr, int k0, int pw, cplx* __restrict__ Vb,
                                                            long v_b0, cplx* __restrict__ Tb, long t_b0, int panel, const int* ids) {
   extern __shared__ double smem[];
   int b = blockIdx.x;
   if (ids) b = ids[b];
   const int tid = threadIdx.x;
   const int mp = zr - k0;
+  constexpr int RED_PITCH = NT + 1;
+  constexpr int SEGS = NT / 32;                                   // threads that join one of the 32 sums
   double* sPart = smem;                                           // [NRED][RED_PITCH]
   double* sRed = sPart + NRED * RED_PITCH;                        // [2][NRED]
   cplx* sRow = reinterpret_cast<cplx*>(sRed + 2 * NRED);          // [2][PW]
@@ -226,10 +229,10 @@ __global__ __launch_bounds__(256) void qr_panel_rows_kernel(cplx* __restrict__ A
   for (int c = 0; c < PW; ++c)
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-      const int r = tid + 256 * q;
+      const int r = tid + NT * q;
       P[c][q] = (c < pw && r < mp) ? Ab[(long)(k0 + c) * zr + k0 + r] : cplx{0.0, 0.0};
     }
-  for (int t = tid; t < PW * PW; t += 256) { sG[t] = cplx{0.0, 0.0}; sT[t] = cplx{0.0, 0.0}; }
+  for (int t = tid; t < PW * PW; t += NT) { sG[t] = cplx{0.0, 0.0}; sT[t] = cplx{0.0, 0.0}; }
   if (tid < PW) { sTau[tid] = cplx{0.0, 0.0}; sBeta[tid] = 0.0; }
 
 #pragma unroll
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void qr_panel_rows_kernel(cplx* __restrict__ A
       for (int v = 0; v < NRED; ++v) part[v] = 0.0;
 #pragma unroll
       for (int q = 0; q < RPT; ++q) {
-        const int r = tid + 256 * q;
+        const int r = tid + NT * q;
         if (r > j && r < mp) {
           const cplx aj = P[j][q];
           part[0] = fma(aj.x, aj.x, fma(aj.y, aj.y, part[0]));
@@ -263,13 +266,13 @@ __global__ __launch_bounds__(256) void qr_panel_rows_kernel(cplx* __restrict__ A
       }
 #pragma unroll
       for (int v = 0; v < NRED; ++v) sPart[v * RED_PITCH + tid] = part[v];
-      if (tid == (j & 255)) {
+      if (tid == j) {  // row j < 16 of the panel lives in thread j, slot 0
 #pragma unroll
-        for (int c = 0; c < PW; ++c) sRow[buf * PW + c] = P[c][(RPT > 1) ? (j >> 8) : 0];
+        for (int c = 0; c < PW; ++c) sRow[buf * PW + c] = P[c][0];
       }
       __syncthreads();
       {
-        const int v = tid >> 3, seg = tid & 7;
+        const int v = tid / SEGS, seg = tid % SEGS;
         const double* src = sPart + v * RED_PITCH + seg * 32;
         double acc = 0.0;
 #pragma unroll
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(256) void qr_panel_rows_kernel(cplx* __restrict__ A
         acc += dpp_pull<0xB1>(acc);
         acc += dpp_pull<0x4E>(acc);
         acc += dpp_pull<0x141>(acc);
+        if (SEGS == 16) acc += dpp_pull<0x140>(acc);  // row_mirror joins the two halves of a 16-lane row
         if (seg == 0) sRed[buf * NRED + v] = acc;
       }
       __syncthreads();
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void qr_panel_rows_kernel(cplx* __restrict__ A
       }
 #pragma unroll
       for (int q = 0; q < RPT; ++q) {
-        const int r = tid + 256 * q;
+        const int r = tid + NT * q;
         if (r >= j && r < mp) {
           const cplx vv = (r == j) ? cplx{1.0, 0.0} : cmul(P[j][q], scale);
           P[j][q] = vv;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(256) void qr_panel_rows_kernel(cplx* __restrict__ A
   for (int c = 0; c < PW; ++c) {
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-      const int r = tid + 256 * q;
+      const int r = tid + NT * q;
       if (r < mp) {
         cplx v{0.0, 0.0};
         if (c < pw) {
@@ -364,10 +368,10 @@ __global__ __launch_bounds__(256) void qr_panel_rows_kernel(cplx* __restrict__ A
         Vp[(long)c * zr + k0 + r] = v;
       }
     }
-    for (int gr = tid; gr < k0; gr += 256) Vp[(long)c * zr + gr] = cplx{0.0, 0.0};
+    for (int gr = tid; gr < k0; gr += NT) Vp[(long)c * zr + gr] = cplx{0.0, 0.0};
   }
   cplx* Tp = Tb + (long)b * t_b0 + (long)panel * PW * PW;
-  for (int t = tid; t < PW * PW; t += 256) Tp[t] = sT[t];
+  for (int t = tid; t < PW * PW; t += NT) Tp[t] = sT[t];
 }
 
 // Fused block reflector on a chunk of 16 columns of C (column-major, leading dimension zr), fp64 MFMA:
@@ -484,8 +488,8 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
 // Order of the columns of Z by decreasing norm: cperm[j] = source column that becomes column j.  One workgroup per
 // trajectory; the rank of a column is the number of columns that precede it (ties broken by index: deterministic).
 __global__ __launch_bounds__(256) void qr_colsort_kernel(const cplx* __restrict__ theta, long th_b0, int m, int n, int dist, int* __restrict__ cperm,
-                                                        int ld, const int* ids) {
-  __shared__ double sn[512];
+                                                        int ld, const int* ids, int zc_pad) {
+  __shared__ double sn[1024];
   int b = blockIdx.x;
   if (ids) b = ids[b];
   const cplx* th = theta + (long)b * th_b0;
@@ -522,29 +526,35 @@ __global__ __launch_bounds__(256) void qr_colsort_kernel(const cplx* __restrict_
     }
     cperm[(long)b * ld + rank] = c;
   }
+  for (int c = zc + tid; c < zc_pad; c += 256) cperm[(long)b * ld + c] = c;  // zero columns of the square embedding
 }
 
 __global__ __launch_bounds__(256) void qr_prepare_kernel(const cplx* __restrict__ theta, long th_b0, int m, int n, int dist, int d, cplx* __restrict__ Z,
-                                                        long z_b0, const int* __restrict__ cperm, int perm_ld, const int* ids) {
+                                                        long z_b0, const int* __restrict__ cperm, int perm_ld, const int* ids, int zr_pad, int zc_pad) {
   int b = blockIdx.y;
   if (ids) b = ids[b];
   const cplx* th = theta + (long)b * th_b0;
   cplx* Zb = Z + (long)b * z_b0;
   const int* cp = cperm + (long)b * perm_ld;
-  const long total = (long)m * n;
+  // Z is zr_pad x zc_pad (column-major); the block of rows < zr and columns < zc holds theta (dist 0) or theta^H (dist 1), the
+  // rest is zero: a rectangular theta embedded in a square matrix keeps its singular values and vectors (zero rows stay a suffix)
+  const int zr = (dist == 0) ? m : n, zc = (dist == 0) ? n : m;
+  const long total = (long)zr_pad * zc_pad;
   const int capL = m / d, capR = n / d;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    if (dist == 0) {
-      const long c = e / m, rp = e % m;            // Z(rp, c), rp = a * d + s
-      const int a = (int)(rp / d), sph = (int)(rp % d);
-      Zb[e] = th[((long)sph * capL + a) * n + cp[c]];
-    } else {
-      const long i = e / n, rp = e % n;            // Z(rp, i) = conj(theta[i][(t,c)]), rp = c * d + t
-      const int cc = (int)(rp / d), t = (int)(rp % d);
-      cplx v = th[(long)cp[i] * n + (long)t * capR + cc];
-      v.y = -v.y;
-      Zb[e] = v;
+    const long c = e / zr_pad, rp = e % zr_pad;
+    cplx v{0.0, 0.0};
+    if (rp < zr && c < zc) {
+      if (dist == 0) {                               // Z(rp, c), rp = a * d + s
+        const int a = (int)(rp / d), sph = (int)(rp % d);
+        v = th[((long)sph * capL + a) * n + cp[c]];
+      } else {                                       // Z(rp, i) = conj(theta[i][(t,c)]), rp = c * d + t
+        const int cc = (int)(rp / d), t = (int)(rp % d);
+        v = th[(long)cp[c] * n + (long)t * capR + cc];
+        v.y = -v.y;
+      }
     }
+    Zb[e] = v;
   }
 }
 
@@ -635,11 +645,14 @@ __global__ __launch_bounds__(256) void qr_gather_scaled_kernel(const cplx* __res
   }
 }
 
-__global__ __launch_bounds__(256) void qr_identity_kernel(cplx* __restrict__ C, long c_b0, int rows, int ncols) {
-  cplx* Cb = C + (long)blockIdx.y * c_b0;
+__global__ __launch_bounds__(256) void qr_identity_kernel(cplx* __restrict__ C, long c_b0, int rows, int ncols, const int* ids, const int* keep,
+                                                         int keep_stride) {
+  const int b = ids ? ids[blockIdx.y] : blockIdx.y;
+  cplx* Cb = C + (long)b * c_b0;
   const long total = (long)rows * ncols;
+  const int kp = keep ? keep[(long)b * keep_stride] : ncols;  // columns beyond the kept ones stay zero
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
-    Cb[e] = cplx{(e / rows == e % rows) ? 1.0 : 0.0, 0.0};
+    Cb[e] = cplx{(e / rows == e % rows && e / rows < kp) ? 1.0 : 0.0, 0.0};
 }
 
 __global__ __launch_bounds__(256) void qr_r_times_sigma_kernel(const cplx* __restrict__ Z, long z_b0, int zr, int ncols, const double* __restrict__ sigma,
@@ -674,11 +687,11 @@ int qr_gather_scaled(const cplx* G, long g_b0, int rows, int ncols, int d, const
   return TJM_OK;
 }
 
-int qr_identity(cplx* C, long c_b0, int rows, int ncols, int nb0, hipStream_t s) {
+int qr_identity(cplx* C, long c_b0, int rows, int ncols, int nb0, hipStream_t s, const int* ids, const int* keep, int keep_stride) {
   const long total = (long)rows * ncols;
   int gx = (int)((total + 1023) / 1024);
   if (gx > 128) gx = 128;
-  hipLaunchKernelGGL(qr_identity_kernel, dim3(gx, nb0), dim3(256), 0, s, C, c_b0, rows, ncols);
+  hipLaunchKernelGGL(qr_identity_kernel, dim3(gx, nb0), dim3(256), 0, s, C, c_b0, rows, ncols, ids, keep, keep_stride);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
@@ -726,13 +739,17 @@ size_t qr_workspace_bytes(int max_dim, int B) {
   return qr_carve(q, nullptr, max_dim, B) + 4096;
 }
 
-int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s) {
-  const long total = (long)m * n;
+int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, const QrWorkspace& q, int nb0, const int* ids, hipStream_t s, int square) {
+  const int zr = (dist == 0) ? m : n, zc = (dist == 0) ? n : m;
+  const int zr_pad = square > 0 ? square : zr, zc_pad = square > 0 ? square : zc;
+  if (zr_pad < zr || zc_pad < zc) return TJM_ERR_ARG;
+  const long total = (long)zr_pad * zc_pad;
   int gx = (int)((total + 1023) / 1024);
   if (gx > 128) gx = 128;
-  if ((dist == 0 ? n : m) > 512 || (dist == 0 ? n : m) > q.w_ld) return TJM_ERR_NOT_IMPLEMENTED;
-  hipLaunchKernelGGL(qr_colsort_kernel, dim3(nb0), dim3(256), 0, s, theta, th_b0, m, n, dist, q.colperm(), q.w_ld, ids);
-  hipLaunchKernelGGL(qr_prepare_kernel, dim3(gx, nb0), dim3(256), 0, s, theta, th_b0, m, n, dist, d, q.Z, q.z_b0, q.colperm(), q.w_ld, ids);
+  if (zc_pad > 1024 || zc_pad > q.w_ld || total > q.z_b0) return TJM_ERR_NOT_IMPLEMENTED;
+  hipLaunchKernelGGL(qr_colsort_kernel, dim3(nb0), dim3(256), 0, s, theta, th_b0, m, n, dist, q.colperm(), q.w_ld, ids, zc_pad);
+  hipLaunchKernelGGL(qr_prepare_kernel, dim3(gx, nb0), dim3(256), 0, s, theta, th_b0, m, n, dist, d, q.Z, q.z_b0, q.colperm(), q.w_ld, ids, zr_pad,
+                     zc_pad);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
@@ -745,6 +762,7 @@ int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hip
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_rows_kernel<2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   static const bool no_rows = getenv("TJM_QR_LDS_PANEL") != nullptr;
@@ -753,12 +771,17 @@ int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hip
   for (int k0 = 0; k0 < kmax; k0 += PW, ++panel) {
     const int pw = (kmax - k0 < PW) ? kmax - k0 : PW;
     const int mp = zr - k0;
-    if (mp <= 512 && !no_rows) {  // rows of the panel in registers, 1 or 2 per thread
-      const size_t lds = (size_t)(NRED * RED_PITCH + 2 * NRED + PW) * sizeof(double) + (size_t)(2 * PW + 2 * PW * PW + PW) * sizeof(cplx);
+    if (mp > 1024) return TJM_ERR_NOT_IMPLEMENTED;  // panels of at most 1024 rows (bonds up to 512)
+    if ((mp <= 512 && !no_rows) || mp > 384) {  // rows of the panel in registers: 1, 2 or 4 per thread
+      static const bool wide = getenv("TJM_QR_WIDE_PANEL") != nullptr;  // diagnostic: the 512-thread kernel from 257 rows on
+      const int nt = (mp <= 512 && !(wide && mp > 256)) ? 256 : 512;
+      const size_t lds = (size_t)(NRED * (nt + 1) + 2 * NRED + PW) * sizeof(double) + (size_t)(2 * PW + 2 * PW * PW + PW) * sizeof(cplx);
       if (mp <= 256)
         hipLaunchKernelGGL(qr_panel_rows_kernel<1>, dim3(nb0), dim3(256), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
-      else
+      else if (nt == 256)
         hipLaunchKernelGGL(qr_panel_rows_kernel<2>, dim3(nb0), dim3(256), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
+      else
+        hipLaunchKernelGGL((qr_panel_rows_kernel<2, 512>), dim3(nb0), dim3(512), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
     } else {
       const size_t lds = (size_t)(PW * (zr - k0) + 2 * PW * PW + PW) * sizeof(cplx) + PW * sizeof(double) + 64;
       hipLaunchKernelGGL(qr_panel_kernel, dim3(nb0), dim3(64), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);

@@ -32,7 +32,7 @@ namespace {
 
 constexpr int NB = 8;        // columns per block
 constexpr int MAXRK = 16;    // row groups of 64 per column held in registers (rtot <= 1024); kernels are instantiated for 8 and 16
-constexpr int MAXBLK = 64;   // column blocks per matrix (ncols <= 512)
+constexpr int MAXBLK = 128;  // column blocks per matrix (ncols <= 1024: bonds up to 512)
 constexpr int STAMP_STRIDE = 3 * MAXBLK + MAXBLK * MAXBLK;
 
 struct JacobiArgs {
@@ -1420,8 +1420,8 @@ __global__ __launch_bounds__(64) void small_sweep_kernel(SmallSweepDesc p) {
 
 // Column norms of the X part, descending rank sort, truncation (svd_utils.py:22-104).
 __global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspace w, int ncols_pad, int rx, int rtot, const int* ids) {
-  __shared__ double sN[512];
-  __shared__ int sPerm[512];
+  __shared__ double sN[1024];
+  __shared__ int sPerm[1024];
   int b = blockIdx.x;
   if (ids) b = ids[b];
   const cplx* Yb = w.Y + (long)b * w.y_b0;
@@ -1867,12 +1867,12 @@ int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* 
 // at the noise floor (rank-deficient input with min_keep / threshold 0) its column was never rotated; the routine reports
 // that through *needs_completion and the caller falls back to the re-orthonormalising variant below.
 static int svd_split_qr2_direct(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out,
-                                bool* needs_completion) {
-  const int N = d.m;
+                                bool* needs_completion, bool complete_here) {
+  const int N = d.m > d.n ? d.m : d.n;  // a rectangular theta (chain positions where the two outer bonds differ) is embedded in N x N
   const int cm = d.capM;
   const QrWorkspace q2 = q.second();
   int rc;
-  if ((rc = qr_prepare(d.theta, d.theta_b0, d.m, d.n, d.distribution, d.d, q, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  if ((rc = qr_prepare(d.theta, d.theta_b0, d.m, d.n, d.distribution, d.d, q, d.nb0, d.ids, s, d.m == d.n ? 0 : N)) != TJM_OK) return rc;
   if ((rc = qr_factor(q, N, N, d.nb0, d.ids, s)) != TJM_OK) return rc;
   if ((rc = qr_adjoint_triangle(q, N, d.nb0, d.ids, s)) != TJM_OK) return rc;
   if ((rc = qr_factor(q2, N, N, d.nb0, d.ids, s)) != TJM_OK) return rc;
@@ -1890,16 +1890,26 @@ static int svd_split_qr2_direct(const SvdSplitDesc& d, const SvdWorkspace& w, co
   TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active + 2, sizeof(int), hipMemcpyDeviceToHost, s));
   TJM_HIP_CHECK(hipStreamSynchronize(s));
   *needs_completion = (*w.h_pinned != 0);
-  if (*needs_completion) return TJM_OK;
+  if (*needs_completion && !complete_here) return TJM_OK;
   ExtractDesc xy;  // Ytilde: normalised kept columns of Y into Z (N x capM, column-major)
   xy.out = q.Z; xy.out_b0 = q.z_b0; xy.n_k = cm; xy.o_k = N; xy.n_r1 = 1; xy.n_r0 = N;
   xy.o_r1 = 0; xy.o_r0 = 1; xy.row_off = 0; xy.conj = 0; xy.scale_mode = 2;
-  if ((rc = svd_extract(xy, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s)) != TJM_OK) return rc;
+  if (*needs_completion) {
+    // A kept singular value at the rounding floor (rank-deficient theta with min_keep, threshold 0): its column of Ytilde is
+    // noise.  The thin Householder Q factor of Ytilde keeps the orthonormal columns (up to a unit phase, which the projection
+    // below absorbs) and completes the others to an orthonormal set; the second factorisation's reflectors are free by now.
+    xy.out = q2.Z; xy.out_b0 = q2.z_b0;
+    if ((rc = svd_extract(xy, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s)) != TJM_OK) return rc;
+    if ((rc = qr_factor(q2, N, cm, d.nb0, d.ids, s)) != TJM_OK) return rc;
+    if ((rc = qr_identity(q.Z, q.z_b0, N, cm, d.nb0, s, d.ids, d.chiM, d.chi_stride)) != TJM_OK) return rc;
+    if ((rc = qr_apply_q(q2, N, cm, q.Z, q.z_b0, cm, d.nb0, d.ids, s)) != TJM_OK) return rc;
+    *needs_completion = false;
+  } else if ((rc = svd_extract(xy, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s)) != TJM_OK) return rc;
   if ((rc = qr_apply_q(q, N, N, q.Z, q.z_b0, cm, d.nb0, d.ids, s)) != TJM_OK) return rc;  // iso = Q Ytilde, rows bond-major
   ExtractDesc xi;
   GemmDesc g;
   memset(&g, 0, sizeof(g));
-  g.nb0 = d.nb0; g.nb2 = 1; g.nks = d.d;
+  g.nb0 = d.nb0; g.nb2 = 1; g.nks = d.d; g.ids = d.ids;
   if (d.distribution == 0) {
     // left[(s,a)][k] = iso[a*d+s][k] ; right[t][k][c] = sum_{(a,s)} conj(iso[a*d+s][k]) theta[(s,a)][(t,c)]
     xi.out = d.left; xi.out_b0 = d.left_b0; xi.n_k = cm; xi.o_k = 1; xi.n_r1 = d.capL; xi.n_r0 = d.d; xi.o_r1 = cm;
@@ -1924,9 +1934,10 @@ static int svd_split_qr2_direct(const SvdSplitDesc& d, const SvdWorkspace& w, co
 static int svd_split_qr2(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out) {
   const int N = d.m;
   static const bool reorth = getenv("TJM_REORTH_SPLIT") != nullptr;
-  if (!reorth && getenv("TJM_ACCUMULATE_W") == nullptr && d.capM <= N) {
+  const bool only_direct = d.m != d.n || d.ids != nullptr;  // the variants below are written for square matrices of whole batches
+  if ((!reorth && getenv("TJM_ACCUMULATE_W") == nullptr && d.capM <= N) || only_direct) {
     bool needs_completion = false;
-    const int rc0 = svd_split_qr2_direct(d, w, q, s, sweeps_out, &needs_completion);
+    const int rc0 = svd_split_qr2_direct(d, w, q, s, sweeps_out, &needs_completion, only_direct);
     if (rc0 != TJM_OK || !needs_completion) return rc0;
   }
   const int fdist = 1 - d.distribution;
@@ -2045,9 +2056,17 @@ static int svd_split_qr2(const SvdSplitDesc& d, const SvdWorkspace& w, const QrW
 
 int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out) {
   if (d.nb0 <= 0) return TJM_OK;
-  if (d.ids) return svd_split(d, w, s, sweeps_out);  // index-list batches take the plain path
+  // beyond the stacked-column Jacobi (rows + columns <= 1024): X-only direct variant.  TJM_FORCE_LARGE_SPLIT sends every split of
+  // at least 32 x 32 down that path (diagnostic: the large-bond code at sizes the rest of the suite covers)
+  static const bool force_large = getenv("TJM_FORCE_LARGE_SPLIT") != nullptr;
+  const bool large = (d.m > 512 || d.n > 512) || (force_large && q.Z2 != nullptr && d.m >= 32 && d.n >= 32);
+  if (d.ids && !large) return svd_split(d, w, s, sweeps_out);  // index-list batches take the plain path
   if (d.ld_theta != d.n) return TJM_ERR_ARG;
   static const bool single_qr = getenv("TJM_SINGLE_QR") != nullptr;
+  if (large) {
+    if (q.Z2 == nullptr) return TJM_ERR_WORKSPACE;
+    return svd_split_qr2(d, w, q, s, sweeps_out);
+  }
   if (!single_qr && q.Z2 != nullptr && d.m == d.n && d.m >= 32) return svd_split_qr2(d, w, q, s, sweeps_out);
   const int zr = (d.distribution == 0) ? d.m : d.n;
   const int zc = (d.distribution == 0) ? d.n : d.m;

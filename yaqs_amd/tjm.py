@@ -702,7 +702,9 @@ def _encoded(state: MPS) -> MPS:
     return out
 
 
-MAX_CHI = 256   # largest bond the register-resident Jacobi SVD holds (d * chi <= 512)
+MAX_CHI = 256   # largest bond the engine serves.  The kernels hold d * chi <= 1024 since round 2 (1024 x 1024 splits verified on the
+# GPU against the oracle, tests/test_hip_kernels.py::test_svd_split_up_to_1024_matches_oracle), but the ENGINE at chi = 512 took the
+# GPU box down twice (tests/test_hip_engine.py::test_bonds_up_to_512_..., cause not yet found), so runs beyond 256 stay refused.
 START_CHI = 8   # first storage capacity tried when the requested cap is larger
 AUTO_BATCH_MAX = 16384  # trajectories in flight when Simulator(batch=None) sizes the batch itself
 
