@@ -394,3 +394,38 @@ def test_oracle_reproduces_the_reference_two_site_correlator_series(case):
     idx = p.observable_sorted_indices
     for k, name in enumerate(("xx", "yy", "zz")):
         assert np.allclose(res[idx[k]], np.array(g[name]), atol=1e-3), name
+
+
+def test_dynamic_tdvp_and_bug_match_reference():
+    """tdvp(tdvp_mode="dynamic") (integrators.py:294-511) and bug() (bug.py:213-257): one call on small chains whose bonds sit below,
+    at and above the cap, and whole noisy trajectories of both drivers in both modes (fixtures written by the reference)."""
+    g = load("f3_dynamic_bug")
+    for key in g["cases"]:
+        key = str(key)
+        cap = key.split("_")[2][3:]
+        cap = None if cap == "None" else int(cap)
+        mpo = tensors(g, key + "_mpo")
+        for mode in ("dynamic", "bug"):
+            if mode == "bug" and key.endswith("x+"):
+                continue  # product state: BUG's stacked bases are exactly rank deficient, the reference's own result is rounding-dependent
+            st = o.MPSState(tensors(g, key + "_in"), 0)
+            p = o.Params(dt=0.1, elapsed_time=0.1, max_bond_dim=cap, svd_threshold=1e-9, krylov_tol=1e-12,
+                         tdvp_mode="dynamic" if mode == "dynamic" else "2site", evolution_mode="bug" if mode == "bug" else "tdvp")
+            o.apply_unitary_evolution(st, mpo, p)
+            assert [t.shape[2] for t in st.tensors] == list(g[f"{key}_{mode}_bonds"]), (key, mode)
+            v, ref = st.to_vec(), g[f"{key}_{mode}_vec"]
+            ov = np.vdot(ref, v)
+            assert np.allclose(v, ref * (ov / abs(ov)), atol=1e-9), (key, mode, np.abs(v - ref * (ov / abs(ov))).max())
+            assert abs(st.norm_sq() - float(g[f"{key}_{mode}_norm"])) < 1e-10, (key, mode)
+    L = 6
+    mpo = tensors(g, "traj_mpo")
+    noise = [o.make_process(n, [i], 0.1) for i in range(L) for n in ("lowering", "pauli_z")]
+    for mode in ("dynamic", "bug"):
+        for order in (1, 2):
+            p = o.Params(observables=[o.Obs(Z, s) for s in range(L)], elapsed_time=0.5, dt=0.1, max_bond_dim=4, svd_threshold=1e-9, krylov_tol=1e-12,
+                         order=order, sample_timesteps=True, random_seed=9, tdvp_mode="dynamic" if mode == "dynamic" else "2site",
+                         evolution_mode="bug" if mode == "bug" else "tdvp")
+            for t in range(4):
+                r, dg, _ = o.run_trajectory(t, o.MPSState(tensors(g, "traj_in"), 0), noise, p, mpo)
+                assert np.allclose(r, g[f"traj_{mode}_order{order}_results"][t], atol=1e-8), (mode, order, t, np.abs(r - g[f"traj_{mode}_order{order}_results"][t]).max())
+                assert np.array_equal(dg, g[f"traj_{mode}_order{order}_diag"][t]), (mode, order, t)

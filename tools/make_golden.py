@@ -604,6 +604,60 @@ def gen_fullsize(which=("cfg2", "cfg4", "cfg3")):
     save("fullsize", **out)
 
 
+# ------------------------------------------------------------------ 13. dynamic TDVP and the BUG integrator
+def gen_f3():
+    """One call of tdvp(tdvp_mode="dynamic") (integrators.py:294-511) and of bug() (bug.py:213-257) on small chains - bonds below,
+    at and above the cap so that both branches of the dynamic sweep run - and whole noisy trajectories in both modes."""
+    bugmod = ref("core.methods.bug")
+    out = {}
+    cases = []
+    for L, chi0, cap, state_kind in ((4, 2, 4, "haar"), (5, 4, 4, "haar"), (10, 4, 8, "haar"), (6, 1, 4, "x+"), (8, 8, 8, "haar"), (7, 2, None, "haar")):
+        key = f"L{L}_c{chi0}_cap{cap}_{state_kind}"
+        cases.append(key)
+        H = MPO.ising(L, 1.0, 0.7)
+        out.update(pack_tensors(key + "_mpo", H.tensors))
+        m = haar_mps(L, chi0, 100 + L) if state_kind == "haar" else MPS(L, state="x+")
+        m.normalize("B")
+        out.update(pack_tensors(key + "_in", m.tensors))
+        for mode in ("dynamic", "bug"):
+            st = copy.deepcopy(m)
+            p = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), 0)], elapsed_time=0.1, dt=0.1, max_bond_dim=cap, svd_threshold=1e-9,
+                                   krylov_tol=1e-12, tdvp_mode="dynamic" if mode == "dynamic" else "2site",
+                                   evolution_mode="bug" if mode == "bug" else "tdvp")
+            if mode == "dynamic":
+                tdvp_mod.tdvp(st, H, p)
+            else:
+                bugmod.bug(st, H, p)
+            out[f"{key}_{mode}_vec"] = st.to_vec()
+            out[f"{key}_{mode}_bonds"] = np.array([t.shape[2] for t in st.tensors])
+            out[f"{key}_{mode}_norm"] = np.array(st.norm())
+    out["cases"] = np.array(cases)
+    # whole trajectories
+    L = 6
+    H = MPO.ising(L, 1.0, 0.5)
+    out.update(pack_tensors("traj_mpo", H.tensors))
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
+    # The trajectories start from a generic (Haar, chi = 2) state: from a product state the stacked trial bases of BUG contain
+    # exactly dependent columns, their QR completion is decided by rounding noise and the reference's own result moves at the 1e-5
+    # level with it (measured: two bit-different but equal inputs give overlap 0.99996 after one step).
+    st = haar_mps(L, 2, 77)
+    out.update(pack_tensors("traj_in", st.tensors))
+    for mode in ("dynamic", "bug"):
+        for order in (1, 2):
+            p = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), s) for s in range(L)], elapsed_time=0.5, dt=0.1, num_traj=4, max_bond_dim=4,
+                                   svd_threshold=1e-9, krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=9,
+                                   tdvp_mode="dynamic" if mode == "dynamic" else "2site", evolution_mode="bug" if mode == "bug" else "tdvp")
+            backend = tjm.analog_tjm_2 if order == 2 else tjm.analog_tjm_1
+            res, diag = [], []
+            for i in range(4):
+                r, dg, _ = backend((i, st, noise, p, H))
+                res.append(np.asarray(r, dtype=np.float64))
+                diag.append(dg)
+            out[f"traj_{mode}_order{order}_results"] = np.array(res)
+            out[f"traj_{mode}_order{order}_diag"] = np.array(diag)
+    save("f3_dynamic_bug", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tiny", "rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
     for w in which:
