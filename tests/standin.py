@@ -1,0 +1,204 @@
+"""Oracle-backed stand-in for ``yaqs_amd.engine.BatchEngine`` (TEST INFRASTRUCTURE ONLY).
+
+The product has no CPU path; this class exists so that the *host logic* above the C ABI - the Python schedule of
+``TrajectoryBatch``, ``Simulator.run`` (chunking, storage grown on demand, result assembly, validation) - runs in the CPU suite.
+Every stage entry point is answered by the CPU oracle on one ``MPSState`` per slot; the uniforms the host hands over are consumed
+the way the engine consumes them (one for the jump test, one more for the channel choice).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import tjm_oracle as o
+
+
+class _ScriptedRng:
+    """The two draws of ``stochastic_process`` from the host's uniforms: ``random()`` and ``choice(n, p)`` (searchsorted of the
+    normalised cumulative sum, side="right": what ``Generator.choice`` does with one double)."""
+
+    def __init__(self, values):
+        self.values, self.used = list(values), 0
+
+    def random(self):
+        v = self.values[self.used]
+        self.used += 1
+        return v
+
+    def choice(self, n, p=None):
+        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+        cdf /= cdf[-1]
+        return int(np.searchsorted(cdf, self.random(), side="right"))
+
+
+class OracleEngine:
+    instances: list = []
+
+    def __init__(self, length, chi_max, batch, mpo, device="cpu", d=2, stream=None):
+        self.L, self.d, self.chi_max, self.B = int(length), int(d), int(chi_max), int(batch)
+        self.mpo = [np.asarray(w, dtype=np.complex128) for w in mpo]
+        self.caps = np.array(o.MPSState.bond_caps(self.L, self.chi_max), dtype=np.int32)
+        self.sets = [[None] * self.B, [None] * self.B]
+        self.noise = None
+        self.filter = None
+        self.params = None
+        self.u = None
+        self._overflow = False
+        self.closed = False
+        OracleEngine.instances.append(self)
+
+    # -- configuration -----------------------------------------------------------------
+    def set_params(self, *, dt, svd_threshold, trunc_mode="discarded_weight", max_bond_dim=None, krylov_tol=1e-4, tdvp_mode="2site",
+                   tdvp_sweeps=1):
+        self.params = o.Params(dt=dt, svd_threshold=svd_threshold, trunc_mode=trunc_mode, max_bond_dim=max_bond_dim, krylov_tol=krylov_tol,
+                               tdvp_mode=tdvp_mode, tdvp_sweeps=tdvp_sweeps)
+
+    def set_mpo(self, mpo):
+        self.mpo = [np.asarray(w, dtype=np.complex128) for w in mpo]
+
+    def set_noise(self, processes, flags):
+        self.noise = [dict(q) for q in processes]
+
+    def set_noise_filter(self, indices=None):
+        self.filter = None if indices is None else list(indices)
+
+    def load_state(self, tensors, set_index=0):
+        for b in range(self.B):
+            self.sets[set_index][b] = o.MPSState([np.array(t, dtype=np.complex128) for t in tensors], 0)
+        self._check()
+
+    def copy_state(self, dst, src):
+        self.sets[dst] = [s.copy() for s in self.sets[src]]
+
+    def export_state(self, b, set_index=0):
+        return [t.copy() for t in self.sets[set_index][b].tensors]
+
+    def adopt(self, src, first=0):
+        for b in range(self.B):
+            self.sets[0][b] = src.sets[0][first + b].copy()
+
+    def set_uniforms(self, u):
+        self.u = np.asarray(u, dtype=np.float64)
+
+    def close(self):
+        self.closed = True
+
+    def synchronize(self):
+        pass
+
+    # -- storage capacity ----------------------------------------------------------------
+    def _check(self):
+        for s in self.sets[0] + self.sets[1]:
+            if s is not None and any(t.shape[2] > self.caps[i + 1] for i, t in enumerate(s.tensors)):
+                self._overflow = True
+
+    def capacity_overflow(self, clear=False):
+        f = self._overflow
+        if clear:
+            self._overflow = False
+        return f
+
+    # -- the path ------------------------------------------------------------------------
+    def _active_noise(self):
+        if self.noise is None:
+            return None
+        if self.filter is None:
+            return self.noise
+        return [self.noise[k] for k in self.filter]
+
+    def tdvp(self, set_index=0):
+        for s in self.sets[set_index]:
+            o.tdvp(s, self.mpo, self.params)
+        self._check()
+
+    def dissipate(self, dt, set_index=0):
+        for s in self.sets[set_index]:
+            o.apply_dissipation(s, self._active_noise() or None, dt, self.params)
+        self._check()
+
+    def stochastic(self, dt, set_index=0):
+        jumped = np.zeros(self.B, dtype=np.int32)
+        dp = np.zeros(self.B)
+        noise = self._active_noise()
+        for b in range(self.B):
+            s = self.sets[set_index][b]
+            dp[b] = 1.0 - s.norm_sq(0)
+            rng = _ScriptedRng(self.u[b])
+            self.sets[set_index][b] = o.stochastic_process(s, noise if noise else None, dt, self.params, rng)
+            jumped[b] = 1 if rng.used > 1 else 0
+        self._check()
+        return jumped, dp
+
+    def site0_normsq(self, set_index=0):
+        return np.array([s.norm_sq(0) for s in self.sets[set_index]])
+
+    def canonicalize_qr(self, center, set_index=0):
+        for s in self.sets[set_index]:
+            s.set_canonical_form(0, "QR")
+
+    def normalize_qr(self, center, set_index=0):
+        for s in self.sets[set_index]:
+            s.normalize("B", "QR")
+
+    def apply_single(self, site, matrix, set_index=0):
+        m = np.asarray(matrix, dtype=np.complex128)
+        for s in self.sets[set_index]:
+            s.tensors[site] = np.einsum("ab,bcd->acd", m, s.tensors[site])
+            s.center = None
+
+    def apply_pair(self, left, matrix, min_keep=1, set_index=0):
+        m = np.asarray(matrix, dtype=np.complex128).reshape(4, 4)
+        p = self.params
+        for s in self.sets[set_index]:
+            a, b = s.tensors[left], s.tensors[left + 1]
+            th = np.einsum("ab,bcd->acd", m, o.merge_two_site(a, b))
+            s.tensors[left], s.tensors[left + 1] = o.split_two_site(th, [2, 2], svd_distribution="right", trunc_mode=p.trunc_mode,
+                                                                    threshold=p.svd_threshold, max_bond_dim=p.max_bond_dim, min_keep=min_keep)
+            s.center = None
+        self._check()
+
+    # -- measurement ---------------------------------------------------------------------
+    def site_moments(self, set_index=0):
+        d = self.d
+        M = np.zeros((self.L, self.B, d, d), dtype=np.complex128)
+        for b, s in enumerate(self.sets[set_index]):
+            for i in range(self.L):
+                for p in range(d):
+                    for q in range(d):
+                        unit = np.zeros((d, d), dtype=np.complex128)
+                        unit[p, q] = 1.0
+                        M[i, b, p, q] = s.full_expect(unit, [i])
+        return M
+
+    def site_moments2(self, set_index=0):
+        M = self.site_moments(set_index)
+        d2 = self.d * self.d
+        M2 = np.zeros((self.L - 1, self.B, d2, d2), dtype=np.complex128)
+        for b, s in enumerate(self.sets[set_index]):
+            for i in range(self.L - 1):
+                for p in range(d2):
+                    for q in range(d2):
+                        unit = np.zeros((d2, d2), dtype=np.complex128)
+                        unit[p, q] = 1.0
+                        M2[i, b, p, q] = s.full_expect(unit, [i, i + 1])
+        return M, M2
+
+    def bond_dims(self, set_index=0):
+        chi = np.ones((self.B, self.L + 1), dtype=np.int32)
+        for b, s in enumerate(self.sets[set_index]):
+            chi[b, 0] = s.tensors[0].shape[1]
+            chi[b, 1:] = [t.shape[2] for t in s.tensors]
+        return chi
+
+    def bond_spectrum(self, site, set_index=0):
+        n = int(self.d * min(self.caps[site], self.caps[site + 2]))
+        out = np.zeros((self.B, n))
+        for b, s in enumerate(self.sets[set_index]):
+            sv = o.bond_singular_values(s, site)
+            out[b, : min(n, len(sv))] = sv[:n]
+        return out
+
+    def bitstring_probability(self, bitstring, set_index=0):
+        return np.array([o.project_onto_bitstring(s, bitstring) for s in self.sets[set_index]])
+
+    def stats(self):
+        return {}

@@ -1,0 +1,117 @@
+"""Host logic above the C ABI on the CPU: ``Simulator.run`` / ``TrajectoryBatch`` with the oracle-backed stand-in engine of
+``tests/standin.py`` in place of the HIP engine (monkeypatched; the product itself has no CPU path).  What is checked here is the
+Python schedule - drivers of both orders, uniform cursors, storage grown on demand with roll-back, result assembly, run-context
+validation - against the oracle's own drivers; the kernels are the business of the ``-m gpu`` tests."""
+import numpy as np
+import pytest
+
+from oracle import tjm_oracle as o
+from standin import OracleEngine
+
+Z = o.PAULI["z"]
+
+
+@pytest.fixture()
+def sim(monkeypatch):
+    import yaqs_amd.tjm as tjm_mod
+
+    monkeypatch.setattr(tjm_mod, "BatchEngine", OracleEngine)
+    OracleEngine.instances.clear()
+    return tjm_mod.Simulator
+
+
+def _oracle_rows(L, noise, kw, mpo, initial, n):
+    on = [o.make_process(q["name"], q["sites"], q["strength"], matrix=q.get("matrix"), factors=q.get("factors")) for q in noise.processes]
+    op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], **kw)
+    return [o.run_trajectory(t, o.MPSState([x.copy() for x in initial], 0), on, op, mpo) for t in range(n)]
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("sample", [True, False])
+def test_python_schedule_with_growing_storage_matches_the_oracle_drivers(sim, order, sample):
+    """8 sites from a product state, max_bond_dim 16: the run starts at capacity 8 and must hand over to 16 mid-run (roll-back of
+    the clipped step, cursors travelling with the trajectories, chunks of 3 trajectories)."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
+
+    L = 8
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.15} for i in range(L) for n in ("lowering", "pauli_x")])
+    kw = dict(elapsed_time=1.2, dt=0.2, max_bond_dim=16, svd_threshold=1e-14, krylov_tol=1e-12, order=order, sample_timesteps=sample, random_seed=21)
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=5, **kw)
+    mpo = MPO.ising(L, 1.0, 1.0)
+    st = MPS(L, state="x+")
+    res = sim(batch=3, native=False).run(st, mpo, p, noise)
+    st.normalize("B")
+    rows = _oracle_rows(L, noise, kw, [np.asarray(w) for w in mpo.tensors], st.tensors, 5)
+    for t in range(5):
+        for s_ in range(L):
+            assert np.allclose(res.trajectories[s_][t], rows[t][0][s_], atol=1e-9), (t, s_)
+    caps = sorted({e.chi_max for e in OracleEngine.instances})
+    assert caps[0] == 8 and caps[-1] == 16, caps           # the storage ladder was climbed
+    assert all(e.closed for e in OracleEngine.instances)    # and every engine handed back
+    d = np.mean([rows[t][1] for t in range(5)], axis=0)
+    assert np.allclose(res.total_bond, d[2]) and np.allclose(res.max_bond, d[1])
+
+
+def test_schmidt_spectrum_entropy_and_pvm_through_the_front_end(sim):
+    """trajectories[u] of a schmidt_spectrum observable is [traj, T, 500], expectation_values[u] the concatenation over trajectories
+    (mps.py:1211, result.py:127-139); entropy and the projector stay scalars - none of them NaN means."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
+
+    L = 6
+    noise = NoiseModel([{"name": "lowering", "sites": [s], "strength": 0.1} for s in range(L)])
+    obs = [Observable(Zg(), 0), Observable("schmidt_spectrum", [2, 3]), Observable("entropy", [2, 3]), Observable(Zg(), 5)]
+    kw = dict(elapsed_time=0.3, dt=0.1, max_bond_dim=8, svd_threshold=1e-12, krylov_tol=1e-12, order=1, sample_timesteps=True, random_seed=5)
+    res = sim(batch=2, native=False).run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), AnalogSimParams(observables=obs, num_traj=3, **kw), noise)
+    spec = res.trajectories[1]
+    assert spec.shape == (3, 4, 500) and res.expectation_values[1].shape == (3 * 4 * 500,)
+    on = [o.make_process("lowering", [s], 0.1) for s in range(L)]
+    op = o.Params(observables=[o.Obs(Z, 0)], get_state=False, **kw)
+    for t in range(3):
+        for j in range(4):
+            sv = spec[t, j][~np.isnan(spec[t, j])]
+            pr = sv ** 2 / np.sum(sv ** 2)
+            assert abs(-np.sum(pr * np.log(pr + np.finfo(float).tiny)) - res.trajectories[2][t, j]) < 1e-10
+        r, _, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), on, op, o.ising_mpo(L, 1.0, 0.5))
+        assert np.allclose(res.trajectories[0][t], r[0], atol=1e-9)
+    assert np.isfinite(res.expectation_values[0]).all() and np.isfinite(res.expectation_values[2]).all()
+
+
+def test_one_site_tdvp_with_a_pair_channel_is_not_confined_to_the_initial_bonds(sim):
+    """tdvp_mode='1site' keeps the bonds of the sweep, but an adjacent non-Pauli pair channel is applied through a truncated merged
+    split: the engine must be allowed to grow (engine_bond_caps(can_grow=True)) and the result is the oracle's."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
+    from yaqs_amd.tjm import _noise_can_grow_bonds, engine_bond_caps
+
+    L = 4
+    noise = NoiseModel([{"name": "lowering_two", "sites": [1, 2], "strength": 0.4}, {"name": "pauli_x", "sites": [0], "strength": 0.2}])
+    assert _noise_can_grow_bonds(noise) and not _noise_can_grow_bonds(NoiseModel([{"name": "pauli_x", "sites": [0], "strength": 0.2}]))
+    kw = dict(elapsed_time=0.3, dt=0.1, max_bond_dim=4, svd_threshold=1e-12, krylov_tol=1e-12, order=1, sample_timesteps=True, random_seed=3,
+              tdvp_mode="1site")
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=4, **kw)
+    st = MPS(L, state="x+")
+    assert engine_bond_caps(p, st) == (1, 1) and engine_bond_caps(p, st, can_grow=True) == (4, 4)
+    mpo = MPO.ising(L, 1.0, 0.5)
+    res = sim(batch=4, native=False).run(st, mpo, p, noise)
+    st.normalize("B")
+    rows = _oracle_rows(L, noise, kw, [np.asarray(w) for w in mpo.tensors], st.tensors, 4)
+    for t in range(4):
+        for s_ in range(L):
+            assert np.allclose(res.trajectories[s_][t], rows[t][0][s_], atol=1e-9), (t, s_)
+
+
+def test_run_context_validation_happens_before_anything_runs(sim):
+    """validate_noise_model_for_run (noise_model.py:668-790) at the top of Simulator.run / run_circuit: non-Pauli long-range noise
+    on the analog MPS path and non-adjacent two-site noise on the digital path are refused with ValueError; no engine is built."""
+    from yaqs_amd.api import AnalogSimParams, DigitalSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
+
+    L = 4
+    low = np.array([[0, 1], [0, 0]], dtype=complex)
+    lr = NoiseModel([{"name": "custom", "sites": [0, 3], "strength": 0.2, "factors": (low, np.diag([1.0, -1.0]).astype(complex))}])
+    p = AnalogSimParams(observables=[Observable(Zg(), 0)], elapsed_time=0.1, dt=0.1, max_bond_dim=4)
+    with pytest.raises(ValueError, match="non-Pauli long-range"):
+        sim(batch=1, native=False).run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p, lr)
+    pauli_lr = NoiseModel([{"name": "longrange_crosstalk_xy", "sites": [0, 2], "strength": 0.1}])
+    dp = DigitalSimParams(observables=[Observable(Zg(), 0)], num_traj=2, max_bond_dim=4)
+    with pytest.raises(ValueError, match="non-adjacent"):
+        sim(batch=1).run_circuit(MPS(L, state="zeros"), [], dp, pauli_lr)
+    assert OracleEngine.instances == []
