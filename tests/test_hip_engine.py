@@ -1859,3 +1859,36 @@ def test_bonds_up_to_512_gate_shift_and_tdvp_match_oracle():
         assert abs(z - ref.full_expect(Z, [s_]).real) < 1e-8, s_
     assert [t.shape[2] for t in e.export_state(0)] == [t.shape[2] for t in ref.tensors]
     e.close()
+
+
+def test_sample_at_and_segment_stitching_match_reference_on_the_engine():
+    """The continuation options of the drivers (analog_tjm.py:206-255, 369-400) through the HIP engine: ``sample_at`` on both orders
+    and an order-2 run cut after 3 of 6 steps, against the reference's outputs (tests/golden/continuation.npz)."""
+    from yaqs_amd.api import AnalogSimParams, MPS, NoiseModel, Observable, Z as Zg
+    from yaqs_amd.tjm import TrajectoryBatch
+
+    g = load("continuation")
+    L = 5
+    mpo = tensors(g, "mpo")
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.15} for i in range(L) for n in ("lowering", "pauli_z")])
+    kw = dict(dt=0.1, max_bond_dim=4, svd_threshold=1e-9, krylov_tol=1e-12, random_seed=31)
+    obs = [Observable(Zg(), s) for s in range(L)]
+    st = MPS(L, state="x+")
+    st.normalize("B")
+    traj = [0, 1, 2, 3]
+    e = make_engine(L, 4, 4, mpo)
+    for order in (1, 2):
+        p = AnalogSimParams(observables=obs, elapsed_time=0.6, sample_timesteps=True, order=order, **kw)
+        r, _ = TrajectoryBatch(e, p, noise).run(traj, st, sample_at=[0, 2, 5])
+        assert np.allclose(r, g[f"sample_at_order{order}"], atol=1e-8), order
+        p1 = AnalogSimParams(observables=obs, elapsed_time=0.6, sample_timesteps=False, order=order, **kw)
+        r, _ = TrajectoryBatch(e, p1, noise).run(traj, st, sample_at=[3])
+        assert np.allclose(r, g[f"sample_at_single_order{order}"], atol=1e-8), order
+    seg = AnalogSimParams(observables=obs, elapsed_time=0.3, sample_timesteps=True, order=2, **kw)
+    tb = TrajectoryBatch(e, seg, noise)
+    r1, _ = tb.run(traj, st, rng_pos=np.zeros(4, dtype=np.int64))
+    tb2 = TrajectoryBatch(e, seg, noise)
+    r2, _ = tb2.run(traj, None, continue_trajectory=True, sample_timestep_offset=3, rng_pos=tb.rng_pos)
+    assert np.allclose(r1, g["whole"][:, :, :4], atol=1e-8) and np.allclose(r2, g["whole"][:, :, 3:], atol=1e-8)
+    assert np.array_equal(e.bond_dims(0)[:, 1:], g["phi_bonds"])
+    e.close()

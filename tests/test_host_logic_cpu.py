@@ -115,3 +115,46 @@ def test_run_context_validation_happens_before_anything_runs(sim):
     with pytest.raises(ValueError, match="non-adjacent"):
         sim(batch=1).run_circuit(MPS(L, state="zeros"), [], dp, pauli_lr)
     assert OracleEngine.instances == []
+
+
+def test_sample_at_and_segment_stitching_of_the_python_schedule(sim):
+    """The continuation options of the drivers (analog_tjm.py:206-255, 369-400) in ``TrajectoryBatch.run``: ``sample_at``, and an
+    order-2 run cut after 3 of 6 steps (cursors of the trajectory streams handed on, phi left in set 0, sample streams on the global
+    timeline) - against the REFERENCE's outputs (tests/golden/continuation.npz), which stitch to the continuous run bit for bit."""
+    import os
+
+    from conftest import GOLDEN
+    from yaqs_amd.api import AnalogSimParams, MPS, NoiseModel, Observable, Z as Zg
+    from yaqs_amd.tjm import TrajectoryBatch
+
+    g = np.load(os.path.join(GOLDEN, "continuation.npz"))
+    L = 5
+    mpo = [g[f"mpo{i}"] for i in range(L)]
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.15} for i in range(L) for n in ("lowering", "pauli_z")])
+    kw = dict(dt=0.1, max_bond_dim=4, svd_threshold=1e-9, krylov_tol=1e-12, random_seed=31)
+    obs = [Observable(Zg(), s) for s in range(L)]
+    st = MPS(L, state="x+")
+    st.normalize("B")
+    traj = [0, 1, 2, 3]
+    for order in (1, 2):
+        e = OracleEngine(L, 4, 4, mpo)
+        p = AnalogSimParams(observables=obs, elapsed_time=0.6, sample_timesteps=True, order=order, **kw)
+        r, _ = TrajectoryBatch(e, p, noise).run(traj, st, sample_at=[0, 2, 5])
+        assert np.allclose(r, g[f"sample_at_order{order}"], atol=1e-9), order
+        p1 = AnalogSimParams(observables=obs, elapsed_time=0.6, sample_timesteps=False, order=order, **kw)
+        r, _ = TrajectoryBatch(e, p1, noise).run(traj, st, sample_at=[3])
+        assert np.allclose(r, g[f"sample_at_single_order{order}"], atol=1e-9), order
+        with pytest.raises(ValueError, match="outside the time grid"):
+            TrajectoryBatch(e, p, noise).run(traj, st, sample_at=[7])
+        with pytest.raises(ValueError, match="requires sample_timesteps=True"):
+            TrajectoryBatch(e, p1, noise).run(traj, st, sample_at=[1, 2])
+    seg = AnalogSimParams(observables=obs, elapsed_time=0.3, sample_timesteps=True, order=2, **kw)
+    e = OracleEngine(L, 4, 4, mpo)
+    tb = TrajectoryBatch(e, seg, noise)
+    r1, _ = tb.run(traj, st, rng_pos=np.zeros(4, dtype=np.int64))
+    tb2 = TrajectoryBatch(e, seg, noise)
+    r2, _ = tb2.run(traj, None, continue_trajectory=True, sample_timestep_offset=3, rng_pos=tb.rng_pos)
+    assert np.allclose(r1, g["segment1"], atol=1e-9) and np.allclose(r2, g["segment2"], atol=1e-9)
+    assert np.allclose(r1, g["whole"][:, :, :4], atol=1e-9) and np.allclose(r2, g["whole"][:, :, 3:], atol=1e-9)
+    assert np.array_equal(e.bond_dims(0)[:, 1:], g["phi_bonds"])
+    assert np.all(tb2.rng_pos > tb.rng_pos)

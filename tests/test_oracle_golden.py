@@ -429,3 +429,39 @@ def test_dynamic_tdvp_and_bug_match_reference():
                 r, dg, _ = o.run_trajectory(t, o.MPSState(tensors(g, "traj_in"), 0), noise, p, mpo)
                 assert np.allclose(r, g[f"traj_{mode}_order{order}_results"][t], atol=1e-8), (mode, order, t, np.abs(r - g[f"traj_{mode}_order{order}_results"][t]).max())
                 assert np.array_equal(dg, g[f"traj_{mode}_order{order}_diag"][t]), (mode, order, t)
+
+
+def _continuation_setup(g):
+    L = 5
+    mpo = tensors(g, "mpo")
+    noise = [o.make_process(n, [i], 0.15) for i in range(L) for n in ("lowering", "pauli_z")]
+    kw = dict(dt=0.1, max_bond_dim=4, svd_threshold=1e-9, krylov_tol=1e-12, random_seed=31)
+    return L, mpo, noise, kw
+
+
+def test_sample_at_and_segment_stitching_match_reference():
+    """The continuation options of analog_tjm_1 / analog_tjm_2 (analog_tjm.py:206-462): ``sample_at`` with and without
+    ``sample_timesteps``, and an order-2 run cut after 3 of 6 steps - shared trajectory stream, phi handed over, sample streams on
+    the global timeline - which the reference stitches to the continuous run bit for bit."""
+    g = load("continuation")
+    L, mpo, noise, kw = _continuation_setup(g)
+    obs = [o.Obs(Z, s) for s in range(L)]
+    init = o.MPSState.product(L, "x+")
+    for order, fn in ((1, o.analog_tjm_1), (2, o.analog_tjm_2)):
+        p = o.Params(observables=obs, elapsed_time=0.6, sample_timesteps=True, order=order, **kw)
+        p1 = o.Params(observables=obs, elapsed_time=0.6, sample_timesteps=False, order=order, **kw)
+        for t in range(4):
+            assert np.allclose(fn(t, init, noise, p, mpo, sample_at=[0, 2, 5])[0], g[f"sample_at_order{order}"][t], atol=1e-9), (order, t)
+            assert np.allclose(fn(t, init, noise, p1, mpo, sample_at=[3])[0], g[f"sample_at_single_order{order}"][t], atol=1e-9), (order, t)
+        with pytest.raises(ValueError, match="outside the time grid"):
+            fn(0, init, noise, p, mpo, sample_at=[7])
+        with pytest.raises(ValueError, match="requires sample_timesteps=True"):
+            fn(0, init, noise, p1, mpo, sample_at=[1, 2])
+    seg = o.Params(observables=obs, elapsed_time=0.3, sample_timesteps=True, order=2, **kw)
+    for t in range(4):
+        rng = o.trajectory_rng(31, t)
+        r1, _, phi = o.analog_tjm_2(t, init, noise, seg, mpo, rng=rng, return_trajectory_state=True)
+        r2, _, phi2 = o.analog_tjm_2(t, phi, noise, seg, mpo, rng=rng, sample_timestep_offset=3, continue_trajectory=True, return_trajectory_state=True)
+        assert np.allclose(r1, g["segment1"][t], atol=1e-9) and np.allclose(r2, g["segment2"][t], atol=1e-9), t
+        assert np.allclose(r1, g["whole"][t][:, :4], atol=1e-9) and np.allclose(r2, g["whole"][t][:, 3:], atol=1e-9), t
+        assert [x.shape[2] for x in phi2.tensors] == list(g["phi_bonds"][t])

@@ -658,6 +658,43 @@ def gen_f3():
     save("f3_dynamic_bug", **out)
 
 
+# ------------------------------------------------------------------ 14. continuation options of the drivers
+def gen_continuation():
+    """analog_tjm_1 / analog_tjm_2 with ``sample_at``, and an order-2 run cut into two segments the way the reference's program
+    runner stitches them (analog_tjm.py:206-366): one trajectory stream shared by both segments, ``return_trajectory_state`` /
+    ``continue_trajectory`` for the hand-off of phi, ``sample_timestep_offset`` for the global sample timeline."""
+    L = 5
+    H = MPO.ising(L, 1.0, 0.6)
+    out = pack_tensors("mpo", H.tensors)
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.15} for i in range(L) for n in ("lowering", "pauli_z")])
+    st = MPS(L, state="x+")
+    st.normalize("B")
+    obs = [sp.Observable(gl.Z(), s) for s in range(L)]
+    kw = dict(dt=0.1, max_bond_dim=4, svd_threshold=1e-9, krylov_tol=1e-12, random_seed=31)
+    ntraj = 4
+    # sample_at on both drivers
+    for order, fn in ((1, tjm.analog_tjm_1), (2, tjm.analog_tjm_2)):
+        p = sp.AnalogSimParams(observables=obs, elapsed_time=0.6, sample_timesteps=True, order=order, **kw)
+        out[f"sample_at_order{order}"] = np.array([np.asarray(fn((i, st, noise, p, H), sample_at=[0, 2, 5])[0], dtype=np.float64) for i in range(ntraj)])
+        p1 = sp.AnalogSimParams(observables=obs, elapsed_time=0.6, sample_timesteps=False, order=order, **kw)
+        out[f"sample_at_single_order{order}"] = np.array([np.asarray(fn((i, st, noise, p1, H), sample_at=[3])[0], dtype=np.float64) for i in range(ntraj)])
+    # one continuous order-2 run of 6 steps, and the same cut after 3 steps
+    full = sp.AnalogSimParams(observables=obs, elapsed_time=0.6, sample_timesteps=True, order=2, **kw)
+    seg = sp.AnalogSimParams(observables=obs, elapsed_time=0.3, sample_timesteps=True, order=2, **kw)
+    whole, first, second, phi_bonds = [], [], [], []
+    for i in range(ntraj):
+        whole.append(np.asarray(tjm.analog_tjm_2((i, st, noise, full, H))[0], dtype=np.float64))
+        rng = rutil.make_trajectory_rng(i, base_seed=31)
+        r1, _, phi = tjm.analog_tjm_2((i, st, noise, seg, H), rng=rng, return_trajectory_state=True)
+        r2, _, phi2 = tjm.analog_tjm_2((i, phi, noise, seg, H), rng=rng, sample_timestep_offset=3, continue_trajectory=True,
+                                       return_trajectory_state=True)
+        first.append(np.asarray(r1, dtype=np.float64))
+        second.append(np.asarray(r2, dtype=np.float64))
+        phi_bonds.append([t.shape[2] for t in phi2.tensors])
+    out["whole"], out["segment1"], out["segment2"], out["phi_bonds"] = np.array(whole), np.array(first), np.array(second), np.array(phi_bonds)
+    save("continuation", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tiny", "rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
     for w in which:

@@ -163,12 +163,29 @@ class TrajectoryBatch:
             pos += 1 + jumped
 
     # ---- drivers --------------------------------------------------------------------
-    def run(self, traj_indices: Sequence[int], initial: MPS | None, native: bool = False, resume: dict | None = None):
+    def run(self, traj_indices: Sequence[int], initial: MPS | None, native: bool = False, resume: dict | None = None, *, sample_at=None,
+            continue_trajectory: bool = False, sample_timestep_offset: int = 0, use_trajectory_rng_for_final_sample: bool = False,
+            rng_pos=None):
         """``native=True`` hands the whole schedule to the C driver (``tjm_engine_run``): same results, no per-step host
-        logic and no dp / jump logs.  The Python schedule below is the readable mirror of analog_tjm.py used by the tests."""
+        logic and no dp / jump logs.  The Python schedule below is the readable mirror of analog_tjm.py used by the tests.
+
+        The keyword options are the reference's continuation options of the drivers (analog_tjm.py:206-255, 369-400), served by the
+        Python schedule: ``sample_at`` = time indices to measure; ``continue_trajectory`` (order 2) = set 0 already holds the
+        handed-off trajectory states phi (``initial`` may be None), no ``initialize``; ``sample_timestep_offset`` shifts the sample
+        streams onto a global timeline; ``rng_pos`` = cursors into the trajectory streams (the reference's external ``rng``: the
+        stream of trajectory t continues where the previous segment left it; the cursors after the run are in ``self.rng_pos``);
+        ``use_trajectory_rng_for_final_sample`` lets the last measurement copy draw from that stream.  The trajectory states stay in
+        set 0 of the engine after the run (``return_trajectory_state``)."""
         e, p = self.e, self.p
         assert len(traj_indices) == e.B
         n_t = len(p.times)
+        self._validate_sample_at(sample_at)
+        self.measure_at = frozenset(int(q) for q in sample_at) if sample_at is not None else None
+        self.sample_offset = int(sample_timestep_offset)
+        self.final_from_traj = bool(use_trajectory_rng_for_final_sample and rng_pos is not None)
+        options = sample_at is not None or continue_trajectory or sample_timestep_offset or rng_pos is not None
+        if continue_trajectory and p.order != 2:
+            raise ValueError("continue_trajectory belongs to the order-2 driver (analog_tjm.py:206-255)")
         has_sched = self.noise is not None and bool(getattr(self.noise, "scheduled_jumps", None))
         if has_sched and p.order != 1:
             raise ValueError(f"scheduled_jumps are only supported for AnalogSimParams(order=1); got order={p.order}.")  # noise_model.py:758-765
@@ -176,7 +193,7 @@ class TrajectoryBatch:
             for j in self.noise.scheduled_jumps:
                 if not np.any(np.isclose(p.times, j["time"], atol=p.dt * 1e-3, rtol=0.0)):
                     raise ValueError(f"Scheduled jump time {j['time']} is not on the simulation time grid.")  # noise_model.py:768-775
-        if native and not self.meta_obs and not has_sched and self.intervals is None:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
+        if native and not options and not self.meta_obs and not has_sched and self.intervals is None:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
             obs = [(o_.first_site, np.asarray(o_.gate.matrix, dtype=np.complex128)) for o_ in self.sorted_obs]
             kw = {}
             if resume is None:
@@ -186,14 +203,16 @@ class TrajectoryBatch:
             return e.run(order=p.order, n_times=n_t, sample_timesteps=p.sample_timesteps, has_noise=self.noise is not None,
                          seed=p.random_seed, traj_indices=traj_indices, observables=obs, **kw)
         cols = n_t if p.sample_timesteps else 1
-        n_draw = 2 * n_t + 2
+        first_pos = np.zeros(e.B, dtype=np.int64) if rng_pos is None else np.asarray(rng_pos, dtype=np.int64).copy()
+        n_draw = 2 * n_t + 4 + int(first_pos.max(initial=0))
         u = np.stack([trajectory_uniforms(p.random_seed, int(t), n_draw) for t in traj_indices])
         e.capacity_overflow(clear=True)
         if resume is None:
             results = np.zeros((e.B, len(self.sorted_obs), cols))
             diagnostics = np.zeros((e.B, 3, cols))
-            e.load_state(initial.tensors, 0)
-            pos = np.zeros(e.B, dtype=np.int64)
+            if not continue_trajectory:
+                e.load_state(initial.tensors, 0)
+            pos = first_pos
             start = (0, 0)
         else:  # continue on this (larger) engine at the time step that ran out of capacity on the previous one
             results, diagnostics = resume["results"], resume["diagnostics"]
@@ -201,10 +220,28 @@ class TrajectoryBatch:
             start = tuple(resume["start"])
         self._out = (results, diagnostics)
         if p.order == 2:
-            self._run_order2(traj_indices, results, diagnostics, u, pos, start)
+            self._run_order2(traj_indices, results, diagnostics, u, pos, start, continue_trajectory)
         else:
             self._run_order1(results, diagnostics, u, pos, start)
+        self.rng_pos = pos
         return results, diagnostics
+
+    def _validate_sample_at(self, sample_at) -> None:
+        """analog_tjm.py:69-84."""
+        if sample_at is None:
+            return
+        n_times = len(self.p.times)
+        for index in sample_at:
+            if isinstance(index, bool) or not isinstance(index, (int, np.integer)) or index < 0 or index >= n_times:
+                raise ValueError(f"sample_at index {index!r} is outside the time grid [0, {n_times}).")
+        if not self.p.sample_timesteps and len(frozenset(sample_at)) > 1:
+            raise ValueError("Selecting multiple sample_at indices requires sample_timesteps=True.")
+
+    def _record(self, j: int) -> bool:
+        """_measure_at (analog_tjm.py:52-66)."""
+        if self.measure_at is not None:
+            return j in self.measure_at
+        return True if self.p.sample_timesteps else j == len(self.p.times) - 1
 
     # ---- storage capacity: per-step rollback of the host schedule (mirror of run_batch in tjm_run.hip) ----
     def _snapshot(self, pos):
@@ -256,7 +293,8 @@ class TrajectoryBatch:
             if first:
                 self._apply_scheduled(first)
                 self._clipped(0, 0, pos)
-            if p.sample_timesteps:
+            self._measure_initial = (0 in self.measure_at) if self.measure_at is not None else p.sample_timesteps
+            if self._measure_initial:
                 self._measure(0, results, diagnostics, 0)
         for j in range(max(1, start[0]), n_t):
             snap = self._snapshot(pos)
@@ -269,39 +307,57 @@ class TrajectoryBatch:
                 else:
                     self._stochastic(0, p.dt, u, pos)
             self._clipped(j, 0, pos, snap)
-            if p.sample_timesteps or j == n_t - 1:
+            if self._record(j):
                 self._measure(0, results, diagnostics, j if p.sample_timesteps else 0)
-        if not p.sample_timesteps and n_t <= 1:
+        if not getattr(self, "_measure_initial", False) and not p.sample_timesteps and n_t <= 1:
             self._measure(0, results, diagnostics, 0)
 
-    def _run_order2(self, traj_indices, results, diagnostics, u, pos, start=(0, 0)):
-        """analog_tjm_2 (analog_tjm.py:206-366), standalone form."""
+    def _run_order2(self, traj_indices, results, diagnostics, u, pos, start=(0, 0), continue_trajectory=False):
+        """analog_tjm_2 (analog_tjm.py:206-366) with its continuation options."""
         e, p = self.e, self.p
         n_t = len(p.times)
+        record = self._record
 
-        def record(j):
-            return True if p.sample_timesteps else j == n_t - 1
-
-        def sample(j):
+        def sample(j, interval):
             if not record(j):
                 return
             e.copy_state(1, 0)  # psi = deepcopy(phi)
-            self._tdvp(1, j - 1)  # capture_sample(phi, j, interval j - 1), analog_tjm.py:347, 360
+            self._tdvp(1, interval)  # capture_sample(phi, j, operator), analog_tjm.py:296-313
             e.dissipate(p.dt / 2, 1)
-            us = np.stack([sample_uniforms(p.random_seed, int(t), j) for t in traj_indices])
             n_dp, n_jump, keys = len(self.dp_log), len(self.jump_log), set(self.schmidt)
-            self._stochastic(1, p.dt, us, None)
+            before = pos.copy()
+            if self.final_from_traj and j == n_t - 1:
+                self._stochastic(1, p.dt, u, pos)  # the last measurement copy draws from the trajectory stream (programs' final segment)
+            else:
+                us = np.stack([sample_uniforms(p.random_seed, int(t), j + self.sample_offset) for t in traj_indices])
+                self._stochastic(1, p.dt, us, None)
             if e.capacity_overflow():  # phi is untouched: only the sampling of step j is repeated on the larger engine
                 del self.dp_log[n_dp:]
                 del self.jump_log[n_jump:]
+                pos[:] = before
                 for key in set(self.schmidt) - keys:
                     del self.schmidt[key]
-                self._clipped(j if j >= 2 else 0, 1 if j >= 2 else 0, pos)
+                first = 1 if continue_trajectory else 2
+                self._clipped(j if j >= first else 0, 1 if j >= first else 0, pos)
             self._measure(1, results, diagnostics, j if p.sample_timesteps else 0)
 
         if n_t == 1:
             if record(0):
                 self._measure(0, results, diagnostics, 0)
+            return
+        if continue_trajectory:
+            # mid-Trotter hand-off: the junction is measured again on the global sample timeline without touching phi, then every
+            # time step is a step_through with the static operator (analog_tjm.py:323-334)
+            if start[0] == 0:
+                sample(0, 0)
+            for j in range(max(1, start[0]), n_t):
+                if not (j == start[0] and start[1] == 1):
+                    snap = self._snapshot(pos)
+                    self._tdvp(0, 0)
+                    e.dissipate(p.dt, 0)
+                    self._stochastic(0, p.dt, u, pos)
+                    self._clipped(j, 0, pos, snap)
+                sample(j, 0)
             return
         if start[0] == 0:
             if record(0):
@@ -309,7 +365,7 @@ class TrajectoryBatch:
             e.dissipate(p.dt / 2, 0)
             self._stochastic(0, p.dt, u, pos)
             self._clipped(0, 0, pos)  # before the first full step: nothing to keep
-            sample(1)
+            sample(1, 0)
         for j in range(max(2, start[0]), n_t):
             if not (j == start[0] and start[1] == 1):
                 snap = self._snapshot(pos)
@@ -317,7 +373,7 @@ class TrajectoryBatch:
                 e.dissipate(p.dt, 0)
                 self._stochastic(0, p.dt, u, pos)
                 self._clipped(j, 0, pos, snap)
-            sample(j)
+            sample(j, j - 1)
 
 
 class DigitalBatch:
