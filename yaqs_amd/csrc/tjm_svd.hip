@@ -19,6 +19,7 @@
 // workgroups; trajectories whose sweep performed no rotation are flagged done and skipped.
 // The isometric output is always read from W and the sigma-weighted output from the rotated
 // X for the two-site split, so that path never divides by a singular value.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <utility>
@@ -865,6 +866,11 @@ __global__ void svd_sweep_check_kernel(int* nrot, int* done, int* n_active, int 
   nrot[b] = 0;
 }
 
+__global__ void svd_iota_kernel(int* out, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = t;
+}
+
 __global__ void svd_reset_kernel(int* nrot, int* done, int nb0, const int* ids) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nb0) return;
@@ -1607,6 +1613,7 @@ size_t svd_carve(SvdWorkspace& w, char* base, int max_dim, int B) {
   w.nrot = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   w.done = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   w.n_active = reinterpret_cast<int*>(take(256));
+  w.iota = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   return off;
 }
 
@@ -1711,19 +1718,34 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   const size_t lds16x = (size_t)2 * NB * rx_top * sizeof(cplx) + 2 * NB * sizeof(double) + 16 * sizeof(int);
   g.rec = accumulate ? w.rec : nullptr;
   const int max_sweeps = 40;
+  // Sub-batches (TJM_SVD_CHUNK=n trajectories, default off): all sweeps of one chunk before the next, so that the chunk's stacked
+  // matrices (1 MiB each at d*chi = 256) stay resident in the 256 MiB Infinity Cache between the rounds instead of streaming from HBM.
+  static const int chunk_env = getenv("TJM_SVD_CHUNK") ? atoi(getenv("TJM_SVD_CHUNK")) : 0;
+  const int chunk = (chunk_env > 0 && chunk_env < src.nb0 && w.iota != nullptr) ? chunk_env : src.nb0;
+  const int* all_ids = src.ids;
+  if (chunk < src.nb0 && all_ids == nullptr) {
+    hipLaunchKernelGGL(svd_iota_kernel, dim3((src.nb0 + 255) / 256), dim3(256), 0, s, w.iota, src.nb0);
+    all_ids = w.iota;
+  }
   int sweep = 0;
-  int n_live = src.nb0;
-  bool converged = false;
-  for (; sweep < max_sweeps && !converged; ++sweep) {
+  bool converged = true;
+  for (int c0 = 0; c0 < src.nb0; c0 += chunk) {
+  const int nb = std::min(chunk, src.nb0 - c0);
+  const int tbc = (nb + 255) / 256;
+  g.ids = all_ids ? all_ids + c0 : nullptr;
+  int sweep_c = 0;
+  int n_live = nb;
+  bool conv_c = false;
+  for (; sweep_c < max_sweeps && !conv_c; ++sweep_c) {
     ++g.clock;
     g.mode = 0;
-    if (big) hipLaunchKernelGGL(jacobi_diag_kernel<16>, dim3(g.nblk, src.nb0), dim3(256), lds, s, g);
-    else hipLaunchKernelGGL(jacobi_diag_kernel<8>, dim3(g.nblk, src.nb0), dim3(256), lds, s, g);
+    if (big) hipLaunchKernelGGL(jacobi_diag_kernel<16>, dim3(g.nblk, nb), dim3(256), lds, s, g);
+    else hipLaunchKernelGGL(jacobi_diag_kernel<8>, dim3(g.nblk, nb), dim3(256), lds, s, g);
     if (tile16) {  // pairs between the two 8-column halves of every 16-column block
       ++g.clock;
       g.mode = 1;
-      if (big) hipLaunchKernelGGL(jacobi_cross_kernel<16>, dim3(g.nblk / 2, src.nb0), dim3(512), lds, s, g);
-      else hipLaunchKernelGGL(jacobi_cross_kernel<8>, dim3(g.nblk / 2, src.nb0), dim3(512), lds, s, g);
+      if (big) hipLaunchKernelGGL(jacobi_cross_kernel<16>, dim3(g.nblk / 2, nb), dim3(512), lds, s, g);
+      else hipLaunchKernelGGL(jacobi_cross_kernel<8>, dim3(g.nblk / 2, nb), dim3(512), lds, s, g);
       g.mode = 0;
     }
     for (int r = 0; r < nrounds; ++r) {
@@ -1741,7 +1763,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
         TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot], s));
       }
       if (split16) {
-        const dim3 gridx(npairs, src.nb0), blockx(512);
+        const dim3 gridx(npairs, nb), blockx(512);
         switch (rx_top / 64) {  // row groups of 64 held in registers
           case 1: hipLaunchKernelGGL(jacobi_cross16x_kernel<1>, gridx, blockx, lds16x, s, g); break;
           case 2: hipLaunchKernelGGL(jacobi_cross16x_kernel<2>, gridx, blockx, lds16x, s, g); break;
@@ -1756,20 +1778,24 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
           TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot + 1], s));
           g_prof.pending.emplace_back(slot, (double)npairs * n_live * 4.0 * NB * rx_top * sizeof(cplx) * 2.0);
         }
-        if (accumulate) hipLaunchKernelGGL(jacobi_cross16w_kernel, dim3(npairs, ncols_pad / 64, src.nb0), dim3(64), 0, s, g, rx_top);
-      } else if (tile16) hipLaunchKernelGGL(jacobi_cross16_kernel<8>, dim3(npairs, src.nb0), dim3(512), lds16, s, g);
-      else if (big) hipLaunchKernelGGL(jacobi_cross_kernel<16>, dim3(npairs, src.nb0), dim3(512), lds, s, g);
-      else hipLaunchKernelGGL(jacobi_cross_kernel<8>, dim3(npairs, src.nb0), dim3(512), lds, s, g);
+        if (accumulate) hipLaunchKernelGGL(jacobi_cross16w_kernel, dim3(npairs, ncols_pad / 64, nb), dim3(64), 0, s, g, rx_top);
+      } else if (tile16) hipLaunchKernelGGL(jacobi_cross16_kernel<8>, dim3(npairs, nb), dim3(512), lds16, s, g);
+      else if (big) hipLaunchKernelGGL(jacobi_cross_kernel<16>, dim3(npairs, nb), dim3(512), lds, s, g);
+      else hipLaunchKernelGGL(jacobi_cross_kernel<8>, dim3(npairs, nb), dim3(512), lds, s, g);
     }
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 2 * sizeof(int), s));
-    hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tb), dim3(256), 0, s, w.nrot, w.done, w.n_active, src.nb0, src.ids);
+    hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tbc), dim3(256), 0, s, w.nrot, w.done, w.n_active, nb, g.ids);
     TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     TJM_HIP_CHECK(hipStreamSynchronize(s));
-    converged = (*w.h_pinned == 0);
-    if (g_debug && src.ncols >= 128) fprintf(stderr, "[svd] ncols %d rx %d sweep %d live %d rotations %d\n", src.ncols, src.rx, sweep, w.h_pinned[0], w.h_pinned[1]);
+    conv_c = (*w.h_pinned == 0);
+    if (g_debug && src.ncols >= 128) fprintf(stderr, "[svd] ncols %d rx %d sweep %d live %d rotations %d\n", src.ncols, src.rx, sweep_c, w.h_pinned[0], w.h_pinned[1]);
     n_live = *w.h_pinned;
     if (g_prof.every > 0) prof_collect();
   }
+  sweep = std::max(sweep, sweep_c);
+  converged = converged && conv_c;
+  }
+  g.ids = src.ids;
   if (sweeps_out) *sweeps_out = sweep;
   TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 2, 0, sizeof(int), s));
   hipLaunchKernelGGL(svd_finish_kernel, dim3(src.nb0), dim3(256), 0, s, tr, w, ncols_pad, rx_top, rtot, src.ids);
