@@ -1809,8 +1809,8 @@ def test_engine_runs_on_the_device_that_owns_its_workspace():
 
 
 @pytest.mark.skipif(os.environ.get("TJM_TEST_CHI512_ENGINE") is None,
-                    reason="DANGEROUS: the engine at chi = 512 took the GPU box down twice in round 2 (cause unknown; the 1024 x 1024 split "
-                           "kernels themselves pass). Run only on a box you can afford to lose: TJM_TEST_CHI512_ENGINE=1")
+                    reason="engine at chi = 512: not yet run on a GPU (round 2 lost two boxes to the FIRST version of this test, whose "
+                           "oracle check contracted chi^4 transfer tensors = 1.1 TB of host memory; fixed, to be verified: TJM_TEST_CHI512_ENGINE=1)")
 def test_bonds_up_to_512_gate_shift_and_tdvp_match_oracle():
     """A 20-site chi = 512 saturated Haar state (centre bonds 512, two-site matrices 1024 x 1024, and the 512 x 1024 pairs next to
     them): one TEBD gate with truncation at the centre (digital_tjm.py:455-533), QR and SVD centre shifts, and one two-site TDVP
@@ -1837,9 +1837,10 @@ def test_bonds_up_to_512_gate_shift_and_tdvp_match_oracle():
     out = e.export_state(0)
     assert [t.shape[2] for t in out] == [t.shape[2] for t in ref.tensors]
     M = e.site_moments()
-    for s_ in (0, 8, 9, 10, 11, 19):
+    zref = ref.site_expectations(Z).real  # boundary-matrix contraction: chi^3 memory (full_expect builds chi^4 transfer tensors)
+    for s_ in range(L):
         z = (M[s_, 0, 0, 0] - M[s_, 0, 1, 1]).real
-        assert abs(z - ref.full_expect(Z, [s_]).real) < 1e-9, s_
+        assert abs(z - zref[s_]) < 1e-9, s_
     # --- SVD shifts (discarded weight 1e-12) from the gate's right site down to site 0, QR back up: gauge moves of the same state
     for i in range(10, 0, -1):
         check(lib.tjm_engine_center_shift(e.h, 0, i, -1, 1), "svd shift")
@@ -1854,9 +1855,10 @@ def test_bonds_up_to_512_gate_shift_and_tdvp_match_oracle():
     ref = o.MPSState([t.copy() for t in st.tensors], 0)
     o.tdvp(ref, mpo, o.Params(dt=0.05, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-10))
     M = e.site_moments()
+    zref = ref.site_expectations(Z).real
     for s_ in range(L):
         z = (M[s_, 0, 0, 0] - M[s_, 0, 1, 1]).real
-        assert abs(z - ref.full_expect(Z, [s_]).real) < 1e-8, s_
+        assert abs(z - zref[s_]) < 1e-8, s_
     assert [t.shape[2] for t in e.export_state(0)] == [t.shape[2] for t in ref.tensors]
     e.close()
 
