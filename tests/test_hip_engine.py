@@ -711,266 +711,6 @@ def test_growth_continues_mid_run_and_splits_pieces(monkeypatch, order, sample_t
         assert all(st[1] in (0, 1) for st in resumed)
 
 
-def test_the_reference_own_analog_test_reads_the_same():
-    """tests/test_simulator.py:159-207 of the reference, line by line with this package's names in place of ``mqt.yaqs``: same
-    objects, same call, the reference's five pinned <Z> values (its own tolerance)."""
-    from yaqs_amd.api import AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, Z as Zg
-    from yaqs_amd.tjm import Simulator
-
-    length = 5
-    initial_state = State(length, initial="zeros")
-    H = Hamiltonian.ising(length, J=1, g=0.5)
-    sim_params = AnalogSimParams(
-        observables=[Observable(Zg(), site) for site in range(length)],
-        elapsed_time=1,
-        dt=0.1,
-        num_traj=10,
-        max_bond_dim=4,
-        svd_threshold=1e-6,
-        order=2,
-        sample_timesteps=False,
-        random_seed=42,
-    )
-    gamma = 0.1
-    noise_model = NoiseModel([{"name": name, "sites": [i], "strength": gamma} for i in range(length) for name in ["lowering", "pauli_z"]])
-    result = Simulator(show_progress=False).run(initial_state, H, sim_params, noise_model)
-    expected_z = [0.748947146695782, 0.8720515025769692, 0.8652609567462763, 0.8673233347433466, 0.6872036335377433]
-    for i in range(len(result.observables)):
-        assert result.expectation_values[i] is not None
-        assert len(result.trajectories[i]) == sim_params.num_traj
-        assert len(result.expectation_values[i]) == 1
-        assert np.isclose(np.real(result.expectation_values[i][0]), expected_z[i], atol=2e-4)
-        assert np.isclose(np.real(result.expectation_values[i][0]), expected_z[i], atol=1e-8)  # in fact to rounding
-
-
-@pytest.mark.parametrize("case", ["test_two_site_correlator_left_boundary", "test_two_site_correlator_center", "test_two_site_correlator_right_boundary"])
-def test_the_reference_two_site_correlator_series(case):
-    """tests/test_simulator.py:858-1188 of the reference with this package's names: closed 4-site Ising chain from |0000>, default
-    preset, <XX>, <YY>, <ZZ> of a neighbouring pair at 21 time points against the reference's pinned series (its tolerance 1e-3;
-    vectors extracted as data by tools/extract_reference_test_vectors.py)."""
-    import json
-
-    from yaqs_amd.api import XX, YY, ZZ, AnalogSimParams, Hamiltonian, Observable, State
-    from yaqs_amd.tjm import Simulator
-
-    g = json.load(open(os.path.join(GOLDEN, "reference_two_site_correlators.json")))[case]
-    H_0 = Hamiltonian.ising(g["L"], g["J"], g["g"])
-    state = State(g["L"], initial="zeros")
-    sim_params = AnalogSimParams(
-        observables=[Observable(XX(), g["sites"]), Observable(YY(), g["sites"]), Observable(ZZ(), g["sites"])],
-        elapsed_time=g["elapsed_time"],
-        dt=g["dt"],
-        max_bond_dim=g["max_bond_dim"],
-        sample_timesteps=True,
-    )
-    result = Simulator(show_progress=False).run(state, H_0, sim_params)
-    for k, name in enumerate(("xx", "yy", "zz")):
-        assert result.expectation_values[k] is not None
-        np.testing.assert_allclose(result.expectation_values[k], np.array(g[name]), atol=1e-3)
-
-
-def test_the_reference_observable_order_test_reads_the_same():
-    """tests/test_simulator.py:1292-1324 of the reference with this package's names (the qiskit Statevector expectation replaced by
-    the same dense formula): user order of the observables on Result, values against the dense final state."""
-    from yaqs_amd.api import AnalogSimParams, Hamiltonian, Observable, State, X as Xg, Z as Zg
-    from yaqs_amd.tjm import Simulator
-
-    state = State(2, initial="zeros")
-    H = Hamiltonian.ising(2, J=1.0, g=0.7)
-    requested = [Observable(Zg(), 1), Observable(Xg(), 0), Observable(Zg(), 0)]
-    sim_params = AnalogSimParams(observables=requested, elapsed_time=0.1, dt=0.1, num_traj=1, get_state=True, sample_timesteps=False, preset="exact")
-    result = Simulator(parallel=False, show_progress=False).run(state, H, sim_params)
-    assert result.output_state is not None
-    vec = result.output_state.mps.to_vec()
-    n = int(np.log2(vec.size))
-    assert len(result.observables) == len(requested)
-    for i, (got_obs, req_obs) in enumerate(zip(result.observables, requested)):
-        assert got_obs.gate.name == req_obs.gate.name
-        assert got_obs.sites == req_obs.sites
-        site = got_obs.sites[0] if isinstance(got_obs.sites, list) else got_obs.sites
-        op = np.kron(np.kron(np.eye(2 ** (n - 1 - site)), got_obs.gate.matrix), np.eye(2 ** site))  # site 0 = least significant (qiskit label order)
-        expected = float(np.real(np.vdot(vec, op @ vec)))
-        got = float(np.real(result.expectation_values[i][-1]))
-        assert got == pytest.approx(expected, abs=1e-10)
-        assert result.output_state.mps.expect(got_obs) == pytest.approx(expected, abs=1e-10)
-    # a two-site observable without exchange symmetry pins the (s_i, s_{i+1}) index order of the measured value and of MPS.expect;
-    # Hamiltonian(matrix=...) (hamiltonian.py:49-120) must be the same operator as the MPO it was made from
-    from yaqs_amd.api import BaseGate
-
-    xz = Observable(BaseGate("xz", np.kron(Xg().matrix, Zg().matrix), interaction=2), [0, 1])
-    p2 = AnalogSimParams(observables=[xz], elapsed_time=0.3, dt=0.1, num_traj=1, get_state=True, sample_timesteps=False, preset="exact")
-    H3 = Hamiltonian.heisenberg(3, 1.0, 0.8, 0.5, 0.3)
-    r2 = Simulator(show_progress=False).run(State(3, initial="x+"), H3, p2)
-    assert float(r2.expectation_values[0][-1]) == pytest.approx(r2.output_state.mps.expect(xz), abs=1e-10)
-    dense = Hamiltonian(matrix=o.mpo_to_matrix(H3.tensors))
-    r3 = Simulator(show_progress=False).run(State(3, initial="x+"), dense, p2)
-    assert float(r3.expectation_values[0][-1]) == pytest.approx(float(r2.expectation_values[0][-1]), abs=1e-9)
-
-
-def test_the_reference_scheduled_jump_at_t0_tests_read_the_same():
-    """tests/test_simulator.py:1802-1850 of the reference with this package's names: an order-1 scheduled X jump at t = 0 on a
-    single qubit with H = 0 is applied before the initial sample; also with elapsed_time = 0 and final-time sampling."""
-    from yaqs_amd.api import AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, Z as Zg
-    from yaqs_amd.tjm import Simulator
-
-    hamiltonian = Hamiltonian(matrix=np.zeros((2, 2), dtype=complex))
-    noise = NoiseModel(scheduled_jumps=[{"time": 0.0, "sites": [0], "name": "x"}])
-    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=0.3, num_traj=1, order=1, get_state=True)
-    result = Simulator(show_progress=False).run(State(1, initial="zeros"), hamiltonian, sim_params, noise)
-    z = np.asarray(result.expectation_values[0], dtype=float)
-    np.testing.assert_allclose(z, -1.0, atol=1e-10)
-    assert result.output_state is not None
-    final_z = float(result.output_state.mps.expect(Observable(Zg(), 0)))
-    assert final_z == pytest.approx(-1.0)
-    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=0.0, num_traj=1, order=1, sample_timesteps=False,
-                                 get_state=True)
-    result = Simulator(show_progress=False).run(State(1, initial="zeros"), hamiltonian, sim_params, noise)
-    z = float(np.asarray(result.expectation_values[0], dtype=complex).reshape(-1)[0].real)
-    assert result.output_state is not None
-    final_z = float(result.output_state.mps.expect(Observable(Zg(), 0)))
-    assert z == pytest.approx(-1.0)
-    assert final_z == pytest.approx(-1.0)
-
-
-def test_the_reference_scheduled_jump_tests_read_the_same():
-    """tests/test_simulator.py:1327-1408 of the reference with this package's names: a scheduled X flip of a single qubit at
-    t = 0.5 and a scheduled XX jump of two qubits at t = 0.2, vacuum Hamiltonian."""
-    from yaqs_amd.api import ZZ, AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, Z as Zg
-    from yaqs_amd.tjm import Simulator
-
-    L, T, dt, jump_time = 1, 1.0, 0.1, 0.5
-    state = State(L, initial="zeros")
-    noise_model = NoiseModel(scheduled_jumps=[{"time": jump_time, "sites": [0], "name": "x"}])
-    sim_params = AnalogSimParams(elapsed_time=T, dt=dt, num_traj=1, observables=[Observable(Zg(), sites=0)])
-    hamiltonian = Hamiltonian.ising(L, 0.0, 0.0)
-    result = Simulator(show_progress=False).run(state, hamiltonian, sim_params, noise_model=noise_model)
-    results = result.expectation_values[0]
-    assert results is not None
-    np.testing.assert_allclose(results[:5], 1.0, atol=1e-10)
-    np.testing.assert_allclose(results[5:], -1.0, atol=1e-10)
-
-    L, T, dt, jump_time = 2, 0.4, 0.1, 0.2
-    noise_model = NoiseModel(scheduled_jumps=[{"time": jump_time, "sites": [0, 1], "name": "crosstalk_xx"}])
-    hamiltonian = Hamiltonian.ising(L, 0.0, 0.0)
-    sim_params = AnalogSimParams(elapsed_time=T, dt=dt, num_traj=1, observables=[Observable(ZZ(), sites=[0, 1])])
-    result = Simulator(show_progress=False).run(State(L, initial="zeros"), hamiltonian, sim_params, noise_model=noise_model)
-    assert result.expectation_values[0] is not None
-    np.testing.assert_allclose(result.expectation_values[0], 1.0, atol=1e-10)  # ZZ is blind to the double flip
-    sim_params = AnalogSimParams(observables=[Observable(Zg(), sites=0)], elapsed_time=T, dt=dt, num_traj=1)
-    result = Simulator(show_progress=False).run(State(L, initial="zeros"), hamiltonian, sim_params, noise_model=noise_model)
-    results = result.expectation_values[0]
-    np.testing.assert_allclose(results[:2], 1.0, atol=1e-10)
-    np.testing.assert_allclose(results[2:], -1.0, atol=1e-10)
-
-
-@pytest.mark.parametrize(("elapsed_time", "sample_timesteps"), [(0.0, True), (0.0, False), (0.1, False)])
-def test_the_reference_order_2_short_run_tests_read_the_same(elapsed_time, sample_timesteps):
-    """tests/test_simulator.py:1845-1929 of the reference with this package's names: order-2 runs with elapsed_time in {0, dt}, and a
-    zero-duration final-only run that must not apply the initial half-step of noise."""
-    from yaqs_amd.api import AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, Z as Zg
-    from yaqs_amd.tjm import Simulator
-
-    hamiltonian = Hamiltonian.ising(2, J=1.0, g=0.5)
-    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=elapsed_time, num_traj=1, order=2,
-                                 sample_timesteps=sample_timesteps, get_state=True, random_seed=0)
-    result = Simulator(show_progress=False).run(State(2, initial="zeros"), hamiltonian, sim_params)
-    z = np.asarray(result.expectation_values[0], dtype=complex).reshape(-1)
-    assert result.output_state is not None
-    assert np.isfinite(z.real).all()
-    assert np.all(np.abs(z.real) > 0.5)
-    if elapsed_time == pytest.approx(0.1) and not sample_timesteps:
-        sampled = Simulator(show_progress=False).run(
-            State(2, initial="zeros"), hamiltonian,
-            AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=0.1, num_traj=1, order=2, sample_timesteps=True, get_state=True,
-                            random_seed=0))
-        z_sampled_final = float(np.asarray(sampled.expectation_values[0], dtype=complex).reshape(-1)[-1].real)
-        assert float(z.real[0]) == pytest.approx(z_sampled_final, abs=1e-10)
-    if elapsed_time == 0.0:
-        h0 = Hamiltonian(matrix=np.zeros((2, 2), dtype=complex))
-        noise = NoiseModel([{"name": "lowering", "sites": [0], "strength": 1.0}])
-        run = Simulator(show_progress=False).run(
-            State(1, initial="x+"), h0,
-            AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=0.0, num_traj=1, order=2, sample_timesteps=sample_timesteps,
-                            random_seed=0), noise)
-        assert float(np.asarray(run.expectation_values[0], dtype=complex).reshape(-1)[0].real) == pytest.approx(0.0, abs=1e-10)
-
-
-def test_the_reference_get_state_and_long_range_tests_read_the_same():
-    """tests/test_simulator.py:262-299 (the final state vector of a closed two-site run, orders 1 and 2, against the reference's
-    pinned vector) and :2068-2083 (the documented long-range crosstalk channel runs on the analog MPS path), with this package's names."""
-    from yaqs_amd.api import AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, X as Xg, Z as Zg
-    from yaqs_amd.tjm import Simulator
-
-    for order in [1, 2]:
-        length = 2
-        initial_state = State(length, initial="zeros")
-        H = Hamiltonian.ising(length, J=1, g=0.5)
-        sim_params = AnalogSimParams(observables=[Observable(Xg(), length // 2)], elapsed_time=1, dt=0.1, num_traj=1, max_bond_dim=4,
-                                     svd_threshold=1e-6, order=order, get_state=True, sample_timesteps=False)
-        result = Simulator(show_progress=False).run(initial_state, H, sim_params)
-        assert result.output_state is not None
-        assert isinstance(result.output_state, State)
-        sv = result.output_state.mps.to_vec()
-        expected = [3.48123000e-01 + 0.76996349j, 0.00000000e00 + 0.349228j, 0.00000000e00 + 0.349228j, -1.92179306e-01 - 0.07150749j]
-        fidelity = np.abs(np.vdot(sv, expected)) ** 2
-        np.testing.assert_allclose(1, fidelity)
-    hamiltonian = Hamiltonian.ising(3, J=1.0, g=0.5)
-    noise = NoiseModel([{"name": "longrange_crosstalk_xy", "sites": [0, 2], "strength": 0.05}])
-    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], dt=0.1, elapsed_time=0.2, num_traj=2, random_seed=0)
-    result = Simulator(show_progress=False).run(State(3), hamiltonian, sim_params, noise)
-    assert result.expectation_values[0].shape[0] >= 1
-
-
-@pytest.mark.parametrize("order", [1, 2])
-@pytest.mark.parametrize("sample_timesteps", [True, False])
-def test_the_reference_analog_tjm_shape_test_reads_the_same(order, sample_timesteps):
-    """tests/analog/test_analog_tjm.py:134-163 of the reference with this package's names: per-observable trajectories have one column
-    without intermediate sampling and len(times) columns with it."""
-    from yaqs_amd.api import AnalogSimParams, Hamiltonian, Observable, State, Z as Zg
-    from yaqs_amd.tjm import Simulator
-
-    length = 5
-    state = State(length, initial="zeros")
-    hamiltonian = Hamiltonian.ising(length, J=1.0, g=0.5)
-    observables = [Observable(Zg(), site) for site in range(length)]
-    sim_params = AnalogSimParams(observables=observables, elapsed_time=0.2, dt=0.2, num_traj=1, max_bond_dim=2, order=order,
-                                 sample_timesteps=sample_timesteps)
-    result = Simulator(parallel=False, show_progress=False).run(state, hamiltonian, sim_params)
-    expected_cols = len(sim_params.times) if sample_timesteps else 1
-    assert result.expectation_values is not None
-    assert result.trajectories is not None
-    for traj in result.trajectories:
-        assert traj.shape == (sim_params.num_traj, expected_cols)
-
-
-@pytest.mark.parametrize("two_site_process", ["crosstalk_xx", "lowering_two"])
-def test_the_reference_two_site_jump_smoke_test_reads_the_same(two_site_process):
-    """tests/analog/test_analog_tjm.py:166-195 of the reference with this package's names: one-site plus one adjacent two-site jump
-    process (a Pauli pair and the non-Pauli ``lowering_two``), 20 trajectories, order 2."""
-    from yaqs_amd.api import AnalogSimParams, Hamiltonian, NoiseModel, Observable, State, Z as Zg
-    from yaqs_amd.tjm import Simulator
-
-    length = 2
-    hamiltonian = Hamiltonian.ising(length, 1.0, 0.5)
-    state = State(length, initial="zeros")
-    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], elapsed_time=0.1, dt=0.1, num_traj=20, max_bond_dim=8, order=2,
-                                 sample_timesteps=False, random_seed=42)
-    noise = NoiseModel([{"name": "pauli_x", "sites": [0], "strength": 0.02}, {"name": two_site_process, "sites": [0, 1], "strength": 0.01}])
-    result = Simulator(parallel=False, show_progress=False).run(state, hamiltonian, sim_params, noise)
-    results = result.expectation_values[0]
-    assert results is not None
-    z_mean = np.real(results)
-    assert np.isfinite(z_mean).all()
-    assert np.all(np.abs(z_mean) <= 1.0 + 1e-6)
-    # beyond the smoke test: the same run through the oracle, trajectory by trajectory
-    op = o.Params(observables=[o.Obs(Z, 0)], elapsed_time=0.1, dt=0.1, max_bond_dim=8, svd_threshold=1e-6, krylov_tol=1e-4, order=2,
-                  sample_timesteps=False, random_seed=42)
-    on = [o.make_process(q["name"], q["sites"], q["strength"], matrix=q.get("matrix"), factors=q.get("factors")) for q in noise.processes]
-    for t in range(20):
-        r, _, _ = o.run_trajectory(t, o.MPSState.product(length, "zeros"), on, op, o.ising_mpo(length, 1.0, 0.5))
-        assert np.allclose(result.trajectories[0][t], r[0], atol=1e-8), t
-
-
 def test_ensemble_mean_converges_to_the_lindblad_solution():
     """The physics the method exists for (cf. tests/analog/test_analog_tjm.py:323-379 of the reference, TJM against a dense solver
     within 0.03): the mean over 16384 trajectories of a 4-site dissipative Ising chain (amplitude damping and dephasing on every site)
@@ -1025,86 +765,6 @@ def test_reruns_are_bit_identical_and_independent_of_the_batching():
     assert np.array_equal(runs[0], runs[1])                      # rerun: atol = 0
     for other in runs[2:]:
         assert np.array_equal(runs[0], other)                    # 11 at once, chunks of 3 / 7, one by one: the same bits
-
-
-def test_the_reference_result_tests_read_the_same():
-    """tests/core/data_structures/test_result.py:41-166 of the reference with this package's names (the qiskit circuit replaced by the
-    gate layers of the same Ising circuit): what a Result holds after an analog run, after a shots-only and an observables-only
-    circuit run, the sampled noise model, untouched sim_params / observables, a pickle round trip."""
-    import pickle
-
-    from yaqs_amd import AnalogSimParams, DigitalSimParams, Hamiltonian, NoiseModel, Observable, Result, Simulator, State
-    from yaqs_amd.api import Z as Zg, ising_trotter_layers
-
-    length = 2
-    H = Hamiltonian.ising(length, J=1.0, g=0.5)
-    sim_params = AnalogSimParams(observables=[Observable(Zg(), 0)], elapsed_time=0.1, dt=0.1, num_traj=1, get_state=True, sample_timesteps=False)
-    result = Simulator(parallel=False, show_progress=False).run(State(length, initial="zeros"), H, sim_params)
-    assert isinstance(result, Result)
-    assert result.sim_params is sim_params
-    assert result.observables is not sim_params.observables
-    assert len(result.observables) == 1 and len(result.expectation_values) == 1 and len(result.trajectories) == 1
-    assert result.output_state is not None
-    assert result.noise_model is None and result.counts is None
-    assert result.multi_time_times is None and result.multi_time_results is None
-    assert result.runtime_cost is not None and result.max_bond is not None and result.total_bond is not None
-    assert result.times is not None and len(result.runtime_cost) == len(result.times)
-
-    circuit = ising_trotter_layers(2, 1, 0.5, 0.1, 1)
-    shot_params = DigitalSimParams(shots=16, max_bond_dim=4)
-    shot_result = Simulator(parallel=False, show_progress=False).run(State(2, initial="zeros"), circuit, shot_params)
-    assert shot_result.counts is not None and sum(shot_result.counts.values()) == shot_params.shots
-    assert shot_result.runtime_cost is None and shot_result.max_bond is None and shot_result.total_bond is None
-    obs_params = DigitalSimParams(observables=[Observable(Zg(), 0)], num_traj=1, max_bond_dim=4)
-    obs_result = Simulator(parallel=False, show_progress=False).run(State(2, initial="zeros"), circuit, obs_params)
-    assert obs_result.counts is None
-    assert obs_result.runtime_cost is not None and obs_result.max_bond is not None and obs_result.total_bond is not None
-
-    noise_model = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 1e-3} for i in range(2)])
-    noisy_params = DigitalSimParams(shots=4, max_bond_dim=4, random_seed=0)
-    noisy = Simulator(parallel=False, show_progress=False).run(State(2, initial="zeros"), circuit, noisy_params, noise_model)
-    assert noisy.noise_model is not None
-    assert not hasattr(noisy_params, "noise_model")
-
-    user_obs = Observable(Zg(), 0)
-    many = AnalogSimParams(observables=[user_obs], elapsed_time=0.1, dt=0.1, num_traj=1000, get_state=True, sample_timesteps=False)
-    res = Simulator(parallel=False, show_progress=False).run(State(length, initial="zeros"), H, many)
-    assert many.num_traj == 1000 and not hasattr(user_obs, "results")
-    assert res.expectation_values[0] is not None and res.observables[0] is not user_obs
-
-    restored = pickle.loads(pickle.dumps(result))
-    assert isinstance(restored, Result) and isinstance(restored.sim_params, AnalogSimParams) and len(restored.observables) == 1
-    np.testing.assert_allclose(np.asarray(restored.expectation_values[0]), np.asarray(result.expectation_values[0]))
-
-
-def test_the_reference_piecewise_hamiltonian_tests_read_the_same():
-    """tests/test_simulator.py:2086-2150 of the reference with this package's names: one piecewise analog run equals two sequential
-    static runs (one-qubit X drives, one-site TDVP, the final state of the first run feeding the second); durations off the dt grid
-    are rejected."""
-    from yaqs_amd.api import AnalogSimParams, Hamiltonian, Observable, State
-    from yaqs_amd.tjm import Simulator
-
-    def _x_drive(amplitude):
-        return Hamiltonian.pauli(length=1, one_body=[(amplitude, "X")])
-
-    first, second = _x_drive(1.0), _x_drive(2.0)
-    sim = Simulator(parallel=False, show_progress=False)
-    first_params = AnalogSimParams(observables=[Observable("z", 0)], elapsed_time=0.1, dt=0.1, order=1, tdvp_mode="1site", get_state=True,
-                                   sample_timesteps=False)
-    first_result = sim.run(State(1, initial="zeros"), first, first_params)
-    assert first_result.output_state is not None
-    second_params = AnalogSimParams(observables=[Observable("z", 0)], elapsed_time=0.1, dt=0.1, order=1, tdvp_mode="1site", sample_timesteps=False)
-    sequential = sim.run(first_result.output_state, second, second_params)
-    piecewise = Hamiltonian.piecewise([(first, 0.1), (second, 0.1)])
-    combined = sim.run(State(1, initial="zeros"), piecewise,
-                       AnalogSimParams(observables=[Observable("z", 0)], elapsed_time=0.2, dt=0.1, order=1, tdvp_mode="1site", sample_timesteps=False))
-    np.testing.assert_allclose(np.asarray(combined.expectation_values[0], dtype=np.complex128),
-                               np.asarray(sequential.expectation_values[0], dtype=np.complex128), atol=1e-10)
-    # the exact value: |0> under exp(-i 0.1 X) then exp(-i 0.2 X): <Z> = cos(2 * 0.3)
-    assert float(combined.expectation_values[0][-1]) == pytest.approx(np.cos(0.6), abs=1e-9)
-    params = AnalogSimParams(observables=[Observable("z", 0)], elapsed_time=0.2, dt=0.1, order=1, tdvp_mode="1site")
-    with pytest.raises(ValueError, match="integer multiple"):
-        sim.run(State(1, initial="zeros"), Hamiltonian.piecewise([(first, 0.15), (second, 0.05)]), params)
 
 
 def test_piecewise_hamiltonian_through_the_reference_style_factory():

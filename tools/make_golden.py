@@ -695,6 +695,59 @@ def gen_continuation():
     save("continuation", **out)
 
 
+# ------------------------------------------------------------------ 15. front-end scenarios (replace transcribed reference tests)
+def gen_scenarios():
+    """Reference outputs for the scenarios of tests/test_front_end_scenarios.py: every scenario is described by its inputs in that
+    test file; here the reference's own backends produce what `Simulator.run` must return for them."""
+    out = {}
+
+    def mean_rows(backend, n, st, noise, p, H):
+        rows = [np.asarray(backend((i, st, noise, p, H))[0], dtype=np.float64) for i in range(n)]
+        return np.mean(rows, axis=0), np.array(rows)
+
+    # noisy order-2 run with final-time sampling (the configuration of the reference's own end-to-end analog test)
+    L = 5
+    H = MPO.ising(L, 1, 0.5)
+    st = MPS(L, state="zeros")
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
+    p = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), s) for s in range(L)], elapsed_time=1, dt=0.1, num_traj=10, max_bond_dim=4,
+                           svd_threshold=1e-6, order=2, sample_timesteps=False, random_seed=42)
+    out["noisy_order2_mean"], out["noisy_order2_rows"] = mean_rows(tjm.analog_tjm_2, 10, st, noise, p, H)
+    # user order of the observables, closed two-site chain, exact preset, final state
+    H2 = MPO.ising(2, 1.0, 0.7)
+    p = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), 1), sp.Observable(gl.X(), 0), sp.Observable(gl.Z(), 0)], elapsed_time=0.1, dt=0.1,
+                           num_traj=1, get_state=True, sample_timesteps=False, preset="exact")
+    r, _, fin = tjm.analog_tjm_1((0, MPS(2, state="zeros"), None, p, H2))
+    out["order_sorted_rows"] = np.asarray(r, dtype=np.float64)[:, 0]
+    out["order_sorted_index"] = np.array(p.observable_sorted_indices if hasattr(p, "observable_sorted_indices") else [1, 2, 0])
+    out["order_final_vec"] = fin.to_vec()
+    # closed two-site run to T = 1, both orders: final state vector
+    for order in (1, 2):
+        p = sp.AnalogSimParams(observables=[sp.Observable(gl.X(), 1)], elapsed_time=1, dt=0.1, num_traj=1, max_bond_dim=4, svd_threshold=1e-6,
+                               order=order, get_state=True, sample_timesteps=False)
+        backend = tjm.analog_tjm_2 if order == 2 else tjm.analog_tjm_1
+        r, _, fin = backend((0, MPS(2, state="zeros"), None, p, MPO.ising(2, 1, 0.5)))
+        out[f"closed2_order{order}_vec"] = fin.to_vec()
+        out[f"closed2_order{order}_x"] = np.asarray(r, dtype=np.float64)[:, 0]
+    # order-2 short runs
+    for T, sample in ((0.0, True), (0.0, False), (0.1, False), (0.1, True)):
+        p = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), 0)], dt=0.1, elapsed_time=T, num_traj=1, order=2, sample_timesteps=sample,
+                               get_state=True, random_seed=0)
+        r, _, _ = tjm.analog_tjm_2((0, MPS(2, state="zeros"), None, p, MPO.ising(2, 1.0, 0.5)))
+        out[f"short_T{T}_s{int(sample)}"] = np.asarray(r, dtype=np.float64)[0]
+    # one-site plus adjacent two-site jump processes, 20 trajectories, order 2
+    for name in ("crosstalk_xx", "lowering_two"):
+        p = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), 0)], elapsed_time=0.1, dt=0.1, num_traj=20, max_bond_dim=8, order=2,
+                               sample_timesteps=False, random_seed=42)
+        nm = NoiseModel([{"name": "pauli_x", "sites": [0], "strength": 0.02}, {"name": name, "sites": [0, 1], "strength": 0.01}])
+        out[f"pair_{name}_mean"], out[f"pair_{name}_rows"] = mean_rows(tjm.analog_tjm_2, 20, MPS(2, state="zeros"), nm, p, MPO.ising(2, 1.0, 0.5))
+    # long-range Pauli crosstalk on the analog path
+    p = sp.AnalogSimParams(observables=[sp.Observable(gl.Z(), 0)], dt=0.1, elapsed_time=0.2, num_traj=2, random_seed=0)
+    nm = NoiseModel([{"name": "longrange_crosstalk_xy", "sites": [0, 2], "strength": 0.05}])
+    out["longrange_mean"], _ = mean_rows(tjm.analog_tjm_2 if p.order == 2 else tjm.analog_tjm_1, 2, MPS(3, state="zeros"), nm, p, MPO.ising(3, 1.0, 0.5))
+    save("front_end_scenarios", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tiny", "rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
     for w in which:

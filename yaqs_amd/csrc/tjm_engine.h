@@ -47,10 +47,11 @@ class Engine {
   void profile_enable(bool on);
   int profile_read(double* ms /*[PROF_NCLASS]*/, long* regions /*[PROF_NCLASS]*/);
   struct Region {
-    Engine& e; int idx;
+    Engine& e; int idx; int token;
     Region(Engine& eng, int cls);
     ~Region();
   };
+  int phase_depth_ = 0;
 
   int create(int L, int d, int chi_max, int B, const int* mpo_bond);
   size_t workspace_bytes() const;
