@@ -140,6 +140,27 @@ int tjm_engine_stats_ex(const tjm_engine* e, int64_t* out, int32_t n);
 int tjm_engine_profile(tjm_engine* e, int32_t enable);
 int tjm_engine_profile_read(tjm_engine* e, double* ms3, int64_t* regions3);
 
+/* ---- site-level steps: sweeps whose schedule the host decides per trajectory ---------- *
+ * Dynamic TDVP (core/methods/tdvp/integrators.py:294-511) takes, site by site, the two-site branch for the trajectories whose
+ * bond is below max_bond_dim and the one-site branch with a QR bond transfer for those that have reached it, so a lock-step
+ * batch splits into two index lists at every site: the Python host reads the bond table (tjm_engine_bond_dims), forms the
+ * lists and calls these steps.  ids = host int32 list of n trajectory slots, or NULL for all of them.
+ *   step_env_init   initialize_right_environments + the left boundary (primitives.py:139-174, integrators.py:325-336)
+ *   step_two_site   merge_two_site, update_site on the pair, split_tdvp: dist 0 = "right", 1 = "left"; capped = 0 is
+ *                   dynamic=True (no max_bond_dim in the truncation, sweep_utils.py:47-84)
+ *   step_one_site   update_site on one tensor (primitives.py:484-520)
+ *   step_env        left = 1: update_left_environment into site + 1; left = 0: update_right_environment into site - 1
+ *   step_qr_bond    right_qr / left_qr of the site, environment update with Q, update_bond on C over dt, C into the neighbour
+ *                   (integrators.py:352-377, 441-466)
+ *   step_cap_bond   _sync_bond_dim where it truncates (sweep_utils.py:110-163): merged pair, sqrt-distributed split capped at
+ *                   `target`, min_keep 1 */
+int tjm_engine_step_env_init(tjm_engine* e, int32_t set);
+int tjm_engine_step_two_site(tjm_engine* e, int32_t set, int32_t site, double dt, int32_t dist, int32_t capped, const int32_t* ids, int32_t n);
+int tjm_engine_step_one_site(tjm_engine* e, int32_t set, int32_t site, double dt, const int32_t* ids, int32_t n);
+int tjm_engine_step_env(tjm_engine* e, int32_t set, int32_t site, int32_t left, const int32_t* ids, int32_t n);
+int tjm_engine_step_qr_bond(tjm_engine* e, int32_t set, int32_t site, int32_t right, double dt, const int32_t* ids, int32_t n);
+int tjm_engine_step_cap_bond(tjm_engine* e, int32_t set, int32_t bond, int32_t target, const int32_t* ids, int32_t n);
+
 /* ---- whole trajectories in one call -------------------------------------------------- *
  * The body of the backend contract: analog_tjm_1 / analog_tjm_2 (analog/analog_tjm.py:206-462) for the B resident
  * trajectories, after set_params / set_mpo / set_noise / load_state.  Observables are given in the reference's

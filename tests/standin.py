@@ -156,6 +156,66 @@ class OracleEngine:
             s.center = None
         self._check()
 
+    # -- site-level steps (tjm_engine_step_*) --------------------------------------------
+    def _slots(self, ids):
+        return range(self.B) if ids is None else [int(b) for b in ids]
+
+    def step_env_init(self, set_index=0):
+        self.env = {}
+        for b, s in enumerate(self.sets[set_index]):
+            rb = o.right_environments(s.tensors, self.mpo)
+            lb = [None] * self.L
+            lb[0] = o.identity_env(s.tensors[0].shape[1], self.mpo[0].shape[2])
+            self.env[b] = (lb, rb)
+
+    def step_two_site(self, site, dt, dist, capped, ids=None, set_index=0):
+        p = self.params
+        for b in self._slots(ids):
+            t = self.sets[set_index][b].tensors
+            lb, rb = self.env[b]
+            theta = o.update_site(lb[site], rb[site + 1], o.merge_mpo_tensors(self.mpo[site], self.mpo[site + 1]), o.merge_two_site(t[site], t[site + 1]),
+                                  dt, p.krylov_tol)
+            t[site], t[site + 1] = o.split_two_site(theta, [2, 2], svd_distribution=dist, trunc_mode=p.trunc_mode, threshold=p.svd_threshold,
+                                                    max_bond_dim=p.max_bond_dim if capped else None, min_keep=o._min_keep(p))
+        self._check()
+
+    def step_one_site(self, site, dt, ids=None, set_index=0):
+        for b in self._slots(ids):
+            t = self.sets[set_index][b].tensors
+            lb, rb = self.env[b]
+            t[site] = o.update_site(lb[site], rb[site], self.mpo[site], t[site], dt, self.params.krylov_tol)
+
+    def step_env(self, site, left, ids=None, set_index=0):
+        for b in self._slots(ids):
+            t = self.sets[set_index][b].tensors
+            lb, rb = self.env[b]
+            if left:
+                lb[site + 1] = o.update_left_environment(t[site], t[site], self.mpo[site], lb[site])
+            else:
+                rb[site - 1] = o.update_right_environment(t[site], t[site], self.mpo[site], rb[site])
+
+    def step_qr_bond(self, site, right, dt, ids=None, set_index=0):
+        tol = self.params.krylov_tol
+        for b in self._slots(ids):
+            t = self.sets[set_index][b].tensors
+            lb, rb = self.env[b]
+            if right:
+                q, c = o.right_qr(t[site])
+                t[site] = q
+                lb[site + 1] = o.update_left_environment(q, q, self.mpo[site], lb[site])
+                c = o.update_bond(lb[site + 1], rb[site], c, dt, tol)
+                t[site + 1] = np.einsum("adc,bd->abc", t[site + 1], c)
+            else:
+                q, c = o.left_qr(t[site])
+                t[site] = q
+                rb[site - 1] = o.update_right_environment(q, q, self.mpo[site], rb[site])
+                c = o.update_bond(lb[site], rb[site - 1], c.transpose(), dt, tol)
+                t[site - 1] = np.einsum("abd,dc->abc", t[site - 1], c)
+
+    def step_cap_bond(self, bond, target, ids=None, set_index=0):
+        for b in self._slots(ids):
+            o._sync_bond_dim(self.sets[set_index][b], bond, target, self.params)
+
     # -- measurement ---------------------------------------------------------------------
     def site_moments(self, set_index=0):
         d = self.d

@@ -659,3 +659,29 @@ def test_svd_split_up_to_1024_matches_oracle(lib, capL, capR, dist):
     assert np.all(left[0][:, :, k:] == 0) and np.all(right[0][:, k:, :] == 0)
     iso = left[0][:, :, :k].reshape(m, k) if dist == 0 else right[0][:, :k, :].transpose(1, 0, 2).reshape(k, n).conj().T
     assert np.allclose(iso.conj().T @ iso, np.eye(k), atol=1e-12)
+
+
+@pytest.mark.parametrize("capL,capR", [(4, 4), (16, 16), (8, 3), (48, 48), (128, 128)])
+def test_svd_split_sqrt_distribution_matches_oracle(lib, capL, capR):
+    """distribution 2 = "sqrt" of split_two_site (decompositions.py:166-171; _sync_bond_dim of the dynamic sweep): sqrt(S) in both
+    factors, capped and thresholded like the oracle's; the merged pair, keep and the balance of the two factors."""
+    from oracle import tjm_oracle as o
+
+    rng = np.random.default_rng(capL * 7 + capR)
+    d, B = 2, 3
+    capM = min(d * capL, d * capR)
+    theta = crand(rng, B, d * capL, d * capR) / np.sqrt(d * capL * d * capR)
+    theta[1] *= 1e-2
+    chiL, chiR = np.full(B, capL, dtype=np.int32), np.full(B, capR, dtype=np.int32)
+    thr, maxb = 1e-8, max(1, capM // 2)
+    left, right, keep, _, _ = svd_split_gpu(lib, theta, d, capL, capR, capM, 2, 0, thr, maxb, 1, chiL, chiR, qr=False)
+    for b in range(B):
+        merged = theta[b].reshape(d, capL, d, capR).transpose(0, 2, 1, 3).reshape(d * d, capL, capR)
+        l_ref, r_ref = o.split_two_site(merged, [d, d], svd_distribution="sqrt", trunc_mode="discarded_weight", threshold=thr, max_bond_dim=maxb, min_keep=1)
+        k = l_ref.shape[2]
+        assert keep[b] == k
+        assert np.allclose(o.merge_two_site(left[b][:, :, :k], right[b][:, :k, :]), o.merge_two_site(l_ref, r_ref), atol=1e-11)
+        gl_ = left[b][:, :, :k].reshape(d * capL, k)
+        gr_ = right[b][:, :k, :].transpose(1, 0, 2).reshape(k, d * capR)
+        assert np.allclose(np.linalg.norm(gl_, axis=0), np.linalg.norm(gr_, axis=1), rtol=1e-9)   # sqrt(S) on both sides
+        assert np.all(left[b][:, :, k:] == 0) and np.all(right[b][:, k:, :] == 0)

@@ -109,6 +109,12 @@ EXPORTS = {
     "tjm_lanczos_expm": (C.c_int, [V, I, I, I, I, I, V, V, V, V, D, D, V, I, V]),
     "tjm_engine_center_shift": (C.c_int, [V, I, I, I, I]),
     "tjm_engine_jump_weights": (C.c_int, [V, I, D, V, V, V]),
+    "tjm_engine_step_env_init": (C.c_int, [V, I]),
+    "tjm_engine_step_two_site": (C.c_int, [V, I, I, D, I, I, V, I]),
+    "tjm_engine_step_one_site": (C.c_int, [V, I, I, D, V, I]),
+    "tjm_engine_step_env": (C.c_int, [V, I, I, I, V, I]),
+    "tjm_engine_step_qr_bond": (C.c_int, [V, I, I, I, D, V, I]),
+    "tjm_engine_step_cap_bond": (C.c_int, [V, I, I, I, V, I]),
     "tjm_engine_profile": (C.c_int, [V, I]),
     "tjm_engine_profile_read": (C.c_int, [V, V, V]),
     "tjm_engine_run": (C.c_int, [V, C.POINTER(RunConfig), V, V, V]),

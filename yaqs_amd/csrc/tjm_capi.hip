@@ -274,6 +274,37 @@ int tjm_engine_jump_weights(tjm_engine* e, int32_t set, double dt, int32_t* orde
   return rc;
 }
 
+int tjm_engine_step_env_init(tjm_engine* e, int32_t set) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.step_env_init(set);
+}
+int tjm_engine_step_two_site(tjm_engine* e, int32_t set, int32_t site, double dt, int32_t dist, int32_t capped, const int32_t* ids, int32_t n) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.step_two_site(set, site, dt, dist, capped, ids, n);
+}
+int tjm_engine_step_one_site(tjm_engine* e, int32_t set, int32_t site, double dt, const int32_t* ids, int32_t n) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.step_one_site(set, site, dt, ids, n);
+}
+int tjm_engine_step_env(tjm_engine* e, int32_t set, int32_t site, int32_t left, const int32_t* ids, int32_t n) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.step_env(set, site, left, ids, n);
+}
+int tjm_engine_step_qr_bond(tjm_engine* e, int32_t set, int32_t site, int32_t right, double dt, const int32_t* ids, int32_t n) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.step_qr_bond(set, site, right, dt, ids, n);
+}
+int tjm_engine_step_cap_bond(tjm_engine* e, int32_t set, int32_t bond, int32_t target, const int32_t* ids, int32_t n) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.step_cap_bond(set, bond, target, ids, n);
+}
+
 int tjm_engine_profile(tjm_engine* e, int32_t enable) {
   if (!e) return TJM_ERR_ARG;
   TJM_ON_DEVICE(e);

@@ -102,9 +102,17 @@ class Engine {
 
   // environment updates on explicit tensors (also the kernel-level parity exports of the C ABI)
   int env_left_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int Dr, const cplx* Lin, long lin_b0, const cplx* WenvL, cplx* Lout,
-                  long lout_b0, int nb);
+                  long lout_b0, int nb, const int* ids = nullptr);
   int env_right_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int Dr, const cplx* Rin, long rin_b0, const cplx* Wm, cplx* Rout,
-                   long rout_b0, int nb);
+                   long rout_b0, int nb, const int* ids = nullptr);
+  // site-level steps of a sweep driven from the host (dynamic TDVP, integrators.py:294-511): host index lists of trajectories
+  int step_env_init(int set);
+  int step_two_site(int set, int i, double dt_, int dist, int capped, const int* host_ids, int n);
+  int step_one_site(int set, int i, double dt_, const int* host_ids, int n);
+  int step_env(int set, int i, int left, const int* host_ids, int n);
+  int step_qr_bond(int set, int i, int right, double dt_, const int* host_ids, int n);
+  int step_cap_bond(int set, int bond, int target, const int* host_ids, int n);
+  int upload_ids(const int* host_ids, int n, const int** dev);
   // kernel-level parity exports (tjm_capi.hip): operands are device arrays of nb <= B slots, W is a host MPO tensor (o,p,l,r)
   int x_heff_apply(int nsites, int ca, int cb, int Dl, int Dr, const cplx* x, const cplx* Lenv, const cplx* Renv, const double* host_w, cplx* y, int nb);
   int x_env_update(int left, int ca, int cb, int Dl, int Dr, const cplx* A, const cplx* env, const double* host_w, cplx* out, int nb);
@@ -165,17 +173,18 @@ class Engine {
   int gemm(const GemmDesc& g) { return launch_gemm(g, stream); }
   int merge_tensor_layout(StateSet& S, int i, cplx* out, long out_b0, const int* ids, int nb0);
   int merge_matrix_layout(StateSet& S, int i, const int* ids, int nb0);
-  int env_left(StateSet& S, int i);    // Lenv[i+1] from Lenv[i], A_i
-  int env_right(StateSet& S, int i);   // Renv[i-1] from Renv[i], A_i
-  int two_site_update(StateSet& S, int i, double dt_, int dist);
-  int one_site_update(StateSet& S, int i, double dt_);
+  int env_left(StateSet& S, int i, const int* ids = nullptr, int nb0 = -1);    // Lenv[i+1] from Lenv[i], A_i
+  int env_right(StateSet& S, int i, const int* ids = nullptr, int nb0 = -1);   // Renv[i-1] from Renv[i], A_i
+  int two_site_update(StateSet& S, int i, double dt_, int dist, const int* ids = nullptr, int nb0 = -1, bool capped = true);
+  int one_site_update(StateSet& S, int i, double dt_, const int* ids = nullptr, int nb0 = -1);
   int sweep_2site(StateSet& S, double scale);
   int split(StateSet& S, int i, int dist, int mode, double thr, int maxb, int min_keep, const int* ids, int nb0);
   int set_nloc(StateSet& S, int bl, int br, int P);
   using ApplyFn = std::function<int(const cplx* x, cplx* y, const int* active)>;
   int krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2, int n3,
                   long o0, long o1, long o2, int nb0, const int* ids);
-  int bond_apply(const cplx* x, int cu, int cv, const cplx* Lenv, long l_b0, const cplx* Renv, long r_b0, int D, cplx* y, const int* active);
+  int bond_apply(const cplx* x, int cu, int cv, const cplx* Lenv, long l_b0, const cplx* Renv, long r_b0, int D, cplx* y, const int* active,
+                 int nb0 = -1, const int* ids = nullptr);
   int sweep_1site(StateSet& S, double scale);
   int qr_site(StateSet& S, int i, bool right, const int* ids = nullptr, int nb0 = -1, bool absorb = false);  // absorb: also multiply C into the neighbour (small bonds only)
     // A_i = Q C (right) or A_i = C^T Q (left); C into Cm_

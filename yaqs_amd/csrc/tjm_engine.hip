@@ -501,13 +501,14 @@ int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cp
   return TJM_OK;
 }
 
-int Engine::env_left(StateSet& S, int i) {
-  return env_left_at(S.A[i], a_b0_[i], cap[i], cap[i + 1], Dm[i], Dm[i + 1], Lenv_[i], l_b0_[i], WenvL_[i], Lenv_[i + 1], l_b0_[i + 1], B);
+int Engine::env_left(StateSet& S, int i, const int* ids, int nb0) {
+  return env_left_at(S.A[i], a_b0_[i], cap[i], cap[i + 1], Dm[i], Dm[i + 1], Lenv_[i], l_b0_[i], WenvL_[i], Lenv_[i + 1], l_b0_[i + 1],
+                     nb0 < 0 ? B : nb0, ids);
 }
 
 // update_left_environment (primitives.py:77-107) on explicit tensors: A [nb][d][ca][cb], Lin [nb][ca][Dl][ca] -> Lout [nb][cb][Dr][cb]
 int Engine::env_left_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int Dr, const cplx* Lin, long lin_b0, const cplx* WenvL, cplx* Lout,
-                        long lout_b0, int nb) {
+                        long lout_b0, int nb, const int* ids) {
   int rc;
   Region prof(*this, PROF_ENV);
   ++stat_env_updates;
@@ -517,7 +518,7 @@ int Engine::env_left_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int Dr
     g.M = ca * Dl; g.K = ca; g.N = cb;
     g.a_rs = ca; g.a_cs = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = (long)d * cb; g.conjB = 1;
     g.nb0 = nb; g.nb1 = d;
-    g.a_b0 = lin_b0; g.b_b0 = a_b0; g.b_b1 = (long)ca * cb; g.c_b0 = t_b0; g.c_b1 = cb;
+    g.a_b0 = lin_b0; g.b_b0 = a_b0; g.b_b1 = (long)ca * cb; g.c_b0 = t_b0; g.c_b1 = cb; g.ids = ids;
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   {  // T2[p][a][r][B] = sum_{o,l} W[o,p,l,r] T1[a][l][o][B]
@@ -525,7 +526,7 @@ int Engine::env_left_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int Dr
     m.in = T1; m.out = T2; m.Wm = WenvL; m.P = d; m.din = Dl; m.dout = Dr; m.na = ca; m.nB = cb;
     m.in_sp = cb; m.in_sb = (long)d * cb; m.in_sa = (long)Dl * d * cb;
     m.out_sp = (long)ca * Dr * cb; m.out_sb = cb; m.out_sa = (long)Dr * cb;
-    m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = nb; m.ids = nullptr; m.active = nullptr;
+    m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = nb; m.ids = ids; m.active = nullptr;
     if ((rc = launch_mpo_apply(m, stream)) != TJM_OK) return rc;
   }
   {  // L'[b,(r,B)] = sum_{(p,a)} A_i[(p,a),b] T2[(p,a),(r,B)]
@@ -533,20 +534,21 @@ int Engine::env_left_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int Dr
     g.A = A; g.B = T2; g.C = Lout;
     g.M = cb; g.K = d * ca; g.N = Dr * cb;
     g.a_rs = 1; g.a_cs = cb; g.b_rs = (long)Dr * cb; g.b_cs = 1; g.c_rs = (long)Dr * cb;
-    g.nb0 = nb; g.a_b0 = a_b0; g.b_b0 = t_b0; g.c_b0 = lout_b0;
+    g.nb0 = nb; g.a_b0 = a_b0; g.b_b0 = t_b0; g.c_b0 = lout_b0; g.ids = ids;
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   return TJM_OK;
 }
 
-int Engine::env_right(StateSet& S, int i) {
+int Engine::env_right(StateSet& S, int i, const int* ids, int nb0) {
   // Renv_[i-1] (bond cap[i], Dm[i]) from Renv_[i] and A_i
-  return env_right_at(S.A[i], a_b0_[i], cap[i], cap[i + 1], Dm[i], Dm[i + 1], Renv_[i], r_b0_[i], W_[i], Renv_[i - 1], r_b0_[i - 1], B);
+  return env_right_at(S.A[i], a_b0_[i], cap[i], cap[i + 1], Dm[i], Dm[i + 1], Renv_[i], r_b0_[i], W_[i], Renv_[i - 1], r_b0_[i - 1],
+                      nb0 < 0 ? B : nb0, ids);
 }
 
 // update_right_environment (primitives.py:110-136) on explicit tensors: A [nb][d][ca][cb], Rin [nb][cb][Dr][cb] -> Rout [nb][ca][Dl][ca]
 int Engine::env_right_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int Dr, const cplx* Rin, long rin_b0, const cplx* Wm, cplx* Rout,
-                         long rout_b0, int nb) {
+                         long rout_b0, int nb, const int* ids) {
   int rc;
   Region prof(*this, PROF_ENV);
   ++stat_env_updates;
@@ -555,7 +557,7 @@ int Engine::env_right_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int D
     g.A = A; g.B = Rin; g.C = T1;
     g.M = d * ca; g.K = cb; g.N = Dr * cb;
     g.a_rs = cb; g.a_cs = 1; g.b_rs = (long)Dr * cb; g.b_cs = 1; g.c_rs = (long)Dr * cb;
-    g.nb0 = nb; g.a_b0 = a_b0; g.b_b0 = rin_b0; g.c_b0 = t_b0;
+    g.nb0 = nb; g.a_b0 = a_b0; g.b_b0 = rin_b0; g.c_b0 = t_b0; g.ids = ids;
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   {  // T2[a][l][o][B] = sum_{p,r} W[o,p,l,r] T1[p][a][r][B]
@@ -563,7 +565,7 @@ int Engine::env_right_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int D
     m.in = T1; m.out = T2; m.Wm = Wm; m.P = d; m.din = Dr; m.dout = Dl; m.na = ca; m.nB = cb;
     m.in_sp = (long)ca * Dr * cb; m.in_sb = cb; m.in_sa = (long)Dr * cb;
     m.out_sp = cb; m.out_sb = (long)d * cb; m.out_sa = (long)Dl * d * cb;
-    m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = nb; m.ids = nullptr; m.active = nullptr;
+    m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = nb; m.ids = ids; m.active = nullptr;
     if ((rc = launch_mpo_apply(m, stream)) != TJM_OK) return rc;
   }
   {  // R'[(a,l),A] = sum_o sum_B T2[(a,l),(o,B)] conj(A_i[o][A][B])
@@ -572,7 +574,7 @@ int Engine::env_right_at(const cplx* A, long a_b0, int ca, int cb, int Dl, int D
     g.M = ca * Dl; g.K = cb; g.N = ca;
     g.a_rs = (long)d * cb; g.a_cs = 1; g.b_rs = 1; g.b_cs = cb; g.c_rs = ca; g.conjB = 1;
     g.nks = d; g.a_ks = cb; g.b_ks = (long)ca * cb;
-    g.nb0 = nb; g.a_b0 = t_b0; g.b_b0 = a_b0; g.c_b0 = rout_b0;
+    g.nb0 = nb; g.a_b0 = t_b0; g.b_b0 = a_b0; g.c_b0 = rout_b0; g.ids = ids;
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   return TJM_OK;
@@ -635,14 +637,15 @@ int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Len
 
 // project_bond (primitives.py:207-226): y[p][w] = sum L[u][a][p] C[u][v] R[v][a][w]
 int Engine::bond_apply(const cplx* x, int cu, int cv, const cplx* Lenv, long l_b0, const cplx* Renv, long r_b0, int D, cplx* y,
-                       const int* active) {
+                       const int* active, int nb0, const int* ids) {
+  if (nb0 < 0) nb0 = B;
   int rc;
   {  // T[u][(a,w)] = C[u][v] R[v][(a,w)]
     GemmDesc g = blank_gemm();
     g.A = x; g.B = Renv; g.C = T1;
     g.M = cu; g.K = cv; g.N = D * cv;
     g.a_rs = cv; g.a_cs = 1; g.b_rs = (long)D * cv; g.b_cs = 1; g.c_rs = (long)D * cv;
-    g.nb0 = B; g.a_b0 = v_b0; g.b_b0 = r_b0; g.c_b0 = t_b0; g.active = active;
+    g.nb0 = nb0; g.ids = ids; g.a_b0 = v_b0; g.b_b0 = r_b0; g.c_b0 = t_b0; g.active = active;
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   {  // y[p][w] = sum_{(u,a)} L[(u,a)][p] T[(u,a)][w]
@@ -650,7 +653,7 @@ int Engine::bond_apply(const cplx* x, int cu, int cv, const cplx* Lenv, long l_b
     g.A = Lenv; g.B = T1; g.C = y;
     g.M = cu; g.K = cu * D; g.N = cv;
     g.a_rs = 1; g.a_cs = cu; g.b_rs = cv; g.b_cs = 1; g.c_rs = cv;
-    g.nb0 = B; g.a_b0 = l_b0; g.b_b0 = t_b0; g.c_b0 = v_b0; g.active = active;
+    g.nb0 = nb0; g.ids = ids; g.a_b0 = l_b0; g.b_b0 = t_b0; g.c_b0 = v_b0; g.active = active;
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   return TJM_OK;
@@ -695,7 +698,7 @@ int Engine::split(StateSet& S, int i, int dist, int mode, double thr, int maxb, 
   static const bool no_qr = getenv("TJM_NO_QR") != nullptr;
   static const bool force_large = getenv("TJM_FORCE_LARGE_SPLIT") != nullptr;
   const bool large = std::max(s.m, s.n) > 512 || (force_large && std::min(s.m, s.n) >= 32);  // bonds beyond 256: only the QR-preconditioned X-only variant holds the columns
-  const bool use_qr = large || (!no_qr && ids == nullptr && std::min(s.m, s.n) >= 64);
+  const bool use_qr = large || (!no_qr && dist != 2 && ids == nullptr && std::min(s.m, s.n) >= 64);  // the sqrt distribution is served by the plain split
   const int rc = use_qr ? svd_split_qr(s, svdw, qrw, stream, &sweeps) : svd_split(s, svdw, stream, &sweeps);
   ++stat_svds;
   stat_svd_mats += nb0;
@@ -703,28 +706,31 @@ int Engine::split(StateSet& S, int i, int dist, int mode, double thr, int maxb, 
   return rc;
 }
 
-int Engine::two_site_update(StateSet& S, int i, double dt_, int dist) {
+int Engine::two_site_update(StateSet& S, int i, double dt_, int dist, const int* ids, int nb0, bool capped) {
+  if (nb0 < 0) nb0 = B;
   const int ca = cap[i], cc = cap[i + 2], P = d * d;
   int rc;
-  if ((rc = merge_tensor_layout(S, i, V, v_b0, nullptr, B)) != TJM_OK) return rc;
+  if ((rc = merge_tensor_layout(S, i, V, v_b0, ids, nb0)) != TJM_OK) return rc;
   if ((rc = set_nloc(S, i, i + 2, P)) != TJM_OK) return rc;
   // result in matrix layout theta[(s,a),(t,c)] from tensor layout [s][t][a][c]
   if ((rc = krylov_site(nullptr, P, ca, cc, Lenv_[i], l_b0_[i], Dm[i], Renv_[i + 1], r_b0_[i + 1], Dm[i + 2], W2_[i], dt_, nloc_,
-                        theta, theta_b0, d, d, ca, cc, (long)ca * d * cc, cc, (long)d * cc, B, nullptr, S.chi + i, S.chi + i + 2)) != TJM_OK) return rc;
-  const int mk = (max_bond > 0) ? std::min(2, max_bond) : 2;
-  if ((rc = split(S, i, dist, trunc_mode, svd_threshold, max_bond, mk, nullptr, B)) != TJM_OK) return rc;
+                        theta, theta_b0, d, d, ca, cc, (long)ca * d * cc, cc, (long)d * cc, nb0, ids, S.chi + i, S.chi + i + 2)) != TJM_OK) return rc;
+  const int mk = (max_bond > 0) ? std::min(2, max_bond) : 2;  // get_min_keep (sweep_utils.py:33-44)
+  // capped = false: split_tdvp(dynamic=True), no max_bond_dim in the truncation (sweep_utils.py:47-84)
+  if ((rc = split(S, i, dist, trunc_mode, svd_threshold, capped ? max_bond : 0, mk, ids, nb0)) != TJM_OK) return rc;
   ++stat_site_updates;
   return TJM_OK;
 }
 
-int Engine::one_site_update(StateSet& S, int i, double dt_) {
+int Engine::one_site_update(StateSet& S, int i, double dt_, const int* ids, int nb0) {
+  if (nb0 < 0) nb0 = B;
   const int ca = cap[i], cb = cap[i + 1];
   int rc;
   TJM_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)v_b0 * sizeof(cplx), S.A[i], (size_t)a_b0_[i] * sizeof(cplx), (size_t)a_b0_[i] * sizeof(cplx), B,
                                  hipMemcpyDeviceToDevice, stream));
   if ((rc = set_nloc(S, i, i + 1, d)) != TJM_OK) return rc;
   return krylov_site(nullptr, d, ca, cb, Lenv_[i], l_b0_[i], Dm[i], Renv_[i], r_b0_[i], Dm[i + 1], W_[i], dt_, nloc_, S.A[i], a_b0_[i], 1,
-                     d, ca, cb, 0, (long)ca * cb, cb, B, nullptr, S.chi + i, S.chi + i + 1);
+                     d, ca, cb, 0, (long)ca * cb, cb, nb0, ids, S.chi + i, S.chi + i + 1);
 }
 
 int Engine::sweep_2site(StateSet& S, double scale) {
@@ -2013,6 +2019,120 @@ int Engine::x_jump_weights(int set, double dt_, int* host_order, double* host_w,
     if (!order.empty() && (!(tot > 0.0) || !std::isfinite(tot))) return TJM_ERR_NUMERIC;  // stochastic_process.py:178-186
   }
   return TJM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Site-level steps for sweeps whose schedule is decided on the host per trajectory (dynamic TDVP, integrators.py:294-511: a site
+// takes the two-site branch while its bond is below max_bond_dim and the one-site branch with a QR bond transfer once it has
+// reached it, so one lock-step batch splits into two index lists at every site).  host_ids = nullptr: every trajectory.
+// ------------------------------------------------------------------------------------------
+int Engine::upload_ids(const int* host_ids, int n, const int** dev) {
+  *dev = nullptr;
+  if (!host_ids) return TJM_OK;
+  if (n < 1 || n > B) return TJM_ERR_ARG;
+  for (int k = 0; k < n; ++k) if (host_ids[k] < 0 || host_ids[k] >= B) return TJM_ERR_ARG;
+  TJM_HIP_CHECK(hipMemcpyAsync(ids_, host_ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  *dev = ids_;
+  return TJM_OK;
+}
+
+// right environments of the whole chain and the left boundary (primitives.py:139-174, integrators.py:186-193)
+int Engine::step_env_init(int set) {
+  if (!bound_ || set < 0 || set > 1) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  int rc;
+  if ((rc = launch_identity_env(Renv_[L - 1], r_b0_[L - 1], cap[L], Dm[L], B, stream)) != TJM_OK) return rc;
+  for (int i = L - 1; i >= 1; --i)
+    if ((rc = env_right(S, i)) != TJM_OK) return rc;
+  return launch_identity_env(Lenv_[0], l_b0_[0], cap[0], Dm[0], B, stream);
+}
+
+// merge (i, i+1), exp(-i dt H_eff), split_tdvp (dist 0 = "right", 1 = "left"; capped = 0: dynamic=True, no max_bond_dim)
+int Engine::step_two_site(int set, int i, double dt_, int dist, int capped, const int* host_ids, int n) {
+  if (!bound_ || set < 0 || set > 1 || i < 0 || i + 1 >= L || (dist != 0 && dist != 1)) return TJM_ERR_ARG;
+  const int* dev;
+  int rc;
+  if ((rc = upload_ids(host_ids, n, &dev)) != TJM_OK) return rc;
+  return two_site_update(sets[set], i, dt_, dist, dev, host_ids ? n : B, capped != 0);
+}
+
+int Engine::step_one_site(int set, int i, double dt_, const int* host_ids, int n) {
+  if (!bound_ || set < 0 || set > 1 || i < 0 || i >= L) return TJM_ERR_ARG;
+  const int* dev;
+  int rc;
+  if ((rc = upload_ids(host_ids, n, &dev)) != TJM_OK) return rc;
+  return one_site_update(sets[set], i, dt_, dev, host_ids ? n : B);
+}
+
+// left = 1: Lenv[i+1] from Lenv[i] and A_i ; left = 0: Renv[i-1] from Renv[i] and A_i
+int Engine::step_env(int set, int i, int left, const int* host_ids, int n) {
+  if (!bound_ || set < 0 || set > 1 || i < 0 || i >= L || (left && i + 1 >= L) || (!left && i < 1)) return TJM_ERR_ARG;
+  const int* dev;
+  int rc;
+  if ((rc = upload_ids(host_ids, n, &dev)) != TJM_OK) return rc;
+  return left ? env_left(sets[set], i, dev, host_ids ? n : B) : env_right(sets[set], i, dev, host_ids ? n : B);
+}
+
+// The bond transfer of the one-site branch (integrators.py:352-377 / 441-466, the body of sweep_1site): thin QR of site i
+// (right = 1: A_i = Q C, right = 0: A_i = C^T Q), environment update with Q, exp(-i dt H_bond) on C, C into the neighbour.
+int Engine::step_qr_bond(int set, int i, int right, double dt_, const int* host_ids, int n) {
+  if (!bound_ || set < 0 || set > 1 || i < 0 || i >= L || (right && i + 1 >= L) || (!right && i < 1)) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  const int* dev;
+  int rc;
+  if ((rc = upload_ids(host_ids, n, &dev)) != TJM_OK) return rc;
+  const int nb = host_ids ? n : B;
+  if (right) {
+    const int cb = cap[i + 1], cc = cap[i + 2];
+    if ((rc = qr_site(S, i, true, dev, nb)) != TJM_OK) return rc;
+    if ((rc = env_left(S, i, dev, nb)) != TJM_OK) return rc;
+    TJM_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)v_b0 * sizeof(cplx), Cm_, (size_t)cb * cb * sizeof(cplx), (size_t)cb * cb * sizeof(cplx), B,
+                                   hipMemcpyDeviceToDevice, stream));
+    ApplyFn f = [&](const cplx* x, cplx* y, const int* active) {
+      return bond_apply(x, cb, cb, Lenv_[i + 1], l_b0_[i + 1], Renv_[i], r_b0_[i], Dm[i + 1], y, active, nb, dev);
+    };
+    if ((rc = krylov_core(f, cb * cb, dt_, nloc_, Cm_, (long)cb * cb, 1, 1, cb, cb, 0, 0, cb, nb, dev)) != TJM_OK) return rc;
+    GemmDesc g = blank_gemm();  // T1[p][l][r] = C[l][x] A_{i+1}[p][x][r]
+    g.A = Cm_; g.B = S.A[i + 1]; g.C = T1;
+    g.M = cb; g.K = cb; g.N = cc;
+    g.a_rs = cb; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = cc;
+    g.nb0 = nb; g.nb1 = d; g.a_b0 = (long)cb * cb; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cb * cc; g.c_b0 = t_b0; g.c_b1 = (long)cb * cc;
+    g.ids = dev;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+    return copy_back(S.A[i + 1], a_b0_[i + 1], T1, t_b0, a_b0_[i + 1], dev, nb);
+  }
+  const int cz = cap[i - 1], ca = cap[i];
+  if ((rc = qr_site(S, i, false, dev, nb)) != TJM_OK) return rc;
+  if ((rc = env_right(S, i, dev, nb)) != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)v_b0 * sizeof(cplx), Cm_, (size_t)ca * ca * sizeof(cplx), (size_t)ca * ca * sizeof(cplx), B,
+                                 hipMemcpyDeviceToDevice, stream));
+  ApplyFn f = [&](const cplx* x, cplx* y, const int* active) {
+    return bond_apply(x, ca, ca, Lenv_[i], l_b0_[i], Renv_[i - 1], r_b0_[i - 1], Dm[i], y, active, nb, dev);
+  };
+  if ((rc = krylov_core(f, ca * ca, dt_, nloc_, Cm_, (long)ca * ca, 1, 1, ca, ca, 0, 0, ca, nb, dev)) != TJM_OK) return rc;
+  GemmDesc g = blank_gemm();  // T1[(p,l)][r] = A_{i-1}[(p,l)][x] C^T[x][r]
+  g.A = S.A[i - 1]; g.B = Cm_; g.C = T1;
+  g.M = d * cz; g.K = ca; g.N = ca;
+  g.a_rs = ca; g.a_cs = 1; g.b_rs = ca; g.b_cs = 1; g.c_rs = ca;
+  g.nb0 = nb; g.a_b0 = a_b0_[i - 1]; g.b_b0 = (long)ca * ca; g.c_b0 = t_b0;
+  g.ids = dev;
+  if ((rc = gemm(g)) != TJM_OK) return rc;
+  return copy_back(S.A[i - 1], a_b0_[i - 1], T1, t_b0, a_b0_[i - 1], dev, nb);
+}
+
+// _sync_bond_dim (sweep_utils.py:110-163) where it truncates: merge (bond, bond+1), split with sqrt(S) into both factors under the
+// run's truncation rule, max_bond_dim = target, min_keep 1.  (Its padding branches do nothing here: a bond has ONE dimension per
+// trajectory in this storage and the entries beyond it are zero.)
+int Engine::step_cap_bond(int set, int bond, int target, const int* host_ids, int n) {
+  if (!bound_ || set < 0 || set > 1 || bond < 0 || bond + 1 >= L || target < 1) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  const int* dev;
+  int rc;
+  if ((rc = upload_ids(host_ids, n, &dev)) != TJM_OK) return rc;
+  const int nb = host_ids ? n : B;
+  if ((rc = merge_matrix_layout(S, bond, dev, nb)) != TJM_OK) return rc;
+  return split(S, bond, 2, trunc_mode, svd_threshold, target, 1, dev, nb);
 }
 
 }  // namespace tjm

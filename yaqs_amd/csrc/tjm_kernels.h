@@ -90,7 +90,7 @@ struct SvdSplitDesc {
   cplx* left;          // [B][d][capL][capM]
   cplx* right;         // [B][d][capM][capR]
   long left_b0, right_b0;
-  int distribution;    // 0 = "right" (left isometric), 1 = "left" (right isometric)
+  int distribution;    // 0 = "right" (left isometric), 1 = "left" (right isometric), 2 = "sqrt" (plain split only)
   int trunc_mode;      // 0 discarded_weight, 1 relative, 2 hard_cutoff, 3 relative_discarded_weight
   double threshold;
   int max_bond;        // <= 0: none
@@ -190,7 +190,7 @@ int small_sweep_pitch(int rows);
 int launch_small_sweep(const SmallSweepDesc& p, hipStream_t s);
 bool svd_shift_small_fits(int d, int ca, int cb, bool left);
 // out[b][k*o_k + r1*o_r1 + r0*o_r0] = scale_k * op(Ycol[perm[k]][row_off + r1*n_r0 + r0]) for k < keep, 0 for keep <= k < n_k
-// scale_mode: 0 none, 1 multiply by sigma_k, 2 divide by sigma_k
+// scale_mode: 0 none, 1 multiply by sigma_k, 2 divide by sigma_k, 3 multiply by sqrt(sigma_k), 4 divide by sqrt(sigma_k)
 struct ExtractDesc {
   cplx* out;
   long out_b0;

@@ -1504,6 +1504,8 @@ __global__ __launch_bounds__(256) void svd_extract_kernel(ExtractDesc x, SvdWork
       if (x.conj) v.y = -v.y;
       if (x.scale_mode == 1) { v.x *= sig[k]; v.y *= sig[k]; }
       else if (x.scale_mode == 2) { const double inv = (sig[k] > 0.0) ? 1.0 / sig[k] : 0.0; v.x *= inv; v.y *= inv; }
+      else if (x.scale_mode == 3) { const double r = sqrt(sig[k]); v.x *= r; v.y *= r; }
+      else if (x.scale_mode == 4) { const double inv = (sig[k] > 0.0) ? 1.0 / sqrt(sig[k]) : 0.0; v.x *= inv; v.y *= inv; }
     }
     out[(long)k * x.o_k + (long)r1 * x.o_r1 + (long)r0 * x.o_r0] = v;
   }
@@ -1822,10 +1824,14 @@ int svd_extract(const ExtractDesc& x, const SvdWorkspace& w, const JacobiShape& 
 // Two-site split: theta (m x n, rows (s,a), cols (t,c)) -> left[d][capL][capM], right[d][capM][capR].
 int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* sweeps_out) {
   if (d.nb0 <= 0) return TJM_OK;
+  // distribution 2 = "sqrt" (decompositions.py:166-171: sqrt(S) into both factors, used by _sync_bond_dim of the dynamic sweep,
+  // sweep_utils.py:146-160): the factorisation of distribution 0 with the scale of the singular values moved at extraction
+  const bool sqrt_dist = d.distribution == 2;
+  const bool orient0 = d.distribution != 1;
   {  // small bonds: everything in one kernel, unless a kept singular value sits at the rounding floor
     static const bool off = getenv("TJM_NO_SMALL_SHIFT") != nullptr;
-    const int rows = d.distribution == 0 ? d.m : d.n, cols = d.distribution == 0 ? d.n : d.m;
-    if (!off && rows <= 64 && cols <= 16 && d.m == d.d * d.capL && d.n == d.d * d.capR && w.n_active != nullptr) {  // wider: the LDS-resident kernel
+    const int rows = orient0 ? d.m : d.n, cols = orient0 ? d.n : d.m;
+    if (!off && !sqrt_dist && rows <= 64 && cols <= 16 && d.m == d.d * d.capL && d.n == d.d * d.capR && w.n_active != nullptr) {  // wider: the LDS-resident kernel
       TruncSpec tr;
       tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
       tr.cap = d.capM; tr.overflow = d.overflow;
@@ -1843,8 +1849,8 @@ int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* 
     }
   }
   JacobiSource src;
-  src.src = d.theta; src.src_b0 = d.theta_b0; src.conj = (d.distribution == 0); src.tri = 0;
-  if (d.distribution == 0) {  // X = theta^H : rows = theta columns, columns = theta rows
+  src.src = d.theta; src.src_b0 = d.theta_b0; src.conj = orient0; src.tri = 0;
+  if (orient0) {  // X = theta^H : rows = theta columns, columns = theta rows
     src.rx = d.n; src.ncols = d.m;
     src.r_n0 = d.n; src.s_r1 = 0; src.s_r0 = 1;
     src.c_n0 = d.m; src.s_c1 = 0; src.s_c0 = d.ld_theta;
@@ -1866,13 +1872,13 @@ int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* 
   ExtractDesc xl;
   xl.out = d.left; xl.out_b0 = d.left_b0; xl.n_k = d.capM; xl.o_k = 1;
   xl.n_r1 = 1; xl.n_r0 = d.d * d.capL; xl.o_r1 = 0; xl.o_r0 = d.capM;
-  xl.row_off = (d.distribution == 0) ? sh.rx_top : 0; xl.conj = 0; xl.scale_mode = 0;
+  xl.row_off = orient0 ? sh.rx_top : 0; xl.conj = 0; xl.scale_mode = sqrt_dist ? 3 : 0;
   if ((rc = svd_extract(xl, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s)) != TJM_OK) return rc;
   // right[t][k][c] = conj of rows (t,c): S V^H (dist 0: X part) or V^H (dist 1: W part)
   ExtractDesc xr;
   xr.out = d.right; xr.out_b0 = d.right_b0; xr.n_k = d.capM; xr.o_k = d.capR;
   xr.n_r1 = d.d; xr.n_r0 = d.capR; xr.o_r1 = (long)d.capM * d.capR; xr.o_r0 = 1;
-  xr.row_off = (d.distribution == 0) ? 0 : sh.rx_top; xr.conj = 1; xr.scale_mode = 0;
+  xr.row_off = orient0 ? 0 : sh.rx_top; xr.conj = 1; xr.scale_mode = sqrt_dist ? 4 : 0;
   return svd_extract(xr, w, sh, d.chiM, d.chi_stride, d.nb0, d.ids, s);
 }
 
@@ -2085,6 +2091,7 @@ int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace
   // beyond the stacked-column Jacobi (rows + columns <= 1024): X-only direct variant.  TJM_FORCE_LARGE_SPLIT sends every split of
   // at least 32 x 32 down that path (diagnostic: the large-bond code at sizes the rest of the suite covers)
   static const bool force_large = getenv("TJM_FORCE_LARGE_SPLIT") != nullptr;
+  if (d.distribution == 2) return (d.m > 512 || d.n > 512) ? TJM_ERR_NOT_IMPLEMENTED : svd_split(d, w, s, sweeps_out);
   const bool large = (d.m > 512 || d.n > 512) || (force_large && q.Z2 != nullptr && d.m >= 32 && d.n >= 32);
   if (d.ids && !large) return svd_split(d, w, s, sweeps_out);  // index-list batches take the plain path
   if (d.ld_theta != d.n) return TJM_ERR_ARG;

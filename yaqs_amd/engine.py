@@ -87,11 +87,12 @@ class BatchEngine:
     # -- configuration ---------------------------------------------------------------
     def set_params(self, *, dt, svd_threshold, trunc_mode="discarded_weight", max_bond_dim=None, krylov_tol=1e-4, tdvp_mode="2site",
                    tdvp_sweeps=1):
-        if tdvp_mode not in ("1site", "2site"):
-            raise NotImplementedError(f"tdvp_mode {tdvp_mode!r} is not built yet in the HIP path")
+        if tdvp_mode not in ("1site", "2site", "dynamic"):
+            raise ValueError(f'tdvp_mode must be one of ("1site", "2site", "dynamic"), got {tdvp_mode!r}.')  # tdvp.py:109-111
+        self.tdvp_mode = tdvp_mode
         _lib.check(self.lib.tjm_engine_set_params(self.h, float(dt), float(svd_threshold), TRUNC_MODES[trunc_mode],
                                                   -1 if max_bond_dim is None else int(max_bond_dim), float(krylov_tol),
-                                                  1 if tdvp_mode == "1site" else 2, int(tdvp_sweeps)),
+                                                  1 if tdvp_mode == "1site" else 2, int(tdvp_sweeps)),  # "dynamic": the host drives the site steps
                    "set_params")
 
     def set_noise(self, processes, is_pauli_flags):
@@ -287,6 +288,39 @@ class BatchEngine:
         bits = np.zeros(u.shape, dtype=np.uint8)
         _lib.check(self.lib.tjm_engine_sample_shots(self.h, set_index, u.shape[1], rot.ctypes.data, u.ctypes.data, bits.ctypes.data), "sample_shots")
         return bits
+
+    # -- site-level steps (sweeps scheduled by the host per trajectory: dynamic TDVP) ----
+    @staticmethod
+    def _ids(ids):
+        if ids is None:
+            return None, 0
+        a = _i32(ids)
+        return a, len(a)
+
+    def step_env_init(self, set_index: int = 0):
+        _lib.check(self.lib.tjm_engine_step_env_init(self.h, set_index), "step_env_init")
+
+    def step_two_site(self, site: int, dt: float, dist: str, capped: bool, ids=None, set_index: int = 0):
+        a, n = self._ids(ids)
+        _lib.check(self.lib.tjm_engine_step_two_site(self.h, set_index, int(site), float(dt), 0 if dist == "right" else 1, int(bool(capped)),
+                                                     None if a is None else a.ctypes.data, n), "step_two_site")
+
+    def step_one_site(self, site: int, dt: float, ids=None, set_index: int = 0):
+        a, n = self._ids(ids)
+        _lib.check(self.lib.tjm_engine_step_one_site(self.h, set_index, int(site), float(dt), None if a is None else a.ctypes.data, n), "step_one_site")
+
+    def step_env(self, site: int, left: bool, ids=None, set_index: int = 0):
+        a, n = self._ids(ids)
+        _lib.check(self.lib.tjm_engine_step_env(self.h, set_index, int(site), int(bool(left)), None if a is None else a.ctypes.data, n), "step_env")
+
+    def step_qr_bond(self, site: int, right: bool, dt: float, ids=None, set_index: int = 0):
+        a, n = self._ids(ids)
+        _lib.check(self.lib.tjm_engine_step_qr_bond(self.h, set_index, int(site), int(bool(right)), float(dt), None if a is None else a.ctypes.data, n),
+                   "step_qr_bond")
+
+    def step_cap_bond(self, bond: int, target: int, ids=None, set_index: int = 0):
+        a, n = self._ids(ids)
+        _lib.check(self.lib.tjm_engine_step_cap_bond(self.h, set_index, int(bond), int(target), None if a is None else a.ctypes.data, n), "step_cap_bond")
 
     def stats(self) -> dict:
         s = np.zeros(9, dtype=np.int64)

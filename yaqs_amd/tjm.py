@@ -51,6 +51,61 @@ def _diagnostics_from_bonds(chi: np.ndarray, d: int) -> np.ndarray:
     return np.stack([cost, max_bond, total], axis=1)
 
 
+def dynamic_tdvp(e, set_index: int, max_bond_dim: int | None, dt: float, sweeps: int = 1) -> None:
+    """``tdvp(tdvp_mode="dynamic")`` (tdvp/tdvp.py:69-111 -> integrators.py:294-511) for a lock-step batch.
+
+    Site by site a trajectory takes the two-site branch (uncapped split, ``split_tdvp(dynamic=True)``) while the bond to its right
+    (left, on the way back) is below ``max_bond_dim`` and the one-site branch with a QR bond transfer once it has reached it.  Bonds
+    differ per trajectory, so the host reads the bond table before every site, forms the two index lists and calls the engine's
+    site-level steps for each (``tjm_engine_step_*``); every contraction, exponential and factorisation is a HIP kernel."""
+    for _ in range(sweeps):
+        _sweep_dynamic(e, set_index, max_bond_dim, dt / sweeps)
+
+
+def _sweep_dynamic(e, s: int, cap: int | None, dt: float) -> None:
+    n = e.L
+    everyone = np.arange(e.B)
+
+    def lists(dims):
+        """(one-site list, two-site list) for the bond dimensions ``dims[B]`` of the bond that decides the branch."""
+        if cap is None:
+            return everyone[:0], everyone
+        at_cap = dims >= cap
+        return everyone[at_cap], everyone[~at_cap]
+
+    if cap is not None:  # _cap_bonds (sweep_utils.py:280-302): bonds the previous sweep left above the cap
+        for bond in range(n - 1):
+            over = everyone[e.bond_dims(s)[:, bond + 1] > cap]
+            if len(over):
+                e.step_cap_bond(bond, cap, over, s)
+    e.step_env_init(s)
+    for i in range(n):                     # left to right (integrators.py:340-424)
+        one, two = lists(e.bond_dims(s)[:, i + 1])
+        if len(one):
+            e.step_one_site(i, 0.5 * dt, one, s)
+            if i != n - 1:
+                e.step_qr_bond(i, True, -0.5 * dt, one, s)
+        if len(two) and i != n - 1:
+            e.step_two_site(i, 0.5 * dt, "right", False, two, s)
+            if i == n - 2:
+                e.step_env(i + 1, False, two, s)
+                e.step_env(i, True, two, s)
+            else:
+                e.step_env(i, True, two, s)
+                e.step_one_site(i + 1, -0.5 * dt, two, s)
+    for i in reversed(range(n)):           # right to left (integrators.py:427-505)
+        one, two = lists(e.bond_dims(s)[:, i])
+        if len(one):
+            e.step_one_site(i, 0.5 * dt, one, s)
+            if i != 0:
+                e.step_qr_bond(i, False, -0.5 * dt, one, s)
+        if len(two) and i != 0:
+            e.step_two_site(i - 1, 0.5 * dt, "left", False, two, s)
+            e.step_env(i, False, two, s)
+            if i != 1:
+                e.step_one_site(i - 1, -0.5 * dt, two, s)
+
+
 class TrajectoryBatch:
     """Runs trajectories ``traj_indices`` (one per engine slot) through one TJM driver."""
 
@@ -58,8 +113,9 @@ class TrajectoryBatch:
         self.e = engine
         self.p = params
         self.noise = noise if (noise is not None and (noise.processes or getattr(noise, "scheduled_jumps", None))) else None
-        if params.tdvp_mode not in ("1site", "2site"):
-            raise NotImplementedError(f"tdvp_mode {params.tdvp_mode!r} is not built yet in the HIP path")
+        if params.tdvp_mode not in ("1site", "2site", "dynamic"):
+            raise ValueError(f'tdvp_mode must be one of ("1site", "2site", "dynamic"), got {params.tdvp_mode!r}.')  # tdvp.py:109-111
+        self.dynamic = params.tdvp_mode == "dynamic" and engine.L > 1  # a one-site chain falls back to 1TDVP (tdvp.py:96-98)
         if getattr(params, "evolution_mode", "tdvp") != "tdvp":
             # bug.py:213-257: two augmented half-sweeps let every bond grow to 4 * max_bond_dim before the compression
             raise NotImplementedError("evolution_mode='bug' (Basis-Update and Galerkin) is not built yet in the HIP path")
@@ -74,8 +130,8 @@ class TrajectoryBatch:
                     raise ValueError("Only nearest-neighbor observables are currently implemented.")  # mps.py:1012-1014
                 self.two_site_obs = True
         engine.set_params(dt=params.dt, svd_threshold=params.svd_threshold, trunc_mode=params.trunc_mode,
-                          max_bond_dim=params.max_bond_dim, krylov_tol=params.krylov_tol, tdvp_mode=params.tdvp_mode,
-                          tdvp_sweeps=params.tdvp_sweeps)
+                          max_bond_dim=params.max_bond_dim, krylov_tol=params.krylov_tol,
+                          tdvp_mode=params.tdvp_mode if (self.dynamic or params.tdvp_mode != "dynamic") else "1site", tdvp_sweeps=params.tdvp_sweeps)
         procs = self.noise.processes if self.noise is not None else []
         engine.set_noise(procs, [is_pauli(q) for q in procs])
         self.sorted_obs = params.sorted_observables
@@ -96,7 +152,10 @@ class TrajectoryBatch:
         if self.intervals is not None and self._interval_loaded != interval:
             self.e.set_mpo(self.intervals[interval])
             self._interval_loaded = interval
-        self.e.tdvp(set_index)
+        if self.dynamic:
+            dynamic_tdvp(self.e, set_index, self.p.max_bond_dim, self.p.dt, self.p.tdvp_sweeps)
+        else:
+            self.e.tdvp(set_index)
 
     # ---- measurement ----------------------------------------------------------------
     def _measure(self, set_index: int, results: np.ndarray, diagnostics: np.ndarray, col: int) -> None:
@@ -193,7 +252,7 @@ class TrajectoryBatch:
             for j in self.noise.scheduled_jumps:
                 if not np.any(np.isclose(p.times, j["time"], atol=p.dt * 1e-3, rtol=0.0)):
                     raise ValueError(f"Scheduled jump time {j['time']} is not on the simulation time grid.")  # noise_model.py:768-775
-        if native and not options and not self.meta_obs and not has_sched and self.intervals is None:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
+        if native and not options and not self.dynamic and not self.meta_obs and not has_sched and self.intervals is None:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
             obs = [(o_.first_site, np.asarray(o_.gate.matrix, dtype=np.complex128)) for o_ in self.sorted_obs]
             kw = {}
             if resume is None:
@@ -783,6 +842,10 @@ def engine_bond_caps(sim_params, initial_state, can_grow: bool = False) -> tuple
     have = max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors)
     exact = 2 ** min(initial_state.length // 2, 30)
     want = exact if sim_params.max_bond_dim is None else min(int(sim_params.max_bond_dim), exact)
+    if getattr(sim_params, "tdvp_mode", "2site") == "dynamic" and sim_params.max_bond_dim is not None:
+        # the two-site branch of the dynamic sweep splits without a cap (split_tdvp(dynamic=True)): a bond next to one below the cap
+        # can reach d * (max_bond_dim - 1) before _cap_bonds cuts it back at the start of the next sweep
+        want = min(2 * int(sim_params.max_bond_dim), exact)
     top = max(want, have)
     if have > MAX_CHI:
         raise NotImplementedError(f"bond dimension {have} of the initial state exceeds the supported chi <= {MAX_CHI}")
