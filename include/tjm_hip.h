@@ -42,6 +42,9 @@ typedef struct tjm_engine tjm_engine;
 
 /* mpo_bond[L+1]: MPO bond dimensions, mpo_bond[0] = mpo_bond[L] = 1 (mpo.py:45-50). */
 int tjm_engine_create(tjm_engine** out, int32_t L, int32_t d, int32_t chi_max, int32_t B, const int32_t* mpo_bond);
+/* The same with storage of bond k = min(chi_max, cap_slack * min(d^k, d^(L-k))): cap_slack = 1 is the exact Schmidt-rank bound of
+ * tjm_engine_create; the BUG integrator (core/methods/bug.py) needs 2 for its stacked trial bases near the chain ends. */
+int tjm_engine_create_ex(tjm_engine** out, int32_t L, int32_t d, int32_t chi_max, int32_t B, const int32_t* mpo_bond, int32_t cap_slack);
 void tjm_engine_destroy(tjm_engine* e);
 size_t tjm_engine_workspace_bytes(const tjm_engine* e);
 /* workspace: device memory of at least workspace_bytes; stream: hipStream_t (0 = default). */

@@ -33,10 +33,11 @@ class _ScriptedRng:
 class OracleEngine:
     instances: list = []
 
-    def __init__(self, length, chi_max, batch, mpo, device="cpu", d=2, stream=None):
+    def __init__(self, length, chi_max, batch, mpo, device="cpu", d=2, stream=None, cap_slack=1):
         self.L, self.d, self.chi_max, self.B = int(length), int(d), int(chi_max), int(batch)
         self.mpo = [np.asarray(w, dtype=np.complex128) for w in mpo]
-        self.caps = np.array(o.MPSState.bond_caps(self.L, self.chi_max), dtype=np.int32)
+        exact = o.MPSState.bond_caps(self.L, 1 << 30)
+        self.caps = np.array([min(self.chi_max, int(cap_slack) * c) if 0 < k < self.L else 1 for k, c in enumerate(exact)], dtype=np.int32)
         self.sets = [[None] * self.B, [None] * self.B]
         self.noise = None
         self.filter = None
@@ -54,6 +55,10 @@ class OracleEngine:
 
     def set_mpo(self, mpo):
         self.mpo = [np.asarray(w, dtype=np.complex128) for w in mpo]
+
+    @property
+    def mpo_tensors(self):
+        return self.mpo
 
     def set_noise(self, processes, flags):
         self.noise = [dict(q) for q in processes]
@@ -134,6 +139,7 @@ class OracleEngine:
     def canonicalize_qr(self, center, set_index=0):
         for s in self.sets[set_index]:
             s.set_canonical_form(0, "QR")
+            s.center = 0
 
     def normalize_qr(self, center, set_index=0):
         for s in self.sets[set_index]:
@@ -215,6 +221,53 @@ class OracleEngine:
     def step_cap_bond(self, bond, target, ids=None, set_index=0):
         for b in self._slots(ids):
             o._sync_bond_dim(self.sets[set_index][b], bond, target, self.params)
+
+    # -- steps of the BUG integrator (tjm_engine_step_bug_*, _flip, _compress) ------------
+    def step_bug_prepare(self, set_index=0):
+        """prepare_canonical_site_tensors (bug.py:35-62) for every slot; the basis-change matrix starts as the identity."""
+        self.bug = {}
+        for b, s in enumerate(self.sets[set_index]):
+            t = s.tensors
+            canon = list(t)
+            lenv = [np.eye(t[0].shape[1], dtype=np.complex128).reshape(t[0].shape[1], 1, t[0].shape[1])]
+            for i in range(1, self.L):
+                q, r = o.right_qr(canon[i - 1])
+                canon[i] = np.tensordot(r, canon[i], axes=(1, 1)).transpose(1, 0, 2)
+                lenv.append(o.update_left_environment(q, q, self.mpo[i - 1], lenv[i - 1]))
+            rdim = t[-1].shape[2]
+            self.bug[b] = dict(canon=canon, lenv=lenv, rblock=np.eye(rdim, dtype=np.complex128).reshape(rdim, 1, rdim),
+                               m=np.eye(rdim, dtype=np.complex128))
+
+    def step_bug_site(self, site, dt, set_index=0):
+        """_local_update (bug.py:93-125): predictor, stacked trial basis, basis-change matrix, transported centre, right block."""
+        tol = self.params.krylov_tol
+        for b, s in enumerate(self.sets[set_index]):
+            t, w = s.tensors, self.bug[b]
+            working = w["canon"][site]
+            predictor = o.update_site(w["lenv"][site], w["rblock"], self.mpo[site], working, dt, tol)
+            old_current = np.tensordot(t[site], w["m"], axes=(2, 0))
+            retained = t[site] if site == self.L - 1 else working
+            new_q, _ = o.left_qr(np.concatenate((retained, predictor), axis=1))
+            w["m"] = np.tensordot(old_current, new_q.conj(), axes=([0, 2], [0, 2]))
+            t[site] = new_q
+            w["canon"][site - 1] = np.tensordot(w["canon"][site - 1], w["m"], axes=(2, 0))
+            w["rblock"] = o.update_right_environment(new_q, new_q, self.mpo[site], w["rblock"])
+        self._check()
+
+    def step_bug_root(self, dt, set_index=0):
+        for b, s in enumerate(self.sets[set_index]):
+            w = self.bug[b]
+            s.tensors[0] = o.update_site(w["lenv"][0], w["rblock"], self.mpo[0], w["canon"][0], dt, self.params.krylov_tol)
+            s.center = 0
+
+    def step_flip(self, set_index=0):
+        for s in self.sets[set_index]:
+            s.flip()
+
+    def step_compress(self, threshold, max_bond_dim, trunc_mode, set_index=0):
+        for s in self.sets[set_index]:
+            o.compress(s, threshold, max_bond_dim, trunc_mode)
+        self._check()
 
     # -- measurement ---------------------------------------------------------------------
     def site_moments(self, set_index=0):

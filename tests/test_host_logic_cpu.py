@@ -200,3 +200,48 @@ def test_dynamic_tdvp_driven_from_the_host_matches_the_reference(sim):
         want = g[f"traj_dynamic_order{order}_results"]
         for s_ in range(L):
             assert np.allclose(res.trajectories[s_], want[:, s_, :], atol=1e-8), (order, s_, np.abs(res.trajectories[s_] - want[:, s_, :]).max())
+
+
+def test_bug_integrator_driven_from_the_host_matches_the_reference(sim):
+    """evolution_mode="bug" (core/methods/bug.py:128-257): the sequence of steps of one BUG time step - two half-sweeps with alternating
+    endpoints, compression, renormalisation - is host logic over the engine's BUG steps.  Single steps on the generic-state chains of
+    tests/golden/f3_dynamic_bug.npz and whole noisy trajectories of both drivers against the REFERENCE's outputs.  (From a product
+    state the reference's own result is decided by rounding noise - exactly dependent columns in the stacked basis - so those cases
+    are not compared.)"""
+    import os
+
+    from conftest import GOLDEN
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
+    from yaqs_amd.tjm import bug_step
+
+    g = np.load(os.path.join(GOLDEN, "f3_dynamic_bug.npz"))
+    for key in g["cases"]:
+        key = str(key)
+        if key.endswith("x+"):
+            continue
+        L = int(key.split("_")[0][1:])
+        cap = key.split("_")[2][3:]
+        cap = None if cap == "None" else int(cap)
+        mpo = [g[f"{key}_mpo{i}"] for i in range(L)]
+        e = OracleEngine(L, 64, 2, mpo)
+        p = AnalogSimParams(observables=[Observable(Zg(), 0)], elapsed_time=0.1, dt=0.1, max_bond_dim=cap, svd_threshold=1e-9, krylov_tol=1e-12,
+                            evolution_mode="bug")
+        e.set_params(dt=0.1, svd_threshold=1e-9, max_bond_dim=cap, krylov_tol=1e-12)
+        e.load_state([g[f"{key}_in{i}"] for i in range(L)])
+        bug_step(e, 0, p, mpo)
+        for b in range(2):
+            out = o.MPSState(e.export_state(b), 0)
+            assert [t.shape[2] for t in out.tensors] == list(g[f"{key}_bug_bonds"]), key
+            v, ref = out.to_vec(), g[f"{key}_bug_vec"]
+            assert abs(abs(np.vdot(ref, v)) - np.vdot(ref, ref).real) < 1e-9, key
+    L = 6
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
+    st = MPS(L, tensors=[g[f"traj_in{i}"] for i in range(L)])
+    H = MPO([g[f"traj_mpo{i}"] for i in range(L)])
+    for order in (1, 2):
+        p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=0.5, dt=0.1, num_traj=4, max_bond_dim=4, svd_threshold=1e-9,
+                            krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=9, evolution_mode="bug")
+        res = sim(batch=4, native=False).run(st, H, p, noise)
+        want = g[f"traj_bug_order{order}_results"]
+        for s_ in range(L):
+            assert np.allclose(res.trajectories[s_], want[:, s_, :], atol=1e-8), (order, s_, np.abs(res.trajectories[s_] - want[:, s_, :]).max())

@@ -69,6 +69,7 @@ EXPORTS = {
     "tjm_version": (C.c_int, []),
     "tjm_error_string": (C.c_char_p, [C.c_int]),
     "tjm_engine_create": (C.c_int, [C.POINTER(V), I, I, I, I, V]),
+    "tjm_engine_create_ex": (C.c_int, [C.POINTER(V), I, I, I, I, V, I]),
     "tjm_engine_destroy": (None, [V]),
     "tjm_engine_workspace_bytes": (C.c_size_t, [V]),
     "tjm_engine_bind": (C.c_int, [V, V, C.c_size_t, V]),

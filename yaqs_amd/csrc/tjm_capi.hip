@@ -62,6 +62,16 @@ int tjm_engine_create(tjm_engine** out, int32_t L, int32_t d, int32_t chi_max, i
   return TJM_OK;
 }
 
+int tjm_engine_create_ex(tjm_engine** out, int32_t L, int32_t d, int32_t chi_max, int32_t B, const int32_t* mpo_bond, int32_t cap_slack) {
+  if (!out || !mpo_bond) return TJM_ERR_ARG;
+  tjm_engine* e = new (std::nothrow) tjm_engine();
+  if (!e) return TJM_ERR_ARG;
+  const int rc = e->impl.create(L, d, chi_max, B, mpo_bond, cap_slack);
+  if (rc != TJM_OK) { delete e; return rc; }
+  *out = e;
+  return TJM_OK;
+}
+
 void tjm_engine_destroy(tjm_engine* e) {
   TJM_ON_DEVICE(e);
   delete e;

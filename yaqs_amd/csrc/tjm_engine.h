@@ -53,7 +53,7 @@ class Engine {
   };
   int phase_depth_ = 0;
 
-  int create(int L, int d, int chi_max, int B, const int* mpo_bond);
+  int create(int L, int d, int chi_max, int B, const int* mpo_bond, int cap_slack = 1);
   size_t workspace_bytes() const;
   int bind(void* ws, size_t bytes, hipStream_t s);
   int set_mpo(const double* host_tensors);   // packed (o,p,l,r) complex128 per site

@@ -123,14 +123,16 @@ Engine::Region::~Region() {
   }
 }
 
-int Engine::create(int L_, int d_, int chi_, int B_, const int* mpo_bond) {
-  if (L_ < 1 || d_ != 2 || chi_ < 1 || B_ < 1) return TJM_ERR_ARG;  // qubit chains only for now
+int Engine::create(int L_, int d_, int chi_, int B_, const int* mpo_bond, int cap_slack) {
+  if (L_ < 1 || d_ != 2 || chi_ < 1 || B_ < 1 || cap_slack < 1) return TJM_ERR_ARG;  // qubit chains only for now
   L = L_; d = d_; chi_max = chi_; B = B_;
+  // storage of bond k: min(chi_max, slack * min(d^k, d^(L-k))).  slack = 1 is the exact Schmidt-rank bound; the stacked trial bases of
+  // the BUG integrator hold up to twice that near the chain ends between a half-sweep and the next canonicalisation (slack = 2)
   cap.assign(L + 1, 1);
   long left = 1;
-  for (int i = 1; i < L; ++i) { left = std::min<long>(left * d, chi_max); cap[i] = (int)left; }
+  for (int i = 1; i < L; ++i) { left = std::min<long>(left * d, (long)chi_max * 4); cap[i] = (int)std::min<long>(left * cap_slack, chi_max); }
   long right = 1;
-  for (int i = L - 1; i > 0; --i) { right = std::min<long>(right * d, chi_max); cap[i] = std::min<int>(cap[i], (int)right); }
+  for (int i = L - 1; i > 0; --i) { right = std::min<long>(right * d, (long)chi_max * 4); cap[i] = std::min<int>(cap[i], (int)std::min<long>(right * cap_slack, chi_max)); }
   Dm.assign(mpo_bond, mpo_bond + L + 1);
   Dmax = *std::max_element(Dm.begin(), Dm.end());
   if (Dm[0] != 1 || Dm[L] != 1) return TJM_ERR_ARG;

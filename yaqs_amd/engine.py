@@ -20,7 +20,8 @@ def _i32(a) -> np.ndarray:
 
 
 class BatchEngine:
-    def __init__(self, length: int, chi_max: int, batch: int, mpo: Sequence[np.ndarray], device: str = "cuda:0", d: int = 2, stream=None):
+    def __init__(self, length: int, chi_max: int, batch: int, mpo: Sequence[np.ndarray], device: str = "cuda:0", d: int = 2, stream=None,
+                 cap_slack: int = 1):
         import torch
 
         if not torch.cuda.is_available():
@@ -32,7 +33,7 @@ class BatchEngine:
         bonds = [int(mpo[0].shape[2])] + [int(w.shape[3]) for w in mpo]
         self.mpo_bonds = _i32(bonds)
         h = C.c_void_p()
-        _lib.check(self.lib.tjm_engine_create(C.byref(h), self.L, self.d, self.chi_max, self.B, self.mpo_bonds.ctypes.data), "create")
+        _lib.check(self.lib.tjm_engine_create_ex(C.byref(h), self.L, self.d, self.chi_max, self.B, self.mpo_bonds.ctypes.data, int(cap_slack)), "create")
         self.h = h
         nbytes = self.lib.tjm_engine_workspace_bytes(self.h)
         self.workspace_bytes = int(nbytes)
@@ -46,18 +47,19 @@ class BatchEngine:
         _lib.check(self.lib.tjm_engine_bind(self.h, self.ws.data_ptr(), nbytes, C.c_void_p(self.stream.cuda_stream)), "bind")
         packed = np.concatenate([np.ascontiguousarray(w, dtype=np.complex128).reshape(-1) for w in mpo])
         _lib.check(self.lib.tjm_engine_set_mpo(self.h, packed.ctypes.data), "set_mpo")
+        self.mpo_tensors = [np.array(w, dtype=np.complex128) for w in mpo]  # the Hamiltonian the engine currently holds
         caps = np.zeros(self.L + 1, dtype=np.int32)
         self.lib.tjm_engine_bond_caps(self.h, caps.ctypes.data)
         self.caps = caps
         self.padded_elems = int(self.lib.tjm_engine_padded_state_elems(self.h))
 
     @staticmethod
-    def workspace_bytes_for(length: int, chi_max: int, batch: int, mpo: Sequence[np.ndarray], d: int = 2) -> int:
+    def workspace_bytes_for(length: int, chi_max: int, batch: int, mpo: Sequence[np.ndarray], d: int = 2, cap_slack: int = 1) -> int:
         """Device bytes an engine of this shape binds (no GPU needed): used to size the batch to the free HBM."""
         lib = _lib.load()
         bonds = _i32([int(mpo[0].shape[2])] + [int(w.shape[3]) for w in mpo])
         h = C.c_void_p()
-        _lib.check(lib.tjm_engine_create(C.byref(h), int(length), int(d), int(chi_max), int(batch), bonds.ctypes.data), "create")
+        _lib.check(lib.tjm_engine_create_ex(C.byref(h), int(length), int(d), int(chi_max), int(batch), bonds.ctypes.data, int(cap_slack)), "create")
         try:
             return int(lib.tjm_engine_workspace_bytes(h))
         finally:
@@ -70,6 +72,7 @@ class BatchEngine:
             raise NotImplementedError("piecewise Hamiltonians must share the MPO bond dimensions the engine was created with")
         packed = np.concatenate([np.ascontiguousarray(w, dtype=np.complex128).reshape(-1) for w in mpo])
         _lib.check(self.lib.tjm_engine_set_mpo(self.h, packed.ctypes.data), "set_mpo")
+        self.mpo_tensors = [np.array(w, dtype=np.complex128) for w in mpo]
 
     def close(self):
         if getattr(self, "h", None):

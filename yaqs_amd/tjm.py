@@ -106,6 +106,37 @@ def _sweep_dynamic(e, s: int, cap: int | None, dt: float) -> None:
                 e.step_one_site(i - 1, -0.5 * dt, two, s)
 
 
+def bug_step(e, set_index: int, params, mpo_tensors) -> None:
+    """One physical step of the Basis-Update and Galerkin integrator, ``bug()`` (core/methods/bug.py:213-257), for a lock-step batch:
+    two half-sweeps of ``dt / 2`` with alternating endpoints (the second on the site-reversed chain with the reflected MPO), one
+    compression with the run's truncation settings, renormalisation.  Each half-sweep (``bug_sweep``, bug.py:128-196) prepares the
+    coefficient-bearing centres and left environments, then walks from the last site to site 1 - Krylov predictor, left QR of the
+    stacked basis ``[retained | predictor]``, basis-change matrix, transported centre, right block - and evolves the root.  The
+    host only sequences the steps; every one of them is a set of HIP kernels behind ``tjm_engine_step_bug_* / _flip / _compress``."""
+    n = e.L
+    half = params.dt / 2.0
+    reflected = [np.ascontiguousarray(np.transpose(np.asarray(w), (0, 1, 3, 2))) for w in reversed(list(mpo_tensors))]  # MPO.reflected, mpo.py:1612-1630
+
+    def sweep():
+        e.step_bug_prepare(set_index)
+        for site in range(n - 1, 0, -1):
+            e.step_bug_site(site, half, set_index)
+        e.step_bug_root(half, set_index)
+
+    sweep()
+    if n > 1:
+        e.step_flip(set_index)
+        e.set_mpo(reflected)
+        e.canonicalize_qr(n - 1, set_index)
+    sweep()
+    if n > 1:
+        e.step_flip(set_index)
+        e.set_mpo(list(mpo_tensors))
+        e.canonicalize_qr(n - 1, set_index)
+    e.step_compress(params.svd_threshold, params.max_bond_dim, params.trunc_mode, set_index)
+    e.normalize_qr(0, set_index)
+
+
 class TrajectoryBatch:
     """Runs trajectories ``traj_indices`` (one per engine slot) through one TJM driver."""
 
@@ -116,9 +147,7 @@ class TrajectoryBatch:
         if params.tdvp_mode not in ("1site", "2site", "dynamic"):
             raise ValueError(f'tdvp_mode must be one of ("1site", "2site", "dynamic"), got {params.tdvp_mode!r}.')  # tdvp.py:109-111
         self.dynamic = params.tdvp_mode == "dynamic" and engine.L > 1  # a one-site chain falls back to 1TDVP (tdvp.py:96-98)
-        if getattr(params, "evolution_mode", "tdvp") != "tdvp":
-            # bug.py:213-257: two augmented half-sweeps let every bond grow to 4 * max_bond_dim before the compression
-            raise NotImplementedError("evolution_mode='bug' (Basis-Update and Galerkin) is not built yet in the HIP path")
+        self.bug = str(getattr(getattr(params, "evolution_mode", "tdvp"), "value", getattr(params, "evolution_mode", "tdvp"))) == "bug"
         self.two_site_obs = False
         self.schmidt: dict = {}  # (sorted row, column) -> [B, 500] Schmidt spectra
         self.meta_obs = any(obs.gate.name in META_OBSERVABLES for obs in params.observables)
@@ -152,7 +181,10 @@ class TrajectoryBatch:
         if self.intervals is not None and self._interval_loaded != interval:
             self.e.set_mpo(self.intervals[interval])
             self._interval_loaded = interval
-        if self.dynamic:
+        if self.bug:  # apply_unitary_evolution (analog/evolution.py:24-51)
+            mpo = [np.array(w) for w in self.e.mpo_tensors]  # the interval's Hamiltonian was loaded just above
+            bug_step(self.e, set_index, self.p, mpo)
+        elif self.dynamic:
             dynamic_tdvp(self.e, set_index, self.p.max_bond_dim, self.p.dt, self.p.tdvp_sweeps)
         else:
             self.e.tdvp(set_index)
@@ -252,7 +284,7 @@ class TrajectoryBatch:
             for j in self.noise.scheduled_jumps:
                 if not np.any(np.isclose(p.times, j["time"], atol=p.dt * 1e-3, rtol=0.0)):
                     raise ValueError(f"Scheduled jump time {j['time']} is not on the simulation time grid.")  # noise_model.py:768-775
-        if native and not options and not self.dynamic and not self.meta_obs and not has_sched and self.intervals is None:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
+        if native and not options and not self.dynamic and not self.bug and not self.meta_obs and not has_sched and self.intervals is None:  # entropy / Schmidt spectrum / PVM are evaluated by the host schedule
             obs = [(o_.first_site, np.asarray(o_.gate.matrix, dtype=np.complex128)) for o_ in self.sorted_obs]
             kw = {}
             if resume is None:
@@ -587,6 +619,7 @@ class Simulator:
         self.parallel, self.max_workers = parallel, max_workers
         self.batch = batch
         self.device = device
+        self._engine_kw: dict = {}
         self.show_progress = show_progress
         self.native = native  # True: the C driver tjm_engine_run runs the schedule; False: the Python mirror of it
 
@@ -597,7 +630,7 @@ class Simulator:
             return max(1, min(int(self.batch), remaining))
         import torch
 
-        per_traj = BatchEngine.workspace_bytes_for(length, chi, 64, mpo) / 64.0
+        per_traj = BatchEngine.workspace_bytes_for(length, chi, 64, mpo, **self._engine_kw) / 64.0
         free, _total = torch.cuda.mem_get_info(torch.device(device))
         fit = int(0.6 * free / per_traj)
         return max(1, min(remaining, AUTO_BATCH_MAX, fit))
@@ -620,7 +653,7 @@ class Simulator:
                 pending.append((lo + fit, hi, src, first + fit, start, None if pos is None else pos[fit:], extra, cap_now))
                 hi = lo + fit
                 pos = None if pos is None else pos[:fit]
-            engine = BatchEngine(length, cap_now, hi - lo, mpo, device=device)
+            engine = BatchEngine(length, cap_now, hi - lo, mpo, device=device, **self._engine_kw)
             batch = make_batch(engine)
             try:
                 resume = None
@@ -697,6 +730,8 @@ class Simulator:
         lo, hi = shard_range(num_traj, rank, world)
         mine = list(range(lo, hi))
         chi, chi_top = engine_bond_caps(sim_params, initial_state, can_grow=_noise_can_grow_bonds(noise_model))
+        mode = getattr(sim_params, "evolution_mode", "tdvp")
+        self._engine_kw = {"cap_slack": 2} if str(getattr(mode, "value", mode)) == "bug" else {}
         cols = len(sim_params.times) if sim_params.sample_timesteps else 1
         n_obs = len(sim_params.observables)
         res_all = np.zeros((len(mine), n_obs, cols))
@@ -761,6 +796,7 @@ class Simulator:
         noisy = noise_model is not None and any(q["strength"] != 0 for q in noise_model.processes)
         num_traj, per_call, distribution = plan_digital_shots(sim_params, noisy)
         device = self.device or f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
+        self._engine_kw = {}
         chi, chi_top = engine_bond_caps(sim_params, initial_state, can_grow=True)  # every TEBD gate is a truncated split
         mid = sim_params.num_mid_measurements if sim_params.sample_layers else 0
         cols = (mid + 2) if sim_params.sample_layers else 1
@@ -841,11 +877,19 @@ def engine_bond_caps(sim_params, initial_state, can_grow: bool = False) -> tuple
     """
     have = max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors)
     exact = 2 ** min(initial_state.length // 2, 30)
+    mode = getattr(sim_params, "evolution_mode", "tdvp")
+    bug = str(getattr(mode, "value", mode)) == "bug"
+    if bug:
+        exact *= 2  # a stacked trial basis holds up to twice the Schmidt rank of its cut until the next canonicalisation (cap_slack = 2)
     want = exact if sim_params.max_bond_dim is None else min(int(sim_params.max_bond_dim), exact)
-    if getattr(sim_params, "tdvp_mode", "2site") == "dynamic" and sim_params.max_bond_dim is not None:
+    if getattr(sim_params, "tdvp_mode", "2site") == "dynamic" and sim_params.max_bond_dim is not None and not bug:
         # the two-site branch of the dynamic sweep splits without a cap (split_tdvp(dynamic=True)): a bond next to one below the cap
         # can reach d * (max_bond_dim - 1) before _cap_bonds cuts it back at the start of the next sweep
         want = min(2 * int(sim_params.max_bond_dim), exact)
+    if bug and sim_params.max_bond_dim is not None:
+        # each of the two half-sweeps of a BUG step stacks [retained | predictor] along the left bond of every site: bonds reach
+        # 4 * max_bond_dim before the single compression at the end of the step (bug.py:213-257)
+        want = min(4 * int(sim_params.max_bond_dim), exact)
     top = max(want, have)
     if have > MAX_CHI:
         raise NotImplementedError(f"bond dimension {have} of the initial state exceeds the supported chi <= {MAX_CHI}")
