@@ -164,6 +164,20 @@ int tjm_engine_step_env(tjm_engine* e, int32_t set, int32_t site, int32_t left, 
 int tjm_engine_step_qr_bond(tjm_engine* e, int32_t set, int32_t site, int32_t right, double dt, const int32_t* ids, int32_t n);
 int tjm_engine_step_cap_bond(tjm_engine* e, int32_t set, int32_t bond, int32_t target, const int32_t* ids, int32_t n);
 
+/* Steps of the Basis-Update and Galerkin integrator (core/methods/bug.py) for the whole batch, sequenced by the host
+ * (yaqs_amd/tjm.py: bug_step = bug(), bug.py:213-257); the engine must have been created with cap_slack >= 2.
+ *   step_bug_prepare  prepare_canonical_site_tensors (bug.py:35-62): coefficient-bearing centres and left environments
+ *   step_bug_site     _local_update + build_trial_basis (bug.py:65-125) at `site` (L-1 ... 1): Krylov predictor, left QR of
+ *                     [retained | predictor] stacked along the left bond, basis-change matrix, transported centre, right block
+ *   step_bug_root     the root update of bug_sweep (bug.py:186-196)
+ *   step_flip         MPS.flip_network (mps.py:680-698); the caller loads the reflected MPO (mpo.py:1612-1630) with set_mpo
+ *   step_compress     MPS.compress (mps.py:841-899) with the given truncation settings (max_bond_dim <= 0: none) */
+int tjm_engine_step_bug_prepare(tjm_engine* e, int32_t set);
+int tjm_engine_step_bug_site(tjm_engine* e, int32_t set, int32_t site, double dt);
+int tjm_engine_step_bug_root(tjm_engine* e, int32_t set, double dt);
+int tjm_engine_step_flip(tjm_engine* e, int32_t set);
+int tjm_engine_step_compress(tjm_engine* e, int32_t set, double threshold, int32_t max_bond_dim, int32_t trunc_mode);
+
 /* ---- whole trajectories in one call -------------------------------------------------- *
  * The body of the backend contract: analog_tjm_1 / analog_tjm_2 (analog/analog_tjm.py:206-462) for the B resident
  * trajectories, after set_params / set_mpo / set_noise / load_state.  Observables are given in the reference's

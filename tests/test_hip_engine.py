@@ -1590,3 +1590,47 @@ def test_dynamic_tdvp_matches_reference_on_the_engine():
         want = g[f"traj_dynamic_order{order}_results"]
         for s_ in range(L):
             assert np.allclose(res.trajectories[s_], want[:, s_, :], atol=1e-8), (order, s_)
+
+
+def test_bug_integrator_matches_reference_on_the_engine():
+    """evolution_mode="bug" (core/methods/bug.py:128-257) through the engine's BUG steps (tjm_engine_step_bug_* / _flip / _compress,
+    engines with cap_slack = 2): one step on the generic-state chains of tests/golden/f3_dynamic_bug.npz, then noisy trajectories of
+    both drivers through Simulator, against the reference's outputs.  (Product-state starts are not compared: the reference's own
+    result is rounding-dependent there, exactly dependent columns in the stacked basis.)"""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
+    from yaqs_amd.engine import BatchEngine
+    from yaqs_amd.tjm import Simulator, bug_step
+
+    g = load("f3_dynamic_bug")
+    for key in g["cases"]:
+        key = str(key)
+        if key.endswith("x+"):
+            continue
+        L = int(key.split("_")[0][1:])
+        cap = key.split("_")[2][3:]
+        cap = None if cap == "None" else int(cap)
+        mpo = tensors(g, key + "_mpo")
+        e = BatchEngine(L, 32, 2, mpo, cap_slack=2)
+        p = AnalogSimParams(observables=[Observable(Zg(), 0)], elapsed_time=0.1, dt=0.1, max_bond_dim=cap, svd_threshold=1e-9, krylov_tol=1e-12,
+                            evolution_mode="bug")
+        e.set_params(dt=0.1, svd_threshold=1e-9, max_bond_dim=cap, krylov_tol=1e-12)
+        e.set_noise([], [])
+        e.load_state(tensors(g, key + "_in"))
+        bug_step(e, 0, p, mpo)
+        assert not e.capacity_overflow()
+        for b in range(2):
+            out = e.export_state(b)
+            assert [t.shape[2] for t in out] == list(g[f"{key}_bug_bonds"]), key
+            v, ref = vec_of(out), g[f"{key}_bug_vec"]
+            assert abs(abs(np.vdot(ref, v)) - np.vdot(ref, ref).real) < 1e-9, key
+        e.close()
+    L = 6
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
+    st = MPS(L, tensors=tensors(g, "traj_in"))
+    for order in (1, 2):
+        p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=0.5, dt=0.1, num_traj=4, max_bond_dim=4, svd_threshold=1e-9,
+                            krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=9, evolution_mode="bug")
+        res = Simulator().run(st, MPO(tensors(g, "traj_mpo")), p, noise)
+        want = g[f"traj_bug_order{order}_results"]
+        for s_ in range(L):
+            assert np.allclose(res.trajectories[s_], want[:, s_, :], atol=1e-8), (order, s_)

@@ -116,6 +116,11 @@ EXPORTS = {
     "tjm_engine_step_env": (C.c_int, [V, I, I, I, V, I]),
     "tjm_engine_step_qr_bond": (C.c_int, [V, I, I, I, D, V, I]),
     "tjm_engine_step_cap_bond": (C.c_int, [V, I, I, I, V, I]),
+    "tjm_engine_step_bug_prepare": (C.c_int, [V, I]),
+    "tjm_engine_step_bug_site": (C.c_int, [V, I, I, D]),
+    "tjm_engine_step_bug_root": (C.c_int, [V, I, D]),
+    "tjm_engine_step_flip": (C.c_int, [V, I]),
+    "tjm_engine_step_compress": (C.c_int, [V, I, D, I, I]),
     "tjm_engine_profile": (C.c_int, [V, I]),
     "tjm_engine_profile_read": (C.c_int, [V, V, V]),
     "tjm_engine_run": (C.c_int, [V, C.POINTER(RunConfig), V, V, V]),

@@ -315,6 +315,32 @@ int tjm_engine_step_cap_bond(tjm_engine* e, int32_t set, int32_t bond, int32_t t
   return e->impl.step_cap_bond(set, bond, target, ids, n);
 }
 
+int tjm_engine_step_bug_prepare(tjm_engine* e, int32_t set) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.step_bug_prepare(set);
+}
+int tjm_engine_step_bug_site(tjm_engine* e, int32_t set, int32_t site, double dt) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.step_bug_site(set, site, dt);
+}
+int tjm_engine_step_bug_root(tjm_engine* e, int32_t set, double dt) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.step_bug_root(set, dt);
+}
+int tjm_engine_step_flip(tjm_engine* e, int32_t set) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.step_flip(set);
+}
+int tjm_engine_step_compress(tjm_engine* e, int32_t set, double threshold, int32_t max_bond_dim, int32_t trunc_mode) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.step_compress(set, threshold, max_bond_dim, trunc_mode);
+}
+
 int tjm_engine_profile(tjm_engine* e, int32_t enable) {
   if (!e) return TJM_ERR_ARG;
   TJM_ON_DEVICE(e);

@@ -112,6 +112,14 @@ class Engine {
   int step_env(int set, int i, int left, const int* host_ids, int n);
   int step_qr_bond(int set, int i, int right, double dt_, const int* host_ids, int n);
   int step_cap_bond(int set, int bond, int target, const int* host_ids, int n);
+  // steps of the BUG integrator (core/methods/bug.py:35-257), whole batch; centres live in set 2, scratch in set 3
+  int step_bug_prepare(int set);
+  int step_bug_site(int set, int site, double dt_);
+  int step_bug_root(int set, double dt_);
+  int step_flip(int set);
+  int step_compress(int set, double threshold, int max_bond_dim, int mode);
+  int copy_site(int dst, int src, int site);
+  int copy_chi_col(int dst, int src, int col);
   int upload_ids(const int* host_ids, int n, const int** dev);
   // kernel-level parity exports (tjm_capi.hip): operands are device arrays of nb <= B slots, W is a host MPO tensor (o,p,l,r)
   int x_heff_apply(int nsites, int ca, int cb, int Dl, int Dr, const cplx* x, const cplx* Lenv, const cplx* Renv, const double* host_w, cplx* y, int nb);
@@ -125,7 +133,8 @@ class Engine {
   int jump_weights(int set, double dt_, const std::vector<double>& nsq, const std::vector<int>& which, std::vector<int>& order,
                    std::vector<double>& w);
 
-  StateSet sets[2];
+  StateSet sets[4];   // 0: trajectory state phi, 1: measurement copy psi; 2, 3: centres and scratch of the BUG steps (engines created with cap_slack > 1)
+  int n_sets = 2;
   // work areas (public for tests)
   cplx *T1 = nullptr, *T2 = nullptr, *V = nullptr, *theta = nullptr;
   long v_b0 = 0, v_ld = 0, t_b0 = 0, theta_b0 = 0;
@@ -150,7 +159,7 @@ class Engine {
   int* opidx_ = nullptr;         // [B]
   int* jsite_ = nullptr;         // [B]
   int* overflow_ = nullptr;      // sticky flag: a truncation was clipped by the storage capacity
-  SmallSiteRef* site_refs_[2] = {nullptr, nullptr};   // device tables of the fused small-bond sweeps
+  SmallSiteRef* site_refs_[4] = {nullptr, nullptr, nullptr, nullptr};   // device tables of the fused small-bond sweeps
   SmallSweepStep* sweep_steps_ = nullptr;
   bool sweep_ok_ = false;
   int run_sweep(int set, const std::vector<SmallSweepStep>& steps, const int* ids, int nb0);

@@ -126,6 +126,7 @@ Engine::Region::~Region() {
 int Engine::create(int L_, int d_, int chi_, int B_, const int* mpo_bond, int cap_slack) {
   if (L_ < 1 || d_ != 2 || chi_ < 1 || B_ < 1 || cap_slack < 1) return TJM_ERR_ARG;  // qubit chains only for now
   L = L_; d = d_; chi_max = chi_; B = B_;
+  n_sets = cap_slack > 1 ? 4 : 2;
   // storage of bond k: min(chi_max, slack * min(d^k, d^(L-k))).  slack = 1 is the exact Schmidt-rank bound; the stacked trial bases of
   // the BUG integrator hold up to twice that near the chain ends between a half-sweep and the next canonicalisation (slack = 2)
   cap.assign(L + 1, 1);
@@ -148,7 +149,7 @@ int Engine::create(int L_, int d_, int chi_, int B_, const int* mpo_bond, int ca
 size_t Engine::workspace_bytes() const {
   const int cm = *std::max_element(cap.begin(), cap.end());
   size_t tot = 0;
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < n_sets; ++s) {
     for (int i = 0; i < L; ++i) tot += align_up((size_t)B * a_b0_[i] * sizeof(cplx));
     tot += align_up((size_t)B * (L + 1) * sizeof(int));
   }
@@ -170,7 +171,7 @@ size_t Engine::workspace_bytes() const {
   tot += (size_t)(3 * L) * align_up((size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx));
   tot += align_up((size_t)(L + 64) * 16 * sizeof(cplx));
   tot += 2 * align_up((size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx));  // MPO matrices of the kernel-level exports
-  tot += align_up((size_t)2 * L * sizeof(SmallSiteRef)) + align_up((size_t)(4 * L + 8) * sizeof(SmallSweepStep));  // fused sweeps
+  tot += align_up((size_t)4 * L * sizeof(SmallSiteRef)) + 4 * 256 + align_up((size_t)(4 * L + 8) * sizeof(SmallSweepStep));  // fused sweeps
   tot += 1 << 16;
   return tot;
 }
@@ -181,7 +182,7 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   char* p = static_cast<char*>(ws);
   auto take = [&](size_t n) { char* q = p; p += align_up(n); return q; };
   const int cm = *std::max_element(cap.begin(), cap.end());
-  for (int st = 0; st < 2; ++st) {
+  for (int st = 0; st < n_sets; ++st) {
     sets[st].A.resize(L);
     for (int i = 0; i < L; ++i) sets[st].A[i] = reinterpret_cast<cplx*>(take((size_t)B * a_b0_[i] * sizeof(cplx)));
     sets[st].chi = reinterpret_cast<int*>(take((size_t)B * (L + 1) * sizeof(int)));
@@ -226,7 +227,7 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   opidx_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   jsite_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   overflow_ = reinterpret_cast<int*>(take(256));
-  for (int st = 0; st < 2; ++st) site_refs_[st] = reinterpret_cast<SmallSiteRef*>(take((size_t)L * sizeof(SmallSiteRef)));
+  for (int st = 0; st < n_sets; ++st) site_refs_[st] = reinterpret_cast<SmallSiteRef*>(take((size_t)L * sizeof(SmallSiteRef)));
   sweep_steps_ = reinterpret_cast<SmallSweepStep*>(take((size_t)(4 * L + 8) * sizeof(SmallSweepStep)));
   TJM_HIP_CHECK(hipMemsetAsync(overflow_, 0, 2 * sizeof(int), s));
   E_ = reinterpret_cast<cplx*>(take((size_t)B * cm * cm * sizeof(cplx)));
@@ -254,7 +255,7 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   sweep_ok_ = !no_sweeps && d == 2 && L >= 2;
   for (int i = 0; i < L && sweep_ok_; ++i)
     sweep_ok_ = svd_shift_small_fits(d, cap[i], cap[i + 1], false) && svd_shift_small_fits(d, cap[i], cap[i + 1], true);
-  for (int st = 0; st < 2; ++st) {
+  for (int st = 0; st < n_sets; ++st) {
     std::vector<SmallSiteRef> refs(L);
     for (int i = 0; i < L; ++i) refs[i] = SmallSiteRef{sets[st].A[i], a_b0_[i], cap[i], cap[i + 1]};
     TJM_HIP_CHECK(hipMemcpyAsync(site_refs_[st], refs.data(), refs.size() * sizeof(SmallSiteRef), hipMemcpyHostToDevice, stream));
@@ -363,7 +364,7 @@ int Engine::load_state(int set, const double* host, const int* bonds) {
 }
 
 int Engine::copy_state(int dst, int src) {
-  if (!bound_ || dst == src) return TJM_ERR_ARG;
+  if (!bound_ || dst == src || dst < 0 || src < 0 || dst >= n_sets || src >= n_sets) return TJM_ERR_ARG;
   for (int i = 0; i < L; ++i)
     TJM_HIP_CHECK(hipMemcpyAsync(sets[dst].A[i], sets[src].A[i], (size_t)B * a_b0_[i] * sizeof(cplx), hipMemcpyDeviceToDevice, stream));
   TJM_HIP_CHECK(hipMemcpyAsync(sets[dst].chi, sets[src].chi, (size_t)B * (L + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
@@ -2135,6 +2136,212 @@ int Engine::step_cap_bond(int set, int bond, int target, const int* host_ids, in
   const int nb = host_ids ? n : B;
   if ((rc = merge_matrix_layout(S, bond, dev, nb)) != TJM_OK) return rc;
   return split(S, bond, 2, trunc_mode, svd_threshold, target, 1, dev, nb);
+}
+
+// ------------------------------------------------------------------------------------------
+// Steps of the Basis-Update and Galerkin integrator (core/methods/bug.py:35-257) for the whole batch.
+// Set `set` holds the state (right-canonical basis tensors, centre 0: the reference's state.tensors), set 2 the coefficient-bearing
+// centres (canon_center_tensors), set 3 is scratch (the Q factors of the preparation, then predictor / stacked basis / new basis).
+// The basis-change matrix M of the site below lives in E_ ([B][c][c'], leading dimension = capacity of that bond).
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ void chi_col_copy_kernel(int* dst, const int* src, int stride, int col, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) dst[(long)b * stride + col] = src[(long)b * stride + col];
+}
+__global__ void chi_reverse_kernel(int* dst, const int* src, int stride, int L, int B) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < B * (L + 1)) {
+    const int b = t / (L + 1), k = t % (L + 1);
+    dst[(long)b * stride + k] = src[(long)b * stride + (L - k)];
+  }
+}
+// out[b][p][c][a] = in[b][p][a][c]   (site tensor of the reversed chain, mps.py:680-698)
+__global__ __launch_bounds__(256) void flip_site_kernel(const cplx* __restrict__ in, long b0, int d, int ca, int cb, cplx* __restrict__ out) {
+  const int b = blockIdx.y;
+  const long n = (long)d * ca * cb;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int a = (int)(e % ca);
+    const long q = e / ca;
+    const int c = (int)(q % cb), p = (int)(q / cb);
+    out[(long)b * b0 + e] = in[(long)b * b0 + ((long)p * ca + a) * cb + c];
+  }
+}
+// Stack along the left bond without gaps (build_trial_basis, bug.py:78-80): out[p][a'][c] = ret[p][a'][c] for a' < n_ret,
+// pred[p][a' - n_ret][c] for n_ret <= a' < n_ret + n_pred, zero beyond; the new left bond goes to chi_out (clipped to ca: flagged).
+__global__ __launch_bounds__(256) void stack_left_kernel(const cplx* __restrict__ ret, const cplx* __restrict__ pred, long b0, int d, int ca, int cb,
+                                                        const int* chi_ret, const int* chi_pred, int* chi_out, int stride, int col,
+                                                        cplx* __restrict__ out, long out_b0, int* overflow) {
+  const int b = blockIdx.y;
+  const int nr = chi_ret[(long)b * stride + col], np_ = chi_pred[(long)b * stride + col];
+  int tot = nr + np_;
+  if (tot > ca) { tot = ca; if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(overflow, 1); }
+  const long n = (long)d * ca * cb;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % cb);
+    const long q = e / cb;
+    const int a = (int)(q % ca), p = (int)(q / ca);
+    cplx v{0.0, 0.0};
+    if (a < nr) v = ret[(long)b * b0 + e];
+    else if (a < tot) v = pred[(long)b * b0 + ((long)p * ca + (a - nr)) * cb + c];
+    out[(long)b * out_b0 + e] = v;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) chi_out[(long)b * stride + col] = tot;
+}
+__global__ void bond_identity_kernel(cplx* M, long m_b0, int n, int B) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (long)B * n * n) {
+    const long r = t % ((long)n * n);
+    M[(t / ((long)n * n)) * m_b0 + r] = cplx{(r / n == r % n) ? 1.0 : 0.0, 0.0};
+  }
+}
+}  // namespace
+
+int Engine::copy_chi_col(int dst, int src, int col) {
+  hipLaunchKernelGGL(chi_col_copy_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, sets[dst].chi, sets[src].chi, L + 1, col, B);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+int Engine::copy_site(int dst, int src, int site) {
+  TJM_HIP_CHECK(hipMemcpyAsync(sets[dst].A[site], sets[src].A[site], (size_t)B * a_b0_[site] * sizeof(cplx), hipMemcpyDeviceToDevice, stream));
+  int rc;
+  if ((rc = copy_chi_col(dst, src, site)) != TJM_OK) return rc;
+  return copy_chi_col(dst, src, site + 1);
+}
+
+// prepare_canonical_site_tensors (bug.py:35-62): centres canon[i] = R_{i-1} A_i into set 2 and the left environments of the Q factors
+int Engine::step_bug_prepare(int set) {
+  if (!bound_ || n_sets < 4 || set < 0 || set > 1) return TJM_ERR_ARG;
+  int rc;
+  if ((rc = copy_state(2, set)) != TJM_OK) return rc;
+  StateSet& Cs = sets[2];
+  StateSet& Qs = sets[3];
+  if ((rc = launch_identity_env(Lenv_[0], l_b0_[0], cap[0], Dm[0], B, stream)) != TJM_OK) return rc;
+  for (int i = 1; i < L; ++i) {
+    const int cb = cap[i], cc = cap[i + 1];
+    if ((rc = copy_site(3, 2, i - 1)) != TJM_OK) return rc;
+    if ((rc = qr_site(Qs, i - 1, true)) != TJM_OK) return rc;            // Q into set 3, R into Cm_, new bond into set 3's table
+    GemmDesc g = blank_gemm();                                           // canon[i][p][l][r] = R[l][x] canon[i][p][x][r]
+    g.A = Cm_; g.B = Cs.A[i]; g.C = T1;
+    g.M = cb; g.K = cb; g.N = cc;
+    g.a_rs = cb; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = cc;
+    g.nb0 = B; g.nb1 = d; g.a_b0 = (long)cb * cb; g.b_b0 = a_b0_[i]; g.b_b1 = (long)cb * cc; g.c_b0 = t_b0; g.c_b1 = (long)cb * cc;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+    if ((rc = copy_back(Cs.A[i], a_b0_[i], T1, t_b0, a_b0_[i], nullptr, B)) != TJM_OK) return rc;
+    if ((rc = copy_chi_col(2, 3, i)) != TJM_OK) return rc;
+    if ((rc = env_left_at(Qs.A[i - 1], a_b0_[i - 1], cap[i - 1], cap[i], Dm[i - 1], Dm[i], Lenv_[i - 1], l_b0_[i - 1], WenvL_[i - 1], Lenv_[i],
+                          l_b0_[i], B)) != TJM_OK) return rc;
+  }
+  if ((rc = launch_identity_env(Renv_[L - 1], r_b0_[L - 1], cap[L], Dm[L], B, stream)) != TJM_OK) return rc;
+  const int cm = *std::max_element(cap.begin(), cap.end());
+  hipLaunchKernelGGL(bond_identity_kernel, dim3((unsigned)(((long)B * cap[L] * cap[L] + 255) / 256)), dim3(256), 0, stream, E_, (long)cm * cm, cap[L], B);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// _local_update (bug.py:93-125) at `site` (L-1 ... 1) for every trajectory
+int Engine::step_bug_site(int set, int site, double dt_) {
+  if (!bound_ || n_sets < 4 || set < 0 || set > 1 || site < 1 || site >= L) return TJM_ERR_ARG;
+  StateSet& Ts = sets[set];
+  StateSet& Cs = sets[2];
+  StateSet& Qs = sets[3];
+  const int cz = cap[site - 1], ca = cap[site], cb = cap[site + 1];
+  const int cm = *std::max_element(cap.begin(), cap.end());
+  const long m_b0 = (long)cm * cm;
+  int rc;
+  // predictor = update_site(lenv[site], right_block, W, working, dt)
+  if ((rc = copy_site(3, 2, site)) != TJM_OK) return rc;
+  if ((rc = one_site_update(Qs, site, dt_)) != TJM_OK) return rc;
+  {  // old_basis_current[p][a][c'] = sum_c old_q[p][a][c] M[c][c']  -> T2
+    GemmDesc g = blank_gemm();
+    g.A = Ts.A[site]; g.B = E_; g.C = T2;
+    g.M = d * ca; g.K = cb; g.N = cb;
+    g.a_rs = cb; g.a_cs = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb;
+    g.nb0 = B; g.a_b0 = a_b0_[site]; g.b_b0 = m_b0; g.c_b0 = t_b0;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  {  // stacked = [retained | predictor] along the left bond; retained = old_q at the endpoint, the working centre elsewhere
+    const bool endpoint = (site == L - 1);
+    const StateSet& Rs = endpoint ? Ts : Cs;
+    const long n = (long)d * ca * cb;
+    int gx = (int)((n + 1023) / 1024);
+    if (gx < 1) gx = 1;
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(stack_left_kernel, dim3(gx, B), dim3(256), 0, stream, Rs.A[site], Qs.A[site], a_b0_[site], d, ca, cb, Rs.chi, Qs.chi, Qs.chi, L + 1,
+                       site, V, v_b0, overflow_);
+    TJM_HIP_CHECK(hipGetLastError());
+    TJM_HIP_CHECK(hipMemcpy2DAsync(Qs.A[site], (size_t)a_b0_[site] * sizeof(cplx), V, (size_t)v_b0 * sizeof(cplx), (size_t)a_b0_[site] * sizeof(cplx), B,
+                                   hipMemcpyDeviceToDevice, stream));
+  }
+  if ((rc = qr_site(Qs, site, false)) != TJM_OK) return rc;  // new_q = left_qr(stacked): right-isometric, new left bond into set 3's table
+  {  // M'[a][b] = sum_{p,c} old_basis_current[p][a][c] conj(new_q[p][b][c])  -> E2_ (leading dimension ca)
+    GemmDesc g = blank_gemm();
+    g.A = T2; g.B = Qs.A[site]; g.C = E2_;
+    g.M = ca; g.K = cb; g.N = ca; g.nks = d;
+    g.a_rs = cb; g.a_cs = 1; g.a_ks = (long)ca * cb; g.b_rs = 1; g.b_cs = cb; g.b_ks = (long)ca * cb; g.conjB = 1; g.c_rs = ca;
+    g.nb0 = B; g.a_b0 = t_b0; g.b_b0 = a_b0_[site]; g.c_b0 = m_b0;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  // state.tensors[site] = new_q
+  TJM_HIP_CHECK(hipMemcpyAsync(Ts.A[site], Qs.A[site], (size_t)B * a_b0_[site] * sizeof(cplx), hipMemcpyDeviceToDevice, stream));
+  if ((rc = copy_chi_col(set, 3, site)) != TJM_OK) return rc;
+  {  // canon[site-1][p][z][b] = sum_a canon[site-1][p][z][a] M'[a][b]
+    GemmDesc g = blank_gemm();
+    g.A = Cs.A[site - 1]; g.B = E2_; g.C = T1;
+    g.M = d * cz; g.K = ca; g.N = ca;
+    g.a_rs = ca; g.a_cs = 1; g.b_rs = ca; g.b_cs = 1; g.c_rs = ca;
+    g.nb0 = B; g.a_b0 = a_b0_[site - 1]; g.b_b0 = m_b0; g.c_b0 = t_b0;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+    if ((rc = copy_back(Cs.A[site - 1], a_b0_[site - 1], T1, t_b0, a_b0_[site - 1], nullptr, B)) != TJM_OK) return rc;
+    if ((rc = copy_chi_col(2, 3, site)) != TJM_OK) return rc;
+  }
+  // right block of the new basis: Renv[site-1] from Renv[site] and new_q
+  if ((rc = env_right_at(Ts.A[site], a_b0_[site], ca, cb, Dm[site], Dm[site + 1], Renv_[site], r_b0_[site], W_[site], Renv_[site - 1], r_b0_[site - 1],
+                         B)) != TJM_OK) return rc;
+  std::swap(E_, E2_);  // M of the next site
+  return TJM_OK;
+}
+
+// root update (bug.py:188-196): state.tensors[0] = update_site(lenv[0], right_block, W_0, canon[0], dt)
+int Engine::step_bug_root(int set, double dt_) {
+  if (!bound_ || n_sets < 4 || set < 0 || set > 1) return TJM_ERR_ARG;
+  int rc;
+  if ((rc = copy_site(set, 2, 0)) != TJM_OK) return rc;
+  return one_site_update(sets[set], 0, dt_);
+}
+
+// MPS.flip_network (mps.py:680-698): reversed site order, virtual legs exchanged (the storage capacities are symmetric)
+int Engine::step_flip(int set) {
+  if (!bound_ || n_sets < 4 || set < 0 || set > 1) return TJM_ERR_ARG;
+  for (int i = 0; i < L; ++i) {
+    const int j = L - 1 - i;
+    if (cap[i] != cap[j + 1] || cap[i + 1] != cap[j]) return TJM_ERR_STATE;
+    const long n = (long)d * cap[i] * cap[i + 1];
+    int gx = (int)((n + 1023) / 1024);
+    if (gx < 1) gx = 1;
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(flip_site_kernel, dim3(gx, B), dim3(256), 0, stream, sets[set].A[i], a_b0_[i], d, cap[i], cap[i + 1], sets[3].A[j]);
+  }
+  hipLaunchKernelGGL(chi_reverse_kernel, dim3((unsigned)(((long)B * (L + 1) + 255) / 256)), dim3(256), 0, stream, sets[3].chi, sets[set].chi, L + 1, L, B);
+  TJM_HIP_CHECK(hipGetLastError());
+  return copy_state(set, 3);
+}
+
+// MPS.compress (mps.py:841-899): right-canonical form by QR, truncated SVD sweep left to right ("right" distribution, min_keep 1),
+// centre back to site 0 by QR
+int Engine::step_compress(int set, double threshold, int max_bond_dim, int mode) {
+  if (!bound_ || set < 0 || set > 1 || mode < 0 || mode > 3) return TJM_ERR_ARG;
+  if (L == 1) return TJM_OK;
+  StateSet& S = sets[set];
+  int rc;
+  if ((rc = canonicalize_qr(set, L - 1)) != TJM_OK) return rc;
+  for (int site = 0; site + 1 < L; ++site) {
+    if ((rc = merge_matrix_layout(S, site, nullptr, B)) != TJM_OK) return rc;
+    if ((rc = split(S, site, 0, mode, threshold, max_bond_dim, 1, nullptr, B)) != TJM_OK) return rc;
+  }
+  return canonicalize_qr(set, L - 1);
 }
 
 }  // namespace tjm

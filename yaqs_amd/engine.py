@@ -325,6 +325,23 @@ class BatchEngine:
         a, n = self._ids(ids)
         _lib.check(self.lib.tjm_engine_step_cap_bond(self.h, set_index, int(bond), int(target), None if a is None else a.ctypes.data, n), "step_cap_bond")
 
+    # -- steps of the BUG integrator (engines created with cap_slack >= 2) -----------------
+    def step_bug_prepare(self, set_index: int = 0):
+        _lib.check(self.lib.tjm_engine_step_bug_prepare(self.h, set_index), "step_bug_prepare")
+
+    def step_bug_site(self, site: int, dt: float, set_index: int = 0):
+        _lib.check(self.lib.tjm_engine_step_bug_site(self.h, set_index, int(site), float(dt)), "step_bug_site")
+
+    def step_bug_root(self, dt: float, set_index: int = 0):
+        _lib.check(self.lib.tjm_engine_step_bug_root(self.h, set_index, float(dt)), "step_bug_root")
+
+    def step_flip(self, set_index: int = 0):
+        _lib.check(self.lib.tjm_engine_step_flip(self.h, set_index), "step_flip")
+
+    def step_compress(self, threshold: float, max_bond_dim, trunc_mode: str = "discarded_weight", set_index: int = 0):
+        _lib.check(self.lib.tjm_engine_step_compress(self.h, set_index, float(threshold), -1 if max_bond_dim is None else int(max_bond_dim),
+                                                     TRUNC_MODES[trunc_mode]), "step_compress")
+
     def stats(self) -> dict:
         s = np.zeros(9, dtype=np.int64)
         self.lib.tjm_engine_stats_ex(self.h, s.ctypes.data, 9)
