@@ -2168,14 +2168,14 @@ __global__ __launch_bounds__(256) void flip_site_kernel(const cplx* __restrict__
   }
 }
 // Stack along the left bond without gaps (build_trial_basis, bug.py:78-80): out[p][a'][c] = ret[p][a'][c] for a' < n_ret,
-// pred[p][a' - n_ret][c] for n_ret <= a' < n_ret + n_pred, zero beyond; the new left bond goes to chi_out (clipped to ca: flagged).
+// pred[p][a' - n_ret][c] for n_ret <= a' < n_ret + n_pred, zero beyond.  The bond table is updated by stack_dims_kernel AFTERWARDS
+// (the workgroups of one trajectory read the old dimensions at different times).
 __global__ __launch_bounds__(256) void stack_left_kernel(const cplx* __restrict__ ret, const cplx* __restrict__ pred, long b0, int d, int ca, int cb,
-                                                        const int* chi_ret, const int* chi_pred, int* chi_out, int stride, int col,
-                                                        cplx* __restrict__ out, long out_b0, int* overflow) {
+                                                        const int* chi_ret, const int* chi_pred, int stride, int col, cplx* __restrict__ out,
+                                                        long out_b0) {
   const int b = blockIdx.y;
   const int nr = chi_ret[(long)b * stride + col], np_ = chi_pred[(long)b * stride + col];
-  int tot = nr + np_;
-  if (tot > ca) { tot = ca; if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(overflow, 1); }
+  const int tot = (nr + np_ > ca) ? ca : nr + np_;
   const long n = (long)d * ca * cb;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
     const int c = (int)(e % cb);
@@ -2186,8 +2186,14 @@ __global__ __launch_bounds__(256) void stack_left_kernel(const cplx* __restrict_
     else if (a < tot) v = pred[(long)b * b0 + ((long)p * ca + (a - nr)) * cb + c];
     out[(long)b * out_b0 + e] = v;
   }
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) chi_out[(long)b * stride + col] = tot;
+}
+// new left bond of the stack: n_ret + n_pred, clipped to the storage (flagged: the caller re-runs on a larger engine)
+__global__ void stack_dims_kernel(const int* chi_ret, const int* chi_pred, int* chi_out, int stride, int col, int ca, int* overflow, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int tot = chi_ret[(long)b * stride + col] + chi_pred[(long)b * stride + col];
+  if (tot > ca) { tot = ca; atomicOr(overflow, 1); }
+  chi_out[(long)b * stride + col] = tot;
 }
 __global__ void bond_identity_kernel(cplx* M, long m_b0, int n, int B) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2269,8 +2275,9 @@ int Engine::step_bug_site(int set, int site, double dt_) {
     int gx = (int)((n + 1023) / 1024);
     if (gx < 1) gx = 1;
     if (gx > 128) gx = 128;
-    hipLaunchKernelGGL(stack_left_kernel, dim3(gx, B), dim3(256), 0, stream, Rs.A[site], Qs.A[site], a_b0_[site], d, ca, cb, Rs.chi, Qs.chi, Qs.chi, L + 1,
-                       site, V, v_b0, overflow_);
+    hipLaunchKernelGGL(stack_left_kernel, dim3(gx, B), dim3(256), 0, stream, Rs.A[site], Qs.A[site], a_b0_[site], d, ca, cb, Rs.chi, Qs.chi, L + 1, site, V,
+                       v_b0);
+    hipLaunchKernelGGL(stack_dims_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, Rs.chi, Qs.chi, Qs.chi, L + 1, site, ca, overflow_, B);
     TJM_HIP_CHECK(hipGetLastError());
     TJM_HIP_CHECK(hipMemcpy2DAsync(Qs.A[site], (size_t)a_b0_[site] * sizeof(cplx), V, (size_t)v_b0 * sizeof(cplx), (size_t)a_b0_[site] * sizeof(cplx), B,
                                    hipMemcpyDeviceToDevice, stream));
