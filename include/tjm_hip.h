@@ -154,7 +154,9 @@ int tjm_engine_profile_read(tjm_engine* e, double* ms3, int64_t* regions3);
  *   step_one_site   update_site on one tensor (primitives.py:484-520)
  *   step_env        left = 1: update_left_environment into site + 1; left = 0: update_right_environment into site - 1
  *   step_qr_bond    right_qr / left_qr of the site, environment update with Q, update_bond on C over dt, C into the neighbour
- *                   (integrators.py:352-377, 441-466)
+ *                   (integrators.py:352-377, 441-466; leftward it is the projector-splitting step of the fixed one-site sweep,
+ *                   integrators.py:126-158 - sweep_dynamic's own leftward line transposes left_qr's factor a second time and
+ *                   is not gauge invariant, see tjm_engine.hip)
  *   step_cap_bond   _sync_bond_dim where it truncates (sweep_utils.py:110-163): merged pair, sqrt-distributed split capped at
  *                   `target`, min_keep 1 */
 int tjm_engine_step_env_init(tjm_engine* e, int32_t set);

@@ -33,6 +33,10 @@ class _ScriptedRng:
 class OracleEngine:
     instances: list = []
 
+    # True: non-gauge-invariant lines of the reference are followed to the letter (step_qr_bond), so that a host schedule run on
+    # this stand-in can be compared with the REFERENCE's outputs; False: what the HIP engine computes (see tjm_engine.hip).
+    reference_quirks = True
+
     def __init__(self, length, chi_max, batch, mpo, device="cpu", d=2, stream=None, cap_slack=1):
         self.L, self.d, self.chi_max, self.B = int(length), int(d), int(chi_max), int(batch)
         self.mpo = [np.asarray(w, dtype=np.complex128) for w in mpo]
@@ -215,7 +219,9 @@ class OracleEngine:
                 q, c = o.left_qr(t[site])
                 t[site] = q
                 rb[site - 1] = o.update_right_environment(q, q, self.mpo[site], rb[site])
-                c = o.update_bond(lb[site], rb[site - 1], c.transpose(), dt, tol)
+                # left_qr hands back R^T = C[left][new]; the reference's dynamic sweep transposes it once more (integrators.py:461).
+                # reference_quirks = True does the same, so that the host schedule can be checked against the reference's outputs.
+                c = o.update_bond(lb[site], rb[site - 1], c.transpose() if self.reference_quirks else c, dt, tol)
                 t[site - 1] = np.einsum("abd,dc->abc", t[site - 1], c)
 
     def step_cap_bond(self, bond, target, ids=None, set_index=0):

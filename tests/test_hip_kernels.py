@@ -10,9 +10,18 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
+from conftest import SIM  # noqa: E402  (TJM_SIM=1: the same tests on tests/hipsim, host memory for device memory)
+
+DEV = "cpu" if SIM else "cuda:0"
+
+
+def _sync():
+    if not SIM:
+        torch.cuda.synchronize()
+
 
 def dev(a):
-    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    return torch.from_numpy(np.array(a, order="C", copy=True)).to(DEV)  # a copy also on the host: kernels work in place
 
 
 def crand(rng, *shape):
@@ -23,6 +32,10 @@ def crand(rng, *shape):
 def lib():
     from yaqs_amd import _lib
 
+    if SIM:
+        from simengine import load_sim
+
+        return load_sim()
     assert torch.cuda.is_available(), "these tests need the MI355X"
     return _lib.load()
 
@@ -36,7 +49,7 @@ def run_gemm(lib, **kw):
     for k, v in defaults.items():
         setattr(d, k, v)
     check(lib.tjm_zgemm_batched(C.byref(d), None), "gemm")
-    torch.cuda.synchronize()
+    _sync()
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 64, 16), (70, 50, 37), (256, 384, 128), (3, 5, 2), (128, 128, 384), (512, 384, 128)])
@@ -46,7 +59,7 @@ def test_gemm_nn_batched(lib, M, N, K, conjA, conjB):
     nb = 3
     a, b = crand(rng, nb, M, K), crand(rng, nb, K, N)
     A, B = dev(a), dev(b)
-    Cc = torch.zeros((nb, M, N), dtype=torch.complex128, device="cuda:0")
+    Cc = torch.zeros((nb, M, N), dtype=torch.complex128, device=DEV)
     run_gemm(lib, A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, a_rs=K, a_cs=1, b_rs=N, b_cs=1, c_rs=N,
              nb0=nb, a_b0=M * K, b_b0=K * N, c_b0=M * N, conjA=conjA, conjB=conjB)
     ref = np.einsum("bmk,bkn->bmn", a.conj() if conjA else a, b.conj() if conjB else b)
@@ -62,7 +75,7 @@ def test_gemm_small_tile_path(lib, M, N, K):
     a, b = crand(rng, nb, O, K, M), crand(rng, nb, O, N, K)  # A stored [K][M] (m contiguous), B stored [N][K] (k contiguous)
     A, B = dev(a), dev(b)
     nks = O if K * O <= 512 else 1
-    Cc = torch.zeros((nb, M, N), dtype=torch.complex128, device="cuda:0")
+    Cc = torch.zeros((nb, M, N), dtype=torch.complex128, device=DEV)
     run_gemm(lib, A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, a_rs=1, a_cs=M, b_rs=1, b_cs=K, c_rs=N,
              nks=nks, a_ks=K * M, b_ks=N * K, nb0=nb, a_b0=O * K * M, b_b0=O * N * K, c_b0=M * N, conjA=1, conjB=1)
     want = np.einsum("bokm,bonk->bmn", a[:, :nks].conj(), b[:, :nks].conj())
@@ -75,7 +88,7 @@ def test_gemm_transposed_operands_ksplit_and_inner_batches(lib):
     M, N, K, nb, P = 96, 80, 150, 2, 4
     a, b = crand(rng, nb, K, M), crand(rng, nb, P, K, N)
     A, B = dev(a), dev(b)
-    Cc = torch.zeros((nb, P, M, N), dtype=torch.complex128, device="cuda:0")
+    Cc = torch.zeros((nb, P, M, N), dtype=torch.complex128, device=DEV)
     run_gemm(lib, A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, a_rs=1, a_cs=M, b_rs=N, b_cs=1, c_rs=N,
              nb0=nb, nb1=P, a_b0=K * M, b_b0=P * K * N, b_b1=K * N, c_b0=P * M * N, c_b1=M * N, conjA=1)
     ref = np.einsum("bkm,bpkn->bpmn", a.conj(), b)
@@ -84,7 +97,7 @@ def test_gemm_transposed_operands_ksplit_and_inner_batches(lib):
     M, N, K, O = 40, 33, 29, 2
     a, b = crand(rng, nb, M, O, K), crand(rng, nb, O, N, K)
     A, B = dev(a), dev(b)
-    Cc = torch.zeros((nb, M, N), dtype=torch.complex128, device="cuda:0")
+    Cc = torch.zeros((nb, M, N), dtype=torch.complex128, device=DEV)
     run_gemm(lib, A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, a_rs=O * K, a_cs=1, b_rs=1, b_cs=K, c_rs=N,
              nks=O, a_ks=K, b_ks=N * K, nb0=nb, a_b0=M * O * K, b_b0=O * N * K, c_b0=M * N, conjB=1)
     ref = np.einsum("bmok,bonk->bmn", a, b.conj())
@@ -93,7 +106,7 @@ def test_gemm_transposed_operands_ksplit_and_inner_batches(lib):
     d, ca, cm, cc = 2, 7, 5, 6
     x, y = crand(rng, nb, d, ca, cm), crand(rng, nb, d, cm, cc)
     X, Y = dev(x), dev(y)
-    Cc = torch.zeros((nb, d, d, ca, cc), dtype=torch.complex128, device="cuda:0")
+    Cc = torch.zeros((nb, d, d, ca, cc), dtype=torch.complex128, device=DEV)
     run_gemm(lib, A=X.data_ptr(), B=Y.data_ptr(), C=Cc.data_ptr(), M=ca, N=cc, K=cm, a_rs=cm, a_cs=1, b_rs=cc, b_cs=1, c_rs=cc,
              nb0=nb, nb1=d, nb2=d, a_b0=d * ca * cm, a_b1=ca * cm, b_b0=d * cm * cc, b_b2=cm * cc, c_b0=d * d * ca * cc,
              c_b1=d * ca * cc, c_b2=ca * cc)
@@ -113,9 +126,9 @@ def test_tridiag_expm_matches_dense(lib, k, dt, scale):
     T = np.diag(alpha[:k]) + np.diag(beta[: k - 1], 1) + np.diag(beta[: k - 1], -1)
     ref = scipy.linalg.expm(-1j * dt * T)[:, 0]
     a, b = dev(alpha), dev(beta)
-    out = torch.zeros(2 * k, dtype=torch.float64, device="cuda:0")
+    out = torch.zeros(2 * k, dtype=torch.float64, device=DEV)
     check(lib.tjm_tridiag_expm(a.data_ptr(), b.data_ptr(), k, dt, out.data_ptr(), None), "expm")
-    torch.cuda.synchronize()
+    _sync()
     got = out.cpu().numpy().view(np.complex128)
     assert np.allclose(got, ref, atol=5e-13)
 
@@ -125,18 +138,18 @@ def svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, mi
 
     B = theta.shape[0]
     th = dev(theta)
-    left = torch.zeros((B, d, capL, capM), dtype=torch.complex128, device="cuda:0")
-    right = torch.zeros((B, d, capM, capR), dtype=torch.complex128, device="cuda:0")
+    left = torch.zeros((B, d, capL, capM), dtype=torch.complex128, device=DEV)
+    right = torch.zeros((B, d, capM, capR), dtype=torch.complex128, device=DEV)
     chi = dev(np.stack([chiL, chiR, np.zeros(B, dtype=np.int32)], axis=1).astype(np.int32))
     spec_ld = d * max(capL, capR)
-    spec = torch.zeros((B, spec_ld), dtype=torch.float64, device="cuda:0")
+    spec = torch.zeros((B, spec_ld), dtype=torch.float64, device=DEV)
     nbytes = (lib.tjm_svd_qr_workspace_bytes if qr else lib.tjm_svd_workspace_bytes)(d * max(capL, capR), B)
     fn = lib.tjm_svd_split_qr if qr else lib.tjm_svd_split
-    work = torch.zeros(nbytes, dtype=torch.uint8, device="cuda:0")
+    work = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
     sweeps = C.c_int32(0)
     check(fn(th.data_ptr(), B, d, capL, capR, capM, left.data_ptr(), right.data_ptr(), dist, mode, thr, max_bond, min_keep,
                             chi.data_ptr(), spec.data_ptr(), spec_ld, work.data_ptr(), nbytes, C.byref(sweeps), None), "svd_split")
-    torch.cuda.synchronize()
+    _sync()
     return left.cpu().numpy(), right.cpu().numpy(), chi.cpu().numpy()[:, 2], spec.cpu().numpy(), sweeps.value
 
 
@@ -471,31 +484,31 @@ def test_project_site_env_updates_and_project_bond_match_reference_outputs(lib):
     H = lambda a: np.ascontiguousarray(a, dtype=np.complex128)  # noqa: E731
     # two-site project_site: x = merge (4, 5, 4), L (5, 3, 5), R (4, 3, 4), merged MPO (4, 4, 3, 3)
     x, L, R, W2 = g["merge"], g["L"], g["R"], H(g["merge_mpo"])
-    y = torch.zeros((2,) + x.shape, dtype=torch.complex128, device="cuda:0")
+    y = torch.zeros((2,) + x.shape, dtype=torch.complex128, device=DEV)
     check(lib.tjm_heff_apply(e.h, 2, 5, 4, 3, 3, _slots(x).data_ptr(), _same(L).data_ptr(), _same(R).data_ptr(),
                              W2.ctypes.data, y.data_ptr(), 2), "heff2")
     got = y.cpu().numpy()
     assert np.allclose(got[0], g["project_site_2"], atol=1e-11) and np.allclose(got[1], 1.5 * g["project_site_2"], atol=1e-11)
     # one-site project_site: x = A (2, 5, 6), L (5, 3, 5), R1 (6, 3, 6), W1 (2, 2, 3, 3)
     a, R1, W1 = g["A"], g["R1"], H(g["W1"])
-    y = torch.zeros((2,) + a.shape, dtype=torch.complex128, device="cuda:0")
+    y = torch.zeros((2,) + a.shape, dtype=torch.complex128, device=DEV)
     check(lib.tjm_heff_apply(e.h, 1, 5, 6, 3, 3, _slots(a).data_ptr(), _same(L).data_ptr(), _same(R1).data_ptr(),
                              W1.ctypes.data, y.data_ptr(), 2), "heff1")
     got = y.cpu().numpy()
     assert np.allclose(got[0], g["project_site_1"], atol=1e-11) and np.allclose(got[1], 1.5 * g["project_site_1"], atol=1e-11)
     # environments: left from (A, W1, L) -> (6, 3, 6); right from (B, W2, R) -> (6, 3, 6); quadratic in the site tensor
-    out = torch.zeros((2, 6, 3, 6), dtype=torch.complex128, device="cuda:0")
+    out = torch.zeros((2, 6, 3, 6), dtype=torch.complex128, device=DEV)
     check(lib.tjm_env_update(e.h, 1, 5, 6, 3, 3, _slots(a).data_ptr(), _same(L).data_ptr(), W1.ctypes.data, out.data_ptr(), 2), "envL")
     got = out.cpu().numpy()
     assert np.allclose(got[0], g["env_left"], atol=1e-11) and np.allclose(got[1], 2.25 * g["env_left"], atol=1e-11)
     b, Wb = g["B"], H(g["W2"])
-    out = torch.zeros((2, 6, 3, 6), dtype=torch.complex128, device="cuda:0")
+    out = torch.zeros((2, 6, 3, 6), dtype=torch.complex128, device=DEV)
     check(lib.tjm_env_update(e.h, 0, 6, 4, 3, 3, _slots(b).data_ptr(), _same(R).data_ptr(), Wb.ctypes.data, out.data_ptr(), 2), "envR")
     got = out.cpu().numpy()
     assert np.allclose(got[0], g["env_right"], atol=1e-11) and np.allclose(got[1], 2.25 * g["env_right"], atol=1e-11)
     # project_bond: C (5, 4), LB (5, 3, 5), R (4, 3, 4)
     c, LB = g["C"], g["LB"]
-    y = torch.zeros((2, 5, 4), dtype=torch.complex128, device="cuda:0")
+    y = torch.zeros((2, 5, 4), dtype=torch.complex128, device=DEV)
     check(lib.tjm_project_bond(e.h, 5, 4, 3, _slots(c).data_ptr(), _same(LB).data_ptr(), _same(R).data_ptr(), y.data_ptr(), 2),
           "project_bond")
     got = y.cpu().numpy()
@@ -517,7 +530,7 @@ def test_lanczos_expm_matches_reference_outputs(lib):
     l0 = np.ones((1, 1, 1), dtype=np.complex128)
     rb = g["renv1"]                                        # (4, 3, 4)
     for tol in (1e-4, 1e-12):
-        y = torch.zeros((2, 4, 1, 4), dtype=torch.complex128, device="cuda:0")
+        y = torch.zeros((2, 4, 1, 4), dtype=torch.complex128, device=DEV)
         check(lib.tjm_lanczos_expm(e.h, 2, 1, 4, 1, 3, _slots(th).data_ptr(), _same(l0).data_ptr(), _same(rb).data_ptr(),
                                    w2.ctypes.data, 0.05, tol, y.data_ptr(), 2, None), "lanczos")
         got = y.cpu().numpy()
@@ -547,7 +560,7 @@ def test_lanczos_expm_general_path_matches_oracle(lib, nsites):
     e = BatchEngine(12, 32, 2, o.ising_mpo(12, 1.0, 0.5))
     wh = np.ascontiguousarray(w, dtype=np.complex128)
     for tol in (1e-4, 1e-12):
-        y = torch.zeros((2, P, ca, cb), dtype=torch.complex128, device="cuda:0")
+        y = torch.zeros((2, P, ca, cb), dtype=torch.complex128, device=DEV)
         mv = C.c_int64(0)
         check(lib.tjm_lanczos_expm(e.h, nsites, ca, cb, D, D, _slots(x).data_ptr(), _same(Lenv).data_ptr(),
                                    _same(Renv).data_ptr(), wh.ctypes.data, 0.02, tol, y.data_ptr(), 2, C.byref(mv)), "lanczos")

@@ -1,0 +1,54 @@
+"""The device code on tests/hipsim: a selection of the ``-m gpu`` tests run on the CPU (TEST INFRASTRUCTURE, no GPU needed).
+
+tests/hipsim compiles the unchanged .hip sources of yaqs_amd/csrc for the host and interprets the HIP execution model (fibres for
+threads, wavefront exchange for the cross-lane and MFMA instructions; see tests/hipsim/hip/hip_runtime.h).  The tests below are the
+bodies of tests/test_hip_engine.py and tests/test_hip_kernels.py, unchanged, with ``BatchEngine`` bound to that library
+(tests/simengine.py).  They check what an interpreter can check - indices, strides, control flow, arithmetic, the host schedules
+on the real engine code - before the code reaches an MI355X; they are not the parity tests (those are ``-m gpu``) and say nothing
+about races between workgroups or speed.  The whole ``-m gpu`` suite runs the same way with ``TJM_SIM=1`` (tests/conftest.py).
+"""
+import importlib
+
+import pytest
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture()
+def on_sim(monkeypatch):
+    import conftest
+    import yaqs_amd.engine as engine_mod
+    import yaqs_amd.tjm as tjm_mod
+    from simengine import SimEngine, load_sim
+
+    load_sim()
+    monkeypatch.setattr(engine_mod, "BatchEngine", SimEngine)
+    monkeypatch.setattr(tjm_mod, "BatchEngine", SimEngine)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (4 << 30, 4 << 30))
+    monkeypatch.setattr(conftest, "SIM", True)
+    mods = {}
+    for name in ("test_hip_engine", "test_hip_kernels"):
+        mods[name] = importlib.import_module(name)
+    k = mods["test_hip_kernels"]
+    monkeypatch.setattr(k, "SIM", True)
+    monkeypatch.setattr(k, "DEV", "cpu")
+    return mods
+
+
+ENGINE_CASES = [
+    "test_one_tdvp_call_matches_reference_fixture",
+    "test_dissipation_and_jump_step_match_reference_fixture",
+    "test_scheduled_jumps_match_reference_fixture",
+    "test_digital_tebd_trajectories_match_reference_fixture",
+    "test_schmidt_spectrum_through_the_front_end",
+    "test_one_site_tdvp_run_with_a_pair_channel_grows_its_storage",
+    "test_sample_at_and_segment_stitching_match_reference_on_the_engine",
+    "test_dynamic_tdvp_matches_reference_on_the_engine",
+    "test_bug_integrator_matches_reference_on_the_engine",
+]
+
+
+@pytest.mark.parametrize("name", ENGINE_CASES)
+def test_engine_case_on_the_simulated_device(on_sim, name):
+    getattr(on_sim["test_hip_engine"], name)()

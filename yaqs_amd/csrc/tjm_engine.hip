@@ -2079,6 +2079,16 @@ int Engine::step_env(int set, int i, int left, const int* host_ids, int n) {
 
 // The bond transfer of the one-site branch (integrators.py:352-377 / 441-466, the body of sweep_1site): thin QR of site i
 // (right = 1: A_i = Q C, right = 0: A_i = C^T Q), environment update with Q, exp(-i dt H_bond) on C, C into the neighbour.
+// right = 1: A_i = Q C, C evolves over dt, A_{i+1} <- C A_{i+1}.  right = 0: A_i = C^T Q, C evolves, A_{i-1} <- A_{i-1} C.
+//
+// Deviation from the reference, on purpose: sweep_dynamic's leftward one-site branch (integrators.py:450-474) calls left_qr, which
+// hands back R^T = C[left][new] (decompositions.py:82), and then transposes once more - a line taken over from the fixed one-site
+// sweep (integrators.py:140) where R comes straight from np.linalg.qr.  The matrix that is evolved and absorbed there is R, whose
+// indices are contracted the wrong way round: the result changes under a change of gauge on the bond, so it depends on the signs
+// and phases LAPACK's SVD and QR happened to pick in the steps before (and is only defined when the factor is square).  No other
+// implementation can reproduce those numbers; this step does what the fixed one-site sweep does, the projector-splitting step.
+// oracle/tjm_oracle.py restates the reference line for line behind Params.reference_dynamic_transpose (default on, pinned to the
+// reference's fixtures); the engine is compared with the oracle with that switch off wherever a bond sits at the cap.
 int Engine::step_qr_bond(int set, int i, int right, double dt_, const int* host_ids, int n) {
   if (!bound_ || set < 0 || set > 1 || i < 0 || i >= L || (right && i + 1 >= L) || (!right && i < 1)) return TJM_ERR_ARG;
   StateSet& S = sets[set];
