@@ -67,8 +67,8 @@ int tjm_engine_adopt_state(tjm_engine* dst, tjm_engine* src, int32_t src_first);
 int tjm_engine_set_mpo(tjm_engine* e, const double* host_mpo);
 /* NoiseModel.processes (noise_model.py:227-243), one entry per process:
  *   nsites[k] in {1,2}; sites[2k], sites[2k+1]; gamma[k]; pauli[k] = is_pauli(process);
- *   mats: 32 doubles per process (1-site: 2x2 row-major in the first 8 doubles);
- *   factors: 16 doubles per process (two 2x2 matrices) when has_factors[k]. */
+ *   mats: 2 d^4 doubles per process (32 for qubits; 1-site: d x d row-major in the leading entries, adjacent pair: d^2 x d^2);
+ *   factors: 4 d^2 doubles per process (two d x d matrices; 16 for qubits) when has_factors[k]. */
 int tjm_engine_set_noise(tjm_engine* e, int32_t nproc, const int32_t* nsites, const int32_t* sites, const double* gamma,
                          const int32_t* pauli, const double* mats, const double* factors, const int32_t* has_factors);
 /* MPS tensors (sigma, chi_l, chi_r) C-contiguous (mps.py:58), sites concatenated; bonds[L+1].
@@ -194,7 +194,7 @@ typedef struct {
   int32_t n_obs;
   const int32_t* obs_nsites; /* [n_obs] 1 or 2 */
   const int32_t* obs_site;   /* [n_obs] first site */
-  const double* obs_matrix;  /* [n_obs][32]: row-major complex 2x2 (first 8 doubles) or 4x4 */
+  const double* obs_matrix;  /* [n_obs][2 d^4] doubles (32 for qubits): row-major complex d x d (leading entries) or d^2 x d^2 */
   /* Continuation after TJM_ERR_CAPACITY (all zero / null for a run from the initial state).
    * start_step = j > 0: set 0 already holds the trajectory states at the START of time step j (tjm_engine_adopt_state), the
    * columns measured before j are already in results / diagnostics, and rng_pos[B] holds every trajectory's cursor into its

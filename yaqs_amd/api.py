@@ -650,59 +650,77 @@ def validate_noise_model_for_run(noise_model, *, length: int, physical_dimension
 class MPS:
     """Tensor list with index order (sigma, chi_left, chi_right) (mps.py:58)."""
 
-    def __init__(self, length: int, tensors: list[np.ndarray] | None = None, state: str = "zeros", pad: int | None = None,
-                 rng: np.random.Generator | None = None, basis_string: str | None = None):
+    def __init__(self, length: int, tensors: list[np.ndarray] | None = None, physical_dimensions: list[int] | int | None = None,
+                 state: str = "zeros", pad: int | None = None, basis_string: str | None = None, rng: np.random.Generator | None = None):
+        """Argument order of the reference (mps.py:71-79); ``rng`` (seeded "random" / "haar-random" states) is an addition.
+
+        ``physical_dimensions``: one local dimension for every site (int or a uniform list), 2, 3 or 4 - the engine's storage is
+        ``[B][d][cap][cap]`` with one d per chain.  The product presets fill a length-d vector exactly as mps.py:224-300 does
+        (the qubit amplitudes in the first two levels)."""
         self.length = length
-        self.physical_dimensions = [2] * length
+        if physical_dimensions is None:
+            dims = [2] * length
+        elif isinstance(physical_dimensions, (int, np.integer)):
+            dims = [int(physical_dimensions)] * length
+        else:
+            dims = [int(q) for q in physical_dimensions]
+        assert len(dims) == length
         if tensors is not None:
             assert len(tensors) == length
             self.tensors = [np.asarray(t, dtype=C128) for t in tensors]
+            if physical_dimensions is None:
+                dims = [int(t.shape[0]) for t in self.tensors]
+        if length and (len(set(dims)) != 1 or not 2 <= dims[0] <= 4):
+            raise NotImplementedError("the HIP path holds one local dimension per chain, 2, 3 or 4 (mixed or larger dimensions are not built)")
+        self.physical_dimensions = dims
+        if tensors is not None:
             return
+        d = dims[0] if length else 2
         s = 1 / np.sqrt(2)
         self.tensors = []
         if state == "haar-random":
             chi = 1 if pad is None else pad
-            caps = self.bond_caps(length, chi)
+            caps = self.bond_caps(length, chi, d)
             rng = rng if rng is not None else np.random.default_rng()
             for i in range(length):
                 cl, cr = caps[i], caps[i + 1]
-                x = rng.standard_normal((2 * cl, cr)) + 1j * rng.standard_normal((2 * cl, cr))
+                x = rng.standard_normal((d * cl, cr)) + 1j * rng.standard_normal((d * cl, cr))
                 q, r = np.linalg.qr(x, mode="reduced")
                 dg = np.diag(r)
                 ph = np.ones_like(dg, dtype=C128)
                 nz = np.abs(dg) > 0
                 ph[nz] = dg[nz] / np.abs(dg[nz])
-                self.tensors.append((q / ph[np.newaxis, :]).reshape(2, cl, cr).astype(C128))
+                self.tensors.append((q / ph[np.newaxis, :]).reshape(d, cl, cr).astype(C128))
             return
         for i in range(length):
-            v = np.zeros(2, dtype=C128)
+            v = np.zeros(d, dtype=C128)
             if state == "zeros":
                 v[0] = 1
             elif state == "ones":
                 v[1] = 1
             elif state == "x+":
-                v[:] = (s, s)
+                v[:2] = (s, s)
             elif state == "x-":
-                v[:] = (s, -s)
+                v[:2] = (s, -s)
             elif state == "y+":
-                v[:] = (s, 1j * s)
+                v[:2] = (s, 1j * s)
             elif state == "y-":
-                v[:] = (s, -1j * s)
+                v[:2] = (s, -1j * s)
             elif state == "Neel":
                 v[0 if i % 2 else 1] = 1
             elif state == "wall":
                 v[0 if i < length // 2 else 1] = 1
             elif state == "random":  # (r, 1 - r) per site, normalised afterwards (mps.py:266-269, 294-295)
                 r = (rng if rng is not None else np.random.default_rng()).random()
-                v[:] = (r, 1 - r)
+                v[:2] = (r, 1 - r)
                 v /= np.linalg.norm(v)
-            elif state == "basis":   # one character per site, site 0 first (mps.py:395-408)
-                if basis_string is None or len(basis_string) != length or set(basis_string) - {"0", "1"}:
-                    raise ValueError("state='basis' needs basis_string of one '0' / '1' per site")
+            elif state == "basis":   # one character per site, site 0 first (mps.py:395-408); digits up to d - 1 for qudits
+                if basis_string is None or len(basis_string) != length or not all(c.isdigit() and int(c) < d for c in basis_string):
+                    raise ValueError("state='basis' needs basis_string of one digit below the local dimension per site")
                 v[int(basis_string[i])] = 1
             else:
                 raise ValueError("Invalid state string")
-            self.tensors.append(v.reshape(2, 1, 1))
+            self.tensors.append(v.reshape(d, 1, 1))
         if pad is not None:
             self.pad_bond_dimension(pad)
 
@@ -897,9 +915,8 @@ class MPO:
     @classmethod
     def identity(cls, length: int, physical_dimension: int = 2) -> "MPO":
         """Identity operator with bond dimension 1 (mpo.py:1015-1028)."""
-        if physical_dimension != 2:
-            raise NotImplementedError("physical dimensions other than 2 are not built yet in the HIP path")
-        return cls([_I.reshape(2, 2, 1, 1).copy() for _ in range(length)])
+        d = int(physical_dimension)
+        return cls([np.eye(d, dtype=C128).reshape(d, d, 1, 1).copy() for _ in range(length)])
 
     def custom(self, tensors, *, transpose: bool = True) -> None:
         """Adopt site tensors; ``transpose=True`` takes them as (chi_left, chi_right, phys_out, phys_in) (mpo.py:1146-1169)."""
@@ -1154,8 +1171,6 @@ class State(MPS):
             raise ValueError("length must be a positive integer.")  # state.py:88-90
         if vector is not None or density_matrix is not None or representation not in (None, "mps"):
             raise NotImplementedError("only representation='mps' is part of the TJM path built here")
-        if physical_dimensions not in (None, 2) and list(np.atleast_1d(physical_dimensions)) != [2] * (length or len(tensors or [])):
-            raise NotImplementedError("physical dimensions other than 2 are not built yet in the HIP path")
         if tensors is not None and (basis_string is not None or pad is not None or seed is not None or initial != "zeros"):
             raise ValueError("initial / pad / basis_string / seed describe a preset state; omit them with tensors=")  # state_utils.py:39-76
         if tensors is not None:
@@ -1163,12 +1178,12 @@ class State(MPS):
                 raise ValueError("tensors must be a non-empty list of MPS cores.")
             if length is not None and length != len(tensors):
                 raise ValueError(f"length={length} does not match len(tensors)={len(tensors)}.")
-            super().__init__(len(tensors), tensors=list(tensors))
+            super().__init__(len(tensors), tensors=list(tensors), physical_dimensions=physical_dimensions)
         else:
             if length is None:
                 raise ValueError("length is required for a preset state.")
             rng = np.random.default_rng(seed) if seed is not None else None
-            super().__init__(length, state=initial, pad=pad, rng=rng, basis_string=basis_string)
+            super().__init__(length, physical_dimensions=physical_dimensions, state=initial, pad=pad, rng=rng, basis_string=basis_string)
         self.initial, self.representation, self.basis_string = initial, "mps", basis_string
 
 

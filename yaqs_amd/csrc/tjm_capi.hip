@@ -114,16 +114,17 @@ int tjm_engine_set_mpo(tjm_engine* e, const double* host_mpo) { TJM_ON_DEVICE(e)
 int tjm_engine_set_noise(tjm_engine* e, int32_t nproc, const int32_t* nsites, const int32_t* sites, const double* gamma,
                          const int32_t* pauli, const double* mats, const double* factors, const int32_t* has_factors) {
   if (!e || nproc < 0) return TJM_ERR_ARG;
+  const size_t dd = (size_t)e->impl.d * e->impl.d, slot = dd * dd;
   std::vector<NoiseProc> v(nproc);
   for (int k = 0; k < nproc; ++k) {
     NoiseProc& p = v[k];
     std::memset(&p, 0, sizeof(p));
     p.nsites = nsites[k]; p.site0 = sites[2 * k]; p.site1 = sites[2 * k + 1]; p.gamma = gamma[k]; p.pauli = pauli[k];
-    std::memcpy(p.mat, mats + 32 * (size_t)k, 32 * sizeof(double));
+    std::memcpy(p.mat, mats + 2 * slot * (size_t)k, 2 * slot * sizeof(double));  // d^4 complex entries per process (16 for qubits)
     p.has_factors = has_factors ? has_factors[k] : 0;
     if (p.has_factors && factors) {
-      std::memcpy(p.f0, factors + 16 * (size_t)k, 8 * sizeof(double));
-      std::memcpy(p.f1, factors + 16 * (size_t)k + 8, 8 * sizeof(double));
+      std::memcpy(p.f0, factors + 4 * dd * (size_t)k, 2 * dd * sizeof(double));
+      std::memcpy(p.f1, factors + 4 * dd * (size_t)k + 2 * dd, 2 * dd * sizeof(double));
     }
     if (p.nsites == 2 && p.site1 - p.site0 > 1 && !p.has_factors) return TJM_ERR_ARG;
   }

@@ -10,13 +10,17 @@
 
 namespace tjm {
 
+constexpr int MAXD = 4;               // local dimension 2, 3 or 4 (uniform along the chain)
+constexpr int MAXDD = MAXD * MAXD;    // entries of a one-site operator
+constexpr int MSLOT = MAXDD * MAXDD;  // entries of an operator on a merged pair
+
 struct NoiseProc {
   int nsites;          // 1 or 2
   int site0, site1;
   double gamma;
   int pauli;           // unit-phase Pauli (L^dag L = 1)
-  cplx mat[16];        // 1-site: d x d ; adjacent 2-site: d^2 x d^2
-  cplx f0[4], f1[4];   // long-range factors
+  cplx mat[MSLOT];     // 1-site: d x d ; adjacent 2-site: d^2 x d^2
+  cplx f0[MAXDD], f1[MAXDD];  // long-range factors (d x d each)
   int has_factors;
 };
 

@@ -20,14 +20,14 @@ namespace {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 inline int round16(int x) { return (x + 15) / 16 * 16; }
 
-// dense expm for tiny matrices (<= 4x4) by scaling and squaring + Taylor
+// dense expm for tiny matrices (<= 16 x 16: a pair of four-level sites) by scaling and squaring + Taylor
 void small_expm(const cplx* in, int n, cplx* out) {
   double nrm = 0.0;
   for (int i = 0; i < n * n; ++i) nrm = std::max(nrm, std::hypot(in[i].x, in[i].y));
   int s = 0;
   while (nrm > 0.25) { nrm *= 0.5; ++s; }
   const double sc = std::ldexp(1.0, -s);
-  cplx a[16], term[16], res[16], tmp[16];
+  cplx a[MSLOT], term[MSLOT], res[MSLOT], tmp[MSLOT];
   for (int i = 0; i < n * n; ++i) {
     a[i] = cscale(in[i], sc);
     term[i] = cplx{(i / n == i % n) ? 1.0 : 0.0, 0.0};
@@ -124,7 +124,7 @@ Engine::Region::~Region() {
 }
 
 int Engine::create(int L_, int d_, int chi_, int B_, const int* mpo_bond, int cap_slack) {
-  if (L_ < 1 || d_ != 2 || chi_ < 1 || B_ < 1 || cap_slack < 1) return TJM_ERR_ARG;  // qubit chains only for now
+  if (L_ < 1 || d_ < 2 || d_ > 4 || chi_ < 1 || B_ < 1 || cap_slack < 1) return TJM_ERR_ARG;  // uniform local dimension 2, 3 or 4
   L = L_; d = d_; chi_max = chi_; B = B_;
   n_sets = cap_slack > 1 ? 4 : 2;
   // storage of bond k: min(chi_max, slack * min(d^k, d^(L-k))).  slack = 1 is the exact Schmidt-rank bound; the stacked trial bases of
@@ -169,7 +169,7 @@ size_t Engine::workspace_bytes() const {
   tot += align_up((size_t)L * B * d * d * d * d * sizeof(cplx));        // M2
   // MPO matrices + operator table
   tot += (size_t)(3 * L) * align_up((size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx));
-  tot += align_up((size_t)(L + 64) * 16 * sizeof(cplx));
+  tot += align_up((size_t)(L + 64) * MSLOT * sizeof(cplx));
   tot += 2 * align_up((size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx));  // MPO matrices of the kernel-level exports
   tot += align_up((size_t)4 * L * sizeof(SmallSiteRef)) + 4 * 256 + align_up((size_t)(4 * L + 8) * sizeof(SmallSweepStep));  // fused sweeps
   tot += 1 << 16;
@@ -242,7 +242,7 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
     WenvL_[i] = reinterpret_cast<cplx*>(take(wsz));
     W2_[i] = reinterpret_cast<cplx*>(take(wsz));
   }
-  ops_ = reinterpret_cast<cplx*>(take((size_t)(L + 64) * 16 * sizeof(cplx)));
+  ops_ = reinterpret_cast<cplx*>(take((size_t)(L + 64) * MSLOT * sizeof(cplx)));
   Wx_[0] = reinterpret_cast<cplx*>(take(wsz));
   Wx_[1] = reinterpret_cast<cplx*>(take(wsz));
   if ((size_t)(p - static_cast<char*>(ws)) > bytes) return TJM_ERR_WORKSPACE;
@@ -1152,9 +1152,9 @@ int Engine::normalize_qr(int set, int center) {
 int Engine::apply_single(int set, int site, const double* host_mat) {
   if (!bound_ || site < 0 || site >= L) return TJM_ERR_ARG;
   StateSet& S = sets[set];
-  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 2) * 16, host_mat, (size_t)d * d * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 2) * d * d * d * d, host_mat, (size_t)d * d * sizeof(cplx), hipMemcpyHostToDevice, stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
-  return launch_apply_local(S.A[site], a_b0_[site], d, (long)cap[site] * cap[site + 1], ops_ + (size_t)(L + 2) * 16, nullptr, B, nullptr, stream);
+  return launch_apply_local(S.A[site], a_b0_[site], d, (long)cap[site] * cap[site + 1], ops_ + (size_t)(L + 2) * d * d * d * d, nullptr, B, nullptr, stream);
 }
 
 // QR shifts of the centre from site `from` to site `to` (either direction) on the whole batch: one launch at small bonds.
@@ -1190,10 +1190,10 @@ int Engine::tebd_gate(int set, int left, const double* host_u, int center) {
   // shift_center_to(left) unless the centre already sits on the pair (digital_tjm.py:503-506); QR shifts only move the gauge
   if (center < left || center > left + 1)
     if ((rc = qr_walk(set, center, left)) != TJM_OK) return rc;
-  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 4) * 16, host_u, 16 * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 4) * d * d * d * d, host_u, (size_t)d * d * d * d * sizeof(cplx), hipMemcpyHostToDevice, stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
   const int mk = (max_bond > 0) ? std::min(2, max_bond) : 2;
-  return two_site_op(S, left, ops_ + (size_t)(L + 4) * 16, nullptr, nullptr, B, mk);
+  return two_site_op(S, left, ops_ + (size_t)(L + 4) * d * d * d * d, nullptr, nullptr, B, mk);
 }
 
 // A d^2 x d^2 operator on the merged pair (left, left+1) followed by the truncated split to the right, in whatever gauge the
@@ -1201,9 +1201,9 @@ int Engine::tebd_gate(int set, int left, const double* host_u, int center) {
 int Engine::apply_pair(int set, int left, const double* host_u, int min_keep) {
   if (!bound_ || left < 0 || left + 1 >= L || !host_u || min_keep < 1) return TJM_ERR_ARG;
   StateSet& S = sets[set];
-  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 4) * 16, host_u, 16 * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 4) * d * d * d * d, host_u, (size_t)d * d * d * d * sizeof(cplx), hipMemcpyHostToDevice, stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
-  return two_site_op(S, left, ops_ + (size_t)(L + 4) * 16, nullptr, nullptr, B, min_keep);
+  return two_site_op(S, left, ops_ + (size_t)(L + 4) * d * d * d * d, nullptr, nullptr, B, min_keep);
 }
 
 // QR sweep from `center` down to site 0 without the final normalisation: with center = L-1 it right-canonicalises a state in
@@ -1279,19 +1279,21 @@ int Engine::dissipate(int set, double dt_, int start_center) {
     }
     if (fits) return run_sweep(set, steps, nullptr, B);
   }
+  const int dd = d * d, slot = dd * dd;  // a one-site operator has dd entries, an operator on a merged pair dd x dd
   for (int i = start_center; i < L - 1; ++i)
     if ((rc = svd_shift_right(S, i, nullptr, B)) != TJM_OK) return rc;
   for (int i = L - 1; i >= 0; --i) {
     double expo = 0.0;
     bool need_matrix = false;
-    cplx gen[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    cplx gen[MAXDD];
+    for (int q = 0; q < dd; ++q) gen[q] = cplx{0.0, 0.0};
     bool any_one = false;
     for (int k : one_by_site_[i]) {
       if (!proc_on_[k]) continue;
       any_one = true;
       const NoiseProc& p = noise_[k];
       if (p.pauli) {
-        gen[0].x += p.gamma; gen[3].x += p.gamma;
+        for (int q = 0; q < d; ++q) gen[q * d + q].x += p.gamma;
       } else {
         need_matrix = true;
         for (int a = 0; a < d; ++a) for (int c = 0; c < d; ++c) {
@@ -1303,8 +1305,8 @@ int Engine::dissipate(int set, double dt_, int start_center) {
     }
     if (any_one && !need_matrix) expo += gen[0].x;
     bool need_matrix2 = false;
-    cplx gen2[16];
-    for (int q = 0; q < 16; ++q) gen2[q] = cplx{0.0, 0.0};
+    cplx gen2[MSLOT];
+    for (int q = 0; q < slot; ++q) gen2[q] = cplx{0.0, 0.0};
     if (i != 0) {
       double adj_pauli = 0.0;
       for (int k : two_by_right_[i]) {
@@ -1316,37 +1318,37 @@ int Engine::dissipate(int set, double dt_, int start_center) {
           expo += p.gamma;
         } else if (p.pauli) {
           adj_pauli += p.gamma;
-          for (int q = 0; q < 4; ++q) gen2[q * 4 + q].x += p.gamma;
+          for (int q = 0; q < dd; ++q) gen2[q * dd + q].x += p.gamma;
         } else {
           need_matrix2 = true;
-          for (int a = 0; a < 4; ++a) for (int c = 0; c < 4; ++c) {
+          for (int a = 0; a < dd; ++a) for (int c = 0; c < dd; ++c) {
             cplx acc{0.0, 0.0};
-            for (int r = 0; r < 4; ++r) cfma(acc, cconj(p.mat[r * 4 + a]), p.mat[r * 4 + c]);
-            gen2[a * 4 + c] = cadd(gen2[a * 4 + c], cscale(acc, p.gamma));
+            for (int r = 0; r < dd; ++r) cfma(acc, cconj(p.mat[r * dd + a]), p.mat[r * dd + c]);
+            gen2[a * dd + c] = cadd(gen2[a * dd + c], cscale(acc, p.gamma));
           }
         }
       }
       if (!need_matrix2) expo += adj_pauli;  // all adjacent processes Pauli: scalar (dissipation.py:156-157)
     }
     if (need_matrix) {
-      cplx arg[4], m[4];
-      for (int q = 0; q < 4; ++q) arg[q] = cscale(gen[q], -0.5 * dt_);
+      cplx arg[MAXDD], m[MAXDD];
+      for (int q = 0; q < dd; ++q) arg[q] = cscale(gen[q], -0.5 * dt_);
       small_expm(arg, d, m);
-      TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)i * 16, m, sizeof(m), hipMemcpyHostToDevice, stream));
+      TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)i * slot, m, (size_t)dd * sizeof(cplx), hipMemcpyHostToDevice, stream));
       TJM_HIP_CHECK(hipStreamSynchronize(stream));
-      if ((rc = launch_apply_local(S.A[i], a_b0_[i], d, (long)cap[i] * cap[i + 1], ops_ + (size_t)i * 16, nullptr, B, nullptr, stream)) != TJM_OK) return rc;
+      if ((rc = launch_apply_local(S.A[i], a_b0_[i], d, (long)cap[i] * cap[i + 1], ops_ + (size_t)i * slot, nullptr, B, nullptr, stream)) != TJM_OK) return rc;
     }
     if (expo != 0.0) {
       hipLaunchKernelGGL(fill_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, scal_, std::exp(-0.5 * dt_ * expo), B);
       if ((rc = launch_scale(S.A[i], a_b0_[i], a_b0_[i], scal_, B, nullptr, nullptr, stream)) != TJM_OK) return rc;
     }
     if (need_matrix2) {  // merged pair (i-1, i): expm(-dt/2 sum gamma L^dag L), truncated split to the right
-      cplx arg[16], m2[16];
-      for (int q = 0; q < 16; ++q) arg[q] = cscale(gen2[q], -0.5 * dt_);
-      small_expm(arg, 4, m2);
-      TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)L * 16, m2, sizeof(m2), hipMemcpyHostToDevice, stream));
+      cplx arg[MSLOT], m2[MSLOT];
+      for (int q = 0; q < slot; ++q) arg[q] = cscale(gen2[q], -0.5 * dt_);
+      small_expm(arg, dd, m2);
+      TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)L * slot, m2, (size_t)slot * sizeof(cplx), hipMemcpyHostToDevice, stream));
       TJM_HIP_CHECK(hipStreamSynchronize(stream));
-      if ((rc = two_site_op(S, i - 1, ops_ + (size_t)L * 16, nullptr, nullptr, B, 1)) != TJM_OK) return rc;
+      if ((rc = two_site_op(S, i - 1, ops_ + (size_t)L * slot, nullptr, nullptr, B, 1)) != TJM_OK) return rc;
     }
     if (i != 0)
       if ((rc = svd_shift_left(S, i, nullptr, B)) != TJM_OK) return rc;
@@ -1676,12 +1678,13 @@ int Engine::jump_weights(int set, double dt_, const std::vector<double>& nsq, co
         nrm = nsq[b];  // unitary jump operator: ||L psi||^2 = ||psi||^2
       } else if (p.nsites == 2) {
         // adjacent non-Pauli: Frobenius weight of the untruncated L theta (stochastic_process.py:53-83)
-        const cplx* M2 = &Mh2[((size_t)p.site0 * B + b) * 16];
+        const int dd = d * d;
+        const cplx* M2 = &Mh2[((size_t)p.site0 * B + b) * dd * dd];
         double acc = 0.0;
-        for (int a = 0; a < 4; ++a) for (int c2 = 0; c2 < 4; ++c2) {
+        for (int a = 0; a < dd; ++a) for (int c2 = 0; c2 < dd; ++c2) {
           cplx ll{0.0, 0.0};
-          for (int r = 0; r < 4; ++r) cfma(ll, cconj(p.mat[r * 4 + a]), p.mat[r * 4 + c2]);
-          acc += ll.x * M2[a * 4 + c2].x - ll.y * M2[a * 4 + c2].y;
+          for (int r = 0; r < dd; ++r) cfma(ll, cconj(p.mat[r * dd + a]), p.mat[r * dd + c2]);
+          acc += ll.x * M2[a * dd + c2].x - ll.y * M2[a * dd + c2].y;
         }
         nrm = acc;
       } else {
@@ -1749,19 +1752,20 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
     else { optab.insert(optab.end(), p.f0, p.f0 + d * d); optab.insert(optab.end(), p.f1, p.f1 + d * d); }
   }
   // adjacent two-site operators (d^2 x d^2) live in a second table behind the one-site ones
+  const int slot = d * d * d * d;
   std::vector<cplx> optab2;
   std::vector<int> op2_index(noise_.size(), -1);
   for (size_t k = 0; k < noise_.size(); ++k) {
     const NoiseProc& p = noise_[k];
     if (p.nsites == 2 && p.site1 == p.site0 + 1) {
-      op2_index[k] = (int)(optab2.size() / 16);
-      optab2.insert(optab2.end(), p.mat, p.mat + 16);
+      op2_index[k] = (int)(optab2.size() / slot);
+      optab2.insert(optab2.end(), p.mat, p.mat + slot);
     }
   }
-  const size_t tab2_off = ((optab.size() + 15) / 16) * 16;
-  if (tab2_off + optab2.size() > (size_t)(L + 64) * 16) return TJM_ERR_WORKSPACE;
+  const size_t tab2_off = ((optab.size() + slot - 1) / slot) * slot;
+  if (tab2_off + optab2.size() > (size_t)(L + 64) * MSLOT) return TJM_ERR_WORKSPACE;
   if (!optab2.empty()) TJM_HIP_CHECK(hipMemcpyAsync(ops_ + tab2_off, optab2.data(), optab2.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
-  if (optab.size() > (size_t)(L + 64) * 16) return TJM_ERR_WORKSPACE;
+  if (optab.size() > (size_t)(L + 64) * MSLOT) return TJM_ERR_WORKSPACE;
   TJM_HIP_CHECK(hipMemcpyAsync(ops_, optab.data(), optab.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
 
   std::vector<int> opi(B, -1), opi2(B, -1), js(B, -1), js2(B, -1), adj_site(B, -1), adj_op(B, -1);

@@ -81,6 +81,9 @@ int launch_mpo_apply(const MpoApplyDesc& d, hipStream_t stream) {
   if (d.P == 2) hipLaunchKernelGGL(mpo_apply_kernel<2>, grid, dim3(256), sh, stream, d);
   else if (d.P == 4) hipLaunchKernelGGL(mpo_apply_kernel<4>, grid, dim3(256), sh, stream, d);
   else if (d.P == 1) hipLaunchKernelGGL(mpo_apply_kernel<1>, grid, dim3(256), sh, stream, d);
+  else if (d.P == 3) hipLaunchKernelGGL(mpo_apply_kernel<3>, grid, dim3(256), sh, stream, d);    // qutrit site
+  else if (d.P == 9) hipLaunchKernelGGL(mpo_apply_kernel<9>, grid, dim3(256), sh, stream, d);    // qutrit pair
+  else if (d.P == 16) hipLaunchKernelGGL(mpo_apply_kernel<16>, grid, dim3(256), sh, stream, d);  // pair of four-level sites
   else return TJM_ERR_NOT_IMPLEMENTED;
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;

@@ -130,7 +130,7 @@ int measure(RunCtx& r, int set, int col) {
   if (rc != TJM_OK) return rc;
   for (int k = 0; k < r.c->n_obs; ++k) {
     const int site = r.c->obs_site[k];
-    const cplx* O = reinterpret_cast<const cplx*>(r.c->obs_matrix) + (size_t)k * 16;
+    const cplx* O = reinterpret_cast<const cplx*>(r.c->obs_matrix) + (size_t)k * dd * dd;
     const int n = (r.c->obs_nsites[k] == 2) ? dd : d;
     for (int b = 0; b < B; ++b) {
       const cplx* Mb = (n == d) ? &r.M[((size_t)site * B + b) * dd] : &r.M2[((size_t)site * B + b) * dd * dd];

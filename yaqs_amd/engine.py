@@ -104,8 +104,9 @@ class BatchEngine:
         sites = np.zeros(2 * max(n, 1), dtype=np.int32)
         gamma = np.zeros(max(n, 1))
         pauli = np.zeros(max(n, 1), dtype=np.int32)
-        mats = np.zeros((max(n, 1), 16), dtype=np.complex128)
-        facs = np.zeros((max(n, 1), 8), dtype=np.complex128)
+        dd = self.d * self.d  # a one-site operator has d^2 entries, an operator on an adjacent pair d^4 (16 for qubits)
+        mats = np.zeros((max(n, 1), dd * dd), dtype=np.complex128)
+        facs = np.zeros((max(n, 1), 2 * dd), dtype=np.complex128)
         hasf = np.zeros(max(n, 1), dtype=np.int32)
         for k, p in enumerate(processes):
             s = list(p["sites"])
@@ -118,8 +119,8 @@ class BatchEngine:
                 m = np.asarray(p["matrix"], dtype=np.complex128).reshape(-1)
                 mats[k, : m.size] = m
             if "factors" in p:
-                facs[k, :4] = np.asarray(p["factors"][0], dtype=np.complex128).reshape(-1)
-                facs[k, 4:] = np.asarray(p["factors"][1], dtype=np.complex128).reshape(-1)
+                facs[k, :dd] = np.asarray(p["factors"][0], dtype=np.complex128).reshape(-1)
+                facs[k, dd:] = np.asarray(p["factors"][1], dtype=np.complex128).reshape(-1)
                 hasf[k] = 1
         _lib.check(self.lib.tjm_engine_set_noise(self.h, n, nsites.ctypes.data, sites.ctypes.data, gamma.ctypes.data, pauli.ctypes.data,
                                                  mats.ctypes.data, facs.ctypes.data, hasf.ctypes.data), "set_noise")
@@ -213,17 +214,18 @@ class BatchEngine:
 
     def run(self, *, order: int, n_times: int, sample_timesteps: bool, has_noise: bool, seed, traj_indices, observables,
             start=(0, 0), rng_pos=None, results=None, diagnostics=None):
-        """Whole trajectories in one C call (tjm_engine_run).  observables: [(first_site, matrix 2x2 | 4x4)] in site-sorted order.
+        """Whole trajectories in one C call (tjm_engine_run).  observables: [(first_site, matrix d x d | d^2 x d^2)] in site-sorted order.
 
         ``start`` / ``rng_pos`` / ``results`` / ``diagnostics`` continue a run that stopped with ``CapacityError`` (whose
         ``resume`` and ``rng_pos`` attributes carry the values to pass) after ``adopt`` has moved the states to this engine."""
         n_obs = len(observables)
         nsites = np.zeros(max(n_obs, 1), dtype=np.int32)
         site = np.zeros(max(n_obs, 1), dtype=np.int32)
-        mats = np.zeros((max(n_obs, 1), 16), dtype=np.complex128)
+        dd = self.d * self.d
+        mats = np.zeros((max(n_obs, 1), dd * dd), dtype=np.complex128)
         for k, (s0, m) in enumerate(observables):
             m = np.asarray(m, dtype=np.complex128)
-            nsites[k] = 2 if m.size == 16 else 1
+            nsites[k] = 2 if m.size == dd * dd else 1
             site[k] = s0
             mats[k, : m.size] = m.reshape(-1)
         pos = np.zeros(self.B, dtype=np.int64) if rng_pos is None else np.ascontiguousarray(rng_pos, dtype=np.int64).copy()

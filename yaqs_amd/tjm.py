@@ -715,7 +715,11 @@ class Simulator:
             hamiltonian = pieces[0]
         if hamiltonian.length != initial_state.length:
             raise ValueError("State and Hamiltonian must have the same number of sites")  # tdvp.py:91-93
-        validate_noise_model_for_run(noise_model, length=initial_state.length, is_digital=False, sim_params=sim_params)  # simulator.py:1488-1516
+        d = int(initial_state.physical_dimensions[0]) if getattr(initial_state, "physical_dimensions", None) else 2
+        if any(int(w.shape[0]) != d or int(w.shape[1]) != d for w in hamiltonian.tensors):
+            raise ValueError("State and Hamiltonian must have the same physical dimensions")
+        validate_noise_model_for_run(noise_model, length=initial_state.length, physical_dimensions=d, is_digital=False,
+                                     sim_params=sim_params)  # simulator.py:1488-1516
         if noise_model is not None:  # one realisation of static disorder per run (simulator.py:1269-1271)
             noise_model = noise_model.sample(rng=disorder_rng(sim_params.random_seed))
         initial_state = _encoded(initial_state)
@@ -732,6 +736,8 @@ class Simulator:
         chi, chi_top = engine_bond_caps(sim_params, initial_state, can_grow=_noise_can_grow_bonds(noise_model))
         mode = getattr(sim_params, "evolution_mode", "tdvp")
         self._engine_kw = {"cap_slack": 2} if str(getattr(mode, "value", mode)) == "bug" else {}
+        if d != 2:
+            self._engine_kw["d"] = d  # qutrits / four-level sites: one local dimension per chain (engine storage [B][d][cap][cap])
         cols = len(sim_params.times) if sim_params.sample_timesteps else 1
         n_obs = len(sim_params.observables)
         res_all = np.zeros((len(mine), n_obs, cols))
@@ -789,6 +795,8 @@ class Simulator:
 
         from .api import CircuitResult
 
+        if any(int(q) != 2 for q in (getattr(initial_state, "physical_dimensions", None) or [2])):
+            raise NotImplementedError("circuit runs are built for qubits (the gate library is 2 x 2 / 4 x 4)")
         validate_noise_model_for_run(noise_model, length=initial_state.length, is_digital=True, sim_params=sim_params)  # simulator.py:1867-1873
         if noise_model is not None:
             noise_model = noise_model.sample(rng=disorder_rng(sim_params.random_seed))
@@ -848,7 +856,8 @@ class Simulator:
 
 def _encoded(state: MPS) -> MPS:
     """``State._encode("mps")`` (state.py:278-297): the run works on a copy brought to B-normal form (centre 0, unit norm)."""
-    out = MPS(state.length, tensors=[np.array(t, dtype=np.complex128, copy=True) for t in state.tensors])
+    out = MPS(state.length, tensors=[np.array(t, dtype=np.complex128, copy=True) for t in state.tensors],
+              physical_dimensions=list(getattr(state, "physical_dimensions", None) or [2] * state.length))
     out.normalize("B")
     return out
 
@@ -876,7 +885,8 @@ def engine_bond_caps(sim_params, initial_state, can_grow: bool = False) -> tuple
     TDVP run is not confined to the bonds of its initial state.
     """
     have = max(max(t.shape[1], t.shape[2]) for t in initial_state.tensors)
-    exact = 2 ** min(initial_state.length // 2, 30)
+    d = int(initial_state.physical_dimensions[0]) if getattr(initial_state, "physical_dimensions", None) else 2
+    exact = min(d ** min(initial_state.length // 2, 30), 1 << 30)
     mode = getattr(sim_params, "evolution_mode", "tdvp")
     bug = str(getattr(mode, "value", mode)) == "bug"
     if bug:
