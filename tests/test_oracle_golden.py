@@ -465,3 +465,40 @@ def test_sample_at_and_segment_stitching_match_reference():
         assert np.allclose(r1, g["segment1"][t], atol=1e-9) and np.allclose(r2, g["segment2"][t], atol=1e-9), t
         assert np.allclose(r1, g["whole"][t][:, :4], atol=1e-9) and np.allclose(r2, g["whole"][t][:, 3:], atol=1e-9), t
         assert [x.shape[2] for x in phi2.tensors] == list(g["phi_bonds"][t])
+
+
+def _qudit_case(g, key):
+    d, L = int(key[1]), int(key.split("_L")[1])
+    b = np.diag(np.sqrt(np.arange(1, d)), 1).astype(complex)
+    n = b.conj().T @ b
+    mpo = tensors(g, key + "_mpo")
+    procs = [("loss", [i], 0.3, b) for i in range(L)] + [("dephasing", [i], 0.1, n) for i in range(L)]
+    init = []
+    for i in range(L):
+        v = np.zeros(d, dtype=complex)
+        v[(i + 1) % d] = 1.0
+        init.append(v.reshape(d, 1, 1))
+    return d, L, n, mpo, procs, init
+
+
+def test_qutrit_and_four_level_chains_match_reference():
+    """Local dimension 3 and 4 (tests/golden/qudit.npz: the reference on Bose-Hubbard chains with loss and dephasing): the oracle is
+    dimension-generic as the reference is - one two-site TDVP step from a random state and noisy trajectories of both drivers."""
+    g = load("qudit")
+    for key in g["cases"]:
+        key = str(key)
+        d, L, n, mpo, procs, init = _qudit_case(g, key)
+        chi = 9 if d == 3 else 8
+        st = o.MPSState([t.copy() for t in tensors(g, key + "_in")], 0)
+        o.tdvp(st, mpo, o.Params(dt=0.05, svd_threshold=1e-10, max_bond_dim=chi, krylov_tol=1e-12))
+        assert [t.shape[2] for t in st.tensors] == list(g[key + "_tdvp_bonds"])
+        ref = g[key + "_tdvp_vec"]
+        assert abs(abs(np.vdot(ref, st.to_vec())) - np.vdot(ref, ref).real) < 1e-10
+        on = [o.make_process(nm, s, gam, matrix=m) for nm, s, gam, m in procs]
+        for order in (1, 2):
+            op = o.Params(observables=[o.Obs(n, s) for s in range(L)], elapsed_time=0.4, dt=0.1, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-12,
+                          order=order, sample_timesteps=True, random_seed=4)
+            want = g[f"{key}_order{order}_results"]
+            for t in range(3):
+                r, _, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, mpo)
+                assert np.allclose(r, want[t], atol=1e-9), (key, order, t)

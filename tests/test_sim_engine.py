@@ -46,6 +46,7 @@ ENGINE_CASES = [
     "test_sample_at_and_segment_stitching_match_reference_on_the_engine",
     "test_dynamic_tdvp_matches_reference_on_the_engine",
     "test_bug_integrator_matches_reference_on_the_engine",
+    "test_bose_hubbard_qudit_chains_match_reference_fixture",
 ]
 
 

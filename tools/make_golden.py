@@ -748,6 +748,48 @@ def gen_scenarios():
     save("front_end_scenarios", **out)
 
 
+# ------------------------------------------------------------------ 16. qutrit / four-level chains
+def gen_qudit():
+    """The reference on chains with local dimension 3 and 4: MPO.bose_hubbard (mpo.py:670-745), Fock product states through
+    MPS(physical_dimensions=...), one-site loss / dephasing with custom d x d matrices, occupation observables; one closed TDVP
+    step from a random state and noisy trajectories of both drivers."""
+
+    out = {}
+    cases = []
+    for d, L, chi in ((3, 5, 9), (4, 4, 8)):
+        key = f"d{d}_L{L}"
+        cases.append(key)
+        H = MPO.bose_hubbard(L, d, 0.7, 0.6, 0.5)
+        out.update(pack_tensors(key + "_mpo", H.tensors))
+        b = np.diag(np.sqrt(np.arange(1, d)), 1).astype(complex)
+        n = b.conj().T @ b
+        # closed two-site TDVP step from a seeded random state
+        rng = np.random.default_rng(d * 10 + L)
+        caps = [1] * (L + 1)
+        for i in range(1, L):
+            caps[i] = min(d ** i, d ** (L - i), chi)
+        st = MPS(L, tensors=[rng.standard_normal((d, caps[i], caps[i + 1])) + 1j * rng.standard_normal((d, caps[i], caps[i + 1])) for i in range(L)],
+                 physical_dimensions=[d] * L)
+        st.normalize("B")
+        out.update(pack_tensors(key + "_in", st.tensors))
+        p = sp.AnalogSimParams(observables=[sp.Observable(n, 0)], elapsed_time=0.05, dt=0.05, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-12)
+        work = MPS(L, tensors=[t.copy() for t in st.tensors], physical_dimensions=[d] * L)
+        ref("core.methods.tdvp.tdvp").tdvp(work, H, p)
+        out[key + "_tdvp_vec"] = work.to_vec()
+        out[key + "_tdvp_bonds"] = np.array([t.shape[2] for t in work.tensors])
+        # noisy trajectories from a Fock state
+        basis = "".join(str((i + 1) % d) for i in range(L))
+        fock = MPS(L, physical_dimensions=[d] * L, state="basis", basis_string=basis)
+        noise = NoiseModel([{"name": "loss", "sites": [i], "strength": 0.3, "matrix": b} for i in range(L)]
+                           + [{"name": "dephasing", "sites": [i], "strength": 0.1, "matrix": n} for i in range(L)])
+        for order, fn in ((1, tjm.analog_tjm_1), (2, tjm.analog_tjm_2)):
+            p = sp.AnalogSimParams(observables=[sp.Observable(n, s) for s in range(L)], elapsed_time=0.4, dt=0.1, num_traj=3, max_bond_dim=chi,
+                                   svd_threshold=1e-10, krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=4)
+            out[f"{key}_order{order}_results"] = np.array([np.asarray(fn((i, fock, noise, p, H))[0], dtype=np.float64) for i in range(3)])
+    out["cases"] = np.array(cases)
+    save("qudit", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tiny", "rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
     for w in which:

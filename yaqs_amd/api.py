@@ -1014,6 +1014,25 @@ class MPO:
             w[1 + k, D - 1] = _Z
         return cls._fsm(length, w)
 
+    @classmethod
+    def bose_hubbard(cls, length: int, local_dim: int, omega: float, hopping_j: float, hubbard_u: float) -> "MPO":
+        """H = sum_i [omega n_i + U/2 n_i (n_i - 1)] - J sum_i (a_i^dag a_{i+1} + h.c.) on sites with ``local_dim`` levels
+        (at most local_dim - 1 bosons per site), the bond-dimension-4 automaton of mpo.py:670-745: state 1 has placed a^dag and
+        waits for -J a, state 2 has placed a and waits for -J a^dag."""
+        if length <= 0:
+            raise ValueError("length must be positive.")
+        d = int(local_dim)
+        a = np.diag(np.sqrt(np.arange(1, d, dtype=np.float64)), 1).astype(C128)
+        ad = a.conj().T
+        n = ad @ a
+        one = np.eye(d, dtype=C128)
+        w = np.zeros((4, 4, d, d), dtype=C128)
+        w[0, 0], w[3, 3] = one, one
+        w[0, 1], w[1, 3] = ad, -hopping_j * a
+        w[0, 2], w[2, 3] = a, -hopping_j * ad
+        w[0, 3] = omega * n + 0.5 * hubbard_u * (n @ (n - one))
+        return cls._fsm(length, w)
+
     @staticmethod
     def _check_bc(bc: str, length: int) -> bool:
         if bc not in ("open", "periodic"):
