@@ -179,6 +179,12 @@ int tjm_engine_step_bug_site(tjm_engine* e, int32_t set, int32_t site, double dt
 int tjm_engine_step_bug_root(tjm_engine* e, int32_t set, double dt);
 int tjm_engine_step_flip(tjm_engine* e, int32_t set);
 int tjm_engine_step_compress(tjm_engine* e, int32_t set, double threshold, int32_t max_bond_dim, int32_t trunc_mode);
+/* Long-range two-qubit gate as a matrix product operator (digital_tjm.py:536-557: MPO.from_gate(gate, L).multiply(state), mpo.py:1511-1548,
+ * the reference's default route for distant pairs): U = sum_k left_ops[k] (x) right_ops[k] on sites (first, last), first < last, identity
+ * threads in between (gate_library.py:29-126); left_ops / right_ops are [rank][d][d] row-major complex (out, in).  Bonds first+1 .. last
+ * grow by the factor `rank` (MPS index first in the fused leg, mpo_utils.py:27-56); a product beyond the storage raises the capacity
+ * flag.  The caller compresses afterwards (tjm_engine_step_compress = MPS.compress, mps.py:841-899). */
+int tjm_engine_apply_gate_mpo(tjm_engine* e, int32_t set, int32_t first, int32_t last, int32_t rank, const double* left_ops, const double* right_ops);
 
 /* ---- whole trajectories in one call -------------------------------------------------- *
  * The body of the backend contract: analog_tjm_1 / analog_tjm_2 (analog/analog_tjm.py:206-462) for the B resident

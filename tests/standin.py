@@ -155,6 +155,29 @@ class OracleEngine:
             s.tensors[site] = np.einsum("ab,bcd->acd", m, s.tensors[site])
             s.center = None
 
+    def apply_gate_mpo(self, first, last, left_ops, right_ops, set_index=0):
+        """The site-by-site product of mpo.py:1511-1548 for U = sum_k left_ops[k] (x) right_ops[k] on (first, last)."""
+        lo, ro = np.asarray(left_ops, dtype=np.complex128), np.asarray(right_ops, dtype=np.complex128)
+        r = lo.shape[0]
+        for s in self.sets[set_index]:
+            for site in range(first, last + 1):
+                a = s.tensors[site]
+                d = a.shape[0]
+                if site == first:
+                    w = lo.transpose(1, 2, 0).reshape(d, d, 1, r)
+                elif site == last:
+                    w = ro.transpose(1, 2, 0).reshape(d, d, r, 1)
+                else:
+                    w = np.zeros((d, d, r, r), dtype=np.complex128)
+                    for k in range(r):
+                        w[:, :, k, k] = np.eye(d)
+                th = np.tensordot(w, a, axes=([1], [0]))
+                po, wl, wr, ml, mr = th.shape
+                s.tensors[site] = th.transpose(0, 3, 1, 4, 2).reshape(po, ml * wl, mr * wr)
+                if s.tensors[site].shape[2] > self.caps[site + 1]:
+                    self._overflow = True
+            s.center = None
+
     def apply_pair(self, left, matrix, min_keep=1, set_index=0):
         m = np.asarray(matrix, dtype=np.complex128).reshape(4, 4)
         p = self.params

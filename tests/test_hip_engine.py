@@ -316,8 +316,8 @@ def test_digital_tebd_trajectories_match_reference_fixture():
     r, d, db = run(noise3, p, lr_layers, list(range(6)), 4)
     assert np.allclose(r, g["lr_noisy_results"], atol=1e-8)
     assert np.array_equal(d, g["lr_noisy_diag"])
-    with pytest.raises(NotImplementedError):  # the default gate_mode="mpo" sends distant pairs through the gate-MPO product
-        run(None, DigitalSimParams(observables=obs, max_bond_dim=4, svd_threshold=1e-8, random_seed=11), lr_layers, [0], 4)
+    with pytest.raises(NotImplementedError):  # the TDVP-window route of distant pairs (digital_tjm.py:408-453) is not built
+        run(None, DigitalSimParams(observables=obs, max_bond_dim=4, svd_threshold=1e-8, random_seed=11, gate_mode="tdvp"), lr_layers, [0], 4)
 
 
 def test_chi256_heisenberg_lowering_step_matches_oracle():
@@ -1758,3 +1758,42 @@ def test_bose_hubbard_qudit_chains_match_reference_fixture():
             want = g[f"{key}_order{order}_results"]
             for s_ in range(L):
                 assert np.allclose(res.trajectories[s_], want[:, s_, :], atol=1e-8), (key, order, s_)
+
+
+def test_long_range_gates_through_the_gate_mpo_match_reference_fixture():
+    """gate_mode="mpo", the reference's DEFAULT for distant pairs (digital_tjm.py:536-557, 616-620): MPO.from_gate(gate, L).multiply(state)
+    (tjm_engine_apply_gate_mpo: operator Schmidt terms on the two target sites, identity threads in between, bonds grown by the rank)
+    and MPS.compress (tjm_engine_step_compress).  tests/golden/digital_mpo.npz holds the REFERENCE's trajectories of the long-range
+    circuit of the SWAP fixture under the default mode, for a cap that bites (4) and one that does not (16); run through
+    Simulator.run with default DigitalSimParams - storage four times the cap, grown on demand."""
+    from yaqs_amd.api import DigitalSimParams, GateLayer, MPS, NoiseModel, Observable, X as Xg, Z as Zg, rx_matrix
+    from yaqs_amd.tjm import Simulator
+
+    g, gd = load("digital_mpo"), load("digital")
+    L = 8
+    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 3)]
+    cx, rzz = gd["lr_cx_matrix"], gd["lr_rzz_matrix"]
+    layers = [GateLayer([(q, rx_matrix(0.3 + 0.1 * q)) for q in range(L)], [(1, 5, cx), (6, 2, rzz)], [(4, 3, cx), (7, 0, cx)], 0) for _ in range(2)]
+    noise = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)] +
+                       [{"name": "crosstalk_zz", "sites": [1, 5], "strength": 0.1}, {"name": "lowering", "sites": [6], "strength": 0.2}])
+    for chi in (4, 16):
+        p = DigitalSimParams(observables=obs, max_bond_dim=chi, svd_threshold=1e-8, random_seed=11, num_traj=1)
+        assert p.gate_mode == "mpo"
+        res = Simulator().run(MPS(L, state="zeros"), layers, p, None)
+        want = g[f"chi{chi}_noiseless_results"][0]
+        idx = p.observable_sorted_indices  # the fixture's rows are in the reference's site-sorted order
+        for u in range(len(obs)):
+            assert np.allclose(res.trajectories[u][0], want[idx[u]], atol=1e-8), (chi, u)
+        # noisy: through the backend class, as the fixture was made (the front end refuses the distant crosstalk pair, noise_model.py)
+        from yaqs_amd.engine import BatchEngine
+        from yaqs_amd.tjm import DigitalBatch
+
+        p = DigitalSimParams(observables=obs, max_bond_dim=chi, svd_threshold=1e-8, random_seed=11, num_traj=6)
+        e = BatchEngine(L, 4 * chi, 6, o.ising_mpo(L, 1.0, 0.5), cap_slack=4)
+        db = DigitalBatch(e, p, noise)
+        r, dg = db.run(list(range(6)), MPS(L, state="zeros"), layers)
+        assert not e.capacity_overflow()
+        e.close()
+        assert np.array(db.jump_log).sum() > 0
+        assert np.allclose(r, g[f"chi{chi}_noisy_results"], atol=1e-8), chi
+        assert np.array_equal(dg, g[f"chi{chi}_noisy_diag"]), chi

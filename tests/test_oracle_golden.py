@@ -302,6 +302,26 @@ def test_digital_long_range_gates_match_reference():
         assert np.array_equal(dg, g["lr_noisy_diag"][i]), i
 
 
+def test_digital_long_range_gates_through_the_gate_mpo_match_reference():
+    """gate_mode="mpo", the reference's default (digital_tjm.py:536-557): distant pairs through MPO.from_gate(...).multiply(state) and
+    MPS.compress; tests/golden/digital_mpo.npz holds the reference's trajectories for a cap that bites (4) and one that does not (16)."""
+    g, gd = load("digital_mpo"), load("digital")
+    L = 8
+    obs = [o.Obs(Z, s) for s in range(L)] + [o.Obs(X, 3)]
+    init = o.MPSState.product(L, "zeros")
+    noise = [o.make_process("pauli_x", [i], 0.05) for i in range(L)] + [o.make_process("crosstalk_zz", [1, 5], 0.1, factors=(Z, Z)),
+                                                                         o.make_process("lowering", [6], 0.2)]
+    for chi in (4, 16):
+        p = o.DigitalParams(observables=obs, max_bond_dim=chi, svd_threshold=1e-8, random_seed=11, gate_mode="mpo")
+        r, dg, _ = o.digital_tjm(0, init, None, p, _long_range_layers(gd, L))
+        assert np.allclose(r, g[f"chi{chi}_noiseless_results"][0], atol=1e-9), chi
+        assert np.array_equal(dg, g[f"chi{chi}_noiseless_diag"][0]), chi
+        for i in range(6):
+            r, dg, _ = o.digital_tjm(i, init, noise, p, _long_range_layers(gd, L))
+            assert np.allclose(r, g[f"chi{chi}_noisy_results"][i], atol=1e-9), (chi, i)
+            assert np.array_equal(dg, g[f"chi{chi}_noisy_diag"][i]), (chi, i)
+
+
 def test_measure_single_shot_matches_reference():
     """Projective sampling of all sites (mps.py:1282-1350) with the recorded draws, in the Z, X and Y bases."""
     g = load("shots")

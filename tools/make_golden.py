@@ -790,6 +790,45 @@ def gen_qudit():
     save("qudit", **out)
 
 
+# ------------------------------------------------------------------ 17. long-range gates through the gate-MPO product (the default gate_mode)
+def gen_digital_mpo():
+    """digital_tjm with gate_mode="mpo" (the default; digital_tjm.py:536-557, 592-620): distant pairs go through
+    MPO.from_gate(...).multiply(state, compress=True), nearest neighbours through TEBD.  Same layers as the SWAP-routed fixture of
+    gen_digital, with a cap that bites (chi = 4) and one that does not (chi = 16)."""
+    dtm = ref("digital.digital_tjm")
+    L = 8
+
+    def lr_layer():
+        singles = []
+        for q in range(L):
+            gt = gl.GateLibrary.rx([0.3 + 0.1 * q]); gt.set_sites(q); singles.append(gt)
+        a = gl.GateLibrary.cx(); a.set_sites(1, 5)
+        b = gl.GateLibrary.rzz([0.7]); b.set_sites(6, 2)
+        c = gl.GateLibrary.cx(); c.set_sites(4, 3)
+        d_ = gl.GateLibrary.cx(); d_.set_sites(7, 0)
+        return dtm._CompiledCircuitLayer(tuple(singles), (a, b), (c, d_), 0)
+
+    out = {}
+    st = MPS(L, state="zeros")
+    st.normalize("B")
+    obs = [sp.Observable(gl.Z(), s) for s in range(L)] + [sp.Observable(gl.X(), 3)]
+    noise = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)] +
+                       [{"name": "crosstalk_zz", "sites": [1, 5], "strength": 0.1}, {"name": "lowering", "sites": [6], "strength": 0.2}])
+    cc = dtm._CompiledCircuit(tuple(lr_layer() for _ in range(2)), 0)
+    for chi in (4, 16):
+        p = sp.DigitalSimParams(observables=obs, max_bond_dim=chi, svd_threshold=1e-8, random_seed=11)
+        assert p.gate_mode == "mpo"
+        for name, nm, ntraj in ((f"chi{chi}_noisy", noise, 6), (f"chi{chi}_noiseless", None, 1)):
+            res, diag = [], []
+            for i in range(ntraj):
+                r, dg, _, _ = dtm.digital_tjm((i, st, nm, p, None), compiled_circuit=cc)
+                res.append(np.asarray(r, dtype=np.float64))
+                diag.append(dg)
+            out[name + "_results"] = np.array(res)
+            out[name + "_diag"] = np.array(diag)
+    save("digital_mpo", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tiny", "rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
     for w in which:

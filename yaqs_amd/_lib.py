@@ -120,6 +120,7 @@ EXPORTS = {
     "tjm_engine_step_bug_site": (C.c_int, [V, I, I, D]),
     "tjm_engine_step_bug_root": (C.c_int, [V, I, D]),
     "tjm_engine_step_flip": (C.c_int, [V, I]),
+    "tjm_engine_apply_gate_mpo": (C.c_int, [V, I, I, I, I, V, V]),
     "tjm_engine_step_compress": (C.c_int, [V, I, D, I, I]),
     "tjm_engine_profile": (C.c_int, [V, I]),
     "tjm_engine_profile_read": (C.c_int, [V, V, V]),

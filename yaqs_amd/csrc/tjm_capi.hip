@@ -342,6 +342,12 @@ int tjm_engine_step_compress(tjm_engine* e, int32_t set, double threshold, int32
   return e->impl.step_compress(set, threshold, max_bond_dim, trunc_mode);
 }
 
+int tjm_engine_apply_gate_mpo(tjm_engine* e, int32_t set, int32_t first, int32_t last, int32_t rank, const double* left_ops, const double* right_ops) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.apply_gate_mpo(set, first, last, rank, left_ops, right_ops);
+}
+
 int tjm_engine_profile(tjm_engine* e, int32_t enable) {
   if (!e) return TJM_ERR_ARG;
   TJM_ON_DEVICE(e);

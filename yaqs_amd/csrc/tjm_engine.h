@@ -77,6 +77,7 @@ class Engine {
   int apply_single(int set, int site, const double* host_mat);
   int tebd_gate(int set, int left, const double* host_u, int center = 0);
   int apply_pair(int set, int left, const double* host_u, int min_keep);
+  int apply_gate_mpo(int set, int first, int last, int r, const double* host_left, const double* host_right);
   int canonicalize_qr(int set, int center);
   int stochastic(int set, double dt_, int* host_jumped /*B or null*/, double* host_dp /*B or null*/);
   int site_moments(int set, double* host_M /*[L][B][d][d] complex*/, double* host_M2 = nullptr /*[L-1][B][d^2][d^2] or null*/);

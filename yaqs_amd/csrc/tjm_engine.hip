@@ -2153,6 +2153,75 @@ int Engine::step_cap_bond(int set, int bond, int target, const int* host_ids, in
 }
 
 // ------------------------------------------------------------------------------------------
+// Long-range gate as a matrix product operator (digital_tjm.py:536-557: MPO.from_gate(...).multiply(state), mpo.py:1511-1548)
+// ------------------------------------------------------------------------------------------
+// One site of the product.  The gate is U = sum_k P_k (x) Q_k on sites (first, last) with identity threads in between
+// (extend_gate, gate_library.py:66-126); the fused virtual legs carry the MPS index first (mpo_utils.py:27-56):
+//   mode 0 (first):  out[p][a][b r + k]       = sum_q P_k[p][q] A[q][a][b]
+//   mode 1 (thread): out[p][a r + k][b r + k] = A[p][a][b]
+//   mode 2 (last):   out[p][a r + k][b]       = sum_q Q_k[p][q] A[q][a][b]
+// Entries beyond the storage are dropped (gate_mpo_dim_kernel raises the overflow flag).
+__global__ __launch_bounds__(256) void gate_mpo_site_kernel(const cplx* __restrict__ A, long a_b0, int d, int ca, int cb, const int* chi, int stride, int site,
+                                                           int mode, int r, const cplx* __restrict__ ops, cplx* __restrict__ out, long out_b0) {
+  const int b = blockIdx.y;
+  const int xa = chi[(long)b * stride + site], xb = chi[(long)b * stride + site + 1];
+  const cplx* Ab = A + (long)b * a_b0;
+  const long n = (long)d * ca * cb;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const int bo = (int)(e % cb);
+    const long q0 = e / cb;
+    const int ao = (int)(q0 % ca), p = (int)(q0 / ca);
+    int a = ao, bi = bo, ka = -1, kb = -1;
+    if (mode != 0) { ka = ao % r; a = ao / r; }
+    if (mode != 2) { kb = bo % r; bi = bo / r; }
+    cplx v{0.0, 0.0};
+    if (a < xa && bi < xb && (mode != 1 || ka == kb)) {
+      if (mode == 1) {
+        v = Ab[((long)p * ca + a) * cb + bi];
+      } else {
+        const cplx* O = ops + (long)(mode == 0 ? kb : ka) * d * d;
+        for (int q = 0; q < d; ++q) cfma(v, O[p * d + q], Ab[((long)q * ca + a) * cb + bi]);
+      }
+    }
+    out[(long)b * out_b0 + e] = v;
+  }
+}
+// bond k grows by the factor r; a product that does not fit the storage is flagged
+__global__ void gate_mpo_dim_kernel(int* chi, int stride, int k, int r, int capk, int* overflow, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int x = chi[(long)b * stride + k] * r;
+  if (x > capk) { x = capk; atomicOr(overflow, 1); }
+  chi[(long)b * stride + k] = x;
+}
+
+int Engine::apply_gate_mpo(int set, int first, int last, int r, const double* host_left, const double* host_right) {
+  if (!bound_ || set < 0 || set > 1 || first < 0 || last >= L || last - first < 1 || r < 1 || r > d * d || !host_left || !host_right) return TJM_ERR_ARG;
+  StateSet& S = sets[set];
+  const size_t dd = (size_t)d * d;
+  cplx* tab = ops_ + (size_t)(L + 8) * dd * dd;  // behind the slots of apply_single / tebd_gate
+  TJM_HIP_CHECK(hipMemcpyAsync(tab, host_left, (size_t)r * dd * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(tab + (size_t)r * dd, host_right, (size_t)r * dd * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  int rc;
+  for (int k = first; k <= last; ++k) {
+    const int mode = (k == first) ? 0 : (k == last ? 2 : 1);
+    const long total = a_b0_[k];
+    int gx = (int)((total + 1023) / 1024);
+    if (gx < 1) gx = 1;
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(gate_mpo_site_kernel, dim3(gx, B), dim3(256), 0, stream, S.A[k], a_b0_[k], d, cap[k], cap[k + 1], S.chi, L + 1, k, mode, r,
+                       mode == 2 ? tab + (size_t)r * dd : tab, T1, t_b0);
+    TJM_HIP_CHECK(hipGetLastError());
+    if ((rc = copy_back(S.A[k], a_b0_[k], T1, t_b0, a_b0_[k], nullptr, B)) != TJM_OK) return rc;
+  }
+  for (int k = first + 1; k <= last; ++k)  // after every site has read the old dimensions
+    hipLaunchKernelGGL(gate_mpo_dim_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, S.chi, L + 1, k, r, cap[k], overflow_, B);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Steps of the Basis-Update and Galerkin integrator (core/methods/bug.py:35-257) for the whole batch.
 // Set `set` holds the state (right-canonical basis tensors, centre 0: the reference's state.tensors), set 2 the coefficient-bearing
 // centres (canon_center_tensors), set 3 is scratch (the Q factors of the preparation, then predictor / stacked basis / new basis).

@@ -340,6 +340,14 @@ class BatchEngine:
     def step_flip(self, set_index: int = 0):
         _lib.check(self.lib.tjm_engine_step_flip(self.h, set_index), "step_flip")
 
+    def apply_gate_mpo(self, first: int, last: int, left_ops: np.ndarray, right_ops: np.ndarray, set_index: int = 0):
+        """U = sum_k left_ops[k] (x) right_ops[k] on the distant pair (first, last) as an MPO product (tjm_engine_apply_gate_mpo); the
+        bonds in between grow by the number of terms until ``step_compress``."""
+        lo = np.ascontiguousarray(left_ops, dtype=np.complex128)
+        ro = np.ascontiguousarray(right_ops, dtype=np.complex128)
+        assert lo.shape == ro.shape == (lo.shape[0], self.d, self.d)
+        _lib.check(self.lib.tjm_engine_apply_gate_mpo(self.h, set_index, int(first), int(last), int(lo.shape[0]), lo.ctypes.data, ro.ctypes.data), "apply_gate_mpo")
+
     def step_compress(self, threshold: float, max_bond_dim, trunc_mode: str = "discarded_weight", set_index: int = 0):
         _lib.check(self.lib.tjm_engine_step_compress(self.h, set_index, float(threshold), -1 if max_bond_dim is None else int(max_bond_dim),
                                                      TRUNC_MODES[trunc_mode]), "step_compress")

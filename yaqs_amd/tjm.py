@@ -506,10 +506,18 @@ class DigitalBatch:
         t = np.asarray(mat, dtype=np.complex128).reshape(2, 2, 2, 2)
         u_lr = t if s0 < s1 else t.transpose(1, 0, 3, 2)  # resolve_lr_tensor (mpo_utils.py:127-159)
         left, right = min(s0, s1), max(s0, s1)
-        if right - left > 1 and getattr(self.p, "gate_mode", "mpo") != "swaps":
-            # digital_tjm.py:592-620: every other mode sends a distant pair through the gate-MPO product (or a TDVP window), whose
-            # intermediate bonds are up to four times max_bond_dim; only the SWAP-routed TEBD route is built here
-            raise NotImplementedError(f"long-range gate on sites ({s0}, {s1}) needs gate_mode='swaps' (got {self.p.gate_mode!r})")
+        mode = getattr(self.p, "gate_mode", "mpo")
+        if right - left > 1 and mode == "mpo":
+            # the reference's default (digital_tjm.py:536-557, 616-620): MPO.from_gate(gate, L).multiply(state) and MPS.compress.
+            # Operator Schmidt decomposition of the gate as split_tensor does it (gate_library.py:29-63: singular values <= 1e-6 dropped)
+            sv_u, sv, sv_vh = np.linalg.svd(u_lr.transpose(0, 2, 1, 3).reshape(4, 4), full_matrices=False)
+            keep = max(1, int(np.sum(sv > 1e-6)))
+            e.apply_gate_mpo(left, right, sv_u[:, :keep].T.reshape(keep, 2, 2), (sv[:keep, None] * sv_vh[:keep]).reshape(keep, 2, 2))
+            e.step_compress(self.p.svd_threshold, self.p.max_bond_dim, self.p.trunc_mode)
+            return {s0, s1}, 0  # step_compress leaves the centre on site 0 (the reference moves it to L // 2: a gauge choice)
+        if right - left > 1 and mode != "swaps":
+            # "tdvp" / "full-tdvp" evolve a window with the gate's generator (digital_tjm.py:408-453): not built
+            raise NotImplementedError(f"long-range gate on sites ({s0}, {s1}) needs gate_mode='mpo' or 'swaps' (got {self.p.gate_mode!r})")
         center = 0
         for i in range(right - 1, left, -1):  # bring the right qubit next to the left one
             e.tebd_gate(i, self._SWAP, center=center)
@@ -805,7 +813,14 @@ class Simulator:
         num_traj, per_call, distribution = plan_digital_shots(sim_params, noisy)
         device = self.device or f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
         self._engine_kw = {}
-        chi, chi_top = engine_bond_caps(sim_params, initial_state, can_grow=True)  # every TEBD gate is a truncated split
+        distant = any(len(en) == 3 and abs(en[0] - en[1]) > 1 for layer in layers for en in list(layer.even) + list(layer.odd))
+        slack = 1
+        if distant and getattr(sim_params, "gate_mode", "mpo") == "mpo":
+            # the gate-MPO product multiplies the bonds under the gate by its operator Schmidt rank (<= 4) until MPS.compress cuts
+            # them back (digital_tjm.py:536-557): the storage holds four times the cap and four times the exact ranks near the ends
+            slack = 4
+            self._engine_kw = {"cap_slack": 4}
+        chi, chi_top = engine_bond_caps(sim_params, initial_state, can_grow=True, slack=slack)  # every TEBD gate is a truncated split
         mid = sim_params.num_mid_measurements if sim_params.sample_layers else 0
         cols = (mid + 2) if sim_params.sample_layers else 1
         res_all = np.zeros((num_traj, len(sim_params.observables), cols))
@@ -871,7 +886,7 @@ START_CHI = 8   # first storage capacity tried when the requested cap is larger
 AUTO_BATCH_MAX = 16384  # trajectories in flight when Simulator(batch=None) sizes the batch itself
 
 
-def engine_bond_caps(sim_params, initial_state, can_grow: bool = False) -> tuple[int, int]:
+def engine_bond_caps(sim_params, initial_state, can_grow: bool = False, slack: int = 1) -> tuple[int, int]:
     """``(first, top)`` storage capacities of the engine.
 
     The reference's bonds are dynamic and its presets ask for ``max_bond_dim`` = 128, 4096 or no cap at all
@@ -891,7 +906,8 @@ def engine_bond_caps(sim_params, initial_state, can_grow: bool = False) -> tuple
     bug = str(getattr(mode, "value", mode)) == "bug"
     if bug:
         exact *= 2  # a stacked trial basis holds up to twice the Schmidt rank of its cut until the next canonicalisation (cap_slack = 2)
-    want = exact if sim_params.max_bond_dim is None else min(int(sim_params.max_bond_dim), exact)
+    exact *= slack  # gate-MPO products: bonds up to `slack` times the exact rank / the cap between the product and its compression
+    want = exact if sim_params.max_bond_dim is None else min(slack * int(sim_params.max_bond_dim), exact)
     if getattr(sim_params, "tdvp_mode", "2site") == "dynamic" and sim_params.max_bond_dim is not None and not bug:
         # the two-site branch of the dynamic sweep splits without a cap (split_tdvp(dynamic=True)): a bond next to one below the cap
         # can reach d * (max_bond_dim - 1) before _cap_bonds cuts it back at the start of the next sweep
