@@ -1181,6 +1181,53 @@ def test_randomised_configurations_match_oracle(case):
         assert np.array_equal(d[t], do), (case, t)
 
 
+@pytest.mark.parametrize("case", range(int(os.environ.get("TJM_FUZZ_GENERAL_CASES", "24"))))
+def test_randomised_general_path_configurations_match_oracle(case):
+    """The differential test of test_randomised_configurations_match_oracle on the THROUGHPUT kernels (bond caps 24 - 128, chains of
+    10 - 20 sites): MFMA GEMMs, Lanczos kernels, Householder panels, tiled / LDS-resident Jacobi with QR preconditioning, the
+    capacity ladder.  Seeded random set-ups: chain length, cap, a chi-saturated or partly saturated Haar state, a truncation rule that
+    leaves ragged bonds, TDVP mode, driver order, Hamiltonian (Ising / Heisenberg D = 5 / exponential-sum long-range D = 4), and a noise
+    model with non-Pauli and Pauli one-site channels plus an adjacent pair channel, strong enough to jump within two steps."""
+    from yaqs_amd.api import AnalogSimParams, MPO, NoiseModel, Observable, X as Xg, Z as Zg
+
+    rng = np.random.default_rng(7000 + case)
+    chi = int([24, 48, 96, 128][case % 4])
+    L = int(rng.integers({24: 10, 48: 12, 96: 14, 128: 14}[chi], {24: 21, 48: 21, 96: 18, 128: 17}[chi]))  # 2**(L//2) >= chi: the cap is reached
+    order = int(rng.choice([1, 2]))
+    mode = str(rng.choice(["2site", "2site", "1site"]))
+    trunc = str(rng.choice(["discarded_weight", "relative"]))
+    thr = float(10.0 ** rng.uniform(-9, -4))  # bites unevenly: the bonds after the first step differ from site to site
+    start = int(rng.choice([chi, max(8, chi // 2)]))  # saturated, or bonds that still grow into the cap (capacity ladder)
+    st = o.MPSState.haar(L, start, np.random.default_rng(case))
+    st.normalize("B")
+    init = [t.copy() for t in st.tensors]
+    procs = []
+    for i in range(L):
+        for name in rng.choice(["lowering", "raising", "pauli_x", "pauli_z"], size=int(rng.integers(1, 3)), replace=False):
+            procs.append({"name": str(name), "sites": [i], "strength": float(rng.uniform(0.05, 0.5))})
+    i = int(rng.integers(0, L - 1))
+    procs.append({"name": "crosstalk_xz", "sites": [i, i + 1], "strength": float(rng.uniform(0.05, 0.3))})
+    if mode == "2site" and rng.random() < 0.5:
+        i = int(rng.integers(0, L - 1))
+        m = np.kron(o.JUMP_OPS["lowering"], np.array([[1, 0], [0, -1]])) + 0.3 * np.kron(np.eye(2), o.JUMP_OPS["raising"])
+        procs.append({"name": "custom", "sites": [i, i + 1], "strength": float(rng.uniform(0.05, 0.3)), "matrix": m})
+    noise = NoiseModel(procs)
+    which = int(rng.integers(0, 3))
+    mpo = [MPO.ising(L, 1.0, 0.6), MPO.heisenberg(L, 1.0, 0.7, 0.4, 0.25), MPO.long_range_ising(L, [0.8, 0.3], [0.5, 0.8], 0.7)][which]
+    sites = sorted(set(int(x) for x in rng.integers(0, L, size=6)))
+    obs = [Observable(Zg(), s_) for s_ in sites] + [Observable(Xg(), sites[0])]
+    oobs = [o.Obs(Z, s_) for s_ in sites] + [o.Obs(X, sites[0])]
+    kw = dict(elapsed_time=0.2, dt=0.1, max_bond_dim=chi, svd_threshold=thr, trunc_mode=trunc, krylov_tol=1e-10, order=order, sample_timesteps=True,
+              random_seed=int(rng.integers(0, 10 ** 6)), tdvp_mode=mode)
+    r, d, tb = _run(L, init, noise, AnalogSimParams(observables=obs, **kw), mpo.tensors, [0, 1], native=bool(rng.integers(0, 2)))
+    op = o.Params(observables=oobs, **kw)
+    on = [o.make_process(q["name"], q["sites"], q["strength"], matrix=q.get("matrix"), factors=q.get("factors")) for q in noise.processes]
+    for t in range(2):
+        ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, [w.copy() for w in mpo.tensors])
+        assert np.allclose(r[t], ro, atol=1e-8), (case, t, np.abs(r[t] - ro).max(), kw, L, which)
+        assert np.array_equal(d[t], do), (case, t)
+
+
 @pytest.mark.parametrize("case", range(int(os.environ.get("TJM_FUZZ_CASES", "80"))))
 def test_randomised_circuits_match_oracle(case):
     """Differential test of the circuit path on seeded random circuits: random one-qubit unitaries, random two-qubit unitaries on
