@@ -164,6 +164,7 @@ class Engine {
   int* opidx_ = nullptr;         // [B]
   int* jsite_ = nullptr;         // [B]
   int* overflow_ = nullptr;      // sticky flag: a truncation was clipped by the storage capacity
+  hipEvent_t krylov_ev_[2] = {nullptr, nullptr};  // pipelined convergence check of the Lanczos loop (krylov_core)
   SmallSiteRef* site_refs_[4] = {nullptr, nullptr, nullptr, nullptr};   // device tables of the fused small-bond sweeps
   SmallSweepStep* sweep_steps_ = nullptr;
   bool sweep_ok_ = false;

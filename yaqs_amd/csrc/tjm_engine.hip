@@ -591,6 +591,11 @@ int Engine::krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc
   int rc, nblk = 1;
   Region prof(*this, PROF_KRYLOV);
   ++stat_krylov_calls;
+  static const bool sync_each = getenv("TJM_KRYLOV_SYNC_EACH") != nullptr;
+  bool pipelined = !sync_each;
+  if (pipelined && !krylov_ev_[0]) {
+    if (hipEventCreate(&krylov_ev_[0]) != hipSuccess || hipEventCreate(&krylov_ev_[1]) != hipSuccess) { (void)hipGetLastError(); pipelined = false; }
+  }
   TJM_HIP_CHECK(hipMemsetAsync(ks.n_active, 0, sizeof(int), stream));
   if ((rc = launch_normsq_partial(V, v_b0, n, part2_, nb0, ids, nullptr, stream, &nblk)) != TJM_OK) return rc;
   if ((rc = launch_lanczos_init(ks, part2_, nblk, nb0, ids, stream)) != TJM_OK) return rc;
@@ -608,9 +613,22 @@ int Engine::krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc
     if ((rc = launch_lanczos_finalize(ks, part1_, part2_, nblk, j, dt_, krylov_tol, nloc_dev, nb0, ids, stream)) != TJM_OK) return rc;
     if (j + 1 < mmax)
       if ((rc = launch_scale(w, v_b0, n, ks.scale, nb0, ids, ks.status, stream)) != TJM_OK) return rc;
-    TJM_HIP_CHECK(hipMemcpyAsync(h_pinned_, ks.n_active, sizeof(int), hipMemcpyDeviceToHost, stream));
-    TJM_HIP_CHECK(hipStreamSynchronize(stream));
-    if (*h_pinned_ == 0) break;
+    if (!pipelined) {
+      TJM_HIP_CHECK(hipMemcpyAsync(h_pinned_, ks.n_active, sizeof(int), hipMemcpyDeviceToHost, stream));
+      TJM_HIP_CHECK(hipStreamSynchronize(stream));
+      if (*h_pinned_ == 0) break;
+      continue;
+    }
+    // The count of still-active trajectories travels to the host behind the iteration; the host looks at it only after it has
+    // queued the NEXT iteration, so the device never idles for the round trip.  When the count was zero, the iteration already
+    // queued runs with every trajectory masked (ks.status) and changes nothing.
+    TJM_HIP_CHECK(hipMemcpyAsync(h_pinned_ + 2 + (j & 1), ks.n_active, sizeof(int), hipMemcpyDeviceToHost, stream));
+    TJM_HIP_CHECK(hipEventRecord(krylov_ev_[j & 1], stream));
+    if (j > 0) {
+      TJM_HIP_CHECK(hipEventSynchronize(krylov_ev_[(j - 1) & 1]));
+      if (h_pinned_[2 + ((j - 1) & 1)] == 0) break;
+    }
+    if (j + 1 == mmax) TJM_HIP_CHECK(hipStreamSynchronize(stream));
   }
   return launch_krylov_combine(V, v_b0, v_ld, ks, out, out_b0, n0, n1, n2, n3, o0, o1, o2, nb0, ids, stream);
 }
