@@ -1844,3 +1844,58 @@ def test_long_range_gates_through_the_gate_mpo_match_reference_fixture():
         assert np.array(db.jump_log).sum() > 0
         assert np.allclose(r, g[f"chi{chi}_noisy_results"], atol=1e-8), chi
         assert np.array_equal(dg, g[f"chi{chi}_noisy_diag"]), chi
+
+
+@pytest.mark.parametrize("native", [False, True])
+def test_non_finite_inputs_fail_loudly_like_the_reference(native):
+    """A NaN or Inf in the initial state never comes back as a number.  The reference (and the oracle) stop at the first measurement
+    ("assert exp.imag < 1e-13", mps.py:1233, false for NaN) or, when nothing is measured before the first jump decision, at the
+    non-finite jump weights (ValueError, stochastic_process.py:178-186); the same exception types come out of both drivers here.
+    Where the reference fails inside LAPACK's tridiagonal solver instead (a NaN reaches the Krylov step first, or sits in the
+    Hamiltonian), the engine ends in one of those two errors as well - never in numbers."""
+    from yaqs_amd.api import AnalogSimParams, MPS, NoiseModel, Observable, Z as Zg
+    from yaqs_amd.tjm import TrajectoryBatch
+
+    L = 4
+    mpo = o.ising_mpo(L, 1.0, 0.5)
+    noise = NoiseModel([{"name": "lowering", "sites": [i], "strength": 0.2} for i in range(L)])
+    on = [o.make_process("lowering", [i], 0.2) for i in range(L)]
+
+    def outcome(fn):
+        try:
+            fn()
+        except Exception as ex:  # noqa: BLE001 - the type is what is compared
+            return type(ex)
+        return None
+
+    for bad in (np.nan, np.inf):
+        for noisy in (True, False):
+            for sample in (True, False):
+                init = [t.copy() for t in o.MPSState.product(L, "x+").tensors]
+                init[1][0, 0, 0] = bad
+                kw = dict(elapsed_time=0.2, dt=0.1, max_bond_dim=4, svd_threshold=1e-9, order=1, sample_timesteps=sample, random_seed=1)
+                p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=2, **kw)
+                op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], **kw)
+
+                def run_engine():
+                    e = make_engine(L, 4, 2, mpo)
+                    try:
+                        TrajectoryBatch(e, p, noise if noisy else None).run([0, 1], MPS(L, tensors=init), native=native)
+                    finally:
+                        e.close()
+
+                want = outcome(lambda: o.run_trajectory(0, o.MPSState([x.copy() for x in init], 0), on if noisy else None, op, mpo))
+                got = outcome(run_engine)
+                assert want is not None, (bad, noisy, sample)
+                if want in (AssertionError, ValueError):
+                    assert got is want, (bad, noisy, sample, got, want)
+                else:  # nothing measured before the first sweep: the reference dies inside LAPACK's tridiagonal solver (LinAlgError)
+                    assert got in (AssertionError, ValueError), (bad, noisy, sample, got, want)
+    broken = [w.copy() for w in mpo]
+    broken[2][0, 1, 0, 0] = np.nan
+    e = make_engine(L, 4, 2, broken)
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=2, elapsed_time=0.2, dt=0.1, max_bond_dim=4, svd_threshold=1e-9,
+                        sample_timesteps=False, random_seed=1)
+    with pytest.raises((AssertionError, ValueError)):
+        TrajectoryBatch(e, p, noise).run([0, 1], MPS(L, state="x+"), native=native)
+    e.close()

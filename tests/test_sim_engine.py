@@ -56,6 +56,11 @@ def test_engine_case_on_the_simulated_device(on_sim, name):
     getattr(on_sim["test_hip_engine"], name)()
 
 
+@pytest.mark.parametrize("native", [False, True])
+def test_non_finite_inputs_on_the_simulated_device(on_sim, native):
+    on_sim["test_hip_engine"].test_non_finite_inputs_fail_loudly_like_the_reference(native)
+
+
 @pytest.mark.parametrize("d,L,chi,order", [(3, 5, 9, 1), (4, 4, 8, 2)])
 def test_qudit_chains_on_the_simulated_device(on_sim, d, L, chi, order):
     on_sim["test_hip_engine"].test_qutrit_and_four_level_chains_match_oracle(d, L, chi, order)

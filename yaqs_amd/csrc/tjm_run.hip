@@ -141,7 +141,7 @@ int measure(RunCtx& r, int set, int col) {
           re += o.x * m.x - o.y * m.y;
           im += o.x * m.y + o.y * m.x;
         }
-      if (im >= 1e-13) return TJM_ERR_ASSERT;  // "Measurement should be real" (mps.py:1233)
+      if (!(im < 1e-13)) return TJM_ERR_ASSERT;  // "assert exp.imag < 1e-13" (mps.py:1233): a NaN fails it too
       r.results[((size_t)b * r.c->n_obs + k) * r.cols + col] = re;
     }
   }

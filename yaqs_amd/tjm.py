@@ -230,8 +230,8 @@ class TrajectoryBatch:
                 val = np.einsum("pq,bpq->b", O, M2[site])   # <theta| O |theta> on the merged pair (mps.py:999-1047)
             else:
                 val = np.einsum("pq,bpq->b", O, M[site])
-            if np.any(val.imag >= 1e-13):
-                raise AssertionError(f"Measurement should be real, got max imag {val.imag.max():.3e}")  # mps.py:1233
+            if not np.all(val.imag < 1e-13):  # "assert exp.imag < 1e-13" (mps.py:1233): a non-finite value fails it too
+                raise AssertionError(f"Measurement should be real, got max imag {np.nanmax(val.imag) if not np.all(np.isnan(val.imag)) else np.nan:.3e}")
             results[:, row, col] = val.real
         diagnostics[:, :, col] = _diagnostics_from_bonds(e.bond_dims(set_index), e.d)
 
