@@ -37,7 +37,14 @@ def _write_if_changed(path: str, text: str) -> None:
         f.write(text)
 
 
-def build(verbose: bool = False) -> str:
+def build(verbose: bool = False, f32: bool = False) -> str:
+    """``f32``: the complex64 variant of the sources (-DTJM_F32, libtjm_sim_f32.so), objects in their own directory."""
+    if f32:
+        return _build(verbose, os.path.join(OUT, "f32"), os.path.join(OUT, "libtjm_sim_f32.so"), ["-DTJM_F32"])
+    return _build(verbose, OUT, LIB, [])
+
+
+def _build(verbose: bool, OUT: str, LIB: str, extra: list) -> str:
     csrc = os.path.join(OUT, "yaqs_amd", "csrc")
     os.makedirs(csrc, exist_ok=True)
     os.makedirs(os.path.join(OUT, "include"), exist_ok=True)
@@ -56,7 +63,7 @@ def build(verbose: bool = False) -> str:
     jobs = [(s, o) for s, o in units if not os.path.exists(o) or os.path.getmtime(o) < max(stamp, os.path.getmtime(s))]
     procs = []
     for src, obj in jobs:
-        cmd = [CXX] + FLAGS + (HOOKS if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
+        cmd = [CXX] + FLAGS + extra + (HOOKS if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -222,6 +222,22 @@ inline hipsim_d4 hipsim_mfma_f64_16x16x4(double a, double b, hipsim_d4 c, int, i
 }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) hipsim_mfma_f64_16x16x4(a, b, c, x, y, z)
 
+// v_mfma_f32_16x16x4_f32: same operand maps; result register v of lane l is D[4 (l >> 4) + v][l & 15] (the dtype-independent C/D map)
+typedef float hipsim_f4 __attribute__((ext_vector_type(4)));
+inline hipsim_f4 hipsim_mfma_f32_16x16x4(float a, float b, hipsim_f4 c, int, int, int) {
+  auto x = hipsim::exchange(hipsim::bits(a), hipsim::bits(b));
+  const int lane = hipsim::cur->lane, col = lane & 15, r0 = 4 * (lane >> 4);
+  hipsim_f4 d = c;
+  for (int v = 0; v < 4; ++v) {
+    const int row = r0 + v;
+    float acc = d[v];
+    for (int k = 0; k < 4; ++k) acc = std::fmaf(hipsim::unbits<float>(x[16 * k + row][0]), hipsim::unbits<float>(x[16 * k + col][1]), acc);
+    d[v] = acc;
+  }
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipsim_mfma_f32_16x16x4(a, b, c, x, y, z)
+
 // ---- scalar helpers ----------------------------------------------------------------------------------------------------------
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
@@ -234,6 +250,10 @@ inline double max(double a, double b) { return std::fmax(a, b); }
 inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 #define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))
 #define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))
+#define __builtin_amdgcn_rsqf(x) (1.0f / std::sqrt((float)(x)))
+#define __builtin_amdgcn_rcpf(x) (1.0f / (float)(x))
+inline int __float_as_int(float v) { return hipsim::unbits<int>(hipsim::bits(v)); }
+inline float __int_as_float(int v) { return hipsim::unbits<float>(hipsim::bits(v)); }
 inline int __double2loint(double v) { return (int)(unsigned)(hipsim::bits(v) & 0xffffffffull); }
 inline int __double2hiint(double v) { return (int)(unsigned)(hipsim::bits(v) >> 32); }
 inline double __hiloint2double(int hi, int lo) {
@@ -244,6 +264,14 @@ inline double __hiloint2double(int hi, int lo) {
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline float atomicAdd(float* p, float v) {
+  unsigned* q = reinterpret_cast<unsigned*>(p);
+  unsigned o = __atomic_load_n(q, __ATOMIC_RELAXED);
+  for (;;) {
+    const unsigned n = hipsim::unbits<unsigned>(hipsim::bits(hipsim::unbits<float>(o) + v));
+    if (__atomic_compare_exchange_n(q, &o, n, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return hipsim::unbits<float>(o);
+  }
+}
 inline double atomicAdd(double* p, double v) {
   unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
   unsigned long long o = __atomic_load_n(q, __ATOMIC_RELAXED);

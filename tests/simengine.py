@@ -19,21 +19,21 @@ sys.path.insert(0, os.path.join(HERE, "hipsim"))
 from yaqs_amd import _lib  # noqa: E402
 from yaqs_amd.engine import BatchEngine, _i32  # noqa: E402
 
-_sim = None
+_sim: dict = {}
 
 
-def load_sim() -> C.CDLL:
-    global _sim
-    if _sim is None:
+def load_sim(dtype: str = "complex128") -> C.CDLL:
+    """The simulated-device library of the fp64 build, or of the complex64 build (-DTJM_F32) for ``dtype="complex64"``."""
+    if dtype not in _sim:
         import build as hipsim_build  # tests/hipsim/build.py
 
-        lib = C.CDLL(hipsim_build.build())
+        lib = C.CDLL(hipsim_build.build(f32=(dtype == "complex64")))
         for name, (res, args) in _lib.EXPORTS.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        _sim = lib
-    return _sim
+        _sim[dtype] = lib
+    return _sim[dtype]
 
 
 class _NoStream:
@@ -46,9 +46,10 @@ class _NoStream:
 class SimEngine(BatchEngine):
     """Same methods as BatchEngine (they only use ``self.lib`` / ``self.h``); construction binds host memory instead of HBM."""
 
-    def __init__(self, length, chi_max, batch, mpo, device="cpu", d=2, stream=None, cap_slack=1):
+    def __init__(self, length, chi_max, batch, mpo, device="cpu", d=2, stream=None, cap_slack=1, dtype="complex128"):
         self.torch = None
-        self.lib = load_sim()
+        self.dtype = dtype
+        self.lib = load_sim(dtype)
         self.L, self.d, self.chi_max, self.B = int(length), int(d), int(chi_max), int(batch)
         self.device = device
         self.mpo_bonds = _i32([int(mpo[0].shape[2])] + [int(w.shape[3]) for w in mpo])
@@ -70,8 +71,8 @@ class SimEngine(BatchEngine):
         self.padded_elems = int(self.lib.tjm_engine_padded_state_elems(self.h))
 
     @staticmethod
-    def workspace_bytes_for(length, chi_max, batch, mpo, d=2, cap_slack=1):
-        lib = load_sim()
+    def workspace_bytes_for(length, chi_max, batch, mpo, d=2, cap_slack=1, dtype="complex128"):
+        lib = load_sim(dtype)
         bonds = _i32([int(mpo[0].shape[2])] + [int(w.shape[3]) for w in mpo])
         h = C.c_void_p()
         _lib.check(lib.tjm_engine_create_ex(C.byref(h), int(length), int(d), int(chi_max), int(batch), bonds.ctypes.data, int(cap_slack)), "create")

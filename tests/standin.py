@@ -37,7 +37,8 @@ class OracleEngine:
     # this stand-in can be compared with the REFERENCE's outputs; False: what the HIP engine computes (see tjm_engine.hip).
     reference_quirks = True
 
-    def __init__(self, length, chi_max, batch, mpo, device="cpu", d=2, stream=None, cap_slack=1):
+    def __init__(self, length, chi_max, batch, mpo, device="cpu", d=2, stream=None, cap_slack=1, dtype="complex128"):
+        self.dtype = "complex128"  # the oracle computes in the reference's precision whatever is asked for
         self.L, self.d, self.chi_max, self.B = int(length), int(d), int(chi_max), int(batch)
         self.mpo = [np.asarray(w, dtype=np.complex128) for w in mpo]
         exact = o.MPSState.bond_caps(self.L, 1 << 30)

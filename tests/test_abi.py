@@ -15,10 +15,12 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(tjm_[a-z0-9_]+)\s*\(", text)))
 
 
-def test_library_exports_every_declared_symbol():
+@pytest.mark.parametrize("dtype", ["complex128", "complex64"])
+def test_library_exports_every_declared_symbol(dtype):
+    """Both builds of the sources - libtjm_hip.so (fp64) and libtjm_hip_f32.so (complex64, -DTJM_F32) - export the whole C ABI."""
     from yaqs_amd import _lib
 
-    lib = _lib.load()
+    lib = _lib.load(dtype)
     names = header_symbols()
     assert len(names) >= 20
     for n in names:

@@ -56,6 +56,14 @@ def test_engine_case_on_the_simulated_device(on_sim, name):
     getattr(on_sim["test_hip_engine"], name)()
 
 
+def test_complex64_build_on_the_simulated_device(on_sim, monkeypatch):
+    """libtjm_hip_f32.so's sources (-DTJM_F32) on the simulated device: fp32-level agreement with the fp64 oracle, equal bonds; and
+    the ensemble comparison at a size an interpreter can afford."""
+    on_sim["test_hip_engine"].test_complex64_engine_tracks_the_fp64_oracle()
+    monkeypatch.setenv("TJM_F32_ENSEMBLE", "8")
+    on_sim["test_hip_engine"].test_complex64_ensemble_means_agree_with_the_fp64_ensemble()
+
+
 @pytest.mark.parametrize("native", [False, True])
 def test_non_finite_inputs_on_the_simulated_device(on_sim, native):
     on_sim["test_hip_engine"].test_non_finite_inputs_fail_loudly_like_the_reference(native)

@@ -10,6 +10,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtjm_hip.so")
+# the complex64 variant: the same sources and the same C ABI (host arrays stay complex128 / float64 and are converted at the boundary),
+# arithmetic and device storage in fp32 (yaqs_amd/csrc/tjm_common.h: -DTJM_F32)
+LIB_PATH_F32 = os.path.join(_HERE, "libtjm_hip_f32.so")
+DTYPES = ("complex128", "complex64")
 
 ERRORS = {
     -1: ValueError,
@@ -137,28 +141,35 @@ EXPORTS = {
 }
 
 _lib = None
+_libs: dict = {}
 
 
-def load() -> C.CDLL:
-    """Load libtjm_hip.so and attach signatures.  Raises if the library is not built."""
+def load(dtype: str = "complex128") -> C.CDLL:
+    """Load libtjm_hip.so (``dtype="complex128"``, the reference's precision) or libtjm_hip_f32.so (``"complex64"``) and attach
+    signatures.  Raises if the library is not built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if dtype not in DTYPES:
+        raise ValueError(f"dtype must be one of {DTYPES}, got {dtype!r}")
+    if dtype in _libs:
+        return _libs[dtype]
+    path = LIB_PATH if dtype == "complex128" else LIB_PATH_F32
+    if not os.path.exists(path):
         raise TjmError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C yaqs_amd/csrc).  yaqs_amd has no CPU fallback."
         )
     # PyTorch ships its own libamdhip64; load it FIRST so that this library binds to the same HIP runtime instance.  Loaded the
     # other way round, the process holds two runtimes and the second one reports "no ROCm-capable device is detected".
     import torch  # noqa: F401
 
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in EXPORTS.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[dtype] = lib
+    if dtype == "complex128":
+        _lib = lib
     return lib
 
 

@@ -120,11 +120,15 @@ int tjm_engine_set_noise(tjm_engine* e, int32_t nproc, const int32_t* nsites, co
     NoiseProc& p = v[k];
     std::memset(&p, 0, sizeof(p));
     p.nsites = nsites[k]; p.site0 = sites[2 * k]; p.site1 = sites[2 * k + 1]; p.gamma = gamma[k]; p.pauli = pauli[k];
-    std::memcpy(p.mat, mats + 2 * slot * (size_t)k, 2 * slot * sizeof(double));  // d^4 complex entries per process (16 for qubits)
+    for (size_t q = 0; q < slot; ++q)  // d^4 complex128 entries per process (16 for qubits)
+      p.mat[q] = cplx{(real)mats[2 * (slot * (size_t)k + q)], (real)mats[2 * (slot * (size_t)k + q) + 1]};
     p.has_factors = has_factors ? has_factors[k] : 0;
     if (p.has_factors && factors) {
-      std::memcpy(p.f0, factors + 4 * dd * (size_t)k, 2 * dd * sizeof(double));
-      std::memcpy(p.f1, factors + 4 * dd * (size_t)k + 2 * dd, 2 * dd * sizeof(double));
+      for (size_t q = 0; q < dd; ++q) {
+        const double* f = factors + 4 * dd * (size_t)k;
+        p.f0[q] = cplx{(real)f[2 * q], (real)f[2 * q + 1]};
+        p.f1[q] = cplx{(real)f[2 * dd + 2 * q], (real)f[2 * dd + 2 * q + 1]};
+      }
     }
     if (p.nsites == 2 && p.site1 - p.site0 > 1 && !p.has_factors) return TJM_ERR_ARG;
   }
@@ -416,7 +420,7 @@ static int svd_split_impl(bool use_qr, const void* theta, int32_t B, int32_t d, 
   s.left_b0 = (long)d * capL * capM; s.right_b0 = (long)d * capM * capR;
   s.distribution = distribution; s.trunc_mode = trunc_mode; s.threshold = threshold; s.max_bond = max_bond; s.min_keep = min_keep;
   s.chiL = chi_lrm; s.chiR = chi_lrm + 1; s.chiM = chi_lrm + 2; s.chi_stride = 3;
-  s.spectrum = spectrum; s.spec_ld = spec_ld; s.nb0 = B; s.ids = nullptr;
+  s.spectrum = reinterpret_cast<real*>(spectrum); s.spec_ld = spec_ld; s.nb0 = B; s.ids = nullptr;  // device array of the build's real type
   int sweeps = 0;
   const int rc = use_qr ? svd_split_qr(s, sw, qw, stream, &sweeps) : svd_split(s, sw, stream, &sweeps);
   if (sweeps_out) *sweeps_out = sweeps;
@@ -456,7 +460,8 @@ int tjm_profile_cross_kernel_read(double* total_ms, double* total_bytes, int64_t
 
 int tjm_tridiag_expm(const double* alpha, const double* beta, int32_t k, double dt, double* out, void* stream) {
   DeviceGuard guard(device_of(out));
-  return launch_tridiag_expm_test(alpha, beta, k, dt, out, static_cast<hipStream_t>(stream));
+  return launch_tridiag_expm_test(reinterpret_cast<const real*>(alpha), reinterpret_cast<const real*>(beta), k, dt, reinterpret_cast<real*>(out),
+                                  static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

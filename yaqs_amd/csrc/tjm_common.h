@@ -9,16 +9,48 @@
 
 namespace tjm {
 
+// Arithmetic type of the build.  libtjm_hip.so computes in fp64 / complex128, the reference's precision; the same sources compiled
+// with -DTJM_F32 give libtjm_hip_f32.so, the complex64 variant (same C ABI: host arrays stay complex128 / float64 and are converted
+// at the boundary).  Everything that depends on the type - the MFMA instruction and its result map, machine epsilon, the cross-lane
+// helpers for 32- / 64-bit payloads - is named here.
+#ifdef TJM_F32
+typedef float real;
+#define TJM_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+// v_mfma_f32_16x16x4_f32: register v of lane l is D[4 (l >> 4) + v][l & 15]
+#define TJM_ACC_ROW(lane, reg) (4 * ((lane) >> 4) + (reg))
+#define TJM_EPS 1.1920929e-7f
+#define TJM_TINY 1e-30f
+#define TJM_JACOBI_TOL2 4e-12f   // one-sided Jacobi: rotate while |<p,q>|^2 > tol2 |p|^2 |q|^2 (relative tolerance 2e-6)
+#define TJM_NOISE_FLOOR2 1e-12f  // columns below sqrt(floor2) ||X||_F are numerically null
+#define TJM_RANK_TOL 1e-5f       // a kept singular value below this fraction of the largest one: rank-deficient, complete the basis
+#define TJM_IMAG_TOL 1e-5        // "measurement should be real": the reference's 1e-13 (mps.py:1233) is an fp64 rounding bound
+#else
+typedef double real;
+#define TJM_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0)
+// v_mfma_f64_16x16x4_f64: register v of lane l is D[(l >> 4) + 4 v][l & 15]
+#define TJM_ACC_ROW(lane, reg) (((lane) >> 4) + 4 * (reg))
+#define TJM_EPS 2.220446049250313e-16
+#define TJM_TINY 1e-300
+#define TJM_JACOBI_TOL2 1e-26
+#define TJM_NOISE_FLOOR2 1e-26
+#define TJM_RANK_TOL 1e-11
+#define TJM_IMAG_TOL 1e-13
+#endif
+
 struct cplx {
+  real x, y;
+};
+// complex128 as the C ABI hands it over (host side only)
+struct zc {
   double x, y;
 };
 
-__host__ __device__ inline cplx cmake(double a, double b) { return cplx{a, b}; }
+__host__ __device__ inline cplx cmake(real a, real b) { return cplx{a, b}; }
 __host__ __device__ inline cplx cadd(cplx a, cplx b) { return cplx{a.x + b.x, a.y + b.y}; }
 __host__ __device__ inline cplx csub(cplx a, cplx b) { return cplx{a.x - b.x, a.y - b.y}; }
 __host__ __device__ inline cplx cmul(cplx a, cplx b) { return cplx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 __host__ __device__ inline cplx cconj(cplx a) { return cplx{a.x, -a.y}; }
-__host__ __device__ inline cplx cscale(cplx a, double s) { return cplx{a.x * s, a.y * s}; }
+__host__ __device__ inline cplx cscale(cplx a, real s) { return cplx{a.x * s, a.y * s}; }
 // acc += a*b
 __host__ __device__ inline void cfma(cplx& acc, cplx a, cplx b) {
   acc.x = fma(a.x, b.x, acc.x);
@@ -27,7 +59,33 @@ __host__ __device__ inline void cfma(cplx& acc, cplx a, cplx b) {
   acc.y = fma(a.y, b.x, acc.y);
 }
 
-typedef double d4 __attribute__((ext_vector_type(4)));
+typedef real real4 __attribute__((ext_vector_type(4)));
+
+// ---- cross-lane moves of one `real` (device only): DPP row operations, v_readlane, the gfx950 row / half-wave swaps ----------------
+#ifdef TJM_F32
+template <int CTRL>
+__device__ inline real tjm_dpp(real v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ inline real tjm_readlane(real v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ inline real tjm_xor16_sum(real v) {
+  const int w = __float_as_int(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+  return __int_as_float(a[0]) + __int_as_float(a[1]);
+}
+__device__ inline real tjm_xor32_sum(real v) {
+  const int w = __float_as_int(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __int_as_float(a[0]) + __int_as_float(a[1]);
+}
+__device__ inline real tjm_rsq(real x) { return __builtin_amdgcn_rsqf(x); }
+__device__ inline void tjm_sincos(real x, real* s, real* c) { sincosf(x, s, c); }
+__device__ inline real tjm_rcp(real x) { return __builtin_amdgcn_rcpf(x); }
+#else
+__device__ inline real tjm_rsq(real x) { return __builtin_amdgcn_rsq(x); }
+__device__ inline void tjm_sincos(real x, real* s, real* c) { sincos(x, s, c); }
+__device__ inline real tjm_rcp(real x) { return __builtin_amdgcn_rcp(x); }
+#endif
 
 // error codes: the TJM_* macros of the C ABI (include/tjm_hip.h)
 

@@ -156,10 +156,10 @@ class Engine {
   std::vector<cplx*> WenvL_;     // [(p,r),(o,l)] : left-env form
   std::vector<cplx*> W2_;        // merged two-site [(o o', l),(p p', r)]
   std::vector<std::vector<cplx>> Whost_;
-  double *part1_ = nullptr, *part2_ = nullptr;
+  real *part1_ = nullptr, *part2_ = nullptr;
   int* nloc_ = nullptr;
-  double* scal_ = nullptr;       // [B] scratch scalars
-  double* normsq_ = nullptr;     // [B]
+  real* scal_ = nullptr;         // [B] scratch scalars
+  real* normsq_ = nullptr;       // [B]
   int* ids_ = nullptr;           // [B] compacted trajectory list
   int* opidx_ = nullptr;         // [B]
   int* jsite_ = nullptr;         // [B]

@@ -18,19 +18,38 @@ namespace tjm {
 
 namespace {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+// The C ABI speaks float64 / complex128 whatever the build computes in (tjm_common.h: real): conversions at the host boundary.
+inline void from_host_c(cplx* dst, const double* src, size_t n) {
+  for (size_t i = 0; i < n; ++i) dst[i] = cplx{(real)src[2 * i], (real)src[2 * i + 1]};
+}
+inline void to_host_c(double* dst, const cplx* src, size_t n) {
+  for (size_t i = 0; i < n; ++i) { dst[2 * i] = src[i].x; dst[2 * i + 1] = src[i].y; }
+}
+// n complex128 numbers of the caller into device memory
+int upload_c(cplx* dev, const double* host, size_t n, hipStream_t s) {
+#ifdef TJM_F32
+  std::vector<cplx> tmp(n);
+  from_host_c(tmp.data(), host, n);
+  TJM_HIP_CHECK(hipMemcpyAsync(dev, tmp.data(), n * sizeof(cplx), hipMemcpyHostToDevice, s));
+  TJM_HIP_CHECK(hipStreamSynchronize(s));  // the staging buffer goes out of scope
+#else
+  TJM_HIP_CHECK(hipMemcpyAsync(dev, host, n * sizeof(cplx), hipMemcpyHostToDevice, s));
+#endif
+  return TJM_OK;
+}
 inline int round16(int x) { return (x + 15) / 16 * 16; }
 
 // dense expm for tiny matrices (<= 16 x 16: a pair of four-level sites) by scaling and squaring + Taylor
 void small_expm(const cplx* in, int n, cplx* out) {
   double nrm = 0.0;
-  for (int i = 0; i < n * n; ++i) nrm = std::max(nrm, std::hypot(in[i].x, in[i].y));
+  for (int i = 0; i < n * n; ++i) nrm = std::max(nrm, (double)std::hypot(in[i].x, in[i].y));
   int s = 0;
   while (nrm > 0.25) { nrm *= 0.5; ++s; }
   const double sc = std::ldexp(1.0, -s);
   cplx a[MSLOT], term[MSLOT], res[MSLOT], tmp[MSLOT];
   for (int i = 0; i < n * n; ++i) {
     a[i] = cscale(in[i], sc);
-    term[i] = cplx{(i / n == i % n) ? 1.0 : 0.0, 0.0};
+    term[i] = cplx{(i / n == i % n) ? real(1) : real(0), 0.0};
     res[i] = term[i];
   }
   for (int k = 1; k <= 24; ++k) {
@@ -209,20 +228,20 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
     char* qbase = take(qr_workspace_bytes(md, B));
     qr_carve(qrw, qbase, md, B);
   }
-  part1_ = reinterpret_cast<double*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));
-  part2_ = reinterpret_cast<double*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));
+  part1_ = reinterpret_cast<real*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));
+  part2_ = reinterpret_cast<real*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));
   ks.mmax = mmax;
-  ks.alpha = reinterpret_cast<double*>(take((size_t)B * mmax * sizeof(double)));
-  ks.beta = reinterpret_cast<double*>(take((size_t)B * mmax * sizeof(double)));
+  ks.alpha = reinterpret_cast<real*>(take((size_t)B * mmax * sizeof(double)));
+  ks.beta = reinterpret_cast<real*>(take((size_t)B * mmax * sizeof(double)));
   ks.coef = reinterpret_cast<cplx*>(take((size_t)B * mmax * sizeof(cplx)));
-  ks.vnorm = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
-  ks.scale = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
+  ks.vnorm = reinterpret_cast<real*>(take((size_t)B * sizeof(double)));
+  ks.scale = reinterpret_cast<real*>(take((size_t)B * sizeof(double)));
   ks.status = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   ks.kfinal = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   ks.n_active = reinterpret_cast<int*>(take(256));
   nloc_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
-  scal_ = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
-  normsq_ = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
+  scal_ = reinterpret_cast<real*>(take((size_t)B * sizeof(double)));
+  normsq_ = reinterpret_cast<real*>(take((size_t)B * sizeof(double)));
   ids_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   opidx_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   jsite_ = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
@@ -282,11 +301,12 @@ int Engine::run_sweep(int set, const std::vector<SmallSweepStep>& steps, const i
 int Engine::set_mpo(const double* host) {
   if (!bound_) return TJM_ERR_STATE;
   Whost_.assign(L, {});
-  const cplx* src = reinterpret_cast<const cplx*>(host);
+  const double* src = host;
   for (int i = 0; i < L; ++i) {
     const int Dl = Dm[i], Dr = Dm[i + 1];
-    Whost_[i].assign(src, src + (size_t)d * d * Dl * Dr);  // (o,p,l,r)
-    src += (size_t)d * d * Dl * Dr;
+    Whost_[i].resize((size_t)d * d * Dl * Dr);  // (o,p,l,r)
+    from_host_c(Whost_[i].data(), src, Whost_[i].size());
+    src += 2 * Whost_[i].size();
   }
   auto W4 = [&](int i, int o, int p, int l, int r) { return Whost_[i][(((size_t)o * d + p) * Dm[i] + l) * Dm[i + 1] + r]; };
   for (int i = 0; i < L; ++i) {
@@ -338,7 +358,7 @@ int Engine::set_noise(const std::vector<NoiseProc>& procs) {
 int Engine::load_state(int set, const double* host, const int* bonds) {
   if (!bound_ || set < 0 || set > 1) return TJM_ERR_STATE;
   StateSet& S = sets[set];
-  const cplx* src = reinterpret_cast<const cplx*>(host);
+  const double* src = host;  // complex128: (re, im) pairs
   std::vector<int> chi((size_t)B * (L + 1));
   for (int b = 0; b < B; ++b) for (int k = 0; k <= L; ++k) chi[(size_t)b * (L + 1) + k] = bonds[k];
   for (int k = 0; k <= L; ++k) if (bonds[k] > cap[k] || bonds[k] < 1) return TJM_ERR_ARG;
@@ -346,9 +366,11 @@ int Engine::load_state(int set, const double* host, const int* bonds) {
   for (int i = 0; i < L; ++i) {
     const int cl = bonds[i], cr = bonds[i + 1];
     std::vector<cplx> pad((size_t)a_b0_[i], cplx{0.0, 0.0});
-    for (int p = 0; p < d; ++p) for (int a = 0; a < cl; ++a) for (int c = 0; c < cr; ++c)
-      pad[((size_t)p * cap[i] + a) * cap[i + 1] + c] = src[((size_t)p * cl + a) * cr + c];
-    src += (size_t)d * cl * cr;
+    for (int p = 0; p < d; ++p) for (int a = 0; a < cl; ++a) for (int c = 0; c < cr; ++c) {
+      const double* z = src + 2 * (((size_t)p * cl + a) * cr + c);
+      pad[((size_t)p * cap[i] + a) * cap[i + 1] + c] = cplx{(real)z[0], (real)z[1]};
+    }
+    src += 2 * (size_t)d * cl * cr;
     // first slot from host, the others by device copies
     TJM_HIP_CHECK(hipMemcpyAsync(S.A[i], pad.data(), pad.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
     TJM_HIP_CHECK(hipStreamSynchronize(stream));
@@ -407,12 +429,16 @@ int Engine::export_state(int set, int b, double* out, int* bonds) {
   if (!bound_ || b < 0 || b >= B) return TJM_ERR_ARG;
   StateSet& S = sets[set];
   TJM_HIP_CHECK(hipMemcpyAsync(bonds, S.chi + (size_t)b * (L + 1), (L + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
-  cplx* dst = reinterpret_cast<cplx*>(out);
+  size_t total = 0;
+  for (int i = 0; i < L; ++i) total += (size_t)a_b0_[i];
+  std::vector<cplx> buf(total);
+  cplx* dst = buf.data();
   for (int i = 0; i < L; ++i) {
     TJM_HIP_CHECK(hipMemcpyAsync(dst, S.A[i] + (size_t)b * a_b0_[i], (size_t)a_b0_[i] * sizeof(cplx), hipMemcpyDeviceToHost, stream));
     dst += a_b0_[i];
   }
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  to_host_c(out, buf.data(), buf.size());
   return TJM_OK;
 }
 
@@ -813,7 +839,7 @@ __global__ __launch_bounds__(256) void z_identity_kernel(cplx* __restrict__ Z, l
   cplx* Zb = Z + (long)b * z_b0;
   const long total = (long)zr * nc;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
-    Zb[e] = cplx{(e / zr == e % zr) ? 1.0 : 0.0, 0.0};
+    Zb[e] = cplx{(e / zr == e % zr) ? real(1) : real(0), 0.0};
 }
 
 // new bond dimension after the thin QR (np.linalg.qr reduced: k = min(rows, cols)), and vec.size of the bond problem
@@ -1094,13 +1120,13 @@ int Engine::copy_back(cplx* dst, long dst_b0, const cplx* src, long src_b0, long
 }
 
 // x *= s (uniform scalar over the batch)
-__global__ void fill_kernel(double* p, double v, int n) {
+__global__ void fill_kernel(real* p, real v, int n) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) p[t] = v;
 }
-__global__ void rsqrt_kernel(const double* in, double* out, int n) {
+__global__ void rsqrt_kernel(const real* in, real* out, int n) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) out[t] = (in[t] > 0.0) ? 1.0 / sqrt(in[t]) : 0.0;
+  if (t < n) out[t] = (in[t] > 0.0) ? real(1.0 / sqrt(in[t])) : real(0);
 }
 
 int Engine::set_noise_filter(int n, const int* idx) {
@@ -1170,7 +1196,7 @@ int Engine::normalize_qr(int set, int center) {
 int Engine::apply_single(int set, int site, const double* host_mat) {
   if (!bound_ || site < 0 || site >= L) return TJM_ERR_ARG;
   StateSet& S = sets[set];
-  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 2) * d * d * d * d, host_mat, (size_t)d * d * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  if (int rcu = upload_c(ops_ + (size_t)(L + 2) * d * d * d * d, host_mat, (size_t)d * d, stream)) return rcu;
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
   return launch_apply_local(S.A[site], a_b0_[site], d, (long)cap[site] * cap[site + 1], ops_ + (size_t)(L + 2) * d * d * d * d, nullptr, B, nullptr, stream);
 }
@@ -1208,7 +1234,7 @@ int Engine::tebd_gate(int set, int left, const double* host_u, int center) {
   // shift_center_to(left) unless the centre already sits on the pair (digital_tjm.py:503-506); QR shifts only move the gauge
   if (center < left || center > left + 1)
     if ((rc = qr_walk(set, center, left)) != TJM_OK) return rc;
-  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 4) * d * d * d * d, host_u, (size_t)d * d * d * d * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  if (int rcu = upload_c(ops_ + (size_t)(L + 4) * d * d * d * d, host_u, (size_t)d * d * d * d, stream)) return rcu;
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
   const int mk = (max_bond > 0) ? std::min(2, max_bond) : 2;
   return two_site_op(S, left, ops_ + (size_t)(L + 4) * d * d * d * d, nullptr, nullptr, B, mk);
@@ -1219,7 +1245,7 @@ int Engine::tebd_gate(int set, int left, const double* host_u, int center) {
 int Engine::apply_pair(int set, int left, const double* host_u, int min_keep) {
   if (!bound_ || left < 0 || left + 1 >= L || !host_u || min_keep < 1) return TJM_ERR_ARG;
   StateSet& S = sets[set];
-  TJM_HIP_CHECK(hipMemcpyAsync(ops_ + (size_t)(L + 4) * d * d * d * d, host_u, (size_t)d * d * d * d * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  if (int rcu = upload_c(ops_ + (size_t)(L + 4) * d * d * d * d, host_u, (size_t)d * d * d * d, stream)) return rcu;
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
   return two_site_op(S, left, ops_ + (size_t)(L + 4) * d * d * d * d, nullptr, nullptr, B, min_keep);
 }
@@ -1378,8 +1404,10 @@ int Engine::site_normsq0(int set, double* host_out) {
   StateSet& S = sets[set];
   int rc;
   if ((rc = launch_normsq(S.A[0], a_b0_[0], a_b0_[0], normsq_, B, nullptr, stream)) != TJM_OK) return rc;
-  TJM_HIP_CHECK(hipMemcpyAsync(host_out, normsq_, B * sizeof(double), hipMemcpyDeviceToHost, stream));
+  std::vector<real> h(B);
+  TJM_HIP_CHECK(hipMemcpyAsync(h.data(), normsq_, B * sizeof(real), hipMemcpyDeviceToHost, stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  for (int b = 0; b < B; ++b) host_out[b] = h[b];
   return TJM_OK;
 }
 
@@ -1422,7 +1450,7 @@ __global__ __launch_bounds__(256) void shot_select_kernel(const cplx* __restrict
   for (int c = lane; c < cb; c += 64) {
     const cplx a = t0[c], q = t1[c];
     const cplx r = pick ? cadd(cmul(rot10, a), cmul(rot11, q)) : cadd(cmul(rot00, a), cmul(rot01, q));
-    vo[c] = cplx{r.x * inv, r.y * inv};
+    vo[c] = cplx{real(r.x * inv), real(r.y * inv)};
   }
   if (lane == 0) bits[(long)b * bits_b0 + (long)sidx * L + site] = (unsigned char)pick;
 }
@@ -1438,10 +1466,11 @@ int Engine::sample_shots(int set, int shots, const double* host_rot, const doubl
   StateSet& S = sets[set];
   const int cm = *std::max_element(cap.begin(), cap.end());
   // buffers inside the Krylov basis area: Vec [S][cm] and T [d][S][cm] per trajectory, uniforms and bits behind them
-  const long per_shot = (long)(1 + d) * cm + (L * (long)sizeof(double) + L + 15) / 16 + 1;
+  const long per_shot = (long)(1 + d) * cm + (L * (long)sizeof(double) + L + (long)sizeof(cplx) - 1) / (long)sizeof(cplx) + 1;
   const long s_max = v_b0 / per_shot;
   if (s_max < 1) return TJM_ERR_WORKSPACE;
-  const cplx* rot = reinterpret_cast<const cplx*>(host_rot);
+  cplx rot[4];
+  from_host_c(rot, host_rot, 4);
   int rc;
   for (int s0 = 0; s0 < shots; s0 += (int)s_max) {
     const int ns = (int)std::min<long>(s_max, shots - s0);
@@ -1485,7 +1514,7 @@ int Engine::bond_spectrum(int set, int i, double* host_spec, int n_out) {
   if ((rc = merge_matrix_layout(S, i, nullptr, B)) != TJM_OK) return rc;
   const int m = d * cap[i], n = d * cap[i + 2];
   const int nsv = std::min(m, n);
-  double* dspec = reinterpret_cast<double*>(T2);
+  real* dspec = reinterpret_cast<real*>(T2);
   int* dchi = reinterpret_cast<int*>(reinterpret_cast<char*>(T2) + align_up((size_t)B * nsv * sizeof(double)));
   TJM_HIP_CHECK(hipMemcpyAsync(dchi, S.chi, (size_t)B * (L + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
   SvdSplitDesc sd;
@@ -1498,8 +1527,8 @@ int Engine::bond_spectrum(int set, int i, double* host_spec, int n_out) {
   sd.spectrum = dspec; sd.spec_ld = nsv; sd.nb0 = B; sd.ids = nullptr;
   int sweeps = 0;
   if ((rc = (std::max(m, n) > 512 ? svd_split_qr(sd, svdw, qrw, stream, &sweeps) : svd_split(sd, svdw, stream, &sweeps))) != TJM_OK) return rc;
-  std::vector<double> h((size_t)B * nsv);
-  TJM_HIP_CHECK(hipMemcpyAsync(h.data(), dspec, h.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+  std::vector<real> h((size_t)B * nsv);
+  TJM_HIP_CHECK(hipMemcpyAsync(h.data(), dspec, h.size() * sizeof(real), hipMemcpyDeviceToHost, stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
   for (int b = 0; b < B; ++b)
     for (int k = 0; k < n_out; ++k) host_spec[(size_t)b * n_out + k] = (k < nsv) ? h[(size_t)b * nsv + k] : 0.0;
@@ -1585,10 +1614,13 @@ int Engine::site_moments(int set, double* host_M, double* host_M2) {
       std::swap(E, En);
     }
   }
-  TJM_HIP_CHECK(hipMemcpyAsync(host_M, M_, (size_t)L * B * d * d * sizeof(cplx), hipMemcpyDeviceToHost, stream));
+  std::vector<cplx> hm((size_t)L * B * d * d), hm2(host_M2 ? (size_t)(L - 1) * B * d * d * d * d : 0);
+  TJM_HIP_CHECK(hipMemcpyAsync(hm.data(), M_, hm.size() * sizeof(cplx), hipMemcpyDeviceToHost, stream));
   if (host_M2)
-    TJM_HIP_CHECK(hipMemcpyAsync(host_M2, M2_, (size_t)(L - 1) * B * d * d * d * d * sizeof(cplx), hipMemcpyDeviceToHost, stream));
+    TJM_HIP_CHECK(hipMemcpyAsync(hm2.data(), M2_, hm2.size() * sizeof(cplx), hipMemcpyDeviceToHost, stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  to_host_c(host_M, hm.data(), hm.size());
+  if (host_M2) to_host_c(host_M2, hm2.data(), hm2.size());
   return TJM_OK;
 }
 
@@ -1679,7 +1711,7 @@ int Engine::jump_weights(int set, double dt_, const std::vector<double>& nsq, co
       need_moments2 = true;
     }
   }
-  std::vector<cplx> Mh, Mh2;
+  std::vector<zc> Mh, Mh2;  // complex128, as site_moments hands them to the host
   if (need_moments || need_moments2) {
     Mh.resize((size_t)L * B * d * d);
     if (need_moments2) Mh2.resize((size_t)(L - 1) * B * d * d * d * d);
@@ -1697,7 +1729,7 @@ int Engine::jump_weights(int set, double dt_, const std::vector<double>& nsq, co
       } else if (p.nsites == 2) {
         // adjacent non-Pauli: Frobenius weight of the untruncated L theta (stochastic_process.py:53-83)
         const int dd = d * d;
-        const cplx* M2 = &Mh2[((size_t)p.site0 * B + b) * dd * dd];
+        const zc* M2 = &Mh2[((size_t)p.site0 * B + b) * dd * dd];
         double acc = 0.0;
         for (int a = 0; a < dd; ++a) for (int c2 = 0; c2 < dd; ++c2) {
           cplx ll{0.0, 0.0};
@@ -1707,7 +1739,7 @@ int Engine::jump_weights(int set, double dt_, const std::vector<double>& nsq, co
         nrm = acc;
       } else {
         // ||L psi||^2 = sum_{p,q} (L^dag L)[p][q] M[p][q]
-        const cplx* M = &Mh[((size_t)p.site0 * B + b) * d * d];
+        const zc* M = &Mh[((size_t)p.site0 * B + b) * d * d];
         double acc = 0.0;
         for (int a = 0; a < d; ++a) for (int c2 = 0; c2 < d; ++c2) {
           cplx ll{0.0, 0.0};
@@ -1751,7 +1783,11 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
     if (host_jumped) host_jumped[b] = jump ? 1 : 0;
   }
   // no-jump branch: QR at site 0 with R discarded (mps.py:736-746)
-  TJM_HIP_CHECK(hipMemcpyAsync(scal_, scale.data(), B * sizeof(double), hipMemcpyHostToDevice, stream));
+  {
+    std::vector<real> sc(scale.begin(), scale.end());
+    TJM_HIP_CHECK(hipMemcpyAsync(scal_, sc.data(), B * sizeof(real), hipMemcpyHostToDevice, stream));
+    TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  }
   if ((rc = launch_scale(S.A[0], a_b0_[0], a_b0_[0], scal_, B, nullptr, nullptr, stream)) != TJM_OK) return rc;
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
   if (jumped.empty()) return TJM_OK;
@@ -1926,10 +1962,10 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
 // ------------------------------------------------------------------------------------------
 int Engine::upload_w(const double* host_w, int P, int Dl, int Dr, cplx** mv, cplx** envl) {
   if (!bound_ || !host_w || P < 1 || P > d * d || Dl < 1 || Dr < 1 || Dl > Dmax || Dr > Dmax) return TJM_ERR_ARG;
-  const cplx* w = reinterpret_cast<const cplx*>(host_w);
   std::vector<cplx> a((size_t)P * Dl * P * Dr), b((size_t)P * Dr * P * Dl);
   for (int o = 0; o < P; ++o) for (int p = 0; p < P; ++p) for (int l = 0; l < Dl; ++l) for (int r = 0; r < Dr; ++r) {
-    const cplx v = w[(((size_t)o * P + p) * Dl + l) * Dr + r];
+    const double* z = host_w + 2 * ((((size_t)o * P + p) * Dl + l) * Dr + r);
+    const cplx v{(real)z[0], (real)z[1]};
     a[(size_t)(o * Dl + l) * (P * Dr) + (p * Dr + r)] = v;
     b[(size_t)(p * Dr + r) * (P * Dl) + (o * Dl + l)] = v;
   }
@@ -2218,8 +2254,8 @@ int Engine::apply_gate_mpo(int set, int first, int last, int r, const double* ho
   StateSet& S = sets[set];
   const size_t dd = (size_t)d * d;
   cplx* tab = ops_ + (size_t)(L + 8) * dd * dd;  // behind the slots of apply_single / tebd_gate
-  TJM_HIP_CHECK(hipMemcpyAsync(tab, host_left, (size_t)r * dd * sizeof(cplx), hipMemcpyHostToDevice, stream));
-  TJM_HIP_CHECK(hipMemcpyAsync(tab + (size_t)r * dd, host_right, (size_t)r * dd * sizeof(cplx), hipMemcpyHostToDevice, stream));
+  if (int rcu = upload_c(tab, host_left, (size_t)r * dd, stream)) return rcu;
+  if (int rcu = upload_c(tab + (size_t)r * dd, host_right, (size_t)r * dd, stream)) return rcu;
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
   int rc;
   for (int k = first; k <= last; ++k) {
@@ -2300,7 +2336,7 @@ __global__ void bond_identity_kernel(cplx* M, long m_b0, int n, int B) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < (long)B * n * n) {
     const long r = t % ((long)n * n);
-    M[(t / ((long)n * n)) * m_b0 + r] = cplx{(r / n == r % n) ? 1.0 : 0.0, 0.0};
+    M[(t / ((long)n * n)) * m_b0 + r] = cplx{(r / n == r % n) ? real(1) : real(0), 0.0};
   }
 }
 }  // namespace

@@ -25,10 +25,10 @@ constexpr int PITCH = 80;  // doubles per k-row in LDS (64 + 16: second k-group 
 
 template <bool A_MCONTIG, bool B_NCONTIG>
 __global__ __launch_bounds__(256, 3) void zgemm_kernel(GemmDesc g) {
-  __shared__ double sAr[BK * PITCH];
-  __shared__ double sAi[BK * PITCH];
-  __shared__ double sBr[BK * PITCH];
-  __shared__ double sBi[BK * PITCH];
+  __shared__ real sAr[BK * PITCH];
+  __shared__ real sAi[BK * PITCH];
+  __shared__ real sBr[BK * PITCH];
+  __shared__ real sBi[BK * PITCH];
 
   int z = blockIdx.z;
   const int b2 = z % g.nb2;
@@ -63,15 +63,15 @@ __global__ __launch_bounds__(256, 3) void zgemm_kernel(GemmDesc g) {
 
   // two accumulators per MFMA tile: Re = Ar Br + (-Ai') Bi' and Im = Ar Bi' + Ai' Br, where the primes carry the conjugation
   // signs (applied once, when the tile is stored to LDS) and the negation is a sign-bit flip of the register operand
-  d4 accRe[2][2], accIm[2][2];
+  real4 accRe[2][2], accIm[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      accRe[i][j] = d4{0, 0, 0, 0};
-      accIm[i][j] = d4{0, 0, 0, 0};
+      accRe[i][j] = real4{0, 0, 0, 0};
+      accIm[i][j] = real4{0, 0, 0, 0};
     }
-  const double sgnA = g.conjA ? -1.0 : 1.0, sgnB = g.conjB ? -1.0 : 1.0;
+  const real sgnA = g.conjA ? -1.0 : 1.0, sgnB = g.conjB ? -1.0 : 1.0;
 
   const int ktiles = (g.K + BK - 1) / BK;
   const int total = ktiles * g.nks;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 3) void zgemm_kernel(GemmDesc g) {
       const int krow = (4 * s + lk) * PITCH;
       const int la = A_MCONTIG ? li : (li ^ swz(4 * s + lk));
       const int lb = B_NCONTIG ? li : (li ^ swz(4 * s + lk));
-      double ar[2], ai[2], br[2], bi[2];
+      real ar[2], ai[2], br[2], bi[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         ar[i] = sAr[krow + wm + 16 * i + la];
@@ -132,19 +132,19 @@ __global__ __launch_bounds__(256, 3) void zgemm_kernel(GemmDesc g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) accRe[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], br[j], accRe[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) accRe[i][j] = TJM_MFMA(ar[i], br[j], accRe[i][j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) accIm[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], bi[j], accIm[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) accIm[i][j] = TJM_MFMA(ar[i], bi[j], accIm[i][j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) accRe[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai[i], bi[j], accRe[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) accRe[i][j] = TJM_MFMA(-ai[i], bi[j], accRe[i][j]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) accIm[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i], br[j], accIm[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) accIm[i][j] = TJM_MFMA(ai[i], br[j], accIm[i][j]);
     }
   }
 
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 3) void zgemm_kernel(GemmDesc g) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int m = m0 + wm + 16 * i + lk + 4 * r;
+        int m = m0 + wm + 16 * i + TJM_ACC_ROW(lane, r);
         int n = n0 + wn + 16 * j + li;
         if (m < g.M && n < g.N) {
           cplx v;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void zgemm_small_kernel(GemmDesc g, int tiles_
   const int li = lane & 15, lk = lane >> 4;
   const int m = m0 + li, n = n0 + li;
   const bool mok = m < g.M, nok = n < g.N;
-  const double sgnA = g.conjA ? -1.0 : 1.0, sgnB = g.conjB ? -1.0 : 1.0;
+  const real sgnA = g.conjA ? -1.0 : 1.0, sgnB = g.conjB ? -1.0 : 1.0;
   const int ksteps = (g.K + 3) / 4;
   const int total = ksteps * g.nks;
   auto fetch = [&](int it, cplx& a, cplx& b) {
@@ -205,22 +205,22 @@ __global__ __launch_bounds__(256) void zgemm_small_kernel(GemmDesc g, int tiles_
     a = (mok && kok) ? Ab[(long)ks * g.a_ks + (long)m * g.a_rs + (long)k * g.a_cs] : cplx{0.0, 0.0};
     b = (nok && kok) ? Bb[(long)ks * g.b_ks + (long)k * g.b_rs + (long)n * g.b_cs] : cplx{0.0, 0.0};
   };
-  d4 accRe = d4{0, 0, 0, 0}, accIm = d4{0, 0, 0, 0};
+  real4 accRe = real4{0, 0, 0, 0}, accIm = real4{0, 0, 0, 0};
   cplx a, b, an, bn;
   fetch(0, a, b);
   for (int it = 0; it < total; ++it) {
     if (it + 1 < total) fetch(it + 1, an, bn);
-    const double ai = sgnA * a.y, bi = sgnB * b.y;
-    accRe = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, accRe, 0, 0, 0);
-    accIm = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bi, accIm, 0, 0, 0);
-    accRe = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai, bi, accRe, 0, 0, 0);
-    accIm = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, b.x, accIm, 0, 0, 0);
+    const real ai = sgnA * a.y, bi = sgnB * b.y;
+    accRe = TJM_MFMA(a.x, b.x, accRe);
+    accIm = TJM_MFMA(a.x, bi, accIm);
+    accRe = TJM_MFMA(-ai, bi, accRe);
+    accIm = TJM_MFMA(ai, b.x, accIm);
     a = an;
     b = bn;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int mm = m0 + lk + 4 * r;
+    const int mm = m0 + TJM_ACC_ROW(lane, r);
     if (mm < g.M && nok) {
       cplx v;
       v.x = accRe[r];

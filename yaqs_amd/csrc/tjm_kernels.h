@@ -23,11 +23,11 @@ int launch_mpo_apply(const MpoApplyDesc& d, hipStream_t stream);
 
 // Per-trajectory Krylov bookkeeping (device arrays, indexed by trajectory slot).
 struct KrylovState {
-  double* alpha;   // [B][mmax]
-  double* beta;    // [B][mmax]
+  real* alpha;   // [B][mmax]
+  real* beta;    // [B][mmax]
   cplx* coef;      // [B][mmax]
-  double* vnorm;   // [B]
-  double* scale;   // [B]  1/beta_j (or 1/|v|)
+  real* vnorm;   // [B]
+  real* scale;   // [B]  1/beta_j (or 1/|v|)
   int* status;     // [B]  1 = still iterating, 0 = finished
   int* kfinal;     // [B]
   int* n_active;   // [1]
@@ -43,7 +43,7 @@ struct SmallKrylovDesc {
   const cplx* Lenv; long l_b0; int Dl;   // L[(a,l)][A]
   const cplx* Renv; long r_b0; int Dr;   // R[b][(r,B)]
   const cplx* Wm;             // [(o,l)][(p,r)] row-major
-  double dt, tol;
+  real dt, tol;
   const int* nloc;            // actual local dimension per trajectory (breakdown threshold)
   int mmax;
   cplx* out; long out_b0;
@@ -55,21 +55,21 @@ struct SmallKrylovDesc {
 bool krylov_small_fits(int P, int ca, int cb, int Dl, int Dr, int mmax, int nb0);
 int launch_krylov_site_small(const SmallKrylovDesc& p, hipStream_t s);
 
-int launch_normsq_partial(const cplx* x, long x_b0, int n, double* part, int nb0, const int* ids, const int* active,
+int launch_normsq_partial(const cplx* x, long x_b0, int n, real* part, int nb0, const int* ids, const int* active,
                           hipStream_t s, int* nblk_out);
-int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n, double* part, int nb0, const int* ids,
+int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n, real* part, int nb0, const int* ids,
                        const int* active, hipStream_t s, int* nblk_out);
-int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, int n, const double* part1, double* part2,
-                        int nblk, const double* beta, int beta_ld, int j, int nb0, const int* ids, const int* active,
+int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, int n, const real* part1, real* part2,
+                        int nblk, const real* beta, int beta_ld, int j, int nb0, const int* ids, const int* active,
                         hipStream_t s);
-int launch_scale(cplx* x, long x_b0, long n, const double* scale, int nb0, const int* ids, const int* active, hipStream_t s);
-int launch_lanczos_init(const KrylovState& ks, const double* part, int nblk, int nb0, const int* ids, hipStream_t s);
-int launch_lanczos_finalize(const KrylovState& ks, const double* part1, const double* part2, int nblk, int j, double dt,
-                            double tol, const int* nloc, int nb0, const int* ids, hipStream_t s);
+int launch_scale(cplx* x, long x_b0, long n, const real* scale, int nb0, const int* ids, const int* active, hipStream_t s);
+int launch_lanczos_init(const KrylovState& ks, const real* part, int nblk, int nb0, const int* ids, hipStream_t s);
+int launch_lanczos_finalize(const KrylovState& ks, const real* part1, const real* part2, int nblk, int j, real dt,
+                            real tol, const int* nloc, int nb0, const int* ids, hipStream_t s);
 int launch_krylov_combine(const cplx* V, long v_b0, long v_ld, const KrylovState& ks, cplx* out, long out_b0, int n0, int n1,
                           int n2, int n3, long o0, long o1, long o2, int nb0, const int* ids, hipStream_t s);
-int launch_tridiag_expm_test(const double* alpha, const double* beta, int k, double dt, double* out, hipStream_t s);
-int launch_normsq(const cplx* x, long x_b0, long n, double* out, int nb0, const int* ids, hipStream_t s);
+int launch_tridiag_expm_test(const real* alpha, const real* beta, int k, real dt, real* out, hipStream_t s);
+int launch_normsq(const cplx* x, long x_b0, long n, real* out, int nb0, const int* ids, hipStream_t s);
 int launch_apply_local(cplx* x, long x_b0, int d, long rest, const cplx* ops, const int* op_index, int nb0, const int* ids,
                        hipStream_t s);
 int launch_identity_env(cplx* E, long e_b0, int n, int D, int nb0, hipStream_t s);
@@ -92,7 +92,7 @@ struct SvdSplitDesc {
   long left_b0, right_b0;
   int distribution;    // 0 = "right" (left isometric), 1 = "left" (right isometric), 2 = "sqrt" (plain split only)
   int trunc_mode;      // 0 discarded_weight, 1 relative, 2 hard_cutoff, 3 relative_discarded_weight
-  double threshold;
+  real threshold;
   int max_bond;        // <= 0: none
   int min_keep;
   int* overflow = nullptr;  // device flag: set when the truncation rule wanted more than capM values (may be null)
@@ -100,7 +100,7 @@ struct SvdSplitDesc {
   const int* chiR;
   int* chiM;           // out: new middle bond
   int chi_stride;
-  double* spectrum;    // optional out [B][spec_ld] singular values (descending), may be null
+  real* spectrum;    // optional out [B][spec_ld] singular values (descending), may be null
   int spec_ld;
   int nb0;
   const int* ids;
@@ -108,10 +108,10 @@ struct SvdSplitDesc {
 struct SvdWorkspace {
   cplx* Y;        // [B][ncols_pad][rtot]  column-major stacked [X; W]
   long y_b0;
-  double* norms;  // [B][ncols_pad]
-  double* fro2;   // [B] squared Frobenius norm of theta (noise floor for the rotations)
+  real* norms;  // [B][ncols_pad]
+  real* fro2;   // [B] squared Frobenius norm of theta (noise floor for the rotations)
   int* perm;      // [B][ncols_pad]
-  double* rec;    // [B][8][256][4] rotation record (split X / W Jacobi), may be null
+  real* rec;    // [B][8][256][4] rotation record (split X / W Jacobi), may be null
   int* stamps;    // [B][1152] visit-pruning stamps of the Jacobi sweeps
   int* nrot;      // [B]
   int* done;      // [B]
@@ -135,7 +135,7 @@ struct JacobiSource {
 // Truncation rule (core/linalg/svd_utils.py:22-104); number of singular values = min(mulA*chiA, mulB*chiB)
 struct TruncSpec {
   int trunc_mode;
-  double threshold;
+  real threshold;
   int max_bond, min_keep;
   int cap = 0;               // storage extent of the new bond (0: unbounded); a wish beyond it is clipped and reported
   int* overflow = nullptr;   // device flag, set when the clip changed the result
@@ -143,7 +143,7 @@ struct TruncSpec {
   const int* chiB; int mulB;
   int* chiOut;
   int chi_stride;
-  double* spectrum;
+  real* spectrum;
   int spec_ld;
 };
 struct JacobiShape { int ncols_pad, rx_top, rtot; };
@@ -154,7 +154,7 @@ struct SmallShiftDesc {
   cplx* nb;   long nb_b0;     // right shift: A_{i+1} [d][cb][cn];  left shift: A_{i-1} [d][cn][ca]
   int d, ca, cb, cn;
   int* chi; int chi_stride;   // chi[b * stride + 0] = left bond of the site, [+1] = right bond
-  double threshold; int min_keep;
+  real threshold; int min_keep;
   const int* ids; int nb0;
   int* flags;                 // flags[1] |= 1 when the Jacobi iteration did not converge
 };
@@ -175,13 +175,13 @@ int launch_qr_site_small(const SmallQrDesc& p, bool right, hipStream_t s);
 // physical index of `site` (op 1: 2x2 matrix m, op 2: real scalar) followed by a shift of the centre away from `site`
 // (kind 1: SVD to the right, 2: SVD to the left, 3: QR to the right, 4: QR to the left, 0: none).
 struct SmallSiteRef { cplx* A; long b0; int ca, cb; };
-struct SmallSweepStep { int site, kind, op; double scal; cplx m[4]; };
+struct SmallSweepStep { int site, kind, op; real scal; cplx m[4]; };
 struct SmallSweepDesc {
   const SmallSiteRef* sites;     // device [L]
   const SmallSweepStep* steps;   // device [nsteps]
   int nsteps, d;
   int* chi; int chi_stride;      // chi[b * stride + k] = bond k
-  double threshold; int min_keep;
+  real threshold; int min_keep;
   const int* ids; int nb0;
   int* flags;
   int pitch;                     // rows of the LDS columns: small_sweep_pitch(largest d * cap of the chain)
@@ -233,11 +233,11 @@ struct QrWorkspace {
 };
 size_t qr_carve(QrWorkspace& q, char* base, int max_dim, int B);  // lays the buffers out behind base, returns the bytes used
 // helpers of the accumulation-free split (tjm_svd.hip: svd_split_qr2)
-int qr_gather_scaled(const cplx* G, long g_b0, int rows, int ncols, int d, const double* sigma, int sig_ld, const int* keep, int keep_stride,
+int qr_gather_scaled(const cplx* G, long g_b0, int rows, int ncols, int d, const real* sigma, int sig_ld, const int* keep, int keep_stride,
                      cplx* Z, long z_b0, int nb0, hipStream_t s);  // Z[k][bond*d+p] = G[(p,bond)][k] / sigma_k (0 beyond keep)
 int qr_identity(cplx* C, long c_b0, int rows, int ncols, int nb0, hipStream_t s, const int* ids = nullptr, const int* keep = nullptr,
                 int keep_stride = 0);
-int qr_r_times_sigma(const cplx* Z, long z_b0, int zr, int ncols, const double* sigma, int sig_ld, const int* keep, int keep_stride, cplx* Rs,
+int qr_r_times_sigma(const cplx* Z, long z_b0, int zr, int ncols, const real* sigma, int sig_ld, const int* keep, int keep_stride, cplx* Rs,
                      long rs_b0, int nb0, hipStream_t s);  // Rs[k][j] = R[k][j] sigma_j for k <= j < keep, else 0 (row-major ncols x ncols)
 int qr_adjoint_triangle(const QrWorkspace& q, int n, int nb0, const int* ids, hipStream_t s);  // Z2 = R^H of the factored Z
 size_t qr_workspace_bytes(int max_dim, int B);

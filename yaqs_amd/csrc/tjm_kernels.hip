@@ -15,7 +15,7 @@ namespace tjm {
 // ------------------------------------------------------------------------------------------
 template <int P>
 __global__ __launch_bounds__(256) void mpo_apply_kernel(MpoApplyDesc d) {
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   cplx* sW = reinterpret_cast<cplx*>(smem);
   int b0 = blockIdx.y;
   if (d.ids) b0 = d.ids[b0];
@@ -92,28 +92,28 @@ int launch_mpo_apply(const MpoApplyDesc& d, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------
 // block reduction helper (256 threads, result valid in every thread)
 // ------------------------------------------------------------------------------------------
-__device__ inline double block_sum(double v, double* sh) {
+__device__ inline real block_sum(real v, real* sh) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) sh[wave] = v;
   __syncthreads();
-  double t = 0.0;
+  real t = 0.0;
   const int nw = (blockDim.x + 63) >> 6;
   for (int w = 0; w < nw; ++w) t += sh[w];
   return t;
 }
 
 // part[b][blk] = sum over this block's chunk of |x|^2          (x = vector j of trajectory b)
-__global__ __launch_bounds__(256) void normsq_partial_kernel(const cplx* __restrict__ x, long x_b0, int n, double* part,
+__global__ __launch_bounds__(256) void normsq_partial_kernel(const cplx* __restrict__ x, long x_b0, int n, real* part,
                                                             int nblk, const int* ids, const int* active) {
-  __shared__ double sh[4];
+  __shared__ real sh[4];
   int b = blockIdx.y;
   if (ids) b = ids[b];
   if (active && active[b] == 0) return;
   const cplx* xb = x + (long)b * x_b0;
-  double acc = 0.0;
+  real acc = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nblk * blockDim.x) {
     cplx v = xb[i];
     acc = fma(v.x, v.x, acc);
@@ -125,15 +125,15 @@ __global__ __launch_bounds__(256) void normsq_partial_kernel(const cplx* __restr
 
 // part[b][blk] = Re <v, w> over the chunk
 __global__ __launch_bounds__(256) void dot_partial_kernel(const cplx* __restrict__ v, const cplx* __restrict__ w, long v_b0,
-                                                         long w_b0, int n, double* part, int nblk, const int* ids,
+                                                         long w_b0, int n, real* part, int nblk, const int* ids,
                                                          const int* active) {
-  __shared__ double sh[4];
+  __shared__ real sh[4];
   int b = blockIdx.y;
   if (ids) b = ids[b];
   if (active && active[b] == 0) return;
   const cplx* vb = v + (long)b * v_b0;
   const cplx* wb = w + (long)b * w_b0;
-  double acc = 0.0;
+  real acc = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nblk * blockDim.x) {
     cplx a = vb[i], c = wb[i];
     acc = fma(a.x, c.x, acc);
@@ -146,20 +146,20 @@ __global__ __launch_bounds__(256) void dot_partial_kernel(const cplx* __restrict
 // w -= alpha v_j + beta_{j-1} v_{j-1};  part2[b][blk] = sum |w|^2.  alpha = sum(part1[b][:]).
 __global__ __launch_bounds__(256) void lanczos_axpy_kernel(cplx* __restrict__ w, const cplx* __restrict__ vj,
                                                           const cplx* __restrict__ vjm1, long v_b0, int n,
-                                                          const double* part1, double* part2, int nblk,
-                                                          const double* beta, int beta_ld, int j, const int* ids,
+                                                          const real* part1, real* part2, int nblk,
+                                                          const real* beta, int beta_ld, int j, const int* ids,
                                                           const int* active) {
-  __shared__ double sh[4];
+  __shared__ real sh[4];
   int b = blockIdx.y;
   if (ids) b = ids[b];
   if (active && active[b] == 0) return;
-  double alpha = 0.0;
+  real alpha = 0.0;
   for (int i = 0; i < nblk; ++i) alpha += part1[(long)b * nblk + i];
-  const double bprev = (j > 0) ? beta[(long)b * beta_ld + j - 1] : 0.0;
+  const real bprev = (j > 0) ? beta[(long)b * beta_ld + j - 1] : 0.0;
   cplx* wb = w + (long)b * v_b0;
   const cplx* vb = vj + (long)b * v_b0;
   const cplx* ub = vjm1 + (long)b * v_b0;
-  double acc = 0.0;
+  real acc = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nblk * blockDim.x) {
     cplx x = wb[i], a = vb[i];
     x.x = fma(-alpha, a.x, x.x);
@@ -178,12 +178,12 @@ __global__ __launch_bounds__(256) void lanczos_axpy_kernel(cplx* __restrict__ w,
 }
 
 // x *= scale[b]
-__global__ __launch_bounds__(256) void scale_kernel(cplx* __restrict__ x, long x_b0, long n, const double* scale, const int* ids,
+__global__ __launch_bounds__(256) void scale_kernel(cplx* __restrict__ x, long x_b0, long n, const real* scale, const int* ids,
                                                    const int* active) {
   int b = blockIdx.y;
   if (ids) b = ids[b];
   if (active && active[b] == 0) return;
-  const double s = scale[b];
+  const real s = scale[b];
   cplx* xb = x + (long)b * x_b0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     cplx v = xb[i];
@@ -201,36 +201,36 @@ __global__ __launch_bounds__(256) void scale_kernel(cplx* __restrict__ x, long x
 // (matrix_exponential.py:147-163); both evaluate the same analytic function.
 // Lane i holds entry i.  Returns phi_i in (pr, pi).
 // ------------------------------------------------------------------------------------------
-__device__ inline void tridiag_expm_e1(const double* alpha, const double* beta, int k, double dt, int lane, double& pr,
-                                       double& pi, int ov_idx = -1, double ov_val = 0.0) {
+__device__ inline void tridiag_expm_e1(const real* alpha, const real* beta, int k, real dt, int lane, real& pr,
+                                       real& pi, int ov_idx = -1, real ov_val = 0.0) {
   // alpha[ov_idx] may have been written by this very wavefront an instant ago: take it from a register
-  const double a = (lane < k) ? ((lane == ov_idx) ? ov_val : alpha[lane]) : 0.0;
-  const double bu = (lane < k - 1) ? beta[lane] : 0.0;                 // couples lane <-> lane+1
-  const double bl = (lane >= 1 && lane < k) ? beta[lane - 1] : 0.0;    // couples lane <-> lane-1
-  double lo = (lane < k) ? a - fabs(bu) - fabs(bl) : 1e300;
-  double hi = (lane < k) ? a + fabs(bu) + fabs(bl) : -1e300;
+  const real a = (lane < k) ? ((lane == ov_idx) ? ov_val : alpha[lane]) : 0.0;
+  const real bu = (lane < k - 1) ? beta[lane] : 0.0;                 // couples lane <-> lane+1
+  const real bl = (lane >= 1 && lane < k) ? beta[lane - 1] : 0.0;    // couples lane <-> lane-1
+  real lo = (lane < k) ? a - fabs(bu) - fabs(bl) : 1e300;
+  real hi = (lane < k) ? a + fabs(bu) + fabs(bl) : -1e300;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     lo = fmin(lo, __shfl_xor(lo, o, 64));
     hi = fmax(hi, __shfl_xor(hi, o, 64));
   }
-  const double mu = 0.5 * (lo + hi);
-  const double rho = fabs(dt) * 0.5 * (hi - lo);
+  const real mu = 0.5 * (lo + hi);
+  const real rho = fabs(dt) * 0.5 * (hi - lo);
   int nsub = (int)ceil(rho);
   if (nsub < 1) nsub = 1;
-  const double h = dt / nsub;
-  const double as = a - mu;
-  double xr = (lane == 0) ? 1.0 : 0.0, xi = 0.0;
+  const real h = dt / nsub;
+  const real as = a - mu;
+  real xr = (lane == 0) ? 1.0 : 0.0, xi = 0.0;
   for (int s = 0; s < nsub; ++s) {
-    double tr = xr, ti = xi, sr = xr, si = xi;
+    real tr = xr, ti = xi, sr = xr, si = xi;
     for (int n = 1; n <= 22; ++n) {
       // t <- (-i h / n) * T t
-      double ur = __shfl_up(tr, 1, 64), ui = __shfl_up(ti, 1, 64);
-      double dr = __shfl_down(tr, 1, 64), di = __shfl_down(ti, 1, 64);
+      real ur = __shfl_up(tr, 1, 64), ui = __shfl_up(ti, 1, 64);
+      real dr = __shfl_down(tr, 1, 64), di = __shfl_down(ti, 1, 64);
       if (lane == 0) { ur = 0.0; ui = 0.0; }
-      double yr = as * tr + bl * ur + bu * dr;
-      double yi = as * ti + bl * ui + bu * di;
-      const double c = h / n;
+      real yr = as * tr + bl * ur + bu * dr;
+      real yi = as * ti + bl * ui + bu * di;
+      const real c = h / n;
       tr = c * yi;   // (-i)(yr + i yi) = yi - i yr
       ti = -c * yr;
       sr += tr;
@@ -240,21 +240,21 @@ __device__ inline void tridiag_expm_e1(const double* alpha, const double* beta, 
     xi = si;
   }
   // global phase exp(-i dt mu)
-  double sn, cs;
-  sincos(-dt * mu, &sn, &cs);
+  real sn, cs;
+  tjm_sincos(-dt * mu, &sn, &cs);
   pr = xr * cs - xi * sn;
   pi = xr * sn + xi * cs;
   if (lane >= k) { pr = 0.0; pi = 0.0; }
 }
 
-__global__ __launch_bounds__(64) void tridiag_expm_test_kernel(const double* alpha, const double* beta, int k, double dt,
-                                                              double* out) {
-  double pr, pi;
+__global__ __launch_bounds__(64) void tridiag_expm_test_kernel(const real* alpha, const real* beta, int k, real dt,
+                                                              real* out) {
+  real pr, pi;
   tridiag_expm_e1(alpha, beta, k, dt, threadIdx.x, pr, pi);
   if ((int)threadIdx.x < k) { out[2 * threadIdx.x] = pr; out[2 * threadIdx.x + 1] = pi; }
 }
 
-int launch_tridiag_expm_test(const double* alpha, const double* beta, int k, double dt, double* out, hipStream_t s) {
+int launch_tridiag_expm_test(const real* alpha, const real* beta, int k, real dt, real* out, hipStream_t s) {
   if (k < 1 || k > 64) return TJM_ERR_ARG;
   hipLaunchKernelGGL(tridiag_expm_test_kernel, dim3(1), dim3(64), 0, s, alpha, beta, k, dt, out);
   TJM_HIP_CHECK(hipGetLastError());
@@ -278,9 +278,9 @@ static size_t krylov_small_lds(int P, int ca, int cb, int Dl, int Dr) {
 }
 
 __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc p) {
-  extern __shared__ double ks_smem[];
+  extern __shared__ real ks_smem[];
   __shared__ cplx sCoef[64];
-  __shared__ double sAl[64], sBe[64], sh[4];
+  __shared__ real sAl[64], sBe[64], sh[4];
   __shared__ int sDone, sK;
   int b = blockIdx.x;
   if (p.ids) b = p.ids[b];
@@ -298,13 +298,13 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
   for (int e = tid; e < ca * Dl * ca; e += 256) sL[e] = p.Lenv[(long)b * p.l_b0 + e];
   for (int e = tid; e < cb * Dr * cb; e += 256) sR[e] = p.Renv[(long)b * p.r_b0 + e];
   for (int e = tid; e < P * Dl * P * Dr; e += 256) sW[e] = p.Wm[e];
-  double acc = 0.0;
+  real acc = 0.0;
   for (int e = tid; e < N; e += 256) {
     const cplx v = Vb[e];
     sX[e] = v;
     acc = fma(v.x, v.x, fma(v.y, v.y, acc));
   }
-  const double nrm = sqrt(block_sum(acc, sh));
+  const real nrm = sqrt(block_sum(acc, sh));
   cplx* __restrict__ ob = p.out + (long)b * p.out_b0;
   auto out_index = [&](int e) -> long {
     long i3 = e % p.n3, r = e / p.n3;
@@ -317,17 +317,17 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
     for (int e = tid; e < N; e += 256) ob[out_index(e)] = cplx{0.0, 0.0};
     return;
   }
-  const double inv0 = 1.0 / nrm;
+  const real inv0 = 1.0 / nrm;
   for (int e = tid; e < N; e += 256) {
     cplx v = sX[e];
     v.x *= inv0; v.y *= inv0;
     sX[e] = v;
     Vb[e] = v;
   }
-  const double eps_cut = 100.0 * (double)p.nloc[b] * 2.220446049250313e-16;
+  const real eps_cut = 100.0 * (real)p.nloc[b] * TJM_EPS;
   const int na = p.chi_l ? min(p.chi_l[(long)b * p.chi_stride], ca) : ca;
   const int nb = p.chi_r ? min(p.chi_r[(long)b * p.chi_stride], cb) : cb;
-  double bprev = 0.0;
+  real bprev = 0.0;
   int kfinal = 0;
   __syncthreads();
   for (int j = 0; j < m; ++j) {
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
     }
     __syncthreads();
     // y[o][A][B] = sum_{(a,l)} L[(a,l)][A] T2[o][(a,l)][B] ;  alpha = Re <x, y>
-    double dot = 0.0;
+    real dot = 0.0;
     for (int e = tid; e < N; e += 256) {
       const int Bc = e % cb, A = (e / cb) % ca, o = e / (cb * ca);
       cplx t{0.0, 0.0};
@@ -363,9 +363,9 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
       const cplx x = sX[e];
       dot = fma(x.x, t.x, fma(x.y, t.y, dot));
     }
-    const double alpha = block_sum(dot, sh);
+    const real alpha = block_sum(dot, sh);
     // w = y - alpha x - beta_{j-1} x_{j-1}
-    double s2 = 0.0;
+    real s2 = 0.0;
     for (int e = tid; e < N; e += 256) {
       cplx w = sY[e];
       const cplx x = sX[e];
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
       sY[e] = w;
       s2 = fma(w.x, w.x, fma(w.y, w.y, s2));
     }
-    const double bj = sqrt(block_sum(s2, sh));
+    const real bj = sqrt(block_sum(s2, sh));
     if (tid == 0) {
       sAl[j] = alpha;
       if (j < m - 1) sBe[j] = bj;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
     __syncthreads();
     const int k = j + 1;
     if (tid < 64) {  // breakdown and adaptive stop (lanczos_finalize_kernel)
-      double pr = 0.0, pi = 0.0;
+      real pr = 0.0, pi = 0.0;
       bool done = false;
       if (j < m - 1 && bj < eps_cut) {
         tridiag_expm_e1(sAl, sBe, k, p.dt, tid, pr, pi);
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
         tridiag_expm_e1(sAl, sBe, k, p.dt, tid, pr, pi);
         if (j == m - 1) done = true;
         else {
-          const double lr = __shfl(pr, k - 1, 64), li = __shfl(pi, k - 1, 64);
+          const real lr = __shfl(pr, k - 1, 64), li = __shfl(pi, k - 1, 64);
           done = (bj * sqrt(lr * lr + li * li) < p.tol);
         }
       }
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
     }
     __syncthreads();
     if (sDone) { kfinal = sK; break; }
-    const double invb = 1.0 / bj;
+    const real invb = 1.0 / bj;
     for (int e = tid; e < N; e += 256) {
       cplx w = sY[e];
       w.x *= invb; w.y *= invb;
@@ -448,13 +448,13 @@ int launch_krylov_site_small(const SmallKrylovDesc& p, hipStream_t s) {
 }
 
 // Lanczos start: vnorm = sqrt(sum part), status, first scale
-__global__ __launch_bounds__(64) void lanczos_init_kernel(KrylovState ks, const double* part, int nblk, int nb, const int* ids) {
+__global__ __launch_bounds__(64) void lanczos_init_kernel(KrylovState ks, const real* part, int nblk, int nb, const int* ids) {
   int b = blockIdx.x;
   if (ids) b = ids[b];
   if (threadIdx.x != 0) return;
-  double s = 0.0;
+  real s = 0.0;
   for (int i = 0; i < nblk; ++i) s += part[(long)b * nblk + i];
-  const double nrm = sqrt(s);
+  const real nrm = sqrt(s);
   ks.vnorm[b] = nrm;
   if (nrm == 0.0) {
     ks.status[b] = 0;  // finished: result is the zero vector
@@ -471,29 +471,29 @@ __global__ __launch_bounds__(64) void lanczos_init_kernel(KrylovState ks, const 
 
 // One wavefront per trajectory: store alpha_j / beta_j, breakdown and adaptive-stop tests
 // (matrix_exponential.py:100-163), coefficient vector on exit.
-__global__ __launch_bounds__(64) void lanczos_finalize_kernel(KrylovState ks, const double* part1, const double* part2, int nblk,
-                                                             int j, double dt, double tol, const int* nloc, const int* ids) {
+__global__ __launch_bounds__(64) void lanczos_finalize_kernel(KrylovState ks, const real* part1, const real* part2, int nblk,
+                                                             int j, real dt, real tol, const int* nloc, const int* ids) {
   int b = blockIdx.x;
   if (ids) b = ids[b];
   if (ks.status[b] == 0) return;
   const int lane = threadIdx.x;
   const int m = ks.mmax;
-  double* al = ks.alpha + (long)b * m;
-  double* be = ks.beta + (long)b * m;
-  double a = 0.0, s2 = 0.0;
+  real* al = ks.alpha + (long)b * m;
+  real* be = ks.beta + (long)b * m;
+  real a = 0.0, s2 = 0.0;
   for (int i = 0; i < nblk; ++i) {
     a += part1[(long)b * nblk + i];
     s2 += part2[(long)b * nblk + i];
   }
-  const double bj = sqrt(s2);
+  const real bj = sqrt(s2);
   if (lane == 0) {
     al[j] = a;
     if (j < m - 1) be[j] = bj;
   }
-  const double eps_cut = 100.0 * (double)nloc[b] * 2.220446049250313e-16;
+  const real eps_cut = 100.0 * (real)nloc[b] * TJM_EPS;
   bool done = false;
   const int k = j + 1;
-  double pr = 0.0, pi = 0.0;
+  real pr = 0.0, pi = 0.0;
   if (j < m - 1 && bj < eps_cut) {
     tridiag_expm_e1(al, be, k, dt, lane, pr, pi, j, a);
     done = true;
@@ -502,12 +502,12 @@ __global__ __launch_bounds__(64) void lanczos_finalize_kernel(KrylovState ks, co
     if (j == m - 1) {
       done = true;
     } else {
-      const double lr = __shfl(pr, k - 1, 64), li = __shfl(pi, k - 1, 64);
+      const real lr = __shfl(pr, k - 1, 64), li = __shfl(pi, k - 1, 64);
       done = (bj * sqrt(lr * lr + li * li) < tol);
     }
   }
   if (done) {
-    const double nrm = ks.vnorm[b];
+    const real nrm = ks.vnorm[b];
     if (lane < k) ks.coef[(long)b * m + lane] = cplx{pr * nrm, pi * nrm};
     if (lane == 0) {
       ks.status[b] = 0;
@@ -552,7 +552,7 @@ static inline int nblk_for(long n) {
   return (int)nb;
 }
 
-int launch_normsq_partial(const cplx* x, long x_b0, int n, double* part, int nb0, const int* ids, const int* active,
+int launch_normsq_partial(const cplx* x, long x_b0, int n, real* part, int nb0, const int* ids, const int* active,
                           hipStream_t s, int* nblk_out) {
   const int nblk = nblk_for(n);
   *nblk_out = nblk;
@@ -561,7 +561,7 @@ int launch_normsq_partial(const cplx* x, long x_b0, int n, double* part, int nb0
   return TJM_OK;
 }
 
-int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n, double* part, int nb0, const int* ids,
+int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n, real* part, int nb0, const int* ids,
                        const int* active, hipStream_t s, int* nblk_out) {
   const int nblk = nblk_for(n);
   *nblk_out = nblk;
@@ -570,8 +570,8 @@ int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n
   return TJM_OK;
 }
 
-int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, int n, const double* part1, double* part2,
-                        int nblk, const double* beta, int beta_ld, int j, int nb0, const int* ids, const int* active,
+int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, int n, const real* part1, real* part2,
+                        int nblk, const real* beta, int beta_ld, int j, int nb0, const int* ids, const int* active,
                         hipStream_t s) {
   hipLaunchKernelGGL(lanczos_axpy_kernel, dim3(nblk, nb0), dim3(256), 0, s, w, vj, vjm1, v_b0, n, part1, part2, nblk, beta,
                      beta_ld, j, ids, active);
@@ -579,7 +579,7 @@ int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, in
   return TJM_OK;
 }
 
-int launch_scale(cplx* x, long x_b0, long n, const double* scale, int nb0, const int* ids, const int* active, hipStream_t s) {
+int launch_scale(cplx* x, long x_b0, long n, const real* scale, int nb0, const int* ids, const int* active, hipStream_t s) {
   int gx = (int)((n + 1023) / 1024);
   if (gx < 1) gx = 1;
   if (gx > 256) gx = 256;
@@ -588,14 +588,14 @@ int launch_scale(cplx* x, long x_b0, long n, const double* scale, int nb0, const
   return TJM_OK;
 }
 
-int launch_lanczos_init(const KrylovState& ks, const double* part, int nblk, int nb0, const int* ids, hipStream_t s) {
+int launch_lanczos_init(const KrylovState& ks, const real* part, int nblk, int nb0, const int* ids, hipStream_t s) {
   hipLaunchKernelGGL(lanczos_init_kernel, dim3(nb0), dim3(64), 0, s, ks, part, nblk, nb0, ids);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
 
-int launch_lanczos_finalize(const KrylovState& ks, const double* part1, const double* part2, int nblk, int j, double dt,
-                            double tol, const int* nloc, int nb0, const int* ids, hipStream_t s) {
+int launch_lanczos_finalize(const KrylovState& ks, const real* part1, const real* part2, int nblk, int j, real dt,
+                            real tol, const int* nloc, int nb0, const int* ids, hipStream_t s) {
   hipLaunchKernelGGL(lanczos_finalize_kernel, dim3(nb0), dim3(64), 0, s, ks, part1, part2, nblk, j, dt, tol, nloc, ids);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
@@ -617,12 +617,12 @@ int launch_krylov_combine(const cplx* V, long v_b0, long v_ld, const KrylovState
 // small per-site kernels
 // ------------------------------------------------------------------------------------------
 // out[b] = sum |x_b|^2   (one block per trajectory)
-__global__ __launch_bounds__(256) void normsq_kernel(const cplx* __restrict__ x, long x_b0, long n, double* out, const int* ids) {
-  __shared__ double sh[4];
+__global__ __launch_bounds__(256) void normsq_kernel(const cplx* __restrict__ x, long x_b0, long n, real* out, const int* ids) {
+  __shared__ real sh[4];
   int b = blockIdx.x;
   if (ids) b = ids[b];
   const cplx* xb = x + (long)b * x_b0;
-  double acc = 0.0;
+  real acc = 0.0;
   for (long i = threadIdx.x; i < n; i += blockDim.x) {
     cplx v = xb[i];
     acc = fma(v.x, v.x, acc);
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void normsq_kernel(const cplx* __restrict__ x,
   if (threadIdx.x == 0) out[b] = acc;
 }
 
-int launch_normsq(const cplx* x, long x_b0, long n, double* out, int nb0, const int* ids, hipStream_t s) {
+int launch_normsq(const cplx* x, long x_b0, long n, real* out, int nb0, const int* ids, hipStream_t s) {
   hipLaunchKernelGGL(normsq_kernel, dim3(nb0), dim3(256), 0, s, x, x_b0, n, out, ids);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
@@ -676,7 +676,7 @@ __global__ void identity_env_kernel(cplx* E, long e_b0, int n, int D, int nb0) {
   int b = blockIdx.x;
   for (int t = threadIdx.x; t < n * D * n; t += blockDim.x) {
     int i = t / (D * n), r = t % (D * n), k = r % n;
-    E[(long)b * e_b0 + t] = cplx{(i == k) ? 1.0 : 0.0, 0.0};
+    E[(long)b * e_b0 + t] = cplx{(i == k) ? real(1) : real(0), 0.0};
   }
 }
 
@@ -689,14 +689,14 @@ int launch_identity_env(cplx* E, long e_b0, int n, int D, int nb0, hipStream_t s
 // M[b][p][q] = <x_p | y_q> = sum_r conj(x[p][r]) y[q][r]   (d x d physical overlap matrix)
 __global__ __launch_bounds__(256) void phys_overlap_kernel(const cplx* __restrict__ x, const cplx* __restrict__ y, long x_b0,
                                                           long y_b0, int d, long rest, cplx* M, const int* ids) {
-  __shared__ double sh[4];
+  __shared__ real sh[4];
   int b = blockIdx.x;
   if (ids) b = ids[b];
   const cplx* xb = x + (long)b * x_b0;
   const cplx* yb = y + (long)b * y_b0;
   for (int p = 0; p < d; ++p)
     for (int q = 0; q < d; ++q) {
-      double ar = 0.0, ai = 0.0;
+      real ar = 0.0, ai = 0.0;
       for (long r = threadIdx.x; r < rest; r += blockDim.x) {
         cplx a = xb[(long)p * rest + r], c = yb[(long)q * rest + r];
         ar += a.x * c.x + a.y * c.y;

@@ -20,7 +20,7 @@ namespace {
 
 constexpr int PW = 16;  // panel width
 
-__device__ inline double block_sum256(double v, double* sh) {
+__device__ inline real block_sum256(real v, real* sh) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -40,17 +40,25 @@ __device__ inline cplx wave_csum(cplx v) {
 }
 
 template <int CTRL>
-__device__ inline double dpp_pull(double v) {
+__device__ inline real dpp_pull(real v) {
+#ifdef TJM_F32
+  return tjm_dpp<CTRL>(v);
+#else
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
+#endif
 }
-__device__ inline double lane_value(double v, int lane) {
+__device__ inline real lane_value(real v, int lane) {
+#ifdef TJM_F32
+  return tjm_readlane(v, lane);
+#else
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+#endif
 }
 // wavefront all-reduce: DPP butterfly inside rows of 16 lanes, then the four row totals via v_readlane
-__device__ inline double wsum(double v) {
+__device__ inline real wsum(real v) {
   v += dpp_pull<0xB1>(v);
   v += dpp_pull<0x4E>(v);
   v += dpp_pull<0x141>(v);
@@ -63,7 +71,7 @@ __device__ inline double wsum(double v) {
 // Householder steps need wavefront reductions only (no workgroup barrier), and the loops stay rolled (small code).
 __global__ __launch_bounds__(64) void qr_panel_kernel(cplx* __restrict__ A, long a_b0, int zr, int k0, int pw, cplx* __restrict__ Vb,
                                                      long v_b0, cplx* __restrict__ Tb, long t_b0, int panel, const int* ids) {
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   int b = blockIdx.x;
   if (ids) b = ids[b];
   const int lane = threadIdx.x;
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(64) void qr_panel_kernel(cplx* __restrict__ A, long
   cplx* sG = P + PW * mp;                   // [PW][PW]
   cplx* sT = sG + PW * PW;                  // [PW][PW]
   cplx* sTau = sT + PW * PW;                // [PW]
-  double* sBeta = reinterpret_cast<double*>(sTau + PW);
+  real* sBeta = reinterpret_cast<real*>(sTau + PW);
   cplx* Ab = A + (long)b * a_b0;
   for (int c = 0; c < pw; ++c)
     for (int r = lane; r < mp; r += 64) P[c * mp + r] = Ab[(long)(k0 + c) * zr + k0 + r];
@@ -83,21 +91,21 @@ __global__ __launch_bounds__(64) void qr_panel_kernel(cplx* __restrict__ A, long
   for (int j = 0; j < pw; ++j) {
     // ---- zlarfg on column j, rows j .. mp-1
     cplx* pj = P + j * mp;
-    double acc = 0.0;
+    real acc = 0.0;
     for (int r = j + 1 + lane; r < mp; r += 64) {
       const cplx v = pj[r];
       acc = fma(v.x, v.x, fma(v.y, v.y, acc));
     }
-    const double xn2 = wsum(acc);
+    const real xn2 = wsum(acc);
     const cplx alpha = (j < mp) ? pj[j] : cplx{0.0, 0.0};
     cplx tau{0.0, 0.0}, scale{0.0, 0.0};
-    double bt = alpha.x;
+    real bt = alpha.x;
     if (j < mp && (xn2 > 0.0 || alpha.y != 0.0)) {
-      const double an = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xn2);
+      const real an = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xn2);
       bt = (alpha.x >= 0.0) ? -an : an;
       tau = cplx{(bt - alpha.x) / bt, -alpha.y / bt};
       const cplx dnm{alpha.x - bt, alpha.y};
-      const double d2 = dnm.x * dnm.x + dnm.y * dnm.y;
+      const real d2 = dnm.x * dnm.x + dnm.y * dnm.y;
       scale = cplx{dnm.x / d2, -dnm.y / d2};
     }
     __builtin_amdgcn_wave_barrier();
@@ -208,20 +216,20 @@ constexpr int NRED = 2 * PW;          // slot 0: xn2, slots 1..15: Re, 17..31: I
 template <int RPT, int NT = 256>
 __global__ __launch_bounds__(NT) void qr_panel_rows_kernel(cplx* __restrict__ A, long a_b0, int zr, int k0, int pw, cplx* __restrict__ Vb,
                                                            long v_b0, cplx* __restrict__ Tb, long t_b0, int panel, const int* ids) {
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   int b = blockIdx.x;
   if (ids) b = ids[b];
   const int tid = threadIdx.x;
   const int mp = zr - k0;
   constexpr int RED_PITCH = NT + 1;
   constexpr int SEGS = NT / 32;                                   // threads that join one of the 32 sums
-  double* sPart = smem;                                           // [NRED][RED_PITCH]
-  double* sRed = sPart + NRED * RED_PITCH;                        // [2][NRED]
+  real* sPart = smem;                                           // [NRED][RED_PITCH]
+  real* sRed = sPart + NRED * RED_PITCH;                        // [2][NRED]
   cplx* sRow = reinterpret_cast<cplx*>(sRed + 2 * NRED);          // [2][PW]
   cplx* sG = sRow + 2 * PW;                                       // [PW][PW]
   cplx* sT = sG + PW * PW;                                        // [PW][PW]
   cplx* sTau = sT + PW * PW;                                      // [PW]
-  double* sBeta = reinterpret_cast<double*>(sTau + PW);           // [PW]
+  real* sBeta = reinterpret_cast<real*>(sTau + PW);           // [PW]
   cplx* Ab = A + (long)b * a_b0;
 
   cplx P[PW][RPT];
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(NT) void qr_panel_rows_kernel(cplx* __restrict__ A,
     if (j < pw && j < mp) {   // uniform
       const int buf = j & 1;
       // ---- partial sums over this thread's rows below j
-      double part[NRED];
+      real part[NRED];
 #pragma unroll
       for (int v = 0; v < NRED; ++v) part[v] = 0.0;
 #pragma unroll
@@ -273,8 +281,8 @@ __global__ __launch_bounds__(NT) void qr_panel_rows_kernel(cplx* __restrict__ A,
       __syncthreads();
       {
         const int v = tid / SEGS, seg = tid % SEGS;
-        const double* src = sPart + v * RED_PITCH + seg * 32;
-        double acc = 0.0;
+        const real* src = sPart + v * RED_PITCH + seg * 32;
+        real acc = 0.0;
 #pragma unroll
         for (int i = 0; i < 32; ++i) acc += src[(i + 4 * seg) & 31];
         acc += dpp_pull<0xB1>(acc);
@@ -285,16 +293,16 @@ __global__ __launch_bounds__(NT) void qr_panel_rows_kernel(cplx* __restrict__ A,
       }
       __syncthreads();
       // ---- zlarfg (every thread, redundantly)
-      const double xn2 = sRed[buf * NRED];
+      const real xn2 = sRed[buf * NRED];
       const cplx alpha = sRow[buf * PW + j];
       cplx tau{0.0, 0.0}, scale{0.0, 0.0};
-      double bt = alpha.x;
+      real bt = alpha.x;
       if (xn2 > 0.0 || alpha.y != 0.0) {
-        const double an = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xn2);
+        const real an = sqrt(alpha.x * alpha.x + alpha.y * alpha.y + xn2);
         bt = (alpha.x >= 0.0) ? -an : an;
         tau = cplx{(bt - alpha.x) / bt, -alpha.y / bt};
         const cplx dnm{alpha.x - bt, alpha.y};
-        const double d2 = dnm.x * dnm.x + dnm.y * dnm.y;
+        const real d2 = dnm.x * dnm.x + dnm.y * dnm.y;
         scale = cplx{dnm.x / d2, -dnm.y / d2};
       }
       if (tid == 0) { sTau[j] = tau; sBeta[j] = bt; }
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
   const int row0 = panel * PW;  // the reflector block is zero above its first row: start there
   {  // W1[i][c] = sum_r conj(V[i][r]) C[c][r]   (K = rows in chunks of 16, split over the four wavefronts).  The order of the
      // K index is free, so lane (li, lk) takes the four CONSECUTIVE rows base + 4 lk + q: 64-byte runs instead of 16-byte ones.
-    d4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
+    real4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
     const int nsteps = (zr - row0 + 15) >> 4;
     const bool cvalid = li < ncw;
     const cplx* vcol = Vp + (long)li * zr;
@@ -413,17 +421,17 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        P = __builtin_amdgcn_mfma_f64_16x16x4f64(v[q].x, x[q].x, P, 0, 0, 0);
-        Q = __builtin_amdgcn_mfma_f64_16x16x4f64(v[q].y, x[q].y, Q, 0, 0, 0);
-        S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[q].x, x[q].y, S1, 0, 0, 0);
-        S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[q].y, x[q].x, S2, 0, 0, 0);
+        P = TJM_MFMA(v[q].x, x[q].x, P);
+        Q = TJM_MFMA(v[q].y, x[q].y, Q);
+        S1 = TJM_MFMA(v[q].x, x[q].y, S1);
+        S2 = TJM_MFMA(v[q].y, x[q].x, S2);
       }
     }
     for (int w = 0; w < 4; ++w) {  // deterministic reduction over the wavefronts
       if (wave == w) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int i = lk + 4 * q, c = li;
+          const int i = TJM_ACC_ROW(lane, q), c = li;
           cplx a = sW1[i * PW + c];
           a.x += P[q] + Q[q];
           a.y += S1[q] - S2[q];
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
   __syncthreads();
   {  // C[c][r] -= sum_i W2[i][c] V[i][r], computed transposed: D[c][row] = sum_i A[c][i] B[i][row] with A = W2^T, B = V^T, so that
      // the 16 lanes of a row group read and write 16 consecutive rows of one column (256-byte runs)
-    double wr[4], wi[4];
+    real wr[4], wi[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const cplx t = sW2[(4 * kk + lk) * PW + li];  // A[c = li][i = 4kk + lk]
@@ -455,19 +463,19 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
     const int nchunks = (zr - row0 + 15) >> 4;
     for (int ch = wave; ch < nchunks; ch += 4) {
       const int r0 = row0 + ch * 16;
-      d4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
+      real4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const cplx v = (r0 + li < zr) ? Vp[(long)(4 * kk + lk) * zr + r0 + li] : cplx{0.0, 0.0};  // B[i = 4kk + lk][row = li]
-        P = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[kk], v.x, P, 0, 0, 0);
-        Q = __builtin_amdgcn_mfma_f64_16x16x4f64(wi[kk], v.y, Q, 0, 0, 0);
-        S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wi[kk], v.x, S1, 0, 0, 0);
-        S2 = __builtin_amdgcn_mfma_f64_16x16x4f64(wr[kk], v.y, S2, 0, 0, 0);
+        P = TJM_MFMA(wr[kk], v.x, P);
+        Q = TJM_MFMA(wi[kk], v.y, Q);
+        S1 = TJM_MFMA(wi[kk], v.x, S1);
+        S2 = TJM_MFMA(wr[kk], v.y, S2);
       }
       if (r0 + li < zr) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int c = lk + 4 * q;  // D: row (= column of C) lk + 4q, column (= row of C) li
+          const int c = TJM_ACC_ROW(lane, q);  // D: row (= column of C) of result register q, column (= row of C) li
           if (c >= ncw) continue;
           const long idx = (long)(c0 + c) * zr + r0 + li;
           cplx x = Cb[idx];
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
 // trajectory; the rank of a column is the number of columns that precede it (ties broken by index: deterministic).
 __global__ __launch_bounds__(256) void qr_colsort_kernel(const cplx* __restrict__ theta, long th_b0, int m, int n, int dist, int* __restrict__ cperm,
                                                         int ld, const int* ids, int zc_pad) {
-  __shared__ double sn[1024];
+  __shared__ real sn[1024];
   int b = blockIdx.x;
   if (ids) b = ids[b];
   const cplx* th = theta + (long)b * th_b0;
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(256) void qr_colsort_kernel(const cplx* __restrict_
   const int zc = (dist == 0) ? n : m;
   if (dist == 0) {  // column c of theta
     for (int c = tid; c < zc; c += 256) {
-      double acc = 0.0;
+      real acc = 0.0;
       for (int r = 0; r < m; ++r) {
         const cplx v = th[(long)r * n + c];
         acc = fma(v.x, v.x, fma(v.y, v.y, acc));
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(256) void qr_colsort_kernel(const cplx* __restrict_
   } else {          // row i of theta, one wavefront per row
     const int lane = tid & 63, wave = tid >> 6;
     for (int i = wave; i < zc; i += 4) {
-      double acc = 0.0;
+      real acc = 0.0;
       for (int k = lane; k < n; k += 64) {
         const cplx v = th[(long)i * n + k];
         acc = fma(v.x, v.x, fma(v.y, v.y, acc));
@@ -518,10 +526,10 @@ __global__ __launch_bounds__(256) void qr_colsort_kernel(const cplx* __restrict_
   }
   __syncthreads();
   for (int c = tid; c < zc; c += 256) {
-    const double mine = sn[c];
+    const real mine = sn[c];
     int rank = 0;
     for (int o = 0; o < zc; ++o) {
-      const double other = sn[o];
+      const real other = sn[o];
       rank += (other > mine || (other == mine && o < c)) ? 1 : 0;
     }
     cperm[(long)b * ld + rank] = c;
@@ -620,7 +628,7 @@ __global__ __launch_bounds__(256) void qr_adjoint_triangle_kernel(const cplx* __
 
 namespace {
 __global__ __launch_bounds__(256) void qr_gather_scaled_kernel(const cplx* __restrict__ G, long g_b0, int rows, int ncols, int d,
-                                                              const double* __restrict__ sigma, int sig_ld, const int* __restrict__ keep,
+                                                              const real* __restrict__ sigma, int sig_ld, const int* __restrict__ keep,
                                                               int keep_stride, cplx* __restrict__ Z, long z_b0) {
   const int b = blockIdx.y;
   const cplx* Gb = G + (long)b * g_b0;
@@ -633,9 +641,9 @@ __global__ __launch_bounds__(256) void qr_gather_scaled_kernel(const cplx* __res
     const int bond = rp / d, ph = rp % d;
     cplx v{0.0, 0.0};
     if (k < kp) {
-      const double sg = sigma[(long)b * sig_ld + k];
+      const real sg = sigma[(long)b * sig_ld + k];
       if (sg > 0.0) {
-        const double inv = 1.0 / sg;
+        const real inv = 1.0 / sg;
         v = Gb[((long)ph * cap + bond) * ncols + k];
         v.x *= inv;
         v.y *= inv;
@@ -652,10 +660,10 @@ __global__ __launch_bounds__(256) void qr_identity_kernel(cplx* __restrict__ C, 
   const long total = (long)rows * ncols;
   const int kp = keep ? keep[(long)b * keep_stride] : ncols;  // columns beyond the kept ones stay zero
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x)
-    Cb[e] = cplx{(e / rows == e % rows && e / rows < kp) ? 1.0 : 0.0, 0.0};
+    Cb[e] = cplx{(e / rows == e % rows && e / rows < kp) ? real(1) : real(0), 0.0};
 }
 
-__global__ __launch_bounds__(256) void qr_r_times_sigma_kernel(const cplx* __restrict__ Z, long z_b0, int zr, int ncols, const double* __restrict__ sigma,
+__global__ __launch_bounds__(256) void qr_r_times_sigma_kernel(const cplx* __restrict__ Z, long z_b0, int zr, int ncols, const real* __restrict__ sigma,
                                                               int sig_ld, const int* __restrict__ keep, int keep_stride, cplx* __restrict__ Rs,
                                                               long rs_b0) {
   const int b = blockIdx.y;
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(256) void qr_r_times_sigma_kernel(const cplx* __res
     const int k = (int)(e / ncols), j = (int)(e % ncols);
     cplx v{0.0, 0.0};
     if (k <= j && j < kp && k < zr) {
-      const double sg = sigma[(long)b * sig_ld + j];
+      const real sg = sigma[(long)b * sig_ld + j];
       v = Zb[(long)j * zr + k];
       v.x *= sg;
       v.y *= sg;
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(256) void qr_r_times_sigma_kernel(const cplx* __res
 }
 }  // namespace
 
-int qr_gather_scaled(const cplx* G, long g_b0, int rows, int ncols, int d, const double* sigma, int sig_ld, const int* keep, int keep_stride,
+int qr_gather_scaled(const cplx* G, long g_b0, int rows, int ncols, int d, const real* sigma, int sig_ld, const int* keep, int keep_stride,
                      cplx* Z, long z_b0, int nb0, hipStream_t s) {
   const long total = (long)rows * ncols;
   int gx = (int)((total + 1023) / 1024);
@@ -696,7 +704,7 @@ int qr_identity(cplx* C, long c_b0, int rows, int ncols, int nb0, hipStream_t s,
   return TJM_OK;
 }
 
-int qr_r_times_sigma(const cplx* Z, long z_b0, int zr, int ncols, const double* sigma, int sig_ld, const int* keep, int keep_stride, cplx* Rs,
+int qr_r_times_sigma(const cplx* Z, long z_b0, int zr, int ncols, const real* sigma, int sig_ld, const int* keep, int keep_stride, cplx* Rs,
                      long rs_b0, int nb0, hipStream_t s) {
   const long total = (long)ncols * ncols;
   int gx = (int)((total + 1023) / 1024);
@@ -775,7 +783,7 @@ int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hip
     if ((mp <= 512 && !no_rows) || mp > 384) {  // rows of the panel in registers: 1, 2 or 4 per thread
       static const bool wide = getenv("TJM_QR_WIDE_PANEL") != nullptr;  // diagnostic: the 512-thread kernel from 257 rows on
       const int nt = (mp <= 512 && !(wide && mp > 256)) ? 256 : 512;
-      const size_t lds = (size_t)(NRED * (nt + 1) + 2 * NRED + PW) * sizeof(double) + (size_t)(2 * PW + 2 * PW * PW + PW) * sizeof(cplx);
+      const size_t lds = (size_t)(NRED * (nt + 1) + 2 * NRED + PW) * sizeof(real) + (size_t)(2 * PW + 2 * PW * PW + PW) * sizeof(cplx);
       if (mp <= 256)
         hipLaunchKernelGGL(qr_panel_rows_kernel<1>, dim3(nb0), dim3(256), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
       else if (nt == 256)
@@ -783,7 +791,7 @@ int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hip
       else
         hipLaunchKernelGGL((qr_panel_rows_kernel<2, 512>), dim3(nb0), dim3(512), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
     } else {
-      const size_t lds = (size_t)(PW * (zr - k0) + 2 * PW * PW + PW) * sizeof(cplx) + PW * sizeof(double) + 64;
+      const size_t lds = (size_t)(PW * (zr - k0) + 2 * PW * PW + PW) * sizeof(cplx) + PW * sizeof(real) + 64;
       hipLaunchKernelGGL(qr_panel_kernel, dim3(nb0), dim3(64), lds, s, q.Z, q.z_b0, zr, k0, pw, q.V, q.v_b0, q.T, q.t_b0, panel, ids);
     }
     TJM_HIP_CHECK(hipGetLastError());

@@ -118,7 +118,7 @@ struct RunCtx {
   int T, cols;
   double* results;      // [B][n_obs][cols]
   double* diagnostics;  // [B][3][cols]
-  std::vector<cplx> M, M2;
+  std::vector<zc> M, M2;  // complex128 (host side of site_moments)
   std::vector<int> chi;
   bool need2 = false;
 };
@@ -130,18 +130,18 @@ int measure(RunCtx& r, int set, int col) {
   if (rc != TJM_OK) return rc;
   for (int k = 0; k < r.c->n_obs; ++k) {
     const int site = r.c->obs_site[k];
-    const cplx* O = reinterpret_cast<const cplx*>(r.c->obs_matrix) + (size_t)k * dd * dd;
+    const zc* O = reinterpret_cast<const zc*>(r.c->obs_matrix) + (size_t)k * dd * dd;
     const int n = (r.c->obs_nsites[k] == 2) ? dd : d;
     for (int b = 0; b < B; ++b) {
-      const cplx* Mb = (n == d) ? &r.M[((size_t)site * B + b) * dd] : &r.M2[((size_t)site * B + b) * dd * dd];
+      const zc* Mb = (n == d) ? &r.M[((size_t)site * B + b) * dd] : &r.M2[((size_t)site * B + b) * dd * dd];
       double re = 0.0, im = 0.0;
       for (int p = 0; p < n; ++p)
         for (int q = 0; q < n; ++q) {
-          const cplx o = O[p * n + q], m = Mb[p * n + q];
+          const zc o = O[p * n + q], m = Mb[p * n + q];
           re += o.x * m.x - o.y * m.y;
           im += o.x * m.y + o.y * m.x;
         }
-      if (!(im < 1e-13)) return TJM_ERR_ASSERT;  // "assert exp.imag < 1e-13" (mps.py:1233): a NaN fails it too
+      if (!(im < TJM_IMAG_TOL)) return TJM_ERR_ASSERT;  // "assert exp.imag < 1e-13" (mps.py:1233): a NaN fails it too
       r.results[((size_t)b * r.c->n_obs + k) * r.cols + col] = re;
     }
   }

@@ -43,13 +43,13 @@ struct JacobiArgs {
   int rx;       // rows of X (top part)
   int nblk;     // number of column blocks (even)
   int round;    // round-robin round
-  double tol2;  // squared relative tolerance
-  const double* fro2;
+  real tol2;  // squared relative tolerance
+  const real* fro2;
   int* nrot;
   const int* done;
   const int* ids;
   int mode;     // 0: round-robin pair of the round ; 1: sibling pair (2p, 2p+1) of 8-column blocks
-  double* rec;  // [B][MAXBLK/4][256][4] rotation record of the split X / W scheme (c, sr, si, flag)
+  real* rec;  // [B][MAXBLK/4][256][4] rotation record of the split X / W scheme (c, sr, si, flag)
   int* stamps;  // [B][STAMP_STRIDE]: mod[MAXBLK] | verd[MAXBLK] | nz[MAXBLK] | ver[MAXBLK*MAXBLK]   (visit pruning)
   int clock;    // launch counter, strictly increasing inside one solve
 };
@@ -70,14 +70,18 @@ __device__ inline void pair_of(int nblk, int round, int p, int& I, int& J) {
 // ---- wavefront all-reduce without LDS traffic: four DPP butterfly stages inside each row of 16 lanes
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row totals are read with v_readlane.
 template <int CTRL>
-__device__ inline double dpp_pull(double v) {
+__device__ inline real dpp_pull(real v) {
+#ifdef TJM_F32
+  return tjm_dpp<CTRL>(v);
+#else
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
+#endif
 }
 
-__device__ inline double row_total(double v) {
+__device__ inline real row_total(real v) {
   v += dpp_pull<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_pull<0x4E>(v);   // quad_perm [2,3,0,1]
   v += dpp_pull<0x141>(v);  // row_half_mirror
@@ -85,25 +89,35 @@ __device__ inline double row_total(double v) {
   return v;
 }
 
-__device__ inline double lane_value(double v, int lane) {
+__device__ inline real lane_value(real v, int lane) {
+#ifdef TJM_F32
+  return tjm_readlane(v, lane);
+#else
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
+#endif
 }
 
-__device__ inline double wave_sum(double v) {
+__device__ inline real wave_sum(real v) {
   v = row_total(v);
   return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
 // sum over lanes l ^ 16 and l ^ 32 with the gfx950 row / half-wave swap instructions (pure VALU, no LDS crossbar)
-__device__ inline double xor16_sum(double v) {
+__device__ inline real xor16_sum(real v) {
+#ifdef TJM_F32
+  return tjm_xor16_sum(v);
+#endif
   const int lo = __double2loint(v), hi = __double2hiint(v);
   const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
   const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
 }
-__device__ inline double xor32_sum(double v) {
+__device__ inline real xor32_sum(real v) {
+#ifdef TJM_F32
+  return tjm_xor32_sum(v);
+#endif
   const int lo = __double2loint(v), hi = __double2hiint(v);
   const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
   const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
@@ -111,19 +125,19 @@ __device__ inline double xor32_sum(double v) {
 }
 
 // Four wavefront sums for the price of two: a halving butterfly.  On return lane l holds the total of p[l & 3].
-__device__ inline double wave_sum4(double p0, double p1, double p2, double p3, int lane) {
+__device__ inline real wave_sum4(real p0, real p1, real p2, real p3, int lane) {
   const bool b0 = lane & 1, b1 = lane & 2;
-  const double x01 = (b0 ? p1 : p0) + dpp_pull<0xB1>(b0 ? p0 : p1);
-  const double x23 = (b0 ? p3 : p2) + dpp_pull<0xB1>(b0 ? p2 : p3);
-  double y = (b1 ? x23 : x01) + dpp_pull<0x4E>(b1 ? x01 : x23);
+  const real x01 = (b0 ? p1 : p0) + dpp_pull<0xB1>(b0 ? p0 : p1);
+  const real x23 = (b0 ? p3 : p2) + dpp_pull<0xB1>(b0 ? p2 : p3);
+  real y = (b1 ? x23 : x01) + dpp_pull<0x4E>(b1 ? x01 : x23);
   y += dpp_pull<0x124>(y);  // row_ror:4
   y += dpp_pull<0x128>(y);  // row_ror:8
   return xor32_sum(xor16_sum(y));
 }
 
-// fp64 reciprocal square root: hardware estimate + two Newton steps (full double precision)
-__device__ inline double fast_rsqrt(double x) {
-  double y = __builtin_amdgcn_rsq(x);
+// fp64 reciprocal square root: hardware estimate + two Newton steps (full real precision)
+__device__ inline real fast_rsqrt(real x) {
+  real y = tjm_rsq(x);
   y = y * fma(-0.5 * x * y, y, 1.5);
   y = y * fma(-0.5 * x * y, y, 1.5);
   return y;
@@ -132,26 +146,26 @@ __device__ inline double fast_rsqrt(double x) {
 // Decide and build the rotation for the column pair with norms (a, d) and inner product g.
 // Returns true when a rotation is applied; (c, sr + i si) as in
 //   y_p' = c y_p - conj(s) y_q ,  y_q' = s y_p + c y_q ,  a' = a - t|g| ,  d' = d + t|g|.
-__device__ inline bool make_rotation(double a, double d, double gx, double gy, double tol2, double nfloor, double& c, double& sr,
-                                     double& si, double& tg) {
-  const double mag2 = fma(gx, gx, gy * gy);
+__device__ inline bool make_rotation(real a, real d, real gx, real gy, real tol2, real nfloor, real& c, real& sr,
+                                     real& si, real& tg) {
+  const real mag2 = fma(gx, gx, gy * gy);
   // rotate only if the pair is non-orthogonal at the tolerance level and neither column sits at the rounding-noise floor of the
   // matrix.  (No lower bound on the angle: a rotation far below 1 ulp of the large column still carries the correction that makes
   // a column ten decades smaller orthogonal to it.) (sigma < 1e-13 ||X||_F: such columns are
   // numerically null, carry no weight, and would otherwise be rotated against rounding noise for ever)
-  if (!(mag2 > tol2 * a * d && a > nfloor && d > nfloor && mag2 > 1e-300)) return false;
-  const double inv_mag = fast_rsqrt(mag2);
-  const double mag = mag2 * inv_mag;
-  const double tau = 0.5 * (d - a) * inv_mag;
-  const double h2 = fma(tau, tau, 1.0);
-  const double hyp = h2 * fast_rsqrt(h2);                       // sqrt(1 + tau^2)
-  const double den = fabs(tau) + hyp;                           // >= 1
-  double t = __builtin_amdgcn_rcp(den);
+  if (!(mag2 > tol2 * a * d && a > nfloor && d > nfloor && mag2 > TJM_TINY)) return false;
+  const real inv_mag = fast_rsqrt(mag2);
+  const real mag = mag2 * inv_mag;
+  const real tau = 0.5 * (d - a) * inv_mag;
+  const real h2 = fma(tau, tau, 1.0);
+  const real hyp = h2 * fast_rsqrt(h2);                       // sqrt(1 + tau^2)
+  const real den = fabs(tau) + hyp;                           // >= 1
+  real t = tjm_rcp(den);
   t = t * fma(-den, t, 2.0);
   t = t * fma(-den, t, 2.0);
   t = (tau >= 0.0) ? t : -t;
   c = fast_rsqrt(fma(t, t, 1.0));
-  const double s = t * c;
+  const real s = t * c;
   sr = s * gx * inv_mag;
   si = s * gy * inv_mag;
   tg = t * mag;
@@ -161,32 +175,32 @@ __device__ inline bool make_rotation(double a, double d, double gx, double gy, d
 // The same decision and rotation, evaluated per lane for wave_sum4 output: lane classes (0,1) carry (Re g, Im g) of
 // the first pair, classes (2,3) of the second.  own = this lane's component of g; (a, d) the norms of its pair.
 // Returns c, sv = s * own / |g| (Re s on even lanes, Im s on odd lanes) and tg; (1, 0, 0) when no rotation applies.
-__device__ inline void make_rotation_lanes(double a, double d, double own, double tol2, double nfloor, double& c, double& sv, double& tg) {
-  const double sq = own * own;
-  const double mag2 = sq + dpp_pull<0xB1>(sq);  // identical in both lanes of the pair (addition commutes)
-  const bool rot = mag2 > tol2 * a * d && a > nfloor && d > nfloor && mag2 > 1e-300;
-  const double inv_mag = fast_rsqrt(mag2);
-  const double mag = mag2 * inv_mag;
-  const double tau = 0.5 * (d - a) * inv_mag;
-  const double h2 = fma(tau, tau, 1.0);
-  const double hyp = h2 * fast_rsqrt(h2);
-  const double den = fabs(tau) + hyp;
-  double t = __builtin_amdgcn_rcp(den);
+__device__ inline void make_rotation_lanes(real a, real d, real own, real tol2, real nfloor, real& c, real& sv, real& tg) {
+  const real sq = own * own;
+  const real mag2 = sq + dpp_pull<0xB1>(sq);  // identical in both lanes of the pair (addition commutes)
+  const bool rot = mag2 > tol2 * a * d && a > nfloor && d > nfloor && mag2 > TJM_TINY;
+  const real inv_mag = fast_rsqrt(mag2);
+  const real mag = mag2 * inv_mag;
+  const real tau = 0.5 * (d - a) * inv_mag;
+  const real h2 = fma(tau, tau, 1.0);
+  const real hyp = h2 * fast_rsqrt(h2);
+  const real den = fabs(tau) + hyp;
+  real t = tjm_rcp(den);
   t = t * fma(-den, t, 2.0);
   t = t * fma(-den, t, 2.0);
   t = (tau >= 0.0) ? t : -t;
-  const double cc = fast_rsqrt(fma(t, t, 1.0));
+  const real cc = fast_rsqrt(fma(t, t, 1.0));
   c = rot ? cc : 1.0;
   sv = rot ? t * cc * own * inv_mag : 0.0;
   tg = rot ? t * mag : 0.0;
 }
 
-__device__ inline void rotate_pair(cplx& p, cplx& q, double c, double sr, double si) {
+__device__ inline void rotate_pair(cplx& p, cplx& q, real c, real sr, real si) {
   // y_p' = c y_p - conj(s) y_q ; y_q' = s y_p + c y_q
-  const double npx = fma(-si, q.y, fma(-sr, q.x, c * p.x));
-  const double npy = fma(si, q.x, fma(-sr, q.y, c * p.y));
-  const double nqx = fma(c, q.x, fma(-si, p.y, sr * p.x));
-  const double nqy = fma(c, q.y, fma(si, p.x, sr * p.y));
+  const real npx = fma(-si, q.y, fma(-sr, q.x, c * p.x));
+  const real npy = fma(si, q.x, fma(-sr, q.y, c * p.y));
+  const real nqx = fma(c, q.x, fma(-si, p.y, sr * p.x));
+  const real nqy = fma(c, q.y, fma(si, p.x, sr * p.y));
   p = cplx{npx, npy};
   q = cplx{nqx, nqy};
 }
@@ -194,14 +208,14 @@ __device__ inline void rotate_pair(cplx& p, cplx& q, double c, double sr, double
 // ---- cross pairs of one block pair -----------------------------------------------------------
 template <int RK>
 __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   int b = blockIdx.y;
   if (g.ids) b = g.ids[b];
   if (g.done[b]) return;
   const int rtot = g.rtot, rx = g.rx;
   const int nrk = rtot >> 6;
   cplx* slots = reinterpret_cast<cplx*>(smem);                  // [8][rtot]
-  double* sN = reinterpret_cast<double*>(slots + NB * rtot);    // [8]
+  real* sN = reinterpret_cast<real*>(slots + NB * rtot);    // [8]
   int* sCnt = reinterpret_cast<int*>(sN + NB);                  // [8]
 
   int I, J;
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
       yJ[k] = cplx{0.0, 0.0};
     }
   }
-  double nI = 0.0, nJ = 0.0;
+  real nI = 0.0, nJ = 0.0;
 #pragma unroll
   for (int k = 0; k < RK; ++k) {
     if (k < nrk && lane + 64 * k < rx) {
@@ -241,10 +255,10 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
   }
   nI = wave_sum(nI);
   nJ = wave_sum(nJ);
-  const double floor2 = 1e-26 * g.fro2[b];
+  const real floor2 = TJM_NOISE_FLOOR2 * g.fro2[b];
   int cnt = 0;
   for (int s = 0; s < NB; ++s) {
-    double gx = 0.0, gy = 0.0;
+    real gx = 0.0, gy = 0.0;
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
       if (k < nrk && lane + 64 * k < rx) {
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
     }
     gx = wave_sum(gx);
     gy = wave_sum(gy);
-    double c, sr, si, tg;
+    real c, sr, si, tg;
     if (make_rotation(nI, nJ, gx, gy, g.tol2, floor2, c, sr, si, tg)) {
 #pragma unroll
       for (int k = 0; k < RK; ++k)
@@ -306,14 +320,14 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
 // column is read from / written to memory once per 256 rotations of the tile instead of once per 64.
 template <int RK>
 __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   int b = blockIdx.y;
   if (g.ids) b = g.ids[b];
   if (g.done[b]) return;
   const int rtot = g.rtot, rx = g.rx;
   const int nrk = rtot >> 6;
   cplx* slots = reinterpret_cast<cplx*>(smem);                      // [8][2][rtot]
-  double* sN = reinterpret_cast<double*>(slots + 2 * NB * rtot);    // [8][2]
+  real* sN = reinterpret_cast<real*>(slots + 2 * NB * rtot);    // [8][2]
   int* sCnt = reinterpret_cast<int*>(sN + 2 * NB);                  // [8]
   int I, J;
   pair_of(g.nblk / 2, g.round, blockIdx.x, I, J);                   // indices of 16-column blocks
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   cplx yI[2][RK], yJ[2][RK];
-  double nI[2] = {0.0, 0.0}, nJ[2] = {0.0, 0.0};
+  real nI[2] = {0.0, 0.0}, nJ[2] = {0.0, 0.0};
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const cplx* cI = Yb + (long)(I * 16 + 2 * w + h) * rtot;
@@ -357,13 +371,13 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
   }
   nI[0] = wave_sum(nI[0]); nI[1] = wave_sum(nI[1]);
   nJ[0] = wave_sum(nJ[0]); nJ[1] = wave_sum(nJ[1]);
-  const double floor2 = 1e-26 * g.fro2[b];
+  const real floor2 = TJM_NOISE_FLOOR2 * g.fro2[b];
   int cnt = 0;
   for (int s = 0; s < NB; ++s) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       // sub 0: (I0,J0) and (I1,J1) ; sub 1: (I0,J1) and (I1,J0) -- the two pairs of a sub-step are independent
-      double gx[2] = {0.0, 0.0}, gy[2] = {0.0, 0.0};
+      real gx[2] = {0.0, 0.0}, gy[2] = {0.0, 0.0};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int hj = h ^ sub;
@@ -380,7 +394,7 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int hj = h ^ sub;
-        double c, sr, si, tg;
+        real c, sr, si, tg;
         if (make_rotation(nI[h], nJ[hj], gx[h], gy[h], g.tol2, floor2, c, sr, si, tg)) {
 #pragma unroll
           for (int k = 0; k < RK; ++k)
@@ -446,17 +460,17 @@ constexpr int REC_PER_VISIT = 2 * NB * 2 * NB;  // 8 steps x 2 sub-steps x 8 wav
 // XRK = row groups of 64 of the X part held in registers: 1 ... 8 (rx_top = 64 XRK; 4 at d*chi = 256)
 template <int XRK>
 __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kernel(JacobiArgs g) {
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   int b = blockIdx.y;
   if (g.ids) b = g.ids[b];
   const bool record = g.rec != nullptr;  // without accumulation nothing replays the rotations
-  double* rec = record ? g.rec + ((long)b * gridDim.x + blockIdx.x) * (REC_PER_VISIT * 4) : nullptr;
+  real* rec = record ? g.rec + ((long)b * gridDim.x + blockIdx.x) * (REC_PER_VISIT * 4) : nullptr;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (g.done[b]) { if (tid == 0 && record) rec[3] = 0.0; return; }
   const int rtot = g.rtot;
   const int xr = 64 * XRK;
   cplx* slots = reinterpret_cast<cplx*>(smem);                    // [8][2][xr]
-  double* sN = reinterpret_cast<double*>(slots + 2 * NB * xr);    // [8][2]
+  real* sN = reinterpret_cast<real*>(slots + 2 * NB * xr);    // [8][2]
   int* sCnt = reinterpret_cast<int*>(sN + 2 * NB);                // [8]
   int I, J;
   pair_of(g.nblk / 2, g.round, blockIdx.x, I, J);
@@ -470,7 +484,7 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
   }
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
   cplx yI[2][XRK], yJ[2][XRK];
-  double nI[2] = {0.0, 0.0}, nJ[2] = {0.0, 0.0};
+  real nI[2] = {0.0, 0.0}, nJ[2] = {0.0, 0.0};
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const cplx* cI = Yb + (long)(I * 16 + 2 * w + h) * rtot;
@@ -485,12 +499,12 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
   }
   nI[0] = wave_sum(nI[0]); nI[1] = wave_sum(nI[1]);
   nJ[0] = wave_sum(nJ[0]); nJ[1] = wave_sum(nJ[1]);
-  const double floor2 = 1e-26 * g.fro2[b];
+  const real floor2 = TJM_NOISE_FLOOR2 * g.fro2[b];
   int cnt = 0;
   for (int s = 0; s < NB; ++s) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      double gx[2] = {0.0, 0.0}, gy[2] = {0.0, 0.0};
+      real gx[2] = {0.0, 0.0}, gy[2] = {0.0, 0.0};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int hj = h ^ sub;
@@ -501,12 +515,12 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
         }
       }
       // both inner products reduced together; both rotations computed side by side in lanes 0..3
-      const double gsum = wave_sum4(gx[0], gy[0], gx[1], gy[1], lane);
+      const real gsum = wave_sum4(gx[0], gy[0], gx[1], gy[1], lane);
       const bool second = lane & 2;
-      double cv, sv, tv;
+      real cv, sv, tv;
       make_rotation_lanes(second ? nI[1] : nI[0], second ? nJ[1 ^ sub] : nJ[sub], gsum, g.tol2, floor2, cv, sv, tv);
       if (record && lane < 4) {
-        double* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + (lane >> 1)) * 4);
+        real* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + (lane >> 1)) * 4);
         if (lane & 1) r4[2] = sv;
         else { r4[0] = cv; r4[1] = sv; }
       }
@@ -515,8 +529,8 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
         const int hj = h ^ sub;
         // applied unconditionally: (c, s) = (1, 0) leaves the columns bit-identical, and in the sweeps that matter almost every
         // pair rotates; the branch only bought register copies at its merge point
-        const double sr = lane_value(sv, 2 * h), si = lane_value(sv, 2 * h + 1);
-        const double c = lane_value(cv, 2 * h), tg = lane_value(tv, 2 * h);
+        const real sr = lane_value(sv, 2 * h), si = lane_value(sv, 2 * h + 1);
+        const real c = lane_value(cv, 2 * h), tg = lane_value(tv, 2 * h);
 #pragma unroll
         for (int k = 0; k < XRK; ++k) rotate_pair(yI[h][k], yJ[hj][k], c, sr, si);
         nI[h] -= tg;
@@ -570,7 +584,7 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
 __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int wrow0) {
   int b = blockIdx.z;
   if (g.ids) b = g.ids[b];
-  const double* __restrict__ rec = g.rec + ((long)b * gridDim.x + blockIdx.x) * (REC_PER_VISIT * 4);
+  const real* __restrict__ rec = g.rec + ((long)b * gridDim.x + blockIdx.x) * (REC_PER_VISIT * 4);
   if (rec[3] == 0.0) return;
   int I, J;
   pair_of(g.nblk / 2, g.round, blockIdx.x, I, J);
@@ -584,10 +598,10 @@ __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int w
     yJ[c] = Yb[(long)(J * 16 + c) * rtot];
   }
   // the 256 rotation records (c, sr, si) are spread over the lanes (4 records per lane) and broadcast with v_readlane
-  double pc[4], psr[4], psi[4];
+  real pc[4], psr[4], psi[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const double* r4 = rec + (long)(threadIdx.x + 64 * q) * 4;
+    const real* r4 = rec + (long)(threadIdx.x + 64 * q) * 4;
     pc[q] = r4[0];
     psr[q] = r4[1];
     psi[q] = r4[2];
@@ -601,9 +615,9 @@ __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int w
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int ridx = ((s * 2 + sub) * NB + w) * 2 + h;   // compile-time constant after unrolling
-          const double c = lane_value(pc[ridx >> 6], ridx & 63);
-          const double sr = lane_value(psr[ridx >> 6], ridx & 63);
-          const double si = lane_value(psi[ridx >> 6], ridx & 63);
+          const real c = lane_value(pc[ridx >> 6], ridx & 63);
+          const real sr = lane_value(psr[ridx >> 6], ridx & 63);
+          const real si = lane_value(psi[ridx >> 6], ridx & 63);
           // wavefront w rotated its I column 2w+h with the J column that started in wavefront (w+s) mod 8
           rotate_pair(yI[2 * w + h], yJ[2 * ((w + s) & (NB - 1)) + (h ^ sub)], c, sr, si);
         }
@@ -621,12 +635,12 @@ __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int w
 // the tiled kernels; zero columns are skipped.
 template <int RK>
 __global__ __launch_bounds__(1024) void jacobi_lds_kernel(JacobiArgs g, int ncols, int max_sweeps, int* n_unconverged) {
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   int b = blockIdx.x;
   if (g.ids) b = g.ids[b];
   const int rtot = g.rtot, rx = g.rx;
   cplx* tile = reinterpret_cast<cplx*>(smem);                     // [ncols][rtot]
-  double* sN = reinterpret_cast<double*>(tile + (long)ncols * rtot);  // [ncols]
+  real* sN = reinterpret_cast<real*>(tile + (long)ncols * rtot);  // [ncols]
   int* sCnt = reinterpret_cast<int*>(sN + ncols);                 // [16]
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -636,10 +650,10 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(JacobiArgs g, int ncol
       if (lane + 64 * k < rtot) tile[c * rtot + lane + 64 * k] = Yb[(long)c * rtot + lane + 64 * k];
   __syncthreads();
   bool converged = false;
-  double floor2 = 0.0;
+  real floor2 = 0.0;
   for (int sweep = 0; sweep < max_sweeps && !converged; ++sweep) {
     for (int c = w; c < ncols; c += 16) {  // column norms of the X part from the tile (no drift from the running updates)
-      double n = 0.0;
+      real n = 0.0;
 #pragma unroll
       for (int k = 0; k < RK; ++k)
         if (lane + 64 * k < rx) {
@@ -651,19 +665,19 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(JacobiArgs g, int ncol
     }
     __syncthreads();
     if (sweep == 0) {
-      double f = 0.0;
+      real f = 0.0;
       for (int c = 0; c < ncols; ++c) f += sN[c];
-      floor2 = 1e-26 * f;
+      floor2 = TJM_NOISE_FLOOR2 * f;
     }
     int cnt = 0;
     for (int s = 0; s < ncols - 1; ++s) {
       for (int pi = w; pi < ncols / 2; pi += 16) {
         int p, q;
         pair_of(ncols, s, pi, p, q);
-        const double a = sN[p], dd = sN[q];
+        const real a = sN[p], dd = sN[q];
         if (a == 0.0 || dd == 0.0) continue;  // padding columns
         cplx yp[RK], yq[RK];
-        double gx = 0.0, gy = 0.0;
+        real gx = 0.0, gy = 0.0;
 #pragma unroll
         for (int k = 0; k < RK; ++k) {
           if (lane + 64 * k < rtot) {
@@ -677,7 +691,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(JacobiArgs g, int ncol
         }
         gx = wave_sum(gx);
         gy = wave_sum(gy);
-        double c, sr, si, tg;
+        real c, sr, si, tg;
         if (make_rotation(a, dd, gx, gy, g.tol2, floor2, c, sr, si, tg)) {
 #pragma unroll
           for (int k = 0; k < RK; ++k) {
@@ -711,14 +725,14 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(JacobiArgs g, int ncol
 // ---- pairs inside one block (LDS resident) -----------------------------------------------------
 template <int RK>
 __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
-  extern __shared__ double smem[];
+  extern __shared__ real smem[];
   int b = blockIdx.y;
   if (g.ids) b = g.ids[b];
   if (g.done[b]) return;
   const int rtot = g.rtot, rx = g.rx;
   const int nrk = rtot >> 6;
   cplx* tile = reinterpret_cast<cplx*>(smem);                  // [8][rtot]
-  double* sN = reinterpret_cast<double*>(tile + NB * rtot);    // [8]
+  real* sN = reinterpret_cast<real*>(tile + NB * rtot);    // [8]
   int* sCnt = reinterpret_cast<int*>(sN + NB);                 // [4]
   int* st = g.stamps + (long)b * STAMP_STRIDE;
   const int I = blockIdx.x;
@@ -727,7 +741,7 @@ __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0 + (long)blockIdx.x * NB * rtot;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int c = w; c < NB; c += 4) {
-    double n = 0.0;
+    real n = 0.0;
     for (int k = 0; k < nrk; ++k) {
       const cplx v = Yb[(long)c * rtot + lane + 64 * k];
       tile[c * rtot + lane + 64 * k] = v;
@@ -737,13 +751,13 @@ __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
     if (lane == 0) sN[c] = n;
   }
   __syncthreads();
-  const double floor2 = 1e-26 * g.fro2[b];
+  const real floor2 = TJM_NOISE_FLOOR2 * g.fro2[b];
   int cnt = 0;
   for (int s = 0; s < NB - 1; ++s) {
     int p, q;
     pair_of(NB, s, w, p, q);
     cplx yp[RK], yq[RK];
-    double gx = 0.0, gy = 0.0;
+    real gx = 0.0, gy = 0.0;
 #pragma unroll
     for (int k = 0; k < RK; ++k) {
       if (k < nrk) {
@@ -757,8 +771,8 @@ __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
     }
     gx = wave_sum(gx);
     gy = wave_sum(gy);
-    double c, sr, si, tg;
-    const double a = sN[p], d = sN[q];
+    real c, sr, si, tg;
+    const real a = sN[p], d = sN[q];
     if (make_rotation(a, d, gx, gy, g.tol2, floor2, c, sr, si, tg)) {
 #pragma unroll
       for (int k = 0; k < RK; ++k) {
@@ -814,12 +828,12 @@ __global__ __launch_bounds__(256) void jacobi_load_kernel(JacobiSource src, cplx
 
 // squared Frobenius norm of the source (noise floor of the rotations)
 __global__ __launch_bounds__(256) void jacobi_fro_kernel(const cplx* __restrict__ Y, long y_b0, int ncols_pad, int rx_top, int rtot,
-                                                        double* fro2, const int* ids) {
-  __shared__ double sh[4];
+                                                        real* fro2, const int* ids) {
+  __shared__ real sh[4];
   int b = blockIdx.x;
   if (ids) b = ids[b];
   const cplx* Yb = Y + (long)b * y_b0;
-  double acc = 0.0;
+  real acc = 0.0;
   const long total = (long)ncols_pad * rx_top;
   for (long e = threadIdx.x; e < total; e += blockDim.x) {
     const long c = e / rx_top, r = e % rx_top;
@@ -890,7 +904,7 @@ constexpr int SMALL_MAXN = 16;
 // straight into the neighbouring tensor.  Replaces ~12 launches and one host synchronisation per sweep.
 // Cyclic-by-rows one-sided Jacobi on the n columns Y[j * pitch + 0 .. pitch) held in LDS by ONE wavefront (lane = row), with the rotation rule of
 // the large kernels.  Returns false when 40 sweeps did not converge.
-__device__ inline bool small_jacobi(cplx* Y, int pitch, int n, int lane, double floor2) {
+__device__ inline bool small_jacobi(cplx* Y, int pitch, int n, int lane, real floor2) {
   bool converged = n < 2;
   const bool mine = lane < pitch;  // rows beyond the pitch do not exist (and would be zero)
   for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
@@ -899,11 +913,11 @@ __device__ inline bool small_jacobi(cplx* Y, int pitch, int n, int lane, double 
       for (int qc = pc + 1; qc < n; ++qc) {
         cplx yp = mine ? Y[pc * pitch + lane] : cplx{0.0, 0.0}, yq = mine ? Y[qc * pitch + lane] : cplx{0.0, 0.0};
         // the four sums of the pair (two norms, the inner product) in ONE packed butterfly; lanes 0..3 hold the totals
-        const double packed = wave_sum4(fma(yp.x, yp.x, yp.y * yp.y), fma(yq.x, yq.x, yq.y * yq.y), fma(yp.x, yq.x, yp.y * yq.y),
+        const real packed = wave_sum4(fma(yp.x, yp.x, yp.y * yp.y), fma(yq.x, yq.x, yq.y * yq.y), fma(yp.x, yq.x, yp.y * yq.y),
                                         fma(yp.x, yq.y, -yp.y * yq.x), lane);
-        const double a = lane_value(packed, 0), dd = lane_value(packed, 1), gx = lane_value(packed, 2), gy = lane_value(packed, 3);
-        double c, sr, si, tg;
-        if (make_rotation(a, dd, gx, gy, 1e-26, floor2, c, sr, si, tg)) {
+        const real a = lane_value(packed, 0), dd = lane_value(packed, 1), gx = lane_value(packed, 2), gy = lane_value(packed, 3);
+        real c, sr, si, tg;
+        if (make_rotation(a, dd, gx, gy, TJM_JACOBI_TOL2, floor2, c, sr, si, tg)) {
           rotate_pair(yp, yq, c, sr, si);
           if (mine) {
             Y[pc * pitch + lane] = yp;
@@ -926,14 +940,14 @@ __device__ inline int truncation_keep(const TruncSpec& d, int nsv, SV sv) {
   if (d.trunc_mode == 2) {  // hard_cutoff
     for (int k = 0; k < nsv; ++k) keep += (sv(k) > d.threshold) ? 1 : 0;
   } else if (d.trunc_mode == 1) {  // relative
-    const double smax = sv(0);
+    const real smax = sv(0);
     if (smax > 0.0)
       for (int k = 0; k < nsv; ++k) keep += ((sv(k) / smax) >= d.threshold) ? 1 : 0;
   } else if (d.trunc_mode == 0) {  // discarded_weight
     keep = nsv;
-    double discard = 0.0;
+    real discard = 0.0;
     for (int idx = 0; idx < nsv; ++idx) {
-      const double s = sv(nsv - 1 - idx);
+      const real s = sv(nsv - 1 - idx);
       discard += s * s;
       if (discard >= d.threshold) {
         keep = nsv - idx;
@@ -942,15 +956,15 @@ __device__ inline int truncation_keep(const TruncSpec& d, int nsv, SV sv) {
       }
     }
   } else {  // relative_discarded_weight
-    const double smax = sv(0);
+    const real smax = sv(0);
     if (smax > 0.0) {
-      double total = 0.0;
-      for (int k = 0; k < nsv; ++k) { const double q = sv(k) / smax; total += q * q; }
+      real total = 0.0;
+      for (int k = 0; k < nsv; ++k) { const real q = sv(k) / smax; total += q * q; }
       keep = nsv;
-      double discard = 0.0;
+      real discard = 0.0;
       for (int idx = 0; idx < nsv; ++idx) {
-        const double q = sv(nsv - 1 - idx) / smax;
-        const double cand = discard + q * q;
+        const real q = sv(nsv - 1 - idx) / smax;
+        const real cand = discard + q * q;
         if (cand / total <= d.threshold) { discard = cand; keep = nsv - idx - 1; }
         else break;
       }
@@ -981,7 +995,7 @@ __device__ inline void small_absorb(cplx* __restrict__ Nb, const cplx (*G)[SMALL
 #pragma unroll
     for (int j = 0; j < SMALL_MAXN; ++j) old[j] = (j < n) ? Nb[base + j * stride] : cplx{0.0, 0.0};
     for (int k = 0; k < ncap; ++k) {
-      double ax = 0.0, ay = 0.0;
+      real ax = 0.0, ay = 0.0;
       if (k < keep) {
 #pragma unroll
         for (int j = 0; j < SMALL_MAXN; ++j) {
@@ -1003,8 +1017,8 @@ struct SmallLds {
   int pitch;
   cplx G[SMALL_MAXN][SMALL_MAXN];
   cplx diag[SMALL_MAXN];
-  double norm[SMALL_MAXN];
-  double beta[SMALL_MAXN];
+  real norm[SMALL_MAXN];
+  real beta[SMALL_MAXN];
   int perm[SMALL_MAXN];
   int keep;
 };
@@ -1014,7 +1028,7 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
   cplx* Y = sm.Y;
   const int pitch = sm.pitch;
   cplx (*G)[SMALL_MAXN] = sm.G;
-  double* sNorm = sm.norm;
+  real* sNorm = sm.norm;
   int* sPerm = sm.perm;
   int& sKeep = sm.keep;
   const int d = p.d, ca = p.ca, cb = p.cb;
@@ -1031,7 +1045,7 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
     if (LEFT) { const int t = r / cb, c = r - t * cb; return ((long)t * ca + j) * cb + c; }
     return (long)r * cb + j;
   };
-  double fro = 0.0;
+  real fro = 0.0;
   for (int j = 0; j < n; ++j) {
     cplx v{0.0, 0.0};
     if (lane < R) {
@@ -1042,22 +1056,22 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
     fro = fma(v.x, v.x, fma(v.y, v.y, fro));
   }
   fro = wave_sum(fro);
-  const double floor2 = 1e-26 * fro;
+  const real floor2 = TJM_NOISE_FLOOR2 * fro;
   __syncthreads();
   const bool converged = small_jacobi(Y, pitch, n, lane, floor2);
   if (!converged && lane == 0 && p.flags) atomicOr(p.flags + 1, 1);
   // norms, descending rank sort (ties by index), truncation
   for (int j = 0; j < n; ++j) {
     const cplx v = (lane < pitch) ? Y[j * pitch + lane] : cplx{0.0, 0.0};
-    const double s2 = wave_sum(fma(v.x, v.x, v.y * v.y));
+    const real s2 = wave_sum(fma(v.x, v.x, v.y * v.y));
     if (lane == 0) sNorm[j] = s2;
   }
   __syncthreads();
   if (lane < n) {
-    const double v = sNorm[lane];
+    const real v = sNorm[lane];
     int rank = 0;
     for (int o = 0; o < n; ++o) {
-      const double u = sNorm[o];
+      const real u = sNorm[o];
       rank += (u > v || (u == v && o < lane)) ? 1 : 0;
     }
     sPerm[rank] = lane;
@@ -1067,9 +1081,9 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
     int keep = 0;
     if (nsv > 0) {
       keep = nsv;
-      double discard = 0.0;
+      real discard = 0.0;
       for (int idx = 0; idx < nsv; ++idx) {
-        const double s = sqrt(sNorm[sPerm[nsv - 1 - idx]]);
+        const real s = sqrt(sNorm[sPerm[nsv - 1 - idx]]);
         discard += s * s;
         if (discard >= p.threshold) {
           keep = nsv - idx;
@@ -1090,8 +1104,8 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
   for (int e = lane; e < keep * n; e += 64) {
     const int k = e / n, j = e - k * n;
     const int col = sPerm[k];
-    const double inv = 1.0 / sqrt(sNorm[col]);
-    double ax = 0.0, ay = 0.0;
+    const real inv = 1.0 / sqrt(sNorm[col]);
+    real ax = 0.0, ay = 0.0;
     for (int r = 0; r < R; ++r) {
       const cplx u = Y[col * pitch + r];
       cplx x = A[site_index(r, j)];
@@ -1113,7 +1127,7 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
       cplx v{0.0, 0.0};
       if (k < keep) {
         const int col = sPerm[k];
-        const double inv = 1.0 / sqrt(sNorm[col]);
+        const real inv = 1.0 / sqrt(sNorm[col]);
         v = Y[col * pitch + lane];
         v.x *= inv;
         v.y *= LEFT ? -inv : inv;
@@ -1124,7 +1138,7 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
   small_absorb<LEFT>(p.nb + (long)b * p.nb_b0, G, d, ca, cb, p.cn, n, keep, ncap, lane);
 }
 
-extern __shared__ double small_dyn_lds[];
+extern __shared__ real small_dyn_lds[];
 
 template <bool LEFT>
 __global__ __launch_bounds__(64) void svd_shift_small_kernel(SmallShiftDesc p, int pitch) {
@@ -1146,7 +1160,7 @@ template <int MAXN>
 __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, TruncSpec tr, int* flags, int pitch) {
   cplx* Y = reinterpret_cast<cplx*>(small_dyn_lds);  // [MAXN][pitch]
   __shared__ cplx G[MAXN][MAXN];
-  __shared__ double sNorm[MAXN];
+  __shared__ real sNorm[MAXN];
   __shared__ int sPerm[MAXN];
   __shared__ int sKeep;
   int b = blockIdx.x;
@@ -1168,7 +1182,7 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
     v.y = -v.y;
     return v;
   };
-  double fro = 0.0;
+  real fro = 0.0;
   for (int j = 0; j < n; ++j) {
     const cplx v = (lane < R) ? theta_at(lane, j) : cplx{0.0, 0.0};
     if (lane < pitch) Y[j * pitch + lane] = v;
@@ -1176,19 +1190,19 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
   }
   fro = wave_sum(fro);
   __syncthreads();
-  const bool converged = small_jacobi(Y, pitch, n, lane, 1e-26 * fro);
+  const bool converged = small_jacobi(Y, pitch, n, lane, TJM_NOISE_FLOOR2 * fro);
   if (!converged && lane == 0) atomicOr(flags + 3, 1);
   for (int j = 0; j < n; ++j) {
     const cplx v = (lane < pitch) ? Y[j * pitch + lane] : cplx{0.0, 0.0};
-    const double s2 = wave_sum(fma(v.x, v.x, v.y * v.y));
+    const real s2 = wave_sum(fma(v.x, v.x, v.y * v.y));
     if (lane == 0) sNorm[j] = s2;
   }
   __syncthreads();
   if (lane < n) {
-    const double v = sNorm[lane];
+    const real v = sNorm[lane];
     int rank = 0;
     for (int o = 0; o < n; ++o) {
-      const double u = sNorm[o];
+      const real u = sNorm[o];
       rank += (u > v || (u == v && o < lane)) ? 1 : 0;
     }
     sPerm[rank] = lane;
@@ -1198,7 +1212,7 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
     const int keep = truncation_keep(tr, min(nsv, n), [&](int k) { return sqrt(sNorm[sPerm[k]]); });
     sKeep = keep;
     tr.chiOut[(long)b * tr.chi_stride] = keep;
-    if (keep > 0 && sqrt(sNorm[sPerm[keep - 1]]) <= 1e-11 * sqrt(sNorm[sPerm[0]])) atomicOr(flags + 2, 1);
+    if (keep > 0 && sqrt(sNorm[sPerm[keep - 1]]) <= TJM_RANK_TOL * sqrt(sNorm[sPerm[0]])) atomicOr(flags + 2, 1);
   }
   if (tr.spectrum)
     for (int k = lane; k < tr.spec_ld; k += 64) tr.spectrum[(long)b * tr.spec_ld + k] = (k < n) ? sqrt(sNorm[sPerm[k]]) : 0.0;
@@ -1208,8 +1222,8 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
   for (int e = lane; e < keep * n; e += 64) {
     const int k = e / n, j = e - k * n;
     const int col = sPerm[k];
-    const double inv = 1.0 / sqrt(sNorm[col]);
-    double ax = 0.0, ay = 0.0;
+    const real inv = 1.0 / sqrt(sNorm[col]);
+    real ax = 0.0, ay = 0.0;
     for (int r = 0; r < R; ++r) {
       const cplx u = Y[col * pitch + r];
       const cplx x = theta_at(r, j);
@@ -1232,7 +1246,7 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
       cplx v{0.0, 0.0};
       if (k < keep) {
         const int col = sPerm[k];
-        const double inv = 1.0 / sqrt(sNorm[col]);
+        const real inv = 1.0 / sqrt(sNorm[col]);
         v = Y[col * pitch + lane];
         v.x *= inv;
         v.y *= d0 ? inv : -inv;
@@ -1272,7 +1286,7 @@ __device__ inline void qr_site_small_body(const SmallQrDesc& p, int b, int lane,
   const int pitch = sm.pitch;
   cplx (*G)[SMALL_MAXN] = sm.G;
   cplx* sDiag = sm.diag;
-  double* sBeta = sm.beta;
+  real* sBeta = sm.beta;
   const int d = p.d, ca = p.ca, cb = p.cb;
   cplx* __restrict__ A = p.site + (long)b * p.site_b0;
   int* chi = p.chi + (long)b * p.chi_stride;
@@ -1291,25 +1305,25 @@ __device__ inline void qr_site_small_body(const SmallQrDesc& p, int b, int lane,
   for (int k = 0; k < kn; ++k) {
     const bool in = lane >= k && lane < rows_act;
     cplx x = in ? Z[k * pitch + lane] : cplx{0.0, 0.0};
-    const double nx2 = wave_sum(fma(x.x, x.x, x.y * x.y));
+    const real nx2 = wave_sum(fma(x.x, x.x, x.y * x.y));
     if (nx2 == 0.0) {  // nothing below the diagonal and a zero pivot: H_k = 1
       if (lane == 0) { sDiag[k] = cplx{0.0, 0.0}; sBeta[k] = 0.0; }
       __syncthreads();
       continue;
     }
     const cplx xk = Z[k * pitch + k];
-    const double nx = sqrt(nx2), ak = sqrt(fma(xk.x, xk.x, xk.y * xk.y));
-    const double px = ak > 0.0 ? xk.x / ak : 1.0, py = ak > 0.0 ? xk.y / ak : 0.0;
+    const real nx = sqrt(nx2), ak = sqrt(fma(xk.x, xk.x, xk.y * xk.y));
+    const real px = ak > 0.0 ? xk.x / ak : 1.0, py = ak > 0.0 ? xk.y / ak : 0.0;
     const cplx alpha{-px * nx, -py * nx};
-    const double beta = 1.0 / (nx * (nx + ak));  // 2 / |v|^2
+    const real beta = 1.0 / (nx * (nx + ak));  // 2 / |v|^2
     if (lane == k) { x.x -= alpha.x; x.y -= alpha.y; }
     __syncthreads();  // every lane has read Z[k][k]
     if (in) Z[k * pitch + lane] = x;
     if (lane == 0) { sDiag[k] = alpha; sBeta[k] = beta; }
     for (int j = k + 1; j < n; ++j) {
       cplx y = in ? Z[j * pitch + lane] : cplx{0.0, 0.0};
-      const double wr = beta * wave_sum(fma(x.x, y.x, x.y * y.y));   // beta * conj(v) . y
-      const double wi = beta * wave_sum(fma(x.x, y.y, -x.y * y.x));
+      const real wr = beta * wave_sum(fma(x.x, y.x, x.y * y.y));   // beta * conj(v) . y
+      const real wi = beta * wave_sum(fma(x.x, y.y, -x.y * y.x));
       if (in) {
         y.x -= wr * x.x - wi * x.y;
         y.y -= wr * x.y + wi * x.x;
@@ -1342,12 +1356,12 @@ __device__ inline void qr_site_small_body(const SmallQrDesc& p, int b, int lane,
     if (c < kn) {
       if (lane == c) q.x = 1.0;
       for (int k = c; k >= 0; --k) {
-        const double beta = sBeta[k];
+        const real beta = sBeta[k];
         if (beta == 0.0) continue;
         const bool in = lane >= k && lane < rows_act;
         const cplx v = in ? Z[k * pitch + lane] : cplx{0.0, 0.0};
-        const double wr = beta * wave_sum(fma(v.x, q.x, v.y * q.y));
-        const double wi = beta * wave_sum(fma(v.x, q.y, -v.y * q.x));
+        const real wr = beta * wave_sum(fma(v.x, q.x, v.y * q.y));
+        const real wi = beta * wave_sum(fma(v.x, q.y, -v.y * q.x));
         q.x -= wr * v.x - wi * v.y;
         q.y -= wr * v.y + wi * v.x;
       }
@@ -1426,7 +1440,7 @@ __global__ __launch_bounds__(64) void small_sweep_kernel(SmallSweepDesc p) {
 
 // Column norms of the X part, descending rank sort, truncation (svd_utils.py:22-104).
 __global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspace w, int ncols_pad, int rx, int rtot, const int* ids) {
-  __shared__ double sN[1024];
+  __shared__ real sN[1024];
   __shared__ int sPerm[1024];
   int b = blockIdx.x;
   if (ids) b = ids[b];
@@ -1434,7 +1448,7 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = wave; c < ncols_pad; c += 4) {
     const cplx* col = Yb + (long)c * rtot;
-    double acc = 0.0;
+    real acc = 0.0;
     for (int r = lane; r < rx; r += 64) {
       cplx v = col[r];
       acc = fma(v.x, v.x, acc);
@@ -1445,17 +1459,17 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspa
   }
   __syncthreads();
   for (int c = tid; c < ncols_pad; c += 256) {
-    const double v = sN[c];
+    const real v = sN[c];
     int rank = 0;
     for (int o = 0; o < ncols_pad; ++o) {
-      const double u = sN[o];
+      const real u = sN[o];
       rank += (u > v || (u == v && o < c)) ? 1 : 0;
     }
     sPerm[rank] = c;
   }
   __syncthreads();
   int* perm = w.perm + (long)b * ncols_pad;
-  double* norms = w.norms + (long)b * ncols_pad;
+  real* norms = w.norms + (long)b * ncols_pad;
   for (int k = tid; k < ncols_pad; k += 256) {
     perm[k] = sPerm[k];
     norms[k] = sqrt(sN[sPerm[k]]);
@@ -1471,8 +1485,8 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspa
     // kept columns at the rounding-noise floor were never rotated: their normalised columns are not orthogonal to the rest,
     // so the caller must not take them as singular vectors (n_active[2] != 0 selects the re-orthonormalising path)
     if (keep > 0 && w.n_active != nullptr) {
-      const double s0 = sqrt(sN[sPerm[0]]);
-      if (sqrt(sN[sPerm[keep - 1]]) <= 1e-11 * s0) atomicOr(w.n_active + 2, 1);
+      const real s0 = sqrt(sN[sPerm[0]]);
+      if (sqrt(sN[sPerm[keep - 1]]) <= TJM_RANK_TOL * s0) atomicOr(w.n_active + 2, 1);
     }
   }
   if (d.spectrum) {
@@ -1487,7 +1501,7 @@ __global__ __launch_bounds__(256) void svd_extract_kernel(ExtractDesc x, SvdWork
   if (ids) b = ids[b];
   const cplx* Yb = w.Y + (long)b * w.y_b0;
   const int* perm = w.perm + (long)b * ncols_pad;
-  const double* sig = w.norms + (long)b * ncols_pad;
+  const real* sig = w.norms + (long)b * ncols_pad;
   const int keep = chi_keep[(long)b * chi_stride];
   cplx* out = x.out + (long)b * x.out_b0;
   const long nrows = (long)x.n_r1 * x.n_r0;
@@ -1503,9 +1517,9 @@ __global__ __launch_bounds__(256) void svd_extract_kernel(ExtractDesc x, SvdWork
       v = Yb[(long)perm[k] * rtot + x.row_off + r];
       if (x.conj) v.y = -v.y;
       if (x.scale_mode == 1) { v.x *= sig[k]; v.y *= sig[k]; }
-      else if (x.scale_mode == 2) { const double inv = (sig[k] > 0.0) ? 1.0 / sig[k] : 0.0; v.x *= inv; v.y *= inv; }
-      else if (x.scale_mode == 3) { const double r = sqrt(sig[k]); v.x *= r; v.y *= r; }
-      else if (x.scale_mode == 4) { const double inv = (sig[k] > 0.0) ? 1.0 / sqrt(sig[k]) : 0.0; v.x *= inv; v.y *= inv; }
+      else if (x.scale_mode == 2) { const real inv = (sig[k] > 0.0) ? 1.0 / sig[k] : 0.0; v.x *= inv; v.y *= inv; }
+      else if (x.scale_mode == 3) { const real r = sqrt(sig[k]); v.x *= r; v.y *= r; }
+      else if (x.scale_mode == 4) { const real inv = (sig[k] > 0.0) ? 1.0 / sqrt(sig[k]) : 0.0; v.x *= inv; v.y *= inv; }
     }
     out[(long)k * x.o_k + (long)r1 * x.o_r1 + (long)r0 * x.o_r0] = v;
   }
@@ -1518,7 +1532,7 @@ struct CrossProfile {
   int every = 0;  // 0 = off, otherwise every N-th launch is bracketed by events
   long counter = 0;
   std::vector<hipEvent_t> pool;
-  std::vector<std::pair<int, double>> pending;  // (event pair index, bytes)
+  std::vector<std::pair<int, real>> pending;  // (event pair index, bytes)
   size_t used = 0;
   double total_ms = 0.0, total_bytes = 0.0;
   long samples = 0;
@@ -1607,10 +1621,10 @@ size_t svd_carve(SvdWorkspace& w, char* base, int max_dim, int B) {
   const int p = round_up(max_dim, 32);
   w.y_b0 = svd_y_elems(max_dim);
   w.Y = reinterpret_cast<cplx*>(take((size_t)B * w.y_b0 * sizeof(cplx)));
-  w.norms = reinterpret_cast<double*>(take((size_t)B * p * sizeof(double)));
+  w.norms = reinterpret_cast<real*>(take((size_t)B * p * sizeof(real)));
   w.perm = reinterpret_cast<int*>(take((size_t)B * p * sizeof(int)));
-  w.fro2 = reinterpret_cast<double*>(take((size_t)B * sizeof(double)));
-  w.rec = reinterpret_cast<double*>(take((size_t)B * (MAXBLK / 4) * REC_PER_VISIT * 4 * sizeof(double)));
+  w.fro2 = reinterpret_cast<real*>(take((size_t)B * sizeof(real)));
+  w.rec = reinterpret_cast<real*>(take((size_t)B * (MAXBLK / 4) * REC_PER_VISIT * 4 * sizeof(real)));
   w.stamps = reinterpret_cast<int*>(take((size_t)B * STAMP_STRIDE * sizeof(int)));
   w.nrot = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   w.done = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
@@ -1658,10 +1672,10 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     if (gx > 256) gx = 256;
     hipLaunchKernelGGL(jacobi_load_kernel, dim3(gx, src.nb0), dim3(256), 0, s, src, w.Y, w.y_b0, ncols_pad, rx_top, rtot);
     JacobiArgs g;
-    g.Y = w.Y; g.y_b0 = w.y_b0; g.rtot = rtot; g.rx = rx_top; g.nblk = ncols_pad / NB; g.tol2 = 1e-26; g.fro2 = nullptr; g.nrot = nullptr;
+    g.Y = w.Y; g.y_b0 = w.y_b0; g.rtot = rtot; g.rx = rx_top; g.nblk = ncols_pad / NB; g.tol2 = TJM_JACOBI_TOL2; g.fro2 = nullptr; g.nrot = nullptr;
     g.done = nullptr; g.ids = src.ids; g.round = 0; g.stamps = nullptr; g.clock = 0; g.mode = 0; g.rec = nullptr;
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 3 * sizeof(int), s));
-    const size_t lds_bytes = (size_t)ncols_pad * rtot * sizeof(cplx) + (size_t)ncols_pad * sizeof(double) + 32 * sizeof(int);
+    const size_t lds_bytes = (size_t)ncols_pad * rtot * sizeof(cplx) + (size_t)ncols_pad * sizeof(real) + 32 * sizeof(int);
     if (rtot <= 64) hipLaunchKernelGGL(jacobi_lds_kernel<1>, dim3(src.nb0), dim3(1024), lds_bytes, s, g, ncols_pad, 40, w.n_active);
     else hipLaunchKernelGGL(jacobi_lds_kernel<2>, dim3(src.nb0), dim3(1024), lds_bytes, s, g, ncols_pad, 40, w.n_active);
     hipLaunchKernelGGL(svd_finish_kernel, dim3(src.nb0), dim3(256), 0, s, tr, w, ncols_pad, rx_top, rtot, src.ids);
@@ -1687,7 +1701,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
     attr_set = true;
   }
-  const size_t lds = (size_t)NB * rtot * sizeof(cplx) + NB * sizeof(double) + 16 * sizeof(int);
+  const size_t lds = (size_t)NB * rtot * sizeof(cplx) + NB * sizeof(real) + 16 * sizeof(int);
   const int tb = (src.nb0 + 255) / 256;
   hipLaunchKernelGGL(svd_reset_kernel, dim3(tb), dim3(256), 0, s, w.nrot, w.done, src.nb0, src.ids);
   {
@@ -1704,7 +1718,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   g.rtot = rtot;
   g.rx = rx_top;
   g.nblk = ncols_pad / NB;
-  g.tol2 = 1e-26;  // relative off-diagonal tolerance 1e-13
+  g.tol2 = TJM_JACOBI_TOL2;  // relative off-diagonal tolerance 1e-13 (fp64)
   g.fro2 = w.fro2;
   g.nrot = w.nrot;
   g.done = w.done;
@@ -1716,8 +1730,8 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   if (g.nblk > MAXBLK) return TJM_ERR_NOT_IMPLEMENTED;
   const int nrounds = tile16 ? (g.nblk / 2 - 1) : (g.nblk - 1);
   const int npairs = tile16 ? g.nblk / 4 : g.nblk / 2;
-  const size_t lds16 = (size_t)2 * NB * rtot * sizeof(cplx) + 2 * NB * sizeof(double) + 16 * sizeof(int);
-  const size_t lds16x = (size_t)2 * NB * rx_top * sizeof(cplx) + 2 * NB * sizeof(double) + 16 * sizeof(int);
+  const size_t lds16 = (size_t)2 * NB * rtot * sizeof(cplx) + 2 * NB * sizeof(real) + 16 * sizeof(int);
+  const size_t lds16x = (size_t)2 * NB * rx_top * sizeof(cplx) + 2 * NB * sizeof(real) + 16 * sizeof(int);
   g.rec = accumulate ? w.rec : nullptr;
   const int max_sweeps = 40;
   // Sub-batches (TJM_SVD_CHUNK=n trajectories, default off): all sweeps of one chunk before the next, so that the chunk's stacked
@@ -1778,7 +1792,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
         }
         if (timed) {  // the timed kernel is the X-rows kernel alone: its tile is the X part of the 32 columns, read + written once
           TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot + 1], s));
-          g_prof.pending.emplace_back(slot, (double)npairs * n_live * 4.0 * NB * rx_top * sizeof(cplx) * 2.0);
+          g_prof.pending.emplace_back(slot, (real)npairs * n_live * 4.0 * NB * rx_top * sizeof(cplx) * 2.0);
         }
         if (accumulate) hipLaunchKernelGGL(jacobi_cross16w_kernel, dim3(npairs, ncols_pad / 64, nb), dim3(64), 0, s, g, rx_top);
       } else if (tile16) hipLaunchKernelGGL(jacobi_cross16_kernel<8>, dim3(npairs, nb), dim3(512), lds16, s, g);

@@ -21,13 +21,14 @@ def _i32(a) -> np.ndarray:
 
 class BatchEngine:
     def __init__(self, length: int, chi_max: int, batch: int, mpo: Sequence[np.ndarray], device: str = "cuda:0", d: int = 2, stream=None,
-                 cap_slack: int = 1):
+                 cap_slack: int = 1, dtype: str = "complex128"):
         import torch
 
         if not torch.cuda.is_available():
             raise _lib.TjmError("yaqs_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU path")
         self.torch = torch
-        self.lib = _lib.load()
+        self.dtype = dtype  # "complex128" (the reference's precision) or "complex64" (libtjm_hip_f32.so: fp32 arithmetic and storage)
+        self.lib = _lib.load(dtype)
         self.L, self.d, self.chi_max, self.B = int(length), int(d), int(chi_max), int(batch)
         self.device = torch.device(device)
         bonds = [int(mpo[0].shape[2])] + [int(w.shape[3]) for w in mpo]
@@ -54,9 +55,10 @@ class BatchEngine:
         self.padded_elems = int(self.lib.tjm_engine_padded_state_elems(self.h))
 
     @staticmethod
-    def workspace_bytes_for(length: int, chi_max: int, batch: int, mpo: Sequence[np.ndarray], d: int = 2, cap_slack: int = 1) -> int:
+    def workspace_bytes_for(length: int, chi_max: int, batch: int, mpo: Sequence[np.ndarray], d: int = 2, cap_slack: int = 1,
+                            dtype: str = "complex128") -> int:
         """Device bytes an engine of this shape binds (no GPU needed): used to size the batch to the free HBM."""
-        lib = _lib.load()
+        lib = _lib.load(dtype)
         bonds = _i32([int(mpo[0].shape[2])] + [int(w.shape[3]) for w in mpo])
         h = C.c_void_p()
         _lib.check(lib.tjm_engine_create_ex(C.byref(h), int(length), int(d), int(chi_max), int(batch), bonds.ctypes.data, int(cap_slack)), "create")

@@ -230,7 +230,8 @@ class TrajectoryBatch:
                 val = np.einsum("pq,bpq->b", O, M2[site])   # <theta| O |theta> on the merged pair (mps.py:999-1047)
             else:
                 val = np.einsum("pq,bpq->b", O, M[site])
-            if not np.all(val.imag < 1e-13):  # "assert exp.imag < 1e-13" (mps.py:1233): a non-finite value fails it too
+            # "assert exp.imag < 1e-13" (mps.py:1233; an fp64 rounding bound: 1e-5 on the complex64 engine): a non-finite value fails it too
+            if not np.all(val.imag < (1e-13 if getattr(e, "dtype", "complex128") == "complex128" else 1e-5)):
                 raise AssertionError(f"Measurement should be real, got max imag {np.nanmax(val.imag) if not np.all(np.isnan(val.imag)) else np.nan:.3e}")
             results[:, row, col] = val.real
         diagnostics[:, :, col] = _diagnostics_from_bonds(e.bond_dims(set_index), e.d)
@@ -621,10 +622,16 @@ class Simulator:
     """
 
     def __init__(self, batch: int | None = None, device: str | None = None, show_progress: bool = False, native: bool = True,
-                 parallel: bool = True, max_workers: int | None = None):
+                 parallel: bool = True, max_workers: int | None = None, dtype: str = "complex128"):
         # parallel / max_workers configure the reference's process pool (simulator.py:60-130); here the trajectories of a run are
         # batched on the GPU instead, so the arguments are accepted for source compatibility and have no effect on the results
         self.parallel, self.max_workers = parallel, max_workers
+        # "complex128": the reference's arithmetic (mps.py:231), trajectory-by-trajectory parity.  "complex64": fp32 arithmetic and
+        # storage on the device (libtjm_hip_f32.so) - half the HBM per trajectory, twice the vector rate; jump decisions are
+        # discontinuous, so parity with the reference is statistical (ensemble means), not per trajectory.
+        if dtype not in ("complex128", "complex64"):
+            raise ValueError(f'dtype must be "complex128" or "complex64", got {dtype!r}')
+        self.dtype = dtype
         self.batch = batch
         self.device = device
         self._engine_kw: dict = {}
@@ -744,6 +751,8 @@ class Simulator:
         chi, chi_top = engine_bond_caps(sim_params, initial_state, can_grow=_noise_can_grow_bonds(noise_model))
         mode = getattr(sim_params, "evolution_mode", "tdvp")
         self._engine_kw = {"cap_slack": 2} if str(getattr(mode, "value", mode)) == "bug" else {}
+        if self.dtype != "complex128":
+            self._engine_kw["dtype"] = self.dtype
         if d != 2:
             self._engine_kw["d"] = d  # qutrits / four-level sites: one local dimension per chain (engine storage [B][d][cap][cap])
         cols = len(sim_params.times) if sim_params.sample_timesteps else 1
@@ -820,6 +829,8 @@ class Simulator:
             # them back (digital_tjm.py:536-557): the storage holds four times the cap and four times the exact ranks near the ends
             slack = 4
             self._engine_kw = {"cap_slack": 4}
+        if self.dtype != "complex128":
+            self._engine_kw["dtype"] = self.dtype
         chi, chi_top = engine_bond_caps(sim_params, initial_state, can_grow=True, slack=slack)  # every TEBD gate is a truncated split
         mid = sim_params.num_mid_measurements if sim_params.sample_layers else 0
         cols = (mid + 2) if sim_params.sample_layers else 1
