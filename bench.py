@@ -240,6 +240,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="tfim", help="tfim is BASELINE.json's headline configuration")
     ap.add_argument("--tdvp-mode", choices=["2site", "1site"], default="2site")
     ap.add_argument("--dt", type=float, default=0.1)
+    ap.add_argument("--dtype", choices=["complex128", "complex64"], default="complex128",
+                    help="complex128 is the reference's arithmetic and the headline; complex64 runs libtjm_hip_f32.so (fp32 arithmetic and storage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, nargs="*", default=[32], help="worker counts of the full-step CPU rows besides P = 1")
     args = ap.parse_args()
@@ -297,7 +299,7 @@ def main():
     first = rank * B
     engines, trajs = [], []
     for k, nb in enumerate(sizes):
-        eng = BatchEngine(L, chi, nb, mpo.tensors, device=device, stream=torch.cuda.Stream(device=device) if E > 1 else None)
+        eng = BatchEngine(L, chi, nb, mpo.tensors, device=device, stream=torch.cuda.Stream(device=device) if E > 1 else None, dtype=args.dtype)
         eng.set_params(dt=dt, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=args.krylov_tol, tdvp_mode=args.tdvp_mode)
         eng.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
         eng.load_state(st.tensors)
@@ -415,7 +417,7 @@ def main():
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f64",  # arithmetic type; the tensors are complex128 (interleaved re, im)
+            "dtype": "f64" if args.dtype == "complex128" else "f32",  # arithmetic type; the tensors are complex (interleaved re, im)
             "data": "synthetic",
             "config": {
                 "workload": f"{L}-site {WORKLOADS[args.workload][0]}, chi={chi}, dt={dt:g}, "
@@ -425,7 +427,7 @@ def main():
                 "engines_per_gpu": E,
                 "steps_per_trajectory": STEPS_PER_TRAJ,
                 "parallelism": f"trajectory-sharded x{world}",
-                "storage": "complex128",
+                "storage": args.dtype,
             },
             "site_updates_per_sec": site_updates,
             "counters_per_step": {k_: v / K / E for k_, v in cnt.items()},
@@ -437,7 +439,7 @@ def main():
                 "bound": "fp64-valu",
                 "kernel": "SVD family: jacobi_cross16x_kernel (dominant) + jacobi_* + qr_* + svd_finish/extract, per batched SVD",
                 "achieved": svd_tf,
-                "peak": FP64_PEAK_TFLOPS,
+                "peak": FP64_PEAK_TFLOPS if args.dtype == "complex128" else 2 * FP64_PEAK_TFLOPS,  # fp32 vector rate = 157.3 TFLOP/s
                 "unit": "TFLOP/s",
                 "frac": (svd_tf / FP64_PEAK_TFLOPS) if svd_tf else None,
                 "traffic": traffic,

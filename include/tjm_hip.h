@@ -4,6 +4,11 @@
  * passes torch.Tensor.data_ptr()).  Every function returns 0 (TJM_OK) or a negative
  * error code.  All complex data is complex128 stored interleaved (re, im).
  *
+ * libtjm_hip_f32.so is the same sources compiled with -DTJM_F32: fp32 arithmetic and complex64 device
+ * storage behind the SAME entry points.  Host arrays of the engine-level calls stay float64 / complex128 and
+ * are converted at the boundary; only the kernel-level parity exports, whose operands are device pointers,
+ * take complex64 / float32 device arrays there.
+ *
  * The reference (munich-quantum-toolkit/yaqs) has no FFI; the seam this library sits
  * behind is its backend-function contract, simulator.py:164-185 / 1539-1547:
  *     backend((traj_idx, MPS, NoiseModel|None, AnalogSimParams, MPO))
