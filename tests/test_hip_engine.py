@@ -1944,6 +1944,37 @@ def test_complex64_engine_tracks_the_fp64_oracle():
             assert np.array_equal(dg[t], do), (order, t)
 
 
+def test_complex64_circuit_paths_track_the_reference_fixtures():
+    """The circuit path on the complex64 engine against the REFERENCE's outputs (tests/golden/digital.npz, digital_mpo.npz) at fp32
+    accuracy with identical bond diagnostics: the noisy Trotter circuit (TEBD gates, Pauli jumps) and the long-range circuit under the
+    default gate_mode (gate-MPO product + compression, local one- and two-site noise)."""
+    from yaqs_amd.api import DigitalSimParams, GateLayer, MPS, NoiseModel, Observable, X as Xg, Z as Zg, ising_trotter_layers, rx_matrix
+    from yaqs_amd.engine import BatchEngine
+    from yaqs_amd.tjm import DigitalBatch
+
+    g, gm = load("digital"), load("digital_mpo")
+    L, steps = 8, 5
+    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 3)]
+    mpo = o.ising_mpo(L, 1.0, 0.5)
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.01} for i in range(L) for n in ("pauli_x", "pauli_y", "pauli_z")])
+    p = DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-9, random_seed=3)
+    e = BatchEngine(L, 16, 6, mpo, dtype="complex64")
+    r, d = DigitalBatch(e, p, noise).run(list(range(6)), MPS(L, state="zeros"), ising_trotter_layers(L, 1.0, 0.5, 0.1, steps))
+    e.close()
+    assert np.allclose(r[:, :, 0], g["noisy_results"][:, :, 0], atol=1e-4)
+    assert np.array_equal(d, g["noisy_diag"])
+    cx, rzz = g["lr_cx_matrix"], g["lr_rzz_matrix"]
+    layers = [GateLayer([(q, rx_matrix(0.3 + 0.1 * q)) for q in range(L)], [(1, 5, cx), (6, 2, rzz)], [(4, 3, cx), (7, 0, cx)], 0) for _ in range(2)]
+    noise3 = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)] +
+                        [{"name": "crosstalk_zz", "sites": [1, 5], "strength": 0.1}, {"name": "lowering", "sites": [6], "strength": 0.2}])
+    p = DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-8, random_seed=11, num_traj=6)
+    e = BatchEngine(L, 64, 6, mpo, cap_slack=4, dtype="complex64")
+    r, d = DigitalBatch(e, p, noise3).run(list(range(6)), MPS(L, state="zeros"), layers)
+    e.close()
+    assert np.allclose(r, gm["chi16_noisy_results"], atol=1e-4)
+    assert np.array_equal(d, gm["chi16_noisy_diag"])
+
+
 def test_complex64_ensemble_means_agree_with_the_fp64_ensemble():
     """The statistical parity the survey asks of the fp32 variant ("ensemble means within 3 sigma / sqrt(N) of the fp64
     ensemble"): N trajectories of a dissipative chain through Simulator(dtype="complex64") and through the fp64 engine; the means of
