@@ -829,6 +829,49 @@ def gen_digital_mpo():
     save("digital_mpo", **out)
 
 
+# ------------------------------------------------------------------ 18. long-range gates by TDVP on a window (gate_mode "tdvp" / "full-tdvp")
+def gen_digital_tdvp():
+    """digital_tjm with gate_mode="tdvp" (distant pairs with a product-form generator by two-site TDVP on a window,
+    digital_tjm.py:408-453; nearest neighbours by TEBD) and "full-tdvp" (nearest neighbours by TDVP too): rzz / rxx / ryy gates on
+    distant and adjacent pairs in both site orders, local noise, with a cap (renorm_drift active) and without."""
+    dtm = ref("digital.digital_tjm")
+    L = 8
+
+    def layer():
+        singles = []
+        for q in range(L):
+            gt = gl.GateLibrary.rx([0.3 + 0.1 * q]); gt.set_sites(q); singles.append(gt)
+        a = gl.GateLibrary.rzz([0.7]); a.set_sites(1, 5)
+        b = gl.GateLibrary.rxx([0.4]); b.set_sites(6, 2)
+        c = gl.GateLibrary.ryy([0.9]); c.set_sites(4, 3)
+        d_ = gl.GateLibrary.rzz([1.1]); d_.set_sites(7, 0)
+        return dtm._CompiledCircuitLayer(tuple(singles), (a, b), (c, d_), 0)
+
+    out = {}
+    for name, g_ in (("rzz07", gl.GateLibrary.rzz([0.7])), ("rxx04", gl.GateLibrary.rxx([0.4])), ("ryy09", gl.GateLibrary.ryy([0.9])), ("rzz11", gl.GateLibrary.rzz([1.1]))):
+        g_.set_sites(0, 1)  # the generator is attached with the sites
+        out[name + "_matrix"] = np.asarray(g_.matrix)
+        out[name + "_gen0"] = np.asarray(g_.generator[0])
+        out[name + "_gen1"] = np.asarray(g_.generator[1])
+    st = MPS(L, state="zeros")
+    st.normalize("B")
+    obs = [sp.Observable(gl.Z(), s) for s in range(L)] + [sp.Observable(gl.X(), 3)]
+    noise = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)] + [{"name": "lowering", "sites": [6], "strength": 0.2}])
+    cc = dtm._CompiledCircuit(tuple(layer() for _ in range(2)), 0)
+    for mode in ("tdvp", "full-tdvp"):
+        for chi in (4, None):
+            p = sp.DigitalSimParams(observables=obs, max_bond_dim=chi, svd_threshold=1e-8, krylov_tol=1e-10, random_seed=11, gate_mode=mode)
+            for name, nm, ntraj in ((f"{mode}_chi{chi}_noisy", noise, 4), (f"{mode}_chi{chi}_noiseless", None, 1)):
+                res, diag = [], []
+                for i in range(ntraj):
+                    r, dg, _, _ = dtm.digital_tjm((i, st, nm, p, None), compiled_circuit=cc)
+                    res.append(np.asarray(r, dtype=np.float64))
+                    diag.append(dg)
+                out[name + "_results"] = np.array(res)
+                out[name + "_diag"] = np.array(diag)
+    save("digital_tdvp", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tiny", "rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
     for w in which:

@@ -517,7 +517,9 @@ class DigitalBatch:
             e.step_compress(self.p.svd_threshold, self.p.max_bond_dim, self.p.trunc_mode)
             return {s0, s1}, 0  # step_compress leaves the centre on site 0 (the reference moves it to L // 2: a gauge choice)
         if right - left > 1 and mode != "swaps":
-            # "tdvp" / "full-tdvp" evolve a window with the gate's generator (digital_tjm.py:408-453): not built
+            # "tdvp" / "full-tdvp" evolve a window with the gate's generator (digital_tjm.py:408-453): not built - the reference's own
+            # numbers are rounding-defined at the 1e-4 level there (a zero singular value kept by min_keep = 2 seeds the next projector;
+            # tests/test_oracle_golden.py::test_digital_gates_by_tdvp_on_a_window_are_rounding_defined), nothing to reproduce to 1e-8
             raise NotImplementedError(f"long-range gate on sites ({s0}, {s1}) needs gate_mode='mpo' or 'swaps' (got {self.p.gate_mode!r})")
         center = 0
         for i in range(right - 1, left, -1):  # bring the right qubit next to the left one
