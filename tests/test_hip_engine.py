@@ -1944,6 +1944,44 @@ def test_complex64_engine_tracks_the_fp64_oracle():
             assert np.array_equal(dg[t], do), (order, t)
 
 
+def test_complex64_dynamic_tdvp_and_bug_track_the_fp64_oracle():
+    """The host-driven integrators on the complex64 engine (site-level steps, stacked bases, compression): one dynamic-TDVP sweep and
+    one BUG step on the generic-state chains of tests/golden/f3_dynamic_bug.npz against the fp64 oracle - same bond dimensions,
+    overlap defect below 1e-5."""
+    from types import SimpleNamespace
+
+    from yaqs_amd.engine import BatchEngine
+    from yaqs_amd.tjm import bug_step, dynamic_tdvp
+
+    g = load("f3_dynamic_bug")
+    for key in ("L5_c4_cap4_haar", "L8_c8_cap8_haar"):
+        L, cap = int(key.split("_")[0][1:]), int(key.split("_")[2][3:])
+        mpo, init = tensors(g, key + "_mpo"), tensors(g, key + "_in")
+        e = BatchEngine(L, 16, 2, mpo, dtype="complex64")
+        e.set_params(dt=0.1, svd_threshold=1e-7, max_bond_dim=cap, krylov_tol=1e-6, tdvp_mode="dynamic")
+        e.load_state(init)
+        dynamic_tdvp(e, 0, cap, 0.1, 1)
+        out = e.export_state(0)
+        e.close()
+        st = o.MPSState([t.copy() for t in init], 0)
+        o.tdvp(st, mpo, o.Params(dt=0.1, svd_threshold=1e-7, max_bond_dim=cap, krylov_tol=1e-10, tdvp_mode="dynamic", reference_dynamic_transpose=False))
+        assert [t.shape[2] for t in out] == [t.shape[2] for t in st.tensors], key
+        ref = st.to_vec()
+        assert abs(abs(np.vdot(ref, vec_of(out))) - np.vdot(ref, ref).real) < 1e-5, key
+        e = BatchEngine(L, 32, 2, mpo, cap_slack=2, dtype="complex64")
+        e.set_params(dt=0.1, svd_threshold=1e-7, max_bond_dim=cap, krylov_tol=1e-6)
+        e.load_state(init)
+        bug_step(e, 0, SimpleNamespace(dt=0.1, svd_threshold=1e-7, max_bond_dim=cap, trunc_mode="discarded_weight"), mpo)
+        e.normalize_qr(0)
+        out = e.export_state(0)
+        e.close()
+        st = o.MPSState([t.copy() for t in init], 0)
+        o.bug(st, mpo, o.Params(dt=0.1, svd_threshold=1e-7, max_bond_dim=cap, krylov_tol=1e-10))
+        assert [t.shape[2] for t in out] == [t.shape[2] for t in st.tensors], key
+        ref = st.to_vec()
+        assert abs(abs(np.vdot(ref, vec_of(out))) - np.vdot(ref, ref).real) < 1e-5, key
+
+
 def test_complex64_circuit_paths_track_the_reference_fixtures():
     """The circuit path on the complex64 engine against the REFERENCE's outputs (tests/golden/digital.npz, digital_mpo.npz) at fp32
     accuracy with identical bond diagnostics: the noisy Trotter circuit (TEBD gates, Pauli jumps) and the long-range circuit under the
