@@ -108,20 +108,22 @@ __device__ inline real wave_sum(real v) {
 __device__ inline real xor16_sum(real v) {
 #ifdef TJM_F32
   return tjm_xor16_sum(v);
-#endif
+#else
   const int lo = __double2loint(v), hi = __double2hiint(v);
   const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
   const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+#endif
 }
 __device__ inline real xor32_sum(real v) {
 #ifdef TJM_F32
   return tjm_xor32_sum(v);
-#endif
+#else
   const int lo = __double2loint(v), hi = __double2hiint(v);
   const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
   const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
   return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+#endif
 }
 
 // Four wavefront sums for the price of two: a halving butterfly.  On return lane l holds the total of p[l & 3].
