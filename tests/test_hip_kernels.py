@@ -698,3 +698,33 @@ def test_svd_split_sqrt_distribution_matches_oracle(lib, capL, capR):
         gr_ = right[b][:, :k, :].transpose(1, 0, 2).reshape(k, d * capR)
         assert np.allclose(np.linalg.norm(gl_, axis=0), np.linalg.norm(gr_, axis=1), rtol=1e-9)   # sqrt(S) on both sides
         assert np.all(left[b][:, :, k:] == 0) and np.all(right[b][:, k:, :] == 0)
+
+
+@pytest.fixture(scope="module")
+def lib32():
+    """libtjm_hip_f32.so (the complex64 build): its kernel-level exports take complex64 / float32 device arrays."""
+    from yaqs_amd import _lib
+
+    if SIM:
+        from simengine import load_sim
+
+        return load_sim("complex64")
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _lib.load("complex64")
+
+
+@pytest.mark.parametrize("M,N,K,conjA,conjB", [(64, 64, 16, 0, 0), (70, 50, 37, 1, 0), (128, 96, 64, 0, 1), (3, 5, 2, 1, 1), (17, 200, 33, 0, 0), (130, 9, 4, 1, 1),
+                                               (31, 31, 127, 0, 1)])
+def test_gemm_of_the_complex64_library(lib32, M, N, K, conjA, conjB):
+    """The batched complex GEMM of the complex64 build (v_mfma_f32_16x16x4_f32, whose result registers map to rows 4 (l >> 4) + v
+    instead of the f64 form's (l >> 4) + 4 v): tiled kernel and one-tile-per-wavefront kernel, conjugated operands, odd shapes."""
+    rng = np.random.default_rng(M * 1000 + N + K)
+    nb = 3
+    a, b = crand(rng, nb, M, K).astype(np.complex64), crand(rng, nb, K, N).astype(np.complex64)
+    A, B = dev(a), dev(b)
+    Cc = torch.zeros((nb, M, N), dtype=torch.complex64, device=DEV)
+    run_gemm(lib32, A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, a_rs=K, a_cs=1, b_rs=N, b_cs=1, c_rs=N,
+             nb0=nb, a_b0=M * K, b_b0=K * N, c_b0=M * N, conjA=conjA, conjB=conjB)
+    a64, b64 = a.astype(np.complex128), b.astype(np.complex128)
+    ref = np.einsum("bmk,bkn->bmn", a64.conj() if conjA else a64, b64.conj() if conjB else b64)
+    assert np.allclose(Cc.cpu().numpy(), ref, atol=3e-6 * K)
