@@ -728,3 +728,39 @@ def test_gemm_of_the_complex64_library(lib32, M, N, K, conjA, conjB):
     a64, b64 = a.astype(np.complex128), b.astype(np.complex128)
     ref = np.einsum("bmk,bkn->bmn", a64.conj() if conjA else a64, b64.conj() if conjB else b64)
     assert np.allclose(Cc.cpu().numpy(), ref, atol=3e-6 * K)
+
+
+@pytest.mark.parametrize("capL,capR,qr", [(8, 8, False), (32, 32, False), (40, 32, True), (64, 64, True)])
+def test_svd_split_of_the_complex64_library(lib32, capL, capR, qr):
+    """Two-site split of the complex64 build (fused small kernel, LDS-resident and tiled Jacobi with fp32 tolerances, Householder
+    panels): singular values to 1e-5 of the largest, isometric left factor, reconstruction of theta to fp32 accuracy."""
+    from yaqs_amd._lib import check
+
+    rng = np.random.default_rng(capL * 10 + capR)
+    d, B = 2, 2
+    capM = min(d * capL, d * capR)
+    theta = crand(rng, B, d * capL, d * capR).astype(np.complex64)
+    th = dev(theta)
+    left = torch.zeros((B, d, capL, capM), dtype=torch.complex64, device=DEV)
+    right = torch.zeros((B, d, capM, capR), dtype=torch.complex64, device=DEV)
+    chi = dev(np.stack([np.full(B, capL), np.full(B, capR), np.zeros(B)], axis=1).astype(np.int32))
+    spec_ld = d * max(capL, capR)
+    spec = torch.zeros((B, spec_ld), dtype=torch.float32, device=DEV)
+    nbytes = (lib32.tjm_svd_qr_workspace_bytes if qr else lib32.tjm_svd_workspace_bytes)(d * max(capL, capR), B)
+    work = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    sweeps = C.c_int32(0)
+    fn = lib32.tjm_svd_split_qr if qr else lib32.tjm_svd_split
+    check(fn(th.data_ptr(), B, d, capL, capR, capM, left.data_ptr(), right.data_ptr(), 0, 0, 0.0, capM, 1, chi.data_ptr(), spec.data_ptr(), spec_ld,
+             work.data_ptr(), nbytes, C.byref(sweeps), None), "svd_split")
+    _sync()
+    for b in range(B):
+        s_ref = np.linalg.svd(theta[b].astype(np.complex128), compute_uv=False)
+        k = int(chi.cpu().numpy()[b, 2])
+        assert k == capM
+        got = spec.cpu().numpy()[b, :k]
+        assert np.allclose(got, s_ref[:k], atol=1e-5 * s_ref[0]), b
+        lf = left.cpu().numpy()[b].astype(np.complex128).reshape(d * capL, capM)
+        rf = right.cpu().numpy()[b].astype(np.complex128).transpose(1, 0, 2).reshape(capM, d * capR)
+        assert np.allclose(lf.conj().T @ lf, np.eye(capM), atol=2e-5)
+        # left[(s,a),k] right[k,(t,c)] = theta[(s,a),(t,c)] with rows (s, a) and columns (t, c)
+        assert np.allclose(lf @ rf, theta[b].astype(np.complex128), atol=2e-5 * s_ref[0])
