@@ -26,15 +26,15 @@ def _inputs(L, chi):
     return api, [np.asarray(t, dtype=np.complex128) for t in st.tensors]
 
 
-def _one_step(L, chi, mpo, proc, gamma, dt, tdvp_mode, tensors, trajs):
+def _one_step(L, chi, mpo, proc, gamma, dt, tdvp_mode, tensors, trajs, dtype="complex128"):
     """tdvp -> dissipate -> stochastic -> <Z_i> through the stage entry points of the C ABI, one slot per trajectory."""
     from yaqs_amd.api import NoiseModel, is_pauli
     from yaqs_amd.engine import BatchEngine
     from yaqs_amd.tjm import trajectory_uniforms
 
     B = len(trajs)
-    e = BatchEngine(L, chi, B, mpo.tensors)
-    e.set_params(dt=dt, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=1e-10, tdvp_mode=tdvp_mode)
+    e = BatchEngine(L, chi, B, mpo.tensors, dtype=dtype)
+    e.set_params(dt=dt, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=1e-10 if dtype == "complex128" else 1e-6, tdvp_mode=tdvp_mode)
     noise = NoiseModel([{"name": proc, "sites": [i], "strength": gamma} for i in range(L)])
     e.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
     e.load_state(tensors)
@@ -89,3 +89,28 @@ def test_config3_full_size_step_matches_the_reference():
         pytest.skip("cfg3 fixture not generated")
     api, t = _inputs(128, 256)
     _check("cfg3", *_one_step(128, 256, api.MPO.heisenberg(128, 1.0, 1.0, 0.5, 0.0), "lowering", 0.05, 0.05, "2site", t, list(g["cfg3_traj"])))
+
+
+@pytest.mark.parametrize("name,L,chi", [("cfg2", 64, 128), ("cfg3", 128, 256)])
+def test_full_size_steps_in_complex64_follow_the_reference(name, L, chi):
+    """BASELINE.json quotes config 3 (and 5) in fp32: the same full-size steps on the complex64 engine (libtjm_hip_f32.so) against the
+    REFERENCE's complex128 outputs - 256 x 256 and 512 x 512 two-site splits, 512 x 256 centre shifts, Lanczos and environments in
+    fp32.  fp32 accuracy: dp and <Z> to 2e-4 where the jump decision coincides (a draw within that distance of dp may flip it), every
+    bond at the cap as in the reference."""
+    g = np.load(os.path.join(GOLDEN, "fullsize.npz"))
+    if name + "_z" not in g:
+        pytest.skip("fixture not generated")
+    api, t = _inputs(L, chi)
+    if name == "cfg2":
+        args = (api.MPO.ising(L, 1.0, 0.5), "pauli_z", 0.1, 0.1, "2site")
+    else:
+        args = (api.MPO.heisenberg(L, 1.0, 1.0, 0.5, 0.0), "lowering", 0.05, 0.05, "2site")
+    z, dp, jumped, bonds = _one_step(L, chi, *args, t, list(g[name + "_traj"]), dtype="complex64")
+    assert np.allclose(dp, g[name + "_dp"], atol=2e-4), (dp, g[name + "_dp"])
+    want_jump = g[name + "_u0"] < g[name + "_dp"]
+    safe = np.abs(g[name + "_u0"] - g[name + "_dp"]) > 1e-3
+    assert np.array_equal(jumped.astype(bool)[safe], want_jump[safe])
+    same = jumped.astype(bool) == want_jump
+    assert same.any()
+    assert np.abs(z[same] - g[name + "_z"][same]).max() < 2e-4
+    assert np.array_equal(bonds[same], g[name + "_bonds"][same])
