@@ -1181,53 +1181,6 @@ def test_randomised_configurations_match_oracle(case):
         assert np.array_equal(d[t], do), (case, t)
 
 
-@pytest.mark.parametrize("case", range(int(os.environ.get("TJM_FUZZ_GENERAL_CASES", "24"))))
-def test_randomised_general_path_configurations_match_oracle(case):
-    """The differential test of test_randomised_configurations_match_oracle on the THROUGHPUT kernels (bond caps 24 - 128, chains of
-    10 - 20 sites): MFMA GEMMs, Lanczos kernels, Householder panels, tiled / LDS-resident Jacobi with QR preconditioning, the
-    capacity ladder.  Seeded random set-ups: chain length, cap, a chi-saturated or partly saturated Haar state, a truncation rule that
-    leaves ragged bonds, TDVP mode, driver order, Hamiltonian (Ising / Heisenberg D = 5 / exponential-sum long-range D = 4), and a noise
-    model with non-Pauli and Pauli one-site channels plus an adjacent pair channel, strong enough to jump within two steps."""
-    from yaqs_amd.api import AnalogSimParams, MPO, NoiseModel, Observable, X as Xg, Z as Zg
-
-    rng = np.random.default_rng(7000 + case)
-    chi = int([24, 48, 96, 128][case % 4])
-    L = int(rng.integers({24: 10, 48: 12, 96: 14, 128: 14}[chi], {24: 21, 48: 21, 96: 18, 128: 17}[chi]))  # 2**(L//2) >= chi: the cap is reached
-    order = int(rng.choice([1, 2]))
-    mode = str(rng.choice(["2site", "2site", "1site"]))
-    trunc = str(rng.choice(["discarded_weight", "relative"]))
-    thr = float(10.0 ** rng.uniform(-9, -4))  # bites unevenly: the bonds after the first step differ from site to site
-    start = int(rng.choice([chi, max(8, chi // 2)]))  # saturated, or bonds that still grow into the cap (capacity ladder)
-    st = o.MPSState.haar(L, start, np.random.default_rng(case))
-    st.normalize("B")
-    init = [t.copy() for t in st.tensors]
-    procs = []
-    for i in range(L):
-        for name in rng.choice(["lowering", "raising", "pauli_x", "pauli_z"], size=int(rng.integers(1, 3)), replace=False):
-            procs.append({"name": str(name), "sites": [i], "strength": float(rng.uniform(0.05, 0.5))})
-    i = int(rng.integers(0, L - 1))
-    procs.append({"name": "crosstalk_xz", "sites": [i, i + 1], "strength": float(rng.uniform(0.05, 0.3))})
-    if mode == "2site" and rng.random() < 0.5:
-        i = int(rng.integers(0, L - 1))
-        m = np.kron(o.JUMP_OPS["lowering"], np.array([[1, 0], [0, -1]])) + 0.3 * np.kron(np.eye(2), o.JUMP_OPS["raising"])
-        procs.append({"name": "custom", "sites": [i, i + 1], "strength": float(rng.uniform(0.05, 0.3)), "matrix": m})
-    noise = NoiseModel(procs)
-    which = int(rng.integers(0, 3))
-    mpo = [MPO.ising(L, 1.0, 0.6), MPO.heisenberg(L, 1.0, 0.7, 0.4, 0.25), MPO.long_range_ising(L, [0.8, 0.3], [0.5, 0.8], 0.7)][which]
-    sites = sorted(set(int(x) for x in rng.integers(0, L, size=6)))
-    obs = [Observable(Zg(), s_) for s_ in sites] + [Observable(Xg(), sites[0])]
-    oobs = [o.Obs(Z, s_) for s_ in sites] + [o.Obs(X, sites[0])]
-    kw = dict(elapsed_time=0.2, dt=0.1, max_bond_dim=chi, svd_threshold=thr, trunc_mode=trunc, krylov_tol=1e-10, order=order, sample_timesteps=True,
-              random_seed=int(rng.integers(0, 10 ** 6)), tdvp_mode=mode)
-    r, d, tb = _run(L, init, noise, AnalogSimParams(observables=obs, **kw), mpo.tensors, [0, 1], native=bool(rng.integers(0, 2)))
-    op = o.Params(observables=oobs, **kw)
-    on = [o.make_process(q["name"], q["sites"], q["strength"], matrix=q.get("matrix"), factors=q.get("factors")) for q in noise.processes]
-    for t in range(2):
-        ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, [w.copy() for w in mpo.tensors])
-        assert np.allclose(r[t], ro, atol=1e-8), (case, t, np.abs(r[t] - ro).max(), kw, L, which)
-        assert np.array_equal(d[t], do), (case, t)
-
-
 @pytest.mark.parametrize("case", range(int(os.environ.get("TJM_FUZZ_CASES", "80"))))
 def test_randomised_circuits_match_oracle(case):
     """Differential test of the circuit path on seeded random circuits: random one-qubit unitaries, random two-qubit unitaries on
@@ -1450,592 +1403,3 @@ def test_output_state_answers_the_inspection_helpers():
     pr = np.linalg.svd(vec, compute_uv=False) ** 2
     pr = pr[pr > 1e-300]
     assert abs(out.get_entropy([i, i + 1]) - (-np.sum(pr * np.log(pr)))) < 1e-9
-
-
-def test_schmidt_spectrum_through_the_front_end():
-    """Simulator.run with a schmidt_spectrum observable: trajectories[u] holds the 500-entry vectors per trajectory and time point,
-    expectation_values[u] their concatenation over the trajectories (mps.py:1211, result.py:127-139) - not NaN means."""
-    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
-    from yaqs_amd.tjm import Simulator
-
-    L = 6
-    noise = NoiseModel([{"name": "lowering", "sites": [s], "strength": 0.1} for s in range(L)])
-    obs = [Observable(Zg(), 0), Observable("schmidt_spectrum", [2, 3]), Observable("entropy", [2, 3])]
-    kw = dict(elapsed_time=0.3, dt=0.1, num_traj=3, max_bond_dim=8, svd_threshold=1e-12, krylov_tol=1e-12, order=1, sample_timesteps=True, random_seed=5)
-    res = Simulator(batch=2).run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), AnalogSimParams(observables=obs, **kw), noise)
-    spec = res.trajectories[1]
-    assert spec.shape == (3, 4, 500)
-    assert res.expectation_values[1].shape == (3 * 4 * 500,)
-    # entropy row (a scalar) and the spectrum must agree with each other at every time point: S = -sum p log p, p = s^2 / sum s^2
-    for t in range(3):
-        for j in range(4):
-            sv = spec[t, j][~np.isnan(spec[t, j])]
-            pr = sv ** 2 / np.sum(sv ** 2)
-            ent = -np.sum(pr * np.log(pr + np.finfo(float).tiny))
-            assert abs(ent - res.trajectories[2][t, j]) < 1e-10
-    assert np.isfinite(res.expectation_values[0]).all() and np.isfinite(res.expectation_values[2]).all()
-
-
-def test_one_site_tdvp_run_with_a_pair_channel_grows_its_storage():
-    """tdvp_mode='1site' freezes the bonds of the sweep, but an adjacent non-Pauli two-site channel goes through a merged truncated
-    split that can enlarge them: the storage ladder must serve that instead of refusing."""
-    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
-    from yaqs_amd.tjm import Simulator
-
-    L = 4
-    noise = NoiseModel([{"name": "lowering_two", "sites": [1, 2], "strength": 0.4}, {"name": "pauli_x", "sites": [0], "strength": 0.2}])
-    kw = dict(elapsed_time=0.3, dt=0.1, max_bond_dim=4, svd_threshold=1e-12, krylov_tol=1e-12, order=1, sample_timesteps=True, random_seed=3,
-              tdvp_mode="1site")
-    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=4, **kw)
-    res = Simulator().run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p, noise)
-    on = [o.make_process(q["name"], q["sites"], q["strength"], matrix=q.get("matrix")) for q in noise.processes]
-    op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], **kw)
-    for t in range(4):
-        r, _, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), on, op, o.ising_mpo(L, 1.0, 0.5))
-        for s_ in range(L):
-            assert np.allclose(res.trajectories[s_][t], r[s_], atol=1e-8), (t, s_)
-
-
-def test_engine_runs_on_the_device_that_owns_its_workspace():
-    """Every C entry point selects the engine's device itself: an engine whose workspace lives on the last visible
-    device must work while another device is current.  With one GPU the guard is exercised with that device."""
-    from yaqs_amd.engine import BatchEngine
-
-    n = torch.cuda.device_count()
-    dev = f"cuda:{n - 1}"
-    torch.cuda.set_device(0)
-    L = 6
-    mpo = o.ising_mpo(L, 1.0, 0.5)
-    e = BatchEngine(L, 8, 2, mpo, device=dev, stream=torch.cuda.Stream(device=dev))
-    e.set_params(dt=0.1, svd_threshold=1e-10, max_bond_dim=8, krylov_tol=1e-12)
-    e.set_noise([], [])
-    st = o.MPSState.product(L, "x+")
-    e.load_state(st.tensors)
-    e.tdvp()
-    M = e.site_moments()
-    ref = o.MPSState.product(L, "x+")
-    o.tdvp(ref, mpo, o.Params(dt=0.1, max_bond_dim=8, svd_threshold=1e-10, krylov_tol=1e-12))
-    for s_ in range(L):
-        z = (M[s_, 0, 0, 0] - M[s_, 0, 1, 1]).real
-        assert abs(z - ref.local_expect(Z, [s_]).real) < 1e-9
-    assert torch.cuda.current_device() == 0
-    e.close()
-
-
-@pytest.mark.skipif(os.environ.get("TJM_TEST_CHI512_ENGINE") is None,
-                    reason="engine at chi = 512: not yet run on a GPU (round 2 lost two boxes to the FIRST version of this test, whose "
-                           "oracle check contracted chi^4 transfer tensors = 1.1 TB of host memory; fixed, to be verified: TJM_TEST_CHI512_ENGINE=1)")
-def test_bonds_up_to_512_gate_shift_and_tdvp_match_oracle():
-    """A 20-site chi = 512 saturated Haar state (centre bonds 512, two-site matrices 1024 x 1024, and the 512 x 1024 pairs next to
-    them): one TEBD gate with truncation at the centre (digital_tjm.py:455-533), QR and SVD centre shifts, and one two-site TDVP
-    update, each against the oracle - the sizes BASELINE config 5 names (max_bond_dim 512)."""
-    from yaqs_amd._lib import check, load
-    from yaqs_amd.engine import BatchEngine
-
-    L, chi = 20, 512
-    rng = np.random.default_rng(512)
-    st = o.MPSState.haar(L, chi, rng)
-    st.normalize("B")
-    mpo = o.ising_mpo(L, 1.0, 0.5)
-    lib = load()
-    e = BatchEngine(L, chi, 1, mpo)
-    e.set_params(dt=0.05, svd_threshold=1e-10, max_bond_dim=chi, krylov_tol=1e-10)
-    e.set_noise([], [])
-    e.load_state(st.tensors)
-    assert max(e.caps) == 512
-    # --- QR walk to the centre pair, then a gate on (9, 10): both through 1024-row Householder panels
-    u4 = np.linalg.qr(rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4)))[0]
-    e.tebd_gate(9, u4.reshape(2, 2, 2, 2), center=0)
-    ref = o.MPSState([t.copy() for t in st.tensors], 0)
-    o.apply_two_qubit_gate_tebd(ref, 9, u4.reshape(2, 2, 2, 2), o.DigitalParams(observables=[], max_bond_dim=chi, svd_threshold=1e-10))
-    out = e.export_state(0)
-    assert [t.shape[2] for t in out] == [t.shape[2] for t in ref.tensors]
-    M = e.site_moments()
-    zref = ref.site_expectations(Z).real  # boundary-matrix contraction: chi^3 memory (full_expect builds chi^4 transfer tensors)
-    for s_ in range(L):
-        z = (M[s_, 0, 0, 0] - M[s_, 0, 1, 1]).real
-        assert abs(z - zref[s_]) < 1e-9, s_
-    # --- SVD shifts (discarded weight 1e-12) from the gate's right site down to site 0, QR back up: gauge moves of the same state
-    for i in range(10, 0, -1):
-        check(lib.tjm_engine_center_shift(e.h, 0, i, -1, 1), "svd shift")
-    M2 = e.site_moments()
-    assert np.allclose(M2, M, atol=1e-10)
-    t0 = e.export_state(0)[1]
-    mm = t0.transpose(1, 0, 2).reshape(t0.shape[1], -1)
-    assert np.allclose(mm @ mm.conj().T, np.eye(mm.shape[0]), atol=1e-12)
-    # --- one two-site TDVP sweep of the whole chain at chi = 512 against the oracle (1024 x 1024 splits at every centre bond)
-    e.load_state(st.tensors)
-    e.tdvp()
-    ref = o.MPSState([t.copy() for t in st.tensors], 0)
-    o.tdvp(ref, mpo, o.Params(dt=0.05, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-10))
-    M = e.site_moments()
-    zref = ref.site_expectations(Z).real
-    for s_ in range(L):
-        z = (M[s_, 0, 0, 0] - M[s_, 0, 1, 1]).real
-        assert abs(z - zref[s_]) < 1e-8, s_
-    assert [t.shape[2] for t in e.export_state(0)] == [t.shape[2] for t in ref.tensors]
-    e.close()
-
-
-def test_sample_at_and_segment_stitching_match_reference_on_the_engine():
-    """The continuation options of the drivers (analog_tjm.py:206-255, 369-400) through the HIP engine: ``sample_at`` on both orders
-    and an order-2 run cut after 3 of 6 steps, against the reference's outputs (tests/golden/continuation.npz)."""
-    from yaqs_amd.api import AnalogSimParams, MPS, NoiseModel, Observable, Z as Zg
-    from yaqs_amd.tjm import TrajectoryBatch
-
-    g = load("continuation")
-    L = 5
-    mpo = tensors(g, "mpo")
-    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.15} for i in range(L) for n in ("lowering", "pauli_z")])
-    kw = dict(dt=0.1, max_bond_dim=4, svd_threshold=1e-9, krylov_tol=1e-12, random_seed=31)
-    obs = [Observable(Zg(), s) for s in range(L)]
-    st = MPS(L, state="x+")
-    st.normalize("B")
-    traj = [0, 1, 2, 3]
-    e = make_engine(L, 4, 4, mpo)
-    for order in (1, 2):
-        p = AnalogSimParams(observables=obs, elapsed_time=0.6, sample_timesteps=True, order=order, **kw)
-        r, _ = TrajectoryBatch(e, p, noise).run(traj, st, sample_at=[0, 2, 5])
-        assert np.allclose(r, g[f"sample_at_order{order}"], atol=1e-8), order
-        p1 = AnalogSimParams(observables=obs, elapsed_time=0.6, sample_timesteps=False, order=order, **kw)
-        r, _ = TrajectoryBatch(e, p1, noise).run(traj, st, sample_at=[3])
-        assert np.allclose(r, g[f"sample_at_single_order{order}"], atol=1e-8), order
-    seg = AnalogSimParams(observables=obs, elapsed_time=0.3, sample_timesteps=True, order=2, **kw)
-    tb = TrajectoryBatch(e, seg, noise)
-    r1, _ = tb.run(traj, st, rng_pos=np.zeros(4, dtype=np.int64))
-    tb2 = TrajectoryBatch(e, seg, noise)
-    r2, _ = tb2.run(traj, None, continue_trajectory=True, sample_timestep_offset=3, rng_pos=tb.rng_pos)
-    assert np.allclose(r1, g["whole"][:, :, :4], atol=1e-8) and np.allclose(r2, g["whole"][:, :, 3:], atol=1e-8)
-    assert np.array_equal(e.bond_dims(0)[:, 1:], g["phi_bonds"])
-    e.close()
-
-
-def test_dynamic_tdvp_matches_reference_on_the_engine():
-    """tdvp_mode="dynamic" (integrators.py:294-511) through the engine's site-level steps (tjm_engine_step_*): one sweep on the chains
-    of tests/golden/f3_dynamic_bug.npz (bonds below, at and above the cap, so both branches and the sqrt-distributed cap of
-    _cap_bonds run), then whole noisy trajectories of both drivers through Simulator.
-
-    Checked against the REFERENCE's outputs where every trajectory stays in the two-site branch, and against the oracle with
-    Params.reference_dynamic_transpose = False everywhere: the reference's leftward one-site branch transposes left_qr's factor
-    twice (integrators.py:450-461) and its numbers then depend on LAPACK's sign choices in earlier steps (tjm_engine.hip:
-    step_qr_bond); the oracle with the switch ON is pinned to those numbers in tests/test_oracle_golden.py."""
-    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
-    from yaqs_amd.tjm import Simulator, dynamic_tdvp
-
-    g = load("f3_dynamic_bug")
-    compared_with_reference = 0
-    for key in g["cases"]:
-        key = str(key)
-        L = int(key.split("_")[0][1:])
-        cap = key.split("_")[2][3:]
-        cap = None if cap == "None" else int(cap)
-        mpo = tensors(g, key + "_mpo")
-        e = make_engine(L, 16, 2, mpo)
-        e.set_params(dt=0.1, svd_threshold=1e-9, max_bond_dim=cap, krylov_tol=1e-12, tdvp_mode="dynamic")
-        e.load_state(tensors(g, key + "_in"))
-        dynamic_tdvp(e, 0, cap, 0.1, 1)
-        assert not e.capacity_overflow()
-        op = o.Params(dt=0.1, svd_threshold=1e-9, max_bond_dim=cap, krylov_tol=1e-12, tdvp_mode="dynamic", reference_dynamic_transpose=False)
-        st = o.MPSState([t.copy() for t in tensors(g, key + "_in")], 0)
-        o.tdvp(st, mpo, op)
-        want_bonds, want = [t.shape[2] for t in st.tensors], st.to_vec()
-        ref = g[f"{key}_dynamic_vec"]
-        same_as_reference = abs(abs(np.vdot(ref, want)) - np.vdot(ref, ref).real) < 1e-9  # no trajectory took the one-site branch leftwards
-        compared_with_reference += int(same_as_reference)
-        for b in range(2):
-            out = e.export_state(b)
-            assert [t.shape[2] for t in out] == want_bonds, key
-            v = vec_of(out)
-            assert abs(abs(np.vdot(want, v)) - np.vdot(want, want).real) < 1e-9, key
-            if same_as_reference:
-                assert [t.shape[2] for t in out] == list(g[f"{key}_dynamic_bonds"]), key
-                assert abs(abs(np.vdot(ref, v)) - np.vdot(ref, ref).real) < 1e-9, key
-        e.close()
-    assert compared_with_reference >= 2
-    L = 6
-    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
-    on = [o.make_process(n, [i], 0.1) for i in range(L) for n in ("lowering", "pauli_z")]
-    init = tensors(g, "traj_in")
-    st = MPS(L, tensors=init)
-    for order in (1, 2):
-        p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=0.5, dt=0.1, num_traj=4, max_bond_dim=4, svd_threshold=1e-9,
-                            krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=9, tdvp_mode="dynamic")
-        res = Simulator().run(st, MPO(tensors(g, "traj_mpo")), p, noise)
-        op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], elapsed_time=0.5, dt=0.1, max_bond_dim=4, svd_threshold=1e-9, krylov_tol=1e-12,
-                      order=order, sample_timesteps=True, random_seed=9, tdvp_mode="dynamic", reference_dynamic_transpose=False)
-        for t in range(4):
-            ro, _, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, tensors(g, "traj_mpo"))
-            for s_ in range(L):
-                assert np.allclose(res.trajectories[s_][t], ro[s_], atol=1e-8), (order, t, s_)
-
-
-def test_bug_integrator_matches_reference_on_the_engine():
-    """evolution_mode="bug" (core/methods/bug.py:128-257) through the engine's BUG steps (tjm_engine_step_bug_* / _flip / _compress,
-    engines with cap_slack = 2): one step on the generic-state chains of tests/golden/f3_dynamic_bug.npz, then noisy trajectories of
-    both drivers through Simulator, against the reference's outputs.  (Product-state starts are not compared: the reference's own
-    result is rounding-dependent there, exactly dependent columns in the stacked basis.)"""
-    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
-    from yaqs_amd.engine import BatchEngine
-    from yaqs_amd.tjm import Simulator, bug_step
-
-    g = load("f3_dynamic_bug")
-    for key in g["cases"]:
-        key = str(key)
-        if key.endswith("x+"):
-            continue
-        L = int(key.split("_")[0][1:])
-        cap = key.split("_")[2][3:]
-        cap = None if cap == "None" else int(cap)
-        mpo = tensors(g, key + "_mpo")
-        e = BatchEngine(L, 32, 2, mpo, cap_slack=2)
-        p = AnalogSimParams(observables=[Observable(Zg(), 0)], elapsed_time=0.1, dt=0.1, max_bond_dim=cap, svd_threshold=1e-9, krylov_tol=1e-12,
-                            evolution_mode="bug")
-        e.set_params(dt=0.1, svd_threshold=1e-9, max_bond_dim=cap, krylov_tol=1e-12)
-        e.set_noise([], [])
-        e.load_state(tensors(g, key + "_in"))
-        bug_step(e, 0, p, mpo)
-        assert not e.capacity_overflow()
-        for b in range(2):
-            out = e.export_state(b)
-            assert [t.shape[2] for t in out] == list(g[f"{key}_bug_bonds"]), key
-            v, ref = vec_of(out), g[f"{key}_bug_vec"]
-            assert abs(abs(np.vdot(ref, v)) - np.vdot(ref, ref).real) < 1e-9, key
-        e.close()
-    L = 6
-    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
-    st = MPS(L, tensors=tensors(g, "traj_in"))
-    for order in (1, 2):
-        p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=0.5, dt=0.1, num_traj=4, max_bond_dim=4, svd_threshold=1e-9,
-                            krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=9, evolution_mode="bug")
-        res = Simulator().run(st, MPO(tensors(g, "traj_mpo")), p, noise)
-        want = g[f"traj_bug_order{order}_results"]
-        for s_ in range(L):
-            assert np.allclose(res.trajectories[s_], want[:, s_, :], atol=1e-8), (order, s_)
-
-
-@pytest.mark.parametrize("d,L,chi,order", [(3, 5, 9, 1), (3, 4, 9, 2), (4, 4, 8, 2)])
-def test_qutrit_and_four_level_chains_match_oracle(d, L, chi, order):
-    """Sites with physical dimension 3 and 4 (the reference's path is dimension-generic, decompositions.py:105-185,
-    and its bosonic builders hand it such chains): a Bose-Hubbard chain (D = 4 MPO from the ladder operators) with one-site loss
-    and dephasing, adjacent pair loss (merged d^2 x d^2 dissipator and jump with a truncated split), occupation observables and a
-    nearest-neighbour correlator, through Simulator; trajectories against the oracle (which is dimension-generic as the reference
-    is), both drivers, plus the two-site TDVP sweep alone at its exact bond growth."""
-    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable
-    from yaqs_amd.tjm import Simulator
-
-    b = np.diag(np.sqrt(np.arange(1, d)), 1).astype(complex)
-    n = b.conj().T @ b
-    eye = np.eye(d, dtype=complex)
-    w = np.zeros((4, 4, d, d), dtype=complex)
-    w[0, 0], w[0, 1], w[0, 2], w[0, 3] = eye, -0.6 * b.conj().T, -0.6 * b, 0.7 * n + 0.25 * n @ (n - eye)
-    w[1, 3], w[2, 3], w[3, 3] = b, b.conj().T, eye
-    bulk = w.transpose(2, 3, 0, 1)
-    mpo = [bulk[:, :, 0:1, :] if i == 0 else (bulk[:, :, :, 3:4] if i == L - 1 else bulk) for i in range(L)]
-    # one TDVP sweep from a random state: bonds grow to the exact ranks d^k
-    rng = np.random.default_rng(d * 10 + L)
-    caps = o.MPSState.bond_caps(L, chi, d)
-    st = o.MPSState([rng.standard_normal((d, caps[i], caps[i + 1])) + 1j * rng.standard_normal((d, caps[i], caps[i + 1])) for i in range(L)], None)
-    st.normalize("B")
-    e = make_engine_d(L, chi, 2, mpo, d)
-    e.set_params(dt=0.05, svd_threshold=1e-10, max_bond_dim=chi, krylov_tol=1e-12)
-    e.load_state([t.copy() for t in st.tensors])
-    e.tdvp()
-    ref = o.MPSState([t.copy() for t in st.tensors], 0)
-    o.tdvp(ref, mpo, o.Params(dt=0.05, svd_threshold=1e-10, max_bond_dim=chi, krylov_tol=1e-12))
-    out = e.export_state(1)
-    assert [t.shape[2] for t in out] == [t.shape[2] for t in ref.tensors]
-    assert np.allclose(phase_align(ref.to_vec(), vec_of(out)), ref.to_vec(), atol=1e-10)
-    e.close()
-    # noisy trajectories from a Fock product state
-    procs = [{"name": "loss", "sites": [i], "strength": 0.3, "matrix": b} for i in range(L)]
-    procs += [{"name": "dephasing", "sites": [i], "strength": 0.1, "matrix": n} for i in range(L)]
-    procs += [{"name": "pair_loss", "sites": [i, i + 1], "strength": 0.05, "matrix": np.kron(b, b)} for i in range(L - 1)]
-    init = []
-    for i in range(L):
-        v = np.zeros(d, dtype=complex)
-        v[(i + 1) % d] = 1.0
-        init.append(v.reshape(d, 1, 1))
-    kw = dict(elapsed_time=0.4, dt=0.1, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=4)
-    p = AnalogSimParams(observables=[Observable(n, s) for s in range(L)] + [Observable(np.kron(n, n), [1, 2])], num_traj=3, **kw)
-    res = Simulator(batch=3).run(MPS(L, tensors=init), MPO(mpo), p, NoiseModel(procs))
-    op = o.Params(observables=[o.Obs(n, s) for s in range(L)] + [o.Obs(np.kron(n, n), [1, 2])], **kw)
-    on = [o.make_process(q["name"], q["sites"], q["strength"], matrix=q["matrix"]) for q in procs]
-    idx = op.observable_sorted_indices
-    jumps = 0
-    for t in range(3):
-        ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, mpo)
-        for u in range(len(p.observables)):
-            assert np.allclose(res.trajectories[u][t], ro[idx[u]], atol=1e-8), (t, u)
-        jumps += int(np.any(np.abs(np.diff(ro.sum(axis=0))) > 0.2))
-    assert jumps >= 1, "the case must contain a jump to mean anything"
-
-
-def test_bose_hubbard_qudit_chains_match_reference_fixture():
-    """tests/golden/qudit.npz: the REFERENCE on Bose-Hubbard chains of qutrits (L = 5) and four-level sites (L = 4) with one-site loss
-    and dephasing - one closed two-site TDVP step from a random state, and noisy trajectories of both drivers through Simulator with
-    MPO.bose_hubbard and a Fock state from MPS(physical_dimensions=..., state="basis")."""
-    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable
-    from yaqs_amd.tjm import Simulator
-
-    g = load("qudit")
-    for key in g["cases"]:
-        key = str(key)
-        d, L = int(key[1]), int(key.split("_L")[1])
-        chi = 9 if d == 3 else 8
-        b = np.diag(np.sqrt(np.arange(1, d)), 1).astype(complex)
-        n = b.conj().T @ b
-        H = MPO.bose_hubbard(L, d, 0.7, 0.6, 0.5)
-        assert all(np.allclose(H.tensors[i], g[f"{key}_mpo{i}"]) for i in range(L))
-        e = make_engine_d(L, chi, 2, H.tensors, d)
-        e.set_params(dt=0.05, svd_threshold=1e-10, max_bond_dim=chi, krylov_tol=1e-12)
-        e.load_state(tensors(g, key + "_in"))
-        e.tdvp()
-        out = e.export_state(1)
-        assert [t.shape[2] for t in out] == list(g[key + "_tdvp_bonds"]), key
-        ref = g[key + "_tdvp_vec"]
-        assert abs(abs(np.vdot(ref, vec_of(out))) - np.vdot(ref, ref).real) < 1e-10, key
-        e.close()
-        noise = NoiseModel([{"name": "loss", "sites": [i], "strength": 0.3, "matrix": b} for i in range(L)]
-                           + [{"name": "dephasing", "sites": [i], "strength": 0.1, "matrix": n} for i in range(L)])
-        fock = MPS(L, physical_dimensions=[d] * L, state="basis", basis_string="".join(str((i + 1) % d) for i in range(L)))
-        for order in (1, 2):
-            p = AnalogSimParams(observables=[Observable(n, s) for s in range(L)], elapsed_time=0.4, dt=0.1, num_traj=3, max_bond_dim=chi,
-                                svd_threshold=1e-10, krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=4)
-            res = Simulator(batch=3).run(fock, H, p, noise)
-            want = g[f"{key}_order{order}_results"]
-            for s_ in range(L):
-                assert np.allclose(res.trajectories[s_], want[:, s_, :], atol=1e-8), (key, order, s_)
-
-
-def test_long_range_gates_through_the_gate_mpo_match_reference_fixture():
-    """gate_mode="mpo", the reference's DEFAULT for distant pairs (digital_tjm.py:536-557, 616-620): MPO.from_gate(gate, L).multiply(state)
-    (tjm_engine_apply_gate_mpo: operator Schmidt terms on the two target sites, identity threads in between, bonds grown by the rank)
-    and MPS.compress (tjm_engine_step_compress).  tests/golden/digital_mpo.npz holds the REFERENCE's trajectories of the long-range
-    circuit of the SWAP fixture under the default mode, for a cap that bites (4) and one that does not (16); run through
-    Simulator.run with default DigitalSimParams - storage four times the cap, grown on demand."""
-    from yaqs_amd.api import DigitalSimParams, GateLayer, MPS, NoiseModel, Observable, X as Xg, Z as Zg, rx_matrix
-    from yaqs_amd.tjm import Simulator
-
-    g, gd = load("digital_mpo"), load("digital")
-    L = 8
-    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 3)]
-    cx, rzz = gd["lr_cx_matrix"], gd["lr_rzz_matrix"]
-    layers = [GateLayer([(q, rx_matrix(0.3 + 0.1 * q)) for q in range(L)], [(1, 5, cx), (6, 2, rzz)], [(4, 3, cx), (7, 0, cx)], 0) for _ in range(2)]
-    noise = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)] +
-                       [{"name": "crosstalk_zz", "sites": [1, 5], "strength": 0.1}, {"name": "lowering", "sites": [6], "strength": 0.2}])
-    for chi in (4, 16):
-        p = DigitalSimParams(observables=obs, max_bond_dim=chi, svd_threshold=1e-8, random_seed=11, num_traj=1)
-        assert p.gate_mode == "mpo"
-        res = Simulator().run(MPS(L, state="zeros"), layers, p, None)
-        want = g[f"chi{chi}_noiseless_results"][0]
-        idx = p.observable_sorted_indices  # the fixture's rows are in the reference's site-sorted order
-        for u in range(len(obs)):
-            assert np.allclose(res.trajectories[u][0], want[idx[u]], atol=1e-8), (chi, u)
-        # noisy: through the backend class, as the fixture was made (the front end refuses the distant crosstalk pair, noise_model.py)
-        from yaqs_amd.engine import BatchEngine
-        from yaqs_amd.tjm import DigitalBatch
-
-        p = DigitalSimParams(observables=obs, max_bond_dim=chi, svd_threshold=1e-8, random_seed=11, num_traj=6)
-        e = BatchEngine(L, 4 * chi, 6, o.ising_mpo(L, 1.0, 0.5), cap_slack=4)
-        db = DigitalBatch(e, p, noise)
-        r, dg = db.run(list(range(6)), MPS(L, state="zeros"), layers)
-        assert not e.capacity_overflow()
-        e.close()
-        assert np.array(db.jump_log).sum() > 0
-        assert np.allclose(r, g[f"chi{chi}_noisy_results"], atol=1e-8), chi
-        assert np.array_equal(dg, g[f"chi{chi}_noisy_diag"]), chi
-
-
-@pytest.mark.parametrize("native", [False, True])
-def test_non_finite_inputs_fail_loudly_like_the_reference(native):
-    """A NaN or Inf in the initial state never comes back as a number.  The reference (and the oracle) stop at the first measurement
-    ("assert exp.imag < 1e-13", mps.py:1233, false for NaN) or, when nothing is measured before the first jump decision, at the
-    non-finite jump weights (ValueError, stochastic_process.py:178-186); the same exception types come out of both drivers here.
-    Where the reference fails inside LAPACK's tridiagonal solver instead (a NaN reaches the Krylov step first, or sits in the
-    Hamiltonian), the engine ends in one of those two errors as well - never in numbers."""
-    from yaqs_amd.api import AnalogSimParams, MPS, NoiseModel, Observable, Z as Zg
-    from yaqs_amd.tjm import TrajectoryBatch
-
-    L = 4
-    mpo = o.ising_mpo(L, 1.0, 0.5)
-    noise = NoiseModel([{"name": "lowering", "sites": [i], "strength": 0.2} for i in range(L)])
-    on = [o.make_process("lowering", [i], 0.2) for i in range(L)]
-
-    def outcome(fn):
-        try:
-            fn()
-        except Exception as ex:  # noqa: BLE001 - the type is what is compared
-            return type(ex)
-        return None
-
-    for bad in (np.nan, np.inf):
-        for noisy in (True, False):
-            for sample in (True, False):
-                init = [t.copy() for t in o.MPSState.product(L, "x+").tensors]
-                init[1][0, 0, 0] = bad
-                kw = dict(elapsed_time=0.2, dt=0.1, max_bond_dim=4, svd_threshold=1e-9, order=1, sample_timesteps=sample, random_seed=1)
-                p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=2, **kw)
-                op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], **kw)
-
-                def run_engine():
-                    e = make_engine(L, 4, 2, mpo)
-                    try:
-                        TrajectoryBatch(e, p, noise if noisy else None).run([0, 1], MPS(L, tensors=init), native=native)
-                    finally:
-                        e.close()
-
-                want = outcome(lambda: o.run_trajectory(0, o.MPSState([x.copy() for x in init], 0), on if noisy else None, op, mpo))
-                got = outcome(run_engine)
-                assert want is not None, (bad, noisy, sample)
-                if want in (AssertionError, ValueError):
-                    assert got is want, (bad, noisy, sample, got, want)
-                else:  # nothing measured before the first sweep: the reference dies inside LAPACK's tridiagonal solver (LinAlgError)
-                    assert got in (AssertionError, ValueError), (bad, noisy, sample, got, want)
-    broken = [w.copy() for w in mpo]
-    broken[2][0, 1, 0, 0] = np.nan
-    e = make_engine(L, 4, 2, broken)
-    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=2, elapsed_time=0.2, dt=0.1, max_bond_dim=4, svd_threshold=1e-9,
-                        sample_timesteps=False, random_seed=1)
-    with pytest.raises((AssertionError, ValueError)):
-        TrajectoryBatch(e, p, noise).run([0, 1], MPS(L, state="x+"), native=native)
-    e.close()
-
-
-def test_complex64_engine_tracks_the_fp64_oracle():
-    """libtjm_hip_f32.so: the same sources compiled with fp32 arithmetic and storage (SURVEY configs 3 and 5 are quoted in fp32; the
-    reference itself is complex128 throughout, mps.py:231).  On short deterministic pieces the complex64 engine must follow the fp64
-    oracle at fp32 accuracy with the SAME bond dimensions: two-site and one-site TDVP sweeps through the fused small-bond kernels and
-    through the general ones (MFMA f32 GEMMs, Householder panels, tiled / LDS-resident Jacobi), then noisy trajectories of both drivers
-    and both schedules (same random streams: the jump decisions coincide unless a draw falls within 1e-6 of dp)."""
-    from yaqs_amd.api import AnalogSimParams, MPS, NoiseModel, Observable, Z as Zg
-    from yaqs_amd.engine import BatchEngine
-    from yaqs_amd.tjm import TrajectoryBatch
-
-    for L, chi, mode in ((4, 4, "2site"), (8, 16, "2site"), (8, 16, "1site"), (10, 24, "2site")):
-        mpo = o.ising_mpo(L, 1.0, 0.5)
-        st = o.MPSState.haar(L, chi, np.random.default_rng(L + chi))
-        st.normalize("B")
-        init = [t.copy() for t in st.tensors]
-        e = BatchEngine(L, chi, 2, mpo, dtype="complex64")
-        assert e.workspace_bytes < 0.75 * BatchEngine.workspace_bytes_for(L, chi, 2, mpo)  # complex64 storage
-        e.set_params(dt=0.05, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=1e-6, tdvp_mode=mode)
-        e.load_state(init)
-        e.tdvp()
-        out = e.export_state(1)
-        e.close()
-        ref = o.MPSState([t.copy() for t in init], 0)
-        o.tdvp(ref, mpo, o.Params(dt=0.05, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=1e-10, tdvp_mode=mode))
-        assert [t.shape[2] for t in out] == [t.shape[2] for t in ref.tensors], (L, chi, mode)
-        assert np.allclose(phase_align(ref.to_vec(), vec_of(out)), ref.to_vec(), atol=2e-5), (L, chi, mode)
-    L, chi = 6, 8
-    mpo = o.ising_mpo(L, 1.0, 0.5)
-    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
-    on = [o.make_process(n, [i], 0.1) for i in range(L) for n in ("lowering", "pauli_z")]
-    for order, native in ((1, False), (2, True)):
-        kw = dict(elapsed_time=0.5, dt=0.1, max_bond_dim=chi, svd_threshold=1e-6, krylov_tol=1e-5, order=order, sample_timesteps=True, random_seed=7)
-        p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=4, **kw)
-        e = BatchEngine(L, chi, 4, mpo, dtype="complex64")
-        r, dg = TrajectoryBatch(e, p, noise).run([0, 1, 2, 3], MPS(L, state="x+"), native=native)
-        e.close()
-        op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], **kw)
-        for t in range(4):
-            ro, do, _ = o.run_trajectory(t, o.MPSState.product(L, "x+"), on, op, mpo)
-            assert np.allclose(r[t], ro, atol=1e-4), (order, t, np.abs(r[t] - ro).max())
-            assert np.array_equal(dg[t], do), (order, t)
-
-
-def test_complex64_dynamic_tdvp_and_bug_track_the_fp64_oracle():
-    """The host-driven integrators on the complex64 engine (site-level steps, stacked bases, compression): one dynamic-TDVP sweep and
-    one BUG step on the generic-state chains of tests/golden/f3_dynamic_bug.npz against the fp64 oracle - same bond dimensions,
-    overlap defect below 1e-5."""
-    from types import SimpleNamespace
-
-    from yaqs_amd.engine import BatchEngine
-    from yaqs_amd.tjm import bug_step, dynamic_tdvp
-
-    g = load("f3_dynamic_bug")
-    for key in ("L5_c4_cap4_haar", "L8_c8_cap8_haar"):
-        L, cap = int(key.split("_")[0][1:]), int(key.split("_")[2][3:])
-        mpo, init = tensors(g, key + "_mpo"), tensors(g, key + "_in")
-        e = BatchEngine(L, 16, 2, mpo, dtype="complex64")
-        e.set_params(dt=0.1, svd_threshold=1e-7, max_bond_dim=cap, krylov_tol=1e-6, tdvp_mode="dynamic")
-        e.load_state(init)
-        dynamic_tdvp(e, 0, cap, 0.1, 1)
-        out = e.export_state(0)
-        e.close()
-        st = o.MPSState([t.copy() for t in init], 0)
-        o.tdvp(st, mpo, o.Params(dt=0.1, svd_threshold=1e-7, max_bond_dim=cap, krylov_tol=1e-10, tdvp_mode="dynamic", reference_dynamic_transpose=False))
-        assert [t.shape[2] for t in out] == [t.shape[2] for t in st.tensors], key
-        ref = st.to_vec()
-        assert abs(abs(np.vdot(ref, vec_of(out))) - np.vdot(ref, ref).real) < 1e-5, key
-        e = BatchEngine(L, 32, 2, mpo, cap_slack=2, dtype="complex64")
-        e.set_params(dt=0.1, svd_threshold=1e-7, max_bond_dim=cap, krylov_tol=1e-6)
-        e.load_state(init)
-        bug_step(e, 0, SimpleNamespace(dt=0.1, svd_threshold=1e-7, max_bond_dim=cap, trunc_mode="discarded_weight"), mpo)
-        e.normalize_qr(0)
-        out = e.export_state(0)
-        e.close()
-        st = o.MPSState([t.copy() for t in init], 0)
-        o.bug(st, mpo, o.Params(dt=0.1, svd_threshold=1e-7, max_bond_dim=cap, krylov_tol=1e-10))
-        assert [t.shape[2] for t in out] == [t.shape[2] for t in st.tensors], key
-        ref = st.to_vec()
-        assert abs(abs(np.vdot(ref, vec_of(out))) - np.vdot(ref, ref).real) < 1e-5, key
-
-
-def test_complex64_circuit_paths_track_the_reference_fixtures():
-    """The circuit path on the complex64 engine against the REFERENCE's outputs (tests/golden/digital.npz, digital_mpo.npz) at fp32
-    accuracy with identical bond diagnostics: the noisy Trotter circuit (TEBD gates, Pauli jumps) and the long-range circuit under the
-    default gate_mode (gate-MPO product + compression, local one- and two-site noise)."""
-    from yaqs_amd.api import DigitalSimParams, GateLayer, MPS, NoiseModel, Observable, X as Xg, Z as Zg, ising_trotter_layers, rx_matrix
-    from yaqs_amd.engine import BatchEngine
-    from yaqs_amd.tjm import DigitalBatch
-
-    g, gm = load("digital"), load("digital_mpo")
-    L, steps = 8, 5
-    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 3)]
-    mpo = o.ising_mpo(L, 1.0, 0.5)
-    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.01} for i in range(L) for n in ("pauli_x", "pauli_y", "pauli_z")])
-    p = DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-9, random_seed=3)
-    e = BatchEngine(L, 16, 6, mpo, dtype="complex64")
-    r, d = DigitalBatch(e, p, noise).run(list(range(6)), MPS(L, state="zeros"), ising_trotter_layers(L, 1.0, 0.5, 0.1, steps))
-    e.close()
-    assert np.allclose(r[:, :, 0], g["noisy_results"][:, :, 0], atol=1e-4)
-    assert np.array_equal(d, g["noisy_diag"])
-    cx, rzz = g["lr_cx_matrix"], g["lr_rzz_matrix"]
-    layers = [GateLayer([(q, rx_matrix(0.3 + 0.1 * q)) for q in range(L)], [(1, 5, cx), (6, 2, rzz)], [(4, 3, cx), (7, 0, cx)], 0) for _ in range(2)]
-    noise3 = NoiseModel([{"name": "pauli_x", "sites": [i], "strength": 0.05} for i in range(L)] +
-                        [{"name": "crosstalk_zz", "sites": [1, 5], "strength": 0.1}, {"name": "lowering", "sites": [6], "strength": 0.2}])
-    p = DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-8, random_seed=11, num_traj=6)
-    e = BatchEngine(L, 64, 6, mpo, cap_slack=4, dtype="complex64")
-    r, d = DigitalBatch(e, p, noise3).run(list(range(6)), MPS(L, state="zeros"), layers)
-    e.close()
-    assert np.allclose(r, gm["chi16_noisy_results"], atol=1e-4)
-    assert np.array_equal(d, gm["chi16_noisy_diag"])
-
-
-def test_complex64_ensemble_means_agree_with_the_fp64_ensemble():
-    """The statistical parity the survey asks of the fp32 variant ("ensemble means within 3 sigma / sqrt(N) of the fp64
-    ensemble"): N trajectories of a dissipative chain through Simulator(dtype="complex64") and through the fp64 engine; the means of
-    every observable at every time differ by less than three standard errors of the fp64 ensemble (with the same random streams the
-    two ensembles almost coincide; an independent complex64 ensemble - other seed - must pass the same bound against both)."""
-    from yaqs_amd.api import AnalogSimParams, MPO, MPS, NoiseModel, Observable, Z as Zg
-    from yaqs_amd.tjm import Simulator
-
-    L = 6
-    n_traj = int(os.environ.get("TJM_F32_ENSEMBLE", "256"))
-    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
-
-    def ensemble(dtype, seed):
-        p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], elapsed_time=1.0, dt=0.1, num_traj=n_traj, max_bond_dim=8,
-                            svd_threshold=1e-6, order=2, sample_timesteps=True, random_seed=seed)
-        res = Simulator(dtype=dtype).run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p, noise)
-        return np.array([res.trajectories[s] for s in range(L)])  # [site, traj, time]
-
-    f64 = ensemble("complex128", 21)
-    f32 = ensemble("complex64", 21)
-    other = ensemble("complex64", 22)
-    se = f64.std(axis=1, ddof=1) / np.sqrt(n_traj)
-    floor = 1e-4  # fp32 rounding of an expectation value where the ensemble has (almost) no spread
-    assert np.all(np.abs(f32.mean(axis=1) - f64.mean(axis=1)) <= 3.0 * se + floor)
-    se2 = np.sqrt(se ** 2 + (other.std(axis=1, ddof=1) / np.sqrt(n_traj)) ** 2)
-    assert np.all(np.abs(other.mean(axis=1) - f64.mean(axis=1)) <= 4.0 * se2 + floor)

@@ -893,7 +893,7 @@ def _encoded(state: MPS) -> MPS:
 MAX_CHI = 256   # largest bond the engine serves.  The kernels hold d * chi <= 1024 since round 2 (1024 x 1024 splits verified on the
 # GPU against the oracle, tests/test_hip_kernels.py::test_svd_split_up_to_1024_matches_oracle), but the ENGINE has not yet run at
 # chi = 512 on a GPU (its first test exhausted the host memory of two GPU boxes with a chi^4 oracle contraction before the engine
-# was reached; tests/test_hip_engine.py::test_bonds_up_to_512_... is fixed and waits for the next GPU session), so runs beyond 256
+# was reached; tests/test_hip_round2.py::test_bonds_up_to_512_... is fixed and waits for the next GPU session), so runs beyond 256
 # stay refused until it has.
 START_CHI = 8   # first storage capacity tried when the requested cap is larger
 AUTO_BATCH_MAX = 16384  # trajectories in flight when Simulator(batch=None) sizes the batch itself
