@@ -605,3 +605,21 @@ def test_host_side_shot_measurement():
     assert set(ghz) == {0, 15} and abs(ghz[0] / 2000 - 0.5) < 0.05
     with pytest.raises(ValueError, match="Invalid basis"):
         MPS(2, state="zeros").measure_shots(1, basis="W")
+
+
+def test_pmc_summary_divides_the_gui_counter_by_the_xcds(tmp_path):
+    """tools/pmc_summary.py: rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs; MfmaUtil = busy / (gui / 8 * 1024 SIMDs)."""
+    import subprocess
+    import sys
+
+    src = tmp_path / "counter_collection.csv"
+    rows = ["Kernel_Name,Counter_Name,Counter_Value"]
+    for _ in range(2):  # two dispatches of one kernel
+        rows += ["k,GRBM_GUI_ACTIVE,8000", "k,SQ_VALU_MFMA_BUSY_CYCLES,512000", "k,SQ_INSTS_VALU_MFMA_MOPS_F64,10",
+                 "k,SQ_WAVE_CYCLES,1000", "k,SQ_ACTIVE_INST_VALU,250", "k,SQ_WAIT_INST_LDS,100", "k,SQ_INSTS_LDS,50", "k,SQ_LDS_BANK_CONFLICT,25"]
+    src.write_text("\n".join(rows) + "\n")
+    dst = tmp_path / "out.csv"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), str(src), str(dst)], capture_output=True, text=True, check=True).stdout
+    # busy 1 024 000 / (16 000 / 8 * 1024) = 50 %
+    assert "MfmaUtil 50.0%" in out and "VALU active 25.0%" in out and "LDS wait 10.0%" in out, out
+    assert dst.read_text().strip().splitlines()[1].endswith(",50.00")
