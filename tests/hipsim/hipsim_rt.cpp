@@ -19,6 +19,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -239,9 +240,13 @@ struct Pool {
     w->tramp = j->tramp;
     w->arg = j->arg;
     w->name = j->name;
+    // HIPSIM_BLOCK_ORDER=reverse: workgroups are handed out last to first.  HIP promises no dispatch order, so results must not
+    // change; with HIPSIM_THREADS=1 this is a deterministic second schedule that exposes workgroups reading what a "later" one writes.
+    static const bool reverse = getenv("HIPSIM_BLOCK_ORDER") && std::string(getenv("HIPSIM_BLOCK_ORDER")) == "reverse";
     for (;;) {
-      const long b = j->next.fetch_add(1);
+      long b = j->next.fetch_add(1);
       if (b >= j->total) break;
+      if (reverse) b = j->total - 1 - b;
       const dim3 bid((uint32_t)(b % j->grid.x), (uint32_t)((b / j->grid.x) % j->grid.y), (uint32_t)(b / ((long)j->grid.x * j->grid.y)));
       run_block(w, j->grid, j->block, bid, j->shmem);
     }
