@@ -46,6 +46,8 @@ class _NoStream:
 class SimEngine(BatchEngine):
     """Same methods as BatchEngine (they only use ``self.lib`` / ``self.h``); construction binds host memory instead of HBM."""
 
+    CANARY = 4096
+
     def __init__(self, length, chi_max, batch, mpo, device="cpu", d=2, stream=None, cap_slack=1, dtype="complex128"):
         self.torch = None
         self.dtype = dtype
@@ -59,8 +61,12 @@ class SimEngine(BatchEngine):
         nbytes = self.lib.tjm_engine_workspace_bytes(self.h)
         self.workspace_bytes = int(nbytes)
         self.stream = _NoStream()
-        self.ws = np.zeros(nbytes + 256, dtype=np.uint8)
-        base = (self.ws.ctypes.data + 255) // 256 * 256
+        # the workspace sits between two canaries: a kernel that writes outside what the engine said it needs is caught at close()
+        self.ws = np.zeros(nbytes + 256 + 2 * self.CANARY, dtype=np.uint8)
+        base = (self.ws.ctypes.data + self.CANARY + 255) // 256 * 256
+        self._lo, self._hi = base - self.ws.ctypes.data, base - self.ws.ctypes.data + nbytes
+        self.ws[: self._lo] = 0xA5
+        self.ws[self._hi:] = 0xA5
         _lib.check(self.lib.tjm_engine_bind(self.h, base, nbytes, None), "bind")
         packed = np.concatenate([np.ascontiguousarray(w, dtype=np.complex128).reshape(-1) for w in mpo])
         _lib.check(self.lib.tjm_engine_set_mpo(self.h, packed.ctypes.data), "set_mpo")
@@ -85,7 +91,10 @@ class SimEngine(BatchEngine):
         if getattr(self, "h", None):
             self.lib.tjm_engine_destroy(self.h)
             self.h = None
+            intact = bool(np.all(self.ws[: self._lo] == 0xA5) and np.all(self.ws[self._hi:] == 0xA5))
             self.ws = None
+            if not intact:
+                raise AssertionError("a kernel wrote outside the workspace the engine asked for")
 
     def synchronize(self):
         pass
