@@ -57,6 +57,7 @@ class Engine {
   };
   int phase_depth_ = 0;
 
+  ~Engine();  // pinned host words and HIP events (the device workspace belongs to the caller)
   int create(int L, int d, int chi_max, int B, const int* mpo_bond, int cap_slack = 1);
   size_t workspace_bytes() const;
   int bind(void* ws, size_t bytes, hipStream_t s);

@@ -142,6 +142,12 @@ Engine::Region::~Region() {
   }
 }
 
+Engine::~Engine() {
+  if (h_pinned_) (void)hipHostFree(h_pinned_);
+  for (hipEvent_t ev : krylov_ev_) if (ev) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : prof_.pool) if (ev) (void)hipEventDestroy(ev);
+}
+
 int Engine::create(int L_, int d_, int chi_, int B_, const int* mpo_bond, int cap_slack) {
   if (L_ < 1 || d_ < 2 || d_ > 4 || chi_ < 1 || B_ < 1 || cap_slack < 1) return TJM_ERR_ARG;  // uniform local dimension 2, 3 or 4
   L = L_; d = d_; chi_max = chi_; B = B_;
