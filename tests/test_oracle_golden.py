@@ -500,6 +500,38 @@ def test_dynamic_tdvp_and_bug_match_reference():
                 assert np.array_equal(dg, g[f"traj_{mode}_order{order}_diag"][t]), (mode, order, t)
 
 
+def test_the_reference_dynamic_sweep_depends_on_the_gauge_of_its_input():
+    """Why the HIP engine does not follow sweep_dynamic's leftward one-site branch to the letter (integrators.py:450-461: left_qr hands
+    back R^T and the sweep transposes it once more, so R - with its indices the wrong way round - is evolved and absorbed).  The same
+    physical state in two gauges - a random unitary inserted on one bond, both copies right-canonical with the centre on site 0 -
+    gives two different states after one sweep of the restated reference (switch on), and one and the same state with the switch
+    off, which is what the engine computes and is compared with.  A result that changes with the gauge depends on the signs and
+    phases LAPACK's SVD and QR picked earlier in the run: no independent implementation can reproduce it."""
+    g = load("f3_dynamic_bug")
+    key = "L5_c4_cap4_haar"  # every bond at the cap: the one-site branch is taken on the way back
+    mpo = tensors(g, key + "_mpo")
+    base = [t.copy() for t in tensors(g, key + "_in")]
+    rng = np.random.default_rng(2)
+    chi = base[1].shape[2]
+    u, _ = np.linalg.qr(rng.standard_normal((chi, chi)) + 1j * rng.standard_normal((chi, chi)))
+    gauged = [t.copy() for t in base]
+    gauged[1] = np.einsum("pab,bc->pac", base[1], u)
+    gauged[2] = np.einsum("cb,pbd->pcd", u.conj().T, base[2])
+    assert np.allclose(o.MPSState(base, 0).to_vec(), o.MPSState(gauged, 0).to_vec(), atol=1e-13)
+    moved = {}
+    for as_reference in (True, False):
+        out = []
+        for t in (base, gauged):
+            st = o.MPSState([x.copy() for x in t], 0)
+            o.tdvp(st, mpo, o.Params(dt=0.1, max_bond_dim=4, svd_threshold=1e-9, krylov_tol=1e-12, tdvp_mode="dynamic",
+                                     reference_dynamic_transpose=as_reference))
+            out.append(st.to_vec())
+        ov = np.vdot(out[0], out[1])
+        moved[as_reference] = float(np.linalg.norm(out[1] - out[0] * (ov / abs(ov))))
+    assert moved[False] < 1e-10, moved
+    assert moved[True] > 1e-3, moved
+
+
 def _continuation_setup(g):
     L = 5
     mpo = tensors(g, "mpo")
