@@ -532,6 +532,31 @@ def test_the_reference_dynamic_sweep_depends_on_the_gauge_of_its_input():
     assert moved[True] > 1e-3, moved
 
 
+def test_the_reference_bug_step_from_a_product_state_is_rounding_defined():
+    """Why the BUG fixtures start from generic states: from a product state the stacked trial basis [retained | predictor] of
+    build_trial_basis (bug.py:65-90) has exactly dependent columns, its QR completes the basis with whatever rounding leaves, and the
+    result moves by 1e-2 when the input is perturbed by 1e-15 (shown on the restatement; the reference's own vector for this case lies
+    as far from the restatement's as the restatement's lies from itself)."""
+    g = load("f3_dynamic_bug")
+    key = "L6_c1_cap4_x+"
+    mpo, base = tensors(g, key + "_mpo"), tensors(g, key + "_in")
+    rng = np.random.default_rng(0)
+
+    def step(ts):
+        st = o.MPSState([x.copy() for x in ts], 0)
+        o.bug(st, mpo, o.Params(dt=0.1, max_bond_dim=4, svd_threshold=1e-9, krylov_tol=1e-12))
+        return st.to_vec()
+
+    def dist(a, b):
+        ov = np.vdot(a, b)
+        return float(np.linalg.norm(b - a * (ov / abs(ov))))
+
+    v0 = step(base)
+    moved = [dist(v0, step([t * (1 + 1e-15 * rng.standard_normal(t.shape)) for t in base])) for _ in range(3)]
+    assert max(moved) > 1e-4, moved
+    assert dist(g[key + "_bug_vec"], v0) < 10 * max(moved) + 1e-2
+
+
 def _continuation_setup(g):
     L = 5
     mpo = tensors(g, "mpo")
