@@ -557,6 +557,41 @@ def test_the_reference_bug_step_from_a_product_state_is_rounding_defined():
     assert dist(g[key + "_bug_vec"], v0) < 10 * max(moved) + 1e-2
 
 
+def _mixed_case(g):
+    dims = [int(x) for x in g["dims"]]
+    L = len(dims)
+    lower = {d_: np.diag(np.sqrt(np.arange(1, d_)), 1).astype(complex) for d_ in set(dims)}
+    number = {d_: lower[d_].conj().T @ lower[d_] for d_ in lower}
+    init = []
+    for i, ch in enumerate(str(g["basis"])):
+        v = np.zeros(dims[i], dtype=complex)
+        v[int(ch)] = 1.0
+        init.append(v.reshape(dims[i], 1, 1))
+    return dims, L, lower, number, init
+
+
+def test_mixed_local_dimensions_match_reference():
+    """A chain whose sites differ in dimension (tests/golden/mixed_dims.npz: the reference on MPO.coupled_transmon, three-level transmons
+    and two-level resonators alternating, loss on every site with its own ladder operator): one closed two-site TDVP step from a random
+    state and noisy trajectories of both drivers, bond diagnostics included."""
+    g = load("mixed_dims")
+    dims, L, lower, number, init = _mixed_case(g)
+    mpo = tensors(g, "mpo")
+    st = o.MPSState([t.copy() for t in tensors(g, "in")], 0)
+    o.tdvp(st, mpo, o.Params(dt=0.05, svd_threshold=1e-10, max_bond_dim=8, krylov_tol=1e-12))
+    assert [t.shape[2] for t in st.tensors] == list(g["tdvp_bonds"])
+    ref = g["tdvp_vec"]
+    assert abs(abs(np.vdot(ref, st.to_vec())) - np.vdot(ref, ref).real) < 1e-10
+    on = [o.make_process("loss", [i], 0.25, matrix=lower[dims[i]]) for i in range(L)]
+    for order in (1, 2):
+        op = o.Params(observables=[o.Obs(number[dims[s]], s) for s in range(L)], elapsed_time=0.4, dt=0.1, max_bond_dim=8, svd_threshold=1e-10,
+                      krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=6)
+        for t in range(3):
+            r, dg, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, mpo)
+            assert np.allclose(r, g[f"order{order}_results"][t], atol=1e-9), (order, t)
+            assert np.array_equal(dg, g[f"order{order}_diag"][t]), (order, t)
+
+
 def _continuation_setup(g):
     L = 5
     mpo = tensors(g, "mpo")

@@ -48,6 +48,7 @@ ENGINE_CASES = [
     "test_bug_integrator_matches_reference_on_the_engine",
     "test_bose_hubbard_qudit_chains_match_reference_fixture",
     "test_long_range_gates_through_the_gate_mpo_match_reference_fixture",
+    "test_mixed_local_dimensions_match_reference_fixture",
 ]
 
 

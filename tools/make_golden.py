@@ -872,6 +872,50 @@ def gen_digital_tdvp():
     save("digital_tdvp", **out)
 
 
+# ------------------------------------------------------------------ 19. mixed local dimensions (coupled transmon chain)
+def gen_mixed_dims():
+    """The reference on a chain whose sites differ in dimension: MPO.coupled_transmon (mpo.py:549-668; three-level transmons on the even
+    sites, two-level resonators on the odd ones), Fock product state through MPS(physical_dimensions=[3, 2, 3, 2, ...]), loss on every
+    site with that site's own ladder operator, occupation observables; one closed TDVP step from a random state and noisy
+    trajectories of both drivers."""
+    out = {}
+    L, dq, dr, chi = 6, 3, 2, 8
+    dims = [dq if i % 2 == 0 else dr for i in range(L)]
+    H = MPO.coupled_transmon(L, dq, dr, 0.9, 0.7, -0.3, 0.25)
+    out.update(pack_tensors("mpo", H.tensors))
+    out["dims"] = np.array(dims)
+    lower = {d_: np.diag(np.sqrt(np.arange(1, d_)), 1).astype(complex) for d_ in (dq, dr)}
+    number = {d_: lower[d_].conj().T @ lower[d_] for d_ in (dq, dr)}
+    rng = np.random.default_rng(17)
+    caps = [1] * (L + 1)
+    for i in range(1, L):
+        caps[i] = min(int(np.prod(dims[:i])), int(np.prod(dims[i:])), chi)
+    st = MPS(L, tensors=[rng.standard_normal((dims[i], caps[i], caps[i + 1])) + 1j * rng.standard_normal((dims[i], caps[i], caps[i + 1])) for i in range(L)],
+             physical_dimensions=list(dims))
+    st.normalize("B")
+    out.update(pack_tensors("in", st.tensors))
+    p = sp.AnalogSimParams(observables=[sp.Observable(number[dims[0]], 0)], elapsed_time=0.05, dt=0.05, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-12)
+    work = MPS(L, tensors=[t.copy() for t in st.tensors], physical_dimensions=list(dims))
+    ref("core.methods.tdvp.tdvp").tdvp(work, H, p)
+    out["tdvp_vec"] = work.to_vec()
+    out["tdvp_bonds"] = np.array([t.shape[2] for t in work.tensors])
+    basis = "".join(str(1 if dims[i] == 2 else 2 - (i // 2) % 2) for i in range(L))
+    out["basis"] = np.array(basis)
+    fock = MPS(L, physical_dimensions=list(dims), state="basis", basis_string=basis)
+    noise = NoiseModel([{"name": "loss", "sites": [i], "strength": 0.25, "matrix": lower[dims[i]]} for i in range(L)])
+    for order, fn in ((1, tjm.analog_tjm_1), (2, tjm.analog_tjm_2)):
+        p = sp.AnalogSimParams(observables=[sp.Observable(number[dims[s]], s) for s in range(L)], elapsed_time=0.4, dt=0.1, num_traj=3, max_bond_dim=chi,
+                               svd_threshold=1e-10, krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=6)
+        rows, diags = [], []
+        for i in range(3):
+            r = fn((i, fock, noise, p, H))
+            rows.append(np.asarray(r[0], dtype=np.float64))
+            diags.append(np.asarray(r[1], dtype=np.float64))
+        out[f"order{order}_results"] = np.array(rows)
+        out[f"order{order}_diag"] = np.array(diags)
+    save("mixed_dims", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tiny", "rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
     for w in which:

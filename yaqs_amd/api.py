@@ -670,19 +670,19 @@ class MPS:
             self.tensors = [np.asarray(t, dtype=C128) for t in tensors]
             if physical_dimensions is None:
                 dims = [int(t.shape[0]) for t in self.tensors]
-        if length and (len(set(dims)) != 1 or not 2 <= dims[0] <= 4):
-            raise NotImplementedError("the HIP path holds one local dimension per chain, 2, 3 or 4 (mixed or larger dimensions are not built)")
+        if length and not all(2 <= q <= 4 for q in dims):
+            raise NotImplementedError("the HIP path holds local dimensions 2, 3 and 4 (larger ones are not built)")
         self.physical_dimensions = dims
         if tensors is not None:
             return
-        d = dims[0] if length else 2
         s = 1 / np.sqrt(2)
         self.tensors = []
         if state == "haar-random":
             chi = 1 if pad is None else pad
-            caps = self.bond_caps(length, chi, d)
+            caps = self.bond_caps(length, chi, dims)
             rng = rng if rng is not None else np.random.default_rng()
             for i in range(length):
+                d = dims[i]
                 cl, cr = caps[i], caps[i + 1]
                 x = rng.standard_normal((d * cl, cr)) + 1j * rng.standard_normal((d * cl, cr))
                 q, r = np.linalg.qr(x, mode="reduced")
@@ -693,6 +693,7 @@ class MPS:
                 self.tensors.append((q / ph[np.newaxis, :]).reshape(d, cl, cr).astype(C128))
             return
         for i in range(length):
+            d = dims[i]
             v = np.zeros(d, dtype=C128)
             if state == "zeros":
                 v[0] = 1
@@ -715,7 +716,7 @@ class MPS:
                 v[:2] = (r, 1 - r)
                 v /= np.linalg.norm(v)
             elif state == "basis":   # one character per site, site 0 first (mps.py:395-408); digits up to d - 1 for qudits
-                if basis_string is None or len(basis_string) != length or not all(c.isdigit() and int(c) < d for c in basis_string):
+                if basis_string is None or len(basis_string) != length or not (basis_string[i].isdigit() and int(basis_string[i]) < d):
                     raise ValueError("state='basis' needs basis_string of one digit below the local dimension per site")
                 v[int(basis_string[i])] = 1
             else:
@@ -860,7 +861,7 @@ class MPS:
     def pad_bond_dimension(self, target_dim: int) -> None:
         """Zero-pad every internal bond k to ``min(target_dim, 2**min(k, L-k))`` and re-canonicalise (mps.py:409-452): the start
         of fixed-chi runs such as one-site TDVP, whose tangent space is spanned by the padded isometries."""
-        caps = self.bond_caps(self.length, target_dim)
+        caps = self.bond_caps(self.length, target_dim, self.physical_dimensions)
         for i, t in enumerate(self.tensors):
             d, cl, cr = t.shape
             if cl > caps[i] or cr > caps[i + 1]:
@@ -889,15 +890,17 @@ class MPS:
         t[0] = t[0] / np.linalg.norm(t[0])
 
     @staticmethod
-    def bond_caps(length: int, target: int, d: int = 2) -> list[int]:
+    def bond_caps(length: int, target: int, d=2) -> list[int]:
+        """Feasible bond dimensions for a target maximum (mps.py:130-168); ``d``: one local dimension or one per site."""
+        dims = [int(d)] * length if np.isscalar(d) else [int(q) for q in d]
         caps = [1] * (length + 1)
         left = 1
         for i in range(1, length):
-            left *= d
+            left *= dims[i - 1]
             caps[i] = left
         right = 1
         for i in range(length - 1, 0, -1):
-            right *= d
+            right *= dims[i]
             caps[i] = min(caps[i], right, target)
         return caps
 
@@ -1032,6 +1035,38 @@ class MPO:
         w[0, 2], w[2, 3] = a, -hopping_j * ad
         w[0, 3] = omega * n + 0.5 * hubbard_u * (n @ (n - one))
         return cls._fsm(length, w)
+
+    @classmethod
+    def coupled_transmon(cls, length: int, qubit_dim: int, resonator_dim: int, qubit_freq: float, resonator_freq: float, anharmonicity: float,
+                         coupling: float) -> "MPO":
+        """Chain of transmons (even sites, ``qubit_dim`` levels, Duffing oscillators w n + alpha/2 n (n - 1)) and resonators (odd sites,
+        ``resonator_dim`` levels, w n), neighbours coupled by g (b + b^dag)(a + a^dag): the bond-dimension-4 MPO of mpo.py:549-668, whose
+        sites differ in dimension.  Channel 0 / 3 carry "nothing placed yet" / "term complete" between a qubit and the next; a resonator
+        hands the channels on crosswise (its own term sits between two qubits)."""
+        def ladder(d_):
+            return np.diag(np.sqrt(np.arange(1, d_, dtype=np.float64)), 1).astype(C128)
+
+        b, a = ladder(int(qubit_dim)), ladder(int(resonator_dim))
+        one_q, one_r = np.eye(b.shape[0], dtype=C128), np.eye(a.shape[0], dtype=C128)
+        n_q, n_r = b.conj().T @ b, a.conj().T @ a
+        h_q = qubit_freq * n_q + 0.5 * anharmonicity * (n_q @ (n_q - one_q))
+        h_r = resonator_freq * n_r
+        x_q, x_r = b + b.conj().T, a + a.conj().T
+        tensors = []
+        for i in range(length):
+            if i % 2 == 0:
+                w = np.zeros((4, 4) + one_q.shape, dtype=C128)
+                w[0, 0], w[0, 1], w[0, 2], w[0, 3] = h_q, one_q, coupling * x_q, one_q
+                w[1, 3], w[3, 3] = coupling * x_q, one_q
+                if i == 0:
+                    w = w[0:1]
+                elif i == length - 1:
+                    w = np.stack([one_q, coupling * x_q, one_q, h_q])[:, None]
+            else:
+                w = np.zeros((4, 4) + one_r.shape, dtype=C128)
+                w[0, 0], w[1, 2], w[2, 0], w[3, 1], w[3, 3] = one_r, h_r, x_r, x_r, one_r
+            tensors.append(np.ascontiguousarray(w.transpose(2, 3, 0, 1)))
+        return cls(tensors)
 
     @staticmethod
     def _check_bc(bc: str, length: int) -> bool:

@@ -732,14 +732,28 @@ class Simulator:
             hamiltonian = pieces[0]
         if hamiltonian.length != initial_state.length:
             raise ValueError("State and Hamiltonian must have the same number of sites")  # tdvp.py:91-93
-        d = int(initial_state.physical_dimensions[0]) if getattr(initial_state, "physical_dimensions", None) else 2
-        if any(int(w.shape[0]) != d or int(w.shape[1]) != d for w in hamiltonian.tensors):
-            raise ValueError("State and Hamiltonian must have the same physical dimensions")
-        validate_noise_model_for_run(noise_model, length=initial_state.length, physical_dimensions=d, is_digital=False,
-                                     sim_params=sim_params)  # simulator.py:1488-1516
+        hamiltonian = _closed_boundaries(hamiltonian)
+        if pieces is not None:
+            pieces = [_closed_boundaries(h_) for h_ in pieces]
+        site_dims = [int(q) for q in (getattr(initial_state, "physical_dimensions", None) or [2] * initial_state.length)]
+        d = max(site_dims)
+        for h_ in (pieces if pieces is not None else [hamiltonian]):
+            if any(int(w.shape[0]) != site_dims[i] or int(w.shape[1]) != site_dims[i] for i, w in enumerate(h_.tensors)):
+                raise ValueError("State and Hamiltonian must have the same physical dimensions")
+        validate_noise_model_for_run(noise_model, length=initial_state.length, physical_dimensions=site_dims if len(set(site_dims)) > 1 else d,
+                                     is_digital=False, sim_params=sim_params)  # simulator.py:1488-1516
         if noise_model is not None:  # one realisation of static disorder per run (simulator.py:1269-1271)
             noise_model = noise_model.sample(rng=disorder_rng(sim_params.random_seed))
         initial_state = _encoded(initial_state)
+        user_params, user_noise = sim_params, noise_model
+        if len(set(site_dims)) > 1:  # sites of different dimension: zero-padded onto the engine's one-dimension storage
+            initial_state, padded, sim_params, noise_model, _ = embed_mixed_dimensions(
+                initial_state, [h_.tensors for h_ in (pieces if pieces is not None else [hamiltonian])], sim_params, noise_model)
+            if pieces is not None:
+                pieces = [MPO(t) for t in padded]
+                hamiltonian = pieces[0]
+            else:
+                hamiltonian = MPO(padded[0])
         rank, world = 0, 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
@@ -794,15 +808,18 @@ class Simulator:
                 use_psi = sim_params.order == 2 and len(sim_params.times) > 1
                 from .api import State
 
-                final = State(tensors=last.export_state(0, 1 if use_psi else 0))  # result.output_state is a State (result.py:155-189)
+                out_t = last.export_state(0, 1 if use_psi else 0)
+                if len(set(site_dims)) > 1:  # back to the chain's own dimensions (the added levels hold exact zeros)
+                    out_t = [t[: site_dims[i]] for i, t in enumerate(out_t)]
+                final = State(tensors=out_t, physical_dimensions=site_dims if d != 2 else None)  # result.output_state is a State (result.py:155-189)
                 last.close()
         if world > 1:
             res_all, diag_all = gather_trajectories(res_all, diag_all, num_traj, lo, device)
             if any(ob.gate.name == "schmidt_spectrum" for ob in sim_params.observables):
                 schmidt = gather_counts_like(schmidt, device)
-        out = Result(sim_params, res_all, diag_all, schmidt=schmidt)
+        out = Result(user_params, res_all, diag_all, schmidt=schmidt)
         out.output_state = final
-        out.noise_model = noise_model  # the sampled realisation the trajectories ran with (result.py:155-189)
+        out.noise_model = user_noise  # the sampled realisation the trajectories ran with (result.py:155-189)
         return out
 
     def run_circuit(self, initial_state: MPS, layers, sim_params, noise_model: NoiseModel | None = None, basis: str = "Z"):
@@ -880,6 +897,73 @@ class Simulator:
         out = CircuitResult(sim_params, res_all if has_obs else None, diag_all, counts if wants_shots else None, schmidt=schmidt)
         out.noise_model = noise_model
         return out
+
+
+def _closed_boundaries(mpo: MPO) -> MPO:
+    """An MPO whose outer bonds are wider than 1 (the reference's coupled-transmon chain of even length ends on a resonator tensor with
+    an open right bond of 4, mpo.py:549-668) meets boundary environments that are the identity for EVERY channel of that bond
+    (integrators.py:186-193, primitives.py:139-174), i.e. the channels are summed: the same operator with outer bonds of 1 is the
+    boundary tensor summed over them."""
+    t = list(mpo.tensors)
+    if t[0].shape[2] == 1 and t[-1].shape[3] == 1:
+        return mpo
+    t[0] = np.asarray(t[0]).sum(axis=2, keepdims=True)
+    t[-1] = np.asarray(t[-1]).sum(axis=3, keepdims=True)
+    return MPO(t)
+
+
+def _pad_operator(matrix, site_dims, d: int) -> np.ndarray:
+    """A local operator on sites of dimensions ``site_dims`` as an operator on sites of dimension ``d`` (zero on the added levels)."""
+    k = len(site_dims)
+    m = np.asarray(matrix, dtype=np.complex128).reshape(tuple(site_dims) * 2)
+    out = np.zeros((d,) * (2 * k), dtype=np.complex128)
+    out[tuple(slice(0, q) for q in site_dims) * 2] = m
+    return out.reshape(d ** k, d ** k)
+
+
+def embed_mixed_dimensions(initial_state, mpos, sim_params, noise_model):
+    """Chains whose sites differ in dimension (the reference's coupled-transmon chains, mpo.py:549-668) run on the engine's uniform
+    storage ``[B][d][cap][cap]`` with d = the largest local dimension: state tensors, MPO tensors, jump operators and observables are
+    zero-padded on the physical legs.  A Hamiltonian, a dissipator and a jump operator that are zero on the added levels never
+    populate them, so every expectation value, jump probability and singular value is that of the original chain; the output state is
+    cut back to its own dimensions.  Returns (state, [mpo tensor lists], sim_params, noise_model, dims)."""
+    import copy
+
+    dims = [int(q) for q in initial_state.physical_dimensions]
+    d = max(dims)
+    st = MPS(initial_state.length, tensors=[np.pad(np.asarray(t, dtype=np.complex128), ((0, d - t.shape[0]), (0, 0), (0, 0))) for t in initial_state.tensors],
+             physical_dimensions=[d] * initial_state.length)
+    padded_mpos = []
+    for tensors in mpos:
+        for i, w in enumerate(tensors):
+            if int(w.shape[0]) != dims[i] or int(w.shape[1]) != dims[i]:
+                raise ValueError("State and Hamiltonian must have the same physical dimensions")
+        padded_mpos.append([np.pad(np.asarray(w, dtype=np.complex128), ((0, d - w.shape[0]), (0, d - w.shape[1]), (0, 0), (0, 0))) for w in tensors])
+    params = copy.copy(sim_params)
+    obs = []
+    for ob in sim_params.observables:
+        if ob.gate.name in META_OBSERVABLES:
+            obs.append(ob)
+            continue
+        sites = list(ob.sites) if isinstance(ob.sites, (list, tuple)) else [ob.sites]
+        clone = copy.copy(ob)
+        clone.gate = copy.copy(ob.gate)
+        clone.gate.matrix = _pad_operator(ob.gate.matrix, [dims[q] for q in sites], d)
+        obs.append(clone)
+    params.observables = obs
+    noise = noise_model
+    if noise_model is not None:
+        noise = copy.copy(noise_model)
+        procs = []
+        for proc in noise_model.processes:
+            q = dict(proc)
+            if "matrix" in q:
+                q["matrix"] = _pad_operator(q["matrix"], [dims[s_] for s_ in q["sites"]], d)
+            if "factors" in q:
+                q["factors"] = tuple(_pad_operator(f, [dims[s_]], d) for f, s_ in zip(q["factors"], q["sites"]))
+            procs.append(q)
+        noise.processes = procs
+    return st, padded_mpos, params, noise, dims
 
 
 def _encoded(state: MPS) -> MPS:
