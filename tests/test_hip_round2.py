@@ -710,3 +710,24 @@ def test_mixed_local_dimensions_match_reference_fixture():
         for s_ in range(L):
             assert np.allclose(res.trajectories[s_], want[:, s_, :], atol=1e-8), (order, s_)
         assert np.array_equal(res.trajectory_diagnostics, g[f"order{order}_diag"]), order  # sum chi^3, largest bond, sum chi: as the reference records them
+
+
+def test_fermi_hubbard_chain_on_four_level_sites_matches_reference_fixture():
+    """MPO.fermi_hubbard_1d (mpo.py:409-520: composite four-level sites, bond dimension 6) against tests/golden/fermi_hubbard.npz - the
+    reference's MPO tensors and one closed two-site TDVP step from a seeded random state (16 x 16 ... 32 x 32 two-site blocks, P = 16
+    MPO stage), through Simulator with get_state."""
+    from yaqs_amd.api import AnalogSimParams, MPO, MPS, Observable
+    from yaqs_amd.tjm import Simulator
+
+    g = load("fermi_hubbard")
+    L = 4
+    H = MPO.fermi_hubbard_1d(L, 1.0, 2.0)
+    assert all(np.allclose(H.tensors[i], g[f"mpo{i}"]) for i in range(L))
+    n_up = np.kron(np.diag([0.0, 1.0]), np.eye(2)).astype(complex)
+    p = AnalogSimParams(observables=[Observable(n_up, 0)], elapsed_time=0.05, dt=0.05, max_bond_dim=8, svd_threshold=1e-10, krylov_tol=1e-12, get_state=True,
+                        sample_timesteps=False)
+    res = Simulator().run(MPS(L, tensors=tensors(g, "in"), physical_dimensions=4), H, p)
+    out = res.output_state
+    assert [t.shape[2] for t in out.tensors] == list(g["tdvp_bonds"])
+    ref = g["tdvp_vec"]
+    assert abs(abs(np.vdot(ref, out.to_vec())) - np.vdot(ref, ref).real) < 1e-9

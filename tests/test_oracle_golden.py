@@ -592,6 +592,16 @@ def test_mixed_local_dimensions_match_reference():
             assert np.array_equal(dg, g[f"order{order}_diag"][t]), (order, t)
 
 
+def test_fermi_hubbard_step_matches_reference():
+    """Composite four-level sites, MPO of bond dimension 6 (tests/golden/fermi_hubbard.npz): one closed two-site TDVP step."""
+    g = load("fermi_hubbard")
+    st = o.MPSState([t.copy() for t in tensors(g, "in")], 0)
+    o.tdvp(st, tensors(g, "mpo"), o.Params(dt=0.05, svd_threshold=1e-10, max_bond_dim=8, krylov_tol=1e-12))
+    assert [t.shape[2] for t in st.tensors] == list(g["tdvp_bonds"])
+    ref = g["tdvp_vec"]
+    assert abs(abs(np.vdot(ref, st.to_vec())) - np.vdot(ref, ref).real) < 1e-10
+
+
 def _continuation_setup(g):
     L = 5
     mpo = tensors(g, "mpo")

@@ -916,6 +916,30 @@ def gen_mixed_dims():
     save("mixed_dims", **out)
 
 
+# ------------------------------------------------------------------ 20. Fermi-Hubbard chain on composite four-level sites
+def gen_fermi_hubbard():
+    """MPO.fermi_hubbard_1d (mpo.py:409-520, fermionic ladder operators on dimension-4 sites, bond dimension 6): the MPO tensors and one
+    closed two-site TDVP step from a seeded random state."""
+    out = {}
+    L, chi = 4, 8
+    H = MPO.fermi_hubbard_1d(L, 1.0, 2.0)
+    out.update(pack_tensors("mpo", H.tensors))
+    rng = np.random.default_rng(23)
+    caps = [1] * (L + 1)
+    for i in range(1, L):
+        caps[i] = min(4 ** i, 4 ** (L - i), chi)
+    st = MPS(L, tensors=[rng.standard_normal((4, caps[i], caps[i + 1])) + 1j * rng.standard_normal((4, caps[i], caps[i + 1])) for i in range(L)],
+             physical_dimensions=[4] * L)
+    st.normalize("B")
+    out.update(pack_tensors("in", st.tensors))
+    n_up = np.kron(np.diag([0.0, 1.0]), np.eye(2))
+    p = sp.AnalogSimParams(observables=[sp.Observable(n_up.astype(complex), 0)], elapsed_time=0.05, dt=0.05, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-12)
+    ref("core.methods.tdvp.tdvp").tdvp(st, H, p)
+    out["tdvp_vec"] = st.to_vec()
+    out["tdvp_bonds"] = np.array([t.shape[2] for t in st.tensors])
+    save("fermi_hubbard", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["tiny", "rng", "truncate", "kernels", "tdvp", "noise", "traj", "digital", "shots", "scheduled", "piecewise"]
     for w in which:

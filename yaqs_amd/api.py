@@ -1037,6 +1037,26 @@ class MPO:
         return cls._fsm(length, w)
 
     @classmethod
+    def fermi_hubbard_1d(cls, length: int, t: float, u: float) -> "MPO":
+        """H = U sum_i n_{i,up} n_{i,down} - t sum_{i,s} (c^dag_{i,s} c_{i+1,s} + h.c.) on composite four-level sites |n_up n_down>, written
+        with the site-local ladder operators c_up = c (x) 1, c_down = 1 (x) c (the fermionic embedding of mpo.py:472-520, not the
+        Jordan-Wigner chain): the bond-dimension-6 automaton whose states 1-4 have placed c_up^dag, c_down^dag, c_up, c_down and wait for
+        -t times the partner operator on the next site."""
+        if length <= 0:
+            raise ValueError("length must be positive.")
+        c = np.array([[0, 1], [0, 0]], dtype=C128)
+        one2 = np.eye(2, dtype=C128)
+        c_up, c_dn = np.kron(c, one2), np.kron(one2, c)
+        n_up, n_dn = np.kron(c.conj().T @ c, one2), np.kron(one2, c.conj().T @ c)
+        one = np.eye(4, dtype=C128)
+        w = np.zeros((6, 6, 4, 4), dtype=C128)
+        w[0, 0], w[5, 5], w[0, 5] = one, one, u * (n_up @ n_dn)
+        for k, (first, partner) in enumerate(((c_up.conj().T, c_up), (c_dn.conj().T, c_dn), (c_up, c_up.conj().T), (c_dn, c_dn.conj().T))):
+            w[0, 1 + k] = first
+            w[1 + k, 5] = -t * partner
+        return cls._fsm(length, w)
+
+    @classmethod
     def coupled_transmon(cls, length: int, qubit_dim: int, resonator_dim: int, qubit_freq: float, resonator_freq: float, anharmonicity: float,
                          coupling: float) -> "MPO":
         """Chain of transmons (even sites, ``qubit_dim`` levels, Duffing oscillators w n + alpha/2 n (n - 1)) and resonators (odd sites,
