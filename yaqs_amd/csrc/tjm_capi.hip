@@ -91,6 +91,11 @@ int tjm_engine_set_params(tjm_engine* e, double dt, double svd_threshold, int32_
   if (!e || !(dt > 0) || trunc_mode < 0 || trunc_mode > 3 || tdvp_sweeps < 1) return TJM_ERR_ARG;
   e->impl.dt = dt; e->impl.svd_threshold = svd_threshold; e->impl.trunc_mode = trunc_mode; e->impl.max_bond = max_bond;
   e->impl.krylov_tol = krylov_tol; e->impl.tdvp_mode = tdvp_mode; e->impl.tdvp_sweeps = tdvp_sweeps;
+#ifdef TJM_F32
+  // the adaptive stop of the Lanczos exponential cannot see below the rounding of its own vectors: a tolerance under ~100 eps would
+  // only run every exponential to the iteration cap
+  if (e->impl.krylov_tol < 100.0 * TJM_EPS) e->impl.krylov_tol = 100.0 * TJM_EPS;
+#endif
   return TJM_OK;
 }
 
