@@ -963,6 +963,14 @@ def embed_mixed_dimensions(initial_state, mpos, sim_params, noise_model):
                 q["factors"] = tuple(_pad_operator(f, [dims[s_]], d) for f, s_ in zip(q["factors"], q["sites"]))
             procs.append(q)
         noise.processes = procs
+        jumps = []
+        for jump in getattr(noise_model, "scheduled_jumps", None) or []:
+            q = dict(jump)
+            if "matrix" in q:
+                q["matrix"] = _pad_operator(q["matrix"], [dims[s_] for s_ in q["sites"]], d)
+            jumps.append(q)
+        if jumps:
+            noise.scheduled_jumps = jumps
     return st, padded_mpos, params, noise, dims
 
 
