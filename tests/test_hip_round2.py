@@ -710,6 +710,15 @@ def test_mixed_local_dimensions_match_reference_fixture():
         for s_ in range(L):
             assert np.allclose(res.trajectories[s_], want[:, s_, :], atol=1e-8), (order, s_)
         assert np.array_equal(res.trajectory_diagnostics, g[f"order{order}_diag"]), order  # sum chi^3, largest bond, sum chi: as the reference records them
+    # scheduled jumps with operators of the sites' own dimensions: one-site on a transmon, a pair on (transmon, resonator)
+    sched = [{"time": 0.1, "sites": [2], "name": "custom", "matrix": lower[3]},
+             {"time": 0.2, "sites": [2, 3], "name": "custom", "matrix": np.kron(number[3] + 0.5 * lower[3], lower[2].conj().T + np.eye(2))}]
+    noise_s = NoiseModel([{"name": "loss", "sites": [i], "strength": 0.1, "matrix": lower[dims[i]]} for i in range(L)], scheduled_jumps=sched)
+    p = AnalogSimParams(observables=[Observable(number[dims[s]], s) for s in range(L)], elapsed_time=0.4, dt=0.1, num_traj=3, max_bond_dim=8,
+                        svd_threshold=1e-10, krylov_tol=1e-12, order=1, sample_timesteps=True, random_seed=8)
+    res = Simulator(batch=3).run(fock, H, p, noise_s)
+    for s_ in range(L):
+        assert np.allclose(res.trajectories[s_], g["scheduled_results"][:, s_, :], atol=1e-8), s_
 
 
 def test_fermi_hubbard_chain_on_four_level_sites_matches_reference_fixture():

@@ -590,6 +590,15 @@ def test_mixed_local_dimensions_match_reference():
             r, dg, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, mpo)
             assert np.allclose(r, g[f"order{order}_results"][t], atol=1e-9), (order, t)
             assert np.array_equal(dg, g[f"order{order}_diag"][t]), (order, t)
+    # scheduled jumps with operators of the sites' own dimensions
+    sched = [{"time": 0.1, "sites": [2], "matrix": lower[3]},
+             {"time": 0.2, "sites": [2, 3], "matrix": np.kron(number[3] + 0.5 * lower[3], lower[2].conj().T + np.eye(2))}]
+    on = [o.make_process("loss", [i], 0.1, matrix=lower[dims[i]]) for i in range(L)]
+    op = o.Params(observables=[o.Obs(number[dims[s]], s) for s in range(L)], elapsed_time=0.4, dt=0.1, max_bond_dim=8, svd_threshold=1e-10, krylov_tol=1e-12,
+                  order=1, sample_timesteps=True, random_seed=8)
+    for t in range(3):
+        r, _, _ = o.analog_tjm_1(t, o.MPSState([x.copy() for x in init], 0), on, op, mpo, scheduled=sched)
+        assert np.allclose(r, g["scheduled_results"][t], atol=1e-9), t
 
 
 def test_fermi_hubbard_step_matches_reference():

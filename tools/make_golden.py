@@ -913,6 +913,13 @@ def gen_mixed_dims():
             diags.append(np.asarray(r[1], dtype=np.float64))
         out[f"order{order}_results"] = np.array(rows)
         out[f"order{order}_diag"] = np.array(diags)
+    # scheduled jumps (scheduled_jumps.py:51-119) with operators of the sites' own dimensions: one-site on a transmon, pair on (transmon, resonator)
+    sched = [{"time": 0.1, "sites": [2], "name": "custom", "matrix": lower[dq]},
+             {"time": 0.2, "sites": [2, 3], "name": "custom", "matrix": np.kron(number[dq] + 0.5 * lower[dq], lower[dr].conj().T + np.eye(dr))}]
+    noise_s = NoiseModel([{"name": "loss", "sites": [i], "strength": 0.1, "matrix": lower[dims[i]]} for i in range(L)], scheduled_jumps=sched)
+    p = sp.AnalogSimParams(observables=[sp.Observable(number[dims[s]], s) for s in range(L)], elapsed_time=0.4, dt=0.1, num_traj=3, max_bond_dim=chi,
+                           svd_threshold=1e-10, krylov_tol=1e-12, order=1, sample_timesteps=True, random_seed=8)
+    out["scheduled_results"] = np.array([np.asarray(tjm.analog_tjm_1((i, fock, noise_s, p, H))[0], dtype=np.float64) for i in range(3)])
     save("mixed_dims", **out)
 
 

@@ -177,11 +177,11 @@ class BatchEngine:
         _lib.check(self.lib.tjm_engine_apply_single(self.h, set_index, int(site), m.ctypes.data), "apply_single")
 
     def tebd_gate(self, left: int, u4: np.ndarray, set_index: int = 0, center: int = 0):
-        u = np.ascontiguousarray(np.asarray(u4, dtype=np.complex128).reshape(4, 4))
+        u = np.ascontiguousarray(np.asarray(u4, dtype=np.complex128).reshape(self.d ** 2, self.d ** 2))
         _lib.check(self.lib.tjm_engine_tebd_gate_at(self.h, set_index, int(left), int(center), u.ctypes.data), "tebd_gate")
 
     def apply_pair(self, left: int, matrix: np.ndarray, min_keep: int = 1, set_index: int = 0):
-        m = np.ascontiguousarray(np.asarray(matrix, dtype=np.complex128).reshape(4, 4))
+        m = np.ascontiguousarray(np.asarray(matrix, dtype=np.complex128).reshape(self.d ** 2, self.d ** 2))
         _lib.check(self.lib.tjm_engine_apply_pair(self.h, set_index, int(left), m.ctypes.data, int(min_keep)), "apply_pair")
 
     def canonicalize_qr(self, center: int, set_index: int = 0):
