@@ -306,7 +306,7 @@ def main():
         engines.append(eng)
         trajs.append(list(range(first, first + nb)))
         first += nb
-    lib = _lib.load()
+    lib = _lib.load(args.dtype)  # the library the engines run on (its Jacobi launch sampler)
 
     class Drive:
         """One host thread per engine: the steps of its trajectories, the measurement at the end of every trajectory."""
