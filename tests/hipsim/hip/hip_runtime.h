@@ -67,7 +67,7 @@ void sync_block();
 void sync_wave();
 // every live lane of the wavefront deposits (a, b); returns the 64 deposited pairs (zero for lanes that have left the kernel)
 const unsigned long long (*exchange(unsigned long long a, unsigned long long b))[2];
-void launch_impl(const char* name, dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* arg);
+void launch_impl(const char* name, dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* arg, const void* kernel);
 
 inline void* dyn_shared() { return blk->dyn; }
 
@@ -99,7 +99,7 @@ template <class... P, class... A>
 inline void launch(const char* name, void (*k)(P...), dim3 grid, dim3 block, size_t shmem, A&&... a) {
   using Tup = std::tuple<std::decay_t<P>...>;
   Thunk<void (*)(P...), Tup> t{k, Tup(std::forward<A>(a)...)};
-  launch_impl(name, grid, block, shmem, &Thunk<void (*)(P...), Tup>::run, &t);
+  launch_impl(name, grid, block, shmem, &Thunk<void (*)(P...), Tup>::run, &t, reinterpret_cast<const void*>(k));
 }
 
 }  // namespace hipsim
@@ -340,8 +340,14 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
   return hipSuccess;
 }
+namespace hipsim {
+void set_max_dynamic_lds(const void* kernel, int bytes);
+}
 template <class F>
-inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(F f, hipFuncAttribute attr, int value) {
+  if (attr == hipFuncAttributeMaxDynamicSharedMemorySize) hipsim::set_max_dynamic_lds(reinterpret_cast<const void*>(f), value);
+  return hipSuccess;
+}
 inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
   a->type = 2;
   a->device = 0;

@@ -361,7 +361,32 @@ void store_hook(uintptr_t addr) {
   f->waiting = 0;
 }
 
-void launch_impl(const char* name, dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* arg) {
+namespace {
+std::mutex attr_mutex;
+std::vector<std::pair<const void*, int>> lds_attr;  // kernels that were granted more than the default dynamic LDS
+}  // namespace
+
+void set_max_dynamic_lds(const void* kernel, int bytes) {
+  std::lock_guard<std::mutex> lk(attr_mutex);
+  for (auto& e : lds_attr)
+    if (e.first == kernel) { e.second = bytes; return; }
+  lds_attr.emplace_back(kernel, bytes);
+}
+
+void launch_impl(const char* name, dim3 grid, dim3 block, size_t shmem, void (*tramp)(void*), void* arg, const void* kernel) {
+  if (shmem > 64 * 1024) {  // the device refuses such a launch unless hipFuncSetAttribute raised the kernel's limit first
+    int granted = 0;
+    {
+      std::lock_guard<std::mutex> lk(attr_mutex);
+      for (auto& e : lds_attr)
+        if (e.first == kernel) granted = e.second;
+    }
+    if ((size_t)granted < shmem) {
+      fprintf(stderr, "[hipsim] launch of %s with %zu bytes of dynamic LDS, but hipFuncAttributeMaxDynamicSharedMemorySize was %s (%d)\n", name, shmem,
+              granted ? "set lower" : "never set", granted);
+      abort();
+    }
+  }
   const long total = (long)grid.x * grid.y * grid.z;
   const int nt = (int)(block.x * block.y * block.z);
   if (total <= 0 || nt <= 0) return;
