@@ -390,6 +390,11 @@ void launch_impl(const char* name, dim3 grid, dim3 block, size_t shmem, void (*t
   const long total = (long)grid.x * grid.y * grid.z;
   const int nt = (int)(block.x * block.y * block.z);
   if (total <= 0 || nt <= 0) return;
+  if (grid.y > 65535u || grid.z > 65535u || block.z > 64u) {
+    fprintf(stderr, "[hipsim] launch of %s: grid (%u,%u,%u) block (%u,%u,%u) exceeds the device limits (grid y / z <= 65535)\n", name, grid.x, grid.y, grid.z,
+            block.x, block.y, block.z);
+    abort();
+  }
   if (nt > MAX_THREADS || shmem > LDS_BYTES) {
     fprintf(stderr, "[hipsim] launch of %s: %d threads, %zu bytes of LDS exceed the device limits\n", name, nt, shmem);
     abort();
