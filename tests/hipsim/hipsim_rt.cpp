@@ -361,7 +361,22 @@ void store_hook(uintptr_t addr) {
   f->waiting = 0;
 }
 
+struct hipsim_bound { const char* name; int threads; };
+extern "C" const hipsim_bound hipsim_bounds[];  // generated by build.py from the kernels' __launch_bounds__
+
 namespace {
+// "(jacobi_diag_kernel<8>)" -> "jacobi_diag_kernel"
+int declared_thread_limit(const char* launch_name) {
+  std::string n(launch_name);
+  size_t b = 0;
+  while (b < n.size() && (n[b] == '(' || n[b] == ' ')) ++b;
+  size_t e = b;
+  while (e < n.size() && (isalnum((unsigned char)n[e]) || n[e] == '_')) ++e;
+  const std::string base = n.substr(b, e - b);
+  for (const hipsim_bound* p = hipsim_bounds; p->name; ++p)
+    if (base == p->name) return p->threads;
+  return 0;
+}
 std::mutex attr_mutex;
 std::vector<std::pair<const void*, int>> lds_attr;  // kernels that were granted more than the default dynamic LDS
 }  // namespace
@@ -390,6 +405,12 @@ void launch_impl(const char* name, dim3 grid, dim3 block, size_t shmem, void (*t
   const long total = (long)grid.x * grid.y * grid.z;
   const int nt = (int)(block.x * block.y * block.z);
   if (total <= 0 || nt <= 0) return;
+  if (const int limit = declared_thread_limit(name)) {
+    if ((int)(block.x * block.y * block.z) > limit) {
+      fprintf(stderr, "[hipsim] launch of %s with %u threads, its __launch_bounds__ allow %d\n", name, block.x * block.y * block.z, limit);
+      abort();
+    }
+  }
   if (grid.y > 65535u || grid.z > 65535u || block.z > 64u) {
     fprintf(stderr, "[hipsim] launch of %s: grid (%u,%u,%u) block (%u,%u,%u) exceeds the device limits (grid y / z <= 65535)\n", name, grid.x, grid.y, grid.z,
             block.x, block.y, block.z);
