@@ -156,6 +156,13 @@ inline int __any(int pred) {
   for (int l = 0; l < 64; ++l) r |= (int)x[l][0];
   return r;
 }
+inline unsigned long long __ballot(int pred) {
+  auto x = hipsim::exchange(pred ? 1ull : 0ull, 0);
+  unsigned long long r = 0;
+  for (int l = 0; l < 64; ++l) r |= (x[l][0] & 1ull) << l;
+  return r;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int hipsim_readlane(int v, int lane) {
   auto x = hipsim::exchange((unsigned long long)(unsigned)v, 0);
   return (int)(unsigned)x[lane & 63][0];
@@ -248,8 +255,18 @@ inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
 inline double min(double a, double b) { return std::fmin(a, b); }
 inline double max(double a, double b) { return std::fmax(a, b); }
 inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
-#define __builtin_amdgcn_rsq(x) (1.0 / std::sqrt((double)(x)))
-#define __builtin_amdgcn_rcp(x) (1.0 / (double)(x))
+// v_rsq_f64 / v_rcp_f64 are estimates good to 2^29 ulp (relative 2^-23): modelled at exactly that resolution (the low 29 bits of the
+// mantissa cleared), so code that needs the full precision has to earn it with its own Newton steps here as on the device
+inline double hipsim_estimate(double v) {
+  if (!std::isfinite(v)) return v;
+  unsigned long long u;
+  std::memcpy(&u, &v, 8);
+  u &= ~((1ull << 29) - 1ull);
+  std::memcpy(&v, &u, 8);
+  return v;
+}
+#define __builtin_amdgcn_rsq(x) hipsim_estimate(1.0 / std::sqrt((double)(x)))
+#define __builtin_amdgcn_rcp(x) hipsim_estimate(1.0 / (double)(x))
 #define __builtin_amdgcn_rsqf(x) (1.0f / std::sqrt((float)(x)))
 #define __builtin_amdgcn_rcpf(x) (1.0f / (float)(x))
 inline int __float_as_int(float v) { return hipsim::unbits<int>(hipsim::bits(v)); }

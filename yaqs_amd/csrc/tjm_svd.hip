@@ -140,9 +140,22 @@ __device__ inline real wave_sum4(real p0, real p1, real p2, real p3, int lane) {
 // fp64 reciprocal square root: hardware estimate + two Newton steps (full real precision)
 __device__ inline real fast_rsqrt(real x) {
   real y = tjm_rsq(x);
-  y = y * fma(-0.5 * x * y, y, 1.5);
-  y = y * fma(-0.5 * x * y, y, 1.5);
+  const real h = 0.5 * x;
+  y = fma(y, fma(-(h * y), y, 0.5), y);  // y (1 + (1/2 - x y^2 / 2))
+  y = fma(y, fma(-(h * y), y, 0.5), y);
   return y;
+}
+
+// sqrt(x), x > 0: the same estimate refined by two coupled (Goldschmidt) steps on g -> sqrt(x), h -> 1 / (2 sqrt(x)); two
+// instructions fewer than x * fast_rsqrt(x)
+__device__ inline real fast_sqrt(real x) {
+  const real y = tjm_rsq(x);
+  real g = x * y, h = 0.5 * y;
+  real e = fma(-g, h, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  e = fma(-g, h, 0.5);
+  return fma(g, e, g);
 }
 
 // Decide and build the rotation for the column pair with norms (a, d) and inner product g.
@@ -156,45 +169,40 @@ __device__ inline bool make_rotation(real a, real d, real gx, real gy, real tol2
   // a column ten decades smaller orthogonal to it.) (sigma < 1e-13 ||X||_F: such columns are
   // numerically null, carry no weight, and would otherwise be rotated against rounding noise for ever)
   if (!(mag2 > tol2 * a * d && a > nfloor && d > nfloor && mag2 > TJM_TINY)) return false;
-  const real inv_mag = fast_rsqrt(mag2);
-  const real mag = mag2 * inv_mag;
-  const real tau = 0.5 * (d - a) * inv_mag;
-  const real h2 = fma(tau, tau, 1.0);
-  const real hyp = h2 * fast_rsqrt(h2);                       // sqrt(1 + tau^2)
-  const real den = fabs(tau) + hyp;                           // >= 1
-  real t = tjm_rcp(den);
-  t = t * fma(-den, t, 2.0);
-  t = t * fma(-den, t, 2.0);
-  t = (tau >= 0.0) ? t : -t;
-  c = fast_rsqrt(fma(t, t, 1.0));
-  const real s = t * c;
-  sr = s * gx * inv_mag;
-  si = s * gy * inv_mag;
-  tg = t * mag;
+  // With delta = (d - a) / 2, r = sqrt(delta^2 + |g|^2), u = |delta| + r  (so u^2 + |g|^2 = 2 r u):
+  //   t = sgn(delta) |g| / u ,  c = u / sqrt(2 r u) ,  s = t c g / |g| = sgn(delta) g / sqrt(2 r u) ,  t |g| = sgn(delta) |g|^2 / u.
+  // Two reciprocal square roots and no division; c^2 + |s|^2 = (u^2 + |g|^2) / (2 r u) = 1 to the rounding of r.
+  const real delta = 0.5 * (d - a);
+  const real x = fma(delta, delta, mag2);
+  const real r = fast_sqrt(x);
+  const real u = fabs(delta) + r;
+  const real q = fast_rsqrt((r + r) * u);                      // 1 / sqrt(2 r u)
+  const real qs = (delta >= 0.0) ? q : -q;
+  c = u * q;
+  sr = qs * gx;
+  si = qs * gy;
+  tg = mag2 * ((r + r) * q) * qs;                              // sgn(delta) |g|^2 / u ,  1 / u = 2 r q^2
   return true;
 }
 
 // The same decision and rotation, evaluated per lane for wave_sum4 output: lane classes (0,1) carry (Re g, Im g) of
 // the first pair, classes (2,3) of the second.  own = this lane's component of g; (a, d) the norms of its pair.
-// Returns c, sv = s * own / |g| (Re s on even lanes, Im s on odd lanes) and tg; (1, 0, 0) when no rotation applies.
-__device__ inline void make_rotation_lanes(real a, real d, real own, real tol2, real nfloor, real& c, real& sv, real& tg) {
+// Gives c, sv = s * own / |g| (Re s on even lanes, Im s on odd lanes) and tg; (1, 0, 0) when no rotation applies.  Returns the
+// decision of this lane's pair.
+__device__ inline bool make_rotation_lanes(real a, real d, real own, real tol2, real nfloor, real& c, real& sv, real& tg) {
   const real sq = own * own;
   const real mag2 = sq + dpp_pull<0xB1>(sq);  // identical in both lanes of the pair (addition commutes)
   const bool rot = mag2 > tol2 * a * d && a > nfloor && d > nfloor && mag2 > TJM_TINY;
-  const real inv_mag = fast_rsqrt(mag2);
-  const real mag = mag2 * inv_mag;
-  const real tau = 0.5 * (d - a) * inv_mag;
-  const real h2 = fma(tau, tau, 1.0);
-  const real hyp = h2 * fast_rsqrt(h2);
-  const real den = fabs(tau) + hyp;
-  real t = tjm_rcp(den);
-  t = t * fma(-den, t, 2.0);
-  t = t * fma(-den, t, 2.0);
-  t = (tau >= 0.0) ? t : -t;
-  const real cc = fast_rsqrt(fma(t, t, 1.0));
-  c = rot ? cc : 1.0;
-  sv = rot ? t * cc * own * inv_mag : 0.0;
-  tg = rot ? t * mag : 0.0;
+  const real delta = 0.5 * (d - a);  // the formulas of make_rotation
+  const real x = fma(delta, delta, mag2);
+  const real r = fast_sqrt(x);
+  const real u = fabs(delta) + r;
+  const real q = fast_rsqrt((r + r) * u);
+  const real qs = (delta >= 0.0) ? q : -q;
+  c = rot ? u * q : 1.0;
+  sv = rot ? qs * own : 0.0;
+  tg = rot ? mag2 * ((r + r) * q) * qs : 0.0;
+  return rot;
 }
 
 __device__ inline void rotate_pair(cplx& p, cplx& q, real c, real sr, real si) {
@@ -520,7 +528,8 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
       const real gsum = wave_sum4(gx[0], gy[0], gx[1], gy[1], lane);
       const bool second = lane & 2;
       real cv, sv, tv;
-      make_rotation_lanes(second ? nI[1] : nI[0], second ? nJ[1 ^ sub] : nJ[sub], gsum, g.tol2, floor2, cv, sv, tv);
+      const bool rot = make_rotation_lanes(second ? nI[1] : nI[0], second ? nJ[1 ^ sub] : nJ[sub], gsum, g.tol2, floor2, cv, sv, tv);
+      cnt += __popcll(__ballot(rot) & 5ull);  // lanes 0 and 2 speak for the two pairs (scalar unit: the compare mask is in SGPRs)
       if (record && lane < 4) {
         real* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + (lane >> 1)) * 4);
         if (lane & 1) r4[2] = sv;
@@ -537,7 +546,6 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
         for (int k = 0; k < XRK; ++k) rotate_pair(yI[h][k], yJ[hj][k], c, sr, si);
         nI[h] -= tg;
         nJ[hj] += tg;
-        cnt += (sr != 0.0 || si != 0.0) ? 1 : 0;
       }
     }
     if (s + 1 < NB) {
