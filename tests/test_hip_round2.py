@@ -133,7 +133,9 @@ def test_bonds_up_to_512_gate_and_centre_shifts_match_oracle():
         check(lib.tjm_engine_center_shift(e.h, 0, i, -1, 1), "svd shift")
     M = e.site_moments()
     assert np.abs(_z_of(M, L) - zref).max() < 1e-9
-    assert np.abs(np.trace(M[:, 0], axis1=1, axis2=2) - 1.0).max() < 1e-10
+    # the gate's split keeps 512 of 1024 singular values and does not renormalise (digital_tjm.py:520-533): the squared norm is below 1
+    norm2 = np.trace(M[:, 0], axis1=1, axis2=2).real
+    assert np.ptp(norm2) < 1e-10 and abs(norm2[0] - ref.site_expectations(np.eye(2, dtype=complex)).real[0]) < 1e-9 and norm2[0] < 1.0
     t1 = e.export_state(0)[1]
     mm = t1.transpose(1, 0, 2).reshape(t1.shape[1], -1)
     assert np.allclose(mm @ mm.conj().T, np.eye(mm.shape[0]), atol=1e-12)
