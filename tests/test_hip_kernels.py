@@ -730,7 +730,8 @@ def test_gemm_of_the_complex64_library(lib32, M, N, K, conjA, conjB):
     assert np.allclose(Cc.cpu().numpy(), ref, atol=3e-6 * K)
 
 
-@pytest.mark.parametrize("capL,capR,qr", [(8, 8, False), (32, 32, False), (40, 32, True), (64, 64, True)])
+@pytest.mark.parametrize("capL,capR,qr", [(8, 8, False), (32, 32, False), (40, 32, True), (64, 64, True), (96, 96, True), (72, 80, True), (128, 128, True),
+                                          (128, 128, False)])
 def test_svd_split_of_the_complex64_library(lib32, capL, capR, qr):
     """Two-site split of the complex64 build (fused small kernel, LDS-resident and tiled Jacobi with fp32 tolerances, Householder
     panels): singular values to 1e-5 of the largest, isometric left factor, reconstruction of theta to fp32 accuracy."""

@@ -139,22 +139,24 @@ __device__ inline real wave_sum4(real p0, real p1, real p2, real p3, int lane) {
 
 // fp64 reciprocal square root: hardware estimate + two Newton steps (full real precision)
 __device__ inline real fast_rsqrt(real x) {
+  const real half = 0.5;  // typed constants: a double literal would pull the complex64 build into fp64 arithmetic
   real y = tjm_rsq(x);
-  const real h = 0.5 * x;
-  y = fma(y, fma(-(h * y), y, 0.5), y);  // y (1 + (1/2 - x y^2 / 2))
-  y = fma(y, fma(-(h * y), y, 0.5), y);
+  const real h = half * x;
+  y = fma(y, fma(-(h * y), y, half), y);  // y (1 + (1/2 - x y^2 / 2))
+  y = fma(y, fma(-(h * y), y, half), y);
   return y;
 }
 
 // sqrt(x), x > 0: the same estimate refined by two coupled (Goldschmidt) steps on g -> sqrt(x), h -> 1 / (2 sqrt(x)); two
 // instructions fewer than x * fast_rsqrt(x)
 __device__ inline real fast_sqrt(real x) {
+  const real half = 0.5;
   const real y = tjm_rsq(x);
-  real g = x * y, h = 0.5 * y;
-  real e = fma(-g, h, 0.5);
+  real g = x * y, h = half * y;
+  real e = fma(-g, h, half);
   g = fma(g, e, g);
   h = fma(h, e, h);
-  e = fma(-g, h, 0.5);
+  e = fma(-g, h, half);
   return fma(g, e, g);
 }
 
@@ -172,12 +174,12 @@ __device__ inline bool make_rotation(real a, real d, real gx, real gy, real tol2
   // With delta = (d - a) / 2, r = sqrt(delta^2 + |g|^2), u = |delta| + r  (so u^2 + |g|^2 = 2 r u):
   //   t = sgn(delta) |g| / u ,  c = u / sqrt(2 r u) ,  s = t c g / |g| = sgn(delta) g / sqrt(2 r u) ,  t |g| = sgn(delta) |g|^2 / u.
   // Two reciprocal square roots and no division; c^2 + |s|^2 = (u^2 + |g|^2) / (2 r u) = 1 to the rounding of r.
-  const real delta = 0.5 * (d - a);
+  const real delta = real(0.5) * (d - a);
   const real x = fma(delta, delta, mag2);
   const real r = fast_sqrt(x);
   const real u = fabs(delta) + r;
   const real q = fast_rsqrt((r + r) * u);                      // 1 / sqrt(2 r u)
-  const real qs = (delta >= 0.0) ? q : -q;
+  const real qs = (delta >= real(0.0)) ? q : -q;
   c = u * q;
   sr = qs * gx;
   si = qs * gy;
@@ -193,15 +195,15 @@ __device__ inline bool make_rotation_lanes(real a, real d, real own, real tol2, 
   const real sq = own * own;
   const real mag2 = sq + dpp_pull<0xB1>(sq);  // identical in both lanes of the pair (addition commutes)
   const bool rot = mag2 > tol2 * a * d && a > nfloor && d > nfloor && mag2 > TJM_TINY;
-  const real delta = 0.5 * (d - a);  // the formulas of make_rotation
+  const real delta = real(0.5) * (d - a);  // the formulas of make_rotation
   const real x = fma(delta, delta, mag2);
   const real r = fast_sqrt(x);
   const real u = fabs(delta) + r;
   const real q = fast_rsqrt((r + r) * u);
-  const real qs = (delta >= 0.0) ? q : -q;
-  c = rot ? u * q : 1.0;
-  sv = rot ? qs * own : 0.0;
-  tg = rot ? mag2 * ((r + r) * q) * qs : 0.0;
+  const real qs = (delta >= real(0.0)) ? q : -q;
+  c = rot ? u * q : real(1.0);
+  sv = rot ? qs * own : real(0.0);
+  tg = rot ? mag2 * ((r + r) * q) * qs : real(0.0);
   return rot;
 }
 
@@ -467,6 +469,123 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
 // wave-uniform parameters and compile-time column indices.
 constexpr int REC_PER_VISIT = 2 * NB * 2 * NB;  // 8 steps x 2 sub-steps x 8 wavefronts x 2 pairs = 256 rotations
 
+// One column of the X part in the registers of a wavefront: XRK row groups of 64 rows, lane = row within its group.  The kernel
+// below is written against these operations; the two arithmetic types differ in how the registers hold the column.
+template <int XRK>
+struct ColFrag {
+#ifdef TJM_F32
+  // complex64: the real parts of two row groups share one register pair and so do the imaginary parts, every operation is a
+  // v_pk_*_f32 on both row groups at once with no swizzle (half the issue slots of the scalar form).  An odd XRK carries a zero
+  // row group, which contributes nothing to a dot product and rotates into zero.
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  static constexpr int NP = (XRK + 1) / 2;
+  static constexpr int LDS_REALS = 4 * 64 * NP;  // per column in the hand-over buffer
+  f2 re[NP], im[NP];
+  static __device__ inline f2 pk(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+  __device__ inline void load(const cplx* __restrict__ col, int lane) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const cplx a = col[lane + 128 * k];
+      const cplx b = (2 * k + 1 < XRK) ? col[lane + 128 * k + 64] : cplx{0.0f, 0.0f};
+      re[k] = f2{a.x, b.x};
+      im[k] = f2{a.y, b.y};
+    }
+  }
+  __device__ inline void store(cplx* __restrict__ col, int lane) const {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      col[lane + 128 * k] = cplx{re[k].x, im[k].x};
+      if (2 * k + 1 < XRK) col[lane + 128 * k + 64] = cplx{re[k].y, im[k].y};
+    }
+  }
+  __device__ inline real norm2() const {
+    f2 n = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < NP; ++k) n = pk(re[k], re[k], pk(im[k], im[k], n));
+    return n.x + n.y;
+  }
+  // this lane's share of <p, q> = sum conj(p) q
+  static __device__ inline void dot(const ColFrag& p, const ColFrag& q, real& gx, real& gy) {
+    f2 x = {0.0f, 0.0f}, y = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      x = pk(p.re[k], q.re[k], pk(p.im[k], q.im[k], x));
+      y = pk(p.re[k], q.im[k], pk(-p.im[k], q.re[k], y));
+    }
+    gx = x.x + x.y;
+    gy = y.x + y.y;
+  }
+  // p' = c p - conj(s) q ; q' = s p + c q
+  static __device__ inline void rotate(ColFrag& p, ColFrag& q, real c, real sr, real si) {
+    const f2 C = {c, c}, SR = {sr, sr}, SI = {si, si};
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const f2 px = pk(-SI, q.im[k], pk(-SR, q.re[k], C * p.re[k]));
+      const f2 py = pk(SI, q.re[k], pk(-SR, q.im[k], C * p.im[k]));
+      const f2 qx = pk(C, q.re[k], pk(-SI, p.im[k], SR * p.re[k]));
+      const f2 qy = pk(C, q.im[k], pk(SI, p.re[k], SR * p.im[k]));
+      p.re[k] = px; p.im[k] = py; q.re[k] = qx; q.im[k] = qy;
+    }
+  }
+  __device__ inline void to_lds(real* slot, int lane) const {
+    f2* s2 = reinterpret_cast<f2*>(slot);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      s2[(2 * k) * 64 + lane] = re[k];
+      s2[(2 * k + 1) * 64 + lane] = im[k];
+    }
+  }
+  __device__ inline void from_lds(const real* slot, int lane) {
+    const f2* s2 = reinterpret_cast<const f2*>(slot);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      re[k] = s2[(2 * k) * 64 + lane];
+      im[k] = s2[(2 * k + 1) * 64 + lane];
+    }
+  }
+#else
+  static constexpr int LDS_REALS = 2 * 64 * XRK;
+  cplx y[XRK];
+  __device__ inline void load(const cplx* __restrict__ col, int lane) {
+#pragma unroll
+    for (int k = 0; k < XRK; ++k) y[k] = col[lane + 64 * k];
+  }
+  __device__ inline void store(cplx* __restrict__ col, int lane) const {
+#pragma unroll
+    for (int k = 0; k < XRK; ++k) col[lane + 64 * k] = y[k];
+  }
+  __device__ inline real norm2() const {
+    real n = 0.0;
+#pragma unroll
+    for (int k = 0; k < XRK; ++k) n = fma(y[k].x, y[k].x, fma(y[k].y, y[k].y, n));
+    return n;
+  }
+  static __device__ inline void dot(const ColFrag& p, const ColFrag& q, real& gx, real& gy) {
+    gx = 0.0;
+    gy = 0.0;
+#pragma unroll
+    for (int k = 0; k < XRK; ++k) {
+      gx = fma(p.y[k].x, q.y[k].x, fma(p.y[k].y, q.y[k].y, gx));
+      gy = fma(p.y[k].x, q.y[k].y, fma(-p.y[k].y, q.y[k].x, gy));
+    }
+  }
+  static __device__ inline void rotate(ColFrag& p, ColFrag& q, real c, real sr, real si) {
+#pragma unroll
+    for (int k = 0; k < XRK; ++k) rotate_pair(p.y[k], q.y[k], c, sr, si);
+  }
+  __device__ inline void to_lds(real* slot, int lane) const {
+    cplx* sc = reinterpret_cast<cplx*>(slot);
+#pragma unroll
+    for (int k = 0; k < XRK; ++k) sc[lane + 64 * k] = y[k];
+  }
+  __device__ inline void from_lds(const real* slot, int lane) {
+    const cplx* sc = reinterpret_cast<const cplx*>(slot);
+#pragma unroll
+    for (int k = 0; k < XRK; ++k) y[k] = sc[lane + 64 * k];
+  }
+#endif
+};
+
 // XRK = row groups of 64 of the X part held in registers: 1 ... 8 (rx_top = 64 XRK; 4 at d*chi = 256)
 template <int XRK>
 __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kernel(JacobiArgs g) {
@@ -478,10 +597,10 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (g.done[b]) { if (tid == 0 && record) rec[3] = 0.0; return; }
   const int rtot = g.rtot;
-  const int xr = 64 * XRK;
-  cplx* slots = reinterpret_cast<cplx*>(smem);                    // [8][2][xr]
-  real* sN = reinterpret_cast<real*>(slots + 2 * NB * xr);    // [8][2]
-  int* sCnt = reinterpret_cast<int*>(sN + 2 * NB);                // [8]
+  typedef ColFrag<XRK> Col;
+  real* slots = smem;                                               // [8][2] columns of Col::LDS_REALS
+  real* sN = slots + 2 * NB * Col::LDS_REALS;                       // [8][2]
+  int* sCnt = reinterpret_cast<int*>(sN + 2 * NB);                  // [8]
   int I, J;
   pair_of(g.nblk / 2, g.round, blockIdx.x, I, J);
   int* st = g.stamps + (long)b * STAMP_STRIDE;
@@ -493,19 +612,14 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
     if (!nzI || !nzJ || ver > m1) { if (tid == 0 && record) rec[3] = 0.0; return; }
   }
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
-  cplx yI[2][XRK], yJ[2][XRK];
-  real nI[2] = {0.0, 0.0}, nJ[2] = {0.0, 0.0};
+  Col yI[2], yJ[2];
+  real nI[2], nJ[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const cplx* cI = Yb + (long)(I * 16 + 2 * w + h) * rtot;
-    const cplx* cJ = Yb + (long)(J * 16 + 2 * w + h) * rtot;
-#pragma unroll
-    for (int k = 0; k < XRK; ++k) {
-      yI[h][k] = cI[lane + 64 * k];
-      yJ[h][k] = cJ[lane + 64 * k];
-      nI[h] = fma(yI[h][k].x, yI[h][k].x, fma(yI[h][k].y, yI[h][k].y, nI[h]));
-      nJ[h] = fma(yJ[h][k].x, yJ[h][k].x, fma(yJ[h][k].y, yJ[h][k].y, nJ[h]));
-    }
+    yI[h].load(Yb + (long)(I * 16 + 2 * w + h) * rtot, lane);
+    yJ[h].load(Yb + (long)(J * 16 + 2 * w + h) * rtot, lane);
+    nI[h] = yI[h].norm2();
+    nJ[h] = yJ[h].norm2();
   }
   nI[0] = wave_sum(nI[0]); nI[1] = wave_sum(nI[1]);
   nJ[0] = wave_sum(nJ[0]); nJ[1] = wave_sum(nJ[1]);
@@ -514,16 +628,9 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
   for (int s = 0; s < NB; ++s) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      real gx[2] = {0.0, 0.0}, gy[2] = {0.0, 0.0};
+      real gx[2], gy[2];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int hj = h ^ sub;
-#pragma unroll
-        for (int k = 0; k < XRK; ++k) {
-          gx[h] = fma(yI[h][k].x, yJ[hj][k].x, fma(yI[h][k].y, yJ[hj][k].y, gx[h]));
-          gy[h] = fma(yI[h][k].x, yJ[hj][k].y, fma(-yI[h][k].y, yJ[hj][k].x, gy[h]));
-        }
-      }
+      for (int h = 0; h < 2; ++h) Col::dot(yI[h], yJ[h ^ sub], gx[h], gy[h]);
       // both inner products reduced together; both rotations computed side by side in lanes 0..3
       const real gsum = wave_sum4(gx[0], gy[0], gx[1], gy[1], lane);
       const bool second = lane & 2;
@@ -542,24 +649,19 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
         // pair rotates; the branch only bought register copies at its merge point
         const real sr = lane_value(sv, 2 * h), si = lane_value(sv, 2 * h + 1);
         const real c = lane_value(cv, 2 * h), tg = lane_value(tv, 2 * h);
-#pragma unroll
-        for (int k = 0; k < XRK; ++k) rotate_pair(yI[h][k], yJ[hj][k], c, sr, si);
+        Col::rotate(yI[h], yJ[hj], c, sr, si);
         nI[h] -= tg;
         nJ[hj] += tg;
       }
     }
     if (s + 1 < NB) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int k = 0; k < XRK; ++k) slots[(w * 2 + h) * xr + lane + 64 * k] = yJ[h][k];
+      for (int h = 0; h < 2; ++h) yJ[h].to_lds(slots + (w * 2 + h) * Col::LDS_REALS, lane);
       if (lane < 2) sN[w * 2 + lane] = (lane == 0) ? nJ[0] : nJ[1];
       __syncthreads();
       const int src = (w + 1) & (NB - 1);
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int k = 0; k < XRK; ++k) yJ[h][k] = slots[(src * 2 + h) * xr + lane + 64 * k];
+      for (int h = 0; h < 2; ++h) yJ[h].from_lds(slots + (src * 2 + h) * Col::LDS_REALS, lane);
       nJ[0] = sN[src * 2];
       nJ[1] = sN[src * 2 + 1];
       __syncthreads();
@@ -579,13 +681,8 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
   const int wj = (w + NB - 1) & (NB - 1);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    cplx* oI = Yb + (long)(I * 16 + 2 * w + h) * rtot;
-    cplx* oJ = Yb + (long)(J * 16 + 2 * wj + h) * rtot;
-#pragma unroll
-    for (int k = 0; k < XRK; ++k) {
-      oI[lane + 64 * k] = yI[h][k];
-      oJ[lane + 64 * k] = yJ[h][k];
-    }
+    yI[h].store(Yb + (long)(I * 16 + 2 * w + h) * rtot, lane);
+    yJ[h].store(Yb + (long)(J * 16 + 2 * wj + h) * rtot, lane);
   }
   if (tid == 0) atomicAdd(&g.nrot[b], total);
 }
@@ -1741,7 +1838,12 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   const int nrounds = tile16 ? (g.nblk / 2 - 1) : (g.nblk - 1);
   const int npairs = tile16 ? g.nblk / 4 : g.nblk / 2;
   const size_t lds16 = (size_t)2 * NB * rtot * sizeof(cplx) + 2 * NB * sizeof(real) + 16 * sizeof(int);
-  const size_t lds16x = (size_t)2 * NB * rx_top * sizeof(cplx) + 2 * NB * sizeof(real) + 16 * sizeof(int);
+#ifdef TJM_F32
+  const int rx_slot = (rx_top + 127) / 128 * 128;  // ColFrag keeps row groups in pairs
+#else
+  const int rx_slot = rx_top;
+#endif
+  const size_t lds16x = (size_t)2 * NB * rx_slot * sizeof(cplx) + 2 * NB * sizeof(real) + 16 * sizeof(int);
   g.rec = accumulate ? w.rec : nullptr;
   const int max_sweeps = 40;
   // Sub-batches (TJM_SVD_CHUNK=n trajectories, default off): all sweeps of one chunk before the next, so that the chunk's stacked
