@@ -137,6 +137,34 @@ __device__ inline real wave_sum4(real p0, real p1, real p2, real p3, int lane) {
   return xor32_sum(xor16_sum(y));
 }
 
+// One halving step of a butterfly with the gfx950 swap instructions - no selects, no LDS crossbar.
+// swap32_add: lanes < 32 get a[l] + a[l + 32], lanes >= 32 get b[l - 32] + b[l].
+// swap16_add: even rows of 16 lanes get a summed over their row pair, odd rows b summed over theirs.
+__device__ inline real swap32_add(real a, real b) {
+#ifdef TJM_F32
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+#else
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+#endif
+}
+__device__ inline real swap16_add(real a, real b) {
+#ifdef TJM_F32
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(a), __float_as_int(b), false, false);
+  return __int_as_float(r[0]) + __int_as_float(r[1]);
+#else
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+#endif
+}
+// Four wavefront sums, one per row of 16 lanes: on return every lane of row r (lanes 16 r ... 16 r + 15) holds the total of p_r.
+__device__ inline real wave_sum4_rows(real p0, real p1, real p2, real p3) {
+  return row_total(swap16_add(swap32_add(p0, p2), swap32_add(p1, p3)));
+}
+
 // fp64 reciprocal square root: hardware estimate + two Newton steps (full real precision)
 __device__ inline real fast_rsqrt(real x) {
   const real half = 0.5;  // typed constants: a double literal would pull the complex64 build into fp64 arithmetic
@@ -187,13 +215,12 @@ __device__ inline bool make_rotation(real a, real d, real gx, real gy, real tol2
   return true;
 }
 
-// The same decision and rotation, evaluated per lane for wave_sum4 output: lane classes (0,1) carry (Re g, Im g) of
-// the first pair, classes (2,3) of the second.  own = this lane's component of g; (a, d) the norms of its pair.
-// Gives c, sv = s * own / |g| (Re s on even lanes, Im s on odd lanes) and tg; (1, 0, 0) when no rotation applies.  Returns the
+// The same decision and rotation, evaluated per lane on the output of wave_sum4_rows: rows 0 and 1 carry (Re g, Im g) of the
+// first pair, rows 2 and 3 of the second.  own = this lane's component of g; (a, d) the norms of its pair.
+// Gives c, sv = s * own / |g| (Re s in the even rows, Im s in the odd rows) and tg; (1, 0, 0) when no rotation applies.  Returns the
 // decision of this lane's pair.
 __device__ inline bool make_rotation_lanes(real a, real d, real own, real tol2, real nfloor, real& c, real& sv, real& tg) {
-  const real sq = own * own;
-  const real mag2 = sq + dpp_pull<0xB1>(sq);  // identical in both lanes of the pair (addition commutes)
+  const real mag2 = xor16_sum(own * own);  // identical in both rows of the pair (addition commutes)
   const bool rot = mag2 > tol2 * a * d && a > nfloor && d > nfloor && mag2 > TJM_TINY;
   const real delta = real(0.5) * (d - a);  // the formulas of make_rotation
   const real x = fma(delta, delta, mag2);
@@ -631,15 +658,16 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
       real gx[2], gy[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) Col::dot(yI[h], yJ[h ^ sub], gx[h], gy[h]);
-      // both inner products reduced together; both rotations computed side by side in lanes 0..3
-      const real gsum = wave_sum4(gx[0], gy[0], gx[1], gy[1], lane);
-      const bool second = lane & 2;
+      // both inner products reduced together (row r of 16 lanes ends up with component r of (Re g0, Im g0, Re g1, Im g1));
+      // both rotations computed side by side, pair h in the half-wave h
+      const real gsum = wave_sum4_rows(gx[0], gy[0], gx[1], gy[1]);
+      const bool second = lane & 32;
       real cv, sv, tv;
       const bool rot = make_rotation_lanes(second ? nI[1] : nI[0], second ? nJ[1 ^ sub] : nJ[sub], gsum, g.tol2, floor2, cv, sv, tv);
-      cnt += __popcll(__ballot(rot) & 5ull);  // lanes 0 and 2 speak for the two pairs (scalar unit: the compare mask is in SGPRs)
-      if (record && lane < 4) {
-        real* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + (lane >> 1)) * 4);
-        if (lane & 1) r4[2] = sv;
+      cnt += __popcll(__ballot(rot) & 0x100000001ull);  // lanes 0 and 32 speak for the two pairs (scalar unit: the mask is in SGPRs)
+      if (record && (lane & 15) == 0) {
+        real* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + (lane >> 5)) * 4);
+        if (lane & 16) r4[2] = sv;
         else { r4[0] = cv; r4[1] = sv; }
       }
 #pragma unroll
@@ -647,8 +675,8 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
         const int hj = h ^ sub;
         // applied unconditionally: (c, s) = (1, 0) leaves the columns bit-identical, and in the sweeps that matter almost every
         // pair rotates; the branch only bought register copies at its merge point
-        const real sr = lane_value(sv, 2 * h), si = lane_value(sv, 2 * h + 1);
-        const real c = lane_value(cv, 2 * h), tg = lane_value(tv, 2 * h);
+        const real sr = lane_value(sv, 32 * h), si = lane_value(sv, 32 * h + 16);
+        const real c = lane_value(cv, 32 * h), tg = lane_value(tv, 32 * h);
         Col::rotate(yI[h], yJ[hj], c, sr, si);
         nI[h] -= tg;
         nJ[hj] += tg;
