@@ -516,6 +516,34 @@ def test_project_site_env_updates_and_project_bond_match_reference_outputs(lib):
     e.close()
 
 
+@pytest.mark.parametrize("D", [8, 20, 28])
+def test_heff_apply_with_wide_mpo_bonds(lib, D):
+    """project_site (primitives.py:180-204) on a qubit pair with MPO bonds of 8, 20 and 28: the merged operator of the MPO stage is
+    (4 D)^2 complex numbers - 16 KiB (default LDS), 100 KiB (needs the kernel's LDS limit raised) and 196 KiB (more than a CU has: read
+    through the caches).  Against the oracle's contraction."""
+    from oracle import tjm_oracle as o  # checker only
+    from yaqs_amd._lib import check
+    from yaqs_amd.engine import BatchEngine
+
+    rng = np.random.default_rng(D)
+    Ls, chi, B = 4, 6, 2
+    mpo = [crand(rng, 2, 2, 1 if i == 0 else D, 1 if i == Ls - 1 else D) for i in range(Ls)]
+    e = BatchEngine(Ls, chi, B, mpo)
+    ca, cb = 4, 4
+    x = crand(rng, 4, ca, cb)
+    lenv, renv = crand(rng, ca, D, ca), crand(rng, cb, D, cb)
+    w2 = np.ascontiguousarray(o.merge_mpo_tensors(mpo[1], mpo[2]), dtype=np.complex128)  # (4, 4, D, D)
+    y = torch.zeros((B, 4, ca, cb), dtype=torch.complex128, device=DEV)
+    check(lib.tjm_heff_apply(e.h, 2, ca, cb, D, D, _slots(x).data_ptr(), _same(lenv).data_ptr(), _same(renv).data_ptr(),
+                             w2.ctypes.data, y.data_ptr(), B), "heff2")
+    _sync()
+    ref = o.project_site(lenv, renv, w2, x)
+    got = y.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.allclose(got[0], ref, atol=1e-12 * scale) and np.allclose(got[1], 1.5 * ref, atol=1e-12 * scale)
+    e.close()
+
+
 def test_lanczos_expm_matches_reference_outputs(lib):
     """tjm_lanczos_expm = update_site (expm_krylov o project_site) on the reference's two-site block of a 6-site chain at both
     tolerances of the fixture (the fused small-bond kernel serves blocks of this size)."""

@@ -11,18 +11,24 @@ namespace tjm {
 
 // ------------------------------------------------------------------------------------------
 // MPO apply:  out[po][bo][a][B] = sum_{pi,bi} Wm[(po,bo),(pi,bi)] * in[pi][bi][a][B]
-// (strides per index are free, B is contiguous on both sides).  One thread per (a, B).
+// (strides per index are free, B is contiguous on both sides).  One thread per (a, B).  The operator is staged in LDS when it fits
+// (w_in_lds; above 64 KiB the launcher raises the kernel's limit first); one larger than the LDS of a CU - a pair of four-level
+// sites with an MPO bond above 6, a qubit pair above 25 - is read through the caches instead (every lane reads the same element).
 // ------------------------------------------------------------------------------------------
 template <int P>
-__global__ __launch_bounds__(256) void mpo_apply_kernel(MpoApplyDesc d) {
+__global__ __launch_bounds__(256) void mpo_apply_kernel(MpoApplyDesc d, int w_in_lds) {
   extern __shared__ real smem[];
-  cplx* sW = reinterpret_cast<cplx*>(smem);
   int b0 = blockIdx.y;
   if (d.ids) b0 = d.ids[b0];
   if (d.active && d.active[b0] == 0) return;
   const int nin = P * d.din, nout = P * d.dout;
-  for (int i = threadIdx.x; i < nin * nout; i += blockDim.x) sW[i] = d.Wm[i];
-  __syncthreads();
+  const cplx* __restrict__ sW = d.Wm;
+  if (w_in_lds) {
+    cplx* stage = reinterpret_cast<cplx*>(smem);
+    for (int i = threadIdx.x; i < nin * nout; i += blockDim.x) stage[i] = d.Wm[i];
+    __syncthreads();
+    sW = stage;
+  }
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)d.na * d.nB) return;
   const int a = idx / d.nB, Bc = idx % d.nB;
@@ -73,20 +79,42 @@ __global__ __launch_bounds__(256) void mpo_apply_kernel(MpoApplyDesc d) {
   }
 }
 
+namespace {
+constexpr size_t LDS_DEFAULT = 64 * 1024, LDS_CU = 160 * 1024;  // dynamic LDS a launch may ask for without / with the attribute
+
+template <int P>
+int launch_mpo_apply_p(const MpoApplyDesc& d, dim3 grid, hipStream_t stream) {
+  size_t sh = sizeof(cplx) * (size_t)(P * d.din) * (P * d.dout);
+  int w_in_lds = 1;
+  if (sh > LDS_CU) {
+    w_in_lds = 0;
+    sh = 0;
+  } else if (sh > LDS_DEFAULT) {
+    static bool raised = false;  // once per process (one process per GPU)
+    if (!raised) {
+      TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mpo_apply_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CU));
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(mpo_apply_kernel<P>, grid, dim3(256), sh, stream, d, w_in_lds);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+}  // namespace
+
 int launch_mpo_apply(const MpoApplyDesc& d, hipStream_t stream) {
   const long n = (long)d.na * d.nB;
   if (n <= 0 || d.nb0 <= 0) return TJM_OK;
   dim3 grid((unsigned)((n + 255) / 256), d.nb0);
-  size_t sh = sizeof(cplx) * (size_t)(d.P * d.din) * (d.P * d.dout);
-  if (d.P == 2) hipLaunchKernelGGL(mpo_apply_kernel<2>, grid, dim3(256), sh, stream, d);
-  else if (d.P == 4) hipLaunchKernelGGL(mpo_apply_kernel<4>, grid, dim3(256), sh, stream, d);
-  else if (d.P == 1) hipLaunchKernelGGL(mpo_apply_kernel<1>, grid, dim3(256), sh, stream, d);
-  else if (d.P == 3) hipLaunchKernelGGL(mpo_apply_kernel<3>, grid, dim3(256), sh, stream, d);    // qutrit site
-  else if (d.P == 9) hipLaunchKernelGGL(mpo_apply_kernel<9>, grid, dim3(256), sh, stream, d);    // qutrit pair
-  else if (d.P == 16) hipLaunchKernelGGL(mpo_apply_kernel<16>, grid, dim3(256), sh, stream, d);  // pair of four-level sites
-  else return TJM_ERR_NOT_IMPLEMENTED;
-  TJM_HIP_CHECK(hipGetLastError());
-  return TJM_OK;
+  switch (d.P) {
+    case 1: return launch_mpo_apply_p<1>(d, grid, stream);
+    case 2: return launch_mpo_apply_p<2>(d, grid, stream);
+    case 4: return launch_mpo_apply_p<4>(d, grid, stream);
+    case 3: return launch_mpo_apply_p<3>(d, grid, stream);    // qutrit site
+    case 9: return launch_mpo_apply_p<9>(d, grid, stream);    // qutrit pair
+    case 16: return launch_mpo_apply_p<16>(d, grid, stream);  // pair of four-level sites
+    default: return TJM_ERR_NOT_IMPLEMENTED;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
