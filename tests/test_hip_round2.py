@@ -159,6 +159,36 @@ def test_bonds_up_to_512_two_site_tdvp_sweep_matches_oracle():
     e.close()
 
 
+@pytest.mark.parametrize("chi", [8, 32])
+def test_two_site_sweep_with_wide_mpo_bonds_matches_oracle(chi):
+    """All-to-all Pauli couplings of every kind on ten sites (``MPO.from_pauli_sum``, mpo.py:1171-1318): MPO bonds up to 17, beyond
+    the six the MPO stage keeps in registers and, at the centre, beyond the 64 KiB of LDS a launch gets without asking
+    ((4 x 17)^2 complex numbers = 72 KiB).  One two-site sweep of a Haar state against the oracle."""
+    from yaqs_amd.api import MPO
+    from yaqs_amd.engine import BatchEngine
+
+    L = 10
+    rng = np.random.default_rng(7)
+    terms = [(rng.standard_normal() / (1 + j - i), f"{a}{i} {b}{j}") for i in range(L) for j in range(i + 1, L) for a in "XYZ" for b in "XYZ"]
+    terms += [(rng.standard_normal(), f"X{i}") for i in range(L)]
+    H = MPO()
+    H.from_pauli_sum(terms=terms, length=L)
+    mpo = [np.ascontiguousarray(t) for t in H.tensors]
+    assert max(t.shape[3] for t in mpo) == 17
+    st = o.MPSState.haar(L, chi, rng)
+    st.normalize("B")
+    e = BatchEngine(L, chi, 2, mpo)
+    e.set_params(dt=0.05, svd_threshold=1e-10, max_bond_dim=chi, krylov_tol=1e-10)
+    e.set_noise([], [])
+    e.load_state(st.tensors)
+    e.tdvp()
+    ref = o.MPSState([t.copy() for t in st.tensors], 0)
+    o.tdvp(ref, mpo, o.Params(dt=0.05, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-10))
+    assert np.abs(_z_of(e.site_moments(), L) - ref.site_expectations(Z).real).max() < 1e-10
+    assert [t.shape[2] for t in e.export_state(0)] == [t.shape[2] for t in ref.tensors]
+    e.close()
+
+
 def test_sample_at_and_segment_stitching_match_reference_on_the_engine():
     """The continuation options of the drivers (analog_tjm.py:206-255, 369-400) through the HIP engine: ``sample_at`` on both orders
     and an order-2 run cut after 3 of 6 steps, against the reference's outputs (tests/golden/continuation.npz)."""

@@ -66,6 +66,13 @@ def test_complex64_build_on_the_simulated_device(on_sim, monkeypatch):
     on_sim["test_hip_round2"].test_complex64_ensemble_means_agree_with_the_fp64_ensemble()
 
 
+def test_wide_mpo_bonds_and_four_level_pairs_on_the_simulated_device(on_sim):
+    """MPO stages whose operator needs more than the default 64 KiB of dynamic LDS (the interpreter aborts such a launch unless the
+    kernel's limit was raised, as the device refuses it): MPO bonds of 17 on qubits, and the Fermi-Hubbard chain on four-level sites."""
+    on_sim["test_hip_round2"].test_two_site_sweep_with_wide_mpo_bonds_matches_oracle(32)
+    on_sim["test_hip_round2"].test_fermi_hubbard_chain_on_four_level_sites_matches_reference_fixture()
+
+
 @pytest.mark.parametrize("native", [False, True])
 def test_non_finite_inputs_on_the_simulated_device(on_sim, native):
     on_sim["test_hip_round2"].test_non_finite_inputs_fail_loudly_like_the_reference(native)
