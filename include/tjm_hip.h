@@ -45,7 +45,8 @@ const char* tjm_error_string(int code);
  * trajectory axis becomes the batch axis of every kernel launch.                          */
 typedef struct tjm_engine tjm_engine;
 
-/* mpo_bond[L+1]: MPO bond dimensions, mpo_bond[0] = mpo_bond[L] = 1 (mpo.py:45-50). */
+/* mpo_bond[L+1]: MPO bond dimensions, mpo_bond[0] = mpo_bond[L] = 1 (mpo.py:45-50).  1 <= B <= 65535 (the trajectory index is a
+ * grid dimension of the kernels; more trajectories run as further engines or further chunks). */
 int tjm_engine_create(tjm_engine** out, int32_t L, int32_t d, int32_t chi_max, int32_t B, const int32_t* mpo_bond);
 /* The same with storage of bond k = min(chi_max, cap_slack * min(d^k, d^(L-k))): cap_slack = 1 is the exact Schmidt-rank bound of
  * tjm_engine_create; the BUG integrator (core/methods/bug.py) needs 2 for its stacked trial bases near the chain ends. */

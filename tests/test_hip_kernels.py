@@ -114,6 +114,20 @@ def test_gemm_transposed_operands_ksplit_and_inner_batches(lib):
     assert np.allclose(Cc.cpu().numpy(), ref, atol=1e-11)
 
 
+def test_gemm_with_more_batches_than_one_grid_dimension_holds(lib):
+    """3 x 150 x 150 = 67 500 batched products through the LDS-tiled kernel: more than the 65 535 of grid z (16 384 trajectories
+    with two physical indices each reach it), so the batch index spills into grid y.  The innermost batch level writes the same C."""
+    rng = np.random.default_rng(11)
+    M, N, K, nb, P, Q = 40, 40, 3, 3, 150, 150
+    a, b = crand(rng, nb, M, K), crand(rng, nb, P, K, N)
+    A, B = dev(a), dev(b)
+    Cc = torch.zeros((nb, P, M, N), dtype=torch.complex128, device=DEV)
+    run_gemm(lib, A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, a_rs=K, a_cs=1, b_rs=N, b_cs=1, c_rs=N,
+             nb0=nb, nb1=P, nb2=Q, a_b0=M * K, b_b0=P * K * N, b_b1=K * N, c_b0=P * M * N, c_b1=M * N)
+    _sync()
+    assert np.allclose(Cc.cpu().numpy(), np.einsum("bmk,bpkn->bpmn", a, b), atol=1e-12)
+
+
 @pytest.mark.parametrize("k,dt,scale", [(1, 0.05, 1.0), (2, 0.1, 3.0), (7, -0.05, 20.0), (25, 0.1, 60.0), (12, 1.0, 40.0)])
 def test_tridiag_expm_matches_dense(lib, k, dt, scale):
     import scipy.linalg

@@ -149,7 +149,8 @@ Engine::~Engine() {
 }
 
 int Engine::create(int L_, int d_, int chi_, int B_, const int* mpo_bond, int cap_slack) {
-  if (L_ < 1 || d_ < 2 || d_ > 4 || chi_ < 1 || B_ < 1 || cap_slack < 1) return TJM_ERR_ARG;  // uniform local dimension 2, 3 or 4
+  // uniform local dimension 2, 3 or 4; the trajectory index is the y or z dimension of most grids (at most 65535)
+  if (L_ < 1 || d_ < 2 || d_ > 4 || chi_ < 1 || B_ < 1 || B_ > 65535 || cap_slack < 1) return TJM_ERR_ARG;
   L = L_; d = d_; chi_max = chi_; B = B_;
   n_sets = cap_slack > 1 ? 4 : 2;
   // storage of bond k: min(chi_max, slack * min(d^k, d^(L-k))).  slack = 1 is the exact Schmidt-rank bound; the stacked trial bases of

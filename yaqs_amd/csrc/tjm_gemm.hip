@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256, 3) void zgemm_kernel(GemmDesc g) {
   __shared__ real sBr[BK * PITCH];
   __shared__ real sBi[BK * PITCH];
 
-  int z = blockIdx.z;
+  int z = blockIdx.y * gridDim.z + blockIdx.z;  // batches beyond the 65535 of one grid dimension spill into y (launch_gemm)
+  if (z >= g.nb0 * g.nb1 * g.nb2) return;
   const int b2 = z % g.nb2;
   z /= g.nb2;
   const int b1 = z % g.nb1;
@@ -248,7 +249,11 @@ int launch_gemm(const GemmDesc& g, hipStream_t stream) {
     TJM_HIP_CHECK(hipGetLastError());
     return TJM_OK;
   }
-  dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), 1, g.nb0 * g.nb1 * g.nb2);
+  // 16384 trajectories x d^2 inner batches already exceed the 65535 of grid z: at most 32768 in z, the rest in y
+  const long batches = (long)g.nb0 * g.nb1 * g.nb2;
+  const long gz = batches < 32768 ? batches : 32768, gy = (batches + gz - 1) / gz;
+  if (gy > 65535) return TJM_ERR_ARG;
+  dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), (unsigned)gy, (unsigned)gz);
   dim3 block(256);
   const bool am = (g.a_rs == 1 && g.a_cs != 1);
   const bool bn = (g.b_cs == 1);

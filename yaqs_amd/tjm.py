@@ -644,7 +644,7 @@ class Simulator:
         """Trajectories resident at once.  ``batch=None``: as many as fit in 60 % of the free HBM (at most ``AUTO_BATCH_MAX``) - small
         bonds are launch-latency-bound, so throughput grows with the batch until the chip is full; an explicit ``batch`` is kept."""
         if self.batch is not None:
-            return max(1, min(int(self.batch), remaining))
+            return max(1, min(int(self.batch), remaining, MAX_ENGINE_BATCH))
         import torch
 
         per_traj = BatchEngine.workspace_bytes_for(length, chi, 64, mpo, **self._engine_kw) / 64.0
@@ -989,6 +989,7 @@ MAX_CHI = 256   # largest bond the engine serves.  The kernels hold d * chi <= 1
 # stay refused until it has.
 START_CHI = 8   # first storage capacity tried when the requested cap is larger
 AUTO_BATCH_MAX = 16384  # trajectories in flight when Simulator(batch=None) sizes the batch itself
+MAX_ENGINE_BATCH = 65535  # the trajectory index is a y / z grid dimension of the kernels: tjm_engine_create refuses more
 
 
 def engine_bond_caps(sim_params, initial_state, can_grow: bool = False, slack: int = 1) -> tuple[int, int]:
