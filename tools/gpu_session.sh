@@ -4,7 +4,7 @@
 # Everything is written under gpurun_out/session/ (merged back by gpurun); copy what is to be judged into profiles/ afterwards.
 # Every step has its own timeout; a failing step does not stop the next one.  The chi = 512 ENGINE test is NOT part of this script
 # (it is the test during which two boxes went down in round 2; its checker is fixed, run it in a call of its own:
-#   gpurun --timeout 1200 -- 'TJM_TEST_CHI512_ENGINE=1 timeout 900 python -m pytest tests/test_hip_round2.py -k bonds_up_to_512 -x -q').
+#   gpurun --timeout 1500 -- 'bash tools/gpu_session_chi512.sh').
 set -u
 OUT=gpurun_out/session
 mkdir -p "$OUT"
