@@ -202,6 +202,8 @@ __device__ inline bool make_rotation(real a, real d, real gx, real gy, real tol2
   // With delta = (d - a) / 2, r = sqrt(delta^2 + |g|^2), u = |delta| + r  (so u^2 + |g|^2 = 2 r u):
   //   t = sgn(delta) |g| / u ,  c = u / sqrt(2 r u) ,  s = t c g / |g| = sgn(delta) g / sqrt(2 r u) ,  t |g| = sgn(delta) |g|^2 / u.
   // Two reciprocal square roots and no division; c^2 + |s|^2 = (u^2 + |g|^2) / (2 r u) = 1 to the rounding of r.
+  // delta^2 is a FOURTH power of the entries: fine in fp64 for any sensible input; the complex64 build needs ||X||_F^2 within about
+  // 1e-15 ... 1e19 (the lower end was already set by TJM_TINY) - the matrices here are slices of normalised states.
   const real delta = real(0.5) * (d - a);
   const real x = fma(delta, delta, mag2);
   const real r = fast_sqrt(x);
