@@ -206,22 +206,54 @@ def pmc_traffic(L, chi, B):
 # ------------------------------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` without torch.distributed.run starts its own ranks
 # ------------------------------------------------------------------------------------------------------------------------
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, script=None, poll=0.2):
+    """Start ranks 0..n-1 of ``script`` (default: this file) as fresh child processes with the torch.distributed.run environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), relay rank 0's stdout, return the worst exit code.  Every child is polled: the
+    first one that ends with a non-zero code takes the others down (SIGTERM, then SIGKILL after 10 s), so a rank that dies
+    before the rendezvous cannot leave rank 0 waiting in the RCCL timeout."""
     import socket
+    import tempfile
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile()  # a file, not a pipe: nobody has to drain it while the children are being polled
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rcs = [None] * n
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            break
+        time.sleep(poll)
+    if failed is not None:
+        print(f"[bench] rank {failed} ended with code {rcs[failed]}: stopping the other ranks", file=sys.stderr)
+        live = [p for r, p in enumerate(procs) if rcs[r] is None]
+        for p in live:
+            p.terminate()
+        deadline = time.time() + 10.0
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        rcs = [p.returncode for p in procs]
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
+    out0.close()
+    if failed is not None:
+        return abs(rcs[failed]) or 1
     return max(abs(rc) for rc in rcs)
 
 
@@ -406,6 +438,9 @@ def main():
         busy = sum(cls_ms.values()) / 1e3
         traffic, traffic_note = pmc_traffic(L, chi, B)
         cross_gbs = (nbytes.value / 1e9) / (ms.value / 1e3) if ms.value > 0 else None
+        f32 = args.dtype != "complex128"
+        peak = 2 * FP64_PEAK_TFLOPS if f32 else FP64_PEAK_TFLOPS  # fp32 vector and matrix rates: 157.3 TFLOP/s
+        valu_bound, mfma_bound = ("fp32-valu", "mfma-f32") if f32 else ("fp64-valu", "mfma-f64")
         out = {
             "metric": "trajectories/sec",
             "value": value,
@@ -436,12 +471,12 @@ def main():
             # one batched SVD (a two-site split or an SVD centre shift of every resident trajectory); algorithmic work = SURVEY 8d's
             # nominal 88 n^3 real flops per (d chi) x (d chi) SVD; duration = HIP events on the engine's stream around every such SVD.
             "roofline": {
-                "bound": "fp64-valu",
+                "bound": valu_bound,
                 "kernel": "SVD family: jacobi_cross16x_kernel (dominant) + jacobi_* + qr_* + svd_finish/extract, per batched SVD",
                 "achieved": svd_tf,
-                "peak": FP64_PEAK_TFLOPS if args.dtype == "complex128" else 2 * FP64_PEAK_TFLOPS,  # fp32 vector rate = 157.3 TFLOP/s
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": (svd_tf / FP64_PEAK_TFLOPS) if svd_tf else None,
+                "frac": (svd_tf / peak) if svd_tf else None,
                 "traffic": traffic,
                 "traffic_note": traffic_note,
                 "algorithmic_flops_per_svd": F_svd,
@@ -455,14 +490,14 @@ def main():
                     "tile_bytes_frac_of_hbm_peak": (cross_gbs / HBM_PEAK_GBS) if cross_gbs else None,
                 },
                 "classes": {
-                    "svd": {"bound": "fp64-valu", "achieved_TFLOPs": svd_tf, "frac": (svd_tf / FP64_PEAK_TFLOPS) if svd_tf else None,
+                    "svd": {"bound": valu_bound, "achieved_TFLOPs": svd_tf, "frac": (svd_tf / peak) if svd_tf else None,
                             "share_of_stream_time": cls_ms["svd"] / 1e3 / busy if busy else None},
-                    "krylov": {"bound": "mfma-f64", "achieved_TFLOPs": kry_tf, "frac": (kry_tf / FP64_PEAK_TFLOPS) if kry_tf else None,
+                    "krylov": {"bound": mfma_bound, "achieved_TFLOPs": kry_tf, "frac": (kry_tf / peak) if kry_tf else None,
                                "share_of_stream_time": cls_ms["krylov"] / 1e3 / busy if busy else None,
                                "note": "H_eff applies (2 MFMA GEMMs + MPO stage) with the Lanczos vector kernels (HBM-bound) inside the region"},
-                    "env": {"bound": "mfma-f64", "achieved_TFLOPs": env_tf, "frac": (env_tf / FP64_PEAK_TFLOPS) if env_tf else None,
+                    "env": {"bound": mfma_bound, "achieved_TFLOPs": env_tf, "frac": (env_tf / peak) if env_tf else None,
                             "share_of_stream_time": cls_ms["env"] / 1e3 / busy if busy else None},
-                    "whole_step": {"achieved_TFLOPs": step_tf, "frac": step_tf / FP64_PEAK_TFLOPS,
+                    "whole_step": {"achieved_TFLOPs": step_tf, "frac": step_tf / peak,
                                    "timed_classes_over_wall": busy / elapsed if elapsed > 0 else None},
                 },
             },

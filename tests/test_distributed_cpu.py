@@ -93,3 +93,56 @@ def test_two_ranks_share_the_trajectories_on_the_gpu(tmp_path):
         assert np.allclose(np.load(tmp_path / f"c{rank}.npy"), np.stack(cres.trajectories), atol=1e-12)
         assert np.array_equal(np.load(tmp_path / f"k{rank}.npy"), np.array(sorted(cres.counts.items()), dtype=np.int64))
     assert sum(cres.counts.values()) == 35
+
+
+# ---- bench.py's own rank launcher (`python bench.py --gpus N` without torch.distributed.run) -----------------------------------
+_RANK_SCRIPT = '''
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+mode = sys.argv[1]
+if mode == "ok":
+    import torch.distributed as dist
+    import torch
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"sum": t.item(), "world": world, "argv": sys.argv[1:]}))
+    sys.exit(0)
+if mode == "die" and rank == 1:
+    sys.exit(7)            # a rank >= 1 that ends before the rendezvous
+if mode == "die":
+    time.sleep(120)        # rank 0 would sit in the rendezvous / the collective's timeout
+'''
+
+
+def test_bench_launcher_starts_ranks_and_relays_rank0(tmp_path, capsys):
+    import bench
+
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    rc = bench.launch_ranks(2, ["ok", "--steps", "3"], script=str(script))
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0
+    out = [ln for ln in out if not ln.startswith("[Gloo]")]  # gloo's own connection banner goes to stdout too
+    assert len(out) == 1  # exactly rank 0's line
+    import json
+
+    rec = json.loads(out[0])
+    assert rec == {"sum": 3.0, "world": 2, "argv": ["ok", "--steps", "3"]}
+
+
+def test_bench_launcher_does_not_hang_when_a_rank_dies(tmp_path):
+    import time
+
+    import bench
+
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    t0 = time.time()
+    rc = bench.launch_ranks(3, ["die"], script=str(script))
+    assert rc == 7                      # the failing rank's code is the launcher's
+    assert time.time() - t0 < 30.0      # and the sleeping ranks were stopped, not waited for
