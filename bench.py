@@ -394,6 +394,8 @@ def main():
     for e in engines:
         e.profile(True)
     lib.tjm_profile_cross_kernel(8 if E == 1 else 0)  # bracket every 8th launch of the dominant kernel with HIP events (one engine only)
+    jw = np.zeros(4)
+    lib.tjm_svd_work_read(jw.ctypes.data, 1)  # reset the executed-work counters of the tiled Jacobi kernels
     barrier()
     t0 = time.perf_counter()
     run_all(K, True)
@@ -413,6 +415,7 @@ def main():
     ms, nbytes, ns = C.c_double(0), C.c_double(0), C.c_int64(0)
     lib.tjm_profile_cross_kernel_read(C.byref(ms), C.byref(nbytes), C.byref(ns))
     lib.tjm_profile_cross_kernel(0)
+    lib.tjm_svd_work_read(jw.ctypes.data, 0)
 
     if rank == 0:
         total_traj = B * world
@@ -434,6 +437,16 @@ def main():
         # with several engines the classes overlap in time on the device: fractions are then of the engines' summed stream time
         tf = lambda fl, msv: (fl / 1e12) / (msv / 1e3) if msv > 0 else None  # noqa: E731
         svd_tf, kry_tf, env_tf = tf(flops_svd, cls_ms["svd"]), tf(flops_kry, cls_ms["krylov"]), tf(flops_env, cls_ms["env"])
+        # Next to the nominal figure: (i) the same convention with every factorisation counted at the size THIS build factors
+        # (a two-site split: n x n; a one-tensor SVD centre shift: (d chi) x chi, Golub & Van Loan's 6 m n^2 + 20 n^3 against 26 n^3
+        # for the square case), (ii) the flops the tiled Jacobi kernels really executed (28 real flops per row of every column pair
+        # of a visited tile: 8 for the dot product, 20 for the plane rotation, identity rotations included; counted on the device)
+        n_mats = sum(s1["svd_matrices"] - s0["svd_matrices"] for s0, s1 in zip(stats0, stats1))
+        splits = wsum("site_updates") if args.tdvp_mode == "2site" else 0
+        F_shift = F_svd * (6.0 * n * chi ** 2 + 20.0 * chi ** 3) / (26.0 * n ** 3)
+        flops_own = F_svd * min(splits, n_mats) + F_shift * max(0, n_mats - splits)
+        flops_exec = 28.0 * float(jw[0])
+        own_tf, exec_tf = tf(flops_own, cls_ms["svd"]), tf(flops_exec, cls_ms["svd"])
         step_tf = (flops_svd + flops_kry + flops_env) / 1e12 / elapsed
         busy = sum(cls_ms.values()) / 1e3
         traffic, traffic_note = pmc_traffic(L, chi, B)
@@ -477,7 +490,17 @@ def main():
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": (svd_tf / peak) if svd_tf else None,
+                "achieved_own_size": own_tf, "frac_own_size": (own_tf / peak) if own_tf else None,
+                "achieved_executed": exec_tf, "frac_executed": (exec_tf / peak) if exec_tf else None,
+                "executed_note": "own_size: centre shifts counted as the (d chi) x chi matrices this build factors instead of the reference's merged "
+                                 "(d chi) x (d chi) ones; executed: 28 flop x rows x column pairs of every visited Jacobi tile (device counter), "
+                                 "over the same SVD-class time (which also holds the QR, GEMM, finish and extract kernels)",
+                "jacobi_sweeps_per_solve": (float(jw[2]) / float(jw[3])) if jw[3] else None,
+                "jacobi_applied_over_executed_rotations": (float(jw[1]) / float(jw[0])) if jw[0] else None,
                 "traffic": traffic,
+                # PMC bytes of the dominant kernel per batched SVD (bytes per launch x its launches per solve) over the bytes a
+                # factorisation has to move (matrix in, factors out: 2 x 16 n^2 per trajectory)
+                "traffic_over_algorithmic": (traffic * (8.0 * ns.value / float(jw[3])) / (2.0 * 16 * n * n * B)) if (traffic and jw[3]) else None,
                 "traffic_note": traffic_note,
                 "algorithmic_flops_per_svd": F_svd,
                 "svds_per_step": cnt["svds"] / K / E,

@@ -140,7 +140,7 @@ int tjm_engine_canonicalize_qr(tjm_engine* e, int32_t set, int32_t center);
 int tjm_engine_sample_shots(tjm_engine* e, int32_t set, int32_t shots, const double* rotation, const double* uniforms, uint8_t* bits);
 int tjm_engine_stats(const tjm_engine* e, int64_t* out5);
 /* the same five counters followed by: two-site H_eff applies (a subset of matvecs), environment updates, centre shifts served by
- * the certified QR path, matrices factorised (batched SVD calls x trajectories in the call); writes min(n, 9) values */
+ * the certified QR path (reserved: always 0), matrices factorised (batched SVD calls x trajectories in the call); writes min(n, 9) values */
 int tjm_engine_stats_ex(const tjm_engine* e, int64_t* out, int32_t n);
 /* Live device time per kernel class of a step, bracketed with HIP events on the engine's stream (the source of bench.py's
  * roofline object): class 0 = SVD family (split_two_site and the SVD centre shifts: QR, Jacobi, truncation, their GEMMs),
@@ -289,6 +289,11 @@ int tjm_tridiag_expm(const double* alpha, const double* beta, int32_t k, double 
  * algorithmic bytes (2 x 16 columns x rows x 16 B per block-pair visit of a live trajectory), sample count. */
 int tjm_profile_cross_kernel(int32_t every);
 int tjm_profile_cross_kernel_read(double* total_ms, double* total_bytes, int64_t* samples);
+/* Work the tiled Jacobi kernels really executed in this process since the last reset (all engines): out4 = { rotation slots x rows
+ * (every column pair of a visited tile: one dot product and one - possibly identity - plane rotation of `rows` complex entries),
+ * applied rotations x rows, sweeps, solves }.  28 real flops per slot-row (8 dot + 20 rotation): bench.py reports the executed
+ * flops next to the nominal 88 n^3 of the reference's zgesdd (core/linalg/svd.py:51-104). */
+int tjm_svd_work_read(double* out4, int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -138,6 +138,7 @@ EXPORTS = {
     "tjm_tridiag_expm": (C.c_int, [V, V, I, D, V, V]),
     "tjm_profile_cross_kernel": (C.c_int, [I]),
     "tjm_profile_cross_kernel_read": (C.c_int, [V, V, V]),
+    "tjm_svd_work_read": (C.c_int, [V, I]),
 }
 
 _lib = None

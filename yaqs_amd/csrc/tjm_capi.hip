@@ -240,7 +240,7 @@ int tjm_engine_stats(const tjm_engine* e, int64_t* o) {
 int tjm_engine_stats_ex(const tjm_engine* e, int64_t* o, int32_t n) {
   if (!e || !o || n < 0) return TJM_ERR_ARG;
   const int64_t v[9] = {e->impl.stat_matvecs, e->impl.stat_krylov_calls, e->impl.stat_svds, e->impl.stat_svd_sweeps,
-                        e->impl.stat_site_updates, e->impl.stat_matvecs2, e->impl.stat_env_updates, e->impl.stat_cert_shifts,
+                        e->impl.stat_site_updates, e->impl.stat_matvecs2, e->impl.stat_env_updates, 0 /* reserved */,
                         e->impl.stat_svd_mats};
   for (int k = 0; k < n && k < 9; ++k) o[k] = v[k];
   return TJM_OK;
@@ -452,6 +452,12 @@ int tjm_svd_split_qr(const void* theta, int32_t B, int32_t d, int32_t capL, int3
 
 int tjm_profile_cross_kernel(int32_t every) {
   profile_enable(every);
+  return TJM_OK;
+}
+
+int tjm_svd_work_read(double* out4, int32_t reset) {
+  if (!out4) return TJM_ERR_ARG;
+  jacobi_work_get(out4, reset != 0);
   return TJM_OK;
 }
 

@@ -99,6 +99,11 @@ __device__ inline real tjm_rcp(real x) { return __builtin_amdgcn_rcp(x); }
     }                                                                                       \
   } while (0)
 
+// Sort key of the rank sorts (squared norms): a NaN compares false with everything, which would leave two entries with the same rank
+// and one slot of the permutation unwritten - a stale index that later addresses memory.  Non-finite input must end in an error
+// (the reference stops at its first measurement or jump weight), never in a fault: NaN sorts as +infinity.
+__device__ inline real tjm_sort_key(real v) { return (v == v) ? v : real(__builtin_huge_val()); }
+
 // Strided batched complex GEMM descriptor.
 //   C[m,n] (+)= sum_{ks} sum_k opA(A)[m,k] * opB(B)[k,n]
 // Element addresses (in complex elements):

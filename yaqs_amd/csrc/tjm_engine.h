@@ -42,7 +42,7 @@ class Engine {
   int trunc_mode = 0, max_bond = 0, tdvp_mode = 2, tdvp_sweeps = 1;
   // statistics
   long stat_matvecs = 0, stat_krylov_calls = 0, stat_svds = 0, stat_svd_sweeps = 0, stat_site_updates = 0;
-  long stat_matvecs2 = 0, stat_env_updates = 0, stat_cert_shifts = 0, stat_svd_mats = 0;  // two-site H_eff applies (subset of matvecs), environment updates, certified shifts
+  long stat_matvecs2 = 0, stat_env_updates = 0, stat_svd_mats = 0;  // two-site H_eff applies (subset of matvecs), environment updates, matrices factorised
 
   // Live timing of the kernel classes of a step with HIP events on the engine's stream (bench.py's roofline object):
   // class 0 = SVD family (two-site splits and SVD centre shifts: QR + Jacobi + finish + their GEMMs), 1 = Krylov exponentials

@@ -207,6 +207,7 @@ size_t svd_workspace_bytes(int max_dim, int B);
 size_t svd_carve(SvdWorkspace& w, char* base, int max_dim, int B);  // lays the buffers out behind base, returns the bytes used
 void profile_enable(int every);
 void profile_get(double* total_ms, double* total_bytes, long* samples);
+void jacobi_work_get(double* out4, bool reset);  // slot x rows, applied rotations x rows, sweeps, solves of the tiled Jacobi since the last reset
 // accumulate = false: rotate X only (no W rows, no rotation record); the caller rebuilds the other factor from X
 int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspace& w, hipStream_t s, JacobiShape* shape_out,
                  int* sweeps_out, bool accumulate = true);

@@ -244,7 +244,9 @@ __device__ inline void tridiag_expm_e1(const real* alpha, const real* beta, int 
   }
   const real mu = 0.5 * (lo + hi);
   const real rho = fabs(dt) * 0.5 * (hi - lo);
-  int nsub = (int)ceil(rho);
+  // a non-finite tridiagonal matrix (non-finite input state or Hamiltonian) must not turn into 2^31 sub-steps: its result is
+  // non-finite whatever the count, and the caller's measurement / jump-weight check reports it
+  int nsub = (rho < real(1e6)) ? (int)ceil(rho) : 1;
   if (nsub < 1) nsub = 1;
   const real h = dt / nsub;
   const real as = a - mu;

@@ -526,10 +526,10 @@ __global__ __launch_bounds__(256) void qr_colsort_kernel(const cplx* __restrict_
   }
   __syncthreads();
   for (int c = tid; c < zc; c += 256) {
-    const real mine = sn[c];
+    const real mine = tjm_sort_key(sn[c]);
     int rank = 0;
     for (int o = 0; o < zc; ++o) {
-      const real other = sn[o];
+      const real other = tjm_sort_key(sn[o]);
       rank += (other > mine || (other == mine && o < c)) ? 1 : 0;
     }
     cperm[(long)b * ld + rank] = c;

@@ -35,6 +35,7 @@ constexpr int NB = 8;        // columns per block
 constexpr int MAXRK = 16;    // row groups of 64 per column held in registers (rtot <= 1024); kernels are instantiated for 8 and 16
 constexpr int MAXBLK = 128;  // column blocks per matrix (ncols <= 1024: bonds up to 512)
 constexpr int STAMP_STRIDE = 3 * MAXBLK + MAXBLK * MAXBLK;
+constexpr int REC_PER_VISIT = 2 * NB * 2 * NB;  // pairs of a 16 x 16 column tile: 8 steps x 2 sub-steps x 8 wavefronts x 2 pairs = 256 rotations
 
 struct JacobiArgs {
   cplx* Y;
@@ -52,6 +53,7 @@ struct JacobiArgs {
   real* rec;  // [B][MAXBLK/4][256][4] rotation record of the split X / W scheme (c, sr, si, flag)
   int* stamps;  // [B][STAMP_STRIDE]: mod[MAXBLK] | verd[MAXBLK] | nz[MAXBLK] | ver[MAXBLK*MAXBLK]   (visit pruning)
   int clock;    // launch counter, strictly increasing inside one solve
+  int* work;    // rotation slots executed in this sweep (tile visits x pairs per visit; the identity rotations of a visited tile count)
 };
 
 __device__ inline void pair_of(int nblk, int round, int p, int& I, int& J) {
@@ -338,6 +340,7 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
   int total = 0;
 #pragma unroll
   for (int q = 0; q < NB; ++q) total += sCnt[q];
+  if (tid == 0 && g.work) atomicAdd(g.work, NB * NB);
   if (total == 0) {  // nothing rotated: memory is already up to date, remember the pair as verified
     if (tid == 0) st[3 * MAXBLK + I * MAXBLK + J] = g.clock;
     return;
@@ -470,6 +473,7 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
   int total = 0;
 #pragma unroll
   for (int q = 0; q < NB; ++q) total += sCnt[q];
+  if (tid == 0 && g.work) atomicAdd(g.work, REC_PER_VISIT);
   if (total == 0) {
     if (tid == 0) st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J] = g.clock;
     return;
@@ -496,7 +500,6 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
 // X / W boundary halves the registers and LDS of the latency-bound kernel (2 workgroups per CU) and turns the W
 // half into a pure FMA stream: one lane per row, all 32 columns of the tile in registers, 256 rotations with
 // wave-uniform parameters and compile-time column indices.
-constexpr int REC_PER_VISIT = 2 * NB * 2 * NB;  // 8 steps x 2 sub-steps x 8 wavefronts x 2 pairs = 256 rotations
 
 // One column of the X part in the registers of a wavefront: XRK row groups of 64 rows, lane = row within its group.  The kernel
 // below is written against these operations; the two arithmetic types differ in how the registers hold the column.
@@ -703,6 +706,7 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
 #pragma unroll
   for (int q = 0; q < NB; ++q) total += sCnt[q];
   if (tid == 0 && record) rec[3] = (total > 0) ? 1.0 : 0.0;  // flag slot of the first record: does the W half have work
+  if (tid == 0 && g.work) atomicAdd(g.work, REC_PER_VISIT);
   if (total == 0) {
     if (tid == 0) st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J] = g.clock;
     return;
@@ -927,6 +931,7 @@ __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
   if (lane == 0) sCnt[w] = cnt;
   __syncthreads();
   const int total = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
+  if (tid == 0 && g.work) atomicAdd(g.work, NB * (NB - 1) / 2);
   if (total == 0) {
     if (tid == 0) st[MAXBLK + I] = g.clock;
     return;
@@ -1205,10 +1210,10 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
   }
   __syncthreads();
   if (lane < n) {
-    const real v = sNorm[lane];
+    const real v = tjm_sort_key(sNorm[lane]);
     int rank = 0;
     for (int o = 0; o < n; ++o) {
-      const real u = sNorm[o];
+      const real u = tjm_sort_key(sNorm[o]);
       rank += (u > v || (u == v && o < lane)) ? 1 : 0;
     }
     sPerm[rank] = lane;
@@ -1336,10 +1341,10 @@ __global__ __launch_bounds__(64) void svd_split_small_kernel(SvdSplitDesc p, Tru
   }
   __syncthreads();
   if (lane < n) {
-    const real v = sNorm[lane];
+    const real v = tjm_sort_key(sNorm[lane]);
     int rank = 0;
     for (int o = 0; o < n; ++o) {
-      const real u = sNorm[o];
+      const real u = tjm_sort_key(sNorm[o]);
       rank += (u > v || (u == v && o < lane)) ? 1 : 0;
     }
     sPerm[rank] = lane;
@@ -1596,10 +1601,10 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspa
   }
   __syncthreads();
   for (int c = tid; c < ncols_pad; c += 256) {
-    const real v = sN[c];
+    const real v = tjm_sort_key(sN[c]);
     int rank = 0;
     for (int o = 0; o < ncols_pad; ++o) {
-      const real u = sN[o];
+      const real u = tjm_sort_key(sN[o]);
       rank += (u > v || (u == v && o < c)) ? 1 : 0;
     }
     sPerm[rank] = c;
@@ -1675,6 +1680,11 @@ struct CrossProfile {
   long samples = 0;
 };
 CrossProfile g_prof;
+// Work actually executed by the tiled Jacobi kernels since the last reset (read once per sweep with the convergence flag):
+// rotation slots x rows (every pair of a visited tile costs its dot product and its - possibly identity - rotation) and
+// applied rotations x rows; bench.py turns them into executed flops next to the nominal 88 n^3.
+struct JacobiWork { double slot_rows = 0.0, rotation_rows = 0.0; long sweeps = 0, solves = 0; };
+JacobiWork g_work;
 const bool g_debug = getenv("TJM_DEBUG_SVD") != nullptr;
 
 void prof_collect() {
@@ -1738,6 +1748,11 @@ void profile_enable(int every) {
   g_prof.total_ms = 0.0;
   g_prof.total_bytes = 0.0;
   g_prof.samples = 0;
+}
+
+void jacobi_work_get(double* out4, bool reset) {
+  out4[0] = g_work.slot_rows; out4[1] = g_work.rotation_rows; out4[2] = (double)g_work.sweeps; out4[3] = (double)g_work.solves;
+  if (reset) g_work = JacobiWork();
 }
 
 void profile_get(double* total_ms, double* total_bytes, long* samples) {
@@ -1810,7 +1825,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     hipLaunchKernelGGL(jacobi_load_kernel, dim3(gx, src.nb0), dim3(256), 0, s, src, w.Y, w.y_b0, ncols_pad, rx_top, rtot);
     JacobiArgs g;
     g.Y = w.Y; g.y_b0 = w.y_b0; g.rtot = rtot; g.rx = rx_top; g.nblk = ncols_pad / NB; g.tol2 = TJM_JACOBI_TOL2; g.fro2 = nullptr; g.nrot = nullptr;
-    g.done = nullptr; g.ids = src.ids; g.round = 0; g.stamps = nullptr; g.clock = 0; g.mode = 0; g.rec = nullptr;
+    g.done = nullptr; g.ids = src.ids; g.round = 0; g.stamps = nullptr; g.clock = 0; g.mode = 0; g.rec = nullptr; g.work = nullptr;
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 3 * sizeof(int), s));
     const size_t lds_bytes = (size_t)ncols_pad * rtot * sizeof(cplx) + (size_t)ncols_pad * sizeof(real) + 32 * sizeof(int);
     if (rtot <= 64) hipLaunchKernelGGL(jacobi_lds_kernel<1>, dim3(src.nb0), dim3(1024), lds_bytes, s, g, ncols_pad, 40, w.n_active);
@@ -1864,7 +1879,10 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   g.stamps = w.stamps;
   g.clock = 1;
   g.mode = 0;
+  g.work = w.n_active + 4;
+  ++g_work.solves;
   if (g.nblk > MAXBLK) return TJM_ERR_NOT_IMPLEMENTED;
+  TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 4, 0, sizeof(int), s));
   const int nrounds = tile16 ? (g.nblk / 2 - 1) : (g.nblk - 1);
   const int npairs = tile16 ? g.nblk / 4 : g.nblk / 2;
   const size_t lds16 = (size_t)2 * NB * rtot * sizeof(cplx) + 2 * NB * sizeof(real) + 16 * sizeof(int);
@@ -1943,9 +1961,13 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     }
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 2 * sizeof(int), s));
     hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tbc), dim3(256), 0, s, w.nrot, w.done, w.n_active, nb, g.ids);
-    TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active, 5 * sizeof(int), hipMemcpyDeviceToHost, s));
+    TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 4, 0, sizeof(int), s));
     TJM_HIP_CHECK(hipStreamSynchronize(s));
     conv_c = (*w.h_pinned == 0);
+    g_work.slot_rows += (double)w.h_pinned[4] * rx_top;
+    g_work.rotation_rows += (double)w.h_pinned[1] * rx_top;
+    ++g_work.sweeps;
     if (g_debug && src.ncols >= 128) fprintf(stderr, "[svd] ncols %d rx %d sweep %d live %d rotations %d\n", src.ncols, src.rx, sweep_c, w.h_pinned[0], w.h_pinned[1]);
     n_live = *w.h_pinned;
     if (g_prof.every > 0) prof_collect();

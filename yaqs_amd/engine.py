@@ -358,7 +358,7 @@ class BatchEngine:
         s = np.zeros(9, dtype=np.int64)
         self.lib.tjm_engine_stats_ex(self.h, s.ctypes.data, 9)
         return dict(matvecs=int(s[0]), krylov_calls=int(s[1]), svds=int(s[2]), svd_sweeps=int(s[3]), site_updates=int(s[4]),
-                    matvecs_two_site=int(s[5]), env_updates=int(s[6]), certified_shifts=int(s[7]), svd_matrices=int(s[8]))
+                    matvecs_two_site=int(s[5]), env_updates=int(s[6]), svd_matrices=int(s[8]))
 
     def profile(self, enable: bool = True):
         """Bracket the kernel classes of every step with HIP events on the engine's stream (tjm_engine_profile)."""
