@@ -162,14 +162,15 @@ int tjm_engine_profile_read(tjm_engine* e, double* ms3, int64_t* regions3);
  *   step_qr_bond    right_qr / left_qr of the site, environment update with Q, update_bond on C over dt, C into the neighbour
  *                   (integrators.py:352-377, 441-466; leftward it is the projector-splitting step of the fixed one-site sweep,
  *                   integrators.py:126-158 - sweep_dynamic's own leftward line transposes left_qr's factor a second time and
- *                   is not gauge invariant, see tjm_engine.hip)
+ *                   is not gauge invariant, see tjm_engine.hip).  max_bond > 0: a new bond the thin QR left above it is cut back
+ *                   to it along the NEW index, "site_tensor[:, :, :cap]; bond_tensor[:cap, :]" (integrators.py:361-364, 452-455)
  *   step_cap_bond   _sync_bond_dim where it truncates (sweep_utils.py:110-163): merged pair, sqrt-distributed split capped at
  *                   `target`, min_keep 1 */
 int tjm_engine_step_env_init(tjm_engine* e, int32_t set);
 int tjm_engine_step_two_site(tjm_engine* e, int32_t set, int32_t site, double dt, int32_t dist, int32_t capped, const int32_t* ids, int32_t n);
 int tjm_engine_step_one_site(tjm_engine* e, int32_t set, int32_t site, double dt, const int32_t* ids, int32_t n);
 int tjm_engine_step_env(tjm_engine* e, int32_t set, int32_t site, int32_t left, const int32_t* ids, int32_t n);
-int tjm_engine_step_qr_bond(tjm_engine* e, int32_t set, int32_t site, int32_t right, double dt, const int32_t* ids, int32_t n);
+int tjm_engine_step_qr_bond(tjm_engine* e, int32_t set, int32_t site, int32_t right, double dt, int32_t max_bond, const int32_t* ids, int32_t n);
 int tjm_engine_step_cap_bond(tjm_engine* e, int32_t set, int32_t bond, int32_t target, const int32_t* ids, int32_t n);
 
 /* Steps of the Basis-Update and Galerkin integrator (core/methods/bug.py) for the whole batch, sequenced by the host

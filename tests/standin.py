@@ -228,19 +228,26 @@ class OracleEngine:
             else:
                 rb[site - 1] = o.update_right_environment(t[site], t[site], self.mpo[site], rb[site])
 
-    def step_qr_bond(self, site, right, dt, ids=None, set_index=0):
+    def step_qr_bond(self, site, right, dt, ids=None, set_index=0, max_bond_dim=None):
         tol = self.params.krylov_tol
+        cap = max_bond_dim
         for b in self._slots(ids):
             t = self.sets[set_index][b].tensors
             lb, rb = self.env[b]
             if right:
                 q, c = o.right_qr(t[site])
+                if cap is not None and q.shape[2] > cap:  # integrators.py:361-364
+                    q, c = q[:, :, :cap], c[:cap, :]
                 t[site] = q
                 lb[site + 1] = o.update_left_environment(q, q, self.mpo[site], lb[site])
                 c = o.update_bond(lb[site + 1], rb[site], c, dt, tol)
                 t[site + 1] = np.einsum("adc,bd->abc", t[site + 1], c)
             else:
                 q, c = o.left_qr(t[site])
+                if cap is not None and q.shape[1] > cap:
+                    # integrators.py:452-455 cuts "bond_tensor[:cap, :]", the LEFT index of left_qr's R^T = C[left][new]; the
+                    # gauge-invariant step cuts the new index
+                    q, c = q[:, :cap, :], (c[:cap, :] if self.reference_quirks else c[:, :cap])
                 t[site] = q
                 rb[site - 1] = o.update_right_environment(q, q, self.mpo[site], rb[site])
                 # left_qr hands back R^T = C[left][new]; the reference's dynamic sweep transposes it once more (integrators.py:461).

@@ -789,3 +789,49 @@ def test_fermi_hubbard_chain_on_four_level_sites_matches_reference_fixture():
     assert [t.shape[2] for t in out.tensors] == list(g["tdvp_bonds"])
     ref = g["tdvp_vec"]
     assert abs(abs(np.vdot(ref, out.to_vec())) - np.vdot(ref, ref).real) < 1e-9
+
+
+@pytest.mark.gpu
+def test_dynamic_tdvp_cuts_an_oversized_qr_bond_back_to_the_cap():
+    """The regime the one-site branch of sweep_dynamic slices in (integrators.py:361-364, 452-455): Haar bonds of 3 under a cap of 4.
+    The forward sweep's uncapped two-site splits push bonds to 6, the backward sweep's left_qr then returns 6 > cap columns and the
+    factor is cut back to the cap.  Engine (tjm_engine_step_qr_bond with max_bond) against the oracle's gauge-invariant step
+    (reference_dynamic_transpose = False: the cut is along the NEW index; the reference's own line cuts left_qr's LEFT index and
+    transposes, which is pinned on the oracle in tests/test_oracle_golden.py): bond dimensions and state after two sweeps."""
+    from yaqs_amd.tjm import dynamic_tdvp
+
+    L, cap = 8, 4
+    rng = np.random.default_rng(11)
+    st0 = o.MPSState.haar(L, 3, rng)
+    st0.normalize("B")
+    mpo = o.ising_mpo(L, 1.0, 0.7)
+    op = o.Params(dt=0.1, svd_threshold=1e-12, max_bond_dim=cap, krylov_tol=1e-12, tdvp_mode="dynamic", reference_dynamic_transpose=False)
+    st = o.MPSState([t.copy() for t in st0.tensors], 0)
+    cuts = []
+    real_left_qr = o.left_qr
+
+    def spy(t):
+        q, c = real_left_qr(t)
+        cuts.append(q.shape[1])
+        return q, c
+
+    o.left_qr = spy
+    try:
+        o.tdvp(st, mpo, op)
+        o.tdvp(st, mpo, op)
+    finally:
+        o.left_qr = real_left_qr
+    assert max(cuts) > cap  # the regime is reached: a thin QR came out above the cap
+    e = make_engine(L, 8, 2, mpo)
+    e.set_params(dt=0.1, svd_threshold=1e-12, max_bond_dim=cap, krylov_tol=1e-12, tdvp_mode="dynamic")
+    e.load_state([t.copy() for t in st0.tensors])
+    dynamic_tdvp(e, 0, cap, 0.1, 1)
+    dynamic_tdvp(e, 0, cap, 0.1, 1)
+    assert not e.capacity_overflow()
+    want = st.to_vec()
+    for b in range(2):
+        out = e.export_state(b)
+        assert [t.shape[2] for t in out] == [t.shape[2] for t in st.tensors]
+        v = vec_of(out)
+        assert abs(abs(np.vdot(want, v)) - np.vdot(want, want).real) < 1e-9
+    e.close()

@@ -45,6 +45,7 @@ ENGINE_CASES = [
     "test_one_site_tdvp_run_with_a_pair_channel_grows_its_storage",
     "test_sample_at_and_segment_stitching_match_reference_on_the_engine",
     "test_dynamic_tdvp_matches_reference_on_the_engine",
+    "test_dynamic_tdvp_cuts_an_oversized_qr_bond_back_to_the_cap",
     "test_bug_integrator_matches_reference_on_the_engine",
     "test_bose_hubbard_qudit_chains_match_reference_fixture",
     "test_long_range_gates_through_the_gate_mpo_match_reference_fixture",

@@ -118,7 +118,7 @@ EXPORTS = {
     "tjm_engine_step_two_site": (C.c_int, [V, I, I, D, I, I, V, I]),
     "tjm_engine_step_one_site": (C.c_int, [V, I, I, D, V, I]),
     "tjm_engine_step_env": (C.c_int, [V, I, I, I, V, I]),
-    "tjm_engine_step_qr_bond": (C.c_int, [V, I, I, I, D, V, I]),
+    "tjm_engine_step_qr_bond": (C.c_int, [V, I, I, I, D, I, V, I]),
     "tjm_engine_step_cap_bond": (C.c_int, [V, I, I, I, V, I]),
     "tjm_engine_step_bug_prepare": (C.c_int, [V, I]),
     "tjm_engine_step_bug_site": (C.c_int, [V, I, I, D]),

@@ -314,10 +314,10 @@ int tjm_engine_step_env(tjm_engine* e, int32_t set, int32_t site, int32_t left, 
   TJM_ON_DEVICE(e);
   return e->impl.step_env(set, site, left, ids, n);
 }
-int tjm_engine_step_qr_bond(tjm_engine* e, int32_t set, int32_t site, int32_t right, double dt, const int32_t* ids, int32_t n) {
+int tjm_engine_step_qr_bond(tjm_engine* e, int32_t set, int32_t site, int32_t right, double dt, int32_t max_bond, const int32_t* ids, int32_t n) {
   if (!e) return TJM_ERR_ARG;
   TJM_ON_DEVICE(e);
-  return e->impl.step_qr_bond(set, site, right, dt, ids, n);
+  return e->impl.step_qr_bond(set, site, right, dt, max_bond, ids, n);
 }
 int tjm_engine_step_cap_bond(tjm_engine* e, int32_t set, int32_t bond, int32_t target, const int32_t* ids, int32_t n) {
   if (!e) return TJM_ERR_ARG;

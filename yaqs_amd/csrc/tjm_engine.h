@@ -116,7 +116,7 @@ class Engine {
   int step_two_site(int set, int i, double dt_, int dist, int capped, const int* host_ids, int n);
   int step_one_site(int set, int i, double dt_, const int* host_ids, int n);
   int step_env(int set, int i, int left, const int* host_ids, int n);
-  int step_qr_bond(int set, int i, int right, double dt_, const int* host_ids, int n);
+  int step_qr_bond(int set, int i, int right, double dt_, int max_bond, const int* host_ids, int n);
   int step_cap_bond(int set, int bond, int target, const int* host_ids, int n);
   // steps of the BUG integrator (core/methods/bug.py:35-257), whole batch; centres live in set 2, scratch in set 3
   int step_bug_prepare(int set);

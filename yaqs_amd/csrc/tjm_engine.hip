@@ -2142,6 +2142,36 @@ int Engine::step_env(int set, int i, int left, const int* host_ids, int n) {
   return left ? env_left(sets[set], i, dev, host_ids ? n : B) : env_right(sets[set], i, dev, host_ids ? n : B);
 }
 
+// The cut of the one-site branch of sweep_dynamic (integrators.py:361-364, 452-455): a thin QR whose new bond came out above
+// max_bond_dim is sliced back to it, "site_tensor[:, :, :cap]; bond_tensor[:cap, :]".  In this storage: the new bond's table
+// entry becomes cap, the dropped Q columns (rows of the left bond for the leftward step) and the dropped rows / columns of the bond
+// matrix along the NEW index are set to zero (entries beyond a bond are zero everywhere), the Krylov length shrinks with it.
+// One workgroup per trajectory.  right = 1: A_i[p][a][k >= cap] = 0, C[k >= cap][*] = 0 ; right = 0: A_i[p][k >= cap][r] = 0, C^T[*][k >= cap] = 0.
+__global__ __launch_bounds__(256) void clip_new_bond_kernel(cplx* __restrict__ A, long a_b0, int d, int ca, int cb, int* chi, int stride, int site, int right,
+                                                           int capv, cplx* __restrict__ Cm, int cdim, int* nloc, const int* ids) {
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  int* slot = chi + (long)b * stride + site + (right ? 1 : 0);
+  const int k = *slot;
+  __syncthreads();
+  if (k <= capv) return;
+  cplx* Ab = A + (long)b * a_b0;
+  const long total = (long)d * ca * cb;
+  for (long e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = (int)(e % cb), l = (int)((e / cb) % ca);
+    if ((right ? r : l) >= capv) Ab[e] = cplx{0.0, 0.0};
+  }
+  cplx* Cb = Cm + (long)b * cdim * cdim;
+  for (int e = threadIdx.x; e < cdim * cdim; e += blockDim.x) {
+    const int row = e / cdim, col = e - row * cdim;
+    if ((right ? row : col) >= capv) Cb[e] = cplx{0.0, 0.0};
+  }
+  if (threadIdx.x == 0) {
+    *slot = capv;
+    if (nloc) nloc[b] = nloc[b] / k * capv;
+  }
+}
+
 // The bond transfer of the one-site branch (integrators.py:352-377 / 441-466, the body of sweep_1site): thin QR of site i
 // (right = 1: A_i = Q C, right = 0: A_i = C^T Q), environment update with Q, exp(-i dt H_bond) on C, C into the neighbour.
 // right = 1: A_i = Q C, C evolves over dt, A_{i+1} <- C A_{i+1}.  right = 0: A_i = C^T Q, C evolves, A_{i-1} <- A_{i-1} C.
@@ -2154,7 +2184,7 @@ int Engine::step_env(int set, int i, int left, const int* host_ids, int n) {
 // implementation can reproduce those numbers; this step does what the fixed one-site sweep does, the projector-splitting step.
 // oracle/tjm_oracle.py restates the reference line for line behind Params.reference_dynamic_transpose (default on, pinned to the
 // reference's fixtures); the engine is compared with the oracle with that switch off wherever a bond sits at the cap.
-int Engine::step_qr_bond(int set, int i, int right, double dt_, const int* host_ids, int n) {
+int Engine::step_qr_bond(int set, int i, int right, double dt_, int max_bond, const int* host_ids, int n) {
   if (!bound_ || set < 0 || set > 1 || i < 0 || i >= L || (right && i + 1 >= L) || (!right && i < 1)) return TJM_ERR_ARG;
   StateSet& S = sets[set];
   const int* dev;
@@ -2164,6 +2194,8 @@ int Engine::step_qr_bond(int set, int i, int right, double dt_, const int* host_
   if (right) {
     const int cb = cap[i + 1], cc = cap[i + 2];
     if ((rc = qr_site(S, i, true, dev, nb)) != TJM_OK) return rc;
+    if (max_bond > 0 && max_bond < cb)
+      hipLaunchKernelGGL(clip_new_bond_kernel, dim3(nb), dim3(256), 0, stream, S.A[i], a_b0_[i], d, cap[i], cb, S.chi, L + 1, i, 1, max_bond, Cm_, cb, nloc_, dev);
     if ((rc = env_left(S, i, dev, nb)) != TJM_OK) return rc;
     TJM_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)v_b0 * sizeof(cplx), Cm_, (size_t)cb * cb * sizeof(cplx), (size_t)cb * cb * sizeof(cplx), B,
                                    hipMemcpyDeviceToDevice, stream));
@@ -2182,6 +2214,8 @@ int Engine::step_qr_bond(int set, int i, int right, double dt_, const int* host_
   }
   const int cz = cap[i - 1], ca = cap[i];
   if ((rc = qr_site(S, i, false, dev, nb)) != TJM_OK) return rc;
+  if (max_bond > 0 && max_bond < ca)
+    hipLaunchKernelGGL(clip_new_bond_kernel, dim3(nb), dim3(256), 0, stream, S.A[i], a_b0_[i], d, ca, cap[i + 1], S.chi, L + 1, i, 0, max_bond, Cm_, ca, nloc_, dev);
   if ((rc = env_right(S, i, dev, nb)) != TJM_OK) return rc;
   TJM_HIP_CHECK(hipMemcpy2DAsync(V, (size_t)v_b0 * sizeof(cplx), Cm_, (size_t)ca * ca * sizeof(cplx), (size_t)ca * ca * sizeof(cplx), B,
                                  hipMemcpyDeviceToDevice, stream));

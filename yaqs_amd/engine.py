@@ -320,10 +320,11 @@ class BatchEngine:
         a, n = self._ids(ids)
         _lib.check(self.lib.tjm_engine_step_env(self.h, set_index, int(site), int(bool(left)), None if a is None else a.ctypes.data, n), "step_env")
 
-    def step_qr_bond(self, site: int, right: bool, dt: float, ids=None, set_index: int = 0):
+    def step_qr_bond(self, site: int, right: bool, dt: float, ids=None, set_index: int = 0, max_bond_dim=None):
+        """``max_bond_dim``: the cut of sweep_dynamic's one-site branch, a new bond above it is sliced back to it (integrators.py:361-364)."""
         a, n = self._ids(ids)
-        _lib.check(self.lib.tjm_engine_step_qr_bond(self.h, set_index, int(site), int(bool(right)), float(dt), None if a is None else a.ctypes.data, n),
-                   "step_qr_bond")
+        _lib.check(self.lib.tjm_engine_step_qr_bond(self.h, set_index, int(site), int(bool(right)), float(dt), -1 if max_bond_dim is None else int(max_bond_dim),
+                                                    None if a is None else a.ctypes.data, n), "step_qr_bond")
 
     def step_cap_bond(self, bond: int, target: int, ids=None, set_index: int = 0):
         a, n = self._ids(ids)

@@ -84,7 +84,7 @@ def _sweep_dynamic(e, s: int, cap: int | None, dt: float) -> None:
         if len(one):
             e.step_one_site(i, 0.5 * dt, one, s)
             if i != n - 1:
-                e.step_qr_bond(i, True, -0.5 * dt, one, s)
+                e.step_qr_bond(i, True, -0.5 * dt, one, s, max_bond_dim=cap)
         if len(two) and i != n - 1:
             e.step_two_site(i, 0.5 * dt, "right", False, two, s)
             if i == n - 2:
@@ -98,7 +98,7 @@ def _sweep_dynamic(e, s: int, cap: int | None, dt: float) -> None:
         if len(one):
             e.step_one_site(i, 0.5 * dt, one, s)
             if i != 0:
-                e.step_qr_bond(i, False, -0.5 * dt, one, s)
+                e.step_qr_bond(i, False, -0.5 * dt, one, s, max_bond_dim=cap)
         if len(two) and i != 0:
             e.step_two_site(i - 1, 0.5 * dt, "left", False, two, s)
             e.step_env(i, False, two, s)
@@ -1017,7 +1017,12 @@ def engine_bond_caps(sim_params, initial_state, can_grow: bool = False, slack: i
     if getattr(sim_params, "tdvp_mode", "2site") == "dynamic" and sim_params.max_bond_dim is not None and not bug:
         # the two-site branch of the dynamic sweep splits without a cap (split_tdvp(dynamic=True)): a bond next to one below the cap
         # can reach d * (max_bond_dim - 1) before _cap_bonds cuts it back at the start of the next sweep
-        want = min(2 * int(sim_params.max_bond_dim), exact)
+        # (d = local dimension: 2 max_bond_dim for qubits, 3 / 4 max_bond_dim for qutrit / four-level chains)
+        want = min(d * int(sim_params.max_bond_dim), exact)
+        if d * want > 512 and want > int(sim_params.max_bond_dim):
+            # _cap_bonds' sqrt-distributed split (tjm_engine_step_cap_bond) is served by the plain Jacobi split, which holds d * bond <= 512
+            raise NotImplementedError(f"tdvp_mode='dynamic' with local dimension {d} and max_bond_dim {sim_params.max_bond_dim}: its uncapped "
+                                      f"two-site splits need bonds up to {want}, the capped re-split holds d * bond <= 512")
     if bug and sim_params.max_bond_dim is not None:
         # each of the two half-sweeps of a BUG step stacks [retained | predictor] along the left bond of every site: bonds reach
         # 4 * max_bond_dim before the single compression at the end of the step (bug.py:213-257)
