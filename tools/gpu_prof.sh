@@ -10,7 +10,7 @@ want() { [[ " $* " == *" $WHAT "* ]]; }
 for WHAT in "${@:-stats pmc}"; do :; done
 ARGS="$*"; [ -z "$ARGS" ] && ARGS="stats pmc"
 if [[ " $ARGS " == *" stats "* ]]; then
-  timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/stats_bench.json" 2> "$OUT/stats.err"
+  timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/stats" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/stats_bench.json" 2> "$OUT/stats.err"
   find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
   rm -rf "$OUT/stats"
   head -12 "$OUT/kernel_stats.csv"
@@ -23,7 +23,7 @@ if [[ " $ARGS " == *" pmc "* ]]; then
              "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
     # shellcheck disable=SC2086
-    timeout 900 rocprofv3 --pmc $pmc -d "$OUT/pmc$i" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --batch 256 --trajectories 256 > "$OUT/pmc${i}_bench.json" 2> "$OUT/pmc$i.err"
+    timeout 900 rocprofv3 --pmc $pmc -f csv -d "$OUT/pmc$i" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --batch 128 --trajectories 128 > "$OUT/pmc${i}_bench.json" 2> "$OUT/pmc$i.err"
     csv=$(find "$OUT/pmc$i" -name "*counter_collection.csv" | head -1)
     [ -n "$csv" ] && python3 tools/pmc_summary.py "$csv" "$OUT/pmc${i}_per_kernel.csv" > "$OUT/pmc${i}_summary.txt" 2>&1
     rm -rf "$OUT/pmc$i"

@@ -99,6 +99,19 @@ __device__ inline real tjm_rcp(real x) { return __builtin_amdgcn_rcp(x); }
     }                                                                                       \
   } while (0)
 
+// Lanczos breakdown test, "beta < 100 * vec.size * eps" (matrix_exponential.py:126-129).  With the fp64 epsilon this is a rounding
+// bound (6e-9 for a two-site block at chi = 256); with the fp32 epsilon the same formula gives 3.1 there - above every beta of a bulk
+// site, so the complex64 build declared "invariant subspace" after the first vector and left the block unevolved (found on the
+// MI355X: config 3 at chi = 256 lost no norm in its truncations).  The complex64 build uses the size of an fp32 rounding residual
+// instead: eps * sqrt(size) per unit of |H|, with the same factor 100.
+__host__ __device__ inline real tjm_breakdown_cut(int nloc) {
+#ifdef TJM_F32
+  return 100.0f * sqrtf((float)nloc) * TJM_EPS;
+#else
+  return 100.0 * (real)nloc * TJM_EPS;
+#endif
+}
+
 // Sort key of the rank sorts (squared norms): a NaN compares false with everything, which would leave two entries with the same rank
 // and one slot of the permutation unwritten - a stale index that later addresses memory.  Non-finite input must end in an error
 // (the reference stops at its first measurement or jump weight), never in a fault: NaN sorts as +infinity.

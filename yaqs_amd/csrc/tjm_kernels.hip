@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
     sX[e] = v;
     Vb[e] = v;
   }
-  const real eps_cut = 100.0 * (real)p.nloc[b] * TJM_EPS;
+  const real eps_cut = tjm_breakdown_cut(p.nloc[b]);
   const int na = p.chi_l ? min(p.chi_l[(long)b * p.chi_stride], ca) : ca;
   const int nb = p.chi_r ? min(p.chi_r[(long)b * p.chi_stride], cb) : cb;
   real bprev = 0.0;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64) void lanczos_finalize_kernel(KrylovState ks, co
     al[j] = a;
     if (j < m - 1) be[j] = bj;
   }
-  const real eps_cut = 100.0 * (real)nloc[b] * TJM_EPS;
+  const real eps_cut = tjm_breakdown_cut(nloc[b]);
   bool done = false;
   const int k = j + 1;
   real pr = 0.0, pi = 0.0;

@@ -1113,6 +1113,13 @@ __device__ inline int truncation_keep(const TruncSpec& d, int nsv, SV sv) {
     }
   }
   if (d.max_bond > 0 && keep > d.max_bond) keep = d.max_bond;
+#ifdef TJM_F32
+  // complex64 build: singular values below the resolution of the arithmetic (TJM_RANK_TOL of the largest one) are rounding noise -
+  // their columns were never rotated and are not orthogonal to the rest (found on the MI355X: the 1e-12 discarded-weight rule of
+  // the centre shifts kept values at 1e-6 of the largest, the "isometric" factor was 0.3 away from an isometry).  They carry
+  // < 1e-10 of the weight each and are dropped with the discarded ones.
+  while (keep > 1 && keep > d.min_keep && sv(keep - 1) <= TJM_RANK_TOL * sv(0)) --keep;
+#endif
   if (keep < d.min_keep) keep = d.min_keep;
   if (keep > nsv) keep = nsv;
   if (d.cap > 0 && keep > d.cap) {  // the engine's storage is smaller than what the truncation rule asks for
@@ -1233,6 +1240,9 @@ __device__ inline void svd_shift_small_body(const SmallShiftDesc& p, int b, int 
           break;
         }
       }
+#ifdef TJM_F32
+      while (keep > 1 && keep > p.min_keep && sqrt(sNorm[sPerm[keep - 1]]) <= TJM_RANK_TOL * sqrt(sNorm[sPerm[0]])) --keep;  // see truncation_keep
+#endif
       if (keep < p.min_keep) keep = p.min_keep;
       if (keep > nsv) keep = nsv;
     }
