@@ -85,11 +85,7 @@ def test_engine_runs_on_the_device_that_owns_its_workspace():
     e.close()
 
 
-CHI512 = pytest.mark.skipif(
-    os.environ.get("TJM_TEST_CHI512_ENGINE") is None,
-    reason="engine at chi = 512: not yet run on a GPU (round 2 lost two boxes to the FIRST version of this test, whose oracle check "
-           "contracted chi^4 transfer tensors = 1.1 TB of host memory; fixed; the gate / shift part passes on tests/hipsim; to be "
-           "verified on the device: TJM_TEST_CHI512_ENGINE=1)")
+CHI512 = pytest.mark.gpu  # the engine at chi = 512: on the MI355X since round 3 (profiles/r03_gpu_logs/c9_chi512_*.log); 13 s + 30 s, host memory < 1 GB
 
 
 def _chi512_case():

@@ -92,8 +92,12 @@ class Engine {
   int krylov_site(cplx* x_in_v0, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0,
                   int Dr, const cplx* Wm, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2,
                   int n3, long o0, long o1, long o2, int nb0, const int* ids, const int* chi_l = nullptr, const int* chi_r = nullptr);
+  // lch / rch: channel of Lenv / Renv certified to be the identity matrix (first or last; -1: none) - its share of the GEMM is a copy
   int heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv,
-                 long r_b0, int Dr, const cplx* Wm, cplx* y, long y_b0, int nb0, const int* ids, const int* active);
+                 long r_b0, int Dr, const cplx* Wm, cplx* y, long y_b0, int nb0, const int* ids, const int* active, int lch = -1, int rch = -1);
+  int identity_channels(int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0, int Dr, int nb0, const int* ids,
+                        const int* chi_l, const int* chi_r, int* lch, int* rch);
+  long stat_ident_calls = 0, stat_ident_hits = 0;  // Krylov calls examined / channels certified (of two per call)
 
   struct Prof {
     bool on = false;

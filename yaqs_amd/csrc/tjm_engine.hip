@@ -505,7 +505,7 @@ int Engine::merge_matrix_layout(StateSet& S, int i, const int* ids, int nb0) {
 }
 
 int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv,
-                       long r_b0, int Dr, const cplx* Wm, cplx* y, long y_b0, int nb0, const int* ids, const int* active) {
+                       long r_b0, int Dr, const cplx* Wm, cplx* y, long y_b0, int nb0, const int* ids, const int* active, int lch, int rch) {
   int rc;
   {  // T1[(p,a),(r,B)] = x[(p,a),b] R[b,(r,B)]
     GemmDesc g = blank_gemm();
@@ -514,6 +514,10 @@ int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cp
     g.a_rs = cb; g.a_cs = 1; g.b_rs = (long)Dr * cb; g.b_cs = 1; g.c_rs = (long)Dr * cb;
     g.nb0 = nb0; g.a_b0 = x_b0; g.b_b0 = r_b0; g.c_b0 = t_b0;
     g.ids = ids; g.active = active;
+    if (rch >= 0) {  // R[b, rch, B] = delta(b, B): that slice of T1 is x itself (the MPO stage reads it there), the GEMM covers the other Dr - 1 channels
+      g.N = (Dr - 1) * cb;
+      if (rch == 0) { g.B = Renv + cb; g.C = T1 + cb; }
+    }
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   {  // T2[o][a][l][B] = sum_{p,r} W[(o,l),(p,r)] T1[p][a][r][B]
@@ -522,6 +526,8 @@ int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cp
     m.in_sp = (long)ca * Dr * cb; m.in_sb = cb; m.in_sa = (long)Dr * cb;
     m.out_sp = (long)ca * Dl * cb; m.out_sb = cb; m.out_sa = (long)Dl * cb;
     m.in_b0 = t_b0; m.out_b0 = t_b0; m.nb0 = nb0; m.ids = ids; m.active = active;
+    if (rch >= 0) { m.in_alt = x; m.in_alt_ch = rch; m.in_alt_b0 = x_b0; m.in_alt_sp = (long)ca * cb; m.in_alt_sa = cb; }
+    if (lch >= 0) { m.out_alt = y; m.out_alt_ch = lch; m.out_alt_b0 = y_b0; m.out_alt_sp = (long)ca * cb; m.out_alt_sa = cb; }
     if ((rc = launch_mpo_apply(m, stream)) != TJM_OK) return rc;
   }
   {  // y[o][A][B] = sum_{(a,l)} L[(a,l)][A] T2[o][(a,l)][B]
@@ -532,8 +538,43 @@ int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cp
     g.nb0 = nb0; g.nb1 = P;
     g.a_b0 = l_b0; g.b_b0 = t_b0; g.b_b1 = (long)ca * Dl * cb; g.c_b0 = y_b0; g.c_b1 = (long)ca * cb;
     g.ids = ids; g.active = active;
+    if (lch >= 0) {  // L[a, lch, A] = delta(a, A): the MPO stage wrote that channel straight into y, the other Dl - 1 are a K-split sum on top of it
+      const long first = (lch == 0) ? 1 : 0;
+      g.A = Lenv + first * ca; g.B = T2 + first * cb;
+      g.K = ca; g.a_cs = (long)Dl * ca; g.b_rs = (long)Dl * cb;
+      g.nks = Dl - 1; g.a_ks = ca; g.b_ks = cb;
+      g.accumulate = 1;
+    }
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
+  return TJM_OK;
+}
+
+// Which channel of the two environments of a Krylov call is the identity matrix for EVERY trajectory of the call (see
+// env_identity_check_kernel)?  One small kernel per environment and one host read per call; -1 when none is.
+int Engine::identity_channels(int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0, int Dr, int nb0, const int* ids,
+                              const int* chi_l, const int* chi_r, int* lch, int* rch) {
+  *lch = -1;
+  *rch = -1;
+  static const bool off = getenv("TJM_NO_IDENTITY_CHANNELS") != nullptr;
+  if (off || ca < 32 || cb < 32 || (Dl < 2 && Dr < 2)) return TJM_OK;
+  int rc;
+  int* flags = ks.n_active + 8;
+#ifdef TJM_F32
+  const real tol = 1e-4f;
+#else
+  const real tol = 1e-9;
+#endif
+  TJM_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(int), stream));
+  if (Dl >= 2 && (rc = launch_env_identity_check(Lenv, l_b0, ca, Dl, chi_l, L + 1, tol, flags, nb0, ids, stream)) != TJM_OK) return rc;
+  if (Dr >= 2 && (rc = launch_env_identity_check(Renv, r_b0, cb, Dr, chi_r, L + 1, tol, flags + 2, nb0, ids, stream)) != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipMemcpyAsync(h_pinned_ + 12, flags, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  const int* f = h_pinned_ + 12;
+  if (Dl >= 2) *lch = !f[1] ? Dl - 1 : (!f[0] ? 0 : -1);
+  if (Dr >= 2) *rch = !f[2] ? 0 : (!f[3] ? Dr - 1 : -1);
+  ++stat_ident_calls;
+  stat_ident_hits += (*lch >= 0) + (*rch >= 0);
   return TJM_OK;
 }
 
@@ -680,8 +721,10 @@ int Engine::krylov_site(cplx* /*unused*/, int P, int ca, int cb, const cplx* Len
     ++stat_krylov_calls;
     return launch_krylov_site_small(q, stream);
   }
+  int lch = -1, rch = -1, rci;
+  if ((rci = identity_channels(ca, cb, Lenv, l_b0, Dl, Renv, r_b0, Dr, nb0, ids, chi_l, chi_r, &lch, &rch)) != TJM_OK) return rci;
   ApplyFn f = [&](const cplx* x, cplx* y, const int* active) {
-    return heff_apply(x, v_b0, P, ca, cb, Lenv, l_b0, Dl, Renv, r_b0, Dr, Wm, y, v_b0, nb0, ids, active);
+    return heff_apply(x, v_b0, P, ca, cb, Lenv, l_b0, Dl, Renv, r_b0, Dr, Wm, y, v_b0, nb0, ids, active, lch, rch);
   };
   krylov_P_ = P;
   const int rc = krylov_core(f, P * ca * cb, dt_, nloc_dev, out, out_b0, n0, n1, n2, n3, o0, o1, o2, nb0, ids);

@@ -18,6 +18,12 @@ struct MpoApplyDesc {
   int nb0;
   const int* ids;
   const int* active;
+  // identity channels of heff_apply: input channel in_alt_ch is read from in_alt ([b][pi][a][B] with its own strides) instead of
+  // `in`, output channel out_alt_ch is written to out_alt instead of `out` (-1: none)
+  const cplx* in_alt = nullptr;
+  cplx* out_alt = nullptr;
+  int in_alt_ch = -1, out_alt_ch = -1;
+  long in_alt_b0 = 0, in_alt_sp = 0, in_alt_sa = 0, out_alt_b0 = 0, out_alt_sp = 0, out_alt_sa = 0;
 };
 int launch_mpo_apply(const MpoApplyDesc& d, hipStream_t stream);
 
@@ -63,6 +69,8 @@ int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, in
                         int nblk, const real* beta, int beta_ld, int j, int nb0, const int* ids, const int* active,
                         hipStream_t s);
 int launch_scale(cplx* x, long x_b0, long n, const real* scale, int nb0, const int* ids, const int* active, hipStream_t s);
+int launch_env_identity_check(const cplx* env, long b0, int c, int D, const int* chi, int chi_stride, real tol, int* flags, int nb0, const int* ids,
+                              hipStream_t s);  // flags[0] / [1] raised when the first / last channel of env[c][D][c] is not the identity
 int launch_lanczos_init(const KrylovState& ks, const real* part, int nblk, int nb0, const int* ids, hipStream_t s);
 int launch_lanczos_finalize(const KrylovState& ks, const real* part1, const real* part2, int nblk, int j, real dt,
                             real tol, const int* nloc, int nb0, const int* ids, hipStream_t s);

@@ -34,6 +34,8 @@ __global__ __launch_bounds__(256) void mpo_apply_kernel(MpoApplyDesc d, int w_in
   const int a = idx / d.nB, Bc = idx % d.nB;
   const cplx* __restrict__ in = d.in + (long)b0 * d.in_b0 + (long)a * d.in_sa + Bc;
   cplx* __restrict__ out = d.out + (long)b0 * d.out_b0 + (long)a * d.out_sa + Bc;
+  const cplx* __restrict__ in_alt = d.in_alt ? d.in_alt + (long)b0 * d.in_alt_b0 + (long)a * d.in_alt_sa + Bc : nullptr;
+  cplx* __restrict__ out_alt = d.out_alt ? d.out_alt + (long)b0 * d.out_alt_b0 + (long)a * d.out_alt_sa + Bc : nullptr;
   constexpr int MAXD = 6;  // MPO bond dimensions held in registers (Ising 3, Heisenberg 5, exponential-sum models K + 2)
   if (d.din <= MAXD) {
     // every input element is loaded once and kept in registers for all dout outputs
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void mpo_apply_kernel(MpoApplyDesc d, int w_in
     for (int pi = 0; pi < P; ++pi)
 #pragma unroll
       for (int bi = 0; bi < MAXD; ++bi)
-        x[pi][bi] = (bi < d.din) ? in[(long)pi * d.in_sp + (long)bi * d.in_sb] : cplx{0.0, 0.0};
+        x[pi][bi] = (bi < d.din) ? ((bi == d.in_alt_ch) ? in_alt[(long)pi * d.in_alt_sp] : in[(long)pi * d.in_sp + (long)bi * d.in_sb]) : cplx{0.0, 0.0};
     for (int bo = 0; bo < d.dout; ++bo) {
       cplx acc[P];
 #pragma unroll
@@ -56,8 +58,13 @@ __global__ __launch_bounds__(256) void mpo_apply_kernel(MpoApplyDesc d, int w_in
             for (int pi = 0; pi < P; ++pi) cfma(acc[po], sW[(po * d.dout + bo) * nin + pi * d.din + bi], x[pi][bi]);
         }
       }
+      if (bo == d.out_alt_ch) {
 #pragma unroll
-      for (int po = 0; po < P; ++po) out[(long)po * d.out_sp + (long)bo * d.out_sb] = acc[po];
+        for (int po = 0; po < P; ++po) out_alt[(long)po * d.out_alt_sp] = acc[po];
+      } else {
+#pragma unroll
+        for (int po = 0; po < P; ++po) out[(long)po * d.out_sp + (long)bo * d.out_sb] = acc[po];
+      }
     }
     return;
   }
@@ -68,14 +75,19 @@ __global__ __launch_bounds__(256) void mpo_apply_kernel(MpoApplyDesc d, int w_in
     for (int bi = 0; bi < d.din; ++bi) {
       cplx x[P];
 #pragma unroll
-      for (int pi = 0; pi < P; ++pi) x[pi] = in[(long)pi * d.in_sp + (long)bi * d.in_sb];
+      for (int pi = 0; pi < P; ++pi) x[pi] = (bi == d.in_alt_ch) ? in_alt[(long)pi * d.in_alt_sp] : in[(long)pi * d.in_sp + (long)bi * d.in_sb];
 #pragma unroll
       for (int po = 0; po < P; ++po)
 #pragma unroll
         for (int pi = 0; pi < P; ++pi) cfma(acc[po], sW[(po * d.dout + bo) * nin + pi * d.din + bi], x[pi]);
     }
+    if (bo == d.out_alt_ch) {
 #pragma unroll
-    for (int po = 0; po < P; ++po) out[(long)po * d.out_sp + (long)bo * d.out_sb] = acc[po];
+      for (int po = 0; po < P; ++po) out_alt[(long)po * d.out_alt_sp] = acc[po];
+    } else {
+#pragma unroll
+      for (int po = 0; po < P; ++po) out[(long)po * d.out_sp + (long)bo * d.out_sb] = acc[po];
+    }
   }
 }
 
@@ -605,6 +617,42 @@ int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, in
                         hipStream_t s) {
   hipLaunchKernelGGL(lanczos_axpy_kernel, dim3(nblk, nb0), dim3(256), 0, s, w, vj, vjm1, v_b0, n, part1, part2, nblk, beta,
                      beta_ld, j, ids, active);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Identity channels of the environments.  An MPO written as a finite-state machine carries "nothing has happened yet" in one bond
+// index and "everything is done" in another (the identity rows / columns of W, mpo.py:326-406): the slice of a left environment
+// in the former and of a right environment in the latter is <A|A> of the sites on that side, i.e. the identity matrix whenever those
+// sites are isometric - which the sweep guarantees by construction.  env_identity_check_kernel CERTIFIES it for the environment
+// handed to a Krylov call (first and last channel; every trajectory of the call): flags[0] / flags[1] are raised when the
+// first / last channel of some trajectory differs from the identity on its actual bond by more than tol.  A certified channel lets
+// heff_apply skip its third of the two GEMMs (the product with the identity is a copy).
+// env layout [c][D][c]: env[(a * D + w) * c + A].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void env_identity_check_kernel(const cplx* __restrict__ env, long b0, int c, int D, const int* chi, int chi_stride,
+                                                                real tol, int* flags, const int* ids) {
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  const int n = chi ? min(chi[(long)b * chi_stride], c) : c;
+  const cplx* e = env + (long)b * b0;
+  int bad0 = 0, bad1 = 0;
+  for (long t = threadIdx.x; t < (long)n * n; t += blockDim.x) {
+    const int a = (int)(t / n), A = (int)(t - (long)a * n);
+    const real want = (a == A) ? real(1.0) : real(0.0);
+    const cplx v0 = e[((long)a * D) * c + A], v1 = e[((long)a * D + (D - 1)) * c + A];
+    bad0 |= !(fabs(v0.x - want) <= tol && fabs(v0.y) <= tol);   // written so that a NaN counts as a mismatch
+    bad1 |= !(fabs(v1.x - want) <= tol && fabs(v1.y) <= tol);
+  }
+  if (bad0) atomicOr(flags, 1);
+  if (bad1) atomicOr(flags + 1, 1);
+}
+
+int launch_env_identity_check(const cplx* env, long b0, int c, int D, const int* chi, int chi_stride, real tol, int* flags, int nb0, const int* ids,
+                              hipStream_t s) {
+  if (nb0 <= 0) return TJM_OK;
+  hipLaunchKernelGGL(env_identity_check_kernel, dim3(nb0), dim3(256), 0, s, env, b0, c, D, chi, chi_stride, tol, flags, ids);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }

@@ -679,7 +679,7 @@ class Simulator:
                     resume = dict(start=start, rng_pos=pos, extra=extra, results=np.ascontiguousarray(res[lo:hi]), diagnostics=np.ascontiguousarray(dg[lo:hi]))
                 res[lo:hi], dg[lo:hi] = run_piece(batch, lo, hi, resume)
             except CapacityError as err:
-                bigger = grown_capacity(cap_now, chi_top)
+                bigger = grown_capacity(cap_now, chi_top, getattr(engine, "d", 2))
                 if err.resume is not None and err.resume[0] > 0:
                     res[lo:hi], dg[lo:hi] = err.results, err.diagnostics  # the columns measured so far
                     pending.append((lo, hi, engine, 0, err.resume, err.rng_pos, getattr(err, "extra", None), bigger))
@@ -982,11 +982,16 @@ def _encoded(state: MPS) -> MPS:
     return out
 
 
-MAX_CHI = 256   # largest bond the engine serves.  The kernels hold d * chi <= 1024 since round 2 (1024 x 1024 splits verified on the
-# GPU against the oracle, tests/test_hip_kernels.py::test_svd_split_up_to_1024_matches_oracle), but the ENGINE has not yet run at
-# chi = 512 on a GPU (its first test exhausted the host memory of two GPU boxes with a chi^4 oracle contraction before the engine
-# was reached; tests/test_hip_round2.py::test_bonds_up_to_512_... is fixed and waits for the next GPU session), so runs beyond 256
-# stay refused until it has.
+MAX_CHI = 512   # largest bond the engine serves: the kernels hold d * chi <= 1024 (1024 x 1024 two-site splits, 1024-row Householder
+# panels).  The engine at chi = 512 - gate, SVD and QR centre shifts, a whole two-site TDVP sweep of a 20-site saturated chain -
+# agrees with the oracle on the MI355X (tests/test_hip_round2.py::test_bonds_up_to_512_*, profiles/r03_gpu_logs/c9_chi512_*.log).
+
+
+def max_chi(d: int = 2) -> int:
+    """Largest bond for local dimension d: the two-site matrix has d * chi rows."""
+    return min(MAX_CHI, 1024 // max(int(d), 2))
+
+
 START_CHI = 8   # first storage capacity tried when the requested cap is larger
 AUTO_BATCH_MAX = 16384  # trajectories in flight when Simulator(batch=None) sizes the batch itself
 MAX_ENGINE_BATCH = 65535  # the trajectory index is a y / z grid dimension of the kernels: tjm_engine_create refuses more
@@ -1028,30 +1033,32 @@ def engine_bond_caps(sim_params, initial_state, can_grow: bool = False, slack: i
         # 4 * max_bond_dim before the single compression at the end of the step (bug.py:213-257)
         want = min(4 * int(sim_params.max_bond_dim), exact)
     top = max(want, have)
-    if have > MAX_CHI:
-        raise NotImplementedError(f"bond dimension {have} of the initial state exceeds the supported chi <= {MAX_CHI}")
+    if have > max_chi(d):
+        raise NotImplementedError(f"bond dimension {have} of the initial state exceeds the supported chi <= {max_chi(d)} for local dimension {d}")
     if getattr(sim_params, "tdvp_mode", "2site") == "1site" and not can_grow:
         return have, have  # one-site TDVP never changes a bond (integrators.py:44-158)
     return max(have, min(top, START_CHI)), top
 
 
-CAPACITY_LADDER = (8, 16, 24, 32, 48, 64, 96, 128, 192, 256)  # steps of x1.5 / x1.33: work grows with chi**3, a re-padding copy is cheap
+CAPACITY_LADDER = (8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512)  # steps of x1.5 / x1.33: work grows with chi**3, a re-padding copy is cheap
 
 
-def grown_capacity(chi: int, top: int) -> int:
+def grown_capacity(chi: int, top: int, d: int = 2) -> int:
     if chi >= top:
         raise RuntimeError("a truncation was clipped although the engine holds max_bond_dim")  # cannot happen: svd_finish_kernel
-    if chi >= MAX_CHI:
-        raise NotImplementedError(f"the run needs bonds beyond {chi}; the HIP path holds chi <= {MAX_CHI}")
-    ladder = CAPACITY_LADDER if os.environ.get("TJM_CAPACITY_DOUBLING") is None else (8, 16, 32, 64, 128, 256)
-    return min(next(c for c in ladder if c > chi), top)
+    limit = max_chi(d)
+    if chi >= limit:
+        raise NotImplementedError(f"the run needs bonds beyond {chi}; the HIP path holds chi <= {limit} for local dimension {d}")
+    ladder = CAPACITY_LADDER if os.environ.get("TJM_CAPACITY_DOUBLING") is None else (8, 16, 32, 64, 128, 256, 512)
+    return min(next(c for c in ladder if c > chi), top, limit)
 
 
 def engine_bond_cap(sim_params, initial_state) -> int:
     """Largest capacity a run can need (``engine_bond_caps(...)[1]``), refused when beyond the supported size."""
     top = engine_bond_caps(sim_params, initial_state)[1]
-    if top > MAX_CHI:
-        raise NotImplementedError(f"bond dimension {top} exceeds the supported chi <= {MAX_CHI}")
+    d = int(initial_state.physical_dimensions[0]) if getattr(initial_state, "physical_dimensions", None) else 2
+    if top > max_chi(d):
+        raise NotImplementedError(f"bond dimension {top} exceeds the supported chi <= {max_chi(d)} for local dimension {d}")
     return top
 
 
