@@ -125,7 +125,6 @@ struct SvdWorkspace {
   int* done;      // [B]
   int* n_active;  // [1]
   int* h_pinned;  // host pinned int for the active counter
-  int* iota = nullptr;  // [B] 0, 1, 2, ...: identity index list for sub-batched sweeps
 };
 // Generic one-sided Jacobi problem: X[r][c] (rx x ncols) read through two-level strided indices
 //   r = r1 * r_n0 + r0 ,  c = c1 * c_n0 + c0 ,  X[r][c] = op(src[b*src_b0 + r1*s_r1 + r0*s_r0 + c1*s_c1 + c0*s_c0])

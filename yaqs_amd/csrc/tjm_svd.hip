@@ -53,6 +53,7 @@ struct JacobiArgs {
   real* rec;  // [B][MAXBLK/4][256][4] rotation record of the split X / W scheme (c, sr, si, flag)
   int* stamps;  // [B][STAMP_STRIDE]: mod[MAXBLK] | verd[MAXBLK] | nz[MAXBLK] | ver[MAXBLK*MAXBLK]   (visit pruning)
   int clock;    // launch counter, strictly increasing inside one solve
+  int fold;     // jacobi_cross16x_kernel: the pairs inside a 16-column block ride along with the tile visits (no diag / sibling launches)
   int* work;    // rotation slots executed in this sweep (tile visits x pairs per visit; the identity rotations of a visited tile count)
 };
 
@@ -618,7 +619,22 @@ struct ColFrag {
 #endif
 };
 
+// Columns of a 16-column block that wavefront w holds in tournament round tr (circle method on 16 players, player 15 fixed): over
+// the 15 rounds every pair of the block is the pair of exactly one wavefront.  tr < 0: the fixed assignment (2 w, 2 w + 1).
+__device__ inline int fold_column(int tr, int w, int h) {
+  if (tr < 0) return 2 * w + h;
+  if (w == 0) return h == 0 ? tr : 15;
+  return h == 0 ? (tr + w) % 15 : (tr - w + 15) % 15;
+}
+
 // XRK = row groups of 64 of the X part held in registers: 1 ... 8 (rx_top = 64 XRK; 4 at d*chi = 256)
+//
+// g.fold (matrices of at least 16 blocks, no accumulated unitary): the pairs INSIDE a 16-column block ride along.  In round r < 15
+// the wavefronts hold the columns of both blocks in the pairing of tournament round r, and one extra sub-step rotates the two
+// in-wavefront pairs (I_a, I_b), (J_a, J_b) before the J columns start to circulate: the 15 rounds of a sweep visit all 120 pairs
+// of every block exactly once, with no launch, no load and no store of their own (the separate diag / sibling kernels cost two
+// launches per sweep, each about as long as a round of this kernel).  The tile's verification stamp then also stands for those
+// pairs; a block whose partner of the round is all zero still gets its in-block sub-step.
 template <int XRK>
 __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kernel(JacobiArgs g) {
   extern __shared__ real smem[];
@@ -636,20 +652,23 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
   int I, J;
   pair_of(g.nblk / 2, g.round, blockIdx.x, I, J);
   int* st = g.stamps + (long)b * STAMP_STRIDE;
+  const int tr = (g.fold && g.round < 15) ? g.round : -1;           // tournament round of the in-block pairs (-1: none in this visit)
+  bool cross;
   {
     const int nzI = st[2 * MAXBLK + 2 * I] | st[2 * MAXBLK + 2 * I + 1];
     const int nzJ = st[2 * MAXBLK + 2 * J] | st[2 * MAXBLK + 2 * J + 1];
     const int ver = st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J];
     const int m1 = max(max(st[2 * I], st[2 * I + 1]), max(st[2 * J], st[2 * J + 1]));
-    if (!nzI || !nzJ || ver > m1) { if (tid == 0 && record) rec[3] = 0.0; return; }
+    cross = nzI && nzJ;
+    if ((!cross && (tr < 0 || (!nzI && !nzJ))) || ver > m1) { if (tid == 0 && record) rec[3] = 0.0; return; }
   }
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
   Col yI[2], yJ[2];
   real nI[2], nJ[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    yI[h].load(Yb + (long)(I * 16 + 2 * w + h) * rtot, lane);
-    yJ[h].load(Yb + (long)(J * 16 + 2 * w + h) * rtot, lane);
+    yI[h].load(Yb + (long)(I * 16 + fold_column(tr, w, h)) * rtot, lane);
+    yJ[h].load(Yb + (long)(J * 16 + fold_column(tr, w, h)) * rtot, lane);
     nI[h] = yI[h].norm2();
     nJ[h] = yJ[h].norm2();
   }
@@ -657,47 +676,54 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
   nJ[0] = wave_sum(nJ[0]); nJ[1] = wave_sum(nJ[1]);
   const real floor2 = TJM_NOISE_FLOOR2 * g.fro2[b];
   int cnt = 0;
-  for (int s = 0; s < NB; ++s) {
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      real gx[2], gy[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) Col::dot(yI[h], yJ[h ^ sub], gx[h], gy[h]);
-      // both inner products reduced together (row r of 16 lanes ends up with component r of (Re g0, Im g0, Re g1, Im g1));
-      // both rotations computed side by side, pair h in the half-wave h
-      const real gsum = wave_sum4_rows(gx[0], gy[0], gx[1], gy[1]);
-      const bool second = lane & 32;
-      real cv, sv, tv;
-      const bool rot = make_rotation_lanes(second ? nI[1] : nI[0], second ? nJ[1 ^ sub] : nJ[sub], gsum, g.tol2, floor2, cv, sv, tv);
-      cnt += __popcll(__ballot(rot) & 0x100000001ull);  // lanes 0 and 32 speak for the two pairs (scalar unit: the mask is in SGPRs)
-      if (record && (lane & 15) == 0) {
-        real* r4 = rec + ((((s * 2 + sub) * NB + w) * 2 + (lane >> 5)) * 4);
-        if (lane & 16) r4[2] = sv;
-        else { r4[0] = cv; r4[1] = sv; }
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int hj = h ^ sub;
-        // applied unconditionally: (c, s) = (1, 0) leaves the columns bit-identical, and in the sweeps that matter almost every
-        // pair rotates; the branch only bought register copies at its merge point
-        const real sr = lane_value(sv, 32 * h), si = lane_value(sv, 32 * h + 16);
-        const real c = lane_value(cv, 32 * h), tg = lane_value(tv, 32 * h);
-        Col::rotate(yI[h], yJ[hj], c, sr, si);
-        nI[h] -= tg;
-        nJ[hj] += tg;
-      }
+  // One sub-step: the independent pairs (p0, q0) and (p1, q1), norms (a0, d0), (a1, d1).  Both inner products are reduced together
+  // (row r of 16 lanes ends up with component r of (Re g0, Im g0, Re g1, Im g1)), both rotations are set up side by side - pair h in
+  // half-wave h - and applied unconditionally: (c, s) = (1, 0) leaves the columns bit-identical, and in the sweeps that matter
+  // almost every pair rotates; a branch only bought register copies at its merge point.
+  auto sub_step = [&](Col& p0, Col& q0, real& a0, real& d0, Col& p1, Col& q1, real& a1, real& d1, int rec_slot) {
+    real gx[2], gy[2];
+    Col::dot(p0, q0, gx[0], gy[0]);
+    Col::dot(p1, q1, gx[1], gy[1]);
+    const real gsum = wave_sum4_rows(gx[0], gy[0], gx[1], gy[1]);
+    const bool second = lane & 32;
+    real cv, sv, tv;
+    const bool rot = make_rotation_lanes(second ? a1 : a0, second ? d1 : d0, gsum, g.tol2, floor2, cv, sv, tv);
+    cnt += __popcll(__ballot(rot) & 0x100000001ull);  // lanes 0 and 32 speak for the two pairs (scalar unit: the mask is in SGPRs)
+    if (record && rec_slot >= 0 && (lane & 15) == 0) {
+      real* r4 = rec + (((rec_slot * NB + w) * 2 + (lane >> 5)) * 4);
+      if (lane & 16) r4[2] = sv;
+      else { r4[0] = cv; r4[1] = sv; }
     }
-    if (s + 1 < NB) {
+    {
+      const real sr = lane_value(sv, 0), si = lane_value(sv, 16), c = lane_value(cv, 0), tg = lane_value(tv, 0);
+      Col::rotate(p0, q0, c, sr, si);
+      a0 -= tg;
+      d0 += tg;
+    }
+    {
+      const real sr = lane_value(sv, 32), si = lane_value(sv, 48), c = lane_value(cv, 32), tg = lane_value(tv, 32);
+      Col::rotate(p1, q1, c, sr, si);
+      a1 -= tg;
+      d1 += tg;
+    }
+  };
+  if (tr >= 0) sub_step(yI[0], yI[1], nI[0], nI[1], yJ[0], yJ[1], nJ[0], nJ[1], -1);  // the in-block pairs of this round
+  if (cross) {
+    for (int s = 0; s < NB; ++s) {
+      sub_step(yI[0], yJ[0], nI[0], nJ[0], yI[1], yJ[1], nI[1], nJ[1], s * 2);
+      sub_step(yI[0], yJ[1], nI[0], nJ[1], yI[1], yJ[0], nI[1], nJ[0], s * 2 + 1);
+      if (s + 1 < NB) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) yJ[h].to_lds(slots + (w * 2 + h) * Col::LDS_REALS, lane);
-      if (lane < 2) sN[w * 2 + lane] = (lane == 0) ? nJ[0] : nJ[1];
-      __syncthreads();
-      const int src = (w + 1) & (NB - 1);
+        for (int h = 0; h < 2; ++h) yJ[h].to_lds(slots + (w * 2 + h) * Col::LDS_REALS, lane);
+        if (lane < 2) sN[w * 2 + lane] = (lane == 0) ? nJ[0] : nJ[1];
+        __syncthreads();
+        const int src = (w + 1) & (NB - 1);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) yJ[h].from_lds(slots + (src * 2 + h) * Col::LDS_REALS, lane);
-      nJ[0] = sN[src * 2];
-      nJ[1] = sN[src * 2 + 1];
-      __syncthreads();
+        for (int h = 0; h < 2; ++h) yJ[h].from_lds(slots + (src * 2 + h) * Col::LDS_REALS, lane);
+        nJ[0] = sN[src * 2];
+        nJ[1] = sN[src * 2 + 1];
+        __syncthreads();
+      }
     }
   }
   if (lane == 0) sCnt[w] = cnt;
@@ -706,17 +732,17 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
 #pragma unroll
   for (int q = 0; q < NB; ++q) total += sCnt[q];
   if (tid == 0 && record) rec[3] = (total > 0) ? 1.0 : 0.0;  // flag slot of the first record: does the W half have work
-  if (tid == 0 && g.work) atomicAdd(g.work, REC_PER_VISIT);
+  if (tid == 0 && g.work) atomicAdd(g.work, (cross ? REC_PER_VISIT : 0) + (tr >= 0 ? 2 * NB : 0));
   if (total == 0) {
     if (tid == 0) st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J] = g.clock;
     return;
   }
   if (tid == 0) { st[2 * I] = g.clock; st[2 * I + 1] = g.clock; st[2 * J] = g.clock; st[2 * J + 1] = g.clock; }
-  const int wj = (w + NB - 1) & (NB - 1);
+  const int wj = cross ? ((w + NB - 1) & (NB - 1)) : w;  // after 7 hand-overs wave w holds the J column pair of wave w - 1
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    yI[h].store(Yb + (long)(I * 16 + 2 * w + h) * rtot, lane);
-    yJ[h].store(Yb + (long)(J * 16 + 2 * wj + h) * rtot, lane);
+    yI[h].store(Yb + (long)(I * 16 + fold_column(tr, w, h)) * rtot, lane);
+    yJ[h].store(Yb + (long)(J * 16 + fold_column(tr, wj, h)) * rtot, lane);
   }
   if (tid == 0) atomicAdd(&g.nrot[b], total);
 }
@@ -1020,11 +1046,6 @@ __global__ void svd_sweep_check_kernel(int* nrot, int* done, int* n_active, int 
     atomicAdd(n_active + 1, nrot[b]);
   }
   nrot[b] = 0;
-}
-
-__global__ void svd_iota_kernel(int* out, int n) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) out[t] = t;
 }
 
 __global__ void svd_reset_kernel(int* nrot, int* done, int nb0, const int* ids) {
@@ -1791,7 +1812,6 @@ size_t svd_carve(SvdWorkspace& w, char* base, int max_dim, int B) {
   w.nrot = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   w.done = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   w.n_active = reinterpret_cast<int*>(take(256));
-  w.iota = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   return off;
 }
 
@@ -1835,7 +1855,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     hipLaunchKernelGGL(jacobi_load_kernel, dim3(gx, src.nb0), dim3(256), 0, s, src, w.Y, w.y_b0, ncols_pad, rx_top, rtot);
     JacobiArgs g;
     g.Y = w.Y; g.y_b0 = w.y_b0; g.rtot = rtot; g.rx = rx_top; g.nblk = ncols_pad / NB; g.tol2 = TJM_JACOBI_TOL2; g.fro2 = nullptr; g.nrot = nullptr;
-    g.done = nullptr; g.ids = src.ids; g.round = 0; g.stamps = nullptr; g.clock = 0; g.mode = 0; g.rec = nullptr; g.work = nullptr;
+    g.done = nullptr; g.ids = src.ids; g.round = 0; g.stamps = nullptr; g.clock = 0; g.mode = 0; g.rec = nullptr; g.work = nullptr; g.fold = 0;
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 3 * sizeof(int), s));
     const size_t lds_bytes = (size_t)ncols_pad * rtot * sizeof(cplx) + (size_t)ncols_pad * sizeof(real) + 32 * sizeof(int);
     if (rtot <= 64) hipLaunchKernelGGL(jacobi_lds_kernel<1>, dim3(src.nb0), dim3(1024), lds_bytes, s, g, ncols_pad, 40, w.n_active);
@@ -1903,31 +1923,24 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
 #endif
   const size_t lds16x = (size_t)2 * NB * rx_slot * sizeof(cplx) + 2 * NB * sizeof(real) + 16 * sizeof(int);
   g.rec = accumulate ? w.rec : nullptr;
+  // in-block pairs folded into the tile visits (jacobi_cross16x_kernel): needs the 15 tournament rounds of a 16-column block inside
+  // one sweep, and no rotation record (the W replay kernel knows the fixed column assignment only)
+  static const bool no_fold = getenv("TJM_NO_FOLD") != nullptr;
+  g.fold = (!no_fold && split16 && !accumulate && nrounds >= 15) ? 1 : 0;
   const int max_sweeps = 40;
-  // Sub-batches (TJM_SVD_CHUNK=n trajectories, default off): all sweeps of one chunk before the next, so that the chunk's stacked
-  // matrices (1 MiB each at d*chi = 256) stay resident in the 256 MiB Infinity Cache between the rounds instead of streaming from HBM.
-  static const int chunk_env = getenv("TJM_SVD_CHUNK") ? atoi(getenv("TJM_SVD_CHUNK")) : 0;
-  const int chunk = (chunk_env > 0 && chunk_env < src.nb0 && w.iota != nullptr) ? chunk_env : src.nb0;
-  const int* all_ids = src.ids;
-  if (chunk < src.nb0 && all_ids == nullptr) {
-    hipLaunchKernelGGL(svd_iota_kernel, dim3((src.nb0 + 255) / 256), dim3(256), 0, s, w.iota, src.nb0);
-    all_ids = w.iota;
-  }
-  int sweep = 0;
-  bool converged = true;
-  for (int c0 = 0; c0 < src.nb0; c0 += chunk) {
-  const int nb = std::min(chunk, src.nb0 - c0);
+  const int nb = src.nb0;
   const int tbc = (nb + 255) / 256;
-  g.ids = all_ids ? all_ids + c0 : nullptr;
   int sweep_c = 0;
   int n_live = nb;
   bool conv_c = false;
   for (; sweep_c < max_sweeps && !conv_c; ++sweep_c) {
     ++g.clock;
     g.mode = 0;
-    if (big) hipLaunchKernelGGL(jacobi_diag_kernel<16>, dim3(g.nblk, nb), dim3(256), lds, s, g);
-    else hipLaunchKernelGGL(jacobi_diag_kernel<8>, dim3(g.nblk, nb), dim3(256), lds, s, g);
-    if (tile16) {  // pairs between the two 8-column halves of every 16-column block
+    if (!g.fold) {
+      if (big) hipLaunchKernelGGL(jacobi_diag_kernel<16>, dim3(g.nblk, nb), dim3(256), lds, s, g);
+      else hipLaunchKernelGGL(jacobi_diag_kernel<8>, dim3(g.nblk, nb), dim3(256), lds, s, g);
+    }
+    if (tile16 && !g.fold) {  // pairs between the two 8-column halves of every 16-column block
       ++g.clock;
       g.mode = 1;
       if (big) hipLaunchKernelGGL(jacobi_cross_kernel<16>, dim3(g.nblk / 2, nb), dim3(512), lds, s, g);
@@ -1982,10 +1995,8 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     n_live = *w.h_pinned;
     if (g_prof.every > 0) prof_collect();
   }
-  sweep = std::max(sweep, sweep_c);
-  converged = converged && conv_c;
-  }
-  g.ids = src.ids;
+  const int sweep = sweep_c;
+  const bool converged = conv_c;
   if (sweeps_out) *sweeps_out = sweep;
   TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 2, 0, sizeof(int), s));
   hipLaunchKernelGGL(svd_finish_kernel, dim3(src.nb0), dim3(256), 0, s, tr, w, ncols_pad, rx_top, rtot, src.ids);
