@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -635,7 +636,11 @@ __device__ inline int fold_column(int tr, int w, int h) {
 // of every block exactly once, with no launch, no load and no store of their own (the separate diag / sibling kernels cost two
 // launches per sweep, each about as long as a round of this kernel).  The tile's verification stamp then also stands for those
 // pairs; a block whose partner of the round is all zero still gets its in-block sub-step.
-template <int XRK>
+//
+// LATE: the variant for the last sweeps (the host launches it once a sweep has rotated less than a quarter of its pairs): a sub-step
+// whose two pairs are both orthogonal already - nearly all of them by then - stops after the inner products and the decision
+// instead of applying two identity rotations.
+template <int XRK, bool LATE>
 __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kernel(JacobiArgs g) {
   extern __shared__ real smem[];
   int b = blockIdx.y;
@@ -688,7 +693,9 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
     const bool second = lane & 32;
     real cv, sv, tv;
     const bool rot = make_rotation_lanes(second ? a1 : a0, second ? d1 : d0, gsum, g.tol2, floor2, cv, sv, tv);
-    cnt += __popcll(__ballot(rot) & 0x100000001ull);  // lanes 0 and 32 speak for the two pairs (scalar unit: the mask is in SGPRs)
+    const unsigned long long both = __ballot(rot) & 0x100000001ull;  // lanes 0 and 32 speak for the two pairs (scalar unit: the mask is in SGPRs)
+    cnt += __popcll(both);
+    if (LATE && !record && both == 0) return;
     if (record && rec_slot >= 0 && (lane & 15) == 0) {
       real* r4 = rec + (((rec_slot * NB + w) * 2 + (lane >> 5)) * 4);
       if (lane & 16) r4[2] = sv;
@@ -1700,17 +1707,23 @@ __global__ __launch_bounds__(256) void svd_extract_kernel(ExtractDesc x, SvdWork
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
-// Optional live timing of the dominant kernel (jacobi_cross_kernel) with HIP events on the launch stream.
+// Optional live timing of the dominant kernel (jacobi_cross16x_kernel) with HIP events on the launch stream.  Several engines of one
+// process run their factorisations on host threads of their own (bench.py --engines): the event pool and the pending samples belong
+// to the calling thread, the totals are shared behind a mutex.
 struct CrossProfile {
   int every = 0;  // 0 = off, otherwise every N-th launch is bracketed by events
+  double total_ms = 0.0, total_bytes = 0.0;
+  long samples = 0;
+};
+struct CrossSampler {
   long counter = 0;
   std::vector<hipEvent_t> pool;
   std::vector<std::pair<int, real>> pending;  // (event pair index, bytes)
   size_t used = 0;
-  double total_ms = 0.0, total_bytes = 0.0;
-  long samples = 0;
 };
 CrossProfile g_prof;
+thread_local CrossSampler t_prof;
+std::mutex g_prof_mutex;
 // Work actually executed by the tiled Jacobi kernels since the last reset (read once per sweep with the convergence flag):
 // rotation slots x rows (every pair of a visited tile costs its dot product and its - possibly identity - rotation) and
 // applied rotations x rows; bench.py turns them into executed flops next to the nominal 88 n^3.
@@ -1719,16 +1732,22 @@ JacobiWork g_work;
 const bool g_debug = getenv("TJM_DEBUG_SVD") != nullptr;
 
 void prof_collect() {
-  for (auto& p : g_prof.pending) {
+  double ms_sum = 0.0, bytes_sum = 0.0;
+  long n = 0;
+  for (auto& p : t_prof.pending) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, g_prof.pool[2 * p.first], g_prof.pool[2 * p.first + 1]) == hipSuccess) {
-      g_prof.total_ms += ms;
-      g_prof.total_bytes += p.second;
-      ++g_prof.samples;
+    if (hipEventElapsedTime(&ms, t_prof.pool[2 * p.first], t_prof.pool[2 * p.first + 1]) == hipSuccess) {
+      ms_sum += ms;
+      bytes_sum += p.second;
+      ++n;
     }
   }
-  g_prof.pending.clear();
-  g_prof.used = 0;
+  t_prof.pending.clear();
+  t_prof.used = 0;
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  g_prof.total_ms += ms_sum;
+  g_prof.total_bytes += bytes_sum;
+  g_prof.samples += n;
 }
 
 }  // namespace
@@ -1774,19 +1793,21 @@ int launch_svd_shift_small(const SmallShiftDesc& p, bool left, hipStream_t s) {
 
 
 void profile_enable(int every) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   g_prof.every = every;
-  g_prof.counter = 0;
   g_prof.total_ms = 0.0;
   g_prof.total_bytes = 0.0;
   g_prof.samples = 0;
 }
 
 void jacobi_work_get(double* out4, bool reset) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   out4[0] = g_work.slot_rows; out4[1] = g_work.rotation_rows; out4[2] = (double)g_work.sweeps; out4[3] = (double)g_work.solves;
   if (reset) g_work = JacobiWork();
 }
 
 void profile_get(double* total_ms, double* total_bytes, long* samples) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   *total_ms = g_prof.total_ms;
   *total_bytes = g_prof.total_bytes;
   *samples = g_prof.samples;
@@ -1876,11 +1897,15 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_diag_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_diag_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
+#define TJM_X16_ATTR(K, BYTES)                                                                                                                         \
+  TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)); \
+  TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16x_kernel<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
+    TJM_X16_ATTR(4, 80 * 1024);
+    TJM_X16_ATTR(5, big_lds);
+    TJM_X16_ATTR(6, big_lds);
+    TJM_X16_ATTR(7, big_lds);
+    TJM_X16_ATTR(8, big_lds);
+#undef TJM_X16_ATTR
     attr_set = true;
   }
   const size_t lds = (size_t)NB * rtot * sizeof(cplx) + NB * sizeof(real) + 16 * sizeof(int);
@@ -1910,7 +1935,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   g.clock = 1;
   g.mode = 0;
   g.work = w.n_active + 4;
-  ++g_work.solves;
+  { std::lock_guard<std::mutex> lock(g_prof_mutex); ++g_work.solves; }
   if (g.nblk > MAXBLK) return TJM_ERR_NOT_IMPLEMENTED;
   TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 4, 0, sizeof(int), s));
   const int nrounds = tile16 ? (g.nblk / 2 - 1) : (g.nblk - 1);
@@ -1933,6 +1958,8 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   int sweep_c = 0;
   int n_live = nb;
   bool conv_c = false;
+  bool late = false;  // the previous sweep rotated less than a quarter of its pairs: the check-first variant of the tile kernel
+  static const bool no_late = getenv("TJM_NO_LATE_SWEEPS") != nullptr;
   for (; sweep_c < max_sweeps && !conv_c; ++sweep_c) {
     ++g.clock;
     g.mode = 0;
@@ -1950,32 +1977,36 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     for (int r = 0; r < nrounds; ++r) {
       g.round = r;
       ++g.clock;
-      const bool timed = g_prof.every > 0 && split16 && (g_prof.counter++ % g_prof.every == 0);  // only the dominant (split X) kernel is sampled
+      const bool timed = g_prof.every > 0 && split16 && (t_prof.counter++ % g_prof.every == 0);  // only the dominant (split X) kernel is sampled
       int slot = -1;
       if (timed) {
-        slot = (int)g_prof.used++;
-        while (g_prof.pool.size() < 2 * g_prof.used) {
+        slot = (int)t_prof.used++;
+        while (t_prof.pool.size() < 2 * t_prof.used) {
           hipEvent_t ev;
           TJM_HIP_CHECK(hipEventCreate(&ev));
-          g_prof.pool.push_back(ev);
+          t_prof.pool.push_back(ev);
         }
-        TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot], s));
+        TJM_HIP_CHECK(hipEventRecord(t_prof.pool[2 * slot], s));
       }
       if (split16) {
         const dim3 gridx(npairs, nb), blockx(512);
+#define TJM_X16_LAUNCH(K)                                                                     \
+  if (late) hipLaunchKernelGGL((jacobi_cross16x_kernel<K, true>), gridx, blockx, lds16x, s, g); \
+  else hipLaunchKernelGGL((jacobi_cross16x_kernel<K, false>), gridx, blockx, lds16x, s, g)
         switch (rx_top / 64) {  // row groups of 64 held in registers
-          case 1: hipLaunchKernelGGL(jacobi_cross16x_kernel<1>, gridx, blockx, lds16x, s, g); break;
-          case 2: hipLaunchKernelGGL(jacobi_cross16x_kernel<2>, gridx, blockx, lds16x, s, g); break;
-          case 3: hipLaunchKernelGGL(jacobi_cross16x_kernel<3>, gridx, blockx, lds16x, s, g); break;
-          case 4: hipLaunchKernelGGL(jacobi_cross16x_kernel<4>, gridx, blockx, lds16x, s, g); break;
-          case 5: hipLaunchKernelGGL(jacobi_cross16x_kernel<5>, gridx, blockx, lds16x, s, g); break;
-          case 6: hipLaunchKernelGGL(jacobi_cross16x_kernel<6>, gridx, blockx, lds16x, s, g); break;
-          case 7: hipLaunchKernelGGL(jacobi_cross16x_kernel<7>, gridx, blockx, lds16x, s, g); break;
-          default: hipLaunchKernelGGL(jacobi_cross16x_kernel<8>, gridx, blockx, lds16x, s, g); break;
+          case 1: TJM_X16_LAUNCH(1); break;
+          case 2: TJM_X16_LAUNCH(2); break;
+          case 3: TJM_X16_LAUNCH(3); break;
+          case 4: TJM_X16_LAUNCH(4); break;
+          case 5: TJM_X16_LAUNCH(5); break;
+          case 6: TJM_X16_LAUNCH(6); break;
+          case 7: TJM_X16_LAUNCH(7); break;
+          default: TJM_X16_LAUNCH(8); break;
         }
+#undef TJM_X16_LAUNCH
         if (timed) {  // the timed kernel is the X-rows kernel alone: its tile is the X part of the 32 columns, read + written once
-          TJM_HIP_CHECK(hipEventRecord(g_prof.pool[2 * slot + 1], s));
-          g_prof.pending.emplace_back(slot, (real)npairs * n_live * 4.0 * NB * rx_top * sizeof(cplx) * 2.0);
+          TJM_HIP_CHECK(hipEventRecord(t_prof.pool[2 * slot + 1], s));
+          t_prof.pending.emplace_back(slot, (real)npairs * n_live * 4.0 * NB * rx_top * sizeof(cplx) * 2.0);
         }
         if (accumulate) hipLaunchKernelGGL(jacobi_cross16w_kernel, dim3(npairs, ncols_pad / 64, nb), dim3(64), 0, s, g, rx_top);
       } else if (tile16) hipLaunchKernelGGL(jacobi_cross16_kernel<8>, dim3(npairs, nb), dim3(512), lds16, s, g);
@@ -1988,11 +2019,15 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 4, 0, sizeof(int), s));
     TJM_HIP_CHECK(hipStreamSynchronize(s));
     conv_c = (*w.h_pinned == 0);
-    g_work.slot_rows += (double)w.h_pinned[4] * rx_top;
-    g_work.rotation_rows += (double)w.h_pinned[1] * rx_top;
-    ++g_work.sweeps;
+    {
+      std::lock_guard<std::mutex> lock(g_prof_mutex);
+      g_work.slot_rows += (double)w.h_pinned[4] * rx_top;
+      g_work.rotation_rows += (double)w.h_pinned[1] * rx_top;
+      ++g_work.sweeps;
+    }
     if (g_debug && src.ncols >= 128) fprintf(stderr, "[svd] ncols %d rx %d sweep %d live %d rotations %d\n", src.ncols, src.rx, sweep_c, w.h_pinned[0], w.h_pinned[1]);
     n_live = *w.h_pinned;
+    late = !no_late && !accumulate && (double)w.h_pinned[1] < 0.25 * 0.5 * (double)ncols_pad * (ncols_pad - 1) * std::max(n_live, 1);
     if (g_prof.every > 0) prof_collect();
   }
   const int sweep = sweep_c;
