@@ -191,7 +191,7 @@ def pmc_traffic(L, chi, B):
     separate FETCH_SIZE and WRITE_SIZE runs of this script, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
     PMC counters cannot be read from inside the timed run, so the number is only reported for the configuration it was
     collected on."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
@@ -199,7 +199,10 @@ def pmc_traffic(L, chi, B):
             continue
         if (rec.get("L"), rec.get("chi")) != (L, chi):
             continue
-        return rec["traffic_bytes_per_launch"], f"{name}: {rec['note']} (collected with {rec.get('batch')} trajectories in flight)"
+        # a launch covers the trajectories of ONE engine: scale the per-launch bytes of the collection run to that many
+        scale = float(B) / float(rec.get("batch") or B)
+        return rec["traffic_bytes_per_launch"] * scale, (f"{name}: {rec['note']} (collected with {rec.get('batch')} trajectories per launch, "
+                                                          f"scaled to the {B} of this run's launches)")
     return None, "no PMC summary committed for this configuration"
 
 
@@ -463,7 +466,7 @@ def main():
         own_tf, exec_tf = tf(flops_own, cls_ms["svd"]), tf(flops_exec, cls_ms["svd"])
         step_tf = (flops_svd + flops_kry + flops_env) / 1e12 / elapsed
         busy = sum(cls_ms.values()) / 1e3
-        traffic, traffic_note = pmc_traffic(L, chi, B)
+        traffic, traffic_note = pmc_traffic(L, chi, sizes[0])
         cross_gbs = (nbytes.value / 1e9) / (ms.value / 1e3) if ms.value > 0 else None
         f32 = args.dtype != "complex128"
         peak = 2 * FP64_PEAK_TFLOPS if f32 else FP64_PEAK_TFLOPS  # fp32 vector and matrix rates: 157.3 TFLOP/s
@@ -514,7 +517,7 @@ def main():
                 "traffic": traffic,
                 # PMC bytes of the dominant kernel per batched SVD (bytes per launch x its launches per solve) over the bytes a
                 # factorisation has to move (matrix in, factors out: 2 x 16 n^2 per trajectory)
-                "traffic_over_algorithmic": (traffic * (8.0 * ns.value / float(jw[3])) / (2.0 * 16 * n * n * B)) if (traffic and jw[3]) else None,
+                "traffic_over_algorithmic": (traffic * (8.0 * ns.value / float(jw[3])) / (2.0 * 16 * n * n * sizes[0])) if (traffic and jw[3]) else None,
                 "traffic_note": traffic_note,
                 "algorithmic_flops_per_svd": F_svd,
                 "svds_per_step": cnt["svds"] / K / E,

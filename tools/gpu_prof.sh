@@ -23,7 +23,7 @@ if [[ " $ARGS " == *" pmc "* ]]; then
              "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
     # shellcheck disable=SC2086
-    timeout 900 rocprofv3 --pmc $pmc -f csv -d "$OUT/pmc$i" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --batch 128 --trajectories 128 > "$OUT/pmc${i}_bench.json" 2> "$OUT/pmc$i.err"
+    timeout 900 rocprofv3 --pmc $pmc -f csv -d "$OUT/pmc$i" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --engines 1 --batch ${PMC_BATCH:-128} --trajectories ${PMC_BATCH:-128} > "$OUT/pmc${i}_bench.json" 2> "$OUT/pmc$i.err"
     csv=$(find "$OUT/pmc$i" -name "*counter_collection.csv" | head -1)
     [ -n "$csv" ] && python3 tools/pmc_summary.py "$csv" "$OUT/pmc${i}_per_kernel.csv" > "$OUT/pmc${i}_summary.txt" 2>&1
     rm -rf "$OUT/pmc$i"
