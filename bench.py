@@ -495,7 +495,8 @@ def main():
                 "storage": args.dtype,
             },
             "site_updates_per_sec": site_updates,
-            "counters_per_step": {k_: v / K / E for k_, v in cnt.items()},
+            # batched calls per step and engine (every engine makes the same calls); svd_matrices counts trajectories: whole GPU
+            "counters_per_step": {k_: v / K / (1 if k_ == "svd_matrices" else E) for k_, v in cnt.items()},
             "mean_Z_site0": float(zsum[0] / total_traj),
             # Dominant kernel class: the SVD family (Jacobi + QR kernels; fp64 VALU-issue-bound, not HBM-bound).  Unit of a "launch" =
             # one batched SVD (a two-site split or an SVD centre shift of every resident trajectory); algorithmic work = SURVEY 8d's

@@ -51,11 +51,10 @@ class Engine {
   void profile_enable(bool on);
   int profile_read(double* ms /*[PROF_NCLASS]*/, long* regions /*[PROF_NCLASS]*/);
   struct Region {
-    Engine& e; int idx; int token;
+    Engine& e; int idx;
     Region(Engine& eng, int cls);
     ~Region();
   };
-  int phase_depth_ = 0;
 
   ~Engine();  // pinned host words and HIP events (the device workspace belongs to the caller)
   int create(int L, int d, int chi_max, int B, const int* mpo_bond, int cap_slack = 1);

@@ -74,16 +74,6 @@ void small_expm(const cplx* in, int n, cplx* out) {
 }
 }  // namespace
 
-// ---- phase tokens between engines that share a GPU (TJM_PHASE_LOCKS=1, default off) ---------------------------------------------
-// The SVD family is fp64-VALU-bound, the Krylov / environment contractions are fp64-MFMA-bound, and the two pipes of a CU run side
-// by side.  With several engines on one GPU (bench.py --engines E: one host thread and one HIP stream each) one token per pipe keeps
-// at most one engine in each class at a time, so the engines fall into anti-phase - one factorises while another contracts - instead
-// of queueing the same kind of kernel behind each other.
-namespace {
-std::mutex g_phase_mutex[2];
-const bool g_phase_locks = getenv("TJM_PHASE_LOCKS") != nullptr;
-}  // namespace
-
 // ---- live class timing -------------------------------------------------------------------------------------------------
 void Engine::profile_enable(bool on) {
   prof_collect();
@@ -110,11 +100,7 @@ int Engine::profile_read(double* ms, long* regions) {
   return TJM_OK;
 }
 
-Engine::Region::Region(Engine& eng, int cls) : e(eng), idx(-1), token(-1) {
-  if (g_phase_locks && e.phase_depth_++ == 0) {
-    token = (cls == PROF_SVD) ? 0 : 1;
-    g_phase_mutex[token].lock();
-  }
+Engine::Region::Region(Engine& eng, int cls) : e(eng), idx(-1) {
   if (!e.prof_.on || e.prof_.depth++ > 0) return;  // nested regions count for the outer class
   if (e.prof_.used >= 8192) e.prof_collect();
   idx = (int)e.prof_.used++;
@@ -132,13 +118,6 @@ Engine::Region::~Region() {
   if (e.prof_.on) {
     --e.prof_.depth;
     if (idx >= 0) (void)hipEventRecord(e.prof_.pool[2 * idx + 1], e.stream);
-  }
-  if (g_phase_locks) {
-    --e.phase_depth_;
-    if (token >= 0) {
-      (void)hipStreamSynchronize(e.stream);  // the token covers the device work of the region, not only its launches
-      g_phase_mutex[token].unlock();
-    }
   }
 }
 
