@@ -835,3 +835,40 @@ def test_dynamic_tdvp_cuts_an_oversized_qr_bond_back_to_the_cap():
         v = vec_of(out)
         assert abs(abs(np.vdot(want, v)) - np.vdot(want, want).real) < 1e-9
     e.close()
+
+
+@pytest.mark.gpu
+def test_a_circuit_whose_bonds_reach_512_grows_the_storage_and_matches_the_oracle():
+    """Simulator.run_circuit up to max_bond_dim = 512 (the size BASELINE config 5 names): a 20-site chain starts from a Haar-random
+    state with bonds of 128, two layers of Haar-random two-qubit gates double the centre bonds twice - 128 -> 256 -> 512, where the
+    cap binds - so the run climbs the capacity ladder 128 -> 192 -> 256 -> 384 -> 512 with its state carried over on the device
+    (TrajectoryBatch / DigitalBatch rollback and tjm_engine_adopt_state), splits 1024 x 1024 matrices at the centre, and ends with
+    the oracle's <Z_i> (1e-8) and the oracle's bond dimensions.  The oracle side is 38 dense SVDs of up to 1024 x 1024 on one host
+    core (about a minute, < 1 GB)."""
+    from conftest import host_bytes_budget
+    from yaqs_amd.api import DigitalSimParams, GateLayer, MPS, Observable, Z as Zg
+    from yaqs_amd.tjm import Simulator
+
+    L, cap = 20, 512
+    host_bytes_budget(40 * 1024 * 1024 * 16 * 4, "the oracle's dense SVDs at chi = 512")
+    rng = np.random.default_rng(2025)
+    st0 = o.MPSState.haar(L, 128, rng)
+    st0.normalize("B")
+
+    def haar4():
+        q, r = np.linalg.qr(rng.standard_normal((4, 4)) + 1j * rng.standard_normal((4, 4)))
+        return (q * (np.diag(r) / np.abs(np.diag(r)))).reshape(2, 2, 2, 2)
+
+    layers = []
+    for _ in range(2):
+        layers.append(GateLayer([], [(q, haar4()) for q in range(0, L - 1, 2)], [(q, haar4()) for q in range(1, L - 1, 2)], 0))
+    obs = [Observable(Zg(), s) for s in range(L)]
+    p = DigitalSimParams(observables=obs, max_bond_dim=cap, svd_threshold=1e-10, random_seed=3, num_traj=1)
+    res = Simulator().run(MPS(L, tensors=[t.copy() for t in st0.tensors]), layers, p, None)
+    olayers = [o.GateLayer(l.singles, l.even, l.odd, l.sample_points) for l in layers]
+    op = o.DigitalParams(observables=[o.Obs(Z, s) for s in range(L)], max_bond_dim=cap, svd_threshold=1e-10, random_seed=3)
+    want, diag, _ = o.digital_tjm(0, o.MPSState([t.copy() for t in st0.tensors], 0), None, op, olayers)
+    assert res.max_bond is not None and int(np.max(res.max_bond)) == cap  # the cap binds at the centre
+    for s_ in range(L):
+        assert np.allclose(res.trajectories[s_][0], want[s_], atol=1e-8), s_
+    assert np.array_equal(np.asarray(res.max_bond).ravel()[-1:], np.asarray(diag[1]).ravel()[-1:])
