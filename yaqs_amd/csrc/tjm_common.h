@@ -142,4 +142,22 @@ struct GemmDesc {
 
 int launch_gemm(const GemmDesc& g, hipStream_t stream);
 
+// First two stages of an H_eff apply in one kernel (tjm_gemm.hip: heff_stage12_kernel): the product with the right environment over
+// its non-identity channels and, as the epilogue of the same tile, the MPO stage - the intermediate T1 never leaves the chip.
+//   T1[p][a][c][B] = sum_b x[p][a][b] R[b][chan(c)][B]          c over the Dr - 1 channels other than rch (R[:, rch, :] = 1)
+//   out[o][a][l][B] = sum_{p,r} W[(o,l),(p,r)] in[p][a][r][B]    in[.., rch, ..] = x, the others T1;  l = lch goes to y, the rest to T2
+struct HeffStage12Desc {
+  const cplx* x;  long x_b0;      // [P][ca][cb]
+  const cplx* R;  long r_b0;      // [cb][Dr][cb]
+  const cplx* Wm;                 // [(o,l)][(p,r)] row-major, (P Dl) x (P Dr)
+  cplx* T2;       long t_b0;      // [P][ca][Dl][cb]
+  cplx* y;        long y_b0;      // [P][ca][cb]
+  int P, ca, cb, Dl, Dr, rch, lch;
+  int nb0;
+  const int* ids;
+  const int* active;
+};
+bool heff_stage12_fits(int P, int ca, int cb, int Dl, int Dr, int rch);
+int launch_heff_stage12(const HeffStage12Desc& d, hipStream_t stream);
+
 }  // namespace tjm

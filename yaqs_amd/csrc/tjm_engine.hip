@@ -486,7 +486,14 @@ int Engine::merge_matrix_layout(StateSet& S, int i, const int* ids, int nb0) {
 int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv,
                        long r_b0, int Dr, const cplx* Wm, cplx* y, long y_b0, int nb0, const int* ids, const int* active, int lch, int rch) {
   int rc;
-  {  // T1[(p,a),(r,B)] = x[(p,a),b] R[b,(r,B)]
+  const bool fused12 = heff_stage12_fits(P, ca, cb, Dl, Dr, rch);
+  if (fused12) {  // stages 1 and 2 in one kernel: T1 stays in the accumulators of the GEMM tile (tjm_gemm.hip)
+    HeffStage12Desc q;
+    q.x = x; q.x_b0 = x_b0; q.R = Renv; q.r_b0 = r_b0; q.Wm = Wm; q.T2 = T2; q.t_b0 = t_b0; q.y = y; q.y_b0 = y_b0;
+    q.P = P; q.ca = ca; q.cb = cb; q.Dl = Dl; q.Dr = Dr; q.rch = rch; q.lch = lch; q.nb0 = nb0; q.ids = ids; q.active = active;
+    if ((rc = launch_heff_stage12(q, stream)) != TJM_OK) return rc;
+  }
+  if (!fused12) {  // T1[(p,a),(r,B)] = x[(p,a),b] R[b,(r,B)]
     GemmDesc g = blank_gemm();
     g.A = x; g.B = Renv; g.C = T1;
     g.M = P * ca; g.K = cb; g.N = Dr * cb;
@@ -499,7 +506,7 @@ int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cp
     }
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
-  {  // T2[o][a][l][B] = sum_{p,r} W[(o,l),(p,r)] T1[p][a][r][B]
+  if (!fused12) {  // T2[o][a][l][B] = sum_{p,r} W[(o,l),(p,r)] T1[p][a][r][B]
     MpoApplyDesc m;
     m.in = T1; m.out = T2; m.Wm = Wm; m.P = P; m.din = Dr; m.dout = Dl; m.na = ca; m.nB = cb;
     m.in_sp = (long)ca * Dr * cb; m.in_sb = cb; m.in_sa = (long)Dr * cb;

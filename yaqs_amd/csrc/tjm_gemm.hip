@@ -172,6 +172,196 @@ __global__ __launch_bounds__(256, 3) void zgemm_kernel(GemmDesc g) {
       }
 }
 
+// Row order of a wavefront's 16 rows in heff_stage12_kernel: chosen per arithmetic type so that the four accumulator registers of a
+// lane hold every physical index p of its bond value(s) (TJM_ACC_ROW: fp64 register v = row (l >> 4) + 4 v, fp32 = row 4 (l >> 4) + v).
+#ifdef TJM_F32
+template <int P> __device__ constexpr int s12_row_p(int rr) { return rr % P; }        // a-major rows: rr = a_loc * P + p
+template <int P> __device__ constexpr int s12_row_a(int rr) { return rr / P; }
+template <int P> __device__ constexpr int s12_reg(int pi, int ai) { return (P == 4) ? pi : (2 * ai + pi); }
+template <int P> __device__ inline int s12_aloc(int lk, int ai) { return (P == 4) ? lk : (2 * lk + ai); }
+#else
+template <int P> __device__ constexpr int s12_row_p(int rr) { return rr / (16 / P); }  // p-major rows: rr = p * (16 / P) + a_loc
+template <int P> __device__ constexpr int s12_row_a(int rr) { return rr % (16 / P); }
+template <int P> __device__ constexpr int s12_reg(int pi, int ai) { return (P == 4) ? pi : (2 * pi + ai); }
+template <int P> __device__ inline int s12_aloc(int lk, int ai) { return (P == 4) ? lk : (lk + 4 * ai); }
+#endif
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// H_eff apply, stages 1 + 2 fused (HeffStage12Desc, tjm_common.h).  Same LDS staging and MFMA schedule as zgemm_kernel, but the
+// block tile is laid out so that every lane ends up with ALL inputs of the MPO stage for its points in its own accumulators:
+//   rows  (64): wavefront w owns 16 rows = P physical indices x (16 / P) bond values, p-major -> accumulator register v of lane l is
+//               row (l >> 4) + 4 v = (p = v, a = l >> 4) for P = 4, (p = v / 2, a = (l >> 4) + 4 (v & 1)) for P = 2;
+//   cols  (64): the NCH = Dr - 1 non-identity channels x (64 / NCH) bond values, channel-major -> MFMA column tile j is channel
+//               j / (4 / NCH), and lane l holds column l & 15 of it.
+// Every wavefront multiplies its 16 rows into all four column tiles (16 MFMAs per k-step, as the 2 x 2 arrangement).  The epilogue
+// is mpo_apply_kernel's arithmetic on registers: 144 complex multiply-adds per point at P = 4, D = 3, with W staged in LDS; the
+// identity input channel comes straight from x, the identity output channel goes straight into y.  The 2 + 2 MB per trajectory
+// that T1 cost on its way through HBM (and the launch of the MPO stage) are gone.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int P, int NCH>
+__global__ __launch_bounds__(256, 3) void heff_stage12_kernel(HeffStage12Desc d) {
+  __shared__ real sAr[BK * PITCH];
+  __shared__ real sAi[BK * PITCH];
+  __shared__ real sBr[BK * PITCH];
+  __shared__ real sBi[BK * PITCH];
+  __shared__ cplx sW[4 * 6 * 4 * 6];  // (P Dl) x (P Dr) <= 24 x 24
+  __shared__ unsigned sMask[4 * 6];   // per row of W: bit k set when entry k is non-zero (MPOs of local Hamiltonians are mostly zeros)
+  constexpr int AT = 64 / P;     // bond values of the row tile
+  constexpr int APW = 16 / P;    // ... per wavefront
+  constexpr int BT = 64 / NCH;   // bond values of the column tile
+  constexpr int CPT = 4 / NCH;   // MFMA column tiles per channel
+  int b0 = blockIdx.y;
+  if (d.ids) b0 = d.ids[b0];
+  if (d.active && d.active[b0] == 0) return;
+  const int ca = d.ca, cb = d.cb, Dl = d.Dl, Dr = d.Dr, rch = d.rch;
+  const int tiles_b = (cb + BT - 1) / BT;
+  const int a0 = (blockIdx.x / tiles_b) * AT, B0 = (blockIdx.x % tiles_b) * BT;
+  const cplx* __restrict__ xb = d.x + (long)b0 * d.x_b0;
+  const cplx* __restrict__ Rb = d.R + (long)b0 * d.r_b0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int ch_shift = (rch == 0) ? 1 : 0;  // channel c of the tile is channel c + ch_shift of R (rch is the first or the last one)
+  for (int t = tid; t < P * Dl * P * Dr; t += 256) sW[t] = d.Wm[t];
+
+  // staging coordinates: A (x) is k-contiguous, B (R) is n-contiguous
+  int am[4], ak[4], bk[4], bn[4];
+  long arow[4], bcol[4];
+  bool aok[4], bok[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int idx = tid + e * 256;
+    ak[e] = idx & 15; am[e] = idx >> 4;
+    bn[e] = idx & 63; bk[e] = idx >> 6;
+    const int w = am[e] >> 4, rr = am[e] & 15;
+    const int p = s12_row_p<P>(rr), a = a0 + w * APW + s12_row_a<P>(rr);
+    aok[e] = a < ca;
+    arow[e] = ((long)p * ca + a) * cb;
+    const int c = bn[e] / BT, Bc = B0 + bn[e] % BT;
+    bok[e] = Bc < cb;
+    bcol[e] = (long)(c + ch_shift) * cb + Bc;
+  }
+  real4 accRe[4], accIm[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { accRe[j] = real4{0, 0, 0, 0}; accIm[j] = real4{0, 0, 0, 0}; }
+  const int ktiles = (cb + BK - 1) / BK;
+  cplx ra[4], rb[4];
+  auto load_tile = [&](int it) {
+    const int k0 = it * BK;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + ak[e];
+      ra[e] = (aok[e] && k < cb) ? xb[arow[e] + k] : cplx{0.0, 0.0};
+      const int kk = k0 + bk[e];
+      rb[e] = (bok[e] && kk < cb) ? Rb[(long)kk * Dr * cb + bcol[e]] : cplx{0.0, 0.0};
+    }
+  };
+  auto swz = [](int k) { return 4 * ((k >> 1) & 3); };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int caL = am[e] ^ swz(ak[e]);
+      sAr[ak[e] * PITCH + caL] = ra[e].x;
+      sAi[ak[e] * PITCH + caL] = ra[e].y;
+      sBr[bk[e] * PITCH + bn[e]] = rb[e].x;
+      sBi[bk[e] * PITCH + bn[e]] = rb[e].y;
+    }
+  };
+  load_tile(0);
+  for (int it = 0; it < ktiles; ++it) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (it + 1 < ktiles) load_tile(it + 1);
+#pragma unroll
+    for (int s = 0; s < BK / 4; ++s) {
+      const int krow = (4 * s + lk) * PITCH;
+      const int la = li ^ swz(4 * s + lk);
+      const real ar = sAr[krow + 16 * wave + la], ai = sAi[krow + 16 * wave + la];
+      real br[4], bi[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { br[j] = sBr[krow + 16 * j + li]; bi[j] = sBi[krow + 16 * j + li]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accRe[j] = TJM_MFMA(ar, br[j], accRe[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accIm[j] = TJM_MFMA(ar, bi[j], accIm[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accRe[j] = TJM_MFMA(-ai, bi[j], accRe[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accIm[j] = TJM_MFMA(ai, br[j], accIm[j]);
+    }
+  }
+  // ---- epilogue: the MPO stage on this lane's points.  One row of W (P Dr entries, broadcast reads from LDS) per output (po, bo),
+  // used for all points of the lane; the zero entries of the row (83 % of them for a nearest-neighbour Pauli Hamiltonian) are
+  // skipped by scalar branches on the row's bit mask.
+  if (tid < P * Dl) {
+    unsigned m = 0;
+    for (int k = 0; k < P * Dr; ++k) {
+      const cplx wv = sW[tid * (P * Dr) + k];
+      if (wv.x != 0.0 || wv.y != 0.0) m |= 1u << k;
+    }
+    sMask[tid] = m;
+  }
+  __syncthreads();
+  cplx* __restrict__ T2b = d.T2 + (long)b0 * d.t_b0;
+  cplx* __restrict__ yb = d.y + (long)b0 * d.y_b0;
+  const int nin = P * Dr;
+  constexpr int NA = 4 / P;          // bond values of this lane: one for P = 4, two for P = 2
+  constexpr int NPT = NA * CPT;      // points of this lane
+  cplx xin[NPT][P];
+  bool ok[NPT];
+  long base[NPT];                    // ((0 * ca + a) * cb + Bc): offset of the point in a [P][ca][cb] tensor
+#pragma unroll
+  for (int ai_ = 0; ai_ < NA; ++ai_)
+#pragma unroll
+    for (int jj = 0; jj < CPT; ++jj) {
+      const int pt = ai_ * CPT + jj;
+      const int a = a0 + wave * APW + s12_aloc<P>(lk, ai_), Bc = B0 + 16 * jj + li;
+      ok[pt] = a < ca && Bc < cb;
+      base[pt] = (long)a * cb + Bc;
+#pragma unroll
+      for (int pi = 0; pi < P; ++pi) xin[pt][pi] = ok[pt] ? xb[(long)pi * ca * cb + base[pt]] : cplx{0.0, 0.0};
+    }
+  for (int bo = 0; bo < Dl; ++bo) {
+#pragma unroll
+    for (int po = 0; po < P; ++po) {
+      const cplx* wrow = sW + (po * Dl + bo) * nin;
+      const unsigned mask = __builtin_amdgcn_readfirstlane(sMask[po * Dl + bo]);
+      cplx out[NPT];
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) out[pt] = cplx{0.0, 0.0};
+#pragma unroll
+      for (int pi = 0; pi < P; ++pi) {
+        if (mask & (1u << (pi * Dr + rch))) {
+          const cplx wx = wrow[pi * Dr + rch];
+#pragma unroll
+          for (int pt = 0; pt < NPT; ++pt) cfma(out[pt], wx, xin[pt][pi]);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (!(mask & (1u << (pi * Dr + c + ch_shift)))) continue;
+          const cplx wc = wrow[pi * Dr + c + ch_shift];
+#pragma unroll
+          for (int ai_ = 0; ai_ < NA; ++ai_)
+#pragma unroll
+            for (int jj = 0; jj < CPT; ++jj) {
+              const int v = s12_reg<P>(pi, ai_);
+              cplx t1;
+              t1.x = accRe[c * CPT + jj][v];
+              t1.y = accIm[c * CPT + jj][v];
+              cfma(out[ai_ * CPT + jj], wc, t1);
+            }
+        }
+      }
+#pragma unroll
+      for (int pt = 0; pt < NPT; ++pt) {
+        if (!ok[pt]) continue;
+        if (bo == d.lch) yb[(long)po * ca * cb + base[pt]] = out[pt];
+        else T2b[((long)po * ca * Dl + bo) * cb + (base[pt] / cb) * (long)Dl * cb + base[pt] % cb] = out[pt];
+      }
+    }
+  }
+}
+
 // Small bonds (chi <= 8, or the narrow products of the centre shifts): a 64 x 64 block tile would be mostly padding and
 // spend its time on barriers.  Here every wavefront owns one 16 x 16 output tile of one batch entry and feeds the MFMA
 // straight from global memory - the operands of such a product are a few KiB and stay in L2 - with the next k-group's loads
@@ -261,6 +451,32 @@ int launch_gemm(const GemmDesc& g, hipStream_t stream) {
   else if (am && !bn) hipLaunchKernelGGL((zgemm_kernel<true, false>), grid, block, 0, stream, g);
   else if (!am && bn) hipLaunchKernelGGL((zgemm_kernel<false, true>), grid, block, 0, stream, g);
   else hipLaunchKernelGGL((zgemm_kernel<false, false>), grid, block, 0, stream, g);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+bool heff_stage12_fits(int P, int ca, int cb, int Dl, int Dr, int rch) {
+  static const bool off = getenv("TJM_NO_FUSED_MPO") != nullptr;
+  if (off || rch < 0 || (rch != 0 && rch != Dr - 1)) return false;
+  const int nch = Dr - 1;
+  if (P != 2 && P != 4) return false;
+  if (nch != 1 && nch != 2 && nch != 4) return false;
+  if (Dl > 6 || Dr > 6 || ca < 16 || cb < 16) return false;
+  return true;
+}
+
+int launch_heff_stage12(const HeffStage12Desc& d, hipStream_t stream) {
+  if (d.nb0 <= 0) return TJM_OK;
+  const int nch = d.Dr - 1;
+  const int AT = 64 / d.P, BT = 64 / nch;
+  dim3 grid(((d.ca + AT - 1) / AT) * ((d.cb + BT - 1) / BT), d.nb0);
+#define TJM_S12(PP, NN) hipLaunchKernelGGL((heff_stage12_kernel<PP, NN>), grid, dim3(256), 0, stream, d)
+  if (d.P == 4) {
+    if (nch == 1) TJM_S12(4, 1); else if (nch == 2) TJM_S12(4, 2); else TJM_S12(4, 4);
+  } else {
+    if (nch == 1) TJM_S12(2, 1); else if (nch == 2) TJM_S12(2, 2); else TJM_S12(2, 4);
+  }
+#undef TJM_S12
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
