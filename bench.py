@@ -279,6 +279,10 @@ def main():
     ap.add_argument("--dt", type=float, default=0.1)
     ap.add_argument("--dtype", choices=["complex128", "complex64"], default="complex128",
                     help="complex128 is the reference's arithmetic and the headline; complex64 runs libtjm_hip_f32.so (fp32 arithmetic and storage)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI, one GPU per rank (the measurement).  gloo: the ranks share the GPUs that exist "
+                         "(device = LOCAL_RANK mod device count) and reduce on the host - a functional check of the N > 1 path on a "
+                         "box with fewer GPUs than ranks, not a scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, nargs="*", default=[32], help="worker counts of the full-step CPU rows besides P = 1")
     args = ap.parse_args()
@@ -311,13 +315,20 @@ def main():
     from yaqs_amd.engine import BatchEngine
     from yaqs_amd.tjm import trajectory_uniforms
 
+    gloo = args.dist_backend == "gloo"
+    if gloo:
+        local = local % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        if gloo:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
         world = dist.get_world_size()  # n_gpus below is what RCCL saw
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
+    red_device = "cpu" if gloo else device  # where the collectives run
 
     scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
     if args.batch is not None:
@@ -406,13 +417,13 @@ def main():
     run_all(K, True)
     zsum = sum(d.zsum for d in drives)
     if world > 1:
-        tz = torch.from_numpy(zsum).to(device)
+        tz = torch.from_numpy(zsum).to(red_device)
         dist.all_reduce(tz, op=dist.ReduceOp.SUM)  # the only collective of the path (RCCL over xGMI)
         zsum = tz.cpu().numpy()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     stats1 = [e.stats() for e in engines]
@@ -491,7 +502,7 @@ def main():
                 "trajectories_in_flight_per_gpu": B,
                 "engines_per_gpu": E,
                 "steps_per_trajectory": STEPS_PER_TRAJ,
-                "parallelism": f"trajectory-sharded x{world}",
+                "parallelism": f"trajectory-sharded x{world}" + (" (gloo: ranks share the visible GPUs - functional check, not a scaling number)" if gloo and world > 1 else ""),
                 "storage": args.dtype,
             },
             "site_updates_per_sec": site_updates,

@@ -146,3 +146,26 @@ def test_bench_launcher_does_not_hang_when_a_rank_dies(tmp_path):
     rc = bench.launch_ranks(3, ["die"], script=str(script))
     assert rc == 7                      # the failing rank's code is the launcher's
     assert time.time() - t0 < 30.0      # and the sleeping ranks were stopped, not waited for
+
+
+@pytest.mark.gpu
+def test_bench_with_two_ranks_on_one_gpu_reproduces_the_single_rank_ensemble():
+    """`bench.py --gpus 2 --dist-backend gloo`: the launcher, the contiguous sharding, the all-reduce of the observable sums and the
+    max-over-ranks timing end to end on a box with ONE GPU (the ranks share it; a functional check, not a scaling number).  The
+    ensemble mean must be the single-rank one bit for bit: trajectories are pure functions of (seed, index)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = [sys.executable, os.path.join(root, "bench.py"), "--length", "8", "--chi", "8", "--trajectories", "8", "--steps", "2", "--warmup", "1",
+              "--no-cpu-baseline", "--engines", "2"]
+    two = subprocess.run(common + ["--gpus", "2", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    one = subprocess.run(common, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    b = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert a["n_gpus"] == 2 and a["scaling"] == "strong" and a["config"]["trajectories"] == 8 and a["config"]["trajectories_in_flight_per_gpu"] == 4
+    assert b["n_gpus"] == 1
+    assert a["mean_Z_site0"] == b["mean_Z_site0"]
