@@ -168,6 +168,8 @@ inline int hipsim_readlane(int v, int lane) {
   return (int)(unsigned)x[lane & 63][0];
 }
 #define __builtin_amdgcn_readlane(v, lane) hipsim_readlane(v, lane)
+// v_readfirstlane_b32: the value of the first lane (all 64 lanes are active wherever the kernels use it)
+#define __builtin_amdgcn_readfirstlane(v) hipsim_readlane((int)(v), 0)
 
 // v_mov_b32 with a DPP control (row_mask = bank_mask = 0xF): quad_perm, row_shl / row_shr / row_ror, row_mirror, row_half_mirror.
 // Lanes whose source falls outside the row read `old` (bound_ctrl: 0).

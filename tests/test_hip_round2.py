@@ -872,3 +872,29 @@ def test_a_circuit_whose_bonds_reach_512_grows_the_storage_and_matches_the_oracl
     for s_ in range(L):
         assert np.allclose(res.trajectories[s_][0], want[s_], atol=1e-8), s_
     assert np.array_equal(np.asarray(res.max_bond).ravel()[-1:], np.asarray(diag[1]).ravel()[-1:])
+
+
+@pytest.mark.gpu
+def test_concurrent_engines_give_the_results_of_one_engine():
+    """Simulator(engines=E): the resident trajectories split over E engines with a host thread and a HIP stream each (the default is
+    4).  A trajectory is a pure function of (seed, index): rows, diagnostics and the measurement histogram of a noisy analog run
+    whose storage grows on the way (bonds 1 -> 16) and of a circuit run with shots are those of a single engine, bit for bit."""
+    from yaqs_amd.api import AnalogSimParams, DigitalSimParams, MPO, MPS, NoiseModel, Observable, X as Xg, Z as Zg, ising_trotter_layers
+    from yaqs_amd.tjm import Simulator
+
+    L = 10
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
+    obs = [Observable(Zg(), s) for s in range(L)] + [Observable(Xg(), 4)]
+    p = AnalogSimParams(observables=obs, elapsed_time=0.6, dt=0.1, num_traj=23, max_bond_dim=16, svd_threshold=1e-10, krylov_tol=1e-10,
+                        sample_timesteps=True, random_seed=5)
+    dp = DigitalSimParams(observables=obs, num_traj=11, shots=44, max_bond_dim=16, svd_threshold=1e-10, random_seed=5)
+    layers = ising_trotter_layers(L, 1.0, 0.5, 0.1, 4)
+    ref = Simulator(engines=1).run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p, noise)
+    cref = Simulator(engines=1).run_circuit(MPS(L, state="zeros"), layers, dp, noise)
+    for E in (3, 4):
+        res = Simulator(engines=E).run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p, noise)
+        assert np.array_equal(np.stack(res.trajectories), np.stack(ref.trajectories)), E
+        assert np.array_equal(res.max_bond, ref.max_bond) and np.array_equal(res.total_bond, ref.total_bond), E
+        cres = Simulator(engines=E).run_circuit(MPS(L, state="zeros"), layers, dp, noise)
+        assert np.array_equal(np.stack(cres.trajectories), np.stack(cref.trajectories)), E
+        assert cres.counts == cref.counts, E
