@@ -141,7 +141,8 @@ int tjm_engine_sample_shots(tjm_engine* e, int32_t set, int32_t shots, const dou
 int tjm_engine_stats(const tjm_engine* e, int64_t* out5);
 /* the same five counters followed by: two-site H_eff applies (a subset of matvecs), environment updates, centre shifts served by
  * the certified QR path (reserved: always 0), matrices factorised (batched SVD calls x trajectories in the call), Krylov calls whose
- * environments were examined for identity channels, channels certified (at most two per call); writes min(n, 11) values */
+ * environments were examined for identity channels, channels certified (at most two per call), trajectory-steps whose scalar dissipation sweep was certified away, jumps applied in
+ * place on certified states; writes min(n, 13) values */
 int tjm_engine_stats_ex(const tjm_engine* e, int64_t* out, int32_t n);
 /* Live device time per kernel class of a step, bracketed with HIP events on the engine's stream (the source of bench.py's
  * roofline object): class 0 = SVD family (split_two_site and the SVD centre shifts: QR, Jacobi, truncation, their GEMMs),

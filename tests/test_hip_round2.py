@@ -898,3 +898,38 @@ def test_concurrent_engines_give_the_results_of_one_engine():
         cres = Simulator(engines=E).run_circuit(MPS(L, state="zeros"), layers, dp, noise)
         assert np.array_equal(np.stack(cres.trajectories), np.stack(cref.trajectories)), E
         assert cres.counts == cref.counts, E
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("native", [False, True])
+def test_certified_scalar_dissipation_and_in_place_jumps_match_the_oracle(native):
+    """Pauli-only noise at bonds above the fused kernels (chi = 32) with the default-preset threshold 1e-6: no bond comes near the
+    shifts' own 1e-12 rule, so the dissipation sweep certifies as a gauge move (one virtual right-going pass, then a scaling) and
+    unitary jumps are applied in place - no QR walk, no SVD sweep back.  The oracle does all of it the long way: per-trajectory
+    <Z_i> at every time (1e-8), bond diagnostics and jump probabilities must agree, and the engine must really have taken the
+    certified paths."""
+    from yaqs_amd.api import AnalogSimParams, MPS, NoiseModel, Observable, Z as Zg
+    from yaqs_amd.tjm import TrajectoryBatch
+
+    L, chi = 12, 32
+    rng = np.random.default_rng(99)
+    st = o.MPSState.haar(L, chi, rng)
+    st.normalize("B")
+    init = [t.copy() for t in st.tensors]
+    names = ("pauli_z", "pauli_x")
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.15} for i in range(L) for n in names])
+    on = [o.make_process(n, [i], 0.15) for i in range(L) for n in names]
+    kw = dict(elapsed_time=0.4, dt=0.1, max_bond_dim=chi, svd_threshold=1e-6, krylov_tol=1e-10, order=1, sample_timesteps=True, random_seed=21)
+    p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=6, **kw)
+    mpo = o.ising_mpo(L, 1.0, 0.5)
+    e = make_engine(L, chi, 6, mpo)
+    tb = TrajectoryBatch(e, p, noise)
+    r, d = tb.run(list(range(6)), MPS(L, tensors=init), native=native)
+    stats = e.stats()
+    e.close()
+    assert stats["certified_dissipations"] > 0 and stats["certified_jumps"] > 0, stats
+    op = o.Params(observables=[o.Obs(Z, s) for s in range(L)], **kw)
+    for t in range(6):
+        ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, mpo)
+        assert np.allclose(r[t], ro, atol=1e-8), (t, np.abs(r[t] - ro).max())
+        assert np.array_equal(d[t], do), t

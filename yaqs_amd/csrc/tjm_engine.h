@@ -96,6 +96,7 @@ class Engine {
                  long r_b0, int Dr, const cplx* Wm, cplx* y, long y_b0, int nb0, const int* ids, const int* active, int lch = -1, int rch = -1);
   int identity_channels(int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0, int Dr, int nb0, const int* ids,
                         const int* chi_l, const int* chi_r, int* lch, int* rch);
+  long stat_cert_traj = 0, stat_cert_jumps = 0;  // trajectory-steps whose scalar dissipation sweep was certified away / jumps applied in place
   long stat_ident_calls = 0, stat_ident_hits = 0;  // Krylov calls examined / channels certified (of two per call)
 
   struct Prof {
@@ -214,6 +215,17 @@ class Engine {
   int svd_shift_right(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left_2site(StateSet& S, int i, const int* ids, int nb0);
+  // Certified scalar dissipation (tjm_engine.hip: dissipate): the right-going SVD pass on scratch copies of the centre tensor
+  int svd_shift_right_virtual(StateSet& S, int i, const cplx* Cin, long cin_b0, cplx* Cout, long cout_b0);
+  int state_checksum(int set, const int* ids, int n, unsigned long long* host_out);
+  int* vchi_ = nullptr;                  // [B][L+1] bond dimensions the virtual pass would leave
+  real* cert_min_ = nullptr;             // [B] smallest squared singular value met by the virtual pass
+  int* cert_flag_ = nullptr;             // [B] the virtual pass would have truncated a bond
+  unsigned long long* csum_ = nullptr;   // [B] checksum scratch
+  std::vector<char> cert_ok_;            // per trajectory: the state is what a certified dissipation left (valid while cert_set_ >= 0)
+  std::vector<unsigned long long> cert_sum_;
+  int cert_set_ = -1;
+  int cert_skip_ = 0;                    // calls of dissipate that skip the virtual pass after one that mostly failed to certify
   int copy_back(cplx* dst, long dst_b0, const cplx* src, long src_b0, long n, const int* ids, int nb0);
   std::vector<int> unitary_jump_;
 };

@@ -177,6 +177,7 @@ size_t Engine::workspace_bytes() const {
   tot += align_up((size_t)(L + 64) * MSLOT * sizeof(cplx));
   tot += 2 * align_up((size_t)(d * d * Dmax) * (d * d * Dmax) * sizeof(cplx));  // MPO matrices of the kernel-level exports
   tot += align_up((size_t)4 * L * sizeof(SmallSiteRef)) + 4 * 256 + align_up((size_t)(4 * L + 8) * sizeof(SmallSweepStep));  // fused sweeps
+  tot += align_up((size_t)B * (L + 1) * sizeof(int)) + 3 * align_up((size_t)B * sizeof(double));  // certified dissipation: virtual bond table, minima, flags, checksums
   tot += 1 << 16;
   return tot;
 }
@@ -250,6 +251,13 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   ops_ = reinterpret_cast<cplx*>(take((size_t)(L + 64) * MSLOT * sizeof(cplx)));
   Wx_[0] = reinterpret_cast<cplx*>(take(wsz));
   Wx_[1] = reinterpret_cast<cplx*>(take(wsz));
+  vchi_ = reinterpret_cast<int*>(take((size_t)B * (L + 1) * sizeof(int)));
+  cert_min_ = reinterpret_cast<real*>(take((size_t)B * sizeof(double)));
+  cert_flag_ = reinterpret_cast<int*>(take((size_t)B * sizeof(double)));
+  csum_ = reinterpret_cast<unsigned long long*>(take((size_t)B * sizeof(double)));
+  cert_ok_.assign(B, 0);
+  cert_sum_.assign(B, 0);
+  cert_set_ = -1;
   if ((size_t)(p - static_cast<char*>(ws)) > bytes) return TJM_ERR_WORKSPACE;
   if (!h_pinned_) TJM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h_pinned_), 256, hipHostMallocDefault));
   svdw.h_pinned = h_pinned_;
@@ -1000,6 +1008,7 @@ int Engine::sweep_1site(StateSet& S, double scale) {
 }
 
 int Engine::tdvp(int set) {
+  cert_set_ = -1;
   if (!bound_) return TJM_ERR_STATE;
   if (tdvp_mode != 2 && tdvp_mode != 1) return TJM_ERR_NOT_IMPLEMENTED;
   StateSet& S = sets[set];
@@ -1129,6 +1138,110 @@ int Engine::svd_shift_left(StateSet& S, int i, const int* ids, int nb0) {
   g.ids = ids;
   if ((rc = gemm(g)) != TJM_OK) return rc;
   return copy_back(S.A[i - 1], a_b0_[i - 1], T1, t_b0, a_b0_[i - 1], ids, nb0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Certified scalar dissipation.  With Pauli-only noise every local factor of apply_dissipation is a scalar (dissipation.py:117-119,
+// 141, 156-157) and the sweep - centre to the last site and back by 2 (L - 1) truncating SVD shifts (mps.py:747-788, discarded weight
+// 1e-12) - changes the state only where a shift truncates.  The right-going pass is run on scratch copies of the centre tensor
+// (svd_shift_right_virtual: the state itself is not touched) and records, per trajectory, whether any bond would lose a singular
+// value and the smallest squared singular value it met.  When nothing is truncated and that minimum times the total scalar factor
+// is still above the threshold, neither pass of the reference's sweep truncates: both are gauge moves, the state the reference ends
+// with is the input times the scalar, and this build leaves it at that (one scaling kernel instead of 63 more shifts).  Trajectories
+// that do not certify take the sweep as before.  stochastic() uses the same certificate: a unitary jump on a certified state needs
+// neither the QR walk to the last site nor the SVD sweep back (normalize("B", "SVD"), mps.py:815-839) - they, too, only move the gauge.
+// The certificate travels with a checksum of the state (64-bit sum over all site tensors), so that any change between the two calls
+// voids it.
+// ------------------------------------------------------------------------------------------
+__global__ void cert_update_kernel(const real* __restrict__ norms, int ncols_pad, const int* vchi_col, const int* chi_col, int stride, real* cert_min,
+                                   int* cert_flag, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int keep = vchi_col[(long)b * stride], have = chi_col[(long)b * stride];
+  if (keep != have) cert_flag[b] = 1;
+  if (keep > 0) {
+    const real s = norms[(long)b * ncols_pad + keep - 1];
+    const real s2 = s * s;
+    if (!(s2 >= cert_min[b])) cert_min[b] = s2;  // a NaN lowers it for good
+  }
+}
+
+__global__ void cert_init_kernel(real* cert_min, int* cert_flag, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) { cert_min[b] = real(3.0e38); cert_flag[b] = 0; }
+}
+
+__global__ __launch_bounds__(256) void state_checksum_kernel(const cplx* __restrict__ A, long a_b0, unsigned long long* csum, const int* ids) {
+  __shared__ unsigned long long sh[256];
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  const unsigned long long* w = reinterpret_cast<const unsigned long long*>(A + (long)b * a_b0);
+  const long nwords = a_b0 * (long)(sizeof(cplx) / sizeof(unsigned long long));
+  unsigned long long acc = 0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nwords; e += (long)gridDim.x * blockDim.x) acc += w[e] * (unsigned long long)(2 * e + 1);
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(&csum[b], sh[0]);
+}
+
+int Engine::state_checksum(int set, const int* ids, int n, unsigned long long* host_out) {
+  StateSet& S = sets[set];
+  TJM_HIP_CHECK(hipMemsetAsync(csum_, 0, (size_t)B * sizeof(unsigned long long), stream));
+  for (int i = 0; i < L; ++i) {
+    int gx = (int)((a_b0_[i] + 4095) / 4096);
+    if (gx < 1) gx = 1;
+    if (gx > 32) gx = 32;
+    hipLaunchKernelGGL(state_checksum_kernel, dim3(gx, n), dim3(256), 0, stream, S.A[i] + 0, a_b0_[i], csum_ + 0, ids);
+  }
+  TJM_HIP_CHECK(hipGetLastError());
+  TJM_HIP_CHECK(hipMemcpyAsync(host_out, csum_, (size_t)B * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+// svd_shift_right on a scratch centre tensor: Cin [B][d][ca][cb] (stride cin_b0) = the centre tensor of site i; Cout [B][d][cb][cc] =
+// (S V^H) A_{i+1}, the centre tensor of site i + 1.  The bond table is read, not written (the kept count goes to vchi_), and
+// cert_min_ / cert_flag_ are updated.  Always the general kernels (the one-wavefront kernels work in place).
+int Engine::svd_shift_right_virtual(StateSet& S, int i, const cplx* Cin, long cin_b0, cplx* Cout, long cout_b0) {
+  const int ca = cap[i], cb = cap[i + 1], cc = cap[i + 2];
+  int rc;
+  Region prof(*this, PROF_SVD);
+  JacobiSource src;
+  src.src = Cin; src.src_b0 = cin_b0; src.rx = d * ca; src.ncols = cb; src.conj = 0; src.tri = 0;
+  src.r_n0 = ca; src.s_r1 = (long)ca * cb; src.s_r0 = cb; src.c_n0 = cb; src.s_c1 = 0; src.s_c0 = 1;
+  src.nb0 = B; src.ids = nullptr;
+  TruncSpec tr;
+  tr.trunc_mode = 0; tr.threshold = 1e-12; tr.max_bond = 0; tr.min_keep = 1;
+  tr.chiA = S.chi + i; tr.mulA = d; tr.chiB = S.chi + i + 1; tr.mulB = 1; tr.chiOut = vchi_ + i + 1; tr.chi_stride = L + 1;
+  tr.spectrum = nullptr; tr.spec_ld = 0;
+  JacobiShape sh;
+  int sweeps = 0;
+  if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps, false)) != TJM_OK) return rc;
+  ++stat_svds; stat_svd_mats += B; stat_svd_sweeps += sweeps;
+  hipLaunchKernelGGL(cert_update_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, svdw.norms, sh.ncols_pad, vchi_ + i + 1, S.chi + i + 1, L + 1,
+                     cert_min_, cert_flag_, B);
+  ExtractDesc xu;  // U[(s,a)][k] = X_final / sigma  (zero beyond keep)
+  xu.out = theta; xu.out_b0 = theta_b0; xu.n_k = cb; xu.o_k = 1; xu.n_r1 = 1; xu.n_r0 = d * ca; xu.o_r1 = 0; xu.o_r0 = cb;
+  xu.row_off = 0; xu.conj = 0; xu.scale_mode = 2;
+  if ((rc = svd_extract(xu, svdw, sh, vchi_ + i + 1, L + 1, B, nullptr, stream)) != TJM_OK) return rc;
+  {
+    GemmDesc g = blank_gemm();  // G[k][j] = sum_{(s,a)} conj(U[(s,a)][k]) C_i[(s,a)][j]
+    g.A = theta; g.B = Cin; g.C = T2;
+    g.M = cb; g.K = d * ca; g.N = cb;
+    g.a_rs = 1; g.a_cs = cb; g.conjA = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb;
+    g.nb0 = B; g.a_b0 = theta_b0; g.b_b0 = cin_b0; g.c_b0 = t_b0;
+    if ((rc = gemm(g)) != TJM_OK) return rc;
+  }
+  GemmDesc g = blank_gemm();  // Cout[t][k][c] = G[k][j] A_{i+1}[t][j][c]
+  g.A = T2; g.B = S.A[i + 1]; g.C = Cout;
+  g.M = cb; g.K = cb; g.N = cc;
+  g.a_rs = cb; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = cc;
+  g.nb0 = B; g.nb1 = d; g.a_b0 = t_b0; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cb * cc; g.c_b0 = cout_b0; g.c_b1 = (long)cb * cc;
+  return gemm(g);
 }
 
 // General centre shift i -> i-1 by the two-site SVD (mps.py:771-788), any gauge.
@@ -1360,6 +1473,80 @@ int Engine::dissipate(int set, double dt_, int start_center) {
     if (fits) return run_sweep(set, steps, nullptr, B);
   }
   const int dd = d * d, slot = dd * dd;  // a one-site operator has dd entries, an operator on a merged pair dd x dd
+  cert_set_ = -1;
+  {  // ---- certified scalar dissipation (see svd_shift_right_virtual)
+    static const bool cert_off = getenv("TJM_NO_CERT_DISSIPATION") != nullptr;
+    bool scalar_only = !cert_off && start_center == 0 && L >= 2;
+    std::vector<double> expo_site(L, 0.0);
+    double expo_total = 0.0;
+    for (int i = L - 1; i >= 0 && scalar_only; --i) {
+      for (int k : one_by_site_[i])
+        if (proc_on_[k]) { if (!noise_[k].pauli) scalar_only = false; else expo_site[i] += noise_[k].gamma; }
+      if (i != 0)
+        for (int k : two_by_right_[i])
+          if (proc_on_[k]) { if (!noise_[k].pauli) scalar_only = false; else expo_site[i] += noise_[k].gamma; }
+      expo_total += expo_site[i];
+    }
+    if (scalar_only && cert_skip_ > 0) { --cert_skip_; scalar_only = false; }
+    if (scalar_only) {
+      hipLaunchKernelGGL(cert_init_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, cert_min_, cert_flag_, B);
+      const cplx* cin = S.A[0];
+      long cin_b0 = a_b0_[0];
+      for (int i = 0; i < L - 1; ++i) {  // the right-going pass on scratch centre tensors (two slots of the idle Krylov basis buffer)
+        cplx* cout = V + (long)(i & 1) * v_ld;
+        if ((rc = svd_shift_right_virtual(S, i, cin, cin_b0, cout, v_b0)) != TJM_OK) return rc;
+        cin = cout;
+        cin_b0 = v_b0;
+      }
+      std::vector<real> mins(B);
+      std::vector<int> flags(B);
+      TJM_HIP_CHECK(hipMemcpyAsync(mins.data(), cert_min_, (size_t)B * sizeof(real), hipMemcpyDeviceToHost, stream));
+      TJM_HIP_CHECK(hipMemcpyAsync(flags.data(), cert_flag_, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+      TJM_HIP_CHECK(hipStreamSynchronize(stream));
+      const double scale = std::exp(-0.5 * dt_ * expo_total);
+      std::vector<int> good, rest;
+      for (int b = 0; b < B; ++b) {
+        // the left-going pass of the reference sees the singular values scaled by the factors already applied (at most `scale`
+        // in all): no truncation anywhere if even the smallest value, fully scaled, clears the threshold (margin: rounding)
+        const bool ok = flags[b] == 0 && (double)mins[b] * scale * scale >= 1e-12 * (1.0 + 1e-6);
+        (ok ? good : rest).push_back(b);
+      }
+      if (getenv("TJM_DEBUG_CERT")) {
+        int nf = 0; double mn = 1e300;
+        for (int b = 0; b < B; ++b) { nf += flags[b]; mn = std::min(mn, (double)mins[b]); }
+        fprintf(stderr, "[cert] B %d flagged %d min sigma^2 %.3e scale^2 %.3e certified %zu\n", B, nf, mn, scale * scale, good.size());
+      }
+      if (good.size() * 2 < (size_t)B) cert_skip_ = 7;  // mostly truncating bonds: take the plain sweep for the next calls
+      if (!good.empty()) {
+        hipLaunchKernelGGL(fill_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, scal_, (real)scale, B);
+        TJM_HIP_CHECK(hipMemcpyAsync(ids_, good.data(), good.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        if ((rc = launch_scale(S.A[0], a_b0_[0], a_b0_[0], scal_, (int)good.size(), ids_, nullptr, stream)) != TJM_OK) return rc;
+        TJM_HIP_CHECK(hipStreamSynchronize(stream));
+      }
+      if (!rest.empty()) {  // the reference's sweep for the others
+        TJM_HIP_CHECK(hipMemcpyAsync(ids_, rest.data(), rest.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        const int nr = (int)rest.size();
+        for (int i = 0; i < L - 1; ++i)
+          if ((rc = svd_shift_right(S, i, ids_, nr)) != TJM_OK) return rc;
+        for (int i = L - 1; i >= 0; --i) {
+          if (expo_site[i] != 0.0) {
+            hipLaunchKernelGGL(fill_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, scal_, (real)std::exp(-0.5 * dt_ * expo_site[i]), B);
+            if ((rc = launch_scale(S.A[i], a_b0_[i], a_b0_[i], scal_, nr, ids_, nullptr, stream)) != TJM_OK) return rc;
+          }
+          if (i != 0 && (rc = svd_shift_left(S, i, ids_, nr)) != TJM_OK) return rc;
+        }
+        TJM_HIP_CHECK(hipStreamSynchronize(stream));
+      }
+      stat_cert_traj += (long)good.size();
+      std::fill(cert_ok_.begin(), cert_ok_.end(), 0);
+      if (!good.empty()) {
+        if ((rc = state_checksum(set, nullptr, B, cert_sum_.data())) != TJM_OK) return rc;
+        for (int b : good) cert_ok_[b] = 1;
+        cert_set_ = set;
+      }
+      return TJM_OK;
+    }
+  }
   for (int i = start_center; i < L - 1; ++i)
     if ((rc = svd_shift_right(S, i, nullptr, B)) != TJM_OK) return rc;
   for (int i = L - 1; i >= 0; --i) {
@@ -1903,22 +2090,49 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
   TJM_HIP_CHECK(hipMemcpyAsync(d_sb, sb.data(), L * sizeof(long), hipMemcpyHostToDevice, stream));
   TJM_HIP_CHECK(hipMemcpyAsync(d_sr, sr.data(), L * sizeof(long), hipMemcpyHostToDevice, stream));
   const int nj = (int)jumped.size();
-  TJM_HIP_CHECK(hipMemcpyAsync(ids_, jumped.data(), nj * sizeof(int), hipMemcpyHostToDevice, stream));
+  // Certified trajectories (dissipate: no bond of theirs is near the truncation threshold; the state is unchanged since - same
+  // checksum) with a unitary jump: the QR walk to the last site, the jump and the SVD sweep back are a gauge move around a local
+  // unitary - the operator is applied where the state is (right-canonical, centre 0) and the trajectory is done.
+  std::vector<int> slow;
+  std::vector<char> fast(B, 0);
+  {
+    bool cert_live = cert_set_ == set;
+    std::vector<unsigned long long> now;
+    if (cert_live) {
+      bool any = false;
+      for (int b : jumped) any = any || (cert_ok_[b] && unitary_jump_[b] && adj_site[b] < 0);
+      if (any) {
+        now.resize(B);
+        if ((rc = state_checksum(set, nullptr, B, now.data())) != TJM_OK) return rc;
+      } else cert_live = false;
+    }
+    for (int b : jumped) {
+      if (cert_live && cert_ok_[b] && unitary_jump_[b] && adj_site[b] < 0 && now[b] == cert_sum_[b]) { fast[b] = 1; ++stat_cert_jumps; }
+      else slow.push_back(b);
+    }
+    cert_set_ = -1;  // consumed: the jumps below change the state
+  }
+  const int ns = (int)slow.size();
   // create_probability_distribution (stochastic_process.py:139-176) walks the orthogonality centre 0 -> L-1 by QR on the state
   // itself, so the jump operator meets a LEFT-canonical chain with the centre on the last site.  The weights above do not
   // depend on the gauge, but the truncations of the renormalising sweep below do: reproduce the gauge move.
-  if (sweep_ok_) {  // small bonds: the whole walk in one launch
-    std::vector<SmallSweepStep> steps;
-    for (int i = 0; i + 1 < L; ++i) {
-      SmallSweepStep st{};
-      st.site = i; st.kind = 3; st.op = 0;
-      steps.push_back(st);
+  if (ns > 0) {
+    TJM_HIP_CHECK(hipMemcpyAsync(ids_, slow.data(), ns * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (sweep_ok_) {  // small bonds: the whole walk in one launch
+      std::vector<SmallSweepStep> steps;
+      for (int i = 0; i + 1 < L; ++i) {
+        SmallSweepStep st{};
+        st.site = i; st.kind = 3; st.op = 0;
+        steps.push_back(st);
+      }
+      if ((rc = run_sweep(set, steps, ids_, ns)) != TJM_OK) return rc;
+    } else {
+      for (int i = 0; i + 1 < L; ++i)
+        if ((rc = qr_shift_right(S, i, ids_, ns)) != TJM_OK) return rc;
     }
-    if ((rc = run_sweep(set, steps, ids_, nj)) != TJM_OK) return rc;
-  } else {
-    for (int i = 0; i + 1 < L; ++i)
-      if ((rc = qr_shift_right(S, i, ids_, nj)) != TJM_OK) return rc;
+    TJM_HIP_CHECK(hipStreamSynchronize(stream));
   }
+  TJM_HIP_CHECK(hipMemcpyAsync(ids_, jumped.data(), nj * sizeof(int), hipMemcpyHostToDevice, stream));
   TJM_HIP_CHECK(hipMemcpyAsync(opidx_, opi.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
   TJM_HIP_CHECK(hipMemcpyAsync(jsite_, js.data(), B * sizeof(int), hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL(apply_local_multi_kernel, dim3(64, nj), dim3(256), 0, stream, d_sp, d_sb, d_sr, d, ops_, opidx_, jsite_, ids_);
@@ -1952,27 +2166,31 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
   // U on the left site and S V^H on the right one); nothing for Pauli jumps.
   {
     std::vector<int> broken(B, -1);
-    for (int b : jumped) {
+    for (int b : slow) {
       if (adj_site[b] >= 0) broken[b] = adj_site[b] + 1;
       else if (!unitary_jump_[b]) broken[b] = js[b];
     }
     std::vector<int> lst_short, lst_full;
     int* ids_full = opidx_;  // the operator-index table is no longer needed: reuse it as the second id list
     bool any_broken = false;
-    for (int b : jumped) any_broken = any_broken || broken[b] >= 0;
-    if (sweep_ok_ && !any_broken) {  // small bonds, unitary jumps only: every pair is a plain centre shift - one launch
+    for (int b : slow) any_broken = any_broken || broken[b] >= 0;
+    if (ns == 0) {
+      // every jump of this call was applied in place
+    } else if (sweep_ok_ && !any_broken) {  // small bonds, unitary jumps only: every pair is a plain centre shift - one launch
       std::vector<SmallSweepStep> steps;
       for (int i = L - 1; i >= 1; --i) {
         SmallSweepStep st{};
         st.site = i; st.kind = 2; st.op = 0;
         steps.push_back(st);
       }
-      if ((rc = run_sweep(set, steps, ids_, nj)) != TJM_OK) return rc;
+      TJM_HIP_CHECK(hipMemcpyAsync(ids_, slow.data(), ns * sizeof(int), hipMemcpyHostToDevice, stream));
+      if ((rc = run_sweep(set, steps, ids_, ns)) != TJM_OK) return rc;
+      TJM_HIP_CHECK(hipStreamSynchronize(stream));
     } else
     for (int i = L - 1; i >= 1; --i) {
       lst_short.clear();
       lst_full.clear();
-      for (int b : jumped) (broken[b] == i - 1 ? lst_full : lst_short).push_back(b);
+      for (int b : slow) (broken[b] == i - 1 ? lst_full : lst_short).push_back(b);
       if (!lst_short.empty()) {
         TJM_HIP_CHECK(hipMemcpyAsync(ids_, lst_short.data(), lst_short.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         if ((rc = svd_shift_left(S, i, ids_, (int)lst_short.size())) != TJM_OK) return rc;
