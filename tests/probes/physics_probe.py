@@ -18,6 +18,7 @@ ap.add_argument("--check", type=int, default=0)
 ap.add_argument("--threshold", type=float, default=1e-12)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--length", type=int, default=64)
+ap.add_argument("--engines", type=int, default=4)
 args = ap.parse_args()
 L, dt = args.length, 0.1
 
@@ -52,7 +53,7 @@ class Rec(orig):
 
 tjm.BatchEngine = Rec
 t0 = time.perf_counter()
-res = tjm.Simulator().run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p, noise)
+res = tjm.Simulator(engines=args.engines).run(MPS(L, state="x+"), MPO.ising(L, 1.0, 0.5), p, noise)
 sec = time.perf_counter() - t0
 out = {"workload": f"{L}-site dissipative TFIM from x+, pauli_z gamma=0.1, max_bond_dim=128, dt=0.1, {args.steps} steps, svd_threshold={args.threshold:g}, "
                    "krylov_tol=1e-4, order 1", "trajectories": args.num_traj, "engines (capacity, batch)": built, "seconds": round(sec, 2),
