@@ -427,6 +427,13 @@ def test_simulation_parameter_classes_validate_like_the_reference():
     for bad in (np.ones(3), np.ones((2, 3))):
         with pytest.raises(ValueError, match="Local operator matrix"):
             Observable(bad, 0)
+    pos = Observable("position", 2, positions=[-1.0, 0.0, 1.0])  # gate_library.py:1845-1872
+    assert pos.gate.name == "position" and pos.sites == 2 and np.array_equal(pos.gate.matrix, np.diag([-1.0, 0.0, 1.0]))
+    for bad, err in (([1j, 0], "real"), ([], "non-empty"), ([[0.0, 1.0]], "non-empty"), ([0.0, np.inf], "finite")):
+        with pytest.raises(ValueError, match=err):
+            Observable("position", 0, positions=bad)
+    with pytest.raises(TypeError, match="positions"):
+        Observable("position", 0)
     with pytest.raises(TypeError, match="unexpected keyword argument 'positions'"):
         Observable("z", 0, positions=[0.0, 1.0])
     with pytest.raises(TypeError, match="only supported for named observables"):

@@ -364,9 +364,11 @@ def test_qutrit_and_four_level_chains_match_oracle(d, L, chi, order):
         v[(i + 1) % d] = 1.0
         init.append(v.reshape(d, 1, 1))
     kw = dict(elapsed_time=0.4, dt=0.1, max_bond_dim=chi, svd_threshold=1e-10, krylov_tol=1e-12, order=order, sample_timesteps=True, random_seed=4)
-    p = AnalogSimParams(observables=[Observable(n, s) for s in range(L)] + [Observable(np.kron(n, n), [1, 2])], num_traj=3, **kw)
+    grid = np.linspace(-1.0, 1.0, d)  # the reference's "position" observable (gate_library.py:1845-1872): diagonal in a position basis
+    p = AnalogSimParams(observables=[Observable(n, s) for s in range(L)] + [Observable(np.kron(n, n), [1, 2]), Observable("position", 2, positions=grid)],
+                        num_traj=3, **kw)
     res = Simulator(batch=3).run(MPS(L, tensors=init), MPO(mpo), p, NoiseModel(procs))
-    op = o.Params(observables=[o.Obs(n, s) for s in range(L)] + [o.Obs(np.kron(n, n), [1, 2])], **kw)
+    op = o.Params(observables=[o.Obs(n, s) for s in range(L)] + [o.Obs(np.kron(n, n), [1, 2]), o.Obs(np.diag(grid).astype(complex), 2)], **kw)
     on = [o.make_process(q["name"], q["sites"], q["strength"], matrix=q["matrix"]) for q in procs]
     idx = op.observable_sorted_indices
     jumps = 0

@@ -99,15 +99,27 @@ class Observable:
     def __init__(self, gate: BaseGate | str | np.ndarray, sites: int | list[int] | None = None, **parameters):
         if isinstance(gate, str):
             table = {"x": X, "y": Y, "z": Z, "id": Id, "xx": XX, "yy": YY, "zz": ZZ, "entropy": Entropy, "schmidt_spectrum": SchmidtSpectrum}
-            if gate == "position":
-                raise NotImplementedError("the 'position' observable lives on sites of physical dimension > 2, which the HIP path does not build")
-            if parameters:
+            if gate == "position":  # gate_library.py:1845-1872: a one-site operator diagonal in a supplied position basis
+                extra = set(parameters) - {"positions"}
+                if extra or "positions" not in parameters:
+                    raise TypeError("Observable 'position' takes exactly the keyword argument 'positions'")
+                pos = np.asarray(parameters["positions"])
+                if np.iscomplexobj(pos):
+                    raise ValueError("positions must contain only real values.")
+                pos = np.asarray(pos, dtype=np.float64)
+                if pos.ndim != 1 or pos.size == 0:
+                    raise ValueError("positions must be a non-empty one-dimensional array.")
+                if not np.all(np.isfinite(pos)):
+                    raise ValueError("positions must contain only finite values.")
+                gate, parameters = BaseGate("position", np.diag(pos).astype(C128), interaction=1), {}
+            if isinstance(gate, str) and parameters:
                 if gate.lower() in table:
                     raise TypeError(f"Observable {gate!r} got an unexpected keyword argument {next(iter(parameters))!r}")
                 if gate == "pvm" or set(gate) <= {"0", "1"}:
                     raise TypeError("'pvm' does not accept observable parameters")
                 raise TypeError(f"Unknown observable {gate!r}")
-            gate = table[gate.lower()]() if gate.lower() in table else PVM(gate)  # simulation_parameters.py:392-401: fall back to a PVM
+            if isinstance(gate, str):
+                gate = table[gate.lower()]() if gate.lower() in table else PVM(gate)  # simulation_parameters.py:392-401: fall back to a PVM
         elif isinstance(gate, np.ndarray):
             if parameters:
                 raise TypeError("Observable parameters are only supported for named observables")
