@@ -295,11 +295,13 @@ __global__ __launch_bounds__(256, 3) void heff_stage12_kernel(HeffStage12Desc d)
   // skipped by scalar branches on the row's bit mask.
   if (tid < P * Dl) {
     unsigned m = 0;
+    bool real_row = true;
     for (int k = 0; k < P * Dr; ++k) {
       const cplx wv = sW[tid * (P * Dr) + k];
       if (wv.x != 0.0 || wv.y != 0.0) m |= 1u << k;
+      real_row = real_row && wv.y == 0.0;
     }
-    sMask[tid] = m;
+    sMask[tid] = m | (real_row ? 0x80000000u : 0u);  // bit 31: every entry of the row is real (Pauli-sum Hamiltonians without Y)
   }
   __syncthreads();
   cplx* __restrict__ T2b = d.T2 + (long)b0 * d.t_b0;
@@ -333,8 +335,13 @@ __global__ __launch_bounds__(256, 3) void heff_stage12_kernel(HeffStage12Desc d)
       for (int pi = 0; pi < P; ++pi) {
         if (mask & (1u << (pi * Dr + rch))) {
           const cplx wx = wrow[pi * Dr + rch];
+          if (mask & 0x80000000u) {
 #pragma unroll
-          for (int pt = 0; pt < NPT; ++pt) cfma(out[pt], wx, xin[pt][pi]);
+            for (int pt = 0; pt < NPT; ++pt) { out[pt].x = fma(wx.x, xin[pt][pi].x, out[pt].x); out[pt].y = fma(wx.x, xin[pt][pi].y, out[pt].y); }
+          } else {
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) cfma(out[pt], wx, xin[pt][pi]);
+          }
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -348,7 +355,10 @@ __global__ __launch_bounds__(256, 3) void heff_stage12_kernel(HeffStage12Desc d)
               cplx t1;
               t1.x = accRe[c * CPT + jj][v];
               t1.y = accIm[c * CPT + jj][v];
-              cfma(out[ai_ * CPT + jj], wc, t1);
+              if (mask & 0x80000000u) {
+                out[ai_ * CPT + jj].x = fma(wc.x, t1.x, out[ai_ * CPT + jj].x);
+                out[ai_ * CPT + jj].y = fma(wc.x, t1.y, out[ai_ * CPT + jj].y);
+              } else cfma(out[ai_ * CPT + jj], wc, t1);
             }
         }
       }
