@@ -1,6 +1,6 @@
 """Stand-alone timing of the batched two-site split (tjm_svd_split_qr) at the headline size, without the 6-minute bench:
 
-    python tools/svd_bench.py [B=1024] [chi=128] [reps=3]           # env switches of DESIGN section 8 apply (TJM_SVD_CHUNK=192 ...)
+    python tools/svd_bench.py [B=1024] [chi=128] [reps=3]           # env switches of DESIGN section 8 apply (TJM_NO_FOLD=1, TJM_NO_LATE_SWEEPS=1 ...)
 
 theta = a chi-saturated two-site tensor after a short evolution: (A_i C) + eps * noise with A_i left-isometric, i.e. 128 large
 singular values and 128 small ones, the regime of the TDVP splits of the bench.  Prints ms per batched SVD, TFLOP/s on the
