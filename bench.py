@@ -551,7 +551,10 @@ def main():
                                "frac_executed": (tf(flops_kry_exec, cls_ms["krylov"]) / peak) if cls_ms["krylov"] > 0 else None,
                                "note": "H_eff applies (2 MFMA GEMMs + MPO stage) with the Lanczos vector kernels (HBM-bound) inside the region; "
                                        "achieved = the reference's nominal flops (SURVEY 8d), executed = without the GEMM blocks of the environments' "
-                                       "certified identity channels (DESIGN section 4), which this build does not compute"},
+                                       "certified identity channels (DESIGN section 4), which this build does not compute; "
+                                       "with several engines per GPU the class time is this class's share of the overlapped stream time, so a "
+                                       "fraction above 1 means the MFMA work ran underneath other engines' VALU-bound factorisations, not that "
+                                       "a kernel beat the pipe: the GEMM kernels alone show 70 % MfmaUtil (profiles/r03_pmc_pass5_*)"},
                     "env": {"bound": mfma_bound, "achieved_TFLOPs": env_tf, "frac": (env_tf / peak) if env_tf else None,
                             "share_of_stream_time": cls_ms["env"] / 1e3 / busy if busy else None},
                     "whole_step": {"achieved_TFLOPs": step_tf, "frac": step_tf / peak,
