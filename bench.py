@@ -454,8 +454,10 @@ def main():
         ident = wsum("identity_channels") / max(1.0, 2.0 * wsum("identity_checks")) if "identity_checks" in stats1[0] else 0.0
         checked = wsum("identity_checks") / max(1.0, wsum("krylov_calls")) if "identity_checks" in stats1[0] else 0.0
         D_eff = D - ident * checked
-        F_mv2x = 8.0 * (2 * d_ ** 2 * D_eff * chi ** 3 + d_ ** 4 * D ** 2 * chi ** 2)
-        F_mv1x = 8.0 * (2 * d_ * D_eff * chi ** 3 + d_ ** 2 * D ** 2 * chi ** 2)
+        # ... and the GEMMs multiply complex numbers with three real products (3M scheme, tjm_gemm.hip): 6 real flops per complex
+        # multiply-add on the matrix pipe instead of the nominal 8
+        F_mv2x = 6.0 * 2 * d_ ** 2 * D_eff * chi ** 3 + 8.0 * d_ ** 4 * D ** 2 * chi ** 2
+        F_mv1x = 6.0 * 2 * d_ * D_eff * chi ** 3 + 8.0 * d_ ** 2 * D ** 2 * chi ** 2
         flops_kry_exec = F_mv2x * wsum("matvecs_two_site") + F_mv1x * (wsum("matvecs") - wsum("matvecs_two_site"))
         cls_ms = {c: sum(p[c]["ms"] for p in prof) for c in ("svd", "krylov", "env")}
         # With several engines the streams overlap on the device and their bracketed times add up to more than the wall time: every
@@ -551,7 +553,8 @@ def main():
                                "frac_executed": (tf(flops_kry_exec, cls_ms["krylov"]) / peak) if cls_ms["krylov"] > 0 else None,
                                "note": "H_eff applies (2 MFMA GEMMs + MPO stage) with the Lanczos vector kernels (HBM-bound) inside the region; "
                                        "achieved = the reference's nominal flops (SURVEY 8d), executed = without the GEMM blocks of the environments' "
-                                       "certified identity channels (DESIGN section 4), which this build does not compute; "
+                                       "certified identity channels (DESIGN section 4), which this build does not compute, and with 6 instead of 8 real flops per "
+                                       "complex multiply-add of the GEMMs (three-product complex multiplication); "
                                        "with several engines per GPU the class time is this class's share of the overlapped stream time, so a "
                                        "fraction above 1 means the MFMA work ran underneath other engines' VALU-bound factorisations, not that "
                                        "a kernel beat the pipe: the GEMM kernels alone show 70 % MfmaUtil (profiles/r03_pmc_pass5_*)"},
