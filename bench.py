@@ -557,7 +557,7 @@ def main():
                                        "complex multiply-add of the GEMMs (three-product complex multiplication); "
                                        "with several engines per GPU the class time is this class's share of the overlapped stream time, so a "
                                        "fraction above 1 means the MFMA work ran underneath other engines' VALU-bound factorisations, not that "
-                                       "a kernel beat the pipe: the GEMM kernels alone show 70 % MfmaUtil (profiles/r03_pmc_pass5_*)"},
+                                       "a kernel beat the pipe: the GEMM kernels alone show 52 - 61 % MfmaUtil (profiles/r03_pmc_pass5_*)"},
                     "env": {"bound": mfma_bound, "achieved_TFLOPs": env_tf, "frac": (env_tf / peak) if env_tf else None,
                             "share_of_stream_time": cls_ms["env"] / 1e3 / busy if busy else None},
                     "whole_step": {"achieved_TFLOPs": step_tf, "frac": step_tf / peak,
