@@ -638,8 +638,9 @@ class Simulator:
         self.batch = batch
         self.device = device
         # engines: the trajectories resident at a time are split over this many engines, each with a host thread and a HIP stream of
-        # its own, so that one engine's VALU-bound factorisations overlap with another's MFMA-bound contractions and the host
-        # round trips of one hide behind the kernels of the others (measured on the MI355X with the headline configuration:
+        # its own, so that the host round trips and latency-bound kernels of one hide behind the kernels of the others (fp64 MFMA
+        # and fp64 vector work share one datapath on gfx950, so this is latency hiding, not pipe overlap; measured on the MI355X
+        # with the headline configuration:
         # 1 -> 4 engines +6 % at 1024 resident trajectories, +16 % at 128).  Results do not depend on it: a trajectory is a pure
         # function of (seed, index).
         self.engines = max(1, int(engines))
