@@ -4,7 +4,7 @@
 #   usage (GPU box, repository root):  bash tools/gpu_prof.sh [stats] [pmc]
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-OUT=gpurun_out/r03/prof
+OUT=gpurun_out/${ROUND:-r04}/prof
 mkdir -p "$OUT"
 want() { [[ " $* " == *" $WHAT "* ]]; }
 for WHAT in "${@:-stats pmc}"; do :; done

@@ -604,6 +604,70 @@ def gen_fullsize(which=("cfg2", "cfg4", "cfg3")):
     save("fullsize", **out)
 
 
+def _steady_one(traj, steps=10, krylov_tol=1e-10):
+    """One trajectory of gen_fullsize_steady (runs in a forked worker)."""
+    import time
+
+    api, tensors = _fullsize_inputs(64, 128)
+    H = MPO()
+    H.tensors = [np.asarray(w, dtype=np.complex128) for w in api.MPO.ising(64, 1.0, 0.5).tensors]
+    H.length = 64
+    H.physical_dimension = 2
+    noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.1} for i in range(64)])
+    obs = [sp.Observable(gl.Z(), s) for s in range(64)]
+    p = sp.AnalogSimParams(observables=obs, elapsed_time=0.1 * steps, dt=0.1, max_bond_dim=128, svd_threshold=1e-12, krylov_tol=krylov_tol,
+                           order=1, sample_timesteps=True, random_seed=42, tdvp_mode="2site", get_state=True)
+    dps, jumped, bonds = [], [], []
+    orig_f, orig_pdf = stoch.calculate_stochastic_factor, stoch.create_probability_distribution
+
+    def spy_f(state):
+        v = orig_f(state)
+        dps.append(float(v))
+        jumped.append(0)
+        return v
+
+    def spy_pdf(state, *a, **k):
+        jumped[-1] = 1
+        # bonds of the state as the jump branch meets it (after the dissipation sweep of this step)
+        return orig_pdf(state, *a, **k)
+
+    orig_sp = stoch.stochastic_process
+
+    def spy_sp(state, *a, **k):
+        out = orig_sp(state, *a, **k)
+        bonds.append([out.tensors[0].shape[1]] + [x.shape[2] for x in out.tensors])
+        return out
+
+    stoch.calculate_stochastic_factor = spy_f
+    stoch.create_probability_distribution = spy_pdf
+    tjm.stochastic_process = spy_sp
+    t0 = time.time()
+    try:
+        st = MPS(64, tensors=[x.copy() for x in tensors])
+        r, dg, final = tjm.analog_tjm_1((traj, st, noise, p, H))
+    finally:
+        stoch.calculate_stochastic_factor, stoch.create_probability_distribution = orig_f, orig_pdf
+        tjm.stochastic_process = orig_sp
+    print(f"  fullsize_steady: trajectory {traj} took {time.time() - t0:.1f} s, dp {dps}, jumped {jumped}", flush=True)
+    return dict(z=np.asarray(r, dtype=np.float64), diag=np.asarray(dg, dtype=np.float64), dp=np.array(dps), jumped=np.array(jumped),
+                bonds=np.array(bonds))
+
+
+def gen_fullsize_steady(trajs=(0, 1, 2), steps=10):
+    """The reference's analog_tjm_1 on BASELINE's config 2 (L=64, chi=128 Haar-saturated, pauli_z 0.1 on every site, dt 0.1,
+    svd_threshold 1e-12, krylov_tol 1e-10) for `steps` CONSECUTIVE steps: the state bench.py's timed region is in after its first
+    steps, where the certified scalar dissipation / in-place jumps of the engine serve most trajectory-steps.  Per trajectory:
+    <Z_i> at every time point, diagnostics, dp of every step, which steps jumped, the bond table after every step."""
+    import multiprocessing as mp
+
+    with mp.get_context("fork").Pool(len(trajs)) as pool:
+        rows = pool.starmap(_steady_one, [(t, steps) for t in trajs])
+    out = {"traj": np.array(trajs), "steps": np.array(steps)}
+    for k in rows[0]:
+        out[k] = np.array([r[k] for r in rows])
+    save("fullsize_steady", **out)
+
+
 # ------------------------------------------------------------------ 13. dynamic TDVP and the BUG integrator (SURVEY 8f-3)
 def gen_f3():
     """One call of tdvp(tdvp_mode="dynamic") (integrators.py:294-511) and of bug() (bug.py:213-257) on small chains - bonds below,

@@ -139,6 +139,7 @@ EXPORTS = {
     "tjm_profile_cross_kernel": (C.c_int, [I]),
     "tjm_profile_cross_kernel_read": (C.c_int, [V, V, V]),
     "tjm_svd_work_read": (C.c_int, [V, I]),
+    "tjm_svd_mixed_read": (C.c_int, [V, I]),
 }
 
 _lib = None

@@ -414,9 +414,12 @@ static int svd_split_impl(bool use_qr, const void* theta, int32_t B, int32_t d, 
   sw.h_pinned = pinned;
   QrWorkspace qw;
   std::memset(&qw, 0, sizeof(qw));
+  MixedWorkspace mw;
   if (use_qr) {
     char* qbase = take(qr_workspace_bytes(mx, B));
     qr_carve(qw, qbase, mx, B);
+    const size_t mb = mixed_split_workspace_bytes(mx, B);
+    if (mb > 0) { mw.base = take(mb); mw.bytes = mb; mw.max_dim = mx; mw.B = B; }
   }
   SvdSplitDesc s;
   s.theta = static_cast<const cplx*>(theta); s.theta_b0 = (long)m * n; s.ld_theta = n; s.m = m; s.n = n; s.d = d;
@@ -427,13 +430,13 @@ static int svd_split_impl(bool use_qr, const void* theta, int32_t B, int32_t d, 
   s.chiL = chi_lrm; s.chiR = chi_lrm + 1; s.chiM = chi_lrm + 2; s.chi_stride = 3;
   s.spectrum = reinterpret_cast<real*>(spectrum); s.spec_ld = spec_ld; s.nb0 = B; s.ids = nullptr;  // device array of the build's real type
   int sweeps = 0;
-  const int rc = use_qr ? svd_split_qr(s, sw, qw, stream, &sweeps) : svd_split(s, sw, stream, &sweeps);
+  const int rc = use_qr ? svd_split_qr(s, sw, qw, stream, &sweeps, &mw) : svd_split(s, sw, stream, &sweeps);
   if (sweeps_out) *sweeps_out = sweeps;
   return rc;
 }
 
 size_t tjm_svd_qr_workspace_bytes(int32_t max_dim, int32_t B) {
-  return tjm_svd_workspace_bytes(max_dim, B) + qr_workspace_bytes(max_dim, B) + 16384;
+  return tjm_svd_workspace_bytes(max_dim, B) + qr_workspace_bytes(max_dim, B) + mixed_split_workspace_bytes(max_dim, B) + 16384;
 }
 
 int tjm_svd_split(const void* theta, int32_t B, int32_t d, int32_t capL, int32_t capR, int32_t capM, void* left, void* right,
@@ -452,6 +455,12 @@ int tjm_svd_split_qr(const void* theta, int32_t B, int32_t d, int32_t capL, int3
 
 int tjm_profile_cross_kernel(int32_t every) {
   profile_enable(every);
+  return TJM_OK;
+}
+
+int tjm_svd_mixed_read(double* out5, int32_t reset) {
+  if (!out5) return TJM_ERR_ARG;
+  mixed_stats_get(out5, reset != 0);
   return TJM_OK;
 }
 

@@ -150,6 +150,7 @@ class Engine {
   long v_b0 = 0, v_ld = 0, t_b0 = 0, theta_b0 = 0;
   SvdWorkspace svdw{};
   QrWorkspace qrw{};
+  MixedWorkspace mixw{};  // complex64 phase of the mixed-precision two-site split (fp64 build, square splits of 128 ... 512 rows)
   KrylovState ks{};
 
  private:

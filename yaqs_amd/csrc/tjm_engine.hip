@@ -167,6 +167,7 @@ size_t Engine::workspace_bytes() const {
   tot += align_up(svd_workspace_bytes(d * cm, B));
   tot += 8 * align_up((size_t)B * sizeof(double) * 4);  // small per-trajectory scalars and index lists
   tot += align_up(qr_workspace_bytes(d * cm, B)) + 4096;
+  tot += align_up(mixed_split_workspace_bytes(d * cm, B));
   tot += 2 * align_up((size_t)B * TJM_MAX_PART * sizeof(double));
   tot += 3 * align_up((size_t)B * mmax * sizeof(cplx));
   tot += 3 * align_up((size_t)B * cm * cm * sizeof(cplx));              // E ping-pong + bond matrix
@@ -214,6 +215,9 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
     const int md = d * cm;
     char* qbase = take(qr_workspace_bytes(md, B));
     qr_carve(qrw, qbase, md, B);
+    mixw = MixedWorkspace();
+    const size_t mb = mixed_split_workspace_bytes(md, B);
+    if (mb > 0) { mixw.base = take(mb); mixw.bytes = mb; mixw.max_dim = md; mixw.B = B; }
   }
   part1_ = reinterpret_cast<real*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));
   part2_ = reinterpret_cast<real*>(take((size_t)B * TJM_MAX_PART * sizeof(double)));
@@ -790,7 +794,7 @@ int Engine::split(StateSet& S, int i, int dist, int mode, double thr, int maxb, 
   static const bool force_large = getenv("TJM_FORCE_LARGE_SPLIT") != nullptr;
   const bool large = std::max(s.m, s.n) > 512 || (force_large && std::min(s.m, s.n) >= 32);  // bonds beyond 256: only the QR-preconditioned X-only variant holds the columns
   const bool use_qr = large || (!no_qr && dist != 2 && ids == nullptr && std::min(s.m, s.n) >= 64);  // the sqrt distribution is served by the plain split
-  const int rc = use_qr ? svd_split_qr(s, svdw, qrw, stream, &sweeps) : svd_split(s, svdw, stream, &sweeps);
+  const int rc = use_qr ? svd_split_qr(s, svdw, qrw, stream, &sweeps, &mixw) : svd_split(s, svdw, stream, &sweeps);
   ++stat_svds;
   stat_svd_mats += nb0;
   stat_svd_sweeps += sweeps;

@@ -197,7 +197,8 @@ int small_sweep_pitch(int rows);
 int launch_small_sweep(const SmallSweepDesc& p, hipStream_t s);
 bool svd_shift_small_fits(int d, int ca, int cb, bool left);
 // out[b][k*o_k + r1*o_r1 + r0*o_r0] = scale_k * op(Ycol[perm[k]][row_off + r1*n_r0 + r0]) for k < keep, 0 for keep <= k < n_k
-// scale_mode: 0 none, 1 multiply by sigma_k, 2 divide by sigma_k, 3 multiply by sqrt(sigma_k), 4 divide by sqrt(sigma_k)
+// scale_mode: 0 none, 1 multiply by sigma_k, 2 divide by sigma_k, 3 multiply by sqrt(sigma_k), 4 divide by sqrt(sigma_k),
+//             5 divide by sigma_k and replace an exactly zero column by the unit vector of its index (completes a square basis)
 struct ExtractDesc {
   cplx* out;
   long out_b0;
@@ -215,9 +216,19 @@ size_t svd_carve(SvdWorkspace& w, char* base, int max_dim, int B);  // lays the 
 void profile_enable(int every);
 void profile_get(double* total_ms, double* total_bytes, long* samples);
 void jacobi_work_get(double* out4, bool reset);  // slot x rows, applied rotations x rows, sweeps, solves of the tiled Jacobi since the last reset
+// Knobs of the tiled iteration for callers that do not want the defaults (the mixed-precision split, tjm_mixed.h)
+struct JacobiOpts {
+  int max_sweeps = 40;
+  real tol2 = TJM_JACOBI_TOL2;           // squared relative off-diagonal tolerance
+  real floor_scale = TJM_NOISE_FLOOR2;   // columns below sqrt(floor_scale) ||X||_F are numerically null (never rotated)
+  bool allow_unconverged = false;        // reaching max_sweeps is not an error (the caller refines the result anyway)
+  bool late_start = false;               // check-first tile kernel from the first sweep on
+  bool late_after_first = false;         // check-first tile kernel from the second sweep on, whatever the first one rotated
+  bool preloaded = false;                // Y holds X already: column-major, pitch = rows, rows and columns multiples of 64 / 32
+};
 // accumulate = false: rotate X only (no W rows, no rotation record); the caller rebuilds the other factor from X
 int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspace& w, hipStream_t s, JacobiShape* shape_out,
-                 int* sweeps_out, bool accumulate = true);
+                 int* sweeps_out, bool accumulate = true, const JacobiOpts* opts = nullptr);
 int svd_extract(const ExtractDesc& x, const SvdWorkspace& w, const JacobiShape& sh, const int* chi_keep, int chi_stride, int nb0,
                 const int* ids, hipStream_t s);
 int svd_split(const SvdSplitDesc& d, const SvdWorkspace& w, hipStream_t s, int* sweeps_out);
@@ -256,6 +267,11 @@ int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hip
 int qr_apply_q(const QrWorkspace& q, int zr, int zc, cplx* C, long c_b0, int nc, int nb0, const int* ids, hipStream_t s);
 int qr_scatter(const cplx* in, long in_b0, int ld, const ExtractDesc& x, const int* chi_keep, int chi_stride, int nb0, const int* ids,
                hipStream_t s);
-int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out);
+// Mixed-precision variant of the square two-site split (fp64 library only, tjm_mixed.h): workspace of its complex64 phase.
+struct MixedWorkspace { void* base = nullptr; size_t bytes = 0; int max_dim = 0, B = 0; };
+size_t mixed_split_workspace_bytes(int max_dim, int B);  // 0: not served (complex64 build, size out of range, TJM_NO_MIXED_SPLIT)
+void mixed_stats_get(double* out5, bool reset);          // solves, complex64 sweeps, fp64 sweeps, fallbacks to the fp64 path, (reserved)
+int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out,
+                 const MixedWorkspace* mx = nullptr);
 
 }  // namespace tjm

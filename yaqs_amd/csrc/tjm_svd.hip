@@ -27,6 +27,9 @@
 #include <vector>
 
 #include "tjm_kernels.h"
+#ifndef TJM_F32
+#include "tjm_mixed.h"
+#endif
 
 namespace tjm {
 
@@ -56,6 +59,7 @@ struct JacobiArgs {
   int clock;    // launch counter, strictly increasing inside one solve
   int fold;     // jacobi_cross16x_kernel: the pairs inside a 16-column block ride along with the tile visits (no diag / sibling launches)
   int* work;    // rotation slots executed in this sweep (tile visits x pairs per visit; the identity rotations of a visited tile count)
+  real floor_scale;  // columns below sqrt(floor_scale) ||X||_F are numerically null (TJM_NOISE_FLOOR2 unless the caller says otherwise)
 };
 
 __device__ inline void pair_of(int nblk, int round, int p, int& I, int& J) {
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(512) void jacobi_cross_kernel(JacobiArgs g) {
   }
   nI = wave_sum(nI);
   nJ = wave_sum(nJ);
-  const real floor2 = TJM_NOISE_FLOOR2 * g.fro2[b];
+  const real floor2 = g.floor_scale * g.fro2[b];
   int cnt = 0;
   for (int s = 0; s < NB; ++s) {
     real gx = 0.0, gy = 0.0;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(512) void jacobi_cross16_kernel(JacobiArgs g) {
   }
   nI[0] = wave_sum(nI[0]); nI[1] = wave_sum(nI[1]);
   nJ[0] = wave_sum(nJ[0]); nJ[1] = wave_sum(nJ[1]);
-  const real floor2 = TJM_NOISE_FLOOR2 * g.fro2[b];
+  const real floor2 = g.floor_scale * g.fro2[b];
   int cnt = 0;
   for (int s = 0; s < NB; ++s) {
 #pragma unroll
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
   }
   nI[0] = wave_sum(nI[0]); nI[1] = wave_sum(nI[1]);
   nJ[0] = wave_sum(nJ[0]); nJ[1] = wave_sum(nJ[1]);
-  const real floor2 = TJM_NOISE_FLOOR2 * g.fro2[b];
+  const real floor2 = g.floor_scale * g.fro2[b];
   int cnt = 0;
   // One sub-step: the independent pairs (p0, q0) and (p1, q1), norms (a0, d0), (a1, d1).  Both inner products are reduced together
   // (row r of 16 lanes ends up with component r of (Re g0, Im g0, Re g1, Im g1)), both rotations are set up side by side - pair h in
@@ -841,7 +845,7 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(JacobiArgs g, int ncol
     if (sweep == 0) {
       real f = 0.0;
       for (int c = 0; c < ncols; ++c) f += sN[c];
-      floor2 = TJM_NOISE_FLOOR2 * f;
+      floor2 = g.floor_scale * f;
     }
     int cnt = 0;
     for (int s = 0; s < ncols - 1; ++s) {
@@ -925,7 +929,7 @@ __global__ __launch_bounds__(256) void jacobi_diag_kernel(JacobiArgs g) {
     if (lane == 0) sN[c] = n;
   }
   __syncthreads();
-  const real floor2 = TJM_NOISE_FLOOR2 * g.fro2[b];
+  const real floor2 = g.floor_scale * g.fro2[b];
   int cnt = 0;
   for (int s = 0; s < NB - 1; ++s) {
     int p, q;
@@ -1700,6 +1704,10 @@ __global__ __launch_bounds__(256) void svd_extract_kernel(ExtractDesc x, SvdWork
       else if (x.scale_mode == 2) { const real inv = (sig[k] > 0.0) ? 1.0 / sig[k] : 0.0; v.x *= inv; v.y *= inv; }
       else if (x.scale_mode == 3) { const real r = sqrt(sig[k]); v.x *= r; v.y *= r; }
       else if (x.scale_mode == 4) { const real inv = (sig[k] > 0.0) ? 1.0 / sqrt(sig[k]) : 0.0; v.x *= inv; v.y *= inv; }
+      else if (x.scale_mode == 5) {  // normalised; an exactly zero column (structural padding) becomes the unit vector of its own index
+        if (sig[k] > 0.0) { const real inv = 1.0 / sig[k]; v.x *= inv; v.y *= inv; }
+        else v = cplx{(r == perm[k]) ? real(1.0) : real(0.0), 0.0};
+      }
     }
     out[(long)k * x.o_k + (long)r1 * x.o_r1 + (long)r0 * x.o_r0] = v;
   }
@@ -1842,8 +1850,10 @@ size_t svd_workspace_bytes(int max_dim, int B) {
 }
 
 int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspace& w, hipStream_t s, JacobiShape* shape_out,
-                 int* sweeps_out, bool accumulate) {
+                 int* sweeps_out, bool accumulate, const JacobiOpts* opts) {
   if (src.nb0 <= 0) return TJM_OK;
+  const JacobiOpts defaults;
+  const JacobiOpts& op = opts ? *opts : defaults;
   static const bool no16 = getenv("TJM_NO_TILE16") != nullptr;
   static const bool no_split = getenv("TJM_NO_SPLIT") != nullptr;
   // without the accumulated unitary the X rows are padded to whole 64-row groups (zero rows cost nothing in the dot products and
@@ -1877,6 +1887,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     JacobiArgs g;
     g.Y = w.Y; g.y_b0 = w.y_b0; g.rtot = rtot; g.rx = rx_top; g.nblk = ncols_pad / NB; g.tol2 = TJM_JACOBI_TOL2; g.fro2 = nullptr; g.nrot = nullptr;
     g.done = nullptr; g.ids = src.ids; g.round = 0; g.stamps = nullptr; g.clock = 0; g.mode = 0; g.rec = nullptr; g.work = nullptr; g.fold = 0;
+    g.floor_scale = op.floor_scale;
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 3 * sizeof(int), s));
     const size_t lds_bytes = (size_t)ncols_pad * rtot * sizeof(cplx) + (size_t)ncols_pad * sizeof(real) + 32 * sizeof(int);
     if (rtot <= 64) hipLaunchKernelGGL(jacobi_lds_kernel<1>, dim3(src.nb0), dim3(1024), lds_bytes, s, g, ncols_pad, 40, w.n_active);
@@ -1915,7 +1926,9 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     const long total = (long)ncols_pad * rtot;
     int gx = (int)((total + 1023) / 1024);
     if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(jacobi_load_kernel, dim3(gx, src.nb0), dim3(256), 0, s, src, w.Y, w.y_b0, ncols_pad, rx_top, rtot);
+    // op.preloaded: the caller has written X into Y already (column-major, pitch rtot; needs rx_top == rx and no padding columns)
+    if (op.preloaded && (rx_top != src.rx || ncols_pad != src.ncols || rtot != rx_top || accumulate)) return TJM_ERR_ARG;
+    if (!op.preloaded) hipLaunchKernelGGL(jacobi_load_kernel, dim3(gx, src.nb0), dim3(256), 0, s, src, w.Y, w.y_b0, ncols_pad, rx_top, rtot);
     hipLaunchKernelGGL(jacobi_fro_kernel, dim3(src.nb0), dim3(256), 0, s, w.Y, w.y_b0, ncols_pad, rx_top, rtot, w.fro2, src.ids);
     hipLaunchKernelGGL(jacobi_stamp_init_kernel, dim3(src.nb0), dim3(256), 0, s, w.Y, w.y_b0, ncols_pad / NB, rx_top, rtot, w.stamps, src.ids);
   }
@@ -1925,7 +1938,8 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   g.rtot = rtot;
   g.rx = rx_top;
   g.nblk = ncols_pad / NB;
-  g.tol2 = TJM_JACOBI_TOL2;  // relative off-diagonal tolerance 1e-13 (fp64)
+  g.tol2 = op.tol2;  // relative off-diagonal tolerance, squared (default 1e-13 in fp64)
+  g.floor_scale = op.floor_scale;
   g.fro2 = w.fro2;
   g.nrot = w.nrot;
   g.done = w.done;
@@ -1952,13 +1966,13 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   // one sweep, and no rotation record (the W replay kernel knows the fixed column assignment only)
   static const bool no_fold = getenv("TJM_NO_FOLD") != nullptr;
   g.fold = (!no_fold && split16 && !accumulate && nrounds >= 15) ? 1 : 0;
-  const int max_sweeps = 40;
+  const int max_sweeps = op.max_sweeps;
   const int nb = src.nb0;
   const int tbc = (nb + 255) / 256;
   int sweep_c = 0;
   int n_live = nb;
   bool conv_c = false;
-  bool late = false;  // the previous sweep rotated less than a quarter of its pairs: the check-first variant of the tile kernel
+  bool late = op.late_start;  // the previous sweep rotated less than 70 % of its pairs: the check-first variant of the tile kernel
   static const bool no_late = getenv("TJM_NO_LATE_SWEEPS") != nullptr;
   for (; sweep_c < max_sweeps && !conv_c; ++sweep_c) {
     ++g.clock;
@@ -2029,7 +2043,8 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     n_live = *w.h_pinned;
     // measured on the MI355X (headline step): fraction 0.25 -> 5.94, 0.7 -> 6.05, 1 (every sweep after the first) -> 5.81 trajectories/s
     static const double late_frac = getenv("TJM_LATE_FRACTION") ? atof(getenv("TJM_LATE_FRACTION")) : 0.7;
-    late = !no_late && !accumulate && (double)w.h_pinned[1] < late_frac * 0.5 * (double)ncols_pad * (ncols_pad - 1) * std::max(n_live, 1);
+    late = !no_late && !accumulate &&
+           (op.late_after_first || (double)w.h_pinned[1] < late_frac * 0.5 * (double)ncols_pad * (ncols_pad - 1) * std::max(n_live, 1));
     if (g_prof.every > 0) prof_collect();
   }
   const int sweep = sweep_c;
@@ -2043,7 +2058,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     shape_out->rx_top = rx_top;
     shape_out->rtot = rtot;
   }
-  return converged ? TJM_OK : TJM_ERR_NUMERIC;
+  return (converged || op.allow_unconverged) ? TJM_OK : TJM_ERR_NUMERIC;
 }
 
 int svd_extract(const ExtractDesc& x, const SvdWorkspace& w, const JacobiShape& sh, const int* chi_keep, int chi_stride, int nb0,
@@ -2322,7 +2337,303 @@ static int svd_split_qr2(const SvdSplitDesc& d, const SvdWorkspace& w, const QrW
   return qr_scatter(q.Z, q.z_b0, N, xx, d.chiM, d.chi_stride, d.nb0, d.ids, s);
 }
 
-int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out) {
+#ifndef TJM_F32
+// ---- mixed-precision two-site split (fp64 library only; tjm_mixed.h) -----------------------------------------------------------
+// Z = theta (dist 0) / theta^H (dist 1) is the matrix whose LEFT singular basis is the isometric factor (the orientation of the
+// direct variant above).  1. complex64: all right singular vectors of Z, approximately (the left singular basis of Z^H by the doubly
+// preconditioned complex64 Jacobi), V0.  2. fp64: one polar step makes it unitary, V = V0 (I + E)^(-1/2) ~ V0 (I - E/2 + 3 E^2 / 8)
+// with E = V0^H V0 - I (||E||_F ~ 1e-6, the remainder 5/16 ||E||^3 is far below rounding; three GEMMs) - checked per trajectory.
+// 3. X1 = Z V (one GEMM, written straight into the Jacobi workspace): the columns of X1 are orthogonal to ~1e-6, so the fp64
+// one-sided Jacobi - no preconditioner needed - converges quadratically: one full sweep, one with a handful of rotations, one that
+// finds nothing to do.  4. As in the direct variant: isometric factor = normalised kept columns of Y = X1 W (here without any
+// reflectors in front), weighted factor = its projection of theta (one GEMM).  Nothing of the complex64 phase survives in the
+// result except the choice of the starting basis: X1 is theta times an exactly unitary matrix.
+// Whatever does not fit (polar residual too large, a kept singular value at the noise floor, no convergence within a few sweeps)
+// makes the whole batch take the all-fp64 path; the counters say how often.
+namespace {
+
+struct float2_t { float x, y; };
+
+// scale[b] = the power of two that brings ||theta_b||_F to about 2^24.  The complex64 rotation set-up squares squared column norms
+// (tjm_svd.hip: make_rotation): with ||X||_F ~ 1 a column at 1e-8 of the largest one underflows there and is never rotated; scaled
+// like this, columns from 1e7 down to the fp32 rounding floor of the matrix (and its own smallest singular values) stay inside the range.  Singular vectors do not
+// depend on the scale, and a power of two changes no mantissa.
+__global__ __launch_bounds__(256) void c64_scale_kernel(const cplx* __restrict__ in, long in_b0, long n, real* __restrict__ scale) {
+  __shared__ real sh[4];
+  const cplx* ib = in + (long)blockIdx.x * in_b0;
+  real acc = 0.0;
+  for (long e = threadIdx.x; e < n; e += blockDim.x) {
+    const cplx v = ib[e];
+    acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const real f2 = sh[0] + sh[1] + sh[2] + sh[3];
+    int e = 0;
+    if (f2 > 0.0 && f2 == f2 && f2 < 1e300) frexp(f2, &e);  // f2 = m 2^e, 0.5 <= m < 1
+    scale[blockIdx.x] = ldexp(1.0, 24 - e / 2);
+  }
+}
+
+__global__ __launch_bounds__(256) void to_c64_kernel(const cplx* __restrict__ in, long in_b0, float2_t* __restrict__ out, long out_b0, long n,
+                                                    const real* __restrict__ scale) {
+  const cplx* ib = in + (long)blockIdx.y * in_b0;
+  float2_t* ob = out + (long)blockIdx.y * out_b0;
+  const real sc = scale[blockIdx.y];
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const cplx v = ib[e];
+    ob[e] = float2_t{(float)(v.x * sc), (float)(v.y * sc)};
+  }
+}
+
+__global__ __launch_bounds__(256) void from_c64_kernel(const float2_t* __restrict__ in, long in_b0, cplx* __restrict__ out, long out_b0, long n) {
+  const float2_t* ib = in + (long)blockIdx.y * in_b0;
+  cplx* ob = out + (long)blockIdx.y * out_b0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+    const float2_t v = ib[e];
+    ob[e] = cplx{(real)v.x, (real)v.y};
+  }
+}
+
+// E <- E - I (row-major N x N) ; fro2[b] += ||E||_F^2
+__global__ __launch_bounds__(256) void polar_residual_kernel(cplx* __restrict__ E, long e_b0, int N, real* __restrict__ fro2) {
+  __shared__ real sh[4];
+  cplx* Eb = E + (long)blockIdx.y * e_b0;
+  const long total = (long)N * N;
+  real acc = 0.0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    cplx v = Eb[e];
+    if (e / N == e % N) { v.x -= 1.0; Eb[e] = v; }
+    acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&fro2[blockIdx.y], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// T = I - E / 2 + 3 E2 / 8 ; e2fro2[b] += ||E2||_F^2   (E Hermitian: ||E||_2^2 = ||E^2||_2 <= ||E^2||_F, the certificate below)
+__global__ __launch_bounds__(256) void polar_poly_kernel(const cplx* __restrict__ E, long e_b0, const cplx* __restrict__ E2, long e2_b0,
+                                                        cplx* __restrict__ T, long t_b0, int N, real* __restrict__ e2fro2) {
+  __shared__ real sh[4];
+  const cplx* Eb = E + (long)blockIdx.y * e_b0;
+  const cplx* Fb = E2 + (long)blockIdx.y * e2_b0;
+  cplx* Tb = T + (long)blockIdx.y * t_b0;
+  const long total = (long)N * N;
+  real acc = 0.0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const cplx a = Eb[e], b = Fb[e];
+    cplx v{fma(0.375, b.x, -0.5 * a.x), fma(0.375, b.y, -0.5 * a.y)};
+    if (e / N == e % N) v.x += 1.0;
+    Tb[e] = v;
+    acc = fma(b.x, b.x, fma(b.y, b.y, acc));
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&e2fro2[blockIdx.y], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// flag |= 1 when a trajectory's certificate fails: the polar series I - E/2 + 3 E^2/8 leaves (5/16) ||E||_2^3 <= (5/16) ||E^2||_F^(3/2),
+// which has to stay at the level of the Jacobi tolerance (1e-13) for X1 to be theta times a unitary matrix to that accuracy
+__global__ void polar_check_kernel(const real* e2fro2, int nb0, real tol2, int* flag) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb0 && !(e2fro2[b] <= tol2)) atomicOr(flag, 1);
+}
+
+struct MixedStats { long solves = 0, c64_sweeps = 0, f64_sweeps = 0, fallbacks = 0; double worst_residual2 = 0.0; };
+MixedStats g_mixed;
+
+}  // namespace
+
+void mixed_stats_get(double* out5, bool reset) {
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
+  out5[0] = (double)g_mixed.solves; out5[1] = (double)g_mixed.c64_sweeps; out5[2] = (double)g_mixed.f64_sweeps;
+  out5[3] = (double)g_mixed.fallbacks; out5[4] = g_mixed.worst_residual2;
+  if (reset) g_mixed = MixedStats();
+}
+
+size_t mixed_split_workspace_bytes(int max_dim, int B) {
+  static const bool off = getenv("TJM_NO_MIXED_SPLIT") != nullptr;
+  if (off || max_dim < 128 || max_dim > 512 || max_dim % 64 != 0) return 0;
+  return tjm32::mixed_workspace_bytes(max_dim, B) + 256;
+}
+
+bool mixed_split_fits(const SvdSplitDesc& d, const QrWorkspace& q, const MixedWorkspace* mx) {
+  static const bool off = getenv("TJM_NO_MIXED_SPLIT") != nullptr;
+  if (off || mx == nullptr || mx->base == nullptr || q.Z2 == nullptr || d.ids != nullptr) return false;
+  if (d.distribution != 0 && d.distribution != 1) return false;
+  if (d.m != d.n || d.ld_theta != d.n || d.m < 128 || d.m % 64 != 0 || d.m > mx->max_dim || d.nb0 > mx->B) return false;
+  return d.capM <= d.m && (long)d.m * d.m <= q.z_b0;
+}
+
+// returns TJM_OK with *done = true when the outputs are written, *done = false when the batch has to take the fp64 path
+static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, const MixedWorkspace& mx, hipStream_t s,
+                           int* sweeps_out, bool* done) {
+  *done = false;
+  const int N = d.m, cm = d.capM, nb = d.nb0;
+  const long nn = (long)N * N;
+  int rc;
+  int gx = (int)((nn + 1023) / 1024);
+  if (gx > 128) gx = 128;
+  float2_t* th32 = static_cast<float2_t*>(mx.base);
+  const long th32_b0 = (long)mx.max_dim * mx.max_dim;
+  hipLaunchKernelGGL(c64_scale_kernel, dim3(nb), dim3(256), 0, s, d.theta, d.theta_b0, nn, w.fro2);  // w.fro2: free until the fp64 sweeps
+  hipLaunchKernelGGL(to_c64_kernel, dim3(gx, nb), dim3(256), 0, s, d.theta, d.theta_b0, th32, th32_b0, nn, w.fro2);
+  TJM_HIP_CHECK(hipGetLastError());
+  tjm32::MixedBasisDesc mb;
+  mb.N = N; mb.d = d.d; mb.dist = 1 - d.distribution; mb.nb0 = nb; mb.h_pinned = w.h_pinned;
+  static const int c64_cap = getenv("TJM_MIXED_C64_SWEEPS") ? atoi(getenv("TJM_MIXED_C64_SWEEPS")) : 10;
+  mb.max_sweeps = c64_cap;
+  const void* basis = nullptr;
+  long basis_b0 = 0;
+  int c64_sweeps = 0;
+  if ((rc = tjm32::mixed_left_basis(mb, mx.base, mx.bytes, mx.max_dim, mx.B, s, &basis, &basis_b0, &c64_sweeps)) != TJM_OK) return rc;
+  // fp64 temporaries: the buffers of the (unused) fp64 preconditioner
+  cplx* V0 = q.Z;   const long v0_b0 = q.z_b0;   // N x N column-major
+  cplx* E = q.Z2;   const long e_b0 = q.z_b0;    // N x N row-major, later V (column-major)
+  cplx* E2 = q.V;   const long e2_b0 = q.v_b0;
+  cplx* T = q.V2;   const long t_b0 = q.v_b0;
+  if (q.v_b0 < nn) return TJM_ERR_WORKSPACE;
+  hipLaunchKernelGGL(from_c64_kernel, dim3(gx, nb), dim3(256), 0, s, static_cast<const float2_t*>(basis), basis_b0, V0, v0_b0, nn);
+  auto blank = [&]() { GemmDesc g; memset(&g, 0, sizeof(g)); g.nks = 1; g.nb0 = nb; g.nb1 = 1; g.nb2 = 1; g.M = N; g.N = N; g.K = N; return g; };
+  {  // E = V0^H V0
+    GemmDesc g = blank();
+    g.A = V0; g.a_rs = N; g.a_cs = 1; g.a_b0 = v0_b0; g.conjA = 1;
+    g.B = V0; g.b_rs = 1; g.b_cs = N; g.b_b0 = v0_b0;
+    g.C = E; g.c_rs = N; g.c_b0 = e_b0;
+    if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
+  }
+  real* fro2 = w.norms;        // [B] scratch: ||E||_F^2 (diagnostic) and ...
+  real* e2fro2 = w.norms + nb;  // ... [B] ||E^2||_F^2 (certificate); the norms are written by the finish kernel long after this
+  int* flag = w.n_active + 3;
+  TJM_HIP_CHECK(hipMemsetAsync(fro2, 0, (size_t)2 * nb * sizeof(real), s));
+  TJM_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
+  hipLaunchKernelGGL(polar_residual_kernel, dim3(gx, nb), dim3(256), 0, s, E, e_b0, N, fro2);
+  if (g_debug) {
+    std::vector<real> h(nb);
+    TJM_HIP_CHECK(hipMemcpyAsync(h.data(), fro2, (size_t)nb * sizeof(real), hipMemcpyDeviceToHost, s));
+    TJM_HIP_CHECK(hipStreamSynchronize(s));
+    real worst = 0.0;
+    for (int b = 0; b < nb; ++b) worst = (h[b] > worst || h[b] != h[b]) ? h[b] : worst;
+    fprintf(stderr, "[svd-mixed] polar residual ||V0^H V0 - I||_F: worst %.3e\n", sqrt(worst));
+    if (getenv("TJM_DEBUG_MIXED_E")) {  // where is the residual: largest entries of E of trajectory 0
+      std::vector<cplx> he((size_t)nn);
+      TJM_HIP_CHECK(hipMemcpy(he.data(), E, (size_t)nn * sizeof(cplx), hipMemcpyDeviceToHost));
+      for (int rep = 0; rep < 6; ++rep) {
+        double best = -1.0; long at = 0;
+        for (long e = 0; e < nn; ++e) { const double m = he[e].x * he[e].x + he[e].y * he[e].y; if (m > best) { best = m; at = e; } }
+        fprintf(stderr, "[svd-mixed]   |E[%ld][%ld]| = %.3e\n", at / N, at % N, sqrt(best));
+        he[at] = cplx{0.0, 0.0};
+      }
+    }
+  }
+  {  // E2 = E E
+    GemmDesc g = blank();
+    g.A = E; g.a_rs = N; g.a_cs = 1; g.a_b0 = e_b0;
+    g.B = E; g.b_rs = N; g.b_cs = 1; g.b_b0 = e_b0;
+    g.C = E2; g.c_rs = N; g.c_b0 = e2_b0;
+    if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
+  }
+  hipLaunchKernelGGL(polar_poly_kernel, dim3(gx, nb), dim3(256), 0, s, E, e_b0, E2, e2_b0, T, t_b0, N, e2fro2);
+  // (5/16) ||E^2||_F^(3/2) <= 1e-13  <=>  ||E^2||_F^2 <= 2.2e-17 ; anything larger says the complex64 basis is not what it should be
+  hipLaunchKernelGGL(polar_check_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, e2fro2, nb, real(2.2e-17), flag);
+  TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 6, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (g_debug) {
+    std::vector<real> h(nb);
+    TJM_HIP_CHECK(hipMemcpyAsync(h.data(), e2fro2, (size_t)nb * sizeof(real), hipMemcpyDeviceToHost, s));
+    TJM_HIP_CHECK(hipStreamSynchronize(s));
+    real worst = 0.0;
+    for (int b = 0; b < nb; ++b) worst = (h[b] > worst || h[b] != h[b]) ? h[b] : worst;
+    fprintf(stderr, "[svd-mixed] certificate ||E^2||_F: worst %.3e (limit 4.7e-9)\n", sqrt(worst));
+  }
+  cplx* V = E;  // column-major N x N: V[r + j N] = sum_i V0[r + i N] T[i][j], written as the row-major matrix C[j][r]
+  {
+    GemmDesc g = blank();
+    g.A = T; g.a_rs = 1; g.a_cs = N; g.a_b0 = t_b0;
+    g.B = V0; g.b_rs = N; g.b_cs = 1; g.b_b0 = v0_b0;
+    g.C = V; g.c_rs = N; g.c_b0 = e_b0;
+    if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
+  }
+  if ((long)N * N > w.y_b0) return TJM_ERR_WORKSPACE;
+  {  // X1 = Z V into the Jacobi workspace, column-major: Y[k * N + r] = sum_(bond, phys) V[(bond * d + phys) + k N] Z[r][(phys, bond)]
+    GemmDesc g = blank();
+    g.nks = d.d;
+    g.A = V; g.a_rs = N; g.a_cs = d.d; g.a_ks = 1; g.a_b0 = e_b0;
+    g.B = d.theta; g.b_b0 = d.theta_b0;
+    if (d.distribution == 0) {  // Z = theta: r = (s, a), sum over (t, c)
+      g.K = d.capR; g.b_rs = 1; g.b_cs = d.ld_theta; g.b_ks = d.capR;
+    } else {                    // Z = theta^H: r = (t, c), sum over (s, a) of conj(theta[(s, a)][r])
+      g.K = d.capL; g.b_rs = d.ld_theta; g.b_cs = 1; g.b_ks = (long)d.capL * d.ld_theta; g.conjB = 1;
+    }
+    g.C = w.Y; g.c_rs = N; g.c_b0 = w.y_b0;
+    if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
+  }
+  JacobiSource src;
+  src.src = nullptr; src.src_b0 = 0; src.rx = N; src.ncols = N; src.conj = 0; src.tri = 0;
+  src.r_n0 = N; src.s_r1 = 0; src.s_r0 = 0; src.c_n0 = N; src.s_c1 = 0; src.s_c0 = 0;
+  src.nb0 = nb; src.ids = nullptr;
+  TruncSpec tr;
+  tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
+  tr.cap = d.capM; tr.overflow = d.overflow;
+  tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
+  tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
+  JacobiOpts op;
+  op.preloaded = true;
+  op.late_after_first = true;
+  static const int f64_cap = getenv("TJM_MIXED_F64_SWEEPS") ? atoi(getenv("TJM_MIXED_F64_SWEEPS")) : 12;
+  op.max_sweeps = f64_cap;
+  op.allow_unconverged = true;  // the caller decides below
+  JacobiShape sh;
+  int f64_sweeps = 0;
+  if ((rc = jacobi_solve(src, tr, w, s, &sh, &f64_sweeps, false, &op)) != TJM_OK) return rc;
+  TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 7, w.n_active + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+  TJM_HIP_CHECK(hipStreamSynchronize(s));
+  const bool bad_polar = w.h_pinned[6] != 0, floor_kept = w.h_pinned[7] != 0, slow = f64_sweeps >= f64_cap;
+  {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    ++g_mixed.solves;
+    g_mixed.c64_sweeps += c64_sweeps;
+    g_mixed.f64_sweeps += f64_sweeps;
+    if (bad_polar || floor_kept || slow) ++g_mixed.fallbacks;
+  }
+  if (g_debug) fprintf(stderr, "[svd-mixed] N %d c64 sweeps %d fp64 sweeps %d polar %d floor %d\n", N, c64_sweeps, f64_sweeps, (int)bad_polar, (int)floor_kept);
+  if (sweeps_out) *sweeps_out = f64_sweeps;
+  if (bad_polar || floor_kept || slow) return TJM_OK;  // *done stays false: theta is untouched, the caller runs the fp64 path
+  ExtractDesc xi;
+  GemmDesc g;
+  memset(&g, 0, sizeof(g));
+  g.nb0 = nb; g.nb2 = 1;
+  if (d.distribution == 0) {
+    // left[(s,a)][k] = Ytilde[(s,a)][k] ; right[t][k][c] = sum_(s,a) conj(left[(s,a)][k]) theta[(s,a)][(t,c)]
+    xi.out = d.left; xi.out_b0 = d.left_b0; xi.n_k = cm; xi.o_k = 1; xi.n_r1 = 1; xi.n_r0 = N; xi.o_r1 = 0; xi.o_r0 = cm;
+    xi.row_off = 0; xi.conj = 0; xi.scale_mode = 2;
+    g.nks = 1; g.nb1 = d.d;
+    g.A = d.left; g.a_rs = 1; g.a_cs = cm; g.a_b0 = d.left_b0; g.conjA = 1; g.M = cm; g.K = N;
+    g.B = d.theta; g.b_rs = d.ld_theta; g.b_cs = 1; g.b_b0 = d.theta_b0; g.b_b1 = d.capR; g.N = d.capR;
+    g.C = d.right; g.c_rs = d.capR; g.c_b0 = d.right_b0; g.c_b1 = (long)cm * d.capR;
+  } else {
+    // right[t][k][c] = conj(Ytilde[(t,c)][k]) ; left[(s,a)][k] = sum_(t,c) theta[(s,a)][(t,c)] conj(right[t][k][c])
+    xi.out = d.right; xi.out_b0 = d.right_b0; xi.n_k = cm; xi.o_k = d.capR; xi.n_r1 = d.d; xi.n_r0 = d.capR;
+    xi.o_r1 = (long)cm * d.capR; xi.o_r0 = 1; xi.row_off = 0; xi.conj = 1; xi.scale_mode = 2;
+    g.nks = d.d; g.nb1 = 1;
+    g.A = d.theta; g.a_rs = d.ld_theta; g.a_cs = 1; g.a_ks = d.capR; g.a_b0 = d.theta_b0; g.M = d.m; g.K = d.capR;
+    g.B = d.right; g.b_rs = 1; g.b_cs = d.capR; g.b_ks = (long)cm * d.capR; g.b_b0 = d.right_b0; g.conjB = 1; g.N = cm;
+    g.C = d.left; g.c_rs = cm; g.c_b0 = d.left_b0;
+  }
+  if ((rc = svd_extract(xi, w, sh, d.chiM, d.chi_stride, nb, nullptr, s)) != TJM_OK) return rc;
+  if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
+  *done = true;
+  return TJM_OK;
+}
+#else
+void mixed_stats_get(double* out5, bool) { for (int i = 0; i < 5; ++i) out5[i] = 0.0; }
+size_t mixed_split_workspace_bytes(int, int) { return 0; }
+#endif
+
+int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out, const MixedWorkspace* mx) {
   if (d.nb0 <= 0) return TJM_OK;
   // beyond the stacked-column Jacobi (rows + columns <= 1024): X-only direct variant.  TJM_FORCE_LARGE_SPLIT sends every split of
   // at least 32 x 32 down that path (diagnostic: the large-bond code at sizes the rest of the suite covers)
@@ -2336,6 +2647,13 @@ int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace
     if (q.Z2 == nullptr) return TJM_ERR_WORKSPACE;
     return svd_split_qr2(d, w, q, s, sweeps_out);
   }
+#ifndef TJM_F32
+  if (!single_qr && mixed_split_fits(d, q, mx)) {
+    bool done = false;
+    const int rcm = svd_split_mixed(d, w, q, *mx, s, sweeps_out, &done);
+    if (rcm != TJM_OK || done) return rcm;
+  }
+#endif
   if (!single_qr && q.Z2 != nullptr && d.m == d.n && d.m >= 32) return svd_split_qr2(d, w, q, s, sweeps_out);
   const int zr = (d.distribution == 0) ? d.m : d.n;
   const int zc = (d.distribution == 0) ? d.n : d.m;
