@@ -412,7 +412,7 @@ def main():
     lib.tjm_profile_cross_kernel(8)  # bracket every 8th launch of the dominant kernel with HIP events on its engine's stream
     jw = np.zeros(4)
     lib.tjm_svd_work_read(jw.ctypes.data, 1)  # reset the executed-work counters of the tiled Jacobi kernels
-    mx = np.zeros(5)
+    mx = np.zeros(6)
     lib.tjm_svd_mixed_read(mx.ctypes.data, 1)  # ... and of the mixed-precision two-site split
     barrier()
     t0 = time.perf_counter()
@@ -534,7 +534,8 @@ def main():
                 # mixed-precision two-site split (tjm_mixed.h): batched splits it served, their complex64 and fp64 sweeps, batches sent
                 # back to the all-fp64 path.  jacobi_sweeps_per_solve above counts every tiled solve of the process, both types.
                 "mixed_split": {"batched_splits": mx[0], "c64_sweeps_per_split": (mx[1] / mx[0]) if mx[0] else None,
-                                "f64_sweeps_per_split": (mx[2] / mx[0]) if mx[0] else None, "fallbacks_to_fp64": mx[3]},
+                                "f64_jacobi_sweeps_per_split": (mx[2] / mx[0]) if mx[0] else None, "batches_sent_to_fp64_path": mx[3],
+                                "trajectories_finished_by_fp64_jacobi": mx[4], "batches_with_second_polar_step": mx[5]},
                 "traffic": traffic,
                 # PMC bytes of the dominant kernel per batched SVD (bytes per launch x its launches per solve) over the bytes a
                 # factorisation has to move (matrix in, factors out: 2 x 16 n^2 per trajectory)

@@ -297,11 +297,14 @@ int tjm_profile_cross_kernel_read(double* total_ms, double* total_bytes, int64_t
  * applied rotations x rows, sweeps, solves }.  28 real flops per slot-row (8 dot + 20 rotation): bench.py reports the executed
  * flops next to the nominal 88 n^3 of the reference's zgesdd (core/linalg/svd.py:51-104). */
 int tjm_svd_work_read(double* out4, int32_t reset);
-/* Mixed-precision two-site split (fp64 library; square splits of 128 ... 512 rows: an approximate singular basis from the complex64
- * Jacobi, made exactly unitary in fp64, then fp64 Jacobi sweeps on theta times that basis - replaces the same reference lines as
- * tjm_svd_split_qr, core/linalg/svd.py:51-104, core/methods/decompositions.py:105-185).  out5 = { batched splits served, complex64
- * sweeps, fp64 sweeps, batches that fell back to the all-fp64 path, reserved } since the last reset.  Zeros in the complex64 library. */
-int tjm_svd_mixed_read(double* out5, int32_t reset);
+/* Mixed-precision two-site split (fp64 library; square splits of 128 ... 512 rows - replaces the same reference lines as
+ * tjm_svd_split_qr, core/linalg/svd.py:51-104, core/methods/decompositions.py:105-185): an approximate singular basis from the complex64
+ * Jacobi (the same kernels, compiled for complex64 into this library), made exactly unitary in fp64 (polar step) and refined to
+ * rounding by first-order eigenvector corrections from the Gram matrix of theta x basis - all fp64 work on the matrix cores; the fp64
+ * Jacobi kernels only finish single trajectories that fail the final check.  out6 = { batched splits served, complex64 sweeps, fp64
+ * Jacobi sweeps, batches sent back to the all-fp64 path, trajectories finished by the fp64 Jacobi, batches that needed a second polar
+ * step } since the last reset.  Zeros in the complex64 library.  Switch: TJM_NO_MIXED_SPLIT. */
+int tjm_svd_mixed_read(double* out6, int32_t reset);
 
 #ifdef __cplusplus
 }

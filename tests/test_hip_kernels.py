@@ -147,7 +147,7 @@ def test_tridiag_expm_matches_dense(lib, k, dt, scale):
     assert np.allclose(got, ref, atol=5e-13)
 
 
-def svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, min_keep, chiL, chiR, qr=False):
+def svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, min_keep, chiL, chiR, qr=False, want_spec=True):
     from yaqs_amd._lib import check
 
     B = theta.shape[0]
@@ -162,7 +162,7 @@ def svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, mi
     work = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
     sweeps = C.c_int32(0)
     check(fn(th.data_ptr(), B, d, capL, capR, capM, left.data_ptr(), right.data_ptr(), dist, mode, thr, max_bond, min_keep,
-                            chi.data_ptr(), spec.data_ptr(), spec_ld, work.data_ptr(), nbytes, C.byref(sweeps), None), "svd_split")
+                            chi.data_ptr(), spec.data_ptr() if want_spec else None, spec_ld, work.data_ptr(), nbytes, C.byref(sweeps), None), "svd_split")
     _sync()
     return left.cpu().numpy(), right.cpu().numpy(), chi.cpu().numpy()[:, 2], spec.cpu().numpy(), sweeps.value
 

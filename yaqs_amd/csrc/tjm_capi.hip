@@ -458,9 +458,9 @@ int tjm_profile_cross_kernel(int32_t every) {
   return TJM_OK;
 }
 
-int tjm_svd_mixed_read(double* out5, int32_t reset) {
-  if (!out5) return TJM_ERR_ARG;
-  mixed_stats_get(out5, reset != 0);
+int tjm_svd_mixed_read(double* out6, int32_t reset) {
+  if (!out6) return TJM_ERR_ARG;
+  mixed_stats_get(out6, reset != 0);
   return TJM_OK;
 }
 

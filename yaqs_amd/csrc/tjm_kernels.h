@@ -222,6 +222,7 @@ struct JacobiOpts {
   real tol2 = TJM_JACOBI_TOL2;           // squared relative off-diagonal tolerance
   real floor_scale = TJM_NOISE_FLOOR2;   // columns below sqrt(floor_scale) ||X||_F are numerically null (never rotated)
   bool allow_unconverged = false;        // reaching max_sweeps is not an error (the caller refines the result anyway)
+  double stop_fraction = 0.0;            // > 0: stop after a sweep that rotated less than this fraction of all pairs (no confirming sweep)
   bool late_start = false;               // check-first tile kernel from the first sweep on
   bool late_after_first = false;         // check-first tile kernel from the second sweep on, whatever the first one rotated
   bool preloaded = false;                // Y holds X already: column-major, pitch = rows, rows and columns multiples of 64 / 32
@@ -270,7 +271,8 @@ int qr_scatter(const cplx* in, long in_b0, int ld, const ExtractDesc& x, const i
 // Mixed-precision variant of the square two-site split (fp64 library only, tjm_mixed.h): workspace of its complex64 phase.
 struct MixedWorkspace { void* base = nullptr; size_t bytes = 0; int max_dim = 0, B = 0; };
 size_t mixed_split_workspace_bytes(int max_dim, int B);  // 0: not served (complex64 build, size out of range, TJM_NO_MIXED_SPLIT)
-void mixed_stats_get(double* out5, bool reset);          // solves, complex64 sweeps, fp64 sweeps, fallbacks to the fp64 path, (reserved)
+void mixed_stats_get(double* out6, bool reset);          // batched splits, complex64 sweeps, fp64 Jacobi sweeps, batches sent to the fp64 path,
+                                                         // trajectories finished by the fp64 Jacobi, batches that needed a second polar step
 int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out,
                  const MixedWorkspace* mx = nullptr);
 

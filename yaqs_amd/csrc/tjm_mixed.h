@@ -24,6 +24,7 @@ struct MixedBasisDesc {
   int dist;       // the basis is the left singular basis of Z' = theta (0) or theta^H (1), rows of Z' bond-major (a * d + s / c * d + t)
   int nb0;        // trajectories (slots 0 ... nb0 - 1 of the workspace)
   int max_sweeps; // cap on the complex64 sweeps; stopping there is fine, fp64 finishes the job
+  double stop_fraction;  // the complex64 iteration ends after a sweep that rotated less than this fraction of the pairs (0: run to convergence)
   int* h_pinned;  // pinned host ints (>= 8) for the sweep loop's convergence reads
 };
 

@@ -81,6 +81,7 @@ int mixed_left_basis(const MixedBasisDesc& m, void* ws, size_t ws_bytes, int max
   JacobiOpts op;
   op.max_sweeps = m.max_sweeps > 0 ? m.max_sweeps : 12;
   op.allow_unconverged = true;
+  op.stop_fraction = m.stop_fraction;
   // every non-zero column is rotated: a column at the fp32 rounding floor is noise, but noise that has been orthogonalised against
   // the rest is what the polar step of the fp64 side can make exactly unitary (an unrotated one is not); the sweep cap bounds the cost
   op.floor_scale = 0.0f;  // (the caller scales theta so that ||theta||_F ~ 2^24: tiny columns stay far above the fp32 underflow range)

@@ -2041,6 +2041,9 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     }
     if (g_debug && src.ncols >= 128) fprintf(stderr, "[svd] ncols %d rx %d sweep %d live %d rotations %d\n", src.ncols, src.rx, sweep_c, w.h_pinned[0], w.h_pinned[1]);
     n_live = *w.h_pinned;
+    // op.stop_fraction: a caller that refines the result anyway (the complex64 phase of the mixed-precision split) does not pay for
+    // the sweeps that only confirm convergence: the iteration ends after a sweep that rotated less than this fraction of the pairs
+    if (op.stop_fraction > 0.0 && (double)w.h_pinned[1] < op.stop_fraction * 0.5 * (double)ncols_pad * (ncols_pad - 1) * std::max(n_live, 1)) conv_c = true;
     // measured on the MI355X (headline step): fraction 0.25 -> 5.94, 0.7 -> 6.05, 1 (every sweep after the first) -> 5.81 trajectories/s
     static const double late_frac = getenv("TJM_LATE_FRACTION") ? atof(getenv("TJM_LATE_FRACTION")) : 0.7;
     late = !no_late && !accumulate &&
@@ -2340,25 +2343,41 @@ static int svd_split_qr2(const SvdSplitDesc& d, const SvdWorkspace& w, const QrW
 #ifndef TJM_F32
 // ---- mixed-precision two-site split (fp64 library only; tjm_mixed.h) -----------------------------------------------------------
 // Z = theta (dist 0) / theta^H (dist 1) is the matrix whose LEFT singular basis is the isometric factor (the orientation of the
-// direct variant above).  1. complex64: all right singular vectors of Z, approximately (the left singular basis of Z^H by the doubly
-// preconditioned complex64 Jacobi), V0.  2. fp64: one polar step makes it unitary, V = V0 (I + E)^(-1/2) ~ V0 (I - E/2 + 3 E^2 / 8)
-// with E = V0^H V0 - I (||E||_F ~ 1e-6, the remainder 5/16 ||E||^3 is far below rounding; three GEMMs) - checked per trajectory.
-// 3. X1 = Z V (one GEMM, written straight into the Jacobi workspace): the columns of X1 are orthogonal to ~1e-6, so the fp64
-// one-sided Jacobi - no preconditioner needed - converges quadratically: one full sweep, one with a handful of rotations, one that
-// finds nothing to do.  4. As in the direct variant: isometric factor = normalised kept columns of Y = X1 W (here without any
-// reflectors in front), weighted factor = its projection of theta (one GEMM).  Nothing of the complex64 phase survives in the
-// result except the choice of the starting basis: X1 is theta times an exactly unitary matrix.
-// Whatever does not fit (polar residual too large, a kept singular value at the noise floor, no convergence within a few sweeps)
-// makes the whole batch take the all-fp64 path; the counters say how often.
+// direct variant above); N = its size, cm = the storage of the new bond.
+//  1. complex64: all right singular vectors of Z, approximately - the left singular basis of Z^H by the doubly preconditioned
+//     complex64 Jacobi (the pairwise, sequential part of the work at the packed-fp32 rate) - V0, orthonormal to ~2e-6.
+//  2. fp64, matrix cores only.  A polar step makes the basis unitary, V = V0 (I + E)^(-1/2) ~ V0 (I - E/2 + 3 E^2/8), E = V0^H V0 - I,
+//     certified per trajectory through ||E^2||_F.  Then X = Z V has columns orthogonal to ~1e-6, and the Gram matrix G = X^H X says
+//     what is left to do: to first order the unitary that diagonalises G is I + C with C_ij = G_ij / (G_jj - G_ii) (anti-Hermitian),
+//     so V <- V (I + C + C^2/2) squares the off-diagonal part (1e-6 -> 1e-10 -> rounding: quadratic convergence, two rounds, four
+//     GEMMs each).  This is a whole Jacobi sweep done as matrix products - possible because every rotation angle is tiny; a pair
+//     whose angle is not (near-degenerate singular values with a sizeable coupling) gets a clamped correction and, if the final
+//     check still finds it, the trajectory goes to the fp64 Jacobi kernels for the rest (from X, which is nearly diagonal by then).
+//     A last polar step removes what the truncated exponentials left of non-unitarity, X = Z V is formed once more from theta
+//     itself and its Gram matrix is the final check: |G_ij| <= 1e-13 sigma_i sigma_j + 1e-14 ||theta|| max(sigma_i, sigma_j) for
+//     every pair that matters - the second term because X is computed with ABSOLUTE error ~1e-15 ||theta||, so the direction of a
+//     column of norm sigma carries 1e-15 / sigma of noise that no iteration on V can remove.
+//  3. Pairs that do not matter.  The truncation keeps at most cm singular triplets.  Columns beyond cm + 32 (in the complex64
+//     order) only have to stay orthogonal to the first cm + 32; among themselves they are never corrected (C_ij = 0): their squared
+//     norms still add up to the discarded weight exactly, and a scaled Gershgorin bound on their Gram block, read from the same G,
+//     certifies per trajectory that none of their singular values reaches the cm-th largest of the others.  This is where the
+//     complex64 basis is worst (directions below 1e-6 of the largest singular value are noise in fp32), so skipping them also skips
+//     the slowest part of the convergence.  Only for the discarded-weight rules and when no spectrum is asked for.
+//  4. Isometric factor = the kept columns of X, normalised and then made exactly isometric by the same polar step (their
+//     orthogonality is 1e-15 ||theta|| / sigma_k, the absolute error above; the span does not change), weighted factor = its
+//     projection of theta (one GEMM), as in the direct variant.  The product is the projection of theta on the span of the kept
+//     columns of theta V with V unitary to rounding: nothing of the complex64 phase survives except the choice of the starting basis.
+// Whatever does not fit (polar certificate, a kept singular value at the noise floor) sends the whole batch to the all-fp64 path;
+// single trajectories that fail the final check or the Gershgorin certificate are finished by the fp64 Jacobi kernels.
 namespace {
 
 struct float2_t { float x, y; };
 
-// scale[b] = the power of two that brings ||theta_b||_F to about 2^24.  The complex64 rotation set-up squares squared column norms
-// (tjm_svd.hip: make_rotation): with ||X||_F ~ 1 a column at 1e-8 of the largest one underflows there and is never rotated; scaled
-// like this, columns from 1e7 down to the fp32 rounding floor of the matrix (and its own smallest singular values) stay inside the range.  Singular vectors do not
-// depend on the scale, and a power of two changes no mantissa.
-__global__ __launch_bounds__(256) void c64_scale_kernel(const cplx* __restrict__ in, long in_b0, long n, real* __restrict__ scale) {
+// scale[b] = the power of two that brings ||theta_b||_F to about 2^24 ; fro2[b] = ||theta_b||_F^2.  The complex64 rotation set-up
+// squares squared column norms (make_rotation): with ||X||_F ~ 1 a column at 1e-8 of the largest one underflows there and is never
+// rotated; scaled like this, columns from 1e7 down to the fp32 rounding floor of the matrix (and its own smallest singular values)
+// stay inside the range.  Singular vectors do not depend on the scale, and a power of two changes no mantissa.
+__global__ __launch_bounds__(256) void c64_scale_kernel(const cplx* __restrict__ in, long in_b0, long n, real* __restrict__ scale, real* __restrict__ fro2) {
   __shared__ real sh[4];
   const cplx* ib = in + (long)blockIdx.x * in_b0;
   real acc = 0.0;
@@ -2374,6 +2393,7 @@ __global__ __launch_bounds__(256) void c64_scale_kernel(const cplx* __restrict__
     int e = 0;
     if (f2 > 0.0 && f2 == f2 && f2 < 1e300) frexp(f2, &e);  // f2 = m 2^e, 0.5 <= m < 1
     scale[blockIdx.x] = ldexp(1.0, 24 - e / 2);
+    fro2[blockIdx.x] = f2;
   }
 }
 
@@ -2397,26 +2417,17 @@ __global__ __launch_bounds__(256) void from_c64_kernel(const float2_t* __restric
   }
 }
 
-// E <- E - I (row-major N x N) ; fro2[b] += ||E||_F^2
-__global__ __launch_bounds__(256) void polar_residual_kernel(cplx* __restrict__ E, long e_b0, int N, real* __restrict__ fro2) {
-  __shared__ real sh[4];
+// E <- E - diag(1 for i < keep) (row-major n x n; keep == nullptr: the whole diagonal)
+__global__ __launch_bounds__(256) void polar_residual_kernel(cplx* __restrict__ E, long e_b0, int n, const int* __restrict__ keep, int keep_stride) {
   cplx* Eb = E + (long)blockIdx.y * e_b0;
-  const long total = (long)N * N;
-  real acc = 0.0;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    cplx v = Eb[e];
-    if (e / N == e % N) { v.x -= 1.0; Eb[e] = v; }
-    acc = fma(v.x, v.x, fma(v.y, v.y, acc));
-  }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&fro2[blockIdx.y], sh[0] + sh[1] + sh[2] + sh[3]);
+  const int kp = keep ? keep[(long)blockIdx.y * keep_stride] : n;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kp && i < n; i += gridDim.x * blockDim.x) Eb[(long)i * n + i].x -= 1.0;
 }
 
-// T = I - E / 2 + 3 E2 / 8 ; e2fro2[b] += ||E2||_F^2   (E Hermitian: ||E||_2^2 = ||E^2||_2 <= ||E^2||_F, the certificate below)
+// T = I - E / 2 + c2 E2 (c2 = 3/8: the series to second order; 0: first order) ; e2fro2[b] += ||E2||_F^2
+// (E Hermitian: ||E||_2^2 = ||E^2||_2 <= ||E^2||_F, the certificate below)
 __global__ __launch_bounds__(256) void polar_poly_kernel(const cplx* __restrict__ E, long e_b0, const cplx* __restrict__ E2, long e2_b0,
-                                                        cplx* __restrict__ T, long t_b0, int N, real* __restrict__ e2fro2) {
+                                                        cplx* __restrict__ T, long t_b0, int N, real c2, real* __restrict__ e2fro2) {
   __shared__ real sh[4];
   const cplx* Eb = E + (long)blockIdx.y * e_b0;
   const cplx* Fb = E2 + (long)blockIdx.y * e2_b0;
@@ -2425,7 +2436,7 @@ __global__ __launch_bounds__(256) void polar_poly_kernel(const cplx* __restrict_
   real acc = 0.0;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const cplx a = Eb[e], b = Fb[e];
-    cplx v{fma(0.375, b.x, -0.5 * a.x), fma(0.375, b.y, -0.5 * a.y)};
+    cplx v{fma(c2, b.x, -0.5 * a.x), fma(c2, b.y, -0.5 * a.y)};
     if (e / N == e % N) v.x += 1.0;
     Tb[e] = v;
     acc = fma(b.x, b.x, fma(b.y, b.y, acc));
@@ -2433,32 +2444,158 @@ __global__ __launch_bounds__(256) void polar_poly_kernel(const cplx* __restrict_
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&e2fro2[blockIdx.y], sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0 && e2fro2) atomicAdd(&e2fro2[blockIdx.y], sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
-// flag |= 1 when a trajectory's certificate fails: the polar series I - E/2 + 3 E^2/8 leaves (5/16) ||E||_2^3 <= (5/16) ||E^2||_F^(3/2),
-// which has to stay at the level of the Jacobi tolerance (1e-13) for X1 to be theta times a unitary matrix to that accuracy
+// flag |= 1 when a trajectory's certificate fails: the polar series I - E/2 + 3 E^2/8 leaves (5/16) ||E||_2^3 <= (5/16) ||E^2||_F^(3/2)
 __global__ void polar_check_kernel(const real* e2fro2, int nb0, real tol2, int* flag) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < nb0 && !(e2fro2[b] <= tol2)) atomicOr(flag, 1);
 }
 
-struct MixedStats { long solves = 0, c64_sweeps = 0, f64_sweeps = 0, fallbacks = 0; double worst_residual2 = 0.0; };
+// Does the pair (i, j) of the Gram matrix still need work?  d_i, d_j its squared column norms, f2 = |G_ij|^2, tr = ||theta||_F^2.
+__device__ inline bool pair_open(real di, real dj, real f2, real tr) {
+  const real floor2 = TJM_NOISE_FLOOR2 * tr;
+  if (!(di > floor2 && dj > floor2)) return false;                       // a numerically null column: nothing to orthogonalise
+  const real dmax = di > dj ? di : dj;
+  return f2 > TJM_JACOBI_TOL2 * di * dj + real(1e-28) * tr * dmax;        // (1e-13 sigma_i sigma_j)^2 + (1e-14 ||theta|| sigma_max)^2
+}
+
+// Columns that are not corrected among themselves (point 3): position >= cm always (never kept), and either beyond skip_col or at the
+// rounding floor of the complex64 arithmetic (sigma < 1e-5 ||theta||: their directions are noise in fp32 wherever they sit).
+__device__ inline bool far_column(int j, real dj, int cm, int skip_col, real tr) { return j >= cm && (j >= skip_col || dj < real(1e-10) * tr); }
+
+// First-order correction of the basis from the Gram matrix G = X^H X (row-major N x N): C_ij = G_ij / (G_jj - G_ii) for the open pairs
+// that are not both "far" columns and whose angle |C_ij| is at most zmax; 0 elsewhere.  C is anti-Hermitian by construction.
+__global__ __launch_bounds__(256) void refine_corr_kernel(const cplx* __restrict__ G, long g_b0, int N, int skip_col, int cm, const real* __restrict__ fro2,
+                                                         real zmax, cplx* __restrict__ Cm, long c_b0) {
+  const cplx* Gb = G + (long)blockIdx.y * g_b0;
+  cplx* Cb = Cm + (long)blockIdx.y * c_b0;
+  const real tr = fro2[blockIdx.y];
+  const long total = (long)N * N;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(e / N), j = (int)(e % N);
+    cplx c{0.0, 0.0};
+    if (i != j) {
+      const real di = Gb[(long)i * N + i].x, dj = Gb[(long)j * N + j].x;
+      const cplx f = Gb[e];
+      const real f2 = fma(f.x, f.x, f.y * f.y);
+      if (!(far_column(i, di, cm, skip_col, tr) && far_column(j, dj, cm, skip_col, tr)) && pair_open(di, dj, f2, tr)) {
+        const real gap = dj - di;
+        const real ag = fabs(gap), af = sqrt(f2);
+        // a (near-)degenerate pair whose angle is not small is left alone: one bounded step would spoil the quadratic convergence
+        // of every pair that shares a column with it (cross terms zmax x |C|), and inside K or inside the complement the mixing is
+        // harmless; if it straddles the truncation the final check sends the trajectory to the Jacobi kernels
+        if (af <= zmax * ag) { const real inv = 1.0 / gap; c = cplx{f.x * inv, f.y * inv}; }
+      }
+    }
+    Cb[e] = c;
+  }
+}
+
+// T = I + C + C2 / 2   (exp(C) to second order: unitary up to |C|^3 / 6, which the last polar step removes)
+__global__ __launch_bounds__(256) void refine_poly_kernel(const cplx* __restrict__ Cm, long c_b0, const cplx* __restrict__ C2, long c2_b0,
+                                                         cplx* __restrict__ T, long t_b0, int N) {
+  const cplx* Cb = Cm + (long)blockIdx.y * c_b0;
+  const cplx* Db = C2 + (long)blockIdx.y * c2_b0;
+  cplx* Tb = T + (long)blockIdx.y * t_b0;
+  const long total = (long)N * N;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const cplx a = Cb[e], b = Db[e];
+    cplx v{fma(0.5, b.x, a.x), fma(0.5, b.y, a.y)};
+    if (e / N == e % N) v.x += 1.0;
+    Tb[e] = v;
+  }
+}
+
+// Final check on G = X^H X, one workgroup per trajectory, after svd_finish_kernel has ranked the columns by norm and applied the
+// truncation rule (perm, keep).  K = the kept columns.  What the result needs:
+//   bit 0  every kept column is a singular direction with respect to everything that is not kept: the tilt |G_ij| / |d_i - d_j| of a
+//          pair (i in K, j not in K) is at most 1e-13 (plus the rounding floor of X, 1e-14 ||theta|| sigma_i / d_i);
+//   bit 1  nothing outside K has a singular value above the smallest kept one: with D = diag(sigma) the matrix D^-1 G_cc D of the
+//          complement has the eigenvalues of G_cc and row sums d_i + sum_j |G_ij| sigma_j / sigma_i, so the largest of those bounds
+//          its largest squared singular value (scaled Gershgorin) - it has to stay below the smallest kept squared norm;
+//   bit 2  the kept columns are orthogonal to 1e-5 among themselves (their polar step takes it from there; a near-degenerate pair
+//          that the correction left alone sits at the 2e-6 of the complex64 basis).
+// Pairs inside K or inside the complement do not have to be diagonal: mixing them changes neither span.
+__global__ __launch_bounds__(256) void refine_check_kernel(const cplx* __restrict__ G, long g_b0, int N, const real* __restrict__ fro2,
+                                                          const int* __restrict__ perm_all, const int* __restrict__ keep_all, int keep_stride,
+                                                          int* __restrict__ status, int* __restrict__ n_bad) {
+  __shared__ real sd[1024];
+  __shared__ unsigned char inK[1024];
+  __shared__ int s_flags;
+  __shared__ real s_bound[4];
+  __shared__ real s_min;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const cplx* Gb = G + (long)b * g_b0;
+  const int* perm = perm_all + (long)b * N;
+  const int keep = keep_all[(long)b * keep_stride];
+  const real tr = fro2[b];
+  for (int i = tid; i < N; i += 256) { sd[i] = Gb[(long)i * N + i].x; inK[i] = 0; }
+  if (tid == 0) s_flags = 0;
+  __syncthreads();
+  for (int k = tid; k < keep; k += 256) inK[perm[k]] = 1;
+  if (tid == 0) s_min = keep > 0 ? sd[perm[keep - 1]] : real(0.0);
+  __syncthreads();
+  int flags = 0;
+  const long total = (long)N * N;
+  for (long e = tid; e < total; e += 256) {
+    const int i = (int)(e / N), j = (int)(e % N);
+    if (i >= j) continue;
+    const cplx f = Gb[e];
+    const real f2 = fma(f.x, f.x, f.y * f.y);
+    const real di = sd[i], dj = sd[j];
+    if (inK[i] != inK[j]) {
+      const real gap = di - dj, dmax = di > dj ? di : dj;
+      if (f2 > real(1e-26) * gap * gap + real(1e-28) * tr * dmax) flags |= 1;
+    } else if (inK[i]) {
+      if (f2 > real(1e-10) * di * dj) flags |= 4;
+    }
+  }
+  real bound = 0.0;
+  for (int i = tid; i < N; i += 256) {
+    if (inK[i]) continue;
+    const real di = sd[i];
+    real row = di;
+    if (di > 0.0) {
+      const real isi = 1.0 / sqrt(di);
+      for (int j = 0; j < N; ++j)
+        if (j != i && !inK[j]) { const cplx f = Gb[(long)i * N + j]; row = fma(sqrt(fma(f.x, f.x, f.y * f.y) * sd[j]), isi, row); }
+    }
+    bound = row > bound ? row : bound;
+  }
+  for (int off = 32; off > 0; off >>= 1) { const real o = __shfl_down(bound, off); bound = o > bound ? o : bound; }
+  if ((tid & 63) == 0) s_bound[tid >> 6] = bound;
+  if (flags) atomicOr(&s_flags, flags);
+  __syncthreads();
+  if (tid == 0) {
+    int st = s_flags;
+    real bmax = s_bound[0];
+    for (int k = 1; k < 4; ++k) bmax = s_bound[k] > bmax ? s_bound[k] : bmax;
+    if (keep > 0 && keep < N && !(bmax <= s_min)) st |= 2;
+    status[b] = st;
+    if (st) atomicAdd(n_bad, 1);
+  }
+}
+
+struct MixedStats { long solves = 0, c64_sweeps = 0, f64_sweeps = 0, fallbacks = 0, jacobi_trajectories = 0, second_polar = 0; };
 MixedStats g_mixed;
 
 }  // namespace
 
-void mixed_stats_get(double* out5, bool reset) {
+void mixed_stats_get(double* out6, bool reset) {
   std::lock_guard<std::mutex> lock(g_prof_mutex);
-  out5[0] = (double)g_mixed.solves; out5[1] = (double)g_mixed.c64_sweeps; out5[2] = (double)g_mixed.f64_sweeps;
-  out5[3] = (double)g_mixed.fallbacks; out5[4] = g_mixed.worst_residual2;
+  out6[0] = (double)g_mixed.solves; out6[1] = (double)g_mixed.c64_sweeps; out6[2] = (double)g_mixed.f64_sweeps;
+  out6[3] = (double)g_mixed.fallbacks; out6[4] = (double)g_mixed.jacobi_trajectories; out6[5] = (double)g_mixed.second_polar;
   if (reset) g_mixed = MixedStats();
 }
 
 size_t mixed_split_workspace_bytes(int max_dim, int B) {
   static const bool off = getenv("TJM_NO_MIXED_SPLIT") != nullptr;
   if (off || max_dim < 128 || max_dim > 512 || max_dim % 64 != 0) return 0;
-  return tjm32::mixed_workspace_bytes(max_dim, B) + 256;
+  // the complex64 phase, two more fp64 matrices per trajectory next to the four of the (idle) fp64 preconditioner, a status word
+  return tjm32::mixed_workspace_bytes(max_dim, B) + 2 * (((size_t)B * max_dim * max_dim * sizeof(cplx) + 255) / 256 * 256) +
+         2 * (((size_t)B * sizeof(int) + 255) / 256 * 256) + 1024;
 }
 
 bool mixed_split_fits(const SvdSplitDesc& d, const QrWorkspace& q, const MixedWorkspace* mx) {
@@ -2466,7 +2603,7 @@ bool mixed_split_fits(const SvdSplitDesc& d, const QrWorkspace& q, const MixedWo
   if (off || mx == nullptr || mx->base == nullptr || q.Z2 == nullptr || d.ids != nullptr) return false;
   if (d.distribution != 0 && d.distribution != 1) return false;
   if (d.m != d.n || d.ld_theta != d.n || d.m < 128 || d.m % 64 != 0 || d.m > mx->max_dim || d.nb0 > mx->B) return false;
-  return d.capM <= d.m && (long)d.m * d.m <= q.z_b0;
+  return d.capM <= d.m && (long)d.m * d.m <= q.z_b0 && (long)d.m * d.m <= q.v_b0;
 }
 
 // returns TJM_OK with *done = true when the outputs are written, *done = false when the batch has to take the fp64 path
@@ -2478,69 +2615,117 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   int rc;
   int gx = (int)((nn + 1023) / 1024);
   if (gx > 128) gx = 128;
+  // ---- workspace: [complex64 phase | fp64 matrix | fp64 matrix | status | id list]
+  const size_t c64_bytes = tjm32::mixed_workspace_bytes(mx.max_dim, mx.B);
+  const size_t mat_bytes = ((size_t)mx.B * mx.max_dim * mx.max_dim * sizeof(cplx) + 255) / 256 * 256;
+  char* tail = static_cast<char*>(mx.base) + (c64_bytes + 255) / 256 * 256;
+  if ((size_t)(tail - static_cast<char*>(mx.base)) + 2 * mat_bytes + 2 * (((size_t)mx.B * sizeof(int) + 255) / 256 * 256) > mx.bytes) return TJM_ERR_WORKSPACE;
+  const long x_b0 = (long)mx.max_dim * mx.max_dim;
+  cplx* S2 = reinterpret_cast<cplx*>(tail);                 // squares (E^2, C^2)
+  cplx* Iso = reinterpret_cast<cplx*>(tail + mat_bytes);    // the kept columns before their polar step
+  int* status = reinterpret_cast<int*>(tail + 2 * mat_bytes);
+  int* idlist = status + (((size_t)mx.B * sizeof(int) + 255) / 256 * 256) / sizeof(int);
+  // fp64 matrices in the buffers of the (idle) fp64 preconditioner
+  cplx* Va = q.Z;  cplx* Vb = q.Z2;  const long v_b0 = q.z_b0;  // the basis, ping-pong (N x N column-major)
+  cplx* Gm = q.V;  cplx* Cm = q.V2;  const long g_b0 = q.v_b0;  // Gram matrix / series, correction (N x N row-major)
+  real* scale = w.norms;            // [B] scratch until the finish kernel writes the norms
+  real* e2fro2 = w.norms + nb;      // [B]
+  real* fro2 = w.fro2;              // [B] ||theta||_F^2 (the fp64 Jacobi of a fallback recomputes it: same quantity)
+  int* flag = w.n_active + 3;
+
   float2_t* th32 = static_cast<float2_t*>(mx.base);
-  const long th32_b0 = (long)mx.max_dim * mx.max_dim;
-  hipLaunchKernelGGL(c64_scale_kernel, dim3(nb), dim3(256), 0, s, d.theta, d.theta_b0, nn, w.fro2);  // w.fro2: free until the fp64 sweeps
-  hipLaunchKernelGGL(to_c64_kernel, dim3(gx, nb), dim3(256), 0, s, d.theta, d.theta_b0, th32, th32_b0, nn, w.fro2);
+  hipLaunchKernelGGL(c64_scale_kernel, dim3(nb), dim3(256), 0, s, d.theta, d.theta_b0, nn, scale, fro2);
+  hipLaunchKernelGGL(to_c64_kernel, dim3(gx, nb), dim3(256), 0, s, d.theta, d.theta_b0, th32, x_b0, nn, scale);
   TJM_HIP_CHECK(hipGetLastError());
   tjm32::MixedBasisDesc mb;
   mb.N = N; mb.d = d.d; mb.dist = 1 - d.distribution; mb.nb0 = nb; mb.h_pinned = w.h_pinned;
   static const int c64_cap = getenv("TJM_MIXED_C64_SWEEPS") ? atoi(getenv("TJM_MIXED_C64_SWEEPS")) : 10;
   mb.max_sweeps = c64_cap;
+  static const double c64_stop = getenv("TJM_MIXED_C64_STOP") ? atof(getenv("TJM_MIXED_C64_STOP")) : 0.1;
+  mb.stop_fraction = c64_stop;
   const void* basis = nullptr;
   long basis_b0 = 0;
   int c64_sweeps = 0;
-  if ((rc = tjm32::mixed_left_basis(mb, mx.base, mx.bytes, mx.max_dim, mx.B, s, &basis, &basis_b0, &c64_sweeps)) != TJM_OK) return rc;
-  // fp64 temporaries: the buffers of the (unused) fp64 preconditioner
-  cplx* V0 = q.Z;   const long v0_b0 = q.z_b0;   // N x N column-major
-  cplx* E = q.Z2;   const long e_b0 = q.z_b0;    // N x N row-major, later V (column-major)
-  cplx* E2 = q.V;   const long e2_b0 = q.v_b0;
-  cplx* T = q.V2;   const long t_b0 = q.v_b0;
-  if (q.v_b0 < nn) return TJM_ERR_WORKSPACE;
-  hipLaunchKernelGGL(from_c64_kernel, dim3(gx, nb), dim3(256), 0, s, static_cast<const float2_t*>(basis), basis_b0, V0, v0_b0, nn);
-  auto blank = [&]() { GemmDesc g; memset(&g, 0, sizeof(g)); g.nks = 1; g.nb0 = nb; g.nb1 = 1; g.nb2 = 1; g.M = N; g.N = N; g.K = N; return g; };
-  {  // E = V0^H V0
-    GemmDesc g = blank();
-    g.A = V0; g.a_rs = N; g.a_cs = 1; g.a_b0 = v0_b0; g.conjA = 1;
-    g.B = V0; g.b_rs = 1; g.b_cs = N; g.b_b0 = v0_b0;
-    g.C = E; g.c_rs = N; g.c_b0 = e_b0;
-    if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
-  }
-  real* fro2 = w.norms;        // [B] scratch: ||E||_F^2 (diagnostic) and ...
-  real* e2fro2 = w.norms + nb;  // ... [B] ||E^2||_F^2 (certificate); the norms are written by the finish kernel long after this
-  int* flag = w.n_active + 3;
-  TJM_HIP_CHECK(hipMemsetAsync(fro2, 0, (size_t)2 * nb * sizeof(real), s));
-  TJM_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
-  hipLaunchKernelGGL(polar_residual_kernel, dim3(gx, nb), dim3(256), 0, s, E, e_b0, N, fro2);
-  if (g_debug) {
-    std::vector<real> h(nb);
-    TJM_HIP_CHECK(hipMemcpyAsync(h.data(), fro2, (size_t)nb * sizeof(real), hipMemcpyDeviceToHost, s));
-    TJM_HIP_CHECK(hipStreamSynchronize(s));
-    real worst = 0.0;
-    for (int b = 0; b < nb; ++b) worst = (h[b] > worst || h[b] != h[b]) ? h[b] : worst;
-    fprintf(stderr, "[svd-mixed] polar residual ||V0^H V0 - I||_F: worst %.3e\n", sqrt(worst));
-    if (getenv("TJM_DEBUG_MIXED_E")) {  // where is the residual: largest entries of E of trajectory 0
-      std::vector<cplx> he((size_t)nn);
-      TJM_HIP_CHECK(hipMemcpy(he.data(), E, (size_t)nn * sizeof(cplx), hipMemcpyDeviceToHost));
-      for (int rep = 0; rep < 6; ++rep) {
-        double best = -1.0; long at = 0;
-        for (long e = 0; e < nn; ++e) { const double m = he[e].x * he[e].x + he[e].y * he[e].y; if (m > best) { best = m; at = e; } }
-        fprintf(stderr, "[svd-mixed]   |E[%ld][%ld]| = %.3e\n", at / N, at % N, sqrt(best));
-        he[at] = cplx{0.0, 0.0};
-      }
+  if ((rc = tjm32::mixed_left_basis(mb, mx.base, c64_bytes, mx.max_dim, mx.B, s, &basis, &basis_b0, &c64_sweeps)) != TJM_OK) return rc;
+  hipLaunchKernelGGL(from_c64_kernel, dim3(gx, nb), dim3(256), 0, s, static_cast<const float2_t*>(basis), basis_b0, Va, v_b0, nn);
+
+  auto square = [&](int n) { GemmDesc g; memset(&g, 0, sizeof(g)); g.nks = 1; g.nb0 = nb; g.nb1 = 1; g.nb2 = 1; g.M = n; g.N = n; g.K = n; return g; };
+  // Gram matrix of a column-major N x N matrix: G[i][j] = sum_r conj(A[r + i N]) A[r + j N]
+  auto gram = [&](const cplx* A, long a_b0, cplx* G, long gb0) {
+    GemmDesc g = square(N);
+    g.A = A; g.a_rs = N; g.a_cs = 1; g.a_b0 = a_b0; g.conjA = 1;
+    g.B = A; g.b_rs = 1; g.b_cs = N; g.b_b0 = a_b0;
+    g.C = G; g.c_rs = N; g.c_b0 = gb0;
+    return launch_gemm(g, s);
+  };
+  // row-major product of two row-major N x N matrices
+  auto rowmul = [&](const cplx* A, long a_b0, const cplx* Bm, long b_b0, cplx* Cc, long c_b0) {
+    GemmDesc g = square(N);
+    g.A = A; g.a_rs = N; g.a_cs = 1; g.a_b0 = a_b0;
+    g.B = Bm; g.b_rs = N; g.b_cs = 1; g.b_b0 = b_b0;
+    g.C = Cc; g.c_rs = N; g.c_b0 = c_b0;
+    return launch_gemm(g, s);
+  };
+  // column-major Vout = Vin T (T row-major), written as the row-major matrix C[j][r] = sum_i T[i][j] Vin[r + i N]
+  auto apply = [&](const cplx* Vin, const cplx* T, long t_b0, cplx* Vout) {
+    GemmDesc g = square(N);
+    g.A = T; g.a_rs = 1; g.a_cs = N; g.a_b0 = t_b0;
+    g.B = Vin; g.b_rs = N; g.b_cs = 1; g.b_b0 = v_b0;
+    g.C = Vout; g.c_rs = N; g.c_b0 = v_b0;
+    return launch_gemm(g, s);
+  };
+  // polar step Vin -> Vout; second = true: series to second order, cert accumulates ||E^2||_F^2 per trajectory;
+  // second = false: I - E/2 only (for ||E|| <~ 1e-6 the second-order term is below rounding)
+  auto polar = [&](const cplx* Vin, cplx* Vout, bool second, real* cert) {
+    int r;
+    if ((r = gram(Vin, v_b0, Gm, g_b0)) != TJM_OK) return r;
+    hipLaunchKernelGGL(polar_residual_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, Gm, g_b0, N, (const int*)nullptr, 0);
+    if (second) {
+      if ((r = rowmul(Gm, g_b0, Gm, g_b0, S2, x_b0)) != TJM_OK) return r;
+      hipLaunchKernelGGL(polar_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, S2, x_b0, Cm, g_b0, N, real(0.375), cert);
+    } else {
+      hipLaunchKernelGGL(polar_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, Gm, g_b0, Cm, g_b0, N, real(0.0), (real*)nullptr);
     }
-  }
-  {  // E2 = E E
-    GemmDesc g = blank();
-    g.A = E; g.a_rs = N; g.a_cs = 1; g.a_b0 = e_b0;
-    g.B = E; g.b_rs = N; g.b_cs = 1; g.b_b0 = e_b0;
-    g.C = E2; g.c_rs = N; g.c_b0 = e2_b0;
-    if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
-  }
-  hipLaunchKernelGGL(polar_poly_kernel, dim3(gx, nb), dim3(256), 0, s, E, e_b0, E2, e2_b0, T, t_b0, N, e2fro2);
+    return apply(Vin, Cm, g_b0, Vout);
+  };
+  // X = Z V into the Jacobi workspace, column-major: Y[k N + r] = sum_(bond, phys) V[(bond d + phys) + k N] Z[r][(phys, bond)]
+  auto form_x = [&](const cplx* V) {
+    GemmDesc g = square(N);
+    g.nks = d.d;
+    g.A = V; g.a_rs = N; g.a_cs = d.d; g.a_ks = 1; g.a_b0 = v_b0;
+    g.B = d.theta; g.b_b0 = d.theta_b0;
+    if (d.distribution == 0) {  // Z = theta: r = (s, a), sum over (t, c)
+      g.K = d.capR; g.b_rs = 1; g.b_cs = d.ld_theta; g.b_ks = d.capR;
+    } else {                    // Z = theta^H: r = (t, c), sum over (s, a) of conj(theta[(s, a)][r])
+      g.K = d.capL; g.b_rs = d.ld_theta; g.b_cs = 1; g.b_ks = (long)d.capL * d.ld_theta; g.conjB = 1;
+    }
+    g.C = w.Y; g.c_rs = N; g.c_b0 = w.y_b0;
+    return launch_gemm(g, s);
+  };
+  if (nn > w.y_b0) return TJM_ERR_WORKSPACE;
+
+  // ---- polar step of the complex64 basis, certified
+  TJM_HIP_CHECK(hipMemsetAsync(e2fro2, 0, (size_t)nb * sizeof(real), s));
+  TJM_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
+  if ((rc = polar(Va, Vb, true, e2fro2)) != TJM_OK) return rc;
   // (5/16) ||E^2||_F^(3/2) <= 1e-13  <=>  ||E^2||_F^2 <= 2.2e-17 ; anything larger says the complex64 basis is not what it should be
   hipLaunchKernelGGL(polar_check_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, e2fro2, nb, real(2.2e-17), flag);
   TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 6, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  TJM_HIP_CHECK(hipStreamSynchronize(s));
+  cplx* Vstart = Vb;
+  cplx* Vspare = Va;
+  if (w.h_pinned[6] != 0) {
+    // the complex64 iteration stopped a little early for some trajectory (its basis is orthonormal to 1e-5 rather than 2e-6): the
+    // polar iteration converges cubically, a second step of the same kind brings every residual to rounding - and is certified again
+    TJM_HIP_CHECK(hipMemsetAsync(e2fro2, 0, (size_t)nb * sizeof(real), s));
+    TJM_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
+    if ((rc = polar(Vb, Va, true, e2fro2)) != TJM_OK) return rc;
+    hipLaunchKernelGGL(polar_check_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, e2fro2, nb, real(2.2e-17), flag);
+    TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 6, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    std::swap(Vstart, Vspare);
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    ++g_mixed.second_polar;
+  }
   if (g_debug) {
     std::vector<real> h(nb);
     TJM_HIP_CHECK(hipMemcpyAsync(h.data(), e2fro2, (size_t)nb * sizeof(real), hipMemcpyDeviceToHost, s));
@@ -2549,87 +2734,150 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     for (int b = 0; b < nb; ++b) worst = (h[b] > worst || h[b] != h[b]) ? h[b] : worst;
     fprintf(stderr, "[svd-mixed] certificate ||E^2||_F: worst %.3e (limit 4.7e-9)\n", sqrt(worst));
   }
-  cplx* V = E;  // column-major N x N: V[r + j N] = sum_i V0[r + i N] T[i][j], written as the row-major matrix C[j][r]
-  {
-    GemmDesc g = blank();
-    g.A = T; g.a_rs = 1; g.a_cs = N; g.a_b0 = t_b0;
-    g.B = V0; g.b_rs = N; g.b_cs = 1; g.b_b0 = v0_b0;
-    g.C = V; g.c_rs = N; g.c_b0 = e_b0;
-    if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
+  // ---- quadratic refinement on the matrix cores
+  // columns beyond skip_col are not corrected among themselves (point 3 above)
+  const bool can_skip = (d.trunc_mode == 0 || d.trunc_mode == 3) && d.spectrum == nullptr && getenv("TJM_MIXED_NO_SKIP") == nullptr;
+  const int skip_col = (can_skip && cm + 32 <= N - 32) ? cm + 32 : N;
+  const int cm_far = can_skip ? cm : N;  // first position a never-corrected column may have (N: every pair is corrected)
+  static const int n_ref = getenv("TJM_MIXED_REFINE") ? atoi(getenv("TJM_MIXED_REFINE")) : 2;
+  cplx* Vcur = Vstart;
+  cplx* Vnext = Vspare;
+  for (int it = 0; it < n_ref; ++it) {
+    if ((rc = form_x(Vcur)) != TJM_OK) return rc;
+    if ((rc = gram(w.Y, w.y_b0, Gm, g_b0)) != TJM_OK) return rc;
+    hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(0.01), Cm, g_b0);
+    if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0)) != TJM_OK) return rc;
+    hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);
+    if ((rc = apply(Vcur, Gm, g_b0, Vnext)) != TJM_OK) return rc;
+    std::swap(Vcur, Vnext);
   }
-  if ((long)N * N > w.y_b0) return TJM_ERR_WORKSPACE;
-  {  // X1 = Z V into the Jacobi workspace, column-major: Y[k * N + r] = sum_(bond, phys) V[(bond * d + phys) + k N] Z[r][(phys, bond)]
-    GemmDesc g = blank();
-    g.nks = d.d;
-    g.A = V; g.a_rs = N; g.a_cs = d.d; g.a_ks = 1; g.a_b0 = e_b0;
-    g.B = d.theta; g.b_b0 = d.theta_b0;
-    if (d.distribution == 0) {  // Z = theta: r = (s, a), sum over (t, c)
-      g.K = d.capR; g.b_rs = 1; g.b_cs = d.ld_theta; g.b_ks = d.capR;
-    } else {                    // Z = theta^H: r = (t, c), sum over (s, a) of conj(theta[(s, a)][r])
-      g.K = d.capL; g.b_rs = d.ld_theta; g.b_cs = 1; g.b_ks = (long)d.capL * d.ld_theta; g.conjB = 1;
-    }
-    g.C = w.Y; g.c_rs = N; g.c_b0 = w.y_b0;
-    if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
+  if (n_ref > 0) {  // the truncated exponentials are unitary to |C|^3 / 6 <= 2e-7 (|C_ij| <= 0.01): a last, first-order polar step
+    if ((rc = polar(Vcur, Vnext, false, nullptr)) != TJM_OK) return rc;
+    std::swap(Vcur, Vnext);
   }
-  JacobiSource src;
-  src.src = nullptr; src.src_b0 = 0; src.rx = N; src.ncols = N; src.conj = 0; src.tri = 0;
-  src.r_n0 = N; src.s_r1 = 0; src.s_r0 = 0; src.c_n0 = N; src.s_c1 = 0; src.s_c0 = 0;
-  src.nb0 = nb; src.ids = nullptr;
+  if ((rc = form_x(Vcur)) != TJM_OK) return rc;
+  if ((rc = gram(w.Y, w.y_b0, Gm, g_b0)) != TJM_OK) return rc;
   TruncSpec tr;
   tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
   tr.cap = d.capM; tr.overflow = d.overflow;
   tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
   tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
-  JacobiOpts op;
-  op.preloaded = true;
-  op.late_after_first = true;
-  static const int f64_cap = getenv("TJM_MIXED_F64_SWEEPS") ? atoi(getenv("TJM_MIXED_F64_SWEEPS")) : 12;
-  op.max_sweeps = f64_cap;
-  op.allow_unconverged = true;  // the caller decides below
   JacobiShape sh;
-  int f64_sweeps = 0;
-  if ((rc = jacobi_solve(src, tr, w, s, &sh, &f64_sweeps, false, &op)) != TJM_OK) return rc;
-  TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 7, w.n_active + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+  sh.ncols_pad = N; sh.rx_top = N; sh.rtot = N;
+  // norms, order, truncation of every trajectory from the columns of X; then the check of what was kept
+  TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 2, 0, sizeof(int), s));
+  TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 5, 0, sizeof(int), s));
+  hipLaunchKernelGGL(svd_finish_kernel, dim3(nb), dim3(256), 0, s, tr, w, N, N, N, (const int*)nullptr);
+  hipLaunchKernelGGL(refine_check_kernel, dim3(nb), dim3(256), 0, s, Gm, g_b0, N, fro2, w.perm, d.chiM, d.chi_stride, status, w.n_active + 5);
+  TJM_HIP_CHECK(hipGetLastError());
+  TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 7, w.n_active + 5, sizeof(int), hipMemcpyDeviceToHost, s));
+  TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 8, w.n_active + 2, sizeof(int), hipMemcpyDeviceToHost, s));
   TJM_HIP_CHECK(hipStreamSynchronize(s));
-  const bool bad_polar = w.h_pinned[6] != 0, floor_kept = w.h_pinned[7] != 0, slow = f64_sweeps >= f64_cap;
+  const bool bad_polar = w.h_pinned[6] != 0;
+  const int n_bad = w.h_pinned[7];
+  bool floor_kept = w.h_pinned[8] != 0;
+  if (g_debug) fprintf(stderr, "[svd-mixed] N %d c64 sweeps %d polar %d floor %d trajectories left to the fp64 Jacobi %d of %d\n", N, c64_sweeps, (int)bad_polar, (int)floor_kept, n_bad, nb);
+  if (bad_polar || floor_kept) {
+    // polar certificate failed, or a kept singular value at the noise floor (the completing variant of the fp64 path serves it)
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    ++g_mixed.solves; ++g_mixed.fallbacks; g_mixed.c64_sweeps += c64_sweeps;
+    return TJM_OK;  // *done stays false: theta is untouched, the caller runs the fp64 path
+  }
+  int f64_sweeps = 0;
+  if (n_bad > 0) {
+    // the trajectories the check did not pass: fp64 Jacobi sweeps on their X (every pair; nearly diagonal already)
+    std::vector<int> hs(nb), ids;
+    TJM_HIP_CHECK(hipMemcpy(hs.data(), status, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < nb; ++b) if (hs[b]) ids.push_back(b);
+    if (g_debug) {
+      int c1 = 0, c2 = 0, c4 = 0;
+      for (int b = 0; b < nb; ++b) { c1 += hs[b] & 1; c2 += (hs[b] >> 1) & 1; c4 += (hs[b] >> 2) & 1; }
+      fprintf(stderr, "[svd-mixed]   kept/not-kept tilt open in %d, Gershgorin certificate failed in %d, kept set not orthogonal in %d trajectories (skip_col %d)\n", c1, c2, c4, skip_col);
+    }
+    TJM_HIP_CHECK(hipMemcpyAsync(idlist, ids.data(), ids.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    TJM_HIP_CHECK(hipStreamSynchronize(s));  // ids is a local
+    JacobiSource src;
+    src.src = nullptr; src.src_b0 = 0; src.rx = N; src.ncols = N; src.conj = 0; src.tri = 0;
+    src.r_n0 = N; src.s_r1 = 0; src.s_r0 = 0; src.c_n0 = N; src.s_c1 = 0; src.s_c0 = 0;
+    src.nb0 = (int)ids.size(); src.ids = idlist;
+    JacobiOpts op;
+    op.preloaded = true;
+    op.late_start = true;
+    if ((rc = jacobi_solve(src, tr, w, s, &sh, &f64_sweeps, false, &op)) != TJM_OK) return rc;  // ends with the finish kernel of these
+    TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 8, w.n_active + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+    TJM_HIP_CHECK(hipStreamSynchronize(s));
+    floor_kept = w.h_pinned[8] != 0;
+  }
   {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     ++g_mixed.solves;
     g_mixed.c64_sweeps += c64_sweeps;
     g_mixed.f64_sweeps += f64_sweeps;
-    if (bad_polar || floor_kept || slow) ++g_mixed.fallbacks;
+    g_mixed.jacobi_trajectories += n_bad;
+    if (floor_kept) ++g_mixed.fallbacks;
   }
-  if (g_debug) fprintf(stderr, "[svd-mixed] N %d c64 sweeps %d fp64 sweeps %d polar %d floor %d\n", N, c64_sweeps, f64_sweeps, (int)bad_polar, (int)floor_kept);
   if (sweeps_out) *sweeps_out = f64_sweeps;
-  if (bad_polar || floor_kept || slow) return TJM_OK;  // *done stays false: theta is untouched, the caller runs the fp64 path
+  if (floor_kept) return TJM_OK;  // a kept singular value at the noise floor: the completing variant of the fp64 path
+  // ---- isometric factor: normalised kept columns, made exactly isometric by a polar step of their own; then the projection
   ExtractDesc xi;
-  GemmDesc g;
-  memset(&g, 0, sizeof(g));
-  g.nb0 = nb; g.nb2 = 1;
+  GemmDesc gg, gt, gp;  // Gram of the raw isometry, raw x T, projection
+  memset(&gg, 0, sizeof(gg)); memset(&gt, 0, sizeof(gt)); memset(&gp, 0, sizeof(gp));
+  gg.nb0 = gt.nb0 = gp.nb0 = nb; gg.nb1 = gg.nb2 = gt.nb2 = gp.nb2 = 1;
+  gg.M = cm; gg.N = cm; gg.C = Gm; gg.c_rs = cm; gg.c_b0 = g_b0;
+  if ((long)cm * cm > g_b0 || (long)N * cm > x_b0) return TJM_ERR_WORKSPACE;
   if (d.distribution == 0) {
-    // left[(s,a)][k] = Ytilde[(s,a)][k] ; right[t][k][c] = sum_(s,a) conj(left[(s,a)][k]) theta[(s,a)][(t,c)]
-    xi.out = d.left; xi.out_b0 = d.left_b0; xi.n_k = cm; xi.o_k = 1; xi.n_r1 = 1; xi.n_r0 = N; xi.o_r1 = 0; xi.o_r0 = cm;
+    // raw[(s,a)][k] = Ytilde[(s,a)][k] (the layout of `left`) ; left = raw T ; right[t][k][c] = sum_(s,a) conj(left[(s,a)][k]) theta[(s,a)][(t,c)]
+    xi.out = Iso; xi.out_b0 = x_b0; xi.n_k = cm; xi.o_k = 1; xi.n_r1 = 1; xi.n_r0 = N; xi.o_r1 = 0; xi.o_r0 = cm;
     xi.row_off = 0; xi.conj = 0; xi.scale_mode = 2;
-    g.nks = 1; g.nb1 = d.d;
-    g.A = d.left; g.a_rs = 1; g.a_cs = cm; g.a_b0 = d.left_b0; g.conjA = 1; g.M = cm; g.K = N;
-    g.B = d.theta; g.b_rs = d.ld_theta; g.b_cs = 1; g.b_b0 = d.theta_b0; g.b_b1 = d.capR; g.N = d.capR;
-    g.C = d.right; g.c_rs = d.capR; g.c_b0 = d.right_b0; g.c_b1 = (long)cm * d.capR;
+    gg.nks = 1; gg.K = N;
+    gg.A = Iso; gg.a_rs = 1; gg.a_cs = cm; gg.a_b0 = x_b0; gg.conjA = 1;
+    gg.B = Iso; gg.b_rs = cm; gg.b_cs = 1; gg.b_b0 = x_b0;
+    gt.nks = 1; gt.nb1 = 1; gt.M = N; gt.N = cm; gt.K = cm;
+    gt.A = Iso; gt.a_rs = cm; gt.a_cs = 1; gt.a_b0 = x_b0;
+    gt.B = Cm; gt.b_rs = cm; gt.b_cs = 1; gt.b_b0 = g_b0;
+    gt.C = d.left; gt.c_rs = cm; gt.c_b0 = d.left_b0;
+    gp.nks = 1; gp.nb1 = d.d;
+    gp.A = d.left; gp.a_rs = 1; gp.a_cs = cm; gp.a_b0 = d.left_b0; gp.conjA = 1; gp.M = cm; gp.K = N;
+    gp.B = d.theta; gp.b_rs = d.ld_theta; gp.b_cs = 1; gp.b_b0 = d.theta_b0; gp.b_b1 = d.capR; gp.N = d.capR;
+    gp.C = d.right; gp.c_rs = d.capR; gp.c_b0 = d.right_b0; gp.c_b1 = (long)cm * d.capR;
   } else {
-    // right[t][k][c] = conj(Ytilde[(t,c)][k]) ; left[(s,a)][k] = sum_(t,c) theta[(s,a)][(t,c)] conj(right[t][k][c])
-    xi.out = d.right; xi.out_b0 = d.right_b0; xi.n_k = cm; xi.o_k = d.capR; xi.n_r1 = d.d; xi.n_r0 = d.capR;
-    xi.o_r1 = (long)cm * d.capR; xi.o_r0 = 1; xi.row_off = 0; xi.conj = 1; xi.scale_mode = 2;
-    g.nks = d.d; g.nb1 = 1;
-    g.A = d.theta; g.a_rs = d.ld_theta; g.a_cs = 1; g.a_ks = d.capR; g.a_b0 = d.theta_b0; g.M = d.m; g.K = d.capR;
-    g.B = d.right; g.b_rs = 1; g.b_cs = d.capR; g.b_ks = (long)cm * d.capR; g.b_b0 = d.right_b0; g.conjB = 1; g.N = cm;
-    g.C = d.left; g.c_rs = cm; g.c_b0 = d.left_b0;
+    // raw[t][k][c] = conj(Ytilde[(t,c)][k]) (the layout of `right`) ; right[t] = T^H raw[t] ; left[(s,a)][k] = sum_(t,c) theta[(s,a)][(t,c)] conj(right[t][k][c])
+    const long tkc = (long)cm * d.capR;
+    xi.out = Iso; xi.out_b0 = x_b0; xi.n_k = cm; xi.o_k = d.capR; xi.n_r1 = d.d; xi.n_r0 = d.capR;
+    xi.o_r1 = tkc; xi.o_r0 = 1; xi.row_off = 0; xi.conj = 1; xi.scale_mode = 2;
+    // Gram[i][j] = sum_(t,c) conj(iso[(t,c)][i]) iso[(t,c)][j] = sum_t sum_c raw[t][i][c] conj(raw[t][j][c])
+    gg.nks = d.d; gg.K = d.capR;
+    gg.A = Iso; gg.a_rs = d.capR; gg.a_cs = 1; gg.a_ks = tkc; gg.a_b0 = x_b0;
+    gg.B = Iso; gg.b_rs = 1; gg.b_cs = d.capR; gg.b_ks = tkc; gg.b_b0 = x_b0; gg.conjB = 1;
+    gt.nks = 1; gt.nb1 = d.d; gt.M = cm; gt.N = d.capR; gt.K = cm;
+    gt.A = Cm; gt.a_rs = 1; gt.a_cs = cm; gt.a_b0 = g_b0; gt.conjA = 1;
+    gt.B = Iso; gt.b_rs = d.capR; gt.b_cs = 1; gt.b_b0 = x_b0; gt.b_b1 = tkc;
+    gt.C = d.right; gt.c_rs = d.capR; gt.c_b0 = d.right_b0; gt.c_b1 = tkc;
+    gp.nks = d.d; gp.nb1 = 1;
+    gp.A = d.theta; gp.a_rs = d.ld_theta; gp.a_cs = 1; gp.a_ks = d.capR; gp.a_b0 = d.theta_b0; gp.M = d.m; gp.K = d.capR;
+    gp.B = d.right; gp.b_rs = 1; gp.b_cs = d.capR; gp.b_ks = tkc; gp.b_b0 = d.right_b0; gp.conjB = 1; gp.N = cm;
+    gp.C = d.left; gp.c_rs = cm; gp.c_b0 = d.left_b0;
   }
   if ((rc = svd_extract(xi, w, sh, d.chiM, d.chi_stride, nb, nullptr, s)) != TJM_OK) return rc;
-  if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
+  if ((rc = launch_gemm(gg, s)) != TJM_OK) return rc;
+  const int gxc = (int)std::min<long>(128, ((long)cm * cm + 1023) / 1024);
+  hipLaunchKernelGGL(polar_residual_kernel, dim3((cm + 255) / 256, nb), dim3(256), 0, s, Gm, g_b0, cm, d.chiM, d.chi_stride);
+  {  // E^2, series
+    GemmDesc g; memset(&g, 0, sizeof(g)); g.nks = 1; g.nb0 = nb; g.nb1 = 1; g.nb2 = 1; g.M = cm; g.N = cm; g.K = cm;
+    g.A = Gm; g.a_rs = cm; g.a_cs = 1; g.a_b0 = g_b0;
+    g.B = Gm; g.b_rs = cm; g.b_cs = 1; g.b_b0 = g_b0;
+    g.C = S2; g.c_rs = cm; g.c_b0 = x_b0;
+    if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
+  }
+  hipLaunchKernelGGL(polar_poly_kernel, dim3(gxc, nb), dim3(256), 0, s, Gm, g_b0, S2, x_b0, Cm, g_b0, cm, real(0.375), (real*)nullptr);
+  TJM_HIP_CHECK(hipGetLastError());
+  if ((rc = launch_gemm(gt, s)) != TJM_OK) return rc;
+  if ((rc = launch_gemm(gp, s)) != TJM_OK) return rc;
   *done = true;
   return TJM_OK;
 }
 #else
-void mixed_stats_get(double* out5, bool) { for (int i = 0; i < 5; ++i) out5[i] = 0.0; }
+void mixed_stats_get(double* out6, bool) { for (int i = 0; i < 6; ++i) out6[i] = 0.0; }
 size_t mixed_split_workspace_bytes(int, int) { return 0; }
 #endif
 
