@@ -186,24 +186,39 @@ def cpu_baseline(L, chi, tol, procs_list, workload="tfim", tdvp_mode="2site", dt
     }
 
 
-def pmc_traffic(L, chi, B):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r0*_pmc_traffic.json:
-    separate FETCH_SIZE and WRITE_SIZE runs of this script, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    PMC counters cannot be read from inside the timed run, so the number is only reported for the configuration it was
-    collected on."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+def pmc_traffic(L, chi, B, kernel_tag):
+    """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC passes (profiles/r0*_pmc_traffic*.json: separate
+    FETCH_SIZE and WRITE_SIZE runs of this script, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters
+    cannot be read from inside the timed run: the number comes from a profile, is only reported for the configuration and the kernel
+    (``kernel_tag``: "tjm32" = the complex64 instance, "tjm::" = the fp64 one) it was collected on, and the source says so."""
+    for name in ("r04_pmc_traffic_c64.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
         except OSError:
             continue
-        if (rec.get("L"), rec.get("chi")) != (L, chi):
+        if (rec.get("L"), rec.get("chi")) != (L, chi) or (kernel_tag == "tjm32") != ("tjm32" in rec.get("kernel", "")):
             continue
         # a launch covers the trajectories of ONE engine: scale the per-launch bytes of the collection run to that many
         scale = float(B) / float(rec.get("batch") or B)
-        return rec["traffic_bytes_per_launch"] * scale, (f"{name}: {rec['note']} (collected with {rec.get('batch')} trajectories per launch, "
-                                                          f"scaled to the {B} of this run's launches)")
-    return None, "no PMC summary committed for this configuration"
+        return rec["traffic_bytes_per_launch"] * scale, {"source": "committed profile", "file": "profiles/" + name, "steps_collected": rec.get("steps", 1),
+                                                          "note": f"{rec['note']} (collected with {rec.get('batch')} trajectories per launch, scaled to "
+                                                                  f"the {B} of this run's launches)"}
+    return None, {"source": "none", "note": "no PMC summary committed for this configuration and kernel"}
+
+
+def shard_rate(B):
+    """Trajectories/s of ONE MI355X with B resident trajectories (profiles/r0*_shard_rates.json, measured with this script)."""
+    for name in ("r04_shard_rates.json", "r03_shard_rates.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f)
+        except OSError:
+            continue
+        row = rec.get("rates", {}).get(str(B))
+        if row is not None:
+            return {"trajectories_per_sec": row, "source": "profiles/" + name}
+    return None
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -365,6 +380,7 @@ def main():
             self.pos = np.zeros(self.nb, dtype=np.int64)
             self.zsum = np.zeros(L)
             self.err = None
+            self.step_s = []  # wall seconds of every timed step of this engine
 
         def step(self):
             e, ar = self.eng, np.arange(self.nb)
@@ -377,7 +393,10 @@ def main():
         def run(self, n, measure):
             try:
                 for k in range(n):
+                    t_step = time.perf_counter()
                     self.step()
+                    if measure:  # stochastic() has read the jump decisions back: the step's work on this stream is done
+                        self.step_s.append(time.perf_counter() - t_step)
                     if measure and ((k + 1) % STEPS_PER_TRAJ == 0 or k == n - 1):
                         M = self.eng.site_moments()
                         self.zsum += np.einsum("lb->l", (M[:, :, 0, 0] - M[:, :, 1, 1]).real)
@@ -412,7 +431,7 @@ def main():
     lib.tjm_profile_cross_kernel(8)  # bracket every 8th launch of the dominant kernel with HIP events on its engine's stream
     jw = np.zeros(4)
     lib.tjm_svd_work_read(jw.ctypes.data, 1)  # reset the executed-work counters of the tiled Jacobi kernels
-    mx = np.zeros(6)
+    mx = np.zeros(10)
     lib.tjm_svd_mixed_read(mx.ctypes.data, 1)  # ... and of the mixed-precision two-site split
     barrier()
     t0 = time.perf_counter()
@@ -432,6 +451,8 @@ def main():
     prof = [e.profile_read() for e in engines]
     ms, nbytes, ns = C.c_double(0), C.c_double(0), C.c_int64(0)
     lib.tjm_profile_cross_kernel_read(C.byref(ms), C.byref(nbytes), C.byref(ns))
+    ms32, nb32, ns32 = C.c_double(0), C.c_double(0), C.c_int64(0)
+    lib.tjm_profile_cross_kernel_read_c64(C.byref(ms32), C.byref(nb32), C.byref(ns32))  # the complex64 instance (mixed-precision split)
     lib.tjm_profile_cross_kernel(0)
     lib.tjm_svd_work_read(jw.ctypes.data, 0)
     lib.tjm_svd_mixed_read(mx.ctypes.data, 0)
@@ -440,6 +461,10 @@ def main():
         total_traj = B * world
         value = total_traj * K / STEPS_PER_TRAJ / elapsed
         site_updates = total_traj * K * (2 * L - 3) / elapsed
+        f32 = args.dtype != "complex128"
+        peak64, peak32 = FP64_PEAK_TFLOPS, 2 * FP64_PEAK_TFLOPS  # vector = matrix rate for both types on this part: 78.6 / 157.3 TFLOP/s
+        peak = peak32 if f32 else peak64
+        valu_bound, mfma_bound = ("fp32-valu", "mfma-f32") if f32 else ("fp64-valu", "mfma-f64")
         # ---- algorithmic work of this rank's timed region (SURVEY section 8d formulas; cMAC = 8 real flops) -----------------
         d_, D = 2, max(int(w.shape[3]) for w in mpo.tensors)
         n = d_ * chi
@@ -449,11 +474,12 @@ def main():
         cnt = {k_: sum(s1[k_] - s0[k_] for s0, s1 in zip(stats0, stats1)) for k_ in stats1[0]}
         # counters count batched calls; each call covers the engine's nb trajectories
         wsum = lambda key: sum((s1[key] - s0[key]) * e.B for s0, s1, e in zip(stats0, stats1, engines))  # noqa: E731
-        flops_svd = F_svd * sum(s1["svd_matrices"] - s0["svd_matrices"] for s0, s1 in zip(stats0, stats1))
-        flops_kry = F_mv2 * wsum("matvecs_two_site") + F_mv1 * (wsum("matvecs") - wsum("matvecs_two_site"))
+        n_mats = sum(s1["svd_matrices"] - s0["svd_matrices"] for s0, s1 in zip(stats0, stats1))
+        flops_svd_nominal = F_svd * n_mats
+        flops_kry_nominal = F_mv2 * wsum("matvecs_two_site") + F_mv1 * (wsum("matvecs") - wsum("matvecs_two_site"))
         flops_env = F_mv1 * wsum("env_updates")
         # executed Krylov flops: a certified identity channel of an environment (identity_channels counter) removes one of the D
-        # blocks of the corresponding GEMM, so the chi^3 terms run with D - (certified channels per call) / 2 on average
+        # blocks of the corresponding GEMM, so the chi^3 terms run with D - (certified channels per call) / 2 on average ...
         ident = wsum("identity_channels") / max(1.0, 2.0 * wsum("identity_checks")) if "identity_checks" in stats1[0] else 0.0
         checked = wsum("identity_checks") / max(1.0, wsum("krylov_calls")) if "identity_checks" in stats1[0] else 0.0
         D_eff = D - ident * checked
@@ -462,31 +488,48 @@ def main():
         F_mv2x = 6.0 * 2 * d_ ** 2 * D_eff * chi ** 3 + 8.0 * d_ ** 4 * D ** 2 * chi ** 2
         F_mv1x = 6.0 * 2 * d_ * D_eff * chi ** 3 + 8.0 * d_ ** 2 * D ** 2 * chi ** 2
         flops_kry_exec = F_mv2x * wsum("matvecs_two_site") + F_mv1x * (wsum("matvecs") - wsum("matvecs_two_site"))
-        cls_ms = {c: sum(p[c]["ms"] for p in prof) for c in ("svd", "krylov", "env")}
-        # With several engines the streams overlap on the device and their bracketed times add up to more than the wall time: every
-        # class then gets its SHARE of the wall time (its summed stream time x wall / sum of all classes) as its duration, which for
-        # one engine is the bracketed time itself.
-        overlap = max(1.0, sum(cls_ms.values()) / (1e3 * elapsed))
-        cls_ms = {c: v / overlap for c, v in cls_ms.items()}
+        # executed SVD-family flops, counted on the device: 28 real flops per row of every column pair of a visited Jacobi tile (8 dot
+        # product + 20 rotation, identity rotations of a visited tile included), for the fp64 kernels and - mixed-precision split -
+        # for the complex64 ones (fp32 flops), plus the GEMMs of the split's fp64 phase at 6 real flops per complex multiply-add
+        flops_jac64 = 28.0 * float(jw[0])
+        flops_jac32 = 28.0 * float(mx[6])
+        flops_mixgemm = 0.75 * float(mx[9])
+        # ---- time: HIP events on every engine's stream around each class.  With E engines the streams overlap on the device and the
+        # bracketed times add up to more than the wall time: `stream_ms` is the raw sum over the engines (what the brackets measured),
+        # `wall_share_ms` = stream_ms x wall / sum of all classes is the class's SHARE of the wall time - an attribution, not a kernel
+        # measurement.  Class rates below are flops / wall share (so that the classes add up to the step); kernel rates use the
+        # sampled launch durations themselves.
+        stream_ms = {c: sum(p[c]["ms"] for p in prof) for c in ("svd", "krylov", "env")}
+        overlap = max(1.0, sum(stream_ms.values()) / (1e3 * elapsed))
+        cls_ms = {c: v / overlap for c, v in stream_ms.items()}
         tf = lambda fl, msv: (fl / 1e12) / (msv / 1e3) if msv > 0 else None  # noqa: E731
-        svd_tf, kry_tf, env_tf = tf(flops_svd, cls_ms["svd"]), tf(flops_kry, cls_ms["krylov"]), tf(flops_env, cls_ms["env"])
-        # Next to the nominal figure: (i) the same convention with every factorisation counted at the size THIS build factors
-        # (a two-site split: n x n; a one-tensor SVD centre shift: (d chi) x chi, Golub & Van Loan's 6 m n^2 + 20 n^3 against 26 n^3
-        # for the square case), (ii) the flops the tiled Jacobi kernels really executed (28 real flops per row of every column pair
-        # of a visited tile: 8 for the dot product, 20 for the plane rotation, identity rotations included; counted on the device)
-        n_mats = sum(s1["svd_matrices"] - s0["svd_matrices"] for s0, s1 in zip(stats0, stats1))
-        splits = wsum("site_updates") if args.tdvp_mode == "2site" else 0
-        F_shift = F_svd * (6.0 * n * chi ** 2 + 20.0 * chi ** 3) / (26.0 * n ** 3)
-        flops_own = F_svd * min(splits, n_mats) + F_shift * max(0, n_mats - splits)
-        flops_exec = 28.0 * float(jw[0])
-        own_tf, exec_tf = tf(flops_own, cls_ms["svd"]), tf(flops_exec, cls_ms["svd"])
-        step_tf = (flops_svd + flops_kry + flops_env) / 1e12 / elapsed
+        frac = lambda x, pk: (x / pk) if x else None  # noqa: E731
         busy = sum(cls_ms.values()) / 1e3
-        traffic, traffic_note = pmc_traffic(L, chi, sizes[0])
-        cross_gbs = (nbytes.value / 1e9) / (ms.value / 1e3) if ms.value > 0 else None
-        f32 = args.dtype != "complex128"
-        peak = 2 * FP64_PEAK_TFLOPS if f32 else FP64_PEAK_TFLOPS  # fp32 vector and matrix rates: 157.3 TFLOP/s
-        valu_bound, mfma_bound = ("fp32-valu", "mfma-f32") if f32 else ("fp64-valu", "mfma-f64")
+        step_tf = (flops_svd_nominal + flops_kry_nominal + flops_env) / 1e12 / elapsed
+        # ---- the dominant kernel: the Jacobi tile kernel, in whichever arithmetic it spends more time (sampled: every 8th launch)
+        k64 = {"ms": ms.value, "samples": int(ns.value), "bytes": nbytes.value, "flops": flops_jac64, "peak": peak, "bound": valu_bound,
+               "name": "jacobi_cross16x_kernel" + (" (complex64 build)" if f32 else " (fp64)")}
+        k32 = {"ms": ms32.value, "samples": int(ns32.value), "bytes": nb32.value, "flops": flops_jac32, "peak": peak32, "bound": "fp32-valu",
+               "name": "tjm32::jacobi_cross16x_kernel (complex64 phase of the mixed-precision two-site split)"}
+        dom = k32 if k32["ms"] > k64["ms"] else k64
+
+        def kernel_line(kk):
+            if not kk["samples"]:
+                return None
+            launches = 8.0 * kk["samples"]  # the sampler brackets every 8th launch
+            avg_us = 1e3 * kk["ms"] / kk["samples"]
+            rate = kk["flops"] / 1e12 / (launches * avg_us / 1e6) if kk["flops"] else None
+            gbs = (kk["bytes"] / 1e9) / (kk["ms"] / 1e3)
+            return {"name": kk["name"], "bound": kk["bound"], "avg_launch_us": avg_us, "launches_sampled": kk["samples"],
+                    "executed_TFLOPs": rate, "peak_TFLOPs": kk["peak"], "frac": frac(rate, kk["peak"]),
+                    "tile_bytes_GBps": gbs, "tile_bytes_frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+
+        dom_line = kernel_line(dom)
+        traffic, traffic_src = pmc_traffic(L, chi, sizes[0], "tjm32" if dom is k32 else "tjm::")
+        alg_bytes_per_launch = (dom["bytes"] / dom["samples"]) if dom["samples"] else None
+        svd_exec_tf = tf(flops_jac64 + flops_jac32 + flops_mixgemm, cls_ms["svd"])
+        kry_exec_tf = tf(flops_kry_exec, cls_ms["krylov"])
+        step_wall = [max(d.step_s[k] for d in drives) for k in range(K)] if all(len(d.step_s) == K for d in drives) else []
         out = {
             "metric": "trajectories/sec",
             "value": value,
@@ -512,75 +555,85 @@ def main():
             },
             "site_updates_per_sec": site_updates,
             # batched calls per step and engine (every engine makes the same calls); svd_matrices counts trajectories: whole GPU
-            "counters_per_step": {k_: v / K / (1 if k_ == "svd_matrices" else E) for k_, v in cnt.items()},
+            "counters_per_step": {k_: v / K / (1 if k_ in ("svd_matrices", "certified_dissipations", "certified_jumps") else E) for k_, v in cnt.items()},
+            # The certified scalar dissipation / in-place jumps depend on the state: nothing certifies in the first
+            # steps from the Haar state, most trajectory-steps do later, so the value depends (by a few per cent) on --steps / --warmup.
+            "certified_fraction_of_trajectory_steps": {"dissipations": cnt.get("certified_dissipations", 0) / max(1, total_traj * K // world),
+                                                      "note": "tests/test_hip_fullsize.py pins this path against the reference at full size (ten consecutive steps)"},
+            "step_wall_seconds": {"first": step_wall[0], "last": step_wall[-1], "all": step_wall} if step_wall else None,
             "mean_Z_site0": float(zsum[0] / total_traj),
-            # Dominant kernel class: the SVD family (Jacobi + QR kernels; fp64 VALU-issue-bound, not HBM-bound).  Unit of a "launch" =
-            # one batched SVD (a two-site split or an SVD centre shift of every resident trajectory); algorithmic work = SURVEY 8d's
-            # nominal 88 n^3 real flops per (d chi) x (d chi) SVD; duration = HIP events on the engine's stream around every such SVD.
+            # ---- roofline of the dominant kernel, EXECUTED work: flops counted on the device / (launches x sampled launch duration)
             "roofline": {
-                "bound": valu_bound,
-                "kernel": "SVD family: jacobi_cross16x_kernel (dominant) + jacobi_* + qr_* + svd_finish/extract, per batched SVD",
-                "achieved": svd_tf,
-                "peak": peak,
+                "bound": dom["bound"],
+                "kernel": dom["name"],
+                "achieved": dom_line["executed_TFLOPs"] if dom_line else None,
+                "peak": dom["peak"],
                 "unit": "TFLOP/s",
-                "frac": (svd_tf / peak) if svd_tf else None,
-                "achieved_own_size": own_tf, "frac_own_size": (own_tf / peak) if own_tf else None,
-                "achieved_executed": exec_tf, "frac_executed": (exec_tf / peak) if exec_tf else None,
-                "executed_note": "own_size: centre shifts counted as the (d chi) x chi matrices this build factors instead of the reference's merged "
-                                 "(d chi) x (d chi) ones; executed: 28 flop x rows x column pairs of every visited Jacobi tile (device counter), "
-                                 "over the same SVD-class time (which also holds the QR, GEMM, finish and extract kernels)",
-                "jacobi_sweeps_per_solve": (float(jw[2]) / float(jw[3])) if jw[3] else None,
-                "jacobi_applied_over_executed_rotations": (float(jw[1]) / float(jw[0])) if jw[0] else None,
-                # mixed-precision two-site split (tjm_mixed.h): batched splits it served, their complex64 and fp64 sweeps, batches sent
-                # back to the all-fp64 path.  jacobi_sweeps_per_solve above counts every tiled solve of the process, both types.
+                "frac": dom_line["frac"] if dom_line else None,
+                "how": "achieved = 28 real flops x rows x column pairs of every visited 32-column tile (device counter; a visited tile executes all "
+                       "its 256 + 16 rotation slots, identity rotations included) / (8 x sampled launches x their average duration, HIP events on "
+                       "the launch stream); peak = the vector rate of the kernel's arithmetic",
+                "avg_launch_us": dom_line["avg_launch_us"] if dom_line else None,
+                "algorithmic_bytes_per_launch": alg_bytes_per_launch,  # every visited tile read and written once
+                "traffic": traffic,
+                "traffic_over_algorithmic_bytes": (traffic / alg_bytes_per_launch) if (traffic and alg_bytes_per_launch) else None,
+                "traffic_source": traffic_src,
+                # nominal convention of SURVEY 8d for the whole SVD class: 88 n^3 per (d chi) x (d chi) factorisation as the reference
+                # executes it (every split AND every centre shift), over the class's share of the wall time
+                "frac_nominal": frac(tf(flops_svd_nominal, cls_ms["svd"]), peak),
+                "achieved_nominal": tf(flops_svd_nominal, cls_ms["svd"]),
+                "algorithmic_flops_per_svd": F_svd,
+                "kernels": {"jacobi_fp64": kernel_line(k64), "jacobi_complex64": kernel_line(k32) if not f32 else None},
+                "jacobi_sweeps_per_solve_fp64": (float(jw[2]) / float(jw[3])) if jw[3] else None,
+                "jacobi_applied_over_executed_rotations_fp64": (float(jw[1]) / float(jw[0])) if jw[0] else None,
+                "jacobi_applied_over_executed_rotations_complex64": (float(mx[7]) / float(mx[6])) if mx[6] else None,
+                # mixed-precision two-site split (tjm_mixed.h)
                 "mixed_split": {"batched_splits": mx[0], "c64_sweeps_per_split": (mx[1] / mx[0]) if mx[0] else None,
                                 "f64_jacobi_sweeps_per_split": (mx[2] / mx[0]) if mx[0] else None, "batches_sent_to_fp64_path": mx[3],
-                                "trajectories_finished_by_fp64_jacobi": mx[4], "batches_with_second_polar_step": mx[5]},
-                "traffic": traffic,
-                # PMC bytes of the dominant kernel per batched SVD (bytes per launch x its launches per solve) over the bytes a
-                # factorisation has to move (matrix in, factors out: 2 x 16 n^2 per trajectory)
-                "traffic_over_algorithmic": (traffic * (8.0 * ns.value / float(jw[3])) / (2.0 * 16 * n * n * sizes[0])) if (traffic and jw[3]) else None,
-                "traffic_note": traffic_note,
-                "algorithmic_flops_per_svd": F_svd,
+                                "trajectories_finished_by_fp64_jacobi": mx[4], "batches_with_second_polar_step": mx[5],
+                                "fp64_gemms_per_split": (mx[8] / mx[0]) if mx[0] else None},
                 "svds_per_step": cnt["svds"] / K / E,
-                "avg_batched_svd_ms": cls_ms["svd"] * overlap / max(1, sum(p["svd"]["regions"] for p in prof)),
                 "stream_overlap": overlap,  # summed stream time of the engines / wall time (1 for a single engine)
-                "dominant_kernel": {
-                    "name": "jacobi_cross16x_kernel",
-                    "avg_launch_us": (1e3 * ms.value / ns.value) if ns.value else None,
-                    "launches_sampled": int(ns.value),
-                    "tile_bytes_GBps": cross_gbs,  # bytes of the 32-column tiles it reads and writes once per launch / duration
-                    "tile_bytes_frac_of_hbm_peak": (cross_gbs / HBM_PEAK_GBS) if cross_gbs else None,
-                },
                 "classes": {
-                    "svd": {"bound": valu_bound, "achieved_TFLOPs": svd_tf, "frac": (svd_tf / peak) if svd_tf else None,
-                            "share_of_stream_time": cls_ms["svd"] / 1e3 / busy if busy else None},
-                    "krylov": {"bound": mfma_bound, "achieved_TFLOPs": kry_tf, "frac": (kry_tf / peak) if kry_tf else None,
+                    "note": "stream_ms = HIP-event brackets summed over the engines' streams (raw); wall_share_ms = stream_ms / stream_overlap, the "
+                            "class's share of the wall time (attribution: the classes add up to the step); rates = flops / wall share",
+                    "svd": {"stream_ms": stream_ms["svd"], "wall_share_ms": cls_ms["svd"], "share_of_stream_time": cls_ms["svd"] / 1e3 / busy if busy else None,
+                            "executed_TFLOPs": svd_exec_tf,
+                            "executed_flops_split": {"jacobi_fp64": flops_jac64, "jacobi_complex64_fp32_flops": flops_jac32, "fp64_gemms_of_the_mixed_split": flops_mixgemm},
+                            "nominal_TFLOPs": tf(flops_svd_nominal, cls_ms["svd"]),
+                            "avg_batched_svd_ms_on_its_stream": stream_ms["svd"] / max(1, sum(p["svd"]["regions"] for p in prof))},
+                    "krylov": {"bound": mfma_bound, "stream_ms": stream_ms["krylov"], "wall_share_ms": cls_ms["krylov"],
                                "share_of_stream_time": cls_ms["krylov"] / 1e3 / busy if busy else None,
-                               "achieved_executed_TFLOPs": tf(flops_kry_exec, cls_ms["krylov"]),
-                               "frac_executed": (tf(flops_kry_exec, cls_ms["krylov"]) / peak) if cls_ms["krylov"] > 0 else None,
-                               "note": "H_eff applies (2 MFMA GEMMs + MPO stage) with the Lanczos vector kernels (HBM-bound) inside the region; "
-                                       "achieved = the reference's nominal flops (SURVEY 8d), executed = without the GEMM blocks of the environments' "
-                                       "certified identity channels (DESIGN section 4), which this build does not compute, and with 6 instead of 8 real flops per "
-                                       "complex multiply-add of the GEMMs (three-product complex multiplication); "
-                                       "with several engines per GPU the class time is this class's share of the overlapped stream time, so a "
-                                       "fraction above 1 means the MFMA work ran underneath other engines' VALU-bound factorisations, not that "
-                                       "a kernel beat the pipe: the GEMM kernels alone show 52 - 61 % MfmaUtil (profiles/r03_pmc_pass5_*)"},
-                    "env": {"bound": mfma_bound, "achieved_TFLOPs": env_tf, "frac": (env_tf / peak) if env_tf else None,
+                               "achieved_TFLOPs": kry_exec_tf, "frac": min(1.0, kry_exec_tf / peak) if kry_exec_tf else None,
+                               "nominal_TFLOPs": tf(flops_kry_nominal, cls_ms["krylov"]),
+                               "note": "H_eff applies (2 MFMA GEMMs + MPO stage) with the Lanczos vector kernels (HBM-bound) inside the region; achieved = "
+                                       "EXECUTED flops (the GEMM blocks of the environments' certified identity channels are not computed; 6 real flops "
+                                       "per complex multiply-add: three-product complex multiplication) over the class's wall share; with several "
+                                       "engines the share understates the time the kernels had the device to themselves, hence the cap at 1 - the "
+                                       "GEMM kernels alone show 52 - 61 % MfmaUtil (profiles/r03_pmc_pass5_*)"},
+                    "env": {"bound": mfma_bound, "stream_ms": stream_ms["env"], "wall_share_ms": cls_ms["env"],
+                            "achieved_TFLOPs": tf(flops_env, cls_ms["env"]), "frac": frac(tf(flops_env, cls_ms["env"]), peak),
                             "share_of_stream_time": cls_ms["env"] / 1e3 / busy if busy else None},
-                    "whole_step": {"achieved_TFLOPs": step_tf, "frac": step_tf / peak,
+                    "whole_step": {"nominal_TFLOPs": step_tf, "frac_nominal": step_tf / peak,
                                    "timed_classes_over_wall": busy / elapsed if elapsed > 0 else None},
                 },
             },
         }
+        if world > 1:
+            # what one GPU does at this shard size (measured on one MI355X, profiles/): the driver's SCALE line can be read against it
+            out["config"]["per_gpu_shard"] = B
+            out["one_gpu_rate_at_this_shard_size"] = shard_rate(B)
         if cpu_ref is not None:
             out["cpu_baseline"] = cpu_ref
-            out["speedup_vs_cpu"] = {"vs_best_whole_host_row": value / cpu_ref["value"], "vs_one_core": value / cpu_ref["per_core_value"]}
-            # the reference's own default is one worker per core (simulator.py:1074-1098: max_workers = available_cpus() - 1): the row
-            # with the most workers, which on this host is memory-bound and SLOWER than the best row the target is measured against
             full = [r for r in cpu_ref.get("rows", []) if r.get("cores") == cpu_ref.get("host_cores")]
-            if full and full[0].get("value"):
-                out["speedup_vs_cpu"]["vs_all_cores_row_reference_default_workers"] = value / full[0]["value"]
+            out["speedup_vs_cpu"] = {
+                "vs_best_measured_whole_host_row": value / cpu_ref["best_measured_full_step"]["value"],  # the ratio north_star's 50 x is read against
+                "vs_best_whole_host_row_incl_extrapolated": value / cpu_ref["value"],
+                "vs_one_core": value / cpu_ref["per_core_value"],
+                # the reference's own default is one worker per core (simulator.py:1074-1098: max_workers = available_cpus() - 1): on this
+                # host that row is memory-bound, SLOWER than the best row, and extrapolated from the slab sample - not a measured full step
+                "vs_all_cores_row_extrapolated": (value / full[0]["value"]) if (full and full[0].get("value")) else None,
+            }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1:

@@ -301,10 +301,14 @@ int tjm_svd_work_read(double* out4, int32_t reset);
  * tjm_svd_split_qr, core/linalg/svd.py:51-104, core/methods/decompositions.py:105-185): an approximate singular basis from the complex64
  * Jacobi (the same kernels, compiled for complex64 into this library), made exactly unitary in fp64 (polar step) and refined to
  * rounding by first-order eigenvector corrections from the Gram matrix of theta x basis - all fp64 work on the matrix cores; the fp64
- * Jacobi kernels only finish single trajectories that fail the final check.  out6 = { batched splits served, complex64 sweeps, fp64
+ * Jacobi kernels only finish single trajectories that fail the final check.  out10 = { batched splits served, complex64 sweeps, fp64
  * Jacobi sweeps, batches sent back to the all-fp64 path, trajectories finished by the fp64 Jacobi, batches that needed a second polar
- * step } since the last reset.  Zeros in the complex64 library.  Switch: TJM_NO_MIXED_SPLIT. */
-int tjm_svd_mixed_read(double* out6, int32_t reset);
+ * step, executed complex64 rotation slots x rows, applied complex64 rotations x rows (28 fp32 flops per slot-row, as in
+ * tjm_svd_work_read), GEMM launches of the fp64 phase, their nominal real flops (8 M N K per complex product) } since the last reset.
+ * Zeros in the complex64 library.  Switch: TJM_NO_MIXED_SPLIT. */
+int tjm_svd_mixed_read(double* out10, int32_t reset);
+/* tjm_profile_cross_kernel also samples the complex64 instance of the tile kernel (the first phase of the mixed split); its totals: */
+int tjm_profile_cross_kernel_read_c64(double* total_ms, double* total_bytes, int64_t* samples);
 
 #ifdef __cplusplus
 }

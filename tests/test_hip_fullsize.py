@@ -89,3 +89,112 @@ def test_config3_full_size_step_matches_the_reference():
         pytest.skip("cfg3 fixture not generated")
     api, t = _inputs(128, 256)
     _check("cfg3", *_one_step(128, 256, api.MPO.heisenberg(128, 1.0, 1.0, 0.5, 0.0), "lowering", 0.05, 0.05, "2site", t, list(g["cfg3_traj"])))
+
+
+# ---- the state bench.py's timed region is in: ten CONSECUTIVE steps of config 2 -------------------------------------------------
+STEADY = os.path.join(GOLDEN, "fullsize_steady.npz")
+NO_CERT = os.environ.get("TJM_NO_CERT_DISSIPATION") is not None
+
+
+def _steady_engine(g, sel=None):
+    from yaqs_amd.api import NoiseModel, is_pauli
+    from yaqs_amd.engine import BatchEngine
+
+    api, t = _inputs(64, 128)
+    trajs = [int(x) for x in g["traj"]]
+    if sel is not None:
+        trajs = [trajs[k] for k in sel]
+    e = BatchEngine(64, 128, len(trajs), api.MPO.ising(64, 1.0, 0.5).tensors)
+    e.set_params(dt=0.1, svd_threshold=1e-12, max_bond_dim=128, krylov_tol=1e-10, tdvp_mode="2site")
+    noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.1} for i in range(64)])
+    e.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
+    e.load_state(t)
+    return e, trajs
+
+
+def _steady_counters(stats):
+    if NO_CERT:
+        assert stats["certified_dissipations"] == 0 and stats["certified_jumps"] == 0, stats
+    else:  # the path that serves most trajectory-steps of the driver's bench run must be the one under test
+        assert stats["certified_dissipations"] > 0 and stats["certified_jumps"] > 0, stats
+
+
+def _steady_stages(g, sel, check=True):
+    """tdvp -> dissipate -> stochastic, ten times, through the stage entry points; with ``check`` every step against the fixture."""
+    from yaqs_amd.tjm import trajectory_uniforms
+
+    e, trajs = _steady_engine(g, sel)
+    steps = int(g["steps"])
+    u = np.stack([trajectory_uniforms(42, t, 2 * steps + 4) for t in trajs])
+    pos = np.zeros(len(trajs), dtype=np.int64)
+    ar = np.arange(len(trajs))
+    for k in range(steps):
+        e.tdvp()
+        e.dissipate(0.1)
+        e.set_uniforms(np.stack([u[ar, pos], u[ar, pos + 1]], axis=1))
+        jumped, dp = e.stochastic(0.1)
+        pos += 1 + jumped
+        if check:
+            assert np.allclose(dp, g["dp"][sel, k], atol=TOL), (k, dp, g["dp"][sel, k])
+            assert np.array_equal(jumped.astype(int), g["jumped"][sel, k]), (k, jumped, g["jumped"][sel, k])
+            assert np.array_equal(e.bond_dims(), g["bonds"][sel, k]), k
+    M = e.site_moments()
+    z = (M[:, :, 0, 0] - M[:, :, 1, 1]).real.T
+    stats = e.stats()
+    assert not e.capacity_overflow()
+    e.close()
+    return z, stats
+
+
+@pytest.mark.skipif(not os.path.exists(STEADY), reason="tests/golden/fullsize_steady.npz not generated")
+def test_config2_ten_consecutive_steps_match_the_reference_through_the_stage_entry_points():
+    """``tools/make_golden.py fullsize_steady[_final]``: the REFERENCE's analog_tjm_1 on config 2 (L = 64, chi = 128 Haar-saturated,
+    krylov_tol 1e-10) for ten consecutive steps, three trajectories, every one of which jumps several times - also after step 6, where
+    the certified scalar dissipation and the in-place jumps of the engine take over.  Per step: the jump
+    probability dp (1e-8), the jump decision and the whole bond table (exact); at the end <Z_i> on every site (1e-8).
+    Then the same trajectories in other batches (one alone, the other two together): whether a trajectory certifies - only part of
+    the thirty trajectory-steps do - is its own affair, so the rows are bit-identical."""
+    g = np.load(STEADY)
+    sel = list(range(len(g["traj"])))
+    z, stats = _steady_stages(g, sel)
+    err = np.abs(z - g["z"][:, :, -1]).max()
+    assert err < TOL, err
+    assert g["jumped"][:, 6:].sum() > 0
+    _steady_counters(stats)
+    if not NO_CERT:
+        assert 0 < stats["certified_dissipations"] < len(sel) * int(g["steps"]), stats  # the partial regime
+    z0, _ = _steady_stages(g, sel[:1], check=False)
+    z12, _ = _steady_stages(g, sel[1:], check=False)
+    assert np.array_equal(z0[0], z[0]) and np.array_equal(z12, z[1:]), (np.abs(z0[0] - z[0]).max(), np.abs(z12 - z[1:]).max())
+
+
+@pytest.mark.skipif(not os.path.exists(STEADY), reason="tests/golden/fullsize_steady.npz not generated")
+def test_config2_ten_consecutive_steps_match_the_reference_through_the_c_driver():
+    """The same run in ONE call of tjm_engine_run (the reference's random streams inside the library): final <Z_i> (1e-8) and the
+    diagnostics row of the final time (exact)."""
+    g = np.load(STEADY)
+    e, trajs = _steady_engine(g)
+    steps = int(g["steps"])
+    zmat = np.diag([1.0, -1.0]).astype(np.complex128)
+    res, diag = e.run(order=1, n_times=steps + 1, sample_timesteps=False, has_noise=True, seed=42, traj_indices=trajs,
+                      observables=[(s, zmat) for s in range(64)])
+    stats = e.stats()
+    e.close()
+    err = np.abs(res[:, :, 0] - g["z"][:, :, -1]).max()
+    assert err < TOL, err
+    assert np.array_equal(diag[:, :, 0], g["diag"][:, :, -1]), (diag[:, :, 0], g["diag"][:, :, -1])
+    _steady_counters(stats)
+
+
+@pytest.mark.skipif(not os.path.exists(STEADY) or NO_CERT, reason="fixture not generated / already the child run")
+def test_config2_ten_consecutive_steps_also_without_the_certified_dissipation():
+    """TJM_NO_CERT_DISSIPATION is read once per process: the two tests above once more in a child process with the switch set (every
+    dissipation by the reference's 2 (L - 1) SVD shifts, every jump through the QR walk and the SVD sweep back)."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, TJM_NO_CERT_DISSIPATION="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "ten_consecutive and not also_without"],
+                         env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__)))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "2 passed" in out.stdout, out.stdout[-2000:]

@@ -903,6 +903,47 @@ def test_concurrent_engines_give_the_results_of_one_engine():
 
 
 @pytest.mark.gpu
+def test_the_certified_path_of_a_trajectory_does_not_depend_on_its_batch():
+    """Pauli-only noise, so the certified scalar dissipation is tried.  Whether a trajectory certifies, and when it tries again after a
+    failure, is a function of that trajectory alone: the same six trajectories run as one batch of six, as 2 + 4 and as 5 + 1 give
+    bit-identical rows and diagnostics, at the shifts' own 1e-12 rule and with a looser truncation of the sweep."""
+    from yaqs_amd.api import AnalogSimParams, MPS, NoiseModel, Observable, Z as Zg
+    from yaqs_amd.tjm import TrajectoryBatch
+
+    L, chi = 12, 32
+    st = o.MPSState.haar(L, chi, np.random.default_rng(7))
+    st.normalize("B")
+    init = [t.copy() for t in st.tensors]
+    noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.1} for i in range(L)])
+    mpo = o.ising_mpo(L, 1.0, 0.5)
+    seen = []
+    for thr in (1e-12, 1e-8):
+        p = AnalogSimParams(observables=[Observable(Zg(), s) for s in range(L)], num_traj=6, elapsed_time=0.8, dt=0.1, max_bond_dim=chi,
+                            svd_threshold=thr, krylov_tol=1e-10, order=1, sample_timesteps=True, random_seed=3)
+
+        def run(ids):
+            e = make_engine(L, chi, len(ids), mpo)
+            r, d = TrajectoryBatch(e, p, noise).run(list(ids), MPS(L, tensors=init), native=False)
+            stats = e.stats()
+            e.close()
+            return r, d, stats["certified_dissipations"]
+
+        r6, d6, c6 = run(range(6))
+        seen.append(c6)
+        for parts in (((0, 1), (2, 3, 4, 5)), ((0, 1, 2, 3, 4), (5,))):
+            rows, diag = {}, {}
+            for ids in parts:
+                r, d, _ = run(ids)
+                for k, t in enumerate(ids):
+                    rows[t], diag[t] = r[k], d[k]
+            for t in range(6):
+                assert np.array_equal(rows[t], r6[t]), (thr, parts, t, np.abs(rows[t] - r6[t]).max())
+                assert np.array_equal(diag[t], d6[t]), (thr, parts, t)
+    assert min(seen) > 0, seen  # the certified path was the one under test (the partial regime is covered at full size,
+    # tests/test_hip_fullsize.py: ten consecutive steps of config 2 in different batches)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("native", [False, True])
 def test_certified_scalar_dissipation_and_in_place_jumps_match_the_oracle(native):
     """Pauli-only noise at bonds above the fused kernels (chi = 32) with the default-preset threshold 1e-6: no bond comes near the

@@ -604,7 +604,7 @@ def gen_fullsize(which=("cfg2", "cfg4", "cfg3")):
     save("fullsize", **out)
 
 
-def _steady_one(traj, steps=10, krylov_tol=1e-10):
+def _steady_one(traj, steps=10, krylov_tol=1e-10, sample=True):
     """One trajectory of gen_fullsize_steady (runs in a forked worker)."""
     import time
 
@@ -616,7 +616,7 @@ def _steady_one(traj, steps=10, krylov_tol=1e-10):
     noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.1} for i in range(64)])
     obs = [sp.Observable(gl.Z(), s) for s in range(64)]
     p = sp.AnalogSimParams(observables=obs, elapsed_time=0.1 * steps, dt=0.1, max_bond_dim=128, svd_threshold=1e-12, krylov_tol=krylov_tol,
-                           order=1, sample_timesteps=True, random_seed=42, tdvp_mode="2site", get_state=True)
+                           order=1, sample_timesteps=sample, random_seed=42, tdvp_mode="2site", get_state=True)
     dps, jumped, bonds = [], [], []
     orig_f, orig_pdf = stoch.calculate_stochastic_factor, stoch.create_probability_distribution
 
@@ -636,6 +636,7 @@ def _steady_one(traj, steps=10, krylov_tol=1e-10):
     def spy_sp(state, *a, **k):
         out = orig_sp(state, *a, **k)
         bonds.append([out.tensors[0].shape[1]] + [x.shape[2] for x in out.tensors])
+        print(f"  fullsize_steady: trajectory {traj} step {len(bonds)} done after {time.time() - t0:.0f} s, dp {dps[-1]:.6f} jumped {jumped[-1]}", flush=True)
         return out
 
     stoch.calculate_stochastic_factor = spy_f
@@ -653,7 +654,14 @@ def _steady_one(traj, steps=10, krylov_tol=1e-10):
                 bonds=np.array(bonds))
 
 
-def gen_fullsize_steady(trajs=(0, 1, 2), steps=10):
+def gen_fullsize_steady_final(trajs=(0, 1, 2), steps=10):
+    """gen_fullsize_steady with final-time sampling only (sample_timesteps=False): the reference's measurement of a state whose gauge
+    it does not know (the initial sample of a run from MPS(tensors=...)) contracts the whole chain once per observable, which at
+    chi = 128 costs more than the ten steps; <Z_i> is then stored for the final time only, everything else as below."""
+    gen_fullsize_steady(trajs, steps, sample=False)
+
+
+def gen_fullsize_steady(trajs=(0, 1, 2), steps=10, sample=True):
     """The reference's analog_tjm_1 on BASELINE's config 2 (L=64, chi=128 Haar-saturated, pauli_z 0.1 on every site, dt 0.1,
     svd_threshold 1e-12, krylov_tol 1e-10) for `steps` CONSECUTIVE steps: the state bench.py's timed region is in after its first
     steps, where the certified scalar dissipation / in-place jumps of the engine serve most trajectory-steps.  Per trajectory:
@@ -661,8 +669,8 @@ def gen_fullsize_steady(trajs=(0, 1, 2), steps=10):
     import multiprocessing as mp
 
     with mp.get_context("fork").Pool(len(trajs)) as pool:
-        rows = pool.starmap(_steady_one, [(t, steps) for t in trajs])
-    out = {"traj": np.array(trajs), "steps": np.array(steps)}
+        rows = pool.starmap(_steady_one, [(t, steps, 1e-10, sample) for t in trajs])
+    out = {"traj": np.array(trajs), "steps": np.array(steps), "sample_timesteps": np.array(int(sample))}
     for k in rows[0]:
         out[k] = np.array([r[k] for r in rows])
     save("fullsize_steady", **out)

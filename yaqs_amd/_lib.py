@@ -140,6 +140,7 @@ EXPORTS = {
     "tjm_profile_cross_kernel_read": (C.c_int, [V, V, V]),
     "tjm_svd_work_read": (C.c_int, [V, I]),
     "tjm_svd_mixed_read": (C.c_int, [V, I]),
+    "tjm_profile_cross_kernel_read_c64": (C.c_int, [V, V, V]),
 }
 
 _lib = None

@@ -455,12 +455,21 @@ int tjm_svd_split_qr(const void* theta, int32_t B, int32_t d, int32_t capL, int3
 
 int tjm_profile_cross_kernel(int32_t every) {
   profile_enable(every);
+  mixed_profile_enable(every);
   return TJM_OK;
 }
 
-int tjm_svd_mixed_read(double* out6, int32_t reset) {
-  if (!out6) return TJM_ERR_ARG;
-  mixed_stats_get(out6, reset != 0);
+int tjm_profile_cross_kernel_read_c64(double* total_ms, double* total_bytes, int64_t* samples) {
+  if (!total_ms || !total_bytes || !samples) return TJM_ERR_ARG;
+  long n = 0;
+  mixed_profile_get(total_ms, total_bytes, &n);
+  *samples = n;
+  return TJM_OK;
+}
+
+int tjm_svd_mixed_read(double* out10, int32_t reset) {
+  if (!out10) return TJM_ERR_ARG;
+  mixed_stats_get(out10, reset != 0);
   return TJM_OK;
 }
 

@@ -217,7 +217,7 @@ class Engine {
   int svd_shift_left(StateSet& S, int i, const int* ids, int nb0);
   int svd_shift_left_2site(StateSet& S, int i, const int* ids, int nb0);
   // Certified scalar dissipation (tjm_engine.hip: dissipate): the right-going SVD pass on scratch copies of the centre tensor
-  int svd_shift_right_virtual(StateSet& S, int i, const cplx* Cin, long cin_b0, cplx* Cout, long cout_b0);
+  int svd_shift_right_virtual(StateSet& S, int i, const cplx* Cin, long cin_b0, cplx* Cout, long cout_b0, const int* ids, int nb0);
   int state_checksum(int set, const int* ids, int n, unsigned long long* host_out);
   int* vchi_ = nullptr;                  // [B][L+1] bond dimensions the virtual pass would leave
   real* cert_min_ = nullptr;             // [B] smallest squared singular value met by the virtual pass
@@ -226,7 +226,7 @@ class Engine {
   std::vector<char> cert_ok_;            // per trajectory: the state is what a certified dissipation left (valid while cert_set_ >= 0)
   std::vector<unsigned long long> cert_sum_;
   int cert_set_ = -1;
-  int cert_skip_ = 0;                    // calls of dissipate that skip the virtual pass after one that mostly failed to certify
+  std::vector<int> cert_wait_;           // per trajectory: calls of dissipate it still sits out after its certificate failed
   int copy_back(cplx* dst, long dst_b0, const cplx* src, long src_b0, long n, const int* ids, int nb0);
   std::vector<int> unitary_jump_;
 };

@@ -357,6 +357,7 @@ int Engine::load_state(int set, const double* host, const int* bonds) {
   if (!bound_ || set < 0 || set > 1) return TJM_ERR_STATE;
   StateSet& S = sets[set];
   const double* src = host;  // complex128: (re, im) pairs
+  cert_wait_.assign(B, 0);  // new trajectories: nobody sits out
   std::vector<int> chi((size_t)B * (L + 1));
   for (int b = 0; b < B; ++b) for (int k = 0; k <= L; ++k) chi[(size_t)b * (L + 1) + k] = bonds[k];
   for (int k = 0; k <= L; ++k) if (bonds[k] > cap[k] || bonds[k] < 1) return TJM_ERR_ARG;
@@ -558,10 +559,14 @@ int Engine::identity_channels(int ca, int cb, const cplx* Lenv, long l_b0, int D
   if (off || ca < 32 || cb < 32 || (Dl < 2 && Dr < 2)) return TJM_OK;
   int rc;
   int* flags = ks.n_active + 8;
+  // The tolerance is a rounding bound, not an approximation the results lean on: an environment channel <A|A> over isometric sites
+  // deviates from the identity by what the isometries and the GEMMs lose to rounding (about 1e-15 per entry and site in fp64, 1e-13
+  // for a site whose isometry comes from a Jacobi sweep; 1e-6 in complex64), i.e. substituting the exact identity changes an H_eff
+  // apply by no more than evaluating the GEMM would.  TJM_IDENTITY_TOL overrides it (diagnostic).
 #ifdef TJM_F32
-  const real tol = 1e-4f;
+  static const real tol = getenv("TJM_IDENTITY_TOL") ? (real)atof(getenv("TJM_IDENTITY_TOL")) : real(3e-5);
 #else
-  const real tol = 1e-9;
+  static const real tol = getenv("TJM_IDENTITY_TOL") ? (real)atof(getenv("TJM_IDENTITY_TOL")) : real(1e-12);
 #endif
   TJM_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(int), stream));
   if (Dl >= 2 && (rc = launch_env_identity_check(Lenv, l_b0, ca, Dl, chi_l, L + 1, tol, flags, nb0, ids, stream)) != TJM_OK) return rc;
@@ -1158,9 +1163,10 @@ int Engine::svd_shift_left(StateSet& S, int i, const int* ids, int nb0) {
 // voids it.
 // ------------------------------------------------------------------------------------------
 __global__ void cert_update_kernel(const real* __restrict__ norms, int ncols_pad, const int* vchi_col, const int* chi_col, int stride, real* cert_min,
-                                   int* cert_flag, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+                                   int* cert_flag, int nb0, const int* ids) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb0) return;
+  const int b = ids ? ids[t] : t;
   const int keep = vchi_col[(long)b * stride], have = chi_col[(long)b * stride];
   if (keep != have) cert_flag[b] = 1;
   if (keep > 0) {
@@ -1210,14 +1216,14 @@ int Engine::state_checksum(int set, const int* ids, int n, unsigned long long* h
 // svd_shift_right on a scratch centre tensor: Cin [B][d][ca][cb] (stride cin_b0) = the centre tensor of site i; Cout [B][d][cb][cc] =
 // (S V^H) A_{i+1}, the centre tensor of site i + 1.  The bond table is read, not written (the kept count goes to vchi_), and
 // cert_min_ / cert_flag_ are updated.  Always the general kernels (the one-wavefront kernels work in place).
-int Engine::svd_shift_right_virtual(StateSet& S, int i, const cplx* Cin, long cin_b0, cplx* Cout, long cout_b0) {
+int Engine::svd_shift_right_virtual(StateSet& S, int i, const cplx* Cin, long cin_b0, cplx* Cout, long cout_b0, const int* ids, int nb0) {
   const int ca = cap[i], cb = cap[i + 1], cc = cap[i + 2];
   int rc;
   Region prof(*this, PROF_SVD);
   JacobiSource src;
   src.src = Cin; src.src_b0 = cin_b0; src.rx = d * ca; src.ncols = cb; src.conj = 0; src.tri = 0;
   src.r_n0 = ca; src.s_r1 = (long)ca * cb; src.s_r0 = cb; src.c_n0 = cb; src.s_c1 = 0; src.s_c0 = 1;
-  src.nb0 = B; src.ids = nullptr;
+  src.nb0 = nb0; src.ids = ids;
   TruncSpec tr;
   tr.trunc_mode = 0; tr.threshold = 1e-12; tr.max_bond = 0; tr.min_keep = 1;
   tr.chiA = S.chi + i; tr.mulA = d; tr.chiB = S.chi + i + 1; tr.mulB = 1; tr.chiOut = vchi_ + i + 1; tr.chi_stride = L + 1;
@@ -1225,26 +1231,26 @@ int Engine::svd_shift_right_virtual(StateSet& S, int i, const cplx* Cin, long ci
   JacobiShape sh;
   int sweeps = 0;
   if ((rc = jacobi_solve(src, tr, svdw, stream, &sh, &sweeps, false)) != TJM_OK) return rc;
-  ++stat_svds; stat_svd_mats += B; stat_svd_sweeps += sweeps;
-  hipLaunchKernelGGL(cert_update_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, svdw.norms, sh.ncols_pad, vchi_ + i + 1, S.chi + i + 1, L + 1,
-                     cert_min_, cert_flag_, B);
+  ++stat_svds; stat_svd_mats += nb0; stat_svd_sweeps += sweeps;
+  hipLaunchKernelGGL(cert_update_kernel, dim3((nb0 + 255) / 256), dim3(256), 0, stream, svdw.norms, sh.ncols_pad, vchi_ + i + 1, S.chi + i + 1, L + 1,
+                     cert_min_, cert_flag_, nb0, ids);
   ExtractDesc xu;  // U[(s,a)][k] = X_final / sigma  (zero beyond keep)
   xu.out = theta; xu.out_b0 = theta_b0; xu.n_k = cb; xu.o_k = 1; xu.n_r1 = 1; xu.n_r0 = d * ca; xu.o_r1 = 0; xu.o_r0 = cb;
   xu.row_off = 0; xu.conj = 0; xu.scale_mode = 2;
-  if ((rc = svd_extract(xu, svdw, sh, vchi_ + i + 1, L + 1, B, nullptr, stream)) != TJM_OK) return rc;
+  if ((rc = svd_extract(xu, svdw, sh, vchi_ + i + 1, L + 1, nb0, ids, stream)) != TJM_OK) return rc;
   {
     GemmDesc g = blank_gemm();  // G[k][j] = sum_{(s,a)} conj(U[(s,a)][k]) C_i[(s,a)][j]
     g.A = theta; g.B = Cin; g.C = T2;
     g.M = cb; g.K = d * ca; g.N = cb;
     g.a_rs = 1; g.a_cs = cb; g.conjA = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb;
-    g.nb0 = B; g.a_b0 = theta_b0; g.b_b0 = cin_b0; g.c_b0 = t_b0;
+    g.nb0 = nb0; g.ids = ids; g.a_b0 = theta_b0; g.b_b0 = cin_b0; g.c_b0 = t_b0;
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   GemmDesc g = blank_gemm();  // Cout[t][k][c] = G[k][j] A_{i+1}[t][j][c]
   g.A = T2; g.B = S.A[i + 1]; g.C = Cout;
   g.M = cb; g.K = cb; g.N = cc;
   g.a_rs = cb; g.a_cs = 1; g.b_rs = cc; g.b_cs = 1; g.c_rs = cc;
-  g.nb0 = B; g.nb1 = d; g.a_b0 = t_b0; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cb * cc; g.c_b0 = cout_b0; g.c_b1 = (long)cb * cc;
+  g.nb0 = nb0; g.ids = ids; g.nb1 = d; g.a_b0 = t_b0; g.b_b0 = a_b0_[i + 1]; g.b_b1 = (long)cb * cc; g.c_b0 = cout_b0; g.c_b1 = (long)cb * cc;
   return gemm(g);
 }
 
@@ -1491,14 +1497,31 @@ int Engine::dissipate(int set, double dt_, int start_center) {
           if (proc_on_[k]) { if (!noise_[k].pauli) scalar_only = false; else expo_site[i] += noise_[k].gamma; }
       expo_total += expo_site[i];
     }
-    if (scalar_only && cert_skip_ > 0) { --cert_skip_; scalar_only = false; }
+    // Which trajectories try the certificate is a function of each trajectory's own history (a trajectory that failed waits seven
+    // calls before it tries again): the code path of a trajectory - and with it the last bits of its result - must not depend on
+    // who else shares its engine.
+    std::vector<int> trying;
     if (scalar_only) {
+      if ((int)cert_wait_.size() != B) cert_wait_.assign(B, 0);
+      for (int b = 0; b < B; ++b) {
+        if (cert_wait_[b] > 0) --cert_wait_[b];
+        else trying.push_back(b);
+      }
+      if (trying.empty()) scalar_only = false;
+    }
+    if (scalar_only) {
+      const int nt = (int)trying.size();
+      int* try_ids = nullptr;  // device list of the trajectories that try (null: all of them)
+      if (nt < B) {
+        try_ids = cert_flag_ + B;  // second half of the flag buffer (carved as B doubles)
+        TJM_HIP_CHECK(hipMemcpyAsync(try_ids, trying.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice, stream));
+      }
       hipLaunchKernelGGL(cert_init_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, cert_min_, cert_flag_, B);
       const cplx* cin = S.A[0];
       long cin_b0 = a_b0_[0];
       for (int i = 0; i < L - 1; ++i) {  // the right-going pass on scratch centre tensors (two slots of the idle Krylov basis buffer)
         cplx* cout = V + (long)(i & 1) * v_ld;
-        if ((rc = svd_shift_right_virtual(S, i, cin, cin_b0, cout, v_b0)) != TJM_OK) return rc;
+        if ((rc = svd_shift_right_virtual(S, i, cin, cin_b0, cout, v_b0, try_ids, nt)) != TJM_OK) return rc;
         cin = cout;
         cin_b0 = v_b0;
       }
@@ -1509,10 +1532,13 @@ int Engine::dissipate(int set, double dt_, int start_center) {
       TJM_HIP_CHECK(hipStreamSynchronize(stream));
       const double scale = std::exp(-0.5 * dt_ * expo_total);
       std::vector<int> good, rest;
+      std::vector<char> tried(B, 0);
+      for (int b : trying) tried[b] = 1;
       for (int b = 0; b < B; ++b) {
         // the left-going pass of the reference sees the singular values scaled by the factors already applied (at most `scale`
         // in all): no truncation anywhere if even the smallest value, fully scaled, clears the threshold (margin: rounding)
-        const bool ok = flags[b] == 0 && (double)mins[b] * scale * scale >= 1e-12 * (1.0 + 1e-6);
+        const bool ok = tried[b] && flags[b] == 0 && (double)mins[b] * scale * scale >= 1e-12 * (1.0 + 1e-6);
+        if (tried[b] && !ok) cert_wait_[b] = 7;  // mostly truncating bonds: this trajectory takes the plain sweep for its next calls
         (ok ? good : rest).push_back(b);
       }
       if (getenv("TJM_DEBUG_CERT")) {
@@ -1520,7 +1546,6 @@ int Engine::dissipate(int set, double dt_, int start_center) {
         for (int b = 0; b < B; ++b) { nf += flags[b]; mn = std::min(mn, (double)mins[b]); }
         fprintf(stderr, "[cert] B %d flagged %d min sigma^2 %.3e scale^2 %.3e certified %zu\n", B, nf, mn, scale * scale, good.size());
       }
-      if (good.size() * 2 < (size_t)B) cert_skip_ = 7;  // mostly truncating bonds: take the plain sweep for the next calls
       if (!good.empty()) {
         hipLaunchKernelGGL(fill_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, scal_, (real)scale, B);
         TJM_HIP_CHECK(hipMemcpyAsync(ids_, good.data(), good.size() * sizeof(int), hipMemcpyHostToDevice, stream));

@@ -271,8 +271,12 @@ int qr_scatter(const cplx* in, long in_b0, int ld, const ExtractDesc& x, const i
 // Mixed-precision variant of the square two-site split (fp64 library only, tjm_mixed.h): workspace of its complex64 phase.
 struct MixedWorkspace { void* base = nullptr; size_t bytes = 0; int max_dim = 0, B = 0; };
 size_t mixed_split_workspace_bytes(int max_dim, int B);  // 0: not served (complex64 build, size out of range, TJM_NO_MIXED_SPLIT)
-void mixed_stats_get(double* out6, bool reset);          // batched splits, complex64 sweeps, fp64 Jacobi sweeps, batches sent to the fp64 path,
-                                                         // trajectories finished by the fp64 Jacobi, batches that needed a second polar step
+void mixed_stats_get(double* out10, bool reset);  // batched splits, complex64 sweeps, fp64 Jacobi sweeps, batches sent to the fp64 path,
+                                                  // trajectories finished by the fp64 Jacobi, batches with a second polar step, executed
+                                                  // complex64 rotation slots x rows, applied complex64 rotations x rows, GEMMs of the
+                                                  // fp64 phase, their nominal real flops
+void mixed_profile_enable(int every);             // launch sampler of the complex64 tile kernel (as profile_enable for the fp64 one)
+void mixed_profile_get(double* total_ms, double* total_bytes, long* samples);
 int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out,
                  const MixedWorkspace* mx = nullptr);
 

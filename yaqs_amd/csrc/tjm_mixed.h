@@ -38,4 +38,10 @@ size_t mixed_workspace_bytes(int max_dim, int B);
 int mixed_left_basis(const MixedBasisDesc& m, void* ws, size_t ws_bytes, int max_dim, int B, hipStream_t s, const void** basis,
                      long* basis_b0, int* sweeps_out);
 
+// Counters and the launch sampler of the complex64 Jacobi kernels (the tjm32 instances of the functions of the same name in
+// tjm_kernels.h; defined by the tjm32 compilation of tjm_svd.hip)
+void jacobi_work_get(double* out4, bool reset);
+void profile_enable(int every);
+void profile_get(double* total_ms, double* total_bytes, long* samples);
+
 }  // namespace tjm32

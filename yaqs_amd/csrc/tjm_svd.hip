@@ -2578,17 +2578,24 @@ __global__ __launch_bounds__(256) void refine_check_kernel(const cplx* __restric
   }
 }
 
-struct MixedStats { long solves = 0, c64_sweeps = 0, f64_sweeps = 0, fallbacks = 0, jacobi_trajectories = 0, second_polar = 0; };
+struct MixedStats { long solves = 0, c64_sweeps = 0, f64_sweeps = 0, fallbacks = 0, jacobi_trajectories = 0, second_polar = 0, gemms = 0; double gemm_flops = 0.0; };
 MixedStats g_mixed;
 
 }  // namespace
 
-void mixed_stats_get(double* out6, bool reset) {
+void mixed_stats_get(double* out10, bool reset) {
+  double w4[4];
+  tjm32::jacobi_work_get(w4, reset);  // executed work of the complex64 Jacobi kernels: rotation slots x rows, applied rotations x rows
   std::lock_guard<std::mutex> lock(g_prof_mutex);
-  out6[0] = (double)g_mixed.solves; out6[1] = (double)g_mixed.c64_sweeps; out6[2] = (double)g_mixed.f64_sweeps;
-  out6[3] = (double)g_mixed.fallbacks; out6[4] = (double)g_mixed.jacobi_trajectories; out6[5] = (double)g_mixed.second_polar;
+  out10[0] = (double)g_mixed.solves; out10[1] = (double)g_mixed.c64_sweeps; out10[2] = (double)g_mixed.f64_sweeps;
+  out10[3] = (double)g_mixed.fallbacks; out10[4] = (double)g_mixed.jacobi_trajectories; out10[5] = (double)g_mixed.second_polar;
+  out10[6] = w4[0]; out10[7] = w4[1];
+  out10[8] = (double)g_mixed.gemms; out10[9] = g_mixed.gemm_flops;
   if (reset) g_mixed = MixedStats();
 }
+
+void mixed_profile_enable(int every) { tjm32::profile_enable(every); }
+void mixed_profile_get(double* total_ms, double* total_bytes, long* samples) { tjm32::profile_get(total_ms, total_bytes, samples); }
 
 size_t mixed_split_workspace_bytes(int max_dim, int B) {
   static const bool off = getenv("TJM_NO_MIXED_SPLIT") != nullptr;
@@ -2607,6 +2614,16 @@ bool mixed_split_fits(const SvdSplitDesc& d, const QrWorkspace& q, const MixedWo
 }
 
 // returns TJM_OK with *done = true when the outputs are written, *done = false when the batch has to take the fp64 path
+// launch_gemm with the nominal work (8 M N K nks real flops per matrix and inner batch) added to the counters of the mixed split
+static int mixed_gemm(const GemmDesc& g, hipStream_t s) {
+  {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    ++g_mixed.gemms;
+    g_mixed.gemm_flops += 8.0 * g.M * g.N * (double)g.K * g.nks * g.nb0 * g.nb1 * g.nb2;
+  }
+  return launch_gemm(g, s);
+}
+
 static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, const MixedWorkspace& mx, hipStream_t s,
                            int* sweeps_out, bool* done) {
   *done = false;
@@ -2656,7 +2673,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     g.A = A; g.a_rs = N; g.a_cs = 1; g.a_b0 = a_b0; g.conjA = 1;
     g.B = A; g.b_rs = 1; g.b_cs = N; g.b_b0 = a_b0;
     g.C = G; g.c_rs = N; g.c_b0 = gb0;
-    return launch_gemm(g, s);
+    return mixed_gemm(g, s);
   };
   // row-major product of two row-major N x N matrices
   auto rowmul = [&](const cplx* A, long a_b0, const cplx* Bm, long b_b0, cplx* Cc, long c_b0) {
@@ -2664,7 +2681,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     g.A = A; g.a_rs = N; g.a_cs = 1; g.a_b0 = a_b0;
     g.B = Bm; g.b_rs = N; g.b_cs = 1; g.b_b0 = b_b0;
     g.C = Cc; g.c_rs = N; g.c_b0 = c_b0;
-    return launch_gemm(g, s);
+    return mixed_gemm(g, s);
   };
   // column-major Vout = Vin T (T row-major), written as the row-major matrix C[j][r] = sum_i T[i][j] Vin[r + i N]
   auto apply = [&](const cplx* Vin, const cplx* T, long t_b0, cplx* Vout) {
@@ -2672,7 +2689,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     g.A = T; g.a_rs = 1; g.a_cs = N; g.a_b0 = t_b0;
     g.B = Vin; g.b_rs = N; g.b_cs = 1; g.b_b0 = v_b0;
     g.C = Vout; g.c_rs = N; g.c_b0 = v_b0;
-    return launch_gemm(g, s);
+    return mixed_gemm(g, s);
   };
   // polar step Vin -> Vout; second = true: series to second order, cert accumulates ||E^2||_F^2 per trajectory;
   // second = false: I - E/2 only (for ||E|| <~ 1e-6 the second-order term is below rounding)
@@ -2700,7 +2717,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
       g.K = d.capL; g.b_rs = d.ld_theta; g.b_cs = 1; g.b_ks = (long)d.capL * d.ld_theta; g.conjB = 1;
     }
     g.C = w.Y; g.c_rs = N; g.c_b0 = w.y_b0;
-    return launch_gemm(g, s);
+    return mixed_gemm(g, s);
   };
   if (nn > w.y_b0) return TJM_ERR_WORKSPACE;
 
@@ -2859,7 +2876,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     gp.C = d.left; gp.c_rs = cm; gp.c_b0 = d.left_b0;
   }
   if ((rc = svd_extract(xi, w, sh, d.chiM, d.chi_stride, nb, nullptr, s)) != TJM_OK) return rc;
-  if ((rc = launch_gemm(gg, s)) != TJM_OK) return rc;
+  if ((rc = mixed_gemm(gg, s)) != TJM_OK) return rc;
   const int gxc = (int)std::min<long>(128, ((long)cm * cm + 1023) / 1024);
   hipLaunchKernelGGL(polar_residual_kernel, dim3((cm + 255) / 256, nb), dim3(256), 0, s, Gm, g_b0, cm, d.chiM, d.chi_stride);
   {  // E^2, series
@@ -2867,17 +2884,19 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     g.A = Gm; g.a_rs = cm; g.a_cs = 1; g.a_b0 = g_b0;
     g.B = Gm; g.b_rs = cm; g.b_cs = 1; g.b_b0 = g_b0;
     g.C = S2; g.c_rs = cm; g.c_b0 = x_b0;
-    if ((rc = launch_gemm(g, s)) != TJM_OK) return rc;
+    if ((rc = mixed_gemm(g, s)) != TJM_OK) return rc;
   }
   hipLaunchKernelGGL(polar_poly_kernel, dim3(gxc, nb), dim3(256), 0, s, Gm, g_b0, S2, x_b0, Cm, g_b0, cm, real(0.375), (real*)nullptr);
   TJM_HIP_CHECK(hipGetLastError());
-  if ((rc = launch_gemm(gt, s)) != TJM_OK) return rc;
-  if ((rc = launch_gemm(gp, s)) != TJM_OK) return rc;
+  if ((rc = mixed_gemm(gt, s)) != TJM_OK) return rc;
+  if ((rc = mixed_gemm(gp, s)) != TJM_OK) return rc;
   *done = true;
   return TJM_OK;
 }
 #else
-void mixed_stats_get(double* out6, bool) { for (int i = 0; i < 6; ++i) out6[i] = 0.0; }
+void mixed_stats_get(double* out10, bool) { for (int i = 0; i < 10; ++i) out10[i] = 0.0; }
+void mixed_profile_enable(int) {}
+void mixed_profile_get(double* total_ms, double* total_bytes, long* samples) { *total_ms = 0.0; *total_bytes = 0.0; *samples = 0; }
 size_t mixed_split_workspace_bytes(int, int) { return 0; }
 #endif
 
