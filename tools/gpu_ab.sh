@@ -14,10 +14,12 @@ import json, sys
 try:
     d = json.load(open(sys.argv[1]))
     r = d["roofline"]
-    print("   traj/s %.3f  s/step %.2f  svd %.1f TF (%.0f%%)  krylov %.1f TF (%.0f%%)  jacobi %.1f us  sweeps/solve %s" % (
-        d["value"], d["ms_per_step"] / 1e3, r["classes"]["svd"]["achieved_TFLOPs"], 100 * r["classes"]["svd"]["share_of_stream_time"],
-        r["classes"]["krylov"]["achieved_TFLOPs"], 100 * r["classes"]["krylov"]["share_of_stream_time"],
-        r["dominant_kernel"]["avg_launch_us"] or 0.0, r.get("jacobi_sweeps_per_solve")))
+    c = r["classes"]
+    m = r.get("mixed_split") or {}
+    print("   traj/s %.3f  s/step %.2f  svd share %.0f%% (%.1f TF executed)  krylov share %.0f%% (%.1f TF executed)  dominant kernel %.1f us, frac %.3f  c64 sweeps/split %s  fp64 GEMMs/split %s" % (
+        d["value"], d["ms_per_step"] / 1e3, 100 * c["svd"]["share_of_stream_time"], c["svd"]["executed_TFLOPs"] or 0.0,
+        100 * c["krylov"]["share_of_stream_time"], c["krylov"]["achieved_TFLOPs"] or 0.0, r.get("avg_launch_us") or 0.0, r.get("frac") or 0.0,
+        m.get("c64_sweeps_per_split"), m.get("fp64_gemms_per_split")))
 except Exception as e:
     print("   FAILED", e)
 PY

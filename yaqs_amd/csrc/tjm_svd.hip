@@ -1047,12 +1047,15 @@ __global__ __launch_bounds__(256) void jacobi_stamp_init_kernel(const cplx* __re
   }
 }
 
-__global__ void svd_sweep_check_kernel(int* nrot, int* done, int* n_active, int nb0, const int* ids) {
+// stop_at: a trajectory is done when its sweep applied at most this many rotations (0: a sweep without rotations, the convergence
+// criterion; > 0: callers that refine the result anyway).  The decision is per trajectory, so what a trajectory gets does not depend
+// on the others in its batch.
+__global__ void svd_sweep_check_kernel(int* nrot, int* done, int* n_active, int nb0, const int* ids, int stop_at) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nb0) return;
   const int b = ids ? ids[t] : t;
   if (!done[b]) {
-    if (nrot[b] == 0) done[b] = 1;
+    if (nrot[b] <= stop_at) done[b] = 1;
     else atomicAdd(n_active, 1);
     atomicAdd(n_active + 1, nrot[b]);
   }
@@ -1967,6 +1970,9 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   static const bool no_fold = getenv("TJM_NO_FOLD") != nullptr;
   g.fold = (!no_fold && split16 && !accumulate && nrounds >= 15) ? 1 : 0;
   const int max_sweeps = op.max_sweeps;
+  // op.stop_fraction: a caller that refines the result anyway (the complex64 phase of the mixed-precision split) does not pay for the
+  // sweeps that only confirm convergence: a trajectory is done after a sweep that rotated at most this fraction of its pairs
+  const int stop_at = op.stop_fraction > 0.0 ? (int)(op.stop_fraction * 0.5 * (double)ncols_pad * (ncols_pad - 1)) : 0;
   const int nb = src.nb0;
   const int tbc = (nb + 255) / 256;
   int sweep_c = 0;
@@ -2028,7 +2034,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
       else hipLaunchKernelGGL(jacobi_cross_kernel<8>, dim3(npairs, nb), dim3(512), lds, s, g);
     }
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 2 * sizeof(int), s));
-    hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tbc), dim3(256), 0, s, w.nrot, w.done, w.n_active, nb, g.ids);
+    hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tbc), dim3(256), 0, s, w.nrot, w.done, w.n_active, nb, g.ids, stop_at);
     TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active, 5 * sizeof(int), hipMemcpyDeviceToHost, s));
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 4, 0, sizeof(int), s));
     TJM_HIP_CHECK(hipStreamSynchronize(s));
@@ -2041,9 +2047,6 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     }
     if (g_debug && src.ncols >= 128) fprintf(stderr, "[svd] ncols %d rx %d sweep %d live %d rotations %d\n", src.ncols, src.rx, sweep_c, w.h_pinned[0], w.h_pinned[1]);
     n_live = *w.h_pinned;
-    // op.stop_fraction: a caller that refines the result anyway (the complex64 phase of the mixed-precision split) does not pay for
-    // the sweeps that only confirm convergence: the iteration ends after a sweep that rotated less than this fraction of the pairs
-    if (op.stop_fraction > 0.0 && (double)w.h_pinned[1] < op.stop_fraction * 0.5 * (double)ncols_pad * (ncols_pad - 1) * std::max(n_live, 1)) conv_c = true;
     // measured on the MI355X (headline step): fraction 0.25 -> 5.94, 0.7 -> 6.05, 1 (every sweep after the first) -> 5.81 trajectories/s
     static const double late_frac = getenv("TJM_LATE_FRACTION") ? atof(getenv("TJM_LATE_FRACTION")) : 0.7;
     late = !no_late && !accumulate &&
@@ -2447,10 +2450,27 @@ __global__ __launch_bounds__(256) void polar_poly_kernel(const cplx* __restrict_
   if (threadIdx.x == 0 && e2fro2) atomicAdd(&e2fro2[blockIdx.y], sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
-// flag |= 1 when a trajectory's certificate fails: the polar series I - E/2 + 3 E^2/8 leaves (5/16) ||E||_2^3 <= (5/16) ||E^2||_F^(3/2)
-__global__ void polar_check_kernel(const real* e2fro2, int nb0, real tol2, int* flag) {
+// need[b] = 1 and flag |= 1 when a trajectory's certificate fails: the polar series I - E/2 + 3 E^2/8 leaves
+// (5/16) ||E||_2^3 <= (5/16) ||E^2||_F^(3/2)
+__global__ void polar_check_kernel(const real* e2fro2, int nb0, real tol2, int* flag, int* need) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < nb0 && !(e2fro2[b] <= tol2)) atomicOr(flag, 1);
+  if (b >= nb0) return;
+  const int bad = !(e2fro2[b] <= tol2) ? 1 : 0;
+  need[b] = bad;
+  if (bad) atomicOr(flag, 1);
+}
+
+__global__ void and_flags_kernel(int* a, const int* b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = (a[i] != 0 && b[i] != 0) ? 1 : 0;
+}
+
+// dst[b] = src[b] for the trajectories with keep_src[b] == 0 (they did not need the second polar step: their basis stays what it was)
+__global__ __launch_bounds__(256) void masked_copy_kernel(cplx* __restrict__ dst, const cplx* __restrict__ src, long b0, long n, const int* __restrict__ keep_src) {
+  if (keep_src[blockIdx.y] != 0) return;
+  const cplx* sb = src + (long)blockIdx.y * b0;
+  cplx* db = dst + (long)blockIdx.y * b0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) db[e] = sb[e];
 }
 
 // Does the pair (i, j) of the Gram matrix still need work?  d_i, d_j its squared column norms, f2 = |G_ij|^2, tr = ||theta||_F^2.
@@ -2467,18 +2487,35 @@ __device__ inline bool far_column(int j, real dj, int cm, int skip_col, real tr)
 
 // First-order correction of the basis from the Gram matrix G = X^H X (row-major N x N): C_ij = G_ij / (G_jj - G_ii) for the open pairs
 // that are not both "far" columns and whose angle |C_ij| is at most zmax; 0 elsewhere.  C is anti-Hermitian by construction.
+//
+// With E = V^H V - I given (the LAST round): the basis is made unitary in the same step.  To first order V (I - E/2) is unitary and
+// turns G into G - (E D + D E) / 2 (D = diag G), so the correction is taken from G'_ij = G_ij - E_ij (d_i + d_j) / 2 with
+// d'_i = d_i (1 - E_ii), and the kernel writes W = C - E/2 (diagonal included) instead of C; the caller applies I + W + W^2/2.  zmax is
+// 1e-4 in that round: |C|^3 / 6 <= 2e-13 is what the truncated exponential then leaves of non-unitarity, with nothing behind it to
+// repair more; a pair that still wants a larger angle after a round of quadratic convergence is not converging (it is left alone and
+// shows up in the final check if it matters).
 __global__ __launch_bounds__(256) void refine_corr_kernel(const cplx* __restrict__ G, long g_b0, int N, int skip_col, int cm, const real* __restrict__ fro2,
-                                                         real zmax, cplx* __restrict__ Cm, long c_b0) {
+                                                         real zmax, cplx* __restrict__ Cm, long c_b0, const cplx* __restrict__ E, long e_b0) {
   const cplx* Gb = G + (long)blockIdx.y * g_b0;
+  const cplx* Eb = E ? E + (long)blockIdx.y * e_b0 : nullptr;
   cplx* Cb = Cm + (long)blockIdx.y * c_b0;
   const real tr = fro2[blockIdx.y];
   const long total = (long)N * N;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int i = (int)(e / N), j = (int)(e % N);
     cplx c{0.0, 0.0};
-    if (i != j) {
-      const real di = Gb[(long)i * N + i].x, dj = Gb[(long)j * N + j].x;
-      const cplx f = Gb[e];
+    if (i == j) {
+      if (Eb) c = cplx{-0.5 * Eb[e].x, 0.0};
+    } else {
+      real di = Gb[(long)i * N + i].x, dj = Gb[(long)j * N + j].x;
+      cplx f = Gb[e];
+      if (Eb) {
+        const cplx ee = Eb[e];
+        const real h = 0.5 * (di + dj);
+        f = cplx{fma(-h, ee.x, f.x), fma(-h, ee.y, f.y)};
+        di *= 1.0 - Eb[(long)i * N + i].x;
+        dj *= 1.0 - Eb[(long)j * N + j].x;
+      }
       const real f2 = fma(f.x, f.x, f.y * f.y);
       if (!(far_column(i, di, cm, skip_col, tr) && far_column(j, dj, cm, skip_col, tr)) && pair_open(di, dj, f2, tr)) {
         const real gap = dj - di;
@@ -2488,6 +2525,7 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(const cplx* __restrict
         // harmless; if it straddles the truncation the final check sends the trajectory to the Jacobi kernels
         if (af <= zmax * ag) { const real inv = 1.0 / gap; c = cplx{f.x * inv, f.y * inv}; }
       }
+      if (Eb) { const cplx ee = Eb[e]; c.x = fma(-0.5, ee.x, c.x); c.y = fma(-0.5, ee.y, c.y); }
     }
     Cb[e] = c;
   }
@@ -2518,9 +2556,11 @@ __global__ __launch_bounds__(256) void refine_poly_kernel(const cplx* __restrict
 //   bit 2  the kept columns are orthogonal to 1e-5 among themselves (their polar step takes it from there; a near-degenerate pair
 //          that the correction left alone sits at the 2e-6 of the complex64 basis).
 // Pairs inside K or inside the complement do not have to be diagonal: mixing them changes neither span.
+// strict (a spectrum is asked for, or a truncation rule that reads single discarded values): every pair has to be diagonal to the
+// Jacobi tolerance, because every column norm is then reported as a singular value.
 __global__ __launch_bounds__(256) void refine_check_kernel(const cplx* __restrict__ G, long g_b0, int N, const real* __restrict__ fro2,
                                                           const int* __restrict__ perm_all, const int* __restrict__ keep_all, int keep_stride,
-                                                          int* __restrict__ status, int* __restrict__ n_bad) {
+                                                          int strict, const int* __restrict__ skip, int* __restrict__ status, int* __restrict__ n_bad) {
   __shared__ real sd[1024];
   __shared__ unsigned char inK[1024];
   __shared__ int s_flags;
@@ -2545,7 +2585,9 @@ __global__ __launch_bounds__(256) void refine_check_kernel(const cplx* __restric
     const cplx f = Gb[e];
     const real f2 = fma(f.x, f.x, f.y * f.y);
     const real di = sd[i], dj = sd[j];
-    if (inK[i] != inK[j]) {
+    if (strict) {
+      if (pair_open(di, dj, f2, tr)) flags |= 1;
+    } else if (inK[i] != inK[j]) {
       const real gap = di - dj, dmax = di > dj ? di : dj;
       if (f2 > real(1e-26) * gap * gap + real(1e-28) * tr * dmax) flags |= 1;
     } else if (inK[i]) {
@@ -2572,10 +2614,25 @@ __global__ __launch_bounds__(256) void refine_check_kernel(const cplx* __restric
     int st = s_flags;
     real bmax = s_bound[0];
     for (int k = 1; k < 4; ++k) bmax = s_bound[k] > bmax ? s_bound[k] : bmax;
-    if (keep > 0 && keep < N && !(bmax <= s_min)) st |= 2;
+    if (!strict && keep > 0 && keep < N && !(bmax <= s_min)) st |= 2;
+    if (skip[b]) st = 0;  // a trajectory whose basis could not be made unitary: the fp64 path serves it at the end
     status[b] = st;
     if (st) atomicAdd(n_bad, 1);
   }
+}
+
+// out[b] = 1 when the trajectory has to be served by the all-fp64 path: its polar certificate failed twice (gave_up), or a KEPT
+// singular value sits at the rounding floor - its column was never rotated / corrected, the completing variant of the fp64 path
+// handles it (the per-trajectory form of the flag svd_finish_kernel raises for the batch)
+__global__ void mixed_fallback_kernel(const real* __restrict__ norms, int ncols_pad, const int* __restrict__ keep_all, int keep_stride,
+                                      const int* __restrict__ gave_up, int nb0, int* __restrict__ out, int* __restrict__ count) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb0) return;
+  const int keep = keep_all[(long)b * keep_stride];
+  const real* nr = norms + (long)b * ncols_pad;
+  const int bad = (gave_up[b] != 0 || (keep > 0 && nr[keep - 1] <= TJM_RANK_TOL * nr[0])) ? 1 : 0;
+  out[b] = bad;
+  if (bad) atomicAdd(count, 1);
 }
 
 struct MixedStats { long solves = 0, c64_sweeps = 0, f64_sweeps = 0, fallbacks = 0, jacobi_trajectories = 0, second_polar = 0, gemms = 0; double gemm_flops = 0.0; };
@@ -2602,7 +2659,7 @@ size_t mixed_split_workspace_bytes(int max_dim, int B) {
   if (off || max_dim < 128 || max_dim > 512 || max_dim % 64 != 0) return 0;
   // the complex64 phase, two more fp64 matrices per trajectory next to the four of the (idle) fp64 preconditioner, a status word
   return tjm32::mixed_workspace_bytes(max_dim, B) + 2 * (((size_t)B * max_dim * max_dim * sizeof(cplx) + 255) / 256 * 256) +
-         2 * (((size_t)B * sizeof(int) + 255) / 256 * 256) + 1024;
+         3 * (((size_t)B * sizeof(int) + 255) / 256 * 256) + 1024;
 }
 
 bool mixed_split_fits(const SvdSplitDesc& d, const QrWorkspace& q, const MixedWorkspace* mx) {
@@ -2632,16 +2689,18 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   int rc;
   int gx = (int)((nn + 1023) / 1024);
   if (gx > 128) gx = 128;
-  // ---- workspace: [complex64 phase | fp64 matrix | fp64 matrix | status | id list]
+  // ---- workspace: [complex64 phase | fp64 matrix | fp64 matrix | status | id list | polar flags]
   const size_t c64_bytes = tjm32::mixed_workspace_bytes(mx.max_dim, mx.B);
   const size_t mat_bytes = ((size_t)mx.B * mx.max_dim * mx.max_dim * sizeof(cplx) + 255) / 256 * 256;
   char* tail = static_cast<char*>(mx.base) + (c64_bytes + 255) / 256 * 256;
-  if ((size_t)(tail - static_cast<char*>(mx.base)) + 2 * mat_bytes + 2 * (((size_t)mx.B * sizeof(int) + 255) / 256 * 256) > mx.bytes) return TJM_ERR_WORKSPACE;
+  const size_t int_bytes = ((size_t)mx.B * sizeof(int) + 255) / 256 * 256;
+  if ((size_t)(tail - static_cast<char*>(mx.base)) + 2 * mat_bytes + 3 * int_bytes > mx.bytes) return TJM_ERR_WORKSPACE;
   const long x_b0 = (long)mx.max_dim * mx.max_dim;
   cplx* S2 = reinterpret_cast<cplx*>(tail);                 // squares (E^2, C^2)
   cplx* Iso = reinterpret_cast<cplx*>(tail + mat_bytes);    // the kept columns before their polar step
   int* status = reinterpret_cast<int*>(tail + 2 * mat_bytes);
-  int* idlist = status + (((size_t)mx.B * sizeof(int) + 255) / 256 * 256) / sizeof(int);
+  int* idlist = status + int_bytes / sizeof(int);
+  int* pneed = idlist + int_bytes / sizeof(int);  // per trajectory: the polar certificate failed (first step: wants a second; after it: gives up)
   // fp64 matrices in the buffers of the (idle) fp64 preconditioner
   cplx* Va = q.Z;  cplx* Vb = q.Z2;  const long v_b0 = q.z_b0;  // the basis, ping-pong (N x N column-major)
   cplx* Gm = q.V;  cplx* Cm = q.V2;  const long g_b0 = q.v_b0;  // Gram matrix / series, correction (N x N row-major)
@@ -2726,19 +2785,22 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   TJM_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
   if ((rc = polar(Va, Vb, true, e2fro2)) != TJM_OK) return rc;
   // (5/16) ||E^2||_F^(3/2) <= 1e-13  <=>  ||E^2||_F^2 <= 2.2e-17 ; anything larger says the complex64 basis is not what it should be
-  hipLaunchKernelGGL(polar_check_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, e2fro2, nb, real(2.2e-17), flag);
+  hipLaunchKernelGGL(polar_check_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, e2fro2, nb, real(2.2e-17), flag, pneed);
   TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 6, flag, sizeof(int), hipMemcpyDeviceToHost, s));
   TJM_HIP_CHECK(hipStreamSynchronize(s));
   cplx* Vstart = Vb;
   cplx* Vspare = Va;
   if (w.h_pinned[6] != 0) {
     // the complex64 iteration stopped a little early for some trajectory (its basis is orthonormal to 1e-5 rather than 2e-6): the
-    // polar iteration converges cubically, a second step of the same kind brings every residual to rounding - and is certified again
+    // polar iteration converges cubically, a second step of the same kind brings its residual to rounding - and is certified again.
+    // The GEMMs run over the whole batch; the trajectories that did not ask for it keep the basis they had (a trajectory's result
+    // must not depend on who shares its batch); one that fails again is left to the fp64 kernels at the end.
     TJM_HIP_CHECK(hipMemsetAsync(e2fro2, 0, (size_t)nb * sizeof(real), s));
     TJM_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
     if ((rc = polar(Vb, Va, true, e2fro2)) != TJM_OK) return rc;
-    hipLaunchKernelGGL(polar_check_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, e2fro2, nb, real(2.2e-17), flag);
-    TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 6, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(masked_copy_kernel, dim3(gx, nb), dim3(256), 0, s, Va, Vb, v_b0, nn, pneed);
+    hipLaunchKernelGGL(polar_check_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, e2fro2, nb, real(2.2e-17), flag, status);
+    hipLaunchKernelGGL(and_flags_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, pneed, status, nb);  // gives up: asked for the second step AND failed it
     std::swap(Vstart, Vspare);
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     ++g_mixed.second_polar;
@@ -2762,14 +2824,21 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   for (int it = 0; it < n_ref; ++it) {
     if ((rc = form_x(Vcur)) != TJM_OK) return rc;
     if ((rc = gram(w.Y, w.y_b0, Gm, g_b0)) != TJM_OK) return rc;
-    hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(0.01), Cm, g_b0);
-    if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0)) != TJM_OK) return rc;
-    hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);
-    if ((rc = apply(Vcur, Gm, g_b0, Vnext)) != TJM_OK) return rc;
-    std::swap(Vcur, Vnext);
-  }
-  if (n_ref > 0) {  // the truncated exponentials are unitary to |C|^3 / 6 <= 2e-7 (|C_ij| <= 0.01): a last, first-order polar step
-    if ((rc = polar(Vcur, Vnext, false, nullptr)) != TJM_OK) return rc;
+    if (it + 1 < n_ref) {
+      hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(0.01), Cm, g_b0, (const cplx*)nullptr, 0L);
+      if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0)) != TJM_OK) return rc;
+      hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);
+      if ((rc = apply(Vcur, Gm, g_b0, Vnext)) != TJM_OK) return rc;
+    } else {
+      // last round: the truncated exponentials of the rounds before are unitary to |C|^3 / 6 <= 2e-7 (|C_ij| <= 0.01); E = V^H V - I
+      // goes into the same factor as the last correction, W = C - E/2, applied as I + W + W^2/2
+      if ((rc = gram(Vcur, v_b0, Iso, x_b0)) != TJM_OK) return rc;
+      hipLaunchKernelGGL(polar_residual_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, Iso, x_b0, N, (const int*)nullptr, 0);
+      hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(1e-4), Cm, g_b0, (const cplx*)Iso, x_b0);
+      if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0)) != TJM_OK) return rc;
+      hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);
+      if ((rc = apply(Vcur, Gm, g_b0, Vnext)) != TJM_OK) return rc;
+    }
     std::swap(Vcur, Vnext);
   }
   if ((rc = form_x(Vcur)) != TJM_OK) return rc;
@@ -2785,21 +2854,13 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 2, 0, sizeof(int), s));
   TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 5, 0, sizeof(int), s));
   hipLaunchKernelGGL(svd_finish_kernel, dim3(nb), dim3(256), 0, s, tr, w, N, N, N, (const int*)nullptr);
-  hipLaunchKernelGGL(refine_check_kernel, dim3(nb), dim3(256), 0, s, Gm, g_b0, N, fro2, w.perm, d.chiM, d.chi_stride, status, w.n_active + 5);
+  const int strict = can_skip ? 0 : 1;
+  hipLaunchKernelGGL(refine_check_kernel, dim3(nb), dim3(256), 0, s, Gm, g_b0, N, fro2, w.perm, d.chiM, d.chi_stride, strict, pneed, status, w.n_active + 5);
   TJM_HIP_CHECK(hipGetLastError());
   TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 7, w.n_active + 5, sizeof(int), hipMemcpyDeviceToHost, s));
-  TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 8, w.n_active + 2, sizeof(int), hipMemcpyDeviceToHost, s));
   TJM_HIP_CHECK(hipStreamSynchronize(s));
-  const bool bad_polar = w.h_pinned[6] != 0;
   const int n_bad = w.h_pinned[7];
-  bool floor_kept = w.h_pinned[8] != 0;
-  if (g_debug) fprintf(stderr, "[svd-mixed] N %d c64 sweeps %d polar %d floor %d trajectories left to the fp64 Jacobi %d of %d\n", N, c64_sweeps, (int)bad_polar, (int)floor_kept, n_bad, nb);
-  if (bad_polar || floor_kept) {
-    // polar certificate failed, or a kept singular value at the noise floor (the completing variant of the fp64 path serves it)
-    std::lock_guard<std::mutex> lock(g_prof_mutex);
-    ++g_mixed.solves; ++g_mixed.fallbacks; g_mixed.c64_sweeps += c64_sweeps;
-    return TJM_OK;  // *done stays false: theta is untouched, the caller runs the fp64 path
-  }
+  if (g_debug) fprintf(stderr, "[svd-mixed] N %d c64 sweeps %d second polar %d trajectories left to the fp64 Jacobi %d of %d\n", N, c64_sweeps, (int)(Vstart == Va), n_bad, nb);
   int f64_sweeps = 0;
   if (n_bad > 0) {
     // the trajectories the check did not pass: fp64 Jacobi sweeps on their X (every pair; nearly diagonal already)
@@ -2821,9 +2882,18 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     op.preloaded = true;
     op.late_start = true;
     if ((rc = jacobi_solve(src, tr, w, s, &sh, &f64_sweeps, false, &op)) != TJM_OK) return rc;  // ends with the finish kernel of these
-    TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 8, w.n_active + 2, sizeof(int), hipMemcpyDeviceToHost, s));
-    TJM_HIP_CHECK(hipStreamSynchronize(s));
-    floor_kept = w.h_pinned[8] != 0;
+  }
+  // which trajectories does the all-fp64 path have to serve (per trajectory: nobody else's result depends on it)
+  TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 5, 0, sizeof(int), s));
+  hipLaunchKernelGGL(mixed_fallback_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, w.norms, N, d.chiM, d.chi_stride, pneed, nb, status, w.n_active + 5);
+  TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 7, w.n_active + 5, sizeof(int), hipMemcpyDeviceToHost, s));
+  TJM_HIP_CHECK(hipStreamSynchronize(s));
+  const int n_fb = w.h_pinned[7];
+  std::vector<int> fb_ids;
+  if (n_fb > 0) {
+    std::vector<int> hs(nb);
+    TJM_HIP_CHECK(hipMemcpy(hs.data(), status, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < nb; ++b) if (hs[b]) fb_ids.push_back(b);
   }
   {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
@@ -2831,10 +2901,10 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     g_mixed.c64_sweeps += c64_sweeps;
     g_mixed.f64_sweeps += f64_sweeps;
     g_mixed.jacobi_trajectories += n_bad;
-    if (floor_kept) ++g_mixed.fallbacks;
+    g_mixed.fallbacks += n_fb;
   }
   if (sweeps_out) *sweeps_out = f64_sweeps;
-  if (floor_kept) return TJM_OK;  // a kept singular value at the noise floor: the completing variant of the fp64 path
+  if (n_fb == nb) return TJM_OK;  // nobody left for this path (*done stays false): the caller runs the fp64 path on the whole batch
   // ---- isometric factor: normalised kept columns, made exactly isometric by a polar step of their own; then the projection
   ExtractDesc xi;
   GemmDesc gg, gt, gp;  // Gram of the raw isometry, raw x T, projection
@@ -2879,17 +2949,22 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   if ((rc = mixed_gemm(gg, s)) != TJM_OK) return rc;
   const int gxc = (int)std::min<long>(128, ((long)cm * cm + 1023) / 1024);
   hipLaunchKernelGGL(polar_residual_kernel, dim3((cm + 255) / 256, nb), dim3(256), 0, s, Gm, g_b0, cm, d.chiM, d.chi_stride);
-  {  // E^2, series
-    GemmDesc g; memset(&g, 0, sizeof(g)); g.nks = 1; g.nb0 = nb; g.nb1 = 1; g.nb2 = 1; g.M = cm; g.N = cm; g.K = cm;
-    g.A = Gm; g.a_rs = cm; g.a_cs = 1; g.a_b0 = g_b0;
-    g.B = Gm; g.b_rs = cm; g.b_cs = 1; g.b_b0 = g_b0;
-    g.C = S2; g.c_rs = cm; g.c_b0 = x_b0;
-    if ((rc = mixed_gemm(g, s)) != TJM_OK) return rc;
-  }
-  hipLaunchKernelGGL(polar_poly_kernel, dim3(gxc, nb), dim3(256), 0, s, Gm, g_b0, S2, x_b0, Cm, g_b0, cm, real(0.375), (real*)nullptr);
+  // (the kept columns are orthogonal to ~1e-15 ||theta|| / sigma_k, 2e-6 for a near-degenerate pair left alone: first order is exact to rounding)
+  hipLaunchKernelGGL(polar_poly_kernel, dim3(gxc, nb), dim3(256), 0, s, Gm, g_b0, Gm, g_b0, Cm, g_b0, cm, real(0.0), (real*)nullptr);
   TJM_HIP_CHECK(hipGetLastError());
   if ((rc = mixed_gemm(gt, s)) != TJM_OK) return rc;
   if ((rc = mixed_gemm(gp, s)) != TJM_OK) return rc;
+  if (n_fb > 0) {
+    // the plain fp64 split (Jacobi with the accumulated unitary: isometric whatever the rank) for the listed trajectories; it
+    // rewrites their outputs and their bond entry
+    TJM_HIP_CHECK(hipMemcpyAsync(idlist, fb_ids.data(), fb_ids.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    TJM_HIP_CHECK(hipStreamSynchronize(s));  // fb_ids is a local
+    SvdSplitDesc d2 = d;
+    d2.ids = idlist;
+    d2.nb0 = n_fb;
+    int sw2 = 0;
+    if ((rc = svd_split(d2, w, s, &sw2)) != TJM_OK) return rc;
+  }
   *done = true;
   return TJM_OK;
 }
