@@ -80,6 +80,8 @@ int tjm_engine_set_noise(tjm_engine* e, int32_t nproc, const int32_t* nsites, co
 /* MPS tensors (sigma, chi_l, chi_r) C-contiguous (mps.py:58), sites concatenated; bonds[L+1].
  * The state is broadcast to all B slots of state set `set` (0 = trajectory state, 1 = measurement copy). */
 int tjm_engine_load_state(tjm_engine* e, int32_t set, const double* host_tensors, const int32_t* bonds);
+/* one slot only (per-trajectory initial states); same tensor layout */
+int tjm_engine_load_state_slot(tjm_engine* e, int32_t set, int32_t b, const double* host_tensors, const int32_t* bonds);
 int tjm_engine_copy_state(tjm_engine* e, int32_t dst_set, int32_t src_set); /* copy.deepcopy(phi), analog_tjm.py:179 */
 size_t tjm_engine_padded_state_elems(const tjm_engine* e);                   /* complex elements per trajectory */
 int tjm_engine_bond_caps(const tjm_engine* e, int32_t* caps);                /* L+1 padded bond extents */
@@ -226,6 +228,12 @@ typedef struct {
  * value (AssertionError in mps.py:1233), TJM_ERR_NUMERIC for zero / non-finite jump weights and TJM_ERR_CAPACITY as soon as
  * a time step needed a bond beyond chi_max (the step is rolled back: see start_step). */
 int tjm_engine_run(tjm_engine* e, const tjm_run_config* cfg, const int64_t* traj, double* results, double* diagnostics);
+/* The same with one status per trajectory (SURVEY 8b's out_status): a trajectory whose state holds a non-finite number - a poisoned
+ * input, a blow-up - is taken out of the run (status[b] = TJM_ERR_NUMERIC, its result rows NaN, its slot refilled with a copy of a
+ * healthy neighbour so that every kernel keeps seeing finite data) and the other B - 1 finish exactly as they would have without it;
+ * the states are screened before the first step and after every step.  The reference loses one job of its pool in that case, not the
+ * pool (core/parallel_utils.py:361-383).  The return code still reports failures that concern the batch (capacity, arguments, HIP). */
+int tjm_engine_run_status(tjm_engine* e, const tjm_run_config* cfg, const int64_t* traj, double* results, double* diagnostics, int32_t* status);
 /* The reference's host random streams, bit-compatible with NumPy (core/random_utils.py:20-69):
  * timestep < 0: make_trajectory_rng(traj, base_seed=seed).random(n); otherwise make_sample_rng(traj, timestep, seed). */
 int tjm_rng_uniforms(int32_t has_seed, uint64_t seed, uint64_t traj, int64_t timestep, int32_t n, double* out);

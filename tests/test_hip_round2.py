@@ -554,6 +554,83 @@ def test_complex64_engine_tracks_the_fp64_oracle():
             assert np.array_equal(dg[t], do), (order, t)
 
 
+def test_a_poisoned_trajectory_is_taken_out_and_its_neighbours_finish_bit_for_bit():
+    """tjm_engine_run_status (SURVEY 8b's out_status; the reference loses one job of its pool, not the pool,
+    core/parallel_utils.py:361-383): slot 2 of five gets a NaN (an Inf) in its initial state.  It comes back with status
+    TJM_ERR_NUMERIC and NaN rows; the other four trajectories return exactly the rows, diagnostics and statuses of a clean run - for
+    both drivers, with and without time-step sampling.  Without the status array the same input fails the batch, as before."""
+    from yaqs_amd import _lib
+    from yaqs_amd.api import NoiseModel, is_pauli
+
+    L, chi, B = 6, 8, 5
+    mpo = o.ising_mpo(L, 1.0, 0.5)
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.1} for i in range(L) for n in ("lowering", "pauli_z")])
+    init = [t.copy() for t in o.MPSState.product(L, "x+").tensors]
+    zmat = np.diag([1.0, -1.0]).astype(np.complex128)
+    obs = [(s_, zmat) for s_ in range(L)]
+    trajs = [3, 4, 5, 6, 7]
+
+    def run(poison, order, sample, with_status=True):
+        e = make_engine(L, chi, B, mpo)
+        e.set_params(dt=0.1, svd_threshold=1e-9, max_bond_dim=chi, krylov_tol=1e-10, tdvp_mode="2site")
+        e.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
+        e.load_state(init)
+        if poison is not None:
+            bad = [t.copy() for t in init]
+            bad[1][0, 0, 0] = poison
+            e.load_state_slot(2, bad)
+        status = np.full(B, -99, dtype=np.int32) if with_status else None
+        try:
+            res, diag = e.run(order=order, n_times=5, sample_timesteps=sample, has_noise=True, seed=11, traj_indices=trajs, observables=obs, status=status)
+        finally:
+            e.close()
+        return res, diag, status
+
+    for order in (1, 2):
+        for sample in (True, False):
+            clean, cdiag, cst = run(None, order, sample)
+            assert np.all(cst == 0) and np.all(np.isfinite(clean))
+            for poison in (np.nan, np.inf):
+                res, diag, st = run(poison, order, sample)
+                assert st[2] == -5 and np.all(np.isnan(res[2])), (order, sample, poison, st, res[2])
+                keep = [0, 1, 3, 4]
+                assert np.all(st[keep] == 0)
+                assert np.array_equal(res[keep], clean[keep]), (order, sample, poison)
+                assert np.array_equal(diag[keep], cdiag[keep]), (order, sample, poison)
+    with pytest.raises((AssertionError, ValueError)):
+        run(np.nan, 1, True, with_status=False)
+
+
+def test_complex64_engine_evolves_under_a_weak_hamiltonian():
+    """The Lanczos breakdown test of the complex64 build is relative to the size of H_eff (max(|alpha_0|, beta_0), tjm_common.h): with
+    couplings of 1e-3 every beta is far below the absolute cut an fp32 epsilon gives (100 sqrt(n) eps ~ 4e-3 for these blocks), which
+    would declare an invariant subspace after the first vector and leave the block unevolved.  Long steps (dt = 2) of a weak TFIM on a
+    Haar state through the fused small-bond kernel (chi = 8) and the general Lanczos loop (chi = 24): the state must follow the
+    fp64 oracle, and it must have moved by much more than the tolerance."""
+    from yaqs_amd.engine import BatchEngine
+
+    for L, chi in ((8, 8), (10, 24)):
+        mpo = o.ising_mpo(L, 2e-3, 1e-3)
+        st = o.MPSState.haar(L, chi, np.random.default_rng(3 * L + chi))
+        st.normalize("B")
+        init = [t.copy() for t in st.tensors]
+        e = BatchEngine(L, chi, 2, mpo, dtype="complex64")
+        e.set_params(dt=2.0, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=1e-6, tdvp_mode="2site")
+        e.load_state(init)
+        for _ in range(3):
+            e.tdvp()
+        out = e.export_state(1)
+        e.close()
+        ref = o.MPSState([t.copy() for t in init], 0)
+        for _ in range(3):
+            o.tdvp(ref, mpo, o.Params(dt=2.0, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=1e-10, tdvp_mode="2site"))
+        v0 = o.MPSState([t.copy() for t in init], 0).to_vec()
+        moved = np.abs(ref.to_vec() - v0).max()
+        err = np.abs(phase_align(ref.to_vec(), vec_of(out)) - ref.to_vec()).max()
+        assert moved > 50 * 2e-5, (L, chi, moved)
+        assert err < 2e-5, (L, chi, err, moved)
+
+
 def test_complex64_dynamic_tdvp_and_bug_track_the_fp64_oracle():
     """The host-driven integrators on the complex64 engine (site-level steps, stacked bases, compression): one dynamic-TDVP sweep and
     one BUG step on the generic-state chains of tests/golden/f3_dynamic_bug.npz against the fp64 oracle - same bond dimensions,

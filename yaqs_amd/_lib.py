@@ -83,6 +83,7 @@ EXPORTS = {
     "tjm_engine_set_mpo": (C.c_int, [V, V]),
     "tjm_engine_set_noise": (C.c_int, [V, I, V, V, V, V, V, V, V]),
     "tjm_engine_load_state": (C.c_int, [V, I, V, V]),
+    "tjm_engine_load_state_slot": (C.c_int, [V, I, I, V, V]),
     "tjm_engine_copy_state": (C.c_int, [V, I, I]),
     "tjm_engine_padded_state_elems": (C.c_size_t, [V]),
     "tjm_engine_bond_caps": (C.c_int, [V, V]),
@@ -129,6 +130,7 @@ EXPORTS = {
     "tjm_engine_profile": (C.c_int, [V, I]),
     "tjm_engine_profile_read": (C.c_int, [V, V, V]),
     "tjm_engine_run": (C.c_int, [V, C.POINTER(RunConfig), V, V, V]),
+    "tjm_engine_run_status": (C.c_int, [V, C.POINTER(RunConfig), V, V, V, V]),
     "tjm_rng_uniforms": (C.c_int, [I, C.c_uint64, C.c_uint64, C.c_int64, I, V]),
     "tjm_zgemm_batched": (C.c_int, [C.POINTER(GemmDesc), V]),
     "tjm_svd_workspace_bytes": (C.c_size_t, [I, I]),

@@ -145,6 +145,10 @@ int tjm_engine_load_state(tjm_engine* e, int32_t set, const double* t, const int
   TJM_ON_DEVICE(e);
   return (e && t && bonds) ? e->impl.load_state(set, t, bonds) : TJM_ERR_ARG;
 }
+int tjm_engine_load_state_slot(tjm_engine* e, int32_t set, int32_t b, const double* t, const int32_t* bonds) {
+  TJM_ON_DEVICE(e);
+  return (e && t && bonds) ? e->impl.load_state_slot(set, b, t, bonds) : TJM_ERR_ARG;
+}
 int tjm_engine_copy_state(tjm_engine* e, int32_t dst, int32_t src) { TJM_ON_DEVICE(e); return e ? e->impl.copy_state(dst, src) : TJM_ERR_ARG; }
 
 size_t tjm_engine_padded_state_elems(const tjm_engine* e) {
@@ -222,6 +226,12 @@ int tjm_engine_run(tjm_engine* e, const tjm_run_config* cfg, const int64_t* traj
   if (!e) return TJM_ERR_ARG;
   TJM_ON_DEVICE(e);
   return run_batch(e->impl, cfg, traj, results, diagnostics);
+}
+
+int tjm_engine_run_status(tjm_engine* e, const tjm_run_config* cfg, const int64_t* traj, double* results, double* diagnostics, int32_t* status) {
+  if (!e || !status) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return run_batch(e->impl, cfg, traj, results, diagnostics, status);
 }
 
 int tjm_rng_uniforms(int32_t has_seed, uint64_t seed, uint64_t traj, int64_t timestep, int32_t n, double* out) {

@@ -103,7 +103,18 @@ __device__ inline real tjm_rcp(real x) { return __builtin_amdgcn_rcp(x); }
 // bound (6e-9 for a two-site block at chi = 256); with the fp32 epsilon the same formula gives 3.1 there - above every beta of a bulk
 // site, so the complex64 build declared "invariant subspace" after the first vector and left the block unevolved (found on the
 // MI355X: config 3 at chi = 256 lost no norm in its truncations).  The complex64 build uses the size of an fp32 rounding residual
-// instead: eps * sqrt(size) per unit of |H|, with the same factor 100.
+// instead: eps * sqrt(size) per unit of |H|, with the same factor 100 - and |H| is estimated by the first Lanczos coefficients,
+// max(|alpha_0|, beta_0) (tjm_breakdown_scale), so that a weak Hamiltonian or a short sub-step, whose beta are all small, is not
+// mistaken for an invariant subspace.  The fp64 build keeps the reference's absolute formula (scale 1): parity with it is the point.
+__host__ __device__ inline real tjm_breakdown_scale(real alpha0, real beta0) {
+#ifdef TJM_F32
+  const real a = alpha0 < 0 ? -alpha0 : alpha0;
+  return a > beta0 ? a : beta0;
+#else
+  (void)alpha0; (void)beta0;
+  return 1.0;
+#endif
+}
 __host__ __device__ inline real tjm_breakdown_cut(int nloc) {
 #ifdef TJM_F32
   return 100.0f * sqrtf((float)nloc) * TJM_EPS;

@@ -59,6 +59,9 @@ class Engine {
   ~Engine();  // pinned host words and HIP events (the device workspace belongs to the caller)
   int create(int L, int d, int chi_max, int B, const int* mpo_bond, int cap_slack = 1);
   size_t workspace_bytes() const;
+  int load_state_slot(int set, int b, const double* host, const int* bonds);
+  int copy_slot(int set, int dst, int src);
+  int finite_check(int set, int* host_flags);
   int bind(void* ws, size_t bytes, hipStream_t s);
   int set_mpo(const double* host_tensors);   // packed (o,p,l,r) complex128 per site
   int set_noise(const std::vector<NoiseProc>& procs);
@@ -233,6 +236,6 @@ class Engine {
 
 // tjm_run.hip
 void rng_uniforms(int has_seed, uint64_t seed, uint64_t traj, int64_t timestep, int n, double* out);
-int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* results, double* diagnostics);
+int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* results, double* diagnostics, int32_t* status = nullptr);
 
 }  // namespace tjm

@@ -384,6 +384,71 @@ int Engine::load_state(int set, const double* host, const int* bonds) {
   return TJM_OK;
 }
 
+// One slot of a state set from host tensors (the others keep what they hold): per-trajectory initial states.
+int Engine::load_state_slot(int set, int b, const double* host, const int* bonds) {
+  if (!bound_ || set < 0 || set > 1 || b < 0 || b >= B) return TJM_ERR_STATE;
+  StateSet& S = sets[set];
+  for (int k = 0; k <= L; ++k) if (bonds[k] > cap[k] || bonds[k] < 1) return TJM_ERR_ARG;
+  if ((int)cert_wait_.size() == B) cert_wait_[b] = 0;
+  TJM_HIP_CHECK(hipMemcpyAsync(S.chi + (long)b * (L + 1), bonds, (size_t)(L + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
+  const double* src = host;
+  for (int i = 0; i < L; ++i) {
+    const int cl = bonds[i], cr = bonds[i + 1];
+    std::vector<cplx> pad((size_t)a_b0_[i], cplx{0.0, 0.0});
+    for (int p = 0; p < d; ++p) for (int a = 0; a < cl; ++a) for (int c = 0; c < cr; ++c) {
+      const double* z = src + 2 * (((size_t)p * cl + a) * cr + c);
+      pad[((size_t)p * cap[i] + a) * cap[i + 1] + c] = cplx{(real)z[0], (real)z[1]};
+    }
+    src += 2 * (size_t)d * cl * cr;
+    TJM_HIP_CHECK(hipMemcpyAsync(S.A[i] + (long)b * a_b0_[i], pad.data(), pad.size() * sizeof(cplx), hipMemcpyHostToDevice, stream));
+    TJM_HIP_CHECK(hipStreamSynchronize(stream));  // pad is a local
+  }
+  cert_set_ = -1;
+  return TJM_OK;
+}
+
+// slot dst of a set = slot src of the same set (tensors and bond row)
+int Engine::copy_slot(int set, int dst, int src) {
+  if (!bound_ || set < 0 || set >= n_sets || dst < 0 || src < 0 || dst >= B || src >= B) return TJM_ERR_ARG;
+  if (dst == src) return TJM_OK;
+  StateSet& S = sets[set];
+  for (int i = 0; i < L; ++i)
+    TJM_HIP_CHECK(hipMemcpyAsync(S.A[i] + (long)dst * a_b0_[i], S.A[i] + (long)src * a_b0_[i], (size_t)a_b0_[i] * sizeof(cplx), hipMemcpyDeviceToDevice, stream));
+  TJM_HIP_CHECK(hipMemcpyAsync(S.chi + (long)dst * (L + 1), S.chi + (long)src * (L + 1), (size_t)(L + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  if ((int)cert_wait_.size() == B) cert_wait_[dst] = cert_wait_[src];
+  cert_set_ = -1;
+  return TJM_OK;
+}
+
+// flags[b] |= 1 when a site tensor of trajectory b holds a NaN or an infinity
+__global__ __launch_bounds__(256) void finite_flags_kernel(const cplx* __restrict__ A, long a_b0, int* __restrict__ flags) {
+  const cplx* Ab = A + (long)blockIdx.y * a_b0;
+  int bad = 0;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < a_b0; e += (long)gridDim.x * blockDim.x) {
+    const cplx v = Ab[e];
+    const real t = v.x - v.x + (v.y - v.y);  // 0 for finite entries, NaN otherwise
+    bad |= (t == real(0.0)) ? 0 : 1;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[blockIdx.y], 1);
+}
+
+// host_flags[b] = 1 when the state of trajectory b holds a non-finite number
+int Engine::finite_check(int set, int* host_flags) {
+  if (!bound_ || set < 0 || set >= n_sets) return TJM_ERR_STATE;
+  StateSet& S = sets[set];
+  TJM_HIP_CHECK(hipMemsetAsync(ids_, 0, (size_t)B * sizeof(int), stream));
+  for (int i = 0; i < L; ++i) {
+    int gx = (int)((a_b0_[i] + 4095) / 4096);
+    if (gx < 1) gx = 1;
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(finite_flags_kernel, dim3(gx, B), dim3(256), 0, stream, S.A[i], a_b0_[i], ids_);
+  }
+  TJM_HIP_CHECK(hipGetLastError());
+  TJM_HIP_CHECK(hipMemcpyAsync(host_flags, ids_, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
 int Engine::copy_state(int dst, int src) {
   if (!bound_ || dst == src || dst < 0 || src < 0 || dst >= n_sets || src >= n_sets) return TJM_ERR_ARG;
   for (int i = 0; i < L; ++i)

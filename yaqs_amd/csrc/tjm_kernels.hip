@@ -5,6 +5,8 @@
 //
 // Reference: core/methods/matrix_exponential.py:33-173 (expm_krylov),
 // core/methods/tdvp/primitives.py:77-226, core/methods/stochastic_process.py:190-292.
+#include <atomic>
+
 #include "tjm_kernels.h"
 
 namespace tjm {
@@ -102,10 +104,10 @@ int launch_mpo_apply_p(const MpoApplyDesc& d, dim3 grid, hipStream_t stream) {
     w_in_lds = 0;
     sh = 0;
   } else if (sh > LDS_DEFAULT) {
-    static bool raised = false;  // once per process (one process per GPU)
-    if (!raised) {
+    static std::atomic<bool> raised{false};  // several engines of one process call this from their own host threads  // once per process (one process per GPU)
+    if (!raised.load(std::memory_order_acquire)) {
       TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(mpo_apply_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CU));
-      raised = true;
+      raised.store(true, std::memory_order_release);
     }
   }
   hipLaunchKernelGGL(mpo_apply_kernel<P>, grid, dim3(256), sh, stream, d, w_in_lds);
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
     if (tid < 64) {  // breakdown and adaptive stop (lanczos_finalize_kernel)
       real pr = 0.0, pi = 0.0;
       bool done = false;
-      if (j < m - 1 && bj < eps_cut) {
+      if (j < m - 1 && bj < eps_cut * tjm_breakdown_scale(j == 0 ? alpha : sAl[0], j == 0 ? bj : sBe[0])) {
         tridiag_expm_e1(sAl, sBe, k, p.dt, tid, pr, pi);
         done = true;
       } else if (j >= 1 || j == m - 1) {
@@ -479,10 +481,10 @@ bool krylov_small_fits(int P, int ca, int cb, int Dl, int Dr, int mmax, int nb0)
 
 int launch_krylov_site_small(const SmallKrylovDesc& p, hipStream_t s) {
   if (p.nb0 <= 0) return TJM_OK;
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<bool> attr{false};  // several engines of one process call this from their own host threads
+  if (!attr.load(std::memory_order_acquire)) {
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(krylov_site_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KS_MAX_LDS));
-    attr = true;
+    attr.store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(krylov_site_small_kernel, dim3(p.nb0), dim3(256), krylov_small_lds(p.P, p.ca, p.cb, p.Dl, p.Dr), s, p);
   TJM_HIP_CHECK(hipGetLastError());
@@ -536,7 +538,7 @@ __global__ __launch_bounds__(64) void lanczos_finalize_kernel(KrylovState ks, co
   bool done = false;
   const int k = j + 1;
   real pr = 0.0, pi = 0.0;
-  if (j < m - 1 && bj < eps_cut) {
+  if (j < m - 1 && bj < eps_cut * tjm_breakdown_scale(j == 0 ? a : al[0], j == 0 ? bj : be[0])) {
     tridiag_expm_e1(al, be, k, dt, lane, pr, pi, j, a);
     done = true;
   } else if (j >= 1 || j == m - 1) {

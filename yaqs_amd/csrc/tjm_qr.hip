@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <atomic>
+
 #include "tjm_kernels.h"
 
 namespace tjm {
@@ -765,13 +767,13 @@ int qr_prepare(const cplx* theta, long th_b0, int m, int n, int dist, int d, con
 // Z (zr x zc, column-major in q.Z) = Q R in place: R in the upper triangle, reflector blocks in q.V / q.T.
 int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hipStream_t s) {
   const int kmax = zr < zc ? zr : zc;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};  // several engines of one process call this from their own host threads
+  if (!attr_set.load(std::memory_order_acquire)) {
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_panel_rows_kernel<2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   static const bool no_rows = getenv("TJM_QR_LDS_PANEL") != nullptr;
   int rc;

@@ -115,6 +115,7 @@ namespace {
 struct RunCtx {
   Engine* e;
   const tjm_run_config* c;
+  const std::vector<char>* dead = nullptr;  // trajectories taken out of the run (their rows are NaN)
   int T, cols;
   double* results;      // [B][n_obs][cols]
   double* diagnostics;  // [B][3][cols]
@@ -141,6 +142,7 @@ int measure(RunCtx& r, int set, int col) {
           re += o.x * m.x - o.y * m.y;
           im += o.x * m.y + o.y * m.x;
         }
+      if (r.dead && (*r.dead)[b]) { r.results[((size_t)b * r.c->n_obs + k) * r.cols + col] = __builtin_nan(""); continue; }
       if (!(im < TJM_IMAG_TOL)) return TJM_ERR_ASSERT;  // "assert exp.imag < 1e-13" (mps.py:1233): a NaN fails it too
       r.results[((size_t)b * r.c->n_obs + k) * r.cols + col] = re;
     }
@@ -162,7 +164,12 @@ int measure(RunCtx& r, int set, int col) {
 
 }  // namespace
 
-int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* results, double* diagnostics) {
+// status == nullptr: one return code for the batch (the first failure ends the call).  With a status array a trajectory whose state
+// holds a non-finite number is TAKEN OUT instead - status[b] = TJM_ERR_NUMERIC, its rows NaN, its slot refilled with a copy of a healthy
+// neighbour so that every kernel keeps seeing finite data - and the other trajectories finish exactly as they would have without it
+// (a trajectory is a pure function of its own slot): the reference loses one job of its pool, not the pool
+// (core/parallel_utils.py:361-383).  The states are screened before the first step and after every step.
+int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* results, double* diagnostics, int32_t* status) {
   if (!c || !traj || !results || !diagnostics) return TJM_ERR_ARG;
   if (c->n_times < 1 || (c->order != 1 && c->order != 2) || c->n_obs < 0) return TJM_ERR_ARG;
   const int B = e.B, L = e.L, d = e.d;
@@ -187,6 +194,23 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
   std::vector<int> pos(B, 0), jumped(B, 0), pos_snap(B, 0);
   std::vector<double> cand((size_t)B * 2);
   int rc, clipped = 0;
+  std::vector<char> dead(B, 0);
+  std::vector<int> nonfinite(B, 0);
+  if (status) { for (int b = 0; b < B; ++b) status[b] = TJM_OK; r.dead = &dead; }
+  auto screen = [&](int set) -> int {
+    if (!status) return TJM_OK;
+    if ((rc = e.finite_check(set, nonfinite.data())) != TJM_OK) return rc;
+    int donor = -1;
+    for (int b = 0; b < B && donor < 0; ++b) if (!nonfinite[b] && !dead[b]) donor = b;
+    for (int b = 0; b < B; ++b) {
+      if (!nonfinite[b]) continue;
+      if (!dead[b]) { dead[b] = 1; status[b] = TJM_ERR_NUMERIC; }
+      if (donor < 0) return TJM_ERR_NUMERIC;  // nobody left to run
+      if ((rc = e.copy_slot(set, b, donor)) != TJM_OK) return rc;
+    }
+    return TJM_OK;
+  };
+  if ((rc = screen(0)) != TJM_OK) return rc;
   const int j0 = c->start_step;
   if (j0 < 0 || j0 >= n_t || (j0 > 0 && !c->rng_pos) || (c->start_phase != 0 && (c->order != 2 || j0 < 2))) return TJM_ERR_ARG;
   if (j0 > 0)
@@ -243,6 +267,7 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
         if ((rc = roll_back()) != TJM_OK) return rc;
         return stop_at(j, 0);
       }
+      if ((rc = screen(0)) != TJM_OK) return rc;
       if (record(j))
         if ((rc = measure(r, 0, col_of(j))) != TJM_OK) return rc;
     }
@@ -285,6 +310,7 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
         if ((rc = roll_back()) != TJM_OK) return rc;
         return stop_at(j, 0);
       }
+      if ((rc = screen(0)) != TJM_OK) return rc;
     }
     if ((rc = sample(j)) != TJM_OK) return rc;
     if (over) return stop_at(j, 1);

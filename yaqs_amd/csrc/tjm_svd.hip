@@ -26,6 +26,8 @@
 #include <utility>
 #include <vector>
 
+#include <atomic>
+
 #include "tjm_kernels.h"
 #ifndef TJM_F32
 #include "tjm_mixed.h"
@@ -1877,11 +1879,11 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   const bool big = rtot > 512;  // 16 row groups per column instead of 8
   static const bool no_lds = getenv("TJM_NO_LDS_JACOBI") != nullptr;
   if (!no_lds && ncols_pad <= 64 && rtot <= 128) {  // the whole problem fits one workgroup's LDS: all sweeps in one launch
-    static bool lds_attr = false;
-    if (!lds_attr) {
+    static std::atomic<bool> lds_attr{false};  // several engines of one process call this from their own host threads
+    if (!lds_attr.load(std::memory_order_acquire)) {
       TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_lds_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
       TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_lds_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-      lds_attr = true;
+      lds_attr.store(true, std::memory_order_release);
     }
     const long total = (long)ncols_pad * rtot;
     int gx = (int)((total + 1023) / 1024);
@@ -1903,8 +1905,8 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     if (shape_out) { shape_out->ncols_pad = ncols_pad; shape_out->rx_top = rx_top; shape_out->rtot = rtot; }
     return (*w.h_pinned == 0) ? TJM_OK : TJM_ERR_NUMERIC;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<bool> attr_set{false};  // several engines of one process call this from their own host threads
+  if (!attr_set.load(std::memory_order_acquire)) {
     const int big_lds = 136 * 1024;
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, big_lds));
@@ -1920,7 +1922,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     TJM_X16_ATTR(7, big_lds);
     TJM_X16_ATTR(8, big_lds);
 #undef TJM_X16_ATTR
-    attr_set = true;
+    attr_set.store(true, std::memory_order_release);
   }
   const size_t lds = (size_t)NB * rtot * sizeof(cplx) + NB * sizeof(real) + 16 * sizeof(int);
   const int tb = (src.nb0 + 255) / 256;

@@ -132,6 +132,12 @@ class BatchEngine:
         packed = np.concatenate([np.ascontiguousarray(t, dtype=np.complex128).reshape(-1) for t in tensors])
         _lib.check(self.lib.tjm_engine_load_state(self.h, set_index, packed.ctypes.data, bonds.ctypes.data), "load_state")
 
+    def load_state_slot(self, b: int, tensors: Sequence[np.ndarray], set_index: int = 0):
+        """One trajectory slot only (the others keep their states): per-trajectory initial states."""
+        bonds = _i32([tensors[0].shape[1]] + [t.shape[2] for t in tensors])
+        packed = np.concatenate([np.ascontiguousarray(t, dtype=np.complex128).reshape(-1) for t in tensors])
+        _lib.check(self.lib.tjm_engine_load_state_slot(self.h, set_index, int(b), packed.ctypes.data, bonds.ctypes.data), "load_state_slot")
+
     def copy_state(self, dst: int, src: int):
         _lib.check(self.lib.tjm_engine_copy_state(self.h, dst, src), "copy_state")
 
@@ -215,7 +221,7 @@ class BatchEngine:
         return out
 
     def run(self, *, order: int, n_times: int, sample_timesteps: bool, has_noise: bool, seed, traj_indices, observables,
-            start=(0, 0), rng_pos=None, results=None, diagnostics=None):
+            start=(0, 0), rng_pos=None, results=None, diagnostics=None, status=None):
         """Whole trajectories in one C call (tjm_engine_run).  observables: [(first_site, matrix d x d | d^2 x d^2)] in site-sorted order.
 
         ``start`` / ``rng_pos`` / ``results`` / ``diagnostics`` continue a run that stopped with ``CapacityError`` (whose
@@ -245,7 +251,12 @@ class BatchEngine:
         assert results.shape == (self.B, n_obs, cols) and diagnostics.shape == (self.B, 3, cols)
         assert results.flags.c_contiguous and diagnostics.flags.c_contiguous
         try:
-            _lib.check(self.lib.tjm_engine_run(self.h, C.byref(cfg), traj.ctypes.data, results.ctypes.data, diagnostics.ctypes.data), "run")
+            if status is not None:  # int32 [B], filled with one code per trajectory: a non-finite trajectory is taken out, the others finish
+                assert status.dtype == np.int32 and status.shape == (self.B,) and status.flags.c_contiguous
+                _lib.check(self.lib.tjm_engine_run_status(self.h, C.byref(cfg), traj.ctypes.data, results.ctypes.data, diagnostics.ctypes.data,
+                                                          status.ctypes.data), "run")
+            else:
+                _lib.check(self.lib.tjm_engine_run(self.h, C.byref(cfg), traj.ctypes.data, results.ctypes.data, diagnostics.ctypes.data), "run")
         except _lib.CapacityError as err:
             err.resume = (int(resume[0]), int(resume[1]))
             err.rng_pos = pos
