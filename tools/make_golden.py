@@ -597,10 +597,18 @@ def gen_fullsize(which=("cfg2", "cfg4", "cfg3")):
     if "cfg4" in which:
         api, tensors = _fullsize_inputs(32, 256)
         mpo = api.MPO.long_range_ising(32, [0.8792, 0.1208], [0.0717, 0.5136], 0.5)
-        _one_step("cfg4", 32, 256, mpo.tensors, "pauli_z", 0.05, 0.05, "1site", tensors, [0], out)
+        # dp = 0.077 per step here: trajectory 0 does not jump; the first one whose opening uniform is below 0.05 does
+        us = [rutil.make_trajectory_rng(t, base_seed=42).random() for t in range(64)]
+        jumper = next(t for t in range(64) if us[t] < 0.05)
+        _one_step("cfg4", 32, 256, mpo.tensors, "pauli_z", 0.05, 0.05, "1site", tensors, [0, jumper], out)
     if "cfg3" in which:
         api, tensors = _fullsize_inputs(128, 256)
-        _one_step("cfg3", 128, 256, api.MPO.heisenberg(128, 1.0, 1.0, 0.5, 0.0).tensors, "lowering", 0.05, 0.05, "2site", tensors, [0], out)
+        # amplitude damping on a Haar state: dp ~ 0.15 per step; one trajectory that does not jump, one that does (non-Pauli jump
+        # operator: the QR walk, the state-dependent jump weights and the SVD sweep back at chi = 256)
+        us = [rutil.make_trajectory_rng(t, base_seed=42).random() for t in range(64)]
+        jumper = next(t for t in range(64) if us[t] < 0.05)
+        quiet = next(t for t in range(64) if us[t] > 0.5)
+        _one_step("cfg3", 128, 256, api.MPO.heisenberg(128, 1.0, 1.0, 0.5, 0.0).tensors, "lowering", 0.05, 0.05, "2site", tensors, [quiet, jumper], out)
     save("fullsize", **out)
 
 
