@@ -230,6 +230,7 @@ class Engine {
   std::vector<unsigned long long> cert_sum_;
   int cert_set_ = -1;
   std::vector<int> cert_wait_;           // per trajectory: calls of dissipate it still sits out after its certificate failed
+  std::vector<int> cert_back_;           // per trajectory: length of its last sit-out (doubles with consecutive failures, at most 4)
   int copy_back(cplx* dst, long dst_b0, const cplx* src, long src_b0, long n, const int* ids, int nb0);
   std::vector<int> unitary_jump_;
 };

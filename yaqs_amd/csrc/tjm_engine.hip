@@ -358,6 +358,7 @@ int Engine::load_state(int set, const double* host, const int* bonds) {
   StateSet& S = sets[set];
   const double* src = host;  // complex128: (re, im) pairs
   cert_wait_.assign(B, 0);  // new trajectories: nobody sits out
+  cert_back_.assign(B, 0);
   std::vector<int> chi((size_t)B * (L + 1));
   for (int b = 0; b < B; ++b) for (int k = 0; k <= L; ++k) chi[(size_t)b * (L + 1) + k] = bonds[k];
   for (int k = 0; k <= L; ++k) if (bonds[k] > cap[k] || bonds[k] < 1) return TJM_ERR_ARG;
@@ -389,7 +390,7 @@ int Engine::load_state_slot(int set, int b, const double* host, const int* bonds
   if (!bound_ || set < 0 || set > 1 || b < 0 || b >= B) return TJM_ERR_STATE;
   StateSet& S = sets[set];
   for (int k = 0; k <= L; ++k) if (bonds[k] > cap[k] || bonds[k] < 1) return TJM_ERR_ARG;
-  if ((int)cert_wait_.size() == B) cert_wait_[b] = 0;
+  if ((int)cert_wait_.size() == B) { cert_wait_[b] = 0; cert_back_[b] = 0; }
   TJM_HIP_CHECK(hipMemcpyAsync(S.chi + (long)b * (L + 1), bonds, (size_t)(L + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
   const double* src = host;
   for (int i = 0; i < L; ++i) {
@@ -415,7 +416,7 @@ int Engine::copy_slot(int set, int dst, int src) {
   for (int i = 0; i < L; ++i)
     TJM_HIP_CHECK(hipMemcpyAsync(S.A[i] + (long)dst * a_b0_[i], S.A[i] + (long)src * a_b0_[i], (size_t)a_b0_[i] * sizeof(cplx), hipMemcpyDeviceToDevice, stream));
   TJM_HIP_CHECK(hipMemcpyAsync(S.chi + (long)dst * (L + 1), S.chi + (long)src * (L + 1), (size_t)(L + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
-  if ((int)cert_wait_.size() == B) cert_wait_[dst] = cert_wait_[src];
+  if ((int)cert_wait_.size() == B) { cert_wait_[dst] = cert_wait_[src]; cert_back_[dst] = cert_back_[src]; }
   cert_set_ = -1;
   return TJM_OK;
 }
@@ -1562,12 +1563,12 @@ int Engine::dissipate(int set, double dt_, int start_center) {
           if (proc_on_[k]) { if (!noise_[k].pauli) scalar_only = false; else expo_site[i] += noise_[k].gamma; }
       expo_total += expo_site[i];
     }
-    // Which trajectories try the certificate is a function of each trajectory's own history (a trajectory that failed waits seven
-    // calls before it tries again): the code path of a trajectory - and with it the last bits of its result - must not depend on
-    // who else shares its engine.
+    // Which trajectories try the certificate is a function of each trajectory's own history (after a failure a trajectory sits out
+    // one call, after the next failure two, then four at most; a success clears it): the code path of a trajectory - and with it
+    // the last bits of its result - must not depend on who else shares its engine.
     std::vector<int> trying;
     if (scalar_only) {
-      if ((int)cert_wait_.size() != B) cert_wait_.assign(B, 0);
+      if ((int)cert_wait_.size() != B) { cert_wait_.assign(B, 0); cert_back_.assign(B, 0); }
       for (int b = 0; b < B; ++b) {
         if (cert_wait_[b] > 0) --cert_wait_[b];
         else trying.push_back(b);
@@ -1603,7 +1604,10 @@ int Engine::dissipate(int set, double dt_, int start_center) {
         // the left-going pass of the reference sees the singular values scaled by the factors already applied (at most `scale`
         // in all): no truncation anywhere if even the smallest value, fully scaled, clears the threshold (margin: rounding)
         const bool ok = tried[b] && flags[b] == 0 && (double)mins[b] * scale * scale >= 1e-12 * (1.0 + 1e-6);
-        if (tried[b] && !ok) cert_wait_[b] = 7;  // mostly truncating bonds: this trajectory takes the plain sweep for its next calls
+        if (tried[b]) {  // truncating bonds: this trajectory takes the plain sweep for its next call(s)
+          cert_back_[b] = ok ? 0 : std::min(4, std::max(1, 2 * cert_back_[b]));
+          cert_wait_[b] = cert_back_[b];
+        }
         (ok ? good : rest).push_back(b);
       }
       if (getenv("TJM_DEBUG_CERT")) {

@@ -2413,11 +2413,18 @@ __global__ __launch_bounds__(256) void to_c64_kernel(const cplx* __restrict__ in
   }
 }
 
-__global__ __launch_bounds__(256) void from_c64_kernel(const float2_t* __restrict__ in, long in_b0, cplx* __restrict__ out, long out_b0, long n) {
+// The complex64 basis (N x N column-major, rows bond-major: bond * d + phys, the row order of the preconditioner) into fp64 with its
+// rows in the NATURAL order of theta's index (phys * cap + bond): X = Z V is then a plain K = N product with contiguous runs of V.
+// (Everything done to the basis afterwards acts on its columns, so the row order is free.)
+__global__ __launch_bounds__(256) void from_c64_kernel(const float2_t* __restrict__ in, long in_b0, cplx* __restrict__ out, long out_b0, int N, int d) {
   const float2_t* ib = in + (long)blockIdx.y * in_b0;
   cplx* ob = out + (long)blockIdx.y * out_b0;
+  const long n = (long)N * N;
+  const int cap = N / d;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
-    const float2_t v = ib[e];
+    const int k = (int)(e / N), q = (int)(e % N);  // destination row q = phys * cap + bond
+    const int ph = q / cap, bond = q % cap;
+    const float2_t v = ib[(long)k * N + (long)bond * d + ph];
     ob[e] = cplx{(real)v.x, (real)v.y};
   }
 }
@@ -2725,7 +2732,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   long basis_b0 = 0;
   int c64_sweeps = 0;
   if ((rc = tjm32::mixed_left_basis(mb, mx.base, c64_bytes, mx.max_dim, mx.B, s, &basis, &basis_b0, &c64_sweeps)) != TJM_OK) return rc;
-  hipLaunchKernelGGL(from_c64_kernel, dim3(gx, nb), dim3(256), 0, s, static_cast<const float2_t*>(basis), basis_b0, Va, v_b0, nn);
+  hipLaunchKernelGGL(from_c64_kernel, dim3(gx, nb), dim3(256), 0, s, static_cast<const float2_t*>(basis), basis_b0, Va, v_b0, N, d.d);
 
   auto square = [&](int n) { GemmDesc g; memset(&g, 0, sizeof(g)); g.nks = 1; g.nb0 = nb; g.nb1 = 1; g.nb2 = 1; g.M = n; g.N = n; g.K = n; return g; };
   // Gram matrix of a column-major N x N matrix: G[i][j] = sum_r conj(A[r + i N]) A[r + j N]
@@ -2766,16 +2773,15 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     }
     return apply(Vin, Cm, g_b0, Vout);
   };
-  // X = Z V into the Jacobi workspace, column-major: Y[k N + r] = sum_(bond, phys) V[(bond d + phys) + k N] Z[r][(phys, bond)]
+  // X = Z V into the Jacobi workspace, column-major: Y[k N + r] = sum_q V[q + k N] Z[r][q], q in theta's own index order
   auto form_x = [&](const cplx* V) {
     GemmDesc g = square(N);
-    g.nks = d.d;
-    g.A = V; g.a_rs = N; g.a_cs = d.d; g.a_ks = 1; g.a_b0 = v_b0;
+    g.A = V; g.a_rs = N; g.a_cs = 1; g.a_b0 = v_b0;
     g.B = d.theta; g.b_b0 = d.theta_b0;
-    if (d.distribution == 0) {  // Z = theta: r = (s, a), sum over (t, c)
-      g.K = d.capR; g.b_rs = 1; g.b_cs = d.ld_theta; g.b_ks = d.capR;
-    } else {                    // Z = theta^H: r = (t, c), sum over (s, a) of conj(theta[(s, a)][r])
-      g.K = d.capL; g.b_rs = d.ld_theta; g.b_cs = 1; g.b_ks = (long)d.capL * d.ld_theta; g.conjB = 1;
+    if (d.distribution == 0) {  // Z = theta: r = (s, a), q = (t, c)
+      g.b_rs = 1; g.b_cs = d.ld_theta;
+    } else {                    // Z = theta^H: r = (t, c), q = (s, a): conj(theta[q][r])
+      g.b_rs = d.ld_theta; g.b_cs = 1; g.conjB = 1;
     }
     g.C = w.Y; g.c_rs = N; g.c_b0 = w.y_b0;
     return mixed_gemm(g, s);
