@@ -518,11 +518,15 @@ def main():
                 return None
             launches = 8.0 * kk["samples"]  # the sampler brackets every 8th launch
             avg_us = 1e3 * kk["ms"] / kk["samples"]
-            rate = kk["flops"] / 1e12 / (launches * avg_us / 1e6) if kk["flops"] else None
-            gbs = (kk["bytes"] / 1e9) / (kk["ms"] / 1e3)
+            # A launch's duration is measured while the other engines' kernels share the device (E streams): the time the kernel
+            # had the device FOR ITSELF is its summed launch time / stream overlap (how much the streams overlap is measured:
+            # summed bracketed stream time / wall).  With one engine the two rates coincide.
+            raw = kk["flops"] / 1e12 / (launches * avg_us / 1e6) if kk["flops"] else None
+            rate = raw * overlap if raw else None
+            gbs = (kk["bytes"] / 1e9) / (kk["ms"] / 1e3) * overlap
             return {"name": kk["name"], "bound": kk["bound"], "avg_launch_us": avg_us, "launches_sampled": kk["samples"],
-                    "executed_TFLOPs": rate, "peak_TFLOPs": kk["peak"], "frac": frac(rate, kk["peak"]),
-                    "tile_bytes_GBps": gbs, "tile_bytes_frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+                    "executed_TFLOPs": rate, "executed_TFLOPs_per_launch_duration_uncorrected": raw, "peak_TFLOPs": kk["peak"],
+                    "frac": frac(rate, kk["peak"]), "tile_bytes_GBps": gbs, "tile_bytes_frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
 
         dom_line = kernel_line(dom)
         traffic, traffic_src = pmc_traffic(L, chi, sizes[0], "tjm32" if dom is k32 else "tjm::")
@@ -572,7 +576,9 @@ def main():
                 "frac": dom_line["frac"] if dom_line else None,
                 "how": "achieved = 28 real flops x rows x column pairs of every visited 32-column tile (device counter; a visited tile executes all "
                        "its 256 + 16 rotation slots, identity rotations included) / (8 x sampled launches x their average duration, HIP events on "
-                       "the launch stream); peak = the vector rate of the kernel's arithmetic",
+                       "the launch stream) x stream_overlap - the launches of the E engines share the device, so a launch's duration is E-fold "
+                       "time-sliced; kernels.*.executed_TFLOPs_per_launch_duration_uncorrected is the same without that factor; peak = the "
+                       "vector rate of the kernel's arithmetic",
                 "avg_launch_us": dom_line["avg_launch_us"] if dom_line else None,
                 "algorithmic_bytes_per_launch": alg_bytes_per_launch,  # every visited tile read and written once
                 "traffic": traffic,

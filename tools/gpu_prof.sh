@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence of one headline step: kernel-trace statistics (full batch) and PMC passes of their own (never with a trace
 # domain; the program itself after "--").  Output: gpurun_out/r03/prof/  ->  copy the summaries to profiles/.
-#   usage (GPU box, repository root):  bash tools/gpu_prof.sh [stats] [pmc]
+#   usage (GPU box, repository root):  bash tools/gpu_prof.sh [stats] [steady] [pmc]
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/${ROUND:-r04}/prof
@@ -15,6 +15,13 @@ if [[ " $ARGS " == *" stats "* ]]; then
   rm -rf "$OUT/stats"
   head -12 "$OUT/kernel_stats.csv"
 fi
+if [[ " $ARGS " == *" steady "* ]]; then
+  # the state the driver times: steps 9 - 11 of a run from the Haar state (most dissipations certified), whole trace of the run
+  timeout 1500 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/steady" -- python3 bench.py --steps 3 --warmup 8 --no-cpu-baseline > "$OUT/steady_bench.json" 2> "$OUT/steady.err"
+  find "$OUT/steady" -name "*kernel_stats.csv" -exec cp {} "$OUT/steady_kernel_stats.csv" \;
+  rm -rf "$OUT/steady"
+  head -12 "$OUT/steady_kernel_stats.csv"
+fi
 if [[ " $ARGS " == *" pmc "* ]]; then
   i=0
   for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS" \
@@ -23,7 +30,7 @@ if [[ " $ARGS " == *" pmc "* ]]; then
              "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
     # shellcheck disable=SC2086
-    timeout 900 rocprofv3 --pmc $pmc -f csv -d "$OUT/pmc$i" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --engines 1 --batch ${PMC_BATCH:-128} --trajectories ${PMC_BATCH:-128} > "$OUT/pmc${i}_bench.json" 2> "$OUT/pmc$i.err"
+    timeout 900 rocprofv3 --pmc $pmc -f csv -d "$OUT/pmc$i" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --engines 1 --batch ${PMC_BATCH:-256} --trajectories ${PMC_BATCH:-256} > "$OUT/pmc${i}_bench.json" 2> "$OUT/pmc$i.err"
     csv=$(find "$OUT/pmc$i" -name "*counter_collection.csv" | head -1)
     [ -n "$csv" ] && python3 tools/pmc_summary.py "$csv" "$OUT/pmc${i}_per_kernel.csv" > "$OUT/pmc${i}_summary.txt" 2>&1
     rm -rf "$OUT/pmc$i"
