@@ -983,7 +983,7 @@ def test_concurrent_engines_give_the_results_of_one_engine():
 def test_the_certified_path_of_a_trajectory_does_not_depend_on_its_batch():
     """Pauli-only noise, so the certified scalar dissipation is tried.  Whether a trajectory certifies, and when it tries again after a
     failure, is a function of that trajectory alone: the same six trajectories run as one batch of six, as 2 + 4 and as 5 + 1 give
-    the same rows (1e-13) and identical diagnostics, at the shifts' own 1e-12 rule and with a looser truncation of the sweep."""
+    bit-identical rows and diagnostics, at the shifts' own 1e-12 rule and with a looser truncation of the sweep."""
     from yaqs_amd.api import AnalogSimParams, MPS, NoiseModel, Observable, Z as Zg
     from yaqs_amd.tjm import TrajectoryBatch
 
@@ -1014,11 +1014,9 @@ def test_the_certified_path_of_a_trajectory_does_not_depend_on_its_batch():
                 for k, t in enumerate(ids):
                     rows[t], diag[t] = r[k], d[k]
             for t in range(6):
-                # 1e-13, not bit-for-bit: at these bonds (general kernels, chi = 32) about one run in ten differs from the others in the last
-                # bit of one trajectory (8e-16) - with or without the certificate, also under serialised launches
-                # (tests/probes/determinism_probe.py; open item in DESIGN section 9).  The batch split itself leaves no trace:
-                # tests/test_hip_fullsize.py compares the same split bit for bit at chi = 128, the engine tests at chi <= 16.
-                assert np.allclose(rows[t], r6[t], rtol=0, atol=1e-13), (thr, parts, t, np.abs(rows[t] - r6[t]).max())
+                # bit for bit (round 4 found and fixed the race that made one run in ten differ in the last bit here: a missing barrier
+                # behind the noise floor of jacobi_lds_kernel, tests/probes/determinism_*_probe.py)
+                assert np.array_equal(rows[t], r6[t]), (thr, parts, t, np.abs(rows[t] - r6[t]).max())
                 assert np.array_equal(diag[t], d6[t]), (thr, parts, t)
     assert min(seen) > 0, seen  # the certified path was the one under test (the partial regime is covered at full size,
     # tests/test_hip_fullsize.py: ten consecutive steps of config 2 in different batches)

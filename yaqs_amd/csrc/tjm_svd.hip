@@ -848,6 +848,11 @@ __global__ __launch_bounds__(1024) void jacobi_lds_kernel(JacobiArgs g, int ncol
       real f = 0.0;
       for (int c = 0; c < ncols; ++c) f += sN[c];
       floor2 = g.floor_scale * f;
+      // every wavefront has to have read the norms before the first rotation updates two of them: a wavefront that was still
+      // summing saw a - t|g| next to the old d and got a different noise floor, and a column AT the floor (bonds with numerically
+      // zero Schmidt values) was then rotated in one run and not in the next - last-bit differences between identical runs, one
+      // run in ten (round 4, tests/probes/determinism_*_probe.py)
+      __syncthreads();
     }
     int cnt = 0;
     for (int s = 0; s < ncols - 1; ++s) {
