@@ -82,3 +82,49 @@ def test_non_finite_inputs_on_the_simulated_device(on_sim, native):
 @pytest.mark.parametrize("d,L,chi,order", [(3, 5, 9, 1), (4, 4, 8, 2)])
 def test_qudit_chains_on_the_simulated_device(on_sim, d, L, chi, order):
     on_sim["test_hip_round2"].test_qutrit_and_four_level_chains_match_oracle(d, L, chi, order)
+
+
+def test_mixed_precision_split_on_the_simulated_device(on_sim):
+    """The mixed-precision two-site split (both arithmetic types in one library) at the smallest size it serves, 128 x
+    128: a full-rank matrix, one of rank 64 (exactly zero singular values: the unit-vector completion of the complex64 basis, the
+    'far' columns of the refinement) and one graded over six decades, for both distributions - truncated reconstruction against
+    LAPACK, exactly isometric factor, zero padding; the counters say that the mixed path served them, without the fp64 Jacobi unless
+    a spectrum is asked for (then every pair has to be diagonal: the graded matrix goes to the Jacobi kernels for the rest)."""
+    import ctypes as C
+
+    import numpy as np
+
+    k = on_sim["test_hip_kernels"]
+    from simengine import load_sim
+
+    lib = load_sim()
+    rng = np.random.default_rng(5)
+    d, cap = 2, 64
+    n = d * cap
+    u = np.linalg.qr(k.crand(rng, n, n))[0]
+    v = np.linalg.qr(k.crand(rng, n, n))[0]
+    graded = (u * np.sort(np.concatenate([np.linspace(1.0, 0.05, cap), 10.0 ** rng.uniform(-6, -2, cap)]))[::-1]) @ v.conj().T
+    low = (k.crand(rng, n, cap) / np.sqrt(n * cap)) @ np.linalg.qr(k.crand(rng, n, cap))[0].conj().T
+    theta = np.stack([k.crand(rng, n, n) / n, low, graded])
+    chi = np.full(3, cap, dtype=np.int32)
+    out = (C.c_double * 10)()
+    lib.tjm_svd_mixed_read(out, 1)
+    for dist in (0, 1):
+        for want_spec in (False, True):
+            left, right, keep, spec, sweeps = k.svd_split_gpu(lib, theta, d, cap, cap, cap, dist, 0, 1e-12, cap, 2, chi, chi, qr=True, want_spec=want_spec)
+            for b in range(3):
+                ru, rs, rvh = np.linalg.svd(theta[b])
+                kb = int(keep[b])
+                assert kb == (cap if b != 1 else 64)
+                L_ = left[b].reshape(n, cap)
+                R_ = right[b].transpose(1, 0, 2).reshape(cap, n)
+                trunc = (ru[:, :kb] * rs[:kb]) @ rvh[:kb]
+                assert np.allclose(L_ @ R_, trunc, atol=1e-13 * max(1.0, rs[0])), (dist, want_spec, b, np.abs(L_ @ R_ - trunc).max())
+                iso = L_[:, :kb] if dist == 0 else R_[:kb].conj().T
+                assert np.allclose(iso.conj().T @ iso, np.eye(kb), atol=1e-13), (dist, want_spec, b)
+                assert np.all(L_[:, kb:] == 0) and np.all(R_[kb:] == 0)
+                if want_spec:
+                    assert np.allclose(spec[b, :n], rs, rtol=0, atol=1e-12 * rs[0]), (dist, b, np.abs(spec[b, :n] - rs).max(), int(np.abs(spec[b, :n] - rs).argmax()))  # numerically null columns stay at the 1e-13 noise floor
+    lib.tjm_svd_mixed_read(out, 0)
+    assert out[0] == 4 and out[3] == 0, list(out)  # four batched splits served, none sent back to the fp64 path
+    assert out[1] > 0 and out[8] > 0               # complex64 sweeps and fp64 GEMMs were counted

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
 
   const int tiles_n = (g.N + BN - 1) / BN;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  if (g.hermitian && tm > tn) return;  // written by the workgroup of the mirror tile
   const int m0 = tm * BM, n0 = tn * BN;
 
   const cplx* __restrict__ Ab = g.A + (long)b0 * g.a_b0 + (long)b1 * g.a_b1 + (long)b2 * g.a_b2;
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
             v.y = (g.accumulate > 0) ? old.y + v.y : old.y - v.y;
           }
           Cb[(long)m * g.c_rs + n] = v;
+          if (g.hermitian && tm != tn) Cb[(long)n * g.c_rs + m] = cplx{v.x, -v.y};
         }
       }
 }

@@ -2690,7 +2690,8 @@ static int mixed_gemm(const GemmDesc& g, hipStream_t s) {
   {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     ++g_mixed.gemms;
-    g_mixed.gemm_flops += 8.0 * g.M * g.N * (double)g.K * g.nks * g.nb0 * g.nb1 * g.nb2;
+    const double tiles = (g.M + 63) / 64;  // a Hermitian result computes the tiles on and above the diagonal only
+    g_mixed.gemm_flops += (g.hermitian ? (tiles + 1.0) / (2.0 * tiles) : 1.0) * 8.0 * g.M * g.N * (double)g.K * g.nks * g.nb0 * g.nb1 * g.nb2;
   }
   return launch_gemm(g, s);
 }
@@ -2746,6 +2747,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     g.A = A; g.a_rs = N; g.a_cs = 1; g.a_b0 = a_b0; g.conjA = 1;
     g.B = A; g.b_rs = 1; g.b_cs = N; g.b_b0 = a_b0;
     g.C = G; g.c_rs = N; g.c_b0 = gb0;
+    g.hermitian = 1;
     return mixed_gemm(g, s);
   };
   // row-major product of two row-major N x N matrices
@@ -2959,6 +2961,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     gp.C = d.left; gp.c_rs = cm; gp.c_b0 = d.left_b0;
   }
   if ((rc = svd_extract(xi, w, sh, d.chiM, d.chi_stride, nb, nullptr, s)) != TJM_OK) return rc;
+  gg.hermitian = 1;
   if ((rc = mixed_gemm(gg, s)) != TJM_OK) return rc;
   const int gxc = (int)std::min<long>(128, ((long)cm * cm + 1023) / 1024);
   hipLaunchKernelGGL(polar_residual_kernel, dim3((cm + 255) / 256, nb), dim3(256), 0, s, Gm, g_b0, cm, d.chiM, d.chi_stride);
