@@ -2435,20 +2435,24 @@ __global__ __launch_bounds__(256) void from_c64_kernel(const float2_t* __restric
 }
 
 // E <- E - diag(1 for i < keep) (row-major n x n; keep == nullptr: the whole diagonal)
-__global__ __launch_bounds__(256) void polar_residual_kernel(cplx* __restrict__ E, long e_b0, int n, const int* __restrict__ keep, int keep_stride) {
-  cplx* Eb = E + (long)blockIdx.y * e_b0;
-  const int kp = keep ? keep[(long)blockIdx.y * keep_stride] : n;
+__global__ __launch_bounds__(256) void polar_residual_kernel(cplx* __restrict__ E, long e_b0, int n, const int* __restrict__ keep, int keep_stride,
+                                                            const int* __restrict__ ids) {
+  const int b = ids ? ids[blockIdx.y] : blockIdx.y;
+  cplx* Eb = E + (long)b * e_b0;
+  const int kp = keep ? keep[(long)b * keep_stride] : n;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kp && i < n; i += gridDim.x * blockDim.x) Eb[(long)i * n + i].x -= 1.0;
 }
 
 // T = I - E / 2 + c2 E2 (c2 = 3/8: the series to second order; 0: first order) ; e2fro2[b] += ||E2||_F^2
 // (E Hermitian: ||E||_2^2 = ||E^2||_2 <= ||E^2||_F, the certificate below)
 __global__ __launch_bounds__(256) void polar_poly_kernel(const cplx* __restrict__ E, long e_b0, const cplx* __restrict__ E2, long e2_b0,
-                                                        cplx* __restrict__ T, long t_b0, int N, real c2, real* __restrict__ e2fro2) {
+                                                        cplx* __restrict__ T, long t_b0, int N, real c2, real* __restrict__ e2fro2,
+                                                        const int* __restrict__ ids) {
   __shared__ real sh[4];
-  const cplx* Eb = E + (long)blockIdx.y * e_b0;
-  const cplx* Fb = E2 + (long)blockIdx.y * e2_b0;
-  cplx* Tb = T + (long)blockIdx.y * t_b0;
+  const int b = ids ? ids[blockIdx.y] : blockIdx.y;
+  const cplx* Eb = E + (long)b * e_b0;
+  const cplx* Fb = E2 + (long)b * e2_b0;
+  cplx* Tb = T + (long)b * t_b0;
   const long total = (long)N * N;
   real acc = 0.0;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -2461,7 +2465,7 @@ __global__ __launch_bounds__(256) void polar_poly_kernel(const cplx* __restrict_
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0 && e2fro2) atomicAdd(&e2fro2[blockIdx.y], sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0 && e2fro2) atomicAdd(&e2fro2[b], sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 // need[b] = 1 and flag |= 1 when a trajectory's certificate fails: the polar series I - E/2 + 3 E^2/8 leaves
@@ -2479,11 +2483,11 @@ __global__ void and_flags_kernel(int* a, const int* b, int n) {
   if (i < n) a[i] = (a[i] != 0 && b[i] != 0) ? 1 : 0;
 }
 
-// dst[b] = src[b] for the trajectories with keep_src[b] == 0 (they did not need the second polar step: their basis stays what it was)
-__global__ __launch_bounds__(256) void masked_copy_kernel(cplx* __restrict__ dst, const cplx* __restrict__ src, long b0, long n, const int* __restrict__ keep_src) {
-  if (keep_src[blockIdx.y] != 0) return;
-  const cplx* sb = src + (long)blockIdx.y * b0;
-  cplx* db = dst + (long)blockIdx.y * b0;
+// dst[b] = src[b] for the listed trajectories (the ones that took the second polar step: the others keep the basis they had)
+__global__ __launch_bounds__(256) void listed_copy_kernel(cplx* __restrict__ dst, const cplx* __restrict__ src, long b0, long n, const int* __restrict__ ids) {
+  const int b = ids[blockIdx.y];
+  const cplx* sb = src + (long)b * b0;
+  cplx* db = dst + (long)b * b0;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) db[e] = sb[e];
 }
 
@@ -2740,7 +2744,9 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   if ((rc = tjm32::mixed_left_basis(mb, mx.base, c64_bytes, mx.max_dim, mx.B, s, &basis, &basis_b0, &c64_sweeps)) != TJM_OK) return rc;
   hipLaunchKernelGGL(from_c64_kernel, dim3(gx, nb), dim3(256), 0, s, static_cast<const float2_t*>(basis), basis_b0, Va, v_b0, N, d.d);
 
-  auto square = [&](int n) { GemmDesc g; memset(&g, 0, sizeof(g)); g.nks = 1; g.nb0 = nb; g.nb1 = 1; g.nb2 = 1; g.M = n; g.N = n; g.K = n; return g; };
+  const int* l_ids = nullptr;  // the batched products below run over all nb trajectories, or over a list of l_nb of them
+  int l_nb = nb;
+  auto square = [&](int n) { GemmDesc g; memset(&g, 0, sizeof(g)); g.nks = 1; g.nb0 = l_nb; g.ids = l_ids; g.nb1 = 1; g.nb2 = 1; g.M = n; g.N = n; g.K = n; return g; };
   // Gram matrix of a column-major N x N matrix: G[i][j] = sum_r conj(A[r + i N]) A[r + j N]
   auto gram = [&](const cplx* A, long a_b0, cplx* G, long gb0) {
     GemmDesc g = square(N);
@@ -2750,9 +2756,11 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     g.hermitian = 1;
     return mixed_gemm(g, s);
   };
-  // row-major product of two row-major N x N matrices
-  auto rowmul = [&](const cplx* A, long a_b0, const cplx* Bm, long b_b0, cplx* Cc, long c_b0) {
+  // row-major product of two row-major N x N matrices; herm: the product is Hermitian (the square of a Hermitian or of an
+  // anti-Hermitian matrix), only the tiles on and above the diagonal are computed
+  auto rowmul = [&](const cplx* A, long a_b0, const cplx* Bm, long b_b0, cplx* Cc, long c_b0, bool herm) {
     GemmDesc g = square(N);
+    g.hermitian = herm ? 1 : 0;
     g.A = A; g.a_rs = N; g.a_cs = 1; g.a_b0 = a_b0;
     g.B = Bm; g.b_rs = N; g.b_cs = 1; g.b_b0 = b_b0;
     g.C = Cc; g.c_rs = N; g.c_b0 = c_b0;
@@ -2771,12 +2779,12 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   auto polar = [&](const cplx* Vin, cplx* Vout, bool second, real* cert) {
     int r;
     if ((r = gram(Vin, v_b0, Gm, g_b0)) != TJM_OK) return r;
-    hipLaunchKernelGGL(polar_residual_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, Gm, g_b0, N, (const int*)nullptr, 0);
+    hipLaunchKernelGGL(polar_residual_kernel, dim3((N + 255) / 256, l_nb), dim3(256), 0, s, Gm, g_b0, N, (const int*)nullptr, 0, l_ids);
     if (second) {
-      if ((r = rowmul(Gm, g_b0, Gm, g_b0, S2, x_b0)) != TJM_OK) return r;
-      hipLaunchKernelGGL(polar_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, S2, x_b0, Cm, g_b0, N, real(0.375), cert);
+      if ((r = rowmul(Gm, g_b0, Gm, g_b0, S2, x_b0, true)) != TJM_OK) return r;  // E is Hermitian
+      hipLaunchKernelGGL(polar_poly_kernel, dim3(gx, l_nb), dim3(256), 0, s, Gm, g_b0, S2, x_b0, Cm, g_b0, N, real(0.375), cert, l_ids);
     } else {
-      hipLaunchKernelGGL(polar_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, Gm, g_b0, Cm, g_b0, N, real(0.0), (real*)nullptr);
+      hipLaunchKernelGGL(polar_poly_kernel, dim3(gx, l_nb), dim3(256), 0, s, Gm, g_b0, Gm, g_b0, Cm, g_b0, N, real(0.0), (real*)nullptr, l_ids);
     }
     return apply(Vin, Cm, g_b0, Vout);
   };
@@ -2805,18 +2813,29 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   TJM_HIP_CHECK(hipStreamSynchronize(s));
   cplx* Vstart = Vb;
   cplx* Vspare = Va;
+  bool took_second = false;
   if (w.h_pinned[6] != 0) {
     // the complex64 iteration stopped a little early for some trajectory (its basis is orthonormal to 1e-5 rather than 2e-6): the
     // polar iteration converges cubically, a second step of the same kind brings its residual to rounding - and is certified again.
-    // The GEMMs run over the whole batch; the trajectories that did not ask for it keep the basis they had (a trajectory's result
-    // must not depend on who shares its batch); one that fails again is left to the fp64 kernels at the end.
+    // Only the trajectories that asked for it take it (index list: a trajectory's result must not depend on who shares its batch,
+    // and a third of the batches of the evolved state hold such a trajectory - usually one or two of 256); one that fails again is
+    // left to the fp64 kernels at the end.
+    std::vector<int> hn(nb), second_ids;
+    TJM_HIP_CHECK(hipMemcpy(hn.data(), pneed, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < nb; ++b) if (hn[b]) second_ids.push_back(b);
+    TJM_HIP_CHECK(hipMemcpy(idlist, second_ids.data(), second_ids.size() * sizeof(int), hipMemcpyHostToDevice));
     TJM_HIP_CHECK(hipMemsetAsync(e2fro2, 0, (size_t)nb * sizeof(real), s));
     TJM_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), s));
-    if ((rc = polar(Vb, Va, true, e2fro2)) != TJM_OK) return rc;
-    hipLaunchKernelGGL(masked_copy_kernel, dim3(gx, nb), dim3(256), 0, s, Va, Vb, v_b0, nn, pneed);
+    l_ids = idlist;
+    l_nb = (int)second_ids.size();
+    rc = polar(Vb, Va, true, e2fro2);
+    l_ids = nullptr;
+    l_nb = nb;
+    if (rc != TJM_OK) return rc;
+    hipLaunchKernelGGL(listed_copy_kernel, dim3(gx, (unsigned)second_ids.size()), dim3(256), 0, s, Vb, Va, v_b0, nn, idlist);
     hipLaunchKernelGGL(polar_check_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, e2fro2, nb, real(2.2e-17), flag, status);
     hipLaunchKernelGGL(and_flags_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, pneed, status, nb);  // gives up: asked for the second step AND failed it
-    std::swap(Vstart, Vspare);
+    took_second = true;
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     ++g_mixed.second_polar;
   }
@@ -2836,27 +2855,66 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   static const int n_ref = getenv("TJM_MIXED_REFINE") ? atoi(getenv("TJM_MIXED_REFINE")) : 2;
   cplx* Vcur = Vstart;
   cplx* Vnext = Vspare;
-  for (int it = 0; it < n_ref; ++it) {
+  // Two rounds (the default): the basis itself is not carried along.  X_1 = X_0 T_1 and X_2 = X_1 T_2 are products of what is there
+  // already (one GEMM each instead of V T and theta (V T); the rounding of X T puts eps |T_jk| sigma_j into column k - 2e-12 of a
+  // column six decades below the largest in the first round, 2e-14 in the last - where theta V puts eps sigma_max), and the
+  // non-unitarity the truncated exponential T_1 leaves is E_1 = T_1^H T_1 - I (the basis behind X_0 is unitary to rounding after the
+  // certified polar step), which the last round removes together with its correction (W = C - E_1 / 2) as before.
+  // TJM_MIXED_UPDATE_V: the rounds on V (V <- V T, X = theta V afresh), two more GEMMs per split.
+  static const bool update_v = getenv("TJM_MIXED_UPDATE_V") != nullptr;
+  const bool on_x = !update_v && n_ref == 2 && 2 * nn <= w.y_b0;
+  if (on_x) {
+    cplx* Xa = w.Y;
+    cplx* Xb = w.Y + nn;  // second half of every trajectory's slab (laid out for rows + columns of the accumulating variant)
+    auto times = [&](const cplx* Xin, const cplx* T, long t_b0, cplx* Xout) {  // column-major Xout = Xin T (T row-major)
+      GemmDesc g = square(N);
+      g.A = T; g.a_rs = 1; g.a_cs = N; g.a_b0 = t_b0;
+      g.B = Xin; g.b_rs = N; g.b_cs = 1; g.b_b0 = w.y_b0;
+      g.C = Xout; g.c_rs = N; g.c_b0 = w.y_b0;
+      return mixed_gemm(g, s);
+    };
+    if ((rc = form_x(Vcur)) != TJM_OK) return rc;
+    if ((rc = gram(Xa, w.y_b0, Gm, g_b0)) != TJM_OK) return rc;
+    hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(0.01), Cm, g_b0, (const cplx*)nullptr, 0L);
+    if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0, true)) != TJM_OK) return rc;  // C is anti-Hermitian: C^2 is Hermitian
+    hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);  // T_1
+    if ((rc = times(Xa, Gm, g_b0, Xb)) != TJM_OK) return rc;
+    {  // E_1 = T_1^H T_1 - I
+      GemmDesc g = square(N);
+      g.A = Gm; g.a_rs = 1; g.a_cs = N; g.a_b0 = g_b0; g.conjA = 1;
+      g.B = Gm; g.b_rs = N; g.b_cs = 1; g.b_b0 = g_b0;
+      g.C = Iso; g.c_rs = N; g.c_b0 = x_b0;
+      g.hermitian = 1;
+      if ((rc = mixed_gemm(g, s)) != TJM_OK) return rc;
+      hipLaunchKernelGGL(polar_residual_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, Iso, x_b0, N, (const int*)nullptr, 0, (const int*)nullptr);
+    }
+    if ((rc = gram(Xb, w.y_b0, Gm, g_b0)) != TJM_OK) return rc;
+    hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(1e-4), Cm, g_b0, (const cplx*)Iso, x_b0);
+    if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0, false)) != TJM_OK) return rc;  // W = C - E/2 is neither
+    hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);  // T_2
+    if ((rc = times(Xb, Gm, g_b0, Xa)) != TJM_OK) return rc;
+  }
+  for (int it = 0; it < n_ref && !on_x; ++it) {
     if ((rc = form_x(Vcur)) != TJM_OK) return rc;
     if ((rc = gram(w.Y, w.y_b0, Gm, g_b0)) != TJM_OK) return rc;
     if (it + 1 < n_ref) {
       hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(0.01), Cm, g_b0, (const cplx*)nullptr, 0L);
-      if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0)) != TJM_OK) return rc;
+      if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0, true)) != TJM_OK) return rc;  // C is anti-Hermitian: C^2 is Hermitian
       hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);
       if ((rc = apply(Vcur, Gm, g_b0, Vnext)) != TJM_OK) return rc;
     } else {
       // last round: the truncated exponentials of the rounds before are unitary to |C|^3 / 6 <= 2e-7 (|C_ij| <= 0.01); E = V^H V - I
       // goes into the same factor as the last correction, W = C - E/2, applied as I + W + W^2/2
       if ((rc = gram(Vcur, v_b0, Iso, x_b0)) != TJM_OK) return rc;
-      hipLaunchKernelGGL(polar_residual_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, Iso, x_b0, N, (const int*)nullptr, 0);
+      hipLaunchKernelGGL(polar_residual_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, Iso, x_b0, N, (const int*)nullptr, 0, (const int*)nullptr);
       hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(1e-4), Cm, g_b0, (const cplx*)Iso, x_b0);
-      if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0)) != TJM_OK) return rc;
+      if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0, false)) != TJM_OK) return rc;  // W = C - E/2 is neither
       hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);
       if ((rc = apply(Vcur, Gm, g_b0, Vnext)) != TJM_OK) return rc;
     }
     std::swap(Vcur, Vnext);
   }
-  if ((rc = form_x(Vcur)) != TJM_OK) return rc;
+  if (!on_x && (rc = form_x(Vcur)) != TJM_OK) return rc;
   if ((rc = gram(w.Y, w.y_b0, Gm, g_b0)) != TJM_OK) return rc;
   TruncSpec tr;
   tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
@@ -2875,7 +2933,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 7, w.n_active + 5, sizeof(int), hipMemcpyDeviceToHost, s));
   TJM_HIP_CHECK(hipStreamSynchronize(s));
   const int n_bad = w.h_pinned[7];
-  if (g_debug) fprintf(stderr, "[svd-mixed] N %d c64 sweeps %d second polar %d trajectories left to the fp64 Jacobi %d of %d\n", N, c64_sweeps, (int)(Vstart == Va), n_bad, nb);
+  if (g_debug) fprintf(stderr, "[svd-mixed] N %d c64 sweeps %d second polar %d trajectories left to the fp64 Jacobi %d of %d\n", N, c64_sweeps, (int)took_second, n_bad, nb);
   int f64_sweeps = 0;
   if (n_bad > 0) {
     // the trajectories the check did not pass: fp64 Jacobi sweeps on their X (every pair; nearly diagonal already)
@@ -2964,9 +3022,9 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   gg.hermitian = 1;
   if ((rc = mixed_gemm(gg, s)) != TJM_OK) return rc;
   const int gxc = (int)std::min<long>(128, ((long)cm * cm + 1023) / 1024);
-  hipLaunchKernelGGL(polar_residual_kernel, dim3((cm + 255) / 256, nb), dim3(256), 0, s, Gm, g_b0, cm, d.chiM, d.chi_stride);
+  hipLaunchKernelGGL(polar_residual_kernel, dim3((cm + 255) / 256, nb), dim3(256), 0, s, Gm, g_b0, cm, d.chiM, d.chi_stride, (const int*)nullptr);
   // (the kept columns are orthogonal to ~1e-15 ||theta|| / sigma_k, 2e-6 for a near-degenerate pair left alone: first order is exact to rounding)
-  hipLaunchKernelGGL(polar_poly_kernel, dim3(gxc, nb), dim3(256), 0, s, Gm, g_b0, Gm, g_b0, Cm, g_b0, cm, real(0.0), (real*)nullptr);
+  hipLaunchKernelGGL(polar_poly_kernel, dim3(gxc, nb), dim3(256), 0, s, Gm, g_b0, Gm, g_b0, Cm, g_b0, cm, real(0.0), (real*)nullptr, (const int*)nullptr);
   TJM_HIP_CHECK(hipGetLastError());
   if ((rc = mixed_gemm(gt, s)) != TJM_OK) return rc;
   if ((rc = mixed_gemm(gp, s)) != TJM_OK) return rc;
