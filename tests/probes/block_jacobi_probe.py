@@ -1,7 +1,8 @@
 """Timing probe of the mixed-precision two-site split alone (GPU): 256 matrices of 256 x 256 with a spectrum like the evolved state's
 (geometric decay over nine decades), through tjm_svd_split_qr.  Prints the wall time per batched split, the counters of the mixed
-path and the sampled launch time of the complex64 Jacobi kernel.  Switches: TJM_NO_BLOCK_JACOBI, TJM_MIXED_BLOCK_INNER, TJM_BJ_DEBUG
-(bit 0: no eigenproblem, bit 1: no tile update, bit 2: no Gram products - timing only, the results are wrong then).
+path and the sampled launch time of the complex64 Jacobi kernel.  Written for the block-Jacobi experiment of round 4 (DESIGN section 5:
+measured, removed - its switches TJM_NO_BLOCK_JACOBI / TJM_MIXED_BLOCK_INNER / TJM_BJ_DEBUG are gone with it); the other switches of
+the mixed split (TJM_MIXED_*) can be compared with it in seconds instead of a bench run.
 
     python tests/probes/block_jacobi_probe.py [B] [reps]
 """
