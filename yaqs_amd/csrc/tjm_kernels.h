@@ -226,6 +226,7 @@ struct JacobiOpts {
   bool late_start = false;               // check-first tile kernel from the first sweep on
   bool late_after_first = false;         // check-first tile kernel from the second sweep on, whatever the first one rotated
   bool preloaded = false;                // Y holds X already: column-major, pitch = rows, rows and columns multiples of 64 / 32
+  bool quad = false;                     // complex64 build, X-only, up to 256 rows: the tile kernel with four columns of each block per wavefront
 };
 // accumulate = false: rotate X only (no W rows, no rotation record); the caller rebuilds the other factor from X
 int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspace& w, hipStream_t s, JacobiShape* shape_out,

@@ -85,6 +85,7 @@ int mixed_left_basis(const MixedBasisDesc& m, void* ws, size_t ws_bytes, int max
   // every non-zero column is rotated: a column at the fp32 rounding floor is noise, but noise that has been orthogonalised against
   // the rest is what the polar step of the fp64 side can make exactly unitary (an unrotated one is not); the sweep cap bounds the cost
   op.floor_scale = 0.0f;  // (the caller scales theta so that ||theta||_F ~ 2^24: tiny columns stay far above the fp32 underflow range)
+  op.quad = true;
   JacobiShape sh;
   if ((rc = jacobi_solve(src, tr, l.w, s, &sh, sweeps_out, false, &op)) != TJM_OK) return rc;
   ExtractDesc xy;  // normalised columns of Y (unit vectors for the structurally zero ones) into Z, N x N column-major

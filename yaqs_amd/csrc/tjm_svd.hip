@@ -760,6 +760,180 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_cross16x_kerne
   if (tid == 0) atomicAdd(&g.nrot[b], total);
 }
 
+// ---- the same visit with FOUR columns of each block per wavefront (4 wavefronts per tile) ---------------------------------------
+// The tile kernel above is bound by instruction issue, and of the ~150 instructions of a sub-step only ~56 are the inner products
+// and rotations of its two pairs; the rest - the cross-lane reduction, the rotation set-up, the broadcasts, the hand-over - costs the
+// same whether a sub-step carries two pairs or four.  Here a wavefront holds four columns of I and four of J: a step is four
+// sub-steps of four independent pairs (the Latin square I_h x J_(h+t)), eight inner-product components are reduced together
+// (wave_sum8_groups: group g of 8 lanes ends up with component g), the four rotations are set up side by side in the four rows of 16
+// lanes, and the J quads circulate over 4 wavefronts in 3 hand-overs instead of 7.  Same pairs per visit (256 + 16 in-block), same
+// rotation formulas; the order of the rotations inside a visit differs, so the iterates differ from the two-column kernel's in the
+// last bits (both are deterministic).  Used without rotation record (X-only solves: the complex64 phase of the mixed split).
+
+// Eight wavefront sums: on return every lane of group g = lane / 8 holds the total of p_g.
+__device__ inline real wave_sum8_groups(real p0, real p1, real p2, real p3, real p4, real p5, real p6, real p7, int lane) {
+  // halves: lower lanes keep p_k, upper lanes p_(k+4); rows: row 0 / 1 keep (p_j, p_(j+2)), rows 2 / 3 (p_(j+4), p_(j+6))
+  const real y0 = swap16_add(swap32_add(p0, p4), swap32_add(p2, p6));  // rows: p0 p2 p4 p6
+  const real y1 = swap16_add(swap32_add(p1, p5), swap32_add(p3, p7));  // rows: p1 p3 p5 p7
+  const bool hi8 = lane & 8;
+  real z = (hi8 ? y1 : y0) + dpp_pull<0x128>(hi8 ? y0 : y1);  // row_ror:8: the two halves of a row of 16 trade what the other one keeps
+  z += dpp_pull<0x141>(z);  // row_half_mirror
+  z += dpp_pull<0xB1>(z);   // quad_perm [1,0,3,2]
+  z += dpp_pull<0x4E>(z);   // quad_perm [2,3,0,1]
+  return z;
+}
+
+// make_rotation_lanes for four pairs: pair = lane / 16, groups of 8 lanes carry (Re g, Im g) of their pair
+__device__ inline bool make_rotation_lanes4(real a, real d, real own, real tol2, real nfloor, real& c, real& sv, real& tg) {
+  const real o2 = own * own;
+  const real mag2 = o2 + dpp_pull<0x128>(o2);
+  const bool rot = mag2 > tol2 * a * d && a > nfloor && d > nfloor && mag2 > TJM_TINY;
+  const real delta = real(0.5) * (d - a);
+  const real x = fma(delta, delta, mag2);
+  const real r = fast_sqrt(x);
+  const real u = fabs(delta) + r;
+  const real q = fast_rsqrt((r + r) * u);
+  const real qs = (delta >= real(0.0)) ? q : -q;
+  c = rot ? u * q : real(1.0);
+  sv = rot ? qs * own : real(0.0);
+  tg = rot ? mag2 * ((r + r) * q) * qs : real(0.0);
+  return rot;
+}
+
+// columns of a 16-column block that wavefront w (of 4) holds in tournament round tr: the pairs 2 w and 2 w + 1 of the round
+__device__ inline int fold_column4(int tr, int w, int h) {
+  if (tr < 0) return 4 * w + h;
+  const int k = 2 * w + (h >> 1);
+  if (k == 0) return (h & 1) == 0 ? tr : 15;
+  return (h & 1) == 0 ? (tr + k) % 15 : (tr - k + 15) % 15;
+}
+
+template <int XRK, bool LATE>
+__global__ __launch_bounds__(256, 4) void jacobi_cross16q_kernel(JacobiArgs g) {
+  extern __shared__ real smem[];
+  int b = blockIdx.y;
+  if (g.ids) b = g.ids[b];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (g.done[b]) return;
+  const int rtot = g.rtot;
+  typedef ColFrag<XRK> Col;
+  real* slots = smem;                                    // [4][4] columns of Col::LDS_REALS
+  real* sN = slots + 16 * Col::LDS_REALS;                // [4][4]
+  int* sCnt = reinterpret_cast<int*>(sN + 16);           // [4]
+  int I, J;
+  pair_of(g.nblk / 2, g.round, blockIdx.x, I, J);
+  int* st = g.stamps + (long)b * STAMP_STRIDE;
+  const int tr = (g.fold && g.round < 15) ? g.round : -1;
+  bool cross;
+  {
+    const int nzI = st[2 * MAXBLK + 2 * I] | st[2 * MAXBLK + 2 * I + 1];
+    const int nzJ = st[2 * MAXBLK + 2 * J] | st[2 * MAXBLK + 2 * J + 1];
+    const int ver = st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J];
+    const int m1 = max(max(st[2 * I], st[2 * I + 1]), max(st[2 * J], st[2 * J + 1]));
+    cross = nzI && nzJ;
+    if ((!cross && (tr < 0 || (!nzI && !nzJ))) || ver > m1) return;
+  }
+  cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
+  Col yI[4], yJ[4];
+  real nI[4], nJ[4];
+  {
+    real pn[8];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      yI[h].load(Yb + (long)(I * 16 + fold_column4(tr, w, h)) * rtot, lane);
+      yJ[h].load(Yb + (long)(J * 16 + fold_column4(tr, w, h)) * rtot, lane);
+      pn[h] = yI[h].norm2();
+      pn[4 + h] = yJ[h].norm2();
+    }
+    const real z = wave_sum8_groups(pn[0], pn[1], pn[2], pn[3], pn[4], pn[5], pn[6], pn[7], lane);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      nI[h] = lane_value(z, 8 * h);
+      nJ[h] = lane_value(z, 32 + 8 * h);
+    }
+  }
+  const real floor2 = g.floor_scale * g.fro2[b];
+  int cnt = 0;
+  // one sub-step: four independent pairs (p_i, q_i) with squared norms (a_i, d_i); applied unconditionally ((c, s) = (1, 0) leaves a
+  // pair bit-identical), LATE: nothing is applied when none of the four needs it
+  auto sub_step = [&](Col& p0, Col& q0, real& a0, real& d0, Col& p1, Col& q1, real& a1, real& d1, Col& p2, Col& q2, real& a2, real& d2, Col& p3, Col& q3,
+                      real& a3, real& d3) {
+    real gx[4], gy[4];
+    Col::dot(p0, q0, gx[0], gy[0]);
+    Col::dot(p1, q1, gx[1], gy[1]);
+    Col::dot(p2, q2, gx[2], gy[2]);
+    Col::dot(p3, q3, gx[3], gy[3]);
+    const real gsum = wave_sum8_groups(gx[0], gy[0], gx[1], gy[1], gx[2], gy[2], gx[3], gy[3], lane);
+    const int pr = lane >> 4;
+    const real a = pr == 0 ? a0 : pr == 1 ? a1 : pr == 2 ? a2 : a3;
+    const real d = pr == 0 ? d0 : pr == 1 ? d1 : pr == 2 ? d2 : d3;
+    real cv, sv, tv;
+    const bool rot = make_rotation_lanes4(a, d, gsum, g.tol2, floor2, cv, sv, tv);
+    const unsigned long long any = __ballot(rot) & 0x0001000100010001ull;  // lanes 0, 16, 32, 48 speak for the four pairs
+    cnt += __popcll(any);
+    if (LATE && any == 0) return;
+    {
+      const real sr = lane_value(sv, 0), si = lane_value(sv, 8), c = lane_value(cv, 0), tg = lane_value(tv, 0);
+      Col::rotate(p0, q0, c, sr, si);
+      a0 -= tg; d0 += tg;
+    }
+    {
+      const real sr = lane_value(sv, 16), si = lane_value(sv, 24), c = lane_value(cv, 16), tg = lane_value(tv, 16);
+      Col::rotate(p1, q1, c, sr, si);
+      a1 -= tg; d1 += tg;
+    }
+    {
+      const real sr = lane_value(sv, 32), si = lane_value(sv, 40), c = lane_value(cv, 32), tg = lane_value(tv, 32);
+      Col::rotate(p2, q2, c, sr, si);
+      a2 -= tg; d2 += tg;
+    }
+    {
+      const real sr = lane_value(sv, 48), si = lane_value(sv, 56), c = lane_value(cv, 48), tg = lane_value(tv, 48);
+      Col::rotate(p3, q3, c, sr, si);
+      a3 -= tg; d3 += tg;
+    }
+  };
+  if (tr >= 0)  // the in-block pairs of this tournament round: two of I and two of J
+    sub_step(yI[0], yI[1], nI[0], nI[1], yI[2], yI[3], nI[2], nI[3], yJ[0], yJ[1], nJ[0], nJ[1], yJ[2], yJ[3], nJ[2], nJ[3]);
+  if (cross) {
+    for (int s = 0; s < 4; ++s) {
+      sub_step(yI[0], yJ[0], nI[0], nJ[0], yI[1], yJ[1], nI[1], nJ[1], yI[2], yJ[2], nI[2], nJ[2], yI[3], yJ[3], nI[3], nJ[3]);
+      sub_step(yI[0], yJ[1], nI[0], nJ[1], yI[1], yJ[2], nI[1], nJ[2], yI[2], yJ[3], nI[2], nJ[3], yI[3], yJ[0], nI[3], nJ[0]);
+      sub_step(yI[0], yJ[2], nI[0], nJ[2], yI[1], yJ[3], nI[1], nJ[3], yI[2], yJ[0], nI[2], nJ[0], yI[3], yJ[1], nI[3], nJ[1]);
+      sub_step(yI[0], yJ[3], nI[0], nJ[3], yI[1], yJ[0], nI[1], nJ[0], yI[2], yJ[1], nI[2], nJ[1], yI[3], yJ[2], nI[3], nJ[2]);
+      if (s + 1 < 4) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) yJ[h].to_lds(slots + (w * 4 + h) * Col::LDS_REALS, lane);
+        if (lane < 4) sN[w * 4 + lane] = lane == 0 ? nJ[0] : lane == 1 ? nJ[1] : lane == 2 ? nJ[2] : nJ[3];
+        __syncthreads();
+        const int src = (w + 1) & 3;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          yJ[h].from_lds(slots + (src * 4 + h) * Col::LDS_REALS, lane);
+          nJ[h] = sN[src * 4 + h];
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (lane == 0) sCnt[w] = cnt;
+  __syncthreads();
+  const int total = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
+  if (tid == 0 && g.work) atomicAdd(g.work, (cross ? REC_PER_VISIT : 0) + (tr >= 0 ? 2 * NB : 0));
+  if (total == 0) {
+    if (tid == 0) st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J] = g.clock;
+    return;
+  }
+  if (tid == 0) { st[2 * I] = g.clock; st[2 * I + 1] = g.clock; st[2 * J] = g.clock; st[2 * J + 1] = g.clock; }
+  const int wj = cross ? ((w + 3) & 3) : w;  // after 3 hand-overs wavefront w holds the J quad of wavefront w - 1
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    yI[h].store(Yb + (long)(I * 16 + fold_column4(tr, w, h)) * rtot, lane);
+    yJ[h].store(Yb + (long)(J * 16 + fold_column4(tr, wj, h)) * rtot, lane);
+  }
+  if (tid == 0) atomicAdd(&g.nrot[b], total);
+}
+
 // Replay of the recorded rotations on the W rows of the same tile: lane = one row, 32 columns in registers.
 __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int wrow0) {
   int b = blockIdx.z;
@@ -1971,6 +2145,15 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   const int rx_slot = rx_top;
 #endif
   const size_t lds16x = (size_t)2 * NB * rx_slot * sizeof(cplx) + 2 * NB * sizeof(real) + 16 * sizeof(int);
+  // four columns of each block per wavefront (jacobi_cross16q_kernel): X-only solves of the complex64 build up to 256 rows
+  bool quad16 = false;
+#ifdef TJM_F32
+  {
+    static const bool no_quad = getenv("TJM_NO_QUAD_TILE") != nullptr;
+    quad16 = !no_quad && op.quad && split16 && !accumulate && rx_top <= 256;
+  }
+#endif
+  const size_t lds16q = lds16x;
   g.rec = accumulate ? w.rec : nullptr;
   // in-block pairs folded into the tile visits (jacobi_cross16x_kernel): needs the 15 tournament rounds of a 16-column block inside
   // one sweep, and no rotation record (the W replay kernel knows the fixed column assignment only)
@@ -2015,7 +2198,23 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
         }
         TJM_HIP_CHECK(hipEventRecord(t_prof.pool[2 * slot], s));
       }
-      if (split16) {
+      if (quad16) {
+        const dim3 gridq(npairs, nb), blockq(256);
+#define TJM_Q16_LAUNCH(K)                                                                     \
+  if (late) hipLaunchKernelGGL((jacobi_cross16q_kernel<K, true>), gridq, blockq, lds16q, s, g); \
+  else hipLaunchKernelGGL((jacobi_cross16q_kernel<K, false>), gridq, blockq, lds16q, s, g)
+        switch (rx_top / 64) {
+          case 1: TJM_Q16_LAUNCH(1); break;
+          case 2: TJM_Q16_LAUNCH(2); break;
+          case 3: TJM_Q16_LAUNCH(3); break;
+          default: TJM_Q16_LAUNCH(4); break;
+        }
+#undef TJM_Q16_LAUNCH
+        if (timed) {
+          TJM_HIP_CHECK(hipEventRecord(t_prof.pool[2 * slot + 1], s));
+          t_prof.pending.emplace_back(slot, (real)npairs * n_live * 4.0 * NB * rx_top * sizeof(cplx) * 2.0);
+        }
+      } else if (split16) {
         const dim3 gridx(npairs, nb), blockx(512);
 #define TJM_X16_LAUNCH(K)                                                                     \
   if (late) hipLaunchKernelGGL((jacobi_cross16x_kernel<K, true>), gridx, blockx, lds16x, s, g); \
