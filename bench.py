@@ -191,7 +191,7 @@ def pmc_traffic(L, chi, B, kernel_tag):
     FETCH_SIZE and WRITE_SIZE runs of this script, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters
     cannot be read from inside the timed run: the number comes from a profile, is only reported for the configuration and the kernel
     (``kernel_tag``: "tjm32" = the complex64 instance, "tjm::" = the fp64 one) it was collected on, and the source says so."""
-    for name in ("r04_pmc_traffic_c64.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic_c64q.json", "r04_pmc_traffic_c64.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
@@ -510,7 +510,7 @@ def main():
         k64 = {"ms": ms.value, "samples": int(ns.value), "bytes": nbytes.value, "flops": flops_jac64, "peak": peak, "bound": valu_bound,
                "name": "jacobi_cross16x_kernel" + (" (complex64 build)" if f32 else " (fp64)")}
         k32 = {"ms": ms32.value, "samples": int(ns32.value), "bytes": nb32.value, "flops": flops_jac32, "peak": peak32, "bound": "fp32-valu",
-               "name": "tjm32::jacobi_cross16x_kernel (complex64 phase of the mixed-precision two-site split)"}
+               "name": "tjm32::jacobi_cross16q_kernel (complex64 phase of the mixed-precision two-site split; four columns of each block per wavefront)"}
         dom = k32 if k32["ms"] > k64["ms"] else k64
 
         def kernel_line(kk):

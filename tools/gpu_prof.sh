@@ -29,6 +29,7 @@ if [[ " $ARGS " == *" pmc "* ]]; then
              "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" \
              "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
     i=$((i + 1))
+    [[ -n "$PMC_PASSES" && " $PMC_PASSES " != *" $i "* ]] && continue  # PMC_PASSES="3 4": only those passes
     # shellcheck disable=SC2086
     timeout 900 rocprofv3 --pmc $pmc -f csv -d "$OUT/pmc$i" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --engines 1 --batch ${PMC_BATCH:-256} --trajectories ${PMC_BATCH:-256} > "$OUT/pmc${i}_bench.json" 2> "$OUT/pmc$i.err"
     csv=$(find "$OUT/pmc$i" -name "*counter_collection.csv" | head -1)

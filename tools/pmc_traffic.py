@@ -1,14 +1,14 @@
 """profiles/r01_pmc_traffic.json from the two per-kernel PMC summaries (tools/pmc_summary.py on a FETCH_SIZE pass and on a WRITE_SIZE pass
 of `bench.py --steps 1 --warmup 0 --no-cpu-baseline`):
     python tools/pmc_traffic.py <fetch_per_kernel.csv> <write_per_kernel.csv> <L> <chi> <batch> <out.json> [kernel substring] [steps]
-(kernel substring: default "tjm::(anonymous namespace)::jacobi_cross16x_kernel<4, false>" = the fp64 tile kernel; "tjm32::" selects the
-complex64 instance of the mixed-precision split)
+(kernel substring: default "tjm::" = the fp64 tile kernels jacobi_cross16x_kernel; "tjm32::" selects the complex64 instances of the
+mixed-precision split - jacobi_cross16q_kernel, four columns per wavefront, since round 4)
 FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md), WRITE_SIZE taken as is; both are in KiB."""
 import csv
 import json
 import sys
 
-KERNEL = "jacobi_cross16x_kernel"
+KERNEL = "jacobi_cross16"  # ..x_kernel (two columns of each block per wavefront) and ..q_kernel (four)
 TAG = sys.argv[7] if len(sys.argv) > 7 else "tjm::"
 STEPS = int(sys.argv[8]) if len(sys.argv) > 8 else 1
 
@@ -32,12 +32,18 @@ def row(path):
     return acc
 
 
+def names(path):
+    import re
+    return sorted({re.search(r"jacobi_cross16\w+", r["kernel"]).group(0) for r in csv.DictReader(open(path))
+                   if KERNEL in r["kernel"] and r["kernel"].lstrip("void ").startswith(TAG)})
+
+
 f, w = row(sys.argv[1]), row(sys.argv[2])
 L, chi, batch = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 n = int(f["dispatches"])
 fetch_kb = float(f["FETCH_SIZE"]) / n
 write_kb = float(w["WRITE_SIZE"]) / int(w["dispatches"])
-rec = {"L": L, "chi": chi, "batch": batch, "kernel": TAG + "(anonymous namespace)::" + KERNEL, "steps": STEPS, "launches": n, "FETCH_SIZE_avg_KB": fetch_kb, "WRITE_SIZE_avg_KB": write_kb,
+rec = {"L": L, "chi": chi, "batch": batch, "kernel": TAG + "(anonymous namespace)::" + "/".join(names(sys.argv[1])), "steps": STEPS, "launches": n, "FETCH_SIZE_avg_KB": fetch_kb, "WRITE_SIZE_avg_KB": write_kb,
        "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
        "note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 --no-cpu-baseline` (B={batch}); "
                f"average over {n} launches; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE taken as is; KB = 1024 B"}
