@@ -128,3 +128,18 @@ def test_mixed_precision_split_on_the_simulated_device(on_sim):
     lib.tjm_svd_mixed_read(out, 0)
     assert out[0] == 4 and out[3] == 0, list(out)  # four batched splits served, none sent back to the fp64 path
     assert out[1] > 0 and out[8] > 0               # complex64 sweeps and fp64 GEMMs were counted
+
+
+@pytest.mark.parametrize("switch", ["TJM_NO_QUAD_TILE", "TJM_MIXED_UPDATE_V", "TJM_MIXED_NO_SKIP"])
+def test_mixed_precision_split_under_its_switches(switch):
+    """The A/B switches of the mixed split name code that is otherwise not run any more (the two-column tile kernel in its complex64
+    instance, the refinement rounds on the basis, the refinement without the never-kept columns left out).  They are read once per
+    process: the test above once more in a child process with the switch set."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, **{switch: "1"})
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "mixed_precision_split_on_the_simulated_device"],
+                         env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__)))
+    assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
