@@ -38,6 +38,14 @@ size_t mixed_workspace_bytes(int max_dim, int B);
 int mixed_left_basis(const MixedBasisDesc& m, void* ws, size_t ws_bytes, int max_dim, int B, hipStream_t s, const void** basis,
                      long* basis_b0, int* sweeps_out);
 
+// out = in x in for N x N row-major complex64 matrices (hermitian != 0: the product is Hermitian, only the tiles on and above the
+// diagonal are computed): the squares of the refinement rounds of the fp64 phase that need three digits only (C^2 / 2 next to
+// I + C with |C| <= 0.01, corrected for exactly in the following round; W^2 / 2 with |W| <= 1e-4).  The complex64 GEMM runs at
+// twice the fp64 rate.  in / out (device, float2, batch stride *b0 elements) are buffers of the workspace that are idle after
+// mixed_left_basis has returned its result to the caller; the caller fills `in`.
+int mixed_square_buffers(void* ws, size_t ws_bytes, int max_dim, int B, void** in, const void** out, long* b0);
+int mixed_square(void* ws, size_t ws_bytes, int max_dim, int B, int N, int nb0, int hermitian, hipStream_t s);
+
 // Counters and the launch sampler of the complex64 Jacobi kernels (the tjm32 instances of the functions of the same name in
 // tjm_kernels.h; defined by the tjm32 compilation of tjm_svd.hip)
 void jacobi_work_get(double* out4, bool reset);

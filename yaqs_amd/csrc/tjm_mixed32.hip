@@ -5,6 +5,8 @@
 #include "tjm_kernels.h"
 #include "tjm_mixed.h"
 
+#include <cstring>
+
 #ifndef TJM_F32
 #error "tjm_mixed32.hip is the complex64 side of the bridge: compile with -DTJM_F32 -Dtjm=tjm32"
 #endif
@@ -96,6 +98,29 @@ int mixed_left_basis(const MixedBasisDesc& m, void* ws, size_t ws_bytes, int max
   *basis = q.Z;
   *basis_b0 = q.z_b0;
   return TJM_OK;
+}
+
+int mixed_square_buffers(void* ws, size_t ws_bytes, int max_dim, int B, void** in, const void** out, long* b0) {
+  Layout l = carve(static_cast<char*>(ws), max_dim, B);
+  if (ws_bytes < l.bytes) return TJM_ERR_WORKSPACE;
+  *in = ws;  // the head (theta in complex64 during the factorisation)
+  *out = l.q.Z2;
+  *b0 = (long)max_dim * max_dim;
+  return TJM_OK;
+}
+
+int mixed_square(void* ws, size_t ws_bytes, int max_dim, int B, int N, int nb0, int hermitian, hipStream_t s) {
+  if (nb0 <= 0) return TJM_OK;
+  Layout l = carve(static_cast<char*>(ws), max_dim, B);
+  if (ws_bytes < l.bytes || N > max_dim || nb0 > B) return TJM_ERR_WORKSPACE;
+  GemmDesc g;
+  memset(&g, 0, sizeof(g));
+  g.nks = 1; g.nb0 = nb0; g.nb1 = 1; g.nb2 = 1; g.M = N; g.N = N; g.K = N;
+  g.A = static_cast<const cplx*>(ws); g.a_rs = N; g.a_cs = 1; g.a_b0 = (long)max_dim * max_dim;
+  g.B = g.A; g.b_rs = N; g.b_cs = 1; g.b_b0 = g.a_b0;
+  g.C = l.q.Z2; g.c_rs = N; g.c_b0 = l.q.z_b0;
+  g.hermitian = hermitian ? 1 : 0;
+  return launch_gemm(g, s);
 }
 
 }  // namespace tjm32

@@ -2712,8 +2712,10 @@ __device__ inline bool far_column(int j, real dj, int cm, int skip_col, real tr)
 // repair more; a pair that still wants a larger angle after a round of quadratic convergence is not converging (it is left alone and
 // shows up in the final check if it matters).
 __global__ __launch_bounds__(256) void refine_corr_kernel(const cplx* __restrict__ G, long g_b0, int N, int skip_col, int cm, const real* __restrict__ fro2,
-                                                         real zmax, cplx* __restrict__ Cm, long c_b0, const cplx* __restrict__ E, long e_b0) {
+                                                         real zmax, cplx* __restrict__ Cm, long c_b0, const cplx* __restrict__ E, long e_b0,
+                                                         float2_t* __restrict__ C32, long c32_b0) {
   const cplx* Gb = G + (long)blockIdx.y * g_b0;
+  float2_t* Cs = C32 ? C32 + (long)blockIdx.y * c32_b0 : nullptr;  // a complex64 copy for the square (tjm32::mixed_square)
   const cplx* Eb = E ? E + (long)blockIdx.y * e_b0 : nullptr;
   cplx* Cb = Cm + (long)blockIdx.y * c_b0;
   const real tr = fro2[blockIdx.y];
@@ -2745,18 +2747,23 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(const cplx* __restrict
       if (Eb) { const cplx ee = Eb[e]; c.x = fma(-0.5, ee.x, c.x); c.y = fma(-0.5, ee.y, c.y); }
     }
     Cb[e] = c;
+    if (Cs) Cs[e] = float2_t{(float)c.x, (float)c.y};
   }
 }
 
 // T = I + C + C2 / 2   (exp(C) to second order: unitary up to |C|^3 / 6, which the last polar step removes)
 __global__ __launch_bounds__(256) void refine_poly_kernel(const cplx* __restrict__ Cm, long c_b0, const cplx* __restrict__ C2, long c2_b0,
-                                                         cplx* __restrict__ T, long t_b0, int N) {
+                                                         cplx* __restrict__ T, long t_b0, int N, const float2_t* __restrict__ C2s, long c2s_b0) {
   const cplx* Cb = Cm + (long)blockIdx.y * c_b0;
   const cplx* Db = C2 + (long)blockIdx.y * c2_b0;
+  const float2_t* Ds = C2s ? C2s + (long)blockIdx.y * c2s_b0 : nullptr;  // the square from the complex64 GEMM instead
   cplx* Tb = T + (long)blockIdx.y * t_b0;
   const long total = (long)N * N;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const cplx a = Cb[e], b = Db[e];
+    const cplx a = Cb[e];
+    cplx b;
+    if (Ds) { const float2_t f = Ds[e]; b = cplx{(real)f.x, (real)f.y}; }
+    else b = Db[e];
     cplx v{fma(0.5, b.x, a.x), fma(0.5, b.y, a.y)};
     if (e / N == e % N) v.x += 1.0;
     Tb[e] = v;
@@ -2852,7 +2859,7 @@ __global__ void mixed_fallback_kernel(const real* __restrict__ norms, int ncols_
   if (bad) atomicAdd(count, 1);
 }
 
-struct MixedStats { long solves = 0, c64_sweeps = 0, f64_sweeps = 0, fallbacks = 0, jacobi_trajectories = 0, second_polar = 0, gemms = 0; double gemm_flops = 0.0; };
+struct MixedStats { long solves = 0, c64_sweeps = 0, f64_sweeps = 0, fallbacks = 0, jacobi_trajectories = 0, second_polar = 0, gemms = 0, c64_gemms = 0; double gemm_flops = 0.0; };
 MixedStats g_mixed;
 
 }  // namespace
@@ -3062,6 +3069,26 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   // TJM_MIXED_UPDATE_V: the rounds on V (V <- V T, X = theta V afresh), two more GEMMs per split.
   static const bool update_v = getenv("TJM_MIXED_UPDATE_V") != nullptr;
   const bool on_x = !update_v && n_ref == 2 && 2 * nn <= w.y_b0;
+  // The squares C^2 and W^2 of those rounds need three digits (C^2 / 2 stands next to I + C with |C| <= 0.01 and what it misses is
+  // measured and removed by the next round - E_1 and the Gram matrix are taken from the actual T_1 and X_1; |W| <= 1e-4 leaves
+  // 1e-7 |W^2| <= 3e-13 at the very worst): they come from the complex64 GEMM at twice the rate, fed by a complex64 copy that the
+  // correction kernel writes along.  TJM_MIXED_FP64_SQUARES: in fp64.
+  static const bool fp64_squares = getenv("TJM_MIXED_FP64_SQUARES") != nullptr;
+  float2_t* sq_in = nullptr;
+  const float2_t* sq_out = nullptr;
+  long c32_b0 = 0;
+  if (on_x && !fp64_squares) {
+    void* in = nullptr;
+    const void* out = nullptr;
+    if ((rc = tjm32::mixed_square_buffers(mx.base, c64_bytes, mx.max_dim, mx.B, &in, &out, &c32_b0)) != TJM_OK) return rc;
+    sq_in = static_cast<float2_t*>(in);
+    sq_out = static_cast<const float2_t*>(out);
+  }
+  auto square_of_c = [&](bool herm) {  // S2 (fp64) or sq_out (complex64) = Cm x Cm
+    if (sq_in == nullptr) return rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0, herm);
+    { std::lock_guard<std::mutex> lock(g_prof_mutex); ++g_mixed.c64_gemms; }
+    return tjm32::mixed_square(mx.base, c64_bytes, mx.max_dim, mx.B, N, nb, herm ? 1 : 0, s);
+  };
   if (on_x) {
     cplx* Xa = w.Y;
     cplx* Xb = w.Y + nn;  // second half of every trajectory's slab (laid out for rows + columns of the accumulating variant)
@@ -3074,9 +3101,9 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     };
     if ((rc = form_x(Vcur)) != TJM_OK) return rc;
     if ((rc = gram(Xa, w.y_b0, Gm, g_b0)) != TJM_OK) return rc;
-    hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(0.01), Cm, g_b0, (const cplx*)nullptr, 0L);
-    if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0, true)) != TJM_OK) return rc;  // C is anti-Hermitian: C^2 is Hermitian
-    hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);  // T_1
+    hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(0.01), Cm, g_b0, (const cplx*)nullptr, 0L, sq_in, c32_b0);
+    if ((rc = square_of_c(true)) != TJM_OK) return rc;  // C is anti-Hermitian: C^2 is Hermitian
+    hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N, sq_out, c32_b0);  // T_1
     if ((rc = times(Xa, Gm, g_b0, Xb)) != TJM_OK) return rc;
     {  // E_1 = T_1^H T_1 - I
       GemmDesc g = square(N);
@@ -3088,27 +3115,27 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
       hipLaunchKernelGGL(polar_residual_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, Iso, x_b0, N, (const int*)nullptr, 0, (const int*)nullptr);
     }
     if ((rc = gram(Xb, w.y_b0, Gm, g_b0)) != TJM_OK) return rc;
-    hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(1e-4), Cm, g_b0, (const cplx*)Iso, x_b0);
-    if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0, false)) != TJM_OK) return rc;  // W = C - E/2 is neither
-    hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);  // T_2
+    hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(1e-4), Cm, g_b0, (const cplx*)Iso, x_b0, sq_in, c32_b0);
+    if ((rc = square_of_c(false)) != TJM_OK) return rc;  // W = C - E/2 is neither
+    hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N, sq_out, c32_b0);  // T_2
     if ((rc = times(Xb, Gm, g_b0, Xa)) != TJM_OK) return rc;
   }
   for (int it = 0; it < n_ref && !on_x; ++it) {
     if ((rc = form_x(Vcur)) != TJM_OK) return rc;
     if ((rc = gram(w.Y, w.y_b0, Gm, g_b0)) != TJM_OK) return rc;
     if (it + 1 < n_ref) {
-      hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(0.01), Cm, g_b0, (const cplx*)nullptr, 0L);
+      hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(0.01), Cm, g_b0, (const cplx*)nullptr, 0L, (float2_t*)nullptr, c32_b0);
       if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0, true)) != TJM_OK) return rc;  // C is anti-Hermitian: C^2 is Hermitian
-      hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);
+      hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N, (const float2_t*)nullptr, c32_b0);
       if ((rc = apply(Vcur, Gm, g_b0, Vnext)) != TJM_OK) return rc;
     } else {
       // last round: the truncated exponentials of the rounds before are unitary to |C|^3 / 6 <= 2e-7 (|C_ij| <= 0.01); E = V^H V - I
       // goes into the same factor as the last correction, W = C - E/2, applied as I + W + W^2/2
       if ((rc = gram(Vcur, v_b0, Iso, x_b0)) != TJM_OK) return rc;
       hipLaunchKernelGGL(polar_residual_kernel, dim3((N + 255) / 256, nb), dim3(256), 0, s, Iso, x_b0, N, (const int*)nullptr, 0, (const int*)nullptr);
-      hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(1e-4), Cm, g_b0, (const cplx*)Iso, x_b0);
+      hipLaunchKernelGGL(refine_corr_kernel, dim3(gx, nb), dim3(256), 0, s, Gm, g_b0, N, skip_col, cm_far, fro2, real(1e-4), Cm, g_b0, (const cplx*)Iso, x_b0, (float2_t*)nullptr, c32_b0);
       if ((rc = rowmul(Cm, g_b0, Cm, g_b0, S2, x_b0, false)) != TJM_OK) return rc;  // W = C - E/2 is neither
-      hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N);
+      hipLaunchKernelGGL(refine_poly_kernel, dim3(gx, nb), dim3(256), 0, s, Cm, g_b0, S2, x_b0, Gm, g_b0, N, (const float2_t*)nullptr, c32_b0);
       if ((rc = apply(Vcur, Gm, g_b0, Vnext)) != TJM_OK) return rc;
     }
     std::swap(Vcur, Vnext);
