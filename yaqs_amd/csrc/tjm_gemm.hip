@@ -22,8 +22,13 @@ namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16;
 constexpr int PITCH = 80;  // doubles per k-row in LDS (64 + 16: second k-group -> banks 32..63)
+constexpr int KP = 18;     // TR: a k-contiguous operand is kept m-major in LDS, 16 k values + 2 per row (64 x 18 <= 16 x 80)
 
-template <bool A_MCONTIG, bool B_NCONTIG>
+// TR: k-contiguous operands (the Gram products X^H X of the mixed split: both operands) are stored as they arrive - 16 consecutive k
+// of one row per 16 lanes go to 16 consecutive LDS words - instead of k-major with the XOR swizzle, whose stores still collide
+// two-way (k and k + 8 share a bank pair); the MFMA operand reads walk the rows with pitch 18 (16 rows x 2 k-groups of a half-wave
+// hit 32 distinct bank pairs).
+template <bool A_MCONTIG, bool B_NCONTIG, bool TR>
 __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
   __shared__ real sAr[BK * PITCH];
   __shared__ real sAi[BK * PITCH];
@@ -103,12 +108,12 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
   auto store_tile = [&]() {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int ca = A_MCONTIG ? am[e] : (am[e] ^ swz(ak[e]));
-      const int cb = B_NCONTIG ? bn[e] : (bn[e] ^ swz(bk[e]));
-      sAr[ak[e] * PITCH + ca] = ra[e].x;
-      sAi[ak[e] * PITCH + ca] = sgnA * ra[e].y;
-      sBr[bk[e] * PITCH + cb] = rb[e].x;
-      sBi[bk[e] * PITCH + cb] = sgnB * rb[e].y;
+      const int ia = A_MCONTIG ? ak[e] * PITCH + am[e] : TR ? am[e] * KP + ak[e] : ak[e] * PITCH + (am[e] ^ swz(ak[e]));
+      const int ib = B_NCONTIG ? bk[e] * PITCH + bn[e] : TR ? bn[e] * KP + bk[e] : bk[e] * PITCH + (bn[e] ^ swz(bk[e]));
+      sAr[ia] = ra[e].x;
+      sAi[ia] = sgnA * ra[e].y;
+      sBr[ib] = rb[e].x;
+      sBi[ib] = sgnB * rb[e].y;
     }
   };
 
@@ -127,10 +132,12 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
       real ar[2], ai[2], br[2], bi[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ar[i] = sAr[krow + wm + 16 * i + la];
-        ai[i] = sAi[krow + wm + 16 * i + la];
-        br[i] = sBr[krow + wn + 16 * i + lb];
-        bi[i] = sBi[krow + wn + 16 * i + lb];
+        const int ia = (!A_MCONTIG && TR) ? (wm + 16 * i + li) * KP + 4 * s + lk : krow + wm + 16 * i + la;
+        const int ib = (!B_NCONTIG && TR) ? (wn + 16 * i + li) * KP + 4 * s + lk : krow + wn + 16 * i + lb;
+        ar[i] = sAr[ia];
+        ai[i] = sAi[ia];
+        br[i] = sBr[ib];
+        bi[i] = sBi[ib];
       }
       // twelve independent accumulators: none is touched again before eleven other MFMAs
       real as[2], bs[2];
@@ -470,10 +477,17 @@ int launch_gemm(const GemmDesc& g, hipStream_t stream) {
   dim3 block(256);
   const bool am = (g.a_rs == 1 && g.a_cs != 1);
   const bool bn = (g.b_cs == 1);
-  if (am && bn) hipLaunchKernelGGL((zgemm_kernel<true, true>), grid, block, 0, stream, g);
-  else if (am && !bn) hipLaunchKernelGGL((zgemm_kernel<true, false>), grid, block, 0, stream, g);
-  else if (!am && bn) hipLaunchKernelGGL((zgemm_kernel<false, true>), grid, block, 0, stream, g);
-  else hipLaunchKernelGGL((zgemm_kernel<false, false>), grid, block, 0, stream, g);
+  static const bool swizzled = getenv("TJM_GEMM_SWIZZLED_LDS") != nullptr;  // diagnostic: the k-major layout for every operand
+  if (am && bn) hipLaunchKernelGGL((zgemm_kernel<true, true, false>), grid, block, 0, stream, g);
+  else if (swizzled) {
+    if (am && !bn) hipLaunchKernelGGL((zgemm_kernel<true, false, false>), grid, block, 0, stream, g);
+    else if (!am && bn) hipLaunchKernelGGL((zgemm_kernel<false, true, false>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((zgemm_kernel<false, false, false>), grid, block, 0, stream, g);
+  } else {
+    if (am && !bn) hipLaunchKernelGGL((zgemm_kernel<true, false, true>), grid, block, 0, stream, g);
+    else if (!am && bn) hipLaunchKernelGGL((zgemm_kernel<false, true, true>), grid, block, 0, stream, g);
+    else hipLaunchKernelGGL((zgemm_kernel<false, false, true>), grid, block, 0, stream, g);
+  }
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
