@@ -232,7 +232,10 @@ int tjm_engine_run(tjm_engine* e, const tjm_run_config* cfg, const int64_t* traj
  * input, a blow-up - is taken out of the run (status[b] = TJM_ERR_NUMERIC, its result rows NaN, its slot refilled with a copy of a
  * healthy neighbour so that every kernel keeps seeing finite data) and the other B - 1 finish exactly as they would have without it;
  * the states are screened before the first step and after every step.  The reference loses one job of its pool in that case, not the
- * pool (core/parallel_utils.py:361-383).  The return code still reports failures that concern the batch (capacity, arguments, HIP). */
+ * pool (core/parallel_utils.py:361-383).  The return code still reports failures that concern the batch (capacity, arguments, HIP).
+ * status is IN / OUT for a continued run (cfg->start_step > 0, e.g. after TJM_ERR_CAPACITY on a larger engine): a trajectory whose
+ * entry is not TJM_OK on entry stays out (its slot holds a donor's state); a fresh run (start_step == 0) overwrites every entry.  The
+ * sampling copy of the order-2 driver and the state after its half-step prelude are screened like the state after every step. */
 int tjm_engine_run_status(tjm_engine* e, const tjm_run_config* cfg, const int64_t* traj, double* results, double* diagnostics, int32_t* status);
 /* The reference's host random streams, bit-compatible with NumPy (core/random_utils.py:20-69):
  * timestep < 0: make_trajectory_rng(traj, base_seed=seed).random(n); otherwise make_sample_rng(traj, timestep, seed). */

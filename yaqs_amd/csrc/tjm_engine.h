@@ -229,8 +229,9 @@ class Engine {
   std::vector<char> cert_ok_;            // per trajectory: the state is what a certified dissipation left (valid while cert_set_ >= 0)
   std::vector<unsigned long long> cert_sum_;
   int cert_set_ = -1;
-  std::vector<int> cert_wait_;           // per trajectory: calls of dissipate it still sits out after its certificate failed
-  std::vector<int> cert_back_;           // per trajectory: length of its last sit-out (doubles with consecutive failures, at most 4)
+  std::vector<int> cert_wait_;           // [set][trajectory]: calls of dissipate it still sits out after its certificate failed
+  std::vector<int> cert_back_;           // [set][trajectory]: length of its last sit-out (doubles with consecutive failures, at most 4)
+  void cert_size() { if (cert_wait_.size() != (size_t)n_sets * B) { cert_wait_.assign((size_t)n_sets * B, 0); cert_back_.assign((size_t)n_sets * B, 0); } }
   int copy_back(cplx* dst, long dst_b0, const cplx* src, long src_b0, long n, const int* ids, int nb0);
   std::vector<int> unitary_jump_;
 };

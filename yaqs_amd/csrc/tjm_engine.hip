@@ -357,8 +357,8 @@ int Engine::load_state(int set, const double* host, const int* bonds) {
   if (!bound_ || set < 0 || set > 1) return TJM_ERR_STATE;
   StateSet& S = sets[set];
   const double* src = host;  // complex128: (re, im) pairs
-  cert_wait_.assign(B, 0);  // new trajectories: nobody sits out
-  cert_back_.assign(B, 0);
+  cert_size();
+  for (int b = 0; b < B; ++b) { cert_wait_[(size_t)set * B + b] = 0; cert_back_[(size_t)set * B + b] = 0; }  // new trajectories: nobody sits out
   std::vector<int> chi((size_t)B * (L + 1));
   for (int b = 0; b < B; ++b) for (int k = 0; k <= L; ++k) chi[(size_t)b * (L + 1) + k] = bonds[k];
   for (int k = 0; k <= L; ++k) if (bonds[k] > cap[k] || bonds[k] < 1) return TJM_ERR_ARG;
@@ -390,7 +390,9 @@ int Engine::load_state_slot(int set, int b, const double* host, const int* bonds
   if (!bound_ || set < 0 || set > 1 || b < 0 || b >= B) return TJM_ERR_STATE;
   StateSet& S = sets[set];
   for (int k = 0; k <= L; ++k) if (bonds[k] > cap[k] || bonds[k] < 1) return TJM_ERR_ARG;
-  if ((int)cert_wait_.size() == B) { cert_wait_[b] = 0; cert_back_[b] = 0; }
+  cert_size();
+  cert_wait_[(size_t)set * B + b] = 0;
+  cert_back_[(size_t)set * B + b] = 0;
   TJM_HIP_CHECK(hipMemcpyAsync(S.chi + (long)b * (L + 1), bonds, (size_t)(L + 1) * sizeof(int), hipMemcpyHostToDevice, stream));
   const double* src = host;
   for (int i = 0; i < L; ++i) {
@@ -416,7 +418,9 @@ int Engine::copy_slot(int set, int dst, int src) {
   for (int i = 0; i < L; ++i)
     TJM_HIP_CHECK(hipMemcpyAsync(S.A[i] + (long)dst * a_b0_[i], S.A[i] + (long)src * a_b0_[i], (size_t)a_b0_[i] * sizeof(cplx), hipMemcpyDeviceToDevice, stream));
   TJM_HIP_CHECK(hipMemcpyAsync(S.chi + (long)dst * (L + 1), S.chi + (long)src * (L + 1), (size_t)(L + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
-  if ((int)cert_wait_.size() == B) { cert_wait_[dst] = cert_wait_[src]; cert_back_[dst] = cert_back_[src]; }
+  cert_size();
+  cert_wait_[(size_t)set * B + dst] = cert_wait_[(size_t)set * B + src];
+  cert_back_[(size_t)set * B + dst] = cert_back_[(size_t)set * B + src];
   cert_set_ = -1;
   return TJM_OK;
 }
@@ -455,6 +459,11 @@ int Engine::copy_state(int dst, int src) {
   for (int i = 0; i < L; ++i)
     TJM_HIP_CHECK(hipMemcpyAsync(sets[dst].A[i], sets[src].A[i], (size_t)B * a_b0_[i] * sizeof(cplx), hipMemcpyDeviceToDevice, stream));
   TJM_HIP_CHECK(hipMemcpyAsync(sets[dst].chi, sets[src].chi, (size_t)B * (L + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+  cert_size();  // the copy inherits the certificate back-off of its source (psi = deepcopy(phi); snapshot / roll-back of a step)
+  for (int b = 0; b < B; ++b) {
+    cert_wait_[(size_t)dst * B + b] = cert_wait_[(size_t)src * B + b];
+    cert_back_[(size_t)dst * B + b] = cert_back_[(size_t)src * B + b];
+  }
   return TJM_OK;
 }
 
@@ -487,6 +496,12 @@ int Engine::adopt(Engine& src, int first) {
   TJM_HIP_CHECK(hipGetLastError());
   TJM_HIP_CHECK(hipMemcpyAsync(sets[0].chi, src.sets[0].chi + (size_t)first * (L + 1), (size_t)B * (L + 1) * sizeof(int), hipMemcpyDeviceToDevice, stream));
   TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  cert_size();
+  src.cert_size();
+  for (int b = 0; b < B; ++b) {  // a run continued on a larger engine keeps every trajectory's back-off
+    cert_wait_[b] = src.cert_wait_[(size_t)first + b];
+    cert_back_[b] = src.cert_back_[(size_t)first + b];
+  }
   return TJM_OK;
 }
 
@@ -1568,9 +1583,10 @@ int Engine::dissipate(int set, double dt_, int start_center) {
     // the last bits of its result - must not depend on who else shares its engine.
     std::vector<int> trying;
     if (scalar_only) {
-      if ((int)cert_wait_.size() != B) { cert_wait_.assign(B, 0); cert_back_.assign(B, 0); }
-      for (int b = 0; b < B; ++b) {
-        if (cert_wait_[b] > 0) --cert_wait_[b];
+      cert_size();
+      int* wait = &cert_wait_[(size_t)set * B];  // the back-off belongs to the state set: the sampling copy of the order-2 driver has
+      for (int b = 0; b < B; ++b) {              // its own, so the main trajectory's path does not depend on sample_timesteps
+        if (wait[b] > 0) --wait[b];
         else trying.push_back(b);
       }
       if (trying.empty()) scalar_only = false;
@@ -1605,8 +1621,9 @@ int Engine::dissipate(int set, double dt_, int start_center) {
         // in all): no truncation anywhere if even the smallest value, fully scaled, clears the threshold (margin: rounding)
         const bool ok = tried[b] && flags[b] == 0 && (double)mins[b] * scale * scale >= 1e-12 * (1.0 + 1e-6);
         if (tried[b]) {  // truncating bonds: this trajectory takes the plain sweep for its next call(s)
-          cert_back_[b] = ok ? 0 : std::min(4, std::max(1, 2 * cert_back_[b]));
-          cert_wait_[b] = cert_back_[b];
+          int& back = cert_back_[(size_t)set * B + b];
+          back = ok ? 0 : std::min(4, std::max(1, 2 * back));
+          cert_wait_[(size_t)set * B + b] = back;
         }
         (ok ? good : rest).push_back(b);
       }

@@ -146,6 +146,7 @@ struct TruncSpec {
   int max_bond, min_keep;
   int cap = 0;               // storage extent of the new bond (0: unbounded); a wish beyond it is clipped and reported
   int* overflow = nullptr;   // device flag, set when the clip changed the result
+  int* overflow_each = nullptr;  // svd_finish_kernel only: [B] words written per trajectory (0 / 1) INSTEAD of the sticky flag
   const int* chiA; int mulA;
   const int* chiB; int mulB;
   int* chiOut;

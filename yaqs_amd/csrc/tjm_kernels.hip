@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void krylov_site_small_kernel(SmallKrylovDesc 
     if (tid < 64) {  // breakdown and adaptive stop (lanczos_finalize_kernel)
       real pr = 0.0, pi = 0.0;
       bool done = false;
-      if (j < m - 1 && bj < eps_cut * tjm_breakdown_scale(j == 0 ? alpha : sAl[0], j == 0 ? bj : sBe[0])) {
+      if (j < m - 1 && (bj < eps_cut * tjm_breakdown_scale(j == 0 ? alpha : sAl[0], j == 0 ? bj : sBe[0]) || !(bj > real(0.0)))) {  // beta = 0 (H v = 0: zero Hamiltonian, dissipation-only model) is a breakdown whatever the scale says: 1 / beta must never be formed
         tridiag_expm_e1(sAl, sBe, k, p.dt, tid, pr, pi);
         done = true;
       } else if (j >= 1 || j == m - 1) {
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64) void lanczos_finalize_kernel(KrylovState ks, co
   bool done = false;
   const int k = j + 1;
   real pr = 0.0, pi = 0.0;
-  if (j < m - 1 && bj < eps_cut * tjm_breakdown_scale(j == 0 ? a : al[0], j == 0 ? bj : be[0])) {
+  if (j < m - 1 && (bj < eps_cut * tjm_breakdown_scale(j == 0 ? a : al[0], j == 0 ? bj : be[0]) || !(bj > real(0.0)))) {  // beta = 0: see krylov_site_small_kernel
     tridiag_expm_e1(al, be, k, dt, lane, pr, pi, j, a);
     done = true;
   } else if (j >= 1 || j == m - 1) {

@@ -490,6 +490,129 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
   }
 }
 
+// SEVERAL block reflectors in a row on a chunk of 16 columns that stays in LDS in between: the chunk is read from and written to
+// memory once for np panels instead of once per panel.  qr_block_apply_kernel streams the whole trailing matrix through the chip
+// for every 16-column panel (16 passes per factorisation of a 256-column matrix, 16 more for Q * C); with the panels grouped in
+// fours the trailing matrix makes 2.5 x fewer trips (qr_factor), and Q * C is a single launch (qr_apply_q).  Per panel the
+// arithmetic is that of qr_block_apply_kernel, instruction for instruction (same MFMA sequence, same order of the partial sums over
+// the four wavefronts): the results are bit-identical to the one-panel-per-launch form.
+//   panels p_first, p_first + p_step, ... (np of them); rows row_lo ... zr - 1 of the chunk are kept (row_lo = 16 x the smallest
+//   panel: the reflectors of a panel are zero above its first row)
+__global__ __launch_bounds__(256) void qr_block_apply_multi_kernel(const cplx* __restrict__ Vb, long v_b0, const cplx* __restrict__ Tb, long t_b0,
+                                                                  int p_first, int p_step, int np, int zr, int t_herm, cplx* __restrict__ C,
+                                                                  long c_b0, int col0, int nc, const int* ids, int row_lo, int pitch) {
+  extern __shared__ real smem[];
+  cplx* sC = reinterpret_cast<cplx*>(smem);   // [PW][pitch]
+  cplx* sPart = sC + PW * pitch;              // [4][PW * PW] partial sums of the four wavefronts
+  cplx* sW1 = sPart + 4 * PW * PW;            // (i, c)
+  cplx* sW2 = sW1 + PW * PW;
+  cplx* sTm = sW2 + PW * PW;
+  int b = blockIdx.y;
+  if (ids) b = ids[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = col0 + blockIdx.x * PW;
+  const int ncw = (nc - blockIdx.x * PW < PW) ? nc - blockIdx.x * PW : PW;
+  cplx* Cb = C + (long)b * c_b0;
+  const int nrows = zr - row_lo;
+  for (int c = 0; c < PW; ++c) {
+    const cplx* src = Cb + (long)(c0 + c) * zr + row_lo;
+    for (int r = tid; r < nrows; r += 256) sC[c * pitch + r] = (c < ncw) ? src[r] : cplx{0.0, 0.0};
+  }
+  const int li = lane & 15, lk = lane >> 4;
+  for (int ip = 0; ip < np; ++ip) {
+    const int panel = p_first + ip * p_step;
+    const cplx* __restrict__ Vp = Vb + (long)b * v_b0 + (long)panel * PW * zr;
+    const cplx* Tp = Tb + (long)b * t_b0 + (long)panel * PW * PW;
+    const int row0 = panel * PW;
+    sTm[tid] = Tp[tid];
+    __syncthreads();  // the chunk (first panel) / the update of the panel before is in LDS
+    {  // W1[i][c] = sum_r conj(V[i][r]) C[c][r], K split over the four wavefronts
+      real4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
+      const int nsteps = (zr - row0 + 15) >> 4;
+      const cplx* vcol = Vp + (long)li * zr;
+      const cplx* ccol = sC + li * pitch - row_lo;
+      for (int s = wave; s < nsteps; s += 4) {
+        const int rb = row0 + 16 * s + 4 * lk;
+        cplx v[4], x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = rb + q;
+          v[q] = (r < zr) ? vcol[r] : cplx{0.0, 0.0};
+          x[q] = (r < zr) ? ccol[r] : cplx{0.0, 0.0};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          P = TJM_MFMA(v[q].x, x[q].x, P);
+          Q = TJM_MFMA(v[q].y, x[q].y, Q);
+          S1 = TJM_MFMA(v[q].x, x[q].y, S1);
+          S2 = TJM_MFMA(v[q].y, x[q].x, S2);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sPart[wave * PW * PW + TJM_ACC_ROW(lane, q) * PW + li] = cplx{P[q] + Q[q], S1[q] - S2[q]};
+    }
+    __syncthreads();
+    {  // the four partial sums in the order of the one-panel kernel: (((0 + p0) + p1) + p2) + p3
+      cplx a{0.0, 0.0};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a.x += sPart[w * PW * PW + tid].x;
+        a.y += sPart[w * PW * PW + tid].y;
+      }
+      sW1[tid] = a;
+    }
+    __syncthreads();
+    {  // W2 = op(T) W1
+      const int i = tid >> 4, c = tid & 15;
+      cplx acc{0.0, 0.0};
+      for (int l = 0; l < PW; ++l) {
+        const cplx t = t_herm ? cconj(sTm[l * PW + i]) : sTm[i * PW + l];
+        cfma(acc, t, sW1[l * PW + c]);
+      }
+      sW2[i * PW + c] = acc;
+    }
+    __syncthreads();
+    {  // C[c][r] -= sum_i W2[i][c] V[i][r] on the chunk in LDS
+      real wr[4], wi[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const cplx t = sW2[(4 * kk + lk) * PW + li];
+        wr[kk] = t.x;
+        wi[kk] = t.y;
+      }
+      const int nchunks = (zr - row0 + 15) >> 4;
+      for (int ch = wave; ch < nchunks; ch += 4) {
+        const int r0 = row0 + ch * 16;
+        real4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const cplx v = (r0 + li < zr) ? Vp[(long)(4 * kk + lk) * zr + r0 + li] : cplx{0.0, 0.0};
+          P = TJM_MFMA(wr[kk], v.x, P);
+          Q = TJM_MFMA(wi[kk], v.y, Q);
+          S1 = TJM_MFMA(wi[kk], v.x, S1);
+          S2 = TJM_MFMA(wr[kk], v.y, S2);
+        }
+        if (r0 + li < zr) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = TJM_ACC_ROW(lane, q);
+            cplx* px = sC + c * pitch + (r0 + li - row_lo);
+            cplx x = *px;
+            x.x -= P[q] - Q[q];
+            x.y -= S1[q] + S2[q];
+            *px = x;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = 0; c < ncw; ++c) {
+    cplx* dst = Cb + (long)(c0 + c) * zr + row_lo;
+    for (int r = tid; r < nrows; r += 256) dst[r] = sC[c * pitch + r];
+  }
+}
+
 // Z (column-major zr x zc) from theta (row-major m x n, rows (s,a), columns (t,c)):
 //   dist 0 -> Z = theta   with rows re-ordered bond-major:  r' = a * d + s
 //   dist 1 -> Z = theta^H with rows re-ordered bond-major:  r' = c * d + t
@@ -605,6 +728,36 @@ int apply_block_reflector(const QrWorkspace& q, int zr, int panel, bool t_herm, 
   if (nc <= 0) return TJM_OK;
   hipLaunchKernelGGL(qr_block_apply_kernel, dim3((nc + PW - 1) / PW, nb0), dim3(256), 0, s, q.V, q.v_b0, q.T, q.t_b0, panel, zr, t_herm ? 1 : 0, C,
                      c_b0, col0, nc, ids);
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
+// LDS of qr_block_apply_multi_kernel for a chunk of `nrows` rows: the chunk (row pitch padded by 16 bytes: the 16 columns of a
+// wavefront's operand read start in different banks) + partial sums, W1, W2, T
+int multi_pitch(int nrows) { return nrows + (int)(16 / sizeof(cplx)); }
+size_t multi_lds_bytes(int nrows) { return ((size_t)PW * multi_pitch(nrows) + 7 * PW * PW) * sizeof(cplx); }
+// panels grouped per pass over the trailing matrix (TJM_QR_GROUP, default 4; 1: one panel per launch as in rounds 1 - 4); the
+// chunk has to leave room for two workgroups per CU
+int multi_group(int zr) {
+  static const int g = getenv("TJM_QR_GROUP") ? atoi(getenv("TJM_QR_GROUP")) : 4;
+  return (g > 1 && multi_lds_bytes(zr) <= 80 * 1024) ? g : 1;
+}
+
+// np panels p_first, p_first + p_step, ... on the columns [col0, col0 + nc) of C in one launch
+int apply_block_reflectors(const QrWorkspace& q, int zr, int p_first, int p_step, int np, bool t_herm, cplx* C, long c_b0, int col0, int nc, int nb0,
+                           const int* ids, hipStream_t s) {
+  if (nc <= 0 || np <= 0) return TJM_OK;
+  if (np == 1) return apply_block_reflector(q, zr, p_first, t_herm, C, c_b0, col0, nc, nb0, ids, s);
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set.load(std::memory_order_acquire)) {
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_block_apply_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_set.store(true, std::memory_order_release);
+  }
+  const int p_last = p_first + (np - 1) * p_step;
+  const int row_lo = PW * (p_first < p_last ? p_first : p_last);
+  const int nrows = zr - row_lo;
+  hipLaunchKernelGGL(qr_block_apply_multi_kernel, dim3((nc + PW - 1) / PW, nb0), dim3(256), multi_lds_bytes(nrows), s, q.V, q.v_b0, q.T, q.t_b0, p_first,
+                     p_step, np, zr, t_herm ? 1 : 0, C, c_b0, col0, nc, ids, row_lo, multi_pitch(nrows));
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
@@ -778,6 +931,7 @@ int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hip
   static const bool no_rows = getenv("TJM_QR_LDS_PANEL") != nullptr;
   int rc;
   int panel = 0;
+  const int group = multi_group(zr);
   for (int k0 = 0; k0 < kmax; k0 += PW, ++panel) {
     const int pw = (kmax - k0 < PW) ? kmax - k0 : PW;
     const int mp = zr - k0;
@@ -798,7 +952,14 @@ int qr_factor(const QrWorkspace& q, int zr, int zc, int nb0, const int* ids, hip
     }
     TJM_HIP_CHECK(hipGetLastError());
     const int col0 = k0 + pw;
-    if ((rc = apply_block_reflector(q, zr, panel, true, q.Z, q.z_b0, col0, zc - col0, nb0, ids, s)) != TJM_OK) return rc;
+    // two-level blocking: the reflectors of a panel go to the rest of its GROUP of panels at once, and to the columns right of the
+    // group together with the other panels of the group, in one pass over those columns (every column still sees the panels in
+    // ascending order: same arithmetic, same results)
+    const int first = (panel / group) * group;
+    const int group_end = (first + group) * PW < zc ? (first + group) * PW : zc;
+    if ((rc = apply_block_reflector(q, zr, panel, true, q.Z, q.z_b0, col0, group_end - col0, nb0, ids, s)) != TJM_OK) return rc;
+    if (panel + 1 == first + group || k0 + PW >= kmax)
+      if ((rc = apply_block_reflectors(q, zr, first, 1, panel - first + 1, true, q.Z, q.z_b0, group_end, zc - group_end, nb0, ids, s)) != TJM_OK) return rc;
   }
   return TJM_OK;
 }
@@ -808,6 +969,8 @@ int qr_apply_q(const QrWorkspace& q, int zr, int zc, cplx* C, long c_b0, int nc,
   const int kmax = zr < zc ? zr : zc;
   const int npanels = (kmax + PW - 1) / PW;
   int rc;
+  if (multi_group(zr) > 1)  // all panels in one launch, the chunk of C resident
+    return apply_block_reflectors(q, zr, npanels - 1, -1, npanels, false, C, c_b0, 0, nc, nb0, ids, s);
   for (int p = npanels - 1; p >= 0; --p)
     if ((rc = apply_block_reflector(q, zr, p, false, C, c_b0, 0, nc, nb0, ids, s)) != TJM_OK) return rc;
   return TJM_OK;

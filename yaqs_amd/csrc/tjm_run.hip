@@ -196,7 +196,16 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
   int rc, clipped = 0;
   std::vector<char> dead(B, 0);
   std::vector<int> nonfinite(B, 0);
-  if (status) { for (int b = 0; b < B; ++b) status[b] = TJM_OK; r.dead = &dead; }
+  // status is in / out: a continued run (start_step > 0, e.g. after a capacity rollback onto a larger engine) keeps the trajectories
+  // that were taken out earlier out - their slots hold a finite copy of a donor that would pass the screen - and a fresh run starts clean
+  if (status) {
+    const bool continued = c->start_step > 0;
+    for (int b = 0; b < B; ++b) {
+      if (continued && status[b] != TJM_OK) dead[b] = 1;
+      else status[b] = TJM_OK;
+    }
+    r.dead = &dead;
+  }
   auto screen = [&](int set) -> int {
     if (!status) return TJM_OK;
     if ((rc = e.finite_check(set, nonfinite.data())) != TJM_OK) return rc;
@@ -287,6 +296,7 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
     if ((rc = e.stochastic(1, dt, nullptr, nullptr)) != TJM_OK) return rc;
     if ((rc = clipped_now(over)) != TJM_OK) return rc;
     if (over) return TJM_OK;  // phi is untouched: the caller stops with phase 1
+    if ((rc = screen(1)) != TJM_OK) return rc;  // a non-finite sampling copy takes its trajectory out, not the batch (measure would assert)
     return measure(r, 1, col_of(j));
   };
   if (j0 == 0) {
@@ -296,6 +306,7 @@ int run_batch(Engine& e, const tjm_run_config* c, const int64_t* traj, double* r
     if ((rc = e.dissipate(0, 0.5 * dt)) != TJM_OK) return rc;
     if ((rc = stochastic_main(0)) != TJM_OK) return rc;
     if ((rc = clipped_now(over)) != TJM_OK) return rc;
+    if (!over && (rc = screen(0)) != TJM_OK) return rc;  // the half-step prelude is screened like every full step
     if (!over && (rc = sample(1)) != TJM_OK) return rc;
     if (over) return stop_at(0, 0);  // before the first full step: nothing to keep
   }

@@ -1848,6 +1848,10 @@ __global__ __launch_bounds__(256) void svd_finish_kernel(TruncSpec d, SvdWorkspa
     const int n_act = d.mulB * d.chiB[(long)b * d.chi_stride];
     int nsv = m_act < n_act ? m_act : n_act;
     if (nsv > ncols_pad) nsv = ncols_pad;
+    if (d.overflow_each) {  // one word per trajectory instead of the sticky flag: the caller decides whose clip counts
+      d.overflow_each[b] = 0;
+      d.overflow = d.overflow_each + b;
+    }
     const int keep = truncation_keep(d, nsv, [&](int k) { return sqrt(sN[sPerm[k]]); });
     d.chiOut[(long)b * d.chi_stride] = keep;
     // kept columns at the rounding-noise floor were never rotated: their normalised columns are not orthogonal to the rest,
@@ -2848,8 +2852,12 @@ __global__ __launch_bounds__(256) void refine_check_kernel(const cplx* __restric
 // out[b] = 1 when the trajectory has to be served by the all-fp64 path: its polar certificate failed twice (gave_up), or a KEPT
 // singular value sits at the rounding floor - its column was never rotated / corrected, the completing variant of the fp64 path
 // handles it (the per-trajectory form of the flag svd_finish_kernel raises for the batch)
+// clipped[b] != 0: the truncation of trajectory b was clipped by the storage of the new bond - raised on the engine's sticky flag
+// only for a trajectory this path serves (one that goes to the fp64 path is truncated again there, from singular values that can
+// be trusted: the column norms of a trajectory whose basis failed the polar certificate are not)
 __global__ void mixed_fallback_kernel(const real* __restrict__ norms, int ncols_pad, const int* __restrict__ keep_all, int keep_stride,
-                                      const int* __restrict__ gave_up, int nb0, int* __restrict__ out, int* __restrict__ count) {
+                                      const int* __restrict__ gave_up, int nb0, int* __restrict__ out, int* __restrict__ count,
+                                      const int* __restrict__ clipped, int* __restrict__ overflow) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb0) return;
   const int keep = keep_all[(long)b * keep_stride];
@@ -2857,6 +2865,7 @@ __global__ void mixed_fallback_kernel(const real* __restrict__ norms, int ncols_
   const int bad = (gave_up[b] != 0 || (keep > 0 && nr[keep - 1] <= TJM_RANK_TOL * nr[0])) ? 1 : 0;
   out[b] = bad;
   if (bad) atomicAdd(count, 1);
+  else if (overflow && clipped[b]) atomicOr(overflow, 1);
 }
 
 struct MixedStats { long solves = 0, c64_sweeps = 0, f64_sweeps = 0, fallbacks = 0, jacobi_trajectories = 0, second_polar = 0, gemms = 0, c64_gemms = 0; double gemm_flops = 0.0; };
@@ -2883,7 +2892,7 @@ size_t mixed_split_workspace_bytes(int max_dim, int B) {
   if (off || max_dim < 128 || max_dim > 512 || max_dim % 64 != 0) return 0;
   // the complex64 phase, two more fp64 matrices per trajectory next to the four of the (idle) fp64 preconditioner, a status word
   return tjm32::mixed_workspace_bytes(max_dim, B) + 2 * (((size_t)B * max_dim * max_dim * sizeof(cplx) + 255) / 256 * 256) +
-         3 * (((size_t)B * sizeof(int) + 255) / 256 * 256) + 1024;
+         4 * (((size_t)B * sizeof(int) + 255) / 256 * 256) + 1024;
 }
 
 bool mixed_split_fits(const SvdSplitDesc& d, const QrWorkspace& q, const MixedWorkspace* mx) {
@@ -2919,13 +2928,14 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   const size_t mat_bytes = ((size_t)mx.B * mx.max_dim * mx.max_dim * sizeof(cplx) + 255) / 256 * 256;
   char* tail = static_cast<char*>(mx.base) + (c64_bytes + 255) / 256 * 256;
   const size_t int_bytes = ((size_t)mx.B * sizeof(int) + 255) / 256 * 256;
-  if ((size_t)(tail - static_cast<char*>(mx.base)) + 2 * mat_bytes + 3 * int_bytes > mx.bytes) return TJM_ERR_WORKSPACE;
+  if ((size_t)(tail - static_cast<char*>(mx.base)) + 2 * mat_bytes + 4 * int_bytes > mx.bytes) return TJM_ERR_WORKSPACE;
   const long x_b0 = (long)mx.max_dim * mx.max_dim;
   cplx* S2 = reinterpret_cast<cplx*>(tail);                 // squares (E^2, C^2)
   cplx* Iso = reinterpret_cast<cplx*>(tail + mat_bytes);    // the kept columns before their polar step
   int* status = reinterpret_cast<int*>(tail + 2 * mat_bytes);
   int* idlist = status + int_bytes / sizeof(int);
   int* pneed = idlist + int_bytes / sizeof(int);  // per trajectory: the polar certificate failed (first step: wants a second; after it: gives up)
+  int* clipped = pneed + int_bytes / sizeof(int);  // per trajectory: the truncation rule wanted more than the storage of the new bond holds
   // fp64 matrices in the buffers of the (idle) fp64 preconditioner
   cplx* Va = q.Z;  cplx* Vb = q.Z2;  const long v_b0 = q.z_b0;  // the basis, ping-pong (N x N column-major)
   cplx* Gm = q.V;  cplx* Cm = q.V2;  const long g_b0 = q.v_b0;  // Gram matrix / series, correction (N x N row-major)
@@ -3144,7 +3154,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   if ((rc = gram(w.Y, w.y_b0, Gm, g_b0)) != TJM_OK) return rc;
   TruncSpec tr;
   tr.trunc_mode = d.trunc_mode; tr.threshold = d.threshold; tr.max_bond = d.max_bond; tr.min_keep = d.min_keep;
-  tr.cap = d.capM; tr.overflow = d.overflow;
+  tr.cap = d.capM; tr.overflow = nullptr; tr.overflow_each = clipped;  // (the fp64 Jacobi of a failed check finishes its trajectories with the same spec)
   tr.chiA = d.chiL; tr.mulA = d.d; tr.chiB = d.chiR; tr.mulB = d.d; tr.chiOut = d.chiM; tr.chi_stride = d.chi_stride;
   tr.spectrum = d.spectrum; tr.spec_ld = d.spec_ld;
   JacobiShape sh;
@@ -3184,7 +3194,8 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   }
   // which trajectories does the all-fp64 path have to serve (per trajectory: nobody else's result depends on it)
   TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 5, 0, sizeof(int), s));
-  hipLaunchKernelGGL(mixed_fallback_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, w.norms, N, d.chiM, d.chi_stride, pneed, nb, status, w.n_active + 5);
+  hipLaunchKernelGGL(mixed_fallback_kernel, dim3((nb + 255) / 256), dim3(256), 0, s, w.norms, N, d.chiM, d.chi_stride, pneed, nb, status, w.n_active + 5,
+                     clipped, d.overflow);
   TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned + 7, w.n_active + 5, sizeof(int), hipMemcpyDeviceToHost, s));
   TJM_HIP_CHECK(hipStreamSynchronize(s));
   const int n_fb = w.h_pinned[7];
@@ -3203,7 +3214,9 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     g_mixed.fallbacks += n_fb;
   }
   if (sweeps_out) *sweeps_out = f64_sweeps;
-  if (n_fb == nb) return TJM_OK;  // nobody left for this path (*done stays false): the caller runs the fp64 path on the whole batch
+  // (n_fb == nb: nobody is left for this path.  The listed trajectories are still served by the SAME code as a partial list - the
+  // plain fp64 split with an index list - so that a trajectory's last bits do not depend on who shares its batch.)
+  if (n_fb < nb) {
   // ---- isometric factor: normalised kept columns, made exactly isometric by a polar step of their own; then the projection
   ExtractDesc xi;
   GemmDesc gg, gt, gp;  // Gram of the raw isometry, raw x T, projection
@@ -3254,6 +3267,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   TJM_HIP_CHECK(hipGetLastError());
   if ((rc = mixed_gemm(gt, s)) != TJM_OK) return rc;
   if ((rc = mixed_gemm(gp, s)) != TJM_OK) return rc;
+  }
   if (n_fb > 0) {
     // the plain fp64 split (Jacobi with the accumulated unitary: isometric whatever the rank) for the listed trajectories; it
     // rewrites their outputs and their bond entry
