@@ -2,7 +2,7 @@
 # A/B runs of the headline bench under diagnostic switches: one JSON line per variant under gpurun_out/r03/ab_<tag>.json
 # usage (on the GPU box, from the repository root):  bash tools/gpu_ab.sh "tag1|ENV=1 ...|--extra args" "tag2||..."
 cd "$(dirname "$0")/.." || exit 1
-OUT=gpurun_out/${ROUND:-r04}
+OUT=gpurun_out/${ROUND:-r05}
 mkdir -p "$OUT"
 for spec in "$@"; do
   IFS='|' read -r tag envs extra <<< "$spec"

@@ -4,7 +4,7 @@
 #   usage (GPU box, repository root):  bash tools/gpu_prof.sh [stats] [steady] [pmc]
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
-OUT=gpurun_out/${ROUND:-r04}/prof
+OUT=gpurun_out/${ROUND:-r05}/prof
 mkdir -p "$OUT"
 want() { [[ " $* " == *" $WHAT "* ]]; }
 for WHAT in "${@:-stats pmc}"; do :; done
@@ -14,6 +14,13 @@ if [[ " $ARGS " == *" stats "* ]]; then
   find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
   rm -rf "$OUT/stats"
   head -12 "$OUT/kernel_stats.csv"
+fi
+if [[ " $ARGS " == *" iso "* ]]; then
+  # ONE engine, 256 trajectories: every kernel alone on the device - its duration here is what it costs, not a time slice
+  timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/iso" -- python3 bench.py --steps ${ISO_STEPS:-1} --warmup ${ISO_WARMUP:-1} --no-cpu-baseline --engines 1 --batch 256 --trajectories 256 > "$OUT/iso_bench.json" 2> "$OUT/iso.err"
+  find "$OUT/iso" -name "*kernel_stats.csv" -exec cp {} "$OUT/iso_kernel_stats.csv" \;
+  rm -rf "$OUT/iso"
+  head -12 "$OUT/iso_kernel_stats.csv"
 fi
 if [[ " $ARGS " == *" steady "* ]]; then
   # the state the driver times: steps 9 - 11 of a run from the Haar state (most dissipations certified), whole trace of the run

@@ -669,7 +669,14 @@ def gen_fullsize_steady_final(trajs=(0, 1, 2), steps=10):
     gen_fullsize_steady(trajs, steps, sample=False)
 
 
-def gen_fullsize_steady(trajs=(0, 1, 2), steps=10, sample=True):
+def gen_fullsize_steady_bench(trajs=(0, 1, 2, 3, 4, 5, 6, 7), steps=10):
+    """The same ten consecutive steps with the EXACT parameters of bench.py's timed region - krylov_tol 1e-4 (the fixtures
+    above use 1e-10) - and eight trajectories: tests/golden/fullsize_steady_tol4.npz.  Final-time sampling as in
+    gen_fullsize_steady_final.  About 5 minutes on eight cores."""
+    gen_fullsize_steady(trajs, steps, sample=False, krylov_tol=1e-4, name="fullsize_steady_tol4")
+
+
+def gen_fullsize_steady(trajs=(0, 1, 2), steps=10, sample=True, krylov_tol=1e-10, name="fullsize_steady"):
     """The reference's analog_tjm_1 on BASELINE's config 2 (L=64, chi=128 Haar-saturated, pauli_z 0.1 on every site, dt 0.1,
     svd_threshold 1e-12, krylov_tol 1e-10) for `steps` CONSECUTIVE steps: the state bench.py's timed region is in after its first
     steps, where the certified scalar dissipation / in-place jumps of the engine serve most trajectory-steps.  Per trajectory:
@@ -677,11 +684,13 @@ def gen_fullsize_steady(trajs=(0, 1, 2), steps=10, sample=True):
     import multiprocessing as mp
 
     with mp.get_context("fork").Pool(len(trajs)) as pool:
-        rows = pool.starmap(_steady_one, [(t, steps, 1e-10, sample) for t in trajs])
+        rows = pool.starmap(_steady_one, [(t, steps, krylov_tol, sample) for t in trajs])
     out = {"traj": np.array(trajs), "steps": np.array(steps), "sample_timesteps": np.array(int(sample))}
+    if name != "fullsize_steady":  # (the round-4 fixture keeps its keys: it regenerates bit for bit)
+        out["krylov_tol"] = np.array(krylov_tol)
     for k in rows[0]:
         out[k] = np.array([r[k] for r in rows])
-    save("fullsize_steady", **out)
+    save(name, **out)
 
 
 # ------------------------------------------------------------------ 13. dynamic TDVP and the BUG integrator

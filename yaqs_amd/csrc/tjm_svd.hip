@@ -934,6 +934,251 @@ __global__ __launch_bounds__(256, 4) void jacobi_cross16q_kernel(JacobiArgs g) {
   if (tid == 0) atomicAdd(&g.nrot[b], total);
 }
 
+// ---- THREE tournament rounds per load: four 16-column blocks per workgroup ---------------------------------------------------------
+// jacobi_cross16q_kernel reads and writes a tile of 32 columns for one round of the tournament: 15 trips of the whole matrix through
+// HBM per sweep, and by its arithmetic intensity (14 flop per byte) the kernel sits on the memory side of the fp32 ridge.  Here a
+// workgroup of 8 wavefronts holds FOUR blocks (A, B, C, D) and plays the three rounds among them - (A,B)(C,D), (A,C)(B,D),
+// (A,D)(B,C), each by two groups of four wavefronts exactly as two workgroups of the tile kernel would - with one block changing
+// groups through LDS between the rounds: one load and one store per THREE rounds.  A sweep of a 256-column matrix is 5 launches of
+// 4 such quads: the 16 blocks are the points of the affine plane AG(2,4), whose 20 lines (5 parallel classes of 4 disjoint lines)
+// contain every pair of points exactly once - so every block pair meets in exactly one quad of one class, as in one round of the
+// circle method.  The pairs INSIDE a block ride along as before; their schedule is the same plane on the 16 columns of a block:
+// in the launch of class c wavefront w of a group holds the four columns of line (c, w), and the three rounds play the three
+// perfect matchings of those four columns - no column changes wavefronts inside a launch, and the 5 x 3 rounds of a sweep visit all
+// 120 pairs of the block once.  Pruning stamps, zero blocks, the rotation rule and the LATE variant are those of the tile kernel
+// (clock + t stands for the launch counter of round t).
+__device__ inline int gf4_mul(int a, int b) { return (0x9C78E400u >> (2 * (4 * a + b))) & 3; }  // GF(4) = {0, 1, x, x + 1}, 2 bits per product
+// k-th point (0 ... 3) of line `line` of parallel class `cls` (0 ... 4) of AG(2,4); points are numbered 4 x + y
+__device__ inline int ag_point(int cls, int line, int k) { return cls == 4 ? 4 * line + k : 4 * k + (gf4_mul(cls, k) ^ line); }
+
+template <int XRK, bool LATE>
+__global__ __launch_bounds__(512, 4) void jacobi_quad64_kernel(JacobiArgs g) {
+  extern __shared__ real smem[];
+  int b = blockIdx.y;
+  if (g.ids) b = __builtin_amdgcn_readfirstlane(g.ids[b]);
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), grp = w >> 2, wl = w & 3;  // (scalar registers)
+  if (g.done[b]) return;
+  const int rtot = g.rtot;
+  typedef ColFrag<XRK> Col;
+  real* slots = smem;                                    // [8][4] columns of Col::LDS_REALS
+  real* sN = slots + 32 * Col::LDS_REALS;                // [8][4]
+  int* sCnt = reinterpret_cast<int*>(sN + 32);           // [8]
+  const int cls = g.round;                               // parallel class of this launch (0 ... 4)
+  int blk[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) blk[k] = ag_point(cls, blockIdx.x, k);
+  int* st = g.stamps + (long)b * STAMP_STRIDE;
+  int mod[4], nz[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    mod[k] = __builtin_amdgcn_readfirstlane(max(st[2 * blk[k]], st[2 * blk[k] + 1]));
+    nz[k] = __builtin_amdgcn_readfirstlane(st[2 * MAXBLK + 2 * blk[k]] | st[2 * MAXBLK + 2 * blk[k] + 1]);
+  }
+  auto ver_of = [&](int i, int j) -> int& { const int I = min(blk[i], blk[j]), J = max(blk[i], blk[j]); return st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J]; };
+  // does the tile of positions (i, j) have anything to do: the rule of the tile kernel
+  auto tile_open = [&](int i, int j) { return (nz[i] || nz[j]) && !(__builtin_amdgcn_readfirstlane(ver_of(i, j)) > max(mod[i], mod[j])); };
+  {
+    // nothing open in the first round and nothing that a rotation of this launch could re-open: leave before the load
+    const bool any = tile_open(0, 1) || tile_open(2, 3) || tile_open(0, 2) || tile_open(1, 3) || tile_open(0, 3) || tile_open(1, 2);
+    if (!any) return;
+  }
+  cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
+  // group 0 holds A as I throughout and B, C, D in turn as J; group 1 holds (C, D), then (B, D), then (B, C); qI / qJ: the lines of the
+  // column plane the quads of this wavefront sit on
+  int qI = wl, qJ = wl;
+  Col yI[4], yJ[4];
+  real nI[4], nJ[4];
+  {
+    const int bI = grp == 0 ? blk[0] : blk[2], bJ = grp == 0 ? blk[1] : blk[3];
+    real pn[8];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      yI[h].load(Yb + (long)(bI * 16 + ag_point(cls, qI, h)) * rtot, lane);
+      yJ[h].load(Yb + (long)(bJ * 16 + ag_point(cls, qJ, h)) * rtot, lane);
+      pn[h] = yI[h].norm2();
+      pn[4 + h] = yJ[h].norm2();
+    }
+    const real z = wave_sum8_groups(pn[0], pn[1], pn[2], pn[3], pn[4], pn[5], pn[6], pn[7], lane);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      nI[h] = lane_value(z, 8 * h);
+      nJ[h] = lane_value(z, 32 + 8 * h);
+    }
+  }
+  const real floor2 = g.floor_scale * g.fro2[b];
+  int cnt = 0;
+  auto sub_step = [&](Col& p0, Col& q0, real& a0, real& d0, Col& p1, Col& q1, real& a1, real& d1, Col& p2, Col& q2, real& a2, real& d2, Col& p3, Col& q3,
+                      real& a3, real& d3) {
+    real gx[4], gy[4];
+    Col::dot(p0, q0, gx[0], gy[0]);
+    Col::dot(p1, q1, gx[1], gy[1]);
+    Col::dot(p2, q2, gx[2], gy[2]);
+    Col::dot(p3, q3, gx[3], gy[3]);
+    const real gsum = wave_sum8_groups(gx[0], gy[0], gx[1], gy[1], gx[2], gy[2], gx[3], gy[3], lane);
+    const int pr = lane >> 4;
+    const real a = pr == 0 ? a0 : pr == 1 ? a1 : pr == 2 ? a2 : a3;
+    const real d = pr == 0 ? d0 : pr == 1 ? d1 : pr == 2 ? d2 : d3;
+    real cv, sv, tv;
+    const bool rot = make_rotation_lanes4(a, d, gsum, g.tol2, floor2, cv, sv, tv);
+    const unsigned long long any = __ballot(rot) & 0x0001000100010001ull;
+    cnt += __popcll(any);
+    if (LATE && any == 0) return;
+    {
+      const real sr = lane_value(sv, 0), si = lane_value(sv, 8), c = lane_value(cv, 0), tg = lane_value(tv, 0);
+      Col::rotate(p0, q0, c, sr, si);
+      a0 -= tg; d0 += tg;
+    }
+    {
+      const real sr = lane_value(sv, 16), si = lane_value(sv, 24), c = lane_value(cv, 16), tg = lane_value(tv, 16);
+      Col::rotate(p1, q1, c, sr, si);
+      a1 -= tg; d1 += tg;
+    }
+    {
+      const real sr = lane_value(sv, 32), si = lane_value(sv, 40), c = lane_value(cv, 32), tg = lane_value(tv, 32);
+      Col::rotate(p2, q2, c, sr, si);
+      a2 -= tg; d2 += tg;
+    }
+    {
+      const real sr = lane_value(sv, 48), si = lane_value(sv, 56), c = lane_value(cv, 48), tg = lane_value(tv, 48);
+      Col::rotate(p3, q3, c, sr, si);
+      a3 -= tg; d3 += tg;
+    }
+  };
+  int total_all = 0, work = 0;
+#pragma unroll 1
+  for (int t = 0; t < 3; ++t) {
+    // both tiles of the round (every thread keeps the stamps of all four blocks), read BEFORE anybody writes a stamp of this round;
+    // constant indices per round: the four stamps stay in scalar registers
+    bool open0, open1, cross0, cross1;
+    if (t == 0) { open0 = tile_open(0, 1); open1 = tile_open(2, 3); cross0 = nz[0] && nz[1]; cross1 = nz[2] && nz[3]; }       // (A, B) (C, D)
+    else if (t == 1) { open0 = tile_open(0, 2); open1 = tile_open(1, 3); cross0 = nz[0] && nz[2]; cross1 = nz[1] && nz[3]; }  // (A, C) (B, D)
+    else { open0 = tile_open(0, 3); open1 = tile_open(1, 2); cross0 = nz[0] && nz[3]; cross1 = nz[1] && nz[2]; }              // (A, D) (B, C)
+    cross0 = cross0 && open0;
+    cross1 = cross1 && open1;
+    const bool open = grp == 0 ? open0 : open1;
+    const bool cross = grp == 0 ? cross0 : cross1;
+    cnt = 0;
+    // the in-block pairs of this round: slots (0, 1) and (2, 3) of each block - the slots are rotated between the rounds (below), so
+    // that one piece of code plays the three perfect matchings of the four columns
+    if (open) sub_step(yI[0], yI[1], nI[0], nI[1], yI[2], yI[3], nI[2], nI[3], yJ[0], yJ[1], nJ[0], nJ[1], yJ[2], yJ[3], nJ[2], nJ[3]);
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+      if (cross) {
+        sub_step(yI[0], yJ[0], nI[0], nJ[0], yI[1], yJ[1], nI[1], nJ[1], yI[2], yJ[2], nI[2], nJ[2], yI[3], yJ[3], nI[3], nJ[3]);
+        sub_step(yI[0], yJ[1], nI[0], nJ[1], yI[1], yJ[2], nI[1], nJ[2], yI[2], yJ[3], nI[2], nJ[3], yI[3], yJ[0], nI[3], nJ[0]);
+        sub_step(yI[0], yJ[2], nI[0], nJ[2], yI[1], yJ[3], nI[1], nJ[3], yI[2], yJ[0], nI[2], nJ[0], yI[3], yJ[1], nI[3], nJ[1]);
+        sub_step(yI[0], yJ[3], nI[0], nJ[3], yI[1], yJ[0], nI[1], nJ[0], yI[2], yJ[1], nI[2], nJ[1], yI[3], yJ[2], nI[3], nJ[2]);
+      }
+      if (s + 1 < 4) {  // the J quads move one wavefront on inside their group (barriers are for the whole workgroup: both groups
+                        // run the same sequence, a closed tile only skips the arithmetic and the traffic)
+        if (cross) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) yJ[h].to_lds(slots + (w * 4 + h) * Col::LDS_REALS, lane);
+          if (lane < 4) sN[w * 4 + lane] = lane == 0 ? nJ[0] : lane == 1 ? nJ[1] : lane == 2 ? nJ[2] : nJ[3];
+        }
+        __syncthreads();
+        if (cross) {
+          const int src = grp * 4 + ((wl + 1) & 3);
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            yJ[h].from_lds(slots + (src * 4 + h) * Col::LDS_REALS, lane);
+            nJ[h] = sN[src * 4 + h];
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (cross) qJ = (qJ + 3) & 3;  // after three hand-overs wavefront w holds the J quad that started at wavefront w + 3
+    if (lane == 0) sCnt[w] = cnt;
+    __syncthreads();
+    const int tot0 = __builtin_amdgcn_readfirstlane(sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3]);
+    const int tot1 = __builtin_amdgcn_readfirstlane(sCnt[4] + sCnt[5] + sCnt[6] + sCnt[7]);
+    const int stamp = g.clock + t;
+    const bool moved0 = open0 && tot0 > 0, moved1 = open1 && tot1 > 0;
+    work += (open0 ? (cross0 ? REC_PER_VISIT : 0) + 2 * NB : 0) + (open1 ? (cross1 ? REC_PER_VISIT : 0) + 2 * NB : 0);  // (scalar, every thread)
+    if (moved0) total_all += tot0;
+    if (moved1) total_all += tot1;
+    if (t == 0) {
+      if (tid == 0) {
+        if (open0 && tot0 == 0) ver_of(0, 1) = stamp;
+        if (open1 && tot1 == 0) ver_of(2, 3) = stamp;
+      }
+      if (moved0) { mod[0] = stamp; mod[1] = stamp; }
+      if (moved1) { mod[2] = stamp; mod[3] = stamp; }
+    } else if (t == 1) {
+      if (tid == 0) {
+        if (open0 && tot0 == 0) ver_of(0, 2) = stamp;
+        if (open1 && tot1 == 0) ver_of(1, 3) = stamp;
+      }
+      if (moved0) { mod[0] = stamp; mod[2] = stamp; }
+      if (moved1) { mod[1] = stamp; mod[3] = stamp; }
+    } else {
+      if (tid == 0) {
+        if (open0 && tot0 == 0) ver_of(0, 3) = stamp;
+        if (open1 && tot1 == 0) ver_of(1, 2) = stamp;
+      }
+      if (moved0) { mod[0] = stamp; mod[3] = stamp; }
+      if (moved1) { mod[1] = stamp; mod[2] = stamp; }
+    }
+    if (t == 2) break;
+    // ---- between the rounds.  (i) Slots 1, 2, 3 of every block rotate: (c0 c1 c2 c3) -> (c0 c2 c3 c1) -> (c0 c3 c1 c2), the three
+    // matchings.  (ii) One block of each group changes sides, always as the J block: group 0 gives B, then C; group 1 - whose fixed
+    // block would have to change with the round - first trades the roles of its two blocks (registers only: (C, D) -> (D, C) gives
+    // C; (D, B) -> (B, D) gives D).  The quads travel as they are: wavefront wl takes what wavefront wl of the other group held.
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      Col* y = q == 0 ? yI : yJ;
+      real* nn = q == 0 ? nI : nJ;
+      const Col c1 = y[1];
+      const real n1 = nn[1];
+      y[1] = y[2]; y[2] = y[3]; y[3] = c1;
+      nn[1] = nn[2]; nn[2] = nn[3]; nn[3] = n1;
+    }
+    if (grp == 1) {
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const Col c = yI[h]; yI[h] = yJ[h]; yJ[h] = c;
+        const real n = nI[h]; nI[h] = nJ[h]; nJ[h] = n;
+      }
+      const int q = qI; qI = qJ; qJ = q;
+    }
+    __syncthreads();  // (the counts above are read; the slots are free)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) yJ[h].to_lds(slots + (w * 4 + h) * Col::LDS_REALS, lane);
+    if (lane < 4) sN[w * 4 + lane] = lane == 0 ? nJ[0] : lane == 1 ? nJ[1] : lane == 2 ? nJ[2] : nJ[3];
+    if (lane == 0) sCnt[w] = qJ;  // the line of the column plane the quad sits on travels with it
+    __syncthreads();
+    {
+      const int src = (1 - grp) * 4 + wl;
+      qJ = __builtin_amdgcn_readfirstlane(sCnt[src]);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) { yJ[h].from_lds(slots + (src * 4 + h) * Col::LDS_REALS, lane); nJ[h] = sN[src * 4 + h]; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && g.work && work) atomicAdd(g.work, work);
+  if (total_all == 0) return;
+  // blocks that were rotated in this launch go back (mod stamps of this launch), by whoever holds them now: group 0 ends with
+  // (A, D), group 1 with (B, C)
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (mod[k] >= g.clock) { st[2 * blk[k]] = mod[k]; st[2 * blk[k] + 1] = mod[k]; }
+    atomicAdd(&g.nrot[b], total_all);
+  }
+  const int bI = grp == 0 ? blk[0] : blk[1], bJ = grp == 0 ? blk[3] : blk[2];
+  const int mI = grp == 0 ? mod[0] : mod[1], mJ = grp == 0 ? mod[3] : mod[2];
+  // after the two rotations slot h holds point (0, 3, 1, 2)[h] of its line
+  if (mI >= g.clock) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) yI[h].store(Yb + (long)(bI * 16 + ag_point(cls, qI, h == 0 ? 0 : h == 1 ? 3 : h - 1)) * rtot, lane);
+  }
+  if (mJ >= g.clock) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) yJ[h].store(Yb + (long)(bJ * 16 + ag_point(cls, qJ, h == 0 ? 0 : h == 1 ? 3 : h - 1)) * rtot, lane);
+  }
+}
+
 // Replay of the recorded rotations on the W rows of the same tile: lane = one row, 32 columns in registers.
 __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int wrow0) {
   int b = blockIdx.z;
@@ -2158,6 +2403,21 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   }
 #endif
   const size_t lds16q = lds16x;
+  // three rounds per load (jacobi_quad64_kernel): 16 blocks of 16 columns = the points of AG(2,4); TJM_NO_QUAD64: one round per launch
+  bool quad64 = false;
+#ifdef TJM_F32
+  {
+    static const bool no_quad64 = getenv("TJM_NO_QUAD64") != nullptr;
+    quad64 = quad16 && !no_quad64 && ncols_pad == 256 && rx_top == 256;
+    static std::atomic<bool> q64_attr{false};
+    if (quad64 && !q64_attr.load(std::memory_order_acquire)) {
+      TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      q64_attr.store(true, std::memory_order_release);
+    }
+  }
+#endif
+  const size_t lds64 = 2 * lds16x + 16 * sizeof(real) + 16 * sizeof(int);
   g.rec = accumulate ? w.rec : nullptr;
   // in-block pairs folded into the tile visits (jacobi_cross16x_kernel): needs the 15 tournament rounds of a 16-column block inside
   // one sweep, and no rotation record (the W replay kernel knows the fixed column assignment only)
@@ -2188,7 +2448,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
       else hipLaunchKernelGGL(jacobi_cross_kernel<8>, dim3(g.nblk / 2, nb), dim3(512), lds, s, g);
       g.mode = 0;
     }
-    for (int r = 0; r < nrounds; ++r) {
+    for (int r = 0; r < (quad64 ? 5 : nrounds); ++r) {
       g.round = r;
       ++g.clock;
       const bool timed = g_prof.every > 0 && split16 && (t_prof.counter++ % g_prof.every == 0);  // only the dominant (split X) kernel is sampled
@@ -2202,7 +2462,17 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
         }
         TJM_HIP_CHECK(hipEventRecord(t_prof.pool[2 * slot], s));
       }
-      if (quad16) {
+      if (quad64) {  // parallel class r of the block plane: three rounds (clock, clock + 1, clock + 2) in one launch
+#ifdef TJM_F32
+        if (late) hipLaunchKernelGGL((jacobi_quad64_kernel<4, true>), dim3(4, nb), dim3(512), lds64, s, g);
+        else hipLaunchKernelGGL((jacobi_quad64_kernel<4, false>), dim3(4, nb), dim3(512), lds64, s, g);
+#endif
+        g.clock += 2;
+        if (timed) {
+          TJM_HIP_CHECK(hipEventRecord(t_prof.pool[2 * slot + 1], s));
+          t_prof.pending.emplace_back(slot, (real)4 * n_live * 8.0 * NB * rx_top * sizeof(cplx) * 2.0);
+        }
+      } else if (quad16) {
         const dim3 gridq(npairs, nb), blockq(256);
 #define TJM_Q16_LAUNCH(K)                                                                     \
   if (late) hipLaunchKernelGGL((jacobi_cross16q_kernel<K, true>), gridq, blockq, lds16q, s, g); \
