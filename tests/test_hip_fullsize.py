@@ -105,7 +105,7 @@ def _steady_engine(g, sel=None):
     if sel is not None:
         trajs = [trajs[k] for k in sel]
     e = BatchEngine(64, 128, len(trajs), api.MPO.ising(64, 1.0, 0.5).tensors)
-    e.set_params(dt=0.1, svd_threshold=1e-12, max_bond_dim=128, krylov_tol=1e-10, tdvp_mode="2site")
+    e.set_params(dt=0.1, svd_threshold=1e-12, max_bond_dim=128, krylov_tol=float(g["krylov_tol"]) if "krylov_tol" in g else 1e-10, tdvp_mode="2site")
     noise = NoiseModel([{"name": "pauli_z", "sites": [i], "strength": 0.1} for i in range(64)])
     e.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
     e.load_state(t)
@@ -198,3 +198,31 @@ def test_config2_ten_consecutive_steps_also_without_the_certified_dissipation():
                          env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__)))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "2 passed" in out.stdout, out.stdout[-2000:]
+
+
+# ---- the same ten steps with the EXACT parameters of the timed region: krylov_tol 1e-4 (bench.py), eight trajectories ----
+STEADY4 = os.path.join(GOLDEN, "fullsize_steady_tol4.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(STEADY4), reason="tests/golden/fullsize_steady_tol4.npz not generated")
+def test_config2_ten_steps_at_the_bench_krylov_tolerance_match_the_reference():
+    """``tools/make_golden.py fullsize_steady_bench``: the fixture above once more with ``krylov_tol = 1e-4`` - the value bench.py times
+    (at 1e-10 a Lanczos call runs to ~12 vectors, at 1e-4 to ~5: another stopping point of the same recurrence, so the iteration count of
+    every one of the 2 x 63 x 10 calls per trajectory has to agree with the reference's for the results to agree) - and EIGHT
+    trajectories (80 trajectory-steps, 42 of them with a jump).  The stopping rule compares an a-posteriori estimate with 1e-4; the
+    engine evaluates the same estimate from the same recurrence, so the bar stays the fp64 one: dp 1e-8 at every step, jump decisions
+    and bond tables exact, final <Z_i> 1e-8.  Through the stage entry points and through the one-call C driver."""
+    g = np.load(STEADY4)
+    assert float(g["krylov_tol"]) == 1e-4 and len(g["traj"]) >= 8
+    sel = list(range(len(g["traj"])))
+    z, stats = _steady_stages(g, sel)
+    err = np.abs(z - g["z"][:, :, -1]).max()
+    assert err < TOL, err
+    _steady_counters(stats)
+    e, trajs = _steady_engine(g)
+    zmat = np.diag([1.0, -1.0]).astype(np.complex128)
+    res, diag = e.run(order=1, n_times=int(g["steps"]) + 1, sample_timesteps=False, has_noise=True, seed=42, traj_indices=trajs,
+                      observables=[(s, zmat) for s in range(64)])
+    e.close()
+    assert np.abs(res[:, :, 0] - g["z"][:, :, -1]).max() < TOL
+    assert np.array_equal(diag[:, :, 0], g["diag"][:, :, -1])

@@ -807,3 +807,113 @@ def test_svd_split_of_the_complex64_library(lib32, capL, capR, qr):
         assert np.allclose(lf.conj().T @ lf, np.eye(capM), atol=2e-5)
         # left[(s,a),k] right[k,(t,c)] = theta[(s,a),(t,c)] with rows (s, a) and columns (t, c)
         assert np.allclose(lf @ rf, theta[b].astype(np.complex128), atol=2e-5 * s_ref[0])
+
+
+# ---- the mixed-precision two-site split in the mode the ENGINE calls it in (no spectrum buffer) -----------------------------------
+def _mixed_matrices(rng, n):
+    """(name, theta, gap at the cut?) for square n x n thetas with the new bond capped at n / 2: full numerical rank without a gap at
+    the cut (a Gaussian matrix), rank n / 4 (exactly zero singular values: unit-vector completion of the complex64 basis, the 'far'
+    columns), a spectrum graded over six decades, and the exponentially decaying spectrum of an evolved two-site tensor."""
+    cap = n // 2
+    u = np.linalg.qr(crand(rng, n, n))[0]
+    v = np.linalg.qr(crand(rng, n, n))[0]
+    graded = (u * np.sort(np.concatenate([np.linspace(1.0, 0.05, cap), 10.0 ** rng.uniform(-6, -2, n - cap)]))[::-1]) @ v.conj().T
+    low = (crand(rng, n, n // 4) / np.sqrt(n * n / 4)) @ np.linalg.qr(crand(rng, n, n // 4))[0].conj().T
+    evolved = (u * np.exp(-np.arange(n) * 16.0 / n)) @ v.conj().T
+    return ["gaussian", "rank n/4", "graded", "evolved"], np.stack([crand(rng, n, n) / n, low, graded, evolved])
+
+
+def _check_engine_mode_split(theta, left, right, keep, d, cap, dist, tol_trunc, tol_iso=1e-13, tol_resid=1e-12):
+    """Against LAPACK: the kept count, the truncated theta (tol_trunc x sigma_0; for a matrix without a gap at the cut the subspace of
+    the kept values is only defined to eps / relative gap, so the gap-free measure is checked too: ||theta - L R||_F against the
+    discarded tail), an isometric factor that is isometric to rounding, exact zero padding."""
+    n = d * cap
+    for b in range(theta.shape[0]):
+        ru, rs, rvh = np.linalg.svd(theta[b])
+        tail = np.cumsum((rs ** 2)[::-1])[::-1]
+        kb_ref = max(2, min(cap, int(np.sum(tail >= 1e-12))))  # discarded_weight rule (svd_utils.py:22-104), min_keep 2, max_bond cap
+        kb = int(keep[b])
+        assert kb == kb_ref, (b, kb, kb_ref)
+        L_ = left[b].reshape(n, cap)
+        R_ = right[b].transpose(1, 0, 2).reshape(cap, n)
+        trunc = (ru[:, :kb] * rs[:kb]) @ rvh[:kb]
+        assert np.abs(L_ @ R_ - trunc).max() <= tol_trunc[b] * rs[0], (dist, b, np.abs(L_ @ R_ - trunc).max() / rs[0])
+        resid = np.linalg.norm(theta[b] - L_ @ R_)
+        assert abs(resid - np.sqrt(np.sum(rs[kb:] ** 2))) <= tol_resid * rs[0], (dist, b, resid, np.sqrt(np.sum(rs[kb:] ** 2)))
+        iso = L_[:, :kb] if dist == 0 else R_[:kb].conj().T
+        assert np.abs(iso.conj().T @ iso - np.eye(kb)).max() <= tol_iso, (dist, b, np.abs(iso.conj().T @ iso - np.eye(kb)).max())
+        assert np.all(L_[:, kb:] == 0) and np.all(R_[kb:] == 0)
+
+
+def _run_engine_mode(lib, n):
+    rng = np.random.default_rng(n)
+    d, cap = 2, n // 2
+    names, theta = _mixed_matrices(rng, n)
+    chi = np.full(len(names), cap, dtype=np.int32)
+    # tolerance of the truncated theta: 1e-12 where the cut sits in a gap (or behind the rank), 1e-10 for the gap-free Gaussian matrix
+    # (relative gap of neighbouring values ~ 1 / n: tilt 1e-13 / gap)
+    tol = [1e-10, 1e-12, 1e-12, 1e-12]
+    out = (C.c_double * 10)()
+    lib.tjm_svd_mixed_read(out, 1)
+    for dist in (0, 1):
+        left, right, keep, _, _ = svd_split_gpu(lib, theta, d, cap, cap, cap, dist, 0, 1e-12, cap, 2, chi, chi, qr=True, want_spec=False)
+        _check_engine_mode_split(theta, left, right, keep, d, cap, dist, tol)
+    lib.tjm_svd_mixed_read(out, 0)
+    return [int(round(out[i])) for i in range(6)] + [out[8]]
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_mixed_split_in_the_mode_of_the_engine_matches_lapack(lib, n):
+    """svd_split_mixed as Engine::split calls it - no spectrum buffer, so columns that can never be kept stay uncorrected among
+    themselves, the refinement works on X and its squares run on the complex64 GEMM (tjm_svd.hip: can_skip) - at the sizes of
+    BASELINE's configs 2 (256 x 256) and 3 (512 x 512), on four kinds of matrices, both distributions, against LAPACK.  The counters
+    say that the mixed path SERVED the calls: two batched solves, complex64 sweeps and fp64 products counted, no trajectory handed to
+    the all-fp64 split."""
+    solves, c64_sweeps, f64_sweeps, fallbacks, jacobi_traj, second_polar, gemms = _run_engine_mode(lib, n)
+    assert solves == 2 and fallbacks == 0, (solves, fallbacks)
+    assert c64_sweeps >= 8 and gemms >= 26, (c64_sweeps, gemms)  # at least four complex64 sweeps and 13 fp64 products per solve
+    assert jacobi_traj <= 2 * 4  # (the fp64 Jacobi may finish single trajectories: the final check decides, per trajectory)
+
+
+@pytest.mark.skipif(SIM, reason="child processes of the GPU run")
+@pytest.mark.parametrize("cap_sweeps,branch", [(4, "second_polar"), (2, "fallback")])
+def test_mixed_split_branches_under_a_loosened_complex64_basis(cap_sweeps, branch):
+    """The rare branches of the mixed split, forced: with the complex64 iteration cut off after four sweeps (TJM_MIXED_C64_SWEEPS,
+    read once per process: a child process) the basis is orthonormal to ~1e-3 only - the polar certificate fails, the listed second
+    polar step runs and the fp64 Jacobi finishes what the final check does not pass; cut off after two sweeps the second step fails
+    too and the trajectories go to the all-fp64 split (one code path whatever the size of the list).  Results against LAPACK as above
+    (isometry 2e-13 where the plain fp64 split with its accumulated rotations served the trajectory)."""
+    import json
+    import subprocess
+    import sys
+
+    code = ("import json, sys; sys.path.insert(0, %r); import test_hip_kernels as k; from yaqs_amd import _lib; "
+            "r = k._run_engine_mode_loose(_lib.load(), 256); print('RESULT ' + json.dumps(r))") % os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, TJM_MIXED_C64_SWEEPS=str(cap_sweeps))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__)))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    solves, c64_sweeps, f64_sweeps, fallbacks, jacobi_traj, second_polar, gemms = r
+    assert solves == 2 and c64_sweeps == 2 * cap_sweeps, r
+    assert second_polar == 2, r  # both batched solves took the listed second polar step
+    if branch == "second_polar":
+        assert fallbacks == 0 and jacobi_traj > 0 and f64_sweeps > 0, r  # served by the mixed path, finished by the fp64 Jacobi on X
+    else:
+        assert fallbacks > 0, r  # handed to the all-fp64 split, per trajectory
+
+
+def _run_engine_mode_loose(lib, n):
+    """_run_engine_mode with the tolerances of a trajectory the all-fp64 split may have served: isometry 2e-13 (accumulated rotations),
+    residual 5e-11 sigma_0 (that path stops rotating a column once it is below its noise floor, 1e-13 ||theta||_F: on the rank n / 4
+    matrix the 3 n / 4 null columns are left 1e-11 sigma_0 away from orthogonal - three decades inside the 1e-8 parity bar)."""
+    rng = np.random.default_rng(n)
+    d, cap = 2, n // 2
+    names, theta = _mixed_matrices(rng, n)
+    chi = np.full(len(names), cap, dtype=np.int32)
+    out = (C.c_double * 10)()
+    lib.tjm_svd_mixed_read(out, 1)
+    for dist in (0, 1):
+        left, right, keep, _, _ = svd_split_gpu(lib, theta, d, cap, cap, cap, dist, 0, 1e-12, cap, 2, chi, chi, qr=True, want_spec=False)
+        _check_engine_mode_split(theta, left, right, keep, d, cap, dist, [1e-10, 5e-11, 5e-11, 5e-11], tol_iso=2e-13, tol_resid=5e-11)
+    lib.tjm_svd_mixed_read(out, 0)
+    return [int(round(out[i])) for i in range(6)] + [out[8]]

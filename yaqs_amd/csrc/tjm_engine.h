@@ -221,6 +221,8 @@ class Engine {
   int svd_shift_left_2site(StateSet& S, int i, const int* ids, int nb0);
   // Certified scalar dissipation (tjm_engine.hip: dissipate): the right-going SVD pass on scratch copies of the centre tensor
   int svd_shift_right_virtual(StateSet& S, int i, const cplx* Cin, long cin_b0, cplx* Cout, long cout_b0, const int* ids, int nb0);
+  bool cert_gram_fits() const;
+  int cert_pass_gram(StateSet& S, const int* ids, int nb0, double cut);
   int state_checksum(int set, const int* ids, int n, unsigned long long* host_out);
   int* vchi_ = nullptr;                  // [B][L+1] bond dimensions the virtual pass would leave
   real* cert_min_ = nullptr;             // [B] smallest squared singular value met by the virtual pass

@@ -8,6 +8,7 @@
 //                     left "density" environments; same expectation values, no gauge moves.
 #include "tjm_engine.h"
 
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <mutex>
@@ -169,7 +170,7 @@ size_t Engine::workspace_bytes() const {
   tot += align_up(qr_workspace_bytes(d * cm, B)) + 4096;
   tot += align_up(mixed_split_workspace_bytes(d * cm, B));
   tot += 2 * align_up((size_t)B * TJM_MAX_PART * sizeof(double));
-  tot += 3 * align_up((size_t)B * mmax * sizeof(cplx));
+  tot += 4 * align_up((size_t)B * mmax * sizeof(cplx));                 // alpha, beta, coef, svec
   tot += 3 * align_up((size_t)B * cm * cm * sizeof(cplx));              // E ping-pong + bond matrix
   tot += align_up((size_t)L * B * d * d * sizeof(cplx));                // M
   tot += align_up((size_t)L * B * d * d * d * d * sizeof(cplx));        // M2
@@ -227,6 +228,7 @@ int Engine::bind(void* ws, size_t bytes, hipStream_t s) {
   ks.coef = reinterpret_cast<cplx*>(take((size_t)B * mmax * sizeof(cplx)));
   ks.vnorm = reinterpret_cast<real*>(take((size_t)B * sizeof(double)));
   ks.scale = reinterpret_cast<real*>(take((size_t)B * sizeof(double)));
+  ks.svec = reinterpret_cast<real*>(take((size_t)B * mmax * sizeof(double)));
   ks.status = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   ks.kfinal = reinterpret_cast<int*>(take((size_t)B * sizeof(int)));
   ks.n_active = reinterpret_cast<int*>(take(256));
@@ -757,7 +759,7 @@ int Engine::krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc
   TJM_HIP_CHECK(hipMemsetAsync(ks.n_active, 0, sizeof(int), stream));
   if ((rc = launch_normsq_partial(V, v_b0, n, part2_, nb0, ids, nullptr, stream, &nblk)) != TJM_OK) return rc;
   if ((rc = launch_lanczos_init(ks, part2_, nblk, nb0, ids, stream)) != TJM_OK) return rc;
-  if ((rc = launch_scale(V, v_b0, n, ks.scale, nb0, ids, ks.status, stream)) != TJM_OK) return rc;
+  // (no normalisation passes: the Krylov vectors stay unnormalised in V, their scales ks.svec ride along - round 5)
   for (int j = 0; j < mmax; ++j) {
     cplx* vj = V + (long)j * v_ld;
     cplx* w = V + (long)(j + 1) * v_ld;
@@ -766,11 +768,9 @@ int Engine::krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc
     ++stat_matvecs;
     if (krylov_P_ == d * d) ++stat_matvecs2;
     if ((rc = launch_dot_partial(vj, w, v_b0, v_b0, n, part1_, nb0, ids, ks.status, stream, &nblk)) != TJM_OK) return rc;
-    if ((rc = launch_lanczos_axpy(w, vj, vjm1, v_b0, n, part1_, part2_, nblk, ks.beta, mmax, j, nb0, ids, ks.status, stream)) != TJM_OK) return rc;
+    if ((rc = launch_lanczos_axpy(w, vj, vjm1, v_b0, n, part1_, part2_, nblk, ks.beta, mmax, j, nb0, ids, ks.status, stream, ks.svec)) != TJM_OK) return rc;
     TJM_HIP_CHECK(hipMemsetAsync(ks.n_active, 0, sizeof(int), stream));
     if ((rc = launch_lanczos_finalize(ks, part1_, part2_, nblk, j, dt_, krylov_tol, nloc_dev, nb0, ids, stream)) != TJM_OK) return rc;
-    if (j + 1 < mmax)
-      if ((rc = launch_scale(w, v_b0, n, ks.scale, nb0, ids, ks.status, stream)) != TJM_OK) return rc;
     if (!pipelined) {
       TJM_HIP_CHECK(hipMemcpyAsync(h_pinned_, ks.n_active, sizeof(int), hipMemcpyDeviceToHost, stream));
       TJM_HIP_CHECK(hipStreamSynchronize(stream));
@@ -1294,6 +1294,127 @@ int Engine::state_checksum(int set, const int* ids, int n, unsigned long long* h
   return TJM_OK;
 }
 
+// ---- the same certificate without a single SVD (round 5) ---------------------------------------------------------------------------
+// What the virtual pass needs from bond k is ONE bit: does every squared singular value of the centre tensor clear the cut
+// 1e-12 / scale^2 (then neither pass of the reference's sweep truncates there: the discarded-weight rule drops a value only while the
+// running sum stays below 1e-12, so nothing goes when even the smallest one is above it).  The squared singular values of the centre
+// tensor at bond k are the eigenvalues of its Gram matrix, and those Gram matrices obey the recursion of the left density
+// environments: with the centre at site 0 and isometric tensors to its right,
+//     G_0 = [1],   G_(k+1) = sum_s A_k[s]^H G_k A_k[s]     (C_k = M A_k with M^H M = G_k, whatever gauge M is in)
+// - two small MFMA products per site, the recursion site_moments runs for the observables.  "lambda_min(G_k) >= cut" is the statement
+// "G_k - cut I is positive definite": a Cholesky factorisation that meets no non-positive pivot (chol_pd_kernel, one workgroup per
+// trajectory, the lower triangle in LDS).  The test only has to be SUFFICIENT (a trajectory that fails it takes the reference's
+// sweep), so the cut carries an absolute margin for the rounding of the recursion and of the factorisation (2e-14: n eps ||G|| with
+// ||G|| <= 1, against eigenvalues that matter at 1e-12).  Per trajectory-step: 63 x 2 products of 128^3 and 63 factorisations of
+// 128 x 128 instead of 63 Jacobi SVDs of 256 x 128 (ten fp64 sweeps each in the evolved state).  fp64 build only: in complex64 the
+// Gram matrix is not resolved at 1e-12.  TJM_CERT_SVD_PASS: the SVD pass of rounds 3 - 4.
+__global__ __launch_bounds__(256) void chol_pd_kernel(const cplx* __restrict__ E, long e_b0, int ld, const int* __restrict__ chi, int chi_stride, real cut,
+                                                     int* __restrict__ flag, const int* ids) {
+  extern __shared__ real chol_smem[];
+  cplx* Lp = reinterpret_cast<cplx*>(chol_smem);  // packed lower triangle, row-major: (i, j <= i) at i (i + 1) / 2 + j
+  __shared__ real s_piv;
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  const int n = chi[(long)b * chi_stride];
+  const cplx* Eb = E + (long)b * e_b0;
+  const int tid = threadIdx.x;
+  const int ntri = n * (n + 1) / 2;
+  for (int e = tid; e < ntri; e += 256) {
+    // row i of entry e: largest i with i (i + 1) / 2 <= e
+    int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+    while (i * (i + 1) / 2 > e) --i;
+    const int j = e - i * (i + 1) / 2;
+    cplx v = Eb[(long)i * ld + j];
+    if (i == j) { v.x -= cut; v.y = 0.0; }
+    Lp[e] = v;
+  }
+  __syncthreads();
+  bool ok = true;
+  for (int j = 0; j < n; ++j) {
+    if (tid == 0) s_piv = Lp[j * (j + 1) / 2 + j].x;
+    __syncthreads();
+    const real piv = s_piv;
+    if (!(piv > real(0.0))) { ok = false; break; }  // uniform: every thread reads the same pivot (a NaN fails too)
+    const real inv = real(1.0) / sqrt(piv);
+    // column j below the diagonal, scaled; every thread keeps its own copy of what it needs: entry (i, j) for its rows
+    for (int i = j + 1 + tid; i < n; i += 256) {
+      cplx& v = Lp[i * (i + 1) / 2 + j];
+      v.x *= inv; v.y *= inv;
+    }
+    __syncthreads();
+    // trailing update: (i, k) -= L(i, j) conj(L(k, j)) for j < k <= i; rows dealt round-robin, a row's entries by the threads of a
+    // group of 16
+    const int grp = tid >> 4, gl = tid & 15;
+    for (int i = j + 1 + grp; i < n; i += 16) {
+      const cplx lij = Lp[i * (i + 1) / 2 + j];
+      for (int k = j + 1 + gl; k <= i; k += 16) {
+        const cplx lkj = Lp[k * (k + 1) / 2 + j];
+        cplx& v = Lp[i * (i + 1) / 2 + k];
+        v.x -= lij.x * lkj.x + lij.y * lkj.y;
+        v.y -= lij.y * lkj.x - lij.x * lkj.y;
+      }
+    }
+    __syncthreads();
+  }
+  if (!ok && tid == 0) flag[b] = 1;
+}
+
+bool Engine::cert_gram_fits() const {
+#ifdef TJM_F32
+  return false;
+#else
+  static const bool svd_pass = getenv("TJM_CERT_SVD_PASS") != nullptr;
+  if (svd_pass) return false;
+  int cm = 1;
+  for (int k = 0; k <= L; ++k) cm = cap[k] > cm ? cap[k] : cm;
+  return (size_t)cm * (cm + 1) / 2 * sizeof(cplx) <= 140 * 1024;
+#endif
+}
+
+__global__ void fill_cplx_kernel(cplx* p, cplx v, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// flags cert_flag_[b] for every listed trajectory one of whose bonds 1 ... L - 1 has a squared singular value below `cut`
+int Engine::cert_pass_gram(StateSet& S, const int* ids, int nb0, double cut) {
+  int rc;
+  static std::atomic<bool> attr_set{false};
+  if (!attr_set.load(std::memory_order_acquire)) {
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_pd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    attr_set.store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(fill_cplx_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, E_, cplx{1.0, 0.0}, (long)B);  // G_0 = [1] (cap[0] = 1)
+  cplx* E = E_;
+  cplx* En = E2_;
+  for (int i = 0; i < L - 1; ++i) {
+    const int ca = cap[i], cb = cap[i + 1];
+    {  // T[p][a][b] = sum_a' G[a][a'] A_i[p][a'][b]
+      GemmDesc g = blank_gemm();
+      g.A = E; g.B = S.A[i]; g.C = T1;
+      g.M = ca; g.K = ca; g.N = cb;
+      g.a_rs = ca; g.a_cs = 1; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb;
+      g.nb0 = nb0; g.ids = ids; g.nb1 = d;
+      g.a_b0 = (long)ca * ca; g.b_b0 = a_b0_[i]; g.b_b1 = (long)ca * cb; g.c_b0 = t_b0; g.c_b1 = (long)ca * cb;
+      if ((rc = gemm(g)) != TJM_OK) return rc;
+    }
+    {  // G'[b][b'] = sum_{(p,a)} conj(A_i[(p,a),b]) T[(p,a),b']
+      GemmDesc g = blank_gemm();
+      g.A = S.A[i]; g.B = T1; g.C = En;
+      g.M = cb; g.K = d * ca; g.N = cb;
+      g.a_rs = 1; g.a_cs = cb; g.b_rs = cb; g.b_cs = 1; g.c_rs = cb; g.conjA = 1;
+      g.nb0 = nb0; g.ids = ids; g.a_b0 = a_b0_[i]; g.b_b0 = t_b0; g.c_b0 = (long)cb * cb;
+      if ((rc = gemm(g)) != TJM_OK) return rc;
+    }
+    std::swap(E, En);
+    const size_t lds = (size_t)cb * (cb + 1) / 2 * sizeof(cplx);
+    hipLaunchKernelGGL(chol_pd_kernel, dim3(nb0), dim3(256), lds, stream, E, (long)cb * cb, cb, S.chi + i + 1, L + 1, (real)cut, cert_flag_, ids);
+  }
+  TJM_HIP_CHECK(hipGetLastError());
+  return TJM_OK;
+}
+
 // svd_shift_right on a scratch centre tensor: Cin [B][d][ca][cb] (stride cin_b0) = the centre tensor of site i; Cout [B][d][cb][cc] =
 // (S V^H) A_{i+1}, the centre tensor of site i + 1.  The bond table is read, not written (the kept count goes to vchi_), and
 // cert_min_ / cert_flag_ are updated.  Always the general kernels (the one-wavefront kernels work in place).
@@ -1585,8 +1706,12 @@ int Engine::dissipate(int set, double dt_, int start_center) {
     if (scalar_only) {
       cert_size();
       int* wait = &cert_wait_[(size_t)set * B];  // the back-off belongs to the state set: the sampling copy of the order-2 driver has
+      // (the back-off dates from the SVD pass, which cost a third of a sweep: with the Gram pass every trajectory tries every time;
+      // TJM_CERT_BACKOFF=1 keeps it)
+      static const bool keep_backoff = getenv("TJM_CERT_BACKOFF") != nullptr;
+      const bool backoff = keep_backoff || !cert_gram_fits();
       for (int b = 0; b < B; ++b) {              // its own, so the main trajectory's path does not depend on sample_timesteps
-        if (wait[b] > 0) --wait[b];
+        if (backoff && wait[b] > 0) --wait[b];
         else trying.push_back(b);
       }
       if (trying.empty()) scalar_only = false;
@@ -1599,20 +1724,27 @@ int Engine::dissipate(int set, double dt_, int start_center) {
         TJM_HIP_CHECK(hipMemcpyAsync(try_ids, trying.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice, stream));
       }
       hipLaunchKernelGGL(cert_init_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, cert_min_, cert_flag_, B);
-      const cplx* cin = S.A[0];
-      long cin_b0 = a_b0_[0];
-      for (int i = 0; i < L - 1; ++i) {  // the right-going pass on scratch centre tensors (two slots of the idle Krylov basis buffer)
-        cplx* cout = V + (long)(i & 1) * v_ld;
-        if ((rc = svd_shift_right_virtual(S, i, cin, cin_b0, cout, v_b0, try_ids, nt)) != TJM_OK) return rc;
-        cin = cout;
-        cin_b0 = v_b0;
+      const double scale = std::exp(-0.5 * dt_ * expo_total);
+      if (cert_gram_fits()) {
+        // no SVD: Gram matrices of the centre tensors by the density-environment recursion, one positive-definiteness test per bond
+        // against the cut the comparison below applies to the smallest singular value (cert_min_ stays at its initial 3e38)
+        Region prof(*this, PROF_SVD);
+        if ((rc = cert_pass_gram(S, try_ids, nt, 1e-12 * (1.0 + 1e-6) / (scale * scale) + 2e-14)) != TJM_OK) return rc;
+      } else {
+        const cplx* cin = S.A[0];
+        long cin_b0 = a_b0_[0];
+        for (int i = 0; i < L - 1; ++i) {  // the right-going pass on scratch centre tensors (two slots of the idle Krylov basis buffer)
+          cplx* cout = V + (long)(i & 1) * v_ld;
+          if ((rc = svd_shift_right_virtual(S, i, cin, cin_b0, cout, v_b0, try_ids, nt)) != TJM_OK) return rc;
+          cin = cout;
+          cin_b0 = v_b0;
+        }
       }
       std::vector<real> mins(B);
       std::vector<int> flags(B);
       TJM_HIP_CHECK(hipMemcpyAsync(mins.data(), cert_min_, (size_t)B * sizeof(real), hipMemcpyDeviceToHost, stream));
       TJM_HIP_CHECK(hipMemcpyAsync(flags.data(), cert_flag_, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
       TJM_HIP_CHECK(hipStreamSynchronize(stream));
-      const double scale = std::exp(-0.5 * dt_ * expo_total);
       std::vector<int> good, rest;
       std::vector<char> tried(B, 0);
       for (int b : trying) tried[b] = 1;

@@ -34,6 +34,8 @@ struct KrylovState {
   cplx* coef;      // [B][mmax]
   real* vnorm;   // [B]
   real* scale;   // [B]  1/beta_j (or 1/|v|)
+  real* svec;    // [B][mmax] scale of Krylov vector j: the basis is stored UNNORMALISED (v_j = svec[j] * V[j]; svec[0] = 1 / |v|,
+                 // svec[j + 1] = 1 / beta_j), the scalars ride along in the vector kernels - no normalisation pass per iteration
   int* status;     // [B]  1 = still iterating, 0 = finished
   int* kfinal;     // [B]
   int* n_active;   // [1]
@@ -67,7 +69,7 @@ int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n
                        const int* active, hipStream_t s, int* nblk_out);
 int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, int n, const real* part1, real* part2,
                         int nblk, const real* beta, int beta_ld, int j, int nb0, const int* ids, const int* active,
-                        hipStream_t s);
+                        hipStream_t s, const real* svec);
 int launch_scale(cplx* x, long x_b0, long n, const real* scale, int nb0, const int* ids, const int* active, hipStream_t s);
 int launch_env_identity_check(const cplx* env, long b0, int c, int D, const int* chi, int chi_stride, real tol, int* flags, int nb0, const int* ids,
                               hipStream_t s);  // flags[0] / [1] raised when the first / last channel of env[c][D][c] is not the identity

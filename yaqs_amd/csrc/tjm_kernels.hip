@@ -186,26 +186,30 @@ __global__ __launch_bounds__(256) void dot_partial_kernel(const cplx* __restrict
 }
 
 // w -= alpha v_j + beta_{j-1} v_{j-1};  part2[b][blk] = sum |w|^2.  alpha = sum(part1[b][:]).
+// The stored vectors are unnormalised (KrylovState::svec): on entry w = H V[j], v_j = s_j V[j], v_{j-1} = s_{j-1} V[j-1] and part1
+// holds <V[j], H V[j]>, so alpha = s_j^2 sum(part1) and the new (unnormalised) vector is s_j (w - alpha V[j]) - beta_{j-1} s_{j-1} V[j-1].
 __global__ __launch_bounds__(256) void lanczos_axpy_kernel(cplx* __restrict__ w, const cplx* __restrict__ vj,
                                                           const cplx* __restrict__ vjm1, long v_b0, int n,
                                                           const real* part1, real* part2, int nblk,
                                                           const real* beta, int beta_ld, int j, const int* ids,
-                                                          const int* active) {
+                                                          const int* active, const real* __restrict__ svec) {
   __shared__ real sh[4];
   int b = blockIdx.y;
   if (ids) b = ids[b];
   if (active && active[b] == 0) return;
   real alpha = 0.0;
   for (int i = 0; i < nblk; ++i) alpha += part1[(long)b * nblk + i];
-  const real bprev = (j > 0) ? beta[(long)b * beta_ld + j - 1] : 0.0;
+  const real sj = svec[(long)b * beta_ld + j];
+  alpha *= sj * sj;
+  const real bprev = (j > 0) ? beta[(long)b * beta_ld + j - 1] * svec[(long)b * beta_ld + j - 1] : 0.0;
   cplx* wb = w + (long)b * v_b0;
   const cplx* vb = vj + (long)b * v_b0;
   const cplx* ub = vjm1 + (long)b * v_b0;
   real acc = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nblk * blockDim.x) {
     cplx x = wb[i], a = vb[i];
-    x.x = fma(-alpha, a.x, x.x);
-    x.y = fma(-alpha, a.y, x.y);
+    x.x = sj * fma(-alpha, a.x, x.x);
+    x.y = sj * fma(-alpha, a.y, x.y);
     if (j > 0) {
       cplx u = ub[i];
       x.x = fma(-bprev, u.x, x.x);
@@ -505,10 +509,12 @@ __global__ __launch_bounds__(64) void lanczos_init_kernel(KrylovState ks, const 
     ks.kfinal[b] = 1;
     ks.coef[(long)b * ks.mmax] = cplx{0.0, 0.0};
     ks.scale[b] = 0.0;
+    ks.svec[(long)b * ks.mmax] = 0.0;
   } else {
     ks.status[b] = 1;
     ks.kfinal[b] = 0;
     ks.scale[b] = 1.0 / nrm;
+    ks.svec[(long)b * ks.mmax] = 1.0 / nrm;
     atomicAdd(ks.n_active, 1);
   }
 }
@@ -530,6 +536,10 @@ __global__ __launch_bounds__(64) void lanczos_finalize_kernel(KrylovState ks, co
     s2 += part2[(long)b * nblk + i];
   }
   const real bj = sqrt(s2);
+  {
+    const real sj = ks.svec[(long)b * m + j];  // part1 holds <V[j], H V[j]> of the unnormalised vector
+    a *= sj * sj;
+  }
   if (lane == 0) {
     al[j] = a;
     if (j < m - 1) be[j] = bj;
@@ -559,6 +569,7 @@ __global__ __launch_bounds__(64) void lanczos_finalize_kernel(KrylovState ks, co
     }
   } else if (lane == 0) {
     ks.scale[b] = 1.0 / bj;
+    ks.svec[(long)b * m + j + 1] = 1.0 / bj;
     atomicAdd(ks.n_active, 1);
   }
 }
@@ -571,7 +582,11 @@ __global__ __launch_bounds__(256) void krylov_combine_kernel(const cplx* __restr
   int b = blockIdx.y;
   if (ids) b = ids[b];
   const int k = ks.kfinal[b];
-  if (threadIdx.x < k) sc[threadIdx.x] = ks.coef[(long)b * ks.mmax + threadIdx.x];
+  if (threadIdx.x < k) {  // the stored vectors are unnormalised: their scales go into the coefficients
+    cplx c = ks.coef[(long)b * ks.mmax + threadIdx.x];
+    const real sv = ks.svec[(long)b * ks.mmax + threadIdx.x];
+    sc[threadIdx.x] = cplx{c.x * sv, c.y * sv};
+  }
   __syncthreads();
   const cplx* Vb = V + (long)b * v_b0;
   cplx* ob = out + (long)b * out_b0;
@@ -616,9 +631,9 @@ int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n
 
 int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, int n, const real* part1, real* part2,
                         int nblk, const real* beta, int beta_ld, int j, int nb0, const int* ids, const int* active,
-                        hipStream_t s) {
+                        hipStream_t s, const real* svec) {
   hipLaunchKernelGGL(lanczos_axpy_kernel, dim3(nblk, nb0), dim3(256), 0, s, w, vj, vjm1, v_b0, n, part1, part2, nblk, beta,
-                     beta_ld, j, ids, active);
+                     beta_ld, j, ids, active, svec);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }

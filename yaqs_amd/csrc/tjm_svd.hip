@@ -2417,7 +2417,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     }
   }
 #endif
-  const size_t lds64 = 2 * lds16x + 16 * sizeof(real) + 16 * sizeof(int);
+  [[maybe_unused]] const size_t lds64 = 2 * lds16x + 16 * sizeof(real) + 16 * sizeof(int);
   g.rec = accumulate ? w.rec : nullptr;
   // in-block pairs folded into the tile visits (jacobi_cross16x_kernel): needs the 15 tournament rounds of a 16-column block inside
   // one sweep, and no rotation record (the W replay kernel knows the fixed column assignment only)
