@@ -126,6 +126,48 @@ def _slab_run(n_updates):
     return (time.perf_counter() - t0) / n_updates
 
 
+def cpu_allowance():
+    """What the host lease allows this process: CPUs in the affinity mask, os.cpu_count(), the cgroup CPU quota (v2 cpu.max or v1
+    cfs_quota_us / cfs_period_us) and the throttling counters of cpu.stat.  ``effective_cores`` = min(affinity, quota)."""
+    info = {"affinity_cpus": len(os.sched_getaffinity(0)), "os_cpu_count": os.cpu_count(), "cgroup_quota_cores": None, "quota_source": None}
+
+    def read(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    v2 = read("/sys/fs/cgroup/cpu.max")
+    if v2:
+        parts = v2.split()
+        info["quota_source"] = "/sys/fs/cgroup/cpu.max = " + v2
+        if parts and parts[0] != "max" and len(parts) > 1 and float(parts[1]) > 0:
+            info["cgroup_quota_cores"] = float(parts[0]) / float(parts[1])
+    else:
+        q, per = read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+        if q and per:
+            info["quota_source"] = f"cpu.cfs_quota_us = {q}, cpu.cfs_period_us = {per}"
+            if float(q) > 0 and float(per) > 0:
+                info["cgroup_quota_cores"] = float(q) / float(per)
+    eff = float(info["affinity_cpus"])
+    if info["cgroup_quota_cores"]:
+        eff = min(eff, info["cgroup_quota_cores"])
+    info["effective_cores"] = eff
+    return info
+
+
+def cpu_throttle_counters():
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            with open(path) as f:
+                kv = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            return {k: int(v) for k, v in kv.items() if k in ("nr_periods", "nr_throttled", "throttled_usec", "throttled_time")}
+        except (OSError, ValueError):
+            continue
+    return None
+
+
 def cpu_baseline(L, chi, tol, procs_list, workload="tfim", tdvp_mode="2site", dt=0.1):
     """The CPU oracle run the way the reference runs: P forked single-BLAS-thread workers, one trajectory each
     (core/parallel_utils.py:331-390).  Bounded sample.  Rows:
@@ -138,6 +180,8 @@ def cpu_baseline(L, chi, tol, procs_list, workload="tfim", tdvp_mode="2site", dt
     import multiprocessing as mp
 
     ncpu = len(os.sched_getaffinity(0))
+    allowance = cpu_allowance()
+    throttle0 = cpu_throttle_counters()
     ctx = mp.get_context("fork")
     rows = []
     t_all = time.perf_counter()
@@ -169,6 +213,18 @@ def cpu_baseline(L, chi, tol, procs_list, workload="tfim", tdvp_mode="2site", dt
         _SLAB.clear()
     best = max(rows, key=lambda r: r["value"])
     measured_best = max((r for r in rows if r["how"].startswith("full")), key=lambda r: r["value"])
+    throttle1 = cpu_throttle_counters()
+    allowance["cpu_stat_before"] = throttle0
+    allowance["cpu_stat_after"] = throttle1
+    if throttle0 and throttle1 and "nr_throttled" in throttle0:
+        allowance["nr_throttled_during_cpu_leg"] = throttle1["nr_throttled"] - throttle0["nr_throttled"]
+    # the reference's own default worker count: available_cpus() - 1 (core/parallel_utils.py:62-98, 216-220)
+    ref_default_workers = max(1, ncpu - 1)
+    ref_rows = [r for r in rows if r["cores"] >= min(ref_default_workers, ncpu) - 1 and r["cores"] <= ncpu]
+    ref_default_row = min(ref_rows, key=lambda r: abs(r["cores"] - ref_default_workers)) if ref_rows else None
+    quota = allowance.get("cgroup_quota_cores")
+    best_label = (f"best row under the lease's CPU allowance (cgroup quota ~ {quota:.1f} cores of {ncpu} in the affinity mask)" if quota and quota < ncpu
+                  else f"best row of the host ({ncpu} CPUs in the affinity mask, no cgroup quota below that)")
     return {
         "value": best["value"],
         "unit": "trajectories/sec",
@@ -179,6 +235,10 @@ def cpu_baseline(L, chi, tol, procs_list, workload="tfim", tdvp_mode="2site", dt
                   f"trajectory; plus a 3-site-update slab sample at P up to all {ncpu} cores giving the contention slow-down; "
                   f"value = best whole-host row ({best['how']}); CPU leg took {time.perf_counter() - t_all:.0f} s",
         "host_cores": ncpu,
+        "cpu_allowance": allowance,
+        "best_row_is": best_label,
+        "reference_default_workers": ref_default_workers,
+        "reference_default_row": ({k: ref_default_row[k] for k in ("cores", "value", "seconds_per_step", "how")} if ref_default_row else None),
         "per_core_value": rows[0]["value"],  # one worker with the host to itself
         "best_measured_full_step": {k: measured_best[k] for k in ("cores", "value", "seconds_per_step")},
         "rows": rows,
@@ -381,6 +441,7 @@ def main():
             self.zsum = np.zeros(L)
             self.err = None
             self.step_s = []  # wall seconds of every timed step of this engine
+            self.warm_s = []  # ... and of the warm-up steps before them
 
         def step(self):
             e, ar = self.eng, np.arange(self.nb)
@@ -395,8 +456,8 @@ def main():
                 for k in range(n):
                     t_step = time.perf_counter()
                     self.step()
-                    if measure:  # stochastic() has read the jump decisions back: the step's work on this stream is done
-                        self.step_s.append(time.perf_counter() - t_step)
+                    # stochastic() has read the jump decisions back: the step's work on this stream is done
+                    (self.step_s if measure else self.warm_s).append(time.perf_counter() - t_step)
                     if measure and ((k + 1) % STEPS_PER_TRAJ == 0 or k == n - 1):
                         M = self.eng.site_moments()
                         self.zsum += np.einsum("lb->l", (M[:, :, 0, 0] - M[:, :, 1, 1]).real)
@@ -457,6 +518,33 @@ def main():
     lib.tjm_svd_work_read(jw.ctypes.data, 0)
     lib.tjm_svd_mixed_read(mx.ctypes.data, 0)
 
+    # ---- ONE engine alone on the device for one more step, EVERY launch of the dominant kernel bracketed by HIP events: the launch
+    # duration the roofline fraction is formed from is a measurement of the kernel by itself, not a time slice of four overlapping
+    # streams times an attribution factor.  The other engines idle; their states are not used again.
+    iso = None
+    if E > 1 or True:
+        jw_i, mx_i = np.zeros(4), np.zeros(10)
+        lib.tjm_svd_work_read(jw_i.ctypes.data, 1)
+        lib.tjm_svd_mixed_read(mx_i.ctypes.data, 1)
+        lib.tjm_profile_cross_kernel(1)
+        torch.cuda.synchronize()
+        t_i = time.perf_counter()
+        drives[0].run(1, False)
+        torch.cuda.synchronize()
+        t_i = time.perf_counter() - t_i
+        if drives[0].err is not None:
+            raise drives[0].err
+        ms_i, nb_i, ns_i = C.c_double(0), C.c_double(0), C.c_int64(0)
+        lib.tjm_profile_cross_kernel_read(C.byref(ms_i), C.byref(nb_i), C.byref(ns_i))
+        ms32_i, nb32_i, ns32_i = C.c_double(0), C.c_double(0), C.c_int64(0)
+        lib.tjm_profile_cross_kernel_read_c64(C.byref(ms32_i), C.byref(nb32_i), C.byref(ns32_i))
+        lib.tjm_profile_cross_kernel(0)
+        lib.tjm_svd_work_read(jw_i.ctypes.data, 0)
+        lib.tjm_svd_mixed_read(mx_i.ctypes.data, 0)
+        iso = {"step_s": t_i, "trajectories": drives[0].nb,
+               "f64": {"ms": ms_i.value, "samples": int(ns_i.value), "bytes": nb_i.value, "flops": 28.0 * float(jw_i[0])},
+               "c64": {"ms": ms32_i.value, "samples": int(ns32_i.value), "bytes": nb32_i.value, "flops": 28.0 * float(mx_i[6])}}
+
     if rank == 0:
         total_traj = B * world
         value = total_traj * K / STEPS_PER_TRAJ / elapsed
@@ -510,8 +598,10 @@ def main():
         k64 = {"ms": ms.value, "samples": int(ns.value), "bytes": nbytes.value, "flops": flops_jac64, "peak": peak, "bound": valu_bound,
                "name": "jacobi_cross16x_kernel" + (" (complex64 build)" if f32 else " (fp64)")}
         k32 = {"ms": ms32.value, "samples": int(ns32.value), "bytes": nb32.value, "flops": flops_jac32, "peak": peak32, "bound": "fp32-valu",
-               "name": "tjm32::jacobi_cross16q_kernel (complex64 phase of the mixed-precision two-site split; four columns of each block per wavefront)"}
+               "name": "tjm32::jacobi_quad64_kernel (complex64 phase of the mixed-precision two-site split: four 16-column blocks per workgroup, three "
+                       "tournament rounds per load; tjm32::jacobi_cross16q_kernel - one round per load - for sizes other than 256 columns)"}
         dom = k32 if k32["ms"] > k64["ms"] else k64
+        k64["iso"], k32["iso"] = (iso["f64"], iso["c64"]) if iso else (None, None)
 
         def kernel_line(kk):
             if not kk["samples"]:
@@ -524,9 +614,22 @@ def main():
             raw = kk["flops"] / 1e12 / (launches * avg_us / 1e6) if kk["flops"] else None
             rate = raw * overlap if raw else None
             gbs = (kk["bytes"] / 1e9) / (kk["ms"] / 1e3) * overlap
-            return {"name": kk["name"], "bound": kk["bound"], "avg_launch_us": avg_us, "launches_sampled": kk["samples"],
-                    "executed_TFLOPs": rate, "executed_TFLOPs_per_launch_duration_uncorrected": raw, "peak_TFLOPs": kk["peak"],
-                    "frac": frac(rate, kk["peak"]), "tile_bytes_GBps": gbs, "tile_bytes_frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+            line = {"name": kk["name"], "bound": kk["bound"], "avg_launch_us_overlapped": avg_us, "launches_sampled_overlapped": kk["samples"],
+                    "executed_TFLOPs_overlapped_x_stream_overlap": rate, "executed_TFLOPs_per_launch_duration_overlapped": raw, "peak_TFLOPs": kk["peak"],
+                    "frac_overlapped": frac(raw, kk["peak"]), "frac_overlapped_x_stream_overlap": frac(rate, kk["peak"])}
+            io = kk.get("iso")
+            if io and io["samples"] and io["flops"]:
+                # the measurement: one engine alone on the device, every launch bracketed - flops of all launches / their summed duration
+                tfl = io["flops"] / 1e12 / (io["ms"] / 1e3)
+                gbs_i = io["bytes"] / 1e9 / (io["ms"] / 1e3)
+                ai = io["flops"] / io["bytes"] if io["bytes"] else None
+                ridge = kk["peak"] * 1e12 / (HBM_PEAK_GBS * 1e9)
+                line.update({"avg_launch_us": 1e3 * io["ms"] / io["samples"], "launches": io["samples"], "flops_per_launch": io["flops"] / io["samples"],
+                             "bytes_per_launch": io["bytes"] / io["samples"], "executed_TFLOPs": tfl, "frac_of_vector_peak": tfl / kk["peak"],
+                             "tile_bytes_GBps": gbs_i, "frac_of_hbm_peak": gbs_i / HBM_PEAK_GBS, "flop_per_byte": ai, "ridge_flop_per_byte": ridge,
+                             "bound_by_arithmetic_intensity": ("hbm" if (ai is not None and ai < ridge) else kk["bound"]),
+                             "frac": max(tfl / kk["peak"], gbs_i / HBM_PEAK_GBS)})
+            return line
 
         dom_line = kernel_line(dom)
         traffic, traffic_src = pmc_traffic(L, chi, sizes[0], "tjm32" if dom is k32 else "tjm::")
@@ -534,6 +637,8 @@ def main():
         svd_exec_tf = tf(flops_jac64 + flops_jac32 + flops_mixgemm, cls_ms["svd"])
         kry_exec_tf = tf(flops_kry_exec, cls_ms["krylov"])
         step_wall = [max(d.step_s[k] for d in drives) for k in range(K)] if all(len(d.step_s) == K for d in drives) else []
+        all_steps = [max((d.warm_s + d.step_s)[k] for d in drives) for k in range(W + K)] if all(len(d.warm_s) + len(d.step_s) >= W + K for d in drives) else []
+        first_ten_rate = (total_traj * 10.0 / STEPS_PER_TRAJ / sum(all_steps[:10])) if len(all_steps) >= 10 else None
         out = {
             "metric": "trajectories/sec",
             "value": value,
@@ -556,6 +661,9 @@ def main():
                 "steps_per_trajectory": STEPS_PER_TRAJ,
                 "parallelism": f"trajectory-sharded x{world}" + (" (gloo: ranks share the visible GPUs - functional check, not a scaling number)" if gloo and world > 1 else ""),
                 "storage": args.dtype,
+                "arithmetic": ("fp64 results: every output of the two-site split is produced by fp64 arithmetic behind per-trajectory certificates "
+                               "(complex64-preconditioned: the starting basis of the split comes from a complex64 Jacobi iteration; "
+                               "Krylov, environments and centre shifts are fp64 throughout)") if args.dtype == "complex128" else "complex64 / fp32 throughout",
             },
             "site_updates_per_sec": site_updates,
             # batched calls per step and engine (every engine makes the same calls); svd_matrices counts trajectories: whole GPU
@@ -565,22 +673,38 @@ def main():
             "certified_fraction_of_trajectory_steps": {"dissipations": cnt.get("certified_dissipations", 0) / max(1, total_traj * K // world),
                                                       "note": "tests/test_hip_fullsize.py pins this path against the reference at full size (ten consecutive steps)"},
             "step_wall_seconds": {"first": step_wall[0], "last": step_wall[-1], "all": step_wall} if step_wall else None,
+            # a trajectory as SURVEY 8d defines it: ten steps from the stated (Haar) initial state - steps 1 - 10 of this run, warm-up
+            # steps included (slowest engine of every step); null when the run has fewer than ten steps
+            "value_steps_1_to_10_from_the_initial_state": first_ten_rate,
             "mean_Z_site0": float(zsum[0] / total_traj),
             # ---- roofline of the dominant kernel, EXECUTED work: flops counted on the device / (launches x sampled launch duration)
             "roofline": {
-                "bound": dom["bound"],
+                "bound": (dom_line or {}).get("bound_by_arithmetic_intensity", dom["bound"]),
                 "kernel": dom["name"],
-                "achieved": dom_line["executed_TFLOPs"] if dom_line else None,
+                "achieved": (dom_line or {}).get("executed_TFLOPs"),
                 "peak": dom["peak"],
                 "unit": "TFLOP/s",
-                "frac": dom_line["frac"] if dom_line else None,
-                "how": "achieved = 28 real flops x rows x column pairs of every visited 32-column tile (device counter; a visited tile executes all "
-                       "its 256 + 16 rotation slots, identity rotations included) / (8 x sampled launches x their average duration, HIP events on "
-                       "the launch stream) x stream_overlap - the launches of the E engines share the device, so a launch's duration is E-fold "
-                       "time-sliced; kernels.*.executed_TFLOPs_per_launch_duration_uncorrected is the same without that factor; peak = the "
-                       "vector rate of the kernel's arithmetic",
-                "avg_launch_us": dom_line["avg_launch_us"] if dom_line else None,
-                "algorithmic_bytes_per_launch": alg_bytes_per_launch,  # every visited tile read and written once
+                "frac": (dom_line or {}).get("frac"),
+                "frac_overlapped": (dom_line or {}).get("frac_overlapped"),
+                "how": "MEASURED ALONE: after the timed region one engine runs one more step with the device to itself and EVERY launch of the kernel "
+                       "bracketed by HIP events on its stream; achieved = executed flops of those launches (28 real flops x rows x column pairs "
+                       "of every visited tile, counted on the device; a visited tile executes all its rotation slots, identity rotations included) / "
+                       "their summed duration; avg_launch_us is that duration per launch - the figure `rocprofv3 --kernel-trace --stats` of a "
+                       "one-engine run reports for the same kernel (profiles/r05/iso_*.csv).  bound: by arithmetic intensity (flops / tile bytes "
+                       "against peak / 8 TB/s); frac = the larger of the vector-peak and HBM-peak fractions.  frac_overlapped: the same ratio from "
+                       "the launches sampled INSIDE the timed region, where four engines' kernels share the device (no correction factor)",
+                "avg_launch_us": (dom_line or {}).get("avg_launch_us"),
+                "flops_per_launch": (dom_line or {}).get("flops_per_launch"),
+                "frac_of_vector_peak": (dom_line or {}).get("frac_of_vector_peak"),
+                "frac_of_hbm_peak": (dom_line or {}).get("frac_of_hbm_peak"),
+                "flop_per_byte": (dom_line or {}).get("flop_per_byte"),
+                "isolated_step_seconds": iso["step_s"] if iso else None,
+                "algorithmic_bytes_per_launch": (dom_line or {}).get("bytes_per_launch") or alg_bytes_per_launch,  # every visited quad of blocks read and written once
+                # minimum HBM traffic of a whole site-update 16 (4 d chi^2 + 3 D chi^2) bytes; of it the split: theta in, two site tensors out
+                "algorithmic_bytes_per_site_update_survey_8d": 16.0 * (4 * d_ * chi ** 2 + 3 * D * chi ** 2),
+                "algorithmic_bytes_per_split": 16.0 * (d_ ** 2 * chi ** 2 + 2 * d_ * chi ** 2),
+                "kernel_bytes_per_split_and_trajectory": ((dom_line or {}).get("bytes_per_launch", 0.0) / max(1, sizes[0])) * (5.0 if chi == 128 else 15.0)
+                                                         * ((mx[1] / mx[0]) if mx[0] else 0.0) if dom is k32 else None,
                 "traffic": traffic,
                 "traffic_over_algorithmic_bytes": (traffic / alg_bytes_per_launch) if (traffic and alg_bytes_per_launch) else None,
                 "traffic_source": traffic_src,
@@ -611,6 +735,7 @@ def main():
                     "krylov": {"bound": mfma_bound, "stream_ms": stream_ms["krylov"], "wall_share_ms": cls_ms["krylov"],
                                "share_of_stream_time": cls_ms["krylov"] / 1e3 / busy if busy else None,
                                "achieved_TFLOPs": kry_exec_tf, "frac": min(1.0, kry_exec_tf / peak) if kry_exec_tf else None,
+                               "frac_uncapped": (kry_exec_tf / peak) if kry_exec_tf else None,
                                "nominal_TFLOPs": tf(flops_kry_nominal, cls_ms["krylov"]),
                                "note": "H_eff applies (2 MFMA GEMMs + MPO stage) with the Lanczos vector kernels (HBM-bound) inside the region; achieved = "
                                        "EXECUTED flops (the GEMM blocks of the environments' certified identity channels are not computed; 6 real flops "
@@ -632,7 +757,11 @@ def main():
         if cpu_ref is not None:
             out["cpu_baseline"] = cpu_ref
             full = [r for r in cpu_ref.get("rows", []) if r.get("cores") == cpu_ref.get("host_cores")]
+            refdef = cpu_ref.get("reference_default_row")
+            strict = min(value / cpu_ref["best_measured_full_step"]["value"], (value / refdef["value"]) if refdef and refdef.get("value") else float("inf"))
             out["speedup_vs_cpu"] = {
+                "stricter_of_best_measured_row_and_reference_default_row": strict,
+                "vs_reference_default_workers_row": (value / refdef["value"]) if refdef and refdef.get("value") else None,  # available_cpus() - 1 workers (parallel_utils.py:62-98)
                 "vs_best_measured_whole_host_row": value / cpu_ref["best_measured_full_step"]["value"],  # the ratio north_star's 50 x is read against
                 "vs_best_whole_host_row_incl_extrapolated": value / cpu_ref["value"],
                 "vs_one_core": value / cpu_ref["per_core_value"],

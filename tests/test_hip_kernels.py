@@ -147,8 +147,14 @@ def test_tridiag_expm_matches_dense(lib, k, dt, scale):
     assert np.allclose(got, ref, atol=5e-13)
 
 
-def svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, min_keep, chiL, chiR, qr=False, want_spec=True):
+def svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, min_keep, chiL, chiR, qr=False, want_spec=True, stream=None):
     from yaqs_amd._lib import check
+
+    if stream is not None:  # the whole call - allocations, uploads, the split, the read-back - on the caller's HIP stream
+        with torch.cuda.stream(stream):
+            out = svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, min_keep, chiL, chiR, qr, want_spec, None)
+            stream.synchronize()
+        return out
 
     B = theta.shape[0]
     th = dev(theta)
@@ -161,8 +167,9 @@ def svd_split_gpu(lib, theta, d, capL, capR, capM, dist, mode, thr, max_bond, mi
     fn = lib.tjm_svd_split_qr if qr else lib.tjm_svd_split
     work = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
     sweeps = C.c_int32(0)
+    cur = None if SIM else C.c_void_p(torch.cuda.current_stream().cuda_stream)  # (the default stream unless a caller's stream is current)
     check(fn(th.data_ptr(), B, d, capL, capR, capM, left.data_ptr(), right.data_ptr(), dist, mode, thr, max_bond, min_keep,
-                            chi.data_ptr(), spec.data_ptr() if want_spec else None, spec_ld, work.data_ptr(), nbytes, C.byref(sweeps), None), "svd_split")
+                            chi.data_ptr(), spec.data_ptr() if want_spec else None, spec_ld, work.data_ptr(), nbytes, C.byref(sweeps), cur), "svd_split")
     _sync()
     return left.cpu().numpy(), right.cpu().numpy(), chi.cpu().numpy()[:, 2], spec.cpu().numpy(), sweeps.value
 
@@ -917,3 +924,47 @@ def _run_engine_mode_loose(lib, n):
         _check_engine_mode_split(theta, left, right, keep, d, cap, dist, [1e-10, 5e-11, 5e-11, 5e-11], tol_iso=2e-13, tol_resid=5e-11)
     lib.tjm_svd_mixed_read(out, 0)
     return [int(round(out[i])) for i in range(6)] + [out[8]]
+
+
+@pytest.mark.skipif(SIM, reason="two host threads on two HIP streams")
+def test_svd_split_is_reentrant_across_host_threads_and_streams(lib):
+    """'one HIP stream per call; re-entrant per device'.  Two host threads run 256 x 256 splits (the mixed path: five host
+    round trips per call, each through a pinned flag block) on two streams at the same time, several times over; every result is
+    bit-identical to the serial one.  (Until round 4 all calls shared one process-global pinned block.)"""
+    import threading
+
+    d, cap = 2, 128
+    n = d * cap
+    jobs = []
+    for seed in (11, 12):
+        rng = np.random.default_rng(seed)
+        u = np.linalg.qr(crand(rng, n, n))[0]
+        v = np.linalg.qr(crand(rng, n, n))[0]
+        evolved = (u * np.exp(-np.arange(n) * (12.0 + seed) / n)) @ v.conj().T
+        jobs.append(np.stack([crand(rng, n, n) / n, evolved, crand(rng, n, n) / n, evolved.conj().T]))
+    chi = np.full(4, cap, dtype=np.int32)
+
+    def run(theta, stream=None):
+        return svd_split_gpu(lib, theta, d, cap, cap, cap, 0, 0, 1e-12, cap, 2, chi, chi, qr=True, want_spec=False, stream=stream)
+
+    serial = [run(t) for t in jobs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rep in range(4):
+        got, errs = [None, None], []
+
+        def work(k):
+            try:
+                torch.cuda.set_device(0)
+                got[k] = run(jobs[k], streams[k])
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        for k in range(2):
+            for a, b in zip(serial[k][:3], got[k][:3]):
+                assert np.array_equal(a, b), (rep, k)

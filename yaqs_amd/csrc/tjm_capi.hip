@@ -1,5 +1,7 @@
 // extern "C" surface of libtjm_hip.so (declared in include/tjm_hip.h).
 #include <cstring>
+#include <mutex>
+#include <vector>
 #include <new>
 
 #include "../../include/tjm_hip.h"
@@ -402,6 +404,27 @@ int tjm_zgemm_batched(const tjm_gemm_desc* t, void* stream) {
 
 size_t tjm_svd_workspace_bytes(int32_t max_dim, int32_t B) { return svd_workspace_bytes(max_dim, B) + (size_t)B * 64 + 4096; }
 
+namespace {
+std::mutex g_pin_mutex;
+std::vector<int*> g_pin_free;  // pinned blocks of 256 bytes, never released (a handful per process)
+struct PinnedLease {
+  int* p = nullptr;
+  int acquire() {
+    {
+      std::lock_guard<std::mutex> lock(g_pin_mutex);
+      if (!g_pin_free.empty()) { p = g_pin_free.back(); g_pin_free.pop_back(); return TJM_OK; }
+    }
+    TJM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&p), 256, hipHostMallocDefault));
+    return TJM_OK;
+  }
+  ~PinnedLease() {
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    g_pin_free.push_back(p);
+  }
+};
+}  // namespace
+
 static int svd_split_impl(bool use_qr, const void* theta, int32_t B, int32_t d, int32_t capL, int32_t capR, int32_t capM, void* left, void* right,
                           int32_t distribution, int32_t trunc_mode, double threshold, int32_t max_bond, int32_t min_keep, int32_t* chi_lrm,
                           double* spectrum, int32_t spec_ld, void* work, size_t work_bytes, int32_t* sweeps_out, void* stream_) {
@@ -419,9 +442,11 @@ static int svd_split_impl(bool use_qr, const void* theta, int32_t B, int32_t d, 
     char* sbase = take(svd_workspace_bytes(mx, B));
     svd_carve(sw, sbase, mx, B);
   }
-  static int* pinned = nullptr;
-  if (!pinned) TJM_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&pinned), 256, hipHostMallocDefault));
-  sw.h_pinned = pinned;
+  // the convergence flags of a call travel through pinned host words: one block per CALL (leased from a pool for its duration), so
+  // that calls from several host threads on their own streams do not read each other's flags (re-entrant per device)
+  PinnedLease lease;
+  if (lease.acquire() != TJM_OK) return TJM_ERR_HIP;
+  sw.h_pinned = lease.p;
   QrWorkspace qw;
   std::memset(&qw, 0, sizeof(qw));
   MixedWorkspace mw;
