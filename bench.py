@@ -168,7 +168,7 @@ def cpu_throttle_counters():
     return None
 
 
-def cpu_baseline(L, chi, tol, procs_list, workload="tfim", tdvp_mode="2site", dt=0.1):
+def cpu_baseline(L, chi, tol, procs_list, workload="tfim", tdvp_mode="2site", dt=0.1, full_steps=True):
     """The CPU oracle run the way the reference runs: P forked single-BLAS-thread workers, one trajectory each
     (core/parallel_utils.py:331-390).  Bounded sample.  Rows:
       * P = 1 and every P of ``procs_list`` that fits the time budget: ONE full order-1 TJM step per worker (slowest worker counts),
@@ -186,10 +186,19 @@ def cpu_baseline(L, chi, tol, procs_list, workload="tfim", tdvp_mode="2site", dt
     rows = []
     t_all = time.perf_counter()
     # --- uncontended: one worker, the whole step
-    t1 = _cpu_step((L, chi, tol, 0, workload, tdvp_mode, dt))
-    rows.append({"cores": 1, "value": 1.0 / (STEPS_PER_TRAJ * t1), "seconds_per_step": t1, "how": "full step, one worker alone on the host"})
+    if full_steps:
+        t1 = _cpu_step((L, chi, tol, 0, workload, tdvp_mode, dt))
+        rows.append({"cores": 1, "value": 1.0 / (STEPS_PER_TRAJ * t1), "seconds_per_step": t1, "how": "full step, one worker alone on the host"})
+    else:
+        # a full step of this configuration takes minutes on a core (chi = 256: 174 s measured in round 1): the bounded sample is the
+        # slab - 3 bulk two-site updates at the chain centre - times the 2 (L - 1) updates of the two TDVP sweeps of a step.  The
+        # dissipation and jump sweeps are NOT included: the CPU row is an UPPER bound of the CPU rate (the stricter direction).
+        _slab_prepare(L, chi, tol, workload, dt)
+        t1 = _slab_run(3) * 2 * (L - 1)
+        rows.append({"cores": 1, "value": 1.0 / (STEPS_PER_TRAJ * t1), "seconds_per_step": t1,
+                     "how": "full-step ESTIMATE, one worker alone: slab sample (3 bulk site-updates) x 2 (L - 1) updates per step, TDVP sweeps only (upper bound of the CPU rate)"})
     # --- full step with P workers side by side
-    for P in procs_list:
+    for P in (procs_list if full_steps else []):
         P = min(P, ncpu)
         if P <= 1 or any(r["cores"] == P and r["how"].startswith("full") for r in rows):
             continue
@@ -212,7 +221,7 @@ def cpu_baseline(L, chi, tol, procs_list, workload="tfim", tdvp_mode="2site", dt
                          "how": f"extrapolated: uncontended full step x slow-down of the 3-site-update slab sample at {P} workers"})
         _SLAB.clear()
     best = max(rows, key=lambda r: r["value"])
-    measured_best = max((r for r in rows if r["how"].startswith("full")), key=lambda r: r["value"])
+    measured_best = max((r for r in rows if r["how"].startswith("full")), key=lambda r: r["value"])  # ("full-step ESTIMATE" when full_steps is off)
     throttle1 = cpu_throttle_counters()
     allowance["cpu_stat_before"] = throttle0
     allowance["cpu_stat_after"] = throttle1
@@ -251,7 +260,7 @@ def pmc_traffic(L, chi, B, kernel_tag):
     FETCH_SIZE and WRITE_SIZE runs of this script, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters
     cannot be read from inside the timed run: the number comes from a profile, is only reported for the configuration and the kernel
     (``kernel_tag``: "tjm32" = the complex64 instance, "tjm::" = the fp64 one) it was collected on, and the source says so."""
-    for name in ("r04_pmc_traffic_c64q.json", "r04_pmc_traffic_c64.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic_quad64.json", "r04_pmc_traffic_c64q.json", "r04_pmc_traffic_c64.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
@@ -335,8 +344,157 @@ def launch_ranks(n, argv, script=None, poll=0.2):
     return max(abs(rc) for rc in rcs)
 
 
+# One flag per row of BASELINE.json's `configs` (1-based): the arithmetic BASELINE quotes the row in, the largest shard one MI355X holds.
+# Config 2 is the headline (the defaults).  Config 5 is the circuit path (run_config5).
+CONFIG_PRESETS = {
+    3: dict(workload="xxz", chi=256, length=128, dt=0.05, dtype="complex64", trajectories=128, batch=128, steps=2, warmup=1),
+    4: dict(workload="lr-ising", tdvp_mode="1site", chi=256, length=32, dt=0.05, trajectories=512, batch=512, steps=3, warmup=1, cpu_procs=[8]),
+}
+
+
+def run_config5(args):
+    """BASELINE config 5: 64-site Trotter circuit (20 Ising layers = 1260 two-qubit gates), depolarising noise gamma = 0.001 after every
+    gate on its sites, max_bond_dim 512, svd_threshold 1e-9, 8192 trajectories, complex64 (BASELINE quotes it in fp32) - through
+    Simulator.run_circuit, the front end a user calls.  From |0...0> the bonds of this circuit stay below 8 (the cap of 512 is never
+    approached): the line times the fused small-bond kernels.  --saturated: the regime the chi = 512 names - a Haar-saturated chi = 512
+    input (268 MB per MPS in complex64), one wave of --trajectories (default 96), --layers Trotter layers (default 1): every gate is a 1024 x 1024 split
+    (digital_tjm.py:455-533).  A 'step' is one Trotter layer."""
+    import torch  # noqa: F401
+
+    import yaqs_amd.tjm as tjm
+    from yaqs_amd import _lib
+    from yaqs_amd.api import DigitalSimParams, MPS, NoiseModel, Observable, Z, ising_trotter_layers
+
+    L, sat = 64, bool(args.saturated)
+    nlayers = args.layers if args.layers else (1 if sat else 20)
+    ntraj = args.trajectories if args.trajectories != 1024 else (96 if sat else 8192)
+    dtype = args.dtype if args.dtype_given else "complex64"
+    layers = ising_trotter_layers(L, 1.0, 0.5, 0.1, nlayers)
+    gates = sum(len(l.even) + len(l.odd) for l in layers)
+    noise = NoiseModel([{"name": name, "sites": [i], "strength": 0.001} for i in range(L) for name in ("pauli_x", "pauli_y", "pauli_z")])
+    p = DigitalSimParams(observables=[Observable(Z(), s) for s in range(L)], num_traj=ntraj, max_bond_dim=512, svd_threshold=1e-9, random_seed=42)
+    if sat:
+        st = MPS(L, state="haar-random", pad=512, rng=np.random.default_rng(1))
+        st.normalize("B")
+    else:
+        st = MPS(L, state="zeros")
+    lib = _lib.load(dtype)
+    sim = tjm.Simulator(dtype=dtype, batch=(ntraj if sat else None))
+    if not sat:  # warm-up: library load, first-touch allocations
+        tjm.Simulator(dtype=dtype).run_circuit(MPS(L, state="zeros"), ising_trotter_layers(L, 1.0, 0.5, 0.1, 1),
+                                               DigitalSimParams(observables=[Observable(Z(), 0)], num_traj=64, max_bond_dim=512, svd_threshold=1e-9, random_seed=1), noise)
+    jw = np.zeros(4)
+    lib.tjm_profile_cross_kernel(8 if sat else 0)
+    lib.tjm_svd_work_read(jw.ctypes.data, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = sim.run_circuit(st, layers, p, noise)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms, nbytes, ns = C.c_double(0), C.c_double(0), C.c_int64(0)
+    lib.tjm_profile_cross_kernel_read(C.byref(ms), C.byref(nbytes), C.byref(ns))
+    lib.tjm_profile_cross_kernel(0)
+    lib.tjm_svd_work_read(jw.ctypes.data, 0)
+    max_bond = int(np.max(res.max_bond))
+    f32 = dtype != "complex128"
+    esz = 8 if f32 else 16
+    peak = 2 * FP64_PEAK_TFLOPS if f32 else FP64_PEAK_TFLOPS
+    if sat and ns.value:
+        tfl = 28.0 * float(jw[0]) / 1e12 / (8.0 * ms.value / 1e3)
+        roof = {"bound": "fp32-valu" if f32 else "fp64-valu", "kernel": "jacobi_cross16x_kernel (X-only tiled Jacobi of the 1024 x 1024 split, large-bond path svd_split_qr2)",
+                "achieved": tfl, "peak": peak, "unit": "TFLOP/s", "frac": tfl / peak, "avg_launch_us": 1e3 * ms.value / ns.value,
+                "how": "28 real flops x rows x column pairs of every visited tile (device counter) / (8 x sampled launches x average duration, HIP events); one engine",
+                "traffic": None}
+    else:
+        # small bonds: launch- / latency-bound fused kernels; the HBM figure is the algorithmic traffic of the gate updates (two site tensors
+        # read and written per noisy gate at the largest bond met) over the wall time - far below any bandwidth bound by construction
+        gbs = ntraj * gates * 2.0 * 2 * (2 * max_bond * max_bond * esz) / 1e9 / el
+        roof = {"bound": "latency (launch-bound fused small-bond kernels: bonds <= %d)" % max_bond, "kernel": "small_sweep_kernel / svd_split_small_kernel",
+                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                "how": "algorithmic bytes of the gate updates (two site tensors read + written per noisy gate, at the largest bond of the run) / wall time"}
+    return {"metric": "trajectories/sec", "value": ntraj / el, "unit": "trajectories/sec", "n_gpus": 1, "steps": nlayers, "warmup": 0 if sat else 1,
+            "ms_per_step": 1e3 * el / nlayers, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if f32 else "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 5{' (chi-saturated variant)' if sat else ''}: {L}-site Ising Trotter circuit, {nlayers} layers ({gates} two-qubit gates), "
+                                   f"depolarising gamma=0.001 per gate and site, max_bond_dim=512, svd_threshold=1e-9, initial state "
+                                   f"{'Haar chi=512 saturated' if sat else '|0...0>'}", "trajectories": ntraj, "storage": dtype, "largest_bond_met": max_bond,
+                       "parallelism": "one MI355X"},
+            "gate_updates_per_sec": ntraj * gates / el, "seconds": el, "roofline": roof}
+
+
+def cpu_config5(saturated, nlayers):
+    """Oracle digital_tjm on host cores, bounded: small bonds - 4 forked workers, one whole trajectory each; saturated - the first gates
+    of one layer on one worker (a 1024 x 1024 zgesdd per gate), extrapolated per gate."""
+    import multiprocessing as mp
+
+    from oracle import tjm_oracle as o
+    from yaqs_amd import api
+
+    L = 64
+    t_all = time.perf_counter()
+    on = [o.make_process(name, [i], 0.001) for i in range(L) for name in ("pauli_x", "pauli_y", "pauli_z")]
+    op = o.DigitalParams(observables=[o.Obs(o.PAULI["z"], s) for s in range(L)], max_bond_dim=512, svd_threshold=1e-9, random_seed=42)
+    if not saturated:
+        layers = [o.GateLayer(l.singles, l.even, l.odd, l.sample_points) for l in api.ising_trotter_layers(L, 1.0, 0.5, 0.1, nlayers)]
+        global _C5
+        _C5 = (on, op, layers)
+        with mp.get_context("fork").Pool(4) as pool:
+            per = pool.map(_c5_one, range(4), chunksize=1)
+        return {"value": 4.0 / max(per), "unit": "trajectories/sec", "cores": 4, "kind": "port", "per_core_value": 1.0 / (sum(per) / 4),
+                "sample": f"oracle digital_tjm, 4 forked single-BLAS-thread workers, one whole trajectory each ({nlayers} layers); slowest {max(per):.1f} s; "
+                          f"CPU leg {time.perf_counter() - t_all:.0f} s", "cpu_allowance": cpu_allowance()}
+    # One noisy gate of the oracle at the saturated chain centre takes 180.5 s on one core (measured once in the build container with
+    # `TJM_CFG5_CPU_FULL=1 python bench.py --config 5 --saturated`: three gates, 571 s; every gate is a 1024 x 1024 zgesdd plus the
+    # SVD / QR sweeps of its local noise over the chain) - too long for a bounded sample.  On the box the sample is ONE 1024 x 1024
+    # zgesdd; the per-gate figure is scaled by its time against the 1.32 s the same call took where the 180.5 s were measured.
+    import scipy.linalg
+
+    full = api.ising_trotter_layers(L, 1.0, 0.5, 0.1, 1)[0]
+    gates = (len(full.even) + len(full.odd)) * nlayers
+    if os.environ.get("TJM_CFG5_CPU_FULL"):
+        st = api.MPS(L, state="haar-random", pad=512, rng=np.random.default_rng(1))
+        st.normalize("B")
+        mid = [g for g in full.even if 28 <= g[0] <= 34][:3]
+        lay = [o.GateLayer([], mid, [], full.sample_points)]
+        s0 = o.MPSState([np.asarray(t, dtype=np.complex128) for t in st.tensors])
+        t0 = time.perf_counter()
+        o.digital_tjm(0, s0, on, op, lay)
+        per_gate = (time.perf_counter() - t0) / max(1, len(mid))
+        how = f"oracle digital_tjm on ONE worker: {len(mid)} noisy gates at the saturated chain centre, {per_gate:.1f} s per gate (measured here)"
+    else:
+        rng = np.random.default_rng(0)
+        a = rng.standard_normal((1024, 1024)) + 1j * rng.standard_normal((1024, 1024))
+        scipy.linalg.svd(a[:256, :256], lapack_driver="gesdd")  # (first call: library load)
+        t0 = time.perf_counter()
+        scipy.linalg.svd(a, full_matrices=False, lapack_driver="gesdd")
+        t_svd = time.perf_counter() - t0
+        per_gate = 180.5 * t_svd / 1.32
+        how = (f"ESTIMATE: one 1024 x 1024 zgesdd on this host ({t_svd:.2f} s) x the oracle's measured cost of a noisy gate at the saturated chain centre in "
+               f"units of that call (180.5 s per gate at 1.32 s per zgesdd, one core, build container; TJM_CFG5_CPU_FULL=1 measures it here: ~10 minutes)")
+    return {"value": 1.0 / (per_gate * gates), "unit": "trajectories/sec", "cores": 1, "kind": "port", "per_core_value": 1.0 / (per_gate * gates),
+            "sample": how + f", extrapolated to the {gates} gates of the run (edge gates are cheaper: an upper bound of the CPU time per trajectory); "
+                            f"CPU leg {time.perf_counter() - t_all:.0f} s", "cpu_allowance": cpu_allowance()}
+
+
+_C5 = None
+
+
+def _c5_one(t):
+    from oracle import tjm_oracle as o
+
+    on, op, layers = _C5
+    t0 = time.perf_counter()
+    o.digital_tjm(t, o.MPSState.product(64, "zeros"), on, op, layers)
+    return time.perf_counter() - t0
+
+
 def main():
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--config", type=int, default=2)
+    cfg_no = pre.parse_known_args()[0].config
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="row of BASELINE.json's configs (1-based); 2 = the headline (default)")
+    ap.add_argument("--saturated", action="store_true", help="config 5 only: Haar-saturated chi = 512 input, one wave, --layers Trotter layers")
+    ap.add_argument("--layers", type=int, default=0, help="config 5: Trotter layers (default 20; 1 with --saturated)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -360,7 +518,21 @@ def main():
                          "box with fewer GPUs than ranks, not a scaling measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-procs", type=int, nargs="*", default=[32], help="worker counts of the full-step CPU rows besides P = 1")
+    if cfg_no in CONFIG_PRESETS:
+        ap.set_defaults(**CONFIG_PRESETS[cfg_no])
     args = ap.parse_args()
+    args.dtype_given = any(a == "--dtype" or a.startswith("--dtype=") for a in sys.argv[1:])
+    if args.config == 5:
+        sys.stdout.flush()
+        real_stdout5 = os.dup(1)
+        os.dup2(2, 1)
+        cpu5 = None if args.no_cpu_baseline else cpu_config5(args.saturated, args.layers if args.layers else (1 if args.saturated else 20))  # before torch / HIP
+        out5 = run_config5(args)
+        if cpu5 is not None:
+            out5["cpu_baseline"] = cpu5
+            out5["speedup_vs_cpu"] = {"vs_cpu_row": out5["value"] / cpu5["value"], "vs_one_core": out5["value"] / cpu5["per_core_value"]}
+        os.write(real_stdout5, (json.dumps(out5) + "\n").encode())
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # nothing has touched the GPU in this process
@@ -380,7 +552,8 @@ def main():
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running on {world} rank(s)", file=sys.stderr)
     cpu_ref = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu_ref = cpu_baseline(args.length, args.chi, args.krylov_tol, args.cpu_procs, args.workload, args.tdvp_mode, args.dt)  # before torch / HIP
+        cpu_ref = cpu_baseline(args.length, args.chi, args.krylov_tol, args.cpu_procs, args.workload, args.tdvp_mode, args.dt,
+                               full_steps=not (args.chi > 128 and args.tdvp_mode == "2site"))  # before torch / HIP
 
     import torch
     import torch.distributed as dist

@@ -8,7 +8,9 @@ import csv
 import json
 import sys
 
-KERNEL = "jacobi_cross16"  # ..x_kernel (two columns of each block per wavefront) and ..q_kernel (four)
+import re
+
+KERNEL = sys.argv[9] if len(sys.argv) > 9 else "jacobi_cross16"  # ..x_kernel / ..q_kernel; "jacobi_quad64" = three rounds per load (round 5)
 TAG = sys.argv[7] if len(sys.argv) > 7 else "tjm::"
 STEPS = int(sys.argv[8]) if len(sys.argv) > 8 else 1
 
@@ -33,8 +35,7 @@ def row(path):
 
 
 def names(path):
-    import re
-    return sorted({re.search(r"jacobi_cross16\w+", r["kernel"]).group(0) for r in csv.DictReader(open(path))
+    return sorted({re.search(KERNEL + r"\w*", r["kernel"]).group(0) for r in csv.DictReader(open(path))
                    if KERNEL in r["kernel"] and r["kernel"].lstrip("void ").startswith(TAG)})
 
 
