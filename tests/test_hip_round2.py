@@ -600,6 +600,30 @@ def test_a_poisoned_trajectory_is_taken_out_and_its_neighbours_finish_bit_for_bi
     with pytest.raises((AssertionError, ValueError)):
         run(np.nan, 1, True, with_status=False)
 
+    # status is IN / OUT for a continued run (start_step > 0: e.g. after a capacity rollback onto a larger engine).  A
+    # trajectory that was taken out earlier holds a finite copy of a donor and would pass every screen: it must stay out - NaN rows,
+    # its status kept - and the others must not notice.
+    def continued(status_in, order):
+        e = make_engine(L, chi, B, mpo)
+        e.set_params(dt=0.1, svd_threshold=1e-9, max_bond_dim=chi, krylov_tol=1e-10, tdvp_mode="2site")
+        e.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
+        e.load_state(init)
+        status = np.array(status_in, dtype=np.int32)
+        try:
+            res, diag = e.run(order=order, n_times=5, sample_timesteps=True, has_noise=True, seed=11, traj_indices=trajs, observables=obs, status=status,
+                              start=(2, 0), rng_pos=np.zeros(B, dtype=np.int64))
+        finally:
+            e.close()
+        return res, diag, status
+
+    for order in (1, 2):
+        r0, d0, s0 = continued([0, 0, 0, 0, 0], order)
+        r1, d1, s1 = continued([0, 0, -5, 0, 0], order)
+        assert np.all(s0 == 0) and s1.tolist() == [0, 0, -5, 0, 0]
+        assert np.all(np.isnan(r1[2][:, 2:])), r1[2]
+        keep = [0, 1, 3, 4]
+        assert np.array_equal(r1[keep], r0[keep]) and np.array_equal(d1[keep], d0[keep]) and np.all(np.isfinite(r0[:, :, 2:]))
+
 
 def test_complex64_engine_evolves_under_a_weak_hamiltonian():
     """The Lanczos breakdown test of the complex64 build is relative to the size of H_eff (max(|alpha_0|, beta_0), tjm_common.h): with
@@ -629,6 +653,30 @@ def test_complex64_engine_evolves_under_a_weak_hamiltonian():
         err = np.abs(phase_align(ref.to_vec(), vec_of(out)) - ref.to_vec()).max()
         assert moved > 50 * 2e-5, (L, chi, moved)
         assert err < 2e-5, (L, chi, err, moved)
+
+
+def test_complex64_engine_under_a_zero_hamiltonian_leaves_the_state_finite_and_unevolved():
+    """with H = 0 (a dissipation-only model, or a locally vanishing block) H_eff v is exactly zero, alpha_0 = beta_0 = 0, and
+    the complex64 breakdown test `beta < cut * max(|alpha_0|, beta_0)` read 0 < 0 - no breakdown, 1 / beta = inf, NaN in the Krylov
+    basis and the state.  beta = 0 is a breakdown whatever the scale says: the sweep returns the state it was given (exp(0) = 1), finite,
+    through the fused small-bond kernel (chi = 8) and the general Lanczos loop (chi = 24)."""
+    from yaqs_amd.engine import BatchEngine
+
+    for L, chi in ((8, 8), (10, 24)):
+        mpo = o.ising_mpo(L, 0.0, 0.0)
+        st = o.MPSState.haar(L, chi, np.random.default_rng(5 * L + chi))
+        st.normalize("B")
+        init = [t.copy() for t in st.tensors]
+        e = BatchEngine(L, chi, 2, mpo, dtype="complex64")
+        e.set_params(dt=0.1, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=1e-6, tdvp_mode="2site")
+        e.load_state(init)
+        e.tdvp()
+        out = e.export_state(1)
+        e.close()
+        v0 = o.MPSState([t.copy() for t in init], 0).to_vec()
+        v1 = vec_of(out)
+        assert np.all(np.isfinite(v1.view(np.float64))), (L, chi)
+        assert np.abs(phase_align(v0, v1) - v0).max() < 2e-5, (L, chi)
 
 
 def test_complex64_dynamic_tdvp_and_bug_track_the_fp64_oracle():

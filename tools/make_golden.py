@@ -413,6 +413,44 @@ def gen_digital():
     save("digital", **out)
 
 
+def gen_config1_tebd():
+    """BASELINE config 1 in its TEBD variant at the stated shape: the gate sequence of
+    create_ising_circuit(10, 1, 0.5, 0.1, 10) (circuit_library.py:28-79: per time step an rx layer, rzz on the even bonds, rzz on the
+    odd bonds), max_bond_dim 16, from |0...0>, <Z_i> and <X_3> after every step: the closed system (one deterministic run) and, so that
+    the 8 trajectories of the row differ, the same circuit with depolarising noise 0.01 after every gate (trajectories 0 ... 7)."""
+    dtm = ref("digital.digital_tjm")
+    L, steps = 10, 10
+    J, g, dt = 1.0, 0.5, 0.1
+
+    def layer():
+        singles = []
+        for q in range(L):
+            gt = gl.GateLibrary.rx([-2 * dt * g]); gt.set_sites(q); singles.append(gt)
+        even, odd = [], []
+        for q in range(0, L - 1, 2):
+            gt = gl.GateLibrary.rzz([-2 * dt * J]); gt.set_sites(q, q + 1); even.append(gt)
+        for q in range(1, L - 1, 2):
+            gt = gl.GateLibrary.rzz([-2 * dt * J]); gt.set_sites(q, q + 1); odd.append(gt)
+        return dtm._CompiledCircuitLayer(tuple(singles), tuple(even), tuple(odd), 1)
+
+    st = MPS(L, state="zeros")
+    st.normalize("B")
+    obs = [sp.Observable(gl.Z(), s) for s in range(L)] + [sp.Observable(gl.X(), 3)]
+    noise = NoiseModel([{"name": n, "sites": [i], "strength": 0.01} for i in range(L) for n in ("pauli_x", "pauli_y", "pauli_z")])
+    cc = dtm._CompiledCircuit(tuple(layer() for _ in range(steps)), steps)
+    p = sp.DigitalSimParams(observables=obs, max_bond_dim=16, svd_threshold=1e-9, random_seed=5, sample_layers=True, num_mid_measurements=steps)
+    out = {}
+    for name, nm, ntraj in (("closed", None, 1), ("noisy", noise, 8)):
+        res, diag = [], []
+        for i in range(ntraj):
+            r, dg, _, _ = dtm.digital_tjm((i, st, nm, p, None), compiled_circuit=cc)
+            res.append(np.asarray(r, dtype=np.float64))
+            diag.append(dg)
+        out[name + "_results"] = np.array(res)
+        out[name + "_diag"] = np.array(diag)
+    save("config1_tebd", **out)
+
+
 def gen_shots():
     """MPS.measure_single_shot (mps.py:1282-1350) with scripted draws: rng.choice(n, p) replaced by its definition
     (searchsorted on the normalised cumulative sum) so that the fixture records the uniforms."""

@@ -30,10 +30,11 @@ constexpr int KP = 18;     // TR: a k-contiguous operand is kept m-major in LDS,
 // hit 32 distinct bank pairs).
 template <bool A_MCONTIG, bool B_NCONTIG, bool TR>
 __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
-  __shared__ real sAr[BK * PITCH];
-  __shared__ real sAi[BK * PITCH];
-  __shared__ real sBr[BK * PITCH];
-  __shared__ real sBi[BK * PITCH];
+  __shared__ real sAll[4 * BK * PITCH];  // one array: the epilogue of a Hermitian product reuses it as a transposition buffer
+  real* const sAr = sAll;
+  real* const sAi = sAll + BK * PITCH;
+  real* const sBr = sAll + 2 * BK * PITCH;
+  real* const sBi = sAll + 3 * BK * PITCH;
 
   int z = blockIdx.y * gridDim.z + blockIdx.z;  // batches beyond the 65535 of one grid dimension spill into y (launch_gemm)
   if (z >= g.nb0 * g.nb1 * g.nb2) return;
@@ -177,9 +178,33 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
             v.y = (g.accumulate > 0) ? old.y + v.y : old.y - v.y;
           }
           Cb[(long)m * g.c_rs + n] = v;
-          if (g.hermitian && tm != tn) Cb[(long)n * g.c_rs + m] = cplx{v.x, -v.y};
+          if (g.hermitian == 2 && tm != tn) Cb[(long)n * g.c_rs + m] = cplx{v.x, -v.y};  // (TJM_GEMM_DIRECT_MIRROR: the form of rounds 1 - 4)
         }
       }
+  // Hermitian product: the mirror tile (tn, tm) = this tile's conjugate transpose.  Written straight from the accumulators every lane
+  // would store 16 bytes at a stride of a whole row (rounds 1 - 4: the Gram products of the mixed split ran 25 % below the other
+  // products); each wavefront turns its 16 x 32 halves over in LDS instead and writes rows of 16 consecutive elements.
+  if (g.hermitian == 1 && tm != tn) {
+    constexpr int TP = 17;                       // pitch of the transposed 32 x 16 block (complex elements)
+    cplx* sT = reinterpret_cast<cplx*>(sAll) + wave * (32 * TP);   // 4 x 544 complex <= 2560
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __syncthreads();  // the operand tiles (first half) / the reads of the half before are done with
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          sT[(16 * j + li) * TP + TJM_ACC_ROW(lane, r)] =
+              cplx{accP[i][j][r] - accQ[i][j][r], -(accS[i][j][r] - accP[i][j][r] - accQ[i][j][r])};
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = lane + 64 * q, nn = e >> 4, mm = e & 15;
+        const int n = n0 + wn + nn, m = m0 + wm + 16 * i + mm;
+        if (m < g.M && n < g.N) Cb[(long)n * g.c_rs + m] = sT[nn * TP + mm];
+      }
+    }
+  }
 }
 
 // Row order of a wavefront's 16 rows in heff_stage12_kernel: chosen per arithmetic type so that the four accumulator registers of a
@@ -458,7 +483,10 @@ __global__ __launch_bounds__(256) void zgemm_small_kernel(GemmDesc g, int tiles_
 
 }  // namespace
 
-int launch_gemm(const GemmDesc& g, hipStream_t stream) {
+int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
+  GemmDesc g = g_in;
+  static const bool direct_mirror = getenv("TJM_GEMM_DIRECT_MIRROR") != nullptr;
+  if (g.hermitian && direct_mirror) g.hermitian = 2;
   if (g.M <= 0 || g.N <= 0 || g.nb0 <= 0 || g.nb1 <= 0 || g.nb2 <= 0) return TJM_OK;
   if (g.K <= 0 || g.nks <= 0) return TJM_ERR_ARG;
   static const bool no_small = getenv("TJM_NO_SMALL_GEMM") != nullptr;
