@@ -2164,6 +2164,7 @@ struct CrossSampler {
 };
 CrossProfile g_prof;
 thread_local CrossSampler t_prof;
+thread_local hipEvent_t t_sweep_ev[2] = {nullptr, nullptr};  // jacobi_solve: the convergence counts of sweep k are read behind sweep k + 1
 std::mutex g_prof_mutex;
 // Work actually executed by the tiled Jacobi kernels since the last reset (read once per sweep with the convergence flag):
 // rotation slots x rows (every pair of a visited tile costs its dot product and its - possibly identity - rotation) and
@@ -2434,6 +2435,17 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   bool conv_c = false;
   bool late = op.late_start;  // the previous sweep rotated less than 70 % of its pairs: the check-first variant of the tile kernel
   static const bool no_late = getenv("TJM_NO_LATE_SWEEPS") != nullptr;
+  static const bool sync_each = getenv("TJM_SVD_SYNC_EACH") != nullptr;
+  bool pipelined = !sync_each && g_prof.every == 0;  // (the sampler reads its events at the end of every sweep)
+  if (pipelined && !t_sweep_ev[0]) {
+    if (hipEventCreate(&t_sweep_ev[0]) != hipSuccess || hipEventCreate(&t_sweep_ev[1]) != hipSuccess) {
+      (void)hipGetLastError();
+      t_sweep_ev[0] = t_sweep_ev[1] = nullptr;
+      pipelined = false;
+    }
+  }
+  int sweeps_done = 0;
+  bool extra_queued = false;
   for (; sweep_c < max_sweeps && !conv_c; ++sweep_c) {
     ++g.clock;
     g.mode = 0;
@@ -2515,24 +2527,47 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     }
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 2 * sizeof(int), s));
     hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tbc), dim3(256), 0, s, w.nrot, w.done, w.n_active, nb, g.ids, stop_at);
-    TJM_HIP_CHECK(hipMemcpyAsync(w.h_pinned, w.n_active, 5 * sizeof(int), hipMemcpyDeviceToHost, s));
+    // The counts of the sweep travel to the host BEHIND the sweep (round 5): the host queues sweep k + 1 before it looks at sweep k, so
+    // the device never idles for the round trip.  Nothing numerical depends on it - a trajectory's `done` flag lives on the device
+    // (every kernel of a queued sweep returns at once for a finished trajectory), and the check-first variant the counts select
+    // applies the same rotations as the unconditional one: the host only decides when to stop queuing.  Price: one masked sweep
+    // (launches that find every trajectory done) at the end.  TJM_SVD_SYNC_EACH / the launch sampler: one round trip per sweep.
+    int* hp = w.h_pinned + 16 + 8 * (sweep_c & 1);
+    TJM_HIP_CHECK(hipMemcpyAsync(hp, w.n_active, 5 * sizeof(int), hipMemcpyDeviceToHost, s));
     TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 4, 0, sizeof(int), s));
-    TJM_HIP_CHECK(hipStreamSynchronize(s));
-    conv_c = (*w.h_pinned == 0);
-    {
-      std::lock_guard<std::mutex> lock(g_prof_mutex);
-      g_work.slot_rows += (double)w.h_pinned[4] * rx_top;
-      g_work.rotation_rows += (double)w.h_pinned[1] * rx_top;
-      ++g_work.sweeps;
+    auto digest = [&](const int* h, int k) {  // the counts of sweep k have arrived
+      conv_c = (h[0] == 0);
+      {
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        g_work.slot_rows += (double)h[4] * rx_top;
+        g_work.rotation_rows += (double)h[1] * rx_top;
+        if (h[4] > 0 || k == 0) ++g_work.sweeps;
+      }
+      if (g_debug && src.ncols >= 128) fprintf(stderr, "[svd] ncols %d rx %d sweep %d live %d rotations %d\n", src.ncols, src.rx, k, h[0], h[1]);
+      n_live = h[0];
+      // measured on the MI355X (headline step): fraction 0.25 -> 5.94, 0.7 -> 6.05, 1 (every sweep after the first) -> 5.81 trajectories/s
+      static const double late_frac = getenv("TJM_LATE_FRACTION") ? atof(getenv("TJM_LATE_FRACTION")) : 0.7;
+      late = !no_late && !accumulate &&
+             (op.late_after_first || (double)h[1] < late_frac * 0.5 * (double)ncols_pad * (ncols_pad - 1) * std::max(n_live, 1));
+    };
+    if (!pipelined) {
+      TJM_HIP_CHECK(hipStreamSynchronize(s));
+      digest(hp, sweep_c);
+      if (g_prof.every > 0) prof_collect();
+      continue;
     }
-    if (g_debug && src.ncols >= 128) fprintf(stderr, "[svd] ncols %d rx %d sweep %d live %d rotations %d\n", src.ncols, src.rx, sweep_c, w.h_pinned[0], w.h_pinned[1]);
-    n_live = *w.h_pinned;
-    // measured on the MI355X (headline step): fraction 0.25 -> 5.94, 0.7 -> 6.05, 1 (every sweep after the first) -> 5.81 trajectories/s
-    static const double late_frac = getenv("TJM_LATE_FRACTION") ? atof(getenv("TJM_LATE_FRACTION")) : 0.7;
-    late = !no_late && !accumulate &&
-           (op.late_after_first || (double)w.h_pinned[1] < late_frac * 0.5 * (double)ncols_pad * (ncols_pad - 1) * std::max(n_live, 1));
-    if (g_prof.every > 0) prof_collect();
+    TJM_HIP_CHECK(hipEventRecord(t_sweep_ev[sweep_c & 1], s));
+    if (sweep_c > 0) {
+      TJM_HIP_CHECK(hipEventSynchronize(t_sweep_ev[(sweep_c - 1) & 1]));
+      digest(w.h_pinned + 16 + 8 * ((sweep_c - 1) & 1), sweep_c - 1);
+      if (conv_c) { sweeps_done = sweep_c; extra_queued = true; break; }  // sweep sweep_c is queued and masked: sweeps 0 ... sweep_c - 1 did the work
+    }
+    if (sweep_c + 1 == max_sweeps) {  // the last sweep the cap allows: wait for it
+      TJM_HIP_CHECK(hipStreamSynchronize(s));
+      digest(hp, sweep_c);
+    }
   }
+  if (extra_queued) sweep_c = sweeps_done;
   const int sweep = sweep_c;
   const bool converged = conv_c;
   if (sweeps_out) *sweeps_out = sweep;
@@ -2993,21 +3028,29 @@ __global__ __launch_bounds__(256) void refine_corr_kernel(const cplx* __restrict
   const cplx* Eb = E ? E + (long)blockIdx.y * e_b0 : nullptr;
   cplx* Cb = Cm + (long)blockIdx.y * c_b0;
   const real tr = fro2[blockIdx.y];
-  const long total = (long)N * N;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int i = (int)(e / N), j = (int)(e % N);
+  // rows dealt to the workgroups, a row's entries to the threads (no 64-bit index divisions; the diagonal - every entry needs d_i and
+  // d_j - staged once per workgroup: the element-per-thread form of round 4 ran at 2.2 TB/s)
+  __shared__ real sD[1024], sDe[1024];
+  for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    sD[k] = Gb[(long)k * N + k].x;
+    sDe[k] = Eb ? Eb[(long)k * N + k].x : real(0.0);
+  }
+  __syncthreads();
+  for (int i = blockIdx.x; i < N; i += gridDim.x)
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    const long e = (long)i * N + j;
     cplx c{0.0, 0.0};
     if (i == j) {
       if (Eb) c = cplx{-0.5 * Eb[e].x, 0.0};
     } else {
-      real di = Gb[(long)i * N + i].x, dj = Gb[(long)j * N + j].x;
+      real di = sD[i], dj = sD[j];
       cplx f = Gb[e];
       if (Eb) {
         const cplx ee = Eb[e];
         const real h = 0.5 * (di + dj);
         f = cplx{fma(-h, ee.x, f.x), fma(-h, ee.y, f.y)};
-        di *= 1.0 - Eb[(long)i * N + i].x;
-        dj *= 1.0 - Eb[(long)j * N + j].x;
+        di *= 1.0 - sDe[i];
+        dj *= 1.0 - sDe[j];
       }
       const real f2 = fma(f.x, f.x, f.y * f.y);
       if (!(far_column(i, di, cm, skip_col, tr) && far_column(j, dj, cm, skip_col, tr)) && pair_open(di, dj, f2, tr)) {
