@@ -278,7 +278,7 @@ def pmc_traffic(L, chi, B, kernel_tag):
 
 def shard_rate(B):
     """Trajectories/s of ONE MI355X with B resident trajectories (profiles/r0*_shard_rates.json, measured with this script)."""
-    for name in ("r04_shard_rates.json", "r03_shard_rates.json"):
+    for name in ("r05_shard_rates.json", "r04_shard_rates.json", "r03_shard_rates.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)

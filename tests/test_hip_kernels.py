@@ -589,16 +589,19 @@ def test_lanczos_expm_matches_reference_outputs(lib):
     e.close()
 
 
+@pytest.mark.parametrize("bond", [24, 64])
 @pytest.mark.parametrize("nsites", [1, 2])
-def test_lanczos_expm_general_path_matches_oracle(lib, nsites):
+def test_lanczos_expm_general_path_matches_oracle(lib, nsites, bond):
     """The same export at bond 24 (block of 1152 / 2304 entries: MFMA GEMMs + Lanczos vector kernels, one host check per iteration)
-    against the oracle's update_site (pinned to the reference by the fixture above), with the adaptive stop at 1e-4 and 1e-12."""
+    against the oracle's update_site (pinned to the reference by the fixture above), with the adaptive stop at 1e-4 and 1e-12; and
+    at bond 64, where the last GEMM of the H_eff apply runs on the tiled kernel and delivers the Lanczos coefficient <v, H v> in its
+    epilogue (round 5: per-tile partial sums instead of a dot-product pass)."""
     from oracle import tjm_oracle as o  # checker only
     from yaqs_amd._lib import check
     from yaqs_amd.engine import BatchEngine
 
-    rng = np.random.default_rng(11 + nsites)
-    ca = cb = 24
+    rng = np.random.default_rng(11 + nsites + bond)
+    ca = cb = bond
     D, P = 3, 2 ** nsites
     mpo = o.ising_mpo(8, 1.0, 0.5)
     w = mpo[3] if nsites == 1 else o.merge_mpo_tensors(mpo[3], mpo[4])
@@ -606,7 +609,7 @@ def test_lanczos_expm_general_path_matches_oracle(lib, nsites):
     Lenv, Renv = herm(crand(rng, ca, D, ca)), herm(crand(rng, cb, D, cb))
     x = crand(rng, P, ca, cb)
     x /= np.linalg.norm(x)
-    e = BatchEngine(12, 32, 2, o.ising_mpo(12, 1.0, 0.5))
+    e = BatchEngine(12, max(32, bond), 2, o.ising_mpo(12, 1.0, 0.5))
     wh = np.ascontiguousarray(w, dtype=np.complex128)
     for tol in (1e-4, 1e-12):
         y = torch.zeros((2, P, ca, cb), dtype=torch.complex128, device=DEV)

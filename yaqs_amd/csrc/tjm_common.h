@@ -151,6 +151,13 @@ struct GemmDesc {
   const int* active;  // optional per-trajectory mask (device, indexed by remapped id); 0 => skip
   int hermitian;      // 1: the result is Hermitian (a Gram matrix, M == N): only the tiles on and above the diagonal are computed, the
                       // others are written as their mirror images (10 of 16 tiles at 256 x 256)
+  // Optional epilogue (tiled kernel only): Re <dot_with, C> over the workgroup's tile, with the FINAL values of C (after accumulate) -
+  // the Lanczos coefficient alpha_j = <v_j, H v_j> without a pass of its own.  dot_with has the element offsets of C (same strides);
+  // the partial sum of tile t of inner batch (b1, b2) goes to dot_part[b0 * dot_ld + (b1 * nb2 + b2) * tiles + t] (no atomics:
+  // one slot per workgroup, added up in a fixed order by the consumer).
+  const cplx* dot_with;
+  real* dot_part;
+  int dot_ld;
 };
 
 int launch_gemm(const GemmDesc& g, hipStream_t stream);

@@ -205,6 +205,9 @@ class Engine {
   int split(StateSet& S, int i, int dist, int mode, double thr, int maxb, int min_keep, const int* ids, int nb0);
   int set_nloc(StateSet& S, int bl, int br, int P);
   using ApplyFn = std::function<int(const cplx* x, cplx* y, const int* active)>;
+  // krylov_core asks the apply it is about to call for Re <x, H x> as well (x = the vector it passes): heff_apply serves it in the
+  // epilogue of its last GEMM when that runs on the tiled kernel (per-tile partial sums in part1_), otherwise the dot-product kernel runs
+  struct DotRequest { const cplx* v = nullptr; bool served = false; int nblk1 = 0; } dot_req_;
   int krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc_dev, cplx* out, long out_b0, int n0, int n1, int n2, int n3,
                   long o0, long o1, long o2, int nb0, const int* ids);
   int bond_apply(const cplx* x, int cu, int cv, const cplx* Lenv, long l_b0, const cplx* Renv, long r_b0, int D, cplx* y, const int* active,

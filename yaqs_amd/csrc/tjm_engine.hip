@@ -627,6 +627,14 @@ int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cp
       g.nks = Dl - 1; g.a_ks = ca; g.b_ks = cb;
       g.accumulate = 1;
     }
+    static const bool no_dot_fusion = getenv("TJM_NO_DOT_EPILOGUE") != nullptr;
+    const int tiles = ((ca + 63) / 64) * ((cb + 63) / 64) * P;
+    if (!no_dot_fusion && dot_req_.v == x && x_b0 == y_b0 && ca >= 64 && cb >= 64 && tiles <= TJM_MAX_PART) {
+      // the Lanczos coefficient <x, H x> in the epilogue of this product: y is final there, x has y's layout
+      g.dot_with = x; g.dot_part = part1_; g.dot_ld = tiles;
+      dot_req_.served = true;
+      dot_req_.nblk1 = tiles;
+    }
     if ((rc = gemm(g)) != TJM_OK) return rc;
   }
   return TJM_OK;
@@ -764,13 +772,21 @@ int Engine::krylov_core(const ApplyFn& apply, int n, double dt_, const int* nloc
     cplx* vj = V + (long)j * v_ld;
     cplx* w = V + (long)(j + 1) * v_ld;
     cplx* vjm1 = V + (long)(j > 0 ? j - 1 : 0) * v_ld;
-    if ((rc = apply(vj, w, ks.status)) != TJM_OK) return rc;
+    dot_req_.v = vj;
+    dot_req_.served = false;
+    rc = apply(vj, w, ks.status);
+    dot_req_.v = nullptr;
+    if (rc != TJM_OK) return rc;
     ++stat_matvecs;
     if (krylov_P_ == d * d) ++stat_matvecs2;
-    if ((rc = launch_dot_partial(vj, w, v_b0, v_b0, n, part1_, nb0, ids, ks.status, stream, &nblk)) != TJM_OK) return rc;
-    if ((rc = launch_lanczos_axpy(w, vj, vjm1, v_b0, n, part1_, part2_, nblk, ks.beta, mmax, j, nb0, ids, ks.status, stream, ks.svec)) != TJM_OK) return rc;
+    int nblk1 = dot_req_.nblk1;  // <v_j, w>: per-tile partial sums from the epilogue of the apply's last GEMM, or a pass of its own
+    if (!dot_req_.served) {
+      if ((rc = launch_dot_partial(vj, w, v_b0, v_b0, n, part1_, nb0, ids, ks.status, stream, &nblk1)) != TJM_OK) return rc;
+    }
+    // (nblk: the grid of the vector kernels for n elements, from the norm pass above)
+    if ((rc = launch_lanczos_axpy(w, vj, vjm1, v_b0, n, part1_, part2_, nblk, ks.beta, mmax, j, nb0, ids, ks.status, stream, ks.svec, nblk1)) != TJM_OK) return rc;
     TJM_HIP_CHECK(hipMemsetAsync(ks.n_active, 0, sizeof(int), stream));
-    if ((rc = launch_lanczos_finalize(ks, part1_, part2_, nblk, j, dt_, krylov_tol, nloc_dev, nb0, ids, stream)) != TJM_OK) return rc;
+    if ((rc = launch_lanczos_finalize(ks, part1_, part2_, nblk, j, dt_, krylov_tol, nloc_dev, nb0, ids, stream, nblk1)) != TJM_OK) return rc;
     if (!pipelined) {
       TJM_HIP_CHECK(hipMemcpyAsync(h_pinned_, ks.n_active, sizeof(int), hipMemcpyDeviceToHost, stream));
       TJM_HIP_CHECK(hipStreamSynchronize(stream));

@@ -160,6 +160,8 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
   }
 
   // epilogue
+  const cplx* __restrict__ Db = g.dot_part ? g.dot_with + (long)b0 * g.c_b0 + (long)b1 * g.c_b1 + (long)b2 * g.c_b2 : nullptr;
+  real dot_acc = 0.0;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -178,9 +180,23 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
             v.y = (g.accumulate > 0) ? old.y + v.y : old.y - v.y;
           }
           Cb[(long)m * g.c_rs + n] = v;
+          if (Db) {
+            const cplx u = Db[(long)m * g.c_rs + n];
+            dot_acc = fma(u.x, v.x, dot_acc);
+            dot_acc = fma(u.y, v.y, dot_acc);
+          }
           if (g.hermitian == 2 && tm != tn) Cb[(long)n * g.c_rs + m] = cplx{v.x, -v.y};  // (TJM_GEMM_DIRECT_MIRROR: the form of rounds 1 - 4)
         }
       }
+  if (g.dot_part) {  // the workgroup's share of Re <dot_with, C>: lanes, then wavefronts, in a fixed order
+    __syncthreads();  // (the operand tiles are done with)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot_acc += __shfl_down(dot_acc, o, 64);
+    if (lane == 0) sAll[wave] = dot_acc;
+    __syncthreads();
+    if (tid == 0)
+      g.dot_part[(long)b0 * g.dot_ld + (long)(b1 * g.nb2 + b2) * gridDim.x + blockIdx.x] = (sAll[0] + sAll[1]) + (sAll[2] + sAll[3]);
+  }
   // Hermitian product: the mirror tile (tn, tm) = this tile's conjugate transpose.  Written straight from the accumulators every lane
   // would store 16 bytes at a stride of a whole row (rounds 1 - 4: the Gram products of the mixed split ran 25 % below the other
   // products); each wavefront turns its 16 x 32 halves over in LDS instead and writes rows of 16 consecutive elements.
@@ -490,7 +506,7 @@ int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.nb0 <= 0 || g.nb1 <= 0 || g.nb2 <= 0) return TJM_OK;
   if (g.K <= 0 || g.nks <= 0) return TJM_ERR_ARG;
   static const bool no_small = getenv("TJM_NO_SMALL_GEMM") != nullptr;
-  if (!no_small && (g.M <= 32 || g.N <= 32) && (long)g.K * g.nks <= 512) {  // long sums keep the LDS-tiled kernel's four-wave k loop
+  if (!no_small && g.dot_part == nullptr && (g.M <= 32 || g.N <= 32) && (long)g.K * g.nks <= 512) {  // long sums keep the LDS-tiled kernel's four-wave k loop
     const int tiles_m = (g.M + 15) / 16, tiles_n = (g.N + 15) / 16;
     const long total_tiles = (long)tiles_m * tiles_n * g.nb0 * g.nb1 * g.nb2;
     hipLaunchKernelGGL(zgemm_small_kernel, dim3((unsigned)((total_tiles + 3) / 4)), dim3(256), 0, stream, g, tiles_m, tiles_n, total_tiles);

@@ -69,13 +69,13 @@ int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n
                        const int* active, hipStream_t s, int* nblk_out);
 int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, int n, const real* part1, real* part2,
                         int nblk, const real* beta, int beta_ld, int j, int nb0, const int* ids, const int* active,
-                        hipStream_t s, const real* svec);
+                        hipStream_t s, const real* svec, int nblk1);
 int launch_scale(cplx* x, long x_b0, long n, const real* scale, int nb0, const int* ids, const int* active, hipStream_t s);
 int launch_env_identity_check(const cplx* env, long b0, int c, int D, const int* chi, int chi_stride, real tol, int* flags, int nb0, const int* ids,
                               hipStream_t s);  // flags[0] / [1] raised when the first / last channel of env[c][D][c] is not the identity
 int launch_lanczos_init(const KrylovState& ks, const real* part, int nblk, int nb0, const int* ids, hipStream_t s);
 int launch_lanczos_finalize(const KrylovState& ks, const real* part1, const real* part2, int nblk, int j, real dt,
-                            real tol, const int* nloc, int nb0, const int* ids, hipStream_t s);
+                            real tol, const int* nloc, int nb0, const int* ids, hipStream_t s, int nblk1);
 int launch_krylov_combine(const cplx* V, long v_b0, long v_ld, const KrylovState& ks, cplx* out, long out_b0, int n0, int n1,
                           int n2, int n3, long o0, long o1, long o2, int nb0, const int* ids, hipStream_t s);
 int launch_tridiag_expm_test(const real* alpha, const real* beta, int k, real dt, real* out, hipStream_t s);

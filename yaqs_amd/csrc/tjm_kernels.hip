@@ -192,13 +192,13 @@ __global__ __launch_bounds__(256) void lanczos_axpy_kernel(cplx* __restrict__ w,
                                                           const cplx* __restrict__ vjm1, long v_b0, int n,
                                                           const real* part1, real* part2, int nblk,
                                                           const real* beta, int beta_ld, int j, const int* ids,
-                                                          const int* active, const real* __restrict__ svec) {
+                                                          const int* active, const real* __restrict__ svec, int nblk1) {
   __shared__ real sh[4];
   int b = blockIdx.y;
   if (ids) b = ids[b];
   if (active && active[b] == 0) return;
   real alpha = 0.0;
-  for (int i = 0; i < nblk; ++i) alpha += part1[(long)b * nblk + i];
+  for (int i = 0; i < nblk1; ++i) alpha += part1[(long)b * nblk1 + i];  // nblk1 partial sums: dot_partial_kernel's blocks or the tiles of the GEMM epilogue
   const real sj = svec[(long)b * beta_ld + j];
   alpha *= sj * sj;
   const real bprev = (j > 0) ? beta[(long)b * beta_ld + j - 1] * svec[(long)b * beta_ld + j - 1] : 0.0;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64) void lanczos_init_kernel(KrylovState ks, const 
 // One wavefront per trajectory: store alpha_j / beta_j, breakdown and adaptive-stop tests
 // (matrix_exponential.py:100-163), coefficient vector on exit.
 __global__ __launch_bounds__(64) void lanczos_finalize_kernel(KrylovState ks, const real* part1, const real* part2, int nblk,
-                                                             int j, real dt, real tol, const int* nloc, const int* ids) {
+                                                             int j, real dt, real tol, const int* nloc, const int* ids, int nblk1) {
   int b = blockIdx.x;
   if (ids) b = ids[b];
   if (ks.status[b] == 0) return;
@@ -531,10 +531,8 @@ __global__ __launch_bounds__(64) void lanczos_finalize_kernel(KrylovState ks, co
   real* al = ks.alpha + (long)b * m;
   real* be = ks.beta + (long)b * m;
   real a = 0.0, s2 = 0.0;
-  for (int i = 0; i < nblk; ++i) {
-    a += part1[(long)b * nblk + i];
-    s2 += part2[(long)b * nblk + i];
-  }
+  for (int i = 0; i < nblk1; ++i) a += part1[(long)b * nblk1 + i];
+  for (int i = 0; i < nblk; ++i) s2 += part2[(long)b * nblk + i];
   const real bj = sqrt(s2);
   {
     const real sj = ks.svec[(long)b * m + j];  // part1 holds <V[j], H V[j]> of the unnormalised vector
@@ -631,9 +629,9 @@ int launch_dot_partial(const cplx* v, const cplx* w, long v_b0, long w_b0, int n
 
 int launch_lanczos_axpy(cplx* w, const cplx* vj, const cplx* vjm1, long v_b0, int n, const real* part1, real* part2,
                         int nblk, const real* beta, int beta_ld, int j, int nb0, const int* ids, const int* active,
-                        hipStream_t s, const real* svec) {
+                        hipStream_t s, const real* svec, int nblk1) {
   hipLaunchKernelGGL(lanczos_axpy_kernel, dim3(nblk, nb0), dim3(256), 0, s, w, vj, vjm1, v_b0, n, part1, part2, nblk, beta,
-                     beta_ld, j, ids, active, svec);
+                     beta_ld, j, ids, active, svec, nblk1);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
@@ -690,8 +688,8 @@ int launch_lanczos_init(const KrylovState& ks, const real* part, int nblk, int n
 }
 
 int launch_lanczos_finalize(const KrylovState& ks, const real* part1, const real* part2, int nblk, int j, real dt,
-                            real tol, const int* nloc, int nb0, const int* ids, hipStream_t s) {
-  hipLaunchKernelGGL(lanczos_finalize_kernel, dim3(nb0), dim3(64), 0, s, ks, part1, part2, nblk, j, dt, tol, nloc, ids);
+                            real tol, const int* nloc, int nb0, const int* ids, hipStream_t s, int nblk1) {
+  hipLaunchKernelGGL(lanczos_finalize_kernel, dim3(nb0), dim3(64), 0, s, ks, part1, part2, nblk, j, dt, tol, nloc, ids, nblk1);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }

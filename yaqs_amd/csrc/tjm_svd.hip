@@ -2164,7 +2164,10 @@ struct CrossSampler {
 };
 CrossProfile g_prof;
 thread_local CrossSampler t_prof;
-thread_local hipEvent_t t_sweep_ev[2] = {nullptr, nullptr};  // jacobi_solve: the convergence counts of sweep k are read behind sweep k + 1
+// jacobi_solve: the convergence counts of sweep k are read behind sweep k + 1.  Events belong to a device: one pair per device the
+// calling thread has used (a process may drive engines on several GPUs: Simulator(device="cuda:k"))
+struct SweepEvents { hipEvent_t ev[16][2] = {}; };
+thread_local SweepEvents t_sweep_events;
 std::mutex g_prof_mutex;
 // Work actually executed by the tiled Jacobi kernels since the last reset (read once per sweep with the convergence flag):
 // rotation slots x rows (every pair of a visited tile costs its dot product and its - possibly identity - rotation) and
@@ -2437,11 +2440,19 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   static const bool no_late = getenv("TJM_NO_LATE_SWEEPS") != nullptr;
   static const bool sync_each = getenv("TJM_SVD_SYNC_EACH") != nullptr;
   bool pipelined = !sync_each && g_prof.every == 0;  // (the sampler reads its events at the end of every sweep)
-  if (pipelined && !t_sweep_ev[0]) {
-    if (hipEventCreate(&t_sweep_ev[0]) != hipSuccess || hipEventCreate(&t_sweep_ev[1]) != hipSuccess) {
-      (void)hipGetLastError();
-      t_sweep_ev[0] = t_sweep_ev[1] = nullptr;
-      pipelined = false;
+  hipEvent_t* t_sweep_ev = nullptr;
+  if (pipelined) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); pipelined = false; }
+    else {
+      t_sweep_ev = t_sweep_events.ev[dev];
+      if (!t_sweep_ev[0]) {
+        if (hipEventCreate(&t_sweep_ev[0]) != hipSuccess || hipEventCreate(&t_sweep_ev[1]) != hipSuccess) {
+          (void)hipGetLastError();
+          t_sweep_ev[0] = t_sweep_ev[1] = nullptr;
+          pipelined = false;
+        }
+      }
     }
   }
   int sweeps_done = 0;
