@@ -130,6 +130,18 @@ def test_mixed_precision_split_on_the_simulated_device(on_sim):
     assert out[1] > 0 and out[8] > 0               # complex64 sweeps and fp64 GEMMs were counted
 
 
+def test_mixed_precision_split_at_256_in_the_mode_of_the_engine_on_the_simulated_device(on_sim):
+    """The size of the headline (256 x 256, no spectrum buffer): the complex64 phase runs the three-rounds-per-load Jacobi kernel
+    (jacobi_quad64_kernel: the AG(2,4) schedule of block quads and of the columns inside a block, the block exchange between the
+    rounds) and the grouped block reflectors (qr_block_apply_multi_kernel) - the body of the GPU test
+    test_mixed_split_in_the_mode_of_the_engine_matches_lapack on the interpreter: LAPACK, isometry, padding, counters."""
+    k = on_sim["test_hip_kernels"]
+    from simengine import load_sim
+
+    solves, c64_sweeps, f64_sweeps, fallbacks, jacobi_traj, second_polar, gemms = k._run_engine_mode(load_sim(), 256)
+    assert solves == 2 and fallbacks == 0 and c64_sweeps >= 8 and gemms >= 26
+
+
 @pytest.mark.parametrize("switch", ["TJM_NO_QUAD_TILE", "TJM_MIXED_UPDATE_V", "TJM_MIXED_NO_SKIP"])
 def test_mixed_precision_split_under_its_switches(switch):
     """The A/B switches of the mixed split name code that is otherwise not run any more (the two-column tile kernel in its complex64
