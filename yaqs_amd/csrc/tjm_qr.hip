@@ -498,6 +498,13 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
 // the four wavefronts): the results are bit-identical to the one-panel-per-launch form.
 //   panels p_first, p_first + p_step, ... (np of them); rows row_lo ... zr - 1 of the chunk are kept (row_lo = 16 x the smallest
 //   panel: the reflectors of a panel are zero above its first row)
+// MAXT: 16-row steps of a panel per wavefront (4: chunks of up to 256 rows, 8: up to 512).  A workgroup walks its panels one after the
+// other and every panel needs the reflector block V twice, in two register layouts, from L2: those loads are issued early - the
+// operands of the rank-16 update right after the inner products have been issued (consumed three barriers later), the operands of
+// the next panel's inner products before the update of this one.  Measured: no change (Q x C of 256 matrices 839 -> 878 us alone on
+// the device): the kernel is not waiting for those loads, it is at half of its matrix-core floor - 268 MFLOP per matrix in four real
+// MFMAs per complex multiply-add = 437 us at the fp32 MFMA peak for the launch; the three-product form would be the next step.
+template <int MAXT>
 __global__ __launch_bounds__(256) void qr_block_apply_multi_kernel(const cplx* __restrict__ Vb, long v_b0, const cplx* __restrict__ Tb, long t_b0,
                                                                   int p_first, int p_step, int np, int zr, int t_herm, cplx* __restrict__ C,
                                                                   long c_b0, int col0, int nc, const int* ids, int row_lo, int pitch) {
@@ -514,14 +521,40 @@ __global__ __launch_bounds__(256) void qr_block_apply_multi_kernel(const cplx* _
   const int ncw = (nc - blockIdx.x * PW < PW) ? nc - blockIdx.x * PW : PW;
   cplx* Cb = C + (long)b * c_b0;
   const int nrows = zr - row_lo;
+  const int li = lane & 15, lk = lane >> 4;
+  const cplx* __restrict__ Vall = Vb + (long)b * v_b0;
+  cplx v1[MAXT][4], v3[MAXT][4];
+  // operands of the inner products of a panel: lane (li, lk) takes rows row0 + 16 s + 4 lk + q of reflector column li, s = wave + 4 t
+  auto load_v1 = [&](int panel) {
+    const int row0 = panel * PW;
+    const int nsteps = (zr - row0 + 15) >> 4;
+    const cplx* vcol = Vall + (long)panel * PW * zr + (long)li * zr;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int rb = row0 + 16 * (wave + 4 * t) + 4 * lk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v1[t][q] = (wave + 4 * t < nsteps && rb + q < zr) ? vcol[rb + q] : cplx{0.0, 0.0};
+    }
+  };
+  // operands of the update: lane (li, lk) takes row r0 + li of reflector columns 4 kk + lk, r0 = row0 + 16 (wave + 4 t)
+  auto load_v3 = [&](int panel) {
+    const int row0 = panel * PW;
+    const int nchunks = (zr - row0 + 15) >> 4;
+    const cplx* Vp = Vall + (long)panel * PW * zr;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      const int r = row0 + 16 * (wave + 4 * t) + li;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) v3[t][kk] = (wave + 4 * t < nchunks && r < zr) ? Vp[(long)(4 * kk + lk) * zr + r] : cplx{0.0, 0.0};
+    }
+  };
+  load_v1(p_first);
   for (int c = 0; c < PW; ++c) {
     const cplx* src = Cb + (long)(c0 + c) * zr + row_lo;
     for (int r = tid; r < nrows; r += 256) sC[c * pitch + r] = (c < ncw) ? src[r] : cplx{0.0, 0.0};
   }
-  const int li = lane & 15, lk = lane >> 4;
   for (int ip = 0; ip < np; ++ip) {
     const int panel = p_first + ip * p_step;
-    const cplx* __restrict__ Vp = Vb + (long)b * v_b0 + (long)panel * PW * zr;
     const cplx* Tp = Tb + (long)b * t_b0 + (long)panel * PW * PW;
     const int row0 = panel * PW;
     sTm[tid] = Tp[tid];
@@ -529,25 +562,25 @@ __global__ __launch_bounds__(256) void qr_block_apply_multi_kernel(const cplx* _
     {  // W1[i][c] = sum_r conj(V[i][r]) C[c][r], K split over the four wavefronts
       real4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
       const int nsteps = (zr - row0 + 15) >> 4;
-      const cplx* vcol = Vp + (long)li * zr;
       const cplx* ccol = sC + li * pitch - row_lo;
-      for (int s = wave; s < nsteps; s += 4) {
-        const int rb = row0 + 16 * s + 4 * lk;
-        cplx v[4], x[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = rb + q;
-          v[q] = (r < zr) ? vcol[r] : cplx{0.0, 0.0};
-          x[q] = (r < zr) ? ccol[r] : cplx{0.0, 0.0};
-        }
+      for (int t = 0; t < MAXT; ++t) {
+        const int s = wave + 4 * t;
+        if (s < nsteps) {
+          const int rb = row0 + 16 * s + 4 * lk;
+          cplx x[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          P = TJM_MFMA(v[q].x, x[q].x, P);
-          Q = TJM_MFMA(v[q].y, x[q].y, Q);
-          S1 = TJM_MFMA(v[q].x, x[q].y, S1);
-          S2 = TJM_MFMA(v[q].y, x[q].x, S2);
+          for (int q = 0; q < 4; ++q) x[q] = (rb + q < zr) ? ccol[rb + q] : cplx{0.0, 0.0};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            P = TJM_MFMA(v1[t][q].x, x[q].x, P);
+            Q = TJM_MFMA(v1[t][q].y, x[q].y, Q);
+            S1 = TJM_MFMA(v1[t][q].x, x[q].y, S1);
+            S2 = TJM_MFMA(v1[t][q].y, x[q].x, S2);
+          }
         }
       }
+      load_v3(panel);  // in flight during the reduction and the product with T
 #pragma unroll
       for (int q = 0; q < 4; ++q) sPart[wave * PW * PW + TJM_ACC_ROW(lane, q) * PW + li] = cplx{P[q] + Q[q], S1[q] - S2[q]};
     }
@@ -572,6 +605,7 @@ __global__ __launch_bounds__(256) void qr_block_apply_multi_kernel(const cplx* _
       sW2[i * PW + c] = acc;
     }
     __syncthreads();
+    if (ip + 1 < np) load_v1(panel + p_step);  // the next panel's inner-product operands, in flight during this panel's update
     {  // C[c][r] -= sum_i W2[i][c] V[i][r] on the chunk in LDS
       real wr[4], wi[4];
 #pragma unroll
@@ -581,26 +615,29 @@ __global__ __launch_bounds__(256) void qr_block_apply_multi_kernel(const cplx* _
         wi[kk] = t.y;
       }
       const int nchunks = (zr - row0 + 15) >> 4;
-      for (int ch = wave; ch < nchunks; ch += 4) {
-        const int r0 = row0 + ch * 16;
-        real4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const cplx v = (r0 + li < zr) ? Vp[(long)(4 * kk + lk) * zr + r0 + li] : cplx{0.0, 0.0};
-          P = TJM_MFMA(wr[kk], v.x, P);
-          Q = TJM_MFMA(wi[kk], v.y, Q);
-          S1 = TJM_MFMA(wi[kk], v.x, S1);
-          S2 = TJM_MFMA(wr[kk], v.y, S2);
-        }
-        if (r0 + li < zr) {
+      for (int t = 0; t < MAXT; ++t) {
+        const int ch = wave + 4 * t;
+        if (ch < nchunks) {
+          const int r0 = row0 + ch * 16;
+          real4 P = {0, 0, 0, 0}, Q = {0, 0, 0, 0}, S1 = {0, 0, 0, 0}, S2 = {0, 0, 0, 0};
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = TJM_ACC_ROW(lane, q);
-            cplx* px = sC + c * pitch + (r0 + li - row_lo);
-            cplx x = *px;
-            x.x -= P[q] - Q[q];
-            x.y -= S1[q] + S2[q];
-            *px = x;
+          for (int kk = 0; kk < 4; ++kk) {
+            P = TJM_MFMA(wr[kk], v3[t][kk].x, P);
+            Q = TJM_MFMA(wi[kk], v3[t][kk].y, Q);
+            S1 = TJM_MFMA(wi[kk], v3[t][kk].x, S1);
+            S2 = TJM_MFMA(wr[kk], v3[t][kk].y, S2);
+          }
+          if (r0 + li < zr) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int c = TJM_ACC_ROW(lane, q);
+              cplx* px = sC + c * pitch + (r0 + li - row_lo);
+              cplx x = *px;
+              x.x -= P[q] - Q[q];
+              x.y -= S1[q] + S2[q];
+              *px = x;
+            }
           }
         }
       }
@@ -750,14 +787,20 @@ int apply_block_reflectors(const QrWorkspace& q, int zr, int p_first, int p_step
   if (np == 1) return apply_block_reflector(q, zr, p_first, t_herm, C, c_b0, col0, nc, nb0, ids, s);
   static std::atomic<bool> attr_set{false};
   if (!attr_set.load(std::memory_order_acquire)) {
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_block_apply_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_block_apply_multi_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_block_apply_multi_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     attr_set.store(true, std::memory_order_release);
   }
   const int p_last = p_first + (np - 1) * p_step;
   const int row_lo = PW * (p_first < p_last ? p_first : p_last);
   const int nrows = zr - row_lo;
-  hipLaunchKernelGGL(qr_block_apply_multi_kernel, dim3((nc + PW - 1) / PW, nb0), dim3(256), multi_lds_bytes(nrows), s, q.V, q.v_b0, q.T, q.t_b0, p_first,
-                     p_step, np, zr, t_herm ? 1 : 0, C, c_b0, col0, nc, ids, row_lo, multi_pitch(nrows));
+  if (nrows > 512) return TJM_ERR_NOT_IMPLEMENTED;  // (multi_group keeps the chunk within 80 KB: never reached)
+  if (nrows <= 256)
+    hipLaunchKernelGGL(qr_block_apply_multi_kernel<4>, dim3((nc + PW - 1) / PW, nb0), dim3(256), multi_lds_bytes(nrows), s, q.V, q.v_b0, q.T, q.t_b0, p_first,
+                       p_step, np, zr, t_herm ? 1 : 0, C, c_b0, col0, nc, ids, row_lo, multi_pitch(nrows));
+  else
+    hipLaunchKernelGGL(qr_block_apply_multi_kernel<8>, dim3((nc + PW - 1) / PW, nb0), dim3(256), multi_lds_bytes(nrows), s, q.V, q.v_b0, q.T, q.t_b0, p_first,
+                       p_step, np, zr, t_herm ? 1 : 0, C, c_b0, col0, nc, ids, row_lo, multi_pitch(nrows));
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }

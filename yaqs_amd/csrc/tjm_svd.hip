@@ -2972,15 +2972,16 @@ __global__ __launch_bounds__(256) void polar_poly_kernel(const cplx* __restrict_
   const cplx* Eb = E + (long)b * e_b0;
   const cplx* Fb = E2 + (long)b * e2_b0;
   cplx* Tb = T + (long)b * t_b0;
-  const long total = (long)N * N;
   real acc = 0.0;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const cplx a = Eb[e], b = Fb[e];
-    cplx v{fma(c2, b.x, -0.5 * a.x), fma(c2, b.y, -0.5 * a.y)};
-    if (e / N == e % N) v.x += 1.0;
-    Tb[e] = v;
-    acc = fma(b.x, b.x, fma(b.y, b.y, acc));
-  }
+  for (int i = blockIdx.x; i < N; i += gridDim.x)  // rows to the workgroups, a row's entries to the threads: no 64-bit index divisions
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const long e = (long)i * N + j;
+      const cplx a = Eb[e], b = Fb[e];
+      cplx v{fma(c2, b.x, -0.5 * a.x), fma(c2, b.y, -0.5 * a.y)};
+      if (i == j) v.x += 1.0;
+      Tb[e] = v;
+      acc = fma(b.x, b.x, fma(b.y, b.y, acc));
+    }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -3086,16 +3087,17 @@ __global__ __launch_bounds__(256) void refine_poly_kernel(const cplx* __restrict
   const cplx* Db = C2 + (long)blockIdx.y * c2_b0;
   const float2_t* Ds = C2s ? C2s + (long)blockIdx.y * c2s_b0 : nullptr;  // the square from the complex64 GEMM instead
   cplx* Tb = T + (long)blockIdx.y * t_b0;
-  const long total = (long)N * N;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const cplx a = Cb[e];
-    cplx b;
-    if (Ds) { const float2_t f = Ds[e]; b = cplx{(real)f.x, (real)f.y}; }
-    else b = Db[e];
-    cplx v{fma(0.5, b.x, a.x), fma(0.5, b.y, a.y)};
-    if (e / N == e % N) v.x += 1.0;
-    Tb[e] = v;
-  }
+  for (int i = blockIdx.x; i < N; i += gridDim.x)
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+      const long e = (long)i * N + j;
+      const cplx a = Cb[e];
+      cplx b;
+      if (Ds) { const float2_t f = Ds[e]; b = cplx{(real)f.x, (real)f.y}; }
+      else b = Db[e];
+      cplx v{fma(0.5, b.x, a.x), fma(0.5, b.y, a.y)};
+      if (i == j) v.x += 1.0;
+      Tb[e] = v;
+    }
 }
 
 // Final check on G = X^H X, one workgroup per trajectory, after svd_finish_kernel has ranked the columns by norm and applied the
