@@ -231,6 +231,19 @@ inline hipsim_d4 hipsim_mfma_f64_16x16x4(double a, double b, hipsim_d4 c, int, i
 }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) hipsim_mfma_f64_16x16x4(a, b, c, x, y, z)
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4 x 4 x 4 products per instruction.  Lane map found by experiment on the MI355X
+// (tools/probes/mfma_4x4x4_layout_probe.hip, gpurun_out/r05/mfma_4x4x4_layout.txt): lane l gives A[blk][i][k] with k = l >> 4,
+// blk = (l >> 2) & 3, i = l & 3, and B[blk][k][j] with the same split (j = l & 3); the result of lane l is D[blk][i][j] with
+// i = l >> 4, blk = (l >> 2) & 3, j = l & 3.
+inline double hipsim_mfma_f64_4x4x4(double a, double b, double c, int, int, int) {
+  auto x = hipsim::exchange(hipsim::bits(a), hipsim::bits(b));
+  const int lane = hipsim::cur->lane, i = lane >> 4, blk = (lane >> 2) & 3, j = lane & 3;
+  double acc = c;
+  for (int k = 0; k < 4; ++k) acc = std::fma(hipsim::unbits<double>(x[16 * k + 4 * blk + i][0]), hipsim::unbits<double>(x[16 * k + 4 * blk + j][1]), acc);
+  return acc;
+}
+#define __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, x, y, z) hipsim_mfma_f64_4x4x4(a, b, c, x, y, z)
+
 // v_mfma_f32_16x16x4_f32: same operand maps; result register v of lane l is D[4 (l >> 4) + v][l & 15] (the dtype-independent C/D map)
 typedef float hipsim_f4 __attribute__((ext_vector_type(4)));
 inline hipsim_f4 hipsim_mfma_f32_16x16x4(float a, float b, hipsim_f4 c, int, int, int) {
