@@ -1071,6 +1071,22 @@ def test_the_certified_path_of_a_trajectory_does_not_depend_on_its_batch():
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("TJM_SIM") is not None or os.environ.get("TJM_CHOL_BLOCKED") is not None, reason="child processes of the GPU run")
+def test_certificate_by_the_blocked_cholesky_kernel_gives_the_same_runs():
+    """Bonds above 128 (BASELINE config 4: chi = 256) test the positive definiteness of G_k - cut I with the blocked factorisation of a
+    working copy in global memory (chol_pd_blocked_kernel) instead of the LDS-resident one.  TJM_CHOL_BLOCKED (read once per process)
+    sends every bond of at least 8 through it: the certified-dissipation test below, at chi = 32, once more in a child process -
+    oracle rows, diagnostics, and the certified paths taken."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, TJM_CHOL_BLOCKED="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "certified_scalar_dissipation"], env=env,
+                         capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__)))
+    assert out.returncode == 0 and "2 passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("native", [False, True])
 def test_certified_scalar_dissipation_and_in_place_jumps_match_the_oracle(native):
     """Pauli-only noise at bonds above the fused kernels (chi = 32) with the default-preset threshold 1e-6: no bond comes near the

@@ -1376,6 +1376,106 @@ __global__ __launch_bounds__(256) void chol_pd_kernel(const cplx* __restrict__ E
   if (!ok && tid == 0) flag[b] = 1;
 }
 
+// The same test for bonds above 128, where the packed triangle (264 KB at 256 x 256) does not fit the LDS: a blocked right-looking
+// Cholesky factorisation of a working copy in global memory (W: the lower triangle of G - cut I, row-major, leading dimension ld), one
+// workgroup per trajectory.  Per block column of 32: the diagonal block is factored in LDS (32 sequential steps), the panel below it is
+// solved against it row by row (X = A L^-H, a thread per row, L in LDS) and staged in LDS, the trailing triangle gets X X^H taken off.
+// n^3 / 3 complex multiply-adds per matrix, 8 trips of the trailing triangle through L2 at n = 256.  Same verdict as chol_pd_kernel:
+// flag[b] = 1 at the first non-positive pivot.
+constexpr int CHB = 32;
+__global__ __launch_bounds__(1024) void chol_pd_blocked_kernel(const cplx* __restrict__ E, long e_b0, int ld, cplx* __restrict__ Wk, long w_b0,
+                                                              const int* __restrict__ chi, int chi_stride, real cut, int* __restrict__ flag,
+                                                              const int* ids) {
+  extern __shared__ real cholb_smem[];
+  cplx* sD = reinterpret_cast<cplx*>(cholb_smem);  // [CHB][CHB + 1] diagonal block
+  cplx* sX = sD + CHB * (CHB + 1);                 // [rows below][CHB + 1] solved panel
+  __shared__ real s_piv;
+  __shared__ int s_bad;
+  int b = blockIdx.x;
+  if (ids) b = ids[b];
+  const int n = chi[(long)b * chi_stride];
+  const cplx* Eb = E + (long)b * e_b0;
+  cplx* W = Wk + (long)b * w_b0;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (long e = tid; e < (long)n * n; e += nt) {  // working copy of the lower triangle, the cut off the diagonal
+    const int i = (int)(e / n), j = (int)(e % n);
+    if (j > i) continue;
+    cplx v = Eb[(long)i * ld + j];
+    if (i == j) { v.x -= cut; v.y = 0.0; }
+    W[(long)i * ld + j] = v;
+  }
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  for (int k0 = 0; k0 < n; k0 += CHB) {
+    const int kb = (n - k0 < CHB) ? n - k0 : CHB;  // columns of this block
+    const int below = n - k0 - kb;                  // rows under the diagonal block
+    for (int e = tid; e < kb * kb; e += nt) {
+      const int i = e / kb, j = e % kb;
+      sD[i * (CHB + 1) + j] = (j <= i) ? W[(long)(k0 + i) * ld + k0 + j] : cplx{0.0, 0.0};
+    }
+    __syncthreads();
+    for (int j = 0; j < kb; ++j) {  // unblocked factorisation of the diagonal block
+      if (tid == 0) s_piv = sD[j * (CHB + 1) + j].x;
+      __syncthreads();
+      const real piv = s_piv;
+      if (!(piv > real(0.0))) { if (tid == 0) s_bad = 1; break; }  // uniform (a NaN fails too)
+      const real inv = real(1.0) / sqrt(piv);
+      if (tid > j && tid < kb) { cplx& v = sD[tid * (CHB + 1) + j]; v.x *= inv; v.y *= inv; }
+      if (tid == 0) sD[j * (CHB + 1) + j] = cplx{sqrt(piv), 0.0};
+      __syncthreads();
+      for (int e = tid; e < kb * kb; e += nt) {
+        const int i = e / kb, c = e % kb;
+        if (c > j && c <= i) {
+          const cplx lij = sD[i * (CHB + 1) + j], lcj = sD[c * (CHB + 1) + j];
+          cplx& v = sD[i * (CHB + 1) + c];
+          v.x -= lij.x * lcj.x + lij.y * lcj.y;
+          v.y -= lij.y * lcj.x - lij.x * lcj.y;
+        }
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+    if (s_bad) break;
+    // panel below: row r of X solves x L^H = a, x_c = (a_c - sum_{k<c} x_k conj(L[c][k])) / L[c][c]
+    for (int r = tid; r < below; r += nt) {
+      const cplx* arow = W + (long)(k0 + kb + r) * ld + k0;
+      cplx* xr = sX + r * (CHB + 1);
+      for (int c = 0; c < kb; ++c) {
+        cplx acc = arow[c];
+        for (int k = 0; k < c; ++k) {
+          const cplx xk = xr[k], l = sD[c * (CHB + 1) + k];
+          acc.x -= xk.x * l.x + xk.y * l.y;
+          acc.y -= xk.y * l.x - xk.x * l.y;
+        }
+        const real dinv = real(1.0) / sD[c * (CHB + 1) + c].x;
+        xr[c] = cplx{acc.x * dinv, acc.y * dinv};
+      }
+    }
+    __syncthreads();
+    // trailing triangle: (i, j <= i) -= X_i . conj(X_j)
+    const long ntri = (long)below * (below + 1) / 2;
+    for (long e = tid; e < ntri; e += nt) {
+      int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+      while ((long)(i + 1) * (i + 2) / 2 <= e) ++i;
+      while ((long)i * (i + 1) / 2 > e) --i;
+      const int j = (int)(e - (long)i * (i + 1) / 2);
+      const cplx* xi = sX + i * (CHB + 1);
+      const cplx* xj = sX + j * (CHB + 1);
+      real ax = 0.0, ay = 0.0;
+      for (int k = 0; k < kb; ++k) {
+        ax += xi[k].x * xj[k].x + xi[k].y * xj[k].y;
+        ay += xi[k].y * xj[k].x - xi[k].x * xj[k].y;
+      }
+      cplx& w = W[(long)(k0 + kb + i) * ld + k0 + kb + j];
+      w.x -= ax;
+      w.y -= ay;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (s_bad && tid == 0) flag[b] = 1;
+}
+
 bool Engine::cert_gram_fits() const {
 #ifdef TJM_F32
   return false;
@@ -1384,7 +1484,9 @@ bool Engine::cert_gram_fits() const {
   if (svd_pass) return false;
   int cm = 1;
   for (int k = 0; k <= L; ++k) cm = cap[k] > cm ? cap[k] : cm;
-  return (size_t)cm * (cm + 1) / 2 * sizeof(cplx) <= 140 * 1024;
+  // up to 128: the packed triangle in LDS (chol_pd_kernel); up to 256: the blocked factorisation of a working copy (the panel of the
+  // first block column, (256 - 32) x 33 complex, and the diagonal block have to fit the LDS; the copy lives in T2)
+  return cm <= 256 && (size_t)cm * cm <= (size_t)t_b0;
 #endif
 }
 
@@ -1399,6 +1501,7 @@ int Engine::cert_pass_gram(StateSet& S, const int* ids, int nb0, double cut) {
   static std::atomic<bool> attr_set{false};
   if (!attr_set.load(std::memory_order_acquire)) {
     TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_pd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_pd_blocked_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
     attr_set.store(true, std::memory_order_release);
   }
   hipLaunchKernelGGL(fill_cplx_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, E_, cplx{1.0, 0.0}, (long)B);  // G_0 = [1] (cap[0] = 1)
@@ -1425,7 +1528,14 @@ int Engine::cert_pass_gram(StateSet& S, const int* ids, int nb0, double cut) {
     }
     std::swap(E, En);
     const size_t lds = (size_t)cb * (cb + 1) / 2 * sizeof(cplx);
-    hipLaunchKernelGGL(chol_pd_kernel, dim3(nb0), dim3(256), lds, stream, E, (long)cb * cb, cb, S.chi + i + 1, L + 1, (real)cut, cert_flag_, ids);
+    static const bool force_blocked = getenv("TJM_CHOL_BLOCKED") != nullptr;  // diagnostic: the blocked kernel at every size
+    if (lds <= 140 * 1024 && !(force_blocked && cb >= 8))
+      hipLaunchKernelGGL(chol_pd_kernel, dim3(nb0), dim3(256), lds, stream, E, (long)cb * cb, cb, S.chi + i + 1, L + 1, (real)cut, cert_flag_, ids);
+    else {
+      const size_t ldsb = ((size_t)CHB * (CHB + 1) + (size_t)(cb > CHB ? cb - CHB : 1) * (CHB + 1)) * sizeof(cplx);
+      hipLaunchKernelGGL(chol_pd_blocked_kernel, dim3(nb0), dim3(1024), ldsb, stream, E, (long)cb * cb, cb, T2, t_b0, S.chi + i + 1, L + 1, (real)cut,
+                         cert_flag_, ids);
+    }
   }
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
