@@ -9,6 +9,7 @@
 // the package never does: yaqs_amd/_lib.py knows one library, the HIP one, and fails without it.  It says nothing about speed or
 // about data races between workgroups; it checks indices, strides, control flow and arithmetic.
 #pragma once
+#define HIPSIM 1  // the kernel sources see the interpreter (tjm_common.h: TJM_GLDS16)
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -244,6 +245,15 @@ inline double hipsim_mfma_f64_4x4x4(double a, double b, double c, int, int, int)
 }
 #define __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, x, y, z) hipsim_mfma_f64_4x4x4(a, b, c, x, y, z)
 
+// global_load_lds_dwordx4: every lane's 16 bytes go from its own global address to LDS at (the wave-uniform base) + lane x 16.
+// The interpreter runs one lane at a time, so the base each lane passes must be the same for the whole wavefront (as the instruction
+// takes it from M0): lane 0's pointer is broadcast and compared.
+inline void hipsim_glds16(const void* gptr, void* lbase) {
+  auto x = hipsim::exchange((unsigned long long)(uintptr_t)lbase, 0);
+  if (x[0][0] != x[hipsim::cur->lane][0]) { fprintf(stderr, "[hipsim] global_load_lds: LDS base differs between lanes\n"); abort(); }
+  std::memcpy((char*)(uintptr_t)x[0][0] + 16 * hipsim::cur->lane, gptr, 16);
+}
+
 // v_mfma_f32_16x16x4_f32: same operand maps; result register v of lane l is D[4 (l >> 4) + v][l & 15] (the dtype-independent C/D map)
 typedef float hipsim_f4 __attribute__((ext_vector_type(4)));
 inline hipsim_f4 hipsim_mfma_f32_16x16x4(float a, float b, hipsim_f4 c, int, int, int) {
@@ -342,6 +352,8 @@ struct hipPointerAttribute_t {
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipsim error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }  // a small 'device': persistent grids stay small
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

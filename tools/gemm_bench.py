@@ -20,7 +20,8 @@ shapes = {
     "L*T  (A m-contig, B n-contig)": dict(M=384, N=512, K=384, a_rs=1, a_cs=384, b_rs=512, b_cs=1),
 }
 if len(sys.argv) > 3:  # K scan at the first shape: fixed cost per tile versus cost per k-tile
-    shapes = {f"K={k}": dict(M=512, N=384, K=k, a_rs=k, a_cs=1, b_rs=384, b_cs=1) for k in (32, 64, 128, 256, 512)}
+    ks = (int(sys.argv[3][2:]),) if sys.argv[3].startswith("K=") else (32, 64, 128, 256, 512)  # "K=512": that K alone (PMC passes)
+    shapes = {f"K={k}": dict(M=512, N=384, K=k, a_rs=k, a_cs=1, b_rs=384, b_cs=1) for k in ks}
 for name, sh in shapes.items():
     M, N, K = sh["M"], sh["N"], sh["K"]
     A = torch.randn(B, M * K, 2, dtype=torch.float64, device="cuda")

@@ -61,6 +61,15 @@ __host__ __device__ inline void cfma(cplx& acc, cplx a, cplx b) {
 
 typedef real real4 __attribute__((ext_vector_type(4)));
 
+// global_load_lds_dwordx4: 16 bytes per lane from a per-lane global address straight into LDS at (wave-uniform base) + lane x 16.
+#ifdef HIPSIM
+#define TJM_GLDS16(gptr, lbase) hipsim_glds16((const void*)(gptr), (void*)(lbase))
+#else
+#define TJM_GLDS16(gptr, lbase)                                                                             \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                   \
+                                   (__attribute__((address_space(3))) void*)(lbase), 16, 0, 0)
+#endif
+
 // ---- cross-lane moves of one `real` (device only): DPP row operations, v_readlane, the gfx950 row / half-wave swaps ----------------
 #ifdef TJM_F32
 template <int CTRL>

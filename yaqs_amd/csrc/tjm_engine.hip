@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(1024) void chol_pd_blocked_kernel(const cplx* __res
       if (!(piv > real(0.0))) { if (tid == 0) s_bad = 1; break; }  // uniform (a NaN fails too)
       const real inv = real(1.0) / sqrt(piv);
       if (tid > j && tid < kb) { cplx& v = sD[tid * (CHB + 1) + j]; v.x *= inv; v.y *= inv; }
-      if (tid == 0) sD[j * (CHB + 1) + j] = cplx{sqrt(piv), 0.0};
+      if (tid == 0) sD[j * (CHB + 1) + j] = cplx{(real)sqrt(piv), 0};
       __syncthreads();
       for (int e = tid; e < kb * kb; e += nt) {
         const int i = e / kb, c = e % kb;

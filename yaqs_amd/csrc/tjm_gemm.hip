@@ -223,6 +223,220 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
   }
 }
 
+#ifndef TJM_F32
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same product on v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks per instruction: 512 flops every 16 cycles, 75 TFLOP/s
+// measured against the 48 of v_mfma_f64_16x16x4_f64 - tools/probes/mfma_cycles_probe.hip), for shapes made of whole tiles (M, N
+// multiples of 64, K of 16).  The instruction multiplies block blk of A (rows 4 blk .. 4 blk + 3 of a 16 x 4 operand tile, lane
+// 16 k + 4 blk + i) with block blk of B (lane 16 k + 4 blk + j) into D (lane 16 i + 4 blk + j), so a 16 x 16 output tile takes four
+// instructions on the same A tile with B in four lane ARRANGEMENTS (column block (blk + r) & 3 in the lanes of block blk, r = 0..3).
+//   * Operand tiles live in LDS in the instruction's own lane order - one 16 x 4 tile = 64 lanes x 16 bytes (re, im) = 1 KiB - filled by
+//     global_load_lds_dwordx4 (one instruction per tile; the per-lane SOURCE address carries the operand's strides, so every layout of
+//     A and B is served by the same code and no staging registers are needed).  A fragment read is one ds_read_b128 at lane x 16; the
+//     arrangements of B are reads of the same tile at (lane & 48) | ((lane + 4 r) & 15).
+//   * A wavefront owns 64 rows x 16 columns: 4 A tiles x 4 arrangements x the three real products of the 3M scheme = 48 instructions
+//     and 48 accumulator registers (doubles) per k-group, fed by 8 ds_read_b128.  The four wavefronts share the A tiles.
+//   * Two k-tiles of 16 in LDS (2 x 32 KiB): the loads of tile t + 1 are in flight during the products of tile t, one barrier per tile.
+//   * Conjugation: the sums of the third product carry the signs (one fma each), Q = Ai Bi is kept raw and signed in the epilogue.
+// ------------------------------------------------------------------------------------------------------------------------------
+typedef double d2v __attribute__((ext_vector_type(2)));
+#define TJM_MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0)
+
+// Persistent: the grid is two workgroups per CU, workgroup w takes tiles w, w + grid, ...; the loop runs over (tile, k-tile) pairs so
+// that the first operand tiles of the NEXT output tile are in flight during the last products of the current one and the stores of
+// an output tile drain behind the next tile's products (at K = 128 the per-tile fixed cost was a fifth of the kernel).
+template <int ABL>  // timing ablations (wrong results): 1 no staging in the loop, 2 no barrier, 4 fragments of k-group 0 for all four, 8 no operand sums
+__global__ __launch_bounds__(256, 2) void zgemm4_kernel(GemmDesc g, int tiles_m, int tiles_n, long total_tiles, int xcd_map) {
+  // [buffer][A tiles (row group, k-group) 16 x 64 | B tiles (column group, k-group) 16 x 64], then four doubles of the dot-product
+  // epilogue (ONE array: a second LDS object beside a global_load_lds target costs a full wait per read)
+  __shared__ d2v sm[2 * 2048 + 2];
+  double* const red = reinterpret_cast<double*>(sm + 2 * 2048);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in a scalar register: the LDS targets of the loads are scalar arithmetic
+  const int li = lane & 15, lk = lane >> 4;
+  const int per = tiles_m * tiles_n;
+  const int ktiles = g.K / BK;
+  const int total = ktiles * g.nks;
+
+  // tile bookkeeping (all wave-uniform): `cur` is the tile being multiplied, `nxt` the one whose operands are being staged
+  struct Tile { long t, pos; int m0, n0, b0, b1, b2; bool mirror; };
+  auto decode = [&](long t, Tile& T) -> bool {  // false: nothing to do for tile t
+    T.t = t;
+    int z = (int)(t / per);
+    const int tt = (int)(t - (long)z * per);
+    const int tm = tt / tiles_n, tn = tt - tm * tiles_n;
+    T.b2 = z % g.nb2;
+    z /= g.nb2;
+    T.b1 = z % g.nb1;
+    T.b0 = z / g.nb1;
+    if (g.ids) T.b0 = g.ids[T.b0];
+    T.m0 = tm * BM;
+    T.n0 = tn * BN;
+    T.mirror = g.hermitian && tm != tn;
+    if (g.active && g.active[T.b0] == 0) return false;
+    if (g.hermitian && tm > tn) return false;
+    return true;
+  };
+  // Position p of this workgroup's list -> tile id.  XCD-aware: workgroups b and b + 8 share an XCD (and its 4 MiB L2), so batch
+  // entry z goes to the workgroups with b % 8 == z % 8 and the 64 of them walk its tiles together - an entry's operands (1 - 2 MB)
+  // are then re-read from ONE L2; dealt flat, the tiles of ten entries are in flight on every XCD at once.  Speed only.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  auto tile_at = [&](long pos) -> long {
+    if (!xcd_map) return blockIdx.x + pos * (long)gridDim.x;
+    const long u = slot + pos * (long)nslots;
+    const long zl = u / per;
+    return (zl * 8 + xcd) * per + (u - zl * per);
+  };
+  auto next_valid = [&](long pos, Tile& T) -> bool {
+    for (;; ++pos) {
+      const long t = tile_at(pos);
+      if (t >= total_tiles) break;
+      if (decode(t, T)) { T.pos = pos; return true; }
+    }
+    T.t = total_tiles;
+    return false;
+  };
+  Tile cur, nxt;
+  if (!next_valid(0, cur)) return;
+
+  // Staging.  This wavefront fills the A tiles of row group `wave` and the B tiles of column group `wave`: per k-tile four pieces
+  // (k-groups) of each, one global_load_lds_dwordx4 per piece.  `ap` / `bp` point at piece 0 of the k-tile to be staged next; the
+  // per-lane part of the address is fixed, everything that moves is scalar.
+  const long a_lane = (long)(16 * wave + li) * g.a_rs + (long)lk * g.a_cs;
+  const long b_lane = (long)lk * g.b_rs + (long)(16 * wave + li) * g.b_cs;
+  const long a_kg = 4 * g.a_cs, b_kg = 4 * g.b_rs;          // k-group step (elements)
+  const long a_kt = BK * g.a_cs, b_kt = BK * g.b_rs;        // k-tile step
+  const long a_wrap = g.a_ks - (long)ktiles * a_kt + a_kt;  // ... from the last k-tile of one k-split term to the first of the next
+  const long b_wrap = g.b_ks - (long)ktiles * b_kt + b_kt;
+  const cplx* ap;
+  const cplx* bp;
+  int kt_st = 0;  // k-tile (inside its k-split term) that ap / bp point at
+  auto set_sources = [&](const Tile& T) {
+    ap = g.A + ((long)T.b0 * g.a_b0 + (long)T.b1 * g.a_b1 + (long)T.b2 * g.a_b2 + (long)T.m0 * g.a_rs) + a_lane;
+    bp = g.B + ((long)T.b0 * g.b_b0 + (long)T.b1 * g.b_b1 + (long)T.b2 * g.b_b2 + (long)T.n0 * g.b_cs) + b_lane;
+    kt_st = 0;
+  };
+  auto stage_piece = [&](int kg, int buf) {
+    d2v* dst = sm + buf * 2048 + wave * 256 + kg * 64;
+    TJM_GLDS16(ap + kg * a_kg, dst);
+    TJM_GLDS16(bp + kg * b_kg, dst + 1024);
+  };
+  auto advance = [&]() {
+    if (++kt_st == ktiles) { kt_st = 0; ap += a_wrap; bp += b_wrap; }
+    else { ap += a_kt; bp += b_kt; }
+  };
+  double accP[4][4], accQ[4][4], accS[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { accP[i][r] = 0.0; accQ[i][r] = 0.0; accS[i][r] = 0.0; }
+  const double sgnA = g.conjA ? -1.0 : 1.0, sgnB = g.conjB ? -1.0 : 1.0;
+  const double sq = sgnA * sgnB;
+  const int blk = (lane >> 2) & 3, lj = lane & 3;
+  int boff[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) boff[r] = 1024 + wave * 256 + ((lane & 48) | ((lane + 4 * r) & 15));
+
+  set_sources(cur);
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) stage_piece(kg, 0);
+  advance();
+  __syncthreads();
+  int it = 0, buf = 0;
+  long dot_slot = -1;
+  for (;;) {
+    // what is staged during this k-tile's products: the tile's next k-tile, or the first one of the workgroup's next tile
+    const bool last = it + 1 == total;
+    bool pending = true, have_next = true;
+    if (last) {
+      have_next = next_valid(cur.pos + 1, nxt);
+      pending = have_next;
+      if (have_next) set_sources(nxt);
+    } else if (ABL & 1) pending = false;
+    const d2v* sb = sm + buf * 2048;
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      d2v a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = sb[(i * 4 + ((ABL & 4) ? 0 : kg)) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[r] = sb[boff[r] + ((ABL & 4) ? 0 : kg) * 64];
+      if (pending) stage_piece(kg, buf ^ 1);  // two loads per k-group: spread over the k-tile, they never queue up in front of the products
+      double as[4], bs[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) as[i] = (ABL & 8) ? a[i].x : fma(sgnA, a[i].y, a[i].x);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[r] = (ABL & 8) ? b[r].y : fma(sgnB, b[r].y, b[r].x);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accP[i][r] = TJM_MFMA4(a[i].x, b[r].x, accP[i][r]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accQ[i][r] = TJM_MFMA4(a[i].y, b[r].y, accQ[i][r]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accS[i][r] = TJM_MFMA4(as[i], bs[r], accS[i][r]);
+    }
+    if (pending) advance();
+    if (last) {
+      // epilogue of tile `cur`: lane l of accumulator (i, r) is row 16 i + 4 blk + (l >> 4), column 4 ((blk + r) & 3) + (l & 3).
+      // (Issuing the stores behind the barrier below - its vmcnt(0) also counts stores - was measured: no gain, 64 more registers.)
+      cplx* __restrict__ Cb = g.C + (long)cur.b0 * g.c_b0 + (long)cur.b1 * g.c_b1 + (long)cur.b2 * g.c_b2;
+      const cplx* __restrict__ Db = g.dot_part ? g.dot_with + (long)cur.b0 * g.c_b0 + (long)cur.b1 * g.c_b1 + (long)cur.b2 * g.c_b2 : nullptr;
+      double dot_acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = cur.m0 + 16 * i + 4 * blk + lk;
+          const int n = cur.n0 + 16 * wave + 4 * ((blk + r) & 3) + lj;
+          cplx v;
+          v.x = accP[i][r] - sq * accQ[i][r];
+          v.y = accS[i][r] - accP[i][r] - sq * accQ[i][r];
+          accP[i][r] = 0.0; accQ[i][r] = 0.0; accS[i][r] = 0.0;
+          if (g.accumulate != 0) {
+            const cplx old = Cb[(long)m * g.c_rs + n];
+            v.x = (g.accumulate > 0) ? old.x + v.x : old.x - v.x;
+            v.y = (g.accumulate > 0) ? old.y + v.y : old.y - v.y;
+          }
+          Cb[(long)m * g.c_rs + n] = v;
+          if (Db) {
+            const cplx u = Db[(long)m * g.c_rs + n];
+            dot_acc = fma(u.x, v.x, dot_acc);
+            dot_acc = fma(u.y, v.y, dot_acc);
+          }
+          if (cur.mirror) Cb[(long)n * g.c_rs + m] = cplx{v.x, -v.y};
+        }
+      if (g.dot_part) {  // the workgroup's share of Re <dot_with, C>: lanes by shuffles, wavefronts through LDS in a fixed order
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dot_acc += __shfl_down(dot_acc, o, 64);
+        if (lane == 0) red[wave] = dot_acc;
+        const int z = (int)(cur.t / per);
+        dot_slot = (long)cur.b0 * g.dot_ld + (long)(z % (g.nb1 * g.nb2)) * per + (cur.t - (long)z * per);
+      }
+      if (!have_next) break;
+      cur = nxt;
+      it = 0;
+    } else {
+      ++it;
+    }
+    buf ^= 1;
+    if (!(ABL & 2)) __syncthreads();  // the staged loads have landed (vmcnt) and every wavefront is done with the buffer just multiplied
+    if (dot_slot >= 0) {  // (the next tile's partial sums are written at least one barrier later)
+      if (tid == 0) g.dot_part[dot_slot] = (red[0] + red[1]) + (red[2] + red[3]);
+      dot_slot = -1;
+    }
+  }
+  if (dot_slot >= 0) {
+    __syncthreads();
+    if (tid == 0) g.dot_part[dot_slot] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+#endif  // !TJM_F32
+
 // Row order of a wavefront's 16 rows in heff_stage12_kernel: chosen per arithmetic type so that the four accumulator registers of a
 // lane hold every physical index p of its bond value(s) (TJM_ACC_ROW: fp64 register v = row (l >> 4) + 4 v, fp32 = row 4 (l >> 4) + v).
 #ifdef TJM_F32
@@ -250,7 +464,7 @@ template <int P> __device__ inline int s12_aloc(int lk, int ai) { return (P == 4
 // that T1 cost on its way through HBM (and the launch of the MPO stage) are gone.
 // ------------------------------------------------------------------------------------------------------------------------------
 template <int P, int NCH>
-__global__ __launch_bounds__(256, 2) void heff_stage12_kernel(HeffStage12Desc d) {
+__global__ __launch_bounds__(256, 2) void heff_stage12_kernel(HeffStage12Desc d, int tiles, int xcd_map) {
   __shared__ real sAr[BK * PITCH];
   __shared__ real sAi[BK * PITCH];
   __shared__ real sBr[BK * PITCH];
@@ -261,12 +475,20 @@ __global__ __launch_bounds__(256, 2) void heff_stage12_kernel(HeffStage12Desc d)
   constexpr int APW = 16 / P;    // ... per wavefront
   constexpr int BT = 64 / NCH;   // bond values of the column tile
   constexpr int CPT = 4 / NCH;   // MFMA column tiles per channel
-  int b0 = blockIdx.y;
+  // XCD-aware order (1-D grid): workgroups w and w + 8 share an XCD and its L2, so the tiles of one trajectory - which all read the
+  // same x (1 MB) and R (0.8 MB) - go to workgroups of equal w % 8; dealt in launch order, tile t of EVERY trajectory lands on XCD t % 8.
+  int b0 = blockIdx.y, tile = blockIdx.x;
+  if (xcd_map) {
+    const int q = blockIdx.x >> 3;
+    tile = q % tiles;
+    b0 = (q / tiles) * 8 + (blockIdx.x & 7);
+    if (b0 >= d.nb0) return;
+  }
   if (d.ids) b0 = d.ids[b0];
   if (d.active && d.active[b0] == 0) return;
   const int ca = d.ca, cb = d.cb, Dl = d.Dl, Dr = d.Dr, rch = d.rch;
   const int tiles_b = (cb + BT - 1) / BT;
-  const int a0 = (blockIdx.x / tiles_b) * AT, B0 = (blockIdx.x % tiles_b) * BT;
+  const int a0 = (tile / tiles_b) * AT, B0 = (tile % tiles_b) * BT;
   const cplx* __restrict__ xb = d.x + (long)b0 * d.x_b0;
   const cplx* __restrict__ Rb = d.R + (long)b0 * d.r_b0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -519,6 +741,33 @@ int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
   if (gy > 65535) return TJM_ERR_ARG;
   dim3 grid(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN), (unsigned)gy, (unsigned)gz);
   dim3 block(256);
+#ifndef TJM_F32
+  static const bool mfma4 = getenv("TJM_GEMM_16X16") == nullptr;  // A/B switch: the 16 x 16 x 4 kernel for every shape
+  if (mfma4 && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0) {
+    static int slots = 0;  // two resident workgroups per CU (64 KiB of LDS, <= 256 registers)
+    if (slots == 0) {
+      int dev = 0, cus = 0;
+      TJM_HIP_CHECK(hipGetDevice(&dev));
+      TJM_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      slots = 2 * (cus > 0 ? cus : 256);
+    }
+    const int tiles_m = g.M / BM, tiles_n = g.N / BN;
+    const long total_tiles = (long)tiles_m * tiles_n * batches;
+    static const bool flat = getenv("TJM_GEMM_FLAT_TILES") != nullptr;
+    const int xcd_map = (!flat && batches >= 16 && total_tiles >= slots && slots % 8 == 0) ? 1 : 0;
+    const unsigned nwg = (unsigned)(total_tiles < slots ? total_tiles : slots);
+    static const int abl = getenv("TJM_GEMM_ABL") ? atoi(getenv("TJM_GEMM_ABL")) : 0;
+#define TJM_Z4(A) hipLaunchKernelGGL(zgemm4_kernel<A>, dim3(nwg), block, 0, stream, g, tiles_m, tiles_n, total_tiles, xcd_map)
+    switch (abl) {
+      case 1: TJM_Z4(1); break; case 2: TJM_Z4(2); break; case 3: TJM_Z4(3); break; case 4: TJM_Z4(4); break;
+      case 7: TJM_Z4(7); break; case 8: TJM_Z4(8); break; case 15: TJM_Z4(15); break;
+      default: TJM_Z4(0);
+    }
+#undef TJM_Z4
+    TJM_HIP_CHECK(hipGetLastError());
+    return TJM_OK;
+  }
+#endif
   const bool am = (g.a_rs == 1 && g.a_cs != 1);
   const bool bn = (g.b_cs == 1);
   static const bool swizzled = getenv("TJM_GEMM_SWIZZLED_LDS") != nullptr;  // diagnostic: the k-major layout for every operand
@@ -550,8 +799,12 @@ int launch_heff_stage12(const HeffStage12Desc& d, hipStream_t stream) {
   if (d.nb0 <= 0) return TJM_OK;
   const int nch = d.Dr - 1;
   const int AT = 64 / d.P, BT = 64 / nch;
-  dim3 grid(((d.ca + AT - 1) / AT) * ((d.cb + BT - 1) / BT), d.nb0);
-#define TJM_S12(PP, NN) hipLaunchKernelGGL((heff_stage12_kernel<PP, NN>), grid, dim3(256), 0, stream, d)
+  const int tiles = ((d.ca + AT - 1) / AT) * ((d.cb + BT - 1) / BT);
+  static const bool flat = getenv("TJM_GEMM_FLAT_TILES") != nullptr;
+  const int xcd_map = (!flat && d.nb0 >= 16 && (long)tiles * ((d.nb0 + 7) / 8 * 8) < (1L << 31)) ? 1 : 0;
+  dim3 grid(tiles, d.nb0);
+  if (xcd_map) grid = dim3((unsigned)(tiles * ((d.nb0 + 7) / 8 * 8)), 1);
+#define TJM_S12(PP, NN) hipLaunchKernelGGL((heff_stage12_kernel<PP, NN>), grid, dim3(256), 0, stream, d, tiles, xcd_map)
   if (d.P == 4) {
     if (nch == 1) TJM_S12(4, 1); else if (nch == 2) TJM_S12(4, 2); else TJM_S12(4, 4);
   } else {
