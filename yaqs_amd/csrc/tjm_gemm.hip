@@ -245,17 +245,20 @@ typedef double d2v __attribute__((ext_vector_type(2)));
 // Persistent: the grid is two workgroups per CU, workgroup w takes tiles w, w + grid, ...; the loop runs over (tile, k-tile) pairs so
 // that the first operand tiles of the NEXT output tile are in flight during the last products of the current one and the stores of
 // an output tile drain behind the next tile's products (at K = 128 the per-tile fixed cost was a fifth of the kernel).
-template <int ABL>  // timing ablations (wrong results): 1 no staging in the loop, 2 no barrier, 4 fragments of k-group 0 for all four, 8 no operand sums
-__global__ __launch_bounds__(256, 2) void zgemm4_kernel(GemmDesc g, int tiles_m, int tiles_n, long total_tiles, int xcd_map) {
+// KG = k-groups of 4 per staged k-tile: 4 (k-tiles of 16, 64 KiB of LDS, two workgroups per CU) or 2 (k-tiles of 8, 32 KiB, THREE workgroups
+// per CU inside 168 registers: a barrier every 96 products instead of 192, but three wavefronts per SIMD to fill each other's stalls).
+template <int ABL, int KG>  // ABL: timing ablations (wrong results): 1 no staging in the loop, 2 no barrier, 4 fragments of k-group 0 for all, 8 no operand sums
+__global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g, int tiles_m, int tiles_n, long total_tiles, int xcd_map) {
   // [buffer][A tiles (row group, k-group) 16 x 64 | B tiles (column group, k-group) 16 x 64], then four doubles of the dot-product
   // epilogue (ONE array: a second LDS object beside a global_load_lds target costs a full wait per read)
-  __shared__ d2v sm[2 * 2048 + 2];
-  double* const red = reinterpret_cast<double*>(sm + 2 * 2048);
+  constexpr int SB = 512 * KG, HB = 256 * KG, WB = 64 * KG, BK4 = 4 * KG;  // doubles-pairs per buffer / offset of the B tiles / per wavefront; k per tile
+  __shared__ d2v sm[2 * SB + 2];
+  double* const red = reinterpret_cast<double*>(sm + 2 * SB);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in a scalar register: the LDS targets of the loads are scalar arithmetic
   const int li = lane & 15, lk = lane >> 4;
   const int per = tiles_m * tiles_n;
-  const int ktiles = g.K / BK;
+  const int ktiles = g.K / BK4;
   const int total = ktiles * g.nks;
 
   // tile bookkeeping (all wave-uniform): `cur` is the tile being multiplied, `nxt` the one whose operands are being staged
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void zgemm4_kernel(GemmDesc g, int tiles_m,
   const long a_lane = (long)(16 * wave + li) * g.a_rs + (long)lk * g.a_cs;
   const long b_lane = (long)lk * g.b_rs + (long)(16 * wave + li) * g.b_cs;
   const long a_kg = 4 * g.a_cs, b_kg = 4 * g.b_rs;          // k-group step (elements)
-  const long a_kt = BK * g.a_cs, b_kt = BK * g.b_rs;        // k-tile step
+  const long a_kt = BK4 * g.a_cs, b_kt = BK4 * g.b_rs;        // k-tile step
   const long a_wrap = g.a_ks - (long)ktiles * a_kt + a_kt;  // ... from the last k-tile of one k-split term to the first of the next
   const long b_wrap = g.b_ks - (long)ktiles * b_kt + b_kt;
   const cplx* ap;
@@ -317,9 +320,9 @@ __global__ __launch_bounds__(256, 2) void zgemm4_kernel(GemmDesc g, int tiles_m,
     kt_st = 0;
   };
   auto stage_piece = [&](int kg, int buf) {
-    d2v* dst = sm + buf * 2048 + wave * 256 + kg * 64;
+    d2v* dst = sm + buf * SB + wave * WB + kg * 64;
     TJM_GLDS16(ap + kg * a_kg, dst);
-    TJM_GLDS16(bp + kg * b_kg, dst + 1024);
+    TJM_GLDS16(bp + kg * b_kg, dst + HB);
   };
   auto advance = [&]() {
     if (++kt_st == ktiles) { kt_st = 0; ap += a_wrap; bp += b_wrap; }
@@ -335,11 +338,11 @@ __global__ __launch_bounds__(256, 2) void zgemm4_kernel(GemmDesc g, int tiles_m,
   const int blk = (lane >> 2) & 3, lj = lane & 3;
   int boff[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) boff[r] = 1024 + wave * 256 + ((lane & 48) | ((lane + 4 * r) & 15));
+  for (int r = 0; r < 4; ++r) boff[r] = HB + wave * WB + ((lane & 48) | ((lane + 4 * r) & 15));
 
   set_sources(cur);
 #pragma unroll
-  for (int kg = 0; kg < 4; ++kg) stage_piece(kg, 0);
+  for (int kg = 0; kg < KG; ++kg) stage_piece(kg, 0);
   advance();
   __syncthreads();
   int it = 0, buf = 0;
@@ -353,12 +356,12 @@ __global__ __launch_bounds__(256, 2) void zgemm4_kernel(GemmDesc g, int tiles_m,
       pending = have_next;
       if (have_next) set_sources(nxt);
     } else if (ABL & 1) pending = false;
-    const d2v* sb = sm + buf * 2048;
+    const d2v* sb = sm + buf * SB;
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
+    for (int kg = 0; kg < KG; ++kg) {
       d2v a[4], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = sb[(i * 4 + ((ABL & 4) ? 0 : kg)) * 64 + lane];
+      for (int i = 0; i < 4; ++i) a[i] = sb[(i * KG + ((ABL & 4) ? 0 : kg)) * 64 + lane];
 #pragma unroll
       for (int r = 0; r < 4; ++r) b[r] = sb[boff[r] + ((ABL & 4) ? 0 : kg) * 64];
       if (pending) stage_piece(kg, buf ^ 1);  // two loads per k-group: spread over the k-tile, they never queue up in front of the products
@@ -743,8 +746,8 @@ int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
   dim3 block(256);
 #ifndef TJM_F32
   static const bool mfma4 = getenv("TJM_GEMM_16X16") == nullptr;  // A/B switch: the 16 x 16 x 4 kernel for every shape
-  if (mfma4 && g.M % BM == 0 && g.N % BN == 0 && g.K % BK == 0) {
-    static int slots = 0;  // two resident workgroups per CU (64 KiB of LDS, <= 256 registers)
+  if (mfma4 && g.M % BM == 0 && g.N % BN == 0 && g.K % 8 == 0) {
+    static int slots = 0, slots3 = 0;  // two resident workgroups per CU (64 KiB of LDS, <= 256 registers)
     if (slots == 0) {
       int dev = 0, cus = 0;
       TJM_HIP_CHECK(hipGetDevice(&dev));
@@ -755,12 +758,17 @@ int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
     const long total_tiles = (long)tiles_m * tiles_n * batches;
     static const bool flat = getenv("TJM_GEMM_FLAT_TILES") != nullptr;
     const int xcd_map = (!flat && batches >= 16 && total_tiles >= slots && slots % 8 == 0) ? 1 : 0;
-    const unsigned nwg = (unsigned)(total_tiles < slots ? total_tiles : slots);
     static const int abl = getenv("TJM_GEMM_ABL") ? atoi(getenv("TJM_GEMM_ABL")) : 0;
-#define TJM_Z4(A) hipLaunchKernelGGL(zgemm4_kernel<A>, dim3(nwg), block, 0, stream, g, tiles_m, tiles_n, total_tiles, xcd_map)
+    static const int kgenv = getenv("TJM_GEMM_KG") ? atoi(getenv("TJM_GEMM_KG")) : 4;
+    const int kg = (kgenv == 2 || g.K % 16 != 0) ? 2 : 4;
+    if (kg == 2 && slots3 == 0) slots3 = slots / 2 * 3;
+    const int use_slots = kg == 2 ? slots3 : slots;
+    const unsigned nwg2 = (unsigned)(total_tiles < use_slots ? total_tiles : use_slots);
+    const int xm = (xcd_map && total_tiles >= use_slots) ? 1 : 0;
+#define TJM_Z4(A) do { if (kg == 2) hipLaunchKernelGGL((zgemm4_kernel<A, 2>), dim3(nwg2), block, 0, stream, g, tiles_m, tiles_n, total_tiles, xm); \
+                       else hipLaunchKernelGGL((zgemm4_kernel<A, 4>), dim3(nwg2), block, 0, stream, g, tiles_m, tiles_n, total_tiles, xm); } while (0)
     switch (abl) {
-      case 1: TJM_Z4(1); break; case 2: TJM_Z4(2); break; case 3: TJM_Z4(3); break; case 4: TJM_Z4(4); break;
-      case 7: TJM_Z4(7); break; case 8: TJM_Z4(8); break; case 15: TJM_Z4(15); break;
+      case 1: TJM_Z4(1); break; case 2: TJM_Z4(2); break; case 15: TJM_Z4(15); break;
       default: TJM_Z4(0);
     }
 #undef TJM_Z4

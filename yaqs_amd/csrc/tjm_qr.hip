@@ -507,18 +507,26 @@ __global__ __launch_bounds__(256) void qr_block_apply_kernel(const cplx* __restr
 template <int MAXT>
 __global__ __launch_bounds__(256) void qr_block_apply_multi_kernel(const cplx* __restrict__ Vb, long v_b0, const cplx* __restrict__ Tb, long t_b0,
                                                                   int p_first, int p_step, int np, int zr, int t_herm, cplx* __restrict__ C,
-                                                                  long c_b0, int col0, int nc, const int* ids, int row_lo, int pitch) {
+                                                                  long c_b0, int col0, int nc, const int* ids, int row_lo, int pitch, int nb0, int xcd_map) {
   extern __shared__ real smem[];
   cplx* sC = reinterpret_cast<cplx*>(smem);   // [PW][pitch]
   cplx* sPart = sC + PW * pitch;              // [4][PW * PW] partial sums of the four wavefronts
   cplx* sW1 = sPart + 4 * PW * PW;            // (i, c)
   cplx* sW2 = sW1 + PW * PW;
   cplx* sTm = sW2 + PW * PW;
-  int b = blockIdx.y;
+  // XCD-aware order (1-D grid): the column chunks of one matrix all read its reflector blocks, so they go to workgroups of equal
+  // blockIdx % 8 - one XCD, one L2 (dealt in launch order, chunk c of every matrix sits on XCD c % 8)
+  int b = blockIdx.y, chunk = blockIdx.x;
+  if (xcd_map) {
+    const int nchunks = (nc + PW - 1) / PW, q = blockIdx.x >> 3;
+    chunk = q % nchunks;
+    b = (q / nchunks) * 8 + (blockIdx.x & 7);
+    if (b >= nb0) return;
+  }
   if (ids) b = ids[b];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c0 = col0 + blockIdx.x * PW;
-  const int ncw = (nc - blockIdx.x * PW < PW) ? nc - blockIdx.x * PW : PW;
+  const int c0 = col0 + chunk * PW;
+  const int ncw = (nc - chunk * PW < PW) ? nc - chunk * PW : PW;
   cplx* Cb = C + (long)b * c_b0;
   const int nrows = zr - row_lo;
   const int li = lane & 15, lk = lane >> 4;
@@ -795,12 +803,16 @@ int apply_block_reflectors(const QrWorkspace& q, int zr, int p_first, int p_step
   const int row_lo = PW * (p_first < p_last ? p_first : p_last);
   const int nrows = zr - row_lo;
   if (nrows > 512) return TJM_ERR_NOT_IMPLEMENTED;  // (multi_group keeps the chunk within 80 KB: never reached)
+  static const bool flat = getenv("TJM_GEMM_FLAT_TILES") != nullptr;
+  const int nchunks = (nc + PW - 1) / PW;
+  const int xcd_map = (!flat && nb0 >= 16) ? 1 : 0;
+  const dim3 grid = xcd_map ? dim3((unsigned)(nchunks * ((nb0 + 7) / 8 * 8)), 1) : dim3(nchunks, nb0);
   if (nrows <= 256)
-    hipLaunchKernelGGL(qr_block_apply_multi_kernel<4>, dim3((nc + PW - 1) / PW, nb0), dim3(256), multi_lds_bytes(nrows), s, q.V, q.v_b0, q.T, q.t_b0, p_first,
-                       p_step, np, zr, t_herm ? 1 : 0, C, c_b0, col0, nc, ids, row_lo, multi_pitch(nrows));
+    hipLaunchKernelGGL(qr_block_apply_multi_kernel<4>, grid, dim3(256), multi_lds_bytes(nrows), s, q.V, q.v_b0, q.T, q.t_b0, p_first,
+                       p_step, np, zr, t_herm ? 1 : 0, C, c_b0, col0, nc, ids, row_lo, multi_pitch(nrows), nb0, xcd_map);
   else
-    hipLaunchKernelGGL(qr_block_apply_multi_kernel<8>, dim3((nc + PW - 1) / PW, nb0), dim3(256), multi_lds_bytes(nrows), s, q.V, q.v_b0, q.T, q.t_b0, p_first,
-                       p_step, np, zr, t_herm ? 1 : 0, C, c_b0, col0, nc, ids, row_lo, multi_pitch(nrows));
+    hipLaunchKernelGGL(qr_block_apply_multi_kernel<8>, grid, dim3(256), multi_lds_bytes(nrows), s, q.V, q.v_b0, q.T, q.t_b0, p_first,
+                       p_step, np, zr, t_herm ? 1 : 0, C, c_b0, col0, nc, ids, row_lo, multi_pitch(nrows), nb0, xcd_map);
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
