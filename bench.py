@@ -260,13 +260,14 @@ def pmc_traffic(L, chi, B, kernel_tag):
     FETCH_SIZE and WRITE_SIZE runs of this script, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters
     cannot be read from inside the timed run: the number comes from a profile, is only reported for the configuration and the kernel
     (``kernel_tag``: "tjm32" = the complex64 instance, "tjm::" = the fp64 one) it was collected on, and the source says so."""
-    for name in ("r05_pmc_traffic_quad64.json", "r04_pmc_traffic_c64q.json", "r04_pmc_traffic_c64.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic_zgemm4.json", "r05_pmc_traffic_quad64.json", "r04_pmc_traffic_c64q.json", "r04_pmc_traffic_c64.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
         except OSError:
             continue
-        if (rec.get("L"), rec.get("chi")) != (L, chi) or (kernel_tag == "tjm32") != ("tjm32" in rec.get("kernel", "")):
+        if (rec.get("L"), rec.get("chi")) != (L, chi) or (kernel_tag == "tjm32") != ("tjm32" in rec.get("kernel", "")) or \
+                (kernel_tag == "zgemm4") != ("zgemm4" in rec.get("kernel", "")):
             continue
         # a launch covers the trajectories of ONE engine: scale the per-launch bytes of the collection run to that many
         scale = float(B) / float(rec.get("batch") or B)
@@ -666,7 +667,8 @@ def main():
     stats0 = [e.stats() for e in engines]
     for e in engines:
         e.profile(True)
-    lib.tjm_profile_cross_kernel(8)  # bracket every 8th launch of the dominant kernel with HIP events on its engine's stream
+    lib.tjm_profile_cross_kernel(8)  # bracket every 8th launch of the Jacobi tile kernels with HIP events on their engine's stream
+    lib.tjm_profile_gemm(8)          # ... and of the fp64 GEMM kernel (zgemm4_kernel; executed tiles counted on the device)
     jw = np.zeros(4)
     lib.tjm_svd_work_read(jw.ctypes.data, 1)  # reset the executed-work counters of the tiled Jacobi kernels
     mx = np.zeros(10)
@@ -692,6 +694,9 @@ def main():
     ms32, nb32, ns32 = C.c_double(0), C.c_double(0), C.c_int64(0)
     lib.tjm_profile_cross_kernel_read_c64(C.byref(ms32), C.byref(nb32), C.byref(ns32))  # the complex64 instance (mixed-precision split)
     lib.tjm_profile_cross_kernel(0)
+    gp = np.zeros(6)
+    lib.tjm_profile_gemm_read(gp.ctypes.data)
+    lib.tjm_profile_gemm(0)
     lib.tjm_svd_work_read(jw.ctypes.data, 0)
     lib.tjm_svd_mixed_read(mx.ctypes.data, 0)
 
@@ -704,6 +709,7 @@ def main():
         lib.tjm_svd_work_read(jw_i.ctypes.data, 1)
         lib.tjm_svd_mixed_read(mx_i.ctypes.data, 1)
         lib.tjm_profile_cross_kernel(1)
+        lib.tjm_profile_gemm(1)
         torch.cuda.synchronize()
         t_i = time.perf_counter()
         drives[0].run(1, False)
@@ -716,9 +722,14 @@ def main():
         ms32_i, nb32_i, ns32_i = C.c_double(0), C.c_double(0), C.c_int64(0)
         lib.tjm_profile_cross_kernel_read_c64(C.byref(ms32_i), C.byref(nb32_i), C.byref(ns32_i))
         lib.tjm_profile_cross_kernel(0)
+        gp_i = np.zeros(6)
+        lib.tjm_profile_gemm_read(gp_i.ctypes.data)
+        lib.tjm_profile_gemm(0)
         lib.tjm_svd_work_read(jw_i.ctypes.data, 0)
         lib.tjm_svd_mixed_read(mx_i.ctypes.data, 0)
         iso = {"step_s": t_i, "trajectories": drives[0].nb,
+               # one 64 x 64 output tile x one unit of K = 3 real matrix-core products x 2 flops x 64 x 64 (three-product complex multiplication)
+               "gemm": {"ms": float(gp_i[0]), "samples": int(gp_i[1]), "launches": int(gp_i[2]), "bytes": float(gp_i[4]), "flops": 6.0 * 64 * 64 * float(gp_i[3])},
                "f64": {"ms": ms_i.value, "samples": int(ns_i.value), "bytes": nb_i.value, "flops": 28.0 * float(jw_i[0])},
                "c64": {"ms": ms32_i.value, "samples": int(ns32_i.value), "bytes": nb32_i.value, "flops": 28.0 * float(mx_i[6])}}
 
@@ -777,8 +788,18 @@ def main():
         k32 = {"ms": ms32.value, "samples": int(ns32.value), "bytes": nb32.value, "flops": flops_jac32, "peak": peak32, "bound": "fp32-valu",
                "name": "tjm32::jacobi_quad64_kernel (complex64 phase of the mixed-precision two-site split: four 16-column blocks per workgroup, three "
                        "tournament rounds per load; tjm32::jacobi_cross16q_kernel - one round per load - for sizes other than 256 columns)"}
-        dom = k32 if k32["ms"] > k64["ms"] else k64
         k64["iso"], k32["iso"] = (iso["f64"], iso["c64"]) if iso else (None, None)
+        # the fp64 GEMM kernel (every product of whole 64 x 64 x 16 tiles: Krylov, environments, the fp64 phase of the two-site split);
+        # flops of the sampled launches = device-counted flops of all launches x sampled / all
+        kgm = {"ms": float(gp[0]), "samples": int(gp[1]), "bytes": float(gp[4]), "flops": 6.0 * 64 * 64 * float(gp[3]) * (gp[1] / gp[2] if gp[2] else 0.0) * 8.0,
+               "peak": peak64, "bound": "mfma",
+               "name": "tjm::zgemm4_kernel (batched complex128 GEMM on v_mfma_f64_4x4x4_4b_f64: persistent workgroups, operand tiles staged by "
+                       "global_load_lds in the instruction's lane order, three real products per complex one; serves the H_eff / environment "
+                       "products and the fp64 phase of the two-site split)",
+               "iso": iso["gemm"] if iso else None}
+        # dominant kernel = the one with the largest summed launch time in the isolated one-engine step (every launch of the three bracketed)
+        iso_ms = lambda kk: (kk.get("iso") or {}).get("ms", 0.0) if kk.get("iso") else kk["ms"]  # noqa: E731
+        dom = max((k32, k64, kgm), key=iso_ms) if not f32 else k64
 
         def kernel_line(kk):
             if not kk["samples"]:
@@ -794,6 +815,8 @@ def main():
             line = {"name": kk["name"], "bound": kk["bound"], "avg_launch_us_overlapped": avg_us, "launches_sampled_overlapped": kk["samples"],
                     "executed_TFLOPs_overlapped_x_stream_overlap": rate, "executed_TFLOPs_per_launch_duration_overlapped": raw, "peak_TFLOPs": kk["peak"],
                     "frac_overlapped": frac(raw, kk["peak"]), "frac_overlapped_x_stream_overlap": frac(rate, kk["peak"])}
+            if kk["bound"] == "mfma":
+                line["frac_of_matrix_peak_overlapped"] = line["frac_overlapped"]
             io = kk.get("iso")
             if io and io["samples"] and io["flops"]:
                 # the measurement: one engine alone on the device, every launch bracketed - flops of all launches / their summed duration
@@ -806,10 +829,12 @@ def main():
                              "tile_bytes_GBps": gbs_i, "frac_of_hbm_peak": gbs_i / HBM_PEAK_GBS, "flop_per_byte": ai, "ridge_flop_per_byte": ridge,
                              "bound_by_arithmetic_intensity": ("hbm" if (ai is not None and ai < ridge) else kk["bound"]),
                              "frac": max(tfl / kk["peak"], gbs_i / HBM_PEAK_GBS)})
+                if kk["bound"] == "mfma":
+                    line["frac_of_matrix_peak"] = line.pop("frac_of_vector_peak")
             return line
 
         dom_line = kernel_line(dom)
-        traffic, traffic_src = pmc_traffic(L, chi, sizes[0], "tjm32" if dom is k32 else "tjm::")
+        traffic, traffic_src = pmc_traffic(L, chi, sizes[0], "zgemm4" if dom is kgm else ("tjm32" if dom is k32 else "tjm::"))
         alg_bytes_per_launch = (dom["bytes"] / dom["samples"]) if dom["samples"] else None
         svd_exec_tf = tf(flops_jac64 + flops_jac32 + flops_mixgemm, cls_ms["svd"])
         kry_exec_tf = tf(flops_kry_exec, cls_ms["krylov"])
@@ -856,23 +881,34 @@ def main():
             "mean_Z_site0": float(zsum[0] / total_traj),
             # ---- roofline of the dominant kernel, EXECUTED work: flops counted on the device / (launches x sampled launch duration)
             "roofline": {
-                "bound": (dom_line or {}).get("bound_by_arithmetic_intensity", dom["bound"]),
+                "bound": (dom_line or {}).get("bound_by_arithmetic_intensity", dom["bound"]),  # "mfma" | "hbm" | "fp32-valu" | "fp64-valu"
                 "kernel": dom["name"],
                 "achieved": (dom_line or {}).get("executed_TFLOPs"),
                 "peak": dom["peak"],
                 "unit": "TFLOP/s",
                 "frac": (dom_line or {}).get("frac"),
                 "frac_overlapped": (dom_line or {}).get("frac_overlapped"),
-                "how": "MEASURED ALONE: after the timed region one engine runs one more step with the device to itself and EVERY launch of the kernel "
-                       "bracketed by HIP events on its stream; achieved = executed flops of those launches (28 real flops x rows x column pairs "
-                       "of every visited tile, counted on the device; a visited tile executes all its rotation slots, identity rotations included) / "
-                       "their summed duration; avg_launch_us is that duration per launch - the figure `rocprofv3 --kernel-trace --stats` of a "
-                       "one-engine run reports for the same kernel (profiles/r05/iso_*.csv).  bound: by arithmetic intensity (flops / tile bytes "
-                       "against peak / 8 TB/s); frac = the larger of the vector-peak and HBM-peak fractions.  frac_overlapped: the same ratio from "
-                       "the launches sampled INSIDE the timed region, where four engines' kernels share the device (no correction factor)",
+                "how": (("MEASURED ALONE: after the timed region one engine runs one more step with the device to itself and EVERY launch of the kernel "
+                         "bracketed by HIP events on its stream; achieved = executed flops of those launches (output tiles x K counted on the device "
+                         "by the kernel itself x 3 real matrix-core products x 2 x 64 x 64: masked trajectories and the mirror tiles of Hermitian "
+                         "products are not counted; nominal complex flops would be 8/6 of it) / their summed duration; avg_launch_us is that "
+                         "duration per launch - the figure `rocprofv3 --kernel-trace --stats` of a one-engine run reports for the same kernel "
+                         "(profiles/r05/iso_*.csv).  The kernel is the dominant one of the step: largest summed launch time of the three sampled "
+                         "kernels in that isolated step (summed_launch_ms_in_the_isolated_step).  bound: by arithmetic intensity (executed flops / "
+                         "operand-and-result bytes of a launch once each, against peak / 8 TB/s); peak = the fp64 matrix-core rate 78.6 TFLOP/s.  "
+                         "frac_overlapped: the same ratio from the launches sampled INSIDE the timed region, where four engines' kernels share the device")
+                        if dom is kgm else
+                        ("MEASURED ALONE: after the timed region one engine runs one more step with the device to itself and EVERY launch of the kernel "
+                         "bracketed by HIP events on its stream; achieved = executed flops of those launches (28 real flops x rows x column pairs "
+                         "of every visited tile, counted on the device; a visited tile executes all its rotation slots, identity rotations included) / "
+                         "their summed duration; avg_launch_us is that duration per launch - the figure `rocprofv3 --kernel-trace --stats` of a "
+                         "one-engine run reports for the same kernel (profiles/r05/iso_*.csv).  bound: by arithmetic intensity (flops / tile bytes "
+                         "against peak / 8 TB/s); frac = the larger of the vector-peak and HBM-peak fractions.  frac_overlapped: the same ratio from "
+                         "the launches sampled INSIDE the timed region, where four engines' kernels share the device (no correction factor)")),
                 "avg_launch_us": (dom_line or {}).get("avg_launch_us"),
                 "flops_per_launch": (dom_line or {}).get("flops_per_launch"),
                 "frac_of_vector_peak": (dom_line or {}).get("frac_of_vector_peak"),
+                "frac_of_matrix_peak": (dom_line or {}).get("frac_of_matrix_peak"),
                 "frac_of_hbm_peak": (dom_line or {}).get("frac_of_hbm_peak"),
                 "flop_per_byte": (dom_line or {}).get("flop_per_byte"),
                 "isolated_step_seconds": iso["step_s"] if iso else None,
@@ -890,7 +926,9 @@ def main():
                 "frac_nominal": frac(tf(flops_svd_nominal, cls_ms["svd"]), peak),
                 "achieved_nominal": tf(flops_svd_nominal, cls_ms["svd"]),
                 "algorithmic_flops_per_svd": F_svd,
-                "kernels": {"jacobi_fp64": kernel_line(k64), "jacobi_complex64": kernel_line(k32) if not f32 else None},
+                "kernels": {"gemm_fp64": kernel_line(kgm) if not f32 else None, "jacobi_fp64": kernel_line(k64), "jacobi_complex64": kernel_line(k32) if not f32 else None},
+                "summed_launch_ms_in_the_isolated_step": {"gemm_fp64": (iso or {}).get("gemm", {}).get("ms"), "jacobi_complex64": (iso or {}).get("c64", {}).get("ms"),
+                                                          "jacobi_fp64": (iso or {}).get("f64", {}).get("ms")} if iso else None,
                 "jacobi_sweeps_per_solve_fp64": (float(jw[2]) / float(jw[3])) if jw[3] else None,
                 "jacobi_applied_over_executed_rotations_fp64": (float(jw[1]) / float(jw[0])) if jw[0] else None,
                 "jacobi_applied_over_executed_rotations_complex64": (float(mx[7]) / float(mx[6])) if mx[6] else None,

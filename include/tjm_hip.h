@@ -320,6 +320,15 @@ int tjm_svd_work_read(double* out4, int32_t reset);
 int tjm_svd_mixed_read(double* out10, int32_t reset);
 /* tjm_profile_cross_kernel also samples the complex64 instance of the tile kernel (the first phase of the mixed split); its totals: */
 int tjm_profile_cross_kernel_read_c64(double* total_ms, double* total_bytes, int64_t* samples);
+/* Launch sampler of the fp64 GEMM kernel on v_mfma_f64_4x4x4_4b_f64 (zgemm4_kernel, tjm_gemm.hip; the products of
+ * core/methods/tdvp/primitives.py:77-226 and of the two-site split's fp64 phase): every `every`-th launch bracketed by HIP events on its
+ * stream, 0 switches it off.  read(): out6 = { summed duration of the sampled launches [ms], sampled launches, all launches, executed output
+ * tiles x K counted ON THE DEVICE over all launches (one 64 x 64 tile x one unit of K = 3 x 2 x 64 x 64 real matrix-core flops: three real
+ * products per complex one; masked trajectories and mirror tiles of Hermitian products are not counted), algorithmic bytes of the sampled
+ * launches (operands and result of a launch once each), the same for all launches }.  Call read() after synchronising the streams.
+ * Zeros in the complex64 library. */
+int tjm_profile_gemm(int32_t every);
+int tjm_profile_gemm_read(double* out6);
 
 #ifdef __cplusplus
 }

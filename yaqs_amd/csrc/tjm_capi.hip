@@ -522,6 +522,17 @@ int tjm_profile_cross_kernel_read(double* total_ms, double* total_bytes, int64_t
   return TJM_OK;
 }
 
+int tjm_profile_gemm(int32_t every) {
+  gemm_profile_enable(every);
+  return TJM_OK;
+}
+
+int tjm_profile_gemm_read(double* out6) {
+  if (!out6) return TJM_ERR_ARG;
+  gemm_profile_get(out6);
+  return TJM_OK;
+}
+
 int tjm_tridiag_expm(const double* alpha, const double* beta, int32_t k, double dt, double* out, void* stream) {
   DeviceGuard guard(device_of(out));
   return launch_tridiag_expm_test(reinterpret_cast<const real*>(alpha), reinterpret_cast<const real*>(beta), k, dt, reinterpret_cast<real*>(out),

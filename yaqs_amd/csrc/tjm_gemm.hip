@@ -14,7 +14,12 @@
 // k-major with a row pitch of 80 doubles so that the two k-groups of a ds_read_b64 half-wave
 // land in disjoint banks.  Global loads for tile k+1 are issued before the MFMAs of tile k.  With 96 accumulator
 // registers the kernel takes about 205 registers: two workgroups share a CU and one's barriers hide behind the other's MFMAs.
+#include <array>
+#include <mutex>
+#include <vector>
+
 #include "tjm_common.h"
+#include "tjm_kernels.h"
 
 namespace tjm {
 
@@ -248,7 +253,7 @@ typedef double d2v __attribute__((ext_vector_type(2)));
 // KG = k-groups of 4 per staged k-tile: 4 (k-tiles of 16, 64 KiB of LDS, two workgroups per CU) or 2 (k-tiles of 8, 32 KiB, THREE workgroups
 // per CU inside 168 registers: a barrier every 96 products instead of 192, but three wavefronts per SIMD to fill each other's stalls).
 template <int ABL, int KG>  // ABL: timing ablations (wrong results): 1 no staging in the loop, 2 no barrier, 4 fragments of k-group 0 for all, 8 no operand sums
-__global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g, int tiles_m, int tiles_n, long total_tiles, int xcd_map) {
+__global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g, int tiles_m, int tiles_n, long total_tiles, int xcd_map, unsigned long long* work_counter) {
   // [buffer][A tiles (row group, k-group) 16 x 64 | B tiles (column group, k-group) 16 x 64], then four doubles of the dot-product
   // epilogue (ONE array: a second LDS object beside a global_load_lds target costs a full wait per read)
   constexpr int SB = 512 * KG, HB = 256 * KG, WB = 64 * KG, BK4 = 4 * KG;  // doubles-pairs per buffer / offset of the B tiles / per wavefront; k per tile
@@ -340,6 +345,7 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
 #pragma unroll
   for (int r = 0; r < 4; ++r) boff[r] = HB + wave * WB + ((lane & 48) | ((lane + 4 * r) & 15));
 
+  int tiles_done = 0;  // (measurement: executed output tiles of this workgroup, added to work_counter at the end)
   set_sources(cur);
 #pragma unroll
   for (int kg = 0; kg < KG; ++kg) stage_piece(kg, 0);
@@ -420,6 +426,7 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
         const int z = (int)(cur.t / per);
         dot_slot = (long)cur.b0 * g.dot_ld + (long)(z % (g.nb1 * g.nb2)) * per + (cur.t - (long)z * per);
       }
+      ++tiles_done;
       if (!have_next) break;
       cur = nxt;
       it = 0;
@@ -437,6 +444,7 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
     __syncthreads();
     if (tid == 0) g.dot_part[dot_slot] = (red[0] + red[1]) + (red[2] + red[3]);
   }
+  if (work_counter && tid == 0) atomicAdd(work_counter, (unsigned long long)tiles_done * (unsigned long long)((long)g.K * g.nks));
 }
 #endif  // !TJM_F32
 
@@ -724,8 +732,106 @@ __global__ __launch_bounds__(256) void zgemm_small_kernel(GemmDesc g, int tiles_
 
 }  // namespace
 
+// ---- measurement: launch sampler of zgemm4_kernel (tjm_profile_gemm of the C ABI).  Every N-th launch is bracketed by HIP events
+// on its stream; the executed work is counted ON THE DEVICE (output tiles x K of every workgroup: masked trajectories and the
+// mirror tiles of Hermitian products are not counted), the bytes are the operands and the result of the launch once each.
+#ifndef TJM_F32
+namespace {
+struct GemmProfile {
+  int every = 0;
+  long counter = 0, launches = 0, samples = 0;
+  double total_ms = 0.0, bytes = 0.0, bytes_all = 0.0;
+  unsigned long long* dev_units = nullptr;  // tiles x K executed (device memory of the device that enabled the sampler)
+  int dev = -1;
+  std::vector<hipEvent_t> pool;
+  std::vector<std::pair<int, double>> pending;  // (event pair, bytes)
+  size_t used = 0;
+};
+GemmProfile g_gp;
+std::mutex g_gp_mutex;
+void gemm_harvest_locked(bool wait) {
+  size_t keep = 0;
+  for (size_t i = 0; i < g_gp.pending.size(); ++i) {
+    const auto p = g_gp.pending[i];
+    if (wait) (void)hipEventSynchronize(g_gp.pool[2 * p.first + 1]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_gp.pool[2 * p.first], g_gp.pool[2 * p.first + 1]) == hipSuccess) {
+      g_gp.total_ms += ms;
+      g_gp.bytes += p.second;
+      ++g_gp.samples;
+    } else if (!wait) g_gp.pending[keep++] = p;
+  }
+  g_gp.pending.resize(wait ? 0 : keep);
+  if (g_gp.pending.empty()) g_gp.used = 0;
+}
+}  // namespace
+#endif
+
+void gemm_profile_enable(int every) {
+#ifndef TJM_F32
+  std::lock_guard<std::mutex> lock(g_gp_mutex);
+  if (every > 0 && g_gp.dev_units == nullptr) {
+    if (hipGetDevice(&g_gp.dev) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&g_gp.dev_units), sizeof(unsigned long long)) != hipSuccess) {
+      g_gp.dev_units = nullptr;
+      return;
+    }
+  }
+  if (every > 0) {
+    (void)hipMemset(g_gp.dev_units, 0, sizeof(unsigned long long));
+    g_gp.counter = g_gp.launches = g_gp.samples = 0;
+    g_gp.total_ms = g_gp.bytes = g_gp.bytes_all = 0.0;
+    g_gp.pending.clear();
+    g_gp.used = 0;
+  }
+  g_gp.every = every > 0 ? every : 0;
+#else
+  (void)every;
+#endif
+}
+
+// out6 = { summed duration of the sampled launches [ms], sampled launches, all launches, executed tiles x K (device counter, all launches),
+//          nominal bytes of the sampled launches, nominal bytes of all launches }; call after the streams have been synchronised
+void gemm_profile_get(double* out6) {
+  for (int i = 0; i < 6; ++i) out6[i] = 0.0;
+#ifndef TJM_F32
+  std::lock_guard<std::mutex> lock(g_gp_mutex);
+  gemm_harvest_locked(true);
+  unsigned long long units = 0;
+  if (g_gp.dev_units) (void)hipMemcpy(&units, g_gp.dev_units, sizeof(units), hipMemcpyDeviceToHost);
+  out6[0] = g_gp.total_ms; out6[1] = (double)g_gp.samples; out6[2] = (double)g_gp.launches; out6[3] = (double)units;
+  out6[4] = g_gp.bytes; out6[5] = g_gp.bytes_all;
+#endif
+}
+
+#ifndef TJM_F32
+namespace {
+// TJM_GEMM_SHAPES=1 (diagnostic): the distinct product shapes of the process with their launch counts, printed at exit
+struct ShapeLog {
+  std::mutex m;
+  std::vector<std::pair<std::array<long, 10>, long>> rows;
+  ~ShapeLog() {
+    for (auto& r : rows)
+      fprintf(stderr, "[tjm_gemm] M %ld N %ld K %ld nks %ld batches %ld herm %ld acc %ld a_mcontig %ld b_ncontig %ld dot %ld : %ld launches\n", r.first[0], r.first[1],
+              r.first[2], r.first[3], r.first[4], r.first[5], r.first[6], r.first[7], r.first[8], r.first[9], r.second);
+  }
+};
+ShapeLog g_shapes;
+}  // namespace
+#endif
+
 int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
   GemmDesc g = g_in;
+#ifndef TJM_F32
+  static const bool log_shapes = getenv("TJM_GEMM_SHAPES") != nullptr;
+  if (log_shapes) {
+    const std::array<long, 10> key = {g.M, g.N, g.K, g.nks, (long)g.nb0 * g.nb1 * g.nb2, g.hermitian, g.accumulate, (g.a_rs == 1 && g.a_cs != 1) ? 1 : 0, g.b_cs == 1 ? 1 : 0, g.dot_part ? 1 : 0};
+    std::lock_guard<std::mutex> lock(g_shapes.m);
+    bool found = false;
+    for (auto& r : g_shapes.rows)
+      if (r.first == key) { ++r.second; found = true; break; }
+    if (!found) g_shapes.rows.emplace_back(key, 1L);
+  }
+#endif
   static const bool direct_mirror = getenv("TJM_GEMM_DIRECT_MIRROR") != nullptr;
   if (g.hermitian && direct_mirror) g.hermitian = 2;
   if (g.M <= 0 || g.N <= 0 || g.nb0 <= 0 || g.nb1 <= 0 || g.nb2 <= 0) return TJM_OK;
@@ -765,12 +871,43 @@ int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
     const int use_slots = kg == 2 ? slots3 : slots;
     const unsigned nwg2 = (unsigned)(total_tiles < use_slots ? total_tiles : use_slots);
     const int xm = (xcd_map && total_tiles >= use_slots) ? 1 : 0;
-#define TJM_Z4(A) do { if (kg == 2) hipLaunchKernelGGL((zgemm4_kernel<A, 2>), dim3(nwg2), block, 0, stream, g, tiles_m, tiles_n, total_tiles, xm); \
-                       else hipLaunchKernelGGL((zgemm4_kernel<A, 4>), dim3(nwg2), block, 0, stream, g, tiles_m, tiles_n, total_tiles, xm); } while (0)
+    // measurement (off unless tjm_profile_gemm was called): bracket every N-th launch, count the executed tiles on the device
+    unsigned long long* wc = nullptr;
+    int ev = -1;
+    double nbytes = 0.0;
+    std::unique_lock<std::mutex> plock(g_gp_mutex, std::defer_lock);
+    if (g_gp.every > 0) {
+      plock.lock();
+      int dev = -1;
+      if (g_gp.every > 0 && hipGetDevice(&dev) == hipSuccess && dev == g_gp.dev) {
+        wc = g_gp.dev_units;
+        nbytes = 16.0 * (double)batches * (((double)g.M * g.K + (double)g.K * g.N) * g.nks + (double)g.M * g.N * (g.accumulate != 0 ? 2.0 : 1.0));
+        ++g_gp.launches;
+        g_gp.bytes_all += nbytes;
+        if (g_gp.counter++ % g_gp.every == 0) {
+          gemm_harvest_locked(false);
+          if (g_gp.pool.size() < 2 * (g_gp.used + 1)) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { g_gp.pool.push_back(a); g_gp.pool.push_back(b); }
+          }
+          if (g_gp.pool.size() >= 2 * (g_gp.used + 1)) {
+            ev = (int)g_gp.used++;
+            (void)hipEventRecord(g_gp.pool[2 * ev], stream);
+          }
+        }
+      }
+    }
+#define TJM_Z4(A) do { if (kg == 2) hipLaunchKernelGGL((zgemm4_kernel<A, 2>), dim3(nwg2), block, 0, stream, g, tiles_m, tiles_n, total_tiles, xm, wc); \
+                       else hipLaunchKernelGGL((zgemm4_kernel<A, 4>), dim3(nwg2), block, 0, stream, g, tiles_m, tiles_n, total_tiles, xm, wc); } while (0)
     switch (abl) {
       case 1: TJM_Z4(1); break; case 2: TJM_Z4(2); break; case 15: TJM_Z4(15); break;
       default: TJM_Z4(0);
     }
+    if (ev >= 0) {
+      (void)hipEventRecord(g_gp.pool[2 * ev + 1], stream);
+      g_gp.pending.emplace_back(ev, nbytes);
+    }
+    if (plock.owns_lock()) plock.unlock();
 #undef TJM_Z4
     TJM_HIP_CHECK(hipGetLastError());
     return TJM_OK;

@@ -217,6 +217,8 @@ long svd_y_elems(int max_dim);  // complex elements of the stacked Jacobi matrix
 size_t svd_workspace_bytes(int max_dim, int B);
 size_t svd_carve(SvdWorkspace& w, char* base, int max_dim, int B);  // lays the buffers out behind base, returns the bytes used
 void profile_enable(int every);
+void gemm_profile_enable(int every);   // launch sampler of zgemm4_kernel (tjm_gemm.hip); get: out6, see there
+void gemm_profile_get(double* out6);
 void profile_get(double* total_ms, double* total_bytes, long* samples);
 void jacobi_work_get(double* out4, bool reset);  // slot x rows, applied rotations x rows, sweeps, solves of the tiled Jacobi since the last reset
 // Knobs of the tiled iteration for callers that do not want the defaults (the mixed-precision split, tjm_mixed.h)
