@@ -288,12 +288,15 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
   // Position p of this workgroup's list -> tile id.  XCD-aware: workgroups b and b + 8 share an XCD (and its 4 MiB L2), so batch
   // entry z goes to the workgroups with b % 8 == z % 8 and the 64 of them walk its tiles together - an entry's operands (1 - 2 MB)
   // are then re-read from ONE L2; dealt flat, the tiles of ten entries are in flight on every XCD at once.  Speed only.
+  // (The unit dealt to an XCD is a TRAJECTORY with all its inner batches: they share the operand without inner batch strides - the
+  // environment blocks of an H_eff apply are read by the products of all d^2 physical index pairs.)
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const long per_traj = (long)per * g.nb1 * g.nb2;
   auto tile_at = [&](long pos) -> long {
     if (!xcd_map) return blockIdx.x + pos * (long)gridDim.x;
     const long u = slot + pos * (long)nslots;
-    const long zl = u / per;
-    return (zl * 8 + xcd) * per + (u - zl * per);
+    const long zl = u / per_traj;
+    return (zl * 8 + xcd) * per_traj + (u - zl * per_traj);
   };
   auto next_valid = [&](long pos, Tile& T) -> bool {
     for (;; ++pos) {
@@ -863,7 +866,7 @@ int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
     const int tiles_m = g.M / BM, tiles_n = g.N / BN;
     const long total_tiles = (long)tiles_m * tiles_n * batches;
     static const bool flat = getenv("TJM_GEMM_FLAT_TILES") != nullptr;
-    const int xcd_map = (!flat && batches >= 16 && total_tiles >= slots && slots % 8 == 0) ? 1 : 0;
+    const int xcd_map = (!flat && g.nb0 >= 16 && total_tiles >= slots && slots % 8 == 0) ? 1 : 0;
     static const int abl = getenv("TJM_GEMM_ABL") ? atoi(getenv("TJM_GEMM_ABL")) : 0;
     static const int kgenv = getenv("TJM_GEMM_KG") ? atoi(getenv("TJM_GEMM_KG")) : 4;
     const int kg = (kgenv == 2 || g.K % 16 != 0) ? 2 : 4;
