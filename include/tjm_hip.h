@@ -141,8 +141,8 @@ int tjm_engine_canonicalize_qr(tjm_engine* e, int32_t set, int32_t center);
  * outcomes, site 0 first (the reference packs them as sum(bit_i << i)). */
 int tjm_engine_sample_shots(tjm_engine* e, int32_t set, int32_t shots, const double* rotation, const double* uniforms, uint8_t* bits);
 int tjm_engine_stats(const tjm_engine* e, int64_t* out5);
-/* the same five counters followed by: two-site H_eff applies (a subset of matvecs), environment updates, centre shifts served by
- * the certified QR path (reserved: always 0), matrices factorised (batched SVD calls x trajectories in the call), Krylov calls whose
+/* the same five counters followed by: two-site H_eff applies (a subset of matvecs), environment updates, H_eff applies served by
+ * the direct form (no T2 tensor: monomial MPO rows behind certified identity channels), matrices factorised (batched SVD calls x trajectories in the call), Krylov calls whose
  * environments were examined for identity channels, channels certified (at most two per call), trajectory-steps whose scalar dissipation sweep was certified away, jumps applied in
  * place on certified states; writes min(n, 13) values */
 int tjm_engine_stats_ex(const tjm_engine* e, int64_t* out, int32_t n);

@@ -368,6 +368,7 @@ inline hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t = nullp
 }
 inline hipError_t hipMemset(void* dst, int v, size_t n) { return hipMemsetAsync(dst, v, n); }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind,
                                    hipStream_t = nullptr) {
   for (size_t r = 0; r < height; ++r) std::memmove(static_cast<char*>(dst) + r * dpitch, static_cast<const char*>(src) + r * spitch, width);

@@ -624,6 +624,47 @@ def test_lanczos_expm_general_path_matches_oracle(lib, nsites, bond):
     e.close()
 
 
+@pytest.mark.parametrize("bond", [64, 128])
+@pytest.mark.parametrize("nsites", [1, 2])
+def test_lanczos_expm_with_identity_channels_takes_the_direct_form(lib, nsites, bond):
+    """Environments as a canonical chain gives them - L[:, 0, :] = 1 and R[:, D - 1, :] = 1 for the Ising MPO - so that the Krylov call
+    certifies both identity channels; the MPO rows of the other left channels are monomial and no entry couples two non-identity
+    channels, so the H_eff apply runs in its direct form (round 5: the fused stage kernel writes only y, the last product reads
+    x[perm] x coef instead of T2; GemmDesc::b_perm / coef on zgemm4_kernel).  Checked against the oracle's update_site, which knows
+    nothing of identity channels; the engine's counter says the direct form served the applies (fp64 library on the device only)."""
+    from oracle import tjm_oracle as o  # checker only
+    from yaqs_amd._lib import check
+    from yaqs_amd.engine import BatchEngine
+
+    rng = np.random.default_rng(211 + nsites + bond)
+    ca = cb = bond
+    D, P = 3, 2 ** nsites
+    mpo = o.ising_mpo(8, 1.0, 0.5)
+    w = mpo[3] if nsites == 1 else o.merge_mpo_tensors(mpo[3], mpo[4])
+    herm = lambda m: m + m.conj().transpose(2, 1, 0)  # noqa: E731
+    Lenv, Renv = herm(crand(rng, ca, D, ca)), herm(crand(rng, cb, D, cb))
+    Lenv[:, 0, :] = np.eye(ca)
+    Renv[:, D - 1, :] = np.eye(cb)
+    x = crand(rng, P, ca, cb)
+    x /= np.linalg.norm(x)
+    e = BatchEngine(16, max(32, bond), 2, o.ising_mpo(16, 1.0, 0.5))  # (16 sites: the storage of the middle bonds reaches 128)
+    wh = np.ascontiguousarray(w, dtype=np.complex128)
+    for tol in (1e-4, 1e-12):
+        y = torch.zeros((2, P, ca, cb), dtype=torch.complex128, device=DEV)
+        mv = C.c_int64(0)
+        check(lib.tjm_lanczos_expm(e.h, nsites, ca, cb, D, D, _slots(x).data_ptr(), _same(Lenv).data_ptr(),
+                                   _same(Renv).data_ptr(), wh.ctypes.data, 0.02, tol, y.data_ptr(), 2, C.byref(mv)), "lanczos")
+        ref = o.update_site(Lenv, Renv, w, x, 0.02, tol)
+        got = y.cpu().numpy()
+        assert np.allclose(got[0], ref, atol=1e-10), (tol, np.abs(got[0] - ref).max())
+        assert np.allclose(got[1], 1.5 * ref, atol=1e-10)
+    st = e.stats()
+    assert st["identity_channels"] >= 2
+    if not os.environ.get("TJM_NO_DIRECT_HEFF") and not os.environ.get("TJM_GEMM_16X16"):
+        assert st["direct_applies"] >= 2, st
+    e.close()
+
+
 def test_center_shifts_are_gauge_moves_with_isometric_factors(lib):
     """tjm_engine_center_shift (shift_orthogonality_center_right / _left, mps.py:719-788), QR and SVD flavour: the state vector is
     unchanged, the tensor left behind is an isometry, the bond obeys the thin-QR rule; at bonds that take the general Householder /

@@ -167,9 +167,16 @@ struct GemmDesc {
   const cplx* dot_with;
   real* dot_part;
   int dot_ld;
+  // Optional (zgemm4_kernel only; launch_gemm refuses it elsewhere): the B operand of k-split term ks and inner batch b1 is block
+  // b_perm[ks * nb1 + b1] of a tensor of blocks (B + b0 * b_b0 + block * b_perm_stride; b_b1 and b_ks are not used), and the term
+  // is multiplied by coef[ks * nb1 + b1] - the direct form of an H_eff apply whose MPO rows are monomial (tjm_engine.hip: heff_apply).
+  const int* b_perm;
+  const cplx* coef;
+  long b_perm_stride;
 };
 
 int launch_gemm(const GemmDesc& g, hipStream_t stream);
+bool gemm4_serves(int M, int N, int K);  // the product goes to zgemm4_kernel (whole tiles; fp64 library)
 
 // First two stages of an H_eff apply in one kernel (tjm_gemm.hip: heff_stage12_kernel): the product with the right environment over
 // its non-identity channels and, as the epilogue of the same tile, the MPO stage - the intermediate T1 never leaves the chip.
@@ -185,6 +192,7 @@ struct HeffStage12Desc {
   int nb0;
   const int* ids;
   const int* active;
+  int skip_t2;  // 1: only the output channel lch (-> y) is computed; the caller does not need T2 (direct form of heff_apply)
 };
 bool heff_stage12_fits(int P, int ca, int cb, int Dl, int Dr, int rch);
 int launch_heff_stage12(const HeffStage12Desc& d, hipStream_t stream);

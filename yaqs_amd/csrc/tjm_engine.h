@@ -3,6 +3,8 @@
 // HIP stream; all tensors live in a caller-provided device workspace.
 #pragma once
 #include <functional>
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "../../include/tjm_hip.h"
@@ -42,6 +44,7 @@ class Engine {
   int trunc_mode = 0, max_bond = 0, tdvp_mode = 2, tdvp_sweeps = 1;
   // statistics
   long stat_matvecs = 0, stat_krylov_calls = 0, stat_svds = 0, stat_svd_sweeps = 0, stat_site_updates = 0;
+  long stat_direct_applies = 0;  // H_eff applies served by the direct form (no T2)
   long stat_matvecs2 = 0, stat_env_updates = 0, stat_svd_mats = 0;  // two-site H_eff applies (subset of matvecs), environment updates, matrices factorised
 
   // Live timing of the kernel classes of a step with HIP events on the engine's stream (bench.py's roofline object):
@@ -165,6 +168,13 @@ class Engine {
   std::vector<cplx*> WenvL_;     // [(p,r),(o,l)] : left-env form
   std::vector<cplx*> W2_;        // merged two-site [(o o', l),(p p', r)]
   std::vector<std::vector<cplx>> Whost_;
+  // Direct form of an H_eff apply (heff_apply): with certified identity channels lch / rch, an MPO matrix none of whose entries
+  // couples a non-identity left channel to a non-identity right channel and whose rows (o, l != lch) hold at most one entry (Pauli-sum
+  // Hamiltonians with nearest-neighbour terms) gives T2[o][.][l][.] = coef x[perm]: the third stage reads x itself.
+  struct DirectForm { bool ok = false; int* perm = nullptr; cplx* coef = nullptr; };
+  std::map<std::tuple<const cplx*, int, int, int, int, int>, DirectForm> direct_;  // (Wm, P, Dl, Dr, lch, rch); cleared whenever an MPO matrix is uploaded
+  const DirectForm* direct_form(const cplx* Wm, int P, int Dl, int Dr, int lch, int rch);
+  void direct_clear();
   real *part1_ = nullptr, *part2_ = nullptr;
   int* nloc_ = nullptr;
   real* scal_ = nullptr;         // [B] scratch scalars

@@ -123,6 +123,7 @@ Engine::Region::~Region() {
 }
 
 Engine::~Engine() {
+  direct_clear();
   if (h_pinned_) (void)hipHostFree(h_pinned_);
   for (hipEvent_t ev : krylov_ev_) if (ev) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : prof_.pool) if (ev) (void)hipEventDestroy(ev);
@@ -298,8 +299,56 @@ int Engine::run_sweep(int set, const std::vector<SmallSweepStep>& steps, const i
   return launch_small_sweep(q, stream);
 }
 
+void Engine::direct_clear() {
+  for (auto& kv : direct_) {
+    if (kv.second.perm) (void)hipFree(kv.second.perm);
+    if (kv.second.coef) (void)hipFree(kv.second.coef);
+  }
+  direct_.clear();
+}
+
+// The direct form of (Wm, lch, rch), analysed once on the host (the matrix is a few hundred entries) and kept until the next upload.
+const Engine::DirectForm* Engine::direct_form(const cplx* Wm, int P, int Dl, int Dr, int lch, int rch) {
+  const auto key = std::make_tuple(Wm, P, Dl, Dr, lch, rch);
+  auto it = direct_.find(key);
+  if (it != direct_.end()) return it->second.ok ? &it->second : nullptr;
+  DirectForm f;
+  const int nin = P * Dr, nl = Dl - 1, first = (lch == 0) ? 1 : 0;
+  std::vector<cplx> w((size_t)P * Dl * nin);
+  bool ok = (lch == 0 || lch == Dl - 1) && nl >= 1 && hipMemcpyAsync(w.data(), Wm, w.size() * sizeof(cplx), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+            hipStreamSynchronize(stream) == hipSuccess;
+  std::vector<int> perm((size_t)nl * P, 0);
+  std::vector<cplx> coef((size_t)nl * P, cplx{0.0, 0.0});
+  for (int ks = 0; ok && ks < nl; ++ks)
+    for (int po = 0; ok && po < P; ++po) {
+      const cplx* row = w.data() + (size_t)(po * Dl + first + ks) * nin;
+      int hits = 0;
+      for (int pi = 0; pi < P; ++pi)
+        for (int r = 0; r < Dr; ++r) {
+          const cplx v = row[pi * Dr + r];
+          if (v.x == 0.0 && v.y == 0.0) continue;
+          if (r != rch) ok = false;  // a term with operators in BOTH environments: the three-stage form
+          ++hits;
+          perm[(size_t)ks * P + po] = pi;
+          coef[(size_t)ks * P + po] = v;
+        }
+      if (hits > 1) ok = false;
+    }
+  if (ok) {
+    ok = hipMalloc(reinterpret_cast<void**>(&f.perm), perm.size() * sizeof(int)) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&f.coef), coef.size() * sizeof(cplx)) == hipSuccess &&
+         hipMemcpyAsync(f.perm, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice, stream) == hipSuccess &&
+         hipMemcpyAsync(f.coef, coef.data(), coef.size() * sizeof(cplx), hipMemcpyHostToDevice, stream) == hipSuccess &&
+         hipStreamSynchronize(stream) == hipSuccess;
+  }
+  f.ok = ok;
+  auto ins = direct_.emplace(key, f);
+  return ok ? &ins.first->second : nullptr;
+}
+
 int Engine::set_mpo(const double* host) {
   if (!bound_) return TJM_ERR_STATE;
+  direct_clear();
   Whost_.assign(L, {});
   const double* src = host;
   for (int i = 0; i < L; ++i) {
@@ -583,10 +632,19 @@ int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cp
                        long r_b0, int Dr, const cplx* Wm, cplx* y, long y_b0, int nb0, const int* ids, const int* active, int lch, int rch) {
   int rc;
   const bool fused12 = heff_stage12_fits(P, ca, cb, Dl, Dr, rch);
+  // Direct form (round 5): when no entry of W couples a non-identity left channel to a non-identity right channel and the rows of
+  // the non-identity left channels are monomial, T2[o][a][l][B] = coef(l, o) x[perm(l, o)][a][B] - the third stage reads x itself
+  // (block perm, factor coef: GemmDesc::b_perm / coef) and T2 is neither written nor read: 7.3 instead of 10.3 MB of HBM traffic per
+  // apply and trajectory at chi = 128 (these products run at 4 TB/s: they are bandwidth-bound).  Switch: TJM_NO_DIRECT_HEFF.
+  static const bool no_direct = getenv("TJM_NO_DIRECT_HEFF") != nullptr;
+  const DirectForm* df = nullptr;
+  if (!no_direct && fused12 && lch >= 0 && rch >= 0 && Dl >= 2 && gemm4_serves(ca, cb, ca)) df = direct_form(Wm, P, Dl, Dr, lch, rch);
+  if (df) ++stat_direct_applies;
   if (fused12) {  // stages 1 and 2 in one kernel: T1 stays in the accumulators of the GEMM tile (tjm_gemm.hip)
     HeffStage12Desc q;
     q.x = x; q.x_b0 = x_b0; q.R = Renv; q.r_b0 = r_b0; q.Wm = Wm; q.T2 = T2; q.t_b0 = t_b0; q.y = y; q.y_b0 = y_b0;
     q.P = P; q.ca = ca; q.cb = cb; q.Dl = Dl; q.Dr = Dr; q.rch = rch; q.lch = lch; q.nb0 = nb0; q.ids = ids; q.active = active;
+    q.skip_t2 = df ? 1 : 0;
     if ((rc = launch_heff_stage12(q, stream)) != TJM_OK) return rc;
   }
   if (!fused12) {  // T1[(p,a),(r,B)] = x[(p,a),b] R[b,(r,B)]
@@ -626,6 +684,10 @@ int Engine::heff_apply(const cplx* x, long x_b0, int P, int ca, int cb, const cp
       g.K = ca; g.a_cs = (long)Dl * ca; g.b_rs = (long)Dl * cb;
       g.nks = Dl - 1; g.a_ks = ca; g.b_ks = cb;
       g.accumulate = 1;
+      if (df) {  // B = x[perm(l, o)] instead of T2[o][.][l][.]
+        g.B = x; g.b_b0 = x_b0; g.b_b1 = 0; g.b_ks = 0; g.b_rs = cb;
+        g.b_perm = df->perm; g.coef = df->coef; g.b_perm_stride = (long)ca * cb;
+      }
     }
     static const bool no_dot_fusion = getenv("TJM_NO_DOT_EPILOGUE") != nullptr;
     const int tiles = ((ca + 63) / 64) * ((cb + 63) / 64) * P;
@@ -2589,6 +2651,7 @@ int Engine::stochastic(int set, double dt_, int* host_jumped, double* host_dp) {
 // ------------------------------------------------------------------------------------------
 int Engine::upload_w(const double* host_w, int P, int Dl, int Dr, cplx** mv, cplx** envl) {
   if (!bound_ || !host_w || P < 1 || P > d * d || Dl < 1 || Dr < 1 || Dl > Dmax || Dr > Dmax) return TJM_ERR_ARG;
+  direct_clear();  // the scratch matrices change content under the same device pointers
   std::vector<cplx> a((size_t)P * Dl * P * Dr), b((size_t)P * Dr * P * Dl);
   for (int o = 0; o < P; ++o) for (int p = 0; p < P; ++p) for (int l = 0; l < Dl; ++l) for (int r = 0; r < Dr; ++r) {
     const double* z = host_w + 2 * ((((size_t)o * P + p) * Dl + l) * Dr + r);

@@ -322,10 +322,19 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
   const cplx* ap;
   const cplx* bp;
   int kt_st = 0;  // k-tile (inside its k-split term) that ap / bp point at
+  const cplx* bp0 = nullptr;  // (b_perm) the tile's B pointer without the block offset
+  int ks_st = 0, st_b1 = 0;   // (b_perm) k-split term and inner batch of the k-tile that ap / bp point at
   auto set_sources = [&](const Tile& T) {
     ap = g.A + ((long)T.b0 * g.a_b0 + (long)T.b1 * g.a_b1 + (long)T.b2 * g.a_b2 + (long)T.m0 * g.a_rs) + a_lane;
-    bp = g.B + ((long)T.b0 * g.b_b0 + (long)T.b1 * g.b_b1 + (long)T.b2 * g.b_b2 + (long)T.n0 * g.b_cs) + b_lane;
+    if (g.b_perm) {
+      bp0 = g.B + ((long)T.b0 * g.b_b0 + (long)T.n0 * g.b_cs) + b_lane;
+      bp = bp0 + (long)g.b_perm[T.b1] * g.b_perm_stride;
+      st_b1 = T.b1;
+    } else {
+      bp = g.B + ((long)T.b0 * g.b_b0 + (long)T.b1 * g.b_b1 + (long)T.b2 * g.b_b2 + (long)T.n0 * g.b_cs) + b_lane;
+    }
     kt_st = 0;
+    ks_st = 0;
   };
   auto stage_piece = [&](int kg, int buf) {
     d2v* dst = sm + buf * SB + wave * WB + kg * 64;
@@ -333,8 +342,13 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
     TJM_GLDS16(bp + kg * b_kg, dst + HB);
   };
   auto advance = [&]() {
-    if (++kt_st == ktiles) { kt_st = 0; ap += a_wrap; bp += b_wrap; }
-    else { ap += a_kt; bp += b_kt; }
+    if (++kt_st == ktiles) {
+      kt_st = 0;
+      ap += a_wrap;
+      ++ks_st;
+      if (g.b_perm) bp = bp0 + (long)g.b_perm[(ks_st < g.nks ? ks_st : 0) * g.nb1 + st_b1] * g.b_perm_stride;  // (behind the tile's last term nothing is staged from it)
+      else bp += b_wrap;
+    } else { ap += a_kt; bp += b_kt; }
   };
   double accP[4][4], accQ[4][4], accS[4][4];
 #pragma unroll
@@ -356,6 +370,9 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
   __syncthreads();
   int it = 0, buf = 0;
   long dot_slot = -1;
+  // (coef) the factor of the k-split term being multiplied: applied to the A fragments (the environment block), skipped when it is 1
+  int kt_c = 0, ks_c = 0;
+  cplx cf = g.coef ? g.coef[cur.b1] : cplx{1.0, 0.0};
   for (;;) {
     // what is staged during this k-tile's products: the tile's next k-tile, or the first one of the workgroup's next tile
     const bool last = it + 1 == total;
@@ -374,6 +391,19 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
 #pragma unroll
       for (int r = 0; r < 4; ++r) b[r] = sb[boff[r] + ((ABL & 4) ? 0 : kg) * 64];
       if (pending) stage_piece(kg, buf ^ 1);  // two loads per k-group: spread over the k-tile, they never queue up in front of the products
+      if (g.coef && !(cf.x == 1.0 && cf.y == 0.0)) {
+        if (cf.y == 0.0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { a[i].x *= cf.x; a[i].y *= cf.x; }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const double re = cf.x * a[i].x - cf.y * a[i].y;
+            a[i].y = fma(cf.x, a[i].y, cf.y * a[i].x);
+            a[i].x = re;
+          }
+        }
+      }
       double as[4], bs[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) as[i] = (ABL & 8) ? a[i].x : fma(sgnA, a[i].y, a[i].x);
@@ -393,6 +423,11 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
         for (int r = 0; r < 4; ++r) accS[i][r] = TJM_MFMA4(as[i], bs[r], accS[i][r]);
     }
     if (pending) advance();
+    if (g.coef && !last && ++kt_c == ktiles) {  // the next k-tile belongs to the tile's next k-split term
+      kt_c = 0;
+      ++ks_c;
+      cf = g.coef[ks_c * g.nb1 + cur.b1];
+    }
     if (last) {
       // epilogue of tile `cur`: lane l of accumulator (i, r) is row 16 i + 4 blk + (l >> 4), column 4 ((blk + r) & 3) + (l & 3).
       // (Issuing the stores behind the barrier below - its vmcnt(0) also counts stores - was measured: no gain, 64 more registers.)
@@ -433,6 +468,7 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
       if (!have_next) break;
       cur = nxt;
       it = 0;
+      if (g.coef) { kt_c = 0; ks_c = 0; cf = g.coef[cur.b1]; }
     } else {
       ++it;
     }
@@ -621,6 +657,7 @@ __global__ __launch_bounds__(256, 2) void heff_stage12_kernel(HeffStage12Desc d,
       for (int pi = 0; pi < P; ++pi) xin[pt][pi] = ok[pt] ? xb[(long)pi * ca * cb + base[pt]] : cplx{0.0, 0.0};
     }
   for (int bo = 0; bo < Dl; ++bo) {
+    if (d.skip_t2 && bo != d.lch) continue;
 #pragma unroll
     for (int po = 0; po < P; ++po) {
       const cplx* wrow = sW + (po * Dl + bo) * nin;
@@ -855,6 +892,7 @@ int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
   dim3 block(256);
 #ifndef TJM_F32
   static const bool mfma4 = getenv("TJM_GEMM_16X16") == nullptr;  // A/B switch: the 16 x 16 x 4 kernel for every shape
+  if ((g.b_perm || g.coef) && !(mfma4 && g.M % BM == 0 && g.N % BN == 0 && g.K % 8 == 0)) return TJM_ERR_NOT_IMPLEMENTED;  // (gemm4_serves)
   if (mfma4 && g.M % BM == 0 && g.N % BN == 0 && g.K % 8 == 0) {
     static int slots = 0, slots3 = 0;  // two resident workgroups per CU (64 KiB of LDS, <= 256 registers)
     if (slots == 0) {
@@ -941,6 +979,17 @@ bool heff_stage12_fits(int P, int ca, int cb, int Dl, int Dr, int rch) {
   if (nch != 1 && nch != 2 && nch != 4) return false;
   if (Dl > 6 || Dr > 6 || ca < 16 || cb < 16) return false;
   return true;
+}
+
+// Does launch_gemm take this product to zgemm4_kernel (the only kernel that knows b_perm / coef)?
+bool gemm4_serves(int M, int N, int K) {
+#ifdef TJM_F32
+  (void)M; (void)N; (void)K;
+  return false;
+#else
+  static const bool mfma4 = getenv("TJM_GEMM_16X16") == nullptr;
+  return mfma4 && M % BM == 0 && N % BN == 0 && K % 8 == 0 && !(M <= 32 || N <= 32);
+#endif
 }
 
 int launch_heff_stage12(const HeffStage12Desc& d, hipStream_t stream) {

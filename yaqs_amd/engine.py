@@ -370,7 +370,7 @@ class BatchEngine:
         s = np.zeros(13, dtype=np.int64)
         self.lib.tjm_engine_stats_ex(self.h, s.ctypes.data, 13)
         return dict(matvecs=int(s[0]), krylov_calls=int(s[1]), svds=int(s[2]), svd_sweeps=int(s[3]), site_updates=int(s[4]),
-                    matvecs_two_site=int(s[5]), env_updates=int(s[6]), svd_matrices=int(s[8]), identity_checks=int(s[9]),
+                    matvecs_two_site=int(s[5]), env_updates=int(s[6]), direct_applies=int(s[7]), svd_matrices=int(s[8]), identity_checks=int(s[9]),
                     identity_channels=int(s[10]), certified_dissipations=int(s[11]), certified_jumps=int(s[12]))
 
     def profile(self, enable: bool = True):
