@@ -262,7 +262,9 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in a scalar register: the LDS targets of the loads are scalar arithmetic
   const int li = lane & 15, lk = lane >> 4;
-  const int per = tiles_m * tiles_n;
+  // tiles per batch entry: a Hermitian product enumerates its upper triangle only (a workgroup that walked all T x T positions met the
+  // same position in every matrix - 64 slots per XCD, 16 positions - and those on a mirror position idled through the whole launch)
+  const int per = (g.hermitian && g.hermitian != 3) ? tiles_m * (tiles_m + 1) / 2 : tiles_m * tiles_n;
   const int ktiles = g.K / BK4;
   const int total = ktiles * g.nks;
 
@@ -271,8 +273,20 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
   auto decode = [&](long t, Tile& T) -> bool {  // false: nothing to do for tile t
     T.t = t;
     int z = (int)(t / per);
-    const int tt = (int)(t - (long)z * per);
-    const int tm = tt / tiles_n, tn = tt - tm * tiles_n;
+    int tt = (int)(t - (long)z * per);
+    int tm, tn;
+    if (g.hermitian == 3) {  // (TJM_GEMM_HERM_ALL: every position enumerated, mirror positions skipped - the first build)
+      tm = tt / tiles_n;
+      tn = tt - tm * tiles_n;
+      if (tm > tn) return false;
+    } else if (g.hermitian) {  // only the tiles on and above the diagonal are enumerated (per = T (T + 1) / 2): row tm holds T - tm of them
+      tm = 0;
+      while (tt >= tiles_n - tm) { tt -= tiles_n - tm; ++tm; }
+      tn = tm + tt;
+    } else {
+      tm = tt / tiles_n;
+      tn = tt - tm * tiles_n;
+    }
     T.b2 = z % g.nb2;
     z /= g.nb2;
     T.b1 = z % g.nb1;
@@ -282,7 +296,6 @@ __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g
     T.n0 = tn * BN;
     T.mirror = g.hermitian && tm != tn;
     if (g.active && g.active[T.b0] == 0) return false;
-    if (g.hermitian && tm > tn) return false;
     return true;
   };
   // Position p of this workgroup's list -> tile id.  XCD-aware: workgroups b and b + 8 share an XCD (and its 4 MiB L2), so batch
@@ -902,7 +915,9 @@ int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
       slots = 2 * (cus > 0 ? cus : 256);
     }
     const int tiles_m = g.M / BM, tiles_n = g.N / BN;
-    const long total_tiles = (long)tiles_m * tiles_n * batches;
+    static const bool herm_all = getenv("TJM_GEMM_HERM_ALL") != nullptr;
+    if (g.hermitian && herm_all) g.hermitian = 3;
+    const long total_tiles = ((g.hermitian && g.hermitian != 3) ? (long)tiles_m * (tiles_m + 1) / 2 : (long)tiles_m * tiles_n) * batches;
     static const bool flat = getenv("TJM_GEMM_FLAT_TILES") != nullptr;
     const int xcd_map = (!flat && g.nb0 >= 16 && total_tiles >= slots && slots % 8 == 0) ? 1 : 0;
     static const int abl = getenv("TJM_GEMM_ABL") ? atoi(getenv("TJM_GEMM_ABL")) : 0;
