@@ -19,7 +19,12 @@ shapes = {
     "x*R  (A k-contig, B n-contig)": dict(M=512, N=384, K=128, a_rs=128, a_cs=1, b_rs=384, b_cs=1),
     "L*T  (A m-contig, B n-contig)": dict(M=384, N=512, K=384, a_rs=1, a_cs=384, b_rs=512, b_cs=1),
 }
-if len(sys.argv) > 3:  # K scan at the first shape: fixed cost per tile versus cost per k-tile
+if len(sys.argv) > 3 and "," in sys.argv[3]:  # explicit shapes "M,N,K,am[;M,N,K,am...]" (am = 1: A stored [K][M], m contiguous)
+    shapes = {}
+    for spec in sys.argv[3].split(";"):
+        M_, N_, K_, am_ = (int(v) for v in spec.split(","))
+        shapes[f"M={M_} N={N_} K={K_} {'A m-contig' if am_ else 'A k-contig'}"] = dict(M=M_, N=N_, K=K_, a_rs=(1 if am_ else K_), a_cs=(M_ if am_ else 1), b_rs=N_, b_cs=1)
+elif len(sys.argv) > 3:  # K scan at the first shape: fixed cost per tile versus cost per k-tile
     ks = (int(sys.argv[3][2:]),) if sys.argv[3].startswith("K=") else (32, 64, 128, 256, 512)  # "K=512": that K alone (PMC passes)
     shapes = {f"K={k}": dict(M=512, N=384, K=k, a_rs=k, a_cs=1, b_rs=384, b_cs=1) for k in ks}
 for name, sh in shapes.items():

@@ -905,8 +905,14 @@ int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
   dim3 block(256);
 #ifndef TJM_F32
   static const bool mfma4 = getenv("TJM_GEMM_16X16") == nullptr;  // A/B switch: the 16 x 16 x 4 kernel for every shape
-  if ((g.b_perm || g.coef) && !(mfma4 && g.M % BM == 0 && g.N % BN == 0 && g.K % 8 == 0)) return TJM_ERR_NOT_IMPLEMENTED;  // (gemm4_serves)
-  if (mfma4 && g.M % BM == 0 && g.N % BN == 0 && g.K % 8 == 0) {
+  // zgemm4_kernel for whole-tile shapes of up to 48 tiles per batch entry.  (Larger outputs - the products of config 4: 256 x 1024,
+  // 512 x 768, 1024 x 256 at K = 256 - run 3 - 5 % FASTER on the register-staged kernel, profiles/r05/gemm_cfg4_shapes.txt, and config 4
+  // as a whole 5.0 against 4.8 trajectories/s; row-shaped instead of tile-shaped staging pieces did not change that, and cost the loop
+  // its immediate LDS offsets.  TJM_GEMM_4X4_ALL lifts the limit.)
+  static const bool all4 = getenv("TJM_GEMM_4X4_ALL") != nullptr;
+  const bool use4 = mfma4 && g.M % BM == 0 && g.N % BN == 0 && g.K % 8 == 0 && (all4 || (g.M / BM) * (g.N / BN) <= 48);
+  if ((g.b_perm || g.coef) && !use4) return TJM_ERR_NOT_IMPLEMENTED;  // (gemm4_serves)
+  if (use4) {
     static int slots = 0, slots3 = 0;  // two resident workgroups per CU (64 KiB of LDS, <= 256 registers)
     if (slots == 0) {
       int dev = 0, cus = 0;
@@ -1003,7 +1009,8 @@ bool gemm4_serves(int M, int N, int K) {
   return false;
 #else
   static const bool mfma4 = getenv("TJM_GEMM_16X16") == nullptr;
-  return mfma4 && M % BM == 0 && N % BN == 0 && K % 8 == 0 && !(M <= 32 || N <= 32);
+  static const bool all4 = getenv("TJM_GEMM_4X4_ALL") != nullptr;
+  return mfma4 && M % BM == 0 && N % BN == 0 && K % 8 == 0 && !(M <= 32 || N <= 32) && (all4 || (M / BM) * (N / BN) <= 48);
 #endif
 }
 
