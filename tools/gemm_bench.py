@@ -22,22 +22,28 @@ shapes = {
 if len(sys.argv) > 3 and "," in sys.argv[3]:  # explicit shapes "M,N,K,am[;M,N,K,am...]" (am = 1: A stored [K][M], m contiguous)
     shapes = {}
     for spec in sys.argv[3].split(";"):
-        M_, N_, K_, am_ = (int(v) for v in spec.split(","))
-        shapes[f"M={M_} N={N_} K={K_} {'A m-contig' if am_ else 'A k-contig'}"] = dict(M=M_, N=N_, K=K_, a_rs=(1 if am_ else K_), a_cs=(M_ if am_ else 1), b_rs=N_, b_cs=1)
+        f = [int(v) for v in spec.split(",")]
+        M_, N_, K_, am_ = f[:4]
+        nks_, nb1_ = (f[4], f[5]) if len(f) >= 6 else (1, 1)  # k-split terms; inner batches sharing A (the last product of an H_eff apply: 128,128,128,1,2,4)
+        shapes[f"M={M_} N={N_} K={K_} x {nks_} terms, {nb1_} inner batches, {'A m-contig' if am_ else 'A k-contig'}"] = dict(
+            M=M_, N=N_, K=K_, a_rs=(1 if am_ else K_ * nks_), a_cs=(M_ * nks_ if am_ else 1), b_rs=N_, b_cs=1, nks=nks_, nb1=nb1_)
 elif len(sys.argv) > 3:  # K scan at the first shape: fixed cost per tile versus cost per k-tile
     ks = (int(sys.argv[3][2:]),) if sys.argv[3].startswith("K=") else (32, 64, 128, 256, 512)  # "K=512": that K alone (PMC passes)
     shapes = {f"K={k}": dict(M=512, N=384, K=k, a_rs=k, a_cs=1, b_rs=384, b_cs=1) for k in ks}
 for name, sh in shapes.items():
     M, N, K = sh["M"], sh["N"], sh["K"]
-    A = torch.randn(B, M * K, 2, dtype=torch.float64, device="cuda")
-    Bm = torch.randn(B, K * N, 2, dtype=torch.float64, device="cuda")
-    Cm = torch.zeros(B, M * N, 2, dtype=torch.float64, device="cuda")
+    nks, nb1 = sh.get("nks", 1), sh.get("nb1", 1)
+    A = torch.randn(B, M * K * nks, 2, dtype=torch.float64, device="cuda")
+    Bm = torch.randn(B, nb1 * nks * K * N, 2, dtype=torch.float64, device="cuda")
+    Cm = torch.zeros(B, nb1 * M * N, 2, dtype=torch.float64, device="cuda")
     g = _lib.GemmDesc()
     g.A, g.B, g.C = A.data_ptr(), Bm.data_ptr(), Cm.data_ptr()
     g.M, g.N, g.K = M, N, K
     g.a_rs, g.a_cs, g.b_rs, g.b_cs, g.c_rs = sh["a_rs"], sh["a_cs"], sh["b_rs"], sh["b_cs"], N
-    g.nks, g.nb0, g.nb1, g.nb2 = 1, B, 1, 1
-    g.a_b0, g.b_b0, g.c_b0 = M * K, K * N, M * N
+    g.nks, g.nb0, g.nb1, g.nb2 = nks, B, nb1, 1
+    g.a_b0, g.b_b0, g.c_b0 = M * K * nks, nb1 * nks * K * N, nb1 * M * N
+    g.a_ks, g.b_ks = (M if sh["a_rs"] == 1 else K), K * N   # A [K x nks][M] (m contiguous) or [M][nks x K]; B [nb1][nks][K][N]
+    g.b_b1, g.c_b1 = nks * K * N, M * N
     for _ in range(3):
         lib.tjm_zgemm_batched(C.byref(g), None)
     torch.cuda.synchronize()
@@ -46,5 +52,5 @@ for name, sh in shapes.items():
         lib.tjm_zgemm_batched(C.byref(g), None)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    flop = 8.0 * M * N * K * B
+    flop = 8.0 * M * N * K * B * nks * nb1
     print(f"{name}: {dt * 1e3:.3f} ms  {flop / dt / 1e12:.1f} TFLOP/s  ({100 * flop / dt / 78.6e12:.0f} % of the fp64 MFMA peak)")
