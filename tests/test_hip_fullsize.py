@@ -163,6 +163,9 @@ def test_config2_ten_consecutive_steps_match_the_reference_through_the_stage_ent
     _steady_counters(stats)
     if not NO_CERT:
         assert 0 < stats["certified_dissipations"] < len(sel) * int(g["steps"]), stats  # the partial regime
+    if not (os.environ.get("TJM_NO_DIRECT_HEFF") or os.environ.get("TJM_GEMM_16X16") or os.environ.get("TJM_NO_IDENTITY_CHANNELS")):
+        # round 5: the H_eff applies of the bulk sites run in their direct form (no T2 tensor) - the path this fixture pins
+        assert stats["direct_applies"] > 0.5 * stats["matvecs"], stats
     z0, _ = _steady_stages(g, sel[:1], check=False)
     z12, _ = _steady_stages(g, sel[1:], check=False)
     assert np.array_equal(z0[0], z[0]) and np.array_equal(z12, z[1:]), (np.abs(z0[0] - z[0]).max(), np.abs(z12 - z[1:]).max())

@@ -230,9 +230,13 @@ __global__ __launch_bounds__(256, 2) void zgemm_kernel(GemmDesc g) {
 
 #ifndef TJM_F32
 // ------------------------------------------------------------------------------------------------------------------------------
-// The same product on v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks per instruction: 512 flops every 16 cycles, 75 TFLOP/s
-// measured against the 48 of v_mfma_f64_16x16x4_f64 - tools/probes/mfma_cycles_probe.hip), for shapes made of whole tiles (M, N
-// multiples of 64, K of 16).  The instruction multiplies block blk of A (rows 4 blk .. 4 blk + 3 of a 16 x 4 operand tile, lane
+// The same product on v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 blocks per instruction: 512 flops every 16 cycles), for
+// shapes made of whole tiles (M, N multiples of 64, K of 8) and outputs of up to 48 tiles.  (In a bare register loop the instruction
+// reaches 75 TFLOP/s where v_mfma_f64_16x16x4_f64 stops at 48 - tools/probes/mfma_cycles_probe.hip -; inside a GEMM both occupy the
+// pipe for 16 cycles per 512 flops - SQ_VALU_MFMA_BUSY_CYCLES, profiles/r05/gemm_pmc_K512.txt - and alone on the device the two
+// kernels tie on the headline's shapes.  What this kernel adds is how it is fed and how it shares the device: no register staging,
+// no LDS bank conflicts, the next tile's operands in flight behind the current tile's last products, an XCD-aware tile order,
+// 178 - 190 registers: +2 % end to end, and the direct H_eff form rests on its per-term operand table: +3 %.)  The instruction multiplies block blk of A (rows 4 blk .. 4 blk + 3 of a 16 x 4 operand tile, lane
 // 16 k + 4 blk + i) with block blk of B (lane 16 k + 4 blk + j) into D (lane 16 i + 4 blk + j), so a 16 x 16 output tile takes four
 // instructions on the same A tile with B in four lane ARRANGEMENTS (column block (blk + r) & 3 in the lanes of block blk, r = 0..3).
 //   * Operand tiles live in LDS in the instruction's own lane order - one 16 x 4 tile = 64 lanes x 16 bytes (re, im) = 1 KiB - filled by
@@ -251,7 +255,8 @@ typedef double d2v __attribute__((ext_vector_type(2)));
 // that the first operand tiles of the NEXT output tile are in flight during the last products of the current one and the stores of
 // an output tile drain behind the next tile's products (at K = 128 the per-tile fixed cost was a fifth of the kernel).
 // KG = k-groups of 4 per staged k-tile: 4 (k-tiles of 16, 64 KiB of LDS, two workgroups per CU) or 2 (k-tiles of 8, 32 KiB, THREE workgroups
-// per CU inside 168 registers: a barrier every 96 products instead of 192, but three wavefronts per SIMD to fill each other's stalls).
+// per CU inside 168 registers: a barrier every 96 products instead of 192, but three wavefronts per SIMD to fill each other's stalls -
+// measured: no gain, it serves the shapes whose K is a multiple of 8 only).
 template <int ABL, int KG>  // ABL: timing ablations (wrong results): 1 no staging in the loop, 2 no barrier, 4 fragments of k-group 0 for all, 8 no operand sums
 __global__ __launch_bounds__(256, KG == 2 ? 3 : 2) void zgemm4_kernel(GemmDesc g, int tiles_m, int tiles_n, long total_tiles, int xcd_map, unsigned long long* work_counter) {
   // [buffer][A tiles (row group, k-group) 16 x 64 | B tiles (column group, k-group) 16 x 64], then four doubles of the dot-product
