@@ -114,6 +114,20 @@ def test_gemm_transposed_operands_ksplit_and_inner_batches(lib):
     assert np.allclose(Cc.cpu().numpy(), ref, atol=1e-11)
 
 
+@pytest.mark.parametrize("M,N,K,nb,P", [(70, 130, 37, 24, 3), (128, 128, 32, 128, 1), (64, 192, 16, 40, 4), (96, 80, 150, 17, 2)])
+def test_gemm_in_xcd_aware_order(lib, M, N, K, nb, P):
+    """Whole-tile launches of at least 16 trajectories and 512 tiles deal their tiles to the persistent workgroups in XCD-aware order
+    (round 5: a trajectory with all its inner batches goes to workgroups of equal index mod 8); beside them ragged shapes and smaller
+    launches with inner batches sharing A, on either kernel."""
+    rng = np.random.default_rng(M + 3 * N + 7 * K + nb)
+    a, b = crand(rng, nb, M, K), crand(rng, nb, P, K, N)
+    A, B = dev(a), dev(b)
+    Cc = torch.zeros((nb, P, M, N), dtype=torch.complex128, device=DEV)
+    run_gemm(lib, A=A.data_ptr(), B=B.data_ptr(), C=Cc.data_ptr(), M=M, N=N, K=K, a_rs=K, a_cs=1, b_rs=N, b_cs=1, c_rs=N,
+             nb0=nb, nb1=P, a_b0=M * K, b_b0=P * K * N, b_b1=K * N, c_b0=P * M * N, c_b1=M * N, conjB=1)
+    assert np.allclose(Cc.cpu().numpy(), np.einsum("bmk,bpkn->bpmn", a, b.conj()), atol=1e-11 * K)
+
+
 def test_gemm_with_more_batches_than_one_grid_dimension_holds(lib):
     """3 x 150 x 150 = 67 500 batched products through the LDS-tiled kernel: more than the 65 535 of grid z (16 384 trajectories
     with two physical indices each reach it), so the batch index spills into grid y.  The innermost batch level writes the same C."""
