@@ -783,9 +783,15 @@ int multi_pitch(int nrows) { return nrows + (int)(16 / sizeof(cplx)); }
 size_t multi_lds_bytes(int nrows) { return ((size_t)PW * multi_pitch(nrows) + 7 * PW * PW) * sizeof(cplx); }
 // panels grouped per pass over the trailing matrix (TJM_QR_GROUP, default 4; 1: one panel per launch as in rounds 1 - 4); the
 // chunk has to leave room for two workgroups per CU
+// (TJM_QR_MULTI_LDS_KB: 160 by default - up to 80 KB two workgroups share a CU, above it one has the CU to itself: the 512-row chunks of
+// the fp64 centre shifts at chi = 256, config 4: 5.03 against 4.96 trajectories/s with the limit at 80)
+size_t multi_lds_limit() {
+  static const size_t kb = getenv("TJM_QR_MULTI_LDS_KB") ? (size_t)atoi(getenv("TJM_QR_MULTI_LDS_KB")) : 160;
+  return kb * 1024;
+}
 int multi_group(int zr) {
   static const int g = getenv("TJM_QR_GROUP") ? atoi(getenv("TJM_QR_GROUP")) : 4;
-  return (g > 1 && multi_lds_bytes(zr) <= 80 * 1024) ? g : 1;
+  return (g > 1 && zr <= 512 && multi_lds_bytes(zr) <= multi_lds_limit()) ? g : 1;  // (the kernel holds chunks of up to 512 rows)
 }
 
 // np panels p_first, p_first + p_step, ... on the columns [col0, col0 + nc) of C in one launch
@@ -795,8 +801,8 @@ int apply_block_reflectors(const QrWorkspace& q, int zr, int p_first, int p_step
   if (np == 1) return apply_block_reflector(q, zr, p_first, t_herm, C, c_b0, col0, nc, nb0, ids, s);
   static std::atomic<bool> attr_set{false};
   if (!attr_set.load(std::memory_order_acquire)) {
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_block_apply_multi_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_block_apply_multi_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_block_apply_multi_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)multi_lds_limit()));
+    TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(qr_block_apply_multi_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)multi_lds_limit()));
     attr_set.store(true, std::memory_order_release);
   }
   const int p_last = p_first + (np - 1) * p_step;
