@@ -144,7 +144,7 @@ int tjm_engine_stats(const tjm_engine* e, int64_t* out5);
 /* the same five counters followed by: two-site H_eff applies (a subset of matvecs), environment updates, H_eff applies served by
  * the direct form (no T2 tensor: monomial MPO rows behind certified identity channels), matrices factorised (batched SVD calls x trajectories in the call), Krylov calls whose
  * environments were examined for identity channels, channels certified (at most two per call), trajectory-steps whose scalar dissipation sweep was certified away, jumps applied in
- * place on certified states; writes min(n, 13) values */
+ * place on certified states, trajectory-bonds whose certificate test ran on the blocked Cholesky kernel (bonds above 128); writes min(n, 14) values */
 int tjm_engine_stats_ex(const tjm_engine* e, int64_t* out, int32_t n);
 /* Live device time per kernel class of a step, bracketed with HIP events on the engine's stream (the source of bench.py's
  * roofline object): class 0 = SVD family (split_two_site and the SVD centre shifts: QR, Jacobi, truncation, their GEMMs),

@@ -229,3 +229,129 @@ def test_config2_ten_steps_at_the_bench_krylov_tolerance_match_the_reference():
     e.close()
     assert np.abs(res[:, :, 0] - g["z"][:, :, -1]).max() < TOL
     assert np.array_equal(diag[:, :, 0], g["diag"][:, :, -1])
+
+
+# ---- configs 4 and 3 in the state their bench lines time: consecutive steps at krylov_tol 1e-4 (round 6) ---------------------------
+STEADY_CFG = {
+    # name: (L, chi, MPO builder, noise process, gamma, dt, tdvp_mode)
+    "cfg4": (32, 256, lambda api: api.MPO.long_range_ising(32, [0.8792, 0.1208], [0.0717, 0.5136], 0.5), "pauli_z", 0.05, 0.05, "1site"),
+    "cfg3": (128, 256, lambda api: api.MPO.heisenberg(128, 1.0, 1.0, 0.5, 0.0), "lowering", 0.05, 0.05, "2site"),
+}
+
+
+def _cfg_fixture(cfg):
+    path = os.path.join(GOLDEN, f"fullsize_steady_{cfg}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"tests/golden/fullsize_steady_{cfg}.npz not generated")
+    return np.load(path)
+
+
+def _cfg_engine(cfg, g, sel=None, dtype="complex128"):
+    from yaqs_amd.api import NoiseModel, is_pauli
+    from yaqs_amd.engine import BatchEngine
+
+    L, chi, make_mpo, proc, gamma, dt, mode = STEADY_CFG[cfg]
+    api, t = _inputs(L, chi)
+    trajs = [int(x) for x in g["traj"]]
+    if sel is not None:
+        trajs = [trajs[k] for k in sel]
+    e = BatchEngine(L, chi, len(trajs), make_mpo(api).tensors, dtype=dtype)
+    e.set_params(dt=dt, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=float(g["krylov_tol"]), tdvp_mode=mode)
+    noise = NoiseModel([{"name": proc, "sites": [i], "strength": gamma} for i in range(L)])
+    e.set_noise(noise.processes, [is_pauli(q) for q in noise.processes])
+    e.load_state(t)
+    return e, trajs, dt
+
+
+def _cfg_stages(cfg, g, sel, check=True, tol=TOL):
+    """tdvp -> dissipate -> stochastic for every step of the fixture through the stage entry points; with ``check`` the jump
+    probability (tol), the jump decision and the whole bond table (exact) of every step against the reference."""
+    from yaqs_amd.tjm import trajectory_uniforms
+
+    e, trajs, dt = _cfg_engine(cfg, g, sel)
+    steps = int(g["steps"])
+    u = np.stack([trajectory_uniforms(42, t, 2 * steps + 4) for t in trajs])
+    pos = np.zeros(len(trajs), dtype=np.int64)
+    ar = np.arange(len(trajs))
+    for k in range(steps):
+        e.tdvp()
+        e.dissipate(dt)
+        e.set_uniforms(np.stack([u[ar, pos], u[ar, pos + 1]], axis=1))
+        jumped, dp = e.stochastic(dt)
+        pos += 1 + jumped
+        if check:
+            assert np.allclose(dp, g["dp"][sel, k], atol=tol), (cfg, k, dp, g["dp"][sel, k])
+            assert np.array_equal(jumped.astype(int), g["jumped"][sel, k]), (cfg, k, jumped, g["jumped"][sel, k])
+            assert np.array_equal(e.bond_dims(), g["bonds"][sel, k]), (cfg, k)
+    M = e.site_moments()
+    z = (M[:, :, 0, 0] - M[:, :, 1, 1]).real.T
+    stats = e.stats()
+    assert not e.capacity_overflow()
+    e.close()
+    return z, stats
+
+
+def test_config4_ten_consecutive_steps_match_the_reference():
+    """``tools/make_golden.py fullsize_steady_cfg4``: the reference's analog_tjm_1 on BASELINE config 4 (L = 32, chi = 256
+    Haar-saturated, long-range Ising MPO, one-site TDVP, pauli_z 0.05, krylov_tol 1e-4 as ``bench.py --config 4``) for ten consecutive
+    steps, three trajectories (one jumps at steps 1, 2 and 5, one at step 2, one at step 5).  Per step dp (1e-8), jump decisions and
+    bond tables (exact), final <Z_i> (1e-8), through the stage entry points and through the one-call C driver.  At chi = 256 the
+    dissipation certificate runs on chol_pd_blocked_kernel (the packed triangle of a 256 x 256 Gram matrix does not fit the LDS): the
+    counters say that it ran and that it certified part of the thirty trajectory-steps - the path that bought config 4 its 25 %."""
+    g = _cfg_fixture("cfg4")
+    sel = list(range(len(g["traj"])))
+    assert g["jumped"].sum() >= 3 and g["jumped"][:, 1:].sum() > 0
+    z, stats = _cfg_stages("cfg4", g, sel)
+    err = np.abs(z - g["z"][:, :, -1]).max()
+    assert err < TOL, err
+    if NO_CERT:
+        assert stats["certified_dissipations"] == 0, stats
+    else:
+        assert stats["certificate_tests_blocked_cholesky"] > 0, stats
+        assert stats["certified_dissipations"] > 0, stats
+    e, trajs, _ = _cfg_engine("cfg4", g)
+    zmat = np.diag([1.0, -1.0]).astype(np.complex128)
+    res, diag = e.run(order=1, n_times=int(g["steps"]) + 1, sample_timesteps=False, has_noise=True, seed=42, traj_indices=trajs,
+                      observables=[(s, zmat) for s in range(32)])
+    e.close()
+    assert np.abs(res[:, :, 0] - g["z"][:, :, -1]).max() < TOL
+    assert np.array_equal(diag[:, :, 0], g["diag"][:, :, -1])
+    # batch independence: the first trajectory alone gives the same row bit for bit
+    z0, _ = _cfg_stages("cfg4", g, sel[:1], check=False)
+    assert np.array_equal(z0[0], z[0]), np.abs(z0[0] - z[0]).max()
+
+
+@pytest.mark.skipif(NO_CERT, reason="already the child run")
+def test_config4_ten_consecutive_steps_also_without_the_certified_dissipation():
+    """The test above once more in a child process with TJM_NO_CERT_DISSIPATION=1 (read once per process): every dissipation by the
+    reference's 2 (L - 1) SVD shifts."""
+    import subprocess
+    import sys
+
+    _cfg_fixture("cfg4")
+    env = dict(os.environ, TJM_NO_CERT_DISSIPATION="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "config4_ten_consecutive and not also_without"],
+                         env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__)))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "1 passed" in out.stdout, out.stdout[-2000:]
+
+
+def test_config3_three_consecutive_steps_match_the_reference():
+    """``tools/make_golden.py fullsize_steady_cfg3``: the reference's analog_tjm_1 on BASELINE config 3 in complex128 (L = 128,
+    chi = 256 Haar-saturated, XXZ, amplitude damping 0.05 on every site - non-Pauli jumps: the real probability sweep, the d x d
+    dissipator, 512 x 512 two-site splits -, krylov_tol 1e-4) for three consecutive steps, two trajectories: from the second step on
+    bonds and gauges are the run's own.  dp 1e-8 per step, jump decisions and bond tables exact, final <Z_i> 1e-8; stage entry
+    points and the one-call C driver."""
+    g = _cfg_fixture("cfg3")
+    sel = list(range(len(g["traj"])))
+    assert g["jumped"].sum() >= 2
+    z, stats = _cfg_stages("cfg3", g, sel)
+    err = np.abs(z - g["z"][:, :, -1]).max()
+    assert err < TOL, err
+    e, trajs, _ = _cfg_engine("cfg3", g)
+    zmat = np.diag([1.0, -1.0]).astype(np.complex128)
+    res, diag = e.run(order=1, n_times=int(g["steps"]) + 1, sample_timesteps=False, has_noise=True, seed=42, traj_indices=trajs,
+                      observables=[(s, zmat) for s in range(128)])
+    e.close()
+    assert np.abs(res[:, :, 0] - g["z"][:, :, -1]).max() < TOL
+    assert np.array_equal(diag[:, :, 0], g["diag"][:, :, -1])

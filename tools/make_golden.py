@@ -731,6 +731,100 @@ def gen_fullsize_steady(trajs=(0, 1, 2), steps=10, sample=True, krylov_tol=1e-10
     save(name, **out)
 
 
+# ------------------------------------------------------------------ 12b. configs 4 and 3: consecutive steps at the bench's krylov_tol
+STEADY_CFGS = {
+    # name: (L, chi, MPO builder, noise process, gamma, dt, tdvp_mode, steps)
+    "cfg4": (32, 256, lambda api: api.MPO.long_range_ising(32, [0.8792, 0.1208], [0.0717, 0.5136], 0.5), "pauli_z", 0.05, 0.05, "1site", 10),
+    "cfg3": (128, 256, lambda api: api.MPO.heisenberg(128, 1.0, 1.0, 0.5, 0.0), "lowering", 0.05, 0.05, "2site", 3),
+}
+
+
+def _steady_cfg_one(cfg, traj, steps, krylov_tol):
+    """One trajectory of gen_fullsize_steady_cfg (forked worker): the reference's analog_tjm_1 for `steps` consecutive steps of
+    BASELINE config 3 or 4 at full size, final-time sampling; dp / jump decision / bond table of every step via spies."""
+    import time
+
+    L, chi, make_mpo, proc, gamma, dt, tdvp_mode, _ = STEADY_CFGS[cfg]
+    api, tensors = _fullsize_inputs(L, chi)
+    H = MPO()
+    H.tensors = [np.asarray(w, dtype=np.complex128) for w in make_mpo(api).tensors]
+    H.length = L
+    H.physical_dimension = 2
+    noise = NoiseModel([{"name": proc, "sites": [i], "strength": gamma} for i in range(L)])
+    obs = [sp.Observable(gl.Z(), s) for s in range(L)]
+    p = sp.AnalogSimParams(observables=obs, elapsed_time=dt * steps, dt=dt, max_bond_dim=chi, svd_threshold=1e-12, krylov_tol=krylov_tol,
+                           order=1, sample_timesteps=False, random_seed=42, tdvp_mode=tdvp_mode, get_state=True)
+    dps, jumped, bonds = [], [], []
+    orig_f, orig_pdf, orig_sp = stoch.calculate_stochastic_factor, stoch.create_probability_distribution, tjm.stochastic_process
+
+    def spy_f(state):
+        v = orig_f(state)
+        dps.append(float(v))
+        jumped.append(0)
+        return v
+
+    def spy_pdf(state, *a, **k):
+        jumped[-1] = 1
+        return orig_pdf(state, *a, **k)
+
+    def spy_sp(state, *a, **k):
+        out = orig_sp(state, *a, **k)
+        bonds.append([out.tensors[0].shape[1]] + [x.shape[2] for x in out.tensors])
+        print(f"  {cfg}: trajectory {traj} step {len(bonds)} done after {time.time() - t0:.0f} s, dp {dps[-1]:.6f} jumped {jumped[-1]}", flush=True)
+        return out
+
+    stoch.calculate_stochastic_factor = spy_f
+    stoch.create_probability_distribution = spy_pdf
+    tjm.stochastic_process = spy_sp
+    t0 = time.time()
+    try:
+        st = MPS(L, tensors=[x.copy() for x in tensors])
+        r, dg, final = tjm.analog_tjm_1((traj, st, noise, p, H))
+    finally:
+        stoch.calculate_stochastic_factor, stoch.create_probability_distribution = orig_f, orig_pdf
+        tjm.stochastic_process = orig_sp
+    print(f"  {cfg}: trajectory {traj} took {time.time() - t0:.1f} s, dp {dps}, jumped {jumped}", flush=True)
+    return dict(z=np.asarray(r, dtype=np.float64), diag=np.asarray(dg, dtype=np.float64), dp=np.array(dps), jumped=np.array(jumped),
+                bonds=np.array(bonds))
+
+
+def _pick_trajs(cfg):
+    """Trajectories chosen from the reference's stream table alone (make_trajectory_rng, base seed 42): one that starts quietly,
+    one whose opening uniform jumps at step 1, one that passes step 1 and has a small uniform right after (a jump once the bonds and
+    gauges are the run's own)."""
+    us = np.array([rutil.make_trajectory_rng(t, base_seed=42).random(4) for t in range(4000)])
+    quiet = int(next(t for t in range(4000) if us[t, 0] > 0.5 and us[t, 1] > 0.5))
+    early = int(next(t for t in range(4000) if us[t, 0] < 0.05 and us[t, 2] < 0.07))  # jumps at step 1 and again at step 2
+    late = int(next(t for t in range(4000) if us[t, 0] > 0.3 and us[t, 1] < 0.04))  # quiet step 1, jumps at step 2
+    return [quiet, early, late] if cfg == "cfg4" else [early, late]
+
+
+def gen_fullsize_steady_cfg4():
+    gen_fullsize_steady_cfg("cfg4")
+
+
+def gen_fullsize_steady_cfg3():
+    gen_fullsize_steady_cfg("cfg3")
+
+
+def gen_fullsize_steady_cfg(cfg, krylov_tol=1e-4):
+    """tests/golden/fullsize_steady_<cfg>.npz: what fullsize_steady_tol4 is for config 2, for the other two analog BASELINE rows - the
+    states bench.py --config 3 / 4 time after their first step (krylov_tol 1e-4 as the bench).  config 4: L = 32, chi = 256, one-site
+    TDVP, long-range Ising MPO, pauli_z 0.05, ten consecutive steps, three trajectories; config 3: L = 128, chi = 256, XXZ with
+    amplitude damping (non-Pauli jumps), three consecutive steps, two trajectories.  One forked worker per trajectory."""
+    import multiprocessing as mp
+
+    steps = STEADY_CFGS[cfg][7]
+    trajs = _pick_trajs(cfg)
+    print(cfg, "trajectories", trajs, flush=True)
+    with mp.get_context("fork").Pool(len(trajs)) as pool:
+        rows = pool.starmap(_steady_cfg_one, [(cfg, t, steps, krylov_tol) for t in trajs])
+    out = {"traj": np.array(trajs), "steps": np.array(steps), "krylov_tol": np.array(krylov_tol)}
+    for k in rows[0]:
+        out[k] = np.array([r[k] for r in rows])
+    save("fullsize_steady_" + cfg, **out)
+
+
 # ------------------------------------------------------------------ 13. dynamic TDVP and the BUG integrator (SURVEY 8f-3)
 def gen_f3():
     """One call of tdvp(tdvp_mode="dynamic") (integrators.py:294-511) and of bug() (bug.py:213-257) on small chains - bonds below,

@@ -251,10 +251,11 @@ int tjm_engine_stats(const tjm_engine* e, int64_t* o) {
 
 int tjm_engine_stats_ex(const tjm_engine* e, int64_t* o, int32_t n) {
   if (!e || !o || n < 0) return TJM_ERR_ARG;
-  const int64_t v[13] = {e->impl.stat_matvecs, e->impl.stat_krylov_calls, e->impl.stat_svds, e->impl.stat_svd_sweeps,
+  const int64_t v[14] = {e->impl.stat_matvecs, e->impl.stat_krylov_calls, e->impl.stat_svds, e->impl.stat_svd_sweeps,
                          e->impl.stat_site_updates, e->impl.stat_matvecs2, e->impl.stat_env_updates, e->impl.stat_direct_applies,
-                         e->impl.stat_svd_mats, e->impl.stat_ident_calls, e->impl.stat_ident_hits, e->impl.stat_cert_traj, e->impl.stat_cert_jumps};
-  for (int k = 0; k < n && k < 13; ++k) o[k] = v[k];
+                         e->impl.stat_svd_mats, e->impl.stat_ident_calls, e->impl.stat_ident_hits, e->impl.stat_cert_traj, e->impl.stat_cert_jumps,
+                         e->impl.stat_cert_blocked};
+  for (int k = 0; k < n && k < 14; ++k) o[k] = v[k];
   return TJM_OK;
 }
 

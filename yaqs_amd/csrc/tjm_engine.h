@@ -103,6 +103,7 @@ class Engine {
   int identity_channels(int ca, int cb, const cplx* Lenv, long l_b0, int Dl, const cplx* Renv, long r_b0, int Dr, int nb0, const int* ids,
                         const int* chi_l, const int* chi_r, int* lch, int* rch);
   long stat_cert_traj = 0, stat_cert_jumps = 0;  // trajectory-steps whose scalar dissipation sweep was certified away / jumps applied in place
+  long stat_cert_blocked = 0;                    // trajectory-bonds whose certificate test ran on chol_pd_blocked_kernel (bonds above 128)
   long stat_ident_calls = 0, stat_ident_hits = 0;  // Krylov calls examined / channels certified (of two per call)
 
   struct Prof {

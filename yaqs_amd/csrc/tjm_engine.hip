@@ -1383,20 +1383,48 @@ int Engine::state_checksum(int set, const int* ids, int n, unsigned long long* h
 // "G_k - cut I is positive definite": a Cholesky factorisation that meets no non-positive pivot (chol_pd_kernel, one workgroup per
 // trajectory, the lower triangle in LDS).  The test only has to be SUFFICIENT (a trajectory that fails it takes the reference's
 // sweep), so the cut carries an absolute margin for the rounding of the recursion and of the factorisation (2e-14: n eps ||G|| with
-// ||G|| <= 1, against eigenvalues that matter at 1e-12).  Per trajectory-step: 63 x 2 products of 128^3 and 63 factorisations of
+// ||G|| <= 1, against eigenvalues that matter at 1e-12; round 6, ADVICE r5: plus a term that follows the chain position, the size and
+// the norm of the matrix, 4 (k + 1) n u ||G_k||_F with u = 2^-53 - the first-order bound of k + 1 recursion steps of inner products
+// of length ~n and of the factorisation, 3e-13 at the end of the headline's chain; a false pass would skip a truncation the
+// reference performs, a false fail only costs the reference's sweep for that trajectory).  Per trajectory-step: 63 x 2 products of 128^3 and 63 factorisations of
 // 128 x 128 instead of 63 Jacobi SVDs of 256 x 128 (ten fp64 sweeps each in the evolved state).  fp64 build only: in complex64 the
 // Gram matrix is not resolved at 1e-12.  TJM_CERT_SVD_PASS: the SVD pass of rounds 3 - 4.
-__global__ __launch_bounds__(256) void chol_pd_kernel(const cplx* __restrict__ E, long e_b0, int ld, const int* __restrict__ chi, int chi_stride, real cut,
-                                                     int* __restrict__ flag, const int* ids) {
+// ||G||_F of the Hermitian matrix whose lower triangle is E (row-major, leading dimension ld), by the whole workgroup; the rounding
+// margin of the positive-definiteness tests below is proportional to it (cert_pass_gram)
+__device__ inline real gram_fro(const cplx* __restrict__ Eb, int ld, int n, real* s_red) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  real acc = 0.0;
+  for (long e = tid; e < (long)n * n; e += nt) {
+    const int i = (int)(e / n), j = (int)(e % n);
+    if (j > i) continue;
+    const cplx v = Eb[(long)i * ld + j];
+    const real a = v.x * v.x + ((i == j) ? real(0.0) : v.y * v.y);
+    acc += (i == j) ? a : a + a;
+  }
+  s_red[tid] = acc;
+  __syncthreads();
+  for (int h = nt >> 1; h > 0; h >>= 1) {
+    if (tid < h) s_red[tid] += s_red[tid + h];
+    __syncthreads();
+  }
+  const real f = sqrt(s_red[0]);
+  __syncthreads();
+  return f;
+}
+
+__global__ __launch_bounds__(256) void chol_pd_kernel(const cplx* __restrict__ E, long e_b0, int ld, const int* __restrict__ chi, int chi_stride, real cut0,
+                                                     real rel_margin, int* __restrict__ flag, const int* ids) {
   extern __shared__ real chol_smem[];
   cplx* Lp = reinterpret_cast<cplx*>(chol_smem);  // packed lower triangle, row-major: (i, j <= i) at i (i + 1) / 2 + j
   __shared__ real s_piv;
+  __shared__ real s_red[256];
   int b = blockIdx.x;
   if (ids) b = ids[b];
   const int n = chi[(long)b * chi_stride];
   const cplx* Eb = E + (long)b * e_b0;
   const int tid = threadIdx.x;
   const int ntri = n * (n + 1) / 2;
+  const real cut = cut0 + rel_margin * gram_fro(Eb, ld, n, s_red);
   for (int e = tid; e < ntri; e += 256) {
     // row i of entry e: largest i with i (i + 1) / 2 <= e
     int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
@@ -1446,19 +1474,21 @@ __global__ __launch_bounds__(256) void chol_pd_kernel(const cplx* __restrict__ E
 // flag[b] = 1 at the first non-positive pivot.
 constexpr int CHB = 32;
 __global__ __launch_bounds__(1024) void chol_pd_blocked_kernel(const cplx* __restrict__ E, long e_b0, int ld, cplx* __restrict__ Wk, long w_b0,
-                                                              const int* __restrict__ chi, int chi_stride, real cut, int* __restrict__ flag,
-                                                              const int* ids) {
+                                                              const int* __restrict__ chi, int chi_stride, real cut0, real rel_margin,
+                                                              int* __restrict__ flag, const int* ids) {
   extern __shared__ real cholb_smem[];
   cplx* sD = reinterpret_cast<cplx*>(cholb_smem);  // [CHB][CHB + 1] diagonal block
   cplx* sX = sD + CHB * (CHB + 1);                 // [rows below][CHB + 1] solved panel
   __shared__ real s_piv;
   __shared__ int s_bad;
+  __shared__ real s_red[1024];
   int b = blockIdx.x;
   if (ids) b = ids[b];
   const int n = chi[(long)b * chi_stride];
   const cplx* Eb = E + (long)b * e_b0;
   cplx* W = Wk + (long)b * w_b0;
   const int tid = threadIdx.x, nt = blockDim.x;
+  const real cut = cut0 + rel_margin * gram_fro(Eb, ld, n, s_red);
   for (long e = tid; e < (long)n * n; e += nt) {  // working copy of the lower triangle, the cut off the diagonal
     const int i = (int)(e / n), j = (int)(e % n);
     if (j > i) continue;
@@ -1591,12 +1621,16 @@ int Engine::cert_pass_gram(StateSet& S, const int* ids, int nb0, double cut) {
     std::swap(E, En);
     const size_t lds = (size_t)cb * (cb + 1) / 2 * sizeof(cplx);
     static const bool force_blocked = getenv("TJM_CHOL_BLOCKED") != nullptr;  // diagnostic: the blocked kernel at every size
+    // rounding margin of this bond's test: 4 (k + 1) n u ||G_k||_F (the kernels measure the norm)
+    static const double margin_c = getenv("TJM_CERT_MARGIN_C") ? atof(getenv("TJM_CERT_MARGIN_C")) : 4.0;
+    const real rel_margin = (real)(margin_c * (double)(i + 1) * (double)cb * 1.1102230246251565e-16);
     if (lds <= 140 * 1024 && !(force_blocked && cb >= 8))
-      hipLaunchKernelGGL(chol_pd_kernel, dim3(nb0), dim3(256), lds, stream, E, (long)cb * cb, cb, S.chi + i + 1, L + 1, (real)cut, cert_flag_, ids);
+      hipLaunchKernelGGL(chol_pd_kernel, dim3(nb0), dim3(256), lds, stream, E, (long)cb * cb, cb, S.chi + i + 1, L + 1, (real)cut, rel_margin, cert_flag_, ids);
     else {
       const size_t ldsb = ((size_t)CHB * (CHB + 1) + (size_t)(cb > CHB ? cb - CHB : 1) * (CHB + 1)) * sizeof(cplx);
       hipLaunchKernelGGL(chol_pd_blocked_kernel, dim3(nb0), dim3(1024), ldsb, stream, E, (long)cb * cb, cb, T2, t_b0, S.chi + i + 1, L + 1, (real)cut,
-                         cert_flag_, ids);
+                         rel_margin, cert_flag_, ids);
+      stat_cert_blocked += nb0;
     }
   }
   TJM_HIP_CHECK(hipGetLastError());

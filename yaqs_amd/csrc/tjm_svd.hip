@@ -62,6 +62,8 @@ struct JacobiArgs {
   int fold;     // jacobi_cross16x_kernel: the pairs inside a 16-column block ride along with the tile visits (no diag / sibling launches)
   int* work;    // rotation slots executed in this sweep (tile visits x pairs per visit; the identity rotations of a visited tile count)
   real floor_scale;  // columns below sqrt(floor_scale) ||X||_F are numerically null (TJM_NOISE_FLOOR2 unless the caller says otherwise)
+  int ngroups;  // jacobi_quad64_kernel: groups of 16 blocks (256 columns) of the matrix ...
+  int ground;   // ... and, in its cross mode (mode 1), the round of the circle method on the groups (round = the shift 0 ... 7)
 };
 
 __device__ inline void pair_of(int nblk, int round, int p, int& I, int& J) {
@@ -809,7 +811,7 @@ __device__ inline int fold_column4(int tr, int w, int h) {
 }
 
 template <int XRK, bool LATE>
-__global__ __launch_bounds__(256, 4) void jacobi_cross16q_kernel(JacobiArgs g) {
+__global__ __launch_bounds__(256, (XRK <= 4) ? 4 : 2) void jacobi_cross16q_kernel(JacobiArgs g) {
   extern __shared__ real smem[];
   int b = blockIdx.y;
   if (g.ids) b = g.ids[b];
@@ -951,8 +953,20 @@ __device__ inline int gf4_mul(int a, int b) { return (0x9C78E400u >> (2 * (4 * a
 // k-th point (0 ... 3) of line `line` of parallel class `cls` (0 ... 4) of AG(2,4); points are numbered 4 x + y
 __device__ inline int ag_point(int cls, int line, int k) { return cls == 4 ? 4 * line + k : 4 * k + (gf4_mul(cls, k) ^ line); }
 
+//
+// Matrices of more than 256 columns (round 6: 512 x 512 is the two-site split of chi = 256, BASELINE config 3).  No resolvable design
+// with lines of four covers 32 points, so the blocks are taken in GROUPS of 16 (256 columns each) and a sweep has two kinds of launches:
+//   mode 0  the plane inside every group, all groups side by side (5 launches x 3 rounds: every pair of blocks of one group, and the
+//           120 in-block pairs of every block, exactly as above);
+//   mode 1  two groups against each other: a quad takes the blocks (2 i, 2 i + 1) of group a and (2 j, 2 j + 1) of group b,
+//           j = i + shift mod 8, as A = a_2i, B = b_2j, C = b_2j+1, D = a_2i+1 and plays only the first TWO rounds - (A,B)(C,D) and
+//           (A,C)(B,D), the four cross tiles; the third, (A,D)(B,C), lies inside the groups and belongs to mode 0.  8 shifts visit
+//           the 256 cross tiles of a group pair once; the group pairs follow the circle method (one pair for 512 columns).  No
+//           in-block pairs ride along here.
+// 512 columns: 5 + 8 = 13 loads and stores of the matrix per sweep instead of 31; XRK = 8 (512 rows) keeps the eight columns of a
+// wavefront in 128 registers and the hand-over buffer in 128 KB of LDS - one workgroup per CU, two wavefronts per SIMD.
 template <int XRK, bool LATE>
-__global__ __launch_bounds__(512, 4) void jacobi_quad64_kernel(JacobiArgs g) {
+__global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_quad64_kernel(JacobiArgs g) {
   extern __shared__ real smem[];
   int b = blockIdx.y;
   if (g.ids) b = __builtin_amdgcn_readfirstlane(g.ids[b]);
@@ -963,10 +977,22 @@ __global__ __launch_bounds__(512, 4) void jacobi_quad64_kernel(JacobiArgs g) {
   real* slots = smem;                                    // [8][4] columns of Col::LDS_REALS
   real* sN = slots + 32 * Col::LDS_REALS;                // [8][4]
   int* sCnt = reinterpret_cast<int*>(sN + 32);           // [8]
-  const int cls = g.round;                               // parallel class of this launch (0 ... 4)
+  const bool plane = g.mode == 0;
+  const int cls = plane ? g.round : 4;                   // parallel class of this launch (0 ... 4); cross mode: the columns 4 w ... 4 w + 3
+  const int last = plane ? 2 : 1;                        // last round played
   int blk[4];
+  if (plane) {
+    const int base = 16 * (blockIdx.x >> 2), line = blockIdx.x & 3;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) blk[k] = ag_point(cls, blockIdx.x, k);
+    for (int k = 0; k < 4; ++k) blk[k] = base + ag_point(cls, line, k);
+  } else {
+    int ga, gb;
+    pair_of(g.ngroups + (g.ngroups & 1), g.ground, blockIdx.x >> 3, ga, gb);
+    if (gb >= g.ngroups) return;                         // (an odd number of groups: the bye of this round)
+    const int i = blockIdx.x & 7, j = (i + g.round) & 7;
+    blk[0] = 16 * ga + 2 * i; blk[3] = blk[0] + 1;
+    blk[1] = 16 * gb + 2 * j; blk[2] = blk[1] + 1;
+  }
   int* st = g.stamps + (long)b * STAMP_STRIDE;
   int mod[4], nz[4];
 #pragma unroll
@@ -979,7 +1005,7 @@ __global__ __launch_bounds__(512, 4) void jacobi_quad64_kernel(JacobiArgs g) {
   auto tile_open = [&](int i, int j) { return (nz[i] || nz[j]) && !(__builtin_amdgcn_readfirstlane(ver_of(i, j)) > max(mod[i], mod[j])); };
   {
     // nothing open in the first round and nothing that a rotation of this launch could re-open: leave before the load
-    const bool any = tile_open(0, 1) || tile_open(2, 3) || tile_open(0, 2) || tile_open(1, 3) || tile_open(0, 3) || tile_open(1, 2);
+    const bool any = tile_open(0, 1) || tile_open(2, 3) || tile_open(0, 2) || tile_open(1, 3) || (plane && (tile_open(0, 3) || tile_open(1, 2)));
     if (!any) return;
   }
   cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0;
@@ -1060,7 +1086,7 @@ __global__ __launch_bounds__(512, 4) void jacobi_quad64_kernel(JacobiArgs g) {
     cnt = 0;
     // the in-block pairs of this round: slots (0, 1) and (2, 3) of each block - the slots are rotated between the rounds (below), so
     // that one piece of code plays the three perfect matchings of the four columns
-    if (open) sub_step(yI[0], yI[1], nI[0], nI[1], yI[2], yI[3], nI[2], nI[3], yJ[0], yJ[1], nJ[0], nJ[1], yJ[2], yJ[3], nJ[2], nJ[3]);
+    if (open && plane) sub_step(yI[0], yI[1], nI[0], nI[1], yI[2], yI[3], nI[2], nI[3], yJ[0], yJ[1], nJ[0], nJ[1], yJ[2], yJ[3], nJ[2], nJ[3]);
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
       if (cross) {
@@ -1095,7 +1121,8 @@ __global__ __launch_bounds__(512, 4) void jacobi_quad64_kernel(JacobiArgs g) {
     const int tot1 = __builtin_amdgcn_readfirstlane(sCnt[4] + sCnt[5] + sCnt[6] + sCnt[7]);
     const int stamp = g.clock + t;
     const bool moved0 = open0 && tot0 > 0, moved1 = open1 && tot1 > 0;
-    work += (open0 ? (cross0 ? REC_PER_VISIT : 0) + 2 * NB : 0) + (open1 ? (cross1 ? REC_PER_VISIT : 0) + 2 * NB : 0);  // (scalar, every thread)
+    const int inb = plane ? 2 * NB : 0;  // rotation slots of the in-block sub-step
+    work += (open0 ? (cross0 ? REC_PER_VISIT : 0) + inb : 0) + (open1 ? (cross1 ? REC_PER_VISIT : 0) + inb : 0);  // (scalar, every thread)
     if (moved0) total_all += tot0;
     if (moved1) total_all += tot1;
     if (t == 0) {
@@ -1120,7 +1147,7 @@ __global__ __launch_bounds__(512, 4) void jacobi_quad64_kernel(JacobiArgs g) {
       if (moved0) { mod[0] = stamp; mod[3] = stamp; }
       if (moved1) { mod[1] = stamp; mod[2] = stamp; }
     }
-    if (t == 2) break;
+    if (t == last) break;
     // ---- between the rounds.  (i) Slots 1, 2, 3 of every block rotate: (c0 c1 c2 c3) -> (c0 c2 c3 c1) -> (c0 c3 c1 c2), the three
     // matchings.  (ii) One block of each group changes sides, always as the J block: group 0 gives B, then C; group 1 - whose fixed
     // block would have to change with the round - first trades the roles of its two blocks (registers only: (C, D) -> (D, C) gives
@@ -1158,24 +1185,31 @@ __global__ __launch_bounds__(512, 4) void jacobi_quad64_kernel(JacobiArgs g) {
   }
   if (tid == 0 && g.work && work) atomicAdd(g.work, work);
   if (total_all == 0) return;
-  // blocks that were rotated in this launch go back (mod stamps of this launch), by whoever holds them now: group 0 ends with
-  // (A, D), group 1 with (B, C)
+  // blocks that were rotated in this launch go back (mod stamps of this launch), by whoever holds them now: after three rounds group 0
+  // ends with (A, D), group 1 with (B, C); after the two rounds of the cross mode group 0 holds (A, C), group 1 (D, B)
   if (tid == 0) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (mod[k] >= g.clock) { st[2 * blk[k]] = mod[k]; st[2 * blk[k] + 1] = mod[k]; }
     atomicAdd(&g.nrot[b], total_all);
   }
-  const int bI = grp == 0 ? blk[0] : blk[1], bJ = grp == 0 ? blk[3] : blk[2];
-  const int mI = grp == 0 ? mod[0] : mod[1], mJ = grp == 0 ? mod[3] : mod[2];
-  // after the two rotations slot h holds point (0, 3, 1, 2)[h] of its line
+  const int kI = plane ? (grp == 0 ? 0 : 1) : (grp == 0 ? 0 : 3), kJ = plane ? (grp == 0 ? 3 : 2) : (grp == 0 ? 2 : 1);
+  const int bI = blk[kI], bJ = blk[kJ];
+  const int mI = mod[kI], mJ = mod[kJ];
+  // after the two rotations slot h holds point (0, 3, 1, 2)[h] of its line; after one (cross mode) point (0, 2, 3, 1)[h]
   if (mI >= g.clock) {
 #pragma unroll
-    for (int h = 0; h < 4; ++h) yI[h].store(Yb + (long)(bI * 16 + ag_point(cls, qI, h == 0 ? 0 : h == 1 ? 3 : h - 1)) * rtot, lane);
+    for (int h = 0; h < 4; ++h) {
+      const int pt = plane ? (h == 0 ? 0 : h == 1 ? 3 : h - 1) : (h == 0 ? 0 : h == 3 ? 1 : h + 1);
+      yI[h].store(Yb + (long)(bI * 16 + ag_point(cls, qI, pt)) * rtot, lane);
+    }
   }
   if (mJ >= g.clock) {
 #pragma unroll
-    for (int h = 0; h < 4; ++h) yJ[h].store(Yb + (long)(bJ * 16 + ag_point(cls, qJ, h == 0 ? 0 : h == 1 ? 3 : h - 1)) * rtot, lane);
+    for (int h = 0; h < 4; ++h) {
+      const int pt = plane ? (h == 0 ? 0 : h == 1 ? 3 : h - 1) : (h == 0 ? 0 : h == 3 ? 1 : h + 1);
+      yJ[h].store(Yb + (long)(bJ * 16 + ag_point(cls, qJ, pt)) * rtot, lane);
+    }
   }
 }
 
@@ -2295,12 +2329,22 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   static const bool no_split = getenv("TJM_NO_SPLIT") != nullptr;
   // without the accumulated unitary the X rows are padded to whole 64-row groups (zero rows cost nothing in the dot products and
   // let the split X kernel serve every height up to 512)
-  const int rx_top = accumulate ? round_up(src.rx, 16) : round_up(src.rx, 64);
+  // X-only solves of the complex64 arithmetic keep up to 1024 rows of a column in the registers of one wavefront (16 row groups, in
+  // pairs: whole groups of 128 rows above 512) - the splits of bonds up to 512 (round 6; TJM_NO_X1024: the 8-column kernels as before)
+#ifdef TJM_F32
+  static const bool no_x1024 = getenv("TJM_NO_X1024") != nullptr;
+  const int x_rows_max = no_x1024 ? 512 : 1024;
+#else
+  const int x_rows_max = 512;
+#endif
+  int rx_top_ = accumulate ? round_up(src.rx, 16) : round_up(src.rx, 64);
+  if (!accumulate && rx_top_ > 512 && rx_top_ <= x_rows_max) rx_top_ = round_up(src.rx, 128);
+  const int rx_top = rx_top_;
   const int ncols32 = round_up(src.ncols, 32);
   // split X / W scheme: 16-column blocks; X rows in whole groups of 64 up to 512 (with the accumulated unitary: exactly 256 or 512
   // and W rows in groups of 64)
   const int wrows32 = accumulate ? ncols32 : 0;  // rows of the accumulated unitary stacked under X
-  const bool split16 = !no16 && !no_split && ncols32 >= 32 && ((!accumulate && rx_top <= 512) || ((rx_top == 256 || rx_top == 512) && ncols32 % 64 == 0)) &&
+  const bool split16 = !no16 && !no_split && ncols32 >= 32 && ((!accumulate && rx_top <= x_rows_max) || ((rx_top == 256 || rx_top == 512) && ncols32 % 64 == 0)) &&
                        (w.rec != nullptr || !accumulate) && src.nb0 <= 65535 && round_up(rx_top + wrows32, 64) <= 64 * MAXRK;
   // fused 16-column blocks for the smaller matrices (two stacked columns per wavefront fit registers and LDS up to 512 rows)
   const bool tile16 = split16 || (!no16 && ncols32 >= 32 && round_up(rx_top + wrows32, 64) <= 512);
@@ -2353,6 +2397,12 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
     TJM_X16_ATTR(6, big_lds);
     TJM_X16_ATTR(7, big_lds);
     TJM_X16_ATTR(8, big_lds);
+#ifdef TJM_F32
+    TJM_X16_ATTR(10, big_lds);
+    TJM_X16_ATTR(12, big_lds);
+    TJM_X16_ATTR(14, big_lds);
+    TJM_X16_ATTR(16, big_lds);
+#endif
 #undef TJM_X16_ATTR
     attr_set.store(true, std::memory_order_release);
   }
@@ -2398,35 +2448,63 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   const int rx_slot = rx_top;
 #endif
   const size_t lds16x = (size_t)2 * NB * rx_slot * sizeof(cplx) + 2 * NB * sizeof(real) + 16 * sizeof(int);
-  // four columns of each block per wavefront (jacobi_cross16q_kernel): X-only solves of the complex64 build up to 256 rows
+  // four columns of each block per wavefront (jacobi_cross16q_kernel): X-only solves of the complex64 arithmetic up to 512 rows (round 6:
+  // every such solve, not only the complex64 phase of the mixed split - the rotation rule is the same, the order inside a visit differs;
+  // TJM_QUAD_ONLY_MIXED: as before, only where the caller asks for it; 256 < rows <= 512: eight row groups, two wavefronts per SIMD)
   bool quad16 = false;
 #ifdef TJM_F32
   {
     static const bool no_quad = getenv("TJM_NO_QUAD_TILE") != nullptr;
-    quad16 = !no_quad && op.quad && split16 && !accumulate && rx_top <= 256;
+    static const bool only_mixed = getenv("TJM_QUAD_ONLY_MIXED") != nullptr;
+    static const bool no_quad512 = getenv("TJM_NO_QUAD512") != nullptr;
+    quad16 = !no_quad && (op.quad || !only_mixed) && split16 && !accumulate && rx_top <= (no_quad512 ? 256 : 512);
+    static std::atomic<bool> q16_attr{false};
+    if (quad16 && rx_top > 256 && !q16_attr.load(std::memory_order_acquire)) {
+#define TJM_Q16_ATTR(K)                                                                                                                              \
+  TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16q_kernel<K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024)); \
+  TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_cross16q_kernel<K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024))
+      TJM_Q16_ATTR(5); TJM_Q16_ATTR(6); TJM_Q16_ATTR(7); TJM_Q16_ATTR(8);
+#undef TJM_Q16_ATTR
+      q16_attr.store(true, std::memory_order_release);
+    }
   }
 #endif
   const size_t lds16q = lds16x;
-  // three rounds per load (jacobi_quad64_kernel): 16 blocks of 16 columns = the points of AG(2,4); TJM_NO_QUAD64: one round per launch
+  // three rounds per load (jacobi_quad64_kernel): groups of 16 blocks of 16 columns = the points of AG(2,4), the groups against each
+  // other two rounds per load; TJM_NO_QUAD64: one round per launch
   bool quad64 = false;
+  [[maybe_unused]] const int ngroups = ncols_pad / 256;
 #ifdef TJM_F32
   {
     static const bool no_quad64 = getenv("TJM_NO_QUAD64") != nullptr;
-    quad64 = quad16 && !no_quad64 && ncols_pad == 256 && rx_top == 256;
+    static const bool no_quad64_groups = getenv("TJM_NO_QUAD64_GROUPS") != nullptr;
+    quad64 = quad16 && !no_quad64 && ncols_pad % 256 == 0 && ngroups <= (no_quad64_groups ? 1 : 4) && (rx_top == 256 || rx_top == 512);
     static std::atomic<bool> q64_attr{false};
     if (quad64 && !q64_attr.load(std::memory_order_acquire)) {
       TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
+      TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
       q64_attr.store(true, std::memory_order_release);
     }
   }
 #endif
   [[maybe_unused]] const size_t lds64 = 2 * lds16x + 16 * sizeof(real) + 16 * sizeof(int);
+  g.ngroups = ngroups;
+  g.ground = 0;
+  // launches of one sweep of the grouped schedule: 5 plane classes (three rounds each), then for every round of the circle method on
+  // the groups 8 shifts (two rounds each)
+  const int q64_geven = ngroups + (ngroups & 1);
+  const int q64_launches = quad64 ? 5 + (ngroups > 1 ? 8 * (q64_geven - 1) : 0) : 0;
   g.rec = accumulate ? w.rec : nullptr;
   // in-block pairs folded into the tile visits (jacobi_cross16x_kernel): needs the 15 tournament rounds of a 16-column block inside
   // one sweep, and no rotation record (the W replay kernel knows the fixed column assignment only)
   static const bool no_fold = getenv("TJM_NO_FOLD") != nullptr;
   g.fold = (!no_fold && split16 && !accumulate && nrounds >= 15) ? 1 : 0;
+  if (g_debug && src.ncols >= 128)
+    fprintf(stderr, "[svd] ncols_pad %d rx_top %d rtot %d batch %d: %s%s\n", ncols_pad, rx_top, rtot, src.nb0,
+            quad64 ? "jacobi_quad64_kernel" : quad16 ? "jacobi_cross16q_kernel" : split16 ? "jacobi_cross16x_kernel" : tile16 ? "jacobi_cross16_kernel" : "jacobi_cross_kernel",
+            g.fold ? " (in-block pairs folded)" : "");
   const int max_sweeps = op.max_sweeps;
   // op.stop_fraction: a caller that refines the result anyway (the complex64 phase of the mixed-precision split) does not pay for the
   // sweeps that only confirm convergence: a trajectory is done after a sweep that rotated at most this fraction of its pairs
@@ -2471,8 +2549,12 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
       else hipLaunchKernelGGL(jacobi_cross_kernel<8>, dim3(g.nblk / 2, nb), dim3(512), lds, s, g);
       g.mode = 0;
     }
-    for (int r = 0; r < (quad64 ? 5 : nrounds); ++r) {
+    for (int r = 0; r < (quad64 ? q64_launches : nrounds); ++r) {
       g.round = r;
+      if (quad64) {
+        g.mode = r < 5 ? 0 : 1;
+        if (r >= 5) { g.ground = (r - 5) >> 3; g.round = (r - 5) & 7; }
+      }
       ++g.clock;
       const bool timed = g_prof.every > 0 && split16 && (t_prof.counter++ % g_prof.every == 0);  // only the dominant (split X) kernel is sampled
       int slot = -1;
@@ -2485,15 +2567,24 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
         }
         TJM_HIP_CHECK(hipEventRecord(t_prof.pool[2 * slot], s));
       }
-      if (quad64) {  // parallel class r of the block plane: three rounds (clock, clock + 1, clock + 2) in one launch
+      if (quad64) {  // parallel class r of the block planes: three rounds (clock, clock + 1, clock + 2) in one launch; group pairs: two
 #ifdef TJM_F32
-        if (late) hipLaunchKernelGGL((jacobi_quad64_kernel<4, true>), dim3(4, nb), dim3(512), lds64, s, g);
-        else hipLaunchKernelGGL((jacobi_quad64_kernel<4, false>), dim3(4, nb), dim3(512), lds64, s, g);
+        const dim3 grid64(g.mode == 0 ? 4 * ngroups : 8 * (q64_geven / 2), nb);
+        if (rx_top == 256) {
+          if (late) hipLaunchKernelGGL((jacobi_quad64_kernel<4, true>), grid64, dim3(512), lds64, s, g);
+          else hipLaunchKernelGGL((jacobi_quad64_kernel<4, false>), grid64, dim3(512), lds64, s, g);
+        } else {
+          if (late) hipLaunchKernelGGL((jacobi_quad64_kernel<8, true>), grid64, dim3(512), lds64, s, g);
+          else hipLaunchKernelGGL((jacobi_quad64_kernel<8, false>), grid64, dim3(512), lds64, s, g);
+        }
+        const int nquads = g.mode == 0 ? 4 * ngroups : 8 * (ngroups / 2);
+#else
+        const int nquads = 0;
 #endif
-        g.clock += 2;
+        g.clock += g.mode == 0 ? 2 : 1;
         if (timed) {
           TJM_HIP_CHECK(hipEventRecord(t_prof.pool[2 * slot + 1], s));
-          t_prof.pending.emplace_back(slot, (real)4 * n_live * 8.0 * NB * rx_top * sizeof(cplx) * 2.0);
+          t_prof.pending.emplace_back(slot, (real)nquads * n_live * 8.0 * NB * rx_top * sizeof(cplx) * 2.0);
         }
       } else if (quad16) {
         const dim3 gridq(npairs, nb), blockq(256);
@@ -2504,7 +2595,15 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
           case 1: TJM_Q16_LAUNCH(1); break;
           case 2: TJM_Q16_LAUNCH(2); break;
           case 3: TJM_Q16_LAUNCH(3); break;
-          default: TJM_Q16_LAUNCH(4); break;
+          case 4: TJM_Q16_LAUNCH(4); break;
+#ifdef TJM_F32
+          case 5: TJM_Q16_LAUNCH(5); break;
+          case 6: TJM_Q16_LAUNCH(6); break;
+          case 7: TJM_Q16_LAUNCH(7); break;
+          default: TJM_Q16_LAUNCH(8); break;
+#else
+          default: break;
+#endif
         }
 #undef TJM_Q16_LAUNCH
         if (timed) {
@@ -2524,7 +2623,15 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
           case 5: TJM_X16_LAUNCH(5); break;
           case 6: TJM_X16_LAUNCH(6); break;
           case 7: TJM_X16_LAUNCH(7); break;
+#ifdef TJM_F32
+          case 8: TJM_X16_LAUNCH(8); break;
+          case 10: TJM_X16_LAUNCH(10); break;
+          case 12: TJM_X16_LAUNCH(12); break;
+          case 14: TJM_X16_LAUNCH(14); break;
+          default: TJM_X16_LAUNCH(16); break;
+#else
           default: TJM_X16_LAUNCH(8); break;
+#endif
         }
 #undef TJM_X16_LAUNCH
         if (timed) {  // the timed kernel is the X-rows kernel alone: its tile is the X part of the 32 columns, read + written once

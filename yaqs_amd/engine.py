@@ -367,11 +367,11 @@ class BatchEngine:
                                                      TRUNC_MODES[trunc_mode]), "step_compress")
 
     def stats(self) -> dict:
-        s = np.zeros(13, dtype=np.int64)
-        self.lib.tjm_engine_stats_ex(self.h, s.ctypes.data, 13)
+        s = np.zeros(14, dtype=np.int64)
+        self.lib.tjm_engine_stats_ex(self.h, s.ctypes.data, 14)
         return dict(matvecs=int(s[0]), krylov_calls=int(s[1]), svds=int(s[2]), svd_sweeps=int(s[3]), site_updates=int(s[4]),
                     matvecs_two_site=int(s[5]), env_updates=int(s[6]), direct_applies=int(s[7]), svd_matrices=int(s[8]), identity_checks=int(s[9]),
-                    identity_channels=int(s[10]), certified_dissipations=int(s[11]), certified_jumps=int(s[12]))
+                    identity_channels=int(s[10]), certified_dissipations=int(s[11]), certified_jumps=int(s[12]), certificate_tests_blocked_cholesky=int(s[13]))
 
     def profile(self, enable: bool = True):
         """Bracket the kernel classes of every step with HIP events on the engine's stream (tjm_engine_profile)."""
