@@ -1119,3 +1119,60 @@ def test_certified_scalar_dissipation_and_in_place_jumps_match_the_oracle(native
         ro, do, _ = o.run_trajectory(t, o.MPSState([x.copy() for x in init], 0), on, op, mpo)
         assert np.allclose(r[t], ro, atol=1e-8), (t, np.abs(r[t] - ro).max())
         assert np.array_equal(d[t], do), t
+
+
+@pytest.mark.gpu
+def test_dissipation_certificate_near_the_cut_follows_the_reference_rule():
+    """the Gram / Cholesky certificate of the scalar dissipation (tjm_engine.hip: cert_pass_gram) says "no bond truncates"
+    when G_k - cut I factorises without a non-positive pivot; the cut carries a rounding margin (2e-14 + 4 (k + 1) n u ||G_k||_F), so a
+    state whose smallest squared Schmidt value sits at the cut must NOT certify and takes the reference's SVD sweep.  A 12-site state
+    with a prescribed spectrum at the middle bond (32 values, the smallest at c x the value the discarded-weight rule of the two
+    passes cuts at): c just below and just above the rule (inside the margin: reference sweep, same bonds as the oracle whichever way
+    its own rounding decides), c = 0.5 (the oracle truncates, so must the engine), c = 3 (clear of the margin: certified, and
+    nothing truncates).  State after the dissipation (1e-10) and bond tables (exact) against the oracle in every case."""
+    L, chi, dt, gamma = 12, 32, 0.1, 0.1
+    rng = np.random.default_rng(5)
+    scale2 = np.exp(-dt * gamma * L)  # the scalar sweep multiplies the squared singular values by at most this
+    procs = [o.make_process("pauli_z", [i], gamma) for i in range(L)]
+    mpo = o.ising_mpo(L, 1.0, 0.5)
+
+    def iso(rows, cols):
+        return np.linalg.qr(rng.standard_normal((rows, cols)) + 1j * rng.standard_normal((rows, cols)))[0]
+
+    def state_with_spectrum(s):
+        caps = o.MPSState.bond_caps(L, chi)
+        ts = []
+        for i in range(L // 2):  # left-isometric: (sigma, l) x r
+            ts.append(iso(2 * caps[i], caps[i + 1]).reshape(2, caps[i], caps[i + 1]))
+        for i in range(L // 2, L):  # right-isometric: l x (sigma, r)
+            q = iso(2 * caps[i + 1], caps[i]).conj().T  # rows orthonormal
+            ts.append(q.reshape(caps[i], 2, caps[i + 1]).transpose(1, 0, 2))
+        ts[L // 2] = np.einsum("a,sab->sab", s, ts[L // 2])
+        st = o.MPSState([t.astype(np.complex128) for t in ts], L // 2)
+        st.shift_center_to(0, "QR")
+        return st
+
+    results = {}
+    for c in (0.5, 0.999, 1.001, 3.0):
+        s2 = np.linspace(1.0, 0.02, chi)
+        s2[-1] = 0.0
+        s2 = s2 / s2.sum()
+        s2[-1] = c * 1e-12 / scale2
+        st = state_with_spectrum(np.sqrt(s2))
+        e = make_engine(L, chi, 2, mpo)
+        e.set_params(dt=dt, svd_threshold=1e-12, max_bond_dim=chi, krylov_tol=1e-12)
+        e.set_noise(procs, [True] * len(procs))
+        e.load_state([t.copy() for t in st.tensors])
+        e.dissipate(dt)
+        stats = e.stats()
+        out = e.export_state(1)
+        e.close()
+        ref = st.copy()
+        o.apply_dissipation(ref, procs, dt, o.Params(dt=dt, max_bond_dim=chi, svd_threshold=1e-12))
+        assert [t.shape[2] for t in out] == [t.shape[2] for t in ref.tensors], (c, [t.shape[2] for t in out], [t.shape[2] for t in ref.tensors])
+        rv = ref.to_vec()
+        assert np.allclose(phase_align(rv, vec_of(out)), rv, atol=1e-10), c
+        results[c] = (stats["certified_dissipations"], ref.tensors[L // 2 - 1].shape[2])
+    assert results[0.5][1] == chi - 1 and results[0.5][0] == 0, results     # the rule cuts the last value: never certified
+    assert results[0.999][0] == 0 and results[1.001][0] == 0, results          # inside the rounding margin: the reference's sweep decides
+    assert results[3.0] == (2, chi), results                                    # clear of it: certified for both trajectories, nothing cut

@@ -894,6 +894,11 @@ int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
   if (g.hermitian && direct_mirror) g.hermitian = 2;
   if (g.M <= 0 || g.N <= 0 || g.nb0 <= 0 || g.nb1 <= 0 || g.nb2 <= 0) return TJM_OK;
   if (g.K <= 0 || g.nks <= 0) return TJM_ERR_ARG;
+  // a Hermitian product added to an old C: the mirror tiles of the two kernels disagree on what they would write and no
+  // caller needs it; the dot-product epilogue's per-tile partial sums are double-buffered by the k loop, which needs two k-tiles per
+  // output tile (K >= 32 in all, the engine asks from 64 on)
+  if (g.hermitian && g.accumulate) return TJM_ERR_NOT_IMPLEMENTED;
+  if (g.dot_part != nullptr && (long)g.K * g.nks < 32) return TJM_ERR_NOT_IMPLEMENTED;
   static const bool no_small = getenv("TJM_NO_SMALL_GEMM") != nullptr;
   if (!no_small && g.dot_part == nullptr && (g.M <= 32 || g.N <= 32) && (long)g.K * g.nks <= 512) {  // long sums keep the LDS-tiled kernel's four-wave k loop
     const int tiles_m = (g.M + 15) / 16, tiles_n = (g.N + 15) / 16;
@@ -937,7 +942,9 @@ int launch_gemm(const GemmDesc& g_in, hipStream_t stream) {
     if (kg == 2 && slots3 == 0) slots3 = slots / 2 * 3;
     const int use_slots = kg == 2 ? slots3 : slots;
     const unsigned nwg2 = (unsigned)(total_tiles < use_slots ? total_tiles : use_slots);
-    const int xm = (xcd_map && total_tiles >= use_slots) ? 1 : 0;
+    // the XCD-aware walk derives its slot count from the grid (gridDim.x >> 3): only for grids that are whole multiples of 8 (ADVICE r5:
+    // 3 x CUs workgroups of the K % 16 == 8 instance on a part whose CU count is not a multiple of 8 walked some tiles twice)
+    const int xm = (xcd_map && total_tiles >= use_slots && use_slots % 8 == 0) ? 1 : 0;
     // measurement (off unless tjm_profile_gemm was called): bracket every N-th launch, count the executed tiles on the device
     unsigned long long* wc = nullptr;
     int ev = -1;

@@ -183,7 +183,9 @@ __device__ inline real fast_rsqrt(real x) {
   real y = tjm_rsq(x);
   const real h = half * x;
   y = fma(y, fma(-(h * y), y, half), y);  // y (1 + (1/2 - x y^2 / 2))
+#ifndef TJM_F32  // (v_rsq_f32 is good to one ulp: ONE step brings it to rounding, and the step sits on the serial chain of every sub-step)
   y = fma(y, fma(-(h * y), y, half), y);
+#endif
   return y;
 }
 
@@ -194,10 +196,14 @@ __device__ inline real fast_sqrt(real x) {
   const real y = tjm_rsq(x);
   real g = x * y, h = half * y;
   real e = fma(-g, h, half);
+#ifdef TJM_F32  // (one step from the one-ulp estimate of v_rsq_f32)
+  return fma(g, e, g);
+#else
   g = fma(g, e, g);
   h = fma(h, e, h);
   e = fma(-g, h, half);
   return fma(g, e, g);
+#endif
 }
 
 // Decide and build the rotation for the column pair with norms (a, d) and inner product g.
@@ -1510,7 +1516,10 @@ __global__ __launch_bounds__(256) void jacobi_stamp_init_kernel(const cplx* __re
 // stop_at: a trajectory is done when its sweep applied at most this many rotations (0: a sweep without rotations, the convergence
 // criterion; > 0: callers that refine the result anyway).  The decision is per trajectory, so what a trajectory gets does not depend
 // on the others in its batch.
-__global__ void svd_sweep_check_kernel(int* nrot, int* done, int* n_active, int nb0, const int* ids, int stop_at) {
+// n_active: the counter slot of THIS sweep (live trajectories, rotations, -, -, rotation slots executed: the tile kernels add to [4]);
+// clear: the slot of the next sweep, zeroed here - the sweeps alternate between two slots, so no fill command sits between them
+__global__ void svd_sweep_check_kernel(int* nrot, int* done, int* n_active, int nb0, const int* ids, int stop_at, int* clear) {
+  if (clear != nullptr && blockIdx.x == 0 && threadIdx.x < 5) clear[threadIdx.x] = 0;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nb0) return;
   const int b = ids ? ids[t] : t;
@@ -1522,8 +1531,10 @@ __global__ void svd_sweep_check_kernel(int* nrot, int* done, int* n_active, int 
   nrot[b] = 0;
 }
 
-__global__ void svd_reset_kernel(int* nrot, int* done, int nb0, const int* ids) {
+__global__ void svd_reset_kernel(int* nrot, int* done, int nb0, const int* ids, int* n_active) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 16) n_active[16 + t] = 0;  // the two counter slots of the sweeps (svd_sweep_check_kernel)
+  if (t == 16) n_active[2] = 0;      // "a kept singular value sits at the noise floor" (svd_finish_kernel)
   if (t >= nb0) return;
   const int b = ids ? ids[t] : t;
   nrot[b] = 0;
@@ -2408,7 +2419,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   }
   const size_t lds = (size_t)NB * rtot * sizeof(cplx) + NB * sizeof(real) + 16 * sizeof(int);
   const int tb = (src.nb0 + 255) / 256;
-  hipLaunchKernelGGL(svd_reset_kernel, dim3(tb), dim3(256), 0, s, w.nrot, w.done, src.nb0, src.ids);
+  hipLaunchKernelGGL(svd_reset_kernel, dim3(tb), dim3(256), 0, s, w.nrot, w.done, src.nb0, src.ids, w.n_active);
   {
     const long total = (long)ncols_pad * rtot;
     int gx = (int)((total + 1023) / 1024);
@@ -2435,10 +2446,9 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   g.stamps = w.stamps;
   g.clock = 1;
   g.mode = 0;
-  g.work = w.n_active + 4;
+  g.work = w.n_active + 16 + 4;  // (slot of the first sweep; zeroed by svd_reset_kernel above)
   { std::lock_guard<std::mutex> lock(g_prof_mutex); ++g_work.solves; }
   if (g.nblk > MAXBLK) return TJM_ERR_NOT_IMPLEMENTED;
-  TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 4, 0, sizeof(int), s));
   const int nrounds = tile16 ? (g.nblk / 2 - 1) : (g.nblk - 1);
   const int npairs = tile16 ? g.nblk / 4 : g.nblk / 2;
   const size_t lds16 = (size_t)2 * NB * rtot * sizeof(cplx) + 2 * NB * sizeof(real) + 16 * sizeof(int);
@@ -2536,6 +2546,8 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   int sweeps_done = 0;
   bool extra_queued = false;
   for (; sweep_c < max_sweeps && !conv_c; ++sweep_c) {
+    int* const slot = w.n_active + 16 + 8 * (sweep_c & 1);  // this sweep's counters; the other slot is the next sweep's
+    g.work = slot + 4;
     ++g.clock;
     g.mode = 0;
     if (!g.fold) {
@@ -2643,16 +2655,14 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
       else if (big) hipLaunchKernelGGL(jacobi_cross_kernel<16>, dim3(npairs, nb), dim3(512), lds, s, g);
       else hipLaunchKernelGGL(jacobi_cross_kernel<8>, dim3(npairs, nb), dim3(512), lds, s, g);
     }
-    TJM_HIP_CHECK(hipMemsetAsync(w.n_active, 0, 2 * sizeof(int), s));
-    hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tbc), dim3(256), 0, s, w.nrot, w.done, w.n_active, nb, g.ids, stop_at);
+    hipLaunchKernelGGL(svd_sweep_check_kernel, dim3(tbc), dim3(256), 0, s, w.nrot, w.done, slot, nb, g.ids, stop_at, w.n_active + 16 + 8 * ((sweep_c + 1) & 1));
     // The counts of the sweep travel to the host BEHIND the sweep (round 5): the host queues sweep k + 1 before it looks at sweep k, so
     // the device never idles for the round trip.  Nothing numerical depends on it - a trajectory's `done` flag lives on the device
     // (every kernel of a queued sweep returns at once for a finished trajectory), and the check-first variant the counts select
     // applies the same rotations as the unconditional one: the host only decides when to stop queuing.  Price: one masked sweep
     // (launches that find every trajectory done) at the end.  TJM_SVD_SYNC_EACH / the launch sampler: one round trip per sweep.
     int* hp = w.h_pinned + 16 + 8 * (sweep_c & 1);
-    TJM_HIP_CHECK(hipMemcpyAsync(hp, w.n_active, 5 * sizeof(int), hipMemcpyDeviceToHost, s));
-    TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 4, 0, sizeof(int), s));
+    TJM_HIP_CHECK(hipMemcpyAsync(hp, slot, 5 * sizeof(int), hipMemcpyDeviceToHost, s));
     auto digest = [&](const int* h, int k) {  // the counts of sweep k have arrived
       conv_c = (h[0] == 0);
       {
@@ -2689,8 +2699,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   const int sweep = sweep_c;
   const bool converged = conv_c;
   if (sweeps_out) *sweeps_out = sweep;
-  TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 2, 0, sizeof(int), s));
-  hipLaunchKernelGGL(svd_finish_kernel, dim3(src.nb0), dim3(256), 0, s, tr, w, ncols_pad, rx_top, rtot, src.ids);
+  hipLaunchKernelGGL(svd_finish_kernel, dim3(src.nb0), dim3(256), 0, s, tr, w, ncols_pad, rx_top, rtot, src.ids);  // (n_active[2] was zeroed by svd_reset_kernel)
   TJM_HIP_CHECK(hipGetLastError());
   if (shape_out) {
     shape_out->ncols_pad = ncols_pad;
@@ -3593,8 +3602,7 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
   JacobiShape sh;
   sh.ncols_pad = N; sh.rx_top = N; sh.rtot = N;
   // norms, order, truncation of every trajectory from the columns of X; then the check of what was kept
-  TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 2, 0, sizeof(int), s));
-  TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 5, 0, sizeof(int), s));
+  TJM_HIP_CHECK(hipMemsetAsync(w.n_active + 2, 0, 4 * sizeof(int), s));  // [2]: finish kernel's rank flag, [5]: the check's count ([3] = the polar flag, read already; [4] unused)
   hipLaunchKernelGGL(svd_finish_kernel, dim3(nb), dim3(256), 0, s, tr, w, N, N, N, (const int*)nullptr);
   const int strict = can_skip ? 0 : 1;
   hipLaunchKernelGGL(refine_check_kernel, dim3(nb), dim3(256), 0, s, Gm, g_b0, N, fro2, w.perm, d.chiM, d.chi_stride, strict, pneed, status, w.n_active + 5);
