@@ -685,6 +685,7 @@ def main():
         e.profile(True)
     lib.tjm_profile_cross_kernel(8)  # bracket every 8th launch of the Jacobi tile kernels with HIP events on their engine's stream
     lib.tjm_profile_gemm(8)          # ... and of the fp64 GEMM kernel (zgemm4_kernel; executed tiles counted on the device)
+    lib.tjm_profile_qr_apply(8)      # ... and of the block-reflector apply of the QR preconditioner
     jw = np.zeros(4)
     lib.tjm_svd_work_read(jw.ctypes.data, 1)  # reset the executed-work counters of the tiled Jacobi kernels
     mx = np.zeros(10)
@@ -713,6 +714,9 @@ def main():
     gp = np.zeros(6)
     lib.tjm_profile_gemm_read(gp.ctypes.data)
     lib.tjm_profile_gemm(0)
+    qr_own, qr_c64 = np.zeros(5), np.zeros(5)
+    lib.tjm_profile_qr_apply_read(qr_own.ctypes.data, qr_c64.ctypes.data)
+    lib.tjm_profile_qr_apply(0)
     lib.tjm_svd_work_read(jw.ctypes.data, 0)
     lib.tjm_svd_mixed_read(mx.ctypes.data, 0)
 
@@ -726,6 +730,7 @@ def main():
         lib.tjm_svd_mixed_read(mx_i.ctypes.data, 1)
         lib.tjm_profile_cross_kernel(1)
         lib.tjm_profile_gemm(1)
+        lib.tjm_profile_qr_apply(1)
         torch.cuda.synchronize()
         t_i = time.perf_counter()
         drives[0].run(1, False)
@@ -742,13 +747,19 @@ def main():
         gp_i = np.zeros(6)
         lib.tjm_profile_gemm_read(gp_i.ctypes.data)
         lib.tjm_profile_gemm(0)
+        qr_own_i, qr_c64_i = np.zeros(5), np.zeros(5)
+        lib.tjm_profile_qr_apply_read(qr_own_i.ctypes.data, qr_c64_i.ctypes.data)
+        lib.tjm_profile_qr_apply(0)
         lib.tjm_svd_work_read(jw_i.ctypes.data, 0)
         lib.tjm_svd_mixed_read(mx_i.ctypes.data, 0)
         iso = {"step_s": t_i, "trajectories": drives[0].nb,
                # one 64 x 64 output tile x one unit of K = 3 real matrix-core products x 2 flops x 64 x 64 (three-product complex multiplication)
                "gemm": {"ms": float(gp_i[0]), "samples": int(gp_i[1]), "launches": int(gp_i[2]), "bytes": float(gp_i[4]), "flops": 6.0 * 64 * 64 * float(gp_i[3])},
                "f64": {"ms": ms_i.value, "samples": int(ns_i.value), "bytes": nb_i.value, "flops": 28.0 * float(jw_i[0])},
-               "c64": {"ms": ms32_i.value, "samples": int(ns32_i.value), "bytes": nb32_i.value, "flops": 28.0 * float(mx_i[6])}}
+               "c64": {"ms": ms32_i.value, "samples": int(ns32_i.value), "bytes": nb32_i.value, "flops": 28.0 * float(mx_i[6])},
+               # block-reflector apply of the QR preconditioner (complex64 in both libraries: the fp64 library's instance serves the mixed split)
+               "qr": {"ms": float((qr_c64_i if args.dtype == "complex128" else qr_own_i)[0]), "flops": float((qr_c64_i if args.dtype == "complex128" else qr_own_i)[1]),
+                      "samples": int((qr_c64_i if args.dtype == "complex128" else qr_own_i)[2])}}
 
     if rank == 0:
         total_traj = B * world
@@ -850,6 +861,18 @@ def main():
                     line["frac_of_matrix_peak"] = line.pop("frac_of_vector_peak")
             return line
 
+        # the complex64 block-reflector apply of the QR preconditioner (qr_block_apply_multi_kernel): matrix-core-bound, measured alone in the
+        # isolated step (every launch bracketed); nominal flops = 8 per complex multiply-add of V^H C and C - V (T V^H C)
+        qr_io = iso["qr"] if iso else None
+        qr_tm = qr_c64 if args.dtype == "complex128" else qr_own
+        qr_line = None
+        if qr_io and qr_io["samples"] and qr_io["ms"] > 0:
+            qr_tf = qr_io["flops"] / 1e12 / (qr_io["ms"] / 1e3)
+            qr_line = {"name": ("tjm32::" if args.dtype == "complex128" else "tjm::") + "qr_block_apply_multi_kernel (block reflectors of the Householder QR preconditioner, four panels per pass)",
+                       "bound": "mfma-f32", "avg_launch_us": 1e3 * qr_io["ms"] / qr_io["samples"], "launches": qr_io["samples"],
+                       "nominal_TFLOPs": qr_tf, "peak_TFLOPs": peak32, "frac": qr_tf / peak32,
+                       "summed_launch_ms_in_the_isolated_step": qr_io["ms"],
+                       "avg_launch_us_overlapped": (1e3 * qr_tm[0] / qr_tm[2]) if qr_tm[2] else None}
         dom_line = kernel_line(dom)
         traffic, traffic_src = pmc_traffic(L, chi, sizes[0], "zgemm4" if dom is kgm else ("tjm32" if dom is k32 else "tjm::"))
         alg_bytes_per_launch = (dom["bytes"] / dom["samples"]) if dom["samples"] else None
@@ -943,7 +966,8 @@ def main():
                 "frac_nominal": frac(tf(flops_svd_nominal, cls_ms["svd"]), peak),
                 "achieved_nominal": tf(flops_svd_nominal, cls_ms["svd"]),
                 "algorithmic_flops_per_svd": F_svd,
-                "kernels": {"gemm_fp64": kernel_line(kgm) if not f32 else None, "jacobi_fp64": kernel_line(k64), "jacobi_complex64": kernel_line(k32) if not f32 else None},
+                "kernels": {"gemm_fp64": kernel_line(kgm) if not f32 else None, "jacobi_fp64": kernel_line(k64), "jacobi_complex64": kernel_line(k32) if not f32 else None,
+                            "qr_apply_complex64": qr_line},
                 "summed_launch_ms_in_the_isolated_step": {"gemm_fp64": (iso or {}).get("gemm", {}).get("ms"), "jacobi_complex64": (iso or {}).get("c64", {}).get("ms"),
                                                           "jacobi_fp64": (iso or {}).get("f64", {}).get("ms")} if iso else None,
                 "jacobi_sweeps_per_solve_fp64": (float(jw[2]) / float(jw[3])) if jw[3] else None,

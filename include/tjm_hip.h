@@ -327,6 +327,12 @@ int tjm_profile_cross_kernel_read_c64(double* total_ms, double* total_bytes, int
  * products per complex one; masked trajectories and mirror tiles of Hermitian products are not counted), algorithmic bytes of the sampled
  * launches (operands and result of a launch once each), the same for all launches }.  Call read() after synchronising the streams.
  * Zeros in the complex64 library. */
+/* Launch sampler of the block-reflector apply of the QR preconditioner (qr_block_apply_multi_kernel): every N-th launch bracketed by
+ * HIP events; out5 = summed duration of the sampled launches (ms), their nominal real flops (8 per complex multiply-add), samples,
+ * all launches, nominal flops of all launches - of the library's own arithmetic and, in the fp64 library, of the complex64 instance
+ * that preconditions the mixed-precision split (zeros in the complex64 library). */
+int tjm_profile_qr_apply(int32_t every);
+int tjm_profile_qr_apply_read(double* out5, double* out5_c64);
 int tjm_profile_gemm(int32_t every);
 int tjm_profile_gemm_read(double* out6);
 

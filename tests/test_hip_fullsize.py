@@ -197,7 +197,7 @@ def test_config2_ten_consecutive_steps_also_without_the_certified_dissipation():
     import sys
 
     env = dict(os.environ, TJM_NO_CERT_DISSIPATION="1")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "ten_consecutive and not also_without"],
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "config2_ten_consecutive and not also_without"],
                          env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__)))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "2 passed" in out.stdout, out.stdout[-2000:]

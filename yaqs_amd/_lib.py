@@ -143,6 +143,8 @@ EXPORTS = {
     "tjm_svd_work_read": (C.c_int, [V, I]),
     "tjm_svd_mixed_read": (C.c_int, [V, I]),
     "tjm_profile_cross_kernel_read_c64": (C.c_int, [V, V, V]),
+    "tjm_profile_qr_apply": (C.c_int, [I]),
+    "tjm_profile_qr_apply_read": (C.c_int, [V, V]),
     "tjm_profile_gemm": (C.c_int, [I]),
     "tjm_profile_gemm_read": (C.c_int, [V]),
 }

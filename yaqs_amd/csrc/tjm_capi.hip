@@ -523,6 +523,19 @@ int tjm_profile_cross_kernel_read(double* total_ms, double* total_bytes, int64_t
   return TJM_OK;
 }
 
+int tjm_profile_qr_apply(int32_t every) {
+  qr_profile_enable(every);
+  mixed_qr_profile_enable(every);
+  return TJM_OK;
+}
+
+int tjm_profile_qr_apply_read(double* out5, double* out5_c64) {
+  if (!out5 || !out5_c64) return TJM_ERR_ARG;
+  qr_profile_get(out5);
+  mixed_qr_profile_get(out5_c64);
+  return TJM_OK;
+}
+
 int tjm_profile_gemm(int32_t every) {
   gemm_profile_enable(every);
   return TJM_OK;

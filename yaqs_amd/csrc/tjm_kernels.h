@@ -281,6 +281,10 @@ void mixed_stats_get(double* out10, bool reset);  // batched splits, complex64 s
                                                   // trajectories finished by the fp64 Jacobi, batches with a second polar step, executed
                                                   // complex64 rotation slots x rows, applied complex64 rotations x rows, GEMMs of the
                                                   // fp64 phase, their nominal real flops
+void qr_profile_enable(int every);                // launch sampler of qr_block_apply_multi_kernel (tjm_qr.hip); get: out5, see there
+void qr_profile_get(double* out5);
+void mixed_qr_profile_enable(int every);          // ... of the complex64 instance inside the fp64 library (the mixed split's preconditioner)
+void mixed_qr_profile_get(double* out5);
 void mixed_profile_enable(int every);             // launch sampler of the complex64 tile kernel (as profile_enable for the fp64 one)
 void mixed_profile_get(double* total_ms, double* total_bytes, long* samples);
 int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace& q, hipStream_t s, int* sweeps_out,

@@ -49,6 +49,8 @@ int mixed_square(void* ws, size_t ws_bytes, int max_dim, int B, int N, int nb0, 
 // Counters and the launch sampler of the complex64 Jacobi kernels (the tjm32 instances of the functions of the same name in
 // tjm_kernels.h; defined by the tjm32 compilation of tjm_svd.hip)
 void jacobi_work_get(double* out4, bool reset);
+void qr_profile_enable(int every);
+void qr_profile_get(double* out5);
 void profile_enable(int every);
 void profile_get(double* total_ms, double* total_bytes, long* samples);
 

@@ -13,6 +13,8 @@
 #include <cstring>
 
 #include <atomic>
+#include <mutex>
+#include <vector>
 
 #include "tjm_kernels.h"
 
@@ -795,6 +797,34 @@ int multi_group(int zr) {
 }
 
 // np panels p_first, p_first + p_step, ... on the columns [col0, col0 + nc) of C in one launch
+// Launch sampler of qr_block_apply_multi_kernel (bench.py's roofline.kernels entry of the QR preconditioner): every N-th launch is
+// bracketed by HIP events on its stream; the work of a launch is the nominal count of its block reflectors, 8 real flops per complex
+// multiply-add: per panel V^H C and C - V (T V^H C), 2 x 16 x rows x columns.  Off unless qr_profile_enable was called.
+struct QrProf {
+  std::mutex m;
+  int every = 0;
+  long counter = 0, samples = 0, launches = 0;
+  double ms = 0.0, flops = 0.0, flops_all = 0.0;
+  std::vector<hipEvent_t> pool;
+  std::vector<std::pair<int, double>> pending;  // (event pair, flops)
+  size_t used = 0;
+};
+QrProf g_qrp;
+
+void qr_prof_harvest_locked() {
+  for (auto& p : g_qrp.pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_qrp.pool[2 * p.first + 1]) == hipSuccess && hipEventElapsedTime(&ms, g_qrp.pool[2 * p.first], g_qrp.pool[2 * p.first + 1]) == hipSuccess) {
+      g_qrp.ms += ms;
+      g_qrp.flops += p.second;
+      ++g_qrp.samples;
+    }
+  }
+  (void)hipGetLastError();
+  g_qrp.pending.clear();
+  g_qrp.used = 0;
+}
+
 int apply_block_reflectors(const QrWorkspace& q, int zr, int p_first, int p_step, int np, bool t_herm, cplx* C, long c_b0, int col0, int nc, int nb0,
                            const int* ids, hipStream_t s) {
   if (nc <= 0 || np <= 0) return TJM_OK;
@@ -813,12 +843,39 @@ int apply_block_reflectors(const QrWorkspace& q, int zr, int p_first, int p_step
   const int nchunks = (nc + PW - 1) / PW;
   const int xcd_map = (!flat && nb0 >= 16) ? 1 : 0;
   const dim3 grid = xcd_map ? dim3((unsigned)(nchunks * ((nb0 + 7) / 8 * 8)), 1) : dim3(nchunks, nb0);
+  int ev = -1;
+  double fl = 0.0;
+  std::unique_lock<std::mutex> plock(g_qrp.m, std::defer_lock);
+  if (g_qrp.every > 0) {
+    plock.lock();
+    if (g_qrp.every > 0) {
+      for (int k = 0; k < np; ++k) fl += 2.0 * 8.0 * PW * (double)(zr - PW * (p_first + k * p_step)) * nc * nb0;
+      ++g_qrp.launches;
+      g_qrp.flops_all += fl;
+      if (g_qrp.counter++ % g_qrp.every == 0) {
+        if (g_qrp.used >= 4096) qr_prof_harvest_locked();
+        if (g_qrp.pool.size() < 2 * (g_qrp.used + 1)) {
+          hipEvent_t a, b;
+          if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) { g_qrp.pool.push_back(a); g_qrp.pool.push_back(b); }
+        }
+        if (g_qrp.pool.size() >= 2 * (g_qrp.used + 1)) {
+          ev = (int)g_qrp.used++;
+          (void)hipEventRecord(g_qrp.pool[2 * ev], s);
+        }
+      }
+    }
+  }
   if (nrows <= 256)
     hipLaunchKernelGGL(qr_block_apply_multi_kernel<4>, grid, dim3(256), multi_lds_bytes(nrows), s, q.V, q.v_b0, q.T, q.t_b0, p_first,
                        p_step, np, zr, t_herm ? 1 : 0, C, c_b0, col0, nc, ids, row_lo, multi_pitch(nrows), nb0, xcd_map);
   else
     hipLaunchKernelGGL(qr_block_apply_multi_kernel<8>, grid, dim3(256), multi_lds_bytes(nrows), s, q.V, q.v_b0, q.T, q.t_b0, p_first,
                        p_step, np, zr, t_herm ? 1 : 0, C, c_b0, col0, nc, ids, row_lo, multi_pitch(nrows), nb0, xcd_map);
+  if (ev >= 0) {
+    (void)hipEventRecord(g_qrp.pool[2 * ev + 1], s);
+    g_qrp.pending.emplace_back(ev, fl);
+  }
+  if (plock.owns_lock()) plock.unlock();
   TJM_HIP_CHECK(hipGetLastError());
   return TJM_OK;
 }
@@ -1035,6 +1092,21 @@ int qr_apply_q(const QrWorkspace& q, int zr, int zc, cplx* C, long c_b0, int nc,
   for (int p = npanels - 1; p >= 0; --p)
     if ((rc = apply_block_reflector(q, zr, p, false, C, c_b0, 0, nc, nb0, ids, s)) != TJM_OK) return rc;
   return TJM_OK;
+}
+
+void qr_profile_enable(int every) {
+  std::lock_guard<std::mutex> lock(g_qrp.m);
+  qr_prof_harvest_locked();
+  g_qrp.every = every;
+  g_qrp.counter = 0; g_qrp.samples = 0; g_qrp.launches = 0;
+  g_qrp.ms = 0.0; g_qrp.flops = 0.0; g_qrp.flops_all = 0.0;
+}
+
+// out5: summed duration of the sampled launches (ms), their nominal flops, samples, all launches, nominal flops of all launches
+void qr_profile_get(double* out5) {
+  std::lock_guard<std::mutex> lock(g_qrp.m);
+  qr_prof_harvest_locked();
+  out5[0] = g_qrp.ms; out5[1] = g_qrp.flops; out5[2] = (double)g_qrp.samples; out5[3] = (double)g_qrp.launches; out5[4] = g_qrp.flops_all;
 }
 
 int qr_scatter(const cplx* in, long in_b0, int ld, const ExtractDesc& x, const int* chi_keep, int chi_stride, int nb0, const int* ids,

@@ -64,6 +64,7 @@ struct JacobiArgs {
   real floor_scale;  // columns below sqrt(floor_scale) ||X||_F are numerically null (TJM_NOISE_FLOOR2 unless the caller says otherwise)
   int ngroups;  // jacobi_quad64_kernel: groups of 16 blocks (256 columns) of the matrix ...
   int ground;   // ... and, in its cross mode (mode 1), the round of the circle method on the groups (round = the shift 0 ... 7)
+  int ablate;   // timing ablation of jacobi_quad64_kernel (TJM_Q64_ABLATE, wrong results): 1 = leave behind the loads and column norms
 };
 
 __device__ inline void pair_of(int nblk, int round, int p, int& I, int& J) {
@@ -1038,6 +1039,10 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_quad64_kernel(
     }
   }
   const real floor2 = g.floor_scale * g.fro2[b];
+  if (g.ablate == 1) {  // (timing only: what the loads and the norms cost)
+    if (nI[0] + nJ[0] + nI[3] + nJ[3] == real(-1.0)) st[0] = 1;
+    return;
+  }
   int cnt = 0;
   auto sub_step = [&](Col& p0, Col& q0, real& a0, real& d0, Col& p1, Col& q1, real& a1, real& d1, Col& p2, Col& q2, real& a2, real& d2, Col& p3, Col& q3,
                       real& a3, real& d3) {
@@ -2502,6 +2507,8 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   [[maybe_unused]] const size_t lds64 = 2 * lds16x + 16 * sizeof(real) + 16 * sizeof(int);
   g.ngroups = ngroups;
   g.ground = 0;
+  static const int q64_ablate = getenv("TJM_Q64_ABLATE") ? atoi(getenv("TJM_Q64_ABLATE")) : 0;
+  g.ablate = q64_ablate;
   // launches of one sweep of the grouped schedule: 5 plane classes (three rounds each), then for every round of the circle method on
   // the groups 8 shifts (two rounds each)
   const int q64_geven = ngroups + (ngroups & 1);
@@ -3326,6 +3333,8 @@ void mixed_stats_get(double* out10, bool reset) {
   if (reset) g_mixed = MixedStats();
 }
 
+void mixed_qr_profile_enable(int every) { tjm32::qr_profile_enable(every); }
+void mixed_qr_profile_get(double* out5) { tjm32::qr_profile_get(out5); }
 void mixed_profile_enable(int every) { tjm32::profile_enable(every); }
 void mixed_profile_get(double* total_ms, double* total_bytes, long* samples) { tjm32::profile_get(total_ms, total_bytes, samples); }
 
@@ -3725,6 +3734,8 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
 }
 #else
 void mixed_stats_get(double* out10, bool) { for (int i = 0; i < 10; ++i) out10[i] = 0.0; }
+void mixed_qr_profile_enable(int) {}
+void mixed_qr_profile_get(double* out5) { for (int i = 0; i < 5; ++i) out5[i] = 0.0; }
 void mixed_profile_enable(int) {}
 void mixed_profile_get(double* total_ms, double* total_bytes, long* samples) { *total_ms = 0.0; *total_bytes = 0.0; *samples = 0; }
 size_t mixed_split_workspace_bytes(int, int) { return 0; }
