@@ -185,6 +185,12 @@ int tjm_engine_step_cap_bond(tjm_engine* e, int32_t set, int32_t bond, int32_t t
  *   step_bug_root     the root update of bug_sweep (bug.py:186-196)
  *   step_flip         MPS.flip_network (mps.py:680-698); the caller loads the reflected MPO (mpo.py:1612-1630) with set_mpo
  *   step_compress     MPS.compress (mps.py:841-899) with the given truncation settings (max_bond_dim <= 0: none) */
+/* Whole sweeps in one call (round 6).  tjm_engine_sweep_dynamic: one sweep of tdvp(tdvp_mode="dynamic") with time step dt
+ * (integrators.py:294-511; sweep_utils.py:280-302 for the bonds a previous sweep left above the cap) - the branch of every
+ * trajectory at every site is decided inside the library from one column of the bond table (max_bond_dim < 1: no cap).
+ * tjm_engine_bug_sweep: one half-sweep of the BUG integrator (bug_sweep, bug.py:128-196). */
+int tjm_engine_sweep_dynamic(tjm_engine* e, int32_t set, int32_t max_bond_dim, double dt);
+int tjm_engine_bug_sweep(tjm_engine* e, int32_t set, double dt);
 int tjm_engine_step_bug_prepare(tjm_engine* e, int32_t set);
 int tjm_engine_step_bug_site(tjm_engine* e, int32_t set, int32_t site, double dt);
 int tjm_engine_step_bug_root(tjm_engine* e, int32_t set, double dt);

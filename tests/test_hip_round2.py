@@ -1176,3 +1176,56 @@ def test_dissipation_certificate_near_the_cut_follows_the_reference_rule():
     assert results[0.5][1] == chi - 1 and results[0.5][0] == 0, results     # the rule cuts the last value: never certified
     assert results[0.999][0] == 0 and results[1.001][0] == 0, results          # inside the rounding margin: the reference's sweep decides
     assert results[3.0] == (2, chi), results                                    # clear of it: certified for both trajectories, nothing cut
+
+
+@pytest.mark.gpu
+def test_sweeps_sequenced_inside_the_library_equal_the_host_sequenced_ones():
+    """Round 6: tjm_engine_sweep_dynamic / tjm_engine_bug_sweep run the site loops of the dynamic TDVP (integrators.py:294-511) and of a
+    BUG half-sweep (bug.py:128-196) in ONE C call each, the branch lists formed inside the library from one bond column per site.
+    yaqs_amd/tjm.py keeps the Python sequencing over the site-level entry points (YAQS_AMD_HOST_SWEEPS=1): same steps, same lists -
+    the states must be bit-identical, on every chain of the f3 fixture (bonds below, at and above the cap) with two trajectories."""
+    import yaqs_amd.tjm as T
+
+    g = load("f3_dynamic_bug")
+    for key in g["cases"]:
+        key = str(key)
+        L = int(key.split("_")[0][1:])
+        cap = key.split("_")[2][3:]
+        cap = None if cap == "None" else int(cap)
+        mpo = tensors(g, key + "_mpo")
+        outs = []
+        for host in (False, True):
+            e = make_engine(L, 16, 2, mpo)
+            e.set_params(dt=0.1, svd_threshold=1e-9, max_bond_dim=cap, krylov_tol=1e-12, tdvp_mode="dynamic")
+            e.load_state(tensors(g, key + "_in"))
+            if host:
+                T._sweep_dynamic(e, 0, cap, 0.1)
+            else:
+                e.sweep_dynamic(cap, 0.1, 0)
+            outs.append([e.export_state(b) for b in range(2)])
+            e.close()
+        for b in range(2):
+            assert all(np.array_equal(x, y) for x, y in zip(outs[0][b], outs[1][b])), key
+    # BUG half-sweep on an engine with the storage slack the integrator needs
+    import yaqs_amd.engine as E
+
+    key = next(str(k) for k in g["cases"] if not str(k).endswith("x+"))
+    L = int(key.split("_")[0][1:])
+    mpo = tensors(g, key + "_mpo")
+    outs = []
+    for host in (False, True):
+        e = E.BatchEngine(L, 32, 2, mpo, cap_slack=2)
+        e.set_params(dt=0.1, svd_threshold=1e-9, max_bond_dim=8, krylov_tol=1e-12)
+        e.set_noise([], [])
+        e.load_state(tensors(g, key + "_in"))
+        if host:
+            e.step_bug_prepare(0)
+            for site in range(L - 1, 0, -1):
+                e.step_bug_site(site, 0.05, 0)
+            e.step_bug_root(0.05, 0)
+        else:
+            e.bug_sweep(0.05, 0)
+        outs.append([e.export_state(b) for b in range(2)])
+        e.close()
+    for b in range(2):
+        assert all(np.array_equal(x, y) for x, y in zip(outs[0][b], outs[1][b]))

@@ -121,6 +121,8 @@ EXPORTS = {
     "tjm_engine_step_env": (C.c_int, [V, I, I, I, V, I]),
     "tjm_engine_step_qr_bond": (C.c_int, [V, I, I, I, D, I, V, I]),
     "tjm_engine_step_cap_bond": (C.c_int, [V, I, I, I, V, I]),
+    "tjm_engine_sweep_dynamic": (C.c_int, [V, I, I, D]),
+    "tjm_engine_bug_sweep": (C.c_int, [V, I, D]),
     "tjm_engine_step_bug_prepare": (C.c_int, [V, I]),
     "tjm_engine_step_bug_site": (C.c_int, [V, I, I, D]),
     "tjm_engine_step_bug_root": (C.c_int, [V, I, D]),

@@ -358,6 +358,16 @@ int tjm_engine_step_flip(tjm_engine* e, int32_t set) {
   TJM_ON_DEVICE(e);
   return e->impl.step_flip(set);
 }
+int tjm_engine_sweep_dynamic(tjm_engine* e, int32_t set, int32_t max_bond_dim, double dt) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.sweep_dynamic(set, max_bond_dim, dt);
+}
+int tjm_engine_bug_sweep(tjm_engine* e, int32_t set, double dt) {
+  if (!e) return TJM_ERR_ARG;
+  TJM_ON_DEVICE(e);
+  return e->impl.bug_sweep(set, dt);
+}
 int tjm_engine_step_compress(tjm_engine* e, int32_t set, double threshold, int32_t max_bond_dim, int32_t trunc_mode) {
   if (!e) return TJM_ERR_ARG;
   TJM_ON_DEVICE(e);

@@ -135,6 +135,9 @@ class Engine {
   int step_bug_root(int set, double dt_);
   int step_flip(int set);
   int step_compress(int set, double threshold, int max_bond_dim, int mode);
+  int bond_column(int set, int bond, std::vector<int>& out);  // chi[b][bond] of every trajectory (host)
+  int sweep_dynamic(int set, int max_bond, double dt_);      // one sweep of the dynamic TDVP, branch lists formed per site from one bond column
+  int bug_sweep(int set, double dt_);                         // one half-sweep of the BUG integrator
   int copy_site(int dst, int src, int site);
   int copy_chi_col(int dst, int src, int col);
   int upload_ids(const int* host_ids, int n, const int** dev);

@@ -2970,6 +2970,85 @@ int Engine::step_cap_bond(int set, int bond, int target, const int* host_ids, in
 }
 
 // ------------------------------------------------------------------------------------------
+// One whole sweep of the dynamic TDVP in one call (round 6): sweep_dynamic (integrators.py:294-511) with its branch lists formed
+// HERE - per site one column of the bond table (B integers) comes to the host instead of the whole table crossing the C ABI and
+// ctypes several times, and the host-side sequencing that yaqs_amd/tjm.py did in Python (its _sweep_dynamic, kept as the readable
+// mirror) is this loop.  max_bond < 1: no cap (every site takes the two-site branch).
+// ------------------------------------------------------------------------------------------
+int Engine::bond_column(int set, int bond, std::vector<int>& out) {
+  out.resize(B);
+  TJM_HIP_CHECK(hipMemcpy2DAsync(out.data(), sizeof(int), sets[set].chi + bond, (size_t)(L + 1) * sizeof(int), sizeof(int), B, hipMemcpyDeviceToHost, stream));
+  TJM_HIP_CHECK(hipStreamSynchronize(stream));
+  return TJM_OK;
+}
+
+int Engine::sweep_dynamic(int set, int max_bond, double dt_) {
+  if (!bound_ || set < 0 || set > 1) return TJM_ERR_ARG;
+  int rc;
+  std::vector<int> dims, one, two;
+  auto lists = [&](int bond) -> int {  // the bond that decides the branch of this site
+    one.clear();
+    two.clear();
+    if (max_bond < 1) { for (int b = 0; b < B; ++b) two.push_back(b); return TJM_OK; }
+    const int r = bond_column(set, bond, dims);
+    if (r != TJM_OK) return r;
+    for (int b = 0; b < B; ++b) (dims[b] >= max_bond ? one : two).push_back(b);
+    return TJM_OK;
+  };
+  if (max_bond >= 1) {  // _cap_bonds (sweep_utils.py:280-302): bonds the previous sweep left above the cap
+    for (int bond = 0; bond + 1 < L; ++bond) {
+      if ((rc = bond_column(set, bond + 1, dims)) != TJM_OK) return rc;
+      one.clear();
+      for (int b = 0; b < B; ++b) if (dims[b] > max_bond) one.push_back(b);
+      if (!one.empty() && (rc = step_cap_bond(set, bond, max_bond, one.data(), (int)one.size())) != TJM_OK) return rc;
+    }
+  }
+  if ((rc = step_env_init(set)) != TJM_OK) return rc;
+  for (int i = 0; i < L; ++i) {  // left to right (integrators.py:340-424)
+    if ((rc = lists(i + 1)) != TJM_OK) return rc;
+    if (!one.empty()) {
+      if ((rc = step_one_site(set, i, 0.5 * dt_, one.data(), (int)one.size())) != TJM_OK) return rc;
+      if (i != L - 1 && (rc = step_qr_bond(set, i, 1, -0.5 * dt_, max_bond, one.data(), (int)one.size())) != TJM_OK) return rc;
+    }
+    if (!two.empty() && i != L - 1) {
+      const int nt = (int)two.size();
+      if ((rc = step_two_site(set, i, 0.5 * dt_, 0, 0, two.data(), nt)) != TJM_OK) return rc;
+      if (i == L - 2) {
+        if ((rc = step_env(set, i + 1, 0, two.data(), nt)) != TJM_OK) return rc;
+        if ((rc = step_env(set, i, 1, two.data(), nt)) != TJM_OK) return rc;
+      } else {
+        if ((rc = step_env(set, i, 1, two.data(), nt)) != TJM_OK) return rc;
+        if ((rc = step_one_site(set, i + 1, -0.5 * dt_, two.data(), nt)) != TJM_OK) return rc;
+      }
+    }
+  }
+  for (int i = L - 1; i >= 0; --i) {  // right to left (integrators.py:427-505)
+    if ((rc = lists(i)) != TJM_OK) return rc;
+    if (!one.empty()) {
+      if ((rc = step_one_site(set, i, 0.5 * dt_, one.data(), (int)one.size())) != TJM_OK) return rc;
+      if (i != 0 && (rc = step_qr_bond(set, i, 0, -0.5 * dt_, max_bond, one.data(), (int)one.size())) != TJM_OK) return rc;
+    }
+    if (!two.empty() && i != 0) {
+      const int nt = (int)two.size();
+      if ((rc = step_two_site(set, i - 1, 0.5 * dt_, 1, 0, two.data(), nt)) != TJM_OK) return rc;
+      if ((rc = step_env(set, i, 0, two.data(), nt)) != TJM_OK) return rc;
+      if (i != 1 && (rc = step_one_site(set, i - 1, -0.5 * dt_, two.data(), nt)) != TJM_OK) return rc;
+    }
+  }
+  return TJM_OK;
+}
+
+// One half-sweep of the BUG integrator (bug_sweep, bug.py:128-196) in one call: the prepared centres and left environments, the walk
+// from the last site to site 1, the root.
+int Engine::bug_sweep(int set, double dt_) {
+  int rc;
+  if ((rc = step_bug_prepare(set)) != TJM_OK) return rc;
+  for (int site = L - 1; site >= 1; --site)
+    if ((rc = step_bug_site(set, site, dt_)) != TJM_OK) return rc;
+  return step_bug_root(set, dt_);
+}
+
+// ------------------------------------------------------------------------------------------
 // Long-range gate as a matrix product operator (digital_tjm.py:536-557: MPO.from_gate(...).multiply(state), mpo.py:1511-1548)
 // ------------------------------------------------------------------------------------------
 // One site of the product.  The gate is U = sum_k P_k (x) Q_k on sites (first, last) with identity threads in between

@@ -341,6 +341,15 @@ class BatchEngine:
         a, n = self._ids(ids)
         _lib.check(self.lib.tjm_engine_step_cap_bond(self.h, set_index, int(bond), int(target), None if a is None else a.ctypes.data, n), "step_cap_bond")
 
+    def sweep_dynamic(self, max_bond_dim, dt: float, set_index: int = 0):
+        """One whole sweep of the dynamic TDVP in one C call (tjm_engine_sweep_dynamic): the branch lists of every site are formed
+        inside the library."""
+        _lib.check(self.lib.tjm_engine_sweep_dynamic(self.h, set_index, -1 if max_bond_dim is None else int(max_bond_dim), float(dt)), "sweep_dynamic")
+
+    def bug_sweep(self, dt: float, set_index: int = 0):
+        """One half-sweep of the BUG integrator in one C call (tjm_engine_bug_sweep)."""
+        _lib.check(self.lib.tjm_engine_bug_sweep(self.h, set_index, float(dt)), "bug_sweep")
+
     # -- steps of the BUG integrator (engines created with cap_slack >= 2) -----------------
     def step_bug_prepare(self, set_index: int = 0):
         _lib.check(self.lib.tjm_engine_step_bug_prepare(self.h, set_index), "step_bug_prepare")

@@ -60,7 +60,15 @@ def dynamic_tdvp(e, set_index: int, max_bond_dim: int | None, dt: float, sweeps:
     differ per trajectory, so the host reads the bond table before every site, forms the two index lists and calls the engine's
     site-level steps for each (``tjm_engine_step_*``); every contraction, exponential and factorisation is a HIP kernel."""
     for _ in range(sweeps):
-        _sweep_dynamic(e, set_index, max_bond_dim, dt / sweeps)
+        if HOST_SEQUENCED_SWEEPS:
+            _sweep_dynamic(e, set_index, max_bond_dim, dt / sweeps)
+        else:  # the same sweep sequenced inside the library (tjm_engine_sweep_dynamic): one C call, one bond column per site to the host
+            e.sweep_dynamic(max_bond_dim, dt / sweeps, set_index)
+
+
+# YAQS_AMD_HOST_SWEEPS=1: the site loops of the dynamic TDVP and of the BUG integrator sequenced from Python (the readable mirror of
+# Engine::sweep_dynamic / bug_sweep, kept for the A/B and as documentation); default: one C entry per sweep
+HOST_SEQUENCED_SWEEPS = os.environ.get("YAQS_AMD_HOST_SWEEPS") == "1"
 
 
 def _sweep_dynamic(e, s: int, cap: int | None, dt: float) -> None:
@@ -119,6 +127,9 @@ def bug_step(e, set_index: int, params, mpo_tensors) -> None:
     reflected = [np.ascontiguousarray(np.transpose(np.asarray(w), (0, 1, 3, 2))) for w in reversed(list(mpo_tensors))]  # MPO.reflected, mpo.py:1612-1630
 
     def sweep():
+        if not HOST_SEQUENCED_SWEEPS:
+            e.bug_sweep(half, set_index)
+            return
         e.step_bug_prepare(set_index)
         for site in range(n - 1, 0, -1):
             e.step_bug_site(site, half, set_index)
