@@ -260,7 +260,7 @@ def pmc_traffic(L, chi, B, kernel_tag):
     FETCH_SIZE and WRITE_SIZE runs of this script, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters
     cannot be read from inside the timed run: the number comes from a profile, is only reported for the configuration and the kernel
     (``kernel_tag``: "tjm32" = the complex64 instance, "tjm::" = the fp64 one) it was collected on, and the source says so."""
-    for name in ("r05_pmc_traffic_zgemm4.json", "r05_pmc_traffic_quad64.json", "r04_pmc_traffic_c64q.json", "r04_pmc_traffic_c64.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic_zgemm4.json", "r05_pmc_traffic_zgemm4.json", "r05_pmc_traffic_quad64.json", "r04_pmc_traffic_c64q.json", "r04_pmc_traffic_c64.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
@@ -279,7 +279,7 @@ def pmc_traffic(L, chi, B, kernel_tag):
 
 def shard_rate(B):
     """Trajectories/s of ONE MI355X with B resident trajectories (profiles/r0*_shard_rates.json, measured with this script)."""
-    for name in ("r05_shard_rates.json", "r04_shard_rates.json", "r03_shard_rates.json"):
+    for name in ("r06_shard_rates.json", "r05_shard_rates.json", "r04_shard_rates.json", "r03_shard_rates.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f)
