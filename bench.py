@@ -498,7 +498,7 @@ def shorten_prose(node):
     if isinstance(node, dict):
         for k, v in list(node.items()):
             if isinstance(v, str) and len(v) > 120 and k not in ("workload", "kernel", "name"):
-                cut = v.split(". ")[0].split(": ")[0]
+                cut = v.split(".  ")[0].split(". ")[0]
                 node[k] = (cut[:117] + "...") if len(cut) > 120 else cut
             else:
                 shorten_prose(v)
@@ -812,7 +812,9 @@ def main():
         step_tf = (flops_svd_nominal + flops_kry_nominal + flops_env) / 1e12 / elapsed
         # ---- the dominant kernel: the Jacobi tile kernel, in whichever arithmetic it spends more time (sampled: every 8th launch)
         k64 = {"ms": ms.value, "samples": int(ns.value), "bytes": nbytes.value, "flops": flops_jac64, "peak": peak, "bound": valu_bound,
-               "name": "jacobi_cross16x_kernel" + (" (complex64 build)" if f32 else " (fp64)")}
+               "name": ("complex64 Jacobi tile kernels of libtjm_hip_f32.so: jacobi_quad64_kernel (256- and 512-column matrices: four 16-column blocks per "
+                        "workgroup, three / two tournament rounds per load), jacobi_cross16q_kernel (four columns per wavefront, other sizes up to 512 rows), "
+                        "jacobi_cross16x_kernel (two columns per wavefront: up to 1024 rows, solves with a rotation record)") if f32 else "jacobi_cross16x_kernel (fp64)"}
         k32 = {"ms": ms32.value, "samples": int(ns32.value), "bytes": nb32.value, "flops": flops_jac32, "peak": peak32, "bound": "fp32-valu",
                "name": "tjm32::jacobi_quad64_kernel (complex64 phase of the mixed-precision two-site split: four 16-column blocks per workgroup, three "
                        "tournament rounds per load; tjm32::jacobi_cross16q_kernel - one round per load - for sizes other than 256 columns)"}
