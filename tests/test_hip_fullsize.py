@@ -355,3 +355,44 @@ def test_config3_three_consecutive_steps_match_the_reference():
     e.close()
     assert np.abs(res[:, :, 0] - g["z"][:, :, -1]).max() < TOL
     assert np.array_equal(diag[:, :, 0], g["diag"][:, :, -1])
+
+
+def test_config3_three_consecutive_steps_in_complex64_follow_the_reference():
+    """BASELINE quotes config 3 in fp32 and ``bench.py --config 3`` times the complex64 library: the three consecutive steps of the
+    fixture above on ``libtjm_hip_f32.so`` (512 x 512 splits on the grouped four-block Jacobi kernel of round 6, Lanczos and
+    environments in fp32) against the REFERENCE's complex128 outputs.  fp32 accuracy over 128 sites and three steps: dp of every step to
+    2e-3, the jump decision wherever the draw is not that close to dp, final <Z_i> to 5e-3 for the trajectories whose decisions all
+    coincided; bonds at the cap in the saturated bulk (towards the chain ends the complex64 build drops Schmidt values below the fp32
+    resolution, TJM_RANK_TOL, so a bond may come out a few below the reference's)."""
+    from yaqs_amd.tjm import trajectory_uniforms
+
+    g = _cfg_fixture("cfg3")
+    sel = list(range(len(g["traj"])))
+    e, trajs, dt = _cfg_engine("cfg3", g, sel, dtype="complex64")
+    steps = int(g["steps"])
+    u = np.stack([trajectory_uniforms(42, t, 2 * steps + 4) for t in trajs])
+    pos = np.zeros(len(trajs), dtype=np.int64)
+    ar = np.arange(len(trajs))
+    alive = np.ones(len(trajs), dtype=bool)  # decisions coincided so far
+    for k in range(steps):
+        e.tdvp()
+        e.dissipate(dt)
+        e.set_uniforms(np.stack([u[ar, pos], u[ar, pos + 1]], axis=1))
+        jumped, dp = e.stochastic(dt)
+        want = g["jumped"][sel, k].astype(bool)
+        assert np.abs(dp - g["dp"][sel, k])[alive].max(initial=0.0) < 2e-3, (k, dp, g["dp"][sel, k])
+        safe = np.abs(u[ar, pos] - g["dp"][sel, k]) > 5e-3
+        assert np.array_equal(jumped.astype(bool)[alive & safe], want[alive & safe]), (k, jumped, want)
+        alive &= jumped.astype(bool) == want
+        pos += 1 + jumped
+    assert alive.any()
+    M = e.site_moments()
+    z = (M[:, :, 0, 0] - M[:, :, 1, 1]).real.T
+    bonds = e.bond_dims()
+    assert not e.capacity_overflow()
+    e.close()
+    assert np.abs(z[alive] - g["z"][sel][alive][:, :, -1]).max() < 5e-3
+    ref_bonds = g["bonds"][sel, steps - 1][alive]
+    L = 128
+    assert np.array_equal(bonds[alive][:, L // 4: 3 * L // 4], ref_bonds[:, L // 4: 3 * L // 4])
+    assert np.all(bonds[alive] <= ref_bonds) and np.all(bonds[alive] >= ref_bonds - 8)
