@@ -297,6 +297,19 @@ class OracleEngine:
             s.tensors[0] = o.update_site(w["lenv"][0], w["rblock"], self.mpo[0], w["canon"][0], dt, self.params.krylov_tol)
             s.center = 0
 
+    def sweep_dynamic(self, max_bond_dim, dt, set_index=0):
+        """The library's one-call sweep (tjm_engine_sweep_dynamic): here the Python mirror over this engine's site-level steps, so that
+        the CPU suite keeps checking that sequencing against the reference."""
+        from yaqs_amd.tjm import _sweep_dynamic
+
+        _sweep_dynamic(self, set_index, max_bond_dim, dt)
+
+    def bug_sweep(self, dt, set_index=0):
+        self.step_bug_prepare(set_index)
+        for site in range(self.L - 1, 0, -1):
+            self.step_bug_site(site, dt, set_index)
+        self.step_bug_root(dt, set_index)
+
     def step_flip(self, set_index=0):
         for s in self.sets[set_index]:
             s.flip()
