@@ -3338,9 +3338,18 @@ void mixed_qr_profile_get(double* out5) { tjm32::qr_profile_get(out5); }
 void mixed_profile_enable(int every) { tjm32::profile_enable(every); }
 void mixed_profile_get(double* total_ms, double* total_bytes, long* samples) { tjm32::profile_get(total_ms, total_bytes, samples); }
 
+// largest square split the mixed path serves: 1024 rows since round 6 - the complex64 instance's tile kernel keeps 1024-row columns in
+// registers now, so it preconditions the splits of bonds up to 512 as well (one stream, 16 matrices of 1024 x 1024: 105 against 254 ms
+// per batched split on the all-fp64 path; the complex64 basis is orthonormal to ~N eps32 there, so every batch takes the listed second
+// polar step).  TJM_MIXED_MAX_DIM=512: as until round 5.
+static int mixed_max_dim() {
+  static const int v = getenv("TJM_MIXED_MAX_DIM") ? atoi(getenv("TJM_MIXED_MAX_DIM")) : 1024;
+  return v < 128 ? 128 : (v > 1024 ? 1024 : v);
+}
+
 size_t mixed_split_workspace_bytes(int max_dim, int B) {
   static const bool off = getenv("TJM_NO_MIXED_SPLIT") != nullptr;
-  if (off || max_dim < 128 || max_dim > 512 || max_dim % 64 != 0) return 0;
+  if (off || max_dim < 128 || max_dim > mixed_max_dim() || max_dim % 64 != 0) return 0;
   // the complex64 phase, two more fp64 matrices per trajectory next to the four of the (idle) fp64 preconditioner, a status word
   return tjm32::mixed_workspace_bytes(max_dim, B) + 2 * (((size_t)B * max_dim * max_dim * sizeof(cplx) + 255) / 256 * 256) +
          4 * (((size_t)B * sizeof(int) + 255) / 256 * 256) + 1024;
@@ -3727,7 +3736,8 @@ static int svd_split_mixed(const SvdSplitDesc& d, const SvdWorkspace& w, const Q
     d2.ids = idlist;
     d2.nb0 = n_fb;
     int sw2 = 0;
-    if ((rc = svd_split(d2, w, s, &sw2)) != TJM_OK) return rc;
+    // (above 512 rows the stacked-column split does not hold the matrix: the X-only direct variant serves index lists as well)
+    if ((rc = (N > 512 ? svd_split_qr2(d2, w, q, s, &sw2) : svd_split(d2, w, s, &sw2))) != TJM_OK) return rc;
   }
   *done = true;
   return TJM_OK;
@@ -3753,6 +3763,13 @@ int svd_split_qr(const SvdSplitDesc& d, const SvdWorkspace& w, const QrWorkspace
   static const bool single_qr = getenv("TJM_SINGLE_QR") != nullptr;
   if (large) {
     if (q.Z2 == nullptr) return TJM_ERR_WORKSPACE;
+#ifndef TJM_F32
+    if (!force_large && !single_qr && mixed_split_fits(d, q, mx)) {  // square splits of 513 ... 1024 rows (TJM_MIXED_MAX_DIM=512: not served, no workspace)
+      bool done = false;
+      const int rcm = svd_split_mixed(d, w, q, *mx, s, sweeps_out, &done);
+      if (rcm != TJM_OK || done) return rcm;
+    }
+#endif
     return svd_split_qr2(d, w, q, s, sweeps_out);
   }
 #ifndef TJM_F32
