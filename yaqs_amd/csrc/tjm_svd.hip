@@ -20,6 +20,7 @@
 // The isometric output is always read from W and the sigma-weighted output from the rotated
 // X for the two-site split, so that path never divides by a singular value.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -2442,6 +2443,19 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   g.rx = rx_top;
   g.nblk = ncols_pad / NB;
   g.tol2 = op.tol2;  // relative off-diagonal tolerance, squared (default 1e-13 in fp64)
+#ifdef TJM_F32
+  {
+    // fp32: the rounding noise of an inner product over r rows is ~ eps sqrt(r) |p| |q| / c0; at 1024 rows the fixed tolerance 2e-6 sits
+    // 3.9 sigma above it (measured: ~50 of 5e5 pairs "rotate" in every late sweep of a 1024 x 512 centre shift, sweep after sweep),
+    // so the tolerance follows the rows: tol >= TJM_JACOBI_TOL_ROWS x eps x sqrt(rows) (1.6: six sigma at 1024 rows = 3e-6, below the
+    // fixed 2e-6 up to 450 rows).  Solves that stop by fraction (the mixed split's first phase) keep the fixed tolerance.
+    static const double c_rows = getenv("TJM_JACOBI_TOL_ROWS") ? atof(getenv("TJM_JACOBI_TOL_ROWS")) : 1.6;
+    if (op.stop_fraction <= 0.0 && c_rows > 0.0) {
+      const double t = c_rows * 5.96e-8 * std::sqrt((double)rx_top);
+      if ((real)(t * t) > g.tol2) g.tol2 = (real)(t * t);
+    }
+  }
+#endif
   g.floor_scale = op.floor_scale;
   g.fro2 = w.fro2;
   g.nrot = w.nrot;
