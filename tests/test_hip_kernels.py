@@ -1038,3 +1038,24 @@ def test_svd_split_is_reentrant_across_host_threads_and_streams(lib):
         for k in range(2):
             for a, b in zip(serial[k][:3], got[k][:3]):
                 assert np.array_equal(a, b), (rep, k)
+
+
+def test_qr_apply_launch_sampler_reports_the_preconditioner_of_the_mixed_split(lib):
+    """tjm_profile_qr_apply / _read (round 6; the source of bench.py's roofline.kernels.qr_apply_complex64): with the sampler on, a
+    256 x 256 split of the fp64 library - whose preconditioner is the complex64 instance - reports launches, a positive summed duration
+    and the nominal flops of its block reflectors in the complex64 block and nothing in the fp64 one; switched off it reports zeros."""
+    rng = np.random.default_rng(3)
+    d, cap = 2, 128
+    theta = np.stack([crand(rng, d * cap, d * cap) / (d * cap) for _ in range(4)])
+    chi = np.full(4, cap, dtype=np.int32)
+    lib.tjm_profile_qr_apply(1)
+    svd_split_gpu(lib, theta, d, cap, cap, cap, 0, 0, 1e-12, cap, 2, chi, chi, qr=True, want_spec=False)
+    own, c64 = np.zeros(5), np.zeros(5)
+    lib.tjm_profile_qr_apply_read(own.ctypes.data, c64.ctypes.data)
+    lib.tjm_profile_qr_apply(0)
+    assert c64[2] > 0 and c64[3] >= c64[2] and c64[0] > 0.0 and c64[1] > 0.0 and c64[4] >= c64[1], c64
+    assert own[2] == 0 and own[0] == 0.0, own
+    # two QR factorisations of 256 x 256 in groups of four 16-column panels + Q x C: per matrix ~ 2 x 8 x 16 x rows x columns per panel
+    assert 1e8 < c64[4] / 4 < 1e10, c64
+    lib.tjm_profile_qr_apply_read(own.ctypes.data, c64.ctypes.data)
+    assert c64[2] == 0 and c64[3] == 0, c64
