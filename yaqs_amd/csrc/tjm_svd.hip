@@ -2507,7 +2507,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   {
     static const bool no_quad64 = getenv("TJM_NO_QUAD64") != nullptr;
     static const bool no_quad64_groups = getenv("TJM_NO_QUAD64_GROUPS") != nullptr;
-    quad64 = quad16 && !no_quad64 && ncols_pad % 256 == 0 && ngroups <= (no_quad64_groups ? 1 : 4) && (rx_top == 256 || rx_top == 512);
+    quad64 = quad16 && !no_quad64 && ncols_pad % 256 == 0 && ngroups <= (no_quad64_groups ? 1 : 2) && (rx_top == 256 || rx_top == 512);  // (the kernel plays any number of groups; the X-only solves of the path have one or two, and only those are tested)
     static std::atomic<bool> q64_attr{false};
     if (quad64 && !q64_attr.load(std::memory_order_acquire)) {
       TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
