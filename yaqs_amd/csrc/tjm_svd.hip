@@ -1225,266 +1225,6 @@ __global__ __launch_bounds__(512, (XRK <= 4) ? 4 : 2) void jacobi_quad64_kernel(
   }
 }
 
-#ifdef TJM_F32
-// ---- the four-block kernel for 512 rows with the ROWS of a column split over two wavefronts (round 6) ----------------------------------
-// jacobi_quad64_kernel<8> holds eight columns of 512 rows per wavefront: 225 registers, one workgroup of 8 wavefronts per CU, two
-// wavefronts per SIMD - and measures as latency-bound there (VALU active 30 % of a wavefront's cycles).  Here a column is shared by TWO
-// wavefronts (rows 0 ... 255 and 256 ... 511): 16 wavefronts per workgroup, each with the register footprint of the 256-row kernel (four
-// row groups per column, <= 128 registers), FOUR wavefronts per SIMD.  The price is one exchange per sub-step: each wavefront reduces
-// the eight inner-product components over its own rows (wave_sum8_groups), leaves them in LDS, and adds its partner's behind a
-// workgroup barrier (the partial sums alternate between two buffers, so one barrier per sub-step is enough); both partners then set up
-// the SAME rotation (a + b = b + a bit for bit) and rotate their halves.  Every wavefront runs the same barrier sequence whatever its
-// tiles need (closed tiles skip the arithmetic, not the barriers).  Schedule, stamps, in-block pairs, hand-overs: jacobi_quad64_kernel.
-template <bool LATE>
-__global__ __launch_bounds__(1024, 4) void jacobi_quad64h_kernel(JacobiArgs g) {
-  extern __shared__ real smem[];
-  constexpr int XRK = 4;  // row groups of 64 per wavefront: half of a 512-row column
-  int b = blockIdx.y;
-  if (g.ids) b = __builtin_amdgcn_readfirstlane(g.ids[b]);
-  const int tid = threadIdx.x, lane = tid & 63, w16 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = w16 >> 3, w = w16 & 7, grp = w >> 2, wl = w & 3;
-  if (g.done[b]) return;
-  const int rtot = g.rtot;
-  typedef ColFrag<XRK> Col;
-  real* slots = smem;                                    // [16][4] half columns of Col::LDS_REALS
-  real* sN = slots + 64 * Col::LDS_REALS;                // [16][4]
-  real* xch = sN + 64;                                   // [2][16][8] partial inner products of the sub-steps
-  int* sCnt = reinterpret_cast<int*>(xch + 256);         // [16]
-  const bool plane = g.mode == 0;
-  const int cls = plane ? g.round : 4;
-  const int last = plane ? 2 : 1;
-  int blk[4];
-  if (plane) {
-    const int base = 16 * (blockIdx.x >> 2), line = blockIdx.x & 3;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) blk[k] = base + ag_point(cls, line, k);
-  } else {
-    int ga, gb;
-    pair_of(g.ngroups + (g.ngroups & 1), g.ground, blockIdx.x >> 3, ga, gb);
-    if (gb >= g.ngroups) return;
-    const int i = blockIdx.x & 7, j = (i + g.round) & 7;
-    blk[0] = 16 * ga + 2 * i; blk[3] = blk[0] + 1;
-    blk[1] = 16 * gb + 2 * j; blk[2] = blk[1] + 1;
-  }
-  int* st = g.stamps + (long)b * STAMP_STRIDE;
-  int mod[4], nz[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    mod[k] = __builtin_amdgcn_readfirstlane(max(st[2 * blk[k]], st[2 * blk[k] + 1]));
-    nz[k] = __builtin_amdgcn_readfirstlane(st[2 * MAXBLK + 2 * blk[k]] | st[2 * MAXBLK + 2 * blk[k] + 1]);
-  }
-  auto ver_of = [&](int i, int j) -> int& { const int I = min(blk[i], blk[j]), J = max(blk[i], blk[j]); return st[3 * MAXBLK + (2 * I) * MAXBLK + 2 * J]; };
-  auto tile_open = [&](int i, int j) { return (nz[i] || nz[j]) && !(__builtin_amdgcn_readfirstlane(ver_of(i, j)) > max(mod[i], mod[j])); };
-  {
-    const bool any = tile_open(0, 1) || tile_open(2, 3) || tile_open(0, 2) || tile_open(1, 3) || (plane && (tile_open(0, 3) || tile_open(1, 2)));
-    if (!any) return;  // (workgroup-uniform: before the first barrier)
-  }
-  cplx* __restrict__ Yb = g.Y + (long)b * g.y_b0 + 256 * half;  // this wavefront's rows of every column
-  int qI = wl, qJ = wl;
-  Col yI[4], yJ[4];
-  real nI[4], nJ[4];
-  int par = 0;  // buffer of the next exchange
-  {
-    const int bI = grp == 0 ? blk[0] : blk[2], bJ = grp == 0 ? blk[1] : blk[3];
-    real pn[8];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      yI[h].load(Yb + (long)(bI * 16 + ag_point(cls, qI, h)) * rtot, lane);
-      yJ[h].load(Yb + (long)(bJ * 16 + ag_point(cls, qJ, h)) * rtot, lane);
-      pn[h] = yI[h].norm2();
-      pn[4 + h] = yJ[h].norm2();
-    }
-    real z = wave_sum8_groups(pn[0], pn[1], pn[2], pn[3], pn[4], pn[5], pn[6], pn[7], lane);
-    if ((lane & 7) == 0) xch[(par * 16 + w16) * 8 + (lane >> 3)] = z;
-    __syncthreads();
-    z += xch[(par * 16 + (w16 ^ 8)) * 8 + (lane >> 3)];
-    par ^= 1;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      nI[h] = lane_value(z, 8 * h);
-      nJ[h] = lane_value(z, 32 + 8 * h);
-    }
-  }
-  const real floor2 = g.floor_scale * g.fro2[b];
-  int cnt = 0;
-  // one sub-step of four pairs; `active` is uniform per wavefront, the barrier inside is met by every wavefront of the workgroup
-  auto sub_step = [&](bool active, Col& p0, Col& q0, real& a0, real& d0, Col& p1, Col& q1, real& a1, real& d1, Col& p2, Col& q2, real& a2, real& d2,
-                      Col& p3, Col& q3, real& a3, real& d3) {
-    real gsum = real(0.0);
-    if (active) {
-      real gx[4], gy[4];
-      Col::dot(p0, q0, gx[0], gy[0]);
-      Col::dot(p1, q1, gx[1], gy[1]);
-      Col::dot(p2, q2, gx[2], gy[2]);
-      Col::dot(p3, q3, gx[3], gy[3]);
-      gsum = wave_sum8_groups(gx[0], gy[0], gx[1], gy[1], gx[2], gy[2], gx[3], gy[3], lane);
-      if ((lane & 7) == 0) xch[(par * 16 + w16) * 8 + (lane >> 3)] = gsum;
-    }
-    __syncthreads();
-    const int rd = (par * 16 + (w16 ^ 8)) * 8 + (lane >> 3);
-    par ^= 1;
-    if (!active) return;
-    gsum += xch[rd];  // (the partner shares this wavefront's tiles: it was active too)
-    const int pr = lane >> 4;
-    const real a = pr == 0 ? a0 : pr == 1 ? a1 : pr == 2 ? a2 : a3;
-    const real d = pr == 0 ? d0 : pr == 1 ? d1 : pr == 2 ? d2 : d3;
-    real cv, sv, tv;
-    const bool rot = make_rotation_lanes4(a, d, gsum, g.tol2, floor2, cv, sv, tv);
-    const unsigned long long any = __ballot(rot) & 0x0001000100010001ull;
-    cnt += __popcll(any);
-    if (LATE && any == 0) return;
-    {
-      const real sr = lane_value(sv, 0), si = lane_value(sv, 8), c = lane_value(cv, 0), tg = lane_value(tv, 0);
-      Col::rotate(p0, q0, c, sr, si);
-      a0 -= tg; d0 += tg;
-    }
-    {
-      const real sr = lane_value(sv, 16), si = lane_value(sv, 24), c = lane_value(cv, 16), tg = lane_value(tv, 16);
-      Col::rotate(p1, q1, c, sr, si);
-      a1 -= tg; d1 += tg;
-    }
-    {
-      const real sr = lane_value(sv, 32), si = lane_value(sv, 40), c = lane_value(cv, 32), tg = lane_value(tv, 32);
-      Col::rotate(p2, q2, c, sr, si);
-      a2 -= tg; d2 += tg;
-    }
-    {
-      const real sr = lane_value(sv, 48), si = lane_value(sv, 56), c = lane_value(cv, 48), tg = lane_value(tv, 48);
-      Col::rotate(p3, q3, c, sr, si);
-      a3 -= tg; d3 += tg;
-    }
-  };
-  int total_all = 0, work = 0;
-#pragma unroll 1
-  for (int t = 0; t < 3; ++t) {
-    bool open0, open1, cross0, cross1;
-    if (t == 0) { open0 = tile_open(0, 1); open1 = tile_open(2, 3); cross0 = nz[0] && nz[1]; cross1 = nz[2] && nz[3]; }
-    else if (t == 1) { open0 = tile_open(0, 2); open1 = tile_open(1, 3); cross0 = nz[0] && nz[2]; cross1 = nz[1] && nz[3]; }
-    else { open0 = tile_open(0, 3); open1 = tile_open(1, 2); cross0 = nz[0] && nz[3]; cross1 = nz[1] && nz[2]; }
-    cross0 = cross0 && open0;
-    cross1 = cross1 && open1;
-    const bool open = grp == 0 ? open0 : open1;
-    const bool cross = grp == 0 ? cross0 : cross1;
-    cnt = 0;
-    if (plane) sub_step(open, yI[0], yI[1], nI[0], nI[1], yI[2], yI[3], nI[2], nI[3], yJ[0], yJ[1], nJ[0], nJ[1], yJ[2], yJ[3], nJ[2], nJ[3]);
-#pragma unroll 1
-    for (int s = 0; s < 4; ++s) {
-      sub_step(cross, yI[0], yJ[0], nI[0], nJ[0], yI[1], yJ[1], nI[1], nJ[1], yI[2], yJ[2], nI[2], nJ[2], yI[3], yJ[3], nI[3], nJ[3]);
-      sub_step(cross, yI[0], yJ[1], nI[0], nJ[1], yI[1], yJ[2], nI[1], nJ[2], yI[2], yJ[3], nI[2], nJ[3], yI[3], yJ[0], nI[3], nJ[0]);
-      sub_step(cross, yI[0], yJ[2], nI[0], nJ[2], yI[1], yJ[3], nI[1], nJ[3], yI[2], yJ[0], nI[2], nJ[0], yI[3], yJ[1], nI[3], nJ[1]);
-      sub_step(cross, yI[0], yJ[3], nI[0], nJ[3], yI[1], yJ[0], nI[1], nJ[0], yI[2], yJ[1], nI[2], nJ[1], yI[3], yJ[2], nI[3], nJ[2]);
-      if (s + 1 < 4) {  // the J quads move one wavefront on inside their group and half
-        if (cross) {
-#pragma unroll
-          for (int h = 0; h < 4; ++h) yJ[h].to_lds(slots + (w16 * 4 + h) * Col::LDS_REALS, lane);
-          if (lane < 4) sN[w16 * 4 + lane] = lane == 0 ? nJ[0] : lane == 1 ? nJ[1] : lane == 2 ? nJ[2] : nJ[3];
-        }
-        __syncthreads();
-        if (cross) {
-          const int src = half * 8 + grp * 4 + ((wl + 1) & 3);
-#pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            yJ[h].from_lds(slots + (src * 4 + h) * Col::LDS_REALS, lane);
-            nJ[h] = sN[src * 4 + h];
-          }
-        }
-        __syncthreads();
-      }
-    }
-    if (cross) qJ = (qJ + 3) & 3;
-    if (lane == 0) sCnt[w16] = cnt;
-    __syncthreads();
-    // (both halves count the same rotations: the upper halves speak)
-    const int tot0 = __builtin_amdgcn_readfirstlane(sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3]);
-    const int tot1 = __builtin_amdgcn_readfirstlane(sCnt[4] + sCnt[5] + sCnt[6] + sCnt[7]);
-    const int stamp = g.clock + t;
-    const bool moved0 = open0 && tot0 > 0, moved1 = open1 && tot1 > 0;
-    const int inb = plane ? 2 * NB : 0;
-    work += (open0 ? (cross0 ? REC_PER_VISIT : 0) + inb : 0) + (open1 ? (cross1 ? REC_PER_VISIT : 0) + inb : 0);
-    if (moved0) total_all += tot0;
-    if (moved1) total_all += tot1;
-    if (t == 0) {
-      if (tid == 0) {
-        if (open0 && tot0 == 0) ver_of(0, 1) = stamp;
-        if (open1 && tot1 == 0) ver_of(2, 3) = stamp;
-      }
-      if (moved0) { mod[0] = stamp; mod[1] = stamp; }
-      if (moved1) { mod[2] = stamp; mod[3] = stamp; }
-    } else if (t == 1) {
-      if (tid == 0) {
-        if (open0 && tot0 == 0) ver_of(0, 2) = stamp;
-        if (open1 && tot1 == 0) ver_of(1, 3) = stamp;
-      }
-      if (moved0) { mod[0] = stamp; mod[2] = stamp; }
-      if (moved1) { mod[1] = stamp; mod[3] = stamp; }
-    } else {
-      if (tid == 0) {
-        if (open0 && tot0 == 0) ver_of(0, 3) = stamp;
-        if (open1 && tot1 == 0) ver_of(1, 2) = stamp;
-      }
-      if (moved0) { mod[0] = stamp; mod[3] = stamp; }
-      if (moved1) { mod[1] = stamp; mod[2] = stamp; }
-    }
-    if (t == last) break;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      Col* y = q == 0 ? yI : yJ;
-      real* nn = q == 0 ? nI : nJ;
-      const Col c1 = y[1];
-      const real n1 = nn[1];
-      y[1] = y[2]; y[2] = y[3]; y[3] = c1;
-      nn[1] = nn[2]; nn[2] = nn[3]; nn[3] = n1;
-    }
-    if (grp == 1) {
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const Col c = yI[h]; yI[h] = yJ[h]; yJ[h] = c;
-        const real n = nI[h]; nI[h] = nJ[h]; nJ[h] = n;
-      }
-      const int q = qI; qI = qJ; qJ = q;
-    }
-    __syncthreads();  // (the counts above are read; the slots are free)
-#pragma unroll
-    for (int h = 0; h < 4; ++h) yJ[h].to_lds(slots + (w16 * 4 + h) * Col::LDS_REALS, lane);
-    if (lane < 4) sN[w16 * 4 + lane] = lane == 0 ? nJ[0] : lane == 1 ? nJ[1] : lane == 2 ? nJ[2] : nJ[3];
-    if (lane == 0) sCnt[w16] = qJ;
-    __syncthreads();
-    {
-      const int src = half * 8 + (1 - grp) * 4 + wl;
-      qJ = __builtin_amdgcn_readfirstlane(sCnt[src]);
-#pragma unroll
-      for (int h = 0; h < 4; ++h) { yJ[h].from_lds(slots + (src * 4 + h) * Col::LDS_REALS, lane); nJ[h] = sN[src * 4 + h]; }
-    }
-    __syncthreads();
-  }
-  if (tid == 0 && g.work && work) atomicAdd(g.work, work);
-  if (total_all == 0) return;
-  if (tid == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (mod[k] >= g.clock) { st[2 * blk[k]] = mod[k]; st[2 * blk[k] + 1] = mod[k]; }
-    atomicAdd(&g.nrot[b], total_all);
-  }
-  const int kI = plane ? (grp == 0 ? 0 : 1) : (grp == 0 ? 0 : 3), kJ = plane ? (grp == 0 ? 3 : 2) : (grp == 0 ? 2 : 1);
-  const int bI = blk[kI], bJ = blk[kJ];
-  const int mI = mod[kI], mJ = mod[kJ];
-  if (mI >= g.clock) {
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int pt = plane ? (h == 0 ? 0 : h == 1 ? 3 : h - 1) : (h == 0 ? 0 : h == 3 ? 1 : h + 1);
-      yI[h].store(Yb + (long)(bI * 16 + ag_point(cls, qI, pt)) * rtot, lane);
-    }
-  }
-  if (mJ >= g.clock) {
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const int pt = plane ? (h == 0 ? 0 : h == 1 ? 3 : h - 1) : (h == 0 ? 0 : h == 3 ? 1 : h + 1);
-      yJ[h].store(Yb + (long)(bJ * 16 + ag_point(cls, qJ, pt)) * rtot, lane);
-    }
-  }
-}
-#endif  // TJM_F32
-
 // Replay of the recorded rotations on the W rows of the same tile: lane = one row, 32 columns in registers.
 __global__ __launch_bounds__(64) void jacobi_cross16w_kernel(JacobiArgs g, int wrow0) {
   int b = blockIdx.z;
@@ -2774,15 +2514,11 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
       TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
       TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
       TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-      TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64h_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
-      TJM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_quad64h_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
       q64_attr.store(true, std::memory_order_release);
     }
   }
 #endif
   [[maybe_unused]] const size_t lds64 = 2 * lds16x + 16 * sizeof(real) + 16 * sizeof(int);
-  // TJM_NO_QUAD64_HALVES: 512 rows on jacobi_quad64_kernel<8> (a whole column per wavefront, two wavefronts per SIMD)
-  [[maybe_unused]] static const bool q64_halves = getenv("TJM_NO_QUAD64_HALVES") == nullptr;
   g.ngroups = ngroups;
   g.ground = 0;
   static const int q64_ablate = getenv("TJM_Q64_ABLATE") ? atoi(getenv("TJM_Q64_ABLATE")) : 0;
@@ -2798,7 +2534,7 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
   g.fold = (!no_fold && split16 && !accumulate && nrounds >= 15) ? 1 : 0;
   if (g_debug && src.ncols >= 128)
     fprintf(stderr, "[svd] ncols_pad %d rx_top %d rtot %d batch %d: %s%s\n", ncols_pad, rx_top, rtot, src.nb0,
-            quad64 ? ((rx_top == 512 && q64_halves) ? "jacobi_quad64h_kernel" : "jacobi_quad64_kernel") : quad16 ? "jacobi_cross16q_kernel" : split16 ? "jacobi_cross16x_kernel" : tile16 ? "jacobi_cross16_kernel" : "jacobi_cross_kernel",
+            quad64 ? "jacobi_quad64_kernel" : quad16 ? "jacobi_cross16q_kernel" : split16 ? "jacobi_cross16x_kernel" : tile16 ? "jacobi_cross16_kernel" : "jacobi_cross_kernel",
             g.fold ? " (in-block pairs folded)" : "");
   const int max_sweeps = op.max_sweeps;
   // op.stop_fraction: a caller that refines the result anyway (the complex64 phase of the mixed-precision split) does not pay for the
@@ -2870,10 +2606,6 @@ int jacobi_solve(const JacobiSource& src, const TruncSpec& tr, const SvdWorkspac
         if (rx_top == 256) {
           if (late) hipLaunchKernelGGL((jacobi_quad64_kernel<4, true>), grid64, dim3(512), lds64, s, g);
           else hipLaunchKernelGGL((jacobi_quad64_kernel<4, false>), grid64, dim3(512), lds64, s, g);
-        } else if (q64_halves) {  // 512 rows, a column shared by two wavefronts: 16 wavefronts per workgroup, four per SIMD
-          const size_t lds64h = (size_t)(64 * 512 + 64 + 256) * sizeof(real) + 16 * sizeof(int);
-          if (late) hipLaunchKernelGGL((jacobi_quad64h_kernel<true>), grid64, dim3(1024), lds64h, s, g);
-          else hipLaunchKernelGGL((jacobi_quad64h_kernel<false>), grid64, dim3(1024), lds64h, s, g);
         } else {
           if (late) hipLaunchKernelGGL((jacobi_quad64_kernel<8, true>), grid64, dim3(512), lds64, s, g);
           else hipLaunchKernelGGL((jacobi_quad64_kernel<8, false>), grid64, dim3(512), lds64, s, g);
