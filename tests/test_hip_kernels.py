@@ -838,7 +838,7 @@ def test_gemm_of_the_complex64_library(lib32, M, N, K, conjA, conjB):
 
 
 @pytest.mark.parametrize("capL,capR,qr", [(8, 8, False), (32, 32, False), (40, 32, True), (64, 64, True), (96, 96, True), (72, 80, True), (128, 128, True),
-                                          (128, 128, False), (256, 256, True), (160, 160, True), (192, 256, True), (256, 256, False), (320, 320, True), (512, 512, True)])
+                                          (128, 128, False), (256, 256, True), (160, 160, True), (192, 256, True), (256, 256, False), (320, 320, True), (384, 384, True), (512, 512, True)])
 def test_svd_split_of_the_complex64_library(lib32, capL, capR, qr):
     """Two-site split of the complex64 build (fused small kernel, LDS-resident and tiled Jacobi with fp32 tolerances, Householder
     panels): singular values to 1e-5 of the largest, isometric left factor, reconstruction of theta to fp32 accuracy.  Round 6: the
@@ -939,7 +939,7 @@ def _run_engine_mode(lib, n):
     return [int(round(out[i])) for i in range(6)] + [out[8]]
 
 
-@pytest.mark.parametrize("n", [256, 512])
+@pytest.mark.parametrize("n", [256, 512, 768, 1024])
 def test_mixed_split_in_the_mode_of_the_engine_matches_lapack(lib, n):
     """svd_split_mixed as Engine::split calls it - no spectrum buffer, so columns that can never be kept stay uncorrected among
     themselves, the refinement works on X and its squares run on the complex64 GEMM (tjm_svd.hip: can_skip) - at the sizes of
