@@ -50,6 +50,8 @@ ENGINE_CASES = [
     "test_bose_hubbard_qudit_chains_match_reference_fixture",
     "test_long_range_gates_through_the_gate_mpo_match_reference_fixture",
     "test_mixed_local_dimensions_match_reference_fixture",
+    "test_dissipation_certificate_near_the_cut_follows_the_reference_rule",
+    "test_sweeps_sequenced_inside_the_library_equal_the_host_sequenced_ones",
 ]
 
 
@@ -155,3 +157,40 @@ def test_mixed_precision_split_under_its_switches(switch):
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "mixed_precision_split_on_the_simulated_device"],
                          env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__)))
     assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_complex64_split_at_512_rows_on_the_simulated_device(on_sim):
+    """Round 6: the two-site split of chi = 256 (BASELINE config 3) in the complex64 library - a 512 x 512 matrix runs the grouped
+    schedule of jacobi_quad64_kernel<8> on the interpreter (five plane launches inside the two groups of 16 blocks, eight cross
+    launches of two rounds between them, in-block pairs riding along, the block exchange between the rounds, the hand-overs of the J
+    quads) behind the two Householder factorisations: singular values, isometry and reconstruction at fp32 accuracy.  One matrix: about
+    a minute of interpreter time."""
+    import ctypes as C
+
+    import numpy as np
+
+    k = on_sim["test_hip_kernels"]
+    from simengine import load_sim
+    from yaqs_amd._lib import check
+
+    lib32 = load_sim("complex64")
+    rng = np.random.default_rng(2560 + 256)
+    d, cap, B = 2, 256, 1
+    n = d * cap
+    theta = k.crand(rng, B, n, n).astype(np.complex64)
+    left = np.zeros((B, d, cap, n), dtype=np.complex64)
+    right = np.zeros((B, d, n, cap), dtype=np.complex64)
+    chi = np.stack([np.full(B, cap), np.full(B, cap), np.zeros(B)], axis=1).astype(np.int32)
+    spec = np.zeros((B, n), dtype=np.float32)
+    nbytes = lib32.tjm_svd_qr_workspace_bytes(n, B)
+    work = np.zeros(nbytes, dtype=np.uint8)
+    sweeps = C.c_int32(0)
+    check(lib32.tjm_svd_split_qr(theta.ctypes.data, B, d, cap, cap, n, left.ctypes.data, right.ctypes.data, 0, 0, 0.0, n, 1, chi.ctypes.data,
+                                 spec.ctypes.data, n, work.ctypes.data, nbytes, C.byref(sweeps), None), "svd_split_qr")
+    s_ref = np.linalg.svd(theta[0].astype(np.complex128), compute_uv=False)
+    assert int(chi[0, 2]) == n
+    assert np.abs(spec[0] - s_ref).max() <= 4e-5 * s_ref[0]
+    lf = left[0].astype(np.complex128).reshape(n, n)
+    rf = right[0].astype(np.complex128).transpose(1, 0, 2).reshape(n, n)
+    assert np.abs(lf.conj().T @ lf - np.eye(n)).max() <= 2e-5
+    assert np.abs(lf @ rf - theta[0]).max() <= 2e-5 * s_ref[0]
